@@ -1,0 +1,168 @@
+/*
+ * jwas_hip.h -- C ABI of libjwas_hip.so: the MI355X (gfx950) marker-effect Gibbs sweep.
+ *
+ * Drop-in boundary for ONE path of reworkhow/JWAS.jl (v2.3.6): the single-site marker-effect
+ * update loop inside runMCMC and the genotype storage/access layer under it.  A host (the bundled
+ * Python host in jwas.jl_amd/, or a Julia `ccall` shim -- see INTEGRATION.md) keeps
+ * get_genotypes()/build_model()/runMCMC(); everything else (fixed effects, pedigree terms, variance
+ * components, pi draws, output files) stays on the host and consumes only the O(n)+O(p)-reducible
+ * statistics returned by jwas_hip_sweep().
+ *
+ * Reference interfaces replaced (paths relative to /root/reference/src/1.JWAS/src/):
+ *   jwas_hip_load_dense_f32*   Genotypes.genotypes + GibbsMats column views
+ *                              (types.jl:98-165, markers/tools4genotypes.jl:8-10,237-258)
+ *   jwas_hip_setup_blocks      GibbsMats x'x and block Grams, get_column_blocks_ref
+ *                              (markers/tools4genotypes.jl:28-36,80-88,259-267)
+ *   jwas_hip_set/get_state     Genotypes.alpha/beta/delta (MCMC/MCMC_BayesianAlphabet.jl:85-117)
+ *   jwas_hip_set/get_residual  the shared ycorr vector (MCMC/MCMC_BayesianAlphabet.jl:131-157)
+ *   jwas_hip_residual_sub_xalpha   ycorr -= X*alpha0 (MCMC/MCMC_BayesianAlphabet.jl:137-146)
+ *   jwas_hip_sweep             BayesABC!  (markers/BayesianAlphabet/BayesABC.jl:60-80,118-188)
+ *                              BayesR!    (markers/BayesianAlphabet/BayesR.jl:45-97,111-193)
+ *                              MTBayesABC! sampler I (markers/BayesianAlphabet/MTBayesABC.jl:57-127,243-333)
+ *                              + the post-sweep reductions consumed by Pi.jl:7-17,20-42 and
+ *                              variance_components.jl:60-112,151-189
+ *   jwas_hip_accumulate        output_posterior_mean_variance, marker part (output.jl:568-577)
+ *   jwas_hip_mul_alpha         getEBV's X*alpha (output.jl:281-306)
+ *
+ * Conventions: every entry point returns 0 on success and a negative JWAS_HIP_E* code on failure
+ * (no exceptions cross the boundary; jwas_hip_last_error() returns the message -- the analogue of
+ * the reference's error(...) strings).  All pointers are plain host pointers unless a parameter
+ * name ends in _dev.  The context owns all device memory it allocates; host arrays are copied
+ * during the call and never retained.  One host thread per context; calls are synchronous unless
+ * stated.  The library never falls back to a CPU path.
+ */
+#ifndef JWAS_HIP_H
+#define JWAS_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct jwas_hip_ctx jwas_hip_ctx;
+
+enum {
+    JWAS_HIP_OK        =  0,
+    JWAS_HIP_EINVAL    = -1,   /* invalid argument (message says which; mirrors error(...) text) */
+    JWAS_HIP_EHIP      = -2,   /* a HIP runtime call failed                                     */
+    JWAS_HIP_ESTATE    = -3,   /* call order violated (e.g. sweep before setup_blocks)          */
+    JWAS_HIP_EUNSUP    = -4,   /* combination not supported by the device path                  */
+    JWAS_HIP_ENOMEM    = -5    /* memory guard / allocation failure                             */
+};
+
+/* Marker-effect samplers (Mi.method / multi_trait_sampler in the reference). */
+enum {
+    JWAS_HIP_BAYESC    = 0,    /* single-trait BayesC: one shared effect variance               */
+    JWAS_HIP_BAYESB    = 1,    /* single-trait BayesB (BayesA = BayesB with pi = 0): per-marker  */
+    JWAS_HIP_BAYESR    = 2,    /* single-trait BayesR, 4-class mixture                          */
+    JWAS_HIP_MTBAYESC1 = 3     /* multi-trait BayesC, Gibbs sampler I                           */
+};
+
+/* Gram precompute modes for jwas_hip_setup_blocks. */
+enum {
+    JWAS_HIP_GRAM_F64  = 0,    /* fp64-accumulated (bit-reproducible vs the CPU oracle); slow    */
+    JWAS_HIP_GRAM_MFMA = 1     /* fp32 MFMA (v_mfma_f32_32x32x2_f32), fp64 chunk combine         */
+};
+
+#define JWAS_HIP_MAX_TRAITS 4
+#define JWAS_HIP_MAX_STATES 16          /* 2^JWAS_HIP_MAX_TRAITS */
+
+/* Parameters of one sweep = one call of BayesABC!/BayesR!/MTBayesABC! in the reference. */
+typedef struct jwas_sweep_params {
+    int32_t  method;                    /* JWAS_HIP_BAYESC ...                                       */
+    int32_t  ntraits;                   /* 1, or t for MTBAYESC1                                     */
+    int32_t  nreps;                     /* within-block repetitions: 1 = exact non-block chain;      */
+                                        /* <= 0 = block size (reference fast_blocks, BayesABC.jl:153) */
+    uint32_t iteration;                 /* MCMC iteration index (enters the RNG counter)             */
+    uint64_t seed;                      /* runMCMC(seed=...) (JWAS.jl:239-251)                       */
+    uint32_t marker_offset;             /* global index of this context's column 0 (marker shards)   */
+    uint32_t reserved;
+    float    vare[JWAS_HIP_MAX_TRAITS * JWAS_HIP_MAX_TRAITS];        /* residual (co)variance, row-major t x t */
+    float    var_effect[JWAS_HIP_MAX_TRAITS * JWAS_HIP_MAX_TRAITS];  /* BayesC: sigma2_alpha; BayesR: sigmaSq; MT: t x t */
+    double   pi;                        /* BayesC/B scalar Pr(effect = 0); ignored if pi_vec != NULL */
+    double   pi_classes[4];             /* BayesR class priors; ignored if pi_matrix != NULL         */
+    double   gamma[4];                  /* BayesR class variances (JWAS.jl:12)                       */
+    double   log_prior_states[JWAS_HIP_MAX_STATES];  /* MT: log pi(state), state = sum delta_k << k  */
+    const float*  var_effect_vec;       /* BayesB: p per-marker variances (host), else NULL          */
+    const double* pi_vec;               /* BayesC/B: p per-marker pi (host), else NULL               */
+    const double* pi_matrix;            /* BayesR: p x 4 row-major per-marker class priors, else NULL */
+} jwas_sweep_params;
+
+/* Reductions the host-side conjugate draws need (Pi.jl, variance_components.jl). */
+typedef struct jwas_sweep_stats {
+    double  sum_delta[JWAS_HIP_MAX_TRAITS];          /* BayesC/B, MT: sum_j delta_jk (MCMC_BayesianAlphabet.jl:309)   */
+    double  alpha_ss[JWAS_HIP_MAX_TRAITS * JWAS_HIP_MAX_TRAITS];   /* alpha'alpha (t x t; [0] single trait)           */
+    double  beta_ss[JWAS_HIP_MAX_TRAITS * JWAS_HIP_MAX_TRAITS];    /* beta'beta  (variance_components.jl:175-177)     */
+    double  resid_ss[JWAS_HIP_MAX_TRAITS * JWAS_HIP_MAX_TRAITS];   /* r_i'r_j    (variance_components.jl:60-66,82-98) */
+    double  resid_sum[JWAS_HIP_MAX_TRAITS];          /* sum_i r_ik (intercept-only location update)                   */
+    double  class_counts[4];                         /* BayesR: markers per class (Pi.jl:11-17)                       */
+    double  bayesr_ssq;                              /* BayesR: sum_{delta>1} alpha^2/gamma_delta                     */
+    double  bayesr_nnz;                              /* BayesR: #{delta > 1}                                          */
+    double  state_counts[JWAS_HIP_MAX_STATES];       /* MT: markers per joint state (Pi.jl:20-42)                     */
+    double  n_events;                                /* markers whose effect changed this sweep (diagnostic)          */
+    double  sweep_ms;                                /* device time of the sweep (hipEvent), milliseconds             */
+} jwas_sweep_stats;
+
+/* ---- context ------------------------------------------------------------------------------- */
+int  jwas_hip_create(int device, jwas_hip_ctx** out);
+void jwas_hip_destroy(jwas_hip_ctx* ctx);
+const char* jwas_hip_last_error(const jwas_hip_ctx* ctx);   /* ctx may be NULL: create() errors */
+/* Launch all work on an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream). */
+int  jwas_hip_set_stream(jwas_hip_ctx* ctx, void* hip_stream);
+int  jwas_hip_device_info(jwas_hip_ctx* ctx, int* n_cu, int64_t* hbm_bytes_total, int64_t* hbm_bytes_free);
+
+/* ---- genotype storage ------------------------------------------------------------------------ */
+/* Copy a column-major (marker-major) n x p fp32 matrix from the host; ld_host >= n is the host
+ * column stride in elements (Julia Matrix{Float32} / numpy order='F': ld_host = n). */
+int  jwas_hip_load_dense_f32(jwas_hip_ctx* ctx, const float* X_host, int64_t n, int64_t p, int64_t ld_host);
+/* Allocate an uninitialised n x p device matrix (filled later by jwas_hip_synth_genotypes). */
+int  jwas_hip_alloc_dense_f32(jwas_hip_ctx* ctx, int64_t n, int64_t p);
+/* Device row stride (elements) of the padded marker-major layout, and its base device pointer. */
+int  jwas_hip_dense_layout(jwas_hip_ctx* ctx, int64_t* n, int64_t* p, int64_t* ld_dev, void** X_dev);
+/* Copy columns [j0, j0+count) back to the host (column-major, ld = n). */
+int  jwas_hip_get_columns(jwas_hip_ctx* ctx, int64_t j0, int64_t count, float* out_host);
+/* Memory guard (tools4genotypes.jl:99-235 analogue for HBM): bytes the dense path needs. */
+int64_t jwas_hip_estimate_bytes(int64_t n, int64_t p, int32_t ntraits, int32_t block_size);
+
+/* Benchmark / test data generator (benchmarks/bayesr_parity_common.jl:34-41 shape): allele
+ * frequency f_j ~ U(0.1,0.4), x_ij = Bernoulli(f_j)+Bernoulli(f_j), optionally centred by the
+ * exact column mean.  kind 1 = X ~ U[0,1) (benchmarks/jwas_nonblock_benchmark.jl:34-51). */
+int  jwas_hip_synth_genotypes(jwas_hip_ctx* ctx, uint64_t seed, int32_t kind, int32_t center);
+
+/* ---- precompute: x'x and block Grams ----------------------------------------------------------- */
+/* block_size in {64,128,256,512}; markers are processed in consecutive blocks of this size. */
+int  jwas_hip_setup_blocks(jwas_hip_ctx* ctx, int32_t block_size, int32_t gram_mode);
+int  jwas_hip_get_xpx(jwas_hip_ctx* ctx, float* out_p);
+int  jwas_hip_get_gram(jwas_hip_ctx* ctx, int64_t block, float* out_bxb);        /* row-major b x b */
+int  jwas_hip_set_gram(jwas_hip_ctx* ctx, int64_t block, const float* in_bxb);
+int  jwas_hip_num_blocks(jwas_hip_ctx* ctx, int64_t* nblocks, int32_t* block_size);
+
+/* ---- chain state ---------------------------------------------------------------------------- */
+/* Declare the sampler so state buffers can be sized: method + ntraits (delta is int32 classes for
+ * BayesR, float 0/1 otherwise -- MCMC_BayesianAlphabet.jl:86,119). */
+int  jwas_hip_init_state(jwas_hip_ctx* ctx, int32_t method, int32_t ntraits);
+/* alpha/beta: p floats; delta: p floats (0/1) or p int32 (BayesR classes).  NULL = leave as is. */
+int  jwas_hip_set_state(jwas_hip_ctx* ctx, int32_t trait, const float* alpha, const float* beta, const void* delta);
+int  jwas_hip_get_state(jwas_hip_ctx* ctx, int32_t trait, float* alpha, float* beta, void* delta);
+/* residual of trait k: n floats */
+int  jwas_hip_set_residual(jwas_hip_ctx* ctx, int32_t trait, const float* r_host);
+int  jwas_hip_get_residual(jwas_hip_ctx* ctx, int32_t trait, float* r_host);
+/* Device pointer / stride of the residual block (t vectors of ld_dev floats) for in-place
+ * collectives on it (marker-shard reconcile). */
+int  jwas_hip_residual_dev(jwas_hip_ctx* ctx, void** r_dev, int64_t* ld_dev);
+/* r_k -= X * alpha_k for the current device alpha (initial ycorr; sequential fmaf in marker order). */
+int  jwas_hip_residual_sub_xalpha(jwas_hip_ctx* ctx, int32_t trait);
+/* out = X * alpha_k (n floats, fp64-accumulated). */
+int  jwas_hip_mul_alpha(jwas_hip_ctx* ctx, int32_t trait, float* out_host);
+
+/* ---- the sweep ------------------------------------------------------------------------------ */
+int  jwas_hip_sweep(jwas_hip_ctx* ctx, const jwas_sweep_params* params, jwas_sweep_stats* stats);
+
+/* ---- posterior accumulators (output.jl:568-577) ---------------------------------------------- */
+int  jwas_hip_accumulate(jwas_hip_ctx* ctx, double nsamples);
+int  jwas_hip_get_posterior(jwas_hip_ctx* ctx, int32_t trait, float* mean_alpha, float* mean_alpha2, float* mean_delta);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

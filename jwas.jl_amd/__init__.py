@@ -1,0 +1,18 @@
+"""jwas.jl_amd -- MI355X-native marker-effect Gibbs sweep behind JWAS.jl's
+get_genotypes() / build_model() / runMCMC() surface.
+
+The directory name carries a dot, so import it as `jwas_jl_amd` (the shim at the repo root
+registers this package under that name).
+"""
+from ._lib import JwasHipError, LIB_PATH  # noqa: F401
+from .engine import HipEngine, BAYESR_GAMMA  # noqa: F401
+
+__all__ = ["HipEngine", "JwasHipError", "BAYESR_GAMMA", "LIB_PATH"]
+
+
+def __getattr__(name):
+    # host-side API (imports pandas etc.) is loaded lazily
+    if name in ("get_genotypes", "build_model", "runMCMC", "Genotypes", "Model", "set_covariate"):
+        from . import api
+        return getattr(api, name)
+    raise AttributeError(name)

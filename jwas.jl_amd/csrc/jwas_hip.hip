@@ -1,0 +1,698 @@
+// jwas_hip.hip -- context, memory and the C ABI of libjwas_hip.so (see include/jwas_hip.h).
+// gfx950 only.  No CPU fallback: every entry point either runs the HIP path or returns an error.
+#include "../../include/jwas_hip.h"
+#include "kernels.hpp"
+
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace jw;
+
+static_assert(JWAS_HIP_MAX_TRAITS == kMaxT, "trait limit mismatch");
+static_assert(JWAS_HIP_MAX_STATES == kMaxStates, "state limit mismatch");
+
+struct jwas_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+
+    int64_t n = 0, p = 0, ld = 0;
+    int nslices = 0;                    // 256-row slices
+    int nrg = 0, ncg = 1;               // k_update_partial grid: row groups x column groups
+    float* X = nullptr;
+
+    int block_size = 0;
+    int64_t nblocks = 0;
+    float* xpx = nullptr;
+    float* gram = nullptr;
+
+    int method = -1, ntraits = 0;
+    float* r = nullptr;                 // [2][kMaxT][ld] ping-pong; buffer 0 is current between sweeps
+    float *alpha = nullptr, *beta = nullptr;
+    void* delta = nullptr;
+    float *mean_a = nullptr, *mean_a2 = nullptr, *mean_d = nullptr;
+
+    double* partials = nullptr;
+    Events* ev = nullptr;               // [2]
+    DevParams* dparams = nullptr;
+    unsigned long long* counters = nullptr;
+    double* fin_out = nullptr;          // [nslices][kMaxT*kMaxT + kMaxT]
+    double* stat_out = nullptr;         // [kStatGrid][kNStat]
+    double* host_buf = nullptr;         // pinned staging for fin_out + stat_out + counters
+    float*  var_vec = nullptr;
+    double* pi_vec = nullptr;
+    double* pi_mat = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+};
+
+static constexpr int kStatGrid = 128;
+static thread_local std::string g_create_error;
+
+static int fail(jwas_hip_ctx* ctx, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(ctx, call)                                                                          \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail((ctx), JWAS_HIP_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                       \
+    } while (0)
+
+#define NEED(ctx, cond, code, ...)                                                                 \
+    do { if (!(cond)) return fail((ctx), (code), __VA_ARGS__); } while (0)
+
+static int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+// t x t inverse: double Gauss-Jordan with partial pivoting, rounded to float (stands in for Julia's
+// inv(::Matrix{Float32}), MTBayesABC.jl:66-67).  Same operation sequence as the oracle's.
+static int inv_small(const float* A, int t, float* Ainv)
+{
+    double M[kMaxT][2 * kMaxT];
+    for (int i = 0; i < t; ++i)
+        for (int j = 0; j < t; ++j) { M[i][j] = A[i * t + j]; M[i][t + j] = (i == j); }
+    for (int c = 0; c < t; ++c) {
+        int piv = c;
+        for (int i = c + 1; i < t; ++i) if (std::fabs(M[i][c]) > std::fabs(M[piv][c])) piv = i;
+        if (M[piv][c] == 0.0) return -1;
+        if (piv != c) for (int j = 0; j < 2 * t; ++j) { double tmp = M[c][j]; M[c][j] = M[piv][j]; M[piv][j] = tmp; }
+        const double d = M[c][c];
+        for (int j = 0; j < 2 * t; ++j) M[c][j] /= d;
+        for (int i = 0; i < t; ++i) if (i != c) {
+            const double f = M[i][c];
+            if (f != 0.0) for (int j = 0; j < 2 * t; ++j) M[i][j] -= f * M[c][j];
+        }
+    }
+    for (int i = 0; i < t; ++i) for (int j = 0; j < t; ++j) Ainv[i * t + j] = (float)M[i][t + j];
+    return 0;
+}
+
+extern "C" {
+
+const char* jwas_hip_last_error(const jwas_hip_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int jwas_hip_create(int device, jwas_hip_ctx** out)
+{
+    if (!out) return fail(nullptr, JWAS_HIP_EINVAL, "jwas_hip_create: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, JWAS_HIP_EHIP, "no HIP device available (%s); the HIP path has no CPU fallback",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return fail(nullptr, JWAS_HIP_EINVAL, "device %d out of range [0,%d)", device, ndev);
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return fail(nullptr, JWAS_HIP_EHIP, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return fail(nullptr, JWAS_HIP_EHIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, JWAS_HIP_EUNSUP, "device %d is %s; this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+    jwas_hip_ctx* c = new jwas_hip_ctx();
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(nullptr, JWAS_HIP_EHIP, "hipStreamCreate failed"); }
+    c->own_stream = true;
+    if (hipEventCreate(&c->ev_start) != hipSuccess || hipEventCreate(&c->ev_stop) != hipSuccess) { delete c; return fail(nullptr, JWAS_HIP_EHIP, "hipEventCreate failed"); }
+    *out = c;
+    return JWAS_HIP_OK;
+}
+
+static void free_state(jwas_hip_ctx* c)
+{
+    (void)hipFree(c->alpha); (void)hipFree(c->beta); (void)hipFree(c->delta);
+    (void)hipFree(c->mean_a); (void)hipFree(c->mean_a2); (void)hipFree(c->mean_d);
+    c->alpha = c->beta = nullptr; c->delta = nullptr; c->mean_a = c->mean_a2 = c->mean_d = nullptr;
+}
+
+static void free_blocks(jwas_hip_ctx* c)
+{
+    (void)hipFree(c->xpx); (void)hipFree(c->gram); (void)hipFree(c->partials);
+    c->xpx = c->gram = nullptr; c->partials = nullptr;
+}
+
+static void free_storage(jwas_hip_ctx* c)
+{
+    (void)hipFree(c->X); (void)hipFree(c->r);
+    c->X = c->r = nullptr;
+    (void)hipFree(c->ev); (void)hipFree(c->dparams); (void)hipFree(c->counters); (void)hipFree(c->fin_out); (void)hipFree(c->stat_out);
+    c->ev = nullptr; c->dparams = nullptr; c->counters = nullptr; c->fin_out = c->stat_out = nullptr;
+    if (c->host_buf) (void)hipHostFree(c->host_buf);
+    c->host_buf = nullptr;
+    (void)hipFree(c->var_vec); (void)hipFree(c->pi_vec); (void)hipFree(c->pi_mat);
+    c->var_vec = nullptr; c->pi_vec = c->pi_mat = nullptr;
+}
+
+void jwas_hip_destroy(jwas_hip_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    free_state(c); free_blocks(c); free_storage(c);
+    if (c->ev_start) (void)hipEventDestroy(c->ev_start);
+    if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int jwas_hip_set_stream(jwas_hip_ctx* c, void* s)
+{
+    NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    c->stream = (hipStream_t)s;
+    c->own_stream = false;
+    return JWAS_HIP_OK;
+}
+
+int jwas_hip_device_info(jwas_hip_ctx* c, int* n_cu, int64_t* total, int64_t* free_b)
+{
+    NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipDeviceProp_t prop;
+    HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
+    size_t f = 0, t = 0;
+    HIPCHK(c, hipMemGetInfo(&f, &t));
+    if (n_cu) *n_cu = prop.multiProcessorCount;
+    if (total) *total = (int64_t)t;
+    if (free_b) *free_b = (int64_t)f;
+    return JWAS_HIP_OK;
+}
+
+int64_t jwas_hip_estimate_bytes(int64_t n, int64_t p, int32_t ntraits, int32_t block_size)
+{
+    // HBM analogue of estimate_marker_memory (tools4genotypes.jl:99-235): X + Grams + x'x + state.
+    const int64_t ld = round_up(n, kSliceRows);
+    int64_t bytes = 4 * ld * p;                                  // X
+    bytes += 4 * (int64_t)block_size * p;                        // Grams (p/b blocks of b*b)
+    bytes += 4 * p;                                              // x'x
+    bytes += (int64_t)ntraits * p * 4 * 6;                       // alpha, beta, delta, 3 running means
+    bytes += (int64_t)kMaxT * ld * 4;                            // residuals
+    bytes += (int64_t)block_size * (ld / kSliceRows) * ntraits * 8;   // slice partials
+    return bytes;
+}
+
+static int alloc_storage(jwas_hip_ctx* c, int64_t n, int64_t p)
+{
+    NEED(c, n > 0 && p > 0, JWAS_HIP_EINVAL, "genotype matrix must be non-empty (n=%lld, p=%lld)", (long long)n, (long long)p);
+    NEED(c, p < (1ll << 31), JWAS_HIP_EUNSUP, "p=%lld exceeds the 2^31 marker limit of one context", (long long)p);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    free_state(c); free_blocks(c); free_storage(c);
+    c->method = -1; c->block_size = 0; c->nblocks = 0;
+    c->n = n; c->p = p; c->ld = round_up(n, kSliceRows);
+    c->nslices = (int)(c->ld / kSliceRows);
+    c->nrg = (c->nslices + kRowGroupSlices - 1) / kRowGroupSlices;
+    // enough workgroups to cover every CU (256 on MI355X), at most 8-fold update redundancy
+    c->ncg = 256 / c->nrg; if (c->ncg < 1) c->ncg = 1; if (c->ncg > 8) c->ncg = 8;
+    size_t fb = 0, tb = 0;
+    HIPCHK(c, hipMemGetInfo(&fb, &tb));
+    const size_t need = (size_t)4 * c->ld * p;
+    NEED(c, need < fb, JWAS_HIP_ENOMEM, "genotype matrix needs %.2f GB but only %.2f GB of HBM is free", need / 1e9, fb / 1e9);
+    HIPCHK(c, hipMalloc(&c->X, need));
+    HIPCHK(c, hipMalloc(&c->r, sizeof(float) * 2 * kMaxT * c->ld));
+    HIPCHK(c, hipMemsetAsync(c->r, 0, sizeof(float) * 2 * kMaxT * c->ld, c->stream));
+    HIPCHK(c, hipMalloc(&c->ev, sizeof(Events) * 2));
+    HIPCHK(c, hipMemsetAsync(c->ev, 0, sizeof(Events) * 2, c->stream));
+    HIPCHK(c, hipMalloc(&c->dparams, sizeof(DevParams)));
+    HIPCHK(c, hipMalloc(&c->counters, sizeof(unsigned long long) * 4));
+    HIPCHK(c, hipMalloc(&c->fin_out, sizeof(double) * c->nslices * (kMaxT * kMaxT + kMaxT)));
+    HIPCHK(c, hipMalloc(&c->stat_out, sizeof(double) * kStatGrid * kNStat));
+    HIPCHK(c, hipHostMalloc(&c->host_buf, sizeof(double) * ((size_t)c->nslices * (kMaxT * kMaxT + kMaxT) + kStatGrid * kNStat + 8)));
+    return JWAS_HIP_OK;
+}
+
+int jwas_hip_load_dense_f32(jwas_hip_ctx* c, const float* Xh, int64_t n, int64_t p, int64_t ld_host)
+{
+    NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
+    NEED(c, Xh, JWAS_HIP_EINVAL, "X_host is NULL");
+    NEED(c, ld_host >= n, JWAS_HIP_EINVAL, "ld_host (%lld) must be >= n (%lld)", (long long)ld_host, (long long)n);
+    int rc = alloc_storage(c, n, p);
+    if (rc) return rc;
+    if (c->ld != n) HIPCHK(c, hipMemsetAsync(c->X, 0, (size_t)4 * c->ld * p, c->stream));
+    HIPCHK(c, hipMemcpy2DAsync(c->X, (size_t)4 * c->ld, Xh, (size_t)4 * ld_host, (size_t)4 * n, (size_t)p,
+                               hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return JWAS_HIP_OK;
+}
+
+int jwas_hip_alloc_dense_f32(jwas_hip_ctx* c, int64_t n, int64_t p)
+{
+    NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
+    return alloc_storage(c, n, p);
+}
+
+int jwas_hip_dense_layout(jwas_hip_ctx* c, int64_t* n, int64_t* p, int64_t* ld, void** Xd)
+{
+    NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
+    NEED(c, c->X, JWAS_HIP_ESTATE, "no genotype matrix loaded");
+    if (n) *n = c->n;
+    if (p) *p = c->p;
+    if (ld) *ld = c->ld;
+    if (Xd) *Xd = c->X;
+    return JWAS_HIP_OK;
+}
+
+int jwas_hip_get_columns(jwas_hip_ctx* c, int64_t j0, int64_t count, float* out)
+{
+    NEED(c, c && out, JWAS_HIP_EINVAL, "NULL argument");
+    NEED(c, c->X, JWAS_HIP_ESTATE, "no genotype matrix loaded");
+    NEED(c, j0 >= 0 && count >= 0 && j0 + count <= c->p, JWAS_HIP_EINVAL, "column range [%lld,%lld) outside [0,%lld)",
+         (long long)j0, (long long)(j0 + count), (long long)c->p);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (count == 0) return JWAS_HIP_OK;
+    HIPCHK(c, hipMemcpy2DAsync(out, (size_t)4 * c->n, c->X + j0 * c->ld, (size_t)4 * c->ld, (size_t)4 * c->n, (size_t)count,
+                               hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return JWAS_HIP_OK;
+}
+
+int jwas_hip_synth_genotypes(jwas_hip_ctx* c, uint64_t seed, int32_t kind, int32_t center)
+{
+    NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
+    NEED(c, c->X, JWAS_HIP_ESTATE, "allocate the matrix first (jwas_hip_alloc_dense_f32)");
+    NEED(c, kind == 0 || kind == 1, JWAS_HIP_EINVAL, "kind must be 0 (0/1/2 genotypes) or 1 (uniform)");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_synth, dim3((unsigned)c->p), dim3(256), 0, c->stream, c->X, c->n, c->ld,
+                       (uint32_t)seed, (uint32_t)(seed >> 32), (int)kind, (int)center);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return JWAS_HIP_OK;
+}
+
+// ---- precompute ---------------------------------------------------------------------------------
+int jwas_hip_setup_blocks(jwas_hip_ctx* c, int32_t bs, int32_t gram_mode)
+{
+    NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
+    NEED(c, c->X, JWAS_HIP_ESTATE, "no genotype matrix loaded");
+    NEED(c, bs == 64 || bs == 128 || bs == 256 || bs == 512, JWAS_HIP_EINVAL, "block_size must be 64, 128, 256 or 512 (got %d)", bs);
+    NEED(c, gram_mode == JWAS_HIP_GRAM_F64 || gram_mode == JWAS_HIP_GRAM_MFMA, JWAS_HIP_EINVAL, "unknown gram_mode %d", gram_mode);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    free_blocks(c);
+    c->block_size = bs;
+    c->nblocks = (c->p + bs - 1) / bs;
+    HIPCHK(c, hipMalloc(&c->xpx, sizeof(float) * c->p));
+    HIPCHK(c, hipMalloc(&c->gram, sizeof(float) * (size_t)c->nblocks * bs * bs));
+    HIPCHK(c, hipMalloc(&c->partials, sizeof(double) * (size_t)bs * c->nrg * kMaxT));
+    hipLaunchKernelGGL(k_xpx, dim3((unsigned)c->p), dim3(256), 0, c->stream, c->X, c->ld, c->xpx);
+    HIPCHK(c, hipGetLastError());
+    // Gram launches are chunked over blocks so grid.y stays below 65536
+    const int64_t ychunk = 32768;
+    for (int64_t y0 = 0; y0 < c->nblocks; y0 += ychunk) {
+        const int64_t ny = (c->nblocks - y0 < ychunk) ? c->nblocks - y0 : ychunk;
+        const float* Xc = c->X + y0 * bs * c->ld;
+        float* Gc = c->gram + y0 * (int64_t)bs * bs;
+        const int64_t pc = c->p - y0 * bs;
+        if (gram_mode == JWAS_HIP_GRAM_F64)
+            hipLaunchKernelGGL(k_gram_f64, dim3(bs, (unsigned)ny), dim3(256), 0, c->stream, Xc, c->ld, pc, (int)bs, Gc);
+        else {
+            const int nt = bs / 64;
+            hipLaunchKernelGGL(k_gram_mfma, dim3(nt * (nt + 1) / 2, (unsigned)ny), dim3(256), 0, c->stream, Xc, c->ld, pc, (int)bs, Gc);
+        }
+        HIPCHK(c, hipGetLastError());
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return JWAS_HIP_OK;
+}
+
+int jwas_hip_num_blocks(jwas_hip_ctx* c, int64_t* nb, int32_t* bs)
+{
+    NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
+    NEED(c, c->block_size, JWAS_HIP_ESTATE, "jwas_hip_setup_blocks has not been called");
+    if (nb) *nb = c->nblocks;
+    if (bs) *bs = c->block_size;
+    return JWAS_HIP_OK;
+}
+
+int jwas_hip_get_xpx(jwas_hip_ctx* c, float* out)
+{
+    NEED(c, c && out, JWAS_HIP_EINVAL, "NULL argument");
+    NEED(c, c->xpx, JWAS_HIP_ESTATE, "jwas_hip_setup_blocks has not been called");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(out, c->xpx, sizeof(float) * c->p, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return JWAS_HIP_OK;
+}
+
+static int block_dims(jwas_hip_ctx* c, int64_t blk, int* b)
+{
+    NEED(c, c->gram, JWAS_HIP_ESTATE, "jwas_hip_setup_blocks has not been called");
+    NEED(c, blk >= 0 && blk < c->nblocks, JWAS_HIP_EINVAL, "block %lld outside [0,%lld)", (long long)blk, (long long)c->nblocks);
+    const int64_t j0 = blk * c->block_size;
+    *b = (int)((j0 + c->block_size <= c->p) ? c->block_size : c->p - j0);
+    return JWAS_HIP_OK;
+}
+
+int jwas_hip_get_gram(jwas_hip_ctx* c, int64_t blk, float* out)
+{
+    NEED(c, c && out, JWAS_HIP_EINVAL, "NULL argument");
+    int b = 0, rc = block_dims(c, blk, &b);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(out, c->gram + blk * (int64_t)c->block_size * c->block_size, sizeof(float) * b * b, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return JWAS_HIP_OK;
+}
+
+int jwas_hip_set_gram(jwas_hip_ctx* c, int64_t blk, const float* in)
+{
+    NEED(c, c && in, JWAS_HIP_EINVAL, "NULL argument");
+    int b = 0, rc = block_dims(c, blk, &b);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(c->gram + blk * (int64_t)c->block_size * c->block_size, in, sizeof(float) * b * b, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return JWAS_HIP_OK;
+}
+
+// ---- chain state ----------------------------------------------------------------------------------
+int jwas_hip_init_state(jwas_hip_ctx* c, int32_t method, int32_t nt)
+{
+    NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
+    NEED(c, c->X, JWAS_HIP_ESTATE, "no genotype matrix loaded");
+    NEED(c, method >= JWAS_HIP_BAYESC && method <= JWAS_HIP_MTBAYESC1, JWAS_HIP_EINVAL, "unknown method %d", method);
+    if (method == JWAS_HIP_MTBAYESC1) NEED(c, nt >= 2 && nt <= kMaxT, JWAS_HIP_EUNSUP, "multi-trait sampler I supports 2..%d traits (got %d)", kMaxT, nt);
+    else NEED(c, nt == 1, JWAS_HIP_EINVAL, "single-trait method requires ntraits == 1 (got %d)", nt);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    free_state(c);
+    c->method = method; c->ntraits = nt;
+    const size_t fb = sizeof(float) * (size_t)nt * c->p;
+    HIPCHK(c, hipMalloc(&c->alpha, fb));
+    HIPCHK(c, hipMalloc(&c->beta, fb));
+    HIPCHK(c, hipMalloc(&c->delta, fb));          // int32 and float are both 4 bytes
+    HIPCHK(c, hipMalloc(&c->mean_a, fb));
+    HIPCHK(c, hipMalloc(&c->mean_a2, fb));
+    HIPCHK(c, hipMalloc(&c->mean_d, fb));
+    HIPCHK(c, hipMemsetAsync(c->alpha, 0, fb, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->beta, 0, fb, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->delta, 0, fb, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->mean_a, 0, fb, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->mean_a2, 0, fb, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->mean_d, 0, fb, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->r, 0, sizeof(float) * 2 * kMaxT * c->ld, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return JWAS_HIP_OK;
+}
+
+#define NEED_TRAIT(c, trait)                                                                       \
+    NEED(c, c->method >= 0, JWAS_HIP_ESTATE, "jwas_hip_init_state has not been called");           \
+    NEED(c, trait >= 0 && trait < c->ntraits, JWAS_HIP_EINVAL, "trait %d outside [0,%d)", trait, c->ntraits)
+
+int jwas_hip_set_state(jwas_hip_ctx* c, int32_t trait, const float* a, const float* b, const void* d)
+{
+    NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
+    NEED_TRAIT(c, trait);
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t nb = sizeof(float) * c->p, off = (size_t)trait * c->p;
+    if (a) HIPCHK(c, hipMemcpyAsync(c->alpha + off, a, nb, hipMemcpyHostToDevice, c->stream));
+    if (b) HIPCHK(c, hipMemcpyAsync(c->beta + off, b, nb, hipMemcpyHostToDevice, c->stream));
+    if (d) HIPCHK(c, hipMemcpyAsync((float*)c->delta + off, d, nb, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return JWAS_HIP_OK;
+}
+
+int jwas_hip_get_state(jwas_hip_ctx* c, int32_t trait, float* a, float* b, void* d)
+{
+    NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
+    NEED_TRAIT(c, trait);
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t nb = sizeof(float) * c->p, off = (size_t)trait * c->p;
+    if (a) HIPCHK(c, hipMemcpyAsync(a, c->alpha + off, nb, hipMemcpyDeviceToHost, c->stream));
+    if (b) HIPCHK(c, hipMemcpyAsync(b, c->beta + off, nb, hipMemcpyDeviceToHost, c->stream));
+    if (d) HIPCHK(c, hipMemcpyAsync(d, (float*)c->delta + off, nb, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return JWAS_HIP_OK;
+}
+
+int jwas_hip_set_residual(jwas_hip_ctx* c, int32_t trait, const float* rh)
+{
+    NEED(c, c && rh, JWAS_HIP_EINVAL, "NULL argument");
+    NEED_TRAIT(c, trait);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(c->r + (size_t)trait * c->ld, rh, sizeof(float) * c->n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return JWAS_HIP_OK;
+}
+
+int jwas_hip_get_residual(jwas_hip_ctx* c, int32_t trait, float* rh)
+{
+    NEED(c, c && rh, JWAS_HIP_EINVAL, "NULL argument");
+    NEED_TRAIT(c, trait);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(rh, c->r + (size_t)trait * c->ld, sizeof(float) * c->n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return JWAS_HIP_OK;
+}
+
+int jwas_hip_residual_dev(jwas_hip_ctx* c, void** rdev, int64_t* ld)
+{
+    NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
+    NEED(c, c->r, JWAS_HIP_ESTATE, "no genotype matrix loaded");
+    if (rdev) *rdev = c->r;
+    if (ld) *ld = c->ld;
+    return JWAS_HIP_OK;
+}
+
+int jwas_hip_residual_sub_xalpha(jwas_hip_ctx* c, int32_t trait)
+{
+    NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
+    NEED_TRAIT(c, trait);
+    HIPCHK(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_sub_xalpha, dim3(c->nslices), dim3(256), 0, c->stream, c->X, c->ld, c->p,
+                       c->alpha + (size_t)trait * c->p, c->r + (size_t)trait * c->ld);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return JWAS_HIP_OK;
+}
+
+int jwas_hip_mul_alpha(jwas_hip_ctx* c, int32_t trait, float* out)
+{
+    NEED(c, c && out, JWAS_HIP_EINVAL, "NULL argument");
+    NEED_TRAIT(c, trait);
+    HIPCHK(c, hipSetDevice(c->device));
+    float* tmp = nullptr;
+    HIPCHK(c, hipMalloc(&tmp, sizeof(float) * c->ld));
+    hipLaunchKernelGGL(k_mul_alpha, dim3(c->nslices), dim3(256), 0, c->stream, c->X, c->ld, c->p,
+                       c->alpha + (size_t)trait * c->p, tmp);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(out, tmp, sizeof(float) * c->n, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return fail(c, JWAS_HIP_EHIP, "jwas_hip_mul_alpha: %s", hipGetErrorString(e));
+    return JWAS_HIP_OK;
+}
+
+}  // extern "C" (templates need C++ linkage)
+
+// ---- the sweep --------------------------------------------------------------------------------------
+template <int NT>
+static void launch_update(jwas_hip_ctx* c, const float* r_in, float* r_out, const Events* ev, int64_t j0, int b)
+{
+    const int ncg = c->ncg < b ? c->ncg : b;
+    hipLaunchKernelGGL((k_update_partial<NT>), dim3(c->nrg, ncg), dim3(512), 0, c->stream,
+                       c->X, c->ld, r_in, r_out, ev, j0, b, c->nslices, c->nrg, ncg, c->partials, c->block_size);
+}
+
+template <int METHOD, int NSUB>
+static void launch_sample_st(jwas_hip_ctx* c, int64_t blk, int64_t j0, int b, Events* ev_out)
+{
+    hipLaunchKernelGGL((k_sample_block<METHOD, NSUB>), dim3(1), dim3(256), 0, c->stream,
+                       c->dparams, c->partials, c->nrg, c->block_size, j0, b, c->xpx,
+                       c->gram + blk * (int64_t)c->block_size * c->block_size,
+                       c->alpha, c->beta, c->delta, ev_out, c->counters);
+}
+
+template <int NT, int NSUB>
+static void launch_sample_mt(jwas_hip_ctx* c, int64_t blk, int64_t j0, int b, Events* ev_out)
+{
+    hipLaunchKernelGGL((k_sample_block_mt1<NT, NSUB>), dim3(1), dim3(256), 0, c->stream,
+                       c->dparams, c->partials, c->nrg, c->block_size, j0, b, c->p, c->xpx,
+                       c->gram + blk * (int64_t)c->block_size * c->block_size,
+                       c->alpha, c->beta, (float*)c->delta, ev_out, c->counters);
+}
+
+template <int NSUB>
+static void launch_sample(jwas_hip_ctx* c, int64_t blk, int64_t j0, int b, Events* ev_out)
+{
+    switch (c->method) {
+        case JWAS_HIP_BAYESC: launch_sample_st<kBayesC, NSUB>(c, blk, j0, b, ev_out); break;
+        case JWAS_HIP_BAYESB: launch_sample_st<kBayesB, NSUB>(c, blk, j0, b, ev_out); break;
+        case JWAS_HIP_BAYESR: launch_sample_st<kBayesR, NSUB>(c, blk, j0, b, ev_out); break;
+        default:
+            if (c->ntraits == 2) launch_sample_mt<2, NSUB>(c, blk, j0, b, ev_out);
+            else if (c->ntraits == 3) launch_sample_mt<3, NSUB>(c, blk, j0, b, ev_out);
+            else launch_sample_mt<4, NSUB>(c, blk, j0, b, ev_out);
+    }
+}
+
+static int upload_vec(jwas_hip_ctx* c, void** dev, const void* host, size_t bytes)
+{
+    if (!*dev) HIPCHK(c, hipMalloc(dev, bytes));
+    HIPCHK(c, hipMemcpyAsync(*dev, host, bytes, hipMemcpyHostToDevice, c->stream));
+    return JWAS_HIP_OK;
+}
+
+extern "C" {
+
+int jwas_hip_sweep(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_sweep_stats* S)
+{
+    NEED(c, c && P && S, JWAS_HIP_EINVAL, "NULL argument");
+    NEED(c, c->method >= 0, JWAS_HIP_ESTATE, "jwas_hip_init_state has not been called");
+    NEED(c, c->block_size, JWAS_HIP_ESTATE, "jwas_hip_setup_blocks has not been called");
+    NEED(c, P->method == c->method && P->ntraits == c->ntraits, JWAS_HIP_EINVAL,
+         "sweep method/ntraits (%d/%d) differ from init_state (%d/%d)", P->method, P->ntraits, c->method, c->ntraits);
+    const int t = c->ntraits;
+    HIPCHK(c, hipSetDevice(c->device));
+
+    DevParams D;
+    std::memset(&D, 0, sizeof D);
+    D.method = c->method; D.ntraits = t; D.nreps = P->nreps;
+    D.iter = P->iteration; D.seed_lo = (uint32_t)P->seed; D.seed_hi = (uint32_t)(P->seed >> 32); D.marker0 = P->marker_offset;
+    for (int i = 0; i < t * t; ++i) { D.vare[i] = P->vare[i]; D.var_effect[i] = P->var_effect[i]; }
+    if (c->method == JWAS_HIP_MTBAYESC1) {
+        NEED(c, inv_small(P->vare, t, D.Rinv) == 0, JWAS_HIP_EINVAL, "residual covariance matrix is singular");
+        NEED(c, inv_small(P->var_effect, t, D.Ginv) == 0, JWAS_HIP_EINVAL, "marker effect covariance matrix is singular");
+        for (int i = 0; i < (1 << t); ++i) D.log_prior[i] = P->log_prior_states[i];
+    } else {
+        NEED(c, P->vare[0] > 0.f, JWAS_HIP_EINVAL, "residual variance must be positive");
+    }
+    if (c->method == JWAS_HIP_BAYESR) {
+        // bayesr_validate_priors / sigmaSq check (BayesR.jl:9-20,50)
+        NEED(c, P->var_effect[0] > 0.f, JWAS_HIP_EINVAL, "BayesR sigmaSq must be positive.");
+        if (!P->pi_matrix) {
+            double s = 0.0;
+            for (int k = 0; k < 4; ++k) { NEED(c, P->pi_classes[k] >= 0.0, JWAS_HIP_EINVAL, "BayesR pi entries must be nonnegative."); s += P->pi_classes[k]; }
+            NEED(c, std::fabs(s - 1.0) <= 1e-8, JWAS_HIP_EINVAL, "BayesR pi must sum to 1.");
+        }
+        for (int k = 0; k < 4; ++k) { D.pi4[k] = P->pi_classes[k]; D.gamma[k] = P->gamma[k]; }
+        if (P->pi_matrix) { int rc = upload_vec(c, (void**)&c->pi_mat, P->pi_matrix, sizeof(double) * 4 * c->p); if (rc) return rc; D.pi_mat = c->pi_mat; }
+    } else if (c->method == JWAS_HIP_BAYESC || c->method == JWAS_HIP_BAYESB) {
+        D.pi = P->pi;
+        if (P->pi_vec) { int rc = upload_vec(c, (void**)&c->pi_vec, P->pi_vec, sizeof(double) * c->p); if (rc) return rc; D.pi_vec = c->pi_vec; }
+        if (c->method == JWAS_HIP_BAYESB) {
+            NEED(c, P->var_effect_vec, JWAS_HIP_EINVAL, "BayesB needs per-marker effect variances (var_effect_vec)");
+            int rc = upload_vec(c, (void**)&c->var_vec, P->var_effect_vec, sizeof(float) * c->p); if (rc) return rc;
+            D.var_vec = c->var_vec;
+        } else NEED(c, P->var_effect[0] > 0.f, JWAS_HIP_EINVAL, "marker effect variance must be positive");
+    }
+    HIPCHK(c, hipMemcpyAsync(c->dparams, &D, sizeof D, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(&c->ev[0].count, 0, sizeof(int32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->counters, 0, sizeof(unsigned long long) * 4, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev_start, c->stream));
+
+    const int bs = c->block_size;
+    for (int64_t blk = 0; blk < c->nblocks; ++blk) {
+        const int64_t j0 = blk * bs;
+        const int b = (int)((j0 + bs <= c->p) ? bs : c->p - j0);
+        const Events* ev_in = &c->ev[blk & 1];
+        Events* ev_out = &c->ev[(blk + 1) & 1];
+        const float* r_in = c->r + (size_t)(blk & 1) * kMaxT * c->ld;
+        float* r_out = c->r + (size_t)((blk + 1) & 1) * kMaxT * c->ld;
+        switch (t) {
+            case 1: launch_update<1>(c, r_in, r_out, ev_in, j0, b); break;
+            case 2: launch_update<2>(c, r_in, r_out, ev_in, j0, b); break;
+            case 3: launch_update<3>(c, r_in, r_out, ev_in, j0, b); break;
+            default: launch_update<4>(c, r_in, r_out, ev_in, j0, b);
+        }
+        switch (bs) {
+            case 64:  launch_sample<1>(c, blk, j0, b, ev_out); break;
+            case 128: launch_sample<2>(c, blk, j0, b, ev_out); break;
+            case 256: launch_sample<4>(c, blk, j0, b, ev_out); break;
+            default:  launch_sample<8>(c, blk, j0, b, ev_out);
+        }
+    }
+    const Events* ev_last = &c->ev[c->nblocks & 1];
+    const float* r_last = c->r + (size_t)(c->nblocks & 1) * kMaxT * c->ld;   // written by the last k_update_partial
+    const int nfin = t * t + t;
+    switch (t) {   // the finished residual always lands in buffer 0
+        case 1: hipLaunchKernelGGL((k_finish<1>), dim3(c->nslices), dim3(256), 0, c->stream, c->X, c->ld, r_last, c->r, ev_last, c->fin_out); break;
+        case 2: hipLaunchKernelGGL((k_finish<2>), dim3(c->nslices), dim3(256), 0, c->stream, c->X, c->ld, r_last, c->r, ev_last, c->fin_out); break;
+        case 3: hipLaunchKernelGGL((k_finish<3>), dim3(c->nslices), dim3(256), 0, c->stream, c->X, c->ld, r_last, c->r, ev_last, c->fin_out); break;
+        default: hipLaunchKernelGGL((k_finish<4>), dim3(c->nslices), dim3(256), 0, c->stream, c->X, c->ld, r_last, c->r, ev_last, c->fin_out);
+    }
+    const double* gamma_dev = reinterpret_cast<const double*>(reinterpret_cast<const char*>(c->dparams) + offsetof(DevParams, gamma));
+    switch (t) {
+        case 1: hipLaunchKernelGGL((k_marker_stats<1>), dim3(kStatGrid), dim3(256), 0, c->stream, c->method, c->p, c->alpha, c->beta, c->delta, gamma_dev, c->stat_out); break;
+        case 2: hipLaunchKernelGGL((k_marker_stats<2>), dim3(kStatGrid), dim3(256), 0, c->stream, c->method, c->p, c->alpha, c->beta, c->delta, gamma_dev, c->stat_out); break;
+        case 3: hipLaunchKernelGGL((k_marker_stats<3>), dim3(kStatGrid), dim3(256), 0, c->stream, c->method, c->p, c->alpha, c->beta, c->delta, gamma_dev, c->stat_out); break;
+        default: hipLaunchKernelGGL((k_marker_stats<4>), dim3(kStatGrid), dim3(256), 0, c->stream, c->method, c->p, c->alpha, c->beta, c->delta, gamma_dev, c->stat_out);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->ev_stop, c->stream));
+
+    double* h_fin = c->host_buf;
+    double* h_stat = h_fin + (size_t)c->nslices * nfin;
+    unsigned long long* h_cnt = reinterpret_cast<unsigned long long*>(h_stat + (size_t)kStatGrid * kNStat);
+    HIPCHK(c, hipMemcpyAsync(h_fin, c->fin_out, sizeof(double) * c->nslices * nfin, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(h_stat, c->stat_out, sizeof(double) * kStatGrid * kNStat, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(h_cnt, c->counters, sizeof(unsigned long long) * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+
+    std::memset(S, 0, sizeof *S);
+    for (int s = 0; s < c->nslices; ++s) {
+        const double* f = h_fin + (size_t)s * nfin;
+        for (int a = 0; a < t; ++a) {
+            for (int b2 = 0; b2 < t; ++b2) S->resid_ss[a * t + b2] += f[a * t + b2];
+            S->resid_sum[a] += f[t * t + a];
+        }
+    }
+    for (int g = 0; g < kStatGrid; ++g) {
+        const double* v = h_stat + (size_t)g * kNStat;
+        for (int a = 0; a < t; ++a) S->sum_delta[a] += v[a];
+        for (int i = 0; i < t * t; ++i) { S->alpha_ss[i] += v[4 + i]; S->beta_ss[i] += v[20 + i]; }
+        for (int k = 0; k < 4; ++k) S->class_counts[k] += v[36 + k];
+        S->bayesr_ssq += v[40]; S->bayesr_nnz += v[41];
+        for (int q = 0; q < (1 << t) && q < kMaxStates; ++q) S->state_counts[q] += v[42 + q];
+    }
+    S->n_events = (double)h_cnt[0];
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev_start, c->ev_stop));
+    S->sweep_ms = ms;
+    return JWAS_HIP_OK;
+}
+
+// ---- posterior accumulators ---------------------------------------------------------------------------
+int jwas_hip_accumulate(jwas_hip_ctx* c, double k)
+{
+    NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
+    NEED(c, c->method >= 0, JWAS_HIP_ESTATE, "jwas_hip_init_state has not been called");
+    NEED(c, k >= 1.0, JWAS_HIP_EINVAL, "nsamples must be >= 1");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int64_t count = (int64_t)c->ntraits * c->p;
+    hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream, count,
+                       (int)(c->method == JWAS_HIP_BAYESR), k, c->alpha, c->delta, c->mean_a, c->mean_a2, c->mean_d);
+    HIPCHK(c, hipGetLastError());
+    return JWAS_HIP_OK;
+}
+
+int jwas_hip_get_posterior(jwas_hip_ctx* c, int32_t trait, float* ma, float* ma2, float* md)
+{
+    NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
+    NEED_TRAIT(c, trait);
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t nb = sizeof(float) * c->p, off = (size_t)trait * c->p;
+    if (ma) HIPCHK(c, hipMemcpyAsync(ma, c->mean_a + off, nb, hipMemcpyDeviceToHost, c->stream));
+    if (ma2) HIPCHK(c, hipMemcpyAsync(ma2, c->mean_a2 + off, nb, hipMemcpyDeviceToHost, c->stream));
+    if (md) HIPCHK(c, hipMemcpyAsync(md, c->mean_d + off, nb, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return JWAS_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,937 @@
+// kernels.hpp -- gfx950 (CDNA4, wave64) kernels of the marker-effect Gibbs sweep.
+//
+// Data layout in HBM (DESIGN.md "Layout"):
+//   X      float [p][ld]   marker-major; ld = n rounded up to 256 rows, pad rows are zero
+//   r      float [t][ld]   residual vectors, pad rows zero
+//   alpha/beta float [t][p], delta float [t][p] (0/1) or int32 [p] (BayesR classes)
+//   gram   float           consecutive b x b row-major symmetric blocks, one per marker block
+//
+// One sweep = for each marker block B_i of b columns:
+//   k_update_partial  (all CUs, HBM-bound): every wavefront owns a 256-row slice of r in
+//                     registers; it first applies the previous block's effect changes
+//                     r += X[:,events] * d  (sparse exit update of BayesABC.jl:181-185), then forms
+//                     the partial block RHS X_b[slice,:]' r[slice] (block_rhs!,
+//                     tools4genotypes.jl:59-78) with wave64 shuffle reductions, fp64-accumulated.
+//   k_sample_block    (one workgroup): reduces the row-group partials to rhs_b, then ONE wavefront
+//                     runs the exact single-site chain of the block (BayesABC.jl:153-179) by
+//                     speculative parallel evaluation: all lanes evaluate their marker against the
+//                     current rhs; the first lane whose effect changes commits, its Gram column
+//                     corrects every rhs (BayesABC.jl:169,172), the rest re-evaluate.  Lanes before
+//                     the first change are final, so the result is the sequential chain's.
+//
+// Arithmetic contract (must match oracle/jwas_oracle.c): compiled with -ffp-contract=off; every
+// fused operation is an explicit fmaf/fma; transcendentals are evaluated in double and rounded to
+// the type the reference holds; inner products accumulate exact fp32 products in double.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "rng.hpp"
+
+namespace jw {
+
+constexpr int kSliceRows = 256;      // rows of r owned by one workgroup of k_update_partial
+constexpr int kMaxBlock  = 512;      // largest marker block
+constexpr int kMaxT      = 4;        // traits
+constexpr int kMaxStates = 16;
+
+enum Method { kBayesC = 0, kBayesB = 1, kBayesR = 2, kMTBayesC1 = 3 };
+
+// Effect changes of one marker block, consumed by the next k_update_partial.
+struct Events {
+    int32_t count;
+    int32_t pad[3];
+    int32_t idx[kMaxBlock];                 // local column index of the changed marker
+    float   delta[kMaxT][kMaxBlock];        // alpha_old - alpha_new per trait (the axpy coefficient)
+};
+
+// Per-sweep scalars, device resident (rewritten before every sweep).
+struct DevParams {
+    int32_t  method, ntraits, nreps;
+    uint32_t iter, seed_lo, seed_hi, marker0, pad0;
+    float    vare[16], var_effect[16];
+    float    Rinv[16], Ginv[16];            // t x t inverses (host: double Gauss-Jordan -> float)
+    double   pi;
+    double   pi4[4], gamma[4];
+    double   log_prior[kMaxStates];
+    const float*  var_vec;                  // p, BayesB
+    const double* pi_vec;                   // p
+    const double* pi_mat;                   // p x 4
+};
+
+// ---------------------------------------------------------------------------------------------
+// wave64 reductions
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <int NV>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double* lds /* [nwaves][NV] */, int nwaves)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = wave_sum(v[i]);
+    if (lane == 0)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) lds[wave * NV + i] = v[i];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        double s = 0.0;
+        for (int w = 0; w < nwaves; ++w) s += lds[w * NV + i];
+        v[i] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K_A: apply the previous block's events to the residual, then the partial block RHS.
+//
+// grid = (nrg, ncg), block = 512 (8 waves).  Row group rg owns 8 consecutive 256-row slices, one
+// per wave (lane l holds rows 4l..4l+3 of its slice as a float4 / four doubles in registers).
+// Column group g owns columns g, g+ncg, ... of the block.  All 8 waves walk the same columns, so
+// one column step reads 8 KB contiguous of X; the 8 per-wave dot products are combined through
+// LDS and ONE partial per (column, row group) goes to HBM: partials[(t*nrg + rg)*bstride + c].
+//
+// The sparse exit update r += X[:,events]*d (BayesABC.jl:181-185) is recomputed by every column
+// group of a row group (reads r_in, never r_out, so there is no read/write race between groups);
+// only column group 0 stores the updated slice to r_out.
+// ---------------------------------------------------------------------------------------------
+constexpr int kRowGroupSlices = 8;
+constexpr int kColChunk = 64;        // columns per LDS flush
+
+template <int NT>
+__global__ __launch_bounds__(512) void k_update_partial(const float* __restrict__ X, int64_t ld,
+                                                        const float* __restrict__ r_in, float* __restrict__ r_out,
+                                                        const Events* __restrict__ ev,
+                                                        int64_t j0, int b, int nslices, int nrg, int ncg,
+                                                        double* __restrict__ partials, int bstride)
+{
+    __shared__ double red[kRowGroupSlices][kColChunk][NT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rg = blockIdx.x, g = blockIdx.y;
+    const int slice = rg * kRowGroupSlices + wave;
+    const bool active = slice < nslices;
+    const int64_t row = (int64_t)(active ? slice : 0) * kSliceRows + lane * 4;
+    const int ncols = (b - g + ncg - 1) / ncg;            // columns of this group (b > g guaranteed by launch)
+
+    // (1) the first batch of column loads does not depend on r: issue it before the update.
+    constexpr int U = 8;
+    const float* xcol = X + (j0 + g) * ld + row;
+    const int64_t cstride = (int64_t)ncg * ld;
+    // (loads are unconditional from clamped, always-valid addresses: a select between a load and a
+    //  constant makes hipcc pick between pointers and emit flat/scratch accesses)
+    float4 xv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        xv[u] = *reinterpret_cast<const float4*>(xcol + (u < ncols ? u : ncols - 1) * cstride);
+
+    // (2) sparse exit update of the previous block: sequential fmaf in marker order, bit-identical
+    //     to the oracle's per-marker axpy sequence.
+    float4 rv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) rv[t] = *reinterpret_cast<const float4*>(r_in + t * ld + row);
+    const int ne = ev->count;
+    if (active) {
+#pragma unroll 4
+        for (int e = 0; e < ne; ++e) {
+            const float4 x = *reinterpret_cast<const float4*>(X + (int64_t)ev->idx[e] * ld + row);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float d = ev->delta[t][e];
+                rv[t].x = fmaf(d, x.x, rv[t].x); rv[t].y = fmaf(d, x.y, rv[t].y);
+                rv[t].z = fmaf(d, x.z, rv[t].z); rv[t].w = fmaf(d, x.w, rv[t].w);
+            }
+        }
+        if (g == 0)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) *reinterpret_cast<float4*>(r_out + t * ld + row) = rv[t];
+    }
+    // an inactive wave (slice beyond the matrix) aliases slice 0 for addressing and contributes 0
+    const float keep = active ? 1.f : 0.f;
+    double rd[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        rd[t][0] = rv[t].x * keep; rd[t][1] = rv[t].y * keep; rd[t][2] = rv[t].z * keep; rd[t][3] = rv[t].w * keep;
+    }
+
+    // (3) partial block RHS, U columns in flight per wave, kColChunk columns per LDS flush.
+    for (int i0 = 0; i0 < ncols; i0 += kColChunk) {
+        const int iend = (i0 + kColChunk < ncols) ? i0 + kColChunk : ncols;
+        for (int ib = i0; ib < iend; ib += U) {
+            if (ib != 0) {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    xv[u] = *reinterpret_cast<const float4*>(xcol + (ib + u < ncols ? ib + u : ncols - 1) * cstride);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    double acc = (double)xv[u].x * rd[t][0];
+                    acc = fma((double)xv[u].y, rd[t][1], acc);
+                    acc = fma((double)xv[u].z, rd[t][2], acc);
+                    acc = fma((double)xv[u].w, rd[t][3], acc);
+                    acc = wave_sum(acc);
+                    if (lane == 0 && ib + u < iend) red[wave][ib + u - i0][t] = acc;
+                }
+            }
+        }
+        __syncthreads();
+        for (int q = tid; q < (iend - i0) * NT; q += 512) {
+            const int i = q / NT, t = q - i * NT;
+            double s = 0.0;
+#pragma unroll
+            for (int w = 0; w < kRowGroupSlices; ++w) s += red[w][i][t];
+            const int c = g + (i0 + i) * ncg;
+            partials[((int64_t)t * nrg + rg) * bstride + c] = s;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K_F: apply the last block's events (r_in -> r_out, may alias) and reduce r'r / sum(r) per
+// slice.  out[slice][NT*NT + NT]
+// ---------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void k_finish(const float* __restrict__ X, int64_t ld, const float* r_in,
+                                                float* r_out,
+                                                const Events* __restrict__ ev, double* __restrict__ out)
+{
+    __shared__ double red[4 * (NT * NT + NT)];
+    const int tid = threadIdx.x;
+    const int64_t row = (int64_t)blockIdx.x * kSliceRows + tid;
+    float rv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) rv[t] = r_in[t * ld + row];
+    const int ne = ev->count;
+    const float* xrow = X + row;
+#pragma unroll 4
+    for (int e = 0; e < ne; ++e) {
+        const float x = xrow[(int64_t)ev->idx[e] * ld];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) rv[t] = fmaf(ev->delta[t][e], x, rv[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) r_out[t * ld + row] = rv[t];
+    double v[NT * NT + NT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a) {
+#pragma unroll
+        for (int c = 0; c < NT; ++c) v[a * NT + c] = (double)rv[a] * (double)rv[c];
+        v[NT * NT + a] = (double)rv[a];
+    }
+    block_sum<NT * NT + NT>(v, red, 4);
+    if (tid == 0)
+#pragma unroll
+        for (int i = 0; i < NT * NT + NT; ++i) out[(int64_t)blockIdx.x * (NT * NT + NT) + i] = v[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// scalar samplers (must mirror oracle/jwas_oracle.c operation for operation)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float logf_via_double(float x) { return (float)log((double)x); }
+
+// BayesA/B/C -- bayesabc_update_marker! (BayesABC.jl:24-58).  Marker constants that do not depend on
+// the running rhs are hoisted; the inclusion test u < 1/(1+exp(lp0-l1)) is evaluated in the
+// equivalent log-odds form (lp0-l1) < log((1-u)/u) so no exp sits on the serial path.
+struct AbcMarker {
+    float  d, iv_unused, lv, invLhs, loglhs, sq, var_j;
+    double lp0, lp1, thr, z;
+    float  beta_excl;                       // (float)(z*sqrt(var_j))   (BayesABC.jl:54)
+    __device__ __forceinline__ void prepare(float d_, float var_, double pi_, float ie, double u, double z_)
+    {
+        d = d_; var_j = var_; z = z_;
+        const float iv = 1.0f / var_;
+        lv  = logf_via_double(var_);
+        lp0 = log(pi_);
+        lp1 = log(1.0 - pi_);
+        const float lhs = d_ * ie + iv;                     // :37
+        invLhs = 1.0f / lhs;                                // :38
+        loglhs = logf_via_double(lhs);
+        sq  = sqrtf(invLhs);
+        thr = log((1.0 - u) / u);
+        beta_excl = (float)(z_ * (double)sqrtf(var_));
+    }
+    // returns include flag; gHat out
+    __device__ __forceinline__ bool evaluate(float rhs_b, float a_old, float ie, float& gHat) const
+    {
+        const float rhs   = (rhs_b + d * a_old) * ie;                       // :36
+        gHat              = rhs * invLhs;                                   // :39
+        const float inner = (loglhs + lv) - gHat * rhs;                     // fp32 part of :40
+        const double l1   = -0.5 * (double)inner + lp1;                     // :40
+        return (lp0 - l1) < thr;                                            // :41,:44
+    }
+    __device__ __forceinline__ float alpha_incl(float gHat) const
+    {
+        return (float)((double)gHat + z * (double)sq);                      // :46
+    }
+};
+
+// BayesR (BayesR.jl:56-96)
+struct BayesRMarker {
+    float  d, die;
+    double lpi[4], invLhs[4], cA[4], z;
+    double u;
+    __device__ __forceinline__ void prepare(float d_, float sigma_sq, const double* pi_j, const double* gamma,
+                                            float ie, double u_, double z_)
+    {
+        d = d_; u = u_; z = z_;
+        die = d_ * ie;
+        lpi[0] = log(pi_j[0]); invLhs[0] = 0.0; cA[0] = 0.0;
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {
+            const double varE = gamma[k] * (double)sigma_sq;
+            const double lhs  = (double)die + 1.0 / varE;
+            invLhs[k] = 1.0 / lhs;
+            cA[k]  = log(invLhs[k]) - log(varE);
+            lpi[k] = log(pi_j[k]);
+        }
+    }
+    // returns class 0..3 and the candidate alpha for that class
+    __device__ __forceinline__ int evaluate(float rhs_b, float a_old, float ie, float& a_new) const
+    {
+        const float rhs = (rhs_b + d * a_old) * ie;                         // :60
+        double lp[4], bh[4];
+        lp[0] = lpi[0]; bh[0] = 0.0;
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {
+            bh[k] = invLhs[k] * (double)rhs;
+            lp[k] = 0.5 * (cA[k] + bh[k] * (double)rhs) + lpi[k];           // :71
+        }
+        double mx = lp[0];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) if (lp[k] > mx) mx = lp[k];
+        double se = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) se += exp(lp[k] - mx);
+        const double log_norm = mx + log(se);
+        int cls = 0;
+        double cp = exp(lp[0] - log_norm);
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {
+            const double pk = exp(lp[k] - log_norm);
+            if (cls == k - 1 && cp <= u) { cls = k; cp += pk; }
+        }
+        double an = 0.0;
+#pragma unroll
+        for (int k = 1; k < 4; ++k) if (cls == k) an = bh[k] + z * sqrt(invLhs[k]);   // :93
+        a_new = (float)an;
+        return cls;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// K_S (single trait): reduce slice partials, then one wavefront samples the block.
+// grid = 1, block = 256 (one wave per SIMD: the sampler wave may use the whole register file).
+// METHOD in {kBayesC, kBayesB, kBayesR}.  NSUB = block/64.
+// ---------------------------------------------------------------------------------------------
+template <int METHOD, int NSUB>
+__global__ __launch_bounds__(256) void k_sample_block(const DevParams* __restrict__ P,
+                                                      const double* __restrict__ partials, int nrg, int bstride,
+                                                       int64_t j0, int b,
+                                                       const float* __restrict__ xpx,
+                                                       const float* __restrict__ gram,   // b x b of this block
+                                                       float* __restrict__ alpha, float* __restrict__ beta,
+                                                       void* __restrict__ delta_v,
+                                                       Events* __restrict__ ev_out,
+                                                       unsigned long long* __restrict__ counters)
+{
+    __shared__ float rhs_lds[NSUB * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    // phase 1: rhs_b[c] = sum over row groups (fp64, fixed order), rounded once to fp32
+    for (int c = tid; c < b; c += 256) {
+        double s = 0.0;
+        for (int rg = 0; rg < nrg; ++rg) s += partials[(int64_t)rg * bstride + c];
+        rhs_lds[c] = (float)s;
+    }
+    __syncthreads();
+    if (wave != 0) {
+        // warm this XCD's L2 with the block's Gram so event-column reads are L2 hits
+        float sink = 0.f;
+        for (int64_t i = (int64_t)(tid - 64) * 32; i < (int64_t)b * b; i += (int64_t)(256 - 64) * 32) sink += gram[i];
+        asm volatile("" ::"v"(sink));
+        return;
+    }
+
+    // phase 2: wave 0, lane l owns markers c = 64*s + l of the block
+    const float ie = 1.0f / P->vare[0];
+    float* delta_f = reinterpret_cast<float*>(delta_v);
+    int32_t* delta_i = reinterpret_cast<int32_t*>(delta_v);
+
+    float rhs[NSUB], a_cur[NSUB], a_start[NSUB], b_out[NSUB], d_out[NSUB];
+    bool  valid[NSUB];
+#pragma unroll
+    for (int s = 0; s < NSUB; ++s) {
+        const int c = 64 * s + lane;
+        valid[s] = c < b;
+        rhs[s] = valid[s] ? rhs_lds[c] : 0.f;
+        a_cur[s] = valid[s] ? alpha[j0 + c] : 0.f;
+        a_start[s] = a_cur[s];
+        b_out[s] = 0.f; d_out[s] = 0.f;
+    }
+    const int nreps = P->nreps > 0 ? P->nreps : b;
+    RngKey key{P->seed_lo, P->seed_hi, P->iter, 0u};
+
+    for (int rep = 0; rep < nreps; ++rep) {
+        key.rep = (uint32_t)rep;
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s) {
+            const int c = 64 * s + lane;
+            const int64_t j = j0 + c;
+            const uint32_t marker = P->marker0 + (uint32_t)j;
+            unsigned long long pending = __ballot(valid[s]);
+            if (pending == 0ull) continue;
+
+            AbcMarker am; BayesRMarker bm;
+            if (valid[s]) {
+                const double u = draw_uniform(key, marker, 0u);
+                const double z = draw_normal(key, marker, 0u);
+                if constexpr (METHOD == kBayesR) {
+                    const double* pj = P->pi_mat ? (P->pi_mat + 4 * j) : P->pi4;
+                    bm.prepare(xpx[j], P->var_effect[0], pj, P->gamma, ie, u, z);
+                } else {
+                    const float var_j = (METHOD == kBayesB) ? P->var_vec[j] : P->var_effect[0];
+                    const double pi_j = P->pi_vec ? P->pi_vec[j] : P->pi;
+                    am.prepare(xpx[j], var_j, pi_j, ie, u, z);
+                }
+            }
+            // speculative rounds
+            while (true) {
+                bool is_event = false, incl = false;
+                float a_new = 0.f, gHat = 0.f;
+                int cls = 0;
+                const bool live = valid[s] && ((pending >> lane) & 1ull);
+                if (live) {
+                    if constexpr (METHOD == kBayesR) {
+                        cls = bm.evaluate(rhs[s], a_cur[s], ie, a_new);
+                        is_event = (cls != 0) || (a_cur[s] != 0.f);
+                    } else {
+                        incl = am.evaluate(rhs[s], a_cur[s], ie, gHat);
+                        is_event = incl || (a_cur[s] != 0.f);
+                    }
+                }
+                const unsigned long long m = __ballot(is_event) & pending;
+                const int k = m ? __builtin_ctzll(m) : 64;
+                // lanes before k (and k itself) are final with the values just computed
+                float Dl = 0.f;
+                if (live && lane <= k) {
+                    if constexpr (METHOD == kBayesR) {
+                        d_out[s] = (float)(cls + 1);                       // stored as class 1..4
+                        const float an = (cls == 0) ? 0.f : a_new;
+                        Dl = a_cur[s] - an;
+                        a_cur[s] = an;
+                    } else {
+                        if (incl) { const float an = am.alpha_incl(gHat); d_out[s] = 1.f; b_out[s] = an; Dl = a_cur[s] - an; a_cur[s] = an; }
+                        else      { d_out[s] = 0.f; b_out[s] = am.beta_excl; Dl = a_cur[s]; a_cur[s] = 0.f; }
+                    }
+                }
+                if (k == 64) break;
+                pending = (k == 63) ? 0ull : (pending & ~((2ull << k) - 1ull));
+                const float D = __shfl(Dl, k, 64);
+                if (D != 0.f) {
+                    const float* grow = gram + (int64_t)(64 * s + k) * b;   // symmetric: row = column
+#pragma unroll
+                    for (int s2 = 0; s2 < NSUB; ++s2) {
+                        const int c2 = 64 * s2 + lane;
+                        if (c2 < b) rhs[s2] = fmaf(D, grow[c2], rhs[s2]);   // BayesABC.jl:169,172
+                    }
+                }
+                if (pending == 0ull) break;
+            }
+        }
+    }
+
+    // write back state and the event list of this block
+    int base = 0;
+#pragma unroll
+    for (int s = 0; s < NSUB; ++s) {
+        const int c = 64 * s + lane;
+        if (valid[s]) {
+            alpha[j0 + c] = a_cur[s];
+            if constexpr (METHOD == kBayesR) delta_i[j0 + c] = (int32_t)d_out[s];
+            else { beta[j0 + c] = b_out[s]; delta_f[j0 + c] = d_out[s]; }
+        }
+        const float dtot = a_start[s] - a_cur[s];
+        const bool changed = valid[s] && (a_start[s] != a_cur[s]);
+        const unsigned long long cm = __ballot(changed);
+        if (changed) {
+            const int pos = base + __popcll(cm & ((1ull << lane) - 1ull));
+            ev_out->idx[pos] = (int32_t)(j0 + c);
+            ev_out->delta[0][pos] = dtot;
+        }
+        base += __popcll(cm);
+    }
+    if (lane == 0) {
+        ev_out->count = base;
+        atomicAdd(&counters[0], (unsigned long long)base);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K_S (multi-trait BayesC, Gibbs sampler I; MTBayesABC.jl:57-127, block form :243-333)
+// ---------------------------------------------------------------------------------------------
+template <int NT, int NSUB>
+__global__ __launch_bounds__(256) void k_sample_block_mt1(const DevParams* __restrict__ P,
+                                                          const double* __restrict__ partials, int nrg, int bstride,
+                                                           int64_t j0, int b, int64_t p,
+                                                           const float* __restrict__ xpx,
+                                                           const float* __restrict__ gram,
+                                                           float* __restrict__ alpha, float* __restrict__ beta,
+                                                           float* __restrict__ delta,
+                                                           Events* __restrict__ ev_out,
+                                                           unsigned long long* __restrict__ counters)
+{
+    __shared__ float rhs_lds[NT][NSUB * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int c = tid; c < b; c += 256) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            double s = 0.0;
+            for (int rg = 0; rg < nrg; ++rg) s += partials[((int64_t)t * nrg + rg) * bstride + c];
+            rhs_lds[t][c] = (float)s;
+        }
+    }
+    __syncthreads();
+    if (wave != 0) {
+        float sink = 0.f;
+        for (int64_t i = (int64_t)(tid - 64) * 32; i < (int64_t)b * b; i += (int64_t)(256 - 64) * 32) sink += gram[i];
+        asm volatile("" ::"v"(sink));
+        return;
+    }
+
+    float Rinv[NT][NT], Ginv[NT][NT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int c = 0; c < NT; ++c) { Rinv[a][c] = P->Rinv[a * NT + c]; Ginv[a][c] = P->Ginv[a * NT + c]; }
+
+    float rhs[NT][NSUB], a_cur[NT][NSUB], a_start[NT][NSUB], b_cur[NT][NSUB], d_cur[NT][NSUB];
+    bool valid[NSUB];
+#pragma unroll
+    for (int s = 0; s < NSUB; ++s) {
+        const int c = 64 * s + lane;
+        valid[s] = c < b;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            rhs[t][s]   = valid[s] ? rhs_lds[t][c] : 0.f;
+            a_cur[t][s] = valid[s] ? alpha[(int64_t)t * p + j0 + c] : 0.f;
+            b_cur[t][s] = valid[s] ? beta[(int64_t)t * p + j0 + c] : 0.f;
+            d_cur[t][s] = valid[s] ? delta[(int64_t)t * p + j0 + c] : 0.f;
+            a_start[t][s] = a_cur[t][s];
+        }
+    }
+    const int nreps = P->nreps > 0 ? P->nreps : b;
+    RngKey key{P->seed_lo, P->seed_hi, P->iter, 0u};
+
+    for (int rep = 0; rep < nreps; ++rep) {
+        key.rep = (uint32_t)rep;
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s) {
+            const int c = 64 * s + lane;
+            const int64_t j = j0 + c;
+            const uint32_t marker = P->marker0 + (uint32_t)j;
+            unsigned long long pending = __ballot(valid[s]);
+            if (pending == 0ull) continue;
+            double u[NT], z[NT];
+            float dj = 0.f;
+            if (valid[s]) {
+                dj = xpx[j];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) { u[t] = draw_uniform(key, marker, (uint32_t)t); z[t] = draw_normal(key, marker, (uint32_t)t); }
+            }
+            while (true) {
+                const bool live = valid[s] && ((pending >> lane) & 1ull);
+                float an[NT], bn[NT], dn[NT], Dl[NT];
+                bool is_event = false;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) { an[t] = a_cur[t][s]; bn[t] = b_cur[t][s]; dn[t] = d_cur[t][s]; Dl[t] = 0.f; }
+                if (live) {
+                    float w[NT];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) w[t] = rhs[t][s] + dj * a_cur[t][s];                 // :82
+#pragma unroll
+                    for (int k = 0; k < NT; ++k) {                                                  // :85
+                        const float Ginv11 = Ginv[k][k];
+                        const float C11 = Ginv11 + Rinv[k][k] * dj;                                 // :89
+                        float rhs0 = 0.f, c12b = 0.f, wR = 0.f;
+#pragma unroll
+                        for (int m = 0; m < NT; ++m) {
+                            wR = wR + w[m] * Rinv[m][k];
+                            if (m == k) continue;
+                            const float C12m = Ginv[k][m] + (dj * dn[m]) * Rinv[k][m];              // :90
+                            rhs0 = rhs0 + Ginv[k][m] * bn[m];
+                            c12b = c12b + C12m * bn[m];
+                        }
+                        rhs0 = -rhs0;                                                               // :93
+                        const float invLhs0 = 1.0f / Ginv11;
+                        const float gHat0 = rhs0 * invLhs0;
+                        const float invLhs1 = 1.0f / C11;
+                        const float rhs1 = wR - c12b;                                               // :96
+                        const float gHat1 = rhs1 * invLhs1;
+                        unsigned s0 = 0u;
+#pragma unroll
+                        for (int m = 0; m < NT; ++m) if (m != k && dn[m] != 0.f) s0 |= 1u << m;
+                        const unsigned s1 = s0 | (1u << k);
+                        const float in0 = logf_via_double(Ginv11) - (gHat0 * gHat0) * Ginv11;       // :104
+                        const float in1 = logf_via_double(C11) - (gHat1 * gHat1) * C11;             // :105
+                        const double* lpr = P->log_prior;
+                        const double logDelta0 = -0.5 * (double)in0 + lpr[s0];
+                        const double logDelta1 = -0.5 * (double)in1 + lpr[s1];
+                        const double thr = log((1.0 - u[k]) / u[k]);
+                        if ((logDelta0 - logDelta1) < thr) {                                        // :107-111
+                            dn[k] = 1.f;
+                            bn[k] = (float)((double)gHat1 + z[k] * (double)sqrtf(invLhs1));
+                            Dl[k] = an[k] - bn[k];
+                            an[k] = bn[k];
+                        } else {                                                                    // :112-119
+                            bn[k] = (float)((double)gHat0 + z[k] * (double)sqrtf(invLhs0));
+                            dn[k] = 0.f;
+                            Dl[k] = an[k];
+                            an[k] = 0.f;
+                        }
+                    }
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) is_event = is_event || (Dl[t] != 0.f);
+                }
+                const unsigned long long m = __ballot(is_event) & pending;
+                const int k = m ? __builtin_ctzll(m) : 64;
+                if (live && lane <= k) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) { a_cur[t][s] = an[t]; b_cur[t][s] = bn[t]; d_cur[t][s] = dn[t]; }
+                }
+                if (k == 64) break;
+                pending = (k == 63) ? 0ull : (pending & ~((2ull << k) - 1ull));
+                const float* grow = gram + (int64_t)(64 * s + k) * b;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const float D = __shfl(Dl[t], k, 64);
+                    if (D != 0.f) {
+#pragma unroll
+                        for (int s2 = 0; s2 < NSUB; ++s2) {
+                            const int c2 = 64 * s2 + lane;
+                            if (c2 < b) rhs[t][s2] = fmaf(D, grow[c2], rhs[t][s2]);                 // :311,317
+                        }
+                    }
+                }
+                if (pending == 0ull) break;
+            }
+        }
+    }
+
+    int base = 0;
+#pragma unroll
+    for (int s = 0; s < NSUB; ++s) {
+        const int c = 64 * s + lane;
+        bool changed = false;
+        if (valid[s]) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                alpha[(int64_t)t * p + j0 + c] = a_cur[t][s];
+                beta[(int64_t)t * p + j0 + c]  = b_cur[t][s];
+                delta[(int64_t)t * p + j0 + c] = d_cur[t][s];
+                changed = changed || (a_start[t][s] != a_cur[t][s]);
+            }
+        }
+        const unsigned long long cm = __ballot(changed);
+        if (changed) {
+            const int pos = base + __popcll(cm & ((1ull << lane) - 1ull));
+            ev_out->idx[pos] = (int32_t)(j0 + c);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) ev_out->delta[t][pos] = a_start[t][s] - a_cur[t][s];
+        }
+        base += __popcll(cm);
+    }
+    if (lane == 0) {
+        ev_out->count = base;
+        atomicAdd(&counters[0], (unsigned long long)base);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// post-sweep reductions over markers (K11).  out[blockIdx.x][kNStat]
+// ---------------------------------------------------------------------------------------------
+constexpr int kNStat = 4 + 16 + 16 + 4 + 2 + 16;   // sum_delta[4] alpha_ss[16] beta_ss[16] class[4] ssq,nnz state[16]
+
+template <int NT>
+__global__ __launch_bounds__(256) void k_marker_stats(int method, int64_t p, const float* __restrict__ alpha,
+                                                      const float* __restrict__ beta, const void* __restrict__ delta_v,
+                                                      const double* __restrict__ gamma_dev /*P->gamma*/,
+                                                      double* __restrict__ out)
+{
+    __shared__ double red[4 * kNStat];
+    double v[kNStat];
+#pragma unroll
+    for (int i = 0; i < kNStat; ++i) v[i] = 0.0;
+    const float* delta_f = reinterpret_cast<const float*>(delta_v);
+    const int32_t* delta_i = reinterpret_cast<const int32_t*>(delta_v);
+    const int64_t chunk = (p + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = (int64_t)blockIdx.x * chunk, hi = (lo + chunk < p) ? lo + chunk : p;
+    for (int64_t j = lo + threadIdx.x; j < hi; j += 256) {
+        if (method == kBayesR) {
+            const int cls = delta_i[j];
+            const double a = alpha[j];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (cls == k + 1) v[36 + k] += 1.0;
+            if (cls > 1) { v[40] += (a * a) / gamma_dev[cls - 1]; v[41] += 1.0; }
+            v[4] += a * a;
+        } else {
+            unsigned st = 0u;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const double dl = delta_f[(int64_t)t * p + j];
+                v[t] += dl;
+                if (dl != 0.0) st |= 1u << t;
+            }
+#pragma unroll
+            for (int a = 0; a < NT; ++a)
+#pragma unroll
+                for (int c = 0; c < NT; ++c) {
+                    v[4 + a * NT + c]  += (double)alpha[(int64_t)a * p + j] * (double)alpha[(int64_t)c * p + j];
+                    v[20 + a * NT + c] += (double)beta[(int64_t)a * p + j] * (double)beta[(int64_t)c * p + j];
+                }
+#pragma unroll
+            for (int q = 0; q < (1 << NT); ++q) if (st == (unsigned)q) v[42 + q] += 1.0;
+        }
+    }
+    block_sum<kNStat>(v, red, 4);
+    if (threadIdx.x == 0)
+#pragma unroll
+        for (int i = 0; i < kNStat; ++i) out[(int64_t)blockIdx.x * kNStat + i] = v[i];
+}
+
+// running posterior means (output.jl:568-577)
+__global__ __launch_bounds__(256) void k_accumulate(int64_t count, int delta_is_class, double k,
+                                                    const float* __restrict__ alpha, const void* __restrict__ delta_v,
+                                                    float* __restrict__ mean_a, float* __restrict__ mean_a2,
+                                                    float* __restrict__ mean_d)
+{
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= count) return;
+    const float a = alpha[j];
+    mean_a[j]  = (float)((double)mean_a[j] + ((double)(a - mean_a[j])) / k);
+    const float a2 = a * a;
+    mean_a2[j] = (float)((double)mean_a2[j] + ((double)(a2 - mean_a2[j])) / k);
+    const float ind = delta_is_class ? (reinterpret_cast<const int32_t*>(delta_v)[j] > 1 ? 1.f : 0.f)
+                                     : reinterpret_cast<const float*>(delta_v)[j];
+    mean_d[j]  = (float)((double)mean_d[j] + ((double)(ind - mean_d[j])) / k);
+}
+
+// ---------------------------------------------------------------------------------------------
+// storage-layer precompute
+// ---------------------------------------------------------------------------------------------
+// x'x per column, fp64 accumulated (getXpRinvX, tools4genotypes.jl:33-36).  grid = p, block 256.
+__global__ __launch_bounds__(256) void k_xpx(const float* __restrict__ X, int64_t ld, float* __restrict__ xpx)
+{
+    __shared__ double red[4];
+    const float* x = X + (int64_t)blockIdx.x * ld;
+    double v[1] = {0.0};
+    for (int64_t i = (int64_t)threadIdx.x * 4; i < ld; i += 1024) {
+        const float4 q = *reinterpret_cast<const float4*>(x + i);
+        v[0] = fma((double)q.x, (double)q.x, v[0]);
+        v[0] = fma((double)q.y, (double)q.y, v[0]);
+        v[0] = fma((double)q.z, (double)q.z, v[0]);
+        v[0] = fma((double)q.w, (double)q.w, v[0]);
+    }
+    block_sum<1>(v, red, 4);
+    if (threadIdx.x == 0) xpx[blockIdx.x] = (float)v[0];
+}
+
+// Exact (fp64-accumulated) Gram of one block: grid = (b, nblocks), block = 256; workgroup (a, blk)
+// writes row a: G[a][c], c <= a, and mirrors.  Test-size path; O(p*b*n/2) VALU work.
+__global__ __launch_bounds__(256) void k_gram_f64(const float* __restrict__ X, int64_t ld, int64_t p, int bsize,
+                                                  float* __restrict__ gram)
+{
+    const int64_t blk = blockIdx.y;
+    const int64_t j0 = blk * bsize;
+    const int b = (int)((j0 + bsize <= p) ? bsize : (p - j0));
+    const int a = blockIdx.x;
+    if (a >= b) return;
+    float* G = gram + blk * (int64_t)bsize * bsize;   // blocks are stored at stride bsize^2, each b x b packed
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* xa = X + (j0 + a) * ld;
+    for (int c = wave; c <= a; c += 4) {
+        const float* xc = X + (j0 + c) * ld;
+        double s = 0.0;
+        for (int64_t i = (int64_t)lane * 4; i < ld; i += 256) {
+            const float4 qa = *reinterpret_cast<const float4*>(xa + i);
+            const float4 qc = *reinterpret_cast<const float4*>(xc + i);
+            s = fma((double)qa.x, (double)qc.x, s);
+            s = fma((double)qa.y, (double)qc.y, s);
+            s = fma((double)qa.z, (double)qc.z, s);
+            s = fma((double)qa.w, (double)qc.w, s);
+        }
+        s = wave_sum(s);
+        if (lane == 0) { G[(int64_t)a * b + c] = (float)s; G[(int64_t)c * b + a] = (float)s; }
+    }
+}
+
+// fp32 MFMA Gram: one workgroup (4 waves) per 64x64 output tile of one block, K = ld rows.
+// v_mfma_f32_32x32x2_f32; K is consumed in 8-row groups with lane (m, h) holding rows 8q+4h..+3 of
+// its column (ds_read_b128 from a [64][36]-float LDS image, conflict-free for 16-lane groups);
+// A and B use the same K permutation so the contraction is unchanged.  Accumulators are folded
+// into fp64 every kGramChunk rows to bound fp32 accumulation error.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kGramKT = 32;          // rows per LDS tile
+constexpr int kGramLd = 36;          // LDS row stride (floats)
+constexpr int kGramChunk = 1024;     // rows per fp32 accumulation chunk
+
+__global__ __launch_bounds__(256) void k_gram_mfma(const float* __restrict__ X, int64_t ld, int64_t p, int bsize,
+                                                   float* __restrict__ gram)
+{
+    __shared__ __attribute__((aligned(16))) float As[64 * kGramLd];
+    __shared__ __attribute__((aligned(16))) float Bs[64 * kGramLd];
+    const int64_t blk = blockIdx.y;
+    const int64_t j0 = blk * bsize;
+    const int b = (int)((j0 + bsize <= p) ? bsize : (p - j0));
+    // tile index -> (ti, tj), ti >= tj, over nt = ceil(bsize/64) tiles per side
+    int ti = 0, rem = blockIdx.x;
+    while (rem > ti) { rem -= ti + 1; ++ti; }
+    const int tj = rem;
+    if (ti * 64 >= b) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;              // wave's 32x32 sub-tile
+    const bool diag = (ti == tj);
+    float* G = gram + blk * (int64_t)bsize * bsize;
+
+    // staging: thread -> (marker m = tid/8 [+32], float4 q = tid%8)
+    const int sm = tid >> 3, sq = tid & 7;
+    const int ma0 = ti * 64 + sm, ma1 = ma0 + 32, mb0 = tj * 64 + sm, mb1 = mb0 + 32;
+    const float* pa0 = X + (j0 + (ma0 < b ? ma0 : 0)) * ld + sq * 4;
+    const float* pa1 = X + (j0 + (ma1 < b ? ma1 : 0)) * ld + sq * 4;
+    const float* pb0 = X + (j0 + (mb0 < b ? mb0 : 0)) * ld + sq * 4;
+    const float* pb1 = X + (j0 + (mb1 < b ? mb1 : 0)) * ld + sq * 4;
+    const float4 zero4{0.f, 0.f, 0.f, 0.f};
+
+    f32x16 acc;
+    double accd[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc[i] = 0.f; accd[i] = 0.0; }
+
+    const int am = lane & 31, ah = lane >> 5;
+    const float* a_rd = As + (wm * 32 + am) * kGramLd + 4 * ah;
+    const float* b_rd = (diag ? As : Bs) + (wn * 32 + am) * kGramLd + 4 * ah;
+
+    int chunk_rows = 0;
+    for (int64_t k0 = 0; k0 < ld; k0 += kGramKT) {
+        // unconditional loads from clamped addresses; out-of-block markers are zeroed by value
+        float4 va0 = *reinterpret_cast<const float4*>(pa0 + k0);
+        float4 va1 = *reinterpret_cast<const float4*>(pa1 + k0);
+        float4 vb0 = zero4, vb1 = zero4;
+        if (!diag) {
+            vb0 = *reinterpret_cast<const float4*>(pb0 + k0);
+            vb1 = *reinterpret_cast<const float4*>(pb1 + k0);
+        }
+        if (ma0 >= b) va0 = zero4;
+        if (ma1 >= b) va1 = zero4;
+        if (mb0 >= b) vb0 = zero4;
+        if (mb1 >= b) vb1 = zero4;
+        __syncthreads();      // previous tile fully consumed
+        *reinterpret_cast<float4*>(&As[sm * kGramLd + sq * 4]) = va0;
+        *reinterpret_cast<float4*>(&As[(sm + 32) * kGramLd + sq * 4]) = va1;
+        if (!diag) {
+            *reinterpret_cast<float4*>(&Bs[sm * kGramLd + sq * 4]) = vb0;
+            *reinterpret_cast<float4*>(&Bs[(sm + 32) * kGramLd + sq * 4]) = vb1;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < kGramKT / 8; ++q) {
+            const float4 fa = *reinterpret_cast<const float4*>(a_rd + 8 * q);
+            const float4 fb = *reinterpret_cast<const float4*>(b_rd + 8 * q);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb.w, acc, 0, 0, 0);
+        }
+        chunk_rows += kGramKT;
+        if (chunk_rows >= kGramChunk) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { accd[i] += (double)acc[i]; acc[i] = 0.f; }
+            chunk_rows = 0;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accd[i] += (double)acc[i];
+
+    // C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // here "row" indexes the A operand (markers of tile ti), "col" the B operand (tile tj).
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int rr = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+        const int ga = ti * 64 + wm * 32 + rr;
+        const int gc = tj * 64 + wn * 32 + (lane & 31);
+        if (ga < b && gc < b) {
+            const float v = (float)accd[i];
+            G[(int64_t)ga * b + gc] = v;
+            if (!diag) G[(int64_t)gc * b + ga] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// X * alpha (EBV, output.jl:302) and r -= X*alpha0 (MCMC_BayesianAlphabet.jl:142)
+// grid = nslices, block = 256: one row per thread, columns in marker order.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mul_alpha(const float* __restrict__ X, int64_t ld, int64_t p,
+                                                   const float* __restrict__ alpha, float* __restrict__ out)
+{
+    const int64_t row = (int64_t)blockIdx.x * kSliceRows + threadIdx.x;
+    const float* xrow = X + row;
+    double s = 0.0;
+    for (int64_t j = 0; j < p; ++j) {
+        const float a = alpha[j];
+        if (a != 0.f) s = fma((double)a, (double)xrow[j * ld], s);
+    }
+    out[row] = (float)s;
+}
+
+__global__ __launch_bounds__(256) void k_sub_xalpha(const float* __restrict__ X, int64_t ld, int64_t p,
+                                                    const float* __restrict__ alpha, float* __restrict__ r)
+{
+    const int64_t row = (int64_t)blockIdx.x * kSliceRows + threadIdx.x;
+    const float* xrow = X + row;
+    float rv = r[row];
+    for (int64_t j = 0; j < p; ++j) {
+        const float a = alpha[j];
+        if (a != 0.f) rv = fmaf(-a, xrow[j * ld], rv);
+    }
+    r[row] = rv;
+}
+
+// ---------------------------------------------------------------------------------------------
+// synthetic genotypes (bench / tests).  grid = p, block = 256.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_synth(float* __restrict__ X, int64_t n, int64_t ld, uint32_t seed_lo,
+                                               uint32_t seed_hi, int kind, int center)
+{
+    __shared__ double red[4];
+    const uint32_t j = blockIdx.x;
+    float* x = X + (int64_t)j * ld;
+    const u32x4 wf = philox4x32_10(j, 0xFFFFFFFFu, 0u, 0u, seed_lo, seed_hi);
+    const float f = 0.1f + 0.3f * ((float)(wf.x >> 8) * 0x1.0p-24f);          // U(0.1, 0.4)
+    double v[1] = {0.0};
+    for (int64_t i = threadIdx.x; i < ld; i += 256) {
+        float val = 0.f;
+        if (i < n) {
+            const u32x4 w = philox4x32_10(j, (uint32_t)i, 1u, 0u, seed_lo, seed_hi);
+            if (kind == 1) val = (float)(w.x >> 8) * 0x1.0p-24f;                // U[0,1)
+            else {
+                const float u1 = (float)(w.x >> 8) * 0x1.0p-24f, u2 = (float)(w.y >> 8) * 0x1.0p-24f;
+                val = (u1 < f ? 1.f : 0.f) + (u2 < f ? 1.f : 0.f);
+            }
+            v[0] += (double)val;
+        }
+        x[i] = val;
+    }
+    if (!center) return;
+    block_sum<1>(v, red, 4);
+    const float mean = (float)(v[0] / (double)n);
+    __syncthreads();
+    for (int64_t i = threadIdx.x; i < n; i += 256) x[i] = x[i] - mean;
+}
+
+}  // namespace jw

@@ -1,0 +1,294 @@
+"""HipEngine: numpy-facing wrapper over the C ABI -- the device side of the marker sweep.
+
+The host MCMC loop (jwas.jl_amd/mcmc.py) drives a *sweep engine* through this small protocol:
+
+    load_dense(X) / alloc_dense(n,p) + synth(...)      genotype storage      (Genotypes.genotypes)
+    setup_blocks(block_size, gram_mode)                x'x + block Grams     (GibbsMats)
+    xpx() / gram(i) / set_gram(i, G)
+    init_state(method, ntraits); set_state/get_state   alpha, beta, delta
+    set_residual/get_residual(trait)                   ycorr
+    sub_xalpha(trait); mul_alpha(trait)
+    sweep(**params) -> dict of reductions              BayesABC!/BayesR!/MTBayesABC!
+    accumulate(k); posterior(trait)                    running posterior means
+
+HipEngine is the only engine the package ships; it raises if libjwas_hip.so or the GPU is missing.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import JwasHipError, SweepParams, SweepStats
+
+METHOD_CODES = {"BayesC": _lib.BAYESC, "BayesB": _lib.BAYESB, "BayesA": _lib.BAYESB,
+                "BayesR": _lib.BAYESR, "MTBayesC": _lib.MTBAYESC1}
+BAYESR_GAMMA = np.array([0.0, 0.01, 0.1, 1.0], dtype=np.float64)   # JWAS.jl:12
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class HipEngine:
+    def __init__(self, device=0):
+        self._L = _lib.load()
+        h = C.c_void_p()
+        rc = self._L.jwas_hip_create(int(device), C.byref(h))
+        if rc != 0:
+            raise JwasHipError(rc, self._L.jwas_hip_last_error(None).decode())
+        self._h = h
+        self.device = int(device)
+        self.n = self.p = 0
+        self.method = None
+        self.ntraits = 0
+        self.block_size = 0
+        self._keep = []   # host arrays referenced by the last sweep call
+
+    # -- plumbing --------------------------------------------------------------------------------
+    def _chk(self, rc):
+        if rc != 0:
+            raise JwasHipError(rc, self._L.jwas_hip_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.jwas_hip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_handle):
+        self._chk(self._L.jwas_hip_set_stream(self._h, C.c_void_p(int(stream_handle))))
+
+    def device_info(self):
+        ncu, tot, free = C.c_int(), C.c_int64(), C.c_int64()
+        self._chk(self._L.jwas_hip_device_info(self._h, C.byref(ncu), C.byref(tot), C.byref(free)))
+        return {"n_cu": ncu.value, "hbm_total": tot.value, "hbm_free": free.value}
+
+    @staticmethod
+    def estimate_bytes(n, p, ntraits=1, block_size=256):
+        return _lib.load().jwas_hip_estimate_bytes(int(n), int(p), int(ntraits), int(block_size))
+
+    # -- storage ---------------------------------------------------------------------------------
+    def load_dense(self, X):
+        """X: n x p float32.  Fortran order is uploaded as is (marker-major, zero re-layout)."""
+        X = np.asarray(X)
+        if X.dtype != np.float32:
+            raise TypeError("the HIP path stores Float32 genotypes (double_precision=false)")
+        if X.ndim != 2:
+            raise ValueError("genotype matrix must be 2-D")
+        if not X.flags.f_contiguous:
+            X = np.asfortranarray(X)
+        n, p = X.shape
+        self._chk(self._L.jwas_hip_load_dense_f32(self._h, _ptr(X), n, p, n))
+        self.n, self.p = n, p
+        self.method, self.block_size = None, 0
+
+    def alloc_dense(self, n, p):
+        self._chk(self._L.jwas_hip_alloc_dense_f32(self._h, int(n), int(p)))
+        self.n, self.p = int(n), int(p)
+        self.method, self.block_size = None, 0
+
+    def synth(self, seed, kind=0, center=True):
+        self._chk(self._L.jwas_hip_synth_genotypes(self._h, int(seed), int(kind), int(bool(center))))
+
+    def layout(self):
+        n, p, ld, ptr = C.c_int64(), C.c_int64(), C.c_int64(), C.c_void_p()
+        self._chk(self._L.jwas_hip_dense_layout(self._h, C.byref(n), C.byref(p), C.byref(ld), C.byref(ptr)))
+        return {"n": n.value, "p": p.value, "ld": ld.value, "ptr": ptr.value}
+
+    def get_columns(self, j0, count):
+        out = np.empty((self.n, int(count)), dtype=np.float32, order="F")
+        self._chk(self._L.jwas_hip_get_columns(self._h, int(j0), int(count), _ptr(out)))
+        return out
+
+    # -- precompute ------------------------------------------------------------------------------
+    def setup_blocks(self, block_size=256, gram_mode="mfma"):
+        mode = {"f64": _lib.GRAM_F64, "mfma": _lib.GRAM_MFMA}[gram_mode]
+        self._chk(self._L.jwas_hip_setup_blocks(self._h, int(block_size), mode))
+        self.block_size = int(block_size)
+
+    @property
+    def nblocks(self):
+        nb, bs = C.c_int64(), C.c_int32()
+        self._chk(self._L.jwas_hip_num_blocks(self._h, C.byref(nb), C.byref(bs)))
+        return nb.value
+
+    def block_starts(self):
+        return np.arange(0, self.p, self.block_size, dtype=np.int64)
+
+    def _bsize(self, i):
+        j0 = i * self.block_size
+        return min(self.block_size, self.p - j0)
+
+    def xpx(self):
+        out = np.empty(self.p, dtype=np.float32)
+        self._chk(self._L.jwas_hip_get_xpx(self._h, _ptr(out)))
+        return out
+
+    def gram(self, i):
+        b = self._bsize(i)
+        out = np.empty((b, b), dtype=np.float32)
+        self._chk(self._L.jwas_hip_get_gram(self._h, int(i), _ptr(out)))
+        return out
+
+    def set_gram(self, i, G):
+        b = self._bsize(i)
+        G = np.ascontiguousarray(G, dtype=np.float32)
+        if G.shape != (b, b):
+            raise ValueError(f"Gram block {i} must be {b} x {b}")
+        self._chk(self._L.jwas_hip_set_gram(self._h, int(i), _ptr(G)))
+
+    def set_grams_packed(self, grams):
+        """grams: concatenated row-major b_i x b_i blocks (the oracle's packing)."""
+        off = 0
+        g = np.ascontiguousarray(grams, dtype=np.float32)
+        for i in range(self.nblocks):
+            b = self._bsize(i)
+            self.set_gram(i, g[off:off + b * b].reshape(b, b))
+            off += b * b
+
+    # -- state -----------------------------------------------------------------------------------
+    def init_state(self, method, ntraits=1):
+        code = METHOD_CODES[method] if isinstance(method, str) else int(method)
+        self._chk(self._L.jwas_hip_init_state(self._h, code, int(ntraits)))
+        self.method, self.ntraits = code, int(ntraits)
+
+    def _delta_dtype(self):
+        return np.int32 if self.method == _lib.BAYESR else np.float32
+
+    def set_state(self, trait=0, alpha=None, beta=None, delta=None):
+        a = None if alpha is None else np.ascontiguousarray(alpha, dtype=np.float32)
+        b = None if beta is None else np.ascontiguousarray(beta, dtype=np.float32)
+        d = None if delta is None else np.ascontiguousarray(delta, dtype=self._delta_dtype())
+        for v in (a, b, d):
+            if v is not None and v.shape != (self.p,):
+                raise ValueError(f"state vectors must have length {self.p}")
+        self._chk(self._L.jwas_hip_set_state(self._h, int(trait), _ptr(a), _ptr(b), _ptr(d)))
+
+    def get_state(self, trait=0):
+        a = np.empty(self.p, dtype=np.float32)
+        b = np.empty(self.p, dtype=np.float32)
+        d = np.empty(self.p, dtype=self._delta_dtype())
+        self._chk(self._L.jwas_hip_get_state(self._h, int(trait), _ptr(a), _ptr(b), _ptr(d)))
+        return a, b, d
+
+    def set_residual(self, r, trait=0):
+        r = np.ascontiguousarray(r, dtype=np.float32)
+        if r.shape != (self.n,):
+            raise ValueError(f"residual must have length {self.n}")
+        self._chk(self._L.jwas_hip_set_residual(self._h, int(trait), _ptr(r)))
+
+    def get_residual(self, trait=0):
+        r = np.empty(self.n, dtype=np.float32)
+        self._chk(self._L.jwas_hip_get_residual(self._h, int(trait), _ptr(r)))
+        return r
+
+    def residual_dev(self):
+        ptr, ld = C.c_void_p(), C.c_int64()
+        self._chk(self._L.jwas_hip_residual_dev(self._h, C.byref(ptr), C.byref(ld)))
+        return ptr.value, ld.value
+
+    def sub_xalpha(self, trait=0):
+        self._chk(self._L.jwas_hip_residual_sub_xalpha(self._h, int(trait)))
+
+    def mul_alpha(self, trait=0):
+        out = np.empty(self.n, dtype=np.float32)
+        self._chk(self._L.jwas_hip_mul_alpha(self._h, int(trait), _ptr(out)))
+        return out
+
+    # -- the sweep -------------------------------------------------------------------------------
+    def sweep(self, *, iteration, seed, vare, var_effect, pi=0.0, pi_classes=None, gamma=BAYESR_GAMMA,
+              log_prior_states=None, var_effect_vec=None, pi_vec=None, pi_matrix=None, nreps=1,
+              marker_offset=0):
+        """One marker sweep.  Argument meaning follows BayesABC!/BayesR!/MTBayesABC!:
+        vare: residual variance (scalar or t x t); var_effect: marker effect variance (BayesC scalar,
+        BayesR sigmaSq, MT t x t); pi: Pr(effect = 0) scalar, or pi_vec per marker (length p, else the
+        reference's length error); pi_classes / pi_matrix: BayesR class priors (4 or p x 4)."""
+        t = self.ntraits
+        P = SweepParams()
+        P.method, P.ntraits, P.nreps = self.method, t, int(nreps)
+        P.iteration, P.seed, P.marker_offset = int(iteration), int(seed), int(marker_offset)
+        ve = np.asarray(vare, dtype=np.float32).reshape(-1)
+        vg = np.asarray(var_effect, dtype=np.float32).reshape(-1)
+        if ve.size != t * t or vg.size != t * t:
+            raise ValueError(f"vare / var_effect must have {t}x{t} entries")
+        for i in range(t * t):
+            P.vare[i] = float(ve[i])
+            P.var_effect[i] = float(vg[i])
+        P.pi = float(pi) if np.ndim(pi) == 0 else 0.0
+        keep = []
+        if self.method in (_lib.BAYESC, _lib.BAYESB):
+            if np.ndim(pi) == 1:
+                pi_vec = pi
+            if pi_vec is not None:
+                pv = np.ascontiguousarray(pi_vec, dtype=np.float64)
+                if pv.shape != (self.p,):
+                    # bayesabc_pi_vector (BayesABC.jl:16-22)
+                    raise ValueError(f"BayesABC pi vector length {pv.size} must match the number of markers ({self.p}).")
+                P.pi_vec = pv.ctypes.data_as(C.POINTER(C.c_double))
+                keep.append(pv)
+            if self.method == _lib.BAYESB:
+                if var_effect_vec is None:
+                    raise ValueError("BayesB needs per-marker effect variances")
+                vv = np.ascontiguousarray(var_effect_vec, dtype=np.float32)
+                if vv.shape != (self.p,):
+                    raise ValueError(f"BayesB variance vector must have length {self.p}")
+                P.var_effect_vec = vv.ctypes.data_as(C.POINTER(C.c_float))
+                keep.append(vv)
+        elif self.method == _lib.BAYESR:
+            g = np.asarray(gamma, dtype=np.float64)
+            for k in range(4):
+                P.gamma[k] = float(g[k])
+            pc = pi_classes
+            if pc is not None and np.ndim(pc) == 2:
+                pi_matrix, pc = pc, None
+            if pi_matrix is not None:
+                pm = np.ascontiguousarray(pi_matrix, dtype=np.float64)
+                # bayesr_validate_priors (BayesR.jl:16-20)
+                if pm.shape[0] != self.p:
+                    raise ValueError("BayesR per-marker pi must have one row per marker.")
+                if pm.shape[1] != 4:
+                    raise ValueError("BayesR per-marker pi must have 4 columns.")
+                P.pi_matrix = pm.ctypes.data_as(C.POINTER(C.c_double))
+                keep.append(pm)
+            else:
+                pc = np.asarray(pc, dtype=np.float64)
+                if pc.shape != (4,):
+                    raise ValueError(f"BayesR pi vector length {pc.size} must match the number of mixture classes (4).")
+                for k in range(4):
+                    P.pi_classes[k] = float(pc[k])
+        else:
+            lp = np.asarray(log_prior_states, dtype=np.float64)
+            if lp.shape != (1 << t,):
+                raise ValueError(f"log_prior_states must have {1 << t} entries")
+            for k in range(1 << t):
+                P.log_prior_states[k] = float(lp[k])
+        self._keep = keep
+        S = SweepStats()
+        self._chk(self._L.jwas_hip_sweep(self._h, C.byref(P), C.byref(S)))
+        return {
+            "sum_delta": np.array(S.sum_delta[:t]),
+            "alpha_ss": np.array(S.alpha_ss[:t * t]).reshape(t, t),
+            "beta_ss": np.array(S.beta_ss[:t * t]).reshape(t, t),
+            "resid_ss": np.array(S.resid_ss[:t * t]).reshape(t, t),
+            "resid_sum": np.array(S.resid_sum[:t]),
+            "class_counts": np.array(S.class_counts[:4]),
+            "bayesr_ssq": S.bayesr_ssq, "bayesr_nnz": S.bayesr_nnz,
+            "state_counts": np.array(S.state_counts[:1 << t]),
+            "n_events": S.n_events, "sweep_ms": S.sweep_ms,
+        }
+
+    # -- posterior accumulators --------------------------------------------------------------------
+    def accumulate(self, nsamples):
+        self._chk(self._L.jwas_hip_accumulate(self._h, float(nsamples)))
+
+    def posterior(self, trait=0):
+        ma = np.empty(self.p, dtype=np.float32)
+        ma2 = np.empty(self.p, dtype=np.float32)
+        md = np.empty(self.p, dtype=np.float32)
+        self._chk(self._L.jwas_hip_get_posterior(self._h, int(trait), _ptr(ma), _ptr(ma2), _ptr(md)))
+        return ma, ma2, md

@@ -1,0 +1,585 @@
+/*
+ * jwas_oracle.c -- CPU ORACLE (test infrastructure only; see jwas_oracle.h for the contract).
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off: no implicit FMA contraction, every fused
+ * operation below is an explicit fmaf/fma).
+ */
+#include "jwas_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------------------------ */
+/* Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3")   */
+/* ------------------------------------------------------------------------------------------ */
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+    uint32_t k0 = key[0], k1 = key[1];
+    for (int round = 0; round < 10; ++round) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+static inline double u52(uint32_t lo, uint32_t hi)
+{
+    uint64_t k = (((uint64_t)hi << 32) | lo) >> 12;            /* 52 random bits           */
+    return ((double)k + 0.5) * 0x1.0p-52;                      /* exact; in (0,1)          */
+}
+
+static inline void draw_block(uint64_t seed, uint32_t marker, uint32_t iter, uint32_t rep,
+                              uint32_t trait, uint32_t slot, uint32_t out[4])
+{
+    uint32_t ctr[4] = { marker, iter, rep, slot + 16u * trait };
+    uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
+    orc_philox4x32_10(ctr, key, out);
+}
+
+double orc_uniform(uint64_t seed, uint32_t marker, uint32_t iter, uint32_t rep, uint32_t trait)
+{
+    uint32_t w[4];
+    draw_block(seed, marker, iter, rep, trait, 0u, w);
+    return u52(w[0], w[1]);
+}
+
+double orc_normal(uint64_t seed, uint32_t marker, uint32_t iter, uint32_t rep, uint32_t trait)
+{
+    uint32_t w[4];
+    draw_block(seed, marker, iter, rep, trait, 1u, w);
+    double u1 = u52(w[0], w[1]), u2 = u52(w[2], w[3]);
+    return sqrt(-2.0 * log(u1)) * cos(6.283185307179586476925286766559 * u2);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* inner products                                                                             */
+/* ------------------------------------------------------------------------------------------ */
+static float dot_acc(const float* a, const float* b, int64_t n, int acc)
+{
+    if (acc == ORC_ACC_F64) {
+        double s = 0.0;
+        for (int64_t i = 0; i < n; ++i) s += (double)a[i] * (double)b[i];   /* exact products */
+        return (float)s;
+    }
+    float s = 0.0f;
+    for (int64_t i = 0; i < n; ++i) s += a[i] * b[i];
+    return s;
+}
+
+static void axpy_f32(float a, const float* x, float* y, int64_t n)
+{
+    for (int64_t i = 0; i < n; ++i) y[i] = fmaf(a, x[i], y[i]);
+}
+
+void orc_xpx(const float* X, int64_t n, int64_t p, int64_t ld, float* xpx, int acc)
+{
+    for (int64_t j = 0; j < p; ++j) xpx[j] = dot_acc(X + j * ld, X + j * ld, n, acc);
+}
+
+void orc_gram(const float* X, int64_t n, int64_t ld, int64_t j0, int64_t b, float* G, int acc)
+{
+    for (int64_t a = 0; a < b; ++a)
+        for (int64_t c = 0; c <= a; ++c) {
+            float v = dot_acc(X + (j0 + a) * ld, X + (j0 + c) * ld, n, acc);
+            G[a * b + c] = v;
+            G[c * b + a] = v;
+        }
+}
+
+void orc_residual_minus_xalpha(const float* X, int64_t n, int64_t p, int64_t ld,
+                               const float* alpha, float* r)
+{
+    for (int64_t j = 0; j < p; ++j)
+        if (alpha[j] != 0.0f) axpy_f32(-alpha[j], X + j * ld, r, n);
+}
+
+static inline float logf_via_double(float x) { return (float)log((double)x); }
+
+/* ------------------------------------------------------------------------------------------ */
+/* BayesA/B/C scalar kernel -- bayesabc_update_marker! (BayesABC.jl:24-58)                     */
+/* s = x_j' r (fp32).  Returns the axpy coefficient (alpha_old - alpha_new); 0 => no axpy.     */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct {
+    float  ie;        /* invVarRes = 1/vare                  (BayesABC.jl:69)                  */
+} abc_sweep_consts;
+
+static inline float abc_update(float s, float d, float* alpha, float* beta, float* delta,
+                               float ie, float var_j, double pi_j, double u, double z)
+{
+    /* per-sweep vectors of BayesABC.jl:66-71, evaluated per marker (same values) */
+    const double lp0 = log(pi_j);                 /* logPi[j]      (Float64)                    */
+    const double lp1 = log(1.0 - pi_j);           /* logPiComp[j]  (Float64)                    */
+    const float  iv  = 1.0f / var_j;              /* invVarEffects[j]                           */
+    const float  lv  = logf_via_double(var_j);    /* logVarEffects[j]                           */
+
+    const float a_old  = *alpha;
+    const float rhs    = (s + d * a_old) * ie;                        /* :36 */
+    const float lhs    = d * ie + iv;                                 /* :37 */
+    const float invLhs = 1.0f / lhs;                                  /* :38 */
+    const float gHat   = rhs * invLhs;                                /* :39 */
+    const float inner  = (logf_via_double(lhs) + lv) - gHat * rhs;    /* Float32 part of :40 */
+    const double logDelta1  = -0.5 * (double)inner + lp1;             /* :40 */
+    const double probDelta1 = 1.0 / (1.0 + exp(lp0 - logDelta1));     /* :41 */
+
+    if (u < probDelta1) {                                             /* :44 */
+        *delta = 1.0f;
+        *beta  = (float)((double)gHat + z * (double)sqrtf(invLhs));   /* :46 */
+        *alpha = *beta;
+        return a_old - *alpha;                                        /* :48 */
+    }
+    *delta = 0.0f;
+    *beta  = (float)(z * (double)sqrtf(var_j));                       /* :54 */
+    *alpha = 0.0f;
+    return a_old;                                                     /* :50-52 (0 => skipped) */
+}
+
+static int abc_args_ok(int64_t n, int64_t p, int64_t ld, float vare)
+{
+    return n > 0 && p >= 0 && ld >= n && vare > 0.0f;
+}
+
+int orc_bayesabc_sweep(const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
+                       float* r, float* alpha, float* beta, float* delta,
+                       float vare, const float* var_effects, const double* pi,
+                       uint64_t seed, uint32_t iter, uint32_t marker0, int acc)
+{
+    if (!abc_args_ok(n, p, ld, vare)) return -1;
+    const float ie = 1.0f / vare;
+    for (int64_t j = 0; j < p; ++j) {                                  /* BayesABC.jl:73-79 */
+        const float* x = X + j * ld;
+        const uint32_t m = marker0 + (uint32_t)j;
+        const float s = dot_acc(x, r, n, acc);                         /* :76 */
+        const double u = orc_uniform(seed, m, iter, 0, 0);
+        const double z = orc_normal(seed, m, iter, 0, 0);
+        const float a = abc_update(s, xpx[j], &alpha[j], &beta[j], &delta[j], ie,
+                                   var_effects[j], pi[j], u, z);
+        if (a != 0.0f) axpy_f32(a, x, r, n);
+    }
+    return 0;
+}
+
+static int blocks_ok(const int64_t* bs, int64_t nblocks, int64_t p)
+{
+    if (nblocks < 1 || bs[0] != 0) return 0;
+    for (int64_t i = 1; i < nblocks; ++i) if (bs[i] <= bs[i - 1] || bs[i] >= p) return 0;
+    return 1;
+}
+
+int orc_bayesabc_block_sweep(const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
+                             const int64_t* block_starts, int64_t nblocks, const float* grams,
+                             float* r, float* alpha, float* beta, float* delta,
+                             float vare, const float* var_effects, const double* pi,
+                             int nreps_arg, uint64_t seed, uint32_t iter, uint32_t marker0, int acc)
+{
+    if (!abc_args_ok(n, p, ld, vare) || !blocks_ok(block_starts, nblocks, p)) return -1;
+    const float ie = 1.0f / vare;
+    const float* G = grams;
+    for (int64_t bi = 0; bi < nblocks; ++bi) {                          /* BayesABC.jl:145 */
+        const int64_t j0 = block_starts[bi];
+        const int64_t b  = (bi + 1 < nblocks ? block_starts[bi + 1] : p) - j0;
+        float* a_old_blk = (float*)malloc(sizeof(float) * (size_t)b);
+        float* rhs_b     = (float*)malloc(sizeof(float) * (size_t)b);
+        memcpy(a_old_blk, alpha + j0, sizeof(float) * (size_t)b);       /* :150 */
+        for (int64_t k = 0; k < b; ++k) rhs_b[k] = dot_acc(X + (j0 + k) * ld, r, n, acc); /* :152 */
+        const int nreps = nreps_arg > 0 ? nreps_arg : (int)b;           /* :153 */
+        for (int rep = 0; rep < nreps; ++rep)
+            for (int64_t k = 0; k < b; ++k) {                           /* :155-178 */
+                const int64_t j = j0 + k;
+                const uint32_t m = marker0 + (uint32_t)j;
+                const double u = orc_uniform(seed, m, iter, (uint32_t)rep, 0);
+                const double z = orc_normal(seed, m, iter, (uint32_t)rep, 0);
+                const float a = abc_update(rhs_b[k], xpx[j], &alpha[j], &beta[j], &delta[j], ie,
+                                           var_effects[j], pi[j], u, z);
+                if (a != 0.0f) axpy_f32(a, G + k * b, rhs_b, b);        /* :169,172 (G symmetric) */
+            }
+        for (int64_t k = 0; k < b; ++k) {                               /* :181-185 */
+            const float d = a_old_blk[k] - alpha[j0 + k];
+            if (d != 0.0f) axpy_f32(d, X + (j0 + k) * ld, r, n);
+        }
+        free(a_old_blk); free(rhs_b);
+        G += b * b;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* BayesR scalar kernel (BayesR.jl:56-96).  Returns axpy coefficient.                          */
+/* ------------------------------------------------------------------------------------------ */
+static inline float bayesr_update(float s, float d, float* alpha, int32_t* delta, float ie,
+                                  float sigma_sq, const double* pi_j, const double* gamma,
+                                  double u, double z)
+{
+    const float a_old = *alpha;
+    const float rhs   = (s + d * a_old) * ie;                                    /* :60 */
+    const float die   = d * ie;                                                  /* Float32 product in :70 */
+    double lp[4], probs[4];
+    lp[0] = log(pi_j[0]);                                                        /* :64 */
+    for (int k = 1; k < 4; ++k) {                                                /* :65-72 */
+        const double varEffect = gamma[k] * (double)sigma_sq;
+        const double invVarEffect = 1.0 / varEffect;
+        const double lhs = (double)die + invVarEffect;
+        const double invLhs = 1.0 / lhs;
+        const double betaHat = invLhs * (double)rhs;
+        lp[k] = 0.5 * (log(invLhs) - log(varEffect) + betaHat * (double)rhs) + log(pi_j[k]);
+    }
+    double mx = lp[0];                                                           /* :1-4 */
+    for (int k = 1; k < 4; ++k) if (lp[k] > mx) mx = lp[k];
+    double se = 0.0;
+    for (int k = 0; k < 4; ++k) se += exp(lp[k] - mx);
+    const double log_norm = mx + log(se);
+    for (int k = 0; k < 4; ++k) probs[k] = exp(lp[k] - log_norm);                /* :75-77 */
+
+    /* rand(Categorical(probs)) (:79): Distributions.jl 0.25 (not vendored) walks the CDF while
+     * cp <= draw; the reference's own replay harness restates it the same way up to ties
+     * (benchmarks/bayesr_parity_replay_jwas.jl:37-41). */
+    int cls = 0;
+    double cp = probs[0];
+    while (cp <= u && cls < 3) { ++cls; cp += probs[cls]; }
+    *delta = cls + 1;                                                            /* :80 */
+
+    if (cls == 0) {                                                              /* :82-86 */
+        *alpha = 0.0f;
+        return a_old;
+    }
+    const double varEffect = gamma[cls] * (double)sigma_sq;                      /* :88-94 */
+    const double lhs = (double)die + 1.0 / varEffect;
+    const double invLhs = 1.0 / lhs;
+    const double betaHat = invLhs * (double)rhs;
+    *alpha = (float)(betaHat + z * sqrt(invLhs));
+    return a_old - *alpha;
+}
+
+static int bayesr_priors_ok(const double* pi, int pi_is_matrix, int64_t p)
+{
+    if (pi_is_matrix) return 1;                      /* BayesR.jl:16-20: shape checks only */
+    (void)p;
+    double s = 0.0;
+    for (int k = 0; k < 4; ++k) { if (pi[k] < 0.0) return 0; s += pi[k]; }
+    return fabs(s - 1.0) <= 1e-8;                    /* BayesR.jl:9-14 */
+}
+
+int orc_bayesr_sweep(const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
+                     float* r, float* alpha, int32_t* delta,
+                     float vare, float sigma_sq, const double* pi, int pi_is_matrix,
+                     const double* gamma, uint64_t seed, uint32_t iter, uint32_t marker0, int acc)
+{
+    if (!abc_args_ok(n, p, ld, vare) || !bayesr_priors_ok(pi, pi_is_matrix, p)) return -1;
+    if (!(sigma_sq > 0.0f)) return -2;
+    const float ie = 1.0f / vare;
+    for (int64_t j = 0; j < p; ++j) {
+        const float* x = X + j * ld;
+        const uint32_t m = marker0 + (uint32_t)j;
+        const float s = dot_acc(x, r, n, acc);
+        const double u = orc_uniform(seed, m, iter, 0, 0);
+        const double z = orc_normal(seed, m, iter, 0, 0);
+        const float a = bayesr_update(s, xpx[j], &alpha[j], &delta[j], ie, sigma_sq,
+                                      pi_is_matrix ? pi + 4 * j : pi, gamma, u, z);
+        if (a != 0.0f) axpy_f32(a, x, r, n);
+    }
+    return 0;
+}
+
+int orc_bayesr_block_sweep(const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
+                           const int64_t* block_starts, int64_t nblocks, const float* grams,
+                           float* r, float* alpha, int32_t* delta,
+                           float vare, float sigma_sq, const double* pi, int pi_is_matrix,
+                           const double* gamma, int nreps_arg,
+                           uint64_t seed, uint32_t iter, uint32_t marker0, int acc)
+{
+    if (!abc_args_ok(n, p, ld, vare) || !bayesr_priors_ok(pi, pi_is_matrix, p) ||
+        !blocks_ok(block_starts, nblocks, p)) return -1;
+    if (!(sigma_sq > 0.0f)) return -2;
+    const float ie = 1.0f / vare;
+    const float* G = grams;
+    for (int64_t bi = 0; bi < nblocks; ++bi) {                          /* BayesR.jl:139-192 */
+        const int64_t j0 = block_starts[bi];
+        const int64_t b  = (bi + 1 < nblocks ? block_starts[bi + 1] : p) - j0;
+        float* a_old_blk = (float*)malloc(sizeof(float) * (size_t)b);
+        float* rhs_b     = (float*)malloc(sizeof(float) * (size_t)b);
+        memcpy(a_old_blk, alpha + j0, sizeof(float) * (size_t)b);
+        for (int64_t k = 0; k < b; ++k) rhs_b[k] = dot_acc(X + (j0 + k) * ld, r, n, acc);
+        const int nreps = nreps_arg > 0 ? nreps_arg : (int)b;
+        for (int rep = 0; rep < nreps; ++rep)
+            for (int64_t k = 0; k < b; ++k) {
+                const int64_t j = j0 + k;
+                const uint32_t m = marker0 + (uint32_t)j;
+                const double u = orc_uniform(seed, m, iter, (uint32_t)rep, 0);
+                const double z = orc_normal(seed, m, iter, (uint32_t)rep, 0);
+                const float a = bayesr_update(rhs_b[k], xpx[j], &alpha[j], &delta[j], ie, sigma_sq,
+                                              pi_is_matrix ? pi + 4 * j : pi, gamma, u, z);
+                if (a != 0.0f) axpy_f32(a, G + k * b, rhs_b, b);        /* :182 */
+            }
+        for (int64_t k = 0; k < b; ++k) {                               /* :186-190 */
+            const float d = a_old_blk[k] - alpha[j0 + k];
+            if (d != 0.0f) axpy_f32(d, X + (j0 + k) * ld, r, n);
+        }
+        free(a_old_blk); free(rhs_b);
+        G += b * b;
+    }
+    return 0;
+}
+
+int orc_bayesr_block_nreps(int64_t iter, int64_t burnin, int64_t block_size)
+{
+    if (block_size < 1) return -1;                                       /* BayesR.jl:23 */
+    return iter <= burnin ? 1 : (int)block_size;                         /* :24 */
+}
+
+void orc_bayesr_sigma_suffstats(const float* alpha, const int32_t* delta, int64_t p,
+                                const double* gamma, double* ssq, int64_t* nnz)
+{
+    /* variance_components.jl:68-79.  The reference accumulates in eltype(alpha) with
+     * alpha[j]^2/gamma[dj] promoted by the Float64 gamma: a Float64 running sum. */
+    double s = 0.0; int64_t c = 0;
+    for (int64_t j = 0; j < p; ++j)
+        if (delta[j] > 1) { s += ((double)alpha[j] * (double)alpha[j]) / gamma[delta[j] - 1]; ++c; }
+    *ssq = s; *nnz = c;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* multi-trait BayesC, sampler I (MTBayesABC.jl:57-127)                                        */
+/* ------------------------------------------------------------------------------------------ */
+#define ORC_MAXT 8
+
+/* t x t inverse in double (Gauss-Jordan with partial pivoting), rounded to float -- stands in
+ * for Julia's inv(::Matrix{Float32}) (LAPACK sgetri; MTBayesABC.jl:66-67). */
+static int inv_small(const float* A, int t, float* Ainv)
+{
+    double M[ORC_MAXT][2 * ORC_MAXT];
+    for (int i = 0; i < t; ++i) {
+        for (int j = 0; j < t; ++j) { M[i][j] = A[i * t + j]; M[i][t + j] = (i == j); }
+    }
+    for (int c = 0; c < t; ++c) {
+        int piv = c;
+        for (int i = c + 1; i < t; ++i) if (fabs(M[i][c]) > fabs(M[piv][c])) piv = i;
+        if (M[piv][c] == 0.0) return -1;
+        if (piv != c) for (int j = 0; j < 2 * t; ++j) { double tmp = M[c][j]; M[c][j] = M[piv][j]; M[piv][j] = tmp; }
+        const double d = M[c][c];
+        for (int j = 0; j < 2 * t; ++j) M[c][j] /= d;
+        for (int i = 0; i < t; ++i) if (i != c) {
+            const double f = M[i][c];
+            if (f != 0.0) for (int j = 0; j < 2 * t; ++j) M[i][j] -= f * M[c][j];
+        }
+    }
+    for (int i = 0; i < t; ++i) for (int j = 0; j < t; ++j) Ainv[i * t + j] = (float)M[i][t + j];
+    return 0;
+}
+
+/* One marker.  w[k] = x'r_k + d*alpha_old_k already formed.  Writes axpy coefficients a[k]. */
+static inline void mt1_update(int t, const float* w, float d, float* alpha, float* beta, float* delta,
+                              int64_t stride, const float* Rinv, const float* Ginv,
+                              const double* log_prior, uint64_t seed, uint32_t marker, uint32_t iter,
+                              uint32_t rep, float* a_out)
+{
+    float b[ORC_MAXT], dl[ORC_MAXT];
+    for (int k = 0; k < t; ++k) { b[k] = beta[k * stride]; dl[k] = delta[k * stride]; }
+    for (int k = 0; k < t; ++k) {                                                /* :85 */
+        const float a_old = alpha[k * stride];
+        const float Ginv11 = Ginv[k * t + k];                                    /* :86 */
+        const float C11 = Ginv11 + Rinv[k * t + k] * d;                          /* :89 */
+        float rhs0 = 0.0f, c12b = 0.0f, wR = 0.0f;
+        for (int m = 0; m < t; ++m) {
+            wR = wR + w[m] * Rinv[m * t + k];                                    /* w'*Rinv[:,k]  :96 */
+            if (m == k) continue;
+            const float C12m = Ginv[k * t + m] + (d * dl[m]) * Rinv[k * t + m];  /* :90 */
+            rhs0 = rhs0 + Ginv[k * t + m] * b[m];                                /* :93 */
+            c12b = c12b + C12m * b[m];                                           /* :96 */
+        }
+        rhs0 = -rhs0;
+        const float invLhs0 = 1.0f / Ginv11;                                     /* :92 */
+        const float gHat0 = rhs0 * invLhs0;                                      /* :94 */
+        const float invLhs1 = 1.0f / C11;                                        /* :95 */
+        const float rhs1 = wR - c12b;                                            /* :96 */
+        const float gHat1 = rhs1 * invLhs1;                                      /* :97 */
+        unsigned s0 = 0, s1 = 0;
+        for (int m = 0; m < t; ++m) {
+            const unsigned bit = (m == k) ? 0u : (dl[m] != 0.0f ? 1u : 0u);
+            s0 |= bit << m; s1 |= bit << m;
+        }
+        s1 |= 1u << k;
+        const float in0 = logf_via_double(Ginv11) - (gHat0 * gHat0) * Ginv11;    /* Float32 part :104 */
+        const float in1 = logf_via_double(C11) - (gHat1 * gHat1) * C11;          /* Float32 part :105 */
+        const double logDelta0 = -0.5 * (double)in0 + log_prior[s0];
+        const double logDelta1 = -0.5 * (double)in1 + log_prior[s1];
+        const double probDelta1 = 1.0 / (1.0 + exp(logDelta0 - logDelta1));      /* :107 */
+        const double u = orc_uniform(seed, marker, iter, rep, (uint32_t)k);
+        const double z = orc_normal(seed, marker, iter, rep, (uint32_t)k);
+        if (u < probDelta1) {                                                    /* :108-111 */
+            dl[k] = 1.0f;
+            b[k] = (float)((double)gHat1 + z * (double)sqrtf(invLhs1));
+            alpha[k * stride] = b[k];
+            a_out[k] = a_old - b[k];
+        } else {                                                                 /* :112-119 */
+            b[k] = (float)((double)gHat0 + z * (double)sqrtf(invLhs0));
+            dl[k] = 0.0f;
+            alpha[k * stride] = 0.0f;
+            a_out[k] = a_old;
+        }
+    }
+    for (int k = 0; k < t; ++k) { beta[k * stride] = b[k]; delta[k * stride] = dl[k]; }
+}
+
+int orc_mtbayesc_I_sweep(const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
+                         int t, float* r, int64_t ld_r, float* alpha, float* beta, float* delta,
+                         const float* vare, const float* var_effect,
+                         const double* log_prior, int prior_is_matrix,
+                         uint64_t seed, uint32_t iter, uint32_t marker0, int acc)
+{
+    if (t < 1 || t > ORC_MAXT || n <= 0 || ld < n || ld_r < n) return -1;
+    float Rinv[ORC_MAXT * ORC_MAXT], Ginv[ORC_MAXT * ORC_MAXT];
+    if (inv_small(vare, t, Rinv) || inv_small(var_effect, t, Ginv)) return -2;
+    const int nstates = 1 << t;
+    for (int64_t j = 0; j < p; ++j) {
+        const float* x = X + j * ld;
+        float w[ORC_MAXT], a[ORC_MAXT];
+        for (int k = 0; k < t; ++k)                                              /* :82 */
+            w[k] = dot_acc(x, r + k * ld_r, n, acc) + xpx[j] * alpha[k * p + j];
+        mt1_update(t, w, xpx[j], alpha + j, beta + j, delta + j, p, Rinv, Ginv,
+                   prior_is_matrix ? log_prior + (int64_t)nstates * j : log_prior,
+                   seed, marker0 + (uint32_t)j, iter, 0, a);
+        for (int k = 0; k < t; ++k) if (a[k] != 0.0f) axpy_f32(a[k], x, r + k * ld_r, n);
+    }
+    return 0;
+}
+
+int orc_mtbayesc_I_block_sweep(const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
+                               const int64_t* block_starts, int64_t nblocks, const float* grams,
+                               int t, float* r, int64_t ld_r, float* alpha, float* beta, float* delta,
+                               const float* vare, const float* var_effect,
+                               const double* log_prior, int prior_is_matrix, int nreps_arg,
+                               uint64_t seed, uint32_t iter, uint32_t marker0, int acc)
+{
+    if (t < 1 || t > ORC_MAXT || n <= 0 || ld < n || ld_r < n || !blocks_ok(block_starts, nblocks, p)) return -1;
+    float Rinv[ORC_MAXT * ORC_MAXT], Ginv[ORC_MAXT * ORC_MAXT];
+    if (inv_small(vare, t, Rinv) || inv_small(var_effect, t, Ginv)) return -2;
+    const int nstates = 1 << t;
+    const float* G = grams;
+    for (int64_t bi = 0; bi < nblocks; ++bi) {                          /* MTBayesABC.jl:243-333 */
+        const int64_t j0 = block_starts[bi];
+        const int64_t b  = (bi + 1 < nblocks ? block_starts[bi + 1] : p) - j0;
+        float* a_old_blk = (float*)malloc(sizeof(float) * (size_t)(b * t));
+        float* rhs_b     = (float*)malloc(sizeof(float) * (size_t)(b * t));
+        for (int k = 0; k < t; ++k) {
+            memcpy(a_old_blk + k * b, alpha + k * p + j0, sizeof(float) * (size_t)b);
+            for (int64_t c = 0; c < b; ++c)
+                rhs_b[k * b + c] = dot_acc(X + (j0 + c) * ld, r + k * ld_r, n, acc);
+        }
+        const int nreps = nreps_arg > 0 ? nreps_arg : (int)b;
+        for (int rep = 0; rep < nreps; ++rep)
+            for (int64_t c = 0; c < b; ++c) {
+                const int64_t j = j0 + c;
+                float w[ORC_MAXT], a[ORC_MAXT];
+                for (int k = 0; k < t; ++k) w[k] = rhs_b[k * b + c] + xpx[j] * alpha[k * p + j];
+                mt1_update(t, w, xpx[j], alpha + j, beta + j, delta + j, p, Rinv, Ginv,
+                           prior_is_matrix ? log_prior + (int64_t)nstates * j : log_prior,
+                           seed, marker0 + (uint32_t)j, iter, (uint32_t)rep, a);
+                for (int k = 0; k < t; ++k)
+                    if (a[k] != 0.0f) axpy_f32(a[k], G + c * b, rhs_b + k * b, b);   /* :311,317 */
+            }
+        for (int k = 0; k < t; ++k)
+            for (int64_t c = 0; c < b; ++c) {                                        /* :329 */
+                const float d = a_old_blk[k * b + c] - alpha[k * p + j0 + c];
+                if (d != 0.0f) axpy_f32(d, X + (j0 + c) * ld, r + k * ld_r, n);
+            }
+        free(a_old_blk); free(rhs_b);
+        G += b * b;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* running posterior means (output.jl:568-577)                                                 */
+/* ------------------------------------------------------------------------------------------ */
+void orc_accumulate(const float* alpha, const void* delta, int delta_is_class, int64_t p, double k,
+                    float* mean_alpha, float* mean_alpha2, float* mean_delta)
+{
+    const float*   df = (const float*)delta;
+    const int32_t* di = (const int32_t*)delta;
+    for (int64_t j = 0; j < p; ++j) {
+        /* Float32 arrays divided by the Float64 sample count, stored back into Float32 arrays */
+        mean_alpha[j]  = (float)((double)mean_alpha[j]  + ((double)(alpha[j] - mean_alpha[j])) / k);
+        const float a2 = alpha[j] * alpha[j];
+        mean_alpha2[j] = (float)((double)mean_alpha2[j] + ((double)(a2 - mean_alpha2[j])) / k);
+        const float ind = delta_is_class ? (di[j] > 1 ? 1.0f : 0.0f) : df[j];
+        mean_delta[j]  = (float)((double)mean_delta[j]  + ((double)(ind - mean_delta[j])) / k);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* 2-bit codec (streaming_genotypes.jl:978-1002)                                               */
+/* ------------------------------------------------------------------------------------------ */
+void orc_decode_marker_2bit(const uint8_t* payload, int64_t n, int64_t j, float mean, int centered,
+                            float* out)
+{
+    const int64_t stride = (n + 3) / 4;                                   /* cld(n,4)  :364-367 */
+    const uint8_t* col = payload + j * stride;
+    for (int64_t i = 0; i < n; ++i) {
+        const unsigned code = (col[i >> 2] >> ((i & 3) << 1)) & 3u;      /* :993-995 */
+        float v = code == 3u ? mean : (float)code;                       /* :996-997 */
+        if (centered) v -= mean;                                         /* :998-999 */
+        out[i] = v;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* CPU baseline timing: the reference's per-marker operation order (sdot, scalar update, saxpy) */
+/* ------------------------------------------------------------------------------------------ */
+static float dot_f32_mt(const float* a, const float* b, int64_t n, int nthreads)
+{
+    float s = 0.0f;
+    if (nthreads <= 1) {
+        /* 8 independent partial sums: what a SIMD sdot kernel does */
+        float p[8] = {0};
+        int64_t i = 0;
+        for (; i + 8 <= n; i += 8)
+            for (int q = 0; q < 8; ++q) p[q] += a[i + q] * b[i + q];
+        for (; i < n; ++i) p[0] += a[i] * b[i];
+        for (int q = 0; q < 8; ++q) s += p[q];
+        return s;
+    }
+#ifdef _OPENMP
+#pragma omp parallel for reduction(+:s) num_threads(nthreads) schedule(static)
+#endif
+    for (int64_t i = 0; i < n; ++i) s += a[i] * b[i];
+    return s;
+}
+
+static void axpy_f32_mt(float a, const float* x, float* y, int64_t n, int nthreads)
+{
+    if (nthreads <= 1) { axpy_f32(a, x, y, n); return; }
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+#endif
+    for (int64_t i = 0; i < n; ++i) y[i] = fmaf(a, x[i], y[i]);
+}
+
+double orc_time_bayesc_sweeps(const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
+                              float* r, float* alpha, float* beta, float* delta,
+                              float vare, float var_effect, double pi,
+                              uint64_t seed, int sweeps, int nthreads)
+{
+    struct timespec t0, t1;
+    const float ie = 1.0f / vare;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int it = 0; it < sweeps; ++it)
+        for (int64_t j = 0; j < p; ++j) {
+            const float* x = X + j * ld;
+            const float s = dot_f32_mt(x, r, n, nthreads);
+            const double u = orc_uniform(seed, (uint32_t)j, (uint32_t)it + 1u, 0, 0);
+            const double z = orc_normal(seed, (uint32_t)j, (uint32_t)it + 1u, 0, 0);
+            const float a = abc_update(s, xpx[j], &alpha[j], &beta[j], &delta[j], ie, var_effect, pi, u, z);
+            if (a != 0.0f) axpy_f32_mt(a, x, r, n, nthreads);
+        }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}

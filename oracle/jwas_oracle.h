@@ -1,0 +1,145 @@
+/*
+ * jwas_oracle.h -- CPU ORACLE for the marker-effect Gibbs sweep.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This is a plain-C restatement of the reference's (reworkhow/JWAS.jl v2.3.6) single-site
+ * marker samplers.  It exists so that tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg can check / time the HIP path against an independent implementation.
+ * Nothing in the shipped package (jwas.jl_amd/) may include, link or call this file.
+ *
+ * PARITY STATUS: "parity unpinned" for sampler OUTPUT VALUES -- the reference ships no golden
+ * vectors for sampler output and Julia is not installed here, so the chain on a given seed
+ * cannot be compared with a Julia run.  What IS pinned against the reference's own tests are
+ * the deterministic / closed-form items (tests/test_oracle_kat.py): BayesR sufficient
+ * statistics, bayesr_block_nreps schedule, degenerate-prior class KAT, genetic2marker,
+ * 2-bit codec tables, the one-marker multi-trait posterior, memory formulas.
+ *
+ * Reference files restated (all under /root/reference/src/1.JWAS/src/):
+ *   markers/BayesianAlphabet/BayesABC.jl:24-80    bayesabc_update_marker!, BayesABC!
+ *   markers/BayesianAlphabet/BayesABC.jl:118-188  BayesABC_block!
+ *   markers/BayesianAlphabet/BayesR.jl:1-97       BayesR!
+ *   markers/BayesianAlphabet/BayesR.jl:111-193    BayesR_block!
+ *   markers/BayesianAlphabet/MTBayesABC.jl:57-127 _MTBayesABC_samplerI!
+ *   markers/tools4genotypes.jl:28-36,59-78,259-267  x'x, block_rhs!, block Grams
+ *   variance_components.jl:68-79                  bayesr_sigma_sufficient_statistics
+ *   output.jl:568-577                             running posterior means
+ *
+ * Numeric conventions (documented in DESIGN.md "Arithmetic contract"):
+ *   - storage types follow the reference's default Float32 path; the scalar chain promotes to
+ *     double exactly where Julia's promotion rules do (pi is Float64, randn()/rand() are Float64);
+ *   - every transcendental is evaluated in double and rounded to the type Julia would hold;
+ *   - x'r / x'x / Gram inner products: ORC_ACC_F64 accumulates exact fp32 products in double
+ *     and rounds once (order-independent to ~1e-16, the mode the HIP path implements);
+ *     ORC_ACC_F32 is a plain fp32 accumulation (what an sdot does, order unspecified);
+ *   - r += a*x is fmaf(a, x, r) per element (OpenBLAS saxpy kernels are FMA kernels);
+ *   - random numbers: counter-based Philox4x32-10 (Salmon et al., SC'11) keyed by the seed and
+ *     indexed by (marker, iteration, repetition, slot/trait), so a draw does not depend on
+ *     block size, shard or device count.  (The reference uses Julia's task-local Xoshiro256++,
+ *     which cannot be reproduced without Julia)
+ */
+#ifndef JWAS_ORACLE_H
+#define JWAS_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { ORC_ACC_F64 = 0, ORC_ACC_F32 = 1 };
+
+/* ---- random numbers -------------------------------------------------------------------- */
+void   orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+/* u in (0,1): 52 random bits, (k+0.5)*2^-52.  slot 0 of (marker,iter,rep,trait). */
+double orc_uniform(uint64_t seed, uint32_t marker, uint32_t iter, uint32_t rep, uint32_t trait);
+/* z ~ N(0,1): Box-Muller on two 52-bit uniforms from slot 1 of (marker,iter,rep,trait). */
+double orc_normal(uint64_t seed, uint32_t marker, uint32_t iter, uint32_t rep, uint32_t trait);
+
+/* ---- storage-layer precompute (tools4genotypes.jl:28-36, 259-267) ------------------------ */
+/* xpx[j] = x_j'x_j, X column-major n x p with leading dimension ld. */
+void orc_xpx(const float* X, int64_t n, int64_t p, int64_t ld, float* xpx, int acc);
+/* Gram of columns [j0, j0+b): G (b x b, row-major, full symmetric) = X_b' X_b. */
+void orc_gram(const float* X, int64_t n, int64_t ld, int64_t j0, int64_t b, float* G, int acc);
+/* out = r - X*alpha  (MCMC_BayesianAlphabet.jl:131-147), sequential fmaf in marker order. */
+void orc_residual_minus_xalpha(const float* X, int64_t n, int64_t p, int64_t ld,
+                               const float* alpha, float* r);
+
+/* ---- single-trait BayesA/B/C, non-block (BayesABC.jl:60-80) ------------------------------ */
+/* var_effects: p values (BayesC: all equal).  pi: p values (probability of a ZERO effect).
+ * marker0: global index of column 0 (enters the RNG counter; 0 unless the caller holds a shard).
+ * Returns 0, or -1 on invalid arguments. */
+int orc_bayesabc_sweep(const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
+                       float* r, float* alpha, float* beta, float* delta,
+                       float vare, const float* var_effects, const double* pi,
+                       uint64_t seed, uint32_t iter, uint32_t marker0, int acc);
+
+/* ---- single-trait BayesA/B/C, exact block form (BayesABC.jl:118-188) --------------------- */
+/* block_starts: nblocks 0-based start columns (ascending, first = 0); grams: concatenated
+ * b_i x b_i row-major Gram blocks.  nreps <= 0 means nreps = block size (the reference's
+ * schedule, BayesABC.jl:153); nreps = 1 is algebraically the non-block chain. */
+int orc_bayesabc_block_sweep(const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
+                             const int64_t* block_starts, int64_t nblocks, const float* grams,
+                             float* r, float* alpha, float* beta, float* delta,
+                             float vare, const float* var_effects, const double* pi,
+                             int nreps, uint64_t seed, uint32_t iter, uint32_t marker0, int acc);
+
+/* ---- single-trait BayesR (BayesR.jl:45-97) and block form (BayesR.jl:111-193) ------------ */
+/* pi: 4 values, or p x 4 row-major when pi_is_matrix != 0.  delta holds classes 1..4 (int32).
+ * gamma: 4 doubles.  Returns -1 on invalid priors (BayesR.jl:9-20), -2 if sigma_sq <= 0. */
+int orc_bayesr_sweep(const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
+                     float* r, float* alpha, int32_t* delta,
+                     float vare, float sigma_sq, const double* pi, int pi_is_matrix,
+                     const double* gamma, uint64_t seed, uint32_t iter, uint32_t marker0, int acc);
+int orc_bayesr_block_sweep(const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
+                           const int64_t* block_starts, int64_t nblocks, const float* grams,
+                           float* r, float* alpha, int32_t* delta,
+                           float vare, float sigma_sq, const double* pi, int pi_is_matrix,
+                           const double* gamma, int nreps,
+                           uint64_t seed, uint32_t iter, uint32_t marker0, int acc);
+/* BayesR.jl:22-25 */
+int orc_bayesr_block_nreps(int64_t iter, int64_t burnin, int64_t block_size);
+/* variance_components.jl:68-79 */
+void orc_bayesr_sigma_suffstats(const float* alpha, const int32_t* delta, int64_t p,
+                                const double* gamma, double* ssq, int64_t* nnz);
+
+/* ---- multi-trait BayesC, Gibbs sampler I (MTBayesABC.jl:57-127), non-block and block ------ */
+/* t traits (<= 8).  r: t residual vectors of length ld_r each (trait-major).  alpha/beta/delta:
+ * t x p trait-major.  vare: t x t row-major.  var_effect: t x t (BayesC: shared by all markers).
+ * log_prior: 2^t values indexed by state = sum_k delta_k << k  (GlobalPiPrior) or p x 2^t when
+ * prior_is_matrix (MarkerSpecificPiPrior). */
+int orc_mtbayesc_I_sweep(const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
+                         int t, float* r, int64_t ld_r, float* alpha, float* beta, float* delta,
+                         const float* vare, const float* var_effect,
+                         const double* log_prior, int prior_is_matrix,
+                         uint64_t seed, uint32_t iter, uint32_t marker0, int acc);
+int orc_mtbayesc_I_block_sweep(const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
+                               const int64_t* block_starts, int64_t nblocks, const float* grams,
+                               int t, float* r, int64_t ld_r, float* alpha, float* beta, float* delta,
+                               const float* vare, const float* var_effect,
+                               const double* log_prior, int prior_is_matrix, int nreps,
+                               uint64_t seed, uint32_t iter, uint32_t marker0, int acc);
+
+/* ---- running posterior means (output.jl:568-577) ------------------------------------------ */
+/* mean += (x-mean)/k ; mean2 += (x^2-mean2)/k ; freq += (ind-freq)/k, ind = delta (BayesC) or
+ * delta>1 (BayesR, delta_is_class != 0). */
+void orc_accumulate(const float* alpha, const void* delta, int delta_is_class, int64_t p, double k,
+                    float* mean_alpha, float* mean_alpha2, float* mean_delta);
+
+/* ---- 2-bit packed genotype codec (streaming_genotypes.jl:364-367, 978-1027) ---------------- */
+/* decode marker j of a .jgb2 payload: stride = ceil(n/4) bytes per marker, individual i in byte
+ * i>>2 at bit shift (i&3)<<1; codes 0/1/2 = genotype, 3 = missing -> mean; subtract mean when
+ * centered. */
+void orc_decode_marker_2bit(const uint8_t* payload, int64_t n, int64_t j, float mean, int centered,
+                            float* out);
+
+/* ---- CPU baseline timing helper (bench.py cpu_baseline leg) ------------------------------- */
+/* Runs `sweeps` non-block BayesC sweeps (ORC_ACC_F32 dot + axpy, the reference's per-marker
+ * operation order) and returns elapsed seconds; nthreads > 1 splits the dot/axpy rows over
+ * POSIX threads the way a threaded BLAS would. */
+double orc_time_bayesc_sweeps(const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
+                              float* r, float* alpha, float* beta, float* delta,
+                              float vare, float var_effect, double pi,
+                              uint64_t seed, int sweeps, int nthreads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

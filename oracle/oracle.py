@@ -1,0 +1,266 @@
+"""ctypes binding of the CPU oracle (oracle/jwas_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The shipped package (jwas.jl_amd/) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libjwas_oracle.so")
+
+ACC_F64 = 0
+ACC_F32 = 1
+GAMMA = np.array([0.0, 0.01, 0.1, 1.0], dtype=np.float64)  # JWAS.jl:12
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "jwas_oracle.c")
+    hdr = os.path.join(_HERE, "jwas_oracle.h")
+    stale = (not os.path.exists(_LIB_PATH)) or any(
+        os.path.exists(f) and os.path.getmtime(f) > os.path.getmtime(_LIB_PATH) for f in (src, hdr))
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libjwas_oracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+_f32p = C.POINTER(C.c_float)
+_f64p = C.POINTER(C.c_double)
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+_u8p = C.POINTER(C.c_uint8)
+_u32p = C.POINTER(C.c_uint32)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        L.orc_uniform.restype = C.c_double
+        L.orc_uniform.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.orc_normal.restype = C.c_double
+        L.orc_normal.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.orc_philox4x32_10.restype = None
+        L.orc_philox4x32_10.argtypes = [_u32p, _u32p, _u32p]
+        L.orc_time_bayesc_sweeps.restype = C.c_double
+        L.orc_bayesr_block_nreps.argtypes = [C.c_int64, C.c_int64, C.c_int64]
+        _lib = L
+    return _lib
+
+
+def _p(a, ty):
+    return a.ctypes.data_as(ty)
+
+
+def _f32(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a
+
+
+def philox(ctr, key):
+    c = np.asarray(ctr, dtype=np.uint32)
+    k = np.asarray(key, dtype=np.uint32)
+    out = np.zeros(4, dtype=np.uint32)
+    lib().orc_philox4x32_10(_p(c, _u32p), _p(k, _u32p), _p(out, _u32p))
+    return out
+
+
+def uniform(seed, marker, it, rep=0, trait=0):
+    return lib().orc_uniform(seed, marker, it, rep, trait)
+
+
+def normal(seed, marker, it, rep=0, trait=0):
+    return lib().orc_normal(seed, marker, it, rep, trait)
+
+
+def _xinfo(X):
+    """X: numpy array n x p, Fortran (column-major, marker-major) float32."""
+    assert X.dtype == np.float32 and X.ndim == 2 and X.flags.f_contiguous
+    n, p = X.shape
+    ld = X.strides[1] // 4 if p > 1 else n
+    return n, p, max(ld, n)
+
+
+def xpx(X, acc=ACC_F64):
+    n, p, ld = _xinfo(X)
+    out = np.zeros(p, dtype=np.float32)
+    lib().orc_xpx(_p(X, _f32p), C.c_int64(n), C.c_int64(p), C.c_int64(ld), _p(out, _f32p), C.c_int(acc))
+    return out
+
+
+def gram(X, j0, b, acc=ACC_F64):
+    n, p, ld = _xinfo(X)
+    out = np.zeros((b, b), dtype=np.float32)
+    lib().orc_gram(_p(X, _f32p), C.c_int64(n), C.c_int64(ld), C.c_int64(j0), C.c_int64(b),
+                   _p(out, _f32p), C.c_int(acc))
+    return out
+
+
+def block_starts_for(p, block_size):
+    return np.arange(0, p, block_size, dtype=np.int64)
+
+
+def grams_for(X, block_starts, acc=ACC_F64):
+    p = X.shape[1]
+    bs = list(block_starts) + [p]
+    return np.concatenate([gram(X, bs[i], bs[i + 1] - bs[i], acc).ravel() for i in range(len(bs) - 1)])
+
+
+def residual_minus_xalpha(X, alpha, r):
+    n, p, ld = _xinfo(X)
+    alpha = _f32(alpha)
+    lib().orc_residual_minus_xalpha(_p(X, _f32p), C.c_int64(n), C.c_int64(p), C.c_int64(ld),
+                                    _p(alpha, _f32p), _p(r, _f32p))
+
+
+def _vec_or_fill(v, p, dtype):
+    v = np.asarray(v, dtype=dtype)
+    if v.ndim == 0:
+        return np.full(p, v, dtype=dtype)
+    return np.ascontiguousarray(v)
+
+
+def bayesabc_sweep(X, xpx_, r, alpha, beta, delta, vare, var_effects, pi, seed, it,
+                   marker0=0, acc=ACC_F64, block_starts=None, grams=None, nreps=1):
+    """In-place sweep.  block_starts=None -> non-block form (BayesABC.jl:60-80)."""
+    n, p, ld = _xinfo(X)
+    ve = _vec_or_fill(var_effects, p, np.float32)
+    pv = np.asarray(pi, dtype=np.float64)
+    if pv.ndim == 1 and pv.shape[0] != p:
+        # bayesabc_pi_vector (BayesABC.jl:16-22)
+        raise ValueError(f"BayesABC pi vector length {pv.shape[0]} must match the number of markers ({p}).")
+    pv = _vec_or_fill(pv, p, np.float64)
+    for a in (r, alpha, beta, delta):
+        assert a.dtype == np.float32 and a.flags.c_contiguous
+    if block_starts is None:
+        rc = lib().orc_bayesabc_sweep(_p(X, _f32p), C.c_int64(n), C.c_int64(p), C.c_int64(ld), _p(xpx_, _f32p),
+                                      _p(r, _f32p), _p(alpha, _f32p), _p(beta, _f32p), _p(delta, _f32p),
+                                      C.c_float(vare), _p(ve, _f32p), _p(pv, _f64p),
+                                      C.c_uint64(seed), C.c_uint32(it), C.c_uint32(marker0), C.c_int(acc))
+    else:
+        bs = np.ascontiguousarray(block_starts, dtype=np.int64)
+        g = _f32(grams)
+        rc = lib().orc_bayesabc_block_sweep(_p(X, _f32p), C.c_int64(n), C.c_int64(p), C.c_int64(ld), _p(xpx_, _f32p),
+                                            _p(bs, _i64p), C.c_int64(len(bs)), _p(g, _f32p),
+                                            _p(r, _f32p), _p(alpha, _f32p), _p(beta, _f32p), _p(delta, _f32p),
+                                            C.c_float(vare), _p(ve, _f32p), _p(pv, _f64p), C.c_int(nreps),
+                                            C.c_uint64(seed), C.c_uint32(it), C.c_uint32(marker0), C.c_int(acc))
+    if rc != 0:
+        raise ValueError(f"oracle BayesABC sweep rejected its arguments (rc={rc})")
+
+
+def bayesr_sweep(X, xpx_, r, alpha, delta, vare, sigma_sq, pi, seed, it, gamma=GAMMA,
+                 marker0=0, acc=ACC_F64, block_starts=None, grams=None, nreps=1):
+    n, p, ld = _xinfo(X)
+    pv = np.ascontiguousarray(pi, dtype=np.float64)
+    is_mat = int(pv.ndim == 2)
+    # bayesr_validate_priors (BayesR.jl:9-20)
+    if is_mat:
+        if pv.shape[0] != p:
+            raise ValueError("BayesR per-marker pi must have one row per marker.")
+        if pv.shape[1] != 4:
+            raise ValueError("BayesR per-marker pi must have 4 columns.")
+    elif pv.shape[0] != 4:
+        raise ValueError(f"BayesR pi vector length {pv.shape[0]} must match the number of mixture classes (4).")
+    assert delta.dtype == np.int32 and alpha.dtype == np.float32 and r.dtype == np.float32
+    g4 = np.ascontiguousarray(gamma, dtype=np.float64)
+    if block_starts is None:
+        rc = lib().orc_bayesr_sweep(_p(X, _f32p), C.c_int64(n), C.c_int64(p), C.c_int64(ld), _p(xpx_, _f32p),
+                                    _p(r, _f32p), _p(alpha, _f32p), _p(delta, _i32p),
+                                    C.c_float(vare), C.c_float(sigma_sq), _p(pv, _f64p), C.c_int(is_mat),
+                                    _p(g4, _f64p), C.c_uint64(seed), C.c_uint32(it), C.c_uint32(marker0), C.c_int(acc))
+    else:
+        bs = np.ascontiguousarray(block_starts, dtype=np.int64)
+        g = _f32(grams)
+        rc = lib().orc_bayesr_block_sweep(_p(X, _f32p), C.c_int64(n), C.c_int64(p), C.c_int64(ld), _p(xpx_, _f32p),
+                                          _p(bs, _i64p), C.c_int64(len(bs)), _p(g, _f32p),
+                                          _p(r, _f32p), _p(alpha, _f32p), _p(delta, _i32p),
+                                          C.c_float(vare), C.c_float(sigma_sq), _p(pv, _f64p), C.c_int(is_mat),
+                                          _p(g4, _f64p), C.c_int(nreps),
+                                          C.c_uint64(seed), C.c_uint32(it), C.c_uint32(marker0), C.c_int(acc))
+    if rc == -2:
+        raise ValueError("BayesR sigmaSq must be positive.")
+    if rc != 0:
+        raise ValueError("BayesR pi entries must be nonnegative and sum to 1.")
+
+
+def bayesr_block_nreps(it, burnin, block_size):
+    v = lib().orc_bayesr_block_nreps(it, burnin, block_size)
+    if v < 0:
+        raise ValueError("BayesR block_size must be at least 1.")
+    return v
+
+
+def bayesr_sigma_suffstats(alpha, delta, gamma=GAMMA):
+    a = _f32(alpha)
+    d = np.ascontiguousarray(delta, dtype=np.int32)
+    g = np.ascontiguousarray(gamma, dtype=np.float64)
+    ssq = C.c_double(0.0)
+    nnz = C.c_int64(0)
+    lib().orc_bayesr_sigma_suffstats(_p(a, _f32p), _p(d, _i32p), C.c_int64(len(a)), _p(g, _f64p),
+                                     C.byref(ssq), C.byref(nnz))
+    return ssq.value, nnz.value
+
+
+def mtbayesc_I_sweep(X, xpx_, r, alpha, beta, delta, vare, var_effect, log_prior, seed, it,
+                     marker0=0, acc=ACC_F64, block_starts=None, grams=None, nreps=1):
+    """r: t x ld_r float32 C-contiguous; alpha/beta/delta: t x p float32 C-contiguous.
+    log_prior: 2^t (global) or p x 2^t (marker-specific), float64."""
+    n, p, ld = _xinfo(X)
+    t = r.shape[0]
+    ld_r = r.shape[1]
+    ve = np.ascontiguousarray(vare, dtype=np.float32)
+    vg = np.ascontiguousarray(var_effect, dtype=np.float32)
+    lp = np.ascontiguousarray(log_prior, dtype=np.float64)
+    is_mat = int(lp.ndim == 2)
+    for a in (r, alpha, beta, delta):
+        assert a.dtype == np.float32 and a.flags.c_contiguous
+    if block_starts is None:
+        rc = lib().orc_mtbayesc_I_sweep(_p(X, _f32p), C.c_int64(n), C.c_int64(p), C.c_int64(ld), _p(xpx_, _f32p),
+                                        C.c_int(t), _p(r, _f32p), C.c_int64(ld_r),
+                                        _p(alpha, _f32p), _p(beta, _f32p), _p(delta, _f32p),
+                                        _p(ve, _f32p), _p(vg, _f32p), _p(lp, _f64p), C.c_int(is_mat),
+                                        C.c_uint64(seed), C.c_uint32(it), C.c_uint32(marker0), C.c_int(acc))
+    else:
+        bs = np.ascontiguousarray(block_starts, dtype=np.int64)
+        g = _f32(grams)
+        rc = lib().orc_mtbayesc_I_block_sweep(_p(X, _f32p), C.c_int64(n), C.c_int64(p), C.c_int64(ld), _p(xpx_, _f32p),
+                                              _p(bs, _i64p), C.c_int64(len(bs)), _p(g, _f32p),
+                                              C.c_int(t), _p(r, _f32p), C.c_int64(ld_r),
+                                              _p(alpha, _f32p), _p(beta, _f32p), _p(delta, _f32p),
+                                              _p(ve, _f32p), _p(vg, _f32p), _p(lp, _f64p), C.c_int(is_mat),
+                                              C.c_int(nreps),
+                                              C.c_uint64(seed), C.c_uint32(it), C.c_uint32(marker0), C.c_int(acc))
+    if rc != 0:
+        raise ValueError(f"oracle MT sampler I rejected its arguments (rc={rc})")
+
+
+def accumulate(alpha, delta, k, mean_alpha, mean_alpha2, mean_delta):
+    a = _f32(alpha)
+    is_class = int(delta.dtype == np.int32)
+    d = np.ascontiguousarray(delta)
+    lib().orc_accumulate(_p(a, _f32p), d.ctypes.data_as(C.c_void_p), C.c_int(is_class), C.c_int64(len(a)),
+                         C.c_double(k), _p(mean_alpha, _f32p), _p(mean_alpha2, _f32p), _p(mean_delta, _f32p))
+
+
+def decode_marker_2bit(payload, n, j, mean, centered=True):
+    pl = np.ascontiguousarray(payload, dtype=np.uint8)
+    out = np.zeros(n, dtype=np.float32)
+    lib().orc_decode_marker_2bit(_p(pl, _u8p), C.c_int64(n), C.c_int64(j), C.c_float(mean),
+                                 C.c_int(int(centered)), _p(out, _f32p))
+    return out
+
+
+def time_bayesc_sweeps(X, xpx_, r, alpha, beta, delta, vare, var_effect, pi, seed, sweeps, nthreads=1):
+    n, p, ld = _xinfo(X)
+    return lib().orc_time_bayesc_sweeps(_p(X, _f32p), C.c_int64(n), C.c_int64(p), C.c_int64(ld), _p(xpx_, _f32p),
+                                        _p(r, _f32p), _p(alpha, _f32p), _p(beta, _f32p), _p(delta, _f32p),
+                                        C.c_float(vare), C.c_float(var_effect), C.c_double(pi),
+                                        C.c_uint64(seed), C.c_int(sweeps), C.c_int(nthreads))

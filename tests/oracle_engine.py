@@ -1,0 +1,147 @@
+"""OracleEngine: the sweep-engine protocol of jwas.jl_amd.engine.HipEngine implemented on the CPU
+oracle (oracle/jwas_oracle.c).  TEST INFRASTRUCTURE: lives under tests/, never imported by the
+package.  It lets the host MCMC loop run on CPU so GPU chains can be compared end to end.
+"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+import oracle as O  # noqa: E402
+
+BAYESC, BAYESB, BAYESR, MTBAYESC1 = 0, 1, 2, 3
+METHOD_CODES = {"BayesC": BAYESC, "BayesB": BAYESB, "BayesA": BAYESB, "BayesR": BAYESR, "MTBayesC": MTBAYESC1}
+
+
+class OracleEngine:
+    """form='block' mirrors the device algorithm (exact block form with the same block size);
+    form='dense' is the literal non-block restatement (BayesABC.jl:60-80)."""
+
+    def __init__(self, form="block", acc=O.ACC_F64):
+        self.form, self.acc = form, acc
+        self.n = self.p = 0
+        self.method = None
+        self.ntraits = 0
+        self.block_size = 0
+
+    def close(self):
+        pass
+
+    def load_dense(self, X):
+        X = np.asfortranarray(np.asarray(X, dtype=np.float32))
+        self.X = X
+        self.n, self.p = X.shape
+
+    def setup_blocks(self, block_size=256, gram_mode="f64"):
+        self.block_size = int(block_size)
+        self._xpx = O.xpx(self.X, self.acc)
+        self._bs = O.block_starts_for(self.p, self.block_size)
+        self._grams = O.grams_for(self.X, self._bs, self.acc)
+
+    @property
+    def nblocks(self):
+        return len(self._bs)
+
+    def block_starts(self):
+        return self._bs
+
+    def xpx(self):
+        return self._xpx.copy()
+
+    def grams_packed(self):
+        return self._grams
+
+    def set_grams_packed(self, g):
+        self._grams = np.ascontiguousarray(g, dtype=np.float32)
+
+    def init_state(self, method, ntraits=1):
+        self.method = METHOD_CODES[method] if isinstance(method, str) else int(method)
+        self.ntraits = int(ntraits)
+        t, p = self.ntraits, self.p
+        self.alpha = np.zeros((t, p), dtype=np.float32)
+        self.beta = np.zeros((t, p), dtype=np.float32)
+        self.delta = np.zeros((t, p), dtype=np.int32 if self.method == BAYESR else np.float32)
+        self.r = np.zeros((t, self.n), dtype=np.float32)
+        self.mean_a = np.zeros((t, p), dtype=np.float32)
+        self.mean_a2 = np.zeros((t, p), dtype=np.float32)
+        self.mean_d = np.zeros((t, p), dtype=np.float32)
+
+    def set_state(self, trait=0, alpha=None, beta=None, delta=None):
+        if alpha is not None:
+            self.alpha[trait] = alpha
+        if beta is not None:
+            self.beta[trait] = beta
+        if delta is not None:
+            self.delta[trait] = delta
+
+    def get_state(self, trait=0):
+        return self.alpha[trait].copy(), self.beta[trait].copy(), self.delta[trait].copy()
+
+    def set_residual(self, r, trait=0):
+        self.r[trait] = r
+
+    def get_residual(self, trait=0):
+        return self.r[trait].copy()
+
+    def sub_xalpha(self, trait=0):
+        O.residual_minus_xalpha(self.X, self.alpha[trait], self.r[trait])
+
+    def mul_alpha(self, trait=0):
+        return (self.X.astype(np.float64) @ self.alpha[trait].astype(np.float64)).astype(np.float32)
+
+    def sweep(self, *, iteration, seed, vare, var_effect, pi=0.0, pi_classes=None, gamma=O.GAMMA,
+              log_prior_states=None, var_effect_vec=None, pi_vec=None, pi_matrix=None, nreps=1,
+              marker_offset=0):
+        t = self.ntraits
+        blk = dict(block_starts=self._bs, grams=self._grams, nreps=nreps) if self.form == "block" else {}
+        a_before = self.alpha.copy()
+        if self.method in (BAYESC, BAYESB):
+            if np.ndim(pi) == 1:
+                pi_vec = pi
+            pv = pi_vec if pi_vec is not None else float(pi)
+            ve = var_effect_vec if self.method == BAYESB else float(np.asarray(var_effect).reshape(-1)[0])
+            O.bayesabc_sweep(self.X, self._xpx, self.r[0], self.alpha[0], self.beta[0], self.delta[0],
+                             float(np.asarray(vare).reshape(-1)[0]), ve, pv, seed, iteration,
+                             marker0=marker_offset, acc=self.acc, **blk)
+        elif self.method == BAYESR:
+            pc = pi_matrix if pi_matrix is not None else pi_classes
+            O.bayesr_sweep(self.X, self._xpx, self.r[0], self.alpha[0], self.delta[0],
+                           float(np.asarray(vare).reshape(-1)[0]), float(np.asarray(var_effect).reshape(-1)[0]),
+                           pc, seed, iteration, gamma=gamma, marker0=marker_offset, acc=self.acc, **blk)
+        else:
+            O.mtbayesc_I_sweep(self.X, self._xpx, self.r, self.alpha, self.beta, self.delta,
+                               np.asarray(vare, dtype=np.float32).reshape(t, t),
+                               np.asarray(var_effect, dtype=np.float32).reshape(t, t),
+                               log_prior_states, seed, iteration, marker0=marker_offset, acc=self.acc, **blk)
+        return self._stats(a_before, gamma)
+
+    def _stats(self, a_before, gamma):
+        t = self.ntraits
+        a64, b64, r64 = self.alpha.astype(np.float64), self.beta.astype(np.float64), self.r.astype(np.float64)
+        out = {
+            "alpha_ss": a64 @ a64.T, "beta_ss": b64 @ b64.T, "resid_ss": r64 @ r64.T,
+            "resid_sum": r64.sum(axis=1), "n_events": float(np.any(a_before != self.alpha, axis=0).sum()),
+            "sweep_ms": 0.0, "class_counts": np.zeros(4), "bayesr_ssq": 0.0, "bayesr_nnz": 0.0,
+            "sum_delta": np.zeros(t), "state_counts": np.zeros(1 << t),
+        }
+        if self.method == BAYESR:
+            d = self.delta[0]
+            out["class_counts"] = np.array([(d == k + 1).sum() for k in range(4)], dtype=np.float64)
+            ssq, nnz = O.bayesr_sigma_suffstats(self.alpha[0], d, gamma)
+            out["bayesr_ssq"], out["bayesr_nnz"] = ssq, float(nnz)
+        else:
+            d = self.delta
+            out["sum_delta"] = d.astype(np.float64).sum(axis=1)
+            state = np.zeros(self.p, dtype=np.int64)
+            for k in range(t):
+                state |= (d[k] != 0).astype(np.int64) << k
+            out["state_counts"] = np.bincount(state, minlength=1 << t).astype(np.float64)
+        return out
+
+    def accumulate(self, nsamples):
+        for k in range(self.ntraits):
+            O.accumulate(self.alpha[k], self.delta[k], float(nsamples), self.mean_a[k], self.mean_a2[k], self.mean_d[k])
+
+    def posterior(self, trait=0):
+        return self.mean_a[trait].copy(), self.mean_a2[trait].copy(), self.mean_d[trait].copy()

@@ -1,0 +1,271 @@
+"""GPU parity tests: the HIP sweep (through the C ABI) against the CPU oracle on identical seeded
+inputs.  Tolerances: delta / class trajectories bit-exact; alpha and the residual within a few
+fp32 ulp (the stated floating-point tolerance is 1e-4 on posterior means, the reference's own
+dense-vs-stream tolerance, test/unit/test_streaming_codec.jl:100,104; observed agreement is ~1e-7).
+"""
+import numpy as np
+import pytest
+
+from conftest import make_dataset
+from oracle_engine import OracleEngine
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import jwas_jl_amd as J
+    e = J.HipEngine(0)
+    yield e
+    e.close()
+
+
+def _pair(hip, data, block_size, method, ntraits=1, gram_mode="f64"):
+    X = data["X"]
+    orc = OracleEngine(form="block")
+    orc.load_dense(X)
+    orc.setup_blocks(block_size)
+    orc.init_state(method, ntraits)
+    hip.load_dense(X)
+    hip.setup_blocks(block_size, gram_mode)
+    hip.init_state(method, ntraits)
+    return orc, hip
+
+
+def _hyper(data, pi=0.95):
+    vare = np.float32(0.5 * data["y"].var())
+    sum2pq = float((2 * data["freq"] * (1 - data["freq"])).sum())
+    varg = np.float32(0.5 * data["y"].var() / ((1 - pi) * sum2pq))
+    return vare, varg
+
+
+def _compare_state(orc, hip, t=0, atol=2e-6):
+    ao, bo, do = orc.get_state(t)
+    ah, bh, dh = hip.get_state(t)
+    assert np.array_equal(do, dh), f"delta trajectories diverged at {np.flatnonzero(do != dh)[:5]}"
+    np.testing.assert_allclose(ah, ao, rtol=0, atol=atol)
+    np.testing.assert_allclose(bh, bo, rtol=0, atol=atol)
+    np.testing.assert_allclose(hip.get_residual(t), orc.get_residual(t), rtol=0, atol=2e-5)
+
+
+def test_xpx_and_gram_exact(hip, small_data):
+    orc, hip = _pair(hip, small_data, 64, "BayesC")
+    xo, xh = orc.xpx(), hip.xpx()
+    np.testing.assert_allclose(xh, xo, rtol=1.2e-7, atol=0)
+    assert (xh == xo).mean() > 0.999
+    off = 0
+    for i in range(hip.nblocks):
+        G = hip.gram(i)
+        b = G.shape[0]
+        Go = orc.grams_packed()[off:off + b * b].reshape(b, b)
+        off += b * b
+        np.testing.assert_allclose(G, Go, rtol=1.2e-7, atol=1e-6)
+        assert np.array_equal(G, G.T)
+
+
+@pytest.mark.parametrize("bs", [64, 128, 256, 512])
+def test_gram_mfma_close(hip, bs):
+    data = make_dataset(n=1500, p=2 * bs + 37, ncausal=5, seed=5)
+    orc, hip = _pair(hip, data, bs, "BayesC", gram_mode="mfma")
+    off = 0
+    for i in range(hip.nblocks):
+        G = hip.gram(i)
+        b = G.shape[0]
+        Go = orc.grams_packed()[off:off + b * b].reshape(b, b)
+        off += b * b
+        scale = np.sqrt(np.outer(np.diag(Go), np.diag(Go)))
+        assert np.abs(G - Go).max() / scale.max() < 2e-6
+        assert np.array_equal(G, G.T)
+
+
+@pytest.mark.parametrize("bs", [64, 128, 256, 512])
+def test_bayesc_chain_parity(hip, bs):
+    # n not a multiple of 256, p not a multiple of the block size
+    data = make_dataset(n=777, p=3 * bs + 41, ncausal=12, seed=100 + bs)
+    orc, hip = _pair(hip, data, bs, "BayesC")
+    r0 = data["y"] - data["y"].mean()
+    orc.set_residual(r0)
+    hip.set_residual(r0)
+    vare, varg = _hyper(data)
+    for it in range(1, 41):
+        so = orc.sweep(iteration=it, seed=2026, vare=vare, var_effect=varg, pi=0.9)
+        sh = hip.sweep(iteration=it, seed=2026, vare=vare, var_effect=varg, pi=0.9)
+        assert so["sum_delta"][0] == sh["sum_delta"][0], f"iteration {it}"
+        assert so["n_events"] == sh["n_events"]
+        np.testing.assert_allclose(sh["alpha_ss"], so["alpha_ss"], rtol=1e-6)
+        np.testing.assert_allclose(sh["resid_ss"], so["resid_ss"], rtol=1e-6)
+        np.testing.assert_allclose(sh["resid_sum"], so["resid_sum"], rtol=0, atol=1e-3)
+    _compare_state(orc, hip)
+
+
+def test_bayesc_all_included_pi0(hip, small_data):
+    """Pi = 0: every marker is in the model every sweep (the reference benchmark's setting,
+    benchmarks/jwas_nonblock_benchmark.jl:34-51): the dense-event path."""
+    orc, hip = _pair(hip, small_data, 128, "BayesC")
+    r0 = small_data["y"] - small_data["y"].mean()
+    orc.set_residual(r0)
+    hip.set_residual(r0)
+    vare, varg = np.float32(0.6), np.float32(0.002)
+    for it in range(1, 6):
+        so = orc.sweep(iteration=it, seed=3, vare=vare, var_effect=varg, pi=0.0)
+        sh = hip.sweep(iteration=it, seed=3, vare=vare, var_effect=varg, pi=0.0)
+        assert sh["sum_delta"][0] == small_data["X"].shape[1] == so["sum_delta"][0]
+    _compare_state(orc, hip, atol=5e-6)
+
+
+def test_bayesc_pi_vector_and_bayesb(hip, small_data):
+    p = small_data["X"].shape[1]
+    rng = np.random.default_rng(0)
+    pi_vec = rng.uniform(0.5, 0.99, size=p)
+    var_vec = rng.uniform(0.001, 0.01, size=p).astype(np.float32)
+    r0 = small_data["y"] - small_data["y"].mean()
+    for method in ("BayesC", "BayesB"):
+        orc, hip_ = _pair(hip, small_data, 64, method)
+        orc.set_residual(r0)
+        hip_.set_residual(r0)
+        kw = dict(seed=9, vare=np.float32(0.5), var_effect=np.float32(0.004), pi=pi_vec)
+        if method == "BayesB":
+            kw["var_effect_vec"] = var_vec
+        for it in range(1, 16):
+            orc.sweep(iteration=it, **kw)
+            hip_.sweep(iteration=it, **kw)
+        _compare_state(orc, hip_)
+    with pytest.raises(ValueError, match="length"):
+        hip.sweep(iteration=1, seed=1, vare=0.5, var_effect=0.004, pi=np.array([0.5]))
+
+
+@pytest.mark.parametrize("bs", [64, 256])
+def test_bayesr_chain_parity(hip, bs):
+    data = make_dataset(n=600, p=2 * bs + 19, ncausal=10, seed=300 + bs)
+    orc, hip = _pair(hip, data, bs, "BayesR")
+    r0 = data["y"] - data["y"].mean()
+    orc.set_residual(r0)
+    hip.set_residual(r0)
+    orc.set_state(delta=np.ones(orc.p, dtype=np.int32))
+    hip.set_state(delta=np.ones(hip.p, dtype=np.int32))
+    pi4 = np.array([0.95, 0.03, 0.015, 0.005])
+    vare, sig = np.float32(0.5), np.float32(0.05)
+    for it in range(1, 31):
+        so = orc.sweep(iteration=it, seed=77, vare=vare, var_effect=sig, pi_classes=pi4)
+        sh = hip.sweep(iteration=it, seed=77, vare=vare, var_effect=sig, pi_classes=pi4)
+        assert np.array_equal(so["class_counts"], sh["class_counts"]), f"iteration {it}"
+        assert so["bayesr_nnz"] == sh["bayesr_nnz"]
+        np.testing.assert_allclose(sh["bayesr_ssq"], so["bayesr_ssq"], rtol=1e-5)
+    ao, _, do = orc.get_state()
+    ah, _, dh = hip.get_state()
+    assert np.array_equal(do, dh)
+    np.testing.assert_allclose(ah, ao, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(hip.get_residual(), orc.get_residual(), rtol=0, atol=2e-5)
+
+
+def test_bayesr_degenerate_priors_kat(hip):
+    """test/unit/test_annotated_bayesr.jl:247-266: per-SNP priors that force delta == [2, 1]."""
+    X = np.asfortranarray(np.array([[0, 2], [1, 1], [2, 0], [1, 1]], dtype=np.float32))
+    hip.load_dense(X)
+    hip.setup_blocks(64, "f64")
+    hip.init_state("BayesR")
+    hip.set_residual(np.array([0.8, -0.1, 0.3, 0.5], dtype=np.float32))
+    snp_pi = np.array([[0.0, 1.0, 0.0, 0.0], [1.0, 0.0, 0.0, 0.0]])
+    for seed in (1, 2, 20260327):
+        hip.set_state(alpha=np.zeros(2), delta=np.ones(2, dtype=np.int32))
+        hip.sweep(iteration=1, seed=seed, vare=1.0, var_effect=0.2, pi_matrix=snp_pi)
+        assert hip.get_state()[2].tolist() == [2, 1]
+
+
+def test_bayesr_error_contracts(hip, small_data):
+    hip.load_dense(small_data["X"])
+    hip.setup_blocks(64, "f64")
+    hip.init_state("BayesR")
+    import jwas_jl_amd as J
+    with pytest.raises(J.JwasHipError, match="sum to 1"):
+        hip.sweep(iteration=1, seed=1, vare=1.0, var_effect=0.2, pi_classes=[0.5, 0.1, 0.1, 0.1])
+    with pytest.raises(J.JwasHipError, match="nonnegative"):
+        hip.sweep(iteration=1, seed=1, vare=1.0, var_effect=0.2, pi_classes=[1.2, -0.2, 0.0, 0.0])
+    with pytest.raises(J.JwasHipError, match="sigmaSq"):
+        hip.sweep(iteration=1, seed=1, vare=1.0, var_effect=0.0, pi_classes=[0.95, 0.03, 0.015, 0.005])
+    with pytest.raises(ValueError, match="mixture classes"):
+        hip.sweep(iteration=1, seed=1, vare=1.0, var_effect=0.2, pi_classes=[0.5, 0.5])
+    with pytest.raises(ValueError, match="one row per marker"):
+        hip.sweep(iteration=1, seed=1, vare=1.0, var_effect=0.2, pi_matrix=np.ones((3, 4)) / 4)
+
+
+@pytest.mark.parametrize("nreps", [3, 0])
+def test_block_repetitions_parity(hip, nreps):
+    """fast_blocks semantics: nreps within-block passes (0 = block size; BayesABC.jl:153)."""
+    data = make_dataset(n=400, p=64 * 3 + 5, ncausal=6, seed=41)
+    orc, hip = _pair(hip, data, 64, "BayesC")
+    r0 = data["y"] - data["y"].mean()
+    orc.set_residual(r0)
+    hip.set_residual(r0)
+    vare, varg = _hyper(data)
+    for it in range(1, 4):
+        orc.sweep(iteration=it, seed=5, vare=vare, var_effect=varg, pi=0.9, nreps=nreps)
+        hip.sweep(iteration=it, seed=5, vare=vare, var_effect=varg, pi=0.9, nreps=nreps)
+    _compare_state(orc, hip, atol=5e-6)
+
+
+@pytest.mark.parametrize("t,bs", [(2, 64), (3, 128), (3, 256)])
+def test_mt_sampler1_parity(hip, t, bs):
+    data = make_dataset(n=500, p=2 * bs + 13, ncausal=10, seed=500 + t)
+    orc, hip = _pair(hip, data, bs, "MTBayesC", ntraits=t)
+    rng = np.random.default_rng(t)
+    Y = np.stack([data["y"] - data["y"].mean() + 0.3 * rng.standard_normal(len(data["y"])).astype(np.float32)
+                  for _ in range(t)]).astype(np.float32)
+    for k in range(t):
+        orc.set_residual(Y[k], k)
+        hip.set_residual(Y[k], k)
+        ones = np.ones(orc.p, dtype=np.float32)
+        orc.set_state(k, delta=ones)
+        hip.set_state(k, delta=ones)
+    A = rng.standard_normal((t, t))
+    vare = (A @ A.T / t + np.eye(t)).astype(np.float32) * 0.5
+    B = rng.standard_normal((t, t))
+    varg = ((B @ B.T / t + np.eye(t)) * 0.002).astype(np.float32)
+    prior = rng.dirichlet(np.ones(1 << t))
+    lp = np.log(prior)
+    for it in range(1, 21):
+        so = orc.sweep(iteration=it, seed=11, vare=vare, var_effect=varg, log_prior_states=lp)
+        sh = hip.sweep(iteration=it, seed=11, vare=vare, var_effect=varg, log_prior_states=lp)
+        assert np.array_equal(so["state_counts"], sh["state_counts"]), f"iteration {it}"
+        np.testing.assert_allclose(sh["beta_ss"], so["beta_ss"], rtol=1e-5)
+        np.testing.assert_allclose(sh["resid_ss"], so["resid_ss"], rtol=1e-5)
+    for k in range(t):
+        _compare_state(orc, hip, k, atol=5e-6)
+
+
+def test_accumulate_mul_alpha_sub_xalpha(hip, small_data):
+    orc, hip = _pair(hip, small_data, 64, "BayesC")
+    rng = np.random.default_rng(3)
+    a0 = np.where(rng.random(orc.p) < 0.1, rng.standard_normal(orc.p) * 0.05, 0).astype(np.float32)
+    y = small_data["y"]
+    for e in (orc, hip):
+        e.set_state(alpha=a0)
+        e.set_residual(y)
+        e.sub_xalpha()
+    np.testing.assert_array_equal(hip.get_residual(), orc.get_residual())
+    np.testing.assert_allclose(hip.mul_alpha(), orc.mul_alpha(), rtol=0, atol=1e-6)
+    vare, varg = _hyper(small_data)
+    for it in range(1, 6):
+        orc.sweep(iteration=it, seed=1, vare=vare, var_effect=varg, pi=0.9)
+        hip.sweep(iteration=it, seed=1, vare=vare, var_effect=varg, pi=0.9)
+        orc.accumulate(it)
+        hip.accumulate(it)
+    for mo, mh in zip(orc.posterior(), hip.posterior()):
+        np.testing.assert_allclose(mh, mo, rtol=0, atol=1e-6)
+
+
+def test_state_machine_errors(hip, small_data):
+    import jwas_jl_amd as J
+    e = J.HipEngine(0)
+    with pytest.raises(J.JwasHipError):
+        e.setup_blocks(64)
+    e.load_dense(small_data["X"])
+    with pytest.raises(J.JwasHipError, match="block_size"):
+        e.setup_blocks(100)
+    e.setup_blocks(64, "f64")
+    with pytest.raises(J.JwasHipError, match="init_state"):
+        e._chk(e._L.jwas_hip_accumulate(e._h, 1.0))
+    with pytest.raises(J.JwasHipError):
+        e.init_state("MTBayesC", 9)
+    e.close()
