@@ -130,7 +130,7 @@ int64_t jwas_hip_estimate_bytes(int64_t n, int64_t p, int32_t ntraits, int32_t b
 int  jwas_hip_synth_genotypes(jwas_hip_ctx* ctx, uint64_t seed, int32_t kind, int32_t center);
 
 /* ---- precompute: x'x and block Grams ----------------------------------------------------------- */
-/* block_size in {64,128,256,512}; markers are processed in consecutive blocks of this size. */
+/* block_size in {64,128,256,512,1024}; markers are processed in consecutive blocks of this size. */
 int  jwas_hip_setup_blocks(jwas_hip_ctx* ctx, int32_t block_size, int32_t gram_mode);
 int  jwas_hip_get_xpx(jwas_hip_ctx* ctx, float* out_p);
 int  jwas_hip_get_gram(jwas_hip_ctx* ctx, int64_t block, float* out_bxb);        /* row-major b x b */

@@ -46,6 +46,8 @@ struct jwas_hip_ctx {
     double* fin_out = nullptr;          // [nslices][kMaxT*kMaxT + kMaxT]
     double* stat_out = nullptr;         // [kStatGrid][kNStat]
     double* host_buf = nullptr;         // pinned staging for fin_out + stat_out + counters
+    double* prep_d = nullptr;           // [kPrepD][p] per-sweep marker constants (k_prepare)
+    float*  prep_f = nullptr;           // [kPrepF][p]
     float*  var_vec = nullptr;
     double* pi_vec = nullptr;
     double* pi_mat = nullptr;
@@ -136,6 +138,7 @@ static void free_state(jwas_hip_ctx* c)
 {
     (void)hipFree(c->alpha); (void)hipFree(c->beta); (void)hipFree(c->delta);
     (void)hipFree(c->mean_a); (void)hipFree(c->mean_a2); (void)hipFree(c->mean_d);
+    (void)hipFree(c->prep_d); (void)hipFree(c->prep_f); c->prep_d = nullptr; c->prep_f = nullptr;
     c->alpha = c->beta = nullptr; c->delta = nullptr; c->mean_a = c->mean_a2 = c->mean_d = nullptr;
 }
 
@@ -300,7 +303,7 @@ int jwas_hip_setup_blocks(jwas_hip_ctx* c, int32_t bs, int32_t gram_mode)
 {
     NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
     NEED(c, c->X, JWAS_HIP_ESTATE, "no genotype matrix loaded");
-    NEED(c, bs == 64 || bs == 128 || bs == 256 || bs == 512, JWAS_HIP_EINVAL, "block_size must be 64, 128, 256 or 512 (got %d)", bs);
+    NEED(c, bs == 64 || bs == 128 || bs == 256 || bs == 512 || bs == 1024, JWAS_HIP_EINVAL, "block_size must be 64, 128, 256, 512 or 1024 (got %d)", bs);
     NEED(c, gram_mode == JWAS_HIP_GRAM_F64 || gram_mode == JWAS_HIP_GRAM_MFMA, JWAS_HIP_EINVAL, "unknown gram_mode %d", gram_mode);
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -400,6 +403,8 @@ int jwas_hip_init_state(jwas_hip_ctx* c, int32_t method, int32_t nt)
     HIPCHK(c, hipMalloc(&c->mean_a, fb));
     HIPCHK(c, hipMalloc(&c->mean_a2, fb));
     HIPCHK(c, hipMalloc(&c->mean_d, fb));
+    HIPCHK(c, hipMalloc(&c->prep_d, sizeof(double) * kPrepD * (size_t)c->p));
+    HIPCHK(c, hipMalloc(&c->prep_f, sizeof(float) * kPrepF * (size_t)c->p));
     HIPCHK(c, hipMemsetAsync(c->alpha, 0, fb, c->stream));
     HIPCHK(c, hipMemsetAsync(c->beta, 0, fb, c->stream));
     HIPCHK(c, hipMemsetAsync(c->delta, 0, fb, c->stream));
@@ -514,8 +519,8 @@ template <int METHOD, int NSUB>
 static void launch_sample_st(jwas_hip_ctx* c, int64_t blk, int64_t j0, int b, Events* ev_out)
 {
     hipLaunchKernelGGL((k_sample_block<METHOD, NSUB>), dim3(1), dim3(256), 0, c->stream,
-                       c->dparams, c->partials, c->nrg, c->block_size, j0, b, c->xpx,
-                       c->gram + blk * (int64_t)c->block_size * c->block_size,
+                       c->dparams, c->partials, c->nrg, c->block_size, j0, b, c->p, c->xpx,
+                       c->gram + blk * (int64_t)c->block_size * c->block_size, c->prep_d, c->prep_f,
                        c->alpha, c->beta, c->delta, ev_out, c->counters);
 }
 
@@ -524,7 +529,7 @@ static void launch_sample_mt(jwas_hip_ctx* c, int64_t blk, int64_t j0, int b, Ev
 {
     hipLaunchKernelGGL((k_sample_block_mt1<NT, NSUB>), dim3(1), dim3(256), 0, c->stream,
                        c->dparams, c->partials, c->nrg, c->block_size, j0, b, c->p, c->xpx,
-                       c->gram + blk * (int64_t)c->block_size * c->block_size,
+                       c->gram + blk * (int64_t)c->block_size * c->block_size, c->prep_d,
                        c->alpha, c->beta, (float*)c->delta, ev_out, c->counters);
 }
 
@@ -597,6 +602,19 @@ int jwas_hip_sweep(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_sweep_stats
     HIPCHK(c, hipMemsetAsync(c->counters, 0, sizeof(unsigned long long) * 4, c->stream));
     HIPCHK(c, hipEventRecord(c->ev_start, c->stream));
 
+    {   // per-sweep marker constants (draws, prior logs, lhs terms) for all p markers in parallel
+        const dim3 pg((unsigned)((c->p + 255) / 256)), pb(256);
+        switch (c->method) {
+            case JWAS_HIP_BAYESC: hipLaunchKernelGGL((k_prepare<kBayesC, 1>), pg, pb, 0, c->stream, c->dparams, c->p, c->xpx, c->prep_d, c->prep_f); break;
+            case JWAS_HIP_BAYESB: hipLaunchKernelGGL((k_prepare<kBayesB, 1>), pg, pb, 0, c->stream, c->dparams, c->p, c->xpx, c->prep_d, c->prep_f); break;
+            case JWAS_HIP_BAYESR: hipLaunchKernelGGL((k_prepare<kBayesR, 1>), pg, pb, 0, c->stream, c->dparams, c->p, c->xpx, c->prep_d, c->prep_f); break;
+            default:
+                if (t == 2) hipLaunchKernelGGL((k_prepare<kMTBayesC1, 2>), pg, pb, 0, c->stream, c->dparams, c->p, c->xpx, c->prep_d, c->prep_f);
+                else if (t == 3) hipLaunchKernelGGL((k_prepare<kMTBayesC1, 3>), pg, pb, 0, c->stream, c->dparams, c->p, c->xpx, c->prep_d, c->prep_f);
+                else hipLaunchKernelGGL((k_prepare<kMTBayesC1, 4>), pg, pb, 0, c->stream, c->dparams, c->p, c->xpx, c->prep_d, c->prep_f);
+        }
+    }
+
     const int bs = c->block_size;
     for (int64_t blk = 0; blk < c->nblocks; ++blk) {
         const int64_t j0 = blk * bs;
@@ -615,7 +633,8 @@ int jwas_hip_sweep(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_sweep_stats
             case 64:  launch_sample<1>(c, blk, j0, b, ev_out); break;
             case 128: launch_sample<2>(c, blk, j0, b, ev_out); break;
             case 256: launch_sample<4>(c, blk, j0, b, ev_out); break;
-            default:  launch_sample<8>(c, blk, j0, b, ev_out);
+            case 512: launch_sample<8>(c, blk, j0, b, ev_out); break;
+            default:  launch_sample<16>(c, blk, j0, b, ev_out);
         }
     }
     const Events* ev_last = &c->ev[c->nblocks & 1];

@@ -30,7 +30,7 @@
 namespace jw {
 
 constexpr int kSliceRows = 256;      // rows of r owned by one workgroup of k_update_partial
-constexpr int kMaxBlock  = 512;      // largest marker block
+constexpr int kMaxBlock  = 1024;     // largest marker block
 constexpr int kMaxT      = 4;        // traits
 constexpr int kMaxStates = 16;
 
@@ -95,12 +95,46 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double* lds /* [nwave
 // one column step reads 8 KB contiguous of X; the 8 per-wave dot products are combined through
 // LDS and ONE partial per (column, row group) goes to HBM: partials[(t*nrg + rg)*bstride + c].
 //
+// Loads are software-pipelined (two register batches of U float4 per wave: ~16 KB in flight per
+// wave, 128 KB per workgroup), and the U per-lane column sums are reduced with a transposed
+// butterfly (U-1 + 3 shuffle-adds instead of 6U).
+//
 // The sparse exit update r += X[:,events]*d (BayesABC.jl:181-185) is recomputed by every column
 // group of a row group (reads r_in, never r_out, so there is no read/write race between groups);
 // only column group 0 stores the updated slice to r_out.
 // ---------------------------------------------------------------------------------------------
 constexpr int kRowGroupSlices = 8;
 constexpr int kColChunk = 64;        // columns per LDS flush
+constexpr int kU = 8;                // columns per register batch
+
+// Transposed butterfly: in = kU per-lane values (one per column); out: lane l holds the wave-wide
+// sum of column ((l>>5)&1)*4 + ((l>>4)&1)*2 + ((l>>3)&1) in every lane of its 8-lane group.
+__device__ __forceinline__ double butterfly8(const double (&v)[kU], int lane)
+{
+    double a[4], b[2], c;
+    const bool h5 = (lane & 32) != 0, h4 = (lane & 16) != 0, h3 = (lane & 8) != 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double send = h5 ? v[i] : v[4 + i];
+        const double keep = h5 ? v[4 + i] : v[i];
+        a[i] = keep + __shfl_xor(send, 32, 64);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const double send = h4 ? a[i] : a[2 + i];
+        const double keep = h4 ? a[2 + i] : a[i];
+        b[i] = keep + __shfl_xor(send, 16, 64);
+    }
+    {
+        const double send = h3 ? b[0] : b[1];
+        const double keep = h3 ? b[1] : b[0];
+        c = keep + __shfl_xor(send, 8, 64);
+    }
+    c += __shfl_xor(c, 4, 64);
+    c += __shfl_xor(c, 2, 64);
+    c += __shfl_xor(c, 1, 64);
+    return c;
+}
 
 template <int NT>
 __global__ __launch_bounds__(512) void k_update_partial(const float* __restrict__ X, int64_t ld,
@@ -114,19 +148,23 @@ __global__ __launch_bounds__(512) void k_update_partial(const float* __restrict_
     const int rg = blockIdx.x, g = blockIdx.y;
     const int slice = rg * kRowGroupSlices + wave;
     const bool active = slice < nslices;
+    // an inactive wave (slice beyond the matrix) aliases slice 0 for addressing and contributes 0
     const int64_t row = (int64_t)(active ? slice : 0) * kSliceRows + lane * 4;
-    const int ncols = (b - g + ncg - 1) / ncg;            // columns of this group (b > g guaranteed by launch)
+    const int ncols = (b - g + ncg - 1) / ncg;            // columns of this group (b > g by launch)
 
-    // (1) the first batch of column loads does not depend on r: issue it before the update.
-    constexpr int U = 8;
+    // Loads are unconditional from clamped, always-valid addresses: a select between a load and a
+    // constant makes hipcc pick between pointers and emit flat/scratch accesses.
     const float* xcol = X + (j0 + g) * ld + row;
     const int64_t cstride = (int64_t)ncg * ld;
-    // (loads are unconditional from clamped, always-valid addresses: a select between a load and a
-    //  constant makes hipcc pick between pointers and emit flat/scratch accesses)
-    float4 xv[U];
+    auto load_batch = [&](float4 (&dst)[kU], int ib) {
 #pragma unroll
-    for (int u = 0; u < U; ++u)
-        xv[u] = *reinterpret_cast<const float4*>(xcol + (u < ncols ? u : ncols - 1) * cstride);
+        for (int u = 0; u < kU; ++u)
+            dst[u] = *reinterpret_cast<const float4*>(xcol + (ib + u < ncols ? ib + u : ncols - 1) * cstride);
+    };
+
+    // (1) the first batch of column loads does not depend on r: issue it before the update.
+    float4 xa[kU], xb[kU];
+    load_batch(xa, 0);
 
     // (2) sparse exit update of the previous block: sequential fmaf in marker order, bit-identical
     //     to the oracle's per-marker axpy sequence.
@@ -134,22 +172,19 @@ __global__ __launch_bounds__(512) void k_update_partial(const float* __restrict_
 #pragma unroll
     for (int t = 0; t < NT; ++t) rv[t] = *reinterpret_cast<const float4*>(r_in + t * ld + row);
     const int ne = ev->count;
-    if (active) {
 #pragma unroll 4
-        for (int e = 0; e < ne; ++e) {
-            const float4 x = *reinterpret_cast<const float4*>(X + (int64_t)ev->idx[e] * ld + row);
+    for (int e = 0; e < ne; ++e) {
+        const float4 x = *reinterpret_cast<const float4*>(X + (int64_t)ev->idx[e] * ld + row);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const float d = ev->delta[t][e];
-                rv[t].x = fmaf(d, x.x, rv[t].x); rv[t].y = fmaf(d, x.y, rv[t].y);
-                rv[t].z = fmaf(d, x.z, rv[t].z); rv[t].w = fmaf(d, x.w, rv[t].w);
-            }
+        for (int t = 0; t < NT; ++t) {
+            const float d = ev->delta[t][e];
+            rv[t].x = fmaf(d, x.x, rv[t].x); rv[t].y = fmaf(d, x.y, rv[t].y);
+            rv[t].z = fmaf(d, x.z, rv[t].z); rv[t].w = fmaf(d, x.w, rv[t].w);
         }
-        if (g == 0)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) *reinterpret_cast<float4*>(r_out + t * ld + row) = rv[t];
     }
-    // an inactive wave (slice beyond the matrix) aliases slice 0 for addressing and contributes 0
+    if (active && g == 0)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) *reinterpret_cast<float4*>(r_out + t * ld + row) = rv[t];
     const float keep = active ? 1.f : 0.f;
     double rd[NT][4];
 #pragma unroll
@@ -157,27 +192,32 @@ __global__ __launch_bounds__(512) void k_update_partial(const float* __restrict_
         rd[t][0] = rv[t].x * keep; rd[t][1] = rv[t].y * keep; rd[t][2] = rv[t].z * keep; rd[t][3] = rv[t].w * keep;
     }
 
-    // (3) partial block RHS, U columns in flight per wave, kColChunk columns per LDS flush.
+    // (3) partial block RHS.
+    auto consume = [&](const float4 (&xv)[kU], int ib, int i0) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            double acc[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                acc[u] = (double)xv[u].x * rd[t][0];
+                acc[u] = fma((double)xv[u].y, rd[t][1], acc[u]);
+                acc[u] = fma((double)xv[u].z, rd[t][2], acc[u]);
+                acc[u] = fma((double)xv[u].w, rd[t][3], acc[u]);
+            }
+            const double s = butterfly8(acc, lane);
+            const int u = lane >> 3;                       // column of this 8-lane group
+            if ((lane & 7) == 0 && ib + u < ncols) red[wave][ib + u - i0][t] = s;
+        }
+    };
+
     for (int i0 = 0; i0 < ncols; i0 += kColChunk) {
         const int iend = (i0 + kColChunk < ncols) ? i0 + kColChunk : ncols;
-        for (int ib = i0; ib < iend; ib += U) {
-            if (ib != 0) {
-#pragma unroll
-                for (int u = 0; u < U; ++u)
-                    xv[u] = *reinterpret_cast<const float4*>(xcol + (ib + u < ncols ? ib + u : ncols - 1) * cstride);
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    double acc = (double)xv[u].x * rd[t][0];
-                    acc = fma((double)xv[u].y, rd[t][1], acc);
-                    acc = fma((double)xv[u].z, rd[t][2], acc);
-                    acc = fma((double)xv[u].w, rd[t][3], acc);
-                    acc = wave_sum(acc);
-                    if (lane == 0 && ib + u < iend) red[wave][ib + u - i0][t] = acc;
-                }
-            }
+        // two batches per trip so both register sets are statically indexed
+        for (int ib = i0; ib < iend; ib += 2 * kU) {
+            if (ib + kU < ncols) load_batch(xb, ib + kU);
+            consume(xa, ib, i0);
+            if (ib + 2 * kU < ncols) load_batch(xa, ib + 2 * kU);
+            if (ib + kU < iend) consume(xb, ib + kU, i0);
         }
         __syncthreads();
         for (int q = tid; q < (iend - i0) * NT; q += 512) {
@@ -232,50 +272,66 @@ __global__ __launch_bounds__(256) void k_finish(const float* __restrict__ X, int
 
 // ---------------------------------------------------------------------------------------------
 // scalar samplers (must mirror oracle/jwas_oracle.c operation for operation)
+//
+// Everything about a marker that does not depend on the running block RHS (its two random draws,
+// the prior logs, lhs, 1/lhs, log lhs ...) is computed ONCE PER SWEEP for all p markers in parallel
+// by k_prepare and stored struct-of-arrays in prep_d [kPrepD][p] / prep_f [kPrepF][p]; the serial
+// sampler wave only loads them.  (Within-block repetitions > 0 recompute them in place.)
 // ---------------------------------------------------------------------------------------------
+constexpr int kPrepD = 12;
+constexpr int kPrepF = 4;
+
 __device__ __forceinline__ float logf_via_double(float x) { return (float)log((double)x); }
 
-// BayesA/B/C -- bayesabc_update_marker! (BayesABC.jl:24-58).  Marker constants that do not depend on
-// the running rhs are hoisted; the inclusion test u < 1/(1+exp(lp0-l1)) is evaluated in the
-// equivalent log-odds form (lp0-l1) < log((1-u)/u) so no exp sits on the serial path.
+// BayesA/B/C -- bayesabc_update_marker! (BayesABC.jl:24-58).  The inclusion test
+// u < 1/(1+exp(lp0-l1)) is evaluated in the equivalent log-odds form (lp0-l1) < log((1-u)/u),
+// so no exp sits on the serial path.
 struct AbcMarker {
-    float  d, iv_unused, lv, invLhs, loglhs, sq, var_j;
-    double lp0, lp1, thr, z;
-    float  beta_excl;                       // (float)(z*sqrt(var_j))   (BayesABC.jl:54)
-    __device__ __forceinline__ void prepare(float d_, float var_, double pi_, float ie, double u, double z_)
+    float  d, invLhs, c1, beta_excl;        // c1 = log(lhs) + log(var_j) (Float32 sum of :40)
+    double lp0, lp1, thr, zs;               // zs = z*sqrt(1/lhs)
+    __device__ __forceinline__ void prepare(float d_, float var_, double pi_, float ie, double u, double z)
     {
-        d = d_; var_j = var_; z = z_;
-        const float iv = 1.0f / var_;
-        lv  = logf_via_double(var_);
-        lp0 = log(pi_);
-        lp1 = log(1.0 - pi_);
+        d = d_;
+        const float iv = 1.0f / var_;                       // invVarEffects[j]   :70
+        const float lv = logf_via_double(var_);             // logVarEffects[j]   :71
+        lp0 = log(pi_);                                     // logPi[j]           :67
+        lp1 = log(1.0 - pi_);                               // logPiComp[j]       :68
         const float lhs = d_ * ie + iv;                     // :37
         invLhs = 1.0f / lhs;                                // :38
-        loglhs = logf_via_double(lhs);
-        sq  = sqrtf(invLhs);
+        c1  = logf_via_double(lhs) + lv;
+        zs  = z * (double)sqrtf(invLhs);
         thr = log((1.0 - u) / u);
-        beta_excl = (float)(z_ * (double)sqrtf(var_));
+        beta_excl = (float)(z * (double)sqrtf(var_));       // :54
     }
-    // returns include flag; gHat out
+    __device__ __forceinline__ void store(double* pd, float* pf, int64_t p, int64_t j) const
+    {
+        pd[0 * p + j] = lp0; pd[1 * p + j] = lp1; pd[2 * p + j] = thr; pd[3 * p + j] = zs;
+        pf[0 * p + j] = invLhs; pf[1 * p + j] = c1; pf[2 * p + j] = beta_excl;
+    }
+    __device__ __forceinline__ void load(const double* pd, const float* pf, int64_t p, int64_t j, float d_)
+    {
+        d = d_;
+        lp0 = pd[0 * p + j]; lp1 = pd[1 * p + j]; thr = pd[2 * p + j]; zs = pd[3 * p + j];
+        invLhs = pf[0 * p + j]; c1 = pf[1 * p + j]; beta_excl = pf[2 * p + j];
+    }
     __device__ __forceinline__ bool evaluate(float rhs_b, float a_old, float ie, float& gHat) const
     {
         const float rhs   = (rhs_b + d * a_old) * ie;                       // :36
         gHat              = rhs * invLhs;                                   // :39
-        const float inner = (loglhs + lv) - gHat * rhs;                     // fp32 part of :40
+        const float inner = c1 - gHat * rhs;                                // fp32 part of :40
         const double l1   = -0.5 * (double)inner + lp1;                     // :40
         return (lp0 - l1) < thr;                                            // :41,:44
     }
     __device__ __forceinline__ float alpha_incl(float gHat) const
     {
-        return (float)((double)gHat + z * (double)sq);                      // :46
+        return (float)((double)gHat + zs);                                  // :46
     }
 };
 
 // BayesR (BayesR.jl:56-96)
 struct BayesRMarker {
     float  d, die;
-    double lpi[4], invLhs[4], cA[4], z;
-    double u;
+    double lpi[4], invLhs[4], cA[4], z, u;
     __device__ __forceinline__ void prepare(float d_, float sigma_sq, const double* pi_j, const double* gamma,
                                             float ie, double u_, double z_)
     {
@@ -290,6 +346,26 @@ struct BayesRMarker {
             cA[k]  = log(invLhs[k]) - log(varE);
             lpi[k] = log(pi_j[k]);
         }
+    }
+    __device__ __forceinline__ void store(double* pd, float* pf, int64_t p, int64_t j) const
+    {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pd[k * p + j] = lpi[k];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) { pd[(3 + k) * p + j] = invLhs[k]; pd[(6 + k) * p + j] = cA[k]; }
+        pd[10 * p + j] = z; pd[11 * p + j] = u;
+        (void)pf;
+    }
+    __device__ __forceinline__ void load(const double* pd, const float* pf, int64_t p, int64_t j, float d_, float ie)
+    {
+        d = d_; die = d_ * ie;
+        invLhs[0] = 0.0; cA[0] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) lpi[k] = pd[k * p + j];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) { invLhs[k] = pd[(3 + k) * p + j]; cA[k] = pd[(6 + k) * p + j]; }
+        z = pd[10 * p + j]; u = pd[11 * p + j];
+        (void)pf;
     }
     // returns class 0..3 and the candidate alpha for that class
     __device__ __forceinline__ int evaluate(float rhs_b, float a_old, float ie, float& a_new) const
@@ -324,21 +400,62 @@ struct BayesRMarker {
     }
 };
 
+// K_P: per-sweep marker constants for repetition 0.  grid = ceil(p/256), block = 256.
+template <int METHOD, int NT>
+__global__ __launch_bounds__(256) void k_prepare(const DevParams* __restrict__ P, int64_t p,
+                                                 const float* __restrict__ xpx,
+                                                 double* __restrict__ prep_d, float* __restrict__ prep_f)
+{
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= p) return;
+    const RngKey key{P->seed_lo, P->seed_hi, P->iter, 0u};
+    const uint32_t marker = P->marker0 + (uint32_t)j;
+    if constexpr (METHOD == kMTBayesC1) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const double u = draw_uniform(key, marker, (uint32_t)t);
+            prep_d[(int64_t)t * p + j] = log((1.0 - u) / u);
+            prep_d[(int64_t)(NT + t) * p + j] = draw_normal(key, marker, (uint32_t)t);
+        }
+    } else {
+        const float ie = 1.0f / P->vare[0];
+        const double u = draw_uniform(key, marker, 0u);
+        const double z = draw_normal(key, marker, 0u);
+        if constexpr (METHOD == kBayesR) {
+            double pj[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pj[k] = P->pi_mat ? P->pi_mat[4 * j + k] : P->pi4[k];
+            BayesRMarker bm;
+            bm.prepare(xpx[j], P->var_effect[0], pj, P->gamma, ie, u, z);
+            bm.store(prep_d, prep_f, p, j);
+        } else {
+            float var_j = P->var_effect[0];
+            if constexpr (METHOD == kBayesB) var_j = P->var_vec[j];
+            double pi_j = P->pi;
+            if (P->pi_vec) pi_j = P->pi_vec[j];
+            AbcMarker am;
+            am.prepare(xpx[j], var_j, pi_j, ie, u, z);
+            am.store(prep_d, prep_f, p, j);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
-// K_S (single trait): reduce slice partials, then one wavefront samples the block.
+// K_S (single trait): reduce row-group partials, then one wavefront samples the block.
 // grid = 1, block = 256 (one wave per SIMD: the sampler wave may use the whole register file).
 // METHOD in {kBayesC, kBayesB, kBayesR}.  NSUB = block/64.
 // ---------------------------------------------------------------------------------------------
 template <int METHOD, int NSUB>
 __global__ __launch_bounds__(256) void k_sample_block(const DevParams* __restrict__ P,
                                                       const double* __restrict__ partials, int nrg, int bstride,
-                                                       int64_t j0, int b,
-                                                       const float* __restrict__ xpx,
-                                                       const float* __restrict__ gram,   // b x b of this block
-                                                       float* __restrict__ alpha, float* __restrict__ beta,
-                                                       void* __restrict__ delta_v,
-                                                       Events* __restrict__ ev_out,
-                                                       unsigned long long* __restrict__ counters)
+                                                      int64_t j0, int b, int64_t p,
+                                                      const float* __restrict__ xpx,
+                                                      const float* __restrict__ gram,   // b x b of this block
+                                                      const double* __restrict__ prep_d, const float* __restrict__ prep_f,
+                                                      float* __restrict__ alpha, float* __restrict__ beta,
+                                                      void* __restrict__ delta_v,
+                                                      Events* __restrict__ ev_out,
+                                                      unsigned long long* __restrict__ counters)
 {
     __shared__ float rhs_lds[NSUB * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -363,14 +480,16 @@ __global__ __launch_bounds__(256) void k_sample_block(const DevParams* __restric
     float* delta_f = reinterpret_cast<float*>(delta_v);
     int32_t* delta_i = reinterpret_cast<int32_t*>(delta_v);
 
-    float rhs[NSUB], a_cur[NSUB], a_start[NSUB], b_out[NSUB], d_out[NSUB];
+    float rhs[NSUB], a_cur[NSUB], a_start[NSUB], b_out[NSUB], d_out[NSUB], dj[NSUB];
     bool  valid[NSUB];
 #pragma unroll
     for (int s = 0; s < NSUB; ++s) {
         const int c = 64 * s + lane;
         valid[s] = c < b;
-        rhs[s] = valid[s] ? rhs_lds[c] : 0.f;
-        a_cur[s] = valid[s] ? alpha[j0 + c] : 0.f;
+        const int cc = valid[s] ? c : 0;
+        rhs[s] = rhs_lds[cc];
+        a_cur[s] = valid[s] ? alpha[j0 + cc] : 0.f;
+        dj[s] = xpx[j0 + cc];
         a_start[s] = a_cur[s];
         b_out[s] = 0.f; d_out[s] = 0.f;
     }
@@ -382,22 +501,29 @@ __global__ __launch_bounds__(256) void k_sample_block(const DevParams* __restric
 #pragma unroll
         for (int s = 0; s < NSUB; ++s) {
             const int c = 64 * s + lane;
-            const int64_t j = j0 + c;
+            const int64_t j = j0 + (valid[s] ? c : 0);
             const uint32_t marker = P->marker0 + (uint32_t)j;
             unsigned long long pending = __ballot(valid[s]);
             if (pending == 0ull) continue;
 
             AbcMarker am; BayesRMarker bm;
-            if (valid[s]) {
+            if (rep == 0) {
+                if constexpr (METHOD == kBayesR) bm.load(prep_d, prep_f, p, j, dj[s], ie);
+                else am.load(prep_d, prep_f, p, j, dj[s]);
+            } else {
                 const double u = draw_uniform(key, marker, 0u);
                 const double z = draw_normal(key, marker, 0u);
                 if constexpr (METHOD == kBayesR) {
-                    const double* pj = P->pi_mat ? (P->pi_mat + 4 * j) : P->pi4;
-                    bm.prepare(xpx[j], P->var_effect[0], pj, P->gamma, ie, u, z);
+                    double pj[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) pj[k] = P->pi_mat ? P->pi_mat[4 * j + k] : P->pi4[k];
+                    bm.prepare(dj[s], P->var_effect[0], pj, P->gamma, ie, u, z);
                 } else {
-                    const float var_j = (METHOD == kBayesB) ? P->var_vec[j] : P->var_effect[0];
-                    const double pi_j = P->pi_vec ? P->pi_vec[j] : P->pi;
-                    am.prepare(xpx[j], var_j, pi_j, ie, u, z);
+                    float var_j = P->var_effect[0];
+                    if constexpr (METHOD == kBayesB) var_j = P->var_vec[j];
+                    double pi_j = P->pi;
+                    if (P->pi_vec) pi_j = P->pi_vec[j];
+                    am.prepare(dj[s], var_j, pi_j, ie, u, z);
                 }
             }
             // speculative rounds
@@ -438,7 +564,8 @@ __global__ __launch_bounds__(256) void k_sample_block(const DevParams* __restric
 #pragma unroll
                     for (int s2 = 0; s2 < NSUB; ++s2) {
                         const int c2 = 64 * s2 + lane;
-                        if (c2 < b) rhs[s2] = fmaf(D, grow[c2], rhs[s2]);   // BayesABC.jl:169,172
+                        const float gv = grow[c2 < b ? c2 : 0];
+                        if (c2 < b) rhs[s2] = fmaf(D, gv, rhs[s2]);         // BayesABC.jl:169,172
                     }
                 }
                 if (pending == 0ull) break;
@@ -478,13 +605,14 @@ __global__ __launch_bounds__(256) void k_sample_block(const DevParams* __restric
 template <int NT, int NSUB>
 __global__ __launch_bounds__(256) void k_sample_block_mt1(const DevParams* __restrict__ P,
                                                           const double* __restrict__ partials, int nrg, int bstride,
-                                                           int64_t j0, int b, int64_t p,
-                                                           const float* __restrict__ xpx,
-                                                           const float* __restrict__ gram,
-                                                           float* __restrict__ alpha, float* __restrict__ beta,
-                                                           float* __restrict__ delta,
-                                                           Events* __restrict__ ev_out,
-                                                           unsigned long long* __restrict__ counters)
+                                                          int64_t j0, int b, int64_t p,
+                                                          const float* __restrict__ xpx,
+                                                          const float* __restrict__ gram,
+                                                          const double* __restrict__ prep_d,
+                                                          float* __restrict__ alpha, float* __restrict__ beta,
+                                                          float* __restrict__ delta,
+                                                          Events* __restrict__ ev_out,
+                                                          unsigned long long* __restrict__ counters)
 {
     __shared__ float rhs_lds[NT][NSUB * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -510,18 +638,20 @@ __global__ __launch_bounds__(256) void k_sample_block_mt1(const DevParams* __res
 #pragma unroll
         for (int c = 0; c < NT; ++c) { Rinv[a][c] = P->Rinv[a * NT + c]; Ginv[a][c] = P->Ginv[a * NT + c]; }
 
-    float rhs[NT][NSUB], a_cur[NT][NSUB], a_start[NT][NSUB], b_cur[NT][NSUB], d_cur[NT][NSUB];
+    float rhs[NT][NSUB], a_cur[NT][NSUB], a_start[NT][NSUB], b_cur[NT][NSUB], d_cur[NT][NSUB], djs[NSUB];
     bool valid[NSUB];
 #pragma unroll
     for (int s = 0; s < NSUB; ++s) {
         const int c = 64 * s + lane;
         valid[s] = c < b;
+        const int cc = valid[s] ? c : 0;
+        djs[s] = xpx[j0 + cc];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            rhs[t][s]   = valid[s] ? rhs_lds[t][c] : 0.f;
-            a_cur[t][s] = valid[s] ? alpha[(int64_t)t * p + j0 + c] : 0.f;
-            b_cur[t][s] = valid[s] ? beta[(int64_t)t * p + j0 + c] : 0.f;
-            d_cur[t][s] = valid[s] ? delta[(int64_t)t * p + j0 + c] : 0.f;
+            rhs[t][s]   = rhs_lds[t][cc];
+            a_cur[t][s] = valid[s] ? alpha[(int64_t)t * p + j0 + cc] : 0.f;
+            b_cur[t][s] = beta[(int64_t)t * p + j0 + cc];
+            d_cur[t][s] = delta[(int64_t)t * p + j0 + cc];
             a_start[t][s] = a_cur[t][s];
         }
     }
@@ -533,16 +663,20 @@ __global__ __launch_bounds__(256) void k_sample_block_mt1(const DevParams* __res
 #pragma unroll
         for (int s = 0; s < NSUB; ++s) {
             const int c = 64 * s + lane;
-            const int64_t j = j0 + c;
+            const int64_t j = j0 + (valid[s] ? c : 0);
             const uint32_t marker = P->marker0 + (uint32_t)j;
             unsigned long long pending = __ballot(valid[s]);
             if (pending == 0ull) continue;
-            double u[NT], z[NT];
-            float dj = 0.f;
-            if (valid[s]) {
-                dj = xpx[j];
+            double thr[NT], z[NT];
+            const float dj = djs[s];
 #pragma unroll
-                for (int t = 0; t < NT; ++t) { u[t] = draw_uniform(key, marker, (uint32_t)t); z[t] = draw_normal(key, marker, (uint32_t)t); }
+            for (int t = 0; t < NT; ++t) {
+                if (rep == 0) { thr[t] = prep_d[(int64_t)t * p + j]; z[t] = prep_d[(int64_t)(NT + t) * p + j]; }
+                else {
+                    const double u = draw_uniform(key, marker, (uint32_t)t);
+                    thr[t] = log((1.0 - u) / u);
+                    z[t] = draw_normal(key, marker, (uint32_t)t);
+                }
             }
             while (true) {
                 const bool live = valid[s] && ((pending >> lane) & 1ull);
@@ -582,8 +716,7 @@ __global__ __launch_bounds__(256) void k_sample_block_mt1(const DevParams* __res
                         const double* lpr = P->log_prior;
                         const double logDelta0 = -0.5 * (double)in0 + lpr[s0];
                         const double logDelta1 = -0.5 * (double)in1 + lpr[s1];
-                        const double thr = log((1.0 - u[k]) / u[k]);
-                        if ((logDelta0 - logDelta1) < thr) {                                        // :107-111
+                        if ((logDelta0 - logDelta1) < thr[k]) {                                     // :107-111
                             dn[k] = 1.f;
                             bn[k] = (float)((double)gHat1 + z[k] * (double)sqrtf(invLhs1));
                             Dl[k] = an[k] - bn[k];
@@ -614,7 +747,8 @@ __global__ __launch_bounds__(256) void k_sample_block_mt1(const DevParams* __res
 #pragma unroll
                         for (int s2 = 0; s2 < NSUB; ++s2) {
                             const int c2 = 64 * s2 + lane;
-                            if (c2 < b) rhs[t][s2] = fmaf(D, grow[c2], rhs[t][s2]);                 // :311,317
+                            const float gv = grow[c2 < b ? c2 : 0];
+                            if (c2 < b) rhs[t][s2] = fmaf(D, gv, rhs[t][s2]);                       // :311,317
                         }
                     }
                 }
@@ -778,7 +912,7 @@ __global__ __launch_bounds__(256) void k_gram_f64(const float* __restrict__ X, i
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kGramKT = 32;          // rows per LDS tile
 constexpr int kGramLd = 36;          // LDS row stride (floats)
-constexpr int kGramChunk = 1024;     // rows per fp32 accumulation chunk
+constexpr int kGramChunk = 64;       // rows per fp32 accumulation chunk (then folded into fp64)
 
 __global__ __launch_bounds__(256) void k_gram_mfma(const float* __restrict__ X, int64_t ld, int64_t p, int bsize,
                                                    float* __restrict__ gram)

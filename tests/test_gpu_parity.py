@@ -64,7 +64,7 @@ def test_xpx_and_gram_exact(hip, small_data):
         assert np.array_equal(G, G.T)
 
 
-@pytest.mark.parametrize("bs", [64, 128, 256, 512])
+@pytest.mark.parametrize("bs", [64, 128, 256, 512, 1024])
 def test_gram_mfma_close(hip, bs):
     data = make_dataset(n=1500, p=2 * bs + 37, ncausal=5, seed=5)
     orc, hip = _pair(hip, data, bs, "BayesC", gram_mode="mfma")
@@ -79,7 +79,7 @@ def test_gram_mfma_close(hip, bs):
         assert np.array_equal(G, G.T)
 
 
-@pytest.mark.parametrize("bs", [64, 128, 256, 512])
+@pytest.mark.parametrize("bs", [64, 128, 256, 512, 1024])
 def test_bayesc_chain_parity(hip, bs):
     # n not a multiple of 256, p not a multiple of the block size
     data = make_dataset(n=777, p=3 * bs + 41, ncausal=12, seed=100 + bs)
@@ -135,7 +135,7 @@ def test_bayesc_pi_vector_and_bayesb(hip, small_data):
         hip.sweep(iteration=1, seed=1, vare=0.5, var_effect=0.004, pi=np.array([0.5]))
 
 
-@pytest.mark.parametrize("bs", [64, 256])
+@pytest.mark.parametrize("bs", [64, 256, 1024])
 def test_bayesr_chain_parity(hip, bs):
     data = make_dataset(n=600, p=2 * bs + 19, ncausal=10, seed=300 + bs)
     orc, hip = _pair(hip, data, bs, "BayesR")
