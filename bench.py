@@ -1,0 +1,212 @@
+#!/usr/bin/env python
+"""bench.py -- MCMC iterations/sec of the marker-effect Gibbs sampler on MI355X.
+
+Metric (BASELINE.json): MCMC iters/sec (full marker sweep), 50k x 600k single-trait BayesC, fp32 dense
+genotypes, pi0 = 0.95 estimated, at 1/2/4/8 GPUs.  One "step" = one MCMC iteration = one full sweep
+over all p markers (device) + the host-side updates of MCMC_BayesianAlphabet.jl:196-220,294-370
+(intercept Gibbs step, pi ~ Beta, marker-effect variance, residual variance).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: markers are sharded over the ranks (jwas.jl_amd/dist.py): each rank sweeps p/N markers from the
+same residual snapshot and one all-reduce (RCCL) of the residual delta reconciles per sweep.  Total
+work is fixed (50k x 600k), so "scaling" is "strong".
+
+Prints ONE JSON line (rank 0) with the contract fields plus
+  "roofline":     HBM roofline of the dominant kernel (k_update_partial), from HIP events recorded on the
+                  sweep's stream around every 4th launch inside the timed region;
+  "cpu_baseline": the CPU oracle's non-block BayesC sweep (the reference's per-marker sdot/saxpy
+                  order) timed on this box's host cores on a marker subsample (N = 1, rank 0 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_IND, P_TOTAL = 50_000, 600_000
+HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--n", type=int, default=N_IND)
+    ap.add_argument("--p", type=int, default=P_TOTAL)
+    ap.add_argument("--block-size", type=int, default=int(os.environ.get("JWAS_BLOCK_SIZE", "256")))
+    ap.add_argument("--seed", type=int, default=2026)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-markers", type=int, default=20000)
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    if world != a.gpus:
+        if rank == 0:
+            print(f"warning: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    import jwas_jl_amd as J
+    from jwas_jl_amd.dist import MarkerShard, shard_range
+
+    n, p_total, bs = a.n, a.p, a.block_size
+    lo, hi = shard_range(p_total, rank, world, align=bs)
+    p_loc = hi - lo
+    eng = J.HipEngine(local_rank)
+    t_setup = time.time()
+    eng.alloc_dense(n, p_loc)
+    eng.synth(a.seed, kind=0, center=True, marker_offset=lo)        # 0/1/2 genotypes, centred, generated on device
+    eng.setup_blocks(bs, "mfma")
+    eng.init_state("BayesC", 1)
+    shard = MarkerShard(eng, lo, hi, rank, world)
+
+    # ---- simulate y = 1 + X beta + e with ncausal QTL, h2 = 0.5
+    rng = np.random.default_rng(a.seed)
+    ncausal = max(1, p_total // 1000)
+    causal = np.sort(rng.choice(p_total, size=ncausal, replace=False))
+    eff = rng.standard_normal(ncausal)
+    a_true = np.zeros(p_loc, dtype=np.float32)
+    m = (causal >= lo) & (causal < hi)
+    a_true[causal[m] - lo] = eff[m]
+    eng.set_state(alpha=a_true)
+    g = shard.allreduce_sum(eng.mul_alpha().astype(np.float64))
+    g *= np.sqrt(0.5 / g.var())
+    y = (1.0 + g + rng.standard_normal(n) * np.sqrt(0.5)).astype(np.float32)
+    eng.set_state(alpha=np.zeros(p_loc), beta=np.zeros(p_loc), delta=np.ones(p_loc))
+
+    # ---- priors (input_data_validation.jl:296-350, tools4genotypes.jl:353-478)
+    df_ = 4.0
+    vary = float(np.var(y.astype(np.float64), ddof=1))
+    vare = np.float32(0.5 * vary)
+    sum2pq = float(shard.allreduce_sum(np.array([eng.xpx().astype(np.float64).sum()]))[0]) / n   # x'x/n = 2pq (centred)
+    pi = 0.95
+    Gval = np.float32(0.5 * vary / ((1.0 - pi) * sum2pq))
+    scale_e = float(vare) * (df_ - 2) / df_
+    scale_g = float(Gval) * (df_ - 2) / df_
+    setup_s = time.time() - t_setup
+
+    state = {"r": y[None, :].copy(), "mu": 0.0, "vare": vare, "G": Gval, "pi": pi, "it": 0}
+    acc = {"sweep_ms": 0.0, "k_ms": 0.0, "k_n": 0.0, "k_bytes": 0.0, "events": 0.0}
+
+    def step():
+        s = state
+        s["it"] += 1
+        # 1. intercept: single-site Gibbs on the 1x1 MME (solver.jl:143-151)
+        r = s["r"][0].astype(np.float64) + s["mu"]
+        s["mu"] = rng.standard_normal() * np.sqrt(float(s["vare"]) / n) + r.sum() / n
+        r -= s["mu"]
+        # 2. marker sweep on the device (+ shard reconcile)
+        r_new, st = shard.sweep(r.astype(np.float32)[None, :], iteration=s["it"], seed=a.seed,
+                                vare=s["vare"], var_effect=s["G"], pi=s["pi"], nreps=1)
+        s["r"] = r_new
+        nl = st["sum_delta"][0]
+        # 3-5. pi, marker-effect variance, residual variance (Pi.jl:7-9, variance_components.jl:60-66,151-162)
+        s["pi"] = float(rng.beta(p_total - nl + 1.0, nl + 1.0))
+        s["G"] = np.float32((np.float32(st["alpha_ss"][0, 0]) + df_ * scale_g) / rng.chisquare(nl + df_))
+        s["vare"] = np.float32((np.float32(st["resid_ss"][0, 0]) + df_ * scale_e) / rng.chisquare(n + df_))
+        acc["sweep_ms"] += st["sweep_ms"]
+        acc["k_ms"] += st["update_kernel_ms"]
+        acc["k_n"] += st["update_kernel_samples"]
+        acc["k_bytes"] += st["update_kernel_bytes"]
+        acc["events"] += st["n_events"]
+        return st
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    for k in acc:
+        acc[k] = 0.0
+    eng.set_kernel_timing(4)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        last = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    eng.set_kernel_timing(0)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    out = None
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / a.steps
+        achieved = (acc["k_bytes"] / 1e9) / (acc["k_ms"] / 1e3) if acc["k_ms"] > 0 else None
+        out = {
+            "metric": "MCMC iters/sec (full marker sweep)", "value": a.steps / elapsed, "unit": "iterations/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"single-trait BayesC, {n} individuals x {p_total} SNPs, fp32 dense genotypes, pi0=0.95 estimated",
+                       "n": n, "p": p_total, "block_size": bs, "parallelism": f"marker-shard x{world}" if world > 1 else "single GPU",
+                       "device_sweep_ms": acc["sweep_ms"] / a.steps, "events_per_sweep": acc["events"] / a.steps,
+                       "markers_in_model": float(last["sum_delta"][0]), "setup_s": setup_s},
+            "roofline": {"bound": "hbm", "kernel": "k_update_partial", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                         "bytes_per_launch": acc["k_bytes"] / acc["k_n"] if acc["k_n"] else None,
+                         "avg_launch_us": 1e3 * acc["k_ms"] / acc["k_n"] if acc["k_n"] else None,
+                         "launches_timed": int(acc["k_n"]),
+                         "sweep_level_GBs": 4.0 * n * p_loc / 1e9 / (acc["sweep_ms"] / a.steps / 1e3)},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(eng, n, p_total, min(a.cpu_sample_markers, p_loc), y, float(vare), float(Gval))
+    eng.close()
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+def cpu_baseline(eng, n, p_total, p_sub, y, vare, Gval):
+    """The CPU oracle's non-block BayesC sweep (oracle/jwas_oracle.c: orc_time_bayesc_sweeps -- per marker
+    fp32 dot, scalar update, conditional fp32 axpy: the reference's operation order, BayesABC.jl:60-80) on
+    the first p_sub markers of the same matrix, scaled linearly in p (the reference's own projection
+    device, benchmarks/streaming_large_benchmark.jl:161-184)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    X = eng.get_columns(0, p_sub)
+    xpx = O.xpx(X, O.ACC_F32)
+    ncores = os.cpu_count() or 1
+    res = {}
+    for threads, sweeps in ((1, 2), (ncores, 2)):
+        r = (y - y.mean()).astype(np.float32)
+        al = np.zeros(p_sub, dtype=np.float32)
+        be = np.zeros(p_sub, dtype=np.float32)
+        de = np.zeros(p_sub, dtype=np.float32)
+        # calibrate the sweep count for ~10 s of CPU work
+        t1 = O.time_bayesc_sweeps(X, xpx, r, al, be, de, vare, Gval, 0.95, 1, 1, threads)
+        sweeps = int(max(1, min(20, round(8.0 / max(t1, 1e-3)))))
+        tt = O.time_bayesc_sweeps(X, xpx, r, al, be, de, vare, Gval, 0.95, 1, sweeps, threads)
+        res[threads] = (tt / sweeps, sweeps)
+    best = min(res, key=lambda k: res[k][0])
+    per_sweep_full = res[best][0] * p_total / p_sub
+    return {"value": 1.0 / per_sweep_full, "unit": "iterations/s", "cores": best, "kind": "port",
+            "sample": (f"{res[best][1]} sweeps over the first {p_sub} of {p_total} markers (n={n}), scaled linearly in p; "
+                       f"1 thread: {res[1][0] * p_total / p_sub:.1f} s/sweep, {ncores} threads (row-split dot/axpy): "
+                       f"{res[ncores][0] * p_total / p_sub:.1f} s/sweep; sweep only, host updates excluded")}
+
+
+if __name__ == "__main__":
+    main()

@@ -101,6 +101,9 @@ typedef struct jwas_sweep_stats {
     double  state_counts[JWAS_HIP_MAX_STATES];       /* MT: markers per joint state (Pi.jl:20-42)                     */
     double  n_events;                                /* markers whose effect changed this sweep (diagnostic)          */
     double  sweep_ms;                                /* device time of the sweep (hipEvent), milliseconds             */
+    double  update_kernel_ms;                        /* sum of the sampled k_update_partial launch durations (ms)     */
+    double  update_kernel_samples;                   /* number of launches timed (see jwas_hip_set_kernel_timing)     */
+    double  update_kernel_bytes;                     /* algorithmic bytes (4*n*b) of the timed launches               */
 } jwas_sweep_stats;
 
 /* ---- context ------------------------------------------------------------------------------- */
@@ -126,8 +129,10 @@ int64_t jwas_hip_estimate_bytes(int64_t n, int64_t p, int32_t ntraits, int32_t b
 
 /* Benchmark / test data generator (benchmarks/bayesr_parity_common.jl:34-41 shape): allele
  * frequency f_j ~ U(0.1,0.4), x_ij = Bernoulli(f_j)+Bernoulli(f_j), optionally centred by the
- * exact column mean.  kind 1 = X ~ U[0,1) (benchmarks/jwas_nonblock_benchmark.jl:34-51). */
-int  jwas_hip_synth_genotypes(jwas_hip_ctx* ctx, uint64_t seed, int32_t kind, int32_t center);
+ * exact column mean.  kind 1 = X ~ U[0,1) (benchmarks/jwas_nonblock_benchmark.jl:34-51).
+ * marker_offset = global index of column 0, so marker shards of one matrix can be generated
+ * independently on different GPUs. */
+int  jwas_hip_synth_genotypes(jwas_hip_ctx* ctx, uint64_t seed, int32_t kind, int32_t center, int64_t marker_offset);
 
 /* ---- precompute: x'x and block Grams ----------------------------------------------------------- */
 /* block_size in {64,128,256,512,1024}; markers are processed in consecutive blocks of this size. */
@@ -150,12 +155,20 @@ int  jwas_hip_get_residual(jwas_hip_ctx* ctx, int32_t trait, float* r_host);
 /* Device pointer / stride of the residual block (t vectors of ld_dev floats) for in-place
  * collectives on it (marker-shard reconcile). */
 int  jwas_hip_residual_dev(jwas_hip_ctx* ctx, void** r_dev, int64_t* ld_dev);
+/* Device-to-device copies of residual k (n floats) from / to a caller-owned device buffer (e.g. a
+ * torch tensor's data_ptr()), ordered on the context's stream -- used around the per-sweep RCCL
+ * all-reduce of the residual delta. */
+int  jwas_hip_residual_to_dev(jwas_hip_ctx* ctx, int32_t trait, void* dst_dev);
+int  jwas_hip_residual_from_dev(jwas_hip_ctx* ctx, int32_t trait, const void* src_dev);
 /* r_k -= X * alpha_k for the current device alpha (initial ycorr; sequential fmaf in marker order). */
 int  jwas_hip_residual_sub_xalpha(jwas_hip_ctx* ctx, int32_t trait);
 /* out = X * alpha_k (n floats, fp64-accumulated). */
 int  jwas_hip_mul_alpha(jwas_hip_ctx* ctx, int32_t trait, float* out_host);
 
 /* ---- the sweep ------------------------------------------------------------------------------ */
+/* Time every `stride`-th k_update_partial launch of subsequent sweeps with HIP events on the
+ * sweep's stream (0 = off); the sums come back in jwas_sweep_stats.update_kernel_*. */
+int  jwas_hip_set_kernel_timing(jwas_hip_ctx* ctx, int32_t stride);
 int  jwas_hip_sweep(jwas_hip_ctx* ctx, const jwas_sweep_params* params, jwas_sweep_stats* stats);
 
 /* ---- posterior accumulators (output.jl:568-577) ---------------------------------------------- */

@@ -24,8 +24,9 @@ SYMBOLS = [
     "jwas_hip_synth_genotypes", "jwas_hip_setup_blocks", "jwas_hip_get_xpx", "jwas_hip_get_gram",
     "jwas_hip_set_gram", "jwas_hip_num_blocks", "jwas_hip_init_state", "jwas_hip_set_state",
     "jwas_hip_get_state", "jwas_hip_set_residual", "jwas_hip_get_residual", "jwas_hip_residual_dev",
-    "jwas_hip_residual_sub_xalpha", "jwas_hip_mul_alpha", "jwas_hip_sweep", "jwas_hip_accumulate",
-    "jwas_hip_get_posterior",
+    "jwas_hip_residual_to_dev", "jwas_hip_residual_from_dev",
+    "jwas_hip_residual_sub_xalpha", "jwas_hip_mul_alpha", "jwas_hip_set_kernel_timing", "jwas_hip_sweep",
+    "jwas_hip_accumulate", "jwas_hip_get_posterior",
 ]
 
 
@@ -54,6 +55,7 @@ class SweepStats(C.Structure):
         ("bayesr_ssq", C.c_double), ("bayesr_nnz", C.c_double),
         ("state_counts", C.c_double * MAX_STATES),
         ("n_events", C.c_double), ("sweep_ms", C.c_double),
+        ("update_kernel_ms", C.c_double), ("update_kernel_samples", C.c_double), ("update_kernel_bytes", C.c_double),
     ]
 
 
@@ -93,7 +95,7 @@ def load():
     L.jwas_hip_get_columns.argtypes = [vp, i64, i64, vp]
     L.jwas_hip_estimate_bytes.argtypes = [i64, i64, i32, i32]
     L.jwas_hip_estimate_bytes.restype = i64
-    L.jwas_hip_synth_genotypes.argtypes = [vp, u64, i32, i32]
+    L.jwas_hip_synth_genotypes.argtypes = [vp, u64, i32, i32, i64]
     L.jwas_hip_setup_blocks.argtypes = [vp, i32, i32]
     L.jwas_hip_get_xpx.argtypes = [vp, vp]
     L.jwas_hip_get_gram.argtypes = [vp, i64, vp]
@@ -105,6 +107,9 @@ def load():
     L.jwas_hip_set_residual.argtypes = [vp, i32, vp]
     L.jwas_hip_get_residual.argtypes = [vp, i32, vp]
     L.jwas_hip_residual_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
+    L.jwas_hip_residual_to_dev.argtypes = [vp, i32, vp]
+    L.jwas_hip_residual_from_dev.argtypes = [vp, i32, vp]
+    L.jwas_hip_set_kernel_timing.argtypes = [vp, i32]
     L.jwas_hip_residual_sub_xalpha.argtypes = [vp, i32]
     L.jwas_hip_mul_alpha.argtypes = [vp, i32, vp]
     L.jwas_hip_sweep.argtypes = [vp, C.POINTER(SweepParams), C.POINTER(SweepStats)]

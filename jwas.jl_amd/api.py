@@ -1,0 +1,284 @@
+"""Host-side mirror of the reference's user API for the marker path:
+get_genotypes() / build_model() / set_covariate() / runMCMC().
+
+Same names, argument meaning and error behaviour as reworkhow/JWAS.jl v2.3.6 (files under
+/root/reference/src/1.JWAS/src/):
+    get_genotypes   markers/readgenotypes.jl:213-448     (dense branch)
+    build_model     build_MME.jl:42-156
+    set_covariate   build_MME.jl:158-181
+    runMCMC         JWAS.jl:161-511  -> MCMC/MCMC_BayesianAlphabet.jl
+Everything that is NOT the marker sweep stays here on the host (numpy): data ingestion and QC,
+model parsing, fixed-effect Gibbs, variance-component and pi draws, output tables.  Model families
+outside the hot path (pedigree / random terms, GBLUP, RR-BLUP, BayesL, categorical / censored traits,
+SEM, RRM, single-step pre-processing, marker annotations) are rejected with an explicit error:
+they stay on the reference.
+"""
+import inspect
+import os
+
+import numpy as np
+
+from .mcmc import run_chain
+
+SUPPORTED_METHODS = ("BayesA", "BayesB", "BayesC", "BayesR")
+BAYESR_DEFAULT_PI = np.array([0.95, 0.03, 0.015, 0.005])      # tools4genotypes.jl:375-377
+BAYESR_GAMMA = np.array([0.0, 0.01, 0.1, 1.0])                # JWAS.jl:12
+
+
+class Variance:
+    """types.jl:56-64"""
+
+    def __init__(self, val, df, scale, estimate_variance=True, estimate_scale=False, constraint=False):
+        self.val, self.df, self.scale = val, df, scale
+        self.estimate_variance, self.estimate_scale, self.constraint = estimate_variance, estimate_scale, constraint
+
+    def __repr__(self):
+        return f"Variance(val={self.val}, df={self.df}, scale={self.scale}, estimate_variance={self.estimate_variance})"
+
+
+class Genotypes:
+    """types.jl:98-165 -- the fields the marker path reads."""
+
+    def __init__(self, obsID, markerID, nObs, nMarkers, alleleFreq, sum2pq, centered, genotypes):
+        self.name = False
+        self.trait_names = False
+        self.obsID, self.markerID = list(obsID), list(markerID)
+        self.nObs, self.nMarkers = int(nObs), int(nMarkers)
+        self.alleleFreq, self.sum2pq, self.centered = alleleFreq, float(sum2pq), bool(centered)
+        self.genotypes = genotypes
+        self.ntraits = False
+        self.genetic_variance = Variance(False, False, False)
+        self.G = Variance(False, False, False)
+        self.method = False
+        self.estimatePi = True
+        self.pi = 0.0
+        self.alpha = False                      # starting values
+        self.storage_mode = "dense"
+        self.multi_trait_sampler = "I"
+
+
+def _is_false(x):
+    return x is False or x is None
+
+
+def get_genotypes(file, G=False, *, method="BayesC", Pi=0.0, estimatePi=True,
+                  G_is_marker_variance=False, df=4.0, estimate_variance=True, estimate_scale=False,
+                  constraint=False, separator=",", header=True, double_precision=False,
+                  quality_control=True, MAF=0.01, missing_value=9.0, center=True, starting_value=False,
+                  annotations=False, multi_trait_sampler="I", storage="dense"):
+    """readgenotypes.jl:213-448.  `file`: path of a delimited text file (first column = individual
+    IDs), a pandas DataFrame (first column IDs) or a 2-D array."""
+    if multi_trait_sampler not in ("auto", "I", "II"):
+        raise ValueError("multi_trait_sampler must be one of :auto, :I, or :II.")            # :229-231
+    if storage not in ("dense", "stream"):
+        raise ValueError("storage must be :dense or :stream.")                                # :232-234
+    if storage == "stream":
+        raise NotImplementedError("storage=:stream (packed 2-bit .jgb2 backend) is not on the device path yet; "
+                                  "use storage=:dense")
+    if double_precision:
+        raise NotImplementedError("the MI355X path is Float32 (double_precision=false), like the reference's "
+                                  "storage=:stream mode (readgenotypes.jl:246-248)")
+    if annotations is not False:
+        raise NotImplementedError("marker annotations stay on the reference path")
+    if method not in SUPPORTED_METHODS:
+        raise NotImplementedError(f"method {method} is not on the device path (supported: {SUPPORTED_METHODS}); "
+                                  "GBLUP / RR-BLUP / BayesL stay on the reference")
+    if multi_trait_sampler == "II":
+        raise NotImplementedError("multi-trait Gibbs sampler II stays on the reference; sampler I is implemented")
+
+    data_type = np.float32
+    try:
+        import pandas as pd
+    except ImportError:                                              # pragma: no cover
+        pd = None
+    if isinstance(file, str):                                                                 # :300-327
+        with open(file) as fh:
+            row1 = [t for t in fh.readline().rstrip("\n").split(separator) if t != ""]
+        ncol = len(row1)
+        markerID = [str(t) for t in row1[1:]] if header else [str(i + 1) for i in range(ncol - 1)]
+        tab = pd.read_csv(file, sep=separator, header=None, skiprows=1 if header else 0, dtype={0: str})
+        obsID = [str(v) for v in tab.iloc[:, 0]]
+        genotypes = np.asfortranarray(tab.iloc[:, 1:].to_numpy(dtype=data_type))
+    elif pd is not None and isinstance(file, pd.DataFrame):                                   # :328-338
+        markerID = [str(c) for c in file.columns[1:]] if header else [str(i + 1) for i in range(file.shape[1] - 1)]
+        obsID = [str(v) for v in file.iloc[:, 0]]
+        genotypes = np.asfortranarray(file.iloc[:, 1:].to_numpy(dtype=data_type))
+    elif isinstance(file, np.ndarray) and file.ndim == 2:                                      # :339-345
+        markerID = [str(i + 1) for i in range(file.shape[1])]
+        obsID = [str(i + 1) for i in range(file.shape[0])]
+        genotypes = np.array(file, dtype=data_type, order="F")
+    else:
+        raise TypeError("The data type is not supported.")                                    # :346-348
+
+    nObs, nMarkers = genotypes.shape
+    if quality_control:                                                                       # :372-382
+        mv = data_type(missing_value)
+        for j in range(nMarkers):
+            col = genotypes[:, j]
+            miss = col == mv
+            if miss.any():
+                col[miss] = col[~miss].mean(dtype=np.float32)
+    if center:                                                                                # :384
+        markerMeans = genotypes.mean(axis=0, dtype=np.float32).astype(np.float32)
+        genotypes -= markerMeans[None, :]
+    else:
+        markerMeans = genotypes.mean(axis=0, dtype=np.float32).astype(np.float32)
+    p = (markerMeans / data_type(2.0)).astype(np.float32)                                     # :385
+    if quality_control:                                                                       # :388-399
+        select1 = (MAF < p) & (p < 1 - MAF)
+        select2 = genotypes.var(axis=0, ddof=1) != 0
+        select = select1 & select2
+        genotypes = np.asfortranarray(genotypes[:, select])
+        p = p[select]
+        markerID = [m for m, s in zip(markerID, select) if s]
+        print(f"{int((~select).sum())} loci which are fixed or have minor allele frequency < {MAF} are removed.")
+    nObs, nMarkers = genotypes.shape
+    sum2pq = float((2.0 * p.astype(np.float32) * (1.0 - p.astype(np.float32))).sum(dtype=np.float32))   # :401
+
+    g = Genotypes(obsID, markerID, nObs, nMarkers, p, sum2pq, center, genotypes)
+    g.G = Variance(G if G_is_marker_variance else False, df, False, estimate_variance, estimate_scale, constraint)   # :424
+    g.genetic_variance = Variance(False if G_is_marker_variance else G, df, False, estimate_variance, estimate_scale, constraint)
+    g.method, g.estimatePi, g.pi = method, estimatePi, Pi
+    g.multi_trait_sampler = multi_trait_sampler
+    print("Genotype informatin:")
+    print(f"#markers: {nMarkers}; #individuals: {nObs}")
+    if not _is_false(starting_value):                                                         # :438-446
+        sv = np.asarray(starting_value, dtype=np.float32).reshape(-1)
+        if sv.size % nMarkers != 0:
+            raise ValueError("length of starting values is wrong.")
+        g.alpha = sv
+    return g
+
+
+class ModelTerm:
+    def __init__(self, trait, name):
+        self.trait, self.name = trait, name
+        self.kind = "intercept" if name == "intercept" else "factor"      # factor | covariate | intercept
+
+
+class Model:
+    """The slice of MME (types.jl:264-346) the marker path needs."""
+
+    def __init__(self, equations, traits, terms, M, R):
+        self.model_equations = equations
+        self.lhsVec = traits
+        self.nModels = len(traits)
+        self.modelTerms = terms                # list (per trait) of ModelTerm
+        self.M = M                             # list of Genotypes
+        self.R = R
+        self.covVec = []
+        self.MCMCinfo = None
+        self.output = None
+
+
+def build_model(model_equations, R=False, *, df=4.0, estimate_variance=True, estimate_scale=False,
+                constraint=False, genotypes=None, **unsupported):
+    """build_MME.jl:42-156.  Genotype terms are found the way the reference does it -- by looking the
+    term name up among the caller's variables (build_MME.jl:88-120 reflects on Main) -- or through an
+    explicit `genotypes={"geno": obj}` mapping."""
+    for k in unsupported:
+        raise NotImplementedError(f"build_model argument '{k}' (neural-network / censored / categorical models) "
+                                  "stays on the reference path")
+    if not isinstance(model_equations, str) or model_equations.strip() == "":
+        raise ValueError("Model equations are wrong.\n To find an example, type ?build_model and press enter.")   # :50-52
+    caller = inspect.currentframe().f_back
+    scope = dict(caller.f_globals)
+    scope.update(caller.f_locals)
+    if genotypes:
+        scope.update(genotypes)
+    eqs = [e.strip() for e in model_equations.replace("\n", ";").split(";") if e.strip()]
+    traits, terms, M = [], [], []
+    for eq in eqs:
+        lhs, rhs = [s.strip() for s in eq.split("=")]
+        traits.append(lhs)
+        tl = []
+        for name in [t.strip() for t in rhs.split("+")]:
+            if "*" in name:
+                raise NotImplementedError("interaction terms stay on the reference path")
+            obj = scope.get(name)
+            if isinstance(obj, Genotypes):                                                    # :91-96
+                if obj not in M:
+                    obj.name = name
+                    M.append(obj)
+            else:
+                tl.append(ModelTerm(lhs, name))
+        terms.append(tl)
+    if len(M) > 1:
+        raise NotImplementedError("one genotype category per model on the device path (reference: 'now only work for one geno')")
+    nModels = len(traits)
+    for Mi in M:                                                                              # :98-112
+        Mi.ntraits = nModels
+        Mi.trait_names = traits
+        if nModels != 1:
+            Mi.G.df = Mi.G.df + nModels
+            Mi.genetic_variance.df = Mi.genetic_variance.df + nModels
+    if nModels == 1:                                                                          # :128-134
+        Rv = False if _is_false(R) else np.float32(R)
+        scale_R = False if _is_false(R) else float(R) * (df - 2) / df
+        df_R = df
+    else:
+        Rv = False if _is_false(R) else np.asarray(R, dtype=np.float32)
+        scale_R = False if _is_false(R) else np.asarray(R, dtype=np.float64) * (df - 1)
+        df_R = df + nModels
+    return Model(model_equations, traits, terms, M, Variance(Rv, np.float32(df_R), scale_R, estimate_variance, estimate_scale, constraint))
+
+
+def set_covariate(model, *names):
+    """build_MME.jl:158-181: declare terms as continuous covariates (default is a class factor)."""
+    flat = []
+    for n in names:
+        flat.extend(n.split())
+    model.covVec.extend(flat)
+    for tl in model.modelTerms:
+        for t in tl:
+            if t.name in flat:
+                t.kind = "covariate"
+
+
+def runMCMC(model, df, *, heterogeneous_residuals=False, chain_length=100, starting_value=False, burnin=0,
+            output_samples_frequency=None, update_priors_frequency=0, single_step_analysis=False, pedigree=False,
+            causal_structure=False, missing_phenotypes=True, RRM=False, outputEBV=True, output_heritability=True,
+            prediction_equation=False, seed=False, printout_model_info=True, printout_frequency=None,
+            big_memory=False, double_precision=False, fast_blocks=False, independent_blocks=False,
+            memory_guard="error", memory_guard_ratio=0.80, output_folder="results",
+            output_samples_for_all_parameters=False,
+            # device options (the analogue of storage=:stream's opt-in knobs)
+            device=0, block_size=None, gram_mode="mfma", engine=None):
+    """JWAS.jl:161-511.  Returns the reference's output Dict (output.jl:108-212) as a dict of pandas
+    DataFrames and writes the same text files under `output_folder`.
+
+    fast_blocks: False -> the exact non-block chain (computed on the device in blocks with one
+    within-block pass, algebraically identical: SURVEY.md section 7 step 4); True / number -> the
+    reference's fast_blocks schedule (block-size repetitions, chain_length rescaled, JWAS.jl:293-316).
+    `engine` injects a sweep engine (tests); the default and only shipped engine is HipEngine."""
+    if independent_blocks and fast_blocks is False:
+        raise ValueError("independent_blocks=true requires fast_blocks != false.")             # :242-244
+    for flag, name in ((heterogeneous_residuals, "heterogeneous_residuals"), (single_step_analysis, "single_step_analysis"),
+                       (causal_structure, "causal_structure"), (RRM, "RRM"), (double_precision, "double_precision"),
+                       (independent_blocks, "independent_blocks"), (update_priors_frequency, "update_priors_frequency"),
+                       (prediction_equation, "prediction_equation")):
+        if not _is_false(flag) and flag != 0:
+            raise NotImplementedError(f"runMCMC(...; {name}=...) is outside the device marker path and stays on the reference")
+    if not model.M:
+        raise NotImplementedError("models without a genotype term have no marker sweep: use the reference")
+    if memory_guard not in ("error", "warn", "off"):
+        raise ValueError("memory_guard must be :error, :warn or :off.")
+    if output_samples_frequency is None:
+        output_samples_frequency = chain_length // 1000 if chain_length > 1000 else 1          # :168
+    if printout_frequency is None:
+        printout_frequency = chain_length + 1
+    # an existing output folder is never overwritten (JWAS.jl:255-262)
+    myfolder, folderi = output_folder, 1
+    while os.path.exists(output_folder):
+        print(f"The folder {output_folder} already exists.")
+        output_folder = myfolder + str(folderi)
+        folderi += 1
+    os.makedirs(output_folder)
+    return run_chain(model, df, chain_length=int(chain_length), burnin=int(burnin),
+                     output_samples_frequency=int(output_samples_frequency), seed=seed,
+                     starting_value=starting_value, fast_blocks=fast_blocks, outputEBV=outputEBV,
+                     output_folder=output_folder, printout_frequency=printout_frequency,
+                     memory_guard=memory_guard, memory_guard_ratio=memory_guard_ratio,
+                     missing_phenotypes=missing_phenotypes, device=device, block_size=block_size,
+                     gram_mode=gram_mode, engine=engine, printout_model_info=printout_model_info,
+                     output_samples_for_all_parameters=output_samples_for_all_parameters)

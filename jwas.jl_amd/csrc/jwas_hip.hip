@@ -52,6 +52,8 @@ struct jwas_hip_ctx {
     double* pi_vec = nullptr;
     double* pi_mat = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    int timing_stride = 0;
+    std::vector<hipEvent_t> kev;        // pairs of events around sampled k_update_partial launches
 };
 
 static constexpr int kStatGrid = 128;
@@ -168,6 +170,7 @@ void jwas_hip_destroy(jwas_hip_ctx* c)
     free_state(c); free_blocks(c); free_storage(c);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+    for (hipEvent_t e : c->kev) (void)hipEventDestroy(e);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -285,14 +288,15 @@ int jwas_hip_get_columns(jwas_hip_ctx* c, int64_t j0, int64_t count, float* out)
     return JWAS_HIP_OK;
 }
 
-int jwas_hip_synth_genotypes(jwas_hip_ctx* c, uint64_t seed, int32_t kind, int32_t center)
+int jwas_hip_synth_genotypes(jwas_hip_ctx* c, uint64_t seed, int32_t kind, int32_t center, int64_t marker_offset)
 {
     NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
     NEED(c, c->X, JWAS_HIP_ESTATE, "allocate the matrix first (jwas_hip_alloc_dense_f32)");
     NEED(c, kind == 0 || kind == 1, JWAS_HIP_EINVAL, "kind must be 0 (0/1/2 genotypes) or 1 (uniform)");
     HIPCHK(c, hipSetDevice(c->device));
+    NEED(c, marker_offset >= 0 && marker_offset + c->p < (1ll << 32), JWAS_HIP_EINVAL, "marker_offset out of range");
     hipLaunchKernelGGL(k_synth, dim3((unsigned)c->p), dim3(256), 0, c->stream, c->X, c->n, c->ld,
-                       (uint32_t)seed, (uint32_t)(seed >> 32), (int)kind, (int)center);
+                       (uint32_t)seed, (uint32_t)(seed >> 32), (int)kind, (int)center, (uint32_t)marker_offset);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return JWAS_HIP_OK;
@@ -475,6 +479,24 @@ int jwas_hip_residual_dev(jwas_hip_ctx* c, void** rdev, int64_t* ld)
     return JWAS_HIP_OK;
 }
 
+int jwas_hip_residual_to_dev(jwas_hip_ctx* c, int32_t trait, void* dst)
+{
+    NEED(c, c && dst, JWAS_HIP_EINVAL, "NULL argument");
+    NEED_TRAIT(c, trait);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(dst, c->r + (size_t)trait * c->ld, sizeof(float) * c->n, hipMemcpyDeviceToDevice, c->stream));
+    return JWAS_HIP_OK;
+}
+
+int jwas_hip_residual_from_dev(jwas_hip_ctx* c, int32_t trait, const void* src)
+{
+    NEED(c, c && src, JWAS_HIP_EINVAL, "NULL argument");
+    NEED_TRAIT(c, trait);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(c->r + (size_t)trait * c->ld, src, sizeof(float) * c->n, hipMemcpyDeviceToDevice, c->stream));
+    return JWAS_HIP_OK;
+}
+
 int jwas_hip_residual_sub_xalpha(jwas_hip_ctx* c, int32_t trait)
 {
     NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
@@ -556,6 +578,14 @@ static int upload_vec(jwas_hip_ctx* c, void** dev, const void* host, size_t byte
 
 extern "C" {
 
+int jwas_hip_set_kernel_timing(jwas_hip_ctx* c, int32_t stride)
+{
+    NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
+    NEED(c, stride >= 0, JWAS_HIP_EINVAL, "stride must be >= 0");
+    c->timing_stride = stride;
+    return JWAS_HIP_OK;
+}
+
 int jwas_hip_sweep(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_sweep_stats* S)
 {
     NEED(c, c && P && S, JWAS_HIP_EINVAL, "NULL argument");
@@ -616,9 +646,16 @@ int jwas_hip_sweep(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_sweep_stats
     }
 
     const int bs = c->block_size;
+    size_t ntimed = 0;
+    double timed_bytes = 0.0;
     for (int64_t blk = 0; blk < c->nblocks; ++blk) {
         const int64_t j0 = blk * bs;
         const int b = (int)((j0 + bs <= c->p) ? bs : c->p - j0);
+        const bool timed = c->timing_stride > 0 && (blk % c->timing_stride) == 0;
+        if (timed) {
+            while (c->kev.size() < 2 * (ntimed + 1)) { hipEvent_t e; HIPCHK(c, hipEventCreate(&e)); c->kev.push_back(e); }
+            HIPCHK(c, hipEventRecord(c->kev[2 * ntimed], c->stream));
+        }
         const Events* ev_in = &c->ev[blk & 1];
         Events* ev_out = &c->ev[(blk + 1) & 1];
         const float* r_in = c->r + (size_t)(blk & 1) * kMaxT * c->ld;
@@ -628,6 +665,11 @@ int jwas_hip_sweep(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_sweep_stats
             case 2: launch_update<2>(c, r_in, r_out, ev_in, j0, b); break;
             case 3: launch_update<3>(c, r_in, r_out, ev_in, j0, b); break;
             default: launch_update<4>(c, r_in, r_out, ev_in, j0, b);
+        }
+        if (timed) {
+            HIPCHK(c, hipEventRecord(c->kev[2 * ntimed + 1], c->stream));
+            ++ntimed;
+            timed_bytes += 4.0 * (double)c->n * (double)b;
         }
         switch (bs) {
             case 64:  launch_sample<1>(c, blk, j0, b, ev_out); break;
@@ -684,6 +726,13 @@ int jwas_hip_sweep(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_sweep_stats
     float ms = 0.f;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev_start, c->ev_stop));
     S->sweep_ms = ms;
+    for (size_t i = 0; i < ntimed; ++i) {
+        float kms = 0.f;
+        HIPCHK(c, hipEventElapsedTime(&kms, c->kev[2 * i], c->kev[2 * i + 1]));
+        S->update_kernel_ms += kms;
+    }
+    S->update_kernel_samples = (double)ntimed;
+    S->update_kernel_bytes = timed_bytes;
     return JWAS_HIP_OK;
 }
 

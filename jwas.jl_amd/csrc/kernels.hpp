@@ -1040,11 +1040,11 @@ __global__ __launch_bounds__(256) void k_sub_xalpha(const float* __restrict__ X,
 // synthetic genotypes (bench / tests).  grid = p, block = 256.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_synth(float* __restrict__ X, int64_t n, int64_t ld, uint32_t seed_lo,
-                                               uint32_t seed_hi, int kind, int center)
+                                               uint32_t seed_hi, int kind, int center, uint32_t marker0)
 {
     __shared__ double red[4];
-    const uint32_t j = blockIdx.x;
-    float* x = X + (int64_t)j * ld;
+    const uint32_t j = marker0 + blockIdx.x;          // global marker index keys the generator
+    float* x = X + (int64_t)blockIdx.x * ld;
     const u32x4 wf = philox4x32_10(j, 0xFFFFFFFFu, 0u, 0u, seed_lo, seed_hi);
     const float f = 0.1f + 0.3f * ((float)(wf.x >> 8) * 0x1.0p-24f);          // U(0.1, 0.4)
     double v[1] = {0.0};

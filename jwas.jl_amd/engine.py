@@ -92,8 +92,8 @@ class HipEngine:
         self.n, self.p = int(n), int(p)
         self.method, self.block_size = None, 0
 
-    def synth(self, seed, kind=0, center=True):
-        self._chk(self._L.jwas_hip_synth_genotypes(self._h, int(seed), int(kind), int(bool(center))))
+    def synth(self, seed, kind=0, center=True, marker_offset=0):
+        self._chk(self._L.jwas_hip_synth_genotypes(self._h, int(seed), int(kind), int(bool(center)), int(marker_offset)))
 
     def layout(self):
         n, p, ld, ptr = C.c_int64(), C.c_int64(), C.c_int64(), C.c_void_p()
@@ -192,6 +192,15 @@ class HipEngine:
         self._chk(self._L.jwas_hip_residual_dev(self._h, C.byref(ptr), C.byref(ld)))
         return ptr.value, ld.value
 
+    def residual_to_dev(self, dst_ptr, trait=0):
+        self._chk(self._L.jwas_hip_residual_to_dev(self._h, int(trait), C.c_void_p(int(dst_ptr))))
+
+    def residual_from_dev(self, src_ptr, trait=0):
+        self._chk(self._L.jwas_hip_residual_from_dev(self._h, int(trait), C.c_void_p(int(src_ptr))))
+
+    def set_kernel_timing(self, stride):
+        self._chk(self._L.jwas_hip_set_kernel_timing(self._h, int(stride)))
+
     def sub_xalpha(self, trait=0):
         self._chk(self._L.jwas_hip_residual_sub_xalpha(self._h, int(trait)))
 
@@ -280,6 +289,8 @@ class HipEngine:
             "bayesr_ssq": S.bayesr_ssq, "bayesr_nnz": S.bayesr_nnz,
             "state_counts": np.array(S.state_counts[:1 << t]),
             "n_events": S.n_events, "sweep_ms": S.sweep_ms,
+            "update_kernel_ms": S.update_kernel_ms, "update_kernel_samples": S.update_kernel_samples,
+            "update_kernel_bytes": S.update_kernel_bytes,
         }
 
     # -- posterior accumulators --------------------------------------------------------------------

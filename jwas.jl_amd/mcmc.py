@@ -1,0 +1,402 @@
+"""Host side of one MCMC chain: everything of MCMC_BayesianAlphabet (MCMC/MCMC_BayesianAlphabet.jl:4-447)
+that is NOT the marker sweep, driving a sweep engine (jwas.jl_amd.engine.HipEngine) for step 2.
+
+Per iteration (the reference's order, MCMC_BayesianAlphabet.jl:184-421):
+  1. location parameters: ycorr += X sol ; rhs = X'ycorr ; single-site Gibbs ; ycorr -= X sol   (:196-220, host)
+  2. marker effects: engine.sweep(...)                                                      (:224-290, DEVICE)
+  3. pi  ~ Beta / Dirichlet from the sweep's counts                                          (:294-317, host)
+  4. marker effect variance from alpha'alpha / ssq / beta'beta                               (:321-326, host)
+  5. residual variance from r'r                                                              (:363-370, host)
+  6. every output_samples_frequency after burn-in: running means (device for markers)       (:399-413)
+The host consumes only O(n) + O(p)-reducible quantities from the device.
+"""
+import os
+import time
+
+import numpy as np
+
+BAYESR_GAMMA = np.array([0.0, 0.01, 0.1, 1.0])
+DEVICE_BLOCK_SIZES = (64, 128, 256, 512, 1024)
+
+
+def _supported_block(b):
+    return min(DEVICE_BLOCK_SIZES, key=lambda s: abs(s - b))
+
+
+class _Running:
+    """mean += (x-mean)/k ; mean2 += (x^2-mean2)/k   (output.jl:556-560)"""
+
+    def __init__(self, like):
+        self.mean = np.zeros_like(np.asarray(like, dtype=np.float64))
+        self.mean2 = np.zeros_like(self.mean)
+
+    def add(self, x, k):
+        x = np.asarray(x, dtype=np.float64)
+        self.mean += (x - self.mean) / k
+        self.mean2 += (x * x - self.mean2) / k
+
+    def sd(self):
+        return np.sqrt(np.abs(self.mean2 - self.mean ** 2))          # output.jl:112,133
+
+
+def _design(model, df, ids_col):
+    """Fixed-effect incidence matrices per trait (build_MME.jl:183-290, dense): intercept = ones,
+    covariate = the column, factor = one 0/1 column per level."""
+    cols, labels = [], []
+    for tl in model.modelTerms:
+        Xk, lab = [], []
+        for term in tl:
+            if term.kind == "intercept":
+                Xk.append(np.ones((len(df), 1)))
+                lab.append((term.trait, "intercept", "intercept"))
+            elif term.kind == "covariate":
+                Xk.append(df[term.name].to_numpy(dtype=np.float64)[:, None])
+                lab.append((term.trait, term.name, term.name))
+            else:
+                if term.name not in df.columns:
+                    raise ValueError(f"{term.name} is not found in the phenotype data (genotype terms must be "
+                                     "Genotypes objects visible to build_model).")
+                lev = df[term.name].astype(str)
+                for lv in sorted(lev.unique()):
+                    Xk.append((lev == lv).to_numpy(dtype=np.float64)[:, None])
+                    lab.append((term.trait, term.name, lv))
+        cols.append(np.hstack(Xk) if Xk else np.zeros((len(df), 0)))
+        labels.append(lab)
+    return cols, labels
+
+
+def genetic2marker(Mi, pi, method, t=1):
+    """Marker-effect (co)variance implied by the genetic variance and pi (tools4genotypes.jl:426-478)."""
+    p = Mi.nMarkers
+    Vg = np.asarray(Mi.genetic_variance.val, dtype=np.float64)
+    if t > 1:                                                          # :426-438 (Dict Pi)
+        pi_arr = np.asarray(pi, dtype=np.float64)
+        denom = np.zeros((t, t))
+        for i in range(t):
+            for j in range(t):
+                sel = [s for s in range(1 << t) if (s >> i) & 1 and (s >> j) & 1]
+                denom[i, j] = Mi.sum2pq * pi_arr[sel].sum()
+        return Vg / denom
+    if method == "BayesR":                                             # :461-467
+        pv = np.asarray(pi, dtype=np.float64)
+        if pv.shape != (4,):
+            raise ValueError("BayesR Pi must have length 4.")
+        denom = Mi.sum2pq * float((BAYESR_GAMMA * pv).sum())
+        if not denom > 0:
+            raise ValueError("BayesR implied variance denominator must be positive.")
+        return float(Vg) / denom
+    if np.ndim(pi) == 1:                                               # :468-475
+        if len(pi) != p:
+            raise ValueError(f"BayesC marker-level Pi must have length {p}.")
+        af = np.asarray(Mi.alleleFreq, dtype=np.float64)
+        denom = float((2 * af * (1 - af) * (1 - np.clip(np.asarray(pi, dtype=np.float64), 0, 1))).sum())
+        if not denom > 0:
+            raise ValueError("BayesC implied variance denominator must be positive.")
+        return float(Vg) / denom
+    return float(Vg) / ((1 - float(pi)) * Mi.sum2pq)                   # :457-459
+
+
+def _gibbs(A, x, b, rng, vare=None):
+    """One sweep of the single-site Gibbs sampler on the MME (iterative_solver/solver.jl:143-162)."""
+    for i in range(len(x)):
+        if A[i, i] != 0.0:
+            invlhs = 1.0 / A[i, i]
+            mu = invlhs * (b[i] - A[:, i] @ x) + x[i]
+            x[i] = rng.standard_normal() * np.sqrt(invlhs * (vare if vare is not None else 1.0)) + mu
+
+
+def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed, starting_value,
+              fast_blocks, outputEBV, output_folder, printout_frequency, memory_guard, memory_guard_ratio,
+              missing_phenotypes, device, block_size, gram_mode, engine, printout_model_info,
+              output_samples_for_all_parameters):
+    import pandas as pd
+    Mi = model.M[0]
+    t = model.nModels
+    method = Mi.method
+    if t > 1 and method != "BayesC":
+        raise NotImplementedError("multi-trait device path implements BayesC (Gibbs sampler I); other methods stay on the reference")
+    if not isinstance(starting_value, bool) or starting_value:
+        raise NotImplementedError("starting values for location parameters stay on the reference; marker starting "
+                                  "values go through get_genotypes(starting_value=...)")
+    seed_int = 0 if seed is False else int(seed)
+    rng = np.random.default_rng(seed_int)                                # host-side draws (JWAS.jl:239-241)
+
+    # ---- align phenotypes and genotypes (input_data_validation.jl:198-294, tools4genotypes.jl:288-323)
+    idcol = df.columns[0]
+    ph = df.copy()
+    ph[idcol] = ph[idcol].astype(str)
+    for tr in model.lhsVec:
+        if tr not in ph.columns:
+            raise ValueError(f"Phenotypes for {tr} are not found in the data.")
+    complete = np.ones(len(ph), dtype=bool)
+    for tr in model.lhsVec:
+        complete &= np.isfinite(ph[tr].to_numpy(dtype=np.float64))
+    if t > 1 and not complete.all():
+        raise NotImplementedError("missing phenotypes in multi-trait analyses (residual imputation, residual.jl:15-73) stay on the reference")
+    geno_index = {g: i for i, g in enumerate(Mi.obsID)}
+    keep = complete & ph[idcol].isin(geno_index).to_numpy()
+    ph = ph.loc[keep].reset_index(drop=True)
+    if len(ph) == 0:
+        raise ValueError("no individual has both phenotypes and genotypes")
+    rows = np.array([geno_index[i] for i in ph[idcol]], dtype=np.int64)
+    X = Mi.genotypes if (len(rows) == Mi.nObs and np.array_equal(rows, np.arange(Mi.nObs))) else np.asfortranarray(Mi.genotypes[rows, :])
+    n, p = X.shape
+    with open(os.path.join(output_folder, "IDs_for_individuals_with_phenotypes.txt"), "w") as fh:
+        fh.write("\n".join(ph[idcol]) + "\n")
+    with open(os.path.join(output_folder, "IDs_for_individuals_with_genotypes.txt"), "w") as fh:
+        fh.write("\n".join(Mi.obsID) + "\n")
+    Y = np.stack([ph[tr].to_numpy(dtype=np.float32) for tr in model.lhsVec])       # t x n
+
+    # ---- default priors (input_data_validation.jl:296-350, tools4genotypes.jl:353-478, build_MME.jl:128-141)
+    phenovar = np.array([np.var(Y[k].astype(np.float64), ddof=1) for k in range(t)])
+    varg = np.diag(phenovar) * 0.5
+    vare0 = np.diag(phenovar) * 0.5
+    R = model.R
+    if R.val is False:
+        R.val = np.float32(vare0[0, 0]) if t == 1 else vare0.astype(np.float32)
+        R.scale = float(R.val) * (float(R.df) - 2) / float(R.df) if t == 1 else np.asarray(R.val, dtype=np.float64) * (float(R.df) - t - 1)
+    if Mi.G.val is False and Mi.genetic_variance.val is False:
+        Mi.genetic_variance.val = varg[0, 0] if t == 1 else varg
+    pi = Mi.pi
+    if t > 1 and (np.isscalar(pi) and pi == 0.0):                      # tools4genotypes.jl:357-373
+        pi = np.zeros(1 << t)
+        pi[(1 << t) - 1] = 1.0
+    if method == "BayesR" and np.isscalar(pi) and pi == 0.0:           # :375-377
+        pi = np.array([0.95, 0.03, 0.015, 0.005])
+    if method == "BayesA":                                             # input_data_validation.jl:33-36
+        method, pi, Mi.estimatePi = "BayesB", 0.0, False
+    if Mi.G.val is False:
+        Mi.G.val = genetic2marker(Mi, pi, method, t)
+        if (t == 1 and not Mi.G.val > 0) or (t > 1 and np.any(np.linalg.eigvalsh(Mi.G.val) <= 0)):
+            raise ValueError("Marker effects variance is negative!" if t == 1 else
+                             "Marker effects covariance matrix is not postive definite! Please modify the argument: Pi.")
+    Gdf = float(Mi.G.df)
+    Mi.G.scale = (np.float64(Mi.G.val) * (Gdf - 2) / Gdf) if t == 1 else np.asarray(Mi.G.val, dtype=np.float64) * (Gdf - t - 1)   # :414-418
+
+    # ---- fast_blocks parsing (JWAS.jl:293-316); device blocks are powers of two >= 64
+    nreps = 1
+    if fast_blocks is not False:
+        if fast_blocks is True:
+            want = int(np.floor(np.sqrt(n)))
+        elif np.isscalar(fast_blocks):
+            want = int(np.floor(fast_blocks))
+        else:
+            raise NotImplementedError("explicit fast_blocks start vectors stay on the reference (device blocks are uniform)")
+        if want < 1:
+            raise ValueError("fast_blocks block size must be at least 1.")
+        block_size = _supported_block(want)
+        if p <= block_size:
+            raise ValueError("fast_blocks block size must create at least two block starts.")
+        chain_length = int(np.floor(chain_length / block_size))
+        nreps = 0                                                       # = block size (BayesABC.jl:153)
+        print(f"BLOCK SIZE: {block_size}")
+    if block_size is None:
+        block_size = 256 if p > 256 else 64
+
+    # ---- engine (the only engine shipped is the HIP one; there is no CPU fallback)
+    own_engine = engine is None
+    if own_engine:
+        from .engine import HipEngine
+        need = HipEngine.estimate_bytes(n, p, t, block_size)
+        engine = HipEngine(device)
+        free = engine.device_info()["hbm_free"]
+        if memory_guard != "off" and need > memory_guard_ratio * free:   # JWAS.jl:422-459 analogue for HBM
+            msg = (f"marker path needs {need / 1e9:.2f} GB of HBM, more than {memory_guard_ratio:.2f} x free "
+                   f"({free / 1e9:.2f} GB)")
+            if memory_guard == "error":
+                engine.close()
+                raise MemoryError(msg)
+            print("WARNING: " + msg)
+    engine.load_dense(X)                       # after alignment (tools4genotypes.jl:310-321)
+    engine.setup_blocks(block_size, gram_mode)
+    engine.init_state("MTBayesC" if t > 1 else method, t)
+
+    # ---- fixed effects
+    Xf, labels = _design(model, ph, idcol)
+    q = [x.shape[1] for x in Xf]
+    sol = np.zeros(sum(q))
+    off = np.cumsum([0] + q)
+
+    # ---- starting state (MCMC_BayesianAlphabet.jl:85-147)
+    alpha0 = np.zeros((t, p), dtype=np.float32)
+    if Mi.alpha is not False:
+        alpha0[:] = np.asarray(Mi.alpha, dtype=np.float32).reshape(t, p)
+    for k in range(t):
+        engine.set_state(k, alpha=alpha0[k], beta=alpha0[k],
+                         delta=np.ones(p, dtype=np.int32 if method == "BayesR" else np.float32))
+        engine.set_residual(Y[k], k)           # sol = 0
+        if alpha0[k].any():
+            engine.sub_xalpha(k)
+
+    vare = np.float32(R.val) if t == 1 else np.asarray(R.val, dtype=np.float32)
+    Gval = np.float32(Mi.G.val) if t == 1 else np.asarray(Mi.G.val, dtype=np.float32)
+    if method == "BayesB":
+        Gvec = np.full(p, Gval, dtype=np.float32)                       # MCMC_BayesianAlphabet.jl:67-69
+    if t == 1 and method in ("BayesC", "BayesB") and np.ndim(pi) == 0:
+        pi = float(pi)
+    if t > 1:
+        lhs_blocks = [[Xf[k].T @ Xf[l] for l in range(t)] for k in range(t)]
+    else:
+        lhs = Xf[0].T @ Xf[0]
+
+    # ---- accumulators and sample files (output.jl:320-437)
+    run_sol, run_vare = _Running(sol), _Running(vare)
+    run_varg = _Running(Gval) if method != "BayesB" else None
+    run_pi = _Running(np.atleast_1d(np.asarray(pi, dtype=np.float64))) if Mi.estimatePi else None
+    ebv_run = [_Running(np.zeros(n)) for _ in range(t)] if outputEBV else None
+    name = Mi.name
+    files = {}
+
+    def _open(key, header):
+        fh = open(os.path.join(output_folder, f"MCMC_samples_{key}.txt"), "w")
+        fh.write(",".join(header) + "\n")
+        files[key] = fh
+
+    rnames = [f"{a}_{b}" for a in model.lhsVec for b in model.lhsVec]
+    _open("residual_variance", rnames if t > 1 else [model.lhsVec[0]])
+    if method != "BayesB":
+        _open(f"marker_effects_variances_{name}", rnames if t > 1 else ["1"])
+    if Mi.estimatePi:
+        _open(f"pi_{name}", [f"pi{i + 1}" for i in range(np.size(pi))] if np.size(pi) > 1 else ["pi"])
+    write_marker_samples = output_samples_for_all_parameters or p <= 20000
+    if write_marker_samples:
+        for k, tr in enumerate(model.lhsVec):
+            _open(f"marker_effects_{name}_{tr}", Mi.markerID)
+
+    t_sweep = 0.0
+    t0 = time.time()
+    # ================================ the chain =================================================
+    for it in range(1, chain_length + 1):
+        # 1. location parameters (host)
+        if sum(q):
+            if t == 1:
+                r = engine.get_residual(0).astype(np.float64)
+                r += Xf[0] @ sol
+                rhs = Xf[0].T @ r
+                _gibbs(lhs, sol, rhs, rng, float(vare))
+                r -= Xf[0] @ sol
+                engine.set_residual(r.astype(np.float32), 0)
+            else:
+                Rinv = np.linalg.inv(np.asarray(vare, dtype=np.float64))
+                rr = [engine.get_residual(k).astype(np.float64) + Xf[k] @ sol[off[k]:off[k + 1]] for k in range(t)]
+                A = np.block([[Rinv[k, l] * lhs_blocks[k][l] for l in range(t)] for k in range(t)])
+                b = np.concatenate([Xf[k].T @ sum(Rinv[k, l] * rr[l] for l in range(t)) for k in range(t)])
+                _gibbs(A, sol, b, rng, None)
+                for k in range(t):
+                    engine.set_residual((rr[k] - Xf[k] @ sol[off[k]:off[k + 1]]).astype(np.float32), k)
+
+        # 2. marker effects (DEVICE)
+        kw = dict(iteration=it, seed=seed_int, vare=vare, nreps=nreps)
+        if t > 1:
+            with np.errstate(divide="ignore"):
+                kw.update(var_effect=Gval, log_prior_states=np.log(np.asarray(pi, dtype=np.float64)))
+        elif method == "BayesR":
+            kw.update(var_effect=Gval, pi_classes=np.asarray(pi, dtype=np.float64))
+            if fast_blocks is not False:                                # bayesr_block_nreps (BayesR.jl:22-25)
+                kw["nreps"] = 1 if it <= burnin else 0
+        elif method == "BayesB":
+            kw.update(var_effect=Gval, var_effect_vec=Gvec, pi=pi)
+        else:
+            kw.update(var_effect=Gval, pi=pi)
+        st = engine.sweep(**kw)
+        t_sweep += st["sweep_ms"]
+
+        # 3. pi (Pi.jl:7-42)
+        if Mi.estimatePi:
+            if t > 1:
+                pi = rng.dirichlet(st["state_counts"] + 1.0)
+            elif method == "BayesR":
+                pi = rng.dirichlet(st["class_counts"] + 1.0)
+            else:
+                pi = float(rng.beta(p - st["sum_delta"][0] + 1.0, st["sum_delta"][0] + 1.0))
+
+        # 4. marker effect variance (variance_components.jl:151-189), re-cast to Float32 (:323-325)
+        if Mi.G.estimate_variance:
+            if t > 1:
+                from scipy.stats import invwishart
+                S = np.asarray(Mi.G.scale, dtype=np.float64) + st["beta_ss"]
+                Gval = np.asarray(invwishart.rvs(df=Gdf + p, scale=(S + S.T) / 2, random_state=rng), dtype=np.float32).reshape(t, t)
+            elif method == "BayesR":
+                Gval = np.float32((st["bayesr_ssq"] + Gdf * Mi.G.scale) / rng.chisquare(st["bayesr_nnz"] + Gdf))
+            elif method == "BayesB":
+                beta = engine.get_state(0)[1].astype(np.float64)
+                Gvec = ((beta * beta + Gdf * Mi.G.scale) / rng.chisquare(1.0 + Gdf, size=p)).astype(np.float32)
+            else:
+                Gval = np.float32((np.float32(st["alpha_ss"][0, 0]) + Gdf * Mi.G.scale) / rng.chisquare(st["sum_delta"][0] + Gdf))
+
+        # 5. residual variance (variance_components.jl:60-66,82-112), re-cast to Float32 (:368-370)
+        if R.estimate_variance:
+            if t > 1:
+                from scipy.stats import invwishart
+                S = np.asarray(R.scale, dtype=np.float64) + st["resid_ss"]
+                vare = np.asarray(invwishart.rvs(df=float(R.df) + n, scale=(S + S.T) / 2, random_state=rng), dtype=np.float32).reshape(t, t)
+            else:
+                vare = np.float32((np.float32(st["resid_ss"][0, 0]) + float(R.df) * R.scale) / rng.chisquare(n + float(R.df)))
+
+        # 6. save (MCMC_BayesianAlphabet.jl:399-413, output.jl:443-604)
+        if it > burnin and (it - burnin) % output_samples_frequency == 0:
+            k = (it - burnin) / output_samples_frequency
+            run_sol.add(sol, k)
+            run_vare.add(vare, k)
+            if run_varg is not None:
+                run_varg.add(Gval, k)
+            if run_pi is not None:
+                run_pi.add(np.atleast_1d(pi), k)
+            engine.accumulate(k)
+            files["residual_variance"].write(",".join(repr(float(v)) for v in np.atleast_1d(vare).ravel()) + "\n")
+            if method != "BayesB":
+                files[f"marker_effects_variances_{name}"].write(",".join(repr(float(v)) for v in np.atleast_1d(Gval).ravel()) + "\n")
+            if Mi.estimatePi:
+                files[f"pi_{name}"].write(",".join(repr(float(v)) for v in np.atleast_1d(pi)) + "\n")
+            if write_marker_samples:
+                for kk, tr in enumerate(model.lhsVec):
+                    a = engine.get_state(kk)[0]
+                    files[f"marker_effects_{name}_{tr}"].write(",".join(repr(float(v)) for v in a) + "\n")
+            if outputEBV:
+                for kk in range(t):
+                    ebv_run[kk].add(engine.mul_alpha(kk), k)
+        if it % printout_frequency == 0 and it > burnin:
+            print(f"\nPosterior means at iteration: {it}")
+            print(f"Residual variance: {np.round(run_vare.mean, 6)}")
+    wall = time.time() - t0
+    for fh in files.values():
+        fh.close()
+
+    # ---- results (output.jl:108-212)
+    out = {}
+    rows_lp = []
+    for k in range(t):
+        for i, (tr, eff, lev) in enumerate(labels[k]):
+            rows_lp.append((tr, eff, lev, run_sol.mean[off[k] + i], run_sol.sd()[off[k] + i]))
+    out["location parameters"] = pd.DataFrame(rows_lp, columns=["Trait", "Effect", "Level", "Estimate", "SD"])
+    cov = rnames if t > 1 else [model.lhsVec[0]]
+    out["residual variance"] = pd.DataFrame({"Covariance": cov, "Estimate": np.atleast_1d(run_vare.mean).ravel(),
+                                             "SD": np.atleast_1d(run_vare.sd()).ravel()})
+    frames = []
+    for k, tr in enumerate(model.lhsVec):
+        ma, ma2, md = engine.posterior(k)
+        sd = np.sqrt(np.abs(ma2.astype(np.float64) - ma.astype(np.float64) ** 2))
+        frames.append(pd.DataFrame({"Trait": tr, "Marker_ID": Mi.markerID, "Estimate": ma, "SD": sd, "Model_Frequency": md}))
+    out[f"marker effects {name}"] = pd.concat(frames, ignore_index=True)
+    if run_varg is not None:
+        out[f"marker effects variance {name}"] = pd.DataFrame({"Covariance": cov, "Estimate": np.atleast_1d(run_varg.mean).ravel(),
+                                                               "SD": np.atleast_1d(run_varg.sd()).ravel()})
+    if run_pi is not None:
+        if t > 1:
+            lab = ["".join(str((s >> k) & 1) for k in range(t)) for s in range(1 << t)]
+        elif method == "BayesR":
+            lab = ["class1", "class2", "class3", "class4"]
+        else:
+            lab = ["π"]
+        out[f"pi_{name}"] = pd.DataFrame({"π": lab, "Estimate": run_pi.mean, "SD": run_pi.sd()})
+    if outputEBV:
+        for k, tr in enumerate(model.lhsVec):
+            m = ebv_run[k].mean
+            out[f"EBV_{tr}"] = pd.DataFrame({"ID": list(ph[idcol]), "EBV": m, "PEV": np.abs(ebv_run[k].mean2 - m ** 2)})
+    for key, tab in out.items():                                         # JWAS.jl:480-482
+        tab.to_csv(os.path.join(output_folder, key.replace(" ", "_") + ".txt"), index=False)
+    out["_timing"] = {"wall_s": wall, "device_sweep_ms_total": t_sweep, "iterations": chain_length,
+                      "block_size": block_size, "n": n, "p": p}
+    if own_engine:
+        engine.close()
+    return out

@@ -1,0 +1,190 @@
+"""Host logic of the chain (get_genotypes / build_model / runMCMC) on CPU, driven through the
+engine-injection point with the oracle engine (tests/oracle_engine.py)."""
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from conftest import make_dataset
+from oracle_engine import OracleEngine
+from jwas_jl_amd import api
+from jwas_jl_amd.mcmc import genetic2marker
+
+
+def _six_animals(with_missing=False):
+    """The 6 x 4 table of test/unit/test_streaming_codec.jl:6-16."""
+    rows = [[0, 1, 2, 0], [1, 0, 1, 2], [2, 9 if with_missing else 1, 0, 1], [0, 2, 1, 0], [1, 1, 2, 2], [2, 0, 0, 1]]
+    ids = ["a1", "a2", "a3", "a4", "a5", "a6"]
+    df = pd.DataFrame(rows, columns=["m1", "m2", "m3", "m4"], dtype=np.float64)
+    df.insert(0, "ID", ids)
+    ph = pd.DataFrame({"ID": ids, "y1": np.array([1.1, -0.3, 0.8, -0.9, 0.5, -0.1], dtype=np.float32)})
+    return df, ph
+
+
+def test_get_genotypes_qc_center_and_missing():
+    df, _ = _six_animals(with_missing=True)
+    g = api.get_genotypes(df, 1.0, method="BayesC", quality_control=True, center=True)
+    assert g.nObs == 6 and g.nMarkers == 4 and g.markerID == ["m1", "m2", "m3", "m4"]
+    assert g.genotypes.dtype == np.float32 and g.genotypes.flags.f_contiguous
+    np.testing.assert_allclose(g.genotypes.mean(axis=0), 0, atol=1e-6)
+    # missing (9) -> column mean of the non-missing, i.e. 0 after centring (readgenotypes.jl:372-384)
+    assert abs(g.genotypes[2, 1]) < 1e-6
+    raw = np.array([1, 0, 2, 1, 0], dtype=np.float64)
+    np.testing.assert_allclose(g.alleleFreq[1], raw.mean() / 2, atol=1e-6)
+    assert g.sum2pq == pytest.approx(float((2 * g.alleleFreq * (1 - g.alleleFreq)).sum()), rel=1e-5)
+
+
+def test_get_genotypes_maf_filter_and_errors(tmp_path):
+    X = np.array([[0, 1, 2], [0, 1, 0], [0, 2, 1], [0, 0, 2]], dtype=np.float64)     # first locus fixed
+    g = api.get_genotypes(X, 1.0)
+    assert g.nMarkers == 2 and g.markerID == ["2", "3"]
+    with pytest.raises(ValueError, match="storage must be"):
+        api.get_genotypes(X, 1.0, storage="disk")
+    with pytest.raises(NotImplementedError, match="Float32"):
+        api.get_genotypes(X, 1.0, double_precision=True)
+    with pytest.raises(NotImplementedError, match="GBLUP"):
+        api.get_genotypes(X, 1.0, method="GBLUP")
+    with pytest.raises(ValueError, match="starting values"):
+        api.get_genotypes(X, 1.0, quality_control=False, starting_value=np.zeros(5))
+    f = tmp_path / "g.csv"
+    f.write_text("ID,m1,m2\na,0,1\nb,1,2\nc,2,0\n")
+    gf = api.get_genotypes(str(f), 1.0, quality_control=False)
+    assert gf.obsID == ["a", "b", "c"] and gf.markerID == ["m1", "m2"]
+
+
+def test_genetic2marker_formulas():
+    """test/unit/test_annotated_bayesc.jl:452-471: G = Vg / ((1-pi) * sum2pq) (+ BayesR / vector / MT forms)."""
+    df = pd.DataFrame({"ID": ["a1", "a2", "a3"], "m1": [0.0, 1.0, 2.0], "m2": [1.0, 1.0, 0.0], "m3": [2.0, 1.0, 1.0]})
+    g = api.get_genotypes(df, 2.5, method="BayesC", Pi=0.3, quality_control=False)
+    assert genetic2marker(g, 0.3, "BayesC") == pytest.approx(2.5 / ((1 - 0.3) * g.sum2pq), rel=1e-6)
+    pi4 = np.array([0.95, 0.03, 0.015, 0.005])
+    assert genetic2marker(g, pi4, "BayesR") == pytest.approx(2.5 / (g.sum2pq * (0.03 * 0.01 + 0.015 * 0.1 + 0.005)), rel=1e-6)
+    piv = np.array([0.2, 0.5, 0.9])
+    af = g.alleleFreq.astype(np.float64)
+    assert genetic2marker(g, piv, "BayesC") == pytest.approx(2.5 / float((2 * af * (1 - af) * (1 - piv)).sum()), rel=1e-6)
+    with pytest.raises(ValueError, match="length 4"):
+        genetic2marker(g, np.array([0.5, 0.5]), "BayesR")
+    with pytest.raises(ValueError, match="must have length 3"):
+        genetic2marker(g, np.array([0.5, 0.5]), "BayesC")
+
+
+def _run(form, ph, geno_df, tmp, **kw):
+    geno = api.get_genotypes(geno_df, 1.0, method=kw.pop("method", "BayesC"), quality_control=False, center=True,
+                             Pi=kw.pop("Pi", 0.0), estimatePi=kw.pop("estimatePi", True))
+    model = api.build_model("y1 = intercept + geno", 1.0)
+    return api.runMCMC(model, ph, chain_length=40, burnin=10, output_samples_frequency=10, seed=2026,
+                       output_folder=os.path.join(tmp, f"res_{form}"), outputEBV=False,
+                       engine=OracleEngine(form), block_size=64, **kw)
+
+
+def test_runmcmc_dense_vs_block_same_seed(tmp_path):
+    """Shape of test/unit/test_streaming_codec.jl:53-105 ("same draws, different storage"): two
+    algebraically identical device forms agree on posterior means to 1e-4 on the 6-animal table."""
+    geno_df, ph = _six_animals()
+    out_d = _run("dense", ph, geno_df, str(tmp_path))
+    out_b = _run("block", ph, geno_df, str(tmp_path))
+    ed = out_d["marker effects geno"]["Estimate"].to_numpy(dtype=np.float64)
+    eb = out_b["marker effects geno"]["Estimate"].to_numpy(dtype=np.float64)
+    assert len(ed) == 4
+    np.testing.assert_allclose(eb, ed, atol=1e-4)
+    assert float(out_b["residual variance"]["Estimate"][0]) == pytest.approx(float(out_d["residual variance"]["Estimate"][0]), abs=1e-4)
+
+
+def test_runmcmc_same_seed_is_deterministic(tmp_path):
+    """test/runtests.jl:302-320: same seed => identical residual-variance estimate."""
+    geno_df, ph = _six_animals()
+    a = _run("block", ph, geno_df, str(tmp_path / "a"))
+    b = _run("block", ph, geno_df, str(tmp_path / "b"))
+    assert a["residual variance"]["Estimate"][0] == b["residual variance"]["Estimate"][0]
+    assert np.array_equal(a["marker effects geno"]["Estimate"], b["marker effects geno"]["Estimate"])
+
+
+@pytest.mark.parametrize("method,Pi", [("BayesC", 0.95), ("BayesB", 0.95), ("BayesA", 0.0), ("BayesR", 0.0)])
+def test_runmcmc_recovers_signal_and_writes_outputs(tmp_path, method, Pi):
+    d = make_dataset(n=300, p=400, ncausal=5, seed=21, center=False)
+    ids = [f"id{i}" for i in range(300)]
+    gdf = pd.DataFrame(d["raw"], columns=[f"snp{j}" for j in range(400)])
+    gdf.insert(0, "ID", ids)
+    ph = pd.DataFrame({"ID": ids[::-1], "y1": d["y"][::-1]})                 # phenotype order differs from genotype order
+    geno = api.get_genotypes(gdf, method=method, Pi=Pi)
+    model = api.build_model("y1 = intercept + geno")
+    folder = str(tmp_path / "out")
+    out = api.runMCMC(model, ph, chain_length=150, burnin=30, seed=7, output_folder=folder,
+                      engine=OracleEngine("block"), block_size=64)
+    me = out["marker effects geno"]
+    assert list(me.columns) == ["Trait", "Marker_ID", "Estimate", "SD", "Model_Frequency"]
+    assert len(me) == geno.nMarkers
+    causal_ids = {f"snp{j}" for j in d["causal"]}
+    top = set(me.reindex(me["Estimate"].abs().sort_values(ascending=False).index)["Marker_ID"].head(8))
+    assert len(top & causal_ids) >= 3
+    ebv = out["EBV_y1"]
+    assert list(ebv.columns) == ["ID", "EBV", "PEV"] and list(ebv["ID"]) == ids[::-1]
+    assert np.corrcoef(ebv["EBV"], ph["y1"])[0, 1] > 0.5
+    assert 0 < float(out["residual variance"]["Estimate"][0]) < 2 * float(np.var(d["y"]))
+    for f in ("marker_effects_geno.txt", "residual_variance.txt", "location_parameters.txt", "EBV_y1.txt",
+              "MCMC_samples_residual_variance.txt", "MCMC_samples_marker_effects_geno_y1.txt",
+              "IDs_for_individuals_with_genotypes.txt", "IDs_for_individuals_with_phenotypes.txt"):
+        assert os.path.exists(os.path.join(folder, f)), f
+    if method in ("BayesC", "BayesB", "BayesR"):
+        assert "pi_geno" in out
+    # an existing folder is never overwritten (JWAS.jl:255-262)
+    geno2 = api.get_genotypes(gdf, method=method, Pi=Pi)
+    model2 = api.build_model("y1 = intercept + geno2", genotypes={"geno2": geno2})
+    api.runMCMC(model2, ph, chain_length=2, seed=7, output_folder=folder, engine=OracleEngine("block"), block_size=64)
+    assert os.path.isdir(folder + "1")
+
+
+def test_runmcmc_multitrait_and_fixed_effects(tmp_path):
+    d = make_dataset(n=250, p=192, ncausal=4, seed=5, center=False)
+    rng = np.random.default_rng(1)
+    ids = [str(i) for i in range(250)]
+    x1 = rng.standard_normal(250)
+    sex = np.where(rng.random(250) < 0.5, "m", "f")
+    y1 = d["y"] + 0.8 * x1 + np.where(sex == "m", 0.5, 0.0)
+    y2 = 0.6 * d["y"] + rng.standard_normal(250) * 0.5
+    ph = pd.DataFrame({"ID": ids, "y1": y1.astype(np.float32), "y2": y2.astype(np.float32), "x1": x1, "sex": sex})
+    gdf = pd.DataFrame(d["raw"], columns=[f"s{j}" for j in range(192)])
+    gdf.insert(0, "ID", ids)
+    geno = api.get_genotypes(gdf, method="BayesC", Pi=0.0, estimatePi=True)
+    model = api.build_model("y1 = intercept + x1 + sex + geno\ny2 = intercept + geno")
+    api.set_covariate(model, "x1")
+    out = api.runMCMC(model, ph, chain_length=60, burnin=10, seed=3, output_folder=str(tmp_path / "mt"),
+                      engine=OracleEngine("block"), block_size=64)
+    lp = out["location parameters"]
+    assert set(lp["Trait"]) == {"y1", "y2"} and {"intercept", "x1", "sex"} <= set(lp["Effect"])
+    assert float(lp[(lp.Trait == "y1") & (lp.Effect == "x1")]["Estimate"].iloc[0]) == pytest.approx(0.8, abs=0.25)
+    assert len(out["marker effects geno"]) == 2 * geno.nMarkers
+    assert out["residual variance"].shape[0] == 4 and out["pi_geno"].shape[0] == 4
+    assert "EBV_y1" in out and "EBV_y2" in out
+
+
+def test_runmcmc_contract_errors(tmp_path):
+    geno_df, ph = _six_animals()
+    geno = api.get_genotypes(geno_df, 1.0, quality_control=False)
+    model = api.build_model("y1 = intercept + geno", 1.0)
+    with pytest.raises(ValueError, match="independent_blocks=true requires fast_blocks"):
+        api.runMCMC(model, ph, independent_blocks=True, output_folder=str(tmp_path / "e1"))     # JWAS.jl:242-244
+    with pytest.raises(NotImplementedError, match="single_step_analysis"):
+        api.runMCMC(model, ph, single_step_analysis=True, output_folder=str(tmp_path / "e2"))
+    with pytest.raises(ValueError, match="at least two block starts"):
+        api.runMCMC(model, ph, fast_blocks=True, output_folder=str(tmp_path / "e3"), engine=OracleEngine("block"))
+    with pytest.raises(ValueError, match="Model equations are wrong"):
+        api.build_model("")
+    nog = api.build_model("y1 = intercept")
+    with pytest.raises(NotImplementedError, match="genotype term"):
+        api.runMCMC(nog, ph, output_folder=str(tmp_path / "e4"))
+
+
+def test_fast_blocks_rescales_chain_length(tmp_path):
+    """JWAS.jl:293-316: a numeric fast_blocks divides chain_length by the block size and runs
+    block-size within-block repetitions; burnin is not rescaled."""
+    d = make_dataset(n=200, p=200, ncausal=3, seed=9, center=False)
+    ids = [str(i) for i in range(200)]
+    gdf = pd.DataFrame(d["raw"]); gdf.insert(0, "ID", ids)
+    ph = pd.DataFrame({"ID": ids, "y1": d["y"]})
+    geno = api.get_genotypes(gdf, method="BayesC", Pi=0.9)
+    model = api.build_model("y1 = intercept + geno")
+    out = api.runMCMC(model, ph, chain_length=640, burnin=2, fast_blocks=64, seed=1, outputEBV=False,
+                      output_folder=str(tmp_path / "fb"), engine=OracleEngine("block"))
+    assert out["_timing"]["iterations"] == 10 and out["_timing"]["block_size"] == 64

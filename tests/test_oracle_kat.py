@@ -1,0 +1,275 @@
+"""CPU tests that PIN THE ORACLE against everything the reference's own tests hold for this path
+(SURVEY.md section 8c): closed-form / deterministic items only -- the reference ships no golden
+vectors for sampler output, so output values on a seed stay "parity unpinned" (oracle header).
+Each test cites the reference test it restates.
+"""
+import numpy as np
+import pytest
+
+import oracle as O
+from conftest import make_dataset
+
+
+# ---- RNG: Philox4x32-10 known-answer vectors (Random123 kat_vectors) -----------------------------
+@pytest.mark.parametrize("ctr,key,exp", [
+    ([0, 0, 0, 0], [0, 0], [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+    ([0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+    ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0],
+     [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]),
+])
+def test_philox_known_answers(ctr, key, exp):
+    assert O.philox(ctr, key).tolist() == exp
+
+
+def test_rng_moments_and_ranges():
+    u = np.array([O.uniform(7, m, 1) for m in range(50000)])
+    z = np.array([O.normal(7, m, 1) for m in range(50000)])
+    assert 0.0 < u.min() and u.max() < 1.0
+    assert abs(u.mean() - 0.5) < 0.01 and abs(u.var() * 12 - 1) < 0.03
+    assert abs(z.mean()) < 0.02 and abs(z.std() - 1) < 0.02
+    assert abs(np.corrcoef(u, z)[0, 1]) < 0.02
+    # draws are keyed by (marker, iteration, rep, trait): changing any of them changes the draw
+    base = O.uniform(1, 5, 3, 0, 0)
+    assert len({base, O.uniform(2, 5, 3), O.uniform(1, 6, 3), O.uniform(1, 5, 4), O.uniform(1, 5, 3, 1), O.uniform(1, 5, 3, 0, 1)}) == 6
+
+
+# ---- test/unit/test_bayesr.jl:244-250 ------------------------------------------------------------
+def test_bayesr_block_nreps_schedule():
+    assert O.bayesr_block_nreps(1, 10, 7) == 1
+    assert O.bayesr_block_nreps(10, 10, 7) == 1
+    assert O.bayesr_block_nreps(11, 10, 7) == 7
+    assert O.bayesr_block_nreps(25, 0, 7) == 7
+    assert O.bayesr_block_nreps(3, 8, 1) == 1
+    with pytest.raises(ValueError):
+        O.bayesr_block_nreps(1, 0, 0)
+
+
+# ---- test/unit/test_bayesr.jl:252-262 ------------------------------------------------------------
+def test_bayesr_sigma_sufficient_statistics():
+    alpha = np.array([0.0, 0.4, -0.3, 0.1, 0.0])
+    delta = np.array([1, 2, 4, 3, 1])
+    gamma = np.array([0.0, 0.01, 0.1, 1.0])
+    ssq, nnz = O.bayesr_sigma_suffstats(alpha, delta, gamma)
+    a32 = alpha.astype(np.float32).astype(np.float64)
+    expected = a32[1] ** 2 / gamma[1] + a32[2] ** 2 / gamma[3] + a32[3] ** 2 / gamma[2]
+    assert ssq == pytest.approx(expected, rel=1e-12)
+    assert nnz == 3
+    # test_bayesr.jl:264-280: sigma2 = (ssq + df*scale) / chisq(nnz + df) is the host formula
+    chi = 5.3
+    assert (ssq + 4.0 * 0.2) / chi == pytest.approx((expected + 0.8) / chi)
+
+
+# ---- test/unit/test_bayesr.jl:202-242: dense and block BayesR kernels on the 4x2 toy ---------------
+def _toy():
+    X = np.asfortranarray(np.array([[0, 2], [1, 1], [2, 0], [1, 1]], dtype=np.float32))
+    return X, O.xpx(X), np.array([0.8, -0.1, 0.3, 0.5], dtype=np.float32)
+
+
+@pytest.mark.parametrize("block", [False, True])
+def test_bayesr_toy_classes_in_range(block):
+    X, xpx, y = _toy()
+    alpha, delta = np.zeros(2, dtype=np.float32), np.ones(2, dtype=np.int32)
+    kw = dict(block_starts=np.array([0]), grams=O.gram(X, 0, 2).ravel(), nreps=0) if block else {}
+    O.bayesr_sweep(X, xpx, y.copy(), alpha, delta, 1.0, 0.2, [0.95, 0.03, 0.015, 0.005], 1234, 1, **kw)
+    assert np.all((1 <= delta) & (delta <= 4)) and alpha.shape == (2,)
+
+
+# ---- test/unit/test_annotated_bayesr.jl:247-266: degenerate per-SNP priors, RNG independent -------
+@pytest.mark.parametrize("seed", [1, 20260327, 99])
+def test_bayesr_degenerate_priors_force_classes(seed):
+    X, xpx, y = _toy()
+    alpha, delta = np.zeros(2, dtype=np.float32), np.ones(2, dtype=np.int32)
+    snp_pi = np.array([[0.0, 1.0, 0.0, 0.0], [1.0, 0.0, 0.0, 0.0]])
+    O.bayesr_sweep(X, xpx, y.copy(), alpha, delta, 1.0, 0.2, snp_pi, seed, 1)
+    assert delta.tolist() == [2, 1]
+    assert alpha[0] != 0 and alpha[1] == 0
+
+
+# ---- BayesR.jl:9-20,50 error contract ---------------------------------------------------------------
+def test_bayesr_prior_validation_errors():
+    X, xpx, y = _toy()
+    a, d = np.zeros(2, dtype=np.float32), np.ones(2, dtype=np.int32)
+    with pytest.raises(ValueError, match="mixture classes"):
+        O.bayesr_sweep(X, xpx, y.copy(), a, d, 1.0, 0.2, [0.5, 0.5], 1, 1)
+    with pytest.raises(ValueError, match="sum to 1"):
+        O.bayesr_sweep(X, xpx, y.copy(), a, d, 1.0, 0.2, [0.5, 0.1, 0.1, 0.1], 1, 1)
+    with pytest.raises(ValueError, match="one row per marker"):
+        O.bayesr_sweep(X, xpx, y.copy(), a, d, 1.0, 0.2, np.full((3, 4), 0.25), 1, 1)
+    with pytest.raises(ValueError, match="sigmaSq"):
+        O.bayesr_sweep(X, xpx, y.copy(), a, d, 1.0, 0.0, [0.95, 0.03, 0.015, 0.005], 1, 1)
+
+
+# ---- test/unit/test_annotated_bayesc.jl:473-490 ------------------------------------------------------
+def test_bayesabc_rejects_mismatched_pi_vector():
+    X = np.asfortranarray(np.eye(2, dtype=np.float32))
+    z = np.zeros(2, dtype=np.float32)
+    with pytest.raises(ValueError, match=r"pi vector length 1 must match the number of markers \(2\)"):
+        O.bayesabc_sweep(X, np.ones(2, dtype=np.float32), np.array([0.2, -0.1], dtype=np.float32), z.copy(), z.copy(),
+                         np.ones(2, dtype=np.float32), 1.0, np.ones(2), np.array([0.5]), 1, 1)
+
+
+# ---- A.1 edge cases: pi = 0 includes everything, pi = 1 nothing -----------
+def test_bayesc_pi_edge_cases(small_data):
+    X, y = small_data["X"], small_data["y"]
+    xpx = O.xpx(X)
+    for pi, expect in ((0.0, X.shape[1]), (1.0, 0)):
+        a = np.zeros(X.shape[1], dtype=np.float32)
+        b, d = a.copy(), a.copy()
+        O.bayesabc_sweep(X, xpx, (y - y.mean()).copy(), a, b, d, 0.5, 0.002, pi, 3, 1)
+        assert int(d.sum()) == expect
+        assert (a != 0).sum() == expect
+        assert np.all(b != 0)          # a normal is drawn for beta even when excluded (BayesABC.jl:54)
+
+
+# ---- the block form with one pass is the non-block chain (benchmarks/reports/2026-03-20-...:38-52) ----
+@pytest.mark.parametrize("bs", [64, 256])
+def test_block_one_pass_equals_dense_chain(small_data, bs):
+    X, y = small_data["X"], small_data["y"]
+    xpx = O.xpx(X)
+    p = X.shape[1]
+    bstarts = O.block_starts_for(p, bs)
+    grams = O.grams_for(X, bstarts)
+    out = []
+    for blk in (False, True):
+        r = (y - y.mean()).copy()
+        a, b, d = (np.zeros(p, dtype=np.float32) for _ in range(3))
+        kw = dict(block_starts=bstarts, grams=grams, nreps=1) if blk else {}
+        for it in range(1, 31):
+            O.bayesabc_sweep(X, xpx, r, a, b, d, 0.5, 0.004, 0.9, 2026, it, **kw)
+        out.append((a, d, r))
+    assert np.array_equal(out[0][1], out[1][1])
+    assert np.abs(out[0][0] - out[1][0]).max() < 5e-6          # the reference saw 5e-8 mean |alpha| drift
+    assert np.abs(out[0][2] - out[1][2]).max() < 5e-5
+
+
+def test_f32_and_f64_accumulation_agree_within_fp32_noise(small_data):
+    X, y = small_data["X"], small_data["y"]
+    p = X.shape[1]
+    res = []
+    for acc in (O.ACC_F64, O.ACC_F32):
+        xpx = O.xpx(X, acc)
+        r = (y - y.mean()).copy()
+        a, b, d = (np.zeros(p, dtype=np.float32) for _ in range(3))
+        O.bayesabc_sweep(X, xpx, r, a, b, d, 0.5, 0.004, 0.9, 5, 1, acc=acc)
+        res.append((a, d))
+    assert (res[0][1] != res[1][1]).sum() <= 1
+    m = res[0][1] == res[1][1]
+    assert np.abs(res[0][0][m] - res[1][0][m]).max() < 1e-4
+
+
+# ---- test/unit/test_multitrait_mcmc.jl:6-31,557-642: one-marker 2-trait closed-form posterior --------
+def _exact_mt_state_probs(x, ys, vare, var_effect, prior):
+    xp = float(x @ x)
+    Rinv, Ginv = np.linalg.inv(vare), np.linalg.inv(var_effect)
+    w = np.array([x @ y for y in ys])
+    logd = np.zeros(4)
+    for s in range(4):
+        D = np.diag([(s >> 0) & 1, (s >> 1) & 1]).astype(float)
+        lhs = D @ Rinv @ D * xp + Ginv
+        rhs = (Rinv @ D).T @ w
+        ghat = np.linalg.solve(lhs, rhs)
+        logd[s] = -0.5 * (np.log(np.linalg.det(lhs)) - rhs @ ghat) + np.log(prior[s])
+    pr = np.exp(logd - logd.max())
+    return pr / pr.sum()
+
+
+@pytest.mark.parametrize("block", [False, True])
+def test_mt_sampler1_matches_closed_form_state_posterior(block):
+    x = np.array([1.0, -0.5, 0.75])
+    ys = [np.array([0.8, -0.1, 0.3]), np.array([0.2, 0.6, -0.4])]
+    vare = np.array([[1.0, 0.25], [0.25, 0.9]])
+    var_effect = np.array([[0.7, 0.15], [0.15, 0.8]])
+    # states indexed delta_1 + 2*delta_2: 00, 10, 01, 11 (annotated_bayesc_mt_state_keys order)
+    prior = np.array([0.35, 0.20, 0.15, 0.30])
+    exact = _exact_mt_state_probs(x, ys, vare, var_effect, prior)
+    X = np.asfortranarray(x.astype(np.float32)[:, None])
+    xpx = O.xpx(X)
+    r = np.ascontiguousarray(np.stack(ys).astype(np.float32))
+    a, b, d = (np.zeros((2, 1), dtype=np.float32) for _ in range(3))
+    kw = dict(block_starts=np.array([0]), grams=O.gram(X, 0, 1).ravel(), nreps=1) if block else {}
+    counts = np.zeros(4)
+    niter, burn = 20000, 3000
+    for it in range(1, niter + 1):
+        O.mtbayesc_I_sweep(X, xpx, r, a, b, d, vare, var_effect, np.log(prior), 20260411, it, **kw)
+        if it > burn:
+            counts[int(d[0, 0]) + 2 * int(d[1, 0])] += 1
+    emp = counts / counts.sum()
+    assert np.abs(emp - exact).max() < 0.02
+
+
+# ---- test/unit/test_streaming_codec.jl:21-51, test_streaming_prepare_lowmem.jl:22-49: 2-bit codec ------
+def _pack_2bit(raw, missing=9):
+    """Marker-major packing of streaming_genotypes.jl:364-367,622-627 (test-side restatement)."""
+    n, p = raw.shape
+    stride = (n + 3) // 4
+    out = np.zeros(p * stride, dtype=np.uint8)
+    for j in range(p):
+        for i in range(n):
+            code = 3 if raw[i, j] == missing else int(raw[i, j])
+            out[j * stride + (i >> 2)] |= code << ((i & 3) << 1)
+    return out
+
+
+@pytest.mark.parametrize("with_missing", [True, False])
+def test_2bit_decode_matches_dense_centered_imputed(with_missing):
+    raw = np.array([[0, 1, 2, 0], [1, 0, 1, 2], [2, 9 if with_missing else 1, 0, 1], [0, 2, 1, 0], [1, 1, 2, 2], [2, 0, 0, 1]], dtype=np.float64)
+    n, p = raw.shape
+    payload = _pack_2bit(raw)
+    assert payload.size == p * ((n + 3) // 4)
+    for j in range(p):
+        col = raw[:, j]
+        nonmiss = col != 9
+        mu = np.float32(col[nonmiss].sum() / nonmiss.sum())
+        dense = np.where(nonmiss, col, mu).astype(np.float32) - mu            # readgenotypes.jl:372-384
+        dec = O.decode_marker_2bit(payload, n, j, mu, centered=True)
+        np.testing.assert_allclose(dec, dense, atol=1e-5)
+        # xpRinvx sidecar formula (streaming_genotypes.jl:283-285): sum v^2 - mu * sum v over non-missing
+        ss = float((col[nonmiss] ** 2).sum() - mu * col[nonmiss].sum())
+        assert float(dec @ dec) == pytest.approx(ss, abs=1e-5)
+        raw_dec = O.decode_marker_2bit(payload, n, j, mu, centered=False)
+        np.testing.assert_allclose(raw_dec, np.where(nonmiss, col, mu), atol=1e-6)
+
+
+# ---- output.jl:568-577 running means ---------------------------------------------------------------
+def test_running_posterior_means_match_direct_moments():
+    rng = np.random.default_rng(0)
+    p, K = 50, 7
+    ma, ma2, md = (np.zeros(p, dtype=np.float32) for _ in range(3))
+    A = rng.standard_normal((K, p)).astype(np.float32)
+    D = (rng.random((K, p)) < 0.4).astype(np.float32)
+    for k in range(K):
+        O.accumulate(A[k], D[k], k + 1, ma, ma2, md)
+    np.testing.assert_allclose(ma, A.mean(axis=0), atol=1e-6)
+    np.testing.assert_allclose(ma2, (A.astype(np.float64) ** 2).mean(axis=0), atol=1e-5)
+    np.testing.assert_allclose(md, D.mean(axis=0), atol=1e-6)
+    # BayesR: model frequency is the running mean of delta > 1 (output.jl:572-574)
+    cls = rng.integers(1, 5, size=(K, p)).astype(np.int32)
+    md[:] = 0; ma[:] = 0; ma2[:] = 0
+    for k in range(K):
+        O.accumulate(A[k], cls[k], k + 1, ma, ma2, md)
+    np.testing.assert_allclose(md, (cls > 1).mean(axis=0), atol=1e-6)
+
+
+# ---- test/unit/test_misc_coverage.jl:211-227: orthogonal blocks make the independent-block mode exact --
+def test_orthogonal_shards_reconcile_exactly():
+    d1 = make_dataset(n=120, p=64, ncausal=3, seed=1)
+    d2 = make_dataset(n=130, p=64, ncausal=3, seed=2)
+    X = np.zeros((250, 128), dtype=np.float32, order="F")
+    X[:120, :64] = d1["X"]
+    X[120:, 64:] = d2["X"]                      # X_1' X_2 = 0
+    y = np.concatenate([d1["y"], d2["y"]]).astype(np.float32)
+    xpx = O.xpx(X)
+    full_r = (y - y.mean()).copy()
+    a, b, d = (np.zeros(128, dtype=np.float32) for _ in range(3))
+    O.bayesabc_sweep(X, xpx, full_r, a, b, d, 0.5, 0.01, 0.8, 4, 1)
+    snap = (y - y.mean()).copy()
+    deltas, a_sh = [], np.zeros(128, dtype=np.float32)
+    for lo, hi in ((0, 64), (64, 128)):
+        Xs = np.asfortranarray(X[:, lo:hi])
+        r = snap.copy()
+        aa, bb, dd = (np.zeros(64, dtype=np.float32) for _ in range(3))
+        O.bayesabc_sweep(Xs, xpx[lo:hi].copy(), r, aa, bb, dd, 0.5, 0.01, 0.8, 4, 1, marker0=lo)
+        deltas.append(r - snap)
+        a_sh[lo:hi] = aa
+    assert np.array_equal(a_sh, a)              # same draws (global marker index), same decisions
+    np.testing.assert_allclose(snap + deltas[0] + deltas[1], full_r, atol=1e-6)
