@@ -44,8 +44,16 @@ def parse():
     ap.add_argument("--block-size", type=int, default=int(os.environ.get("JWAS_BLOCK_SIZE", "256")))
     ap.add_argument("--seed", type=int, default=2026)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-markers", type=int, default=20000)
+    ap.add_argument("--cpu-sample-markers", type=int, default=4000)
     return ap.parse_args()
+
+
+_T0 = time.time()
+
+
+def log(msg):
+    if os.environ.get("JWAS_BENCH_VERBOSE", "0") != "0" and int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.time() - _T0:8.2f}s] {msg}", file=sys.stderr, flush=True)
 
 
 def main():
@@ -71,9 +79,9 @@ def main():
     p_loc = hi - lo
     eng = J.HipEngine(local_rank)
     t_setup = time.time()
-    eng.alloc_dense(n, p_loc)
+    log('engine created'); eng.alloc_dense(n, p_loc); log('alloc done')
     eng.synth(a.seed, kind=0, center=True, marker_offset=lo)        # 0/1/2 genotypes, centred, generated on device
-    eng.setup_blocks(bs, "mfma")
+    log('synth done'); eng.setup_blocks(bs, "mfma"); log('setup_blocks done')
     eng.init_state("BayesC", 1)
     shard = MarkerShard(eng, lo, hi, rank, world)
 
@@ -86,7 +94,7 @@ def main():
     m = (causal >= lo) & (causal < hi)
     a_true[causal[m] - lo] = eff[m]
     eng.set_state(alpha=a_true)
-    g = shard.allreduce_sum(eng.mul_alpha().astype(np.float64))
+    g = shard.allreduce_sum(eng.mul_alpha().astype(np.float64)); log('mul_alpha done')
     g *= np.sqrt(0.5 / g.var())
     y = (1.0 + g + rng.standard_normal(n) * np.sqrt(0.5)).astype(np.float32)
     eng.set_state(alpha=np.zeros(p_loc), beta=np.zeros(p_loc), delta=np.ones(p_loc))
@@ -100,7 +108,7 @@ def main():
     Gval = np.float32(0.5 * vary / ((1.0 - pi) * sum2pq))
     scale_e = float(vare) * (df_ - 2) / df_
     scale_g = float(Gval) * (df_ - 2) / df_
-    setup_s = time.time() - t_setup
+    setup_s = time.time() - t_setup; log(f'setup done {setup_s:.1f}s')
 
     state = {"r": y[None, :].copy(), "mu": 0.0, "vare": vare, "G": Gval, "pi": pi, "it": 0}
     acc = {"sweep_ms": 0.0, "k_ms": 0.0, "k_n": 0.0, "k_bytes": 0.0, "events": 0.0}
@@ -134,7 +142,7 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(a.warmup):
-        step()
+        st_ = step(); log(f"warmup step: sweep_ms={st_['sweep_ms']:.1f} events={st_['n_events']:.0f} in_model={st_['sum_delta'][0]:.0f}")
     for k in acc:
         acc[k] = 0.0
     eng.set_kernel_timing(4)
@@ -144,7 +152,7 @@ def main():
         last = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    eng.set_kernel_timing(0)
+    eng.set_kernel_timing(0); log(f'timed region done: {elapsed:.2f}s')
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -183,29 +191,34 @@ def cpu_baseline(eng, n, p_total, p_sub, y, vare, Gval):
     """The CPU oracle's non-block BayesC sweep (oracle/jwas_oracle.c: orc_time_bayesc_sweeps -- per marker
     fp32 dot, scalar update, conditional fp32 axpy: the reference's operation order, BayesABC.jl:60-80) on
     the first p_sub markers of the same matrix, scaled linearly in p (the reference's own projection
-    device, benchmarks/streaming_large_benchmark.jl:161-184)."""
+    device, benchmarks/streaming_large_benchmark.jl:161-184).  Timed single-threaded and with the
+    dot/axpy rows split over a few threads (what a threaded BLAS does per marker; more threads than ~8
+    only add fork/join cost on 50k-element vectors); the faster one is reported with its thread count."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
     X = eng.get_columns(0, p_sub)
     xpx = O.xpx(X, O.ACC_F32)
     ncores = os.cpu_count() or 1
     res = {}
-    for threads, sweeps in ((1, 2), (ncores, 2)):
+    for threads in sorted({1, min(ncores, 8)}):
         r = (y - y.mean()).astype(np.float32)
         al = np.zeros(p_sub, dtype=np.float32)
         be = np.zeros(p_sub, dtype=np.float32)
         de = np.zeros(p_sub, dtype=np.float32)
-        # calibrate the sweep count for ~10 s of CPU work
-        t1 = O.time_bayesc_sweeps(X, xpx, r, al, be, de, vare, Gval, 0.95, 1, 1, threads)
-        sweeps = int(max(1, min(20, round(8.0 / max(t1, 1e-3)))))
+        # one calibration sweep on a tenth of the sample, then ~6 s of timed work
+        pc = max(200, p_sub // 10)
+        t1 = O.time_bayesc_sweeps(np.asfortranarray(X[:, :pc]), xpx[:pc].copy(), r.copy(), al[:pc].copy(), be[:pc].copy(),
+                                  de[:pc].copy(), vare, Gval, 0.95, 1, 1, threads) * (p_sub / pc)
+        sweeps = int(max(1, min(10, round(6.0 / max(t1, 1e-3)))))
         tt = O.time_bayesc_sweeps(X, xpx, r, al, be, de, vare, Gval, 0.95, 1, sweeps, threads)
         res[threads] = (tt / sweeps, sweeps)
+        log(f"cpu baseline {threads} thread(s): {tt / sweeps:.3f} s per {p_sub}-marker sweep")
     best = min(res, key=lambda k: res[k][0])
     per_sweep_full = res[best][0] * p_total / p_sub
+    detail = "; ".join(f"{k} thread(s): {v[0] * p_total / p_sub:.1f} s/sweep" for k, v in sorted(res.items()))
     return {"value": 1.0 / per_sweep_full, "unit": "iterations/s", "cores": best, "kind": "port",
             "sample": (f"{res[best][1]} sweeps over the first {p_sub} of {p_total} markers (n={n}), scaled linearly in p; "
-                       f"1 thread: {res[1][0] * p_total / p_sub:.1f} s/sweep, {ncores} threads (row-split dot/axpy): "
-                       f"{res[ncores][0] * p_total / p_sub:.1f} s/sweep; sweep only, host updates excluded")}
+                       f"{detail}; host has {ncores} logical cores; sweep only, host updates excluded")}
 
 
 if __name__ == "__main__":
