@@ -14,7 +14,7 @@ same residual snapshot and one all-reduce (RCCL) of the residual delta reconcile
 work is fixed (50k x 600k), so "scaling" is "strong".
 
 Prints ONE JSON line (rank 0) with the contract fields plus
-  "roofline":     HBM roofline of the dominant kernel (k_update_partial), from HIP events recorded on the
+  "roofline":     HBM roofline of the dominant kernel (k_block_step: sampler of block k-1 || update+partial RHS of block k), from HIP events recorded on the
                   sweep's stream around every 4th launch inside the timed region;
   "cpu_baseline": the CPU oracle's non-block BayesC sweep (the reference's per-marker sdot/saxpy
                   order) timed on this box's host cores on a marker subsample (N = 1, rank 0 only).
@@ -170,7 +170,7 @@ def main():
                        "n": n, "p": p_total, "block_size": bs, "parallelism": f"marker-shard x{world}" if world > 1 else "single GPU",
                        "device_sweep_ms": acc["sweep_ms"] / a.steps, "events_per_sweep": acc["events"] / a.steps,
                        "markers_in_model": float(last["sum_delta"][0]), "setup_s": setup_s},
-            "roofline": {"bound": "hbm", "kernel": "k_update_partial", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_block_step", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
                          "bytes_per_launch": acc["k_bytes"] / acc["k_n"] if acc["k_n"] else None,
                          "avg_launch_us": 1e3 * acc["k_ms"] / acc["k_n"] if acc["k_n"] else None,

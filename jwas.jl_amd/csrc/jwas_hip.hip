@@ -1,7 +1,7 @@
 // jwas_hip.hip -- context, memory and the C ABI of libjwas_hip.so (see include/jwas_hip.h).
 // gfx950 only.  No CPU fallback: every entry point either runs the HIP path or returns an error.
 #include "../../include/jwas_hip.h"
-#include "kernels.hpp"
+#include "sweep.hpp"
 
 #include <hip/hip_runtime.h>
 #include <cmath>
@@ -32,6 +32,7 @@ struct jwas_hip_ctx {
     int64_t nblocks = 0;
     float* xpx = nullptr;
     float* gram = nullptr;
+    float* cross = nullptr;             // cross-Grams X_{b-1}'X_b, block b at offset b*bs*bs (block 0 unused)
 
     int method = -1, ntraits = 0;
     float* r = nullptr;                 // [2][kMaxT][ld] ping-pong; buffer 0 is current between sweeps
@@ -146,8 +147,8 @@ static void free_state(jwas_hip_ctx* c)
 
 static void free_blocks(jwas_hip_ctx* c)
 {
-    (void)hipFree(c->xpx); (void)hipFree(c->gram); (void)hipFree(c->partials);
-    c->xpx = c->gram = nullptr; c->partials = nullptr;
+    (void)hipFree(c->xpx); (void)hipFree(c->gram); (void)hipFree(c->cross); (void)hipFree(c->partials);
+    c->xpx = c->gram = c->cross = nullptr; c->partials = nullptr;
 }
 
 static void free_storage(jwas_hip_ctx* c)
@@ -224,8 +225,8 @@ static int alloc_storage(jwas_hip_ctx* c, int64_t n, int64_t p)
     c->n = n; c->p = p; c->ld = round_up(n, kSliceRows);
     c->nslices = (int)(c->ld / kSliceRows);
     c->nrg = (c->nslices + kRowGroupSlices - 1) / kRowGroupSlices;
-    // enough workgroups to cover every CU (256 on MI355X), at most 8-fold update redundancy
-    c->ncg = 256 / c->nrg; if (c->ncg < 1) c->ncg = 1; if (c->ncg > 8) c->ncg = 8;
+    // enough workgroups to cover the CUs (256 on MI355X, one is the sampler's), at most 8-fold update redundancy
+    c->ncg = 255 / c->nrg; if (c->ncg < 1) c->ncg = 1; if (c->ncg > 8) c->ncg = 8;
     size_t fb = 0, tb = 0;
     HIPCHK(c, hipMemGetInfo(&fb, &tb));
     const size_t need = (size_t)4 * c->ld * p;
@@ -316,7 +317,8 @@ int jwas_hip_setup_blocks(jwas_hip_ctx* c, int32_t bs, int32_t gram_mode)
     c->nblocks = (c->p + bs - 1) / bs;
     HIPCHK(c, hipMalloc(&c->xpx, sizeof(float) * c->p));
     HIPCHK(c, hipMalloc(&c->gram, sizeof(float) * (size_t)c->nblocks * bs * bs));
-    HIPCHK(c, hipMalloc(&c->partials, sizeof(double) * (size_t)bs * c->nrg * kMaxT));
+    HIPCHK(c, hipMalloc(&c->cross, sizeof(float) * (size_t)c->nblocks * bs * bs));
+    HIPCHK(c, hipMalloc(&c->partials, sizeof(double) * 2 * (size_t)bs * c->nrg * kMaxT));   // ping-pong
     hipLaunchKernelGGL(k_xpx, dim3((unsigned)c->p), dim3(256), 0, c->stream, c->X, c->ld, c->xpx);
     HIPCHK(c, hipGetLastError());
     // Gram launches are chunked over blocks so grid.y stays below 65536
@@ -326,11 +328,15 @@ int jwas_hip_setup_blocks(jwas_hip_ctx* c, int32_t bs, int32_t gram_mode)
         const float* Xc = c->X + y0 * bs * c->ld;
         float* Gc = c->gram + y0 * (int64_t)bs * bs;
         const int64_t pc = c->p - y0 * bs;
-        if (gram_mode == JWAS_HIP_GRAM_F64)
+        float* Cc = c->cross + y0 * (int64_t)bs * bs;
+        const int64_t nyc = (y0 + ny < c->nblocks) ? ny : ny - 1;      // cross blocks y0+1 .. (last block has none after it)
+        if (gram_mode == JWAS_HIP_GRAM_F64) {
             hipLaunchKernelGGL(k_gram_f64, dim3(bs, (unsigned)ny), dim3(256), 0, c->stream, Xc, c->ld, pc, (int)bs, Gc);
-        else {
+            if (nyc > 0) hipLaunchKernelGGL(k_cross_f64, dim3(bs, (unsigned)nyc), dim3(256), 0, c->stream, Xc, c->ld, pc, (int)bs, Cc);
+        } else {
             const int nt = bs / 64;
-            hipLaunchKernelGGL(k_gram_mfma, dim3(nt * (nt + 1) / 2, (unsigned)ny), dim3(256), 0, c->stream, Xc, c->ld, pc, (int)bs, Gc);
+            hipLaunchKernelGGL(k_gram_mfma, dim3(nt * (nt + 1) / 2, (unsigned)ny), dim3(256), 0, c->stream, Xc, c->ld, pc, (int)bs, Gc, 0);
+            if (nyc > 0) hipLaunchKernelGGL(k_gram_mfma, dim3(nt * nt, (unsigned)nyc), dim3(256), 0, c->stream, Xc, c->ld, pc, (int)bs, Cc, 1);
         }
         HIPCHK(c, hipGetLastError());
     }
@@ -529,43 +535,32 @@ int jwas_hip_mul_alpha(jwas_hip_ctx* c, int32_t trait, float* out)
 }  // extern "C" (templates need C++ linkage)
 
 // ---- the sweep --------------------------------------------------------------------------------------
-template <int NT>
-static void launch_update(jwas_hip_ctx* c, const float* r_in, float* r_out, const Events* ev, int64_t j0, int b)
+template <int METHOD, int NT>
+static hipError_t launch_step(jwas_hip_ctx* c, const UpdateArgs& U, const SamplerArgs& S, int do_sample)
 {
-    const int ncg = c->ncg < b ? c->ncg : b;
-    hipLaunchKernelGGL((k_update_partial<NT>), dim3(c->nrg, ncg), dim3(512), 0, c->stream,
-                       c->X, c->ld, r_in, r_out, ev, j0, b, c->nslices, c->nrg, ncg, c->partials, c->block_size);
+    const StepSmem SM(c->block_size, NT);
+    static bool attr_set = false;
+    if (!attr_set) {   // allow > 64 KB of dynamic LDS
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_block_step<METHOD, NT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_block_step<METHOD, NT>), dim3(1 + c->nrg * U.ncg), dim3(kStepThreads), SM.bytes, c->stream,
+                       U, S, do_sample);
+    return hipSuccess;
 }
 
-template <int METHOD, int NSUB>
-static void launch_sample_st(jwas_hip_ctx* c, int64_t blk, int64_t j0, int b, Events* ev_out)
-{
-    hipLaunchKernelGGL((k_sample_block<METHOD, NSUB>), dim3(1), dim3(256), 0, c->stream,
-                       c->dparams, c->partials, c->nrg, c->block_size, j0, b, c->p, c->xpx,
-                       c->gram + blk * (int64_t)c->block_size * c->block_size, c->prep_d, c->prep_f,
-                       c->alpha, c->beta, c->delta, ev_out, c->counters);
-}
-
-template <int NT, int NSUB>
-static void launch_sample_mt(jwas_hip_ctx* c, int64_t blk, int64_t j0, int b, Events* ev_out)
-{
-    hipLaunchKernelGGL((k_sample_block_mt1<NT, NSUB>), dim3(1), dim3(256), 0, c->stream,
-                       c->dparams, c->partials, c->nrg, c->block_size, j0, b, c->p, c->xpx,
-                       c->gram + blk * (int64_t)c->block_size * c->block_size, c->prep_d,
-                       c->alpha, c->beta, (float*)c->delta, ev_out, c->counters);
-}
-
-template <int NSUB>
-static void launch_sample(jwas_hip_ctx* c, int64_t blk, int64_t j0, int b, Events* ev_out)
+static hipError_t launch_step_any(jwas_hip_ctx* c, const UpdateArgs& U, const SamplerArgs& S, int do_sample)
 {
     switch (c->method) {
-        case JWAS_HIP_BAYESC: launch_sample_st<kBayesC, NSUB>(c, blk, j0, b, ev_out); break;
-        case JWAS_HIP_BAYESB: launch_sample_st<kBayesB, NSUB>(c, blk, j0, b, ev_out); break;
-        case JWAS_HIP_BAYESR: launch_sample_st<kBayesR, NSUB>(c, blk, j0, b, ev_out); break;
+        case JWAS_HIP_BAYESC: return launch_step<kBayesC, 1>(c, U, S, do_sample);
+        case JWAS_HIP_BAYESB: return launch_step<kBayesB, 1>(c, U, S, do_sample);
+        case JWAS_HIP_BAYESR: return launch_step<kBayesR, 1>(c, U, S, do_sample);
         default:
-            if (c->ntraits == 2) launch_sample_mt<2, NSUB>(c, blk, j0, b, ev_out);
-            else if (c->ntraits == 3) launch_sample_mt<3, NSUB>(c, blk, j0, b, ev_out);
-            else launch_sample_mt<4, NSUB>(c, blk, j0, b, ev_out);
+            if (c->ntraits == 2) return launch_step<kMTBayesC1, 2>(c, U, S, do_sample);
+            if (c->ntraits == 3) return launch_step<kMTBayesC1, 3>(c, U, S, do_sample);
+            return launch_step<kMTBayesC1, 4>(c, U, S, do_sample);
     }
 }
 
@@ -646,43 +641,57 @@ int jwas_hip_sweep(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_sweep_stats
     }
 
     const int bs = c->block_size;
+    // one-block lookahead pipeline (sweep.hpp): launch k = sampler(block k-1) || update/partial(block k)
+    const size_t rstride = (size_t)kMaxT * c->ld;
+    const size_t pstride = (size_t)bs * c->nrg * kMaxT;
+    HIPCHK(c, hipMemcpyAsync(c->r + rstride, c->r, sizeof(float) * (size_t)t * c->ld, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(&c->ev[1].count, 0, sizeof(int32_t), c->stream));
     size_t ntimed = 0;
     double timed_bytes = 0.0;
-    for (int64_t blk = 0; blk < c->nblocks; ++blk) {
-        const int64_t j0 = blk * bs;
-        const int b = (int)((j0 + bs <= c->p) ? bs : c->p - j0);
-        const bool timed = c->timing_stride > 0 && (blk % c->timing_stride) == 0;
+    const int64_t nb = c->nblocks;
+    for (int64_t k = 0; k <= nb; ++k) {
+        UpdateArgs U;
+        U.X = c->X; U.ld = c->ld;
+        U.r_in = c->r + ((k + 1) & 1) * rstride; U.r_out = c->r + (k & 1) * rstride;
+        U.ev = &c->ev[k & 1];
+        U.j0 = (k < nb) ? k * bs : 0;
+        U.b = (k < nb) ? (int)((U.j0 + bs <= c->p) ? bs : c->p - U.j0) : 0;
+        U.nslices = c->nslices; U.nrg = c->nrg;
+        U.ncg = (U.b > 0 && c->ncg > U.b) ? U.b : c->ncg;
+        U.partials = c->partials + (k & 1) * pstride; U.bstride = bs;
+        SamplerArgs S;
+        std::memset(&S, 0, sizeof S);
+        const int64_t sb = k - 1;
+        if (sb >= 0) {
+            S.P = c->dparams;
+            S.partials = c->partials + (sb & 1) * pstride; S.nrg = c->nrg; S.bstride = bs;
+            S.j0 = sb * bs; S.b = (int)((S.j0 + bs <= c->p) ? bs : c->p - S.j0); S.p = c->p;
+            S.j0_prev = sb > 0 ? (sb - 1) * bs : 0;
+            S.bsz = bs;
+            S.xpx = c->xpx;
+            S.gram = c->gram + sb * (int64_t)bs * bs;
+            S.cross = c->cross + sb * (int64_t)bs * bs;
+            S.prep_d = c->prep_d; S.prep_f = c->prep_f;
+            S.alpha = c->alpha; S.beta = c->beta; S.delta = c->delta;
+            S.ev_prev = &c->ev[k & 1]; S.ev_out = &c->ev[(k - 1) & 1];
+            S.counters = c->counters;
+        }
+        const bool timed = c->timing_stride > 0 && k < nb && (k % c->timing_stride) == 0;
         if (timed) {
             while (c->kev.size() < 2 * (ntimed + 1)) { hipEvent_t e; HIPCHK(c, hipEventCreate(&e)); c->kev.push_back(e); }
             HIPCHK(c, hipEventRecord(c->kev[2 * ntimed], c->stream));
         }
-        const Events* ev_in = &c->ev[blk & 1];
-        Events* ev_out = &c->ev[(blk + 1) & 1];
-        const float* r_in = c->r + (size_t)(blk & 1) * kMaxT * c->ld;
-        float* r_out = c->r + (size_t)((blk + 1) & 1) * kMaxT * c->ld;
-        switch (t) {
-            case 1: launch_update<1>(c, r_in, r_out, ev_in, j0, b); break;
-            case 2: launch_update<2>(c, r_in, r_out, ev_in, j0, b); break;
-            case 3: launch_update<3>(c, r_in, r_out, ev_in, j0, b); break;
-            default: launch_update<4>(c, r_in, r_out, ev_in, j0, b);
-        }
+        HIPCHK(c, launch_step_any(c, U, S, sb >= 0));
         if (timed) {
             HIPCHK(c, hipEventRecord(c->kev[2 * ntimed + 1], c->stream));
             ++ntimed;
-            timed_bytes += 4.0 * (double)c->n * (double)b;
-        }
-        switch (bs) {
-            case 64:  launch_sample<1>(c, blk, j0, b, ev_out); break;
-            case 128: launch_sample<2>(c, blk, j0, b, ev_out); break;
-            case 256: launch_sample<4>(c, blk, j0, b, ev_out); break;
-            case 512: launch_sample<8>(c, blk, j0, b, ev_out); break;
-            default:  launch_sample<16>(c, blk, j0, b, ev_out);
+            timed_bytes += 4.0 * (double)c->n * (double)U.b;
         }
     }
-    const Events* ev_last = &c->ev[c->nblocks & 1];
-    const float* r_last = c->r + (size_t)(c->nblocks & 1) * kMaxT * c->ld;   // written by the last k_update_partial
+    const Events* ev_last = &c->ev[(nb - 1) & 1];
+    const float* r_last = c->r + (nb & 1) * rstride;          // r(nb-2), written by the last step
     const int nfin = t * t + t;
-    switch (t) {   // the finished residual always lands in buffer 0
+    switch (t) {   // apply the last block's changes; the finished residual always lands in buffer 0
         case 1: hipLaunchKernelGGL((k_finish<1>), dim3(c->nslices), dim3(256), 0, c->stream, c->X, c->ld, r_last, c->r, ev_last, c->fin_out); break;
         case 2: hipLaunchKernelGGL((k_finish<2>), dim3(c->nslices), dim3(256), 0, c->stream, c->X, c->ld, r_last, c->r, ev_last, c->fin_out); break;
         case 3: hipLaunchKernelGGL((k_finish<3>), dim3(c->nslices), dim3(256), 0, c->stream, c->X, c->ld, r_last, c->r, ev_last, c->fin_out); break;

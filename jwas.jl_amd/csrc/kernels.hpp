@@ -87,7 +87,7 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double* lds /* [nwave
 }
 
 // ---------------------------------------------------------------------------------------------
-// K_A: apply the previous block's events to the residual, then the partial block RHS.
+// Update/partial role (see sweep.hpp): apply a block's events to the residual, then the partial block RHS.
 //
 // grid = (nrg, ncg), block = 512 (8 waves).  Row group rg owns 8 consecutive 256-row slices, one
 // per wave (lane l holds rows 4l..4l+3 of its slice as a float4 / four doubles in registers).
@@ -134,102 +134,6 @@ __device__ __forceinline__ double butterfly8(const double (&v)[kU], int lane)
     c += __shfl_xor(c, 2, 64);
     c += __shfl_xor(c, 1, 64);
     return c;
-}
-
-template <int NT>
-__global__ __launch_bounds__(512) void k_update_partial(const float* __restrict__ X, int64_t ld,
-                                                        const float* __restrict__ r_in, float* __restrict__ r_out,
-                                                        const Events* __restrict__ ev,
-                                                        int64_t j0, int b, int nslices, int nrg, int ncg,
-                                                        double* __restrict__ partials, int bstride)
-{
-    __shared__ double red[kRowGroupSlices][kColChunk][NT];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int rg = blockIdx.x, g = blockIdx.y;
-    const int slice = rg * kRowGroupSlices + wave;
-    const bool active = slice < nslices;
-    // an inactive wave (slice beyond the matrix) aliases slice 0 for addressing and contributes 0
-    const int64_t row = (int64_t)(active ? slice : 0) * kSliceRows + lane * 4;
-    const int ncols = (b - g + ncg - 1) / ncg;            // columns of this group (b > g by launch)
-
-    // Loads are unconditional from clamped, always-valid addresses: a select between a load and a
-    // constant makes hipcc pick between pointers and emit flat/scratch accesses.
-    const float* xcol = X + (j0 + g) * ld + row;
-    const int64_t cstride = (int64_t)ncg * ld;
-    auto load_batch = [&](float4 (&dst)[kU], int ib) {
-#pragma unroll
-        for (int u = 0; u < kU; ++u)
-            dst[u] = *reinterpret_cast<const float4*>(xcol + (ib + u < ncols ? ib + u : ncols - 1) * cstride);
-    };
-
-    // (1) the first batch of column loads does not depend on r: issue it before the update.
-    float4 xa[kU], xb[kU];
-    load_batch(xa, 0);
-
-    // (2) sparse exit update of the previous block: sequential fmaf in marker order, bit-identical
-    //     to the oracle's per-marker axpy sequence.
-    float4 rv[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) rv[t] = *reinterpret_cast<const float4*>(r_in + t * ld + row);
-    const int ne = ev->count;
-#pragma unroll 4
-    for (int e = 0; e < ne; ++e) {
-        const float4 x = *reinterpret_cast<const float4*>(X + (int64_t)ev->idx[e] * ld + row);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const float d = ev->delta[t][e];
-            rv[t].x = fmaf(d, x.x, rv[t].x); rv[t].y = fmaf(d, x.y, rv[t].y);
-            rv[t].z = fmaf(d, x.z, rv[t].z); rv[t].w = fmaf(d, x.w, rv[t].w);
-        }
-    }
-    if (active && g == 0)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) *reinterpret_cast<float4*>(r_out + t * ld + row) = rv[t];
-    const float keep = active ? 1.f : 0.f;
-    double rd[NT][4];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        rd[t][0] = rv[t].x * keep; rd[t][1] = rv[t].y * keep; rd[t][2] = rv[t].z * keep; rd[t][3] = rv[t].w * keep;
-    }
-
-    // (3) partial block RHS.
-    auto consume = [&](const float4 (&xv)[kU], int ib, int i0) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            double acc[kU];
-#pragma unroll
-            for (int u = 0; u < kU; ++u) {
-                acc[u] = (double)xv[u].x * rd[t][0];
-                acc[u] = fma((double)xv[u].y, rd[t][1], acc[u]);
-                acc[u] = fma((double)xv[u].z, rd[t][2], acc[u]);
-                acc[u] = fma((double)xv[u].w, rd[t][3], acc[u]);
-            }
-            const double s = butterfly8(acc, lane);
-            const int u = lane >> 3;                       // column of this 8-lane group
-            if ((lane & 7) == 0 && ib + u < ncols) red[wave][ib + u - i0][t] = s;
-        }
-    };
-
-    for (int i0 = 0; i0 < ncols; i0 += kColChunk) {
-        const int iend = (i0 + kColChunk < ncols) ? i0 + kColChunk : ncols;
-        // two batches per trip so both register sets are statically indexed
-        for (int ib = i0; ib < iend; ib += 2 * kU) {
-            if (ib + kU < ncols) load_batch(xb, ib + kU);
-            consume(xa, ib, i0);
-            if (ib + 2 * kU < ncols) load_batch(xa, ib + 2 * kU);
-            if (ib + kU < iend) consume(xb, ib + kU, i0);
-        }
-        __syncthreads();
-        for (int q = tid; q < (iend - i0) * NT; q += 512) {
-            const int i = q / NT, t = q - i * NT;
-            double s = 0.0;
-#pragma unroll
-            for (int w = 0; w < kRowGroupSlices; ++w) s += red[w][i][t];
-            const int c = g + (i0 + i) * ncg;
-            partials[((int64_t)t * nrg + rg) * bstride + c] = s;
-        }
-        __syncthreads();
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -441,352 +345,6 @@ __global__ __launch_bounds__(256) void k_prepare(const DevParams* __restrict__ P
 }
 
 // ---------------------------------------------------------------------------------------------
-// K_S (single trait): reduce row-group partials, then one wavefront samples the block.
-// grid = 1, block = 256 (one wave per SIMD: the sampler wave may use the whole register file).
-// METHOD in {kBayesC, kBayesB, kBayesR}.  NSUB = block/64.
-// ---------------------------------------------------------------------------------------------
-template <int METHOD, int NSUB>
-__global__ __launch_bounds__(256) void k_sample_block(const DevParams* __restrict__ P,
-                                                      const double* __restrict__ partials, int nrg, int bstride,
-                                                      int64_t j0, int b, int64_t p,
-                                                      const float* __restrict__ xpx,
-                                                      const float* __restrict__ gram,   // b x b of this block
-                                                      const double* __restrict__ prep_d, const float* __restrict__ prep_f,
-                                                      float* __restrict__ alpha, float* __restrict__ beta,
-                                                      void* __restrict__ delta_v,
-                                                      Events* __restrict__ ev_out,
-                                                      unsigned long long* __restrict__ counters)
-{
-    __shared__ float rhs_lds[NSUB * 64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-
-    // phase 1: rhs_b[c] = sum over row groups (fp64, fixed order), rounded once to fp32
-    for (int c = tid; c < b; c += 256) {
-        double s = 0.0;
-        for (int rg = 0; rg < nrg; ++rg) s += partials[(int64_t)rg * bstride + c];
-        rhs_lds[c] = (float)s;
-    }
-    __syncthreads();
-    if (wave != 0) {
-        // warm this XCD's L2 with the block's Gram so event-column reads are L2 hits
-        float sink = 0.f;
-        for (int64_t i = (int64_t)(tid - 64) * 32; i < (int64_t)b * b; i += (int64_t)(256 - 64) * 32) sink += gram[i];
-        asm volatile("" ::"v"(sink));
-        return;
-    }
-
-    // phase 2: wave 0, lane l owns markers c = 64*s + l of the block
-    const float ie = 1.0f / P->vare[0];
-    float* delta_f = reinterpret_cast<float*>(delta_v);
-    int32_t* delta_i = reinterpret_cast<int32_t*>(delta_v);
-
-    float rhs[NSUB], a_cur[NSUB], a_start[NSUB], b_out[NSUB], d_out[NSUB], dj[NSUB];
-    bool  valid[NSUB];
-#pragma unroll
-    for (int s = 0; s < NSUB; ++s) {
-        const int c = 64 * s + lane;
-        valid[s] = c < b;
-        const int cc = valid[s] ? c : 0;
-        rhs[s] = rhs_lds[cc];
-        a_cur[s] = valid[s] ? alpha[j0 + cc] : 0.f;
-        dj[s] = xpx[j0 + cc];
-        a_start[s] = a_cur[s];
-        b_out[s] = 0.f; d_out[s] = 0.f;
-    }
-    const int nreps = P->nreps > 0 ? P->nreps : b;
-    RngKey key{P->seed_lo, P->seed_hi, P->iter, 0u};
-
-    for (int rep = 0; rep < nreps; ++rep) {
-        key.rep = (uint32_t)rep;
-#pragma unroll
-        for (int s = 0; s < NSUB; ++s) {
-            const int c = 64 * s + lane;
-            const int64_t j = j0 + (valid[s] ? c : 0);
-            const uint32_t marker = P->marker0 + (uint32_t)j;
-            unsigned long long pending = __ballot(valid[s]);
-            if (pending == 0ull) continue;
-
-            AbcMarker am; BayesRMarker bm;
-            if (rep == 0) {
-                if constexpr (METHOD == kBayesR) bm.load(prep_d, prep_f, p, j, dj[s], ie);
-                else am.load(prep_d, prep_f, p, j, dj[s]);
-            } else {
-                const double u = draw_uniform(key, marker, 0u);
-                const double z = draw_normal(key, marker, 0u);
-                if constexpr (METHOD == kBayesR) {
-                    double pj[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) pj[k] = P->pi_mat ? P->pi_mat[4 * j + k] : P->pi4[k];
-                    bm.prepare(dj[s], P->var_effect[0], pj, P->gamma, ie, u, z);
-                } else {
-                    float var_j = P->var_effect[0];
-                    if constexpr (METHOD == kBayesB) var_j = P->var_vec[j];
-                    double pi_j = P->pi;
-                    if (P->pi_vec) pi_j = P->pi_vec[j];
-                    am.prepare(dj[s], var_j, pi_j, ie, u, z);
-                }
-            }
-            // speculative rounds
-            while (true) {
-                bool is_event = false, incl = false;
-                float a_new = 0.f, gHat = 0.f;
-                int cls = 0;
-                const bool live = valid[s] && ((pending >> lane) & 1ull);
-                if (live) {
-                    if constexpr (METHOD == kBayesR) {
-                        cls = bm.evaluate(rhs[s], a_cur[s], ie, a_new);
-                        is_event = (cls != 0) || (a_cur[s] != 0.f);
-                    } else {
-                        incl = am.evaluate(rhs[s], a_cur[s], ie, gHat);
-                        is_event = incl || (a_cur[s] != 0.f);
-                    }
-                }
-                const unsigned long long m = __ballot(is_event) & pending;
-                const int k = m ? __builtin_ctzll(m) : 64;
-                // lanes before k (and k itself) are final with the values just computed
-                float Dl = 0.f;
-                if (live && lane <= k) {
-                    if constexpr (METHOD == kBayesR) {
-                        d_out[s] = (float)(cls + 1);                       // stored as class 1..4
-                        const float an = (cls == 0) ? 0.f : a_new;
-                        Dl = a_cur[s] - an;
-                        a_cur[s] = an;
-                    } else {
-                        if (incl) { const float an = am.alpha_incl(gHat); d_out[s] = 1.f; b_out[s] = an; Dl = a_cur[s] - an; a_cur[s] = an; }
-                        else      { d_out[s] = 0.f; b_out[s] = am.beta_excl; Dl = a_cur[s]; a_cur[s] = 0.f; }
-                    }
-                }
-                if (k == 64) break;
-                pending = (k == 63) ? 0ull : (pending & ~((2ull << k) - 1ull));
-                const float D = __shfl(Dl, k, 64);
-                if (D != 0.f) {
-                    const float* grow = gram + (int64_t)(64 * s + k) * b;   // symmetric: row = column
-#pragma unroll
-                    for (int s2 = 0; s2 < NSUB; ++s2) {
-                        const int c2 = 64 * s2 + lane;
-                        const float gv = grow[c2 < b ? c2 : 0];
-                        if (c2 < b) rhs[s2] = fmaf(D, gv, rhs[s2]);         // BayesABC.jl:169,172
-                    }
-                }
-                if (pending == 0ull) break;
-            }
-        }
-    }
-
-    // write back state and the event list of this block
-    int base = 0;
-#pragma unroll
-    for (int s = 0; s < NSUB; ++s) {
-        const int c = 64 * s + lane;
-        if (valid[s]) {
-            alpha[j0 + c] = a_cur[s];
-            if constexpr (METHOD == kBayesR) delta_i[j0 + c] = (int32_t)d_out[s];
-            else { beta[j0 + c] = b_out[s]; delta_f[j0 + c] = d_out[s]; }
-        }
-        const float dtot = a_start[s] - a_cur[s];
-        const bool changed = valid[s] && (a_start[s] != a_cur[s]);
-        const unsigned long long cm = __ballot(changed);
-        if (changed) {
-            const int pos = base + __popcll(cm & ((1ull << lane) - 1ull));
-            ev_out->idx[pos] = (int32_t)(j0 + c);
-            ev_out->delta[0][pos] = dtot;
-        }
-        base += __popcll(cm);
-    }
-    if (lane == 0) {
-        ev_out->count = base;
-        atomicAdd(&counters[0], (unsigned long long)base);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// K_S (multi-trait BayesC, Gibbs sampler I; MTBayesABC.jl:57-127, block form :243-333)
-// ---------------------------------------------------------------------------------------------
-template <int NT, int NSUB>
-__global__ __launch_bounds__(256) void k_sample_block_mt1(const DevParams* __restrict__ P,
-                                                          const double* __restrict__ partials, int nrg, int bstride,
-                                                          int64_t j0, int b, int64_t p,
-                                                          const float* __restrict__ xpx,
-                                                          const float* __restrict__ gram,
-                                                          const double* __restrict__ prep_d,
-                                                          float* __restrict__ alpha, float* __restrict__ beta,
-                                                          float* __restrict__ delta,
-                                                          Events* __restrict__ ev_out,
-                                                          unsigned long long* __restrict__ counters)
-{
-    __shared__ float rhs_lds[NT][NSUB * 64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int c = tid; c < b; c += 256) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            double s = 0.0;
-            for (int rg = 0; rg < nrg; ++rg) s += partials[((int64_t)t * nrg + rg) * bstride + c];
-            rhs_lds[t][c] = (float)s;
-        }
-    }
-    __syncthreads();
-    if (wave != 0) {
-        float sink = 0.f;
-        for (int64_t i = (int64_t)(tid - 64) * 32; i < (int64_t)b * b; i += (int64_t)(256 - 64) * 32) sink += gram[i];
-        asm volatile("" ::"v"(sink));
-        return;
-    }
-
-    float Rinv[NT][NT], Ginv[NT][NT];
-#pragma unroll
-    for (int a = 0; a < NT; ++a)
-#pragma unroll
-        for (int c = 0; c < NT; ++c) { Rinv[a][c] = P->Rinv[a * NT + c]; Ginv[a][c] = P->Ginv[a * NT + c]; }
-
-    float rhs[NT][NSUB], a_cur[NT][NSUB], a_start[NT][NSUB], b_cur[NT][NSUB], d_cur[NT][NSUB], djs[NSUB];
-    bool valid[NSUB];
-#pragma unroll
-    for (int s = 0; s < NSUB; ++s) {
-        const int c = 64 * s + lane;
-        valid[s] = c < b;
-        const int cc = valid[s] ? c : 0;
-        djs[s] = xpx[j0 + cc];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            rhs[t][s]   = rhs_lds[t][cc];
-            a_cur[t][s] = valid[s] ? alpha[(int64_t)t * p + j0 + cc] : 0.f;
-            b_cur[t][s] = beta[(int64_t)t * p + j0 + cc];
-            d_cur[t][s] = delta[(int64_t)t * p + j0 + cc];
-            a_start[t][s] = a_cur[t][s];
-        }
-    }
-    const int nreps = P->nreps > 0 ? P->nreps : b;
-    RngKey key{P->seed_lo, P->seed_hi, P->iter, 0u};
-
-    for (int rep = 0; rep < nreps; ++rep) {
-        key.rep = (uint32_t)rep;
-#pragma unroll
-        for (int s = 0; s < NSUB; ++s) {
-            const int c = 64 * s + lane;
-            const int64_t j = j0 + (valid[s] ? c : 0);
-            const uint32_t marker = P->marker0 + (uint32_t)j;
-            unsigned long long pending = __ballot(valid[s]);
-            if (pending == 0ull) continue;
-            double thr[NT], z[NT];
-            const float dj = djs[s];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                if (rep == 0) { thr[t] = prep_d[(int64_t)t * p + j]; z[t] = prep_d[(int64_t)(NT + t) * p + j]; }
-                else {
-                    const double u = draw_uniform(key, marker, (uint32_t)t);
-                    thr[t] = log((1.0 - u) / u);
-                    z[t] = draw_normal(key, marker, (uint32_t)t);
-                }
-            }
-            while (true) {
-                const bool live = valid[s] && ((pending >> lane) & 1ull);
-                float an[NT], bn[NT], dn[NT], Dl[NT];
-                bool is_event = false;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) { an[t] = a_cur[t][s]; bn[t] = b_cur[t][s]; dn[t] = d_cur[t][s]; Dl[t] = 0.f; }
-                if (live) {
-                    float w[NT];
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) w[t] = rhs[t][s] + dj * a_cur[t][s];                 // :82
-#pragma unroll
-                    for (int k = 0; k < NT; ++k) {                                                  // :85
-                        const float Ginv11 = Ginv[k][k];
-                        const float C11 = Ginv11 + Rinv[k][k] * dj;                                 // :89
-                        float rhs0 = 0.f, c12b = 0.f, wR = 0.f;
-#pragma unroll
-                        for (int m = 0; m < NT; ++m) {
-                            wR = wR + w[m] * Rinv[m][k];
-                            if (m == k) continue;
-                            const float C12m = Ginv[k][m] + (dj * dn[m]) * Rinv[k][m];              // :90
-                            rhs0 = rhs0 + Ginv[k][m] * bn[m];
-                            c12b = c12b + C12m * bn[m];
-                        }
-                        rhs0 = -rhs0;                                                               // :93
-                        const float invLhs0 = 1.0f / Ginv11;
-                        const float gHat0 = rhs0 * invLhs0;
-                        const float invLhs1 = 1.0f / C11;
-                        const float rhs1 = wR - c12b;                                               // :96
-                        const float gHat1 = rhs1 * invLhs1;
-                        unsigned s0 = 0u;
-#pragma unroll
-                        for (int m = 0; m < NT; ++m) if (m != k && dn[m] != 0.f) s0 |= 1u << m;
-                        const unsigned s1 = s0 | (1u << k);
-                        const float in0 = logf_via_double(Ginv11) - (gHat0 * gHat0) * Ginv11;       // :104
-                        const float in1 = logf_via_double(C11) - (gHat1 * gHat1) * C11;             // :105
-                        const double* lpr = P->log_prior;
-                        const double logDelta0 = -0.5 * (double)in0 + lpr[s0];
-                        const double logDelta1 = -0.5 * (double)in1 + lpr[s1];
-                        if ((logDelta0 - logDelta1) < thr[k]) {                                     // :107-111
-                            dn[k] = 1.f;
-                            bn[k] = (float)((double)gHat1 + z[k] * (double)sqrtf(invLhs1));
-                            Dl[k] = an[k] - bn[k];
-                            an[k] = bn[k];
-                        } else {                                                                    // :112-119
-                            bn[k] = (float)((double)gHat0 + z[k] * (double)sqrtf(invLhs0));
-                            dn[k] = 0.f;
-                            Dl[k] = an[k];
-                            an[k] = 0.f;
-                        }
-                    }
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) is_event = is_event || (Dl[t] != 0.f);
-                }
-                const unsigned long long m = __ballot(is_event) & pending;
-                const int k = m ? __builtin_ctzll(m) : 64;
-                if (live && lane <= k) {
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) { a_cur[t][s] = an[t]; b_cur[t][s] = bn[t]; d_cur[t][s] = dn[t]; }
-                }
-                if (k == 64) break;
-                pending = (k == 63) ? 0ull : (pending & ~((2ull << k) - 1ull));
-                const float* grow = gram + (int64_t)(64 * s + k) * b;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const float D = __shfl(Dl[t], k, 64);
-                    if (D != 0.f) {
-#pragma unroll
-                        for (int s2 = 0; s2 < NSUB; ++s2) {
-                            const int c2 = 64 * s2 + lane;
-                            const float gv = grow[c2 < b ? c2 : 0];
-                            if (c2 < b) rhs[t][s2] = fmaf(D, gv, rhs[t][s2]);                       // :311,317
-                        }
-                    }
-                }
-                if (pending == 0ull) break;
-            }
-        }
-    }
-
-    int base = 0;
-#pragma unroll
-    for (int s = 0; s < NSUB; ++s) {
-        const int c = 64 * s + lane;
-        bool changed = false;
-        if (valid[s]) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                alpha[(int64_t)t * p + j0 + c] = a_cur[t][s];
-                beta[(int64_t)t * p + j0 + c]  = b_cur[t][s];
-                delta[(int64_t)t * p + j0 + c] = d_cur[t][s];
-                changed = changed || (a_start[t][s] != a_cur[t][s]);
-            }
-        }
-        const unsigned long long cm = __ballot(changed);
-        if (changed) {
-            const int pos = base + __popcll(cm & ((1ull << lane) - 1ull));
-            ev_out->idx[pos] = (int32_t)(j0 + c);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) ev_out->delta[t][pos] = a_start[t][s] - a_cur[t][s];
-        }
-        base += __popcll(cm);
-    }
-    if (lane == 0) {
-        ev_out->count = base;
-        atomicAdd(&counters[0], (unsigned long long)base);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // post-sweep reductions over markers (K11).  out[blockIdx.x][kNStat]
 // ---------------------------------------------------------------------------------------------
 constexpr int kNStat = 4 + 16 + 16 + 4 + 2 + 16;   // sum_delta[4] alpha_ss[16] beta_ss[16] class[4] ssq,nnz state[16]
@@ -914,29 +472,36 @@ constexpr int kGramKT = 32;          // rows per LDS tile
 constexpr int kGramLd = 36;          // LDS row stride (floats)
 constexpr int kGramChunk = 64;       // rows per fp32 accumulation chunk (then folded into fp64)
 
+// cross != 0: the cross-Gram of consecutive blocks C = X_{blk-1}' X_blk for blk = blockIdx.y + 1 (all
+// nt x nt tiles, rows = markers of the previous block, row stride = size of block blk).
 __global__ __launch_bounds__(256) void k_gram_mfma(const float* __restrict__ X, int64_t ld, int64_t p, int bsize,
-                                                   float* __restrict__ gram)
+                                                   float* __restrict__ gram, int cross)
 {
     __shared__ __attribute__((aligned(16))) float As[64 * kGramLd];
     __shared__ __attribute__((aligned(16))) float Bs[64 * kGramLd];
-    const int64_t blk = blockIdx.y;
-    const int64_t j0 = blk * bsize;
+    const int64_t blk = cross ? (int64_t)blockIdx.y + 1 : (int64_t)blockIdx.y;
+    const int64_t j0 = blk * bsize;                        // block of the B operand (columns of the output)
     const int b = (int)((j0 + bsize <= p) ? bsize : (p - j0));
-    // tile index -> (ti, tj), ti >= tj, over nt = ceil(bsize/64) tiles per side
-    int ti = 0, rem = blockIdx.x;
-    while (rem > ti) { rem -= ti + 1; ++ti; }
-    const int tj = rem;
-    if (ti * 64 >= b) return;
+    const int64_t jA = cross ? j0 - bsize : j0;            // block of the A operand (rows of the output)
+    const int bA = cross ? bsize : b;
+    int ti = 0, tj = 0;
+    if (cross) { const int nt = bsize / 64; ti = blockIdx.x / nt; tj = blockIdx.x % nt; }
+    else {   // tile index -> (ti, tj), ti >= tj, over nt = ceil(bsize/64) tiles per side
+        int rem = blockIdx.x;
+        while (rem > ti) { rem -= ti + 1; ++ti; }
+        tj = rem;
+    }
+    if (ti * 64 >= bA || tj * 64 >= b) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;              // wave's 32x32 sub-tile
-    const bool diag = (ti == tj);
+    const bool diag = !cross && (ti == tj);
     float* G = gram + blk * (int64_t)bsize * bsize;
 
     // staging: thread -> (marker m = tid/8 [+32], float4 q = tid%8)
     const int sm = tid >> 3, sq = tid & 7;
     const int ma0 = ti * 64 + sm, ma1 = ma0 + 32, mb0 = tj * 64 + sm, mb1 = mb0 + 32;
-    const float* pa0 = X + (j0 + (ma0 < b ? ma0 : 0)) * ld + sq * 4;
-    const float* pa1 = X + (j0 + (ma1 < b ? ma1 : 0)) * ld + sq * 4;
+    const float* pa0 = X + (jA + (ma0 < bA ? ma0 : 0)) * ld + sq * 4;
+    const float* pa1 = X + (jA + (ma1 < bA ? ma1 : 0)) * ld + sq * 4;
     const float* pb0 = X + (j0 + (mb0 < b ? mb0 : 0)) * ld + sq * 4;
     const float* pb1 = X + (j0 + (mb1 < b ? mb1 : 0)) * ld + sq * 4;
     const float4 zero4{0.f, 0.f, 0.f, 0.f};
@@ -960,8 +525,8 @@ __global__ __launch_bounds__(256) void k_gram_mfma(const float* __restrict__ X, 
             vb0 = *reinterpret_cast<const float4*>(pb0 + k0);
             vb1 = *reinterpret_cast<const float4*>(pb1 + k0);
         }
-        if (ma0 >= b) va0 = zero4;
-        if (ma1 >= b) va1 = zero4;
+        if (ma0 >= bA) va0 = zero4;
+        if (ma1 >= bA) va1 = zero4;
         if (mb0 >= b) vb0 = zero4;
         if (mb1 >= b) vb1 = zero4;
         __syncthreads();      // previous tile fully consumed
@@ -998,10 +563,10 @@ __global__ __launch_bounds__(256) void k_gram_mfma(const float* __restrict__ X, 
         const int rr = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
         const int ga = ti * 64 + wm * 32 + rr;
         const int gc = tj * 64 + wn * 32 + (lane & 31);
-        if (ga < b && gc < b) {
+        if (ga < bA && gc < b) {
             const float v = (float)accd[i];
             G[(int64_t)ga * b + gc] = v;
-            if (!diag) G[(int64_t)gc * b + ga] = v;
+            if (!diag && !cross) G[(int64_t)gc * b + ga] = v;
         }
     }
 }

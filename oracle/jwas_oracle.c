@@ -497,6 +497,171 @@ int orc_mtbayesc_I_block_sweep(const float* X, int64_t n, int64_t p, int64_t ld,
     return 0;
 }
 
+
+/* ------------------------------------------------------------------------------------------ */
+/* One-block LOOKAHEAD form of the exact block chain (the schedule the HIP path runs).          */
+/*                                                                                              */
+/* Algebra (exact arithmetic): with r(b-2) the residual that holds the exit updates of blocks   */
+/* <= b-2,   X_b' r(b-1) = X_b' r(b-2) + (X_b' X_{b-1}) d_{b-1},   d = alpha_old - alpha_new.    */
+/* So the block RHS can be formed from the STALE residual r(b-2) (which lets the device stream   */
+/* block b while block b-1 is still being sampled) and corrected with the cross-Gram columns of  */
+/* the markers of block b-1 that changed.  Everything else is BayesABC_block! (BayesABC.jl:     */
+/* 145-187).  Rounding differs from the plain block form only in how rhs_b is assembled:         */
+/*   s[c]  = fl32( sum_i x_ic * r(b-2)_i )            (fp64 accumulation, rounded once)          */
+/*   s[c]  = fmaf(d_j, fl32(x_j'x_c), s[c])           for the changed markers j of block b-1,    */
+/*                                                    in marker order                            */
+/* then r(b-1) = r(b-2) + X_{b-1} d_{b-1} by per-marker fmaf, as before.                         */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct { int64_t n, ld; const float* X; int acc; } la_ctx;
+
+/* rhs (t x b) for block [j0, j0+b) from the stale residuals, corrected by the previous block's
+ * net changes dprev (t x bprev, 0 where unchanged), then the previous exit update is applied. */
+static void la_block_rhs(const la_ctx* L, int t, float* r, int64_t ld_r, int64_t j0, int64_t b,
+                         int64_t jprev, int64_t bprev, const float* dprev, float* rhs)
+{
+    for (int k = 0; k < t; ++k)
+        for (int64_t c = 0; c < b; ++c)
+            rhs[k * b + c] = dot_acc(L->X + (j0 + c) * L->ld, r + k * ld_r, L->n, L->acc);
+    for (int64_t e = 0; e < bprev; ++e) {
+        int any = 0;
+        for (int k = 0; k < t; ++k) any |= (dprev[k * bprev + e] != 0.0f);
+        if (!any) continue;
+        const float* xe = L->X + (jprev + e) * L->ld;
+        for (int64_t c = 0; c < b; ++c) {
+            const float g = dot_acc(xe, L->X + (j0 + c) * L->ld, L->n, L->acc);      /* cross-Gram entry */
+            for (int k = 0; k < t; ++k) rhs[k * b + c] = fmaf(dprev[k * bprev + e], g, rhs[k * b + c]);
+        }
+    }
+    for (int64_t e = 0; e < bprev; ++e)
+        for (int k = 0; k < t; ++k)
+            if (dprev[k * bprev + e] != 0.0f) axpy_f32(dprev[k * bprev + e], L->X + (jprev + e) * L->ld, r + k * ld_r, L->n);
+}
+
+int orc_bayesabc_lookahead_sweep(const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
+                                 const int64_t* block_starts, int64_t nblocks, const float* grams,
+                                 float* r, float* alpha, float* beta, float* delta,
+                                 float vare, const float* var_effects, const double* pi,
+                                 int nreps_arg, uint64_t seed, uint32_t iter, uint32_t marker0, int acc)
+{
+    if (!abc_args_ok(n, p, ld, vare) || !blocks_ok(block_starts, nblocks, p)) return -1;
+    const float ie = 1.0f / vare;
+    const la_ctx L = { n, ld, X, acc };
+    const float* G = grams;
+    float* dprev = NULL; int64_t jprev = 0, bprev = 0;
+    for (int64_t bi = 0; bi < nblocks; ++bi) {
+        const int64_t j0 = block_starts[bi];
+        const int64_t b  = (bi + 1 < nblocks ? block_starts[bi + 1] : p) - j0;
+        float* rhs_b = (float*)malloc(sizeof(float) * (size_t)b);
+        float* a0    = (float*)malloc(sizeof(float) * (size_t)b);
+        la_block_rhs(&L, 1, r, ld, j0, b, jprev, bprev, dprev, rhs_b);
+        memcpy(a0, alpha + j0, sizeof(float) * (size_t)b);
+        const int nreps = nreps_arg > 0 ? nreps_arg : (int)b;
+        for (int rep = 0; rep < nreps; ++rep)
+            for (int64_t k = 0; k < b; ++k) {
+                const int64_t j = j0 + k;
+                const uint32_t m = marker0 + (uint32_t)j;
+                const double u = orc_uniform(seed, m, iter, (uint32_t)rep, 0);
+                const double z = orc_normal(seed, m, iter, (uint32_t)rep, 0);
+                const float a = abc_update(rhs_b[k], xpx[j], &alpha[j], &beta[j], &delta[j], ie, var_effects[j], pi[j], u, z);
+                if (a != 0.0f) axpy_f32(a, G + k * b, rhs_b, b);
+            }
+        for (int64_t k = 0; k < b; ++k) a0[k] = a0[k] - alpha[j0 + k];          /* net change of the block */
+        free(dprev); free(rhs_b);
+        dprev = a0; jprev = j0; bprev = b;
+        G += b * b;
+    }
+    for (int64_t e = 0; e < bprev; ++e) if (dprev[e] != 0.0f) axpy_f32(dprev[e], X + (jprev + e) * ld, r, n);
+    free(dprev);
+    return 0;
+}
+
+int orc_bayesr_lookahead_sweep(const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
+                               const int64_t* block_starts, int64_t nblocks, const float* grams,
+                               float* r, float* alpha, int32_t* delta,
+                               float vare, float sigma_sq, const double* pi, int pi_is_matrix,
+                               const double* gamma, int nreps_arg,
+                               uint64_t seed, uint32_t iter, uint32_t marker0, int acc)
+{
+    if (!abc_args_ok(n, p, ld, vare) || !bayesr_priors_ok(pi, pi_is_matrix, p) ||
+        !blocks_ok(block_starts, nblocks, p)) return -1;
+    if (!(sigma_sq > 0.0f)) return -2;
+    const float ie = 1.0f / vare;
+    const la_ctx L = { n, ld, X, acc };
+    const float* G = grams;
+    float* dprev = NULL; int64_t jprev = 0, bprev = 0;
+    for (int64_t bi = 0; bi < nblocks; ++bi) {
+        const int64_t j0 = block_starts[bi];
+        const int64_t b  = (bi + 1 < nblocks ? block_starts[bi + 1] : p) - j0;
+        float* rhs_b = (float*)malloc(sizeof(float) * (size_t)b);
+        float* a0    = (float*)malloc(sizeof(float) * (size_t)b);
+        la_block_rhs(&L, 1, r, ld, j0, b, jprev, bprev, dprev, rhs_b);
+        memcpy(a0, alpha + j0, sizeof(float) * (size_t)b);
+        const int nreps = nreps_arg > 0 ? nreps_arg : (int)b;
+        for (int rep = 0; rep < nreps; ++rep)
+            for (int64_t k = 0; k < b; ++k) {
+                const int64_t j = j0 + k;
+                const uint32_t m = marker0 + (uint32_t)j;
+                const double u = orc_uniform(seed, m, iter, (uint32_t)rep, 0);
+                const double z = orc_normal(seed, m, iter, (uint32_t)rep, 0);
+                const float a = bayesr_update(rhs_b[k], xpx[j], &alpha[j], &delta[j], ie, sigma_sq,
+                                              pi_is_matrix ? pi + 4 * j : pi, gamma, u, z);
+                if (a != 0.0f) axpy_f32(a, G + k * b, rhs_b, b);
+            }
+        for (int64_t k = 0; k < b; ++k) a0[k] = a0[k] - alpha[j0 + k];
+        free(dprev); free(rhs_b);
+        dprev = a0; jprev = j0; bprev = b;
+        G += b * b;
+    }
+    for (int64_t e = 0; e < bprev; ++e) if (dprev[e] != 0.0f) axpy_f32(dprev[e], X + (jprev + e) * ld, r, n);
+    free(dprev);
+    return 0;
+}
+
+int orc_mtbayesc_I_lookahead_sweep(const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
+                                   const int64_t* block_starts, int64_t nblocks, const float* grams,
+                                   int t, float* r, int64_t ld_r, float* alpha, float* beta, float* delta,
+                                   const float* vare, const float* var_effect,
+                                   const double* log_prior, int prior_is_matrix, int nreps_arg,
+                                   uint64_t seed, uint32_t iter, uint32_t marker0, int acc)
+{
+    if (t < 1 || t > ORC_MAXT || n <= 0 || ld < n || ld_r < n || !blocks_ok(block_starts, nblocks, p)) return -1;
+    float Rinv[ORC_MAXT * ORC_MAXT], Ginv[ORC_MAXT * ORC_MAXT];
+    if (inv_small(vare, t, Rinv) || inv_small(var_effect, t, Ginv)) return -2;
+    const int nstates = 1 << t;
+    const la_ctx L = { n, ld, X, acc };
+    const float* G = grams;
+    float* dprev = NULL; int64_t jprev = 0, bprev = 0;
+    for (int64_t bi = 0; bi < nblocks; ++bi) {
+        const int64_t j0 = block_starts[bi];
+        const int64_t b  = (bi + 1 < nblocks ? block_starts[bi + 1] : p) - j0;
+        float* rhs_b = (float*)malloc(sizeof(float) * (size_t)(b * t));
+        float* a0    = (float*)malloc(sizeof(float) * (size_t)(b * t));
+        la_block_rhs(&L, t, r, ld_r, j0, b, jprev, bprev, dprev, rhs_b);
+        for (int k = 0; k < t; ++k) memcpy(a0 + k * b, alpha + k * p + j0, sizeof(float) * (size_t)b);
+        const int nreps = nreps_arg > 0 ? nreps_arg : (int)b;
+        for (int rep = 0; rep < nreps; ++rep)
+            for (int64_t c = 0; c < b; ++c) {
+                const int64_t j = j0 + c;
+                float w[ORC_MAXT], a[ORC_MAXT];
+                for (int k = 0; k < t; ++k) w[k] = rhs_b[k * b + c] + xpx[j] * alpha[k * p + j];
+                mt1_update(t, w, xpx[j], alpha + j, beta + j, delta + j, p, Rinv, Ginv,
+                           prior_is_matrix ? log_prior + (int64_t)nstates * j : log_prior,
+                           seed, marker0 + (uint32_t)j, iter, (uint32_t)rep, a);
+                for (int k = 0; k < t; ++k) if (a[k] != 0.0f) axpy_f32(a[k], G + c * b, rhs_b + k * b, b);
+            }
+        for (int k = 0; k < t; ++k)
+            for (int64_t c = 0; c < b; ++c) a0[k * b + c] = a0[k * b + c] - alpha[k * p + j0 + c];
+        free(dprev); free(rhs_b);
+        dprev = a0; jprev = j0; bprev = b;
+        G += b * b;
+    }
+    for (int64_t e = 0; e < bprev; ++e)
+        for (int k = 0; k < t; ++k)
+            if (dprev[k * bprev + e] != 0.0f) axpy_f32(dprev[k * bprev + e], X + (jprev + e) * ld, r + k * ld_r, n);
+    free(dprev);
+    return 0;
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* running posterior means (output.jl:568-577)                                                 */
 /* ------------------------------------------------------------------------------------------ */

@@ -117,6 +117,29 @@ int orc_mtbayesc_I_block_sweep(const float* X, int64_t n, int64_t p, int64_t ld,
                                const double* log_prior, int prior_is_matrix, int nreps,
                                uint64_t seed, uint32_t iter, uint32_t marker0, int acc);
 
+/* ---- one-block LOOKAHEAD schedule of the exact block chain (what the HIP path runs) ---------- */
+/* Same chain as the *_block_sweep functions in exact arithmetic; the block RHS is assembled from the
+ * residual that lacks the previous block's exit update, then corrected with the cross-Gram of the
+ * previous block's changed markers (see jwas_oracle.c).  Lets the device overlap sampling of block b
+ * with streaming block b+1. */
+int orc_bayesabc_lookahead_sweep(const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
+                                 const int64_t* block_starts, int64_t nblocks, const float* grams,
+                                 float* r, float* alpha, float* beta, float* delta,
+                                 float vare, const float* var_effects, const double* pi,
+                                 int nreps, uint64_t seed, uint32_t iter, uint32_t marker0, int acc);
+int orc_bayesr_lookahead_sweep(const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
+                               const int64_t* block_starts, int64_t nblocks, const float* grams,
+                               float* r, float* alpha, int32_t* delta,
+                               float vare, float sigma_sq, const double* pi, int pi_is_matrix,
+                               const double* gamma, int nreps,
+                               uint64_t seed, uint32_t iter, uint32_t marker0, int acc);
+int orc_mtbayesc_I_lookahead_sweep(const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
+                                   const int64_t* block_starts, int64_t nblocks, const float* grams,
+                                   int t, float* r, int64_t ld_r, float* alpha, float* beta, float* delta,
+                                   const float* vare, const float* var_effect,
+                                   const double* log_prior, int prior_is_matrix, int nreps,
+                                   uint64_t seed, uint32_t iter, uint32_t marker0, int acc);
+
 /* ---- running posterior means (output.jl:568-577) ------------------------------------------ */
 /* mean += (x-mean)/k ; mean2 += (x^2-mean2)/k ; freq += (ind-freq)/k, ind = delta (BayesC) or
  * delta>1 (BayesR, delta_is_class != 0). */

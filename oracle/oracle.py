@@ -128,8 +128,9 @@ def _vec_or_fill(v, p, dtype):
 
 
 def bayesabc_sweep(X, xpx_, r, alpha, beta, delta, vare, var_effects, pi, seed, it,
-                   marker0=0, acc=ACC_F64, block_starts=None, grams=None, nreps=1):
-    """In-place sweep.  block_starts=None -> non-block form (BayesABC.jl:60-80)."""
+                   marker0=0, acc=ACC_F64, block_starts=None, grams=None, nreps=1, lookahead=False):
+    """In-place sweep.  block_starts=None -> non-block form (BayesABC.jl:60-80); lookahead=True ->
+    the one-block lookahead schedule of the block form (what the HIP path runs)."""
     n, p, ld = _xinfo(X)
     ve = _vec_or_fill(var_effects, p, np.float32)
     pv = np.asarray(pi, dtype=np.float64)
@@ -147,7 +148,8 @@ def bayesabc_sweep(X, xpx_, r, alpha, beta, delta, vare, var_effects, pi, seed, 
     else:
         bs = np.ascontiguousarray(block_starts, dtype=np.int64)
         g = _f32(grams)
-        rc = lib().orc_bayesabc_block_sweep(_p(X, _f32p), C.c_int64(n), C.c_int64(p), C.c_int64(ld), _p(xpx_, _f32p),
+        fn = lib().orc_bayesabc_lookahead_sweep if lookahead else lib().orc_bayesabc_block_sweep
+        rc = fn(_p(X, _f32p), C.c_int64(n), C.c_int64(p), C.c_int64(ld), _p(xpx_, _f32p),
                                             _p(bs, _i64p), C.c_int64(len(bs)), _p(g, _f32p),
                                             _p(r, _f32p), _p(alpha, _f32p), _p(beta, _f32p), _p(delta, _f32p),
                                             C.c_float(vare), _p(ve, _f32p), _p(pv, _f64p), C.c_int(nreps),
@@ -157,7 +159,7 @@ def bayesabc_sweep(X, xpx_, r, alpha, beta, delta, vare, var_effects, pi, seed, 
 
 
 def bayesr_sweep(X, xpx_, r, alpha, delta, vare, sigma_sq, pi, seed, it, gamma=GAMMA,
-                 marker0=0, acc=ACC_F64, block_starts=None, grams=None, nreps=1):
+                 marker0=0, acc=ACC_F64, block_starts=None, grams=None, nreps=1, lookahead=False):
     n, p, ld = _xinfo(X)
     pv = np.ascontiguousarray(pi, dtype=np.float64)
     is_mat = int(pv.ndim == 2)
@@ -179,7 +181,8 @@ def bayesr_sweep(X, xpx_, r, alpha, delta, vare, sigma_sq, pi, seed, it, gamma=G
     else:
         bs = np.ascontiguousarray(block_starts, dtype=np.int64)
         g = _f32(grams)
-        rc = lib().orc_bayesr_block_sweep(_p(X, _f32p), C.c_int64(n), C.c_int64(p), C.c_int64(ld), _p(xpx_, _f32p),
+        fn = lib().orc_bayesr_lookahead_sweep if lookahead else lib().orc_bayesr_block_sweep
+        rc = fn(_p(X, _f32p), C.c_int64(n), C.c_int64(p), C.c_int64(ld), _p(xpx_, _f32p),
                                           _p(bs, _i64p), C.c_int64(len(bs)), _p(g, _f32p),
                                           _p(r, _f32p), _p(alpha, _f32p), _p(delta, _i32p),
                                           C.c_float(vare), C.c_float(sigma_sq), _p(pv, _f64p), C.c_int(is_mat),
@@ -210,7 +213,7 @@ def bayesr_sigma_suffstats(alpha, delta, gamma=GAMMA):
 
 
 def mtbayesc_I_sweep(X, xpx_, r, alpha, beta, delta, vare, var_effect, log_prior, seed, it,
-                     marker0=0, acc=ACC_F64, block_starts=None, grams=None, nreps=1):
+                     marker0=0, acc=ACC_F64, block_starts=None, grams=None, nreps=1, lookahead=False):
     """r: t x ld_r float32 C-contiguous; alpha/beta/delta: t x p float32 C-contiguous.
     log_prior: 2^t (global) or p x 2^t (marker-specific), float64."""
     n, p, ld = _xinfo(X)
@@ -231,7 +234,8 @@ def mtbayesc_I_sweep(X, xpx_, r, alpha, beta, delta, vare, var_effect, log_prior
     else:
         bs = np.ascontiguousarray(block_starts, dtype=np.int64)
         g = _f32(grams)
-        rc = lib().orc_mtbayesc_I_block_sweep(_p(X, _f32p), C.c_int64(n), C.c_int64(p), C.c_int64(ld), _p(xpx_, _f32p),
+        fn = lib().orc_mtbayesc_I_lookahead_sweep if lookahead else lib().orc_mtbayesc_I_block_sweep
+        rc = fn(_p(X, _f32p), C.c_int64(n), C.c_int64(p), C.c_int64(ld), _p(xpx_, _f32p),
                                               _p(bs, _i64p), C.c_int64(len(bs)), _p(g, _f32p),
                                               C.c_int(t), _p(r, _f32p), C.c_int64(ld_r),
                                               _p(alpha, _f32p), _p(beta, _f32p), _p(delta, _f32p),

@@ -64,7 +64,7 @@ def main():
     X = centered(raw)
     blob = {"raw": raw, "y1": y1, "y2": y2, "seed": np.int64(SEED)}
     for name, case in CASES.items():
-        res = run_case(OracleEngine("block"), X, [y1, y2], case)
+        res = run_case(OracleEngine("lookahead"), X, [y1, y2], case)
         for k, v in res.items():
             blob[f"{name}/{k}"] = v
     np.savez_compressed(os.path.join(HERE, "sweep_golden.npz"), **blob)

@@ -15,7 +15,8 @@ METHOD_CODES = {"BayesC": BAYESC, "BayesB": BAYESB, "BayesA": BAYESB, "BayesR": 
 
 
 class OracleEngine:
-    """form='block' mirrors the device algorithm (exact block form with the same block size);
+    """form='lookahead' mirrors the device schedule exactly (exact block form, one-block lookahead,
+    same block size); form='block' is the plain block restatement (BayesABC.jl:118-188);
     form='dense' is the literal non-block restatement (BayesABC.jl:60-80)."""
 
     def __init__(self, form="block", acc=O.ACC_F64):
@@ -94,7 +95,8 @@ class OracleEngine:
               log_prior_states=None, var_effect_vec=None, pi_vec=None, pi_matrix=None, nreps=1,
               marker_offset=0):
         t = self.ntraits
-        blk = dict(block_starts=self._bs, grams=self._grams, nreps=nreps) if self.form == "block" else {}
+        blk = (dict(block_starts=self._bs, grams=self._grams, nreps=nreps, lookahead=(self.form == "lookahead"))
+               if self.form in ("block", "lookahead") else {})
         a_before = self.alpha.copy()
         if self.method in (BAYESC, BAYESB):
             if np.ndim(pi) == 1:

@@ -31,7 +31,7 @@ def test_library_contains_gfx950_code_object():
     from jwas_jl_amd import _lib
     blob = open(_lib.LIB_PATH, "rb").read()
     assert b"gfx950" in blob
-    assert b"k_update_partial" in blob and b"k_sample_block" in blob
+    assert b"k_block_step" in blob and b"k_prepare" in blob
 
 
 def test_memory_estimate_formula():

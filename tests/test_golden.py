@@ -27,7 +27,7 @@ def _check(engine, name):
 
 @pytest.mark.parametrize("name", list(MG.CASES))
 def test_oracle_reproduces_golden(name):
-    _check(OracleEngine("block"), name)
+    _check(OracleEngine("lookahead"), name)
 
 
 @pytest.mark.gpu

@@ -26,7 +26,7 @@ def _setup(method, Pi, n=400, p=1500, seed=31):
 def test_runmcmc_gpu_matches_oracle_chain(tmp_path, method, Pi):
     gdf, ph, d = _setup(method, Pi)
     outs = {}
-    for tag, eng in (("orc", OracleEngine("block")), ("hip", None)):
+    for tag, eng in (("orc", OracleEngine("lookahead")), ("hip", None)):
         geno = api.get_genotypes(gdf, method=method, Pi=Pi)
         model = api.build_model("y1 = intercept + geno")
         outs[tag] = api.runMCMC(model, ph, chain_length=200, burnin=40, seed=2026, output_folder=str(tmp_path / tag),

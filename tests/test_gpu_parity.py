@@ -23,7 +23,7 @@ def hip():
 
 def _pair(hip, data, block_size, method, ntraits=1, gram_mode="f64"):
     X = data["X"]
-    orc = OracleEngine(form="block")
+    orc = OracleEngine(form="lookahead")
     orc.load_dense(X)
     orc.setup_blocks(block_size)
     orc.init_state(method, ntraits)
