@@ -237,10 +237,10 @@ static int alloc_storage(jwas_hip_ctx* c, int64_t n, int64_t p)
     HIPCHK(c, hipMalloc(&c->ev, sizeof(Events) * 2));
     HIPCHK(c, hipMemsetAsync(c->ev, 0, sizeof(Events) * 2, c->stream));
     HIPCHK(c, hipMalloc(&c->dparams, sizeof(DevParams)));
-    HIPCHK(c, hipMalloc(&c->counters, sizeof(unsigned long long) * 4));
+    HIPCHK(c, hipMalloc(&c->counters, sizeof(unsigned long long) * 8));
     HIPCHK(c, hipMalloc(&c->fin_out, sizeof(double) * c->nslices * (kMaxT * kMaxT + kMaxT)));
     HIPCHK(c, hipMalloc(&c->stat_out, sizeof(double) * kStatGrid * kNStat));
-    HIPCHK(c, hipHostMalloc(&c->host_buf, sizeof(double) * ((size_t)c->nslices * (kMaxT * kMaxT + kMaxT) + kStatGrid * kNStat + 8)));
+    HIPCHK(c, hipHostMalloc(&c->host_buf, sizeof(double) * ((size_t)c->nslices * (kMaxT * kMaxT + kMaxT) + kStatGrid * kNStat + 16)));
     return JWAS_HIP_OK;
 }
 
@@ -538,7 +538,7 @@ int jwas_hip_mul_alpha(jwas_hip_ctx* c, int32_t trait, float* out)
 template <int METHOD, int NT>
 static hipError_t launch_step(jwas_hip_ctx* c, const UpdateArgs& U, const SamplerArgs& S, int do_sample)
 {
-    const StepSmem SM(c->block_size, NT);
+    const StepSmem SM(c->block_size, NT, METHOD == kMTBayesC1 ? 0 : (METHOD == kBayesR ? 12 : 4), METHOD == kMTBayesC1 ? 0 : (METHOD == kBayesR ? 1 : 4));
     static bool attr_set = false;
     if (!attr_set) {   // allow > 64 KB of dynamic LDS
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_block_step<METHOD, NT>),
@@ -546,8 +546,11 @@ static hipError_t launch_step(jwas_hip_ctx* c, const UpdateArgs& U, const Sample
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_block_step<METHOD, NT>), dim3(1 + c->nrg * U.ncg), dim3(kStepThreads), SM.bytes, c->stream,
-                       U, S, do_sample);
+    // JWAS_HIP_DEBUG_ROLE (timing experiments only; results are wrong): 1 = update role only, 2 = sampler only
+    static const int dbg = std::getenv("JWAS_HIP_DEBUG_ROLE") ? std::atoi(std::getenv("JWAS_HIP_DEBUG_ROLE")) : 0;
+    const unsigned grid = (dbg == 2) ? 1u : (unsigned)(1 + c->nrg * U.ncg);
+    hipLaunchKernelGGL((k_block_step<METHOD, NT>), dim3(grid), dim3(kStepThreads), SM.bytes, c->stream,
+                       U, S, (dbg == 1) ? 0 : do_sample);
     return hipSuccess;
 }
 
@@ -624,7 +627,7 @@ int jwas_hip_sweep(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_sweep_stats
     }
     HIPCHK(c, hipMemcpyAsync(c->dparams, &D, sizeof D, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(&c->ev[0].count, 0, sizeof(int32_t), c->stream));
-    HIPCHK(c, hipMemsetAsync(c->counters, 0, sizeof(unsigned long long) * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->counters, 0, sizeof(unsigned long long) * 8, c->stream));
     HIPCHK(c, hipEventRecord(c->ev_start, c->stream));
 
     {   // per-sweep marker constants (draws, prior logs, lhs terms) for all p markers in parallel
@@ -712,7 +715,7 @@ int jwas_hip_sweep(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_sweep_stats
     unsigned long long* h_cnt = reinterpret_cast<unsigned long long*>(h_stat + (size_t)kStatGrid * kNStat);
     HIPCHK(c, hipMemcpyAsync(h_fin, c->fin_out, sizeof(double) * c->nslices * nfin, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(h_stat, c->stat_out, sizeof(double) * kStatGrid * kNStat, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(h_cnt, c->counters, sizeof(unsigned long long) * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(h_cnt, c->counters, sizeof(unsigned long long) * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
 
     std::memset(S, 0, sizeof *S);
@@ -732,6 +735,9 @@ int jwas_hip_sweep(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_sweep_stats
         for (int q = 0; q < (1 << t) && q < kMaxStates; ++q) S->state_counts[q] += v[42 + q];
     }
     S->n_events = (double)h_cnt[0];
+    if (std::getenv("JWAS_HIP_DEBUG_PHASES"))
+        std::fprintf(stderr, "[jwas_hip] blocks=%lld events=%llu unstaged=%llu cycles: front=%llu cand=%llu stage=%llu serial=%llu write=%llu rounds=%llu\n",
+                     (long long)c->nblocks, h_cnt[0], h_cnt[1], h_cnt[2], h_cnt[3], h_cnt[4], h_cnt[5], h_cnt[6], h_cnt[7]);
     float ms = 0.f;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev_start, c->ev_stop));
     S->sweep_ms = ms;

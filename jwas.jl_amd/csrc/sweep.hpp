@@ -33,24 +33,31 @@ namespace jw {
 
 constexpr int kStepThreads = 512;
 constexpr int kRowsBytes = 96 * 1024;          // LDS budget for staged Gram rows (sampler role)
-
-// Dynamic-LDS carve of one step workgroup (bytes); B = block size, NT = traits.
+// Dynamic-LDS carve of one step workgroup (bytes); B = block size, NT = traits, (nd, nf) = doubles /
+// floats of per-marker sampler constants staged for the serial wave (0 = none).
+constexpr int kLdsBytes = 160 * 1024;
 struct StepSmem {
     int B, NT, max_cand;
-    int rhs_off, acur_off, bcur_off, dcur_off, slot_off, cand_off, wcnt_off, rows_off, bytes;
-    __host__ __device__ StepSmem(int B_, int NT_) : B(B_), NT(NT_)
+    int rhs_off, acur_off, astart_off, bcur_off, dcur_off, slot_off, cand_off, wcnt_off, log_off, prepd_off, prepf_off, rows_off, bytes;
+    __host__ __device__ StepSmem(int B_, int NT_, int nd, int nf) : B(B_), NT(NT_)
     {
-        max_cand = kRowsBytes / (4 * B);
-        if (max_cand > B) max_cand = B;
         rhs_off  = 0;                               // float [NT][B]  running block RHS
         acur_off = rhs_off + NT * B * 4;            // float [NT][B]  current alpha
-        bcur_off = acur_off + NT * B * 4;           // float [NT][B]  current beta   (multi-trait)
+        astart_off = acur_off + NT * B * 4;         // float [NT][B]  alpha at block entry
+        bcur_off = astart_off + NT * B * 4;         // float [NT][B]  current beta   (multi-trait)
         dcur_off = bcur_off + NT * B * 4;           // float [NT][B]  current delta  (multi-trait)
         slot_off = dcur_off + NT * B * 4;           // int16 [B]      LDS slot of a marker's Gram row, -1 = not staged
-        cand_off = slot_off + B * 2;                // int16 [max_cand]
-        wcnt_off = (cand_off + max_cand * 2 + 15) / 16 * 16;   // int [16]
-        rows_off = wcnt_off + 64;                   // float [max_cand][B]
-        const int samp = rows_off + max_cand * B * 4;
+        cand_off = slot_off + B * 2;                // int16 [B]
+        wcnt_off = (cand_off + B * 2 + 15) / 16 * 16;          // int [16]
+        log_off  = wcnt_off + 64;                   // int2  [B]      committed changes of this block: {slot, bits(D)}
+        prepd_off = log_off + B * 8;                // double [nd][B] per-marker constants (rep 0)
+        prepf_off = prepd_off + nd * B * 8;         // float  [nf][B]
+        rows_off = prepf_off + nf * B * 4;          // float [max_cand + 1][B] staged Gram rows + one overflow row
+        int room = (kLdsBytes - 1024 - rows_off) / (4 * B) - 1;
+        if (room > kRowsBytes / (4 * B)) room = kRowsBytes / (4 * B);
+        max_cand = room < B ? room : B;
+        if (max_cand < 1) max_cand = 1;
+        const int samp = rows_off + (max_cand + 1) * B * 4;
         const int red = kRowGroupSlices * kColChunk * NT * 8;   // update role: double [8][64][NT]
         bytes = samp > red ? samp : red;
     }
@@ -88,7 +95,10 @@ __device__ __forceinline__ void update_role(char* smem, int rg, int g,
     };
 
     // (1) the first batch of column loads does not depend on r: issue it before the update.
-    float4 xa[kU], xb[kU];
+    //     In-flight depth is ONE batch per wave (8 KB): with ~1600 waves streaming that is ~13 MB outstanding,
+    //     enough for full HBM rate; doubling it only lengthens the memory queues (Little's law) and with them
+    //     the latency of every dependent load of the concurrently running sampler role.
+    float4 xa[kU];
     load_batch(xa, 0);
 
     // (2) sparse exit update: sequential fmaf in marker order, bit-identical to the oracle's per-marker
@@ -119,31 +129,26 @@ __device__ __forceinline__ void update_role(char* smem, int rg, int g,
     }
 
     // (3) partial block RHS.
-    auto consume = [&](const float4 (&xv)[kU], int ib, int i0) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            double acc[kU];
-#pragma unroll
-            for (int u = 0; u < kU; ++u) {
-                acc[u] = (double)xv[u].x * rd[t][0];
-                acc[u] = fma((double)xv[u].y, rd[t][1], acc[u]);
-                acc[u] = fma((double)xv[u].z, rd[t][2], acc[u]);
-                acc[u] = fma((double)xv[u].w, rd[t][3], acc[u]);
-            }
-            const double s = butterfly8(acc, lane);
-            const int u = lane >> 3;                       // column of this 8-lane group
-            if ((lane & 7) == 0 && ib + u < ncols) red[wave][ib + u - i0][t] = s;
-        }
-    };
-
     for (int i0 = 0; i0 < ncols; i0 += kColChunk) {
         const int iend = (i0 + kColChunk < ncols) ? i0 + kColChunk : ncols;
-        // two batches per trip so both register sets are statically indexed
-        for (int ib = i0; ib < iend; ib += 2 * kU) {
-            if (ib + kU < ncols) load_batch(xb, ib + kU);
-            consume(xa, ib, i0);
-            if (ib + 2 * kU < ncols) load_batch(xa, ib + 2 * kU);
-            if (ib + kU < iend) consume(xb, ib + kU, i0);
+        for (int ib = i0; ib < iend; ib += kU) {
+            double acc[NT][kU];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int u = 0; u < kU; ++u) {
+                    acc[t][u] = (double)xa[u].x * rd[t][0];
+                    acc[t][u] = fma((double)xa[u].y, rd[t][1], acc[t][u]);
+                    acc[t][u] = fma((double)xa[u].z, rd[t][2], acc[t][u]);
+                    acc[t][u] = fma((double)xa[u].w, rd[t][3], acc[t][u]);
+                }
+            if (ib + kU < ncols) load_batch(xa, ib + kU);      // registers are free again: next batch in flight
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const double s = butterfly8(acc[t], lane);
+                const int u = lane >> 3;                       // column of this 8-lane group
+                if ((lane & 7) == 0 && ib + u < ncols) red[wave][ib + u - i0][t] = s;
+            }
         }
         __syncthreads();
         for (int q = tid; q < (iend - i0) * NT; q += kStepThreads) {
@@ -189,34 +194,61 @@ __device__ __forceinline__ void sampler_front(char* smem, const StepSmem& SM, co
     const int tid = threadIdx.x;
     const int b = A.b;
     // rhs_b[c] = sum over row groups (fp64, fixed order), rounded once to fp32; then the lookahead
-    // correction for the previous block's changed markers, in marker order.
+    // correction for the previous block's changed markers, in marker order.  All loads of a column are
+    // independent of each other: they are issued back to back (one memory latency, not one per load).
+    constexpr int kPB = 16;                       // row-group partials per batch
+    constexpr int kEB = 8;                        // cross-Gram entries per batch
     const int ne = A.ev_prev->count;
     for (int c = tid; c < B; c += kStepThreads) {
         const int cc = c < b ? c : 0;
+        float a0[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) a0[t] = A.alpha[(int64_t)t * A.p + A.j0 + cc];
+        float g0[kEB];
+#pragma unroll
+        for (int u = 0; u < kEB; ++u)             // first cross batch: rows of (possibly stale) idx entries are valid addresses
+            g0[u] = A.cross[(int64_t)(((u < ne) ? A.ev_prev->idx[u] : (int)A.j0_prev) - A.j0_prev) * b + cc];
         float rv[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
+            const double* pp = A.partials + (int64_t)t * A.nrg * A.bstride + cc;
             double s = 0.0;
-            for (int rg = 0; rg < A.nrg; ++rg) s += A.partials[((int64_t)t * A.nrg + rg) * A.bstride + cc];
+            for (int rg = 0; rg < A.nrg; rg += kPB) {
+                double v[kPB];
+#pragma unroll
+                for (int u = 0; u < kPB; ++u) v[u] = pp[(int64_t)(rg + u < A.nrg ? rg + u : A.nrg - 1) * A.bstride];
+#pragma unroll
+                for (int u = 0; u < kPB; ++u) if (rg + u < A.nrg) s += v[u];
+            }
             rv[t] = (float)s;
         }
-#pragma unroll 8
-        for (int e = 0; e < ne; ++e) {
-            const float g = A.cross[(int64_t)(A.ev_prev->idx[e] - A.j0_prev) * b + cc];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) rv[t] = fmaf(A.ev_prev->delta[t][e], g, rv[t]);
+        for (int u = 0; u < kEB; ++u)
+            if (u < ne)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) rv[t] = fmaf(A.ev_prev->delta[t][u], g0[u], rv[t]);
+        for (int e0 = kEB; e0 < ne; e0 += kEB) {
+            float g[kEB];
+#pragma unroll
+            for (int u = 0; u < kEB; ++u)
+                g[u] = A.cross[(int64_t)(A.ev_prev->idx[e0 + u < ne ? e0 + u : ne - 1] - A.j0_prev) * b + cc];
+#pragma unroll
+            for (int u = 0; u < kEB; ++u)
+                if (e0 + u < ne)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) rv[t] = fmaf(A.ev_prev->delta[t][e0 + u], g[u], rv[t]);
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             rhs_lds[t * B + c] = rv[t];
-            acur[t * B + c] = (c < b) ? A.alpha[(int64_t)t * A.p + A.j0 + cc] : 0.f;
+            acur[t * B + c] = (c < b) ? a0[t] : 0.f;
         }
     }
     __syncthreads();
 }
 
 // Stage the Gram rows of the candidate markers (cand[q] for marker c = tid + q*kStepThreads) in LDS.
-__device__ __forceinline__ void stage_rows(char* smem, const StepSmem& SM, const SamplerArgs& A, const bool (&cand)[2])
+__device__ __forceinline__ int stage_rows(char* smem, const StepSmem& SM, const SamplerArgs& A, const bool (&cand)[2])
 {
     const int B = SM.B;
     short* slot_of = reinterpret_cast<short*>(smem + SM.slot_off);
@@ -247,11 +279,23 @@ __device__ __forceinline__ void stage_rows(char* smem, const StepSmem& SM, const
         __syncthreads();
     }
     const int ncand = base < SM.max_cand ? base : SM.max_cand;
-    for (int s = wave; s < ncand; s += kStepThreads / 64) {
-        const float* grow = A.gram + (int64_t)cand_list[s] * b;
-        for (int c = lane; c < B; c += 64) rows[s * B + c] = grow[c < b ? c : 0];
+    // (row, 64-column chunk) tasks, 8 independent loads in flight per wave
+    const int nchunk = B / 64, ntask = ncand * nchunk;
+    for (int t0 = wave * 8; t0 < ntask; t0 += (kStepThreads / 64) * 8) {
+        float v[8];
+        int dst[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int task = (t0 + u < ntask) ? t0 + u : ntask - 1;
+            const int row = task / nchunk, c = (task - row * nchunk) * 64 + lane;
+            v[u] = A.gram[(int64_t)cand_list[row] * b + (c < b ? c : 0)];
+            dst[u] = row * B + c;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (t0 + u < ntask) rows[dst[u]] = v[u];
     }
     __syncthreads();
+    return ncand;
 }
 
 // rhs[t][:] += D[t] * G[ce][:]  for the committed marker ce (BayesABC.jl:169,172); one wave.
@@ -263,13 +307,23 @@ __device__ __forceinline__ void apply_gram_row(char* smem, const StepSmem& SM, c
     float* rhs_lds = reinterpret_cast<float*>(smem + SM.rhs_off);
     const short* slot_of = reinterpret_cast<const short*>(smem + SM.slot_off);
     const float* rows = reinterpret_cast<const float*>(smem + SM.rows_off);
-    const int sl = slot_of[ce];
-    const float* grow = A.gram + (int64_t)ce * b;                 // symmetric: row = column
-    for (int c2 = lane; c2 < B; c2 += 64) {
-        const float g = (sl >= 0) ? rows[sl * B + c2] : grow[c2 < b ? c2 : 0];
+    const int sl = __builtin_amdgcn_readfirstlane((int)slot_of[ce]);
+    if (sl >= 0) {                                               // staged row: LDS only (explicit branch --
+        for (int c2 = lane; c2 < B; c2 += 64) {                  // a select would still issue the global load)
+            const float g = rows[sl * B + c2];
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
-            if (D[t] != 0.f) rhs_lds[t * B + c2] = fmaf(D[t], g, rhs_lds[t * B + c2]);
+            for (int t = 0; t < NT; ++t)
+                if (D[t] != 0.f) rhs_lds[t * B + c2] = fmaf(D[t], g, rhs_lds[t * B + c2]);
+        }
+    } else {
+        const float* grow = A.gram + (int64_t)ce * b;             // symmetric: row = column
+        for (int c2 = lane; c2 < B; c2 += 64) {
+            const float g = grow[c2 < b ? c2 : 0];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                if (D[t] != 0.f) rhs_lds[t * B + c2] = fmaf(D[t], g, rhs_lds[t * B + c2]);
+        }
+        atomicAdd(&A.counters[1], 1ull);                          // diagnostic: changes whose row was not staged
     }
 }
 
@@ -279,47 +333,124 @@ __device__ __forceinline__ void apply_gram_row(char* smem, const StepSmem& SM, c
 template <int METHOD>
 __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A)
 {
-    const StepSmem SM(A.bsz, 1);
+    constexpr int ND = (METHOD == kBayesR) ? 12 : 4, NF = (METHOD == kBayesR) ? 1 : 4;
+    const StepSmem SM(A.bsz, 1, ND, NF);
     const int B = SM.B;
     const DevParams* P = A.P;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = A.b;
     const int64_t j0 = A.j0, p = A.p;
     const float ie = 1.0f / P->vare[0];
+    double* lpd = reinterpret_cast<double*>(smem + SM.prepd_off);     // [ND][B]
+    float* lpf = reinterpret_cast<float*>(smem + SM.prepf_off);       // [NF][B]
     float* rhs_lds = reinterpret_cast<float*>(smem + SM.rhs_off);
     float* acur = reinterpret_cast<float*>(smem + SM.acur_off);
+    float* astart = reinterpret_cast<float*>(smem + SM.astart_off);
+    const long long tk0 = clock64();
 
-    sampler_front<1>(smem, SM, A);
-
-    // candidates: markers whose effect changes if evaluated against the entry rhs (all threads)
+    // ---- phase A (all threads, ONE memory latency): for its marker every thread issues, back to back, the
+    // loads of alpha, the sweep constants, the row-group partials and the first cross-Gram entries; then
+    //   rhs = fl32(sum of partials) ; rhs = fmaf(d_j, C[j][c], rhs) for the previous block's changes (marker order)
+    // and decides candidacy (does the effect change if evaluated against the entry rhs?).  Under full-rate
+    // streaming by the update role a dependent global load costs microseconds, so nothing here waits twice.
+    constexpr int kPB = 32;                       // row-group partials in the first batch
+    constexpr int kEB = 8;                        // cross-Gram entries in the first batch
+    const int ne = A.ev_prev->count;
     bool cand[2] = {false, false};
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int c = tid + q * kStepThreads;
-        if (c < b) {
-            const int64_t j = j0 + c;
-            const float a0 = acur[c];
-            if (a0 != 0.f) cand[q] = true;
-            else if constexpr (METHOD == kBayesR) {
-                BayesRMarker bm; float an;
-                bm.load(A.prep_d, A.prep_f, p, j, A.xpx[j], ie);
-                cand[q] = bm.evaluate(rhs_lds[c], 0.f, ie, an) != 0;
-            } else {
-                AbcMarker am; float gh;
-                am.load(A.prep_d, A.prep_f, p, j, A.xpx[j]);
-                cand[q] = am.evaluate(rhs_lds[c], 0.f, ie, gh);
-            }
+        if (c >= B) continue;                     // (B may be smaller than the workgroup)
+        const int cc = c < b ? c : 0;
+        const int64_t j = j0 + cc;
+        const float a0 = A.alpha[j];
+        const float dj = A.xpx[j];
+        AbcMarker am; BayesRMarker bm;
+        if constexpr (METHOD == kBayesR) bm.load(A.prep_d, A.prep_f, p, j, dj, ie);
+        else am.load(A.prep_d, A.prep_f, p, j, dj);
+        const double* pp = A.partials + cc;
+        double v[kPB];
+#pragma unroll
+        for (int u = 0; u < kPB; ++u) v[u] = pp[(int64_t)(u < A.nrg ? u : A.nrg - 1) * A.bstride];
+        float g0[kEB];
+#pragma unroll
+        for (int u = 0; u < kEB; ++u) {           // (needs the previous block's change list: issued last)
+            const int row = A.ev_prev->idx[u] - (int)A.j0_prev;
+            g0[u] = A.cross[(int64_t)((u < ne && row >= 0 && row < B) ? row : 0) * b + cc];
+        }
+        double sum = 0.0;
+#pragma unroll
+        for (int u = 0; u < kPB; ++u) if (u < A.nrg) sum += v[u];
+        for (int rg = kPB; rg < A.nrg; rg += 16) {                    // very tall matrices only
+            double w[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) w[u] = pp[(int64_t)(rg + u < A.nrg ? rg + u : A.nrg - 1) * A.bstride];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) if (rg + u < A.nrg) sum += w[u];
+        }
+        float rhs0 = (float)sum;
+#pragma unroll
+        for (int u = 0; u < kEB; ++u) if (u < ne) rhs0 = fmaf(A.ev_prev->delta[0][u], g0[u], rhs0);
+        for (int e0 = kEB; e0 < ne; e0 += kEB) {                      // dense-change blocks only
+            float g[kEB];
+#pragma unroll
+            for (int u = 0; u < kEB; ++u)
+                g[u] = A.cross[(int64_t)(A.ev_prev->idx[e0 + u < ne ? e0 + u : ne - 1] - A.j0_prev) * b + cc];
+#pragma unroll
+            for (int u = 0; u < kEB; ++u) if (e0 + u < ne) rhs0 = fmaf(A.ev_prev->delta[0][e0 + u], g[u], rhs0);
+        }
+        rhs_lds[c] = rhs0;
+        const float a_in = (c < b) ? a0 : 0.f;
+        acur[c] = a_in;
+        astart[c] = a_in;
+        // park the constants in LDS for the serial wave
+        if constexpr (METHOD == kBayesR) {
+            float an;
+            bm.store(lpd, lpf, B, c);
+            lpf[c] = dj;
+            cand[q] = (c < b) && ((a_in != 0.f) || (bm.evaluate(rhs0, 0.f, ie, an) != 0));
+        } else {
+            float gh;
+            am.store(lpd, lpf, B, c);
+            lpf[3 * B + c] = dj;
+            cand[q] = (c < b) && ((a_in != 0.f) || am.evaluate(rhs0, 0.f, ie, gh));
         }
     }
-    stage_rows(smem, SM, A, cand);
+    __syncthreads();
+    const long long tk1 = clock64();
+    const long long tk2 = clock64();
+    int nstaged = stage_rows(smem, SM, A, cand);
     if (wave != 0) return;
+    const long long tk3 = clock64();
+    int nrounds = 0;
 
     // wave 0: lane l owns marker c = 64*s + l of sub-block s
     float* delta_f = reinterpret_cast<float*>(A.delta);
     int32_t* delta_i = reinterpret_cast<int32_t*>(A.delta);
+    const short* slot_of = reinterpret_cast<const short*>(smem + SM.slot_off);
+    const float* rows = reinterpret_cast<const float*>(smem + SM.rows_off);
+    int2* evlog = reinterpret_cast<int2*>(smem + SM.log_off);
     const int nsub = (b + 63) / 64;
     const int nreps = P->nreps > 0 ? P->nreps : b;
+    const bool lazy = (nreps == 1);     // single pass: corrections reach a sub-block when it becomes active
     RngKey key{P->seed_lo, P->seed_hi, P->iter, 0u};
+    int nlog = 0;
+
+    // The serial wave reads Gram rows from LDS ONLY (a value that may come from LDS or global compiles to
+    // flat loads whose vmcnt(0) wait also drains the prefetch of the next sub-block).  A committed change
+    // whose row was not staged is copied into a free slot first; when the slots are exhausted it goes to the
+    // overflow row and is applied to the remaining sub-blocks at once instead of being logged.
+    float* rows_w = reinterpret_cast<float*>(smem + SM.rows_off);
+    auto fetch_row = [&](int ce, int slot) {
+        const float* grow = A.gram + (int64_t)ce * b;
+        for (int c0 = 0; c0 < B; c0 += 512) {          // 8 loads in flight per lane
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int col = c0 + 64 * u + lane; v[u] = grow[col < b ? col : 0]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int col = c0 + 64 * u + lane; if (col < B) rows_w[slot * B + col] = v[u]; }
+        }
+    };
 
     for (int rep = 0; rep < nreps; ++rep) {
         key.rep = (uint32_t)rep;
@@ -330,15 +461,27 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
             const int64_t j = j0 + (valid ? c : 0);
             const uint32_t marker = P->marker0 + (uint32_t)j;
             unsigned long long pending = __ballot(valid);
-            const float dj = A.xpx[j];
             float a_cur = acur[c];
+            float rhs = rhs_lds[c];                       // register copy of the active sub-block's rhs
+            const int my_slot = slot_of[c];
             float b_out = 0.f, d_out = 0.f;
+            if (lazy) {
+                // bring this sub-block up to date: the changes committed so far, in commit order
+                // (same fmaf sequence per entry as an immediate update)
+#pragma unroll 4
+                for (int e = 0; e < nlog; ++e) {
+                    const int2 le = evlog[e];
+                    rhs = fmaf(__int_as_float(le.y), rows[le.x * B + c], rhs);
+                }
+            }
 
             AbcMarker am; BayesRMarker bm;
-            if (rep == 0) {
-                if constexpr (METHOD == kBayesR) bm.load(A.prep_d, A.prep_f, p, j, dj, ie);
-                else am.load(A.prep_d, A.prep_f, p, j, dj);
+            if (rep == 0) {            // constants parked in LDS by the parallel phase (no global loads here)
+                const int cl = valid ? c : 0;
+                if constexpr (METHOD == kBayesR) bm.load(lpd, lpf, B, cl, lpf[cl], ie);
+                else am.load(lpd, lpf, B, cl, lpf[3 * B + cl]);
             } else {
+                const float dj = A.xpx[j];
                 const double u = draw_uniform(key, marker, 0u);
                 const double z = draw_normal(key, marker, 0u);
                 if constexpr (METHOD == kBayesR) {
@@ -356,7 +499,7 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
             }
             // speculative rounds
             while (true) {
-                const float rhs = rhs_lds[c];
+                ++nrounds;
                 bool is_event = false, incl = false;
                 float a_new = 0.f, gHat = 0.f;
                 int cls = 0;
@@ -371,7 +514,14 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
                     }
                 }
                 const unsigned long long m = __ballot(is_event) & pending;
-                const int k = m ? __builtin_ctzll(m) : 64;
+                if (m == 0ull) {          // no further change in this sub-block: everyone pending is final
+                    if (live) {
+                        if constexpr (METHOD == kBayesR) d_out = 1.f;
+                        else { d_out = 0.f; b_out = am.beta_excl; }
+                    }
+                    break;
+                }
+                const int k = __builtin_amdgcn_readfirstlane(__builtin_ctzll(m));
                 // lanes before k (and k itself) are final with the values just computed
                 float Dl = 0.f;
                 if (live && lane <= k) {
@@ -385,13 +535,35 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
                         else      { d_out = 0.f; b_out = am.beta_excl; Dl = a_cur; a_cur = 0.f; }
                     }
                 }
-                if (k == 64) break;
                 pending = (k == 63) ? 0ull : (pending & ~((2ull << k) - 1ull));
-                const float D[1] = {__shfl(Dl, k, 64)};
-                if (D[0] != 0.f) apply_gram_row<1>(smem, SM, A, 64 * s + k, D, lane);
+                const float D = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Dl), k));
+                if (D != 0.f) {
+                    // rhs += D * G[ce][:] (BayesABC.jl:169,172).  The active sub-block is corrected in its register
+                    // copy -- the only value the next round waits for.
+                    const int ce = 64 * s + k;
+                    int sl = __builtin_amdgcn_readlane(my_slot, k);
+                    bool overflow = false;
+                    if (sl < 0) {                                            // rare: not staged at entry
+                        if (nstaged < SM.max_cand) sl = nstaged++; else { sl = SM.max_cand; overflow = true; }
+                        fetch_row(ce, sl);
+                        if (lane == 0) atomicAdd(&A.counters[1], 1ull);      // diagnostic
+                    }
+                    const float* grow = rows + sl * B;
+                    rhs = fmaf(D, grow[c], rhs);
+                    if (lazy && !overflow) {
+                        if (lane == 0) evlog[nlog] = make_int2(sl, __float_as_int(D));
+                        ++nlog;
+                    } else {
+                        for (int s2 = lazy ? s + 1 : 0; s2 < nsub; ++s2) {
+                            const int c2 = 64 * s2 + lane;
+                            if (s2 != s) rhs_lds[c2] = fmaf(D, grow[c2], rhs_lds[c2]);
+                        }
+                    }
+                }
                 if (pending == 0ull) break;
             }
             acur[c] = a_cur;
+            rhs_lds[c] = rhs;
             if (valid) {
                 if constexpr (METHOD == kBayesR) delta_i[j] = (int32_t)d_out;
                 else { A.beta[j] = b_out; delta_f[j] = d_out; }
@@ -400,13 +572,14 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
     }
 
     // write back alpha and the net changes of this block
+    const long long tk4 = clock64();
     int base = 0;
 #pragma unroll 1
     for (int s = 0; s < nsub; ++s) {
         const int c = 64 * s + lane;
         const bool valid = c < b;
         const int64_t j = j0 + (valid ? c : 0);
-        const float a_start = A.alpha[j];
+        const float a_start = astart[c];
         const float a_fin = acur[c];
         const bool changed = valid && (a_start != a_fin);
         const unsigned long long cm = __ballot(changed);
@@ -421,6 +594,13 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
     if (lane == 0) {
         A.ev_out->count = base;
         atomicAdd(&A.counters[0], (unsigned long long)base);
+        const long long tk5 = clock64();                      // phase cycle counts (diagnostics)
+        atomicAdd(&A.counters[2], (unsigned long long)(tk1 - tk0));
+        atomicAdd(&A.counters[3], (unsigned long long)(tk2 - tk1));
+        atomicAdd(&A.counters[4], (unsigned long long)(tk3 - tk2));
+        atomicAdd(&A.counters[5], (unsigned long long)(tk4 - tk3));
+        atomicAdd(&A.counters[6], (unsigned long long)(tk5 - tk4));
+        atomicAdd(&A.counters[7], (unsigned long long)nrounds);
     }
 }
 
@@ -430,7 +610,7 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
 template <int NT>
 __device__ __forceinline__ void sampler_role_mt1(char* smem, const SamplerArgs& A)
 {
-    const StepSmem SM(A.bsz, NT);
+    const StepSmem SM(A.bsz, NT, 0, 0);
     const int B = SM.B;
     const DevParams* P = A.P;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
