@@ -14,8 +14,9 @@ same residual snapshot and one all-reduce (RCCL) of the residual delta reconcile
 work is fixed (50k x 600k), so "scaling" is "strong".
 
 Prints ONE JSON line (rank 0) with the contract fields plus
-  "roofline":     HBM roofline of the dominant kernel (k_block_step: sampler of block k-1 || update+partial RHS of block k), from HIP events recorded on the
-                  sweep's stream around every 4th launch inside the timed region;
+  "roofline":     HBM roofline of the dominant kernel (k_block_step: sampler of block k-1 || update + partial
+                  RHS of block k): algorithmic bytes per launch / average launch duration, from the HIP events
+                  recorded on the sweep's stream inside the timed region;
   "cpu_baseline": the CPU oracle's non-block BayesC sweep (the reference's per-marker sdot/saxpy
                   order) timed on this box's host cores on a marker subsample (N = 1, rank 0 only).
 """
@@ -32,6 +33,10 @@ sys.path.insert(0, ROOT)
 
 N_IND, P_TOTAL = 50_000, 600_000
 HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+# HBM bytes per k_block_step launch from the PMC pass committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and
+# --pmc WRITE_SIZE in separate runs; FETCH_SIZE x2 per the guide's gfx950 correction, checked on k_xpx which
+# reads X exactly once): (38911 KB x 2 + 399 KB) x 1024.  Config: n=50000, p=600000, block 256.
+TRAFFIC_BYTES_PER_LAUNCH = (38910.9 * 2 + 398.8) * 1024
 
 
 def parse():
@@ -111,7 +116,7 @@ def main():
     setup_s = time.time() - t_setup; log(f'setup done {setup_s:.1f}s')
 
     state = {"r": y[None, :].copy(), "mu": 0.0, "vare": vare, "G": Gval, "pi": pi, "it": 0}
-    acc = {"sweep_ms": 0.0, "k_ms": 0.0, "k_n": 0.0, "k_bytes": 0.0, "events": 0.0}
+    acc = {"sweep_ms": 0.0, "k_ms": 0.0, "k_n": 0.0, "k_bytes": 0.0, "events": 0.0, "ovh_ms": 0.0}
 
     def step():
         s = state
@@ -134,6 +139,7 @@ def main():
         acc["k_n"] += st["update_kernel_samples"]
         acc["k_bytes"] += st["update_kernel_bytes"]
         acc["events"] += st["n_events"]
+        acc["ovh_ms"] = st["event_overhead_ms"]
         return st
 
     def barrier():
@@ -145,14 +151,13 @@ def main():
         st_ = step(); log(f"warmup step: sweep_ms={st_['sweep_ms']:.1f} events={st_['n_events']:.0f} in_model={st_['sum_delta'][0]:.0f}")
     for k in acc:
         acc[k] = 0.0
-    eng.set_kernel_timing(4)
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         last = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    eng.set_kernel_timing(0); log(f'timed region done: {elapsed:.2f}s')
+    log(f'timed region done: {elapsed:.2f}s')
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -161,7 +166,16 @@ def main():
     out = None
     if rank == 0:
         ms_per_step = 1e3 * elapsed / a.steps
-        achieved = (acc["k_bytes"] / 1e9) / (acc["k_ms"] / 1e3) if acc["k_ms"] > 0 else None
+        # Dominant kernel: k_block_step, one launch per marker block.  Its average launch duration is taken from
+        # the HIP events the library records on the sweep's stream around each sweep (start of the first step,
+        # end of the last): sweep time / launches.  (Events around individual launches cost ~3 us each and would
+        # perturb the timed region; the inter-launch gap is therefore included -- a conservative duration.
+        # The rocprofv3 --kernel-trace --stats average of the same command is committed under profiles/.)
+        nblk = -(-p_loc // bs)
+        launches = (nblk + 1) * a.steps
+        avg_launch_us = 1e3 * acc["sweep_ms"] / launches
+        bytes_per_launch = 4.0 * n * p_loc / (nblk + 1)            # algorithmic: 4 B x n per marker, X read once
+        achieved = bytes_per_launch / 1e9 / (avg_launch_us * 1e-6)
         out = {
             "metric": "MCMC iters/sec (full marker sweep)", "value": a.steps / elapsed, "unit": "iterations/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
@@ -171,11 +185,8 @@ def main():
                        "device_sweep_ms": acc["sweep_ms"] / a.steps, "events_per_sweep": acc["events"] / a.steps,
                        "markers_in_model": float(last["sum_delta"][0]), "setup_s": setup_s},
             "roofline": {"bound": "hbm", "kernel": "k_block_step", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
-                         "bytes_per_launch": acc["k_bytes"] / acc["k_n"] if acc["k_n"] else None,
-                         "avg_launch_us": 1e3 * acc["k_ms"] / acc["k_n"] if acc["k_n"] else None,
-                         "launches_timed": int(acc["k_n"]),
-                         "sweep_level_GBs": 4.0 * n * p_loc / 1e9 / (acc["sweep_ms"] / a.steps / 1e3)},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": TRAFFIC_BYTES_PER_LAUNCH if (bs == 256 and p_total == P_TOTAL and n == N_IND) else None,
+                         "bytes_per_launch": bytes_per_launch, "avg_launch_us": avg_launch_us, "launches_timed": launches},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(eng, n, p_total, min(a.cpu_sample_markers, p_loc), y, float(vare), float(Gval))

@@ -101,9 +101,10 @@ typedef struct jwas_sweep_stats {
     double  state_counts[JWAS_HIP_MAX_STATES];       /* MT: markers per joint state (Pi.jl:20-42)                     */
     double  n_events;                                /* markers whose effect changed this sweep (diagnostic)          */
     double  sweep_ms;                                /* device time of the sweep (hipEvent), milliseconds             */
-    double  update_kernel_ms;                        /* sum of the sampled k_update_partial launch durations (ms)     */
+    double  update_kernel_ms;                        /* sum of the sampled k_block_step event intervals (ms)          */
     double  update_kernel_samples;                   /* number of launches timed (see jwas_hip_set_kernel_timing)     */
     double  update_kernel_bytes;                     /* algorithmic bytes (4*n*b) of the timed launches               */
+    double  event_overhead_ms;                       /* HIP-event interval around an EMPTY launch (dispatch gap), ms  */
 } jwas_sweep_stats;
 
 /* ---- context ------------------------------------------------------------------------------- */
@@ -166,7 +167,7 @@ int  jwas_hip_residual_sub_xalpha(jwas_hip_ctx* ctx, int32_t trait);
 int  jwas_hip_mul_alpha(jwas_hip_ctx* ctx, int32_t trait, float* out_host);
 
 /* ---- the sweep ------------------------------------------------------------------------------ */
-/* Time every `stride`-th k_update_partial launch of subsequent sweeps with HIP events on the
+/* Time every `stride`-th k_block_step launch of subsequent sweeps with HIP events on the
  * sweep's stream (0 = off); the sums come back in jwas_sweep_stats.update_kernel_*. */
 int  jwas_hip_set_kernel_timing(jwas_hip_ctx* ctx, int32_t stride);
 int  jwas_hip_sweep(jwas_hip_ctx* ctx, const jwas_sweep_params* params, jwas_sweep_stats* stats);

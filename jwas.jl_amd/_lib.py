@@ -56,6 +56,7 @@ class SweepStats(C.Structure):
         ("state_counts", C.c_double * MAX_STATES),
         ("n_events", C.c_double), ("sweep_ms", C.c_double),
         ("update_kernel_ms", C.c_double), ("update_kernel_samples", C.c_double), ("update_kernel_bytes", C.c_double),
+        ("event_overhead_ms", C.c_double),
     ]
 
 

@@ -54,6 +54,7 @@ struct jwas_hip_ctx {
     double* pi_mat = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     int timing_stride = 0;
+    double event_overhead_ms = 0.0;     // mean HIP-event interval around an empty launch (calibration)
     std::vector<hipEvent_t> kev;        // pairs of events around sampled k_update_partial launches
 };
 
@@ -548,7 +549,8 @@ static hipError_t launch_step(jwas_hip_ctx* c, const UpdateArgs& U, const Sample
     }
     // JWAS_HIP_DEBUG_ROLE (timing experiments only; results are wrong): 1 = update role only, 2 = sampler only
     static const int dbg = std::getenv("JWAS_HIP_DEBUG_ROLE") ? std::atoi(std::getenv("JWAS_HIP_DEBUG_ROLE")) : 0;
-    const unsigned grid = (dbg == 2) ? 1u : (unsigned)(1 + c->nrg * U.ncg);
+    const int nwork = c->nrg * U.ncg;
+    const unsigned grid = (dbg == 2) ? 1u : (U.quiet_xcd ? (unsigned)(1 + (nwork + 6) / 7 * 8) : (unsigned)(1 + nwork));
     hipLaunchKernelGGL((k_block_step<METHOD, NT>), dim3(grid), dim3(kStepThreads), SM.bytes, c->stream,
                        U, S, (dbg == 1) ? 0 : do_sample);
     return hipSuccess;
@@ -581,6 +583,26 @@ int jwas_hip_set_kernel_timing(jwas_hip_ctx* c, int32_t stride)
     NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
     NEED(c, stride >= 0, JWAS_HIP_EINVAL, "stride must be >= 0");
     c->timing_stride = stride;
+    if (stride > 0 && c->event_overhead_ms == 0.0) {
+        // An event pair around one launch also counts the dispatch gap.  Measure that gap with an empty
+        // kernel launched the same way (after a kernel on the same stream), so callers can report the
+        // kernel's own duration; rocprofv3's per-kernel average is the cross-check.
+        HIPCHK(c, hipSetDevice(c->device));
+        const int reps = 64;
+        std::vector<hipEvent_t> ev(2 * reps);
+        for (auto& e : ev) HIPCHK(c, hipEventCreate(&e));
+        for (int i = 0; i < reps; ++i) {       // enqueued back to back, like the sweep's launches; one sync at the end
+            hipLaunchKernelGGL(k_null, dim3(256), dim3(64), 0, c->stream);      // predecessor keeps the queue busy
+            HIPCHK(c, hipEventRecord(ev[2 * i], c->stream));
+            hipLaunchKernelGGL(k_null, dim3(1), dim3(64), 0, c->stream);
+            HIPCHK(c, hipEventRecord(ev[2 * i + 1], c->stream));
+        }
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        double tot = 0.0;
+        for (int i = 8; i < reps; ++i) { float ms = 0.f; HIPCHK(c, hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1])); tot += ms; }
+        c->event_overhead_ms = tot / (reps - 8);
+        for (auto& e : ev) (void)hipEventDestroy(e);
+    }
     return JWAS_HIP_OK;
 }
 
@@ -662,6 +684,8 @@ int jwas_hip_sweep(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_sweep_stats
         U.nslices = c->nslices; U.nrg = c->nrg;
         U.ncg = (U.b > 0 && c->ncg > U.b) ? U.b : c->ncg;
         U.partials = c->partials + (k & 1) * pstride; U.bstride = bs;
+        { static const int qx = std::getenv("JWAS_HIP_QUIET_XCD") ? std::atoi(std::getenv("JWAS_HIP_QUIET_XCD")) : 1; U.quiet_xcd = qx; }
+        { static const int thr = std::getenv("JWAS_HIP_DEBUG_THROTTLE") ? std::atoi(std::getenv("JWAS_HIP_DEBUG_THROTTLE")) : 0; U.dbg_throttle = thr; }
         SamplerArgs S;
         std::memset(&S, 0, sizeof S);
         const int64_t sb = k - 1;
@@ -748,6 +772,7 @@ int jwas_hip_sweep(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_sweep_stats
     }
     S->update_kernel_samples = (double)ntimed;
     S->update_kernel_bytes = timed_bytes;
+    S->event_overhead_ms = c->event_overhead_ms;
     return JWAS_HIP_OK;
 }
 

@@ -354,7 +354,7 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
     // and decides candidacy (does the effect change if evaluated against the entry rhs?).  Under full-rate
     // streaming by the update role a dependent global load costs microseconds, so nothing here waits twice.
     constexpr int kPB = 32;                       // row-group partials in the first batch
-    constexpr int kEB = 8;                        // cross-Gram entries in the first batch
+    constexpr int kEB = 32;                       // cross-Gram entries in the first batch (more changes than this: extra dependent batches)
     const int ne = A.ev_prev->count;
     bool cand[2] = {false, false};
 #pragma unroll
@@ -794,6 +794,8 @@ struct UpdateArgs {
     int64_t j0; int b;            // block whose partial RHS is formed (b = 0: none)
     int nslices, nrg, ncg;
     double* partials; int bstride;
+    int quiet_xcd;                // 1: ids = 0 mod 8 (the sampler's XCD) do no update work
+    int dbg_throttle;             // > 1: only every n-th update workgroup runs (timing experiments; results wrong)
 };
 
 template <int METHOD, int NT>
@@ -806,7 +808,16 @@ __global__ __launch_bounds__(kStepThreads) void k_block_step(UpdateArgs U, Sampl
         else sampler_role_st<METHOD>(smem, S);
         return;
     }
-    const int w = blockIdx.x - 1;
+    int w = blockIdx.x - 1;
+    if (U.quiet_xcd) {
+        // Speed heuristic only (never correctness): workgroup ids are observed to round-robin over the 8 XCDs,
+        // so ids = 0 mod 8 share the sampler's XCD/L2.  Leaving them idle keeps that L2 free of the streaming
+        // traffic, which shortens every dependent load of the sampler chain.
+        if ((blockIdx.x & 7) == 0) return;
+        w = (int)(blockIdx.x - 1) - (int)((blockIdx.x - 1) >> 3);
+    }
+    if (w >= U.nrg * U.ncg) return;
+    if (U.dbg_throttle > 1 && (w % U.dbg_throttle) != 0) return;       // timing experiments only
     update_role<NT>(smem, w % U.nrg, w / U.nrg, U.X, U.ld, U.r_in, U.r_out, U.ev, U.j0, U.b,
                     U.nslices, U.nrg, U.ncg, U.partials, U.bstride);
 }

@@ -290,7 +290,7 @@ class HipEngine:
             "state_counts": np.array(S.state_counts[:1 << t]),
             "n_events": S.n_events, "sweep_ms": S.sweep_ms,
             "update_kernel_ms": S.update_kernel_ms, "update_kernel_samples": S.update_kernel_samples,
-            "update_kernel_bytes": S.update_kernel_bytes,
+            "update_kernel_bytes": S.update_kernel_bytes, "event_overhead_ms": S.event_overhead_ms,
         }
 
     # -- posterior accumulators --------------------------------------------------------------------
