@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--n", type=int, default=N_IND)
     ap.add_argument("--p", type=int, default=P_TOTAL)
-    ap.add_argument("--block-size", type=int, default=int(os.environ.get("JWAS_BLOCK_SIZE", "256")))
+    ap.add_argument("--block-size", type=int, default=int(os.environ.get("JWAS_BLOCK_SIZE", "512")))
     ap.add_argument("--seed", type=int, default=2026)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-markers", type=int, default=4000)

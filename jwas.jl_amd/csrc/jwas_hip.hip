@@ -33,6 +33,7 @@ struct jwas_hip_ctx {
     float* xpx = nullptr;
     float* gram = nullptr;
     float* cross = nullptr;             // cross-Grams X_{b-1}'X_b, block b at offset b*bs*bs (block 0 unused)
+    float* corr = nullptr;              // [2][kMaxT][bs] lookahead corrections (ping-pong: read by launch k, written for k+1)
 
     int method = -1, ntraits = 0;
     float* r = nullptr;                 // [2][kMaxT][ld] ping-pong; buffer 0 is current between sweeps
@@ -148,8 +149,8 @@ static void free_state(jwas_hip_ctx* c)
 
 static void free_blocks(jwas_hip_ctx* c)
 {
-    (void)hipFree(c->xpx); (void)hipFree(c->gram); (void)hipFree(c->cross); (void)hipFree(c->partials);
-    c->xpx = c->gram = c->cross = nullptr; c->partials = nullptr;
+    (void)hipFree(c->xpx); (void)hipFree(c->gram); (void)hipFree(c->cross); (void)hipFree(c->corr); (void)hipFree(c->partials);
+    c->xpx = c->gram = c->cross = c->corr = nullptr; c->partials = nullptr;
 }
 
 static void free_storage(jwas_hip_ctx* c)
@@ -319,6 +320,7 @@ int jwas_hip_setup_blocks(jwas_hip_ctx* c, int32_t bs, int32_t gram_mode)
     HIPCHK(c, hipMalloc(&c->xpx, sizeof(float) * c->p));
     HIPCHK(c, hipMalloc(&c->gram, sizeof(float) * (size_t)c->nblocks * bs * bs));
     HIPCHK(c, hipMalloc(&c->cross, sizeof(float) * (size_t)c->nblocks * bs * bs));
+    HIPCHK(c, hipMalloc(&c->corr, sizeof(float) * 2 * kMaxT * (size_t)bs));
     HIPCHK(c, hipMalloc(&c->partials, sizeof(double) * 2 * (size_t)bs * c->nrg * kMaxT));   // ping-pong
     hipLaunchKernelGGL(k_xpx, dim3((unsigned)c->p), dim3(256), 0, c->stream, c->X, c->ld, c->xpx);
     HIPCHK(c, hipGetLastError());
@@ -671,6 +673,7 @@ int jwas_hip_sweep(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_sweep_stats
     const size_t pstride = (size_t)bs * c->nrg * kMaxT;
     HIPCHK(c, hipMemcpyAsync(c->r + rstride, c->r, sizeof(float) * (size_t)t * c->ld, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(&c->ev[1].count, 0, sizeof(int32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->corr, 0, sizeof(float) * 2 * kMaxT * (size_t)bs, c->stream));   // block 0 has no predecessor
     size_t ntimed = 0;
     double timed_bytes = 0.0;
     const int64_t nb = c->nblocks;
@@ -693,14 +696,19 @@ int jwas_hip_sweep(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_sweep_stats
             S.P = c->dparams;
             S.partials = c->partials + (sb & 1) * pstride; S.nrg = c->nrg; S.bstride = bs;
             S.j0 = sb * bs; S.b = (int)((S.j0 + bs <= c->p) ? bs : c->p - S.j0); S.p = c->p;
-            S.j0_prev = sb > 0 ? (sb - 1) * bs : 0;
             S.bsz = bs;
             S.xpx = c->xpx;
             S.gram = c->gram + sb * (int64_t)bs * bs;
-            S.cross = c->cross + sb * (int64_t)bs * bs;
+            // the correction of block sb was written by the sampler of block sb-1 (launch k-1) into corr[sb&1];
+            // this sampler writes the one of block sb+1 into corr[(sb+1)&1]
+            const int64_t jn = (sb + 1) * bs;
+            S.b_next = (sb + 1 < nb) ? (int)((jn + bs <= c->p) ? bs : c->p - jn) : 0;
+            S.cross_next = c->cross + (sb + 1 < nb ? sb + 1 : sb) * (int64_t)bs * bs;
+            S.corr_in = c->corr + (sb & 1) * (size_t)kMaxT * bs;
+            S.corr_out = c->corr + ((sb + 1) & 1) * (size_t)kMaxT * bs;
             S.prep_d = c->prep_d; S.prep_f = c->prep_f;
             S.alpha = c->alpha; S.beta = c->beta; S.delta = c->delta;
-            S.ev_prev = &c->ev[k & 1]; S.ev_out = &c->ev[(k - 1) & 1];
+            S.ev_out = &c->ev[(k - 1) & 1];
             S.counters = c->counters;
         }
         const bool timed = c->timing_stride > 0 && k < nb && (k % c->timing_stride) == 0;

@@ -173,14 +173,15 @@ struct SamplerArgs {
     const double* partials;       // [NT][nrg][bstride] of THIS block
     int nrg, bstride;
     int64_t j0; int b; int64_t p;
-    int64_t j0_prev;              // first column of the previous block
     int bsz;                      // nominal block size (LDS strides)
     const float* xpx;
     const float* gram;            // b x b, this block
-    const float* cross;           // bprev x b: X_prev' X_this (row = marker of the previous block)
+    const float* cross_next;      // b x b_next: X_this' X_next (row = marker of THIS block); b_next = 0: none
+    int b_next;
+    const float* corr_in;         // [NT][bsz] lookahead correction of THIS block (written by the previous sampler)
+    float* corr_out;              // [NT][bsz] lookahead correction of the NEXT block
     const double* prep_d; const float* prep_f;
     float* alpha; float* beta; void* delta;
-    const Events* ev_prev;        // changes of the previous block (for the lookahead correction)
     Events* ev_out;
     unsigned long long* counters;
 };
@@ -191,60 +192,99 @@ __device__ __forceinline__ void sampler_front(char* smem, const StepSmem& SM, co
     const int B = SM.B;
     float* rhs_lds = reinterpret_cast<float*>(smem + SM.rhs_off);
     float* acur = reinterpret_cast<float*>(smem + SM.acur_off);
+    float* astart = reinterpret_cast<float*>(smem + SM.astart_off);
     const int tid = threadIdx.x;
     const int b = A.b;
-    // rhs_b[c] = sum over row groups (fp64, fixed order), rounded once to fp32; then the lookahead
-    // correction for the previous block's changed markers, in marker order.  All loads of a column are
-    // independent of each other: they are issued back to back (one memory latency, not one per load).
-    constexpr int kPB = 16;                       // row-group partials per batch
-    constexpr int kEB = 8;                        // cross-Gram entries per batch
-    const int ne = A.ev_prev->count;
+    // rhs_b[c] = fl32(sum over row groups, fp64, fixed order) + corr[c]   (one load batch: nothing here
+    // depends on another load)
+    constexpr int kPB = 32;
     for (int c = tid; c < B; c += kStepThreads) {
         const int cc = c < b ? c : 0;
-        float a0[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) a0[t] = A.alpha[(int64_t)t * A.p + A.j0 + cc];
-        float g0[kEB];
-#pragma unroll
-        for (int u = 0; u < kEB; ++u)             // first cross batch: rows of (possibly stale) idx entries are valid addresses
-            g0[u] = A.cross[(int64_t)(((u < ne) ? A.ev_prev->idx[u] : (int)A.j0_prev) - A.j0_prev) * b + cc];
-        float rv[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
+            const float a0 = A.alpha[(int64_t)t * A.p + A.j0 + cc];
+            const float co = A.corr_in[t * B + c];
             const double* pp = A.partials + (int64_t)t * A.nrg * A.bstride + cc;
-            double s = 0.0;
-            for (int rg = 0; rg < A.nrg; rg += kPB) {
-                double v[kPB];
+            double v[kPB];
 #pragma unroll
-                for (int u = 0; u < kPB; ++u) v[u] = pp[(int64_t)(rg + u < A.nrg ? rg + u : A.nrg - 1) * A.bstride];
+            for (int u = 0; u < kPB; ++u) v[u] = pp[(int64_t)(u < A.nrg ? u : A.nrg - 1) * A.bstride];
+            double sum = 0.0;
 #pragma unroll
-                for (int u = 0; u < kPB; ++u) if (rg + u < A.nrg) s += v[u];
+            for (int u = 0; u < kPB; ++u) if (u < A.nrg) sum += v[u];
+            for (int rg = kPB; rg < A.nrg; rg += 16) {
+                double w[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) w[u] = pp[(int64_t)(rg + u < A.nrg ? rg + u : A.nrg - 1) * A.bstride];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) if (rg + u < A.nrg) sum += w[u];
             }
-            rv[t] = (float)s;
-        }
-#pragma unroll
-        for (int u = 0; u < kEB; ++u)
-            if (u < ne)
-#pragma unroll
-                for (int t = 0; t < NT; ++t) rv[t] = fmaf(A.ev_prev->delta[t][u], g0[u], rv[t]);
-        for (int e0 = kEB; e0 < ne; e0 += kEB) {
-            float g[kEB];
-#pragma unroll
-            for (int u = 0; u < kEB; ++u)
-                g[u] = A.cross[(int64_t)(A.ev_prev->idx[e0 + u < ne ? e0 + u : ne - 1] - A.j0_prev) * b + cc];
-#pragma unroll
-            for (int u = 0; u < kEB; ++u)
-                if (e0 + u < ne)
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) rv[t] = fmaf(A.ev_prev->delta[t][e0 + u], g[u], rv[t]);
-        }
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            rhs_lds[t * B + c] = rv[t];
-            acur[t * B + c] = (c < b) ? a0[t] : 0.f;
+            rhs_lds[t * B + c] = (float)sum + co;
+            const float a_in = (c < b) ? a0 : 0.f;
+            acur[t * B + c] = a_in;
+            astart[t * B + c] = a_in;
         }
     }
     __syncthreads();
+}
+
+// End of the sampler role (all threads): the lookahead correction of the NEXT block from the net changes
+// of this one,  corr[c] = fmaf(d_e, C[e][c], corr[c])  from 0 in marker order (C = X_this' X_next).
+// fin (LDS, int2 {local column, bits(d)} per trait-0 ... ) holds the compact change list; dlds the
+// per-trait changes [NT][B] indexed by local column.
+template <int NT>
+__device__ __forceinline__ void corr_phase(char* smem, const StepSmem& SM, const SamplerArgs& A, int nfin)
+{
+    const int B = SM.B;
+    const int* fin = reinterpret_cast<const int*>(smem + SM.log_off);              // local columns, marker order
+    const float* acur = reinterpret_cast<const float*>(smem + SM.acur_off);
+    const float* astart = reinterpret_cast<const float*>(smem + SM.astart_off);
+    const int bn = A.b_next;
+    for (int c = threadIdx.x; c < B; c += kStepThreads) {
+        float corr[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) corr[t] = 0.f;
+        if (c < bn) {
+            for (int e0 = 0; e0 < nfin; e0 += 16) {
+                float g[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    g[u] = A.cross_next[(int64_t)fin[e0 + u < nfin ? e0 + u : nfin - 1] * bn + c];
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (e0 + u < nfin) {
+                        const int ce = fin[e0 + u];
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) corr[t] = fmaf(astart[t * B + ce] - acur[t * B + ce], g[u], corr[t]);
+                    }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) A.corr_out[t * B + c] = corr[t];
+    }
+}
+
+// Waves 1..7: touch the cross-Gram rows (X_this' X_next) of the staged candidates so that corr_phase finds
+// them in L2 instead of paying an HBM round trip at the end of the chain.
+__device__ __forceinline__ void prefetch_cross_rows(char* smem, const StepSmem& SM, const SamplerArgs& A, int ncand)
+{
+    const short* cand_list = reinterpret_cast<const short*>(smem + SM.cand_off);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bn = A.b_next;
+    if (wave == 0 || bn <= 0) return;
+    const int nchunk = (bn + 63) / 64, ntask = ncand * nchunk;
+    float sink = 0.f;
+    for (int t0 = (wave - 1) * 8; t0 < ntask; t0 += (kStepThreads / 64 - 1) * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int task = (t0 + u < ntask) ? t0 + u : ntask - 1;
+            const int row = task / nchunk, c = (task - row * nchunk) * 64 + lane;
+            v[u] = A.cross_next[(int64_t)cand_list[row] * bn + (c < bn ? c : 0)];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sink += v[u];
+    }
+    asm volatile("" ::"v"(sink));
 }
 
 // Stage the Gram rows of the candidate markers (cand[q] for marker c = tid + q*kStepThreads) in LDS.
@@ -349,13 +389,11 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
     const long long tk0 = clock64();
 
     // ---- phase A (all threads, ONE memory latency): for its marker every thread issues, back to back, the
-    // loads of alpha, the sweep constants, the row-group partials and the first cross-Gram entries; then
-    //   rhs = fl32(sum of partials) ; rhs = fmaf(d_j, C[j][c], rhs) for the previous block's changes (marker order)
+    // loads of alpha, the sweep constants, the row-group partials and the lookahead correction; then
+    //   rhs = fl32(sum of partials) + corr
     // and decides candidacy (does the effect change if evaluated against the entry rhs?).  Under full-rate
     // streaming by the update role a dependent global load costs microseconds, so nothing here waits twice.
     constexpr int kPB = 32;                       // row-group partials in the first batch
-    constexpr int kEB = 32;                       // cross-Gram entries in the first batch (more changes than this: extra dependent batches)
-    const int ne = A.ev_prev->count;
     bool cand[2] = {false, false};
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -365,6 +403,7 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
         const int64_t j = j0 + cc;
         const float a0 = A.alpha[j];
         const float dj = A.xpx[j];
+        const float co = A.corr_in[c];
         AbcMarker am; BayesRMarker bm;
         if constexpr (METHOD == kBayesR) bm.load(A.prep_d, A.prep_f, p, j, dj, ie);
         else am.load(A.prep_d, A.prep_f, p, j, dj);
@@ -372,12 +411,6 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
         double v[kPB];
 #pragma unroll
         for (int u = 0; u < kPB; ++u) v[u] = pp[(int64_t)(u < A.nrg ? u : A.nrg - 1) * A.bstride];
-        float g0[kEB];
-#pragma unroll
-        for (int u = 0; u < kEB; ++u) {           // (needs the previous block's change list: issued last)
-            const int row = A.ev_prev->idx[u] - (int)A.j0_prev;
-            g0[u] = A.cross[(int64_t)((u < ne && row >= 0 && row < B) ? row : 0) * b + cc];
-        }
         double sum = 0.0;
 #pragma unroll
         for (int u = 0; u < kPB; ++u) if (u < A.nrg) sum += v[u];
@@ -388,17 +421,7 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
 #pragma unroll
             for (int u = 0; u < 16; ++u) if (rg + u < A.nrg) sum += w[u];
         }
-        float rhs0 = (float)sum;
-#pragma unroll
-        for (int u = 0; u < kEB; ++u) if (u < ne) rhs0 = fmaf(A.ev_prev->delta[0][u], g0[u], rhs0);
-        for (int e0 = kEB; e0 < ne; e0 += kEB) {                      // dense-change blocks only
-            float g[kEB];
-#pragma unroll
-            for (int u = 0; u < kEB; ++u)
-                g[u] = A.cross[(int64_t)(A.ev_prev->idx[e0 + u < ne ? e0 + u : ne - 1] - A.j0_prev) * b + cc];
-#pragma unroll
-            for (int u = 0; u < kEB; ++u) if (e0 + u < ne) rhs0 = fmaf(A.ev_prev->delta[0][e0 + u], g[u], rhs0);
-        }
+        const float rhs0 = (float)sum + co;       // + lookahead correction formed by the previous block's sampler
         rhs_lds[c] = rhs0;
         const float a_in = (c < b) ? a0 : 0.f;
         acur[c] = a_in;
@@ -420,7 +443,9 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
     const long long tk1 = clock64();
     const long long tk2 = clock64();
     int nstaged = stage_rows(smem, SM, A, cand);
-    if (wave != 0) return;
+    prefetch_cross_rows(smem, SM, A, nstaged);          // waves 1..7, for corr_phase at the end
+    int* wcnt_s = reinterpret_cast<int*>(smem + SM.wcnt_off);
+    if (wave == 0) {
     const long long tk3 = clock64();
     int nrounds = 0;
 
@@ -588,11 +613,13 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
             A.ev_out->idx[pos] = (int32_t)j;
             A.ev_out->delta[0][pos] = a_start - a_fin;
             A.alpha[j] = a_fin;
+            reinterpret_cast<int*>(smem + SM.log_off)[pos] = c;      // compact change list for corr_phase
         }
         base += __popcll(cm);
     }
     if (lane == 0) {
         A.ev_out->count = base;
+        wcnt_s[15] = base;
         atomicAdd(&A.counters[0], (unsigned long long)base);
         const long long tk5 = clock64();                      // phase cycle counts (diagnostics)
         atomicAdd(&A.counters[2], (unsigned long long)(tk1 - tk0));
@@ -602,6 +629,9 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
         atomicAdd(&A.counters[6], (unsigned long long)(tk5 - tk4));
         atomicAdd(&A.counters[7], (unsigned long long)nrounds);
     }
+    }   // wave 0
+    __syncthreads();
+    if (A.b_next > 0) corr_phase<1>(smem, SM, A, wcnt_s[15]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -640,8 +670,10 @@ __device__ __forceinline__ void sampler_role_mt1(char* smem, const SamplerArgs& 
 #pragma unroll
             for (int t = 0; t < NT; ++t) cand[q] = cand[q] || (acur[t * B + c] != 0.f);
     }
-    stage_rows(smem, SM, A, cand);      // (its barriers also publish bcur/dcur)
-    if (wave != 0) return;
+    const int nstaged_mt = stage_rows(smem, SM, A, cand);      // (its barriers also publish bcur/dcur)
+    prefetch_cross_rows(smem, SM, A, nstaged_mt);
+    int* wcnt_s = reinterpret_cast<int*>(smem + SM.wcnt_off);
+    if (wave == 0) {
 
     float Rinv[NT][NT], Ginv[NT][NT];
 #pragma unroll
@@ -755,9 +787,10 @@ __device__ __forceinline__ void sampler_role_mt1(char* smem, const SamplerArgs& 
         const int64_t j = j0 + (valid ? c : 0);
         bool changed = false;
         float dd[NT];
+        const float* astart = reinterpret_cast<const float*>(smem + SM.astart_off);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const float a0 = A.alpha[(int64_t)t * p + j];
+            const float a0 = astart[t * B + c];
             dd[t] = a0 - acur[t * B + c];
             changed = changed || (valid && a0 != acur[t * B + c]);
         }
@@ -775,13 +808,18 @@ __device__ __forceinline__ void sampler_role_mt1(char* smem, const SamplerArgs& 
             A.ev_out->idx[pos] = (int32_t)j;
 #pragma unroll
             for (int t = 0; t < NT; ++t) A.ev_out->delta[t][pos] = dd[t];
+            reinterpret_cast<int*>(smem + SM.log_off)[pos] = c;
         }
         base += __popcll(cm);
     }
     if (lane == 0) {
         A.ev_out->count = base;
+        wcnt_s[15] = base;
         atomicAdd(&A.counters[0], (unsigned long long)base);
     }
+    }   // wave 0
+    __syncthreads();
+    if (A.b_next > 0) corr_phase<NT>(smem, SM, A, wcnt_s[15]);
 }
 
 // ---------------------------------------------------------------------------------------------

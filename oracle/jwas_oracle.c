@@ -507,9 +507,10 @@ int orc_mtbayesc_I_block_sweep(const float* X, int64_t n, int64_t p, int64_t ld,
 /* block b while block b-1 is still being sampled) and corrected with the cross-Gram columns of  */
 /* the markers of block b-1 that changed.  Everything else is BayesABC_block! (BayesABC.jl:     */
 /* 145-187).  Rounding differs from the plain block form only in how rhs_b is assembled:         */
-/*   s[c]  = fl32( sum_i x_ic * r(b-2)_i )            (fp64 accumulation, rounded once)          */
-/*   s[c]  = fmaf(d_j, fl32(x_j'x_c), s[c])           for the changed markers j of block b-1,    */
-/*                                                    in marker order                            */
+/*   s[c]    = fl32( sum_i x_ic * r(b-2)_i )          (fp64 accumulation, rounded once)          */
+/*   corr[c] = fmaf(d_j, fl32(x_j'x_c), corr[c])      from 0, over the changed markers j of      */
+/*                                                    block b-1 in marker order                  */
+/*   rhs[c]  = s[c] + corr[c]                         (one fp32 add)                             */
 /* then r(b-1) = r(b-2) + X_{b-1} d_{b-1} by per-marker fmaf, as before.                         */
 /* ------------------------------------------------------------------------------------------ */
 typedef struct { int64_t n, ld; const float* X; int acc; } la_ctx;
@@ -522,6 +523,10 @@ static void la_block_rhs(const la_ctx* L, int t, float* r, int64_t ld_r, int64_t
     for (int k = 0; k < t; ++k)
         for (int64_t c = 0; c < b; ++c)
             rhs[k * b + c] = dot_acc(L->X + (j0 + c) * L->ld, r + k * ld_r, L->n, L->acc);
+    /* corr[c] = sum over the changed markers of the previous block, accumulated from 0 in marker order with
+     * fmaf; then ONE fp32 add onto the rounded dot product (the device forms corr at the end of the previous
+     * block's sampler, before this block's partial sums exist). */
+    float* corr = (float*)calloc((size_t)(b * t), sizeof(float));
     for (int64_t e = 0; e < bprev; ++e) {
         int any = 0;
         for (int k = 0; k < t; ++k) any |= (dprev[k * bprev + e] != 0.0f);
@@ -529,9 +534,11 @@ static void la_block_rhs(const la_ctx* L, int t, float* r, int64_t ld_r, int64_t
         const float* xe = L->X + (jprev + e) * L->ld;
         for (int64_t c = 0; c < b; ++c) {
             const float g = dot_acc(xe, L->X + (j0 + c) * L->ld, L->n, L->acc);      /* cross-Gram entry */
-            for (int k = 0; k < t; ++k) rhs[k * b + c] = fmaf(dprev[k * bprev + e], g, rhs[k * b + c]);
+            for (int k = 0; k < t; ++k) corr[k * b + c] = fmaf(dprev[k * bprev + e], g, corr[k * b + c]);
         }
     }
+    for (int64_t i = 0; i < b * t; ++i) rhs[i] = rhs[i] + corr[i];
+    free(corr);
     for (int64_t e = 0; e < bprev; ++e)
         for (int k = 0; k < t; ++k)
             if (dprev[k * bprev + e] != 0.0f) axpy_f32(dprev[k * bprev + e], L->X + (jprev + e) * L->ld, r + k * ld_r, L->n);
