@@ -191,7 +191,18 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         nreps = 0                                                       # = block size (BayesABC.jl:153)
         print(f"BLOCK SIZE: {block_size}")
     if block_size is None:
-        block_size = 256 if p > 256 else 64
+        # Device block size.  Sparse priors (few markers change per sweep): big blocks amortise the per-launch cost.
+        # Dense priors (every marker is in the model: Pi = 0 / BayesA / the multi-trait default of all-ones) change
+        # every marker every sweep, so the whole block Gram must sit in LDS: 128 x 128 floats.
+        if t > 1:
+            dense = float(np.asarray(pi, dtype=np.float64)[(1 << t) - 1]) > 0.5
+        elif method == "BayesR":
+            dense = float(np.asarray(pi, dtype=np.float64)[0]) < 0.5
+        else:
+            dense = float(np.mean(pi)) < 0.5
+        block_size = 128 if dense else 512
+        while block_size > 64 and p <= block_size:
+            block_size //= 2
 
     # ---- engine (the only engine shipped is the HIP one; there is no CPU fallback)
     own_engine = engine is None

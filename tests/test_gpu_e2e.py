@@ -107,3 +107,44 @@ def test_larger_problem_invariants_without_oracle():
         e.close()
     same = (res[256][1] == res[1024][1]).mean()
     assert same > 0.999                      # identical draws; only fp32 rounding of the two Gram layouts differs
+
+
+def test_marker_shard_with_nccl_backend_single_rank(tmp_path):
+    """The collective path (RCCL all-reduce of the residual delta and of the packed statistics) with the real
+    nccl backend: one rank, collectives forced, must reproduce the plain sweep up to the fp32 rounding of
+    snapshot + (local - snapshot)."""
+    import subprocess
+    import sys
+    import os
+    script = tmp_path / "nccl_one_rank.py"
+    script.write_text("""
+import os, sys
+import numpy as np
+sys.path[:0] = [os.environ["REPO"], os.path.join(os.environ["REPO"], "tests")]
+import torch, torch.distributed as dist
+from conftest import make_dataset
+import jwas_jl_amd as J
+from jwas_jl_amd.dist import MarkerShard
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)
+d = make_dataset(n=500, p=700, ncausal=5, seed=8)
+r0 = (d["y"] - d["y"].mean()).astype(np.float32)
+outs = []
+for force in (False, True):
+    e = J.HipEngine(0); e.load_dense(d["X"]); e.setup_blocks(256, "f64"); e.init_state("BayesC")
+    sh = MarkerShard(e, 0, 700, 0, 1, force_collective=force)
+    r = r0[None, :].copy()
+    for it in range(1, 4):
+        r, st = sh.sweep(r, iteration=it, seed=3, vare=np.float32(0.5), var_effect=np.float32(0.004), pi=0.9)
+    outs.append((e.get_state()[0], r.copy(), float(st["resid_ss"][0, 0]), float(st["sum_delta"][0])))
+    e.close()
+# r_snapshot + (r_local - r_snapshot) differs from r_local by fp32 rounding (<= 1 ulp per sweep)
+assert np.abs(outs[0][0] - outs[1][0]).max() <= 1e-5 and np.abs(outs[0][1] - outs[1][1]).max() <= 1e-5
+assert abs(outs[0][2] - outs[1][2]) <= 1e-5 * abs(outs[0][2]) and outs[0][3] == outs[1][3]
+dist.destroy_process_group()
+print("NCCL_ONE_RANK_OK")
+""")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", REPO=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "NCCL_ONE_RANK_OK" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
