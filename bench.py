@@ -42,8 +42,8 @@ TRAFFIC_BYTES_PER_LAUNCH = (38910.9 * 2 + 398.8) * 1024
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--n", type=int, default=N_IND)
     ap.add_argument("--p", type=int, default=P_TOTAL)
     ap.add_argument("--block-size", type=int, default=int(os.environ.get("JWAS_BLOCK_SIZE", "512")))

@@ -493,10 +493,16 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
             if (lazy) {
                 // bring this sub-block up to date: the changes committed so far, in commit order
                 // (same fmaf sequence per entry as an immediate update)
-#pragma unroll 4
-                for (int e = 0; e < nlog; ++e) {
-                    const int2 le = evlog[e];
-                    rhs = fmaf(__int_as_float(le.y), rows[le.x * B + c], rhs);
+                // two-phase chunks so the dependent LDS reads (log entry -> row element) are pipelined
+                for (int e0 = 0; e0 < nlog; e0 += 8) {
+                    int2 le[8];
+                    float gv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) le[u] = evlog[e0 + u < nlog ? e0 + u : nlog - 1];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) gv[u] = rows[le[u].x * B + c];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) if (e0 + u < nlog) rhs = fmaf(__int_as_float(le[u].y), gv[u], rhs);
                 }
             }
 
