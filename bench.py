@@ -33,10 +33,12 @@ sys.path.insert(0, ROOT)
 
 N_IND, P_TOTAL = 50_000, 600_000
 HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
-# HBM bytes per k_block_step launch from the PMC pass committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and
-# --pmc WRITE_SIZE in separate runs; FETCH_SIZE x2 per the guide's gfx950 correction, checked on k_xpx which
-# reads X exactly once): (38911 KB x 2 + 399 KB) x 1024.  Config: n=50000, p=600000, block 256.
-TRAFFIC_BYTES_PER_LAUNCH = (38910.9 * 2 + 398.8) * 1024
+# HBM bytes per k_block_step launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and
+# --pmc WRITE_SIZE in separate runs of this command, averaged over the launches of the last three sweeps = the
+# steady state the timed region runs in; FETCH_SIZE x2 per the guide's gfx950 correction, checked on k_xpx which
+# reads X exactly once: 58 800 454 KB x 2 = 120.4 GB): (51 683 KB x 2 + 602 KB) x 1024.
+# Valid for the default config only: n=50000, p=600000, block 512.
+TRAFFIC_BYTES_PER_LAUNCH = (51682.7 * 2 + 602.0) * 1024
 
 
 def parse():
@@ -185,7 +187,7 @@ def main():
                        "device_sweep_ms": acc["sweep_ms"] / a.steps, "events_per_sweep": acc["events"] / a.steps,
                        "markers_in_model": float(last["sum_delta"][0]), "setup_s": setup_s},
             "roofline": {"bound": "hbm", "kernel": "k_block_step", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": TRAFFIC_BYTES_PER_LAUNCH if (bs == 256 and p_total == P_TOTAL and n == N_IND) else None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": TRAFFIC_BYTES_PER_LAUNCH if (bs == 512 and p_total == P_TOTAL and n == N_IND and world == 1) else None,
                          "bytes_per_launch": bytes_per_launch, "avg_launch_us": avg_launch_us, "launches_timed": launches},
         }
         if world == 1 and not a.no_cpu_baseline:
