@@ -55,7 +55,11 @@ enum {
     JWAS_HIP_BAYESC    = 0,    /* single-trait BayesC: one shared effect variance               */
     JWAS_HIP_BAYESB    = 1,    /* single-trait BayesB (BayesA = BayesB with pi = 0): per-marker  */
     JWAS_HIP_BAYESR    = 2,    /* single-trait BayesR, 4-class mixture                          */
-    JWAS_HIP_MTBAYESC1 = 3     /* multi-trait BayesC, Gibbs sampler I                           */
+    JWAS_HIP_MTBAYESC1 = 3,    /* multi-trait BayesC, Gibbs sampler I  (MTBayesABC.jl:57-127)    */
+    JWAS_HIP_MTBAYESC2 = 4,    /* multi-trait BayesC, Gibbs sampler II (MTBayesABC.jl:129-210):  */
+                               /* joint indicator state; candidate states in bitmask order       */
+    JWAS_HIP_MEGABAYESC = 5    /* megaBayesABC! (BayesABC.jl:1-8, G.constraint = true): t         */
+                               /* independent single-trait BayesC chains sharing one pass over X */
 };
 
 /* Gram precompute modes for jwas_hip_setup_blocks. */
@@ -70,7 +74,7 @@ enum {
 /* Parameters of one sweep = one call of BayesABC!/BayesR!/MTBayesABC! in the reference. */
 typedef struct jwas_sweep_params {
     int32_t  method;                    /* JWAS_HIP_BAYESC ...                                       */
-    int32_t  ntraits;                   /* 1, or t for MTBAYESC1                                     */
+    int32_t  ntraits;                   /* 1, or t (2..4) for the multi-trait methods                */
     int32_t  nreps;                     /* within-block repetitions: 1 = exact non-block chain;      */
                                         /* <= 0 = block size (reference fast_blocks, BayesABC.jl:153) */
     uint32_t iteration;                 /* MCMC iteration index (enters the RNG counter)             */
@@ -78,9 +82,10 @@ typedef struct jwas_sweep_params {
     uint32_t marker_offset;             /* global index of this context's column 0 (marker shards)   */
     uint32_t reserved;
     float    vare[JWAS_HIP_MAX_TRAITS * JWAS_HIP_MAX_TRAITS];        /* residual (co)variance, row-major t x t */
-    float    var_effect[JWAS_HIP_MAX_TRAITS * JWAS_HIP_MAX_TRAITS];  /* BayesC: sigma2_alpha; BayesR: sigmaSq; MT: t x t */
+    float    var_effect[JWAS_HIP_MAX_TRAITS * JWAS_HIP_MAX_TRAITS];  /* BayesC: sigma2_alpha; BayesR: sigmaSq; MT: t x t (MEGA: diagonal used) */
     double   pi;                        /* BayesC/B scalar Pr(effect = 0); ignored if pi_vec != NULL */
-    double   pi_classes[4];             /* BayesR class priors; ignored if pi_matrix != NULL         */
+    double   pi_classes[4];             /* BayesR class priors; ignored if pi_matrix != NULL.        */
+                                        /* MEGABAYESC: pi_classes[k] = Pr(effect = 0) of trait k     */
     double   gamma[4];                  /* BayesR class variances (JWAS.jl:12)                       */
     double   log_prior_states[JWAS_HIP_MAX_STATES];  /* MT: log pi(state), state = sum delta_k << k  */
     const float*  var_effect_vec;       /* BayesB: p per-marker variances (host), else NULL          */

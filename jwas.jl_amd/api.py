@@ -83,8 +83,6 @@ def get_genotypes(file, G=False, *, method="BayesC", Pi=0.0, estimatePi=True,
     if method not in SUPPORTED_METHODS:
         raise NotImplementedError(f"method {method} is not on the device path (supported: {SUPPORTED_METHODS}); "
                                   "GBLUP / RR-BLUP / BayesL stay on the reference")
-    if multi_trait_sampler == "II":
-        raise NotImplementedError("multi-trait Gibbs sampler II stays on the reference; sampler I is implemented")
 
     data_type = np.float32
     try:

@@ -402,8 +402,8 @@ int jwas_hip_init_state(jwas_hip_ctx* c, int32_t method, int32_t nt)
 {
     NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
     NEED(c, c->X, JWAS_HIP_ESTATE, "no genotype matrix loaded");
-    NEED(c, method >= JWAS_HIP_BAYESC && method <= JWAS_HIP_MTBAYESC1, JWAS_HIP_EINVAL, "unknown method %d", method);
-    if (method == JWAS_HIP_MTBAYESC1) NEED(c, nt >= 2 && nt <= kMaxT, JWAS_HIP_EUNSUP, "multi-trait sampler I supports 2..%d traits (got %d)", kMaxT, nt);
+    NEED(c, method >= JWAS_HIP_BAYESC && method <= JWAS_HIP_MEGABAYESC, JWAS_HIP_EINVAL, "unknown method %d", method);
+    if (method >= JWAS_HIP_MTBAYESC1) NEED(c, nt >= 2 && nt <= kMaxT, JWAS_HIP_EUNSUP, "multi-trait samplers support 2..%d traits (got %d)", kMaxT, nt);
     else NEED(c, nt == 1, JWAS_HIP_EINVAL, "single-trait method requires ntraits == 1 (got %d)", nt);
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -541,7 +541,7 @@ int jwas_hip_mul_alpha(jwas_hip_ctx* c, int32_t trait, float* out)
 template <int METHOD, int NT>
 static hipError_t launch_step(jwas_hip_ctx* c, const UpdateArgs& U, const SamplerArgs& S, int do_sample)
 {
-    const StepSmem SM(c->block_size, NT, METHOD == kMTBayesC1 ? 0 : (METHOD == kBayesR ? 12 : 4), METHOD == kMTBayesC1 ? 0 : (METHOD == kBayesR ? 1 : 4));
+    const StepSmem SM(c->block_size, NT, is_mt_method(METHOD) ? 0 : (METHOD == kBayesR ? 12 : 4), is_mt_method(METHOD) ? 0 : (METHOD == kBayesR ? 1 : 4));
     static bool attr_set = false;
     if (!attr_set) {   // allow > 64 KB of dynamic LDS
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_block_step<METHOD, NT>),
@@ -564,10 +564,14 @@ static hipError_t launch_step_any(jwas_hip_ctx* c, const UpdateArgs& U, const Sa
         case JWAS_HIP_BAYESC: return launch_step<kBayesC, 1>(c, U, S, do_sample);
         case JWAS_HIP_BAYESB: return launch_step<kBayesB, 1>(c, U, S, do_sample);
         case JWAS_HIP_BAYESR: return launch_step<kBayesR, 1>(c, U, S, do_sample);
-        default:
-            if (c->ntraits == 2) return launch_step<kMTBayesC1, 2>(c, U, S, do_sample);
-            if (c->ntraits == 3) return launch_step<kMTBayesC1, 3>(c, U, S, do_sample);
-            return launch_step<kMTBayesC1, 4>(c, U, S, do_sample);
+#define JW_MT_STEP(M)                                                            \
+            if (c->ntraits == 2) return launch_step<M, 2>(c, U, S, do_sample);       \
+            if (c->ntraits == 3) return launch_step<M, 3>(c, U, S, do_sample);       \
+            return launch_step<M, 4>(c, U, S, do_sample);
+        case JWAS_HIP_MTBAYESC2: JW_MT_STEP(kMTBayesC2)
+        case JWAS_HIP_MEGABAYESC: JW_MT_STEP(kMegaBayesC)
+        default: JW_MT_STEP(kMTBayesC1)
+#undef JW_MT_STEP
     }
 }
 
@@ -623,10 +627,21 @@ int jwas_hip_sweep(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_sweep_stats
     D.method = c->method; D.ntraits = t; D.nreps = P->nreps;
     D.iter = P->iteration; D.seed_lo = (uint32_t)P->seed; D.seed_hi = (uint32_t)(P->seed >> 32); D.marker0 = P->marker_offset;
     for (int i = 0; i < t * t; ++i) { D.vare[i] = P->vare[i]; D.var_effect[i] = P->var_effect[i]; }
-    if (c->method == JWAS_HIP_MTBAYESC1) {
+    if (c->method == JWAS_HIP_MTBAYESC1 || c->method == JWAS_HIP_MTBAYESC2) {
         NEED(c, inv_small(P->vare, t, D.Rinv) == 0, JWAS_HIP_EINVAL, "residual covariance matrix is singular");
         NEED(c, inv_small(P->var_effect, t, D.Ginv) == 0, JWAS_HIP_EINVAL, "marker effect covariance matrix is singular");
-        for (int i = 0; i < (1 << t); ++i) D.log_prior[i] = P->log_prior_states[i];
+        bool any_finite = false;
+        for (int i = 0; i < (1 << t); ++i) { D.log_prior[i] = P->log_prior_states[i]; any_finite = any_finite || std::isfinite(D.log_prior[i]); }
+        if (c->method == JWAS_HIP_MTBAYESC2)      // MTBayesABC.jl:190
+            NEED(c, any_finite, JWAS_HIP_EINVAL, "All MTBayesABC sampler II state probabilities are zero or invalid.");
+    } else if (c->method == JWAS_HIP_MEGABAYESC) {
+        // megaBayesABC! (BayesABC.jl:1-8): trait k uses vare[k,k], var_effect[k,k] and its own pi (pi_classes[k])
+        for (int k = 0; k < t; ++k) {
+            NEED(c, P->vare[k * t + k] > 0.f, JWAS_HIP_EINVAL, "residual variance must be positive");
+            NEED(c, P->var_effect[k * t + k] > 0.f, JWAS_HIP_EINVAL, "marker effect variance must be positive");
+            NEED(c, P->pi_classes[k] >= 0.0 && P->pi_classes[k] <= 1.0, JWAS_HIP_EINVAL, "pi must lie in [0,1]");
+            D.pi4[k] = P->pi_classes[k];
+        }
     } else {
         NEED(c, P->vare[0] > 0.f, JWAS_HIP_EINVAL, "residual variance must be positive");
     }
@@ -660,10 +675,15 @@ int jwas_hip_sweep(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_sweep_stats
             case JWAS_HIP_BAYESC: hipLaunchKernelGGL((k_prepare<kBayesC, 1>), pg, pb, 0, c->stream, c->dparams, c->p, c->xpx, c->prep_d, c->prep_f); break;
             case JWAS_HIP_BAYESB: hipLaunchKernelGGL((k_prepare<kBayesB, 1>), pg, pb, 0, c->stream, c->dparams, c->p, c->xpx, c->prep_d, c->prep_f); break;
             case JWAS_HIP_BAYESR: hipLaunchKernelGGL((k_prepare<kBayesR, 1>), pg, pb, 0, c->stream, c->dparams, c->p, c->xpx, c->prep_d, c->prep_f); break;
-            default:
-                if (t == 2) hipLaunchKernelGGL((k_prepare<kMTBayesC1, 2>), pg, pb, 0, c->stream, c->dparams, c->p, c->xpx, c->prep_d, c->prep_f);
-                else if (t == 3) hipLaunchKernelGGL((k_prepare<kMTBayesC1, 3>), pg, pb, 0, c->stream, c->dparams, c->p, c->xpx, c->prep_d, c->prep_f);
-                else hipLaunchKernelGGL((k_prepare<kMTBayesC1, 4>), pg, pb, 0, c->stream, c->dparams, c->p, c->xpx, c->prep_d, c->prep_f);
+#define JW_MT_PREP(M)                                                                                                                        \
+                if (t == 2) hipLaunchKernelGGL((k_prepare<M, 2>), pg, pb, 0, c->stream, c->dparams, c->p, c->xpx, c->prep_d, c->prep_f);          \
+                else if (t == 3) hipLaunchKernelGGL((k_prepare<M, 3>), pg, pb, 0, c->stream, c->dparams, c->p, c->xpx, c->prep_d, c->prep_f);     \
+                else hipLaunchKernelGGL((k_prepare<M, 4>), pg, pb, 0, c->stream, c->dparams, c->p, c->xpx, c->prep_d, c->prep_f);                 \
+                break;
+            case JWAS_HIP_MTBAYESC2: JW_MT_PREP(kMTBayesC2)
+            case JWAS_HIP_MEGABAYESC: JW_MT_PREP(kMegaBayesC)
+            default: JW_MT_PREP(kMTBayesC1)
+#undef JW_MT_PREP
         }
     }
 

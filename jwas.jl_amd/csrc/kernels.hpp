@@ -34,7 +34,8 @@ constexpr int kMaxBlock  = 1024;     // largest marker block
 constexpr int kMaxT      = 4;        // traits
 constexpr int kMaxStates = 16;
 
-enum Method { kBayesC = 0, kBayesB = 1, kBayesR = 2, kMTBayesC1 = 3 };
+enum Method { kBayesC = 0, kBayesB = 1, kBayesR = 2, kMTBayesC1 = 3, kMTBayesC2 = 4, kMegaBayesC = 5 };
+__host__ __device__ constexpr bool is_mt_method(int m) { return m >= kMTBayesC1; }
 
 // Effect changes of one marker block, consumed by the next k_update_partial.
 struct Events {
@@ -314,11 +315,11 @@ __global__ __launch_bounds__(256) void k_prepare(const DevParams* __restrict__ P
     if (j >= p) return;
     const RngKey key{P->seed_lo, P->seed_hi, P->iter, 0u};
     const uint32_t marker = P->marker0 + (uint32_t)j;
-    if constexpr (METHOD == kMTBayesC1) {
+    if constexpr (is_mt_method(METHOD)) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const double u = draw_uniform(key, marker, (uint32_t)t);
-            prep_d[(int64_t)t * p + j] = log((1.0 - u) / u);
+            prep_d[(int64_t)t * p + j] = (METHOD == kMTBayesC2) ? u : log((1.0 - u) / u);   // sampler II keeps the raw uniform
             prep_d[(int64_t)(NT + t) * p + j] = draw_normal(key, marker, (uint32_t)t);
         }
     } else {

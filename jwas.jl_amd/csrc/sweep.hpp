@@ -641,10 +641,237 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
 }
 
 // ---------------------------------------------------------------------------------------------
-// SAMPLER role, multi-trait BayesC Gibbs sampler I (MTBayesABC.jl:57-127, block form :243-333)
+// Per-marker evaluation of the multi-trait samplers.  Inputs: w[k] = rhs_k + d*alpha_k (fp32), the
+// marker's current (alpha, beta, delta), its draws.  Outputs: new (an, bn, dn) and the axpy
+// coefficients Dl[k] (alpha_old - alpha_new; 0 = no change).  Operation for operation the oracle's
+// mt1_update / mt2_update / mega_update.
 // ---------------------------------------------------------------------------------------------
 template <int NT>
-__device__ __forceinline__ void sampler_role_mt1(char* smem, const SamplerArgs& A)
+struct MtConsts {
+    float Rinv[NT][NT], Ginv[NT][NT];
+    // mega (constraint = true): per-trait single-trait BayesC constants
+    float ie[NT], var[NT], iv[NT], lv[NT];
+    double lp0[NT], lp1[NT];
+};
+
+// Gibbs sampler I (MTBayesABC.jl:85-120)
+template <int NT>
+__device__ __forceinline__ void mt1_eval(const MtConsts<NT>& K, const double* lpr, const float (&w)[NT], float dj,
+                                         const double (&thr)[NT], const double (&z)[NT],
+                                         float (&an)[NT], float (&bn)[NT], float (&dn)[NT], float (&Dl)[NT])
+{
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {                                                  // :85
+        const float Ginv11 = K.Ginv[k][k];
+        const float C11 = Ginv11 + K.Rinv[k][k] * dj;                               // :89
+        float rhs0 = 0.f, c12b = 0.f, wR = 0.f;
+#pragma unroll
+        for (int m = 0; m < NT; ++m) {
+            wR = wR + w[m] * K.Rinv[m][k];
+            if (m == k) continue;
+            const float C12m = K.Ginv[k][m] + (dj * dn[m]) * K.Rinv[k][m];          // :90
+            rhs0 = rhs0 + K.Ginv[k][m] * bn[m];
+            c12b = c12b + C12m * bn[m];
+        }
+        rhs0 = -rhs0;                                                               // :93
+        const float invLhs0 = 1.0f / Ginv11;
+        const float gHat0 = rhs0 * invLhs0;
+        const float invLhs1 = 1.0f / C11;
+        const float rhs1 = wR - c12b;                                               // :96
+        const float gHat1 = rhs1 * invLhs1;
+        unsigned s0 = 0u;
+#pragma unroll
+        for (int m = 0; m < NT; ++m) if (m != k && dn[m] != 0.f) s0 |= 1u << m;
+        const unsigned s1 = s0 | (1u << k);
+        const float in0 = logf_via_double(Ginv11) - (gHat0 * gHat0) * Ginv11;       // :104
+        const float in1 = logf_via_double(C11) - (gHat1 * gHat1) * C11;             // :105
+        const double logDelta0 = -0.5 * (double)in0 + lpr[s0];
+        const double logDelta1 = -0.5 * (double)in1 + lpr[s1];
+        if ((logDelta0 - logDelta1) < thr[k]) {                                     // :107-111
+            dn[k] = 1.f;
+            bn[k] = (float)((double)gHat1 + z[k] * (double)sqrtf(invLhs1));
+            Dl[k] = an[k] - bn[k];
+            an[k] = bn[k];
+        } else {                                                                    // :112-119
+            bn[k] = (float)((double)gHat0 + z[k] * (double)sqrtf(invLhs0));
+            dn[k] = 0.f;
+            Dl[k] = an[k];
+            an[k] = 0.f;
+        }
+    }
+}
+
+// megaBayesABC! (BayesABC.jl:1-8): trait k is an independent single-trait BayesC update (BayesABC.jl:24-58)
+template <int NT>
+__device__ __forceinline__ void mega_eval(const MtConsts<NT>& K, const float (&w)[NT], float dj,
+                                          const double (&thr)[NT], const double (&z)[NT],
+                                          float (&an)[NT], float (&bn)[NT], float (&dn)[NT], float (&Dl)[NT])
+{
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+        const float rhs    = w[k] * K.ie[k];                                        // :36
+        const float lhs    = dj * K.ie[k] + K.iv[k];                                // :37
+        const float invLhs = 1.0f / lhs;                                            // :38
+        const float gHat   = rhs * invLhs;                                          // :39
+        const float inner  = (logf_via_double(lhs) + K.lv[k]) - gHat * rhs;
+        const double l1    = -0.5 * (double)inner + K.lp1[k];                       // :40
+        if ((K.lp0[k] - l1) < thr[k]) {                                             // :41,:44
+            dn[k] = 1.f;
+            bn[k] = (float)((double)gHat + z[k] * (double)sqrtf(invLhs));           // :46
+            Dl[k] = an[k] - bn[k];
+            an[k] = bn[k];
+        } else {
+            dn[k] = 0.f;
+            bn[k] = (float)(z[k] * (double)sqrtf(K.var[k]));                        // :54
+            Dl[k] = an[k];
+            an[k] = 0.f;
+        }
+    }
+}
+
+// lower Cholesky factor of an SPD NT x NT matrix (fixed operation order, shared with the oracle's chol_lower)
+template <int NT>
+__device__ __forceinline__ void chol_lower(const double (&A)[NT][NT], double (&L)[NT][NT])
+{
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        double s = A[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) s = s - L[j][k] * L[j][k];
+        L[j][j] = sqrt(s);
+#pragma unroll
+        for (int i = j + 1; i < NT; ++i) {
+            double v = A[i][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) v = v - L[i][k] * L[j][k];
+            L[i][j] = v / L[j][j];
+        }
+    }
+}
+
+// Gibbs sampler II, one candidate state (MTBayesABC.jl:178-185).  st: bit k = trait k in the model.
+// q = -0.5*(log det lhs - rhs'gHat); cand = gHat + chol(lhs^-1)*z only when want_cand.
+template <int NT>
+__device__ __forceinline__ void mt2_state(const MtConsts<NT>& K, unsigned st, const float (&w)[NT], float dj,
+                                          const double (&z)[NT], bool want_cand, double& q, double (&cand)[NT])
+{
+    double lhs[NT][NT], L[NT][NT], M[NT][NT], inv[NT][NT], rhs[NT], gHat[NT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a) {
+        const double Da = ((st >> a) & 1u) ? 1.0 : 0.0;
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+            const double Dc = ((st >> c) & 1u) ? 1.0 : 0.0;
+            const double rl = (Da * (double)K.Rinv[a][c]) * Dc;                     // D*Rinv*D  :159
+            lhs[a][c] = rl * (double)dj + (double)K.Ginv[a][c];                     // :179
+        }
+        double s = 0.0;
+#pragma unroll
+        for (int m = 0; m < NT; ++m) s = s + ((double)K.Rinv[m][a] * Da) * (double)w[m];   // (Rinv*D)'w :180
+        rhs[a] = s;
+    }
+    chol_lower<NT>(lhs, L);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {                                                  // M = L^-1
+        M[j][j] = 1.0 / L[j][j];
+#pragma unroll
+        for (int i = j + 1; i < NT; ++i) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = j; k < i; ++k) s = s + L[i][k] * M[k][j];
+            M[i][j] = -s / L[i][i];
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < NT; ++a)                                                    // inv(lhs) = M'M  :181
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = (a > c ? a : c); k < NT; ++k) s = s + M[k][a] * M[k][c];
+            inv[a][c] = s;
+        }
+    double det = 1.0;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) det = det * (L[j][j] * L[j][j]);
+    double quad = 0.0;
+#pragma unroll
+    for (int a = 0; a < NT; ++a) {                                                  // gHat = invLhs*rhs :183
+        double s = 0.0;
+#pragma unroll
+        for (int c = 0; c < NT; ++c) s = s + inv[a][c] * rhs[c];
+        gHat[a] = s;
+        quad = quad + rhs[a] * s;
+    }
+    q = -0.5 * (log(det) - quad);                                                   // :184
+    if (want_cand) {
+        double C[NT][NT];
+        chol_lower<NT>(inv, C);                                                     // cholesky(Hermitian(invLhs)).L :182
+#pragma unroll
+        for (int a = 0; a < NT; ++a) {                                              // gHat + L*z  :185
+            double s = gHat[a];
+#pragma unroll
+            for (int c = 0; c <= a; ++c) s = s + C[a][c] * z[c];
+            cand[a] = s;
+        }
+    }
+}
+
+// Gibbs sampler II, one marker (MTBayesABC.jl:160-208).  u = the marker's uniform (slot 0).
+template <int NT>
+__device__ __forceinline__ void mt2_eval(const MtConsts<NT>& K, const double* lpr, const float (&w)[NT], float dj,
+                                         double u, const double (&z)[NT],
+                                         float (&an)[NT], float (&bn)[NT], float (&dn)[NT], float (&Dl)[NT])
+{
+    constexpr int NS = 1 << NT;
+    double ld[NS], cand[NT];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) ld[s] = 0.0;
+    int which = NS - 1;
+    // passes 0..NS-1 evaluate the states; pass NS re-evaluates the chosen one for its candidate effects
+#pragma unroll 1
+    for (int pass = 0; pass <= NS; ++pass) {
+        const unsigned st = pass < NS ? (unsigned)pass : (unsigned)which;
+        double q;
+        mt2_state<NT>(K, st, w, dj, z, pass == NS, q, cand);
+        if (pass < NS) {
+            const double v = q + lpr[pass];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) ld[s] = (s == pass) ? v : ld[s];
+        }
+        if (pass == NS - 1) {                                                       // :188-198
+            double mx = -INFINITY;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) if (ld[s] > mx) mx = ld[s];
+            double den = 0.0;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) { ld[s] = exp(ld[s] - mx); den += ld[s]; }
+            double cp = 0.0;
+            bool found = false;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                cp += ld[s] / den;
+                if (!found && u < cp) { which = s; found = true; }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+        const double dk = ((which >> k) & 1) ? 1.0 : 0.0;
+        const double a_new = dk * cand[k];                                          // diagm(delta)*beta :201
+        Dl[k] = (float)((double)an[k] - a_new);                                     // oldα-newα -> axpy :204
+        bn[k] = (float)cand[k];
+        dn[k] = (float)dk;
+        an[k] = (float)a_new;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// SAMPLER role, multi-trait: Gibbs sampler I (MTBayesABC.jl:57-127, block form :243-333), sampler II
+// (:129-210) and megaBayesABC! (BayesABC.jl:1-8) share the schedule; only the per-marker evaluation differs.
+// ---------------------------------------------------------------------------------------------
+template <int METHOD, int NT>
+__device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A)
 {
     const StepSmem SM(A.bsz, NT, 0, 0);
     const int B = SM.B;
@@ -681,11 +908,21 @@ __device__ __forceinline__ void sampler_role_mt1(char* smem, const SamplerArgs& 
     int* wcnt_s = reinterpret_cast<int*>(smem + SM.wcnt_off);
     if (wave == 0) {
 
-    float Rinv[NT][NT], Ginv[NT][NT];
+    MtConsts<NT> K;
 #pragma unroll
-    for (int a = 0; a < NT; ++a)
+    for (int a = 0; a < NT; ++a) {
 #pragma unroll
-        for (int c = 0; c < NT; ++c) { Rinv[a][c] = P->Rinv[a * NT + c]; Ginv[a][c] = P->Ginv[a * NT + c]; }
+        for (int c = 0; c < NT; ++c) { K.Rinv[a][c] = P->Rinv[a * NT + c]; K.Ginv[a][c] = P->Ginv[a * NT + c]; }
+        if constexpr (METHOD == kMegaBayesC) {
+            K.ie[a]  = 1.0f / P->vare[a * NT + a];                  // invVarRes          BayesABC.jl:69
+            K.var[a] = P->var_effect[a * NT + a];
+            K.iv[a]  = 1.0f / K.var[a];                             // invVarEffects[j]   :70
+            K.lv[a]  = logf_via_double(K.var[a]);                   // logVarEffects[j]   :71
+            K.lp0[a] = log(P->pi4[a]);                              // logPi              :67
+            K.lp1[a] = log(1.0 - P->pi4[a]);                        // logPiComp          :68
+        }
+    }
+    const double* lpr = P->log_prior;
 
     const int nsub = (b + 63) / 64;
     const int nreps = P->nreps > 0 ? P->nreps : b;
@@ -709,7 +946,7 @@ __device__ __forceinline__ void sampler_role_mt1(char* smem, const SamplerArgs& 
                 if (rep == 0) { thr[t] = A.prep_d[(int64_t)t * p + j]; z[t] = A.prep_d[(int64_t)(NT + t) * p + j]; }
                 else {
                     const double u = draw_uniform(key, marker, (uint32_t)t);
-                    thr[t] = log((1.0 - u) / u);
+                    thr[t] = (METHOD == kMTBayesC2) ? u : log((1.0 - u) / u);
                     z[t] = draw_normal(key, marker, (uint32_t)t);
                 }
             }
@@ -723,46 +960,9 @@ __device__ __forceinline__ void sampler_role_mt1(char* smem, const SamplerArgs& 
                     float w[NT];
 #pragma unroll
                     for (int t = 0; t < NT; ++t) w[t] = rhs_lds[t * B + c] + dj * a_cur[t];           // :82
-#pragma unroll
-                    for (int k = 0; k < NT; ++k) {                                                  // :85
-                        const float Ginv11 = Ginv[k][k];
-                        const float C11 = Ginv11 + Rinv[k][k] * dj;                                 // :89
-                        float rhs0 = 0.f, c12b = 0.f, wR = 0.f;
-#pragma unroll
-                        for (int m = 0; m < NT; ++m) {
-                            wR = wR + w[m] * Rinv[m][k];
-                            if (m == k) continue;
-                            const float C12m = Ginv[k][m] + (dj * dn[m]) * Rinv[k][m];              // :90
-                            rhs0 = rhs0 + Ginv[k][m] * bn[m];
-                            c12b = c12b + C12m * bn[m];
-                        }
-                        rhs0 = -rhs0;                                                               // :93
-                        const float invLhs0 = 1.0f / Ginv11;
-                        const float gHat0 = rhs0 * invLhs0;
-                        const float invLhs1 = 1.0f / C11;
-                        const float rhs1 = wR - c12b;                                               // :96
-                        const float gHat1 = rhs1 * invLhs1;
-                        unsigned s0 = 0u;
-#pragma unroll
-                        for (int m = 0; m < NT; ++m) if (m != k && dn[m] != 0.f) s0 |= 1u << m;
-                        const unsigned s1 = s0 | (1u << k);
-                        const float in0 = logf_via_double(Ginv11) - (gHat0 * gHat0) * Ginv11;       // :104
-                        const float in1 = logf_via_double(C11) - (gHat1 * gHat1) * C11;             // :105
-                        const double* lpr = P->log_prior;
-                        const double logDelta0 = -0.5 * (double)in0 + lpr[s0];
-                        const double logDelta1 = -0.5 * (double)in1 + lpr[s1];
-                        if ((logDelta0 - logDelta1) < thr[k]) {                                     // :107-111
-                            dn[k] = 1.f;
-                            bn[k] = (float)((double)gHat1 + z[k] * (double)sqrtf(invLhs1));
-                            Dl[k] = an[k] - bn[k];
-                            an[k] = bn[k];
-                        } else {                                                                    // :112-119
-                            bn[k] = (float)((double)gHat0 + z[k] * (double)sqrtf(invLhs0));
-                            dn[k] = 0.f;
-                            Dl[k] = an[k];
-                            an[k] = 0.f;
-                        }
-                    }
+                    if constexpr (METHOD == kMTBayesC1) mt1_eval<NT>(K, lpr, w, dj, thr, z, an, bn, dn, Dl);
+                    else if constexpr (METHOD == kMTBayesC2) mt2_eval<NT>(K, lpr, w, dj, thr[0], z, an, bn, dn, Dl);
+                    else mega_eval<NT>(K, w, dj, thr, z, an, bn, dn, Dl);
 #pragma unroll
                     for (int t = 0; t < NT; ++t) is_event = is_event || (Dl[t] != 0.f);
                 }
@@ -848,7 +1048,7 @@ __global__ __launch_bounds__(kStepThreads) void k_block_step(UpdateArgs U, Sampl
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (blockIdx.x == 0) {
         if (!do_sample) return;
-        if constexpr (METHOD == kMTBayesC1) sampler_role_mt1<NT>(smem, S);
+        if constexpr (is_mt_method(METHOD)) sampler_role_mt<METHOD, NT>(smem, S);
         else sampler_role_st<METHOD>(smem, S);
         return;
     }

@@ -21,7 +21,8 @@ from . import _lib
 from ._lib import JwasHipError, SweepParams, SweepStats
 
 METHOD_CODES = {"BayesC": _lib.BAYESC, "BayesB": _lib.BAYESB, "BayesA": _lib.BAYESB,
-                "BayesR": _lib.BAYESR, "MTBayesC": _lib.MTBAYESC1}
+                "BayesR": _lib.BAYESR, "MTBayesC": _lib.MTBAYESC1, "MTBayesC_II": _lib.MTBAYESC2,
+                "MegaBayesC": _lib.MEGABAYESC}
 BAYESR_GAMMA = np.array([0.0, 0.01, 0.1, 1.0], dtype=np.float64)   # JWAS.jl:12
 
 
@@ -228,7 +229,7 @@ class HipEngine:
         for i in range(t * t):
             P.vare[i] = float(ve[i])
             P.var_effect[i] = float(vg[i])
-        P.pi = float(pi) if np.ndim(pi) == 0 else 0.0
+        P.pi = float(pi) if np.ndim(pi) == 0 else 0.0      # (vector pi: per marker, or per trait for megaBayesABC)
         keep = []
         if self.method in (_lib.BAYESC, _lib.BAYESB):
             if np.ndim(pi) == 1:
@@ -270,6 +271,13 @@ class HipEngine:
                     raise ValueError(f"BayesR pi vector length {pc.size} must match the number of mixture classes (4).")
                 for k in range(4):
                     P.pi_classes[k] = float(pc[k])
+        elif self.method == _lib.MEGABAYESC:
+            # megaBayesABC! (BayesABC.jl:1-8): one pi per trait (genotypes.pi[i])
+            pt = np.asarray(pi, dtype=np.float64).reshape(-1)
+            if pt.shape != (t,):
+                raise ValueError(f"megaBayesABC needs one pi per trait ({t}), got {pt.size}")
+            for k in range(t):
+                P.pi_classes[k] = float(pt[k])
         else:
             lp = np.asarray(log_prior_states, dtype=np.float64)
             if lp.shape != (1 << t,):

@@ -114,7 +114,11 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
     t = model.nModels
     method = Mi.method
     if t > 1 and method != "BayesC":
-        raise NotImplementedError("multi-trait device path implements BayesC (Gibbs sampler I); other methods stay on the reference")
+        raise NotImplementedError("multi-trait device path implements BayesC (Gibbs samplers I, II and the constraint=true "
+                                  "megaBayesABC! path); other methods stay on the reference")
+    mega = t > 1 and bool(Mi.G.constraint)                              # megaBayesABC! (MCMC_BayesianAlphabet.jl:233-234)
+    if t == 1 and (Mi.G.constraint or model.R.constraint):
+        raise ValueError("constraint==true is for multi-trait only")     # input_data_validation.jl:534-535,550-551
     if not isinstance(starting_value, bool) or starting_value:
         raise NotImplementedError("starting values for location parameters stay on the reference; marker starting "
                                   "values go through get_genotypes(starting_value=...)")
@@ -158,6 +162,20 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
     if Mi.G.val is False and Mi.genetic_variance.val is False:
         Mi.genetic_variance.val = varg[0, 0] if t == 1 else varg
     pi = Mi.pi
+    if isinstance(pi, dict):
+        # the reference's multi-trait Pi: Dict(state vector => probability), e.g. Dict([1.0,0.0] => 0.1, ...)
+        # (tools4genotypes.jl:357-373, test/runtests.jl); device order: state index = sum_k delta_k << k
+        if t == 1:
+            raise ValueError("a Dict Pi is for multi-trait analyses only")
+        tab = np.zeros(1 << t)
+        for key, val in pi.items():
+            key = tuple(float(v) for v in key)
+            if len(key) != t or any(v not in (0.0, 1.0) for v in key):
+                raise ValueError(f"Pi keys must be 0/1 vectors of length {t} (got {key})")
+            tab[sum(1 << k for k in range(t) if key[k] == 1.0)] = float(val)
+        if abs(tab.sum() - 1.0) > 1e-6:
+            raise ValueError("Summation of probabilities of Pi is not equal to one.")       # input_data_validation.jl
+        pi = tab
     if t > 1 and (np.isscalar(pi) and pi == 0.0):                      # tools4genotypes.jl:357-373
         pi = np.zeros(1 << t)
         pi[(1 << t) - 1] = 1.0
@@ -172,6 +190,26 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
                              "Marker effects covariance matrix is not postive definite! Please modify the argument: Pi.")
     Gdf = float(Mi.G.df)
     Mi.G.scale = (np.float64(Mi.G.val) * (Gdf - 2) / Gdf) if t == 1 else np.asarray(Mi.G.val, dtype=np.float64) * (Gdf - t - 1)   # :414-418
+    Rdf = float(R.df)
+    if t > 1 and R.constraint:                                         # R_constraint! (input_data_validation.jl:530-540)
+        Rdf -= t
+        R.scale = np.diag(np.diag(np.asarray(R.scale, dtype=np.float64)) / (Rdf - 1)) * (Rdf - 2) / Rdf
+        R.val = np.diag(np.diag(np.asarray(R.val, dtype=np.float32)))
+    pi_t = None
+    if mega:                                                           # G_constraint! (input_data_validation.jl:543-559)
+        Gdf -= t
+        Mi.G.scale = np.diag(np.diag(np.asarray(Mi.G.scale, dtype=np.float64)) / (Gdf - 1)) * (Gdf - 2) / Gdf
+        Mi.G.val = np.diag(np.diag(np.asarray(Mi.G.val, dtype=np.float32)))
+        # megaBayesABC! reads one pi per trait (genotypes.pi[i], BayesABC.jl:5).  The reference only holds the joint
+        # 2^t table before the first samplePi; the per-trait value used here is its marginal Pr(delta_k = 0).
+        pa = np.asarray(pi, dtype=np.float64)
+        pi_t = np.array([pa[[s_ for s_ in range(1 << t) if not (s_ >> k) & 1]].sum() for k in range(t)]) if pa.size == (1 << t) else pa
+        if pi_t.shape != (t,):
+            raise ValueError(f"Pi must hold one value per trait or one per joint state (got {pa.size} entries for {t} traits)")
+    sampler = getattr(Mi, "multi_trait_sampler", "I")                   # mt_bayesc_sampler_mode (MTBayesABC.jl:20-25)
+    if t > 1 and sampler == "auto":
+        sampler = "I" if np.size(pi) == (1 << t) else "II"
+    mt_method = "MegaBayesC" if mega else ("MTBayesC_II" if sampler == "II" else "MTBayesC")
 
     # ---- fast_blocks parsing (JWAS.jl:293-316); device blocks are powers of two >= 64
     nreps = 1
@@ -194,7 +232,9 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         # Device block size.  Sparse priors (few markers change per sweep): big blocks amortise the per-launch cost.
         # Dense priors (every marker is in the model: Pi = 0 / BayesA / the multi-trait default of all-ones) change
         # every marker every sweep, so the whole block Gram must sit in LDS: 128 x 128 floats.
-        if t > 1:
+        if mega:
+            dense = float(np.mean(pi_t)) < 0.5
+        elif t > 1:
             dense = float(np.asarray(pi, dtype=np.float64)[(1 << t) - 1]) > 0.5
         elif method == "BayesR":
             dense = float(np.asarray(pi, dtype=np.float64)[0]) < 0.5
@@ -220,7 +260,7 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
             print("WARNING: " + msg)
     engine.load_dense(X)                       # after alignment (tools4genotypes.jl:310-321)
     engine.setup_blocks(block_size, gram_mode)
-    engine.init_state("MTBayesC" if t > 1 else method, t)
+    engine.init_state(mt_method if t > 1 else method, t)
 
     # ---- fixed effects
     Xf, labels = _design(model, ph, idcol)
@@ -253,7 +293,7 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
     # ---- accumulators and sample files (output.jl:320-437)
     run_sol, run_vare = _Running(sol), _Running(vare)
     run_varg = _Running(Gval) if method != "BayesB" else None
-    run_pi = _Running(np.atleast_1d(np.asarray(pi, dtype=np.float64))) if Mi.estimatePi else None
+    run_pi = _Running(np.atleast_1d(np.asarray(pi_t if mega else pi, dtype=np.float64))) if Mi.estimatePi else None
     ebv_run = [_Running(np.zeros(n)) for _ in range(t)] if outputEBV else None
     name = Mi.name
     files = {}
@@ -268,7 +308,8 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
     if method != "BayesB":
         _open(f"marker_effects_variances_{name}", rnames if t > 1 else ["1"])
     if Mi.estimatePi:
-        _open(f"pi_{name}", [f"pi{i + 1}" for i in range(np.size(pi))] if np.size(pi) > 1 else ["pi"])
+        npi = t if mega else np.size(pi)
+        _open(f"pi_{name}", [f"pi{i + 1}" for i in range(npi)] if npi > 1 else ["pi"])
     write_marker_samples = output_samples_for_all_parameters or p <= 20000
     if write_marker_samples:
         for k, tr in enumerate(model.lhsVec):
@@ -298,7 +339,9 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
 
         # 2. marker effects (DEVICE)
         kw = dict(iteration=it, seed=seed_int, vare=vare, nreps=nreps)
-        if t > 1:
+        if mega:
+            kw.update(var_effect=Gval, pi=pi_t)
+        elif t > 1:
             with np.errstate(divide="ignore"):
                 kw.update(var_effect=Gval, log_prior_states=np.log(np.asarray(pi, dtype=np.float64)))
         elif method == "BayesR":
@@ -314,7 +357,9 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
 
         # 3. pi (Pi.jl:7-42)
         if Mi.estimatePi:
-            if t > 1:
+            if mega:                                                    # MCMC_BayesianAlphabet.jl:300-301
+                pi_t = np.array([rng.beta(p - st["sum_delta"][k] + 1.0, st["sum_delta"][k] + 1.0) for k in range(t)])
+            elif t > 1:
                 pi = rng.dirichlet(st["state_counts"] + 1.0)
             elif method == "BayesR":
                 pi = rng.dirichlet(st["class_counts"] + 1.0)
@@ -323,7 +368,9 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
 
         # 4. marker effect variance (variance_components.jl:151-189), re-cast to Float32 (:323-325)
         if Mi.G.estimate_variance:
-            if t > 1:
+            if mega:                                                    # diagonal only (variance_components.jl:104-109)
+                Gval = np.diag([(st["beta_ss"][k, k] + Gdf * Mi.G.scale[k, k]) / rng.chisquare(p + Gdf) for k in range(t)]).astype(np.float32)
+            elif t > 1:
                 from scipy.stats import invwishart
                 S = np.asarray(Mi.G.scale, dtype=np.float64) + st["beta_ss"]
                 Gval = np.asarray(invwishart.rvs(df=Gdf + p, scale=(S + S.T) / 2, random_state=rng), dtype=np.float32).reshape(t, t)
@@ -337,12 +384,14 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
 
         # 5. residual variance (variance_components.jl:60-66,82-112), re-cast to Float32 (:368-370)
         if R.estimate_variance:
-            if t > 1:
+            if t > 1 and R.constraint:                                  # variance_components.jl:104-109
+                vare = np.diag([(st["resid_ss"][k, k] + Rdf * R.scale[k, k]) / rng.chisquare(n + Rdf) for k in range(t)]).astype(np.float32)
+            elif t > 1:
                 from scipy.stats import invwishart
                 S = np.asarray(R.scale, dtype=np.float64) + st["resid_ss"]
-                vare = np.asarray(invwishart.rvs(df=float(R.df) + n, scale=(S + S.T) / 2, random_state=rng), dtype=np.float32).reshape(t, t)
+                vare = np.asarray(invwishart.rvs(df=Rdf + n, scale=(S + S.T) / 2, random_state=rng), dtype=np.float32).reshape(t, t)
             else:
-                vare = np.float32((np.float32(st["resid_ss"][0, 0]) + float(R.df) * R.scale) / rng.chisquare(n + float(R.df)))
+                vare = np.float32((np.float32(st["resid_ss"][0, 0]) + Rdf * R.scale) / rng.chisquare(n + Rdf))
 
         # 6. save (MCMC_BayesianAlphabet.jl:399-413, output.jl:443-604)
         if it > burnin and (it - burnin) % output_samples_frequency == 0:
@@ -352,13 +401,13 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
             if run_varg is not None:
                 run_varg.add(Gval, k)
             if run_pi is not None:
-                run_pi.add(np.atleast_1d(pi), k)
+                run_pi.add(np.atleast_1d(pi_t if mega else pi), k)
             engine.accumulate(k)
             files["residual_variance"].write(",".join(repr(float(v)) for v in np.atleast_1d(vare).ravel()) + "\n")
             if method != "BayesB":
                 files[f"marker_effects_variances_{name}"].write(",".join(repr(float(v)) for v in np.atleast_1d(Gval).ravel()) + "\n")
             if Mi.estimatePi:
-                files[f"pi_{name}"].write(",".join(repr(float(v)) for v in np.atleast_1d(pi)) + "\n")
+                files[f"pi_{name}"].write(",".join(repr(float(v)) for v in np.atleast_1d(pi_t if mega else pi)) + "\n")
             if write_marker_samples:
                 for kk, tr in enumerate(model.lhsVec):
                     a = engine.get_state(kk)[0]
@@ -393,7 +442,9 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         out[f"marker effects variance {name}"] = pd.DataFrame({"Covariance": cov, "Estimate": np.atleast_1d(run_varg.mean).ravel(),
                                                                "SD": np.atleast_1d(run_varg.sd()).ravel()})
     if run_pi is not None:
-        if t > 1:
+        if mega:
+            lab = list(model.lhsVec)
+        elif t > 1:
             lab = ["".join(str((s >> k) & 1) for k in range(t)) for s in range(1 << t)]
         elif method == "BayesR":
             lab = ["class1", "class2", "class3", "class4"]

@@ -429,7 +429,152 @@ static inline void mt1_update(int t, const float* w, float d, float* alpha, floa
     for (int k = 0; k < t; ++k) { beta[k * stride] = b[k]; delta[k * stride] = dl[k]; }
 }
 
-int orc_mtbayesc_I_sweep(const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
+/* ------------------------------------------------------------------------------------------ */
+/* multi-trait BayesC, sampler II: joint state (MTBayesABC.jl:129-210).                          */
+/* States are indexed by bitmask s (bit k = trait k in the model); the reference iterates        */
+/* collect(keys(pi)) (Dict order, unspecified) -- the label order only decides which uniform      */
+/* interval maps to which state.  Temporaries are Float64 as in the reference (:153-157).         */
+/* The t x t algebra (inv, cholesky, det: LAPACK in the reference) is restated with one fixed     */
+/* operation order shared with the device: Cholesky lhs = L L', M = L^-1, inv = M'M,              */
+/* det = prod L_ii^2, chol(inv) lower.                                                           */
+/* ------------------------------------------------------------------------------------------ */
+static void chol_lower(int t, const double* A, double* L)
+{
+    for (int i = 0; i < t * t; ++i) L[i] = 0.0;
+    for (int j = 0; j < t; ++j) {
+        double s = A[j * t + j];
+        for (int k = 0; k < j; ++k) s = s - L[j * t + k] * L[j * t + k];
+        L[j * t + j] = sqrt(s);
+        for (int i = j + 1; i < t; ++i) {
+            double v = A[i * t + j];
+            for (int k = 0; k < j; ++k) v = v - L[i * t + k] * L[j * t + k];
+            L[i * t + j] = v / L[j * t + j];
+        }
+    }
+}
+
+static void mt2_state(int t, unsigned st, const float* w, float d, const float* Rinv, const float* Ginv,
+                      const double* z, double* logdet_quad /* out: -0.5*(log det lhs - rhs'gHat) */, double* cand)
+{
+    double lhs[ORC_MAXT * ORC_MAXT], L[ORC_MAXT * ORC_MAXT], M[ORC_MAXT * ORC_MAXT], inv[ORC_MAXT * ORC_MAXT];
+    double C[ORC_MAXT * ORC_MAXT], rhs[ORC_MAXT], gHat[ORC_MAXT];
+    for (int a = 0; a < t; ++a)
+        for (int c = 0; c < t; ++c) {
+            const double Da = (st >> a) & 1u ? 1.0 : 0.0, Dc = (st >> c) & 1u ? 1.0 : 0.0;
+            const double rl = (Da * (double)Rinv[a * t + c]) * Dc;                  /* D*Rinv*D       :159 */
+            lhs[a * t + c] = rl * (double)d + (double)Ginv[a * t + c];             /* :179 */
+        }
+    for (int a = 0; a < t; ++a) {                                                  /* (Rinv*D)'w     :180 */
+        const double Da = (st >> a) & 1u ? 1.0 : 0.0;
+        double s = 0.0;
+        for (int m = 0; m < t; ++m) s = s + ((double)Rinv[m * t + a] * Da) * (double)w[m];
+        rhs[a] = s;
+    }
+    chol_lower(t, lhs, L);
+    for (int i = 0; i < t * t; ++i) M[i] = 0.0;
+    for (int j = 0; j < t; ++j) {                                                  /* M = L^-1 */
+        M[j * t + j] = 1.0 / L[j * t + j];
+        for (int i = j + 1; i < t; ++i) {
+            double s = 0.0;
+            for (int k = j; k < i; ++k) s = s + L[i * t + k] * M[k * t + j];
+            M[i * t + j] = -s / L[i * t + i];
+        }
+    }
+    for (int a = 0; a < t; ++a)                                                    /* inv(lhs) = M'M :181 */
+        for (int c = 0; c < t; ++c) {
+            double s = 0.0;
+            for (int k = (a > c ? a : c); k < t; ++k) s = s + M[k * t + a] * M[k * t + c];
+            inv[a * t + c] = s;
+        }
+    double det = 1.0;
+    for (int j = 0; j < t; ++j) det = det * (L[j * t + j] * L[j * t + j]);
+    double quad = 0.0;
+    for (int a = 0; a < t; ++a) {                                                  /* gHat = invLhs*rhs :183 */
+        double s = 0.0;
+        for (int c = 0; c < t; ++c) s = s + inv[a * t + c] * rhs[c];
+        gHat[a] = s;
+        quad = quad + rhs[a] * s;
+    }
+    *logdet_quad = -0.5 * (log(det) - quad);                                       /* :184 */
+    chol_lower(t, inv, C);                                                         /* cholesky(Hermitian(invLhs)).L :182 */
+    for (int a = 0; a < t; ++a) {                                                  /* gHat + L*z     :185 */
+        double s = gHat[a];
+        for (int c = 0; c <= a; ++c) s = s + C[a * t + c] * z[c];
+        cand[a] = s;
+    }
+}
+
+static inline void mt2_update(int t, const float* w, float d, float* alpha, float* beta, float* delta,
+                              int64_t stride, const float* Rinv, const float* Ginv,
+                              const double* log_prior, uint64_t seed, uint32_t marker, uint32_t iter,
+                              uint32_t rep, float* a_out)
+{
+    const int ns = 1 << t;
+    double z[ORC_MAXT], logDelta[1 << ORC_MAXT], cand[(1 << ORC_MAXT) * ORC_MAXT];
+    for (int k = 0; k < t; ++k) z[k] = orc_normal(seed, marker, iter, rep, (uint32_t)k);   /* randn(ntraits) :176 */
+    const double u = orc_uniform(seed, marker, iter, rep, 0);
+    double mx = -INFINITY;
+    for (int s = 0; s < ns; ++s) {
+        double q;
+        mt2_state(t, (unsigned)s, w, d, Rinv, Ginv, z, &q, cand + s * t);
+        logDelta[s] = q + log_prior[s];
+        if (logDelta[s] > mx) mx = logDelta[s];
+    }
+    double den = 0.0;                                                              /* :188-196 */
+    for (int s = 0; s < ns; ++s) { logDelta[s] = exp(logDelta[s] - mx); den += logDelta[s]; }
+    int which = ns - 1;                                                            /* rand(Categorical(probDelta)) :198 */
+    double cp = 0.0;
+    for (int s = 0; s < ns; ++s) { cp += logDelta[s] / den; if (u < cp) { which = s; break; } }
+    for (int k = 0; k < t; ++k) {
+        const double dk = (which >> k) & 1 ? 1.0 : 0.0;
+        const double b_new = cand[which * t + k];
+        const double a_new = dk * b_new;                                           /* diagm(delta)*beta :201 */
+        const float a_old = alpha[k * stride];
+        a_out[k] = (float)((double)a_old - a_new);                                 /* oldα-newα (Float64) -> axpy :204 */
+        beta[k * stride]  = (float)b_new;
+        delta[k * stride] = (float)dk;
+        alpha[k * stride] = (float)a_new;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* megaBayesABC! (BayesABC.jl:1-8): G.constraint == true -> t independent single-trait BayesC   */
+/* sweeps with vare[k,k], var_effect[k,k] and a per-trait pi (passed in prior[k]); draws of     */
+/* trait k use slot k.                                                                          */
+/* ------------------------------------------------------------------------------------------ */
+static inline void mega_update(int t, const float* w_minus /* rhs_b (without d*alpha) */, float d, float* alpha,
+                               float* beta, float* delta, int64_t stride, const float* vare, const float* var_effect,
+                               const double* pi, uint64_t seed, uint32_t marker, uint32_t iter, uint32_t rep,
+                               float* a_out)
+{
+    for (int k = 0; k < t; ++k) {
+        const double u = orc_uniform(seed, marker, iter, rep, (uint32_t)k);
+        const double z = orc_normal(seed, marker, iter, rep, (uint32_t)k);
+        const float ie = 1.0f / vare[k * t + k];
+        a_out[k] = abc_update(w_minus[k], d, &alpha[k * stride], &beta[k * stride], &delta[k * stride], ie,
+                              var_effect[k * t + k], pi[k], u, z);
+    }
+}
+
+enum { MT_SAMPLER_I = 1, MT_SAMPLER_II = 2, MT_MEGA = 3 };
+
+/* s[k] = x'r_k (or the block rhs entry); dispatch on the multi-trait sampler kind */
+static inline void mt_update(int kind, int t, const float* s, float d, float* alpha, float* beta, float* delta,
+                             int64_t stride, const float* Rinv, const float* Ginv, const float* vare,
+                             const float* var_effect, const double* prior, uint64_t seed, uint32_t marker,
+                             uint32_t iter, uint32_t rep, float* a_out)
+{
+    if (kind == MT_MEGA) {
+        mega_update(t, s, d, alpha, beta, delta, stride, vare, var_effect, prior, seed, marker, iter, rep, a_out);
+        return;
+    }
+    float w[ORC_MAXT];
+    for (int k = 0; k < t; ++k) w[k] = s[k] + d * alpha[k * stride];              /* MTBayesABC.jl:82,172 */
+    if (kind == MT_SAMPLER_I) mt1_update(t, w, d, alpha, beta, delta, stride, Rinv, Ginv, prior, seed, marker, iter, rep, a_out);
+    else                      mt2_update(t, w, d, alpha, beta, delta, stride, Rinv, Ginv, prior, seed, marker, iter, rep, a_out);
+}
+
+int orc_mt_sweep(int kind, const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
                          int t, float* r, int64_t ld_r, float* alpha, float* beta, float* delta,
                          const float* vare, const float* var_effect,
                          const double* log_prior, int prior_is_matrix,
@@ -437,22 +582,22 @@ int orc_mtbayesc_I_sweep(const float* X, int64_t n, int64_t p, int64_t ld, const
 {
     if (t < 1 || t > ORC_MAXT || n <= 0 || ld < n || ld_r < n) return -1;
     float Rinv[ORC_MAXT * ORC_MAXT], Ginv[ORC_MAXT * ORC_MAXT];
+    if (kind < MT_SAMPLER_I || kind > MT_MEGA) return -1;
     if (inv_small(vare, t, Rinv) || inv_small(var_effect, t, Ginv)) return -2;
     const int nstates = 1 << t;
     for (int64_t j = 0; j < p; ++j) {
         const float* x = X + j * ld;
         float w[ORC_MAXT], a[ORC_MAXT];
-        for (int k = 0; k < t; ++k)                                              /* :82 */
-            w[k] = dot_acc(x, r + k * ld_r, n, acc) + xpx[j] * alpha[k * p + j];
-        mt1_update(t, w, xpx[j], alpha + j, beta + j, delta + j, p, Rinv, Ginv,
-                   prior_is_matrix ? log_prior + (int64_t)nstates * j : log_prior,
-                   seed, marker0 + (uint32_t)j, iter, 0, a);
+        for (int k = 0; k < t; ++k) w[k] = dot_acc(x, r + k * ld_r, n, acc);     /* :82 */
+        mt_update(kind, t, w, xpx[j], alpha + j, beta + j, delta + j, p, Rinv, Ginv, vare, var_effect,
+                  prior_is_matrix ? log_prior + (int64_t)nstates * j : log_prior,
+                  seed, marker0 + (uint32_t)j, iter, 0, a);
         for (int k = 0; k < t; ++k) if (a[k] != 0.0f) axpy_f32(a[k], x, r + k * ld_r, n);
     }
     return 0;
 }
 
-int orc_mtbayesc_I_block_sweep(const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
+int orc_mt_block_sweep(int kind, const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
                                const int64_t* block_starts, int64_t nblocks, const float* grams,
                                int t, float* r, int64_t ld_r, float* alpha, float* beta, float* delta,
                                const float* vare, const float* var_effect,
@@ -461,6 +606,7 @@ int orc_mtbayesc_I_block_sweep(const float* X, int64_t n, int64_t p, int64_t ld,
 {
     if (t < 1 || t > ORC_MAXT || n <= 0 || ld < n || ld_r < n || !blocks_ok(block_starts, nblocks, p)) return -1;
     float Rinv[ORC_MAXT * ORC_MAXT], Ginv[ORC_MAXT * ORC_MAXT];
+    if (kind < MT_SAMPLER_I || kind > MT_MEGA) return -1;
     if (inv_small(vare, t, Rinv) || inv_small(var_effect, t, Ginv)) return -2;
     const int nstates = 1 << t;
     const float* G = grams;
@@ -479,10 +625,10 @@ int orc_mtbayesc_I_block_sweep(const float* X, int64_t n, int64_t p, int64_t ld,
             for (int64_t c = 0; c < b; ++c) {
                 const int64_t j = j0 + c;
                 float w[ORC_MAXT], a[ORC_MAXT];
-                for (int k = 0; k < t; ++k) w[k] = rhs_b[k * b + c] + xpx[j] * alpha[k * p + j];
-                mt1_update(t, w, xpx[j], alpha + j, beta + j, delta + j, p, Rinv, Ginv,
-                           prior_is_matrix ? log_prior + (int64_t)nstates * j : log_prior,
-                           seed, marker0 + (uint32_t)j, iter, (uint32_t)rep, a);
+                for (int k = 0; k < t; ++k) w[k] = rhs_b[k * b + c];
+                mt_update(kind, t, w, xpx[j], alpha + j, beta + j, delta + j, p, Rinv, Ginv, vare, var_effect,
+                          prior_is_matrix ? log_prior + (int64_t)nstates * j : log_prior,
+                          seed, marker0 + (uint32_t)j, iter, (uint32_t)rep, a);
                 for (int k = 0; k < t; ++k)
                     if (a[k] != 0.0f) axpy_f32(a[k], G + c * b, rhs_b + k * b, b);   /* :311,317 */
             }
@@ -624,7 +770,7 @@ int orc_bayesr_lookahead_sweep(const float* X, int64_t n, int64_t p, int64_t ld,
     return 0;
 }
 
-int orc_mtbayesc_I_lookahead_sweep(const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
+int orc_mt_lookahead_sweep(int kind, const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
                                    const int64_t* block_starts, int64_t nblocks, const float* grams,
                                    int t, float* r, int64_t ld_r, float* alpha, float* beta, float* delta,
                                    const float* vare, const float* var_effect,
@@ -633,6 +779,7 @@ int orc_mtbayesc_I_lookahead_sweep(const float* X, int64_t n, int64_t p, int64_t
 {
     if (t < 1 || t > ORC_MAXT || n <= 0 || ld < n || ld_r < n || !blocks_ok(block_starts, nblocks, p)) return -1;
     float Rinv[ORC_MAXT * ORC_MAXT], Ginv[ORC_MAXT * ORC_MAXT];
+    if (kind < MT_SAMPLER_I || kind > MT_MEGA) return -1;
     if (inv_small(vare, t, Rinv) || inv_small(var_effect, t, Ginv)) return -2;
     const int nstates = 1 << t;
     const la_ctx L = { n, ld, X, acc };
@@ -650,10 +797,10 @@ int orc_mtbayesc_I_lookahead_sweep(const float* X, int64_t n, int64_t p, int64_t
             for (int64_t c = 0; c < b; ++c) {
                 const int64_t j = j0 + c;
                 float w[ORC_MAXT], a[ORC_MAXT];
-                for (int k = 0; k < t; ++k) w[k] = rhs_b[k * b + c] + xpx[j] * alpha[k * p + j];
-                mt1_update(t, w, xpx[j], alpha + j, beta + j, delta + j, p, Rinv, Ginv,
-                           prior_is_matrix ? log_prior + (int64_t)nstates * j : log_prior,
-                           seed, marker0 + (uint32_t)j, iter, (uint32_t)rep, a);
+                for (int k = 0; k < t; ++k) w[k] = rhs_b[k * b + c];
+                mt_update(kind, t, w, xpx[j], alpha + j, beta + j, delta + j, p, Rinv, Ginv, vare, var_effect,
+                          prior_is_matrix ? log_prior + (int64_t)nstates * j : log_prior,
+                          seed, marker0 + (uint32_t)j, iter, (uint32_t)rep, a);
                 for (int k = 0; k < t; ++k) if (a[k] != 0.0f) axpy_f32(a[k], G + c * b, rhs_b + k * b, b);
             }
         for (int k = 0; k < t; ++k)
@@ -668,6 +815,41 @@ int orc_mtbayesc_I_lookahead_sweep(const float* X, int64_t n, int64_t p, int64_t
     free(dprev);
     return 0;
 }
+
+/* sampler I entry points (kept for the existing callers) */
+int orc_mtbayesc_I_sweep(const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
+                         int t, float* r, int64_t ld_r, float* alpha, float* beta, float* delta,
+                         const float* vare, const float* var_effect,
+                         const double* log_prior, int prior_is_matrix,
+                         uint64_t seed, uint32_t iter, uint32_t marker0, int acc)
+{
+    return orc_mt_sweep(MT_SAMPLER_I, X, n, p, ld, xpx, t, r, ld_r, alpha, beta, delta, vare, var_effect,
+                        log_prior, prior_is_matrix, seed, iter, marker0, acc);
+}
+
+int orc_mtbayesc_I_block_sweep(const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
+                               const int64_t* block_starts, int64_t nblocks, const float* grams,
+                               int t, float* r, int64_t ld_r, float* alpha, float* beta, float* delta,
+                               const float* vare, const float* var_effect,
+                               const double* log_prior, int prior_is_matrix, int nreps_arg,
+                               uint64_t seed, uint32_t iter, uint32_t marker0, int acc)
+{
+    return orc_mt_block_sweep(MT_SAMPLER_I, X, n, p, ld, xpx, block_starts, nblocks, grams, t, r, ld_r, alpha, beta,
+                              delta, vare, var_effect, log_prior, prior_is_matrix, nreps_arg, seed, iter, marker0, acc);
+}
+
+int orc_mtbayesc_I_lookahead_sweep(const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
+                                   const int64_t* block_starts, int64_t nblocks, const float* grams,
+                                   int t, float* r, int64_t ld_r, float* alpha, float* beta, float* delta,
+                                   const float* vare, const float* var_effect,
+                                   const double* log_prior, int prior_is_matrix, int nreps_arg,
+                                   uint64_t seed, uint32_t iter, uint32_t marker0, int acc)
+{
+    return orc_mt_lookahead_sweep(MT_SAMPLER_I, X, n, p, ld, xpx, block_starts, nblocks, grams, t, r, ld_r, alpha,
+                                  beta, delta, vare, var_effect, log_prior, prior_is_matrix, nreps_arg, seed, iter,
+                                  marker0, acc);
+}
+
 
 /* ------------------------------------------------------------------------------------------ */
 /* running posterior means (output.jl:568-577)                                                 */

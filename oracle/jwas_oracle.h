@@ -140,6 +140,28 @@ int orc_mtbayesc_I_lookahead_sweep(const float* X, int64_t n, int64_t p, int64_t
                                    const double* log_prior, int prior_is_matrix, int nreps,
                                    uint64_t seed, uint32_t iter, uint32_t marker0, int acc);
 
+/* ---- multi-trait, any sampler kind: 1 = Gibbs sampler I (MTBayesABC.jl:57-127), 2 = sampler II (joint
+ * state, MTBayesABC.jl:129-210), 3 = megaBayesABC! (BayesABC.jl:1-8: t independent single-trait BayesC sweeps
+ * with vare[k,k], var_effect[k,k]; `log_prior` then holds the per-trait pi (probability of a zero effect),
+ * t values).  Same argument meaning as the sampler-I functions; dense, block and lookahead forms. */
+#define ORC_MT_SAMPLER_I  1
+#define ORC_MT_SAMPLER_II 2
+#define ORC_MT_MEGA       3
+int orc_mt_sweep(int kind, const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
+                 int t, float* r, int64_t ld_r, float* alpha, float* beta, float* delta,
+                 const float* vare, const float* var_effect, const double* log_prior, int prior_is_matrix,
+                 uint64_t seed, uint32_t iter, uint32_t marker0, int acc);
+int orc_mt_block_sweep(int kind, const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
+                       const int64_t* block_starts, int64_t nblocks, const float* grams,
+                       int t, float* r, int64_t ld_r, float* alpha, float* beta, float* delta,
+                       const float* vare, const float* var_effect, const double* log_prior, int prior_is_matrix,
+                       int nreps, uint64_t seed, uint32_t iter, uint32_t marker0, int acc);
+int orc_mt_lookahead_sweep(int kind, const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
+                           const int64_t* block_starts, int64_t nblocks, const float* grams,
+                           int t, float* r, int64_t ld_r, float* alpha, float* beta, float* delta,
+                           const float* vare, const float* var_effect, const double* log_prior, int prior_is_matrix,
+                           int nreps, uint64_t seed, uint32_t iter, uint32_t marker0, int acc);
+
 /* ---- running posterior means (output.jl:568-577) ------------------------------------------ */
 /* mean += (x-mean)/k ; mean2 += (x^2-mean2)/k ; freq += (ind-freq)/k, ind = delta (BayesC) or
  * delta>1 (BayesR, delta_is_class != 0). */

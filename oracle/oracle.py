@@ -212,10 +212,14 @@ def bayesr_sigma_suffstats(alpha, delta, gamma=GAMMA):
     return ssq.value, nnz.value
 
 
-def mtbayesc_I_sweep(X, xpx_, r, alpha, beta, delta, vare, var_effect, log_prior, seed, it,
-                     marker0=0, acc=ACC_F64, block_starts=None, grams=None, nreps=1, lookahead=False):
-    """r: t x ld_r float32 C-contiguous; alpha/beta/delta: t x p float32 C-contiguous.
-    log_prior: 2^t (global) or p x 2^t (marker-specific), float64."""
+MT_SAMPLER_I, MT_SAMPLER_II, MT_MEGA = 1, 2, 3
+
+
+def mt_sweep(kind, X, xpx_, r, alpha, beta, delta, vare, var_effect, log_prior, seed, it,
+             marker0=0, acc=ACC_F64, block_starts=None, grams=None, nreps=1, lookahead=False):
+    """Multi-trait sweep, kind = MT_SAMPLER_I / MT_SAMPLER_II / MT_MEGA.
+    r: t x ld_r float32 C-contiguous; alpha/beta/delta: t x p float32 C-contiguous.
+    log_prior: 2^t (global) or p x 2^t (marker-specific) float64; for MT_MEGA the t per-trait pi values."""
     n, p, ld = _xinfo(X)
     t = r.shape[0]
     ld_r = r.shape[1]
@@ -226,24 +230,28 @@ def mtbayesc_I_sweep(X, xpx_, r, alpha, beta, delta, vare, var_effect, log_prior
     for a in (r, alpha, beta, delta):
         assert a.dtype == np.float32 and a.flags.c_contiguous
     if block_starts is None:
-        rc = lib().orc_mtbayesc_I_sweep(_p(X, _f32p), C.c_int64(n), C.c_int64(p), C.c_int64(ld), _p(xpx_, _f32p),
-                                        C.c_int(t), _p(r, _f32p), C.c_int64(ld_r),
-                                        _p(alpha, _f32p), _p(beta, _f32p), _p(delta, _f32p),
-                                        _p(ve, _f32p), _p(vg, _f32p), _p(lp, _f64p), C.c_int(is_mat),
-                                        C.c_uint64(seed), C.c_uint32(it), C.c_uint32(marker0), C.c_int(acc))
+        rc = lib().orc_mt_sweep(C.c_int(kind), _p(X, _f32p), C.c_int64(n), C.c_int64(p), C.c_int64(ld), _p(xpx_, _f32p),
+                                C.c_int(t), _p(r, _f32p), C.c_int64(ld_r),
+                                _p(alpha, _f32p), _p(beta, _f32p), _p(delta, _f32p),
+                                _p(ve, _f32p), _p(vg, _f32p), _p(lp, _f64p), C.c_int(is_mat),
+                                C.c_uint64(seed), C.c_uint32(it), C.c_uint32(marker0), C.c_int(acc))
     else:
         bs = np.ascontiguousarray(block_starts, dtype=np.int64)
         g = _f32(grams)
-        fn = lib().orc_mtbayesc_I_lookahead_sweep if lookahead else lib().orc_mtbayesc_I_block_sweep
-        rc = fn(_p(X, _f32p), C.c_int64(n), C.c_int64(p), C.c_int64(ld), _p(xpx_, _f32p),
-                                              _p(bs, _i64p), C.c_int64(len(bs)), _p(g, _f32p),
-                                              C.c_int(t), _p(r, _f32p), C.c_int64(ld_r),
-                                              _p(alpha, _f32p), _p(beta, _f32p), _p(delta, _f32p),
-                                              _p(ve, _f32p), _p(vg, _f32p), _p(lp, _f64p), C.c_int(is_mat),
-                                              C.c_int(nreps),
-                                              C.c_uint64(seed), C.c_uint32(it), C.c_uint32(marker0), C.c_int(acc))
+        fn = lib().orc_mt_lookahead_sweep if lookahead else lib().orc_mt_block_sweep
+        rc = fn(C.c_int(kind), _p(X, _f32p), C.c_int64(n), C.c_int64(p), C.c_int64(ld), _p(xpx_, _f32p),
+                _p(bs, _i64p), C.c_int64(len(bs)), _p(g, _f32p),
+                C.c_int(t), _p(r, _f32p), C.c_int64(ld_r),
+                _p(alpha, _f32p), _p(beta, _f32p), _p(delta, _f32p),
+                _p(ve, _f32p), _p(vg, _f32p), _p(lp, _f64p), C.c_int(is_mat),
+                C.c_int(nreps),
+                C.c_uint64(seed), C.c_uint32(it), C.c_uint32(marker0), C.c_int(acc))
     if rc != 0:
-        raise ValueError(f"oracle MT sampler I rejected its arguments (rc={rc})")
+        raise ValueError(f"oracle multi-trait sweep (kind {kind}) rejected its arguments (rc={rc})")
+
+
+def mtbayesc_I_sweep(X, xpx_, r, alpha, beta, delta, vare, var_effect, log_prior, seed, it, **kw):
+    mt_sweep(MT_SAMPLER_I, X, xpx_, r, alpha, beta, delta, vare, var_effect, log_prior, seed, it, **kw)
 
 
 def accumulate(alpha, delta, k, mean_alpha, mean_alpha2, mean_delta):

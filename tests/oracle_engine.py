@@ -10,8 +10,9 @@ import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
 import oracle as O  # noqa: E402
 
-BAYESC, BAYESB, BAYESR, MTBAYESC1 = 0, 1, 2, 3
-METHOD_CODES = {"BayesC": BAYESC, "BayesB": BAYESB, "BayesA": BAYESB, "BayesR": BAYESR, "MTBayesC": MTBAYESC1}
+BAYESC, BAYESB, BAYESR, MTBAYESC1, MTBAYESC2, MEGABAYESC = 0, 1, 2, 3, 4, 5
+METHOD_CODES = {"BayesC": BAYESC, "BayesB": BAYESB, "BayesA": BAYESB, "BayesR": BAYESR, "MTBayesC": MTBAYESC1,
+                "MTBayesC_II": MTBAYESC2, "MegaBayesC": MEGABAYESC}
 
 
 class OracleEngine:
@@ -112,10 +113,12 @@ class OracleEngine:
                            float(np.asarray(vare).reshape(-1)[0]), float(np.asarray(var_effect).reshape(-1)[0]),
                            pc, seed, iteration, gamma=gamma, marker0=marker_offset, acc=self.acc, **blk)
         else:
-            O.mtbayesc_I_sweep(self.X, self._xpx, self.r, self.alpha, self.beta, self.delta,
-                               np.asarray(vare, dtype=np.float32).reshape(t, t),
-                               np.asarray(var_effect, dtype=np.float32).reshape(t, t),
-                               log_prior_states, seed, iteration, marker0=marker_offset, acc=self.acc, **blk)
+            kind = {MTBAYESC1: O.MT_SAMPLER_I, MTBAYESC2: O.MT_SAMPLER_II, MEGABAYESC: O.MT_MEGA}[self.method]
+            prior = np.asarray(pi, dtype=np.float64).reshape(-1) if self.method == MEGABAYESC else log_prior_states
+            O.mt_sweep(kind, self.X, self._xpx, self.r, self.alpha, self.beta, self.delta,
+                       np.asarray(vare, dtype=np.float32).reshape(t, t),
+                       np.asarray(var_effect, dtype=np.float32).reshape(t, t),
+                       prior, seed, iteration, marker0=marker_offset, acc=self.acc, **blk)
         return self._stats(a_before, gamma)
 
     def _stats(self, a_before, gamma):

@@ -234,6 +234,96 @@ def test_mt_sampler1_parity(hip, t, bs):
         _compare_state(orc, hip, k, atol=5e-6)
 
 
+@pytest.mark.parametrize("t,bs,nreps", [(2, 64, 1), (2, 128, 1), (3, 128, 1), (4, 64, 1), (2, 64, 2)])
+def test_mt_sampler2_parity(hip, t, bs, nreps):
+    """Joint-state Gibbs sampler II (MTBayesABC.jl:129-210) against the oracle's restatement."""
+    data = make_dataset(n=500, p=2 * bs + 13, ncausal=10, seed=600 + t)
+    orc, hip = _pair(hip, data, bs, "MTBayesC_II", ntraits=t)
+    rng = np.random.default_rng(10 + t)
+    Y = np.stack([data["y"] - data["y"].mean() + 0.3 * rng.standard_normal(len(data["y"])).astype(np.float32)
+                  for _ in range(t)]).astype(np.float32)
+    for k in range(t):
+        orc.set_residual(Y[k], k)
+        hip.set_residual(Y[k], k)
+    A = rng.standard_normal((t, t))
+    vare = (A @ A.T / t + np.eye(t)).astype(np.float32) * 0.5
+    B = rng.standard_normal((t, t))
+    varg = ((B @ B.T / t + np.eye(t)) * 0.002).astype(np.float32)
+    prior = rng.dirichlet(np.ones(1 << t)) * 0.2
+    prior[0] += 0.8                                     # most markers out of the model
+    lp = np.log(prior)
+    for it in range(1, 13):
+        so = orc.sweep(iteration=it, seed=13, vare=vare, var_effect=varg, log_prior_states=lp, nreps=nreps)
+        sh = hip.sweep(iteration=it, seed=13, vare=vare, var_effect=varg, log_prior_states=lp, nreps=nreps)
+        assert np.array_equal(so["state_counts"], sh["state_counts"]), f"iteration {it}"
+        np.testing.assert_allclose(sh["beta_ss"], so["beta_ss"], rtol=1e-5)
+        np.testing.assert_allclose(sh["resid_ss"], so["resid_ss"], rtol=1e-5)
+    assert so["state_counts"][1:].sum() > 0
+    for k in range(t):
+        _compare_state(orc, hip, k, atol=5e-6)
+
+
+def test_mt_sampler2_restrictive_prior_all_or_none(hip):
+    """Sampler II exists for priors with zero-probability states ('a locus affects all traits or none',
+    MTBayesABC.jl:4): only states 00 and 11 may appear; an all-zero prior is the reference's error (:190)."""
+    data = make_dataset(n=300, p=150, ncausal=5, seed=71)
+    orc, hip = _pair(hip, data, 64, "MTBayesC_II", ntraits=2)
+    y = data["y"] - data["y"].mean()
+    for k in range(2):
+        orc.set_residual(y * (1 + k), k)
+        hip.set_residual(y * (1 + k), k)
+    vare = np.array([[0.5, 0.1], [0.1, 0.9]], dtype=np.float32)
+    varg = np.array([[0.003, 0.001], [0.001, 0.004]], dtype=np.float32)
+    with np.errstate(divide="ignore"):
+        lp = np.log(np.array([0.7, 0.0, 0.0, 0.3]))
+    for it in range(1, 9):
+        so = orc.sweep(iteration=it, seed=2, vare=vare, var_effect=varg, log_prior_states=lp)
+        sh = hip.sweep(iteration=it, seed=2, vare=vare, var_effect=varg, log_prior_states=lp)
+        assert sh["state_counts"][1] == 0 and sh["state_counts"][2] == 0
+        assert np.array_equal(so["state_counts"], sh["state_counts"])
+    assert sh["state_counts"][3] > 0
+    for k in range(2):
+        _compare_state(orc, hip, k, atol=5e-6)
+    import jwas_jl_amd as J
+    with pytest.raises(J.JwasHipError, match="state probabilities are zero or invalid"):
+        hip.sweep(iteration=1, seed=2, vare=vare, var_effect=varg, log_prior_states=np.full(4, -np.inf))
+
+
+@pytest.mark.parametrize("t,bs", [(2, 64), (3, 256), (4, 128)])
+def test_mega_bayesc_parity(hip, t, bs):
+    """megaBayesABC! (BayesABC.jl:1-8): t independent single-trait chains in one pass over X; trait 0 is
+    bit-identical to the single-trait BayesC chain (same draw slot)."""
+    data = make_dataset(n=500, p=2 * bs + 29, ncausal=10, seed=700 + t)
+    orc, hip = _pair(hip, data, bs, "MegaBayesC", ntraits=t)
+    rng = np.random.default_rng(20 + t)
+    Y = np.stack([(1 + 0.5 * k) * (data["y"] - data["y"].mean()) + 0.3 * rng.standard_normal(len(data["y"])).astype(np.float32)
+                  for k in range(t)]).astype(np.float32)
+    for k in range(t):
+        orc.set_residual(Y[k], k)
+        hip.set_residual(Y[k], k)
+    v, g = _hyper(data)
+    vare = np.diag([float(v) * (1 + 0.3 * k) for k in range(t)]).astype(np.float32)
+    varg = np.diag([float(g) * (1 + 0.2 * k) for k in range(t)]).astype(np.float32)
+    pis = np.array([0.95 - 0.1 * k for k in range(t)])
+    for it in range(1, 16):
+        so = orc.sweep(iteration=it, seed=17, vare=vare, var_effect=varg, pi=pis)
+        sh = hip.sweep(iteration=it, seed=17, vare=vare, var_effect=varg, pi=pis)
+        assert np.array_equal(so["sum_delta"], sh["sum_delta"]), f"iteration {it}"
+    for k in range(t):
+        _compare_state(orc, hip, k, atol=5e-6)
+    # trait 0 == the single-trait chain
+    a_mega, b_mega, d_mega = hip.get_state(0)
+    r_mega = hip.get_residual(0)
+    hip.init_state("BayesC", 1)
+    hip.set_residual(Y[0])
+    for it in range(1, 16):
+        hip.sweep(iteration=it, seed=17, vare=vare[0, 0], var_effect=varg[0, 0], pi=float(pis[0]))
+    a1, b1, d1 = hip.get_state(0)
+    assert np.array_equal(d1, d_mega)
+    np.testing.assert_allclose(a1, a_mega, rtol=0, atol=5e-6)
+    np.testing.assert_allclose(hip.get_residual(0), r_mega, rtol=0, atol=2e-5)
+
+
 def test_accumulate_mul_alpha_sub_xalpha(hip, small_data):
     orc, hip = _pair(hip, small_data, 64, "BayesC")
     rng = np.random.default_rng(3)

@@ -159,6 +159,57 @@ def test_runmcmc_multitrait_and_fixed_effects(tmp_path):
     assert "EBV_y1" in out and "EBV_y2" in out
 
 
+def _two_trait(n=250, p=192, seed=5):
+    d = make_dataset(n=n, p=p, ncausal=4, seed=seed, center=False)
+    rng = np.random.default_rng(1)
+    ids = [str(i) for i in range(n)]
+    y2 = 0.6 * d["y"] + rng.standard_normal(n) * 0.5
+    ph = pd.DataFrame({"ID": ids, "y1": d["y"].astype(np.float32), "y2": y2.astype(np.float32)})
+    gdf = pd.DataFrame(d["raw"], columns=[f"s{j}" for j in range(p)])
+    gdf.insert(0, "ID", ids)
+    return d, ph, gdf
+
+
+def test_runmcmc_multitrait_sampler_II(tmp_path):
+    """multi_trait_sampler=:II (readgenotypes.jl:227, MTBayesABC.jl:129-210): joint-state sampler; with the
+    restrictive all-or-none prior only states 00 and 11 keep mass."""
+    d, ph, gdf = _two_trait()
+    Pi = {(0.0, 0.0): 0.7, (1.0, 0.0): 0.0, (0.0, 1.0): 0.0, (1.0, 1.0): 0.3}
+    geno = api.get_genotypes(gdf, method="BayesC", Pi=Pi, estimatePi=False, multi_trait_sampler="II")
+    model = api.build_model("y1 = intercept + geno\ny2 = intercept + geno")
+    out = api.runMCMC(model, ph, chain_length=60, burnin=10, seed=3, output_folder=str(tmp_path / "mt2"),
+                      engine=OracleEngine("block"), block_size=64)
+    me = out["marker effects geno"]
+    f1 = me[me.Trait == "y1"]["Model_Frequency"].to_numpy()
+    f2 = me[me.Trait == "y2"]["Model_Frequency"].to_numpy()
+    assert np.array_equal(f1, f2)                       # a locus affects both traits or none
+    assert 0 < f1.mean() < 1
+    causal = [f"s{j}" for j in d["causal"]]
+    top = set(me[me.Trait == "y1"].sort_values("Model_Frequency", ascending=False)["Marker_ID"].head(10))
+    assert len(top & set(causal)) >= 2
+
+
+def test_runmcmc_constraint_true_runs_mega_path(tmp_path):
+    """constraint=true on G and R (readgenotypes.jl:219, build_MME.jl): megaBayesABC! = independent single-trait
+    chains, diagonal variance draws, one pi per trait (MCMC_BayesianAlphabet.jl:233-234,300-301)."""
+    d, ph, gdf = _two_trait()
+    geno = api.get_genotypes(gdf, method="BayesC", Pi={(0.0, 0.0): 0.8, (1.0, 0.0): 0.05, (0.0, 1.0): 0.05, (1.0, 1.0): 0.1},
+                             estimatePi=True, constraint=True)
+    model = api.build_model("y1 = intercept + geno\ny2 = intercept + geno", constraint=True)
+    out = api.runMCMC(model, ph, chain_length=60, burnin=10, seed=3, output_folder=str(tmp_path / "mega"),
+                      engine=OracleEngine("block"), block_size=64)
+    rv = out["residual variance"]["Estimate"].to_numpy().reshape(2, 2)
+    gv = out["marker effects variance geno"]["Estimate"].to_numpy().reshape(2, 2)
+    assert rv[0, 1] == 0 and rv[1, 0] == 0 and gv[0, 1] == 0 and gv[1, 0] == 0
+    assert rv[0, 0] > 0 and gv[1, 1] > 0
+    assert list(out["pi_geno"]["π"]) == ["y1", "y2"]
+    assert np.all((out["pi_geno"]["Estimate"] > 0.5) & (out["pi_geno"]["Estimate"] < 1))
+    single = api.get_genotypes(gdf, method="BayesC", Pi=0.5, constraint=True)
+    m1 = api.build_model("y1 = intercept + single", genotypes={"single": single})
+    with pytest.raises(ValueError, match="constraint==true is for multi-trait only"):
+        api.runMCMC(m1, ph, chain_length=2, output_folder=str(tmp_path / "e"), engine=OracleEngine("block"), block_size=64)
+
+
 def test_runmcmc_contract_errors(tmp_path):
     geno_df, ph = _six_animals()
     geno = api.get_genotypes(geno_df, 1.0, quality_control=False)

@@ -197,6 +197,94 @@ def test_mt_sampler1_matches_closed_form_state_posterior(block):
     assert np.abs(emp - exact).max() < 0.02
 
 
+@pytest.mark.parametrize("block", [False, True])
+def test_mt_sampler2_matches_closed_form_state_posterior(block):
+    """Sampler II draws the joint state from its marginal full conditional (MTBayesABC.jl:129-210):
+    same one-marker closed form as above, plus E[beta | state 11] = lhs^-1 rhs."""
+    x = np.array([1.0, -0.5, 0.75])
+    ys = [np.array([0.8, -0.1, 0.3]), np.array([0.2, 0.6, -0.4])]
+    vare = np.array([[1.0, 0.25], [0.25, 0.9]])
+    var_effect = np.array([[0.7, 0.15], [0.15, 0.8]])
+    prior = np.array([0.35, 0.20, 0.15, 0.30])
+    exact = _exact_mt_state_probs(x, ys, vare, var_effect, prior)
+    X = np.asfortranarray(x.astype(np.float32)[:, None])
+    xpx = O.xpx(X)
+    r = np.ascontiguousarray(np.stack(ys).astype(np.float32))
+    a, b, d = (np.zeros((2, 1), dtype=np.float32) for _ in range(3))
+    kw = dict(block_starts=np.array([0]), grams=O.gram(X, 0, 1).ravel(), nreps=1) if block else {}
+    counts = np.zeros(4)
+    bsum, nb = np.zeros(2), 0
+    for it in range(1, 12001):
+        O.mt_sweep(O.MT_SAMPLER_II, X, xpx, r, a, b, d, vare, var_effect, np.log(prior), 20260411, it, **kw)
+        st = int(d[0, 0]) + 2 * int(d[1, 0])
+        counts[st] += 1
+        assert np.array_equal(a[:, 0], b[:, 0] * d[:, 0])              # alpha = D * beta (:201)
+        if st == 3:
+            bsum += b[:, 0]; nb += 1
+    assert np.abs(counts / counts.sum() - exact).max() < 0.02
+    xp = float(x @ x)
+    Rinv, Ginv = np.linalg.inv(vare), np.linalg.inv(var_effect)
+    ghat = np.linalg.solve(Rinv * xp + Ginv, Rinv.T @ np.array([x @ y for y in ys]))
+    assert np.abs(bsum / nb - ghat).max() < 0.05
+    # the residual identity holds: r = y - x*alpha
+    assert np.abs(r - (np.stack(ys) - np.outer(a[:, 0], x))).max() < 1e-5
+
+
+@pytest.mark.parametrize("kind", ["II", "mega"])
+def test_mt_block_and_lookahead_forms_equal_dense_chain(small_data, kind):
+    X = small_data["X"][:, :600]
+    n, p = X.shape
+    rng = np.random.default_rng(3)
+    Y = np.stack([small_data["y"], small_data["y"][::-1] + rng.normal(size=n).astype(np.float32)]).astype(np.float32)
+    Y -= Y.mean(axis=1, keepdims=True)
+    xpx = O.xpx(X)
+    bstarts = O.block_starts_for(p, 64)
+    grams = O.grams_for(X, bstarts)
+    vare = np.array([[0.6, 0.1], [0.1, 0.8]], dtype=np.float32)
+    vg = np.array([[0.004, 0.001], [0.001, 0.005]], dtype=np.float32)
+    if kind == "mega":
+        k, prior = O.MT_MEGA, np.array([0.9, 0.8])
+        vare, vg = np.diag(np.diag(vare)), np.diag(np.diag(vg))
+    else:
+        k, prior = O.MT_SAMPLER_II, np.log(np.array([0.8, 0.05, 0.05, 0.1]))
+    out = []
+    for form in ("dense", "block", "lookahead"):
+        r = np.ascontiguousarray(Y.copy())
+        a, b, d = (np.zeros((2, p), dtype=np.float32) for _ in range(3))
+        kw = {} if form == "dense" else dict(block_starts=bstarts, grams=grams, nreps=1, lookahead=(form == "lookahead"))
+        for it in range(1, 13):
+            O.mt_sweep(k, X, xpx, r, a, b, d, vare, vg, prior, 77, it, **kw)
+        out.append((a, d, r))
+        assert np.abs(r - (Y - (X.astype(np.float64) @ a.T.astype(np.float64)).T)).max() < 2e-4
+    for o in out[1:]:
+        assert np.array_equal(out[0][1], o[1])
+        assert np.abs(out[0][0] - o[0]).max() < 2e-5
+        assert np.abs(out[0][2] - o[2]).max() < 2e-4
+    assert 0 < out[0][1].sum() < 2 * p
+
+
+def test_mega_trait0_is_the_single_trait_chain(small_data):
+    """megaBayesABC! = t independent BayesABC! sweeps (BayesABC.jl:1-8): trait 0 (draw slot 0) reproduces the
+    single-trait oracle bit for bit."""
+    X = small_data["X"][:, :500]
+    n, p = X.shape
+    y = small_data["y"] - small_data["y"].mean()
+    Y = np.ascontiguousarray(np.stack([y, 0.5 * y[::-1]]).astype(np.float32))
+    xpx = O.xpx(X)
+    vare = np.diag([0.5, 0.7]).astype(np.float32)
+    vg = np.diag([0.004, 0.002]).astype(np.float32)
+    r = Y.copy()
+    a, b, d = (np.zeros((2, p), dtype=np.float32) for _ in range(3))
+    r1 = Y[0].copy()
+    a1, b1, d1 = (np.zeros(p, dtype=np.float32) for _ in range(3))
+    for it in range(1, 9):
+        O.mt_sweep(O.MT_MEGA, X, xpx, r, a, b, d, vare, vg, np.array([0.9, 0.7]), 11, it)
+        O.bayesabc_sweep(X, xpx, r1, a1, b1, d1, 0.5, 0.004, 0.9, 11, it)
+    assert np.array_equal(a[0], a1) and np.array_equal(b[0], b1) and np.array_equal(d[0], d1)
+    assert np.array_equal(r[0], r1)
+    assert d[1].sum() > 0
+
+
 # ---- test/unit/test_streaming_codec.jl:21-51, test_streaming_prepare_lowmem.jl:22-49: 2-bit codec ------
 def _pack_2bit(raw, missing=9):
     """Marker-major packing of streaming_genotypes.jl:364-367,622-627 (test-side restatement)."""
