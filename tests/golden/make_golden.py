@@ -1,5 +1,5 @@
 """Generates tests/golden/sweep_golden.npz: seeded inputs and the CPU oracle's outputs for a handful of
-sweeps (BayesC at two block sizes, BayesR, 2-trait BayesC sampler I).  The reference ships no golden
+sweeps (BayesC at two block sizes, BayesR, 2-trait BayesC samplers I and II, 2-trait megaBayesABC).  The reference ships no golden
 vectors for sampler output and cannot run here (no Julia), so these vectors pin the ORACLE's behaviour
 (regression) and give the GPU box a checker-independent target; what ties the oracle to the reference
 is tests/test_oracle_kat.py.    Run:  python tests/golden/make_golden.py
@@ -23,6 +23,13 @@ CASES = {
                     kw=dict(vare=np.array([[0.5, 0.1], [0.1, 0.4]], dtype=np.float32),
                             var_effect=np.array([[0.004, 0.001], [0.001, 0.003]], dtype=np.float32),
                             log_prior_states=np.log(np.array([0.6, 0.1, 0.1, 0.2])))),
+    "mt2_sampler2_b64": dict(method="MTBayesC_II", bs=64, sweeps=8, t=2,
+                             kw=dict(vare=np.array([[0.5, 0.1], [0.1, 0.4]], dtype=np.float32),
+                                     var_effect=np.array([[0.004, 0.001], [0.001, 0.003]], dtype=np.float32),
+                                     log_prior_states=np.log(np.array([0.7, 0.05, 0.05, 0.2])))),
+    "mega2_b128": dict(method="MegaBayesC", bs=128, sweeps=8, t=2,
+                       kw=dict(vare=np.diag([0.5, 0.4]).astype(np.float32),
+                               var_effect=np.diag([0.004, 0.003]).astype(np.float32), pi=np.array([0.9, 0.8]))),
 }
 SEED = 424242
 
