@@ -80,7 +80,9 @@ typedef struct jwas_sweep_params {
     uint32_t iteration;                 /* MCMC iteration index (enters the RNG counter)             */
     uint64_t seed;                      /* runMCMC(seed=...) (JWAS.jl:239-251)                       */
     uint32_t marker_offset;             /* global index of this context's column 0 (marker shards)   */
-    uint32_t reserved;
+    uint32_t independent_blocks;        /* != 0: independent-block sweep (MCMCinfo.independent_blocks,   */
+                                        /* BayesABC.jl:190-255): every block starts from the same        */
+                                        /* residual snapshot; reconcile r += sum_b X_b*dalpha_b afterwards */
     float    vare[JWAS_HIP_MAX_TRAITS * JWAS_HIP_MAX_TRAITS];        /* residual (co)variance, row-major t x t */
     float    var_effect[JWAS_HIP_MAX_TRAITS * JWAS_HIP_MAX_TRAITS];  /* BayesC: sigma2_alpha; BayesR: sigmaSq; MT: t x t (MEGA: diagonal used) */
     double   pi;                        /* BayesC/B scalar Pr(effect = 0); ignored if pi_vec != NULL */

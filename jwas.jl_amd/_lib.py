@@ -33,7 +33,7 @@ SYMBOLS = [
 class SweepParams(C.Structure):
     _fields_ = [
         ("method", C.c_int32), ("ntraits", C.c_int32), ("nreps", C.c_int32), ("iteration", C.c_uint32),
-        ("seed", C.c_uint64), ("marker_offset", C.c_uint32), ("reserved", C.c_uint32),
+        ("seed", C.c_uint64), ("marker_offset", C.c_uint32), ("independent_blocks", C.c_uint32),
         ("vare", C.c_float * (MAX_TRAITS * MAX_TRAITS)),
         ("var_effect", C.c_float * (MAX_TRAITS * MAX_TRAITS)),
         ("pi", C.c_double), ("pi_classes", C.c_double * 4), ("gamma", C.c_double * 4),

@@ -248,12 +248,14 @@ def runMCMC(model, df, *, heterogeneous_residuals=False, chain_length=100, start
     fast_blocks: False -> the exact non-block chain (computed on the device in blocks with one
     within-block pass, algebraically identical: SURVEY.md section 7 step 4); True / number -> the
     reference's fast_blocks schedule (block-size repetitions, chain_length rescaled, JWAS.jl:293-316).
+    independent_blocks=True (needs fast_blocks): every block starts from the same residual snapshot and all blocks are
+    sampled concurrently on the device (BayesABC.jl:190-255) -- the reference's approximate parallel mode.
     `engine` injects a sweep engine (tests); the default and only shipped engine is HipEngine."""
     if independent_blocks and fast_blocks is False:
         raise ValueError("independent_blocks=true requires fast_blocks != false.")             # :242-244
     for flag, name in ((heterogeneous_residuals, "heterogeneous_residuals"), (single_step_analysis, "single_step_analysis"),
                        (causal_structure, "causal_structure"), (RRM, "RRM"), (double_precision, "double_precision"),
-                       (independent_blocks, "independent_blocks"), (update_priors_frequency, "update_priors_frequency"),
+                       (update_priors_frequency, "update_priors_frequency"),
                        (prediction_equation, "prediction_equation")):
         if not _is_false(flag) and flag != 0:
             raise NotImplementedError(f"runMCMC(...; {name}=...) is outside the device marker path and stays on the reference")
@@ -274,7 +276,8 @@ def runMCMC(model, df, *, heterogeneous_residuals=False, chain_length=100, start
     os.makedirs(output_folder)
     return run_chain(model, df, chain_length=int(chain_length), burnin=int(burnin),
                      output_samples_frequency=int(output_samples_frequency), seed=seed,
-                     starting_value=starting_value, fast_blocks=fast_blocks, outputEBV=outputEBV,
+                     starting_value=starting_value, fast_blocks=fast_blocks,
+                     independent_blocks=bool(independent_blocks), outputEBV=outputEBV,
                      output_folder=output_folder, printout_frequency=printout_frequency,
                      memory_guard=memory_guard, memory_guard_ratio=memory_guard_ratio,
                      missing_phenotypes=missing_phenotypes, device=device, block_size=block_size,

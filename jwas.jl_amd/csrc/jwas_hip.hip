@@ -43,6 +43,13 @@ struct jwas_hip_ctx {
 
     double* partials = nullptr;
     Events* ev = nullptr;               // [2]
+    // independent-block mode (allocated on first use)
+    double* ipartials = nullptr;        // [nblocks][t][nrg][bs]
+    Events* ev_all = nullptr;           // [nblocks] per-block change lists
+    int32_t* ev_offs = nullptr;         // [nblocks + 1] exclusive scan of the counts; [nblocks] = total
+    int32_t* idx_all = nullptr;         // [p] compacted change list, (block, marker) order
+    float* delta_all = nullptr;         // [kMaxT][p]
+    int ind_traits = 0;
     DevParams* dparams = nullptr;
     unsigned long long* counters = nullptr;
     double* fin_out = nullptr;          // [nslices][kMaxT*kMaxT + kMaxT]
@@ -151,6 +158,8 @@ static void free_blocks(jwas_hip_ctx* c)
 {
     (void)hipFree(c->xpx); (void)hipFree(c->gram); (void)hipFree(c->cross); (void)hipFree(c->corr); (void)hipFree(c->partials);
     c->xpx = c->gram = c->cross = c->corr = nullptr; c->partials = nullptr;
+    (void)hipFree(c->ipartials); (void)hipFree(c->ev_all); (void)hipFree(c->ev_offs); (void)hipFree(c->idx_all); (void)hipFree(c->delta_all);
+    c->ipartials = nullptr; c->ev_all = nullptr; c->ev_offs = nullptr; c->idx_all = nullptr; c->delta_all = nullptr; c->ind_traits = 0;
 }
 
 static void free_storage(jwas_hip_ctx* c)
@@ -582,6 +591,82 @@ static int upload_vec(jwas_hip_ctx* c, void** dev, const void* host, size_t byte
     return JWAS_HIP_OK;
 }
 
+// Independent-block sweep (BayesABC_block_independent!, BayesABC.jl:190-255): all block RHS from the residual
+// snapshot (one pass over X), all blocks sampled concurrently, change lists compacted in (block, marker) order;
+// the caller's k_finish applies them to the residual.
+template <int METHOD, int NT>
+static hipError_t launch_indep(jwas_hip_ctx* c, const UpdateArgs& U, const SamplerArgs& S, int64_t pstride)
+{
+    const StepSmem SM(c->block_size, NT, is_mt_method(METHOD) ? 0 : (METHOD == kBayesR ? 12 : 4), is_mt_method(METHOD) ? 0 : (METHOD == kBayesR ? 1 : 4));
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_indep_sample<METHOD, NT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const size_t red = sizeof(double) * kRowGroupSlices * kColChunk * NT;
+    hipLaunchKernelGGL((k_indep_rhs<NT>), dim3((unsigned)(U.nrg * U.ncg), (unsigned)c->nblocks), dim3(kStepThreads), red, c->stream,
+                       U, c->p, c->block_size, pstride);
+    hipLaunchKernelGGL((k_indep_sample<METHOD, NT>), dim3((unsigned)c->nblocks), dim3(kStepThreads), SM.bytes, c->stream,
+                       S, pstride, c->ev_all);
+    return hipGetLastError();
+}
+
+static int sweep_independent(jwas_hip_ctx* c, EventList* out)
+{
+    const int t = c->ntraits, bs = c->block_size;
+    const int64_t nb = c->nblocks;
+    NEED(c, nb <= 65535, JWAS_HIP_EUNSUP, "independent blocks: at most 65535 blocks (got %lld)", (long long)nb);
+    const int64_t pstride = (int64_t)t * c->nrg * bs;
+    if (!c->ev_all || c->ind_traits != t) {
+        (void)hipFree(c->ipartials); (void)hipFree(c->ev_all); (void)hipFree(c->ev_offs); (void)hipFree(c->idx_all); (void)hipFree(c->delta_all);
+        c->ipartials = nullptr; c->ev_all = nullptr; c->ev_offs = nullptr; c->idx_all = nullptr; c->delta_all = nullptr;
+        HIPCHK(c, hipMalloc(&c->ipartials, sizeof(double) * (size_t)nb * pstride));
+        HIPCHK(c, hipMalloc(&c->ev_all, sizeof(Events) * (size_t)nb));
+        HIPCHK(c, hipMalloc(&c->ev_offs, sizeof(int32_t) * (size_t)(nb + 1)));
+        HIPCHK(c, hipMalloc(&c->idx_all, sizeof(int32_t) * (size_t)c->p));
+        HIPCHK(c, hipMalloc(&c->delta_all, sizeof(float) * (size_t)kMaxT * c->p));
+        c->ind_traits = t;
+    }
+    HIPCHK(c, hipMemsetAsync(c->corr, 0, sizeof(float) * 2 * kMaxT * (size_t)bs, c->stream));   // corr_in = 0 for every block
+    UpdateArgs U;
+    std::memset(&U, 0, sizeof U);
+    U.X = c->X; U.ld = c->ld; U.r_in = c->r; U.r_out = nullptr;
+    U.ev = &c->ev[0];                               // count zeroed by the caller: nothing to apply
+    U.nslices = c->nslices; U.nrg = c->nrg; U.ncg = c->ncg;
+    U.partials = c->ipartials; U.bstride = bs;
+    SamplerArgs S;
+    std::memset(&S, 0, sizeof S);
+    S.P = c->dparams; S.partials = c->ipartials; S.nrg = c->nrg; S.bstride = bs;
+    S.p = c->p; S.bsz = bs; S.xpx = c->xpx; S.gram = c->gram;
+    S.cross_next = c->gram; S.b_next = 0; S.corr_in = c->corr; S.corr_out = c->corr + (size_t)kMaxT * bs;
+    S.prep_d = c->prep_d; S.prep_f = c->prep_f;
+    S.alpha = c->alpha; S.beta = c->beta; S.delta = c->delta;
+    S.counters = c->counters;
+    hipError_t e;
+    switch (c->method) {
+        case JWAS_HIP_BAYESC: e = launch_indep<kBayesC, 1>(c, U, S, pstride); break;
+        case JWAS_HIP_BAYESB: e = launch_indep<kBayesB, 1>(c, U, S, pstride); break;
+        case JWAS_HIP_BAYESR: e = launch_indep<kBayesR, 1>(c, U, S, pstride); break;
+#define JW_MT_IND(M)                                                              \
+            if (t == 2) e = launch_indep<M, 2>(c, U, S, pstride);                 \
+            else if (t == 3) e = launch_indep<M, 3>(c, U, S, pstride);            \
+            else e = launch_indep<M, 4>(c, U, S, pstride);                        \
+            break;
+        case JWAS_HIP_MTBAYESC2: JW_MT_IND(kMTBayesC2)
+        case JWAS_HIP_MEGABAYESC: JW_MT_IND(kMegaBayesC)
+        default: JW_MT_IND(kMTBayesC1)
+#undef JW_MT_IND
+    }
+    HIPCHK(c, e);
+    hipLaunchKernelGGL(k_indep_scan, dim3(1), dim3(1024), 0, c->stream, c->ev_all, (int)nb, c->ev_offs, c->ev_offs + nb);
+    hipLaunchKernelGGL(k_indep_gather, dim3((unsigned)nb), dim3(256), 0, c->stream, c->ev_all, c->ev_offs, t, c->idx_all, c->delta_all, c->p);
+    HIPCHK(c, hipGetLastError());
+    *out = EventList{c->ev_offs + nb, c->idx_all, c->delta_all, c->p};
+    return JWAS_HIP_OK;
+}
+
 extern "C" {
 
 int jwas_hip_set_kernel_timing(jwas_hip_ctx* c, int32_t stride)
@@ -688,15 +773,22 @@ int jwas_hip_sweep(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_sweep_stats
     }
 
     const int bs = c->block_size;
-    // one-block lookahead pipeline (sweep.hpp): launch k = sampler(block k-1) || update/partial(block k)
     const size_t rstride = (size_t)kMaxT * c->ld;
     const size_t pstride = (size_t)bs * c->nrg * kMaxT;
-    HIPCHK(c, hipMemcpyAsync(c->r + rstride, c->r, sizeof(float) * (size_t)t * c->ld, hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(c, hipMemsetAsync(&c->ev[1].count, 0, sizeof(int32_t), c->stream));
-    HIPCHK(c, hipMemsetAsync(c->corr, 0, sizeof(float) * 2 * kMaxT * (size_t)bs, c->stream));   // block 0 has no predecessor
     size_t ntimed = 0;
     double timed_bytes = 0.0;
     const int64_t nb = c->nblocks;
+    const bool independent = P->independent_blocks != 0;
+    EventList ev_list{nullptr, nullptr, nullptr, 0};
+    const float* r_last = c->r;
+    if (independent) {
+        int rc = sweep_independent(c, &ev_list);
+        if (rc) return rc;
+    } else {
+    // one-block lookahead pipeline (sweep.hpp): launch k = sampler(block k-1) || update/partial(block k)
+    HIPCHK(c, hipMemcpyAsync(c->r + rstride, c->r, sizeof(float) * (size_t)t * c->ld, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(&c->ev[1].count, 0, sizeof(int32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->corr, 0, sizeof(float) * 2 * kMaxT * (size_t)bs, c->stream));   // block 0 has no predecessor
     for (int64_t k = 0; k <= nb; ++k) {
         UpdateArgs U;
         U.X = c->X; U.ld = c->ld;
@@ -743,14 +835,17 @@ int jwas_hip_sweep(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_sweep_stats
             timed_bytes += 4.0 * (double)c->n * (double)U.b;
         }
     }
-    const Events* ev_last = &c->ev[(nb - 1) & 1];
-    const float* r_last = c->r + (nb & 1) * rstride;          // r(nb-2), written by the last step
+    }   // lookahead pipeline
+    if (!independent) {
+        ev_list = event_list(&c->ev[(nb - 1) & 1]);
+        r_last = c->r + (nb & 1) * rstride;                   // r(nb-2), written by the last step
+    }
     const int nfin = t * t + t;
     switch (t) {   // apply the last block's changes; the finished residual always lands in buffer 0
-        case 1: hipLaunchKernelGGL((k_finish<1>), dim3(c->nslices), dim3(256), 0, c->stream, c->X, c->ld, r_last, c->r, ev_last, c->fin_out); break;
-        case 2: hipLaunchKernelGGL((k_finish<2>), dim3(c->nslices), dim3(256), 0, c->stream, c->X, c->ld, r_last, c->r, ev_last, c->fin_out); break;
-        case 3: hipLaunchKernelGGL((k_finish<3>), dim3(c->nslices), dim3(256), 0, c->stream, c->X, c->ld, r_last, c->r, ev_last, c->fin_out); break;
-        default: hipLaunchKernelGGL((k_finish<4>), dim3(c->nslices), dim3(256), 0, c->stream, c->X, c->ld, r_last, c->r, ev_last, c->fin_out);
+        case 1: hipLaunchKernelGGL((k_finish<1>), dim3(c->nslices), dim3(256), 0, c->stream, c->X, c->ld, r_last, c->r, ev_list, c->fin_out); break;
+        case 2: hipLaunchKernelGGL((k_finish<2>), dim3(c->nslices), dim3(256), 0, c->stream, c->X, c->ld, r_last, c->r, ev_list, c->fin_out); break;
+        case 3: hipLaunchKernelGGL((k_finish<3>), dim3(c->nslices), dim3(256), 0, c->stream, c->X, c->ld, r_last, c->r, ev_list, c->fin_out); break;
+        default: hipLaunchKernelGGL((k_finish<4>), dim3(c->nslices), dim3(256), 0, c->stream, c->X, c->ld, r_last, c->r, ev_list, c->fin_out);
     }
     const double* gamma_dev = reinterpret_cast<const double*>(reinterpret_cast<const char*>(c->dparams) + offsetof(DevParams, gamma));
     switch (t) {

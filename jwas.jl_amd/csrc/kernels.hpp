@@ -141,10 +141,19 @@ __device__ __forceinline__ double butterfly8(const double (&v)[kU], int lane)
 // K_F: apply the last block's events (r_in -> r_out, may alias) and reduce r'r / sum(r) per
 // slice.  out[slice][NT*NT + NT]
 // ---------------------------------------------------------------------------------------------
+// A list of effect changes in global memory: count, column indices, per-trait coefficients (trait stride dstride).
+struct EventList {
+    const int32_t* count; const int32_t* idx; const float* delta; int64_t dstride;
+};
+__host__ __device__ inline EventList event_list(const Events* ev)
+{
+    return EventList{&ev->count, ev->idx, &ev->delta[0][0], (int64_t)kMaxBlock};
+}
+
 template <int NT>
 __global__ __launch_bounds__(256) void k_finish(const float* __restrict__ X, int64_t ld, const float* r_in,
                                                 float* r_out,
-                                                const Events* __restrict__ ev, double* __restrict__ out)
+                                                EventList ev, double* __restrict__ out)
 {
     __shared__ double red[4 * (NT * NT + NT)];
     const int tid = threadIdx.x;
@@ -152,13 +161,18 @@ __global__ __launch_bounds__(256) void k_finish(const float* __restrict__ X, int
     float rv[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) rv[t] = r_in[t * ld + row];
-    const int ne = ev->count;
+    const int ne = *ev.count;
     const float* xrow = X + row;
-#pragma unroll 4
-    for (int e = 0; e < ne; ++e) {
-        const float x = xrow[(int64_t)ev->idx[e] * ld];
+    // sequential fmaf in list order (= marker order); 16 independent column loads in flight per thread
+    for (int e0 = 0; e0 < ne; e0 += 16) {
+        float x[16];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) rv[t] = fmaf(ev->delta[t][e], x, rv[t]);
+        for (int u = 0; u < 16; ++u) x[u] = xrow[(int64_t)ev.idx[e0 + u < ne ? e0 + u : ne - 1] * ld];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (e0 + u < ne)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) rv[t] = fmaf(ev.delta[t * ev.dstride + e0 + u], x[u], rv[t]);
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t) r_out[t * ld + row] = rv[t];

@@ -117,7 +117,7 @@ __device__ __forceinline__ void update_role(char* smem, int rg, int g,
             rv[t].z = fmaf(d, x.z, rv[t].z); rv[t].w = fmaf(d, x.w, rv[t].w);
         }
     }
-    if (active && g == 0)
+    if (active && g == 0 && r_out != nullptr)
 #pragma unroll
         for (int t = 0; t < NT; ++t) *reinterpret_cast<float4*>(r_out + t * ld + row) = rv[t];
     if (ncols == 0) return;
@@ -1091,6 +1091,83 @@ __global__ __launch_bounds__(256) void k_cross_f64(const float* __restrict__ X, 
         }
         s = wave_sum(s);
         if (lane == 0) C[(int64_t)a * b + c] = (float)s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// INDEPENDENT-BLOCK mode (BayesABC_block_independent!, BayesABC.jl:190-255; BayesR.jl:195-273;
+// MTBayesABC.jl:335-440): every block's RHS comes from the SAME residual snapshot, the blocks are
+// sampled independently (here: all at once, one workgroup each), and the residual is reconciled
+// afterwards with r += sum_b X_b * (alpha_old_b - alpha_new_b) in (block, marker) order.
+// ---------------------------------------------------------------------------------------------
+// Block RHS of ALL blocks from the snapshot.  grid = (nrg*ncg, nblocks), block = 512.
+template <int NT>
+__global__ __launch_bounds__(kStepThreads) void k_indep_rhs(UpdateArgs U, int64_t p, int bsz, int64_t pstride)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int64_t blk = blockIdx.y;
+    const int64_t j0 = blk * bsz;
+    const int b = (int)((j0 + bsz <= p) ? bsz : p - j0);
+    const int ncg = U.ncg < b ? U.ncg : b;
+    const int w = blockIdx.x;
+    if (w >= U.nrg * ncg) return;
+    update_role<NT>(smem, w % U.nrg, w / U.nrg, U.X, U.ld, U.r_in, nullptr, U.ev, j0, b,
+                    U.nslices, U.nrg, ncg, U.partials + blk * pstride, U.bstride);
+}
+
+// All blocks sampled concurrently.  grid = nblocks, block = 512, dynamic LDS as k_block_step.
+template <int METHOD, int NT>
+__global__ __launch_bounds__(kStepThreads) void k_indep_sample(SamplerArgs S, int64_t pstride, Events* ev_all)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int64_t blk = blockIdx.x;
+    S.j0 = blk * S.bsz;
+    S.b = (int)((S.j0 + S.bsz <= S.p) ? S.bsz : S.p - S.j0);
+    S.partials += blk * pstride;
+    S.gram += blk * (int64_t)S.bsz * S.bsz;
+    S.ev_out = ev_all + blk;
+    S.b_next = 0;                                   // no lookahead correction in this mode
+    if constexpr (is_mt_method(METHOD)) sampler_role_mt<METHOD, NT>(smem, S);
+    else sampler_role_st<METHOD>(smem, S);
+}
+
+// Exclusive scan of the per-block change counts.  grid = 1, block = 1024.
+__global__ __launch_bounds__(1024) void k_indep_scan(const Events* __restrict__ ev_all, int nblocks,
+                                                     int32_t* __restrict__ offs, int32_t* __restrict__ total)
+{
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nblocks; base += 1024) {
+        const int i = base + tid;
+        const int v = i < nblocks ? ev_all[i].count : 0;
+        int x = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int y = __shfl_up(x, off, 64); if (lane >= off) x += y; }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        int wpre = 0, tot = 0;
+        for (int q = 0; q < 16; ++q) { if (q < wave) wpre += wsum[q]; tot += wsum[q]; }
+        if (i < nblocks) offs[i] = carry + wpre + x - v;
+        __syncthreads();
+        if (tid == 0) carry += tot;
+        __syncthreads();
+    }
+    if (tid == 0) *total = carry;
+}
+
+// Compact the per-block change lists into one list in (block, marker) order.  grid = nblocks, block = 256.
+__global__ __launch_bounds__(256) void k_indep_gather(const Events* __restrict__ ev_all, const int32_t* __restrict__ offs,
+                                                      int nt, int32_t* __restrict__ idx_all, float* __restrict__ delta_all,
+                                                      int64_t dstride)
+{
+    const Events* ev = ev_all + blockIdx.x;
+    const int ne = ev->count, off = offs[blockIdx.x];
+    for (int e = threadIdx.x; e < ne; e += 256) {
+        idx_all[off + e] = ev->idx[e];
+        for (int t = 0; t < nt; ++t) delta_all[t * dstride + off + e] = ev->delta[t][e];
     }
 }
 

@@ -213,7 +213,7 @@ class HipEngine:
     # -- the sweep -------------------------------------------------------------------------------
     def sweep(self, *, iteration, seed, vare, var_effect, pi=0.0, pi_classes=None, gamma=BAYESR_GAMMA,
               log_prior_states=None, var_effect_vec=None, pi_vec=None, pi_matrix=None, nreps=1,
-              marker_offset=0):
+              marker_offset=0, independent_blocks=False):
         """One marker sweep.  Argument meaning follows BayesABC!/BayesR!/MTBayesABC!:
         vare: residual variance (scalar or t x t); var_effect: marker effect variance (BayesC scalar,
         BayesR sigmaSq, MT t x t); pi: Pr(effect = 0) scalar, or pi_vec per marker (length p, else the
@@ -222,6 +222,7 @@ class HipEngine:
         P = SweepParams()
         P.method, P.ntraits, P.nreps = self.method, t, int(nreps)
         P.iteration, P.seed, P.marker_offset = int(iteration), int(seed), int(marker_offset)
+        P.independent_blocks = 1 if independent_blocks else 0          # BayesABC_block_independent! (BayesABC.jl:190-255)
         ve = np.asarray(vare, dtype=np.float32).reshape(-1)
         vg = np.asarray(var_effect, dtype=np.float32).reshape(-1)
         if ve.size != t * t or vg.size != t * t:

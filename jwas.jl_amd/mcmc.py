@@ -106,7 +106,7 @@ def _gibbs(A, x, b, rng, vare=None):
 
 
 def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed, starting_value,
-              fast_blocks, outputEBV, output_folder, printout_frequency, memory_guard, memory_guard_ratio,
+              fast_blocks, independent_blocks=False, outputEBV, output_folder, printout_frequency, memory_guard, memory_guard_ratio,
               missing_phenotypes, device, block_size, gram_mode, engine, printout_model_info,
               output_samples_for_all_parameters):
     import pandas as pd
@@ -339,6 +339,8 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
 
         # 2. marker effects (DEVICE)
         kw = dict(iteration=it, seed=seed_int, vare=vare, nreps=nreps)
+        if independent_blocks:
+            kw["independent_blocks"] = True
         if mega:
             kw.update(var_effect=Gval, pi=pi_t)
         elif t > 1:

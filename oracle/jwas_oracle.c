@@ -175,14 +175,15 @@ static int blocks_ok(const int64_t* bs, int64_t nblocks, int64_t p)
     return 1;
 }
 
-int orc_bayesabc_block_sweep(const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
+static int bayesabc_block_sweep_impl(const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
                              const int64_t* block_starts, int64_t nblocks, const float* grams,
                              float* r, float* alpha, float* beta, float* delta,
                              float vare, const float* var_effects, const double* pi,
-                             int nreps_arg, uint64_t seed, uint32_t iter, uint32_t marker0, int acc)
+                             int nreps_arg, uint64_t seed, uint32_t iter, uint32_t marker0, int acc, int independent)
 {
     if (!abc_args_ok(n, p, ld, vare) || !blocks_ok(block_starts, nblocks, p)) return -1;
     const float ie = 1.0f / vare;
+    float* dall = independent ? (float*)calloc((size_t)(p > 0 ? p : 1), sizeof(float)) : NULL;
     const float* G = grams;
     for (int64_t bi = 0; bi < nblocks; ++bi) {                          /* BayesABC.jl:145 */
         const int64_t j0 = block_starts[bi];
@@ -204,10 +205,15 @@ int orc_bayesabc_block_sweep(const float* X, int64_t n, int64_t p, int64_t ld, c
             }
         for (int64_t k = 0; k < b; ++k) {                               /* :181-185 */
             const float d = a_old_blk[k] - alpha[j0 + k];
-            if (d != 0.0f) axpy_f32(d, X + (j0 + k) * ld, r, n);
+            if (independent) dall[j0 + k] = d;                          /* block_deltas[i]  :247-248 */
+            else if (d != 0.0f) axpy_f32(d, X + (j0 + k) * ld, r, n);
         }
         free(a_old_blk); free(rhs_b);
         G += b * b;
+    }
+    if (independent) {                                                  /* reconcile  :251-253 */
+        for (int64_t j = 0; j < p; ++j) if (dall[j] != 0.0f) axpy_f32(dall[j], X + j * ld, r, n);
+        free(dall);
     }
     return 0;
 }
@@ -289,17 +295,18 @@ int orc_bayesr_sweep(const float* X, int64_t n, int64_t p, int64_t ld, const flo
     return 0;
 }
 
-int orc_bayesr_block_sweep(const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
+static int bayesr_block_sweep_impl(const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
                            const int64_t* block_starts, int64_t nblocks, const float* grams,
                            float* r, float* alpha, int32_t* delta,
                            float vare, float sigma_sq, const double* pi, int pi_is_matrix,
                            const double* gamma, int nreps_arg,
-                           uint64_t seed, uint32_t iter, uint32_t marker0, int acc)
+                           uint64_t seed, uint32_t iter, uint32_t marker0, int acc, int independent)
 {
     if (!abc_args_ok(n, p, ld, vare) || !bayesr_priors_ok(pi, pi_is_matrix, p) ||
         !blocks_ok(block_starts, nblocks, p)) return -1;
     if (!(sigma_sq > 0.0f)) return -2;
     const float ie = 1.0f / vare;
+    float* dall = independent ? (float*)calloc((size_t)(p > 0 ? p : 1), sizeof(float)) : NULL;
     const float* G = grams;
     for (int64_t bi = 0; bi < nblocks; ++bi) {                          /* BayesR.jl:139-192 */
         const int64_t j0 = block_starts[bi];
@@ -321,10 +328,15 @@ int orc_bayesr_block_sweep(const float* X, int64_t n, int64_t p, int64_t ld, con
             }
         for (int64_t k = 0; k < b; ++k) {                               /* :186-190 */
             const float d = a_old_blk[k] - alpha[j0 + k];
-            if (d != 0.0f) axpy_f32(d, X + (j0 + k) * ld, r, n);
+            if (independent) dall[j0 + k] = d;                          /* BayesR.jl:264-265 */
+            else if (d != 0.0f) axpy_f32(d, X + (j0 + k) * ld, r, n);
         }
         free(a_old_blk); free(rhs_b);
         G += b * b;
+    }
+    if (independent) {                                                  /* BayesR.jl:269-271 */
+        for (int64_t j = 0; j < p; ++j) if (dall[j] != 0.0f) axpy_f32(dall[j], X + j * ld, r, n);
+        free(dall);
     }
     return 0;
 }
@@ -597,18 +609,19 @@ int orc_mt_sweep(int kind, const float* X, int64_t n, int64_t p, int64_t ld, con
     return 0;
 }
 
-int orc_mt_block_sweep(int kind, const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
+static int mt_block_sweep_impl(int kind, const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
                                const int64_t* block_starts, int64_t nblocks, const float* grams,
                                int t, float* r, int64_t ld_r, float* alpha, float* beta, float* delta,
                                const float* vare, const float* var_effect,
                                const double* log_prior, int prior_is_matrix, int nreps_arg,
-                               uint64_t seed, uint32_t iter, uint32_t marker0, int acc)
+                               uint64_t seed, uint32_t iter, uint32_t marker0, int acc, int independent)
 {
     if (t < 1 || t > ORC_MAXT || n <= 0 || ld < n || ld_r < n || !blocks_ok(block_starts, nblocks, p)) return -1;
     float Rinv[ORC_MAXT * ORC_MAXT], Ginv[ORC_MAXT * ORC_MAXT];
     if (kind < MT_SAMPLER_I || kind > MT_MEGA) return -1;
     if (inv_small(vare, t, Rinv) || inv_small(var_effect, t, Ginv)) return -2;
     const int nstates = 1 << t;
+    float* dall = independent ? (float*)calloc((size_t)((p > 0 ? p : 1) * t), sizeof(float)) : NULL;
     const float* G = grams;
     for (int64_t bi = 0; bi < nblocks; ++bi) {                          /* MTBayesABC.jl:243-333 */
         const int64_t j0 = block_starts[bi];
@@ -635,10 +648,17 @@ int orc_mt_block_sweep(int kind, const float* X, int64_t n, int64_t p, int64_t l
         for (int k = 0; k < t; ++k)
             for (int64_t c = 0; c < b; ++c) {                                        /* :329 */
                 const float d = a_old_blk[k * b + c] - alpha[k * p + j0 + c];
-                if (d != 0.0f) axpy_f32(d, X + (j0 + c) * ld, r + k * ld_r, n);
+                if (independent) dall[k * p + j0 + c] = d;                           /* :425-428 */
+                else if (d != 0.0f) axpy_f32(d, X + (j0 + c) * ld, r + k * ld_r, n);
             }
         free(a_old_blk); free(rhs_b);
         G += b * b;
+    }
+    if (independent) {                                                               /* :431-435 */
+        for (int64_t j = 0; j < p; ++j)
+            for (int k = 0; k < t; ++k)
+                if (dall[k * p + j] != 0.0f) axpy_f32(dall[k * p + j], X + j * ld, r + k * ld_r, n);
+        free(dall);
     }
     return 0;
 }
@@ -814,6 +834,66 @@ int orc_mt_lookahead_sweep(int kind, const float* X, int64_t n, int64_t p, int64
             if (dprev[k * bprev + e] != 0.0f) axpy_f32(dprev[k * bprev + e], X + (jprev + e) * ld, r + k * ld_r, n);
     free(dprev);
     return 0;
+}
+
+/* exported block forms: exact chain (independent = 0) and independent blocks (BayesABC.jl:190-255, BayesR.jl:195-273,
+ * MTBayesABC.jl:335-440: every block RHS from the same residual snapshot; r += sum_b X_b*(alpha_old_b - alpha_b) afterwards) */
+int orc_bayesabc_block_sweep(const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
+                             const int64_t* block_starts, int64_t nblocks, const float* grams,
+                             float* r, float* alpha, float* beta, float* delta,
+                             float vare, const float* var_effects, const double* pi,
+                             int nreps_arg, uint64_t seed, uint32_t iter, uint32_t marker0, int acc)
+{
+    return bayesabc_block_sweep_impl(X, n, p, ld, xpx, block_starts, nblocks, grams, r, alpha, beta, delta, vare, var_effects, pi, nreps_arg, seed, iter, marker0, acc, 0);
+}
+
+int orc_bayesabc_indep_sweep(const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
+                             const int64_t* block_starts, int64_t nblocks, const float* grams,
+                             float* r, float* alpha, float* beta, float* delta,
+                             float vare, const float* var_effects, const double* pi,
+                             int nreps_arg, uint64_t seed, uint32_t iter, uint32_t marker0, int acc)
+{
+    return bayesabc_block_sweep_impl(X, n, p, ld, xpx, block_starts, nblocks, grams, r, alpha, beta, delta, vare, var_effects, pi, nreps_arg, seed, iter, marker0, acc, 1);
+}
+
+int orc_bayesr_block_sweep(const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
+                           const int64_t* block_starts, int64_t nblocks, const float* grams,
+                           float* r, float* alpha, int32_t* delta,
+                           float vare, float sigma_sq, const double* pi, int pi_is_matrix,
+                           const double* gamma, int nreps_arg,
+                           uint64_t seed, uint32_t iter, uint32_t marker0, int acc)
+{
+    return bayesr_block_sweep_impl(X, n, p, ld, xpx, block_starts, nblocks, grams, r, alpha, delta, vare, sigma_sq, pi, pi_is_matrix, gamma, nreps_arg, seed, iter, marker0, acc, 0);
+}
+
+int orc_bayesr_indep_sweep(const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
+                           const int64_t* block_starts, int64_t nblocks, const float* grams,
+                           float* r, float* alpha, int32_t* delta,
+                           float vare, float sigma_sq, const double* pi, int pi_is_matrix,
+                           const double* gamma, int nreps_arg,
+                           uint64_t seed, uint32_t iter, uint32_t marker0, int acc)
+{
+    return bayesr_block_sweep_impl(X, n, p, ld, xpx, block_starts, nblocks, grams, r, alpha, delta, vare, sigma_sq, pi, pi_is_matrix, gamma, nreps_arg, seed, iter, marker0, acc, 1);
+}
+
+int orc_mt_block_sweep(int kind, const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
+                               const int64_t* block_starts, int64_t nblocks, const float* grams,
+                               int t, float* r, int64_t ld_r, float* alpha, float* beta, float* delta,
+                               const float* vare, const float* var_effect,
+                               const double* log_prior, int prior_is_matrix, int nreps_arg,
+                               uint64_t seed, uint32_t iter, uint32_t marker0, int acc)
+{
+    return mt_block_sweep_impl(kind, X, n, p, ld, xpx, block_starts, nblocks, grams, t, r, ld_r, alpha, beta, delta, vare, var_effect, log_prior, prior_is_matrix, nreps_arg, seed, iter, marker0, acc, 0);
+}
+
+int orc_mt_indep_sweep(int kind, const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
+                               const int64_t* block_starts, int64_t nblocks, const float* grams,
+                               int t, float* r, int64_t ld_r, float* alpha, float* beta, float* delta,
+                               const float* vare, const float* var_effect,
+                               const double* log_prior, int prior_is_matrix, int nreps_arg,
+                               uint64_t seed, uint32_t iter, uint32_t marker0, int acc)
+{
+    return mt_block_sweep_impl(kind, X, n, p, ld, xpx, block_starts, nblocks, grams, t, r, ld_r, alpha, beta, delta, vare, var_effect, log_prior, prior_is_matrix, nreps_arg, seed, iter, marker0, acc, 1);
 }
 
 /* sampler I entry points (kept for the existing callers) */

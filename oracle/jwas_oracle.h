@@ -162,6 +162,27 @@ int orc_mt_lookahead_sweep(int kind, const float* X, int64_t n, int64_t p, int64
                            const float* vare, const float* var_effect, const double* log_prior, int prior_is_matrix,
                            int nreps, uint64_t seed, uint32_t iter, uint32_t marker0, int acc);
 
+/* ---- independent blocks (independent_blocks=true; BayesABC.jl:190-255, BayesR.jl:195-273, MTBayesABC.jl:335-440):
+ * same arguments as the *_block_sweep functions; every block RHS is formed from the residual as it is at entry,
+ * blocks are sampled independently and r += sum_b X_b*(alpha_old_b - alpha_b) is applied at the end in
+ * (block, marker) order. */
+int orc_bayesabc_indep_sweep(const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
+                             const int64_t* block_starts, int64_t nblocks, const float* grams,
+                             float* r, float* alpha, float* beta, float* delta,
+                             float vare, const float* var_effects, const double* pi,
+                             int nreps, uint64_t seed, uint32_t iter, uint32_t marker0, int acc);
+int orc_bayesr_indep_sweep(const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
+                           const int64_t* block_starts, int64_t nblocks, const float* grams,
+                           float* r, float* alpha, int32_t* delta,
+                           float vare, float sigma_sq, const double* pi, int pi_is_matrix,
+                           const double* gamma, int nreps,
+                           uint64_t seed, uint32_t iter, uint32_t marker0, int acc);
+int orc_mt_indep_sweep(int kind, const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
+                       const int64_t* block_starts, int64_t nblocks, const float* grams,
+                       int t, float* r, int64_t ld_r, float* alpha, float* beta, float* delta,
+                       const float* vare, const float* var_effect, const double* log_prior, int prior_is_matrix,
+                       int nreps, uint64_t seed, uint32_t iter, uint32_t marker0, int acc);
+
 /* ---- running posterior means (output.jl:568-577) ------------------------------------------ */
 /* mean += (x-mean)/k ; mean2 += (x^2-mean2)/k ; freq += (ind-freq)/k, ind = delta (BayesC) or
  * delta>1 (BayesR, delta_is_class != 0). */

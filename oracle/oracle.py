@@ -128,7 +128,7 @@ def _vec_or_fill(v, p, dtype):
 
 
 def bayesabc_sweep(X, xpx_, r, alpha, beta, delta, vare, var_effects, pi, seed, it,
-                   marker0=0, acc=ACC_F64, block_starts=None, grams=None, nreps=1, lookahead=False):
+                   marker0=0, acc=ACC_F64, block_starts=None, grams=None, nreps=1, lookahead=False, independent=False):
     """In-place sweep.  block_starts=None -> non-block form (BayesABC.jl:60-80); lookahead=True ->
     the one-block lookahead schedule of the block form (what the HIP path runs)."""
     n, p, ld = _xinfo(X)
@@ -148,7 +148,7 @@ def bayesabc_sweep(X, xpx_, r, alpha, beta, delta, vare, var_effects, pi, seed, 
     else:
         bs = np.ascontiguousarray(block_starts, dtype=np.int64)
         g = _f32(grams)
-        fn = lib().orc_bayesabc_lookahead_sweep if lookahead else lib().orc_bayesabc_block_sweep
+        fn = lib().orc_bayesabc_indep_sweep if independent else (lib().orc_bayesabc_lookahead_sweep if lookahead else lib().orc_bayesabc_block_sweep)
         rc = fn(_p(X, _f32p), C.c_int64(n), C.c_int64(p), C.c_int64(ld), _p(xpx_, _f32p),
                                             _p(bs, _i64p), C.c_int64(len(bs)), _p(g, _f32p),
                                             _p(r, _f32p), _p(alpha, _f32p), _p(beta, _f32p), _p(delta, _f32p),
@@ -159,7 +159,7 @@ def bayesabc_sweep(X, xpx_, r, alpha, beta, delta, vare, var_effects, pi, seed, 
 
 
 def bayesr_sweep(X, xpx_, r, alpha, delta, vare, sigma_sq, pi, seed, it, gamma=GAMMA,
-                 marker0=0, acc=ACC_F64, block_starts=None, grams=None, nreps=1, lookahead=False):
+                 marker0=0, acc=ACC_F64, block_starts=None, grams=None, nreps=1, lookahead=False, independent=False):
     n, p, ld = _xinfo(X)
     pv = np.ascontiguousarray(pi, dtype=np.float64)
     is_mat = int(pv.ndim == 2)
@@ -181,7 +181,7 @@ def bayesr_sweep(X, xpx_, r, alpha, delta, vare, sigma_sq, pi, seed, it, gamma=G
     else:
         bs = np.ascontiguousarray(block_starts, dtype=np.int64)
         g = _f32(grams)
-        fn = lib().orc_bayesr_lookahead_sweep if lookahead else lib().orc_bayesr_block_sweep
+        fn = lib().orc_bayesr_indep_sweep if independent else (lib().orc_bayesr_lookahead_sweep if lookahead else lib().orc_bayesr_block_sweep)
         rc = fn(_p(X, _f32p), C.c_int64(n), C.c_int64(p), C.c_int64(ld), _p(xpx_, _f32p),
                                           _p(bs, _i64p), C.c_int64(len(bs)), _p(g, _f32p),
                                           _p(r, _f32p), _p(alpha, _f32p), _p(delta, _i32p),
@@ -216,7 +216,7 @@ MT_SAMPLER_I, MT_SAMPLER_II, MT_MEGA = 1, 2, 3
 
 
 def mt_sweep(kind, X, xpx_, r, alpha, beta, delta, vare, var_effect, log_prior, seed, it,
-             marker0=0, acc=ACC_F64, block_starts=None, grams=None, nreps=1, lookahead=False):
+             marker0=0, acc=ACC_F64, block_starts=None, grams=None, nreps=1, lookahead=False, independent=False):
     """Multi-trait sweep, kind = MT_SAMPLER_I / MT_SAMPLER_II / MT_MEGA.
     r: t x ld_r float32 C-contiguous; alpha/beta/delta: t x p float32 C-contiguous.
     log_prior: 2^t (global) or p x 2^t (marker-specific) float64; for MT_MEGA the t per-trait pi values."""
@@ -238,7 +238,7 @@ def mt_sweep(kind, X, xpx_, r, alpha, beta, delta, vare, var_effect, log_prior, 
     else:
         bs = np.ascontiguousarray(block_starts, dtype=np.int64)
         g = _f32(grams)
-        fn = lib().orc_mt_lookahead_sweep if lookahead else lib().orc_mt_block_sweep
+        fn = lib().orc_mt_indep_sweep if independent else (lib().orc_mt_lookahead_sweep if lookahead else lib().orc_mt_block_sweep)
         rc = fn(C.c_int(kind), _p(X, _f32p), C.c_int64(n), C.c_int64(p), C.c_int64(ld), _p(xpx_, _f32p),
                 _p(bs, _i64p), C.c_int64(len(bs)), _p(g, _f32p),
                 C.c_int(t), _p(r, _f32p), C.c_int64(ld_r),

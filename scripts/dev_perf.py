@@ -17,6 +17,8 @@ ap.add_argument("--method", default="BayesC")      # BayesC | BayesR | MT
 ap.add_argument("--traits", type=int, default=3)
 ap.add_argument("--gram", default="mfma")
 ap.add_argument("--kind", type=int, default=0)
+ap.add_argument("--independent", action="store_true")
+ap.add_argument("--nreps", type=int, default=1)
 a = ap.parse_args()
 
 e = J.HipEngine(0)
@@ -39,16 +41,17 @@ for bs in a.bs:
     varg = np.float32(0.5 / ((1 - pi) * s2pq))
     pi4 = np.array([0.95, 0.03, 0.015, 0.005]); sig = np.float32(0.5 / (s2pq * (0.03 * 0.01 + 0.015 * 0.1 + 0.005)))
     lp = np.full(1 << t, -np.inf); lp[(1 << t) - 1] = np.log(1 - pi); lp[0] = np.log(pi)
+    xkw = dict(independent_blocks=a.independent, nreps=a.nreps)
     for it in range(1, a.sweeps + 1):
         if a.method == "BayesR":
-            st = e.sweep(iteration=it, seed=1, vare=np.float32(0.5), var_effect=sig, pi_classes=pi4)
+            st = e.sweep(iteration=it, seed=1, vare=np.float32(0.5), var_effect=sig, pi_classes=pi4, **xkw)
             nin = st["class_counts"][1:].sum(); pi4 = (st["class_counts"] + 1) / (a.p + 4)
         elif a.method == "MT":
-            st = e.sweep(iteration=it, seed=1, vare=(np.eye(t) * 0.5).astype(np.float32), var_effect=(np.eye(t) * varg).astype(np.float32), log_prior_states=lp)
+            st = e.sweep(iteration=it, seed=1, vare=(np.eye(t) * 0.5).astype(np.float32), var_effect=(np.eye(t) * varg).astype(np.float32), log_prior_states=lp, **xkw)
             nin = st["sum_delta"][0]
             pr = (st["state_counts"] + 1) / (a.p + (1 << t)); lp = np.log(pr)
         else:
-            st = e.sweep(iteration=it, seed=1, vare=np.float32(0.5), var_effect=varg, pi=pi)
+            st = e.sweep(iteration=it, seed=1, vare=np.float32(0.5), var_effect=varg, pi=pi, **xkw)
             nin = st["sum_delta"][0]; pi = float(1 - (nin + 1) / (a.p + 2))
         if it <= 2 or it % 4 == 0:
             print(f"  it{it}: sweep_ms={st['sweep_ms']:.2f} events={st['n_events']:.0f} in_model={nin:.0f} -> {gb / (st['sweep_ms'] * 1e-3):.0f} GB/s algorithmic", flush=True)

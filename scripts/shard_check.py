@@ -1,0 +1,72 @@
+"""Statistical check of the marker-shard (independent_blocks with one block per GPU) approximation: emulates G
+shards on ONE GPU (G contexts) and compares the chain's hyper-parameter trajectory with the exact chain (G = 1)."""
+import argparse
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import jwas_jl_amd as J
+from jwas_jl_amd.dist import shard_range
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--n", type=int, default=50000)
+ap.add_argument("--p", type=int, default=600000)
+ap.add_argument("--shards", type=int, nargs="+", default=[1, 8])
+ap.add_argument("--iters", type=int, default=120)
+ap.add_argument("--bs", type=int, default=512)
+ap.add_argument("--seed", type=int, default=2026)
+a = ap.parse_args()
+n, p = a.n, a.p
+for G in a.shards:
+    rng = np.random.default_rng(a.seed)
+    engs, rngs = [], []
+    ncausal = max(1, p // 1000)
+    causal = np.sort(rng.choice(p, size=ncausal, replace=False))
+    eff = rng.standard_normal(ncausal)
+    g = np.zeros(n)
+    s2pq = 0.0
+    for k in range(G):
+        lo, hi = shard_range(p, k, G, align=a.bs)
+        e = J.HipEngine(0)
+        e.alloc_dense(n, hi - lo); e.synth(a.seed, kind=0, center=True, marker_offset=lo); e.setup_blocks(a.bs, "mfma")
+        e.init_state("BayesC", 1)
+        at = np.zeros(hi - lo, dtype=np.float32)
+        m = (causal >= lo) & (causal < hi)
+        at[causal[m] - lo] = eff[m]
+        e.set_state(alpha=at)
+        g += e.mul_alpha().astype(np.float64)
+        s2pq += float(e.xpx().astype(np.float64).sum()) / n
+        e.set_state(alpha=np.zeros(hi - lo), beta=np.zeros(hi - lo), delta=np.ones(hi - lo))
+        engs.append((e, lo, hi))
+    g *= np.sqrt(0.5 / g.var())
+    y = (1.0 + g + rng.standard_normal(n) * np.sqrt(0.5)).astype(np.float32)
+    df_ = 4.0
+    vary = float(np.var(y.astype(np.float64), ddof=1))
+    vare = np.float32(0.5 * vary); pi = 0.95
+    Gval = np.float32(0.5 * vary / ((1.0 - pi) * s2pq))
+    scale_e = float(vare) * (df_ - 2) / df_; scale_g = float(Gval) * (df_ - 2) / df_
+    r = y.astype(np.float64).copy(); mu = 0.0
+    hist = []
+    for it in range(1, a.iters + 1):
+        r += mu
+        mu = rng.standard_normal() * np.sqrt(float(vare) / n) + r.sum() / n
+        r -= mu
+        snap = r.astype(np.float32)
+        dr = np.zeros(n, dtype=np.float32); nl = 0.0; ass = 0.0
+        for e, lo, hi in engs:
+            e.set_residual(snap)
+            st = e.sweep(iteration=it, seed=a.seed, vare=vare, var_effect=Gval, pi=pi, nreps=1, marker_offset=lo)
+            dr += e.get_residual() - snap
+            nl += st["sum_delta"][0]; ass += st["alpha_ss"][0, 0]
+        r = (snap + dr).astype(np.float64)
+        pi = float(rng.beta(p - nl + 1.0, nl + 1.0))
+        Gval = np.float32((np.float32(ass) + df_ * scale_g) / rng.chisquare(nl + df_))
+        vare = np.float32((np.float32(r @ r) + df_ * scale_e) / rng.chisquare(n + df_))
+        hist.append((nl, float(vare), pi, float(Gval)))
+        if it <= 3 or it % 20 == 0:
+            ghat = y.astype(np.float64) - mu - r
+            print(f"G={G} it{it}: in_model={nl:.0f} vare={vare:.4f} pi={pi:.5f} varg={Gval:.3e} cor(ghat,g)={np.corrcoef(ghat, g)[0, 1]:.4f}", flush=True)
+    h = np.array(hist[a.iters // 2:])
+    print(f"G={G} second-half means: in_model={h[:, 0].mean():.1f} vare={h[:, 1].mean():.4f} pi={h[:, 2].mean():.5f} varg={h[:, 3].mean():.3e}", flush=True)
+    for e, _, _ in engs:
+        e.close()

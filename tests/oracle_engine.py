@@ -94,10 +94,13 @@ class OracleEngine:
 
     def sweep(self, *, iteration, seed, vare, var_effect, pi=0.0, pi_classes=None, gamma=O.GAMMA,
               log_prior_states=None, var_effect_vec=None, pi_vec=None, pi_matrix=None, nreps=1,
-              marker_offset=0):
+              marker_offset=0, independent_blocks=False):
         t = self.ntraits
-        blk = (dict(block_starts=self._bs, grams=self._grams, nreps=nreps, lookahead=(self.form == "lookahead"))
+        blk = (dict(block_starts=self._bs, grams=self._grams, nreps=nreps, lookahead=(self.form == "lookahead"),
+                    independent=bool(independent_blocks))
                if self.form in ("block", "lookahead") else {})
+        if independent_blocks and not blk:
+            raise ValueError("independent blocks need a block form")
         a_before = self.alpha.copy()
         if self.method in (BAYESC, BAYESB):
             if np.ndim(pi) == 1:

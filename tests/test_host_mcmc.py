@@ -239,3 +239,17 @@ def test_fast_blocks_rescales_chain_length(tmp_path):
     out = api.runMCMC(model, ph, chain_length=640, burnin=2, fast_blocks=64, seed=1, outputEBV=False,
                       output_folder=str(tmp_path / "fb"), engine=OracleEngine("block"))
     assert out["_timing"]["iterations"] == 10 and out["_timing"]["block_size"] == 64
+
+
+def test_independent_blocks_through_runmcmc(tmp_path):
+    """runMCMC(fast_blocks=..., independent_blocks=true) (JWAS.jl:242-244, MCMC_BayesianAlphabet.jl:251)."""
+    d = make_dataset(n=200, p=260, ncausal=3, seed=9, center=False)
+    ids = [str(i) for i in range(200)]
+    gdf = pd.DataFrame(d["raw"]); gdf.insert(0, "ID", ids)
+    ph = pd.DataFrame({"ID": ids, "y1": d["y"]})
+    geno = api.get_genotypes(gdf, method="BayesC", Pi=0.9)
+    model = api.build_model("y1 = intercept + geno")
+    out = api.runMCMC(model, ph, chain_length=64 * 12, burnin=2, fast_blocks=64, independent_blocks=True, seed=1,
+                      output_folder=str(tmp_path / "ib"), engine=OracleEngine("block"))
+    assert out["_timing"]["iterations"] == 12
+    assert np.corrcoef(out["EBV_y1"]["EBV"], ph["y1"])[0, 1] > 0.4

@@ -285,6 +285,70 @@ def test_mega_trait0_is_the_single_trait_chain(small_data):
     assert d[1].sum() > 0
 
 
+# ---- independent blocks (test_misc_coverage.jl:211-227; docs/src/manual/block_bayesc.md:95-134) ----------
+def test_independent_blocks_exact_when_blocks_are_orthogonal():
+    """X_b'X_c = 0 for b != c  =>  the independent-block sweep IS the sequential block sweep."""
+    rng = np.random.default_rng(5)
+    n, bsz, nblk = 192, 64, 3
+    X = np.zeros((n, bsz * nblk), dtype=np.float32)
+    for b in range(nblk):                                   # disjoint row supports -> orthogonal column blocks
+        X[b * 64:(b + 1) * 64, b * bsz:(b + 1) * bsz] = rng.standard_normal((64, bsz)).astype(np.float32)
+    X = np.asfortranarray(X)
+    y = rng.standard_normal(n).astype(np.float32)
+    xpx = O.xpx(X)
+    bstarts = O.block_starts_for(X.shape[1], bsz)
+    grams = O.grams_for(X, bstarts)
+    res = []
+    for indep in (False, True):
+        r = y.copy()
+        a, b, d = (np.zeros(X.shape[1], dtype=np.float32) for _ in range(3))
+        for it in range(1, 6):
+            O.bayesabc_sweep(X, xpx, r, a, b, d, 0.5, 0.05, 0.7, 9, it, block_starts=bstarts, grams=grams, nreps=2,
+                             independent=indep)
+        res.append((a, d, r))
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][0], res[1][0])
+    assert np.abs(res[0][2] - res[1][2]).max() < 1e-5
+
+
+@pytest.mark.parametrize("method", ["BayesC", "BayesR", "MT"])
+def test_independent_blocks_keep_the_residual_identity(small_data, method):
+    """r = y - X alpha after the deferred reconcile (BayesABC.jl:251-253), and the chain differs from the
+    sequential one when blocks are correlated (it is an approximation)."""
+    X = small_data["X"][:, :640]
+    n, p = X.shape
+    y = (small_data["y"] - small_data["y"].mean()).astype(np.float32)
+    xpx = O.xpx(X)
+    bstarts = O.block_starts_for(p, 128)
+    grams = O.grams_for(X, bstarts)
+    kw = dict(block_starts=bstarts, grams=grams, nreps=1)
+    out = []
+    for indep in (False, True):
+        if method == "MT":
+            r = np.ascontiguousarray(np.stack([y, 0.5 * y[::-1]]).astype(np.float32))
+            y0 = r.copy()
+            a, b, d = (np.zeros((2, p), dtype=np.float32) for _ in range(3))
+            for it in range(1, 7):
+                O.mt_sweep(O.MT_SAMPLER_I, X, xpx, r, a, b, d, np.array([[0.5, 0.1], [0.1, 0.6]]),
+                           np.array([[0.004, 0.001], [0.001, 0.004]]), np.log([0.7, 0.1, 0.1, 0.1]), 3, it,
+                           independent=indep, **kw)
+            assert np.abs(r - (y0 - (X.astype(np.float64) @ a.T.astype(np.float64)).T)).max() < 2e-4
+        else:
+            r = y.copy()
+            a = np.zeros(p, dtype=np.float32)
+            if method == "BayesC":
+                b, d = np.zeros(p, dtype=np.float32), np.zeros(p, dtype=np.float32)
+                for it in range(1, 7):
+                    O.bayesabc_sweep(X, xpx, r, a, b, d, 0.5, 0.004, 0.9, 3, it, independent=indep, **kw)
+            else:
+                d = np.ones(p, dtype=np.int32)
+                for it in range(1, 7):
+                    O.bayesr_sweep(X, xpx, r, a, d, 0.5, 0.05, np.array([0.9, 0.05, 0.03, 0.02]), 3, it,
+                                   independent=indep, **kw)
+            assert np.abs(r - (y - X.astype(np.float64) @ a.astype(np.float64))).max() < 2e-4
+        out.append(a.copy())
+    assert not np.array_equal(out[0], out[1])
+
+
 # ---- test/unit/test_streaming_codec.jl:21-51, test_streaming_prepare_lowmem.jl:22-49: 2-bit codec ------
 def _pack_2bit(raw, missing=9):
     """Marker-major packing of streaming_genotypes.jl:364-367,622-627 (test-side restatement)."""
