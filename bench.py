@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--p", type=int, default=P_TOTAL)
     ap.add_argument("--block-size", type=int, default=int(os.environ.get("JWAS_BLOCK_SIZE", "512")))
     ap.add_argument("--seed", type=int, default=2026)
+    ap.add_argument("--storage", choices=["dense", "packed2bit"], default="dense",
+                    help="dense = the metric's fp32 dense genotypes (default); packed2bit = the reference's 2-bit packed "
+                         "streaming payload kept packed in HBM (same genotypes, same chain; extra, not the headline config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-markers", type=int, default=4000)
     return ap.parse_args()
@@ -86,7 +89,7 @@ def main():
     p_loc = hi - lo
     eng = J.HipEngine(local_rank)
     t_setup = time.time()
-    log('engine created'); eng.alloc_dense(n, p_loc); log('alloc done')
+    log('engine created'); (eng.alloc_packed if a.storage == 'packed2bit' else eng.alloc_dense)(n, p_loc); log('alloc done')
     eng.synth(a.seed, kind=0, center=True, marker_offset=lo)        # 0/1/2 genotypes, centred, generated on device
     log('synth done'); eng.setup_blocks(bs, "mfma"); log('setup_blocks done')
     eng.init_state("BayesC", 1)
@@ -176,18 +179,20 @@ def main():
         nblk = -(-p_loc // bs)
         launches = (nblk + 1) * a.steps
         avg_launch_us = 1e3 * acc["sweep_ms"] / launches
-        bytes_per_launch = 4.0 * n * p_loc / (nblk + 1)            # algorithmic: 4 B x n per marker, X read once
+        elem_bytes = 0.25 if a.storage == 'packed2bit' else 4.0
+        bytes_per_launch = elem_bytes * n * p_loc / (nblk + 1)     # algorithmic: 4 B (2 bits if packed) x n per marker, X read once
         achieved = bytes_per_launch / 1e9 / (avg_launch_us * 1e-6)
         out = {
             "metric": "MCMC iters/sec (full marker sweep)", "value": a.steps / elapsed, "unit": "iterations/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"single-trait BayesC, {n} individuals x {p_total} SNPs, fp32 dense genotypes, pi0=0.95 estimated",
+            "config": {"workload": f"single-trait BayesC, {n} individuals x {p_total} SNPs, " + ("2-bit packed genotypes (decoded to fp32 on the fly)" if a.storage == "packed2bit" else "fp32 dense genotypes") + ", pi0=0.95 estimated",
+                       "storage": a.storage,
                        "n": n, "p": p_total, "block_size": bs, "parallelism": f"marker-shard x{world}" if world > 1 else "single GPU",
                        "device_sweep_ms": acc["sweep_ms"] / a.steps, "events_per_sweep": acc["events"] / a.steps,
                        "markers_in_model": float(last["sum_delta"][0]), "setup_s": setup_s},
             "roofline": {"bound": "hbm", "kernel": "k_block_step", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": TRAFFIC_BYTES_PER_LAUNCH if (bs == 512 and p_total == P_TOTAL and n == N_IND and world == 1) else None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": TRAFFIC_BYTES_PER_LAUNCH if (bs == 512 and p_total == P_TOTAL and n == N_IND and world == 1 and a.storage == "dense") else None,
                          "bytes_per_launch": bytes_per_launch, "avg_launch_us": avg_launch_us, "launches_timed": launches},
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -62,6 +62,12 @@ enum {
                                /* independent single-trait BayesC chains sharing one pass over X */
 };
 
+/* Genotype storage kinds (Genotypes.storage_mode in the reference, types.jl:149-150). */
+enum {
+    JWAS_HIP_STORAGE_DENSE_F32  = 0,   /* storage=:dense, Float32 matrix                                 */
+    JWAS_HIP_STORAGE_PACKED2BIT = 1    /* storage=:stream's 2-bit packed marker-major payload (.jgb2)   */
+};
+
 /* Gram precompute modes for jwas_hip_setup_blocks. */
 enum {
     JWAS_HIP_GRAM_F64  = 0,    /* fp64-accumulated (bit-reproducible vs the CPU oracle); slow    */
@@ -128,12 +134,28 @@ int  jwas_hip_device_info(jwas_hip_ctx* ctx, int* n_cu, int64_t* hbm_bytes_total
 int  jwas_hip_load_dense_f32(jwas_hip_ctx* ctx, const float* X_host, int64_t n, int64_t p, int64_t ld_host);
 /* Allocate an uninitialised n x p device matrix (filled later by jwas_hip_synth_genotypes). */
 int  jwas_hip_alloc_dense_f32(jwas_hip_ctx* ctx, int64_t n, int64_t p);
+/* ---- 2-bit packed storage: the reference's Packed2BitBackend kept packed in HBM (16x fewer bytes than fp32) ----
+ * Layout (streaming_genotypes.jl:364-367,622-627): marker-major, marker j at bytes [j*stride, (j+1)*stride),
+ * stride >= cld(n,4); individual i in byte i>>2 at bit shift (i&3)<<1; codes 0/1/2 = genotype, 3 = missing.
+ * Every kernel decodes on the fly exactly as decode_marker! (:978-1002): v = code==3 ? mean_j : Float32(code),
+ * x = centered ? v - mean_j : v, so all results equal those of the dense path on the decoded matrix.
+ * jwas_hip_load_jgb2 replaces load_streaming_backend (:884-971): `path` is the prefix, or <prefix>.meta / .jgb2;
+ * it reads the tab-separated manifest (nObs, nMarkers, stride_bytes, centered, data_path, mean_path) and the
+ * .mean.f32 sidecar.  x'x is recomputed on the device; a host that wants the .xpRinvx.f32 sidecar values instead
+ * passes them to jwas_hip_set_xpx after jwas_hip_setup_blocks. */
+int  jwas_hip_load_jgb2(jwas_hip_ctx* ctx, const char* path);
+int  jwas_hip_load_packed2bit(jwas_hip_ctx* ctx, const uint8_t* payload, int64_t n, int64_t p, int64_t stride_bytes,
+                              const float* marker_means, int32_t centered);
+int  jwas_hip_alloc_packed2bit(jwas_hip_ctx* ctx, int64_t n, int64_t p, int32_t centered);   /* + jwas_hip_synth_genotypes */
+int  jwas_hip_storage_info(jwas_hip_ctx* ctx, int32_t* kind, int64_t* n, int64_t* p, int64_t* bytes);
 /* Device row stride (elements) of the padded marker-major layout, and its base device pointer. */
 int  jwas_hip_dense_layout(jwas_hip_ctx* ctx, int64_t* n, int64_t* p, int64_t* ld_dev, void** X_dev);
 /* Copy columns [j0, j0+count) back to the host (column-major, ld = n). */
 int  jwas_hip_get_columns(jwas_hip_ctx* ctx, int64_t j0, int64_t count, float* out_host);
 /* Memory guard (tools4genotypes.jl:99-235 analogue for HBM): bytes the dense path needs. */
 int64_t jwas_hip_estimate_bytes(int64_t n, int64_t p, int32_t ntraits, int32_t block_size);
+/* Same for a given storage kind (estimate_marker_memory(...; storage_mode), tools4genotypes.jl:99-235). */
+int64_t jwas_hip_estimate_bytes_storage(int64_t n, int64_t p, int32_t ntraits, int32_t block_size, int32_t storage);
 
 /* Benchmark / test data generator (benchmarks/bayesr_parity_common.jl:34-41 shape): allele
  * frequency f_j ~ U(0.1,0.4), x_ij = Bernoulli(f_j)+Bernoulli(f_j), optionally centred by the
@@ -146,6 +168,8 @@ int  jwas_hip_synth_genotypes(jwas_hip_ctx* ctx, uint64_t seed, int32_t kind, in
 /* block_size in {64,128,256,512,1024}; markers are processed in consecutive blocks of this size. */
 int  jwas_hip_setup_blocks(jwas_hip_ctx* ctx, int32_t block_size, int32_t gram_mode);
 int  jwas_hip_get_xpx(jwas_hip_ctx* ctx, float* out_p);
+/* Overwrite x'x (e.g. with the .xpRinvx.f32 sidecar of a streaming backend, streaming_genotypes.jl:283-285). */
+int  jwas_hip_set_xpx(jwas_hip_ctx* ctx, const float* in_p);
 int  jwas_hip_get_gram(jwas_hip_ctx* ctx, int64_t block, float* out_bxb);        /* row-major b x b */
 int  jwas_hip_set_gram(jwas_hip_ctx* ctx, int64_t block, const float* in_bxb);
 int  jwas_hip_num_blocks(jwas_hip_ctx* ctx, int64_t* nblocks, int32_t* block_size);

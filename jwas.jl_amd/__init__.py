@@ -15,4 +15,7 @@ def __getattr__(name):
     if name in ("get_genotypes", "build_model", "runMCMC", "Genotypes", "Model", "set_covariate"):
         from . import api
         return getattr(api, name)
+    if name in ("prepare_streaming_genotypes", "load_streaming_backend"):
+        from . import streaming
+        return getattr(streaming, name)
     raise AttributeError(name)

@@ -27,7 +27,10 @@ SYMBOLS = [
     "jwas_hip_residual_to_dev", "jwas_hip_residual_from_dev",
     "jwas_hip_residual_sub_xalpha", "jwas_hip_mul_alpha", "jwas_hip_set_kernel_timing", "jwas_hip_sweep",
     "jwas_hip_accumulate", "jwas_hip_get_posterior",
+    "jwas_hip_load_jgb2", "jwas_hip_load_packed2bit", "jwas_hip_alloc_packed2bit", "jwas_hip_storage_info",
+    "jwas_hip_set_xpx", "jwas_hip_estimate_bytes_storage",
 ]
+STORAGE_DENSE_F32, STORAGE_PACKED2BIT = 0, 1
 
 
 class SweepParams(C.Structure):
@@ -116,6 +119,13 @@ def load():
     L.jwas_hip_sweep.argtypes = [vp, C.POINTER(SweepParams), C.POINTER(SweepStats)]
     L.jwas_hip_accumulate.argtypes = [vp, C.c_double]
     L.jwas_hip_get_posterior.argtypes = [vp, i32, vp, vp, vp]
+    L.jwas_hip_load_jgb2.argtypes = [vp, C.c_char_p]
+    L.jwas_hip_load_packed2bit.argtypes = [vp, vp, i64, i64, i64, vp, i32]
+    L.jwas_hip_alloc_packed2bit.argtypes = [vp, i64, i64, i32]
+    L.jwas_hip_storage_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
+    L.jwas_hip_set_xpx.argtypes = [vp, vp]
+    L.jwas_hip_estimate_bytes_storage.argtypes = [i64, i64, i32, i32, i32]
+    L.jwas_hip_estimate_bytes_storage.restype = i64
     for name in SYMBOLS:
         fn = getattr(L, name)
         if name not in ("jwas_hip_destroy", "jwas_hip_last_error", "jwas_hip_estimate_bytes"):

@@ -53,7 +53,8 @@ class Genotypes:
         self.estimatePi = True
         self.pi = 0.0
         self.alpha = False                      # starting values
-        self.storage_mode = "dense"
+        self.storage_mode = "dense"            # "dense" | "stream" (types.jl:149-150)
+        self.stream_backend = None             # metadata of the 2-bit packed backend (streaming.load_streaming_backend)
         self.multi_trait_sampler = "I"
 
 
@@ -72,9 +73,36 @@ def get_genotypes(file, G=False, *, method="BayesC", Pi=0.0, estimatePi=True,
         raise ValueError("multi_trait_sampler must be one of :auto, :I, or :II.")            # :229-231
     if storage not in ("dense", "stream"):
         raise ValueError("storage must be :dense or :stream.")                                # :232-234
-    if storage == "stream":
-        raise NotImplementedError("storage=:stream (packed 2-bit .jgb2 backend) is not on the device path yet; "
-                                  "use storage=:dense")
+    if storage == "stream":                                                                   # :236-295
+        if not isinstance(file, str):
+            raise ValueError("storage=:stream requires a file path or prefix produced by prepare_streaming_genotypes.")
+        if double_precision:
+            raise ValueError("storage=:stream MVP supports Float32 only (double_precision=false).")
+        if annotations is not False:
+            raise NotImplementedError("marker annotations stay on the reference path")
+        if method not in SUPPORTED_METHODS:
+            raise NotImplementedError(f"method {method} is not on the device path (supported: {SUPPORTED_METHODS})")
+        from .streaming import load_streaming_backend
+        backend = load_streaming_backend(file)
+        if center != backend["centered"]:
+            print(f"The argument center={center} is ignored for storage=:stream. Backend metadata "
+                  f"centered={backend['centered']} is used.")
+        g = Genotypes(backend["obsID"], backend["markerID"], backend["nObs"], backend["nMarkers"],
+                      backend["allele_freq"].astype(np.float32), backend["sum2pq"], backend["centered"],
+                      np.zeros((backend["nObs"], 0), dtype=np.float32))
+        g.storage_mode, g.stream_backend = "stream", backend
+        g.G = Variance(G if G_is_marker_variance else False, df, False, estimate_variance, estimate_scale, constraint)
+        g.genetic_variance = Variance(False if G_is_marker_variance else G, df, False, estimate_variance, estimate_scale, constraint)
+        g.method, g.estimatePi, g.pi = method, estimatePi, Pi
+        g.multi_trait_sampler = multi_trait_sampler
+        print("Genotype informatin:")
+        print(f"#markers: {backend['nMarkers']}; #individuals: {backend['nObs']} (storage=:stream)")
+        if not _is_false(starting_value):
+            sv = np.asarray(starting_value, dtype=np.float32).reshape(-1)
+            if sv.size % backend["nMarkers"] != 0:
+                raise ValueError("length of starting values is wrong.")
+            g.alpha = sv
+        return g
     if double_precision:
         raise NotImplementedError("the MI355X path is Float32 (double_precision=false), like the reference's "
                                   "storage=:stream mode (readgenotypes.jl:246-248)")

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdarg>
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -26,7 +27,11 @@ struct jwas_hip_ctx {
     int64_t n = 0, p = 0, ld = 0;
     int nslices = 0;                    // 256-row slices
     int nrg = 0, ncg = 1;               // k_update_partial grid: row groups x column groups
-    float* X = nullptr;
+    float* X = nullptr;                 // dense fp32 storage ...
+    uint8_t* Q = nullptr;               // ... or the reference's 2-bit packed storage [p][ld/4] + per-marker means
+    float* qmean = nullptr;
+    bool packed = false;
+    int centered = 1;
 
     int block_size = 0;
     int64_t nblocks = 0;
@@ -116,6 +121,16 @@ static int inv_small(const float* A, int t, float* Ainv)
     return 0;
 }
 
+// Run f(cols) with the accessor of the context's storage (columns from j_off on).
+template <class F>
+static auto with_cols(jwas_hip_ctx* c, int64_t j_off, F&& f)
+{
+    if (c->packed) return f(PackedCols{c->Q + j_off * (c->ld >> 2), c->ld, c->qmean + j_off, c->n, c->centered});
+    return f(DenseCols{c->X + j_off * c->ld, c->ld});
+}
+#define HAVE_STORAGE(c) ((c)->X != nullptr || (c)->Q != nullptr)
+
+
 extern "C" {
 
 const char* jwas_hip_last_error(const jwas_hip_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
@@ -164,8 +179,8 @@ static void free_blocks(jwas_hip_ctx* c)
 
 static void free_storage(jwas_hip_ctx* c)
 {
-    (void)hipFree(c->X); (void)hipFree(c->r);
-    c->X = c->r = nullptr;
+    (void)hipFree(c->X); (void)hipFree(c->r); (void)hipFree(c->Q); (void)hipFree(c->qmean);
+    c->X = c->r = nullptr; c->Q = nullptr; c->qmean = nullptr; c->packed = false;
     (void)hipFree(c->ev); (void)hipFree(c->dparams); (void)hipFree(c->counters); (void)hipFree(c->fin_out); (void)hipFree(c->stat_out);
     c->ev = nullptr; c->dparams = nullptr; c->counters = nullptr; c->fin_out = c->stat_out = nullptr;
     if (c->host_buf) (void)hipHostFree(c->host_buf);
@@ -217,7 +232,7 @@ int64_t jwas_hip_estimate_bytes(int64_t n, int64_t p, int32_t ntraits, int32_t b
     // HBM analogue of estimate_marker_memory (tools4genotypes.jl:99-235): X + Grams + x'x + state.
     const int64_t ld = round_up(n, kSliceRows);
     int64_t bytes = 4 * ld * p;                                  // X
-    bytes += 4 * (int64_t)block_size * p;                        // Grams (p/b blocks of b*b)
+    bytes += 2 * 4 * (int64_t)block_size * p;                    // Grams + cross-Grams (p/b blocks of b*b each)
     bytes += 4 * p;                                              // x'x
     bytes += (int64_t)ntraits * p * 4 * 6;                       // alpha, beta, delta, 3 running means
     bytes += (int64_t)kMaxT * ld * 4;                            // residuals
@@ -225,7 +240,15 @@ int64_t jwas_hip_estimate_bytes(int64_t n, int64_t p, int32_t ntraits, int32_t b
     return bytes;
 }
 
-static int alloc_storage(jwas_hip_ctx* c, int64_t n, int64_t p)
+int64_t jwas_hip_estimate_bytes_storage(int64_t n, int64_t p, int32_t ntraits, int32_t block_size, int32_t storage)
+{
+    const int64_t ld = round_up(n, kSliceRows);
+    int64_t bytes = jwas_hip_estimate_bytes(n, p, ntraits, block_size);
+    if (storage == JWAS_HIP_STORAGE_PACKED2BIT) bytes += (ld >> 2) * p + 4 * p - 4 * ld * p;   // payload + means instead of fp32 X
+    return bytes;
+}
+
+static int alloc_storage(jwas_hip_ctx* c, int64_t n, int64_t p, bool packed = false)
 {
     NEED(c, n > 0 && p > 0, JWAS_HIP_EINVAL, "genotype matrix must be non-empty (n=%lld, p=%lld)", (long long)n, (long long)p);
     NEED(c, p < (1ll << 31), JWAS_HIP_EUNSUP, "p=%lld exceeds the 2^31 marker limit of one context", (long long)p);
@@ -240,9 +263,13 @@ static int alloc_storage(jwas_hip_ctx* c, int64_t n, int64_t p)
     c->ncg = 255 / c->nrg; if (c->ncg < 1) c->ncg = 1; if (c->ncg > 8) c->ncg = 8;
     size_t fb = 0, tb = 0;
     HIPCHK(c, hipMemGetInfo(&fb, &tb));
-    const size_t need = (size_t)4 * c->ld * p;
+    const size_t need = packed ? (size_t)(c->ld >> 2) * p : (size_t)4 * c->ld * p;
     NEED(c, need < fb, JWAS_HIP_ENOMEM, "genotype matrix needs %.2f GB but only %.2f GB of HBM is free", need / 1e9, fb / 1e9);
-    HIPCHK(c, hipMalloc(&c->X, need));
+    c->packed = packed;
+    if (packed) {
+        HIPCHK(c, hipMalloc(&c->Q, need));
+        HIPCHK(c, hipMalloc(&c->qmean, sizeof(float) * p));
+    } else HIPCHK(c, hipMalloc(&c->X, need));
     HIPCHK(c, hipMalloc(&c->r, sizeof(float) * 2 * kMaxT * c->ld));
     HIPCHK(c, hipMemsetAsync(c->r, 0, sizeof(float) * 2 * kMaxT * c->ld, c->stream));
     HIPCHK(c, hipMalloc(&c->ev, sizeof(Events) * 2));
@@ -275,10 +302,120 @@ int jwas_hip_alloc_dense_f32(jwas_hip_ctx* c, int64_t n, int64_t p)
     return alloc_storage(c, n, p);
 }
 
+int jwas_hip_alloc_packed2bit(jwas_hip_ctx* c, int64_t n, int64_t p, int32_t centered)
+{
+    NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
+    int rc = alloc_storage(c, n, p, true);
+    if (rc) return rc;
+    c->centered = centered ? 1 : 0;
+    return JWAS_HIP_OK;
+}
+
+int jwas_hip_load_packed2bit(jwas_hip_ctx* c, const uint8_t* payload, int64_t n, int64_t p, int64_t stride_bytes,
+                             const float* means, int32_t centered)
+{
+    NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
+    NEED(c, payload && means, JWAS_HIP_EINVAL, "payload / means is NULL");
+    NEED(c, stride_bytes >= (n + 3) / 4, JWAS_HIP_EINVAL, "stride_bytes (%lld) must be >= cld(n,4) = %lld", (long long)stride_bytes, (long long)((n + 3) / 4));
+    int rc = alloc_storage(c, n, p, true);
+    if (rc) return rc;
+    c->centered = centered ? 1 : 0;
+    const size_t sb = (size_t)(c->ld >> 2), src = (size_t)((n + 3) / 4);
+    HIPCHK(c, hipMemsetAsync(c->Q, 0, sb * p, c->stream));
+    HIPCHK(c, hipMemcpy2DAsync(c->Q, sb, payload, (size_t)stride_bytes, src, (size_t)p, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->qmean, means, sizeof(float) * p, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return JWAS_HIP_OK;
+}
+
+// load_streaming_backend (streaming_genotypes.jl:884-971): manifest = tab-separated key/value lines
+static bool read_manifest(const std::string& path, std::vector<std::pair<std::string, std::string>>* kv)
+{
+    FILE* f = std::fopen(path.c_str(), "r");
+    if (!f) return false;
+    char line[8192];
+    while (std::fgets(line, sizeof line, f)) {
+        std::string s(line);
+        while (!s.empty() && (s.back() == '\n' || s.back() == '\r')) s.pop_back();
+        const size_t tab = s.find('\t');
+        if (tab != std::string::npos) kv->emplace_back(s.substr(0, tab), s.substr(tab + 1));
+    }
+    std::fclose(f);
+    return true;
+}
+
+int jwas_hip_load_jgb2(jwas_hip_ctx* c, const char* path)
+{
+    NEED(c, c && path, JWAS_HIP_EINVAL, "NULL argument");
+    std::string prefix(path);                                   // _resolve_streaming_prefix (:97-105)
+    for (const char* ext : {".meta", ".jgb2"}) {
+        const size_t L = std::strlen(ext);
+        if (prefix.size() >= L && prefix.compare(prefix.size() - L, L, ext) == 0) { prefix.resize(prefix.size() - L); break; }
+    }
+    std::vector<std::pair<std::string, std::string>> kv;
+    NEED(c, read_manifest(prefix + ".meta", &kv), JWAS_HIP_EINVAL, "Streaming manifest is not found: %s.meta", prefix.c_str());
+    auto get = [&](const char* k) -> std::string { for (auto& e : kv) if (e.first == k) return e.second; return std::string(); };
+    const std::string sn = get("nObs"), sp = get("nMarkers"), ss = get("stride_bytes"), sc = get("centered");
+    NEED(c, !sn.empty() && !sp.empty() && !ss.empty() && !sc.empty(), JWAS_HIP_EINVAL, "Streaming manifest %s.meta lacks nObs / nMarkers / stride_bytes / centered", prefix.c_str());
+    const int64_t n = std::atoll(sn.c_str()), p = std::atoll(sp.c_str()), stride = std::atoll(ss.c_str());
+    const int centered = std::atoi(sc.c_str()) == 1;
+    NEED(c, n > 0 && p > 0 && stride >= (n + 3) / 4, JWAS_HIP_EINVAL, "Streaming manifest %s.meta is inconsistent", prefix.c_str());
+    // recorded paths may be stale if the files were moved: fall back to <prefix>.jgb2 / <prefix>.mean.f32
+    auto open_first = [&](const std::string& a, const std::string& b) -> FILE* {
+        FILE* f = a.empty() ? nullptr : std::fopen(a.c_str(), "rb");
+        return f ? f : std::fopen(b.c_str(), "rb");
+    };
+    FILE* fd = open_first(get("data_path"), prefix + ".jgb2");
+    NEED(c, fd, JWAS_HIP_EINVAL, "Packed genotype file is not found for %s", prefix.c_str());
+    std::fseek(fd, 0, SEEK_END);
+    const int64_t fsz = (int64_t)std::ftell(fd);
+    std::fseek(fd, 0, SEEK_SET);
+    if (fsz != p * stride) { std::fclose(fd); return fail(c, JWAS_HIP_EINVAL, "Packed genotype file size does not match metadata for %s", prefix.c_str()); }
+    FILE* fm = open_first(get("mean_path"), prefix + ".mean.f32");
+    if (!fm) { std::fclose(fd); return fail(c, JWAS_HIP_EINVAL, "marker mean sidecar is not found for %s", prefix.c_str()); }
+    std::vector<float> means((size_t)p);
+    const size_t got = std::fread(means.data(), sizeof(float), (size_t)p, fm);
+    std::fclose(fm);
+    if ((int64_t)got != p) { std::fclose(fd); return fail(c, JWAS_HIP_EINVAL, "marker mean sidecar of %s is truncated", prefix.c_str()); }
+    int rc = alloc_storage(c, n, p, true);
+    if (rc) { std::fclose(fd); return rc; }
+    c->centered = centered;
+    const size_t sb = (size_t)(c->ld >> 2);
+    hipError_t e = hipMemsetAsync(c->Q, 0, sb * p, c->stream);
+    // stream the file through a pinned staging buffer, <= 64 MB of markers at a time
+    const int64_t chunk = std::max<int64_t>(1, (64ll << 20) / stride);
+    void* stage = nullptr;
+    if (e == hipSuccess) e = hipHostMalloc(&stage, (size_t)(chunk * stride));
+    for (int64_t j0 = 0; e == hipSuccess && j0 < p; j0 += chunk) {
+        const int64_t m = std::min(chunk, p - j0);
+        if ((int64_t)std::fread(stage, (size_t)stride, (size_t)m, fd) != m) { e = hipErrorUnknown; break; }
+        e = hipMemcpy2DAsync(c->Q + j0 * sb, sb, stage, (size_t)stride, (size_t)((n + 3) / 4), (size_t)m, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    }
+    std::fclose(fd);
+    if (stage) (void)hipHostFree(stage);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->qmean, means.data(), sizeof(float) * p, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) return fail(c, JWAS_HIP_EHIP, "jwas_hip_load_jgb2: reading / uploading %s.jgb2 failed (%s)", prefix.c_str(), hipGetErrorString(e));
+    return JWAS_HIP_OK;
+}
+
+int jwas_hip_storage_info(jwas_hip_ctx* c, int32_t* kind, int64_t* n, int64_t* p, int64_t* bytes)
+{
+    NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
+    NEED(c, HAVE_STORAGE(c), JWAS_HIP_ESTATE, "no genotype matrix loaded");
+    if (kind) *kind = c->packed ? JWAS_HIP_STORAGE_PACKED2BIT : JWAS_HIP_STORAGE_DENSE_F32;
+    if (n) *n = c->n;
+    if (p) *p = c->p;
+    if (bytes) *bytes = c->packed ? (c->ld >> 2) * c->p : 4 * c->ld * c->p;
+    return JWAS_HIP_OK;
+}
+
 int jwas_hip_dense_layout(jwas_hip_ctx* c, int64_t* n, int64_t* p, int64_t* ld, void** Xd)
 {
     NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
-    NEED(c, c->X, JWAS_HIP_ESTATE, "no genotype matrix loaded");
+    NEED(c, HAVE_STORAGE(c), JWAS_HIP_ESTATE, "no genotype matrix loaded");
+    NEED(c, !c->packed, JWAS_HIP_EUNSUP, "the context holds 2-bit packed genotypes (see jwas_hip_storage_info)");
     if (n) *n = c->n;
     if (p) *p = c->p;
     if (ld) *ld = c->ld;
@@ -289,24 +426,48 @@ int jwas_hip_dense_layout(jwas_hip_ctx* c, int64_t* n, int64_t* p, int64_t* ld, 
 int jwas_hip_get_columns(jwas_hip_ctx* c, int64_t j0, int64_t count, float* out)
 {
     NEED(c, c && out, JWAS_HIP_EINVAL, "NULL argument");
-    NEED(c, c->X, JWAS_HIP_ESTATE, "no genotype matrix loaded");
+    NEED(c, HAVE_STORAGE(c), JWAS_HIP_ESTATE, "no genotype matrix loaded");
     NEED(c, j0 >= 0 && count >= 0 && j0 + count <= c->p, JWAS_HIP_EINVAL, "column range [%lld,%lld) outside [0,%lld)",
          (long long)j0, (long long)(j0 + count), (long long)c->p);
     HIPCHK(c, hipSetDevice(c->device));
     if (count == 0) return JWAS_HIP_OK;
-    HIPCHK(c, hipMemcpy2DAsync(out, (size_t)4 * c->n, c->X + j0 * c->ld, (size_t)4 * c->ld, (size_t)4 * c->n, (size_t)count,
-                               hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!c->packed) {
+        HIPCHK(c, hipMemcpy2DAsync(out, (size_t)4 * c->n, c->X + j0 * c->ld, (size_t)4 * c->ld, (size_t)4 * c->n, (size_t)count,
+                                   hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return JWAS_HIP_OK;
+    }
+    // packed storage: decode on the device (decode_marker!, streaming_genotypes.jl:978-1002), <= 4096 columns at a time
+    const int64_t chunk = 4096;
+    float* tmp = nullptr;
+    HIPCHK(c, hipMalloc(&tmp, sizeof(float) * (size_t)c->n * (size_t)std::min(chunk, count)));
+    hipError_t e = hipSuccess;
+    for (int64_t k0 = 0; e == hipSuccess && k0 < count; k0 += chunk) {
+        const int64_t m = std::min(chunk, count - k0);
+        hipLaunchKernelGGL((k_get_columns<PackedCols>), dim3((unsigned)m), dim3(256), 0, c->stream,
+                           PackedCols{c->Q, c->ld, c->qmean, c->n, c->centered}, j0 + k0, c->n, tmp);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(out + k0 * c->n, tmp, sizeof(float) * (size_t)c->n * m, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    }
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return fail(c, JWAS_HIP_EHIP, "jwas_hip_get_columns: %s", hipGetErrorString(e));
     return JWAS_HIP_OK;
 }
 
 int jwas_hip_synth_genotypes(jwas_hip_ctx* c, uint64_t seed, int32_t kind, int32_t center, int64_t marker_offset)
 {
     NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
-    NEED(c, c->X, JWAS_HIP_ESTATE, "allocate the matrix first (jwas_hip_alloc_dense_f32)");
+    NEED(c, HAVE_STORAGE(c), JWAS_HIP_ESTATE, "allocate the matrix first (jwas_hip_alloc_dense_f32 / jwas_hip_alloc_packed2bit)");
     NEED(c, kind == 0 || kind == 1, JWAS_HIP_EINVAL, "kind must be 0 (0/1/2 genotypes) or 1 (uniform)");
     HIPCHK(c, hipSetDevice(c->device));
     NEED(c, marker_offset >= 0 && marker_offset + c->p < (1ll << 32), JWAS_HIP_EINVAL, "marker_offset out of range");
+    if (c->packed) {
+        NEED(c, kind == 0, JWAS_HIP_EUNSUP, "2-bit packed storage holds 0/1/2 genotypes only (kind 0)");
+        c->centered = center ? 1 : 0;
+        hipLaunchKernelGGL(k_synth_packed, dim3((unsigned)c->p), dim3(256), 0, c->stream, c->Q, c->qmean, c->n, c->ld,
+                           (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)marker_offset);
+    } else
     hipLaunchKernelGGL(k_synth, dim3((unsigned)c->p), dim3(256), 0, c->stream, c->X, c->n, c->ld,
                        (uint32_t)seed, (uint32_t)(seed >> 32), (int)kind, (int)center, (uint32_t)marker_offset);
     HIPCHK(c, hipGetLastError());
@@ -318,7 +479,7 @@ int jwas_hip_synth_genotypes(jwas_hip_ctx* c, uint64_t seed, int32_t kind, int32
 int jwas_hip_setup_blocks(jwas_hip_ctx* c, int32_t bs, int32_t gram_mode)
 {
     NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
-    NEED(c, c->X, JWAS_HIP_ESTATE, "no genotype matrix loaded");
+    NEED(c, HAVE_STORAGE(c), JWAS_HIP_ESTATE, "no genotype matrix loaded");
     NEED(c, bs == 64 || bs == 128 || bs == 256 || bs == 512 || bs == 1024, JWAS_HIP_EINVAL, "block_size must be 64, 128, 256, 512 or 1024 (got %d)", bs);
     NEED(c, gram_mode == JWAS_HIP_GRAM_F64 || gram_mode == JWAS_HIP_GRAM_MFMA, JWAS_HIP_EINVAL, "unknown gram_mode %d", gram_mode);
     HIPCHK(c, hipSetDevice(c->device));
@@ -331,25 +492,31 @@ int jwas_hip_setup_blocks(jwas_hip_ctx* c, int32_t bs, int32_t gram_mode)
     HIPCHK(c, hipMalloc(&c->cross, sizeof(float) * (size_t)c->nblocks * bs * bs));
     HIPCHK(c, hipMalloc(&c->corr, sizeof(float) * 2 * kMaxT * (size_t)bs));
     HIPCHK(c, hipMalloc(&c->partials, sizeof(double) * 2 * (size_t)bs * c->nrg * kMaxT));   // ping-pong
-    hipLaunchKernelGGL(k_xpx, dim3((unsigned)c->p), dim3(256), 0, c->stream, c->X, c->ld, c->xpx);
+    with_cols(c, 0, [&](auto cx) {
+        hipLaunchKernelGGL((k_xpx<decltype(cx)>), dim3((unsigned)c->p), dim3(256), 0, c->stream, cx, c->xpx);
+        return 0;
+    });
     HIPCHK(c, hipGetLastError());
     // Gram launches are chunked over blocks so grid.y stays below 65536
     const int64_t ychunk = 32768;
     for (int64_t y0 = 0; y0 < c->nblocks; y0 += ychunk) {
         const int64_t ny = (c->nblocks - y0 < ychunk) ? c->nblocks - y0 : ychunk;
-        const float* Xc = c->X + y0 * bs * c->ld;
         float* Gc = c->gram + y0 * (int64_t)bs * bs;
         const int64_t pc = c->p - y0 * bs;
         float* Cc = c->cross + y0 * (int64_t)bs * bs;
         const int64_t nyc = (y0 + ny < c->nblocks) ? ny : ny - 1;      // cross blocks y0+1 .. (last block has none after it)
-        if (gram_mode == JWAS_HIP_GRAM_F64) {
-            hipLaunchKernelGGL(k_gram_f64, dim3(bs, (unsigned)ny), dim3(256), 0, c->stream, Xc, c->ld, pc, (int)bs, Gc);
-            if (nyc > 0) hipLaunchKernelGGL(k_cross_f64, dim3(bs, (unsigned)nyc), dim3(256), 0, c->stream, Xc, c->ld, pc, (int)bs, Cc);
-        } else {
-            const int nt = bs / 64;
-            hipLaunchKernelGGL(k_gram_mfma, dim3(nt * (nt + 1) / 2, (unsigned)ny), dim3(256), 0, c->stream, Xc, c->ld, pc, (int)bs, Gc, 0);
-            if (nyc > 0) hipLaunchKernelGGL(k_gram_mfma, dim3(nt * nt, (unsigned)nyc), dim3(256), 0, c->stream, Xc, c->ld, pc, (int)bs, Cc, 1);
-        }
+        with_cols(c, y0 * bs, [&](auto Xc) {
+            using CX = decltype(Xc);
+            if (gram_mode == JWAS_HIP_GRAM_F64) {
+                hipLaunchKernelGGL((k_gram_f64<CX>), dim3(bs, (unsigned)ny), dim3(256), 0, c->stream, Xc, pc, (int)bs, Gc);
+                if (nyc > 0) hipLaunchKernelGGL((k_cross_f64<CX>), dim3(bs, (unsigned)nyc), dim3(256), 0, c->stream, Xc, pc, (int)bs, Cc);
+            } else {
+                const int nt = bs / 64;
+                hipLaunchKernelGGL((k_gram_mfma<CX>), dim3(nt * (nt + 1) / 2, (unsigned)ny), dim3(256), 0, c->stream, Xc, pc, (int)bs, Gc, 0);
+                if (nyc > 0) hipLaunchKernelGGL((k_gram_mfma<CX>), dim3(nt * nt, (unsigned)nyc), dim3(256), 0, c->stream, Xc, pc, (int)bs, Cc, 1);
+            }
+            return 0;
+        });
         HIPCHK(c, hipGetLastError());
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -371,6 +538,16 @@ int jwas_hip_get_xpx(jwas_hip_ctx* c, float* out)
     NEED(c, c->xpx, JWAS_HIP_ESTATE, "jwas_hip_setup_blocks has not been called");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(out, c->xpx, sizeof(float) * c->p, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return JWAS_HIP_OK;
+}
+
+int jwas_hip_set_xpx(jwas_hip_ctx* c, const float* in)
+{
+    NEED(c, c && in, JWAS_HIP_EINVAL, "NULL argument");
+    NEED(c, c->xpx, JWAS_HIP_ESTATE, "jwas_hip_setup_blocks has not been called");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(c->xpx, in, sizeof(float) * c->p, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return JWAS_HIP_OK;
 }
@@ -410,7 +587,7 @@ int jwas_hip_set_gram(jwas_hip_ctx* c, int64_t blk, const float* in)
 int jwas_hip_init_state(jwas_hip_ctx* c, int32_t method, int32_t nt)
 {
     NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
-    NEED(c, c->X, JWAS_HIP_ESTATE, "no genotype matrix loaded");
+    NEED(c, HAVE_STORAGE(c), JWAS_HIP_ESTATE, "no genotype matrix loaded");
     NEED(c, method >= JWAS_HIP_BAYESC && method <= JWAS_HIP_MEGABAYESC, JWAS_HIP_EINVAL, "unknown method %d", method);
     if (method >= JWAS_HIP_MTBAYESC1) NEED(c, nt >= 2 && nt <= kMaxT, JWAS_HIP_EUNSUP, "multi-trait samplers support 2..%d traits (got %d)", kMaxT, nt);
     else NEED(c, nt == 1, JWAS_HIP_EINVAL, "single-trait method requires ntraits == 1 (got %d)", nt);
@@ -520,8 +697,11 @@ int jwas_hip_residual_sub_xalpha(jwas_hip_ctx* c, int32_t trait)
     NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
     NEED_TRAIT(c, trait);
     HIPCHK(c, hipSetDevice(c->device));
-    hipLaunchKernelGGL(k_sub_xalpha, dim3(c->nslices), dim3(256), 0, c->stream, c->X, c->ld, c->p,
-                       c->alpha + (size_t)trait * c->p, c->r + (size_t)trait * c->ld);
+    with_cols(c, 0, [&](auto cx) {
+        hipLaunchKernelGGL((k_sub_xalpha<decltype(cx)>), dim3(c->nslices), dim3(256), 0, c->stream, cx, c->p,
+                           c->alpha + (size_t)trait * c->p, c->r + (size_t)trait * c->ld);
+        return 0;
+    });
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return JWAS_HIP_OK;
@@ -534,8 +714,11 @@ int jwas_hip_mul_alpha(jwas_hip_ctx* c, int32_t trait, float* out)
     HIPCHK(c, hipSetDevice(c->device));
     float* tmp = nullptr;
     HIPCHK(c, hipMalloc(&tmp, sizeof(float) * c->ld));
-    hipLaunchKernelGGL(k_mul_alpha, dim3(c->nslices), dim3(256), 0, c->stream, c->X, c->ld, c->p,
-                       c->alpha + (size_t)trait * c->p, tmp);
+    with_cols(c, 0, [&](auto cx) {
+        hipLaunchKernelGGL((k_mul_alpha<decltype(cx)>), dim3(c->nslices), dim3(256), 0, c->stream, cx, c->p,
+                           c->alpha + (size_t)trait * c->p, tmp);
+        return 0;
+    });
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(out, tmp, sizeof(float) * c->n, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -547,13 +730,16 @@ int jwas_hip_mul_alpha(jwas_hip_ctx* c, int32_t trait, float* out)
 }  // extern "C" (templates need C++ linkage)
 
 // ---- the sweep --------------------------------------------------------------------------------------
-template <int METHOD, int NT>
-static hipError_t launch_step(jwas_hip_ctx* c, const UpdateArgs& U, const SamplerArgs& S, int do_sample)
+template <int METHOD, int NT, class CX>
+static hipError_t launch_step_cx(jwas_hip_ctx* c, const CX& cx, const UpdateArgs& U0, const SamplerArgs& S, int do_sample)
 {
+    UpdateArgsT<CX> U;
+    static_cast<UpdateArgs&>(U) = U0;
+    U.cx = cx;
     const StepSmem SM(c->block_size, NT, is_mt_method(METHOD) ? 0 : (METHOD == kBayesR ? 12 : 4), is_mt_method(METHOD) ? 0 : (METHOD == kBayesR ? 1 : 4));
     static bool attr_set = false;
     if (!attr_set) {   // allow > 64 KB of dynamic LDS
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_block_step<METHOD, NT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_block_step<METHOD, NT, CX>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
@@ -562,9 +748,15 @@ static hipError_t launch_step(jwas_hip_ctx* c, const UpdateArgs& U, const Sample
     static const int dbg = std::getenv("JWAS_HIP_DEBUG_ROLE") ? std::atoi(std::getenv("JWAS_HIP_DEBUG_ROLE")) : 0;
     const int nwork = c->nrg * U.ncg;
     const unsigned grid = (dbg == 2) ? 1u : (U.quiet_xcd ? (unsigned)(1 + (nwork + 6) / 7 * 8) : (unsigned)(1 + nwork));
-    hipLaunchKernelGGL((k_block_step<METHOD, NT>), dim3(grid), dim3(kStepThreads), SM.bytes, c->stream,
+    hipLaunchKernelGGL((k_block_step<METHOD, NT, CX>), dim3(grid), dim3(kStepThreads), SM.bytes, c->stream,
                        U, S, (dbg == 1) ? 0 : do_sample);
     return hipSuccess;
+}
+
+template <int METHOD, int NT>
+static hipError_t launch_step(jwas_hip_ctx* c, const UpdateArgs& U, const SamplerArgs& S, int do_sample)
+{
+    return with_cols(c, 0, [&](auto cx) { return launch_step_cx<METHOD, NT, decltype(cx)>(c, cx, U, S, do_sample); });
 }
 
 static hipError_t launch_step_any(jwas_hip_ctx* c, const UpdateArgs& U, const SamplerArgs& S, int do_sample)
@@ -594,9 +786,12 @@ static int upload_vec(jwas_hip_ctx* c, void** dev, const void* host, size_t byte
 // Independent-block sweep (BayesABC_block_independent!, BayesABC.jl:190-255): all block RHS from the residual
 // snapshot (one pass over X), all blocks sampled concurrently, change lists compacted in (block, marker) order;
 // the caller's k_finish applies them to the residual.
-template <int METHOD, int NT>
-static hipError_t launch_indep(jwas_hip_ctx* c, const UpdateArgs& U, const SamplerArgs& S, int64_t pstride)
+template <int METHOD, int NT, class CX>
+static hipError_t launch_indep_cx(jwas_hip_ctx* c, const CX& cx, const UpdateArgs& U0, const SamplerArgs& S, int64_t pstride)
 {
+    UpdateArgsT<CX> U;
+    static_cast<UpdateArgs&>(U) = U0;
+    U.cx = cx;
     const StepSmem SM(c->block_size, NT, is_mt_method(METHOD) ? 0 : (METHOD == kBayesR ? 12 : 4), is_mt_method(METHOD) ? 0 : (METHOD == kBayesR ? 1 : 4));
     static bool attr_set = false;
     if (!attr_set) {
@@ -606,11 +801,17 @@ static hipError_t launch_indep(jwas_hip_ctx* c, const UpdateArgs& U, const Sampl
         attr_set = true;
     }
     const size_t red = sizeof(double) * kRowGroupSlices * kColChunk * NT;
-    hipLaunchKernelGGL((k_indep_rhs<NT>), dim3((unsigned)(U.nrg * U.ncg), (unsigned)c->nblocks), dim3(kStepThreads), red, c->stream,
+    hipLaunchKernelGGL((k_indep_rhs<NT, CX>), dim3((unsigned)(U.nrg * U.ncg), (unsigned)c->nblocks), dim3(kStepThreads), red, c->stream,
                        U, c->p, c->block_size, pstride);
     hipLaunchKernelGGL((k_indep_sample<METHOD, NT>), dim3((unsigned)c->nblocks), dim3(kStepThreads), SM.bytes, c->stream,
                        S, pstride, c->ev_all);
     return hipGetLastError();
+}
+
+template <int METHOD, int NT>
+static hipError_t launch_indep(jwas_hip_ctx* c, const UpdateArgs& U, const SamplerArgs& S, int64_t pstride)
+{
+    return with_cols(c, 0, [&](auto cx) { return launch_indep_cx<METHOD, NT, decltype(cx)>(c, cx, U, S, pstride); });
 }
 
 static int sweep_independent(jwas_hip_ctx* c, EventList* out)
@@ -632,7 +833,7 @@ static int sweep_independent(jwas_hip_ctx* c, EventList* out)
     HIPCHK(c, hipMemsetAsync(c->corr, 0, sizeof(float) * 2 * kMaxT * (size_t)bs, c->stream));   // corr_in = 0 for every block
     UpdateArgs U;
     std::memset(&U, 0, sizeof U);
-    U.X = c->X; U.ld = c->ld; U.r_in = c->r; U.r_out = nullptr;
+    U.r_in = c->r; U.r_out = nullptr;
     U.ev = &c->ev[0];                               // count zeroed by the caller: nothing to apply
     U.nslices = c->nslices; U.nrg = c->nrg; U.ncg = c->ncg;
     U.partials = c->ipartials; U.bstride = bs;
@@ -791,7 +992,6 @@ int jwas_hip_sweep(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_sweep_stats
     HIPCHK(c, hipMemsetAsync(c->corr, 0, sizeof(float) * 2 * kMaxT * (size_t)bs, c->stream));   // block 0 has no predecessor
     for (int64_t k = 0; k <= nb; ++k) {
         UpdateArgs U;
-        U.X = c->X; U.ld = c->ld;
         U.r_in = c->r + ((k + 1) & 1) * rstride; U.r_out = c->r + (k & 1) * rstride;
         U.ev = &c->ev[k & 1];
         U.j0 = (k < nb) ? k * bs : 0;
@@ -841,12 +1041,16 @@ int jwas_hip_sweep(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_sweep_stats
         r_last = c->r + (nb & 1) * rstride;                   // r(nb-2), written by the last step
     }
     const int nfin = t * t + t;
+    with_cols(c, 0, [&](auto cx) {
+    using CX = decltype(cx);
     switch (t) {   // apply the last block's changes; the finished residual always lands in buffer 0
-        case 1: hipLaunchKernelGGL((k_finish<1>), dim3(c->nslices), dim3(256), 0, c->stream, c->X, c->ld, r_last, c->r, ev_list, c->fin_out); break;
-        case 2: hipLaunchKernelGGL((k_finish<2>), dim3(c->nslices), dim3(256), 0, c->stream, c->X, c->ld, r_last, c->r, ev_list, c->fin_out); break;
-        case 3: hipLaunchKernelGGL((k_finish<3>), dim3(c->nslices), dim3(256), 0, c->stream, c->X, c->ld, r_last, c->r, ev_list, c->fin_out); break;
-        default: hipLaunchKernelGGL((k_finish<4>), dim3(c->nslices), dim3(256), 0, c->stream, c->X, c->ld, r_last, c->r, ev_list, c->fin_out);
+        case 1: hipLaunchKernelGGL((k_finish<1, CX>), dim3(c->nslices), dim3(256), 0, c->stream, cx, r_last, c->r, ev_list, c->fin_out); break;
+        case 2: hipLaunchKernelGGL((k_finish<2, CX>), dim3(c->nslices), dim3(256), 0, c->stream, cx, r_last, c->r, ev_list, c->fin_out); break;
+        case 3: hipLaunchKernelGGL((k_finish<3, CX>), dim3(c->nslices), dim3(256), 0, c->stream, cx, r_last, c->r, ev_list, c->fin_out); break;
+        default: hipLaunchKernelGGL((k_finish<4, CX>), dim3(c->nslices), dim3(256), 0, c->stream, cx, r_last, c->r, ev_list, c->fin_out);
     }
+    return 0;
+    });
     const double* gamma_dev = reinterpret_cast<const double*>(reinterpret_cast<const char*>(c->dparams) + offsetof(DevParams, gamma));
     switch (t) {
         case 1: hipLaunchKernelGGL((k_marker_stats<1>), dim3(kStatGrid), dim3(256), 0, c->stream, c->method, c->p, c->alpha, c->beta, c->delta, gamma_dev, c->stat_out); break;

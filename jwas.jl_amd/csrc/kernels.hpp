@@ -60,6 +60,125 @@ struct DevParams {
 };
 
 // ---------------------------------------------------------------------------------------------
+// Genotype storage accessors.  Every kernel that reads genotypes is templated on one of these.
+//   DenseCols : fp32, marker-major, column stride ld (a multiple of 256 rows, pad rows zero).
+//   PackedCols: the reference's 2-bit packed backend (Packed2BitBackend, streaming_genotypes.jl:7-25):
+//               marker j occupies bytes [j*sb, (j+1)*sb); individual i is in byte i>>2 at bit shift (i&3)<<1;
+//               codes 0/1/2 = genotype, 3 = missing -> the marker mean; decoded exactly as decode_marker!
+//               (streaming_genotypes.jl:978-1002):  v = code == 3 ? mu : Float32(code);  x = centered ? v - mu : v.
+//               On the device sb = ld/4 (>= cld(n,4), padded to 64 bytes); rows >= n decode to 0.
+// load4(j, row): rows row..row+3 (row % 4 == 0) of column j;  load1(j, row): one element.
+// ---------------------------------------------------------------------------------------------
+struct DenseCols {
+    const float* X; int64_t ld;
+    // streaming interface of the update role: raw load now, decode when consumed; kDepth = register batches kept
+    // in flight per wave (dense: one 8 KB batch per wave already saturates HBM, see update_role)
+    typedef float4 Raw;
+    typedef float4 SRaw;
+    static constexpr int kDepth = 1;
+    // column stream of the update role: element i = rows row..row+3 of marker j0 + i*jstride
+    struct Stream {
+        const float* p; int64_t stride;
+        __device__ __forceinline__ SRaw load_raw(int i) const { return *reinterpret_cast<const float4*>(p + (int64_t)i * stride); }
+        __device__ __forceinline__ float load_mean(int) const { return 0.f; }
+        static __device__ __forceinline__ unsigned flags(const SRaw&) { return 0u; }
+        __device__ __forceinline__ float4 decode_fast(const SRaw& r, float) const { return r; }
+        __device__ __forceinline__ float4 decode_patch(const SRaw& r, float) const { return r; }
+    };
+    __device__ __forceinline__ Stream stream(int64_t j0, int jstride, int64_t row) const
+    {
+        return Stream{X + j0 * ld + row, (int64_t)jstride * ld};
+    }
+    __device__ __forceinline__ float4 load4(int64_t j, int64_t row) const
+    {
+        return *reinterpret_cast<const float4*>(X + j * ld + row);
+    }
+    __device__ __forceinline__ float load1(int64_t j, int64_t row) const { return X[j * ld + row]; }
+};
+
+struct PackedCols {
+    const uint8_t* Q; int64_t ld;            // ld = padded row count; byte stride of a marker = ld / 4
+    const float* mean; int64_t n; int32_t centered;
+    __device__ __forceinline__ float dec(unsigned code, float mu) const
+    {
+        const float v = (code == 3u) ? mu : (float)code;           // streaming_genotypes.jl:994
+        return centered ? v - mu : v;                              // :995
+    }
+    // a lane's share of a column is ONE byte, so many columns can be in flight for the price of a few registers:
+    // the streaming loop is latency-bound, not bandwidth-bound, and wants depth
+    struct Raw { unsigned byte; float mu; };
+    static constexpr int kDepth = 8;
+    __device__ __forceinline__ Raw load_raw(int64_t j, int64_t row) const
+    {
+        return Raw{Q[j * (ld >> 2) + (row >> 2)], mean[j]};
+    }
+    __device__ __forceinline__ float4 decode(const Raw& r, int64_t row) const
+    {
+        // Float32(code) - mu for the four codes of the byte; the (rare) missing code 3 is patched under a branch the
+        // whole wave skips when no lane holds one
+        const unsigned b = r.byte;
+        const float sub = centered ? r.mu : 0.f;
+        float4 x;
+        x.x = (float)(b & 3u) - sub; x.y = (float)((b >> 2) & 3u) - sub;
+        x.z = (float)((b >> 4) & 3u) - sub; x.w = (float)(b >> 6) - sub;
+        const unsigned miss = b & (b >> 1) & 0x55u;                // bit 2k set <=> code k == 3
+        if (miss) {
+            const float mv = centered ? 0.f : r.mu;                // v = mu  ->  x = centered ? mu - mu : mu
+            if (miss & 0x01u) x.x = mv;
+            if (miss & 0x04u) x.y = mv;
+            if (miss & 0x10u) x.z = mv;
+            if (miss & 0x40u) x.w = mv;
+        }
+        if (row + 4 > n) {                                         // pad rows (last slice only)
+            if (row >= n) x.x = 0.f;
+            if (row + 1 >= n) x.y = 0.f;
+            if (row + 2 >= n) x.z = 0.f;
+            if (row + 3 >= n) x.w = 0.f;
+        }
+        return x;
+    }
+    __device__ __forceinline__ float4 load4(int64_t j, int64_t row) const { return decode(load_raw(j, row), row); }
+    // column stream of the update role (no pad-row masking: the consumer multiplies pad rows by r = 0).
+    // The marker means are NOT fetched per column: a scalar load in the streaming loop forces s_waitcnt lgkmcnt(0)
+    // (SMEM returns out of order), i.e. a full memory round trip per batch.  Lane i of the wave loads the mean of
+    // stream element i0 + i once per 64-column chunk; columns read it with v_readlane.
+    typedef unsigned SRaw;
+    struct Stream {
+        const uint8_t* q; int64_t qstride; const float* m; int64_t mstride; int32_t centered;
+        __device__ __forceinline__ SRaw load_raw(int i) const { return q[(int64_t)i * qstride]; }
+        __device__ __forceinline__ float load_mean(int i) const { return m[(int64_t)i * mstride]; }
+        static __device__ __forceinline__ unsigned flags(const SRaw& b) { return b & (b >> 1) & 0x55u; }   // any code == 3
+        __device__ __forceinline__ float4 decode_fast(const SRaw& b, float mu) const           // no missing code in the byte
+        {
+            const float sub = centered ? mu : 0.f;
+            float4 x;
+            x.x = (float)(b & 3u) - sub; x.y = (float)((b >> 2) & 3u) - sub;
+            x.z = (float)((b >> 4) & 3u) - sub; x.w = (float)(b >> 6) - sub;
+            return x;
+        }
+        __device__ __forceinline__ float4 decode_patch(const SRaw& b, float mu) const
+        {
+            float4 x = decode_fast(b, mu);
+            const unsigned miss = flags(b);
+            const float mv = centered ? 0.f : mu;
+            x.x = (miss & 0x01u) ? mv : x.x; x.y = (miss & 0x04u) ? mv : x.y;
+            x.z = (miss & 0x10u) ? mv : x.z; x.w = (miss & 0x40u) ? mv : x.w;
+            return x;
+        }
+    };
+    __device__ __forceinline__ Stream stream(int64_t j0, int jstride, int64_t row) const
+    {
+        return Stream{Q + j0 * (ld >> 2) + (row >> 2), (int64_t)jstride * (ld >> 2), mean + j0, (int64_t)jstride, centered};
+    }
+    __device__ __forceinline__ float load1(int64_t j, int64_t row) const
+    {
+        if (row >= n) return 0.f;
+        const unsigned byte = Q[j * (ld >> 2) + (row >> 2)];
+        return dec((byte >> ((row & 3) << 1)) & 3u, mean[j]);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
 // wave64 reductions
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ double wave_sum(double v)
@@ -150,11 +269,12 @@ __host__ __device__ inline EventList event_list(const Events* ev)
     return EventList{&ev->count, ev->idx, &ev->delta[0][0], (int64_t)kMaxBlock};
 }
 
-template <int NT>
-__global__ __launch_bounds__(256) void k_finish(const float* __restrict__ X, int64_t ld, const float* r_in,
+template <int NT, class CX>
+__global__ __launch_bounds__(256) void k_finish(CX cx, const float* r_in,
                                                 float* r_out,
                                                 EventList ev, double* __restrict__ out)
 {
+    const int64_t ld = cx.ld;
     __shared__ double red[4 * (NT * NT + NT)];
     const int tid = threadIdx.x;
     const int64_t row = (int64_t)blockIdx.x * kSliceRows + tid;
@@ -162,12 +282,11 @@ __global__ __launch_bounds__(256) void k_finish(const float* __restrict__ X, int
 #pragma unroll
     for (int t = 0; t < NT; ++t) rv[t] = r_in[t * ld + row];
     const int ne = *ev.count;
-    const float* xrow = X + row;
     // sequential fmaf in list order (= marker order); 16 independent column loads in flight per thread
     for (int e0 = 0; e0 < ne; e0 += 16) {
         float x[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) x[u] = xrow[(int64_t)ev.idx[e0 + u < ne ? e0 + u : ne - 1] * ld];
+        for (int u = 0; u < 16; ++u) x[u] = cx.load1(ev.idx[e0 + u < ne ? e0 + u : ne - 1], row);
 #pragma unroll
         for (int u = 0; u < 16; ++u)
             if (e0 + u < ne)
@@ -432,13 +551,14 @@ __global__ __launch_bounds__(256) void k_accumulate(int64_t count, int delta_is_
 // storage-layer precompute
 // ---------------------------------------------------------------------------------------------
 // x'x per column, fp64 accumulated (getXpRinvX, tools4genotypes.jl:33-36).  grid = p, block 256.
-__global__ __launch_bounds__(256) void k_xpx(const float* __restrict__ X, int64_t ld, float* __restrict__ xpx)
+template <class CX>
+__global__ __launch_bounds__(256) void k_xpx(CX cx, float* __restrict__ xpx)
 {
     __shared__ double red[4];
-    const float* x = X + (int64_t)blockIdx.x * ld;
+    const int64_t ld = cx.ld;
     double v[1] = {0.0};
     for (int64_t i = (int64_t)threadIdx.x * 4; i < ld; i += 1024) {
-        const float4 q = *reinterpret_cast<const float4*>(x + i);
+        const float4 q = cx.load4(blockIdx.x, i);
         v[0] = fma((double)q.x, (double)q.x, v[0]);
         v[0] = fma((double)q.y, (double)q.y, v[0]);
         v[0] = fma((double)q.z, (double)q.z, v[0]);
@@ -450,9 +570,11 @@ __global__ __launch_bounds__(256) void k_xpx(const float* __restrict__ X, int64_
 
 // Exact (fp64-accumulated) Gram of one block: grid = (b, nblocks), block = 256; workgroup (a, blk)
 // writes row a: G[a][c], c <= a, and mirrors.  Test-size path; O(p*b*n/2) VALU work.
-__global__ __launch_bounds__(256) void k_gram_f64(const float* __restrict__ X, int64_t ld, int64_t p, int bsize,
+template <class CX>
+__global__ __launch_bounds__(256) void k_gram_f64(CX cx, int64_t p, int bsize,
                                                   float* __restrict__ gram)
 {
+    const int64_t ld = cx.ld;
     const int64_t blk = blockIdx.y;
     const int64_t j0 = blk * bsize;
     const int b = (int)((j0 + bsize <= p) ? bsize : (p - j0));
@@ -460,13 +582,11 @@ __global__ __launch_bounds__(256) void k_gram_f64(const float* __restrict__ X, i
     if (a >= b) return;
     float* G = gram + blk * (int64_t)bsize * bsize;   // blocks are stored at stride bsize^2, each b x b packed
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float* xa = X + (j0 + a) * ld;
     for (int c = wave; c <= a; c += 4) {
-        const float* xc = X + (j0 + c) * ld;
         double s = 0.0;
         for (int64_t i = (int64_t)lane * 4; i < ld; i += 256) {
-            const float4 qa = *reinterpret_cast<const float4*>(xa + i);
-            const float4 qc = *reinterpret_cast<const float4*>(xc + i);
+            const float4 qa = cx.load4(j0 + a, i);
+            const float4 qc = cx.load4(j0 + c, i);
             s = fma((double)qa.x, (double)qc.x, s);
             s = fma((double)qa.y, (double)qc.y, s);
             s = fma((double)qa.z, (double)qc.z, s);
@@ -489,9 +609,11 @@ constexpr int kGramChunk = 64;       // rows per fp32 accumulation chunk (then f
 
 // cross != 0: the cross-Gram of consecutive blocks C = X_{blk-1}' X_blk for blk = blockIdx.y + 1 (all
 // nt x nt tiles, rows = markers of the previous block, row stride = size of block blk).
-__global__ __launch_bounds__(256) void k_gram_mfma(const float* __restrict__ X, int64_t ld, int64_t p, int bsize,
+template <class CX>
+__global__ __launch_bounds__(256) void k_gram_mfma(CX cx, int64_t p, int bsize,
                                                    float* __restrict__ gram, int cross)
 {
+    const int64_t ld = cx.ld;
     __shared__ __attribute__((aligned(16))) float As[64 * kGramLd];
     __shared__ __attribute__((aligned(16))) float Bs[64 * kGramLd];
     const int64_t blk = cross ? (int64_t)blockIdx.y + 1 : (int64_t)blockIdx.y;
@@ -515,10 +637,8 @@ __global__ __launch_bounds__(256) void k_gram_mfma(const float* __restrict__ X, 
     // staging: thread -> (marker m = tid/8 [+32], float4 q = tid%8)
     const int sm = tid >> 3, sq = tid & 7;
     const int ma0 = ti * 64 + sm, ma1 = ma0 + 32, mb0 = tj * 64 + sm, mb1 = mb0 + 32;
-    const float* pa0 = X + (jA + (ma0 < bA ? ma0 : 0)) * ld + sq * 4;
-    const float* pa1 = X + (jA + (ma1 < bA ? ma1 : 0)) * ld + sq * 4;
-    const float* pb0 = X + (j0 + (mb0 < b ? mb0 : 0)) * ld + sq * 4;
-    const float* pb1 = X + (j0 + (mb1 < b ? mb1 : 0)) * ld + sq * 4;
+    const int64_t ja0 = jA + (ma0 < bA ? ma0 : 0), ja1 = jA + (ma1 < bA ? ma1 : 0);
+    const int64_t jb0 = j0 + (mb0 < b ? mb0 : 0), jb1 = j0 + (mb1 < b ? mb1 : 0);
     const float4 zero4{0.f, 0.f, 0.f, 0.f};
 
     f32x16 acc;
@@ -533,12 +653,12 @@ __global__ __launch_bounds__(256) void k_gram_mfma(const float* __restrict__ X, 
     int chunk_rows = 0;
     for (int64_t k0 = 0; k0 < ld; k0 += kGramKT) {
         // unconditional loads from clamped addresses; out-of-block markers are zeroed by value
-        float4 va0 = *reinterpret_cast<const float4*>(pa0 + k0);
-        float4 va1 = *reinterpret_cast<const float4*>(pa1 + k0);
+        float4 va0 = cx.load4(ja0, k0 + sq * 4);
+        float4 va1 = cx.load4(ja1, k0 + sq * 4);
         float4 vb0 = zero4, vb1 = zero4;
         if (!diag) {
-            vb0 = *reinterpret_cast<const float4*>(pb0 + k0);
-            vb1 = *reinterpret_cast<const float4*>(pb1 + k0);
+            vb0 = cx.load4(jb0, k0 + sq * 4);
+            vb1 = cx.load4(jb1, k0 + sq * 4);
         }
         if (ma0 >= bA) va0 = zero4;
         if (ma1 >= bA) va1 = zero4;
@@ -590,28 +710,28 @@ __global__ __launch_bounds__(256) void k_gram_mfma(const float* __restrict__ X, 
 // X * alpha (EBV, output.jl:302) and r -= X*alpha0 (MCMC_BayesianAlphabet.jl:142)
 // grid = nslices, block = 256: one row per thread, columns in marker order.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_mul_alpha(const float* __restrict__ X, int64_t ld, int64_t p,
+template <class CX>
+__global__ __launch_bounds__(256) void k_mul_alpha(CX cx, int64_t p,
                                                    const float* __restrict__ alpha, float* __restrict__ out)
 {
     const int64_t row = (int64_t)blockIdx.x * kSliceRows + threadIdx.x;
-    const float* xrow = X + row;
     double s = 0.0;
     for (int64_t j = 0; j < p; ++j) {
         const float a = alpha[j];
-        if (a != 0.f) s = fma((double)a, (double)xrow[j * ld], s);
+        if (a != 0.f) s = fma((double)a, (double)cx.load1(j, row), s);
     }
     out[row] = (float)s;
 }
 
-__global__ __launch_bounds__(256) void k_sub_xalpha(const float* __restrict__ X, int64_t ld, int64_t p,
+template <class CX>
+__global__ __launch_bounds__(256) void k_sub_xalpha(CX cx, int64_t p,
                                                     const float* __restrict__ alpha, float* __restrict__ r)
 {
     const int64_t row = (int64_t)blockIdx.x * kSliceRows + threadIdx.x;
-    const float* xrow = X + row;
     float rv = r[row];
     for (int64_t j = 0; j < p; ++j) {
         const float a = alpha[j];
-        if (a != 0.f) rv = fmaf(-a, xrow[j * ld], rv);
+        if (a != 0.f) rv = fmaf(-a, cx.load1(j, row), rv);
     }
     r[row] = rv;
 }
@@ -646,6 +766,44 @@ __global__ __launch_bounds__(256) void k_synth(float* __restrict__ X, int64_t n,
     const float mean = (float)(v[0] / (double)n);
     __syncthreads();
     for (int64_t i = threadIdx.x; i < n; i += 256) x[i] = x[i] - mean;
+}
+
+// Same generator, written as the reference's 2-bit codes + per-marker mean (kind 0 only: 0/1/2 genotypes).
+// Q: [p][sb] bytes, sb = ld/4.  The decoded matrix equals k_synth's output bit for bit.
+__global__ __launch_bounds__(256) void k_synth_packed(uint8_t* __restrict__ Q, float* __restrict__ mean, int64_t n, int64_t ld,
+                                                      uint32_t seed_lo, uint32_t seed_hi, uint32_t marker0)
+{
+    __shared__ double red[4];
+    const uint32_t j = marker0 + blockIdx.x;
+    uint8_t* q = Q + (int64_t)blockIdx.x * (ld >> 2);
+    const u32x4 wf = philox4x32_10(j, 0xFFFFFFFFu, 0u, 0u, seed_lo, seed_hi);
+    const float f = 0.1f + 0.3f * ((float)(wf.x >> 8) * 0x1.0p-24f);
+    double v[1] = {0.0};
+    for (int64_t i4 = threadIdx.x; i4 < (ld >> 2); i4 += 256) {
+        unsigned byte = 0u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t i = i4 * 4 + k;
+            if (i < n) {
+                const u32x4 w = philox4x32_10(j, (uint32_t)i, 1u, 0u, seed_lo, seed_hi);
+                const float u1 = (float)(w.x >> 8) * 0x1.0p-24f, u2 = (float)(w.y >> 8) * 0x1.0p-24f;
+                const unsigned code = (u1 < f ? 1u : 0u) + (u2 < f ? 1u : 0u);
+                byte |= code << (2 * k);
+                v[0] += (double)code;
+            }
+        }
+        q[i4] = (uint8_t)byte;
+    }
+    block_sum<1>(v, red, 4);
+    if (threadIdx.x == 0) mean[blockIdx.x] = (float)(v[0] / (double)n);
+}
+
+// Decode columns [j0, j0+count) into a dense column-major n x count host-visible buffer (ld_out = n).
+template <class CX>
+__global__ __launch_bounds__(256) void k_get_columns(CX cx, int64_t j0, int64_t n, float* __restrict__ out)
+{
+    const int64_t j = j0 + blockIdx.x;
+    for (int64_t i = threadIdx.x; i < n; i += 256) out[(int64_t)blockIdx.x * n + i] = cx.load1(j, i);
 }
 
 // empty kernel: calibrates what a HIP-event pair around ONE launch measures beyond the kernel itself

@@ -66,9 +66,9 @@ struct StepSmem {
 // ---------------------------------------------------------------------------------------------
 // UPDATE/PARTIAL role
 // ---------------------------------------------------------------------------------------------
-template <int NT>
+template <int NT, class CX>
 __device__ __forceinline__ void update_role(char* smem, int rg, int g,
-                                            const float* __restrict__ X, int64_t ld,
+                                            const CX& cx,
                                             const float* __restrict__ r_in, float* __restrict__ r_out,
                                             const Events* __restrict__ ev,
                                             int64_t j0, int b, int nslices, int nrg, int ncg,
@@ -82,24 +82,29 @@ __device__ __forceinline__ void update_role(char* smem, int rg, int g,
     // an inactive wave (slice beyond the matrix) aliases slice 0 for addressing and contributes 0
     const int64_t row = (int64_t)(active ? slice : 0) * kSliceRows + lane * 4;
     const int ncols = (b > g) ? (b - g + ncg - 1) / ncg : 0;
+    const int64_t ld = cx.ld;
 
     // Loads are unconditional from clamped, always-valid addresses: a select between a load and a
     // constant makes hipcc pick between pointers and emit flat/scratch accesses.
-    const float* xcol = X + (j0 + (ncols > 0 ? g : 0)) * ld + row;
-    const int64_t cstride = (int64_t)ncg * ld;
+    const int64_t jc0 = j0 + (ncols > 0 ? g : 0);
     const int nc1 = ncols > 0 ? ncols - 1 : 0;
-    auto load_batch = [&](float4 (&dst)[kU], int ib) {
+    typedef typename CX::SRaw Raw;
+    constexpr int D = CX::kDepth;                      // register batches in flight per wave
+    const typename CX::Stream st = cx.stream(jc0, ncg, row);     // element i = marker jc0 + i*ncg, this lane's 4 rows
+    auto load_batch = [&](Raw (&dst)[kU], int ib) {
 #pragma unroll
-        for (int u = 0; u < kU; ++u)
-            dst[u] = *reinterpret_cast<const float4*>(xcol + (ib + u < ncols ? ib + u : nc1) * cstride);
+        for (int u = 0; u < kU; ++u) dst[u] = st.load_raw(ib + u < ncols ? ib + u : nc1);
     };
 
-    // (1) the first batch of column loads does not depend on r: issue it before the update.
-    //     In-flight depth is ONE batch per wave (8 KB): with ~1600 waves streaming that is ~13 MB outstanding,
+    // (1) the first batch(es) of column loads do not depend on r: issue them before the update.
+    //     Dense: in-flight depth is ONE batch per wave (8 KB): with ~1600 waves streaming that is ~13 MB outstanding,
     //     enough for full HBM rate; doubling it only lengthens the memory queues (Little's law) and with them
     //     the latency of every dependent load of the concurrently running sampler role.
-    float4 xa[kU];
-    load_batch(xa, 0);
+    //     2-bit packed: a batch is 8 x 64 B per wave, so the loop is latency-bound and keeps D batches in flight.
+    float mnext = st.load_mean(lane < ncols ? lane : nc1);     // packed storage: marker means of the first 64 stream elements
+    Raw xr[D][kU];
+#pragma unroll
+    for (int s = 0; s < D; ++s) load_batch(xr[s], s * kU);
 
     // (2) sparse exit update: sequential fmaf in marker order, bit-identical to the oracle's per-marker
     //     axpy sequence.  Every column group recomputes it (reads r_in only); group 0 stores r_out.
@@ -109,7 +114,7 @@ __device__ __forceinline__ void update_role(char* smem, int rg, int g,
     const int ne = ev->count;
 #pragma unroll 8
     for (int e = 0; e < ne; ++e) {
-        const float4 x = *reinterpret_cast<const float4*>(X + (int64_t)ev->idx[e] * ld + row);
+        const float4 x = cx.load4(ev->idx[e], row);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const float d = ev->delta[t][e];
@@ -128,26 +133,43 @@ __device__ __forceinline__ void update_role(char* smem, int rg, int g,
         rd[t][0] = rv[t].x * keep; rd[t][1] = rv[t].y * keep; rd[t][2] = rv[t].z * keep; rd[t][3] = rv[t].w * keep;
     }
 
-    // (3) partial block RHS.
+    // (3) partial block RHS.  (kColChunk / kU batches per chunk is a multiple of D, so ring slot = batch % D.)
     for (int i0 = 0; i0 < ncols; i0 += kColChunk) {
         const int iend = (i0 + kColChunk < ncols) ? i0 + kColChunk : ncols;
-        for (int ib = i0; ib < iend; ib += kU) {
-            double acc[NT][kU];
+        const float mcur = mnext;                                // lane i: mean of stream element i0 + i
+        if (i0 + kColChunk < ncols) mnext = st.load_mean(i0 + kColChunk + lane < ncols ? i0 + kColChunk + lane : nc1);
+        for (int ib0 = i0; ib0 < iend; ib0 += kU * D) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
+            for (int s = 0; s < D; ++s) {
+                const int ib = ib0 + s * kU;
+                if (ib >= iend) break;
+                double acc[NT][kU];
+                auto products = [&](auto dec) {
 #pragma unroll
-                for (int u = 0; u < kU; ++u) {
-                    acc[t][u] = (double)xa[u].x * rd[t][0];
-                    acc[t][u] = fma((double)xa[u].y, rd[t][1], acc[t][u]);
-                    acc[t][u] = fma((double)xa[u].z, rd[t][2], acc[t][u]);
-                    acc[t][u] = fma((double)xa[u].w, rd[t][3], acc[t][u]);
+                    for (int u = 0; u < kU; ++u) {
+                        const float mu = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mcur), ib + u - i0));
+                        const float4 xa = dec(xr[s][u], mu);
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            acc[t][u] = (double)xa.x * rd[t][0];
+                            acc[t][u] = fma((double)xa.y, rd[t][1], acc[t][u]);
+                            acc[t][u] = fma((double)xa.z, rd[t][2], acc[t][u]);
+                            acc[t][u] = fma((double)xa.w, rd[t][3], acc[t][u]);
+                        }
+                    }
+                };
+                unsigned fl = 0u;                              // packed storage: does any byte of the batch hold a missing code?
+#pragma unroll
+                for (int u = 0; u < kU; ++u) fl |= CX::Stream::flags(xr[s][u]);
+                if (__any(fl != 0u)) products([&](const Raw& r, float mu) { return st.decode_patch(r, mu); });   // wave-uniform branch
+                else products([&](const Raw& r, float mu) { return st.decode_fast(r, mu); });
+                if (ib + kU * D < ncols) load_batch(xr[s], ib + kU * D);   // registers are free again: refill the slot
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const double sum = butterfly8(acc[t], lane);
+                    const int u = lane >> 3;                   // column of this 8-lane group
+                    if ((lane & 7) == 0 && ib + u < ncols) red[wave][ib + u - i0][t] = sum;
                 }
-            if (ib + kU < ncols) load_batch(xa, ib + kU);      // registers are free again: next batch in flight
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const double s = butterfly8(acc[t], lane);
-                const int u = lane >> 3;                       // column of this 8-lane group
-                if ((lane & 7) == 0 && ib + u < ncols) red[wave][ib + u - i0][t] = s;
             }
         }
         __syncthreads();
@@ -1032,7 +1054,6 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
 // The fused step.  grid = 1 + nrg*ncg, block = 512.
 // ---------------------------------------------------------------------------------------------
 struct UpdateArgs {
-    const float* X; int64_t ld;
     const float* r_in; float* r_out;
     const Events* ev;             // changes to apply (block k-2)
     int64_t j0; int b;            // block whose partial RHS is formed (b = 0: none)
@@ -1041,9 +1062,13 @@ struct UpdateArgs {
     int quiet_xcd;                // 1: ids = 0 mod 8 (the sampler's XCD) do no update work
     int dbg_throttle;             // > 1: only every n-th update workgroup runs (timing experiments; results wrong)
 };
+template <class CX>
+struct UpdateArgsT : UpdateArgs {
+    CX cx;                        // genotype storage accessor
+};
 
-template <int METHOD, int NT>
-__global__ __launch_bounds__(kStepThreads) void k_block_step(UpdateArgs U, SamplerArgs S, int do_sample)
+template <int METHOD, int NT, class CX>
+__global__ __launch_bounds__(kStepThreads) void k_block_step(UpdateArgsT<CX> U, SamplerArgs S, int do_sample)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (blockIdx.x == 0) {
@@ -1062,28 +1087,28 @@ __global__ __launch_bounds__(kStepThreads) void k_block_step(UpdateArgs U, Sampl
     }
     if (w >= U.nrg * U.ncg) return;
     if (U.dbg_throttle > 1 && (w % U.dbg_throttle) != 0) return;       // timing experiments only
-    update_role<NT>(smem, w % U.nrg, w / U.nrg, U.X, U.ld, U.r_in, U.r_out, U.ev, U.j0, U.b,
-                    U.nslices, U.nrg, U.ncg, U.partials, U.bstride);
+    update_role<NT, CX>(smem, w % U.nrg, w / U.nrg, U.cx, U.r_in, U.r_out, U.ev, U.j0, U.b,
+                        U.nslices, U.nrg, U.ncg, U.partials, U.bstride);
 }
 
 // Cross-Gram of consecutive blocks, exact (fp64-accumulated): C[a][c] = x_{jp+a}' x_{j0+c}.
 // grid = (bsize, nblocks-1), block = 256; workgroup (a, i) writes row a of cross block i+1.
-__global__ __launch_bounds__(256) void k_cross_f64(const float* __restrict__ X, int64_t ld, int64_t p, int bsize,
+template <class CX>
+__global__ __launch_bounds__(256) void k_cross_f64(CX cx, int64_t p, int bsize,
                                                    float* __restrict__ cross)
 {
+    const int64_t ld = cx.ld;
     const int64_t blk = (int64_t)blockIdx.y + 1;
     const int64_t j0 = blk * bsize, jp = j0 - bsize;
     const int b = (int)((j0 + bsize <= p) ? bsize : (p - j0));
     const int a = blockIdx.x;
     float* C = cross + blk * (int64_t)bsize * bsize;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float* xa = X + (jp + a) * ld;
     for (int c = wave; c < b; c += 4) {
-        const float* xc = X + (j0 + c) * ld;
         double s = 0.0;
         for (int64_t i = (int64_t)lane * 4; i < ld; i += 256) {
-            const float4 qa = *reinterpret_cast<const float4*>(xa + i);
-            const float4 qc = *reinterpret_cast<const float4*>(xc + i);
+            const float4 qa = cx.load4(jp + a, i);
+            const float4 qc = cx.load4(j0 + c, i);
             s = fma((double)qa.x, (double)qc.x, s);
             s = fma((double)qa.y, (double)qc.y, s);
             s = fma((double)qa.z, (double)qc.z, s);
@@ -1101,8 +1126,8 @@ __global__ __launch_bounds__(256) void k_cross_f64(const float* __restrict__ X, 
 // afterwards with r += sum_b X_b * (alpha_old_b - alpha_new_b) in (block, marker) order.
 // ---------------------------------------------------------------------------------------------
 // Block RHS of ALL blocks from the snapshot.  grid = (nrg*ncg, nblocks), block = 512.
-template <int NT>
-__global__ __launch_bounds__(kStepThreads) void k_indep_rhs(UpdateArgs U, int64_t p, int bsz, int64_t pstride)
+template <int NT, class CX>
+__global__ __launch_bounds__(kStepThreads) void k_indep_rhs(UpdateArgsT<CX> U, int64_t p, int bsz, int64_t pstride)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int64_t blk = blockIdx.y;
@@ -1111,8 +1136,8 @@ __global__ __launch_bounds__(kStepThreads) void k_indep_rhs(UpdateArgs U, int64_
     const int ncg = U.ncg < b ? U.ncg : b;
     const int w = blockIdx.x;
     if (w >= U.nrg * ncg) return;
-    update_role<NT>(smem, w % U.nrg, w / U.nrg, U.X, U.ld, U.r_in, nullptr, U.ev, j0, b,
-                    U.nslices, U.nrg, ncg, U.partials + blk * pstride, U.bstride);
+    update_role<NT, CX>(smem, w % U.nrg, w / U.nrg, U.cx, U.r_in, nullptr, U.ev, j0, b,
+                        U.nslices, U.nrg, ncg, U.partials + blk * pstride, U.bstride);
 }
 
 // All blocks sampled concurrently.  grid = nblocks, block = 512, dynamic LDS as k_block_step.

@@ -70,8 +70,9 @@ class HipEngine:
         return {"n_cu": ncu.value, "hbm_total": tot.value, "hbm_free": free.value}
 
     @staticmethod
-    def estimate_bytes(n, p, ntraits=1, block_size=256):
-        return _lib.load().jwas_hip_estimate_bytes(int(n), int(p), int(ntraits), int(block_size))
+    def estimate_bytes(n, p, ntraits=1, block_size=256, storage="dense"):
+        kind = _lib.STORAGE_PACKED2BIT if storage in ("stream", "packed2bit") else _lib.STORAGE_DENSE_F32
+        return _lib.load().jwas_hip_estimate_bytes_storage(int(n), int(p), int(ntraits), int(block_size), kind)
 
     # -- storage ---------------------------------------------------------------------------------
     def load_dense(self, X):
@@ -92,6 +93,44 @@ class HipEngine:
         self._chk(self._L.jwas_hip_alloc_dense_f32(self._h, int(n), int(p)))
         self.n, self.p = int(n), int(p)
         self.method, self.block_size = None, 0
+
+    # 2-bit packed storage (the reference's Packed2BitBackend kept packed in HBM) ----------------
+    def load_packed2bit(self, payload, n, means, centered=True):
+        """payload: p x stride uint8 (marker-major rows, stride >= cld(n,4)); means: p float32."""
+        payload = np.ascontiguousarray(payload, dtype=np.uint8)
+        if payload.ndim != 2:
+            raise ValueError("payload must be a p x stride_bytes uint8 array")
+        means = np.ascontiguousarray(means, dtype=np.float32)
+        p, stride = payload.shape
+        if means.shape != (p,):
+            raise ValueError("one marker mean per packed marker is required")
+        self._chk(self._L.jwas_hip_load_packed2bit(self._h, _ptr(payload), int(n), p, stride, _ptr(means), int(bool(centered))))
+        self.n, self.p = int(n), p
+        self.method, self.block_size = None, 0
+
+    def load_jgb2(self, path):
+        """load_streaming_backend (streaming_genotypes.jl:884-971): prefix, or <prefix>.meta / <prefix>.jgb2."""
+        self._chk(self._L.jwas_hip_load_jgb2(self._h, str(path).encode()))
+        info = self.storage_info()
+        self.n, self.p = info["n"], info["p"]
+        self.method, self.block_size = None, 0
+
+    def alloc_packed(self, n, p, centered=True):
+        self._chk(self._L.jwas_hip_alloc_packed2bit(self._h, int(n), int(p), int(bool(centered))))
+        self.n, self.p = int(n), int(p)
+        self.method, self.block_size = None, 0
+
+    def storage_info(self):
+        k, n, p, b = C.c_int32(), C.c_int64(), C.c_int64(), C.c_int64()
+        self._chk(self._L.jwas_hip_storage_info(self._h, C.byref(k), C.byref(n), C.byref(p), C.byref(b)))
+        return {"kind": "packed2bit" if k.value == _lib.STORAGE_PACKED2BIT else "dense_f32", "n": n.value, "p": p.value,
+                "bytes": b.value}
+
+    def set_xpx(self, xpx):
+        x = np.ascontiguousarray(xpx, dtype=np.float32)
+        if x.shape != (self.p,):
+            raise ValueError(f"x'x must have length {self.p}")
+        self._chk(self._L.jwas_hip_set_xpx(self._h, _ptr(x)))
 
     def synth(self, seed, kind=0, center=True, marker_offset=0):
         self._chk(self._L.jwas_hip_synth_genotypes(self._h, int(seed), int(kind), int(bool(center)), int(marker_offset)))

@@ -137,14 +137,25 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         complete &= np.isfinite(ph[tr].to_numpy(dtype=np.float64))
     if t > 1 and not complete.all():
         raise NotImplementedError("missing phenotypes in multi-trait analyses (residual imputation, residual.jl:15-73) stay on the reference")
-    geno_index = {g: i for i, g in enumerate(Mi.obsID)}
-    keep = complete & ph[idcol].isin(geno_index).to_numpy()
-    ph = ph.loc[keep].reset_index(drop=True)
-    if len(ph) == 0:
-        raise ValueError("no individual has both phenotypes and genotypes")
-    rows = np.array([geno_index[i] for i in ph[idcol]], dtype=np.int64)
-    X = Mi.genotypes if (len(rows) == Mi.nObs and np.array_equal(rows, np.arange(Mi.nObs))) else np.asfortranarray(Mi.genotypes[rows, :])
-    n, p = X.shape
+    stream = getattr(Mi, "storage_mode", "dense") == "stream"
+    if stream:
+        # the packed payload goes from the file straight to HBM and is never re-ordered: like the reference's stream
+        # mode, phenotype IDs must match the genotype IDs exactly and in order (JWAS.jl:388-398)
+        if not complete.all() or list(ph[idcol]) != list(Mi.obsID):
+            raise ValueError("storage=:stream MVP requires exact genotype/phenotype ID match and order. "
+                             "Please reorder phenotypes to match genotype IDs.")
+        print("storage=:stream is enabled; genotype alignment is skipped and original ID order is used.")
+        X = None
+        n, p = Mi.nObs, Mi.nMarkers
+    else:
+        geno_index = {g: i for i, g in enumerate(Mi.obsID)}
+        keep = complete & ph[idcol].isin(geno_index).to_numpy()
+        ph = ph.loc[keep].reset_index(drop=True)
+        if len(ph) == 0:
+            raise ValueError("no individual has both phenotypes and genotypes")
+        rows = np.array([geno_index[i] for i in ph[idcol]], dtype=np.int64)
+        X = Mi.genotypes if (len(rows) == Mi.nObs and np.array_equal(rows, np.arange(Mi.nObs))) else np.asfortranarray(Mi.genotypes[rows, :])
+        n, p = X.shape
     with open(os.path.join(output_folder, "IDs_for_individuals_with_phenotypes.txt"), "w") as fh:
         fh.write("\n".join(ph[idcol]) + "\n")
     with open(os.path.join(output_folder, "IDs_for_individuals_with_genotypes.txt"), "w") as fh:
@@ -248,7 +259,7 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
     own_engine = engine is None
     if own_engine:
         from .engine import HipEngine
-        need = HipEngine.estimate_bytes(n, p, t, block_size)
+        need = HipEngine.estimate_bytes(n, p, t, block_size, "stream" if stream else "dense")
         engine = HipEngine(device)
         free = engine.device_info()["hbm_free"]
         if memory_guard != "off" and need > memory_guard_ratio * free:   # JWAS.jl:422-459 analogue for HBM
@@ -258,7 +269,10 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
                 engine.close()
                 raise MemoryError(msg)
             print("WARNING: " + msg)
-    engine.load_dense(X)                       # after alignment (tools4genotypes.jl:310-321)
+    if stream:
+        engine.load_jgb2(Mi.stream_backend["prefix"])          # payload stays 2-bit packed in HBM
+    else:
+        engine.load_dense(X)                   # after alignment (tools4genotypes.jl:310-321)
     engine.setup_blocks(block_size, gram_mode)
     engine.init_state(mt_method if t > 1 else method, t)
 

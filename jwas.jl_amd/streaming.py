@@ -1,0 +1,153 @@
+"""The reference's streaming genotype backend on disk (`storage=:stream`): 2-bit packed, marker-major `.jgb2`
+payload + sidecars, written / read in the reference's own format so that the outputs of the reference's
+`prepare_streaming_genotypes` load directly (and vice versa).
+
+Format (src/1.JWAS/src/markers/streaming_genotypes.jl:364-367,600-654,884-971):
+    <prefix>.jgb2          nMarkers rows of stride = cld(nObs,4) bytes; individual i (0-based) of a marker sits in
+                           byte i>>2 at bit shift (i&3)<<1; codes 0/1/2 = genotype, 3 = missing
+    <prefix>.meta          tab-separated key/value manifest (version, *_path, nObs, nMarkers, nMarkersAll,
+                           stride_bytes, centered, sum2pq)
+    <prefix>.obsid.txt / .markerid.txt     one ID per line
+    <prefix>.selected.i32  1-based raw-column index of every kept marker (little-endian Int32)
+    <prefix>.mean.f32 / .xpRinvx.f32 / .afreq.f32   per-marker Float32 vectors (little-endian)
+
+`prepare_streaming_genotypes` here is the dense-mode host converter (the reference's default conversion for inputs
+that fit memory, streaming_genotypes.jl:499-656); QC follows get_genotypes (readgenotypes.jl:372-401).
+"""
+import os
+
+import numpy as np
+
+
+def pack_2bit(raw_codes):
+    """raw_codes: n x p uint8 in {0,1,2,3} -> p x cld(n,4) uint8 payload."""
+    n, p = raw_codes.shape
+    stride = (n + 3) // 4
+    pad = np.zeros((stride * 4, p), dtype=np.uint8)
+    pad[:n] = raw_codes
+    q = pad.reshape(stride, 4, p)
+    payload = q[:, 0] | (q[:, 1] << 2) | (q[:, 2] << 4) | (q[:, 3] << 6)
+    return np.ascontiguousarray(payload.T.astype(np.uint8))
+
+
+def unpack_2bit(payload, n):
+    """p x stride payload -> n x p uint8 codes."""
+    p, stride = payload.shape
+    q = np.empty((stride, 4, p), dtype=np.uint8)
+    pt = payload.T
+    for k in range(4):
+        q[:, k] = (pt >> (2 * k)) & 3
+    return q.reshape(stride * 4, p)[:n]
+
+
+def prepare_streaming_genotypes(genotypes, output_prefix, *, obs_ids=None, marker_ids=None, missing_value=9.0,
+                                quality_control=True, MAF=0.01, center=True):
+    """genotypes: n x p array of 0/1/2 (missing_value = missing).  Writes <output_prefix>.{jgb2,meta,...} and
+    returns the prefix.  Mirrors prepare_streaming_genotypes (streaming_genotypes.jl:819-877) for in-memory input."""
+    G = np.asarray(genotypes)
+    n, p_all = G.shape
+    miss = (G == missing_value)
+    vals = np.where(miss, 0, G).astype(np.float64)
+    if np.any((vals != np.round(vals)) | (vals < 0) | (vals > 2)):
+        raise ValueError("Streaming backend supports only genotype values 0, 1, 2 (and the missing value).")
+    cnt = (~miss).sum(axis=0)
+    s1 = vals.sum(axis=0)
+    s2 = (vals * vals).sum(axis=0)
+    mean = np.where(cnt > 0, s1 / np.maximum(cnt, 1), 0.0).astype(np.float32)
+    afreq = (mean / np.float32(2.0)).astype(np.float32)
+    if quality_control:                                             # readgenotypes.jl:388-399
+        var = np.where(cnt > 0, s2 / np.maximum(cnt, 1) - mean.astype(np.float64) ** 2, 0.0)
+        keep = (afreq >= MAF) & (afreq <= 1 - MAF) & (var > 0)
+    else:
+        keep = np.ones(p_all, dtype=bool)
+    selected = np.flatnonzero(keep)
+    mean, afreq = mean[selected], afreq[selected]
+    mu = mean.astype(np.float64)
+    # x'x of the centred, mean-imputed column: sum v^2 - mu*sum v over non-missing (streaming_genotypes.jl:283-285)
+    xp = ((s2[selected] - mu * s1[selected]) if center else (s2[selected] + (n - cnt[selected]) * mu * mu)).astype(np.float32)
+    codes = np.where(miss[:, selected], 3, vals[:, selected]).astype(np.uint8)
+    payload = pack_2bit(codes)
+    prefix = os.path.abspath(str(output_prefix))
+    for ext in (".meta", ".jgb2"):
+        if prefix.endswith(ext):
+            prefix = prefix[:-len(ext)]
+    os.makedirs(os.path.dirname(prefix) or ".", exist_ok=True)
+    obs_ids = [str(i + 1) for i in range(n)] if obs_ids is None else [str(v) for v in obs_ids]
+    marker_all = [f"m{j + 1}" for j in range(p_all)] if marker_ids is None else [str(v) for v in marker_ids]
+    marker_ids = [marker_all[j] for j in selected]
+    paths = {k: prefix + ext for k, ext in (("data_path", ".jgb2"), ("obs_path", ".obsid.txt"), ("marker_path", ".markerid.txt"),
+                                             ("selected_path", ".selected.i32"), ("mean_path", ".mean.f32"),
+                                             ("xp_path", ".xpRinvx.f32"), ("afreq_path", ".afreq.f32"))}
+    payload.tofile(paths["data_path"])
+    with open(paths["obs_path"], "w") as fh:
+        fh.write("".join(v + "\n" for v in obs_ids))
+    with open(paths["marker_path"], "w") as fh:
+        fh.write("".join(v + "\n" for v in marker_ids))
+    (selected + 1).astype("<i4").tofile(paths["selected_path"])
+    mean.astype("<f4").tofile(paths["mean_path"])
+    xp.astype("<f4").tofile(paths["xp_path"])
+    afreq.astype("<f4").tofile(paths["afreq_path"])
+    sum2pq = float((np.float32(2.0) * afreq * (np.float32(1.0) - afreq)).sum(dtype=np.float32))
+    entries = [("version", "1")] + list(paths.items()) + [
+        ("nObs", str(n)), ("nMarkers", str(len(selected))), ("nMarkersAll", str(p_all)),
+        ("stride_bytes", str((n + 3) // 4)), ("centered", "1" if center else "0"), ("sum2pq", repr(sum2pq))]
+    with open(prefix + ".meta", "w") as fh:
+        fh.write("".join(f"{k}\t{v}\n" for k, v in entries))
+    return prefix
+
+
+def resolve_prefix(path):
+    path = os.path.abspath(str(path))
+    for ext in (".meta", ".jgb2"):                                  # _resolve_streaming_prefix (:97-105)
+        if path.endswith(ext):
+            return path[:-len(ext)]
+    return path
+
+
+def load_streaming_backend(path):
+    """Host-side metadata of a streaming backend (load_streaming_backend, streaming_genotypes.jl:884-971): everything
+    except the payload, which goes straight from the file to HBM (jwas_hip_load_jgb2)."""
+    prefix = resolve_prefix(path)
+    meta_path = prefix + ".meta"
+    if not os.path.isfile(meta_path):
+        raise FileNotFoundError(f"Streaming manifest is not found: {meta_path}")
+    meta = {}
+    with open(meta_path) as fh:
+        for line in fh:
+            parts = line.rstrip("\n").split("\t", 1)
+            if len(parts) == 2:
+                meta[parts[0]] = parts[1]
+    n, p, stride = int(meta["nObs"]), int(meta["nMarkers"]), int(meta["stride_bytes"])
+
+    def side(key, ext):
+        f = meta.get(key, "")
+        return f if f and os.path.isfile(f) else prefix + ext
+
+    data_path = side("data_path", ".jgb2")
+    if os.path.getsize(data_path) != p * stride:
+        raise ValueError(f"Packed genotype file size does not match metadata for {data_path}")
+    obs = [v for v in open(side("obs_path", ".obsid.txt")).read().split("\n") if v]
+    markers = [v for v in open(side("marker_path", ".markerid.txt")).read().split("\n") if v]
+    if len(obs) != n:
+        raise ValueError("Number of IDs does not match nObs in manifest.")
+    if len(markers) != p:
+        raise ValueError("Number of markers does not match nMarkers in manifest.")
+    return {
+        "prefix": prefix, "data_path": data_path, "nObs": n, "nMarkers": p, "stride_bytes": stride,
+        "nMarkersAll": int(meta.get("nMarkersAll", p)), "centered": int(meta["centered"]) == 1,
+        "sum2pq": float(meta["sum2pq"]), "obsID": obs, "markerID": markers,
+        "marker_means": np.fromfile(side("mean_path", ".mean.f32"), dtype="<f4", count=p),
+        "xpRinvx": np.fromfile(side("xp_path", ".xpRinvx.f32"), dtype="<f4", count=p),
+        "allele_freq": np.fromfile(side("afreq_path", ".afreq.f32"), dtype="<f4", count=p),
+    }
+
+
+def decode_markers(backend, j0=0, count=None):
+    """CPU decode of markers [j0, j0+count) (decode_marker!, :978-1002) -- small inputs / checks only."""
+    p, stride, n = backend["nMarkers"], backend["stride_bytes"], backend["nObs"]
+    count = p - j0 if count is None else count
+    payload = np.fromfile(backend["data_path"], dtype=np.uint8, count=count * stride, offset=j0 * stride).reshape(count, stride)
+    codes = unpack_2bit(payload, n)
+    mu = backend["marker_means"][j0:j0 + count].astype(np.float32)
+    v = np.where(codes == 3, mu[None, :], codes.astype(np.float32)).astype(np.float32)
+    return np.asfortranarray(v - mu[None, :] if backend["centered"] else v)

@@ -18,11 +18,12 @@ ap.add_argument("--traits", type=int, default=3)
 ap.add_argument("--gram", default="mfma")
 ap.add_argument("--kind", type=int, default=0)
 ap.add_argument("--independent", action="store_true")
+ap.add_argument("--packed", action="store_true")
 ap.add_argument("--nreps", type=int, default=1)
 a = ap.parse_args()
 
 e = J.HipEngine(0)
-t0 = time.time(); e.alloc_dense(a.n, a.p); e.synth(2026, a.kind, True); print("synth s", round(time.time() - t0, 2), flush=True)
+t0 = time.time(); (e.alloc_packed if a.packed else e.alloc_dense)(a.n, a.p); e.synth(2026, a.kind, True); print("synth s", round(time.time() - t0, 2), flush=True)
 rng = np.random.default_rng(1)
 for bs in a.bs:
     t0 = time.time(); e.setup_blocks(bs, a.gram); print(f"bs={bs} setup {time.time() - t0:.2f}s", flush=True)

@@ -35,6 +35,11 @@ class OracleEngine:
         self.X = X
         self.n, self.p = X.shape
 
+    def load_jgb2(self, path):
+        """CPU stand-in for jwas_hip_load_jgb2: decode the packed backend (decode_marker!) and keep it dense."""
+        from jwas_jl_amd import streaming as S
+        self.load_dense(S.decode_markers(S.load_streaming_backend(path)))
+
     def setup_blocks(self, block_size=256, gram_mode="f64"):
         self.block_size = int(block_size)
         self._xpx = O.xpx(self.X, self.acc)
