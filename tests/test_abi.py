@@ -36,12 +36,15 @@ def test_library_contains_gfx950_code_object():
 
 def test_memory_estimate_formula():
     """HBM analogue of estimate_marker_memory (tools4genotypes.jl:99-235; test_memory_guardrails.jl:9-60):
-    dense X (rows padded to 256) + block Grams (p*b) + x'x + state + residuals + partials."""
+    dense X (rows padded to 256) + block Grams and cross-Grams (2*p*b) + x'x + state + residuals + partials;
+    stream storage: 2-bit payload + means instead of the fp32 matrix (the reference's stream formula has the same
+    ceil(n/4) term, test_memory_guardrails.jl:62-75)."""
     from jwas_jl_amd import HipEngine
     n, p, t, b = 1000, 5000, 1, 256
     ld = 1024
-    expect = 4 * ld * p + 4 * b * p + 4 * p + t * p * 4 * 6 + 4 * ld * 4 + b * (ld // 256) * t * 8
-    assert HipEngine.estimate_bytes(n, p, t, b) == expect
+    rest = 2 * 4 * b * p + 4 * p + t * p * 4 * 6 + 4 * ld * 4 + b * (ld // 256) * t * 8
+    assert HipEngine.estimate_bytes(n, p, t, b) == 4 * ld * p + rest
+    assert HipEngine.estimate_bytes(n, p, t, b, storage="stream") == (ld // 4) * p + 4 * p + rest
     assert HipEngine.estimate_bytes(50_000, 600_000, 1, 256) < 288e9        # config 2 fits one MI355X
 
 
