@@ -369,6 +369,26 @@ def test_independent_blocks_parity(hip, method, bs, nreps):
     assert sh["n_events"] > 0
 
 
+def test_real_valued_imputed_genotypes_parity(hip):
+    """Single-step input (SSBR.jl:83-142): the non-genotyped rows of X are real-valued parent-average-like mixtures,
+    not 0/1/2 -- the device path is the dense fp32 one, nothing assumes integer codes."""
+    data = make_dataset(n=420, p=300, ncausal=8, seed=77)
+    rng = np.random.default_rng(7)
+    X = data["X"].copy()
+    W = rng.dirichlet(np.ones(4), size=200).astype(np.float32)              # 200 "imputed" rows = mixtures of genotyped rows
+    X[220:] = W @ X[rng.integers(0, 220, 4)]
+    X = np.asfortranarray(X - X.mean(axis=0, dtype=np.float32))
+    d2 = dict(data, X=X)
+    orc, hip = _pair(hip, d2, 128, "BayesC")
+    r0 = data["y"] - data["y"].mean()
+    orc.set_residual(r0); hip.set_residual(r0)
+    vare, varg = _hyper(data, 0.9)
+    for it in range(1, 21):
+        orc.sweep(iteration=it, seed=8, vare=vare, var_effect=varg, pi=0.9)
+        hip.sweep(iteration=it, seed=8, vare=vare, var_effect=varg, pi=0.9)
+    _compare_state(orc, hip, atol=5e-6)
+
+
 def test_accumulate_mul_alpha_sub_xalpha(hip, small_data):
     orc, hip = _pair(hip, small_data, 64, "BayesC")
     rng = np.random.default_rng(3)
