@@ -34,11 +34,10 @@ sys.path.insert(0, ROOT)
 N_IND, P_TOTAL = 50_000, 600_000
 HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 # HBM bytes per k_block_step launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and
-# --pmc WRITE_SIZE in separate runs of this command, averaged over the launches of the last three sweeps = the
-# steady state the timed region runs in; FETCH_SIZE x2 per the guide's gfx950 correction, checked on k_xpx which
-# reads X exactly once: 58 800 454 KB x 2 = 120.4 GB): (51 683 KB x 2 + 602 KB) x 1024.
-# Valid for the default config only: n=50000, p=600000, block 512.
-TRAFFIC_BYTES_PER_LAUNCH = (51682.7 * 2 + 602.0) * 1024
+# --pmc WRITE_SIZE in separate runs of this command, averaged over the launches of the timed region's steady state;
+# FETCH_SIZE x2 per the guide's gfx950 correction, checked on k_xpx which reads X exactly once).
+# Valid for the default config only (n=50000, p=600000, adaptive blocks -> 1024 in the timed region); None = not measured.
+TRAFFIC_BYTES_PER_LAUNCH = None
 
 
 def parse():
@@ -48,7 +47,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--n", type=int, default=N_IND)
     ap.add_argument("--p", type=int, default=P_TOTAL)
-    ap.add_argument("--block-size", type=int, default=int(os.environ.get("JWAS_BLOCK_SIZE", "512")))
+    ap.add_argument("--block-size", type=int, default=int(os.environ.get("JWAS_BLOCK_SIZE", "0")),
+                    help="0 (default) = the host loop's policy (jwas.jl_amd/mcmc.py): blocks of 512 markers while many effects "
+                         "change per sweep, 1024 once fewer than 1.25 %% do; or a fixed size in {64,...,1024}")
     ap.add_argument("--seed", type=int, default=2026)
     ap.add_argument("--storage", choices=["dense", "packed2bit"], default="dense",
                     help="dense = the metric's fp32 dense genotypes (default); packed2bit = the reference's 2-bit packed "
@@ -76,22 +77,32 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # JWAS_BENCH_BACKEND=gloo + JWAS_BENCH_ONE_DEVICE=1: debug only -- exercises the N > 1 code path on a box with
+        # a single GPU (all ranks share device 0, the exchange goes through host memory)
+        backend = os.environ.get("JWAS_BENCH_BACKEND", "nccl")
+        if os.environ.get("JWAS_BENCH_ONE_DEVICE"):
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     if world != a.gpus:
         if rank == 0:
             print(f"warning: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     import jwas_jl_amd as J
     from jwas_jl_amd.dist import MarkerShard, shard_range
 
-    n, p_total, bs = a.n, a.p, a.block_size
-    lo, hi = shard_range(p_total, rank, world, align=bs)
+    from jwas_jl_amd.mcmc import pick_block_size
+    adaptive = a.block_size == 0
+    n, p_total, bs = a.n, a.p, (512 if adaptive else a.block_size)
+    lo, hi = shard_range(p_total, rank, world, align=1024 if adaptive else bs)
     p_loc = hi - lo
     eng = J.HipEngine(local_rank)
     t_setup = time.time()
     log('engine created'); (eng.alloc_packed if a.storage == 'packed2bit' else eng.alloc_dense)(n, p_loc); log('alloc done')
     eng.synth(a.seed, kind=0, center=True, marker_offset=lo)        # 0/1/2 genotypes, centred, generated on device
-    log('synth done'); eng.setup_blocks(bs, "mfma"); log('setup_blocks done')
+    log('synth done'); eng.setup_blocks(bs, "mfma")
+    if adaptive:
+        eng.add_block_size(1024, "mfma")
+    log('setup_blocks done')
     eng.init_state("BayesC", 1)
     shard = MarkerShard(eng, lo, hi, rank, world)
 
@@ -120,8 +131,8 @@ def main():
     scale_g = float(Gval) * (df_ - 2) / df_
     setup_s = time.time() - t_setup; log(f'setup done {setup_s:.1f}s')
 
-    state = {"r": y[None, :].copy(), "mu": 0.0, "vare": vare, "G": Gval, "pi": pi, "it": 0}
-    acc = {"sweep_ms": 0.0, "k_ms": 0.0, "k_n": 0.0, "k_bytes": 0.0, "events": 0.0, "ovh_ms": 0.0}
+    state = {"r": y[None, :].copy(), "mu": 0.0, "vare": vare, "G": Gval, "pi": pi, "it": 0, "bs": bs}
+    acc = {"sweep_ms": 0.0, "k_ms": 0.0, "k_n": 0.0, "k_bytes": 0.0, "events": 0.0, "ovh_ms": 0.0, "launches": 0.0, "bytes": 0.0}
 
     def step():
         s = state
@@ -134,6 +145,11 @@ def main():
         r_new, st = shard.sweep(r.astype(np.float32)[None, :], iteration=s["it"], seed=a.seed,
                                 vare=s["vare"], var_effect=s["G"], pi=s["pi"], nreps=1)
         s["r"] = r_new
+        if adaptive:       # n_events is the all-shard total after the reconcile: every rank takes the same decision
+            eng.select_block_size(pick_block_size(st["n_events"], p_total))
+        acc["launches"] += -(-p_loc // s["bs"]) + 1
+        acc["bytes"] += 4.0 * n * p_loc if a.storage == "dense" else 0.25 * n * p_loc
+        s["bs"] = eng.block_size
         nl = st["sum_delta"][0]
         # 3-5. pi, marker-effect variance, residual variance (Pi.jl:7-9, variance_components.jl:60-66,151-162)
         s["pi"] = float(rng.beta(p_total - nl + 1.0, nl + 1.0))
@@ -164,7 +180,7 @@ def main():
     elapsed = time.perf_counter() - t0
     log(f'timed region done: {elapsed:.2f}s')
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if torch.distributed.get_backend() == "nccl" else "cpu")
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -176,11 +192,10 @@ def main():
         # end of the last): sweep time / launches.  (Events around individual launches cost ~3 us each and would
         # perturb the timed region; the inter-launch gap is therefore included -- a conservative duration.
         # The rocprofv3 --kernel-trace --stats average of the same command is committed under profiles/.)
-        nblk = -(-p_loc // bs)
-        launches = (nblk + 1) * a.steps
+        launches = acc["launches"]                                 # k_block_step launches of the timed sweeps (nblocks + 1 each)
         avg_launch_us = 1e3 * acc["sweep_ms"] / launches
-        elem_bytes = 0.25 if a.storage == 'packed2bit' else 4.0
-        bytes_per_launch = elem_bytes * n * p_loc / (nblk + 1)     # algorithmic: 4 B (2 bits if packed) x n per marker, X read once
+        bytes_per_launch = acc["bytes"] / launches                 # algorithmic: 4 B (2 bits if packed) x n per marker, X read once
+        bs = state["bs"]
         achieved = bytes_per_launch / 1e9 / (avg_launch_us * 1e-6)
         out = {
             "metric": "MCMC iters/sec (full marker sweep)", "value": a.steps / elapsed, "unit": "iterations/s",
@@ -188,11 +203,11 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"single-trait BayesC, {n} individuals x {p_total} SNPs, " + ("2-bit packed genotypes (decoded to fp32 on the fly)" if a.storage == "packed2bit" else "fp32 dense genotypes") + ", pi0=0.95 estimated",
                        "storage": a.storage,
-                       "n": n, "p": p_total, "block_size": bs, "parallelism": f"marker-shard x{world}" if world > 1 else "single GPU",
+                       "n": n, "p": p_total, "block_size": bs, "block_policy": "adaptive 512/1024" if adaptive else "fixed", "parallelism": f"marker-shard x{world}" if world > 1 else "single GPU",
                        "device_sweep_ms": acc["sweep_ms"] / a.steps, "events_per_sweep": acc["events"] / a.steps,
                        "markers_in_model": float(last["sum_delta"][0]), "setup_s": setup_s},
             "roofline": {"bound": "hbm", "kernel": "k_block_step", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": TRAFFIC_BYTES_PER_LAUNCH if (bs == 512 and p_total == P_TOTAL and n == N_IND and world == 1 and a.storage == "dense") else None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": TRAFFIC_BYTES_PER_LAUNCH if (TRAFFIC_BYTES_PER_LAUNCH and adaptive and bs == 1024 and p_total == P_TOTAL and n == N_IND and world == 1 and a.storage == "dense") else None,
                          "bytes_per_launch": bytes_per_launch, "avg_launch_us": avg_launch_us, "launches_timed": launches},
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -173,6 +173,12 @@ int  jwas_hip_set_xpx(jwas_hip_ctx* ctx, const float* in_p);
 int  jwas_hip_get_gram(jwas_hip_ctx* ctx, int64_t block, float* out_bxb);        /* row-major b x b */
 int  jwas_hip_set_gram(jwas_hip_ctx* ctx, int64_t block, const float* in_bxb);
 int  jwas_hip_num_blocks(jwas_hip_ctx* ctx, int64_t* nblocks, int32_t* block_size);
+/* Several block sizes can be resident (Grams + cross-Grams each: 8*p*block_size bytes).  The random draws do not depend
+ * on the block size, so a host may switch between sweeps: large blocks amortise the per-launch cost when few markers
+ * change per sweep, smaller ones keep the serial within-block chain short when many do (the reference's block size is
+ * a free tuning knob too: fast_blocks=<number>, JWAS.jl:293-316).  get/set_gram and num_blocks act on the selected size. */
+int  jwas_hip_add_block_size(jwas_hip_ctx* ctx, int32_t block_size, int32_t gram_mode);
+int  jwas_hip_select_block_size(jwas_hip_ctx* ctx, int32_t block_size);
 
 /* ---- chain state ---------------------------------------------------------------------------- */
 /* Declare the sampler so state buffers can be sized: method + ntraits (delta is int32 classes for

@@ -33,6 +33,10 @@ struct jwas_hip_ctx {
     bool packed = false;
     int centered = 1;
 
+    // Active block configuration (a view of one entry of `sets`; several block sizes can be resident so the host
+    // can pick per sweep: big blocks when few markers change, smaller ones when many do).
+    struct BlockSet { int bs; int64_t nblocks; float *gram, *cross, *corr; double* partials; };
+    std::vector<BlockSet> sets;
     int block_size = 0;
     int64_t nblocks = 0;
     float* xpx = nullptr;
@@ -171,8 +175,11 @@ static void free_state(jwas_hip_ctx* c)
 
 static void free_blocks(jwas_hip_ctx* c)
 {
-    (void)hipFree(c->xpx); (void)hipFree(c->gram); (void)hipFree(c->cross); (void)hipFree(c->corr); (void)hipFree(c->partials);
+    (void)hipFree(c->xpx);
+    for (auto& b : c->sets) { (void)hipFree(b.gram); (void)hipFree(b.cross); (void)hipFree(b.corr); (void)hipFree(b.partials); }
+    c->sets.clear();
     c->xpx = c->gram = c->cross = c->corr = nullptr; c->partials = nullptr;
+    c->block_size = 0; c->nblocks = 0;
     (void)hipFree(c->ipartials); (void)hipFree(c->ev_all); (void)hipFree(c->ev_offs); (void)hipFree(c->idx_all); (void)hipFree(c->delta_all);
     c->ipartials = nullptr; c->ev_all = nullptr; c->ev_offs = nullptr; c->idx_all = nullptr; c->delta_all = nullptr; c->ind_traits = 0;
 }
@@ -476,35 +483,35 @@ int jwas_hip_synth_genotypes(jwas_hip_ctx* c, uint64_t seed, int32_t kind, int32
 }
 
 // ---- precompute ---------------------------------------------------------------------------------
-int jwas_hip_setup_blocks(jwas_hip_ctx* c, int32_t bs, int32_t gram_mode)
+static void select_set(jwas_hip_ctx* c, size_t i)
 {
-    NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
-    NEED(c, HAVE_STORAGE(c), JWAS_HIP_ESTATE, "no genotype matrix loaded");
-    NEED(c, bs == 64 || bs == 128 || bs == 256 || bs == 512 || bs == 1024, JWAS_HIP_EINVAL, "block_size must be 64, 128, 256, 512 or 1024 (got %d)", bs);
-    NEED(c, gram_mode == JWAS_HIP_GRAM_F64 || gram_mode == JWAS_HIP_GRAM_MFMA, JWAS_HIP_EINVAL, "unknown gram_mode %d", gram_mode);
-    HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    free_blocks(c);
-    c->block_size = bs;
-    c->nblocks = (c->p + bs - 1) / bs;
-    HIPCHK(c, hipMalloc(&c->xpx, sizeof(float) * c->p));
-    HIPCHK(c, hipMalloc(&c->gram, sizeof(float) * (size_t)c->nblocks * bs * bs));
-    HIPCHK(c, hipMalloc(&c->cross, sizeof(float) * (size_t)c->nblocks * bs * bs));
-    HIPCHK(c, hipMalloc(&c->corr, sizeof(float) * 2 * kMaxT * (size_t)bs));
-    HIPCHK(c, hipMalloc(&c->partials, sizeof(double) * 2 * (size_t)bs * c->nrg * kMaxT));   // ping-pong
-    with_cols(c, 0, [&](auto cx) {
-        hipLaunchKernelGGL((k_xpx<decltype(cx)>), dim3((unsigned)c->p), dim3(256), 0, c->stream, cx, c->xpx);
-        return 0;
-    });
-    HIPCHK(c, hipGetLastError());
+    const auto& b = c->sets[i];
+    c->block_size = b.bs; c->nblocks = b.nblocks;
+    c->gram = b.gram; c->cross = b.cross; c->corr = b.corr; c->partials = b.partials;
+    // independent-mode buffers are sized by the block configuration: rebuild them on next use
+    (void)hipFree(c->ipartials); (void)hipFree(c->ev_all); (void)hipFree(c->ev_offs); (void)hipFree(c->idx_all); (void)hipFree(c->delta_all);
+    c->ipartials = nullptr; c->ev_all = nullptr; c->ev_offs = nullptr; c->idx_all = nullptr; c->delta_all = nullptr; c->ind_traits = 0;
+}
+
+// Grams and cross-Grams of one block size (x'x must exist).
+static int build_block_set(jwas_hip_ctx* c, int32_t bs, int32_t gram_mode)
+{
+    jwas_hip_ctx::BlockSet B{};
+    B.bs = bs;
+    B.nblocks = (c->p + bs - 1) / bs;
+    HIPCHK(c, hipMalloc(&B.gram, sizeof(float) * (size_t)B.nblocks * bs * bs));
+    HIPCHK(c, hipMalloc(&B.cross, sizeof(float) * (size_t)B.nblocks * bs * bs));
+    HIPCHK(c, hipMalloc(&B.corr, sizeof(float) * 2 * kMaxT * (size_t)bs));
+    HIPCHK(c, hipMalloc(&B.partials, sizeof(double) * 2 * (size_t)bs * c->nrg * kMaxT));   // ping-pong
+    c->sets.push_back(B);
     // Gram launches are chunked over blocks so grid.y stays below 65536
     const int64_t ychunk = 32768;
-    for (int64_t y0 = 0; y0 < c->nblocks; y0 += ychunk) {
-        const int64_t ny = (c->nblocks - y0 < ychunk) ? c->nblocks - y0 : ychunk;
-        float* Gc = c->gram + y0 * (int64_t)bs * bs;
+    for (int64_t y0 = 0; y0 < B.nblocks; y0 += ychunk) {
+        const int64_t ny = (B.nblocks - y0 < ychunk) ? B.nblocks - y0 : ychunk;
+        float* Gc = B.gram + y0 * (int64_t)bs * bs;
         const int64_t pc = c->p - y0 * bs;
-        float* Cc = c->cross + y0 * (int64_t)bs * bs;
-        const int64_t nyc = (y0 + ny < c->nblocks) ? ny : ny - 1;      // cross blocks y0+1 .. (last block has none after it)
+        float* Cc = B.cross + y0 * (int64_t)bs * bs;
+        const int64_t nyc = (y0 + ny < B.nblocks) ? ny : ny - 1;      // cross blocks y0+1 .. (last block has none after it)
         with_cols(c, y0 * bs, [&](auto Xc) {
             using CX = decltype(Xc);
             if (gram_mode == JWAS_HIP_GRAM_F64) {
@@ -521,6 +528,56 @@ int jwas_hip_setup_blocks(jwas_hip_ctx* c, int32_t bs, int32_t gram_mode)
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return JWAS_HIP_OK;
+}
+
+static int check_block_args(jwas_hip_ctx* c, int32_t bs, int32_t gram_mode)
+{
+    NEED(c, HAVE_STORAGE(c), JWAS_HIP_ESTATE, "no genotype matrix loaded");
+    NEED(c, bs == 64 || bs == 128 || bs == 256 || bs == 512 || bs == 1024, JWAS_HIP_EINVAL, "block_size must be 64, 128, 256, 512 or 1024 (got %d)", bs);
+    NEED(c, gram_mode == JWAS_HIP_GRAM_F64 || gram_mode == JWAS_HIP_GRAM_MFMA, JWAS_HIP_EINVAL, "unknown gram_mode %d", gram_mode);
+    return JWAS_HIP_OK;
+}
+
+int jwas_hip_setup_blocks(jwas_hip_ctx* c, int32_t bs, int32_t gram_mode)
+{
+    NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
+    int rc = check_block_args(c, bs, gram_mode);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    free_blocks(c);
+    HIPCHK(c, hipMalloc(&c->xpx, sizeof(float) * c->p));
+    with_cols(c, 0, [&](auto cx) {
+        hipLaunchKernelGGL((k_xpx<decltype(cx)>), dim3((unsigned)c->p), dim3(256), 0, c->stream, cx, c->xpx);
+        return 0;
+    });
+    HIPCHK(c, hipGetLastError());
+    rc = build_block_set(c, bs, gram_mode);
+    if (rc) return rc;
+    select_set(c, 0);
+    return JWAS_HIP_OK;
+}
+
+int jwas_hip_add_block_size(jwas_hip_ctx* c, int32_t bs, int32_t gram_mode)
+{
+    NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
+    int rc = check_block_args(c, bs, gram_mode);
+    if (rc) return rc;
+    NEED(c, !c->sets.empty(), JWAS_HIP_ESTATE, "jwas_hip_setup_blocks has not been called");
+    for (auto& b : c->sets) NEED(c, b.bs != bs, JWAS_HIP_EINVAL, "block size %d is already resident", bs);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return build_block_set(c, bs, gram_mode);
+}
+
+int jwas_hip_select_block_size(jwas_hip_ctx* c, int32_t bs)
+{
+    NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < c->sets.size(); ++i)
+        if (c->sets[i].bs == bs) { if (c->block_size != bs) select_set(c, i); return JWAS_HIP_OK; }
+    return fail(c, JWAS_HIP_EINVAL, "block size %d is not resident (jwas_hip_setup_blocks / jwas_hip_add_block_size)", bs);
 }
 
 int jwas_hip_num_blocks(jwas_hip_ctx* c, int64_t* nb, int32_t* bs)

@@ -151,6 +151,15 @@ class HipEngine:
         self._chk(self._L.jwas_hip_setup_blocks(self._h, int(block_size), mode))
         self.block_size = int(block_size)
 
+    def add_block_size(self, block_size, gram_mode="mfma"):
+        """Make a second block size resident (see jwas_hip_add_block_size); select_block_size switches between sweeps."""
+        mode = {"f64": _lib.GRAM_F64, "mfma": _lib.GRAM_MFMA}[gram_mode]
+        self._chk(self._L.jwas_hip_add_block_size(self._h, int(block_size), mode))
+
+    def select_block_size(self, block_size):
+        self._chk(self._L.jwas_hip_select_block_size(self._h, int(block_size)))
+        self.block_size = int(block_size)
+
     @property
     def nblocks(self):
         nb, bs = C.c_int64(), C.c_int32()

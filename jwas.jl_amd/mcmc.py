@@ -96,6 +96,14 @@ def genetic2marker(Mi, pi, method, t=1):
     return float(Vg) / ((1 - float(pi)) * Mi.sum2pq)                   # :457-459
 
 
+ADAPTIVE_CHANGE_FRACTION = 0.0125        # measured crossover of block 512 vs 1024
+
+
+def pick_block_size(n_events, p, small=512, large=1024):
+    """Block size of the next sweep from the number of markers whose effect changed in the last one."""
+    return large if n_events < ADAPTIVE_CHANGE_FRACTION * p else small
+
+
 def _gibbs(A, x, b, rng, vare=None):
     """One sweep of the single-site Gibbs sampler on the MME (iterative_solver/solver.jl:143-162)."""
     for i in range(len(x)):
@@ -239,6 +247,7 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         chain_length = int(np.floor(chain_length / block_size))
         nreps = 0                                                       # = block size (BayesABC.jl:153)
         print(f"BLOCK SIZE: {block_size}")
+    adaptive = False
     if block_size is None:
         # Device block size.  Sparse priors (few markers change per sweep): big blocks amortise the per-launch cost.
         # Dense priors (every marker is in the model: Pi = 0 / BayesA / the multi-trait default of all-ones) change
@@ -254,6 +263,10 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         block_size = 128 if dense else 512
         while block_size > 64 and p <= block_size:
             block_size //= 2
+        # Sparse priors: keep a second, larger block size resident and pick per sweep from the previous sweep's number
+        # of effect changes (a chain quantity, so runs stay reproducible): 1024-marker blocks amortise the per-launch cost
+        # once fewer than ~1.3 % of the markers change per sweep (measured crossover at 50k x 600k: 8 900 changes).
+        adaptive = (not dense) and block_size == 512 and p > 4 * 1024
 
     # ---- engine (the only engine shipped is the HIP one; there is no CPU fallback)
     own_engine = engine is None
@@ -274,6 +287,8 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
     else:
         engine.load_dense(X)                   # after alignment (tools4genotypes.jl:310-321)
     engine.setup_blocks(block_size, gram_mode)
+    if adaptive:
+        engine.add_block_size(1024, gram_mode)
     engine.init_state(mt_method if t > 1 else method, t)
 
     # ---- fixed effects
@@ -370,6 +385,8 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
             kw.update(var_effect=Gval, pi=pi)
         st = engine.sweep(**kw)
         t_sweep += st["sweep_ms"]
+        if adaptive:
+            engine.select_block_size(pick_block_size(st["n_events"], p))
 
         # 3. pi (Pi.jl:7-42)
         if Mi.estimatePi:

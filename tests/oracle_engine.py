@@ -45,6 +45,15 @@ class OracleEngine:
         self._xpx = O.xpx(self.X, self.acc)
         self._bs = O.block_starts_for(self.p, self.block_size)
         self._grams = O.grams_for(self.X, self._bs, self.acc)
+        self._sets = {self.block_size: (self._bs, self._grams)}
+
+    def add_block_size(self, block_size, gram_mode="f64"):
+        bs = O.block_starts_for(self.p, int(block_size))
+        self._sets[int(block_size)] = (bs, O.grams_for(self.X, bs, self.acc))
+
+    def select_block_size(self, block_size):
+        self._bs, self._grams = self._sets[int(block_size)]
+        self.block_size = int(block_size)
 
     @property
     def nblocks(self):

@@ -389,6 +389,36 @@ def test_real_valued_imputed_genotypes_parity(hip):
     _compare_state(orc, hip, atol=5e-6)
 
 
+def test_switching_resident_block_sizes_mid_chain(hip):
+    """Two block sizes resident (jwas_hip_add_block_size); the host switches between sweeps.  The draws do not depend
+    on the block size, so this is the same chain; the oracle follows the same switches."""
+    data = make_dataset(n=400, p=2 * 512 + 100, ncausal=10, seed=91)
+    orc, hip = _pair(hip, data, 256, "BayesC")
+    orc.add_block_size(512); hip.add_block_size(512, "f64")
+    import jwas_jl_amd as J
+    with pytest.raises(J.JwasHipError, match="already resident"):
+        hip.add_block_size(512, "f64")
+    with pytest.raises(J.JwasHipError, match="not resident"):
+        hip.select_block_size(128)
+    r0 = data["y"] - data["y"].mean()
+    orc.set_residual(r0); hip.set_residual(r0)
+    vare, varg = _hyper(data, 0.9)
+    for it in range(1, 19):
+        bs = 512 if (it // 3) % 2 else 256
+        orc.select_block_size(bs); hip.select_block_size(bs)
+        assert hip.nblocks == orc.nblocks
+        so = orc.sweep(iteration=it, seed=6, vare=vare, var_effect=varg, pi=0.9)
+        sh = hip.sweep(iteration=it, seed=6, vare=vare, var_effect=varg, pi=0.9)
+        assert so["n_events"] == sh["n_events"]
+    _compare_state(orc, hip, atol=5e-6)
+    # an independent-block sweep after a switch sizes its buffers for the selected configuration
+    for e in (orc, hip):
+        e.select_block_size(256)
+    orc.sweep(iteration=19, seed=6, vare=vare, var_effect=varg, pi=0.9, independent_blocks=True)
+    hip.sweep(iteration=19, seed=6, vare=vare, var_effect=varg, pi=0.9, independent_blocks=True)
+    _compare_state(orc, hip, atol=5e-6)
+
+
 def test_accumulate_mul_alpha_sub_xalpha(hip, small_data):
     orc, hip = _pair(hip, small_data, 64, "BayesC")
     rng = np.random.default_rng(3)

@@ -253,3 +253,33 @@ def test_independent_blocks_through_runmcmc(tmp_path):
                       output_folder=str(tmp_path / "ib"), engine=OracleEngine("block"))
     assert out["_timing"]["iterations"] == 12
     assert np.corrcoef(out["EBV_y1"]["EBV"], ph["y1"])[0, 1] > 0.4
+
+
+def test_adaptive_block_size_policy(tmp_path):
+    """Sparse priors keep block sizes 512 and 1024 resident; the next sweep's size follows the last sweep's number of
+    effect changes (mcmc.pick_block_size) -- a chain quantity, so the run is reproducible."""
+    from jwas_jl_amd.mcmc import pick_block_size
+    assert pick_block_size(100, 600_000) == 1024 and pick_block_size(20_000, 600_000) == 512
+
+    class Spy(OracleEngine):
+        def __init__(self):
+            super().__init__("block")
+            self.sizes = []
+
+        def sweep(self, **kw):
+            self.sizes.append(self.block_size)
+            return super().sweep(**kw)
+
+    d = make_dataset(n=120, p=4300, ncausal=4, seed=3, center=False)
+    ids = [str(i) for i in range(120)]
+    gdf = pd.DataFrame(d["raw"]); gdf.insert(0, "ID", ids)
+    ph = pd.DataFrame({"ID": ids, "y1": d["y"]})
+    outs = []
+    for rep in range(2):
+        geno = api.get_genotypes(gdf, method="BayesC", Pi=0.99)
+        model = api.build_model("y1 = intercept + geno")
+        spy = Spy()
+        outs.append(api.runMCMC(model, ph, chain_length=12, burnin=2, seed=5, outputEBV=False,
+                                output_folder=str(tmp_path / f"ad{rep}"), engine=spy))
+        assert spy.sizes[0] == 512 and set(spy.sizes) <= {512, 1024} and 1024 in spy.sizes
+    assert np.array_equal(outs[0]["marker effects geno"]["Estimate"], outs[1]["marker effects geno"]["Estimate"])
