@@ -282,10 +282,10 @@ static int alloc_storage(jwas_hip_ctx* c, int64_t n, int64_t p, bool packed = fa
     HIPCHK(c, hipMalloc(&c->ev, sizeof(Events) * 2));
     HIPCHK(c, hipMemsetAsync(c->ev, 0, sizeof(Events) * 2, c->stream));
     HIPCHK(c, hipMalloc(&c->dparams, sizeof(DevParams)));
-    HIPCHK(c, hipMalloc(&c->counters, sizeof(unsigned long long) * 8));
+    HIPCHK(c, hipMalloc(&c->counters, sizeof(unsigned long long) * 16));
     HIPCHK(c, hipMalloc(&c->fin_out, sizeof(double) * c->nslices * (kMaxT * kMaxT + kMaxT)));
     HIPCHK(c, hipMalloc(&c->stat_out, sizeof(double) * kStatGrid * kNStat));
-    HIPCHK(c, hipHostMalloc(&c->host_buf, sizeof(double) * ((size_t)c->nslices * (kMaxT * kMaxT + kMaxT) + kStatGrid * kNStat + 16)));
+    HIPCHK(c, hipHostMalloc(&c->host_buf, sizeof(double) * ((size_t)c->nslices * (kMaxT * kMaxT + kMaxT) + kStatGrid * kNStat + 32)));
     return JWAS_HIP_OK;
 }
 
@@ -793,7 +793,7 @@ static hipError_t launch_step_cx(jwas_hip_ctx* c, const CX& cx, const UpdateArgs
     UpdateArgsT<CX> U;
     static_cast<UpdateArgs&>(U) = U0;
     U.cx = cx;
-    const StepSmem SM(c->block_size, NT, is_mt_method(METHOD) ? 0 : (METHOD == kBayesR ? 12 : 4), is_mt_method(METHOD) ? 0 : (METHOD == kBayesR ? 1 : 4));
+    const StepSmem SM(c->block_size, NT, is_mt_method(METHOD) ? 0 : (METHOD == kBayesR ? 14 : 4), is_mt_method(METHOD) ? 0 : (METHOD == kBayesR ? 1 : 4));
     static bool attr_set = false;
     if (!attr_set) {   // allow > 64 KB of dynamic LDS
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_block_step<METHOD, NT, CX>),
@@ -849,7 +849,7 @@ static hipError_t launch_indep_cx(jwas_hip_ctx* c, const CX& cx, const UpdateArg
     UpdateArgsT<CX> U;
     static_cast<UpdateArgs&>(U) = U0;
     U.cx = cx;
-    const StepSmem SM(c->block_size, NT, is_mt_method(METHOD) ? 0 : (METHOD == kBayesR ? 12 : 4), is_mt_method(METHOD) ? 0 : (METHOD == kBayesR ? 1 : 4));
+    const StepSmem SM(c->block_size, NT, is_mt_method(METHOD) ? 0 : (METHOD == kBayesR ? 14 : 4), is_mt_method(METHOD) ? 0 : (METHOD == kBayesR ? 1 : 4));
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_indep_sample<METHOD, NT>),
@@ -1009,7 +1009,7 @@ int jwas_hip_sweep(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_sweep_stats
     }
     HIPCHK(c, hipMemcpyAsync(c->dparams, &D, sizeof D, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(&c->ev[0].count, 0, sizeof(int32_t), c->stream));
-    HIPCHK(c, hipMemsetAsync(c->counters, 0, sizeof(unsigned long long) * 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->counters, 0, sizeof(unsigned long long) * 16, c->stream));
     HIPCHK(c, hipEventRecord(c->ev_start, c->stream));
 
     {   // per-sweep marker constants (draws, prior logs, lhs terms) for all p markers in parallel
@@ -1123,7 +1123,7 @@ int jwas_hip_sweep(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_sweep_stats
     unsigned long long* h_cnt = reinterpret_cast<unsigned long long*>(h_stat + (size_t)kStatGrid * kNStat);
     HIPCHK(c, hipMemcpyAsync(h_fin, c->fin_out, sizeof(double) * c->nslices * nfin, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(h_stat, c->stat_out, sizeof(double) * kStatGrid * kNStat, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(h_cnt, c->counters, sizeof(unsigned long long) * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(h_cnt, c->counters, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
 
     std::memset(S, 0, sizeof *S);
@@ -1144,8 +1144,8 @@ int jwas_hip_sweep(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_sweep_stats
     }
     S->n_events = (double)h_cnt[0];
     if (std::getenv("JWAS_HIP_DEBUG_PHASES"))
-        std::fprintf(stderr, "[jwas_hip] blocks=%lld events=%llu unstaged=%llu cycles: front=%llu cand=%llu stage=%llu serial=%llu write=%llu rounds=%llu\n",
-                     (long long)c->nblocks, h_cnt[0], h_cnt[1], h_cnt[2], h_cnt[3], h_cnt[4], h_cnt[5], h_cnt[6], h_cnt[7]);
+        std::fprintf(stderr, "[jwas_hip] blocks=%lld events=%llu unstaged=%llu cycles: front=%llu cand=%llu stage=%llu serial=%llu write=%llu rounds=%llu slow_rounds=%llu\n",
+                     (long long)c->nblocks, h_cnt[0], h_cnt[1], h_cnt[2], h_cnt[3], h_cnt[4], h_cnt[5], h_cnt[6], h_cnt[7], h_cnt[8]);
     float ms = 0.f;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev_start, c->ev_stop));
     S->sweep_ms = ms;

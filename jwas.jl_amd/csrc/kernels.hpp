@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void k_finish(CX cx, const float* r_in,
 // by k_prepare and stored struct-of-arrays in prep_d [kPrepD][p] / prep_f [kPrepF][p]; the serial
 // sampler wave only loads them.  (Within-block repetitions > 0 recompute them in place.)
 // ---------------------------------------------------------------------------------------------
-constexpr int kPrepD = 12;
+constexpr int kPrepD = 14;
 constexpr int kPrepF = 4;
 
 __device__ __forceinline__ float logf_via_double(float x) { return (float)log((double)x); }
@@ -369,13 +369,13 @@ struct AbcMarker {
 // BayesR (BayesR.jl:56-96)
 struct BayesRMarker {
     float  d, die;
-    double lpi[4], invLhs[4], cA[4], z, u;
+    double lpi[4], invLhs[4], cA[4], zs[4], u;          // zs[k] = z*sqrt(1/lhs_k): the normal draw scaled for class k (:93)
     __device__ __forceinline__ void prepare(float d_, float sigma_sq, const double* pi_j, const double* gamma,
                                             float ie, double u_, double z_)
     {
-        d = d_; u = u_; z = z_;
+        d = d_; u = u_;
         die = d_ * ie;
-        lpi[0] = log(pi_j[0]); invLhs[0] = 0.0; cA[0] = 0.0;
+        lpi[0] = log(pi_j[0]); invLhs[0] = 0.0; cA[0] = 0.0; zs[0] = 0.0;
 #pragma unroll
         for (int k = 1; k < 4; ++k) {
             const double varE = gamma[k] * (double)sigma_sq;
@@ -383,6 +383,7 @@ struct BayesRMarker {
             invLhs[k] = 1.0 / lhs;
             cA[k]  = log(invLhs[k]) - log(varE);
             lpi[k] = log(pi_j[k]);
+            zs[k]  = z_ * sqrt(invLhs[k]);
         }
     }
     __device__ __forceinline__ void store(double* pd, float* pf, int64_t p, int64_t j) const
@@ -390,19 +391,19 @@ struct BayesRMarker {
 #pragma unroll
         for (int k = 0; k < 4; ++k) pd[k * p + j] = lpi[k];
 #pragma unroll
-        for (int k = 1; k < 4; ++k) { pd[(3 + k) * p + j] = invLhs[k]; pd[(6 + k) * p + j] = cA[k]; }
-        pd[10 * p + j] = z; pd[11 * p + j] = u;
+        for (int k = 1; k < 4; ++k) { pd[(3 + k) * p + j] = invLhs[k]; pd[(6 + k) * p + j] = cA[k]; pd[(9 + k) * p + j] = zs[k]; }
+        pd[13 * p + j] = u;
         (void)pf;
     }
     __device__ __forceinline__ void load(const double* pd, const float* pf, int64_t p, int64_t j, float d_, float ie)
     {
         d = d_; die = d_ * ie;
-        invLhs[0] = 0.0; cA[0] = 0.0;
+        invLhs[0] = 0.0; cA[0] = 0.0; zs[0] = 0.0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) lpi[k] = pd[k * p + j];
 #pragma unroll
-        for (int k = 1; k < 4; ++k) { invLhs[k] = pd[(3 + k) * p + j]; cA[k] = pd[(6 + k) * p + j]; }
-        z = pd[10 * p + j]; u = pd[11 * p + j];
+        for (int k = 1; k < 4; ++k) { invLhs[k] = pd[(3 + k) * p + j]; cA[k] = pd[(6 + k) * p + j]; zs[k] = pd[(9 + k) * p + j]; }
+        u = pd[13 * p + j];
         (void)pf;
     }
     // returns class 0..3 and the candidate alpha for that class
@@ -432,8 +433,40 @@ struct BayesRMarker {
         }
         double an = 0.0;
 #pragma unroll
-        for (int k = 1; k < 4; ++k) if (cls == k) an = bh[k] + z * sqrt(invLhs[k]);   // :93
+        for (int k = 1; k < 4; ++k) if (cls == k) an = bh[k] + zs[k];                  // :93
         a_new = (float)an;
+        return cls;
+    }
+    // Same decision with single-precision exponentials: the class is the number of cumulative-probability boundaries
+    // <= u.  The approximate boundaries are within ~6e-6 of the exact ones (2 ulp of v_exp_f32, 6e-8*|lp - max| from
+    // rounding the exponent to float for |lp - max| < 88, beyond that the class weight is < 1e-38), so whenever u is
+    // further than kFastMargin from all of them the double-precision evaluation above would pick the same class.
+    // `sure` = false otherwise: the caller then re-evaluates with evaluate() (about 1 % of the rounds).
+    // The effect of the chosen class is computed in double exactly as in evaluate().
+    static constexpr float kFastMargin = 3e-5f;
+    __device__ __forceinline__ int evaluate_fast(float rhs_b, float a_old, float ie, float& a_new, bool& sure) const
+    {
+        const float rhs = (rhs_b + d * a_old) * ie;                         // :60
+        double lp[4], bh[4];
+        lp[0] = lpi[0]; bh[0] = 0.0;
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {
+            bh[k] = invLhs[k] * (double)rhs;
+            lp[k] = 0.5 * (cA[k] + bh[k] * (double)rhs) + lpi[k];           // :71
+        }
+        double mx = lp[0];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) if (lp[k] > mx) mx = lp[k];
+        float e[4], se = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { e[k] = __expf((float)(lp[k] - mx)); se += e[k]; }
+        const float inv = __fdividef(1.0f, se);
+        const float uf = (float)u;
+        const float c0 = e[0] * inv, c1 = c0 + e[1] * inv, c2 = c1 + e[2] * inv;
+        const int cls = (c0 <= uf ? 1 : 0) + (c1 <= uf ? 1 : 0) + (c2 <= uf ? 1 : 0);
+        sure = fabsf(uf - c0) > kFastMargin && fabsf(uf - c1) > kFastMargin && fabsf(uf - c2) > kFastMargin;
+        const double bc = cls == 1 ? bh[1] + zs[1] : (cls == 2 ? bh[2] + zs[2] : bh[3] + zs[3]);
+        a_new = cls == 0 ? 0.f : (float)bc;                                 // :93
         return cls;
     }
 };

@@ -341,20 +341,22 @@ __device__ __forceinline__ int stage_rows(char* smem, const StepSmem& SM, const 
         __syncthreads();
     }
     const int ncand = base < SM.max_cand ? base : SM.max_cand;
-    // (row, 64-column chunk) tasks, 8 independent loads in flight per wave
+    // (row, 64-column chunk) tasks, kSL independent loads in flight per wave (the fetch is latency-bound: with many
+    // candidates -- BayesR, early chain -- depth is what shortens it)
+    constexpr int kSL = 16;
     const int nchunk = B / 64, ntask = ncand * nchunk;
-    for (int t0 = wave * 8; t0 < ntask; t0 += (kStepThreads / 64) * 8) {
-        float v[8];
-        int dst[8];
+    for (int t0 = wave * kSL; t0 < ntask; t0 += (kStepThreads / 64) * kSL) {
+        float v[kSL];
+        int dst[kSL];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < kSL; ++u) {
             const int task = (t0 + u < ntask) ? t0 + u : ntask - 1;
             const int row = task / nchunk, c = (task - row * nchunk) * 64 + lane;
             v[u] = A.gram[(int64_t)cand_list[row] * b + (c < b ? c : 0)];
             dst[u] = row * B + c;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) if (t0 + u < ntask) rows[dst[u]] = v[u];
+        for (int u = 0; u < kSL; ++u) if (t0 + u < ntask) rows[dst[u]] = v[u];
     }
     __syncthreads();
     return ncand;
@@ -395,7 +397,7 @@ __device__ __forceinline__ void apply_gram_row(char* smem, const StepSmem& SM, c
 template <int METHOD>
 __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A)
 {
-    constexpr int ND = (METHOD == kBayesR) ? 12 : 4, NF = (METHOD == kBayesR) ? 1 : 4;
+    constexpr int ND = (METHOD == kBayesR) ? 14 : 4, NF = (METHOD == kBayesR) ? 1 : 4;
     const StepSmem SM(A.bsz, 1, ND, NF);
     const int B = SM.B;
     const DevParams* P = A.P;
@@ -469,7 +471,7 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
     int* wcnt_s = reinterpret_cast<int*>(smem + SM.wcnt_off);
     if (wave == 0) {
     const long long tk3 = clock64();
-    int nrounds = 0;
+    int nrounds = 0, nslow = 0;
 
     // wave 0: lane l owns marker c = 64*s + l of sub-block s
     float* delta_f = reinterpret_cast<float*>(A.delta);
@@ -557,10 +559,19 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
                 float a_new = 0.f, gHat = 0.f;
                 int cls = 0;
                 const bool live = valid && ((pending >> lane) & 1ull);
+                if constexpr (METHOD == kBayesR) {
+                    // class decision with fp32 exponentials; the double-precision evaluation only when some live lane's
+                    // uniform falls within the error margin of a class boundary (wave-uniform branch, ~1 % of rounds)
+                    bool sure = true;
+                    if (live) cls = bm.evaluate_fast(rhs, a_cur, ie, a_new, sure);
+                    if (__any(live && !sure)) {
+                        if (live) cls = bm.evaluate(rhs, a_cur, ie, a_new);
+                        if (lane == 0) ++nslow;
+                    }
+                    if (live) is_event = (cls != 0) || (a_cur != 0.f);
+                }
                 if (live) {
                     if constexpr (METHOD == kBayesR) {
-                        cls = bm.evaluate(rhs, a_cur, ie, a_new);
-                        is_event = (cls != 0) || (a_cur != 0.f);
                     } else {
                         incl = am.evaluate(rhs, a_cur, ie, gHat);
                         is_event = incl || (a_cur != 0.f);
@@ -656,6 +667,7 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
         atomicAdd(&A.counters[5], (unsigned long long)(tk4 - tk3));
         atomicAdd(&A.counters[6], (unsigned long long)(tk5 - tk4));
         atomicAdd(&A.counters[7], (unsigned long long)nrounds);
+        if (nslow) atomicAdd(&A.counters[8], (unsigned long long)nslow);      // BayesR: rounds that needed the double-precision evaluation
     }
     }   // wave 0
     __syncthreads();
