@@ -164,6 +164,13 @@ int64_t jwas_hip_estimate_bytes_storage(int64_t n, int64_t p, int32_t ntraits, i
  * independently on different GPUs. */
 int  jwas_hip_synth_genotypes(jwas_hip_ctx* ctx, uint64_t seed, int32_t kind, int32_t center, int64_t marker_offset);
 
+/* Residual weights R^-1 (n floats; NULL = unit weights): mme.invweights = 1 ./ df.weights (build_MME.jl:305-310).
+ * With non-unit weights x'x becomes x'R^-1 x (getXpRinvX, tools4genotypes.jl:28-31), the Grams X_b'R^-1 X_b (:263-266),
+ * the block RHS X_b'R^-1 r (block_rhs!, :59-78) and the residual statistics r'R^-1 r / 1'R^-1 r
+ * (variance_components.jl:82-98); the residual update itself uses the plain column (BayesABC.jl:48).
+ * Call after loading genotypes and BEFORE jwas_hip_setup_blocks (resident block configurations are dropped). */
+int  jwas_hip_set_weights(jwas_hip_ctx* ctx, const float* rinv_n);
+
 /* ---- precompute: x'x and block Grams ----------------------------------------------------------- */
 /* block_size in {64,128,256,512,1024}; markers are processed in consecutive blocks of this size. */
 int  jwas_hip_setup_blocks(jwas_hip_ctx* ctx, int32_t block_size, int32_t gram_mode);

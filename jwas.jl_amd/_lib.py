@@ -29,6 +29,7 @@ SYMBOLS = [
     "jwas_hip_accumulate", "jwas_hip_get_posterior",
     "jwas_hip_load_jgb2", "jwas_hip_load_packed2bit", "jwas_hip_alloc_packed2bit", "jwas_hip_storage_info",
     "jwas_hip_set_xpx", "jwas_hip_estimate_bytes_storage", "jwas_hip_add_block_size", "jwas_hip_select_block_size",
+    "jwas_hip_set_weights",
 ]
 STORAGE_DENSE_F32, STORAGE_PACKED2BIT = 0, 1
 
@@ -124,6 +125,7 @@ def load():
     L.jwas_hip_alloc_packed2bit.argtypes = [vp, i64, i64, i32]
     L.jwas_hip_storage_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
     L.jwas_hip_set_xpx.argtypes = [vp, vp]
+    L.jwas_hip_set_weights.argtypes = [vp, vp]
     L.jwas_hip_add_block_size.argtypes = [vp, i32, i32]
     L.jwas_hip_select_block_size.argtypes = [vp, i32]
     L.jwas_hip_estimate_bytes_storage.argtypes = [i64, i64, i32, i32, i32]

@@ -281,7 +281,7 @@ def runMCMC(model, df, *, heterogeneous_residuals=False, chain_length=100, start
     `engine` injects a sweep engine (tests); the default and only shipped engine is HipEngine."""
     if independent_blocks and fast_blocks is False:
         raise ValueError("independent_blocks=true requires fast_blocks != false.")             # :242-244
-    for flag, name in ((heterogeneous_residuals, "heterogeneous_residuals"), (single_step_analysis, "single_step_analysis"),
+    for flag, name in ((single_step_analysis, "single_step_analysis"),
                        (causal_structure, "causal_structure"), (RRM, "RRM"), (double_precision, "double_precision"),
                        (update_priors_frequency, "update_priors_frequency"),
                        (prediction_equation, "prediction_equation")):
@@ -305,7 +305,8 @@ def runMCMC(model, df, *, heterogeneous_residuals=False, chain_length=100, start
     return run_chain(model, df, chain_length=int(chain_length), burnin=int(burnin),
                      output_samples_frequency=int(output_samples_frequency), seed=seed,
                      starting_value=starting_value, fast_blocks=fast_blocks,
-                     independent_blocks=bool(independent_blocks), outputEBV=outputEBV,
+                     independent_blocks=bool(independent_blocks), heterogeneous_residuals=bool(heterogeneous_residuals),
+                     outputEBV=outputEBV,
                      output_folder=output_folder, printout_frequency=printout_frequency,
                      memory_guard=memory_guard, memory_guard_ratio=memory_guard_ratio,
                      missing_phenotypes=missing_phenotypes, device=device, block_size=block_size,

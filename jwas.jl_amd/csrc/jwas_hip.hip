@@ -32,6 +32,8 @@ struct jwas_hip_ctx {
     float* qmean = nullptr;
     bool packed = false;
     int centered = 1;
+    float* w = nullptr;                 // [ld] residual weights R^-1 (ones unless jwas_hip_set_weights; pad rows 0)
+    bool weighted = false;
 
     // Active block configuration (a view of one entry of `sets`; several block sizes can be resident so the host
     // can pick per sweep: big blocks when few markers change, smaller ones when many do).
@@ -129,8 +131,8 @@ static int inv_small(const float* A, int t, float* Ainv)
 template <class F>
 static auto with_cols(jwas_hip_ctx* c, int64_t j_off, F&& f)
 {
-    if (c->packed) return f(PackedCols{c->Q + j_off * (c->ld >> 2), c->ld, c->qmean + j_off, c->n, c->centered});
-    return f(DenseCols{c->X + j_off * c->ld, c->ld});
+    if (c->packed) return f(PackedCols{c->Q + j_off * (c->ld >> 2), c->ld, c->qmean + j_off, c->n, c->centered, c->w, (int32_t)c->weighted});
+    return f(DenseCols{c->X + j_off * c->ld, c->ld, c->w, (int32_t)c->weighted});
 }
 #define HAVE_STORAGE(c) ((c)->X != nullptr || (c)->Q != nullptr)
 
@@ -186,8 +188,8 @@ static void free_blocks(jwas_hip_ctx* c)
 
 static void free_storage(jwas_hip_ctx* c)
 {
-    (void)hipFree(c->X); (void)hipFree(c->r); (void)hipFree(c->Q); (void)hipFree(c->qmean);
-    c->X = c->r = nullptr; c->Q = nullptr; c->qmean = nullptr; c->packed = false;
+    (void)hipFree(c->X); (void)hipFree(c->r); (void)hipFree(c->Q); (void)hipFree(c->qmean); (void)hipFree(c->w);
+    c->X = c->r = nullptr; c->Q = nullptr; c->qmean = nullptr; c->packed = false; c->w = nullptr; c->weighted = false;
     (void)hipFree(c->ev); (void)hipFree(c->dparams); (void)hipFree(c->counters); (void)hipFree(c->fin_out); (void)hipFree(c->stat_out);
     c->ev = nullptr; c->dparams = nullptr; c->counters = nullptr; c->fin_out = c->stat_out = nullptr;
     if (c->host_buf) (void)hipHostFree(c->host_buf);
@@ -277,6 +279,13 @@ static int alloc_storage(jwas_hip_ctx* c, int64_t n, int64_t p, bool packed = fa
         HIPCHK(c, hipMalloc(&c->Q, need));
         HIPCHK(c, hipMalloc(&c->qmean, sizeof(float) * p));
     } else HIPCHK(c, hipMalloc(&c->X, need));
+    {   // unit residual weights by default
+        std::vector<float> ones((size_t)c->ld, 0.f);
+        std::fill(ones.begin(), ones.begin() + n, 1.f);
+        HIPCHK(c, hipMalloc(&c->w, sizeof(float) * c->ld));
+        HIPCHK(c, hipMemcpy(c->w, ones.data(), sizeof(float) * c->ld, hipMemcpyHostToDevice));
+        c->weighted = false;
+    }
     HIPCHK(c, hipMalloc(&c->r, sizeof(float) * 2 * kMaxT * c->ld));
     HIPCHK(c, hipMemsetAsync(c->r, 0, sizeof(float) * 2 * kMaxT * c->ld, c->stream));
     HIPCHK(c, hipMalloc(&c->ev, sizeof(Events) * 2));
@@ -407,6 +416,26 @@ int jwas_hip_load_jgb2(jwas_hip_ctx* c, const char* path)
     return JWAS_HIP_OK;
 }
 
+int jwas_hip_set_weights(jwas_hip_ctx* c, const float* rinv)
+{
+    NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
+    NEED(c, HAVE_STORAGE(c), JWAS_HIP_ESTATE, "no genotype matrix loaded");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<float> wv((size_t)c->ld, 0.f);
+    bool unit = true;
+    for (int64_t i = 0; i < c->n; ++i) {
+        const float v = rinv ? rinv[i] : 1.f;
+        NEED(c, std::isfinite(v) && v > 0.f, JWAS_HIP_EINVAL, "residual weights must be positive and finite (row %lld: %g)", (long long)i, (double)v);
+        wv[(size_t)i] = v;
+        unit = unit && (v == 1.f);                              // is_unit_weights (tools4genotypes.jl:43-51)
+    }
+    HIPCHK(c, hipMemcpy(c->w, wv.data(), sizeof(float) * c->ld, hipMemcpyHostToDevice));
+    c->weighted = !unit;
+    free_blocks(c);                                             // x'R^-1 x and the Grams depend on the weights
+    return JWAS_HIP_OK;
+}
+
 int jwas_hip_storage_info(jwas_hip_ctx* c, int32_t* kind, int64_t* n, int64_t* p, int64_t* bytes)
 {
     NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
@@ -452,7 +481,7 @@ int jwas_hip_get_columns(jwas_hip_ctx* c, int64_t j0, int64_t count, float* out)
     for (int64_t k0 = 0; e == hipSuccess && k0 < count; k0 += chunk) {
         const int64_t m = std::min(chunk, count - k0);
         hipLaunchKernelGGL((k_get_columns<PackedCols>), dim3((unsigned)m), dim3(256), 0, c->stream,
-                           PackedCols{c->Q, c->ld, c->qmean, c->n, c->centered}, j0 + k0, c->n, tmp);
+                           PackedCols{c->Q, c->ld, c->qmean, c->n, c->centered, c->w, (int32_t)c->weighted}, j0 + k0, c->n, tmp);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(out + k0 * c->n, tmp, sizeof(float) * (size_t)c->n * m, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);

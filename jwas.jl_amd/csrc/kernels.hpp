@@ -71,6 +71,7 @@ struct DevParams {
 // ---------------------------------------------------------------------------------------------
 struct DenseCols {
     const float* X; int64_t ld;
+    const float* w; int32_t weighted;      // residual weights R^-1 (ld floats, pad rows 0; all ones when unweighted)
     // streaming interface of the update role: raw load now, decode when consumed; kDepth = register batches kept
     // in flight per wave (dense: one 8 KB batch per wave already saturates HBM, see update_role)
     typedef float4 Raw;
@@ -99,6 +100,7 @@ struct DenseCols {
 struct PackedCols {
     const uint8_t* Q; int64_t ld;            // ld = padded row count; byte stride of a marker = ld / 4
     const float* mean; int64_t n; int32_t centered;
+    const float* w; int32_t weighted;        // residual weights R^-1 (as DenseCols)
     __device__ __forceinline__ float dec(unsigned code, float mu) const
     {
         const float v = (code == 3u) ? mu : (float)code;           // streaming_genotypes.jl:994
@@ -295,12 +297,14 @@ __global__ __launch_bounds__(256) void k_finish(CX cx, const float* r_in,
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t) r_out[t * ld + row] = rv[t];
+    // r_a' R^-1 r_c and 1' R^-1 r_a (sample_variance with invweights, variance_components.jl:82-98; weights = 1: r'r, sum r)
+    const double wr = (double)cx.w[row];
     double v[NT * NT + NT];
 #pragma unroll
     for (int a = 0; a < NT; ++a) {
 #pragma unroll
-        for (int c = 0; c < NT; ++c) v[a * NT + c] = (double)rv[a] * (double)rv[c];
-        v[NT * NT + a] = (double)rv[a];
+        for (int c = 0; c < NT; ++c) v[a * NT + c] = ((double)rv[a] * (double)rv[c]) * wr;
+        v[NT * NT + a] = (double)rv[a] * wr;
     }
     block_sum<NT * NT + NT>(v, red, 4);
     if (tid == 0)
@@ -592,10 +596,11 @@ __global__ __launch_bounds__(256) void k_xpx(CX cx, float* __restrict__ xpx)
     double v[1] = {0.0};
     for (int64_t i = (int64_t)threadIdx.x * 4; i < ld; i += 1024) {
         const float4 q = cx.load4(blockIdx.x, i);
-        v[0] = fma((double)q.x, (double)q.x, v[0]);
-        v[0] = fma((double)q.y, (double)q.y, v[0]);
-        v[0] = fma((double)q.z, (double)q.z, v[0]);
-        v[0] = fma((double)q.w, (double)q.w, v[0]);
+        const float4 wv = *reinterpret_cast<const float4*>(cx.w + i);          // x'R^-1 x (getXpRinvX, tools4genotypes.jl:28-31)
+        v[0] = fma((double)q.x, (double)(q.x * wv.x), v[0]);
+        v[0] = fma((double)q.y, (double)(q.y * wv.y), v[0]);
+        v[0] = fma((double)q.z, (double)(q.z * wv.z), v[0]);
+        v[0] = fma((double)q.w, (double)(q.w * wv.w), v[0]);
     }
     block_sum<1>(v, red, 4);
     if (threadIdx.x == 0) xpx[blockIdx.x] = (float)v[0];
@@ -620,10 +625,11 @@ __global__ __launch_bounds__(256) void k_gram_f64(CX cx, int64_t p, int bsize,
         for (int64_t i = (int64_t)lane * 4; i < ld; i += 256) {
             const float4 qa = cx.load4(j0 + a, i);
             const float4 qc = cx.load4(j0 + c, i);
-            s = fma((double)qa.x, (double)qc.x, s);
-            s = fma((double)qa.y, (double)qc.y, s);
-            s = fma((double)qa.z, (double)qc.z, s);
-            s = fma((double)qa.w, (double)qc.w, s);
+            const float4 wv = *reinterpret_cast<const float4*>(cx.w + i);      // X_b' R^-1 X_b (tools4genotypes.jl:263-266)
+            s = fma((double)qa.x, (double)(qc.x * wv.x), s);
+            s = fma((double)qa.y, (double)(qc.y * wv.y), s);
+            s = fma((double)qa.z, (double)(qc.z * wv.z), s);
+            s = fma((double)qa.w, (double)(qc.w * wv.w), s);
         }
         s = wave_sum(s);
         if (lane == 0) { G[(int64_t)a * b + c] = (float)s; G[(int64_t)c * b + a] = (float)s; }
@@ -664,7 +670,8 @@ __global__ __launch_bounds__(256) void k_gram_mfma(CX cx, int64_t p, int bsize,
     if (ti * 64 >= bA || tj * 64 >= b) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;              // wave's 32x32 sub-tile
-    const bool diag = !cross && (ti == tj);
+    const bool same = !cross && (ti == tj);
+    const bool diag = same && !cx.weighted;           // unweighted diagonal tile: B operand = A operand
     float* G = gram + blk * (int64_t)bsize * bsize;
 
     // staging: thread -> (marker m = tid/8 [+32], float4 q = tid%8)
@@ -697,6 +704,11 @@ __global__ __launch_bounds__(256) void k_gram_mfma(CX cx, int64_t p, int bsize,
         if (ma1 >= bA) va1 = zero4;
         if (mb0 >= b) vb0 = zero4;
         if (mb1 >= b) vb1 = zero4;
+        if (!diag) {                                           // the B operand carries R^-1
+            const float4 wv = *reinterpret_cast<const float4*>(cx.w + k0 + sq * 4);
+            vb0.x *= wv.x; vb0.y *= wv.y; vb0.z *= wv.z; vb0.w *= wv.w;
+            vb1.x *= wv.x; vb1.y *= wv.y; vb1.z *= wv.z; vb1.w *= wv.w;
+        }
         __syncthreads();      // previous tile fully consumed
         *reinterpret_cast<float4*>(&As[sm * kGramLd + sq * 4]) = va0;
         *reinterpret_cast<float4*>(&As[(sm + 32) * kGramLd + sq * 4]) = va1;
@@ -734,7 +746,7 @@ __global__ __launch_bounds__(256) void k_gram_mfma(CX cx, int64_t p, int bsize,
         if (ga < bA && gc < b) {
             const float v = (float)accd[i];
             G[(int64_t)ga * b + gc] = v;
-            if (!diag && !cross) G[(int64_t)gc * b + ga] = v;
+            if (!same && !cross) G[(int64_t)gc * b + ga] = v;
         }
     }
 }

@@ -126,11 +126,14 @@ __device__ __forceinline__ void update_role(char* smem, int rg, int g,
 #pragma unroll
         for (int t = 0; t < NT; ++t) *reinterpret_cast<float4*>(r_out + t * ld + row) = rv[t];
     if (ncols == 0) return;
-    const float keep = active ? 1.f : 0.f;
+    // the RHS is X_b' R^-1 r (block_rhs!, tools4genotypes.jl:59-78): the weights go onto r once per launch (weights = 1
+    // when unweighted: exact), the streaming loop is untouched
+    float4 wv = *reinterpret_cast<const float4*>(cx.w + row);
+    if (!active) wv = float4{0.f, 0.f, 0.f, 0.f};
     double rd[NT][4];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        rd[t][0] = rv[t].x * keep; rd[t][1] = rv[t].y * keep; rd[t][2] = rv[t].z * keep; rd[t][3] = rv[t].w * keep;
+        rd[t][0] = rv[t].x * wv.x; rd[t][1] = rv[t].y * wv.y; rd[t][2] = rv[t].z * wv.z; rd[t][3] = rv[t].w * wv.w;
     }
 
     // (3) partial block RHS.  (kColChunk / kU batches per chunk is a multiple of D, so ring slot = batch % D.)
@@ -1121,10 +1124,11 @@ __global__ __launch_bounds__(256) void k_cross_f64(CX cx, int64_t p, int bsize,
         for (int64_t i = (int64_t)lane * 4; i < ld; i += 256) {
             const float4 qa = cx.load4(jp + a, i);
             const float4 qc = cx.load4(j0 + c, i);
-            s = fma((double)qa.x, (double)qc.x, s);
-            s = fma((double)qa.y, (double)qc.y, s);
-            s = fma((double)qa.z, (double)qc.z, s);
-            s = fma((double)qa.w, (double)qc.w, s);
+            const float4 wv = *reinterpret_cast<const float4*>(cx.w + i);
+            s = fma((double)qa.x, (double)(qc.x * wv.x), s);
+            s = fma((double)qa.y, (double)(qc.y * wv.y), s);
+            s = fma((double)qa.z, (double)(qc.z * wv.z), s);
+            s = fma((double)qa.w, (double)(qc.w * wv.w), s);
         }
         s = wave_sum(s);
         if (lane == 0) C[(int64_t)a * b + c] = (float)s;

@@ -132,6 +132,17 @@ class HipEngine:
             raise ValueError(f"x'x must have length {self.p}")
         self._chk(self._L.jwas_hip_set_xpx(self._h, _ptr(x)))
 
+    def set_weights(self, rinv):
+        """Residual weights R^-1 = 1 ./ weights (build_MME.jl:305-310); None = unit.  Call before setup_blocks."""
+        if rinv is None:
+            self._chk(self._L.jwas_hip_set_weights(self._h, None))
+        else:
+            w = np.ascontiguousarray(rinv, dtype=np.float32)
+            if w.shape != (self.n,):
+                raise ValueError(f"one weight per individual is required ({self.n}), got {w.shape}")
+            self._chk(self._L.jwas_hip_set_weights(self._h, _ptr(w)))
+        self.block_size = 0
+
     def synth(self, seed, kind=0, center=True, marker_offset=0):
         self._chk(self._L.jwas_hip_synth_genotypes(self._h, int(seed), int(kind), int(bool(center)), int(marker_offset)))
 

@@ -114,7 +114,7 @@ def _gibbs(A, x, b, rng, vare=None):
 
 
 def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed, starting_value,
-              fast_blocks, independent_blocks=False, outputEBV, output_folder, printout_frequency, memory_guard, memory_guard_ratio,
+              fast_blocks, independent_blocks=False, heterogeneous_residuals=False, outputEBV, output_folder, printout_frequency, memory_guard, memory_guard_ratio,
               missing_phenotypes, device, block_size, gram_mode, engine, printout_model_info,
               output_samples_for_all_parameters):
     import pandas as pd
@@ -169,6 +169,14 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
     with open(os.path.join(output_folder, "IDs_for_individuals_with_genotypes.txt"), "w") as fh:
         fh.write("\n".join(Mi.obsID) + "\n")
     Y = np.stack([ph[tr].to_numpy(dtype=np.float32) for tr in model.lhsVec])       # t x n
+    invw = None
+    if heterogeneous_residuals:                                           # build_MME.jl:305-310
+        if "weights" not in ph.columns:
+            raise ValueError("heterogeneous_residuals=true requires a column named weights in the phenotype data.")
+        invw = (1.0 / ph["weights"].to_numpy(dtype=np.float64)).astype(np.float32)
+        if not np.all(np.isfinite(invw) & (invw > 0)):
+            raise ValueError("weights must be positive and finite.")
+    w64 = np.ones(len(ph)) if invw is None else invw.astype(np.float64)
 
     # ---- default priors (input_data_validation.jl:296-350, tools4genotypes.jl:353-478, build_MME.jl:128-141)
     phenovar = np.array([np.var(Y[k].astype(np.float64), ddof=1) for k in range(t)])
@@ -286,6 +294,8 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         engine.load_jgb2(Mi.stream_backend["prefix"])          # payload stays 2-bit packed in HBM
     else:
         engine.load_dense(X)                   # after alignment (tools4genotypes.jl:310-321)
+    if invw is not None:
+        engine.set_weights(invw)               # x'R^-1 x, X_b'R^-1 X_b, X_b'R^-1 r on the device (GibbsMats with Rinv)
     engine.setup_blocks(block_size, gram_mode)
     if adaptive:
         engine.add_block_size(1024, gram_mode)
@@ -315,9 +325,9 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
     if t == 1 and method in ("BayesC", "BayesB") and np.ndim(pi) == 0:
         pi = float(pi)
     if t > 1:
-        lhs_blocks = [[Xf[k].T @ Xf[l] for l in range(t)] for k in range(t)]
+        lhs_blocks = [[Xf[k].T @ (w64[:, None] * Xf[l]) for l in range(t)] for k in range(t)]    # X'RiX, Ri = kron(R^-1, diag(w))
     else:
-        lhs = Xf[0].T @ Xf[0]
+        lhs = Xf[0].T @ (w64[:, None] * Xf[0])                          # X'R^-1 X (build_MME.jl:339)
 
     # ---- accumulators and sample files (output.jl:320-437)
     run_sol, run_vare = _Running(sol), _Running(vare)
@@ -353,7 +363,7 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
             if t == 1:
                 r = engine.get_residual(0).astype(np.float64)
                 r += Xf[0] @ sol
-                rhs = Xf[0].T @ r
+                rhs = Xf[0].T @ (w64 * r)                               # MCMC_BayesianAlphabet.jl:211
                 _gibbs(lhs, sol, rhs, rng, float(vare))
                 r -= Xf[0] @ sol
                 engine.set_residual(r.astype(np.float32), 0)
@@ -361,7 +371,7 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
                 Rinv = np.linalg.inv(np.asarray(vare, dtype=np.float64))
                 rr = [engine.get_residual(k).astype(np.float64) + Xf[k] @ sol[off[k]:off[k + 1]] for k in range(t)]
                 A = np.block([[Rinv[k, l] * lhs_blocks[k][l] for l in range(t)] for k in range(t)])
-                b = np.concatenate([Xf[k].T @ sum(Rinv[k, l] * rr[l] for l in range(t)) for k in range(t)])
+                b = np.concatenate([Xf[k].T @ (w64 * sum(Rinv[k, l] * rr[l] for l in range(t))) for k in range(t)])
                 _gibbs(A, sol, b, rng, None)
                 for k in range(t):
                     engine.set_residual((rr[k] - Xf[k] @ sol[off[k]:off[k + 1]]).astype(np.float32), k)

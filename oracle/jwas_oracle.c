@@ -64,8 +64,20 @@ double orc_normal(uint64_t seed, uint32_t marker, uint32_t iter, uint32_t rep, u
 /* ------------------------------------------------------------------------------------------ */
 /* inner products                                                                             */
 /* ------------------------------------------------------------------------------------------ */
+/* Residual weights R^-1 (mme.invweights).  Every inner product of the path is a' R^-1 b with the weight carried by
+ * the RIGHT operand, b_i -> fl32(w_i * b_i):  x'R^-1 r (BayesABC.jl:76 with xRinvArray, block_rhs! tools4genotypes.jl:
+ * 59-78), x'R^-1 x (getXpRinvX, :28-31), X_b'R^-1 X_b (:263-266) and the lookahead cross-Grams.  NULL = unit weights.
+ * The pointer is borrowed (test infrastructure: one oracle context per process). */
+static const float* g_rinv = NULL;
+void orc_set_weights(const float* rinv) { g_rinv = rinv; }
+
 static float dot_acc(const float* a, const float* b, int64_t n, int acc)
 {
+    if (g_rinv) {
+        double s = 0.0;
+        for (int64_t i = 0; i < n; ++i) s += (double)a[i] * (double)(b[i] * g_rinv[i]);
+        return (float)s;
+    }
     if (acc == ORC_ACC_F64) {
         double s = 0.0;
         for (int64_t i = 0; i < n; ++i) s += (double)a[i] * (double)b[i];   /* exact products */

@@ -183,6 +183,9 @@ int orc_mt_indep_sweep(int kind, const float* X, int64_t n, int64_t p, int64_t l
                        const float* vare, const float* var_effect, const double* log_prior, int prior_is_matrix,
                        int nreps, uint64_t seed, uint32_t iter, uint32_t marker0, int acc);
 
+/* ---- residual weights R^-1 (n floats, borrowed; NULL = unit): all inner products become a'R^-1 b ------------ */
+void orc_set_weights(const float* rinv);
+
 /* ---- running posterior means (output.jl:568-577) ------------------------------------------ */
 /* mean += (x-mean)/k ; mean2 += (x^2-mean2)/k ; freq += (ind-freq)/k, ind = delta (BayesC) or
  * delta>1 (BayesR, delta_is_class != 0). */

@@ -262,6 +262,20 @@ def accumulate(alpha, delta, k, mean_alpha, mean_alpha2, mean_delta):
                          C.c_double(k), _p(mean_alpha, _f32p), _p(mean_alpha2, _f32p), _p(mean_delta, _f32p))
 
 
+_weights_keepalive = None
+
+
+def set_weights(rinv):
+    """Residual weights R^-1 for every inner product of the oracle (None = unit).  The array is kept alive here."""
+    global _weights_keepalive
+    if rinv is None:
+        _weights_keepalive = None
+        lib().orc_set_weights(None)
+        return
+    _weights_keepalive = np.ascontiguousarray(rinv, dtype=np.float32)
+    lib().orc_set_weights(_p(_weights_keepalive, _f32p))
+
+
 def decode_marker_2bit(payload, n, j, mean, centered=True):
     pl = np.ascontiguousarray(payload, dtype=np.uint8)
     out = np.zeros(n, dtype=np.float32)

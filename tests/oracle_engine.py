@@ -35,6 +35,16 @@ class OracleEngine:
         self.X = X
         self.n, self.p = X.shape
 
+    def set_weights(self, rinv):
+        """Residual weights R^-1 (jwas_hip_set_weights); like the device, drops the block configurations."""
+        self._rinv = None if rinv is None else np.ascontiguousarray(rinv, dtype=np.float32)
+        if self._rinv is not None and np.all(self._rinv == 1):
+            self._rinv = None
+        self.block_size = 0
+
+    def _w(self):
+        O.set_weights(getattr(self, "_rinv", None))
+
     def load_jgb2(self, path):
         """CPU stand-in for jwas_hip_load_jgb2: decode the packed backend (decode_marker!) and keep it dense."""
         from jwas_jl_amd import streaming as S
@@ -42,14 +52,18 @@ class OracleEngine:
 
     def setup_blocks(self, block_size=256, gram_mode="f64"):
         self.block_size = int(block_size)
+        self._w()
         self._xpx = O.xpx(self.X, self.acc)
         self._bs = O.block_starts_for(self.p, self.block_size)
         self._grams = O.grams_for(self.X, self._bs, self.acc)
         self._sets = {self.block_size: (self._bs, self._grams)}
+        O.set_weights(None)
 
     def add_block_size(self, block_size, gram_mode="f64"):
+        self._w()
         bs = O.block_starts_for(self.p, int(block_size))
         self._sets[int(block_size)] = (bs, O.grams_for(self.X, bs, self.acc))
+        O.set_weights(None)
 
     def select_block_size(self, block_size):
         self._bs, self._grams = self._sets[int(block_size)]
@@ -116,6 +130,16 @@ class OracleEngine:
         if independent_blocks and not blk:
             raise ValueError("independent blocks need a block form")
         a_before = self.alpha.copy()
+        self._w()
+        try:
+            self._sweep_inner(t, blk, iteration, seed, vare, var_effect, pi, pi_classes, gamma, log_prior_states,
+                              var_effect_vec, pi_vec, pi_matrix, marker_offset)
+        finally:
+            O.set_weights(None)
+        return self._stats(a_before, gamma)
+
+    def _sweep_inner(self, t, blk, iteration, seed, vare, var_effect, pi, pi_classes, gamma, log_prior_states,
+                     var_effect_vec, pi_vec, pi_matrix, marker_offset):
         if self.method in (BAYESC, BAYESB):
             if np.ndim(pi) == 1:
                 pi_vec = pi
@@ -136,14 +160,14 @@ class OracleEngine:
                        np.asarray(vare, dtype=np.float32).reshape(t, t),
                        np.asarray(var_effect, dtype=np.float32).reshape(t, t),
                        prior, seed, iteration, marker0=marker_offset, acc=self.acc, **blk)
-        return self._stats(a_before, gamma)
 
     def _stats(self, a_before, gamma):
         t = self.ntraits
         a64, b64, r64 = self.alpha.astype(np.float64), self.beta.astype(np.float64), self.r.astype(np.float64)
+        w64 = np.ones(self.n) if getattr(self, "_rinv", None) is None else self._rinv.astype(np.float64)
         out = {
-            "alpha_ss": a64 @ a64.T, "beta_ss": b64 @ b64.T, "resid_ss": r64 @ r64.T,
-            "resid_sum": r64.sum(axis=1), "n_events": float(np.any(a_before != self.alpha, axis=0).sum()),
+            "alpha_ss": a64 @ a64.T, "beta_ss": b64 @ b64.T, "resid_ss": (r64 * w64) @ r64.T,      # r'R^-1 r
+            "resid_sum": (r64 * w64).sum(axis=1), "n_events": float(np.any(a_before != self.alpha, axis=0).sum()),
             "sweep_ms": 0.0, "class_counts": np.zeros(4), "bayesr_ssq": 0.0, "bayesr_nnz": 0.0,
             "sum_delta": np.zeros(t), "state_counts": np.zeros(1 << t),
         }

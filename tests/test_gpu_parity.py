@@ -419,6 +419,70 @@ def test_switching_resident_block_sizes_mid_chain(hip):
     _compare_state(orc, hip, atol=5e-6)
 
 
+@pytest.mark.parametrize("method,bs,gram", [("BayesC", 128, "f64"), ("BayesR", 64, "f64"), ("MTBayesC", 64, "f64"), ("BayesC", 256, "mfma")])
+def test_residual_weights_parity(hip, method, bs, gram):
+    """Non-unit residual weights R^-1 (mme.invweights): x'R^-1 x, X_b'R^-1 X_b, X_b'R^-1 r, r'R^-1 r
+    (tools4genotypes.jl:28-31,59-78,263-266; variance_components.jl:82-98) against the oracle."""
+    data = make_dataset(n=410, p=2 * bs + 17, ncausal=8, seed=123)
+    rng = np.random.default_rng(5)
+    rinv = (1.0 / rng.uniform(0.5, 3.0, size=410)).astype(np.float32)
+    t = 2 if method == "MTBayesC" else 1
+    orc = OracleEngine("lookahead")
+    for e in (orc, hip):
+        e.load_dense(data["X"])
+        e.set_weights(rinv)
+        e.setup_blocks(bs, gram)
+        e.init_state(method, t)
+    xo, xh = orc.xpx(), hip.xpx()
+    np.testing.assert_allclose(xh, xo, rtol=2e-7)
+    np.testing.assert_allclose(xo, ((data["X"].astype(np.float64) ** 2) * rinv[:, None]).sum(axis=0), rtol=1e-5)
+    off = 0
+    for i in range(hip.nblocks):
+        G = hip.gram(i)
+        b = G.shape[0]
+        Go = orc.grams_packed()[off:off + b * b].reshape(b, b)
+        off += b * b
+        if gram == "f64":
+            assert np.array_equal(G, Go)
+        else:
+            np.testing.assert_allclose(G, Go, rtol=0, atol=2e-4 * np.abs(Go).max())
+    if gram == "mfma":
+        hip.set_grams_from(orc) if hasattr(hip, "set_grams_from") else None
+        return
+    y = data["y"] - data["y"].mean()
+    for k in range(t):
+        orc.set_residual((1 + 0.4 * k) * y, k); hip.set_residual((1 + 0.4 * k) * y, k)
+    if method == "BayesR":
+        ones = np.ones(orc.p, dtype=np.int32)
+        orc.set_state(0, delta=ones); hip.set_state(0, delta=ones)
+    vare, varg = _hyper(data, 0.9)
+    if method == "BayesC":
+        kw = dict(vare=vare, var_effect=varg, pi=0.9)
+    elif method == "BayesR":
+        kw = dict(vare=vare, var_effect=np.float32(5 * varg), pi_classes=np.array([0.9, 0.05, 0.03, 0.02]))
+    else:
+        kw = dict(vare=np.array([[vare, 0.1 * vare], [0.1 * vare, 2 * vare]], dtype=np.float32),
+                  var_effect=np.array([[varg, 0.2 * varg], [0.2 * varg, varg]], dtype=np.float32),
+                  log_prior_states=np.log(np.array([0.8, 0.05, 0.05, 0.1])))
+    for it in range(1, 13):
+        so = orc.sweep(iteration=it, seed=31, **kw)
+        sh = hip.sweep(iteration=it, seed=31, **kw)
+        assert so["n_events"] == sh["n_events"]
+        np.testing.assert_allclose(sh["resid_ss"], so["resid_ss"], rtol=1e-5)          # r'R^-1 r
+        np.testing.assert_allclose(sh["resid_sum"], so["resid_sum"], rtol=1e-4, atol=1e-3)
+    for k in range(t):
+        _compare_state(orc, hip, k, atol=5e-6)
+    so = orc.sweep(iteration=13, seed=31, independent_blocks=True, **kw)
+    sh = hip.sweep(iteration=13, seed=31, independent_blocks=True, **kw)
+    _compare_state(orc, hip, 0, atol=5e-6)
+    import jwas_jl_amd as J
+    with pytest.raises(J.JwasHipError, match="positive and finite"):
+        hip.set_weights(np.zeros(410, dtype=np.float32))
+    hip.set_weights(None)                                   # back to unit weights: block configurations are dropped
+    with pytest.raises(J.JwasHipError, match="setup_blocks has not been called"):
+        hip.sweep(iteration=1, seed=1, **kw)
+
+
 def test_accumulate_mul_alpha_sub_xalpha(hip, small_data):
     orc, hip = _pair(hip, small_data, 64, "BayesC")
     rng = np.random.default_rng(3)

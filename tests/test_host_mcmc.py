@@ -283,3 +283,29 @@ def test_adaptive_block_size_policy(tmp_path):
                                 output_folder=str(tmp_path / f"ad{rep}"), engine=spy))
         assert spy.sizes[0] == 512 and set(spy.sizes) <= {512, 1024} and 1024 in spy.sizes
     assert np.array_equal(outs[0]["marker effects geno"]["Estimate"], outs[1]["marker effects geno"]["Estimate"])
+
+
+def test_heterogeneous_residuals_weights(tmp_path):
+    """runMCMC(heterogeneous_residuals=true): invweights = 1 ./ df.weights (build_MME.jl:305-310) enters the marker
+    sweep, the location-parameter equations and the residual-variance draw."""
+    d = make_dataset(n=220, p=150, ncausal=4, seed=14, center=False)
+    rng = np.random.default_rng(2)
+    ids = [str(i) for i in range(220)]
+    wts = rng.uniform(0.5, 4.0, 220)
+    y = d["y"] + rng.standard_normal(220) * np.sqrt(wts) * 0.3              # noisier records carry larger weights
+    gdf = pd.DataFrame(d["raw"]); gdf.insert(0, "ID", ids)
+    ph = pd.DataFrame({"ID": ids, "y1": y.astype(np.float32), "weights": wts})
+    outs = {}
+    for het in (False, True):
+        geno = api.get_genotypes(gdf, method="BayesC", Pi=0.9)
+        model = api.build_model("y1 = intercept + geno")
+        outs[het] = api.runMCMC(model, ph, chain_length=40, burnin=5, seed=9, heterogeneous_residuals=het,
+                                output_folder=str(tmp_path / f"w{het}"), engine=OracleEngine("block"), block_size=64)
+    a, b = outs[False]["marker effects geno"]["Estimate"], outs[True]["marker effects geno"]["Estimate"]
+    assert not np.allclose(a, b)
+    assert np.corrcoef(outs[True]["EBV_y1"]["EBV"], ph["y1"])[0, 1] > 0.4
+    with pytest.raises(ValueError, match="requires a column named weights"):
+        geno = api.get_genotypes(gdf, method="BayesC", Pi=0.9)
+        model = api.build_model("y1 = intercept + geno")
+        api.runMCMC(model, ph.drop(columns="weights"), chain_length=2, heterogeneous_residuals=True,
+                    output_folder=str(tmp_path / "w_err"), engine=OracleEngine("block"), block_size=64)
