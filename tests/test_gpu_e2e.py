@@ -41,6 +41,57 @@ def test_runmcmc_gpu_matches_oracle_chain(tmp_path, method, Pi):
     np.testing.assert_allclose(outs["hip"]["EBV_y1"]["EBV"], outs["orc"]["EBV_y1"]["EBV"], atol=1e-3)
 
 
+def test_config1_full_chain_gpu_vs_oracle(tmp_path, config1_data):
+    """BASELINE.json configs[0] / SURVEY 8d config 1: single-trait BayesC, pi0 = 0.95 estimated, 500 x 2000, 1000
+    iterations, burn-in 100 -- the whole chain on the device against the oracle-driven chain, same seed.
+    Tier-1 tolerance: |d posterior mean alpha| <= 1e-4, |d sigma2_e| / sigma2_e <= 1e-4."""
+    d = config1_data
+    n, p = d["X"].shape
+    ids = [f"i{i}" for i in range(n)]
+    gdf = pd.DataFrame(d["raw"], columns=[f"m{j}" for j in range(p)])
+    gdf.insert(0, "ID", ids)
+    ph = pd.DataFrame({"ID": ids, "y1": d["y"]})
+    outs = {}
+    for tag, eng in (("orc", OracleEngine("lookahead")), ("hip", None)):
+        geno = api.get_genotypes(gdf, method="BayesC", Pi=0.95, estimatePi=True)
+        model = api.build_model("y1 = intercept + geno")
+        outs[tag] = api.runMCMC(model, ph, chain_length=1000, burnin=100, seed=2026, outputEBV=False,
+                                output_folder=str(tmp_path / tag), engine=eng, block_size=256, gram_mode="f64")
+    eo, eh = outs["orc"]["marker effects geno"], outs["hip"]["marker effects geno"]
+    assert np.abs(eh["Estimate"] - eo["Estimate"]).max() <= 1e-4
+    assert np.abs(eh["Model_Frequency"] - eo["Model_Frequency"]).max() <= 1e-4
+    ro, rh = (float(outs[k]["residual variance"]["Estimate"][0]) for k in ("orc", "hip"))
+    assert abs(rh - ro) / ro <= 1e-4
+    po, phh = (float(outs[k]["pi_geno"]["Estimate"][0]) for k in ("orc", "hip"))
+    assert abs(phh - po) <= 1e-4
+    causal = {f"m{j}" for j in d["causal"]}
+    top = set(eh.reindex(eh["Model_Frequency"].sort_values(ascending=False).index)["Marker_ID"].head(20))
+    assert len(top & causal) >= 8
+
+
+def test_three_trait_chain_gpu_vs_oracle(tmp_path):
+    """Config 4 shape (3-trait BayesC, sampler I, residual covariance drawn on the host), scaled down."""
+    d = make_dataset(n=300, p=450, ncausal=6, seed=77, center=False)
+    rng = np.random.default_rng(4)
+    ids = [f"i{i}" for i in range(300)]
+    gdf = pd.DataFrame(d["raw"], columns=[f"m{j}" for j in range(450)])
+    gdf.insert(0, "ID", ids)
+    ph = pd.DataFrame({"ID": ids, "y1": d["y"], "y2": (0.7 * d["y"] + 0.5 * rng.standard_normal(300)).astype(np.float32),
+                       "y3": (-0.4 * d["y"] + 0.8 * rng.standard_normal(300)).astype(np.float32)})
+    Pi = {tuple(float(b) for b in f"{s:03b}"): pr for s, pr in enumerate([0.6, 0.05, 0.05, 0.05, 0.05, 0.05, 0.05, 0.1])}
+    outs = {}
+    for tag, eng in (("orc", OracleEngine("lookahead")), ("hip", None)):
+        geno = api.get_genotypes(gdf, method="BayesC", Pi=Pi, estimatePi=True)
+        model = api.build_model("y1 = intercept + geno\ny2 = intercept + geno\ny3 = intercept + geno")
+        outs[tag] = api.runMCMC(model, ph, chain_length=80, burnin=10, seed=11, outputEBV=False,
+                                output_folder=str(tmp_path / tag), engine=eng, block_size=128, gram_mode="f64")
+    eo, eh = outs["orc"]["marker effects geno"], outs["hip"]["marker effects geno"]
+    assert len(eh) == 3 * 450
+    np.testing.assert_allclose(eh["Estimate"], eo["Estimate"], atol=1e-4)
+    np.testing.assert_allclose(eh["Model_Frequency"], eo["Model_Frequency"], atol=1e-4)
+    np.testing.assert_allclose(outs["hip"]["residual variance"]["Estimate"], outs["orc"]["residual variance"]["Estimate"], rtol=1e-3)
+
+
 def test_runmcmc_gpu_mfma_gram_statistically_equivalent(tmp_path):
     """With the production (fp32 MFMA) Gram the chain may round differently from the oracle; the
     posterior summaries still agree within Monte-Carlo noise of a short chain."""

@@ -309,3 +309,26 @@ def test_heterogeneous_residuals_weights(tmp_path):
         model = api.build_model("y1 = intercept + geno")
         api.runMCMC(model, ph.drop(columns="weights"), chain_length=2, heterogeneous_residuals=True,
                     output_folder=str(tmp_path / "w_err"), engine=OracleEngine("block"), block_size=64)
+
+
+def test_config1_plumbing_on_the_oracle(tmp_path, config1_data):
+    """BASELINE.json configs[0]: single-trait BayesC pi=0.95, 500 x 2000, 1000 iterations, CPU only (the oracle engine
+    drives the same host loop the device path uses): the chain runs, outputs have the reference's shape, QTL are found."""
+    d = config1_data
+    n, p = d["X"].shape
+    ids = [f"i{i}" for i in range(n)]
+    gdf = pd.DataFrame(d["raw"], columns=[f"m{j}" for j in range(p)])
+    gdf.insert(0, "ID", ids)
+    ph = pd.DataFrame({"ID": ids, "y1": d["y"]})
+    geno = api.get_genotypes(gdf, method="BayesC", Pi=0.95, estimatePi=True)
+    model = api.build_model("y1 = intercept + geno")
+    out = api.runMCMC(model, ph, chain_length=1000, burnin=100, seed=2026, output_folder=str(tmp_path / "c1"),
+                      engine=OracleEngine("block"), block_size=256)
+    me = out["marker effects geno"]
+    assert len(me) == geno.nMarkers and out["_timing"]["iterations"] == 1000
+    top = set(me.reindex(me["Model_Frequency"].sort_values(ascending=False).index)["Marker_ID"].head(20))
+    assert len(top & {f"m{j}" for j in d["causal"]}) >= 8
+    assert 0.9 < float(out["pi_geno"]["Estimate"][0]) < 1.0
+    h2 = 1 - float(out["residual variance"]["Estimate"][0]) / float(np.var(d["y"]))
+    assert 0.25 < h2 < 0.75
+    assert np.corrcoef(out["EBV_y1"]["EBV"], ph["y1"])[0, 1] > 0.6
