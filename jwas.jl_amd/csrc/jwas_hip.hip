@@ -268,8 +268,11 @@ static int alloc_storage(jwas_hip_ctx* c, int64_t n, int64_t p, bool packed = fa
     c->n = n; c->p = p; c->ld = round_up(n, kSliceRows);
     c->nslices = (int)(c->ld / kSliceRows);
     c->nrg = (c->nslices + kRowGroupSlices - 1) / kRowGroupSlices;
-    // enough workgroups to cover the CUs (256 on MI355X, one is the sampler's), at most 8-fold update redundancy
-    c->ncg = 255 / c->nrg; if (c->ncg < 1) c->ncg = 1; if (c->ncg > 8) c->ncg = 8;
+    // Column groups: as many workgroups as fit in ONE scheduling round.  The step kernel's dynamic LDS (sized for the
+    // sampler role) allows one workgroup per CU, and the quiet-XCD placement leaves every 8th CU idle, so 224 of the
+    // 256 CUs stream; more workgroups than that run as a second round and cost up to 2x (measured: 5.5-6.1 TB/s with
+    // <= 224 workgroups, 3.8-4.1 TB/s with 235-245).  At most 8-fold update redundancy.
+    c->ncg = 224 / c->nrg; if (c->ncg < 1) c->ncg = 1; if (c->ncg > 8) c->ncg = 8;
     size_t fb = 0, tb = 0;
     HIPCHK(c, hipMemGetInfo(&fb, &tb));
     const size_t need = packed ? (size_t)(c->ld >> 2) * p : (size_t)4 * c->ld * p;
