@@ -52,6 +52,10 @@ def parse():
                     help="0 (default) = the host loop's policy (jwas.jl_amd/mcmc.py): blocks of 512 markers while many effects "
                          "change per sweep, 1024 once fewer than 1.25 %% do; or a fixed size in {64,...,1024}")
     ap.add_argument("--seed", type=int, default=2026)
+    ap.add_argument("--workload", choices=["config2", "refbench"], default="config2",
+                    help="config2 = the metric's workload (default).  refbench = the shape of the reference's own published "
+                         "benchmark (benchmarks/jwas_nonblock_benchmark.jl:34-51): X ~ U[0,1) fp32 uncentred, y ~ N(0,1), Pi = 0 "
+                         "(every marker in the model, estimatePi = false), marker variance fixed; use with --p 100000 / 200000")
     ap.add_argument("--storage", choices=["dense", "packed2bit"], default="dense",
                     help="dense = the metric's fp32 dense genotypes (default); packed2bit = the reference's 2-bit packed "
                          "streaming payload kept packed in HBM (same genotypes, same chain; extra, not the headline config)")
@@ -92,14 +96,18 @@ def main():
     from jwas_jl_amd.dist import MarkerShard, shard_range
 
     from jwas_jl_amd.mcmc import pick_block_size
-    adaptive = a.block_size == 0
-    n, p_total, bs = a.n, a.p, (512 if adaptive else a.block_size)
+    refbench = a.workload == "refbench"
+    adaptive = a.block_size == 0 and not refbench
+    n, p_total, bs = a.n, a.p, (512 if adaptive else (a.block_size or 128))      # dense prior (refbench): 128-marker blocks
     lo, hi = shard_range(p_total, rank, world, align=1024 if adaptive else bs)
     p_loc = hi - lo
     eng = J.HipEngine(local_rank)
     t_setup = time.time()
     log('engine created'); (eng.alloc_packed if a.storage == 'packed2bit' else eng.alloc_dense)(n, p_loc); log('alloc done')
-    eng.synth(a.seed, kind=0, center=True, marker_offset=lo)        # 0/1/2 genotypes, centred, generated on device
+    if refbench:
+        eng.synth(a.seed, kind=1, center=False, marker_offset=lo)   # X ~ U[0,1), uncentred (jwas_nonblock_benchmark.jl:38,46)
+    else:
+        eng.synth(a.seed, kind=0, center=True, marker_offset=lo)    # 0/1/2 genotypes, centred, generated on device
     log('synth done'); eng.setup_blocks(bs, "mfma")
     if adaptive:
         eng.add_block_size(1024, "mfma")
@@ -119,6 +127,8 @@ def main():
     g = shard.allreduce_sum(eng.mul_alpha().astype(np.float64)); log('mul_alpha done')
     g *= np.sqrt(0.5 / g.var())
     y = (1.0 + g + rng.standard_normal(n) * np.sqrt(0.5)).astype(np.float32)
+    if refbench:
+        y = rng.standard_normal(n).astype(np.float32)                # y1 = randn(Float32, n)  (:35)
     eng.set_state(alpha=np.zeros(p_loc), beta=np.zeros(p_loc), delta=np.ones(p_loc))
 
     # ---- priors (input_data_validation.jl:296-350, tools4genotypes.jl:353-478)
@@ -128,6 +138,10 @@ def main():
     sum2pq = float(shard.allreduce_sum(np.array([eng.xpx().astype(np.float64).sum()]))[0]) / n   # x'x/n = 2pq (centred)
     pi = 0.95
     Gval = np.float32(0.5 * vary / ((1.0 - pi) * sum2pq))
+    if refbench:      # get_genotypes(X, 1.0; ...) and build_model(..., 1.0): genetic variance 1, residual variance 1, Pi = 0
+        xbar2 = 0.25                                                 # alleleFreq = mean/2 of U[0,1) columns (readgenotypes.jl:385)
+        pi, vare = 0.0, np.float32(1.0)
+        Gval = np.float32(1.0 / (p_total * 2.0 * xbar2 * (1.0 - xbar2)))
     scale_e = float(vare) * (df_ - 2) / df_
     scale_g = float(Gval) * (df_ - 2) / df_
     setup_s = time.time() - t_setup; log(f'setup done {setup_s:.1f}s')
@@ -153,8 +167,9 @@ def main():
         s["bs"] = eng.block_size
         nl = st["sum_delta"][0]
         # 3-5. pi, marker-effect variance, residual variance (Pi.jl:7-9, variance_components.jl:60-66,151-162)
-        s["pi"] = float(rng.beta(p_total - nl + 1.0, nl + 1.0))
-        s["G"] = np.float32((np.float32(st["alpha_ss"][0, 0]) + df_ * scale_g) / rng.chisquare(nl + df_))
+        if not refbench:                                             # refbench: estimatePi = false, estimate_variance = false
+            s["pi"] = float(rng.beta(p_total - nl + 1.0, nl + 1.0))
+            s["G"] = np.float32((np.float32(st["alpha_ss"][0, 0]) + df_ * scale_g) / rng.chisquare(nl + df_))
         s["vare"] = np.float32((np.float32(st["resid_ss"][0, 0]) + df_ * scale_e) / rng.chisquare(n + df_))
         acc["sweep_ms"] += st["sweep_ms"]
         acc["k_ms"] += st["update_kernel_ms"]
@@ -202,7 +217,9 @@ def main():
             "metric": "MCMC iters/sec (full marker sweep)", "value": a.steps / elapsed, "unit": "iterations/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"single-trait BayesC, {n} individuals x {p_total} SNPs, " + ("2-bit packed genotypes (decoded to fp32 on the fly)" if a.storage == "packed2bit" else "fp32 dense genotypes") + ", pi0=0.95 estimated",
+            "config": {"workload": (f"reference benchmark shape (jwas_nonblock_benchmark.jl): BayesC, {n} x {p_total}, X~U[0,1) fp32 uncentred, y~N(0,1), Pi=0 fixed, marker variance fixed"
+                                    if refbench else
+                                    f"single-trait BayesC, {n} individuals x {p_total} SNPs, " + ("2-bit packed genotypes (decoded to fp32 on the fly)" if a.storage == "packed2bit" else "fp32 dense genotypes") + ", pi0=0.95 estimated"),
                        "storage": a.storage,
                        "n": n, "p": p_total, "block_size": bs, "block_policy": "adaptive 512/1024" if adaptive else "fixed", "parallelism": f"marker-shard x{world}" if world > 1 else "single GPU",
                        "device_sweep_ms": acc["sweep_ms"] / a.steps, "events_per_sweep": acc["events"] / a.steps,
