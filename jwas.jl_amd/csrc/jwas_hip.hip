@@ -73,6 +73,7 @@ struct jwas_hip_ctx {
     double* pi_mat = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     int timing_stride = 0;
+    double last_events = -1.0;          // effect changes of the previous sweep (-1: none yet)
     double event_overhead_ms = 0.0;     // mean HIP-event interval around an empty launch (calibration)
     std::vector<hipEvent_t> kev;        // pairs of events around sampled k_update_partial launches
 };
@@ -1088,7 +1089,12 @@ int jwas_hip_sweep(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_sweep_stats
         U.nslices = c->nslices; U.nrg = c->nrg;
         U.ncg = (U.b > 0 && c->ncg > U.b) ? U.b : c->ncg;
         U.partials = c->partials + (k & 1) * pstride; U.bstride = bs;
-        { static const int qx = std::getenv("JWAS_HIP_QUIET_XCD") ? std::atoi(std::getenv("JWAS_HIP_QUIET_XCD")) : 1; U.quiet_xcd = qx; }
+        {   // Placement heuristic (speed only): keep XCD 0 free of streaming traffic for the sampler while the sampler chain
+            // is the critical path (many changes per sweep); in the steady state the sampler has slack and all 8 XCDs
+            // stream (+4-5 % bandwidth).  Decided from the previous sweep's change count; JWAS_HIP_QUIET_XCD=0|1 overrides.
+            static const int qx = std::getenv("JWAS_HIP_QUIET_XCD") ? std::atoi(std::getenv("JWAS_HIP_QUIET_XCD")) : -1;
+            U.quiet_xcd = qx >= 0 ? qx : (c->last_events < 0 || c->last_events > 0.0125 * (double)c->p ? 1 : 0);
+        }
         { static const int thr = std::getenv("JWAS_HIP_DEBUG_THROTTLE") ? std::atoi(std::getenv("JWAS_HIP_DEBUG_THROTTLE")) : 0; U.dbg_throttle = thr; }
         SamplerArgs S;
         std::memset(&S, 0, sizeof S);
@@ -1175,6 +1181,7 @@ int jwas_hip_sweep(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_sweep_stats
         for (int q = 0; q < (1 << t) && q < kMaxStates; ++q) S->state_counts[q] += v[42 + q];
     }
     S->n_events = (double)h_cnt[0];
+    c->last_events = (double)h_cnt[0];
     if (std::getenv("JWAS_HIP_DEBUG_PHASES"))
         std::fprintf(stderr, "[jwas_hip] blocks=%lld events=%llu unstaged=%llu cycles: front=%llu cand=%llu stage=%llu serial=%llu write=%llu rounds=%llu slow_rounds=%llu\n",
                      (long long)c->nblocks, h_cnt[0], h_cnt[1], h_cnt[2], h_cnt[3], h_cnt[4], h_cnt[5], h_cnt[6], h_cnt[7], h_cnt[8]);
