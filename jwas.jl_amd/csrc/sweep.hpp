@@ -38,7 +38,8 @@ constexpr int kRowsBytes = 96 * 1024;          // LDS budget for staged Gram row
 constexpr int kLdsBytes = 160 * 1024;
 struct StepSmem {
     int B, NT, max_cand;
-    int rhs_off, acur_off, astart_off, bcur_off, dcur_off, slot_off, cand_off, wcnt_off, log_off, prepd_off, prepf_off, rows_off, bytes;
+    int rhs_off, acur_off, astart_off, bcur_off, dcur_off, slot_off, cand_off, wcnt_off, log_off, prepd_off, prepf_off, rows_off, cross_off, bytes;
+    bool has_cross;
     __host__ __device__ StepSmem(int B_, int NT_, int nd, int nf) : B(B_), NT(NT_)
     {
         rhs_off  = 0;                               // float [NT][B]  running block RHS
@@ -57,7 +58,11 @@ struct StepSmem {
         if (room > kRowsBytes / (4 * B)) room = kRowsBytes / (4 * B);
         max_cand = room < B ? room : B;
         if (max_cand < 1) max_cand = 1;
-        const int samp = rows_off + (max_cand + 1) * B * 4;
+        // small blocks (B <= 128, all rows staged): the cross-Gram rows X_this'X_next of the block are copied to LDS too
+        // (by the waves that idle during the serial phase), so the lookahead correction at the end reads LDS only
+        cross_off = rows_off + (max_cand + 1) * B * 4;
+        has_cross = (B <= 128) && (max_cand >= B) && (cross_off + B * B * 4 <= kLdsBytes - 1024);
+        const int samp = cross_off + (has_cross ? B * B * 4 : 0);
         const int red = kRowGroupSlices * kColChunk * NT * 8;   // update role: double [8][64][NT]
         bytes = samp > red ? samp : red;
     }
@@ -266,7 +271,7 @@ __device__ __forceinline__ void sampler_front(char* smem, const StepSmem& SM, co
 // fin (LDS, int2 {local column, bits(d)} per trait-0 ... ) holds the compact change list; dlds the
 // per-trait changes [NT][B] indexed by local column.
 template <int NT>
-__device__ __forceinline__ void corr_phase(char* smem, const StepSmem& SM, const SamplerArgs& A, int nfin)
+__device__ __forceinline__ void corr_phase(char* smem, const StepSmem& SM, const SamplerArgs& A, int nfin, bool cross_in_lds = false)
 {
     const int B = SM.B;
     const int* fin = reinterpret_cast<const int*>(smem + SM.log_off);              // local columns, marker order
@@ -278,6 +283,15 @@ __device__ __forceinline__ void corr_phase(char* smem, const StepSmem& SM, const
 #pragma unroll
         for (int t = 0; t < NT; ++t) corr[t] = 0.f;
         if (c < bn) {
+            if (cross_in_lds) {                                  // rows copied by copy_cross_rows during the serial phase
+                const float* crossL = reinterpret_cast<const float*>(smem + SM.cross_off);
+                for (int e = 0; e < nfin; ++e) {
+                    const int ce = fin[e];
+                    const float g = crossL[ce * B + c];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) corr[t] = fmaf(astart[t * B + ce] - acur[t * B + ce], g, corr[t]);
+                }
+            } else
             for (int e0 = 0; e0 < nfin; e0 += 16) {
                 float g[16];
 #pragma unroll
@@ -319,6 +333,35 @@ __device__ __forceinline__ void prefetch_cross_rows(char* smem, const StepSmem& 
         for (int u = 0; u < 8; ++u) sink += v[u];
     }
     asm volatile("" ::"v"(sink));
+}
+
+// Waves 1..7 (small blocks): copy the block's cross-Gram rows X_this' X_next (b rows x bn columns) into LDS while wave 0
+// runs the serial phase; corr_phase then needs no global access at the end of the chain.
+__device__ __forceinline__ void copy_cross_rows(char* smem, const StepSmem& SM, const SamplerArgs& A)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bn = A.b_next, b = A.b, B = SM.B;
+    if (wave == 0 || bn <= 0) return;
+    float* crossL = reinterpret_cast<float*>(smem + SM.cross_off);
+    const int nchunk = (bn + 63) / 64, ntask = b * nchunk;
+    constexpr int kD = 16;
+    for (int t0 = (wave - 1) * kD; t0 < ntask; t0 += (kStepThreads / 64 - 1) * kD) {
+        float v[kD];
+#pragma unroll
+        for (int u = 0; u < kD; ++u) {
+            const int task = (t0 + u < ntask) ? t0 + u : ntask - 1;
+            const int row = task / nchunk, c = (task - row * nchunk) * 64 + lane;
+            v[u] = A.cross_next[(int64_t)row * bn + (c < bn ? c : 0)];
+        }
+#pragma unroll
+        for (int u = 0; u < kD; ++u) {
+            const int task = t0 + u;
+            if (task < ntask) {
+                const int row = task / nchunk, c = (task - row * nchunk) * 64 + lane;
+                if (c < B) crossL[row * B + c] = v[u];
+            }
+        }
+    }
 }
 
 // Stage the Gram rows of the candidate markers (cand[q] for marker c = tid + q*kStepThreads) in LDS.
@@ -445,8 +488,11 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
             const int row = ec / per_row, c4 = (ec - row * per_row) * 4;
             // rows are b floats apart in global memory (b may be < B for the last block): element-wise clamped loads
             const float* src = A.gram + (int64_t)row * b;
-            gpre[u].x = src[c4 < b ? c4 : 0]; gpre[u].y = src[c4 + 1 < b ? c4 + 1 : 0];
-            gpre[u].z = src[c4 + 2 < b ? c4 + 2 : 0]; gpre[u].w = src[c4 + 3 < b ? c4 + 3 : 0];
+            if (b == B) gpre[u] = *reinterpret_cast<const float4*>(src + c4);       // full block: rows are 16-byte aligned
+            else {
+                gpre[u].x = src[c4 < b ? c4 : 0]; gpre[u].y = src[c4 + 1 < b ? c4 + 1 : 0];
+                gpre[u].z = src[c4 + 2 < b ? c4 + 2 : 0]; gpre[u].w = src[c4 + 3 < b ? c4 + 3 : 0];
+            }
         }
     }
     bool cand[2] = {false, false};
@@ -527,7 +573,9 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
     const long long tk1 = clock64();
     const long long tk2 = clock64();
     int nstaged = prestage ? b : stage_rows(smem, SM, A, cand);
-    prefetch_cross_rows(smem, SM, A, nstaged);          // waves 1..7, for corr_phase at the end
+    const bool cross_lds = prestage && SM.has_cross;
+    if (cross_lds) copy_cross_rows(smem, SM, A);         // waves 1..7, while wave 0 runs the serial phase
+    else prefetch_cross_rows(smem, SM, A, nstaged);      // waves 1..7: pull the rows into L2 for corr_phase at the end
     int* wcnt_s = reinterpret_cast<int*>(smem + SM.wcnt_off);
     if (wave == 0) {
     const long long tk3 = clock64();
@@ -787,7 +835,7 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
     }
     }   // wave 0
     __syncthreads();
-    if (A.b_next > 0) corr_phase<1>(smem, SM, A, wcnt_s[15]);
+    if (A.b_next > 0) corr_phase<1>(smem, SM, A, wcnt_s[15], cross_lds);
 }
 
 // ---------------------------------------------------------------------------------------------
