@@ -847,21 +847,49 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
 template <int NT>
 struct MtConsts {
     float Rinv[NT][NT], Ginv[NT][NT];
+    float invG[NT], lG[NT], sG[NT];                   // sampler I: 1/Ginv_kk, log Ginv_kk, sqrt(1/Ginv_kk)
     // mega (constraint = true): per-trait single-trait BayesC constants
-    float ie[NT], var[NT], iv[NT], lv[NT];
+    float ie[NT], var[NT], iv[NT], lv[NT], sv[NT];   // sv = sqrt(var)
     double lp0[NT], lp1[NT];
 };
 
+// Per-marker quantities that depend only on x'x (not on the running rhs): computed once per marker, SIMD across the
+// markers of a sub-block, instead of inside every evaluation (each holds a double-precision log).
+template <int NT>
+struct MtPre {
+    float C11[NT], invLhs1[NT], lC11[NT], s1[NT];     // sampler I: C11, 1/C11, log C11, sqrt(1/C11)
+                                                      // mega:      lhs, 1/lhs, log(lhs) + log(var), sqrt(1/lhs)
+};
+template <int METHOD, int NT>
+__device__ __forceinline__ MtPre<NT> mt_precompute(const MtConsts<NT>& K, float dj)
+{
+    MtPre<NT> R;
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+        if constexpr (METHOD == kMegaBayesC) {
+            R.C11[k] = dj * K.ie[k] + K.iv[k];                                     // BayesABC.jl:37
+            R.invLhs1[k] = 1.0f / R.C11[k];                                        // :38
+            R.lC11[k] = logf_via_double(R.C11[k]) + K.lv[k];
+        } else {
+            R.C11[k] = K.Ginv[k][k] + K.Rinv[k][k] * dj;                           // MTBayesABC.jl:89
+            R.invLhs1[k] = 1.0f / R.C11[k];                                        // :95
+            R.lC11[k] = logf_via_double(R.C11[k]);
+        }
+        R.s1[k] = sqrtf(R.invLhs1[k]);
+    }
+    return R;
+}
+
 // Gibbs sampler I (MTBayesABC.jl:85-120)
 template <int NT>
-__device__ __forceinline__ void mt1_eval(const MtConsts<NT>& K, const double* lpr, const float (&w)[NT], float dj,
+__device__ __forceinline__ void mt1_eval(const MtConsts<NT>& K, const MtPre<NT>& Q, const double* lpr, const float (&w)[NT], float dj,
                                          const double (&thr)[NT], const double (&z)[NT],
                                          float (&an)[NT], float (&bn)[NT], float (&dn)[NT], float (&Dl)[NT])
 {
 #pragma unroll
     for (int k = 0; k < NT; ++k) {                                                  // :85
         const float Ginv11 = K.Ginv[k][k];
-        const float C11 = Ginv11 + K.Rinv[k][k] * dj;                               // :89
+        const float C11 = Q.C11[k];                                                 // :89
         float rhs0 = 0.f, c12b = 0.f, wR = 0.f;
 #pragma unroll
         for (int m = 0; m < NT; ++m) {
@@ -872,26 +900,26 @@ __device__ __forceinline__ void mt1_eval(const MtConsts<NT>& K, const double* lp
             c12b = c12b + C12m * bn[m];
         }
         rhs0 = -rhs0;                                                               // :93
-        const float invLhs0 = 1.0f / Ginv11;
+        const float invLhs0 = K.invG[k];
         const float gHat0 = rhs0 * invLhs0;
-        const float invLhs1 = 1.0f / C11;
+        const float invLhs1 = Q.invLhs1[k];
         const float rhs1 = wR - c12b;                                               // :96
         const float gHat1 = rhs1 * invLhs1;
         unsigned s0 = 0u;
 #pragma unroll
         for (int m = 0; m < NT; ++m) if (m != k && dn[m] != 0.f) s0 |= 1u << m;
         const unsigned s1 = s0 | (1u << k);
-        const float in0 = logf_via_double(Ginv11) - (gHat0 * gHat0) * Ginv11;       // :104
-        const float in1 = logf_via_double(C11) - (gHat1 * gHat1) * C11;             // :105
+        const float in0 = K.lG[k] - (gHat0 * gHat0) * Ginv11;                       // :104
+        const float in1 = Q.lC11[k] - (gHat1 * gHat1) * C11;                        // :105
         const double logDelta0 = -0.5 * (double)in0 + lpr[s0];
         const double logDelta1 = -0.5 * (double)in1 + lpr[s1];
         if ((logDelta0 - logDelta1) < thr[k]) {                                     // :107-111
             dn[k] = 1.f;
-            bn[k] = (float)((double)gHat1 + z[k] * (double)sqrtf(invLhs1));
+            bn[k] = (float)((double)gHat1 + z[k] * (double)Q.s1[k]);
             Dl[k] = an[k] - bn[k];
             an[k] = bn[k];
         } else {                                                                    // :112-119
-            bn[k] = (float)((double)gHat0 + z[k] * (double)sqrtf(invLhs0));
+            bn[k] = (float)((double)gHat0 + z[k] * (double)K.sG[k]);
             dn[k] = 0.f;
             Dl[k] = an[k];
             an[k] = 0.f;
@@ -901,30 +929,30 @@ __device__ __forceinline__ void mt1_eval(const MtConsts<NT>& K, const double* lp
 
 // megaBayesABC! (BayesABC.jl:1-8): trait k is an independent single-trait BayesC update (BayesABC.jl:24-58)
 template <int NT>
-__device__ __forceinline__ void mega_eval(const MtConsts<NT>& K, const float (&w)[NT], float dj,
+__device__ __forceinline__ void mega_eval(const MtConsts<NT>& K, const MtPre<NT>& Q, const float (&w)[NT], float dj,
                                           const double (&thr)[NT], const double (&z)[NT],
                                           float (&an)[NT], float (&bn)[NT], float (&dn)[NT], float (&Dl)[NT])
 {
 #pragma unroll
     for (int k = 0; k < NT; ++k) {
         const float rhs    = w[k] * K.ie[k];                                        // :36
-        const float lhs    = dj * K.ie[k] + K.iv[k];                                // :37
-        const float invLhs = 1.0f / lhs;                                            // :38
+        const float invLhs = Q.invLhs1[k];                                          // :37-38
         const float gHat   = rhs * invLhs;                                          // :39
-        const float inner  = (logf_via_double(lhs) + K.lv[k]) - gHat * rhs;
+        const float inner  = Q.lC11[k] - gHat * rhs;                                // (log lhs + log var) - gHat*rhs
         const double l1    = -0.5 * (double)inner + K.lp1[k];                       // :40
         if ((K.lp0[k] - l1) < thr[k]) {                                             // :41,:44
             dn[k] = 1.f;
-            bn[k] = (float)((double)gHat + z[k] * (double)sqrtf(invLhs));           // :46
+            bn[k] = (float)((double)gHat + z[k] * (double)Q.s1[k]);                 // :46
             Dl[k] = an[k] - bn[k];
             an[k] = bn[k];
         } else {
             dn[k] = 0.f;
-            bn[k] = (float)(z[k] * (double)sqrtf(K.var[k]));                        // :54
+            bn[k] = (float)(z[k] * (double)K.sv[k]);                                // :54
             Dl[k] = an[k];
             an[k] = 0.f;
         }
     }
+    (void)dj;
 }
 
 // lower Cholesky factor of an SPD NT x NT matrix (fixed operation order, shared with the oracle's chol_lower)
@@ -1111,11 +1139,15 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
     for (int a = 0; a < NT; ++a) {
 #pragma unroll
         for (int c = 0; c < NT; ++c) { K.Rinv[a][c] = P->Rinv[a * NT + c]; K.Ginv[a][c] = P->Ginv[a * NT + c]; }
+        K.invG[a] = 1.0f / K.Ginv[a][a];                            // MTBayesABC.jl:92
+        K.lG[a] = logf_via_double(K.Ginv[a][a]);
+        K.sG[a] = sqrtf(K.invG[a]);
         if constexpr (METHOD == kMegaBayesC) {
             K.ie[a]  = 1.0f / P->vare[a * NT + a];                  // invVarRes          BayesABC.jl:69
             K.var[a] = P->var_effect[a * NT + a];
             K.iv[a]  = 1.0f / K.var[a];                             // invVarEffects[j]   :70
             K.lv[a]  = logf_via_double(K.var[a]);                   // logVarEffects[j]   :71
+            K.sv[a]  = sqrtf(K.var[a]);
             K.lp0[a] = log(P->pi4[a]);                              // logPi              :67
             K.lp1[a] = log(1.0 - P->pi4[a]);                        // logPiComp          :68
         }
@@ -1126,7 +1158,81 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
     const int nreps = P->nreps > 0 ? P->nreps : b;
     RngKey key{P->seed_lo, P->seed_hi, P->iter, 0u};
 
-    for (int rep = 0; rep < nreps; ++rep) {
+    // ---- DENSE blocks (every marker of a <= 128-marker block is in the model for some trait -- the default all-ones
+    // multi-trait prior): sequential walk instead of speculative rounds, exactly as in the single-trait sampler: the
+    // block's running rhs (NT x 2 registers per lane), marker operands broadcast with v_readlane, Gram row from LDS.
+    bool dense_done = false;
+    if (METHOD != kMTBayesC2 && nreps == 1 && B <= 128 && nstaged_mt == b) {
+        auto bcast_f = [](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
+        auto bcast_d = [](double v, int l) {
+            return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+        };
+        const short* slot_of = reinterpret_cast<const short*>(smem + SM.slot_off);
+        const float* rows = reinterpret_cast<const float*>(smem + SM.rows_off);
+        float rhsq[NT][2], aq[NT][2], bq[NT][2], dq[NT][2], djq[2];
+        double thrq[NT][2], zq[NT][2];
+        MtPre<NT> Qq[2];
+        int slq[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int c = (64 * q + lane < b) ? 64 * q + lane : 0;
+            djq[q] = A.xpx[j0 + c]; slq[q] = slot_of[c];
+            Qq[q] = mt_precompute<METHOD, NT>(K, djq[q]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                rhsq[t][q] = rhs_lds[t * B + c]; aq[t][q] = acur[t * B + c]; bq[t][q] = bcur[t * B + c]; dq[t][q] = dcur[t * B + c];
+                thrq[t][q] = A.prep_d[(int64_t)t * p + j0 + c]; zq[t][q] = A.prep_d[(int64_t)(NT + t) * p + j0 + c];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int jend = (b < 64 * (q + 1)) ? b : 64 * (q + 1);
+#pragma unroll 1
+            for (int jj = 64 * q; jj < jend; ++jj) {
+                const int l = jj - 64 * q;
+                const float* grow = rows + __builtin_amdgcn_readlane(slq[q], l) * B;
+                const float g0 = grow[lane];
+                const float g1 = (B > 64) ? grow[64 + lane] : 0.f;
+                const float dj = bcast_f(djq[q], l);
+                float w[NT], an[NT], bn[NT], dn[NT], Dl[NT];
+                double thr[NT], z[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    an[t] = bcast_f(aq[t][q], l); bn[t] = bcast_f(bq[t][q], l); dn[t] = bcast_f(dq[t][q], l); Dl[t] = 0.f;
+                    thr[t] = bcast_d(thrq[t][q], l); z[t] = bcast_d(zq[t][q], l);
+                    w[t] = bcast_f(rhsq[t][q], l) + dj * an[t];                                         // :82
+                }
+                MtPre<NT> Qm;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    Qm.C11[t] = bcast_f(Qq[q].C11[t], l); Qm.invLhs1[t] = bcast_f(Qq[q].invLhs1[t], l);
+                    Qm.lC11[t] = bcast_f(Qq[q].lC11[t], l); Qm.s1[t] = bcast_f(Qq[q].s1[t], l);
+                }
+                if constexpr (METHOD == kMTBayesC1) mt1_eval<NT>(K, Qm, lpr, w, dj, thr, z, an, bn, dn, Dl);
+                else if constexpr (METHOD == kMTBayesC2) mt2_eval<NT>(K, lpr, w, dj, thr[0], z, an, bn, dn, Dl);
+                else mega_eval<NT>(K, Qm, w, dj, thr, z, an, bn, dn, Dl);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    if (lane == l) { aq[t][q] = an[t]; bq[t][q] = bn[t]; dq[t][q] = dn[t]; }
+                    rhsq[t][0] = fmaf(Dl[t], g0, rhsq[t][0]);                                           // Dl = 0: exact no-op
+                    if (B > 64) rhsq[t][1] = fmaf(Dl[t], g1, rhsq[t][1]);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int c = 64 * q + lane;
+            if (c < B)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    acur[t * B + c] = (c < b) ? aq[t][q] : 0.f; bcur[t * B + c] = bq[t][q]; dcur[t * B + c] = dq[t][q];
+                    rhs_lds[t * B + c] = rhsq[t][q];
+                }
+        }
+        dense_done = true;
+    }
+
+    for (int rep = 0; rep < (dense_done ? 0 : nreps); ++rep) {
         key.rep = (uint32_t)rep;
 #pragma unroll 1
         for (int s = 0; s < nsub; ++s) {
@@ -1148,6 +1254,7 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
                     z[t] = draw_normal(key, marker, (uint32_t)t);
                 }
             }
+            const MtPre<NT> Qm = mt_precompute<METHOD, NT>(K, dj);      // x'x-only terms, once per marker (SIMD over the sub-block)
             while (true) {
                 const bool live = valid && ((pending >> lane) & 1ull);
                 float an[NT], bn[NT], dn[NT], Dl[NT];
@@ -1158,9 +1265,9 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
                     float w[NT];
 #pragma unroll
                     for (int t = 0; t < NT; ++t) w[t] = rhs_lds[t * B + c] + dj * a_cur[t];           // :82
-                    if constexpr (METHOD == kMTBayesC1) mt1_eval<NT>(K, lpr, w, dj, thr, z, an, bn, dn, Dl);
+                    if constexpr (METHOD == kMTBayesC1) mt1_eval<NT>(K, Qm, lpr, w, dj, thr, z, an, bn, dn, Dl);
                     else if constexpr (METHOD == kMTBayesC2) mt2_eval<NT>(K, lpr, w, dj, thr[0], z, an, bn, dn, Dl);
-                    else mega_eval<NT>(K, w, dj, thr, z, an, bn, dn, Dl);
+                    else mega_eval<NT>(K, Qm, w, dj, thr, z, an, bn, dn, Dl);
 #pragma unroll
                     for (int t = 0; t < NT; ++t) is_event = is_event || (Dl[t] != 0.f);
                 }

@@ -483,6 +483,39 @@ def test_residual_weights_parity(hip, method, bs, gram):
         hip.sweep(iteration=1, seed=1, **kw)
 
 
+@pytest.mark.parametrize("method,t,bs", [("MTBayesC", 3, 128), ("MTBayesC", 2, 64), ("MTBayesC_II", 2, 128), ("MegaBayesC", 3, 64)])
+def test_multitrait_dense_blocks_parity(hip, method, t, bs):
+    """The default multi-trait prior puts all mass on the all-ones state (tools4genotypes.jl:357-373): every marker stays
+    in the model and every block is dense -- the sampler walks such blocks sequentially; results must not change."""
+    data = make_dataset(n=380, p=2 * bs + 41, ncausal=10, seed=800 + t)
+    orc, hip = _pair(hip, data, bs, method, ntraits=t)
+    rng = np.random.default_rng(t)
+    y = data["y"] - data["y"].mean()
+    for k in range(t):
+        yk = ((1 + 0.3 * k) * y + 0.2 * rng.standard_normal(len(y))).astype(np.float32)
+        orc.set_residual(yk, k); hip.set_residual(yk, k)
+        ones = np.ones(orc.p, dtype=np.float32)
+        a0 = (0.01 * rng.standard_normal(orc.p)).astype(np.float32)          # every marker already in the model
+        orc.set_state(k, alpha=a0, beta=a0, delta=ones); hip.set_state(k, alpha=a0, beta=a0, delta=ones)
+        orc.sub_xalpha(k); hip.sub_xalpha(k)
+    A = rng.standard_normal((t, t))
+    vare = (A @ A.T / t + np.eye(t)).astype(np.float32) * 0.5
+    Bm = rng.standard_normal((t, t))
+    varg = ((Bm @ Bm.T / t + np.eye(t)) * 0.002).astype(np.float32)
+    if method == "MegaBayesC":
+        kw = dict(vare=np.diag(np.diag(vare)), var_effect=np.diag(np.diag(varg)), pi=np.zeros(t))
+    else:
+        prior = np.full(1 << t, 1e-12); prior[-1] = 1.0; prior /= prior.sum()
+        kw = dict(vare=vare, var_effect=varg, log_prior_states=np.log(prior))
+    for it in range(1, 9):
+        so = orc.sweep(iteration=it, seed=21, **kw)
+        sh = hip.sweep(iteration=it, seed=21, **kw)
+        assert so["n_events"] == sh["n_events"] == orc.p, f"iteration {it}"
+        np.testing.assert_allclose(sh["resid_ss"], so["resid_ss"], rtol=1e-5)
+    for k in range(t):
+        _compare_state(orc, hip, k, atol=5e-6)
+
+
 def test_accumulate_mul_alpha_sub_xalpha(hip, small_data):
     orc, hip = _pair(hip, small_data, 64, "BayesC")
     rng = np.random.default_rng(3)
