@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void k_finish(CX cx, const float* r_in,
 // by k_prepare and stored struct-of-arrays in prep_d [kPrepD][p] / prep_f [kPrepF][p]; the serial
 // sampler wave only loads them.  (Within-block repetitions > 0 recompute them in place.)
 // ---------------------------------------------------------------------------------------------
-constexpr int kPrepD = 14;
+constexpr int kPrepD = 17;
 constexpr int kPrepF = 4;
 
 __device__ __forceinline__ float logf_via_double(float x) { return (float)log((double)x); }
@@ -374,6 +374,55 @@ struct AbcMarker {
 struct BayesRMarker {
     float  d, die;
     double lpi[4], invLhs[4], cA[4], zs[4], u;          // zs[k] = z*sqrt(1/lhs_k): the normal draw scaled for class k (:93)
+    // Class thresholds.  With s = rhs^2 every class log-weight is LINEAR in s (lp_k = 0.5*invLhs_k*s + const_k, slopes
+    // increasing with the class variance), so the family has a monotone likelihood ratio in s and every cumulative
+    // probability cum_k(s) = P(class <= k | s) DECREASES in s.  For the marker's uniform u the rule "class = number of
+    // k in {0,1,2} with cum_k <= u" (:73-79) is therefore "number of k with s >= T[k]", T[k] the root of cum_k(s) = u.
+    // The roots depend on the marker and its draw only, not on the running rhs: they are found once per sweep, for
+    // all markers in parallel (k_prepare), and the serial chain decides a class with one multiply and three compares
+    // instead of seven double-precision exp/log.  T = -1: boundary always passed; T = +inf: never.
+    double T[3];
+    __device__ __forceinline__ double cum(int kk, double s) const          // cum_kk(s), same formulas as evaluate()
+    {
+        double lp[4];
+        lp[0] = lpi[0];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) lp[k] = 0.5 * (cA[k] + invLhs[k] * s) + lpi[k];
+        double mx = lp[0];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) if (lp[k] > mx) mx = lp[k];
+        double e[4], se = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { e[k] = exp(lp[k] - mx); se += e[k]; }
+        double c = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) if (k <= kk) c += e[k];
+        return c / se;
+    }
+    __device__ __forceinline__ void find_thresholds()
+    {
+#pragma unroll 1
+        for (int kk = 0; kk < 3; ++kk) {
+            double t;
+            if (!(cum(kk, 0.0) > u)) t = -1.0;                              // already <= u at s = 0 (or NaN priors)
+            else {
+                double lo = 0.0, hi = 1e-4;
+                int it = 0;
+                while (cum(kk, hi) > u && it < 80) { lo = hi; hi *= 4.0; ++it; }
+                if (it >= 80) t = INFINITY;                                 // never reached (the classes above have zero mass)
+                else {
+#pragma unroll 1
+                    for (int q = 0; q < 56; ++q) {
+                        const double mid = 0.5 * (lo + hi);
+                        if (cum(kk, mid) > u) lo = mid; else hi = mid;
+                    }
+                    t = hi;
+                }
+            }
+            // (no dynamic indexing: T must stay in registers for the serial chain)
+            if (kk == 0) T[0] = t; else if (kk == 1) T[1] = t; else T[2] = t;
+        }
+    }
     __device__ __forceinline__ void prepare(float d_, float sigma_sq, const double* pi_j, const double* gamma,
                                             float ie, double u_, double z_)
     {
@@ -389,6 +438,7 @@ struct BayesRMarker {
             lpi[k] = log(pi_j[k]);
             zs[k]  = z_ * sqrt(invLhs[k]);
         }
+        find_thresholds();
     }
     __device__ __forceinline__ void store(double* pd, float* pf, int64_t p, int64_t j) const
     {
@@ -397,6 +447,8 @@ struct BayesRMarker {
 #pragma unroll
         for (int k = 1; k < 4; ++k) { pd[(3 + k) * p + j] = invLhs[k]; pd[(6 + k) * p + j] = cA[k]; pd[(9 + k) * p + j] = zs[k]; }
         pd[13 * p + j] = u;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pd[(14 + k) * p + j] = T[k];
         (void)pf;
     }
     __device__ __forceinline__ void load(const double* pd, const float* pf, int64_t p, int64_t j, float d_, float ie)
@@ -408,7 +460,23 @@ struct BayesRMarker {
 #pragma unroll
         for (int k = 1; k < 4; ++k) { invLhs[k] = pd[(3 + k) * p + j]; cA[k] = pd[(6 + k) * p + j]; zs[k] = pd[(9 + k) * p + j]; }
         u = pd[13 * p + j];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) T[k] = pd[(14 + k) * p + j];
         (void)pf;
+    }
+    // The subset the serial wave needs (parked in LDS, kFastD doubles per marker): 1/lhs_k, z*sqrt(1/lhs_k), T_k.
+    static constexpr int kFastD = 9;
+    __device__ __forceinline__ void store_fast(double* pd, int64_t p, int64_t j) const
+    {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { pd[k * p + j] = invLhs[k + 1]; pd[(3 + k) * p + j] = zs[k + 1]; pd[(6 + k) * p + j] = T[k]; }
+    }
+    __device__ __forceinline__ void load_fast(const double* pd, int64_t p, int64_t j, float d_, float ie)
+    {
+        d = d_; die = d_ * ie;
+        invLhs[0] = 0.0; zs[0] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { invLhs[k + 1] = pd[k * p + j]; zs[k + 1] = pd[(3 + k) * p + j]; T[k] = pd[(6 + k) * p + j]; }
     }
     // returns class 0..3 and the candidate alpha for that class
     __device__ __forceinline__ int evaluate(float rhs_b, float a_old, float ie, float& a_new) const
@@ -441,35 +509,18 @@ struct BayesRMarker {
         a_new = (float)an;
         return cls;
     }
-    // Same decision with single-precision exponentials: the class is the number of cumulative-probability boundaries
-    // <= u.  The approximate boundaries are within ~6e-6 of the exact ones (2 ulp of v_exp_f32, 6e-8*|lp - max| from
-    // rounding the exponent to float for |lp - max| < 88, beyond that the class weight is < 1e-38), so whenever u is
-    // further than kFastMargin from all of them the double-precision evaluation above would pick the same class.
-    // `sure` = false otherwise: the caller then re-evaluates with evaluate() (about 1 % of the rounds).
-    // The effect of the chosen class is computed in double exactly as in evaluate().
-    static constexpr float kFastMargin = 3e-5f;
-    __device__ __forceinline__ int evaluate_fast(float rhs_b, float a_old, float ie, float& a_new, bool& sure) const
+    // The same decision from the precomputed thresholds.  `sure` is false when s lies within a relative 1e-9 of a
+    // threshold (the bisection resolves the root to ~1e-16; the exact formulas round at ~1e-15): the caller then
+    // re-evaluates with evaluate().  The effect of the chosen class is computed exactly as in evaluate().
+    __device__ __forceinline__ int evaluate_thr(float rhs_b, float a_old, float ie, float& a_new, bool& sure) const
     {
         const float rhs = (rhs_b + d * a_old) * ie;                         // :60
-        double lp[4], bh[4];
-        lp[0] = lpi[0]; bh[0] = 0.0;
+        const double rd = (double)rhs, s = rd * rd;
+        const int cls = (s >= T[0] ? 1 : 0) + (s >= T[1] ? 1 : 0) + (s >= T[2] ? 1 : 0);
+        sure = true;
 #pragma unroll
-        for (int k = 1; k < 4; ++k) {
-            bh[k] = invLhs[k] * (double)rhs;
-            lp[k] = 0.5 * (cA[k] + bh[k] * (double)rhs) + lpi[k];           // :71
-        }
-        double mx = lp[0];
-#pragma unroll
-        for (int k = 1; k < 4; ++k) if (lp[k] > mx) mx = lp[k];
-        float e[4], se = 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { e[k] = __expf((float)(lp[k] - mx)); se += e[k]; }
-        const float inv = __fdividef(1.0f, se);
-        const float uf = (float)u;
-        const float c0 = e[0] * inv, c1 = c0 + e[1] * inv, c2 = c1 + e[2] * inv;
-        const int cls = (c0 <= uf ? 1 : 0) + (c1 <= uf ? 1 : 0) + (c2 <= uf ? 1 : 0);
-        sure = fabsf(uf - c0) > kFastMargin && fabsf(uf - c1) > kFastMargin && fabsf(uf - c2) > kFastMargin;
-        const double bc = cls == 1 ? bh[1] + zs[1] : (cls == 2 ? bh[2] + zs[2] : bh[3] + zs[3]);
+        for (int k = 0; k < 3; ++k) sure = sure && !(T[k] < 1e300 && fabs(s - T[k]) <= 1e-9 * T[k]);     // (T = -1 / inf: never close)
+        const double bc = cls == 1 ? invLhs[1] * rd + zs[1] : (cls == 2 ? invLhs[2] * rd + zs[2] : invLhs[3] * rd + zs[3]);
         a_new = cls == 0 ? 0.f : (float)bc;                                 // :93
         return cls;
     }

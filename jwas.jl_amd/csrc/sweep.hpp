@@ -452,7 +452,7 @@ __device__ __forceinline__ void apply_gram_row(char* smem, const StepSmem& SM, c
 template <int METHOD>
 __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A)
 {
-    constexpr int ND = (METHOD == kBayesR) ? 14 : 4, NF = (METHOD == kBayesR) ? 1 : 4;
+    constexpr int ND = (METHOD == kBayesR) ? BayesRMarker::kFastD : 4, NF = (METHOD == kBayesR) ? 1 : 4;
     const StepSmem SM(A.bsz, 1, ND, NF);
     const int B = SM.B;
     const DevParams* P = A.P;
@@ -530,9 +530,12 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
         // park the constants in LDS for the serial wave
         if constexpr (METHOD == kBayesR) {
             float an;
-            bm.store(lpd, lpf, B, c);
+            bool sure;
+            bm.store_fast(lpd, B, c);
             lpf[c] = dj;
-            cand[q] = (c < b) && ((a_in != 0.f) || (bm.evaluate(rhs0, 0.f, ie, an) != 0));
+            int cl0 = bm.evaluate_thr(rhs0, 0.f, ie, an, sure);
+            if (!sure) cl0 = bm.evaluate(rhs0, 0.f, ie, an);
+            cand[q] = (c < b) && ((a_in != 0.f) || (cl0 != 0));
         } else {
             float gh;
             am.store(lpd, lpf, B, c);
@@ -587,6 +590,8 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
     const short* slot_of = reinterpret_cast<const short*>(smem + SM.slot_off);
     const float* rows = reinterpret_cast<const float*>(smem + SM.rows_off);
     int2* evlog = reinterpret_cast<int2*>(smem + SM.log_off);
+    float* bpark = reinterpret_cast<float*>(smem + SM.bcur_off);       // [B] beta / [B] delta of the block (single trait:
+    float* dpark = reinterpret_cast<float*>(smem + SM.dcur_off);       // the multi-trait slots are free)
     const int nsub = (b + 63) / 64;
     const int nreps = P->nreps > 0 ? P->nreps : b;
     const bool lazy = (nreps == 1);     // single pass: corrections reach a sub-block when it becomes active
@@ -697,7 +702,7 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
             AbcMarker am; BayesRMarker bm;
             if (rep == 0) {            // constants parked in LDS by the parallel phase (no global loads here)
                 const int cl = valid ? c : 0;
-                if constexpr (METHOD == kBayesR) bm.load(lpd, lpf, B, cl, lpf[cl], ie);
+                if constexpr (METHOD == kBayesR) bm.load_fast(lpd, B, cl, lpf[cl], ie);
                 else am.load(lpd, lpf, B, cl, lpf[3 * B + cl]);
             } else {
                 const float dj = A.xpx[j];
@@ -724,11 +729,12 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
                 int cls = 0;
                 const bool live = valid && ((pending >> lane) & 1ull);
                 if constexpr (METHOD == kBayesR) {
-                    // class decision with fp32 exponentials; the double-precision evaluation only when some live lane's
-                    // uniform falls within the error margin of a class boundary (wave-uniform branch, ~1 % of rounds)
+                    // class decision from the per-sweep thresholds in s = rhs^2 (BayesRMarker); the exponentials only
+                    // when some live lane sits on a threshold (wave-uniform branch)
                     bool sure = true;
-                    if (live) cls = bm.evaluate_fast(rhs, a_cur, ie, a_new, sure);
-                    if (__any(live && !sure)) {
+                    if (live) cls = bm.evaluate_thr(rhs, a_cur, ie, a_new, sure);
+                    if (__any(live && !sure)) {                     // (practically never: s within 1e-9 of a class threshold)
+                        if (rep == 0) bm.load(A.prep_d, A.prep_f, p, j, lpf[valid ? c : 0], ie);   // full constants from global
                         if (live) cls = bm.evaluate(rhs, a_cur, ie, a_new);
                         if (lane == 0) ++nslow;
                     }
@@ -792,9 +798,18 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
             }
             acur[c] = a_cur;
             rhs_lds[c] = rhs;
-            if (valid) {
-                if constexpr (METHOD == kBayesR) delta_i[j] = (int32_t)d_out;
-                else { A.beta[j] = b_out; delta_f[j] = d_out; }
+            // beta / delta are parked in LDS and written to global memory after the serial phase: a global store here
+            // would put a vector-memory wait (s_waitcnt vmcnt) on the first round of the next sub-block
+            bpark[c] = b_out; dpark[c] = d_out;
+        }
+    }
+    if (!dense_done) {
+#pragma unroll 1
+        for (int s = 0; s < nsub; ++s) {
+            const int c = 64 * s + lane;
+            if (c < b) {
+                if constexpr (METHOD == kBayesR) delta_i[j0 + c] = (int32_t)dpark[c];
+                else { A.beta[j0 + c] = bpark[c]; delta_f[j0 + c] = dpark[c]; }
             }
         }
     }
