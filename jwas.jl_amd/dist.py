@@ -41,6 +41,7 @@ class MarkerShard:
         self._dist = None
         self._dev = None
         self._coll = world > 1 or force_collective      # force_collective: exercise the exchange with one rank (tests)
+        self._stream_set = False
         if self._coll:
             import torch
             import torch.distributed as dist
@@ -59,20 +60,33 @@ class MarkerShard:
         return t.cpu().numpy()
 
     def sweep(self, r_snapshot, **params):
-        """r_snapshot: t x n float32 (replicated).  Returns (r_new t x n, stats) after reconcile."""
+        """r_snapshot: t x n float32 (replicated).  Returns (r_new t x n, stats) after reconcile.
+
+        Reconcile:  r_new = fl32( r_snapshot + sum_g (r_local_g - r_snapshot) ),  the differences and their sum in
+        float64 (exact for one rank; rank-order independent up to the fixed reduction order of the collective), in ONE
+        all-reduce that also carries the packed O(p) statistics."""
         eng = self.engine
         t = r_snapshot.shape[0]
+        if self._dev is not None:
+            return self._sweep_device(r_snapshot, **params)
         for k in range(t):
             eng.set_residual(r_snapshot[k], k)
         st = eng.sweep(marker_offset=self.lo, **params)
         if not self._coll:
             r_new = np.stack([eng.get_residual(k) for k in range(t)])
             return r_new, st
-        delta = np.stack([eng.get_residual(k) for k in range(t)]) - r_snapshot        # dr_g (fp32)
+        snap64 = r_snapshot.astype(np.float64)
+        delta = np.stack([eng.get_residual(k) for k in range(t)]).astype(np.float64) - snap64          # dr_g
         packed = np.concatenate([np.atleast_1d(np.asarray(st[k], dtype=np.float64)).ravel() for k in _PACK])
-        delta = self.allreduce_sum(delta.astype(np.float32))
-        packed = self.allreduce_sum(packed)
-        r_new = (r_snapshot + delta).astype(np.float32)
+        total = self.allreduce_sum(np.concatenate([delta.ravel(), packed]))
+        r_new = (snap64 + total[:delta.size].reshape(delta.shape)).astype(np.float32)
+        self._unpack(st, total[delta.size:], r_new)
+        for k in range(t):
+            eng.set_residual(r_new[k], k)
+        return r_new, st
+
+    @staticmethod
+    def _unpack(st, packed, r_new):
         off = 0
         for k in _PACK:
             shape = np.shape(st[k])
@@ -83,6 +97,31 @@ class MarkerShard:
         r64 = r_new.astype(np.float64)
         st["resid_ss"] = r64 @ r64.T
         st["resid_sum"] = r64.sum(axis=1)
+
+    def _sweep_device(self, r_snapshot, **params):
+        """nccl backend: the residual stays on the GPU between the sweep and the collective (device-to-device copies in
+        and out of the library on torch's stream, RCCL all-reduce over xGMI, one host copy of the reconciled residual)."""
+        torch, eng = self._torch, self.engine
+        t, n = r_snapshot.shape
+        if not self._stream_set:
+            eng.set_stream(torch.cuda.current_stream().cuda_stream)     # order the library's work with torch's
+            self._stream_set = True
+        snap = torch.from_numpy(np.ascontiguousarray(r_snapshot, dtype=np.float32)).to(self._dev)
         for k in range(t):
-            eng.set_residual(r_new[k], k)
+            eng.residual_from_dev(snap[k].data_ptr(), k)
+        st = eng.sweep(marker_offset=self.lo, **params)
+        if not self._coll:
+            r_new = np.stack([eng.get_residual(k) for k in range(t)])
+            return r_new, st
+        rloc = torch.empty((t, n), dtype=torch.float32, device=self._dev)
+        for k in range(t):
+            eng.residual_to_dev(rloc[k].data_ptr(), k)
+        packed = np.concatenate([np.atleast_1d(np.asarray(st[k], dtype=np.float64)).ravel() for k in _PACK])
+        buf = torch.cat([(rloc.double() - snap.double()).reshape(-1), torch.from_numpy(packed).to(self._dev)])
+        self._dist.all_reduce(buf, op=self._dist.ReduceOp.SUM, group=self.group)
+        r_dev = (snap.double() + buf[:t * n].reshape(t, n)).float().contiguous()
+        for k in range(t):
+            eng.residual_from_dev(r_dev[k].data_ptr(), k)
+        r_new = r_dev.cpu().numpy()
+        self._unpack(st, buf[t * n:].cpu().numpy(), r_new)
         return r_new, st
