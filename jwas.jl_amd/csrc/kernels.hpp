@@ -40,7 +40,10 @@ __host__ __device__ constexpr bool is_mt_method(int m) { return m >= kMTBayesC1;
 // Effect changes of one marker block, consumed by the next k_update_partial.
 struct Events {
     int32_t count;
-    int32_t pad[3];
+    // single-trait header: the first 7 changes again, in the same 64-byte line as the count, so that the consumer's
+    // count -> index -> column chain of dependent loads is one step shorter in the common case (<= 7 changes per block)
+    int32_t hidx[7];
+    float   hdelta[8];
     int32_t idx[kMaxBlock];                 // local column index of the changed marker
     float   delta[kMaxT][kMaxBlock];        // alpha_old - alpha_new per trait (the axpy coefficient)
 };

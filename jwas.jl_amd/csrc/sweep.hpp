@@ -120,6 +120,20 @@ __device__ __forceinline__ void update_role(char* smem, int rg, int g,
     // stays in list order)
     const int ne = ev->count;
     constexpr int kEB = 16;
+    if (NT == 1 && ne <= 7) {
+        // header path: indices and coefficients arrived with the count (one 64-byte line)
+        float4 x[7];
+#pragma unroll
+        for (int u = 0; u < 7; ++u) x[u] = cx.load4(ev->hidx[u < ne ? u : 0], row);
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+            if (u < ne) {
+                const float d = ev->hdelta[u];
+                rv[0].x = fmaf(d, x[u].x, rv[0].x); rv[0].y = fmaf(d, x[u].y, rv[0].y);
+                rv[0].z = fmaf(d, x[u].z, rv[0].z); rv[0].w = fmaf(d, x[u].w, rv[0].w);
+            }
+        }
+    } else
     for (int e0 = 0; e0 < ne; e0 += kEB) {
         float4 x[kEB];
 #pragma unroll
@@ -830,6 +844,7 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
             const int pos = base + __popcll(cm & ((1ull << lane) - 1ull));
             A.ev_out->idx[pos] = (int32_t)j;
             A.ev_out->delta[0][pos] = a_start - a_fin;
+            if (pos < 7) { A.ev_out->hidx[pos] = (int32_t)j; A.ev_out->hdelta[pos] = a_start - a_fin; }
             A.alpha[j] = a_fin;
             reinterpret_cast<int*>(smem + SM.log_off)[pos] = c;      // compact change list for corr_phase
         }
