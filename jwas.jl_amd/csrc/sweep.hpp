@@ -124,7 +124,7 @@ __device__ __forceinline__ void update_role(char* smem, int rg, int g,
         // header path: indices and coefficients arrived with the count (one 64-byte line)
         float4 x[7];
 #pragma unroll
-        for (int u = 0; u < 7; ++u) x[u] = cx.load4(ev->hidx[u < ne ? u : 0], row);
+        for (int u = 0; u < 7; ++u) x[u] = cx.load4(u < ne ? ev->hidx[u] : 0, row);     // (unused slots: column 0, always valid)
 #pragma unroll
         for (int u = 0; u < 7; ++u) {
             if (u < ne) {
