@@ -454,7 +454,9 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
             if write_marker_samples:
                 for kk, tr in enumerate(model.lhsVec):
                     a = engine.get_state(kk)[0]
-                    files[f"marker_effects_{name}_{tr}"].write(",".join(repr(float(v)) for v in a) + "\n")
+                    fh = files[f"marker_effects_{name}_{tr}"]
+                    a.tofile(fh, sep=",", format="%.9g")          # text at C speed; 9 significant digits round-trip Float32
+                    fh.write("\n")
             if outputEBV:
                 for kk in range(t):
                     ebv_run[kk].add(engine.mul_alpha(kk), k)
