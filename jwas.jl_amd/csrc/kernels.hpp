@@ -520,14 +520,38 @@ struct BayesRMarker {
         const float rhs = (rhs_b + d * a_old) * ie;                         // :60
         const double rd = (double)rhs, s = rd * rd;
         const int cls = (s >= T[0] ? 1 : 0) + (s >= T[1] ? 1 : 0) + (s >= T[2] ? 1 : 0);
+        // "close to a threshold" in single precision: |s - T| <= 1e-6*T is a superset of the 1e-9 band that matters
+        // (T = -1: never close; T = +inf: inf - inf = NaN, the comparison is false)
+        const float sf = (float)s;
         sure = true;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) sure = sure && !(T[k] < 1e300 && fabs(s - T[k]) <= 1e-9 * T[k]);     // (T = -1 / inf: never close)
-        const double bc = cls == 1 ? invLhs[1] * rd + zs[1] : (cls == 2 ? invLhs[2] * rd + zs[2] : invLhs[3] * rd + zs[3]);
-        a_new = cls == 0 ? 0.f : (float)bc;                                 // :93
+        for (int k = 0; k < 3; ++k) { const float tf = (float)T[k]; sure = sure && !(fabsf(sf - tf) <= 1e-6f * tf); }
+        const double il = cls == 1 ? invLhs[1] : (cls == 2 ? invLhs[2] : invLhs[3]);
+        const double zz = cls == 1 ? zs[1] : (cls == 2 ? zs[2] : zs[3]);
+        a_new = cls == 0 ? 0.f : (float)(il * rd + zz);                     // bh_k + z*sqrt(1/lhs_k)  :93
         return cls;
     }
 };
+
+// The serial wave's evaluation of a BayesR marker from plain scalars passed BY VALUE (an object with the constants --
+// even one with scalar members only -- is kept in scratch memory by hipcc once any sibling object is, and the
+// class-dependent selects then become scratch loads with a full memory wait inside every round).
+// Thresholds are ordered T0 <= T1 <= T2 (the classes nest); same arithmetic as BayesRMarker::evaluate_thr.
+__device__ __forceinline__ int bayesr_eval_thr(float rhs_b, float a_old, float ie, float d,
+                                               double il1, double il2, double il3, double zs1, double zs2, double zs3,
+                                               double T0, double T1, double T2, float& a_new, bool& sure)
+{
+    const float rhs = (rhs_b + d * a_old) * ie;                         // :60
+    const double rd = (double)rhs, s = rd * rd;
+    const bool g1 = s >= T0, g2 = s >= T1, g3 = s >= T2;
+    const int cls = (g1 ? 1 : 0) + (g2 ? 1 : 0) + (g3 ? 1 : 0);
+    const float sf = (float)s, t0 = (float)T0, t1 = (float)T1, t2 = (float)T2;
+    sure = !(fabsf(sf - t0) <= 1e-6f * t0) && !(fabsf(sf - t1) <= 1e-6f * t1) && !(fabsf(sf - t2) <= 1e-6f * t2);
+    const double il = g3 ? il3 : (g2 ? il2 : il1);
+    const double zz = g3 ? zs3 : (g2 ? zs2 : zs1);
+    a_new = g1 ? (float)(il * rd + zz) : 0.f;                           // bh_k + z*sqrt(1/lhs_k)  :93
+    return cls;
+}
 
 // K_P: per-sweep marker constants for repetition 0.  grid = ceil(p/256), block = 256.
 template <int METHOD, int NT>

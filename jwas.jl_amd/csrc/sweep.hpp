@@ -714,9 +714,17 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
             }
 
             AbcMarker am; BayesRMarker bm;
+            // BayesR: the serial chain's constants as plain scalars (see bayesr_eval_thr)
+            float r_d = 0.f;
+            double r_il1 = 0.0, r_il2 = 0.0, r_il3 = 0.0, r_zs1 = 0.0, r_zs2 = 0.0, r_zs3 = 0.0, r_T0 = 0.0, r_T1 = 0.0, r_T2 = 0.0;
             if (rep == 0) {            // constants parked in LDS by the parallel phase (no global loads here)
                 const int cl = valid ? c : 0;
-                if constexpr (METHOD == kBayesR) bm.load_fast(lpd, B, cl, lpf[cl], ie);
+                if constexpr (METHOD == kBayesR) {
+                    r_d = lpf[cl];
+                    r_il1 = lpd[0 * B + cl]; r_il2 = lpd[1 * B + cl]; r_il3 = lpd[2 * B + cl];
+                    r_zs1 = lpd[3 * B + cl]; r_zs2 = lpd[4 * B + cl]; r_zs3 = lpd[5 * B + cl];
+                    r_T0 = lpd[6 * B + cl]; r_T1 = lpd[7 * B + cl]; r_T2 = lpd[8 * B + cl];
+                }
                 else am.load(lpd, lpf, B, cl, lpf[3 * B + cl]);
             } else {
                 const float dj = A.xpx[j];
@@ -727,6 +735,10 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
 #pragma unroll
                     for (int k = 0; k < 4; ++k) pj[k] = P->pi_mat ? P->pi_mat[4 * j + k] : P->pi4[k];
                     bm.prepare(dj, P->var_effect[0], pj, P->gamma, ie, u, z);
+                    r_d = dj;
+                    r_il1 = bm.invLhs[1]; r_il2 = bm.invLhs[2]; r_il3 = bm.invLhs[3];
+                    r_zs1 = bm.zs[1]; r_zs2 = bm.zs[2]; r_zs3 = bm.zs[3];
+                    r_T0 = bm.T[0]; r_T1 = bm.T[1]; r_T2 = bm.T[2];
                 } else {
                     float var_j = P->var_effect[0];
                     if constexpr (METHOD == kBayesB) var_j = P->var_vec[j];
@@ -746,7 +758,7 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
                     // class decision from the per-sweep thresholds in s = rhs^2 (BayesRMarker); the exponentials only
                     // when some live lane sits on a threshold (wave-uniform branch)
                     bool sure = true;
-                    if (live) cls = bm.evaluate_thr(rhs, a_cur, ie, a_new, sure);
+                    if (live) cls = bayesr_eval_thr(rhs, a_cur, ie, r_d, r_il1, r_il2, r_il3, r_zs1, r_zs2, r_zs3, r_T0, r_T1, r_T2, a_new, sure);
                     if (__any(live && !sure)) {                     // (practically never: s within 1e-9 of a class threshold)
                         if (rep == 0) bm.load(A.prep_d, A.prep_f, p, j, lpf[valid ? c : 0], ie);   // full constants from global
                         if (live) cls = bm.evaluate(rhs, a_cur, ie, a_new);
