@@ -36,9 +36,9 @@ HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8 TB/s 
 # HBM bytes per k_block_step launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and
 # --pmc WRITE_SIZE in separate runs of this command, averaged over the launches of the timed region's steady state;
 # FETCH_SIZE x2 per the guide's gfx950 correction, checked on k_xpx which reads X exactly once).
-# Valid for the default config only (n=50000, p=600000, adaptive blocks -> 1024 in the timed region): 212.2 MB per launch
-# against 204.4 MB algorithmic (1.04x).
-TRAFFIC_BYTES_PER_LAUNCH = (103092.2 * 2 + 1006.9) * 1024          # profiles/r01_pmc_{fetch,write}_summary.csv, last rows
+# Valid for the default config only (n=50000, p=600000, adaptive blocks -> 1024 in the timed region): 213.7 MB per launch
+# against 204.4 MB algorithmic (1.05x).
+TRAFFIC_BYTES_PER_LAUNCH = (103854.5 * 2 + 1006.9) * 1024          # profiles/r01_pmc_{fetch,write}_summary.csv, last rows
 
 
 def parse():
