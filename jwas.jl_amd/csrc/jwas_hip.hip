@@ -826,7 +826,7 @@ static hipError_t launch_step_cx(jwas_hip_ctx* c, const CX& cx, const UpdateArgs
     UpdateArgsT<CX> U;
     static_cast<UpdateArgs&>(U) = U0;
     U.cx = cx;
-    const StepSmem SM(c->block_size, NT, is_mt_method(METHOD) ? 0 : (METHOD == kBayesR ? BayesRMarker::kFastD : 4), is_mt_method(METHOD) ? 0 : (METHOD == kBayesR ? 1 : 4));
+    const StepSmem SM(c->block_size, NT, is_mt_method(METHOD) ? mt_park_nd(c->block_size, NT) : (METHOD == kBayesR ? BayesRMarker::kFastD : 4), is_mt_method(METHOD) ? mt_park_nf(c->block_size, NT) : (METHOD == kBayesR ? 1 : 4));
     static bool attr_set = false;
     if (!attr_set) {   // allow > 64 KB of dynamic LDS
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_block_step<METHOD, NT, CX>),
@@ -882,7 +882,7 @@ static hipError_t launch_indep_cx(jwas_hip_ctx* c, const CX& cx, const UpdateArg
     UpdateArgsT<CX> U;
     static_cast<UpdateArgs&>(U) = U0;
     U.cx = cx;
-    const StepSmem SM(c->block_size, NT, is_mt_method(METHOD) ? 0 : (METHOD == kBayesR ? BayesRMarker::kFastD : 4), is_mt_method(METHOD) ? 0 : (METHOD == kBayesR ? 1 : 4));
+    const StepSmem SM(c->block_size, NT, is_mt_method(METHOD) ? mt_park_nd(c->block_size, NT) : (METHOD == kBayesR ? BayesRMarker::kFastD : 4), is_mt_method(METHOD) ? mt_park_nf(c->block_size, NT) : (METHOD == kBayesR ? 1 : 4));
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_indep_sample<METHOD, NT>),

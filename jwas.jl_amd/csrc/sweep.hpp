@@ -38,7 +38,7 @@ constexpr int kRowsBytes = 96 * 1024;          // LDS budget for staged Gram row
 constexpr int kLdsBytes = 160 * 1024;
 struct StepSmem {
     int B, NT, max_cand;
-    int rhs_off, acur_off, astart_off, bcur_off, dcur_off, slot_off, cand_off, wcnt_off, log_off, prepd_off, prepf_off, rows_off, cross_off, bytes;
+    int rhs_off, acur_off, astart_off, bcur_off, dcur_off, slot_off, cand_off, wcnt_off, lpr_off, log_off, prepd_off, prepf_off, rows_off, cross_off, bytes;
     bool has_cross;
     __host__ __device__ StepSmem(int B_, int NT_, int nd, int nf) : B(B_), NT(NT_)
     {
@@ -50,7 +50,8 @@ struct StepSmem {
         slot_off = dcur_off + NT * B * 4;           // int16 [B]      LDS slot of a marker's Gram row, -1 = not staged
         cand_off = slot_off + B * 2;                // int16 [B]
         wcnt_off = (cand_off + B * 2 + 15) / 16 * 16;          // int [16]
-        log_off  = wcnt_off + 64;                   // int2  [B]      committed changes of this block: {slot, bits(D)}
+        lpr_off  = wcnt_off + 64;                   // double [16]    multi-trait: log prior probability of each of the 2^NT states
+        log_off  = lpr_off + 128;                   // int2  [B]      committed changes of this block: {slot, bits(D)}
         prepd_off = log_off + B * 8;                // double [nd][B] per-marker constants (rep 0)
         prepf_off = prepd_off + nd * B * 8;         // float  [nf][B]
         rows_off = prepf_off + nf * B * 4;          // float [max_cand + 1][B] staged Gram rows + one overflow row
@@ -67,6 +68,11 @@ struct StepSmem {
         bytes = samp > red ? samp : red;
     }
 };
+
+// Multi-trait samplers park the per-marker draws of repetition 0 (NT thresholds + NT normals, fp64) and x'x in LDS
+// when the block is small enough to leave room for the staged Gram rows; otherwise the serial wave reads them from HBM.
+__host__ __device__ constexpr int mt_park_nd(int B, int NT) { return (B * NT <= 2048) ? 2 * NT : 0; }
+__host__ __device__ constexpr int mt_park_nf(int B, int NT) { return (B * NT <= 2048) ? 1 : 0; }
 
 // ---------------------------------------------------------------------------------------------
 // UPDATE/PARTIAL role
@@ -238,47 +244,6 @@ struct SamplerArgs {
     Events* ev_out;
     unsigned long long* counters;
 };
-
-template <int NT>
-__device__ __forceinline__ void sampler_front(char* smem, const StepSmem& SM, const SamplerArgs& A)
-{
-    const int B = SM.B;
-    float* rhs_lds = reinterpret_cast<float*>(smem + SM.rhs_off);
-    float* acur = reinterpret_cast<float*>(smem + SM.acur_off);
-    float* astart = reinterpret_cast<float*>(smem + SM.astart_off);
-    const int tid = threadIdx.x;
-    const int b = A.b;
-    // rhs_b[c] = fl32(sum over row groups, fp64, fixed order) + corr[c]   (one load batch: nothing here
-    // depends on another load)
-    constexpr int kPB = 32;
-    for (int c = tid; c < B; c += kStepThreads) {
-        const int cc = c < b ? c : 0;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const float a0 = A.alpha[(int64_t)t * A.p + A.j0 + cc];
-            const float co = A.corr_in[t * B + c];
-            const double* pp = A.partials + (int64_t)t * A.nrg * A.bstride + cc;
-            double v[kPB];
-#pragma unroll
-            for (int u = 0; u < kPB; ++u) v[u] = pp[(int64_t)(u < A.nrg ? u : A.nrg - 1) * A.bstride];
-            double sum = 0.0;
-#pragma unroll
-            for (int u = 0; u < kPB; ++u) if (u < A.nrg) sum += v[u];
-            for (int rg = kPB; rg < A.nrg; rg += 16) {
-                double w[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) w[u] = pp[(int64_t)(rg + u < A.nrg ? rg + u : A.nrg - 1) * A.bstride];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) if (rg + u < A.nrg) sum += w[u];
-            }
-            rhs_lds[t * B + c] = (float)sum + co;
-            const float a_in = (c < b) ? a0 : 0.f;
-            acur[t * B + c] = a_in;
-            astart[t * B + c] = a_in;
-        }
-    }
-    __syncthreads();
-}
 
 // End of the sampler role (all threads): the lookahead correction of the NEXT block from the net changes
 // of this one,  corr[c] = fmaf(d_e, C[e][c], corr[c])  from 0 in marker order (C = X_this' X_next).
@@ -456,7 +421,7 @@ __device__ __forceinline__ void apply_gram_row(char* smem, const StepSmem& SM, c
             for (int t = 0; t < NT; ++t)
                 if (D[t] != 0.f) rhs_lds[t * B + c2] = fmaf(D[t], g, rhs_lds[t * B + c2]);
         }
-        atomicAdd(&A.counters[1], 1ull);                          // diagnostic: changes whose row was not staged
+        if (lane == 0) atomicAdd(&A.counters[1], 1ull);           // diagnostic: changes whose row was not staged
     }
 }
 
@@ -1141,40 +1106,21 @@ __device__ __forceinline__ void mt2_eval(const MtConsts<NT>& K, const double* lp
 template <int METHOD, int NT>
 __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A)
 {
-    const StepSmem SM(A.bsz, NT, 0, 0);
+    const StepSmem SM(A.bsz, NT, mt_park_nd(A.bsz, NT), mt_park_nf(A.bsz, NT));
     const int B = SM.B;
+    const bool parked = mt_park_nd(B, NT) != 0;
     const DevParams* P = A.P;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = A.b;
     const int64_t j0 = A.j0, p = A.p;
     float* rhs_lds = reinterpret_cast<float*>(smem + SM.rhs_off);
     float* acur = reinterpret_cast<float*>(smem + SM.acur_off);
+    float* astart = reinterpret_cast<float*>(smem + SM.astart_off);
     float* bcur = reinterpret_cast<float*>(smem + SM.bcur_off);
     float* dcur = reinterpret_cast<float*>(smem + SM.dcur_off);
+    double* lpd = reinterpret_cast<double*>(smem + SM.prepd_off);     // [2 NT][B] thresholds, normals (if parked)
+    float* lpf = reinterpret_cast<float*>(smem + SM.prepf_off);       // [B] x'x (if parked)
     float* delta = reinterpret_cast<float*>(A.delta);
-
-    sampler_front<NT>(smem, SM, A);
-    for (int c = tid; c < B; c += kStepThreads) {
-        const int cc = c < b ? c : 0;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            bcur[t * B + c] = A.beta[(int64_t)t * p + j0 + cc];
-            dcur[t * B + c] = delta[(int64_t)t * p + j0 + cc];
-        }
-    }
-    // candidates: markers already in the model for some trait (their effects always change)
-    bool cand[2] = {false, false};
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int c = tid + q * kStepThreads;
-        if (c < b)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) cand[q] = cand[q] || (acur[t * B + c] != 0.f);
-    }
-    const int nstaged_mt = stage_rows(smem, SM, A, cand);      // (its barriers also publish bcur/dcur)
-    prefetch_cross_rows(smem, SM, A, nstaged_mt);
-    int* wcnt_s = reinterpret_cast<int*>(smem + SM.wcnt_off);
-    if (wave == 0) {
 
     MtConsts<NT> K;
 #pragma unroll
@@ -1194,7 +1140,91 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
             K.lp1[a] = log(1.0 - P->pi4[a]);                        // logPiComp          :68
         }
     }
-    const double* lpr = P->log_prior;
+    // the 2^NT log prior state probabilities are indexed by the running state inside every evaluation: a global load
+    // there would put a memory latency (microseconds under full-rate streaming) on each trait of each round -- LDS copy
+    double* lpr = reinterpret_cast<double*>(smem + SM.lpr_off);
+    const double lpr_mine = P->log_prior[tid < (1 << NT) ? tid : 0];
+
+    // ---- front (all threads, ONE memory latency): every thread issues the loads of its marker's state, draws, x'x,
+    // lookahead correction and row-group partials back to back, forms  rhs = fl32(sum of partials) + corr,  parks
+    // everything the serial wave needs in LDS, and decides candidacy: a marker already in the model for some trait
+    // (its effects always change) or one whose evaluation against the entry rhs changes an effect.  Candidates get
+    // their Gram row staged in LDS; a change of a non-candidate reads its row from HBM inside the serial phase.
+    constexpr int kPB = 32;
+    bool cand[2] = {false, false};
+    float djq_[2], a0[2][NT], b0[2][NT], d0[2][NT], w0[2][NT];
+    double thr0[2][NT], z0[2][NT];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int c = tid + q * kStepThreads;
+        if (c >= B) continue;
+        const int cc = c < b ? c : 0;
+        const int64_t j = j0 + cc;
+        const float dj = A.xpx[j];
+        float co[NT];
+        djq_[q] = dj;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            a0[q][t] = A.alpha[(int64_t)t * p + j]; b0[q][t] = A.beta[(int64_t)t * p + j]; d0[q][t] = delta[(int64_t)t * p + j];
+            co[t] = A.corr_in[t * B + c];
+            thr0[q][t] = A.prep_d[(int64_t)t * p + j]; z0[q][t] = A.prep_d[(int64_t)(NT + t) * p + j];
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const double* pp = A.partials + (int64_t)t * A.nrg * A.bstride + cc;
+            double v[kPB];
+#pragma unroll
+            for (int u = 0; u < kPB; ++u) v[u] = pp[(int64_t)(u < A.nrg ? u : A.nrg - 1) * A.bstride];
+            double sum = 0.0;
+#pragma unroll
+            for (int u = 0; u < kPB; ++u) if (u < A.nrg) sum += v[u];
+            for (int rg = kPB; rg < A.nrg; rg += 16) {
+                double w[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) w[u] = pp[(int64_t)(rg + u < A.nrg ? rg + u : A.nrg - 1) * A.bstride];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) if (rg + u < A.nrg) sum += w[u];
+            }
+            const float rhs0 = (float)sum + co[t];
+            const float a_in = (c < b) ? a0[q][t] : 0.f;
+            rhs_lds[t * B + c] = rhs0;
+            acur[t * B + c] = a_in; astart[t * B + c] = a_in;
+            bcur[t * B + c] = b0[q][t]; dcur[t * B + c] = d0[q][t];
+            w0[q][t] = rhs0 + dj * a_in;                                                             // :82
+            if (parked) { lpd[t * B + c] = thr0[q][t]; lpd[(NT + t) * B + c] = z0[q][t]; }
+            a0[q][t] = a_in;
+        }
+        if (parked) lpf[c] = dj;
+    }
+    if (tid < (1 << NT)) lpr[tid] = lpr_mine;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int c = tid + q * kStepThreads;
+        if (c >= b) continue;
+        bool in_model = false;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) in_model = in_model || (a0[q][t] != 0.f);
+        bool moves = false;
+        if (!in_model) {
+            const float dj = djq_[q];
+            const MtPre<NT> Q0 = mt_precompute<METHOD, NT>(K, dj);
+            float an[NT], bn[NT], dn[NT], Dl[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { an[t] = a0[q][t]; bn[t] = b0[q][t]; dn[t] = d0[q][t]; Dl[t] = 0.f; }
+            if constexpr (METHOD == kMTBayesC1) mt1_eval<NT>(K, Q0, lpr, w0[q], dj, thr0[q], z0[q], an, bn, dn, Dl);
+            else if constexpr (METHOD == kMTBayesC2) mt2_eval<NT>(K, lpr, w0[q], dj, thr0[q][0], z0[q], an, bn, dn, Dl);
+            else mega_eval<NT>(K, Q0, w0[q], dj, thr0[q], z0[q], an, bn, dn, Dl);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) moves = moves || (Dl[t] != 0.f);
+        }
+        cand[q] = in_model || moves;
+    }
+    const int nstaged_mt = stage_rows(smem, SM, A, cand);
+    prefetch_cross_rows(smem, SM, A, nstaged_mt);
+    int* wcnt_s = reinterpret_cast<int*>(smem + SM.wcnt_off);
+    if (wave == 0) {
+
 
     const int nsub = (b + 63) / 64;
     const int nreps = P->nreps > 0 ? P->nreps : b;
@@ -1218,12 +1248,12 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int c = (64 * q + lane < b) ? 64 * q + lane : 0;
-            djq[q] = A.xpx[j0 + c]; slq[q] = slot_of[c];
+            djq[q] = lpf[c]; slq[q] = slot_of[c];                   // (B <= 128: the draws are always parked in LDS)
             Qq[q] = mt_precompute<METHOD, NT>(K, djq[q]);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 rhsq[t][q] = rhs_lds[t * B + c]; aq[t][q] = acur[t * B + c]; bq[t][q] = bcur[t * B + c]; dq[t][q] = dcur[t * B + c];
-                thrq[t][q] = A.prep_d[(int64_t)t * p + j0 + c]; zq[t][q] = A.prep_d[(int64_t)(NT + t) * p + j0 + c];
+                thrq[t][q] = lpd[t * B + c]; zq[t][q] = lpd[(NT + t) * B + c];
             }
         }
 #pragma unroll
@@ -1283,13 +1313,16 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
             const int64_t j = j0 + (valid ? c : 0);
             const uint32_t marker = P->marker0 + (uint32_t)j;
             unsigned long long pending = __ballot(valid);
-            const float dj = A.xpx[j];
+            const float dj = parked ? lpf[c] : A.xpx[j];
             double thr[NT], z[NT];
             float a_cur[NT], b_cur[NT], d_cur[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 a_cur[t] = acur[t * B + c]; b_cur[t] = bcur[t * B + c]; d_cur[t] = dcur[t * B + c];
-                if (rep == 0) { thr[t] = A.prep_d[(int64_t)t * p + j]; z[t] = A.prep_d[(int64_t)(NT + t) * p + j]; }
+                if (rep == 0) {
+                    if (parked) { thr[t] = lpd[t * B + c]; z[t] = lpd[(NT + t) * B + c]; }
+                    else { thr[t] = A.prep_d[(int64_t)t * p + j]; z[t] = A.prep_d[(int64_t)(NT + t) * p + j]; }
+                }
                 else {
                     const double u = draw_uniform(key, marker, (uint32_t)t);
                     thr[t] = (METHOD == kMTBayesC2) ? u : log((1.0 - u) / u);

@@ -20,6 +20,8 @@ ap.add_argument("--kind", type=int, default=0)
 ap.add_argument("--independent", action="store_true")
 ap.add_argument("--packed", action="store_true")
 ap.add_argument("--nreps", type=int, default=1)
+ap.add_argument("--mtprior", default="corners")   # corners: only 0..0 and 1..1 | spread: (1-pi) split over all non-null states
+ap.add_argument("--sampler", default="I")
 a = ap.parse_args()
 
 e = J.HipEngine(0)
@@ -28,7 +30,7 @@ rng = np.random.default_rng(1)
 for bs in a.bs:
     t0 = time.time(); e.setup_blocks(bs, a.gram); print(f"bs={bs} setup {time.time() - t0:.2f}s", flush=True)
     t = a.traits if a.method == "MT" else 1
-    e.init_state("MTBayesC" if a.method == "MT" else a.method, t)
+    e.init_state(("MTBayesC_II" if a.sampler == "II" else "MTBayesC") if a.method == "MT" else a.method, t)
     # y with a few causal markers
     at = np.zeros(a.p, dtype=np.float32); idx = rng.choice(a.p, max(1, a.p // 1000), replace=False); at[idx] = rng.standard_normal(len(idx))
     e.set_state(0, alpha=at); g = e.mul_alpha(0); g = g / g.std() * np.sqrt(0.5)
@@ -42,6 +44,8 @@ for bs in a.bs:
     varg = np.float32(0.5 / ((1 - pi) * s2pq))
     pi4 = np.array([0.95, 0.03, 0.015, 0.005]); sig = np.float32(0.5 / (s2pq * (0.03 * 0.01 + 0.015 * 0.1 + 0.005)))
     lp = np.full(1 << t, -np.inf); lp[(1 << t) - 1] = np.log(1 - pi); lp[0] = np.log(pi)
+    if a.mtprior == "spread":
+        lp[1:] = np.log((1 - pi) / ((1 << t) - 1))
     xkw = dict(independent_blocks=a.independent, nreps=a.nreps)
     for it in range(1, a.sweeps + 1):
         if a.method == "BayesR":
