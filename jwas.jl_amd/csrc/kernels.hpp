@@ -569,6 +569,16 @@ __global__ __launch_bounds__(256) void k_prepare(const DevParams* __restrict__ P
             const double u = draw_uniform(key, marker, (uint32_t)t);
             prep_d[(int64_t)t * p + j] = (METHOD == kMTBayesC2) ? u : log((1.0 - u) / u);   // sampler II keeps the raw uniform
             prep_d[(int64_t)(NT + t) * p + j] = draw_normal(key, marker, (uint32_t)t);
+            // log of the marker's "in the model" left-hand side (depends on x'x and this sweep's variances only): the
+            // double-precision log is taken here, for all markers in parallel, not inside the serial sampler
+            const float dj = xpx[j];
+            if constexpr (METHOD == kMegaBayesC) {
+                const float var = P->var_effect[t * NT + t];
+                const float lhs = dj * (1.0f / P->vare[t * NT + t]) + 1.0f / var;                     // BayesABC.jl:37
+                prep_f[(int64_t)t * p + j] = logf_via_double(lhs) + logf_via_double(var);
+            } else {
+                prep_f[(int64_t)t * p + j] = logf_via_double(P->Ginv[t * NT + t] + P->Rinv[t * NT + t] * dj);   // MTBayesABC.jl:89
+            }
         }
     } else {
         const float ie = 1.0f / P->vare[0];

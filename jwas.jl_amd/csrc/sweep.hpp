@@ -72,7 +72,7 @@ struct StepSmem {
 // Multi-trait samplers park the per-marker draws of repetition 0 (NT thresholds + NT normals, fp64) and x'x in LDS
 // when the block is small enough to leave room for the staged Gram rows; otherwise the serial wave reads them from HBM.
 __host__ __device__ constexpr int mt_park_nd(int B, int NT) { return (B * NT <= 2048) ? 2 * NT : 0; }
-__host__ __device__ constexpr int mt_park_nf(int B, int NT) { return (B * NT <= 2048) ? 1 : 0; }
+__host__ __device__ constexpr int mt_park_nf(int B, int NT) { return (B * NT <= 2048) ? 1 + NT : 0; }   // x'x, log C11 per trait
 
 // ---------------------------------------------------------------------------------------------
 // UPDATE/PARTIAL role
@@ -244,6 +244,33 @@ struct SamplerArgs {
     Events* ev_out;
     unsigned long long* counters;
 };
+
+// fp64 sum of one column's row-group partials in fixed (ascending row group) order; the first N loads are issued
+// back to back from clamped addresses (no load depends on another).
+template <int N>
+__device__ __forceinline__ double sum_partials_n(const double* pp, int nrg, int64_t stride)
+{
+    double v[N];
+#pragma unroll
+    for (int u = 0; u < N; ++u) v[u] = pp[(int64_t)(u < nrg ? u : nrg - 1) * stride];
+    double sum = 0.0;
+#pragma unroll
+    for (int u = 0; u < N; ++u) if (u < nrg) sum += v[u];
+    for (int rg = N; rg < nrg; rg += 16) {                        // very tall matrices only
+        double w[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) w[u] = pp[(int64_t)(rg + u < nrg ? rg + u : nrg - 1) * stride];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) if (rg + u < nrg) sum += w[u];
+    }
+    return sum;
+}
+__device__ __forceinline__ double sum_partials(const double* pp, int nrg, int64_t stride)
+{
+    if (nrg <= 8) return sum_partials_n<8>(pp, nrg, stride);      // (uniform branches: nrg is a launch constant)
+    if (nrg <= 16) return sum_partials_n<16>(pp, nrg, stride);
+    return sum_partials_n<32>(pp, nrg, stride);
+}
 
 // End of the sampler role (all threads): the lookahead correction of the NEXT block from the net changes
 // of this one,  corr[c] = fmaf(d_e, C[e][c], corr[c])  from 0 in marker order (C = X_this' X_next).
@@ -451,7 +478,6 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
     //   rhs = fl32(sum of partials) + corr
     // and decides candidacy (does the effect change if evaluated against the entry rhs?).  Under full-rate
     // streaming by the update role a dependent global load costs microseconds, so nothing here waits twice.
-    constexpr int kPB = 32;                       // row-group partials in the first batch
     // Small blocks (B <= 128: the host's choice for dense priors): the whole Gram block fits the row slots, and it does
     // not depend on anything this launch computes -- fetch it with the very first loads instead of after the candidates
     // are known (one dependent memory latency less per block).  Slot of marker c = c.
@@ -487,20 +513,7 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
         AbcMarker am; BayesRMarker bm;
         if constexpr (METHOD == kBayesR) bm.load(A.prep_d, A.prep_f, p, j, dj, ie);
         else am.load(A.prep_d, A.prep_f, p, j, dj);
-        const double* pp = A.partials + cc;
-        double v[kPB];
-#pragma unroll
-        for (int u = 0; u < kPB; ++u) v[u] = pp[(int64_t)(u < A.nrg ? u : A.nrg - 1) * A.bstride];
-        double sum = 0.0;
-#pragma unroll
-        for (int u = 0; u < kPB; ++u) if (u < A.nrg) sum += v[u];
-        for (int rg = kPB; rg < A.nrg; rg += 16) {                    // very tall matrices only
-            double w[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) w[u] = pp[(int64_t)(rg + u < A.nrg ? rg + u : A.nrg - 1) * A.bstride];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) if (rg + u < A.nrg) sum += w[u];
-        }
+        const double sum = sum_partials(A.partials + cc, A.nrg, A.bstride);
         const float rhs0 = (float)sum + co;       // + lookahead correction formed by the previous block's sampler
         rhs_lds[c] = rhs0;
         const float a_in = (c < b) ? a0 : 0.f;
@@ -867,8 +880,9 @@ struct MtPre {
     float C11[NT], invLhs1[NT], lC11[NT], s1[NT];     // sampler I: C11, 1/C11, log C11, sqrt(1/C11)
                                                       // mega:      lhs, 1/lhs, log(lhs) + log(var), sqrt(1/lhs)
 };
+// lc = the logs k_prepare took for this marker (prep_f rows 0..NT-1)
 template <int METHOD, int NT>
-__device__ __forceinline__ MtPre<NT> mt_precompute(const MtConsts<NT>& K, float dj)
+__device__ __forceinline__ MtPre<NT> mt_precompute(const MtConsts<NT>& K, float dj, const float (&lc)[NT])
 {
     MtPre<NT> R;
 #pragma unroll
@@ -876,12 +890,11 @@ __device__ __forceinline__ MtPre<NT> mt_precompute(const MtConsts<NT>& K, float 
         if constexpr (METHOD == kMegaBayesC) {
             R.C11[k] = dj * K.ie[k] + K.iv[k];                                     // BayesABC.jl:37
             R.invLhs1[k] = 1.0f / R.C11[k];                                        // :38
-            R.lC11[k] = logf_via_double(R.C11[k]) + K.lv[k];
         } else {
             R.C11[k] = K.Ginv[k][k] + K.Rinv[k][k] * dj;                           // MTBayesABC.jl:89
             R.invLhs1[k] = 1.0f / R.C11[k];                                        // :95
-            R.lC11[k] = logf_via_double(R.C11[k]);
         }
+        R.lC11[k] = lc[k];
         R.s1[k] = sqrtf(R.invLhs1[k]);
     }
     return R;
@@ -1121,6 +1134,7 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
     double* lpd = reinterpret_cast<double*>(smem + SM.prepd_off);     // [2 NT][B] thresholds, normals (if parked)
     float* lpf = reinterpret_cast<float*>(smem + SM.prepf_off);       // [B] x'x (if parked)
     float* delta = reinterpret_cast<float*>(A.delta);
+    const long long tk0 = clock64();
 
     MtConsts<NT> K;
 #pragma unroll
@@ -1150,9 +1164,8 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
     // everything the serial wave needs in LDS, and decides candidacy: a marker already in the model for some trait
     // (its effects always change) or one whose evaluation against the entry rhs changes an effect.  Candidates get
     // their Gram row staged in LDS; a change of a non-candidate reads its row from HBM inside the serial phase.
-    constexpr int kPB = 32;
     bool cand[2] = {false, false};
-    float djq_[2], a0[2][NT], b0[2][NT], d0[2][NT], w0[2][NT];
+    float djq_[2], a0[2][NT], b0[2][NT], d0[2][NT], w0[2][NT], lc0[2][NT];
     double thr0[2][NT], z0[2][NT];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -1168,30 +1181,18 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
             a0[q][t] = A.alpha[(int64_t)t * p + j]; b0[q][t] = A.beta[(int64_t)t * p + j]; d0[q][t] = delta[(int64_t)t * p + j];
             co[t] = A.corr_in[t * B + c];
             thr0[q][t] = A.prep_d[(int64_t)t * p + j]; z0[q][t] = A.prep_d[(int64_t)(NT + t) * p + j];
+            lc0[q][t] = A.prep_f[(int64_t)t * p + j];
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const double* pp = A.partials + (int64_t)t * A.nrg * A.bstride + cc;
-            double v[kPB];
-#pragma unroll
-            for (int u = 0; u < kPB; ++u) v[u] = pp[(int64_t)(u < A.nrg ? u : A.nrg - 1) * A.bstride];
-            double sum = 0.0;
-#pragma unroll
-            for (int u = 0; u < kPB; ++u) if (u < A.nrg) sum += v[u];
-            for (int rg = kPB; rg < A.nrg; rg += 16) {
-                double w[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) w[u] = pp[(int64_t)(rg + u < A.nrg ? rg + u : A.nrg - 1) * A.bstride];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) if (rg + u < A.nrg) sum += w[u];
-            }
+            const double sum = sum_partials(A.partials + (int64_t)t * A.nrg * A.bstride + cc, A.nrg, A.bstride);
             const float rhs0 = (float)sum + co[t];
             const float a_in = (c < b) ? a0[q][t] : 0.f;
             rhs_lds[t * B + c] = rhs0;
             acur[t * B + c] = a_in; astart[t * B + c] = a_in;
             bcur[t * B + c] = b0[q][t]; dcur[t * B + c] = d0[q][t];
             w0[q][t] = rhs0 + dj * a_in;                                                             // :82
-            if (parked) { lpd[t * B + c] = thr0[q][t]; lpd[(NT + t) * B + c] = z0[q][t]; }
+            if (parked) { lpd[t * B + c] = thr0[q][t]; lpd[(NT + t) * B + c] = z0[q][t]; lpf[(1 + t) * B + c] = lc0[q][t]; }
             a0[q][t] = a_in;
         }
         if (parked) lpf[c] = dj;
@@ -1208,7 +1209,7 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
         bool moves = false;
         if (!in_model) {
             const float dj = djq_[q];
-            const MtPre<NT> Q0 = mt_precompute<METHOD, NT>(K, dj);
+            const MtPre<NT> Q0 = mt_precompute<METHOD, NT>(K, dj, lc0[q]);
             float an[NT], bn[NT], dn[NT], Dl[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) { an[t] = a0[q][t]; bn[t] = b0[q][t]; dn[t] = d0[q][t]; Dl[t] = 0.f; }
@@ -1220,10 +1221,13 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
         }
         cand[q] = in_model || moves;
     }
+    const long long tk1 = clock64();
     const int nstaged_mt = stage_rows(smem, SM, A, cand);
     prefetch_cross_rows(smem, SM, A, nstaged_mt);
     int* wcnt_s = reinterpret_cast<int*>(smem + SM.wcnt_off);
     if (wave == 0) {
+    const long long tk3 = clock64();
+    int nrounds = 0;
 
 
     const int nsub = (b + 63) / 64;
@@ -1249,7 +1253,10 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
         for (int q = 0; q < 2; ++q) {
             const int c = (64 * q + lane < b) ? 64 * q + lane : 0;
             djq[q] = lpf[c]; slq[q] = slot_of[c];                   // (B <= 128: the draws are always parked in LDS)
-            Qq[q] = mt_precompute<METHOD, NT>(K, djq[q]);
+            float lcq[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) lcq[t] = lpf[(1 + t) * B + c];
+            Qq[q] = mt_precompute<METHOD, NT>(K, djq[q], lcq);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 rhsq[t][q] = rhs_lds[t * B + c]; aq[t][q] = acur[t * B + c]; bq[t][q] = bcur[t * B + c]; dq[t][q] = dcur[t * B + c];
@@ -1329,7 +1336,10 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
                     z[t] = draw_normal(key, marker, (uint32_t)t);
                 }
             }
-            const MtPre<NT> Qm = mt_precompute<METHOD, NT>(K, dj);      // x'x-only terms, once per marker (SIMD over the sub-block)
+            float lcm[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) lcm[t] = parked ? lpf[(1 + t) * B + c] : A.prep_f[(int64_t)t * p + j];
+            const MtPre<NT> Qm = mt_precompute<METHOD, NT>(K, dj, lcm); // x'x-only terms, once per marker (SIMD over the sub-block)
             while (true) {
                 const bool live = valid && ((pending >> lane) & 1ull);
                 float an[NT], bn[NT], dn[NT], Dl[NT];
@@ -1346,6 +1356,7 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
 #pragma unroll
                     for (int t = 0; t < NT; ++t) is_event = is_event || (Dl[t] != 0.f);
                 }
+                ++nrounds;
                 const unsigned long long m = __ballot(is_event) & pending;
                 const int k = m ? __builtin_ctzll(m) : 64;
                 if (live && lane <= k) {
@@ -1365,6 +1376,7 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
         }
     }
 
+    const long long tk4 = clock64();
     int base = 0;
 #pragma unroll 1
     for (int s = 0; s < nsub; ++s) {
@@ -1402,6 +1414,12 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
         A.ev_out->count = base;
         wcnt_s[15] = base;
         atomicAdd(&A.counters[0], (unsigned long long)base);
+        const long long tk5 = clock64();                      // phase cycle counts (diagnostics)
+        atomicAdd(&A.counters[2], (unsigned long long)(tk1 - tk0));
+        atomicAdd(&A.counters[4], (unsigned long long)(tk3 - tk1));
+        atomicAdd(&A.counters[5], (unsigned long long)(tk4 - tk3));
+        atomicAdd(&A.counters[6], (unsigned long long)(tk5 - tk4));
+        atomicAdd(&A.counters[7], (unsigned long long)nrounds);
     }
     }   // wave 0
     __syncthreads();
