@@ -68,6 +68,7 @@ struct jwas_hip_ctx {
     double* host_buf = nullptr;         // pinned staging for fin_out + stat_out + counters
     double* prep_d = nullptr;           // [kPrepD][p] per-sweep marker constants (k_prepare)
     float*  prep_f = nullptr;           // [kPrepF][p]
+    double* mt2_tab = nullptr;          // sampler II, <= 3 traits: [2^t * (t(t+1)/2 + 1)][p] state tables
     float*  var_vec = nullptr;
     double* pi_vec = nullptr;
     double* pi_mat = nullptr;
@@ -173,6 +174,7 @@ static void free_state(jwas_hip_ctx* c)
     (void)hipFree(c->alpha); (void)hipFree(c->beta); (void)hipFree(c->delta);
     (void)hipFree(c->mean_a); (void)hipFree(c->mean_a2); (void)hipFree(c->mean_d);
     (void)hipFree(c->prep_d); (void)hipFree(c->prep_f); c->prep_d = nullptr; c->prep_f = nullptr;
+    (void)hipFree(c->mt2_tab); c->mt2_tab = nullptr;
     c->alpha = c->beta = nullptr; c->delta = nullptr; c->mean_a = c->mean_a2 = c->mean_d = nullptr;
 }
 
@@ -694,6 +696,8 @@ int jwas_hip_init_state(jwas_hip_ctx* c, int32_t method, int32_t nt)
     HIPCHK(c, hipMalloc(&c->mean_d, fb));
     HIPCHK(c, hipMalloc(&c->prep_d, sizeof(double) * kPrepD * (size_t)c->p));
     HIPCHK(c, hipMalloc(&c->prep_f, sizeof(float) * kPrepF * (size_t)c->p));
+    if (method == JWAS_HIP_MTBAYESC2 && nt <= 3)
+        HIPCHK(c, hipMalloc(&c->mt2_tab, sizeof(double) * (size_t)((1 << nt) * (nt * (nt + 1) / 2 + 1)) * (size_t)c->p));
     HIPCHK(c, hipMemsetAsync(c->alpha, 0, fb, c->stream));
     HIPCHK(c, hipMemsetAsync(c->beta, 0, fb, c->stream));
     HIPCHK(c, hipMemsetAsync(c->delta, 0, fb, c->stream));
@@ -932,7 +936,7 @@ static int sweep_independent(jwas_hip_ctx* c, EventList* out)
     S.P = c->dparams; S.partials = c->ipartials; S.nrg = c->nrg; S.bstride = bs;
     S.p = c->p; S.bsz = bs; S.xpx = c->xpx; S.gram = c->gram;
     S.cross_next = c->gram; S.b_next = 0; S.corr_in = c->corr; S.corr_out = c->corr + (size_t)kMaxT * bs;
-    S.prep_d = c->prep_d; S.prep_f = c->prep_f;
+    S.prep_d = c->prep_d; S.prep_f = c->prep_f; S.mt2_tab = c->mt2_tab;
     S.alpha = c->alpha; S.beta = c->beta; S.delta = c->delta;
     S.counters = c->counters;
     hipError_t e;
@@ -1056,7 +1060,10 @@ int jwas_hip_sweep(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_sweep_stats
                 else if (t == 3) hipLaunchKernelGGL((k_prepare<M, 3>), pg, pb, 0, c->stream, c->dparams, c->p, c->xpx, c->prep_d, c->prep_f);     \
                 else hipLaunchKernelGGL((k_prepare<M, 4>), pg, pb, 0, c->stream, c->dparams, c->p, c->xpx, c->prep_d, c->prep_f);                 \
                 break;
-            case JWAS_HIP_MTBAYESC2: JW_MT_PREP(kMTBayesC2)
+            case JWAS_HIP_MTBAYESC2:
+                if (t == 2) hipLaunchKernelGGL((k_prepare_mt2<2>), pg, pb, 0, c->stream, c->dparams, c->p, c->xpx, c->mt2_tab);
+                else if (t == 3) hipLaunchKernelGGL((k_prepare_mt2<3>), pg, pb, 0, c->stream, c->dparams, c->p, c->xpx, c->mt2_tab);
+                JW_MT_PREP(kMTBayesC2)
             case JWAS_HIP_MEGABAYESC: JW_MT_PREP(kMegaBayesC)
             default: JW_MT_PREP(kMTBayesC1)
 #undef JW_MT_PREP
@@ -1113,7 +1120,7 @@ int jwas_hip_sweep(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_sweep_stats
             S.cross_next = c->cross + (sb + 1 < nb ? sb + 1 : sb) * (int64_t)bs * bs;
             S.corr_in = c->corr + (sb & 1) * (size_t)kMaxT * bs;
             S.corr_out = c->corr + ((sb + 1) & 1) * (size_t)kMaxT * bs;
-            S.prep_d = c->prep_d; S.prep_f = c->prep_f;
+            S.prep_d = c->prep_d; S.prep_f = c->prep_f; S.mt2_tab = c->mt2_tab;
             S.alpha = c->alpha; S.beta = c->beta; S.delta = c->delta;
             S.ev_out = &c->ev[(k - 1) & 1];
             S.counters = c->counters;

@@ -240,6 +240,7 @@ struct SamplerArgs {
     const float* corr_in;         // [NT][bsz] lookahead correction of THIS block (written by the previous sampler)
     float* corr_out;              // [NT][bsz] lookahead correction of the NEXT block
     const double* prep_d; const float* prep_f;
+    const double* mt2_tab;        // sampler II, <= 3 traits: per-marker state tables (k_prepare_mt2), else NULL
     float* alpha; float* beta; void* delta;
     Events* ev_out;
     unsigned long long* counters;
@@ -997,11 +998,14 @@ __device__ __forceinline__ void chol_lower(const double (&A)[NT][NT], double (&L
 
 // Gibbs sampler II, one candidate state (MTBayesABC.jl:178-185).  st: bit k = trait k in the model.
 // q = -0.5*(log det lhs - rhs'gHat); cand = gHat + chol(lhs^-1)*z only when want_cand.
+// The evaluation of one state is split in three: the part that depends on the marker's x'x and the sweep's variances
+// only (lhs, its inverse and log determinant -- both Cholesky factorisations' worth of divisions and square roots),
+// the part that depends on the running rhs (a handful of multiply-adds), and the candidate effects of the chosen state.
+// mt2_state = pre + post (+ cand): one operation order, shared with the oracle's mt2_state.
 template <int NT>
-__device__ __forceinline__ void mt2_state(const MtConsts<NT>& K, unsigned st, const float (&w)[NT], float dj,
-                                          const double (&z)[NT], bool want_cand, double& q, double (&cand)[NT])
+__device__ __forceinline__ void mt2_state_pre(const MtConsts<NT>& K, unsigned st, float dj, double (&inv)[NT][NT], double& logdet)
 {
-    double lhs[NT][NT], L[NT][NT], M[NT][NT], inv[NT][NT], rhs[NT], gHat[NT];
+    double lhs[NT][NT], L[NT][NT], M[NT][NT];
 #pragma unroll
     for (int a = 0; a < NT; ++a) {
         const double Da = ((st >> a) & 1u) ? 1.0 : 0.0;
@@ -1011,10 +1015,6 @@ __device__ __forceinline__ void mt2_state(const MtConsts<NT>& K, unsigned st, co
             const double rl = (Da * (double)K.Rinv[a][c]) * Dc;                     // D*Rinv*D  :159
             lhs[a][c] = rl * (double)dj + (double)K.Ginv[a][c];                     // :179
         }
-        double s = 0.0;
-#pragma unroll
-        for (int m = 0; m < NT; ++m) s = s + ((double)K.Rinv[m][a] * Da) * (double)w[m];   // (Rinv*D)'w :180
-        rhs[a] = s;
     }
     chol_lower<NT>(lhs, L);
 #pragma unroll
@@ -1035,11 +1035,26 @@ __device__ __forceinline__ void mt2_state(const MtConsts<NT>& K, unsigned st, co
             double s = 0.0;
 #pragma unroll
             for (int k = (a > c ? a : c); k < NT; ++k) s = s + M[k][a] * M[k][c];
-            inv[a][c] = s;
+            inv[a][c] = s;                                                          // (bitwise symmetric: products commute)
         }
     double det = 1.0;
 #pragma unroll
     for (int j = 0; j < NT; ++j) det = det * (L[j][j] * L[j][j]);
+    logdet = log(det);
+}
+template <int NT>
+__device__ __forceinline__ void mt2_state_post(const MtConsts<NT>& K, unsigned st, const float (&w)[NT],
+                                               const double (&inv)[NT][NT], double logdet, double& q, double (&gHat)[NT])
+{
+    double rhs[NT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a) {
+        const double Da = ((st >> a) & 1u) ? 1.0 : 0.0;
+        double s = 0.0;
+#pragma unroll
+        for (int m = 0; m < NT; ++m) s = s + ((double)K.Rinv[m][a] * Da) * (double)w[m];   // (Rinv*D)'w :180
+        rhs[a] = s;
+    }
     double quad = 0.0;
 #pragma unroll
     for (int a = 0; a < NT; ++a) {                                                  // gHat = invLhs*rhs :183
@@ -1049,17 +1064,134 @@ __device__ __forceinline__ void mt2_state(const MtConsts<NT>& K, unsigned st, co
         gHat[a] = s;
         quad = quad + rhs[a] * s;
     }
-    q = -0.5 * (log(det) - quad);                                                   // :184
-    if (want_cand) {
-        double C[NT][NT];
-        chol_lower<NT>(inv, C);                                                     // cholesky(Hermitian(invLhs)).L :182
+    q = -0.5 * (logdet - quad);                                                     // :184
+}
+template <int NT>
+__device__ __forceinline__ void mt2_state_cand(const double (&inv)[NT][NT], const double (&gHat)[NT], const double (&z)[NT],
+                                               double (&cand)[NT])
+{
+    double C[NT][NT];
+    chol_lower<NT>(inv, C);                                                         // cholesky(Hermitian(invLhs)).L :182
 #pragma unroll
-        for (int a = 0; a < NT; ++a) {                                              // gHat + L*z  :185
-            double s = gHat[a];
+    for (int a = 0; a < NT; ++a) {                                                  // gHat + L*z  :185
+        double s = gHat[a];
 #pragma unroll
-            for (int c = 0; c <= a; ++c) s = s + C[a][c] * z[c];
-            cand[a] = s;
+        for (int c = 0; c <= a; ++c) s = s + C[a][c] * z[c];
+        cand[a] = s;
+    }
+}
+template <int NT>
+__device__ __forceinline__ void mt2_state(const MtConsts<NT>& K, unsigned st, const float (&w)[NT], float dj,
+                                          const double (&z)[NT], bool want_cand, double& q, double (&cand)[NT])
+{
+    double inv[NT][NT], gHat[NT], logdet;
+    mt2_state_pre<NT>(K, st, dj, inv, logdet);
+    mt2_state_post<NT>(K, st, w, inv, logdet, q, gHat);
+    if (want_cand) mt2_state_cand<NT>(inv, gHat, z, cand);
+}
+
+// Per-marker table of the state-dependent, rhs-independent quantities (sampler II, NT <= 3): for each of the 2^NT
+// states the NT(NT+1)/2 unique entries of inv(lhs) (row-major upper triangle) and log det lhs.  Filled once per sweep
+// for all markers in parallel (k_prepare_mt2); layout [state][value][p].
+template <int NT>
+struct Mt2Tab {
+    static constexpr int NS = 1 << NT, NV = NT * (NT + 1) / 2 + 1, kRows = NS * NV;
+};
+template <int NT>
+__device__ __forceinline__ void mt2_unpack(const double (&row)[Mt2Tab<NT>::NV], double (&inv)[NT][NT], double& logdet)
+{
+    int v = 0;
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int c = a; c < NT; ++c) { inv[a][c] = row[v]; inv[c][a] = row[v]; ++v; }
+    logdet = row[v];
+}
+template <int NT>
+__global__ __launch_bounds__(256) void k_prepare_mt2(const DevParams* __restrict__ P, int64_t p, const float* __restrict__ xpx,
+                                                     double* __restrict__ tab)
+{
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= p) return;
+    MtConsts<NT> K;
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int c = 0; c < NT; ++c) { K.Rinv[a][c] = P->Rinv[a * NT + c]; K.Ginv[a][c] = P->Ginv[a * NT + c]; }
+    const float dj = xpx[j];
+#pragma unroll 1
+    for (int st = 0; st < Mt2Tab<NT>::NS; ++st) {
+        double inv[NT][NT], logdet;
+        mt2_state_pre<NT>(K, (unsigned)st, dj, inv, logdet);
+        int v = 0;
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+            for (int c = a; c < NT; ++c) { tab[((int64_t)st * Mt2Tab<NT>::NV + v) * p + j] = inv[a][c]; ++v; }
+        tab[((int64_t)st * Mt2Tab<NT>::NV + v) * p + j] = logdet;
+    }
+}
+template <int NT>
+__device__ __forceinline__ void mt2_load_tab(const double* __restrict__ tab, int64_t p, int64_t j,
+                                             double (&T)[Mt2Tab<NT>::NS][Mt2Tab<NT>::NV])
+{
+#pragma unroll
+    for (int st = 0; st < Mt2Tab<NT>::NS; ++st)
+#pragma unroll
+        for (int v = 0; v < Mt2Tab<NT>::NV; ++v) T[st][v] = tab[((int64_t)st * Mt2Tab<NT>::NV + v) * p + j];
+}
+
+// Gibbs sampler II, one marker, from its state table (same results as mt2_eval).
+template <int NT>
+__device__ __forceinline__ void mt2_eval_tab(const MtConsts<NT>& K, const double* lpr, const float (&w)[NT],
+                                             const double (&T)[Mt2Tab<NT>::NS][Mt2Tab<NT>::NV],
+                                             double u, const double (&z)[NT],
+                                             float (&an)[NT], float (&bn)[NT], float (&dn)[NT], float (&Dl)[NT])
+{
+    constexpr int NS = Mt2Tab<NT>::NS, NV = Mt2Tab<NT>::NV;
+    double ld[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        double inv[NT][NT], lg, q, gh[NT];
+        mt2_unpack<NT>(T[s], inv, lg);
+        mt2_state_post<NT>(K, (unsigned)s, w, inv, lg, q, gh);
+        ld[s] = q + lpr[s];
+    }
+    int which = NS - 1;
+    {                                                                               // :188-198
+        double mx = -INFINITY;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) if (ld[s] > mx) mx = ld[s];
+        double den = 0.0;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { ld[s] = exp(ld[s] - mx); den += ld[s]; }
+        double cp = 0.0;
+        bool found = false;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            cp += ld[s] / den;
+            if (!found && u < cp) { which = s; found = true; }
         }
+    }
+    double row[NV];                                                                 // the chosen state's row: select chain
+#pragma unroll
+    for (int v = 0; v < NV; ++v) row[v] = T[0][v];
+#pragma unroll
+    for (int s = 1; s < NS; ++s)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) row[v] = (which == s) ? T[s][v] : row[v];
+    double inv[NT][NT], lg, q, gh[NT], cand[NT];
+    mt2_unpack<NT>(row, inv, lg);
+    mt2_state_post<NT>(K, (unsigned)which, w, inv, lg, q, gh);
+    mt2_state_cand<NT>(inv, gh, z, cand);
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+        const double dk = ((which >> k) & 1) ? 1.0 : 0.0;
+        const double a_new = dk * cand[k];                                          // diagm(delta)*beta :201
+        Dl[k] = (float)((double)an[k] - a_new);                                     // oldα-newα -> axpy :204
+        bn[k] = (float)cand[k];
+        dn[k] = (float)dk;
+        an[k] = (float)a_new;
     }
 }
 
@@ -1122,6 +1254,8 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
     const StepSmem SM(A.bsz, NT, mt_park_nd(A.bsz, NT), mt_park_nf(A.bsz, NT));
     const int B = SM.B;
     const bool parked = mt_park_nd(B, NT) != 0;
+    constexpr bool kTab = (METHOD == kMTBayesC2) && (NT <= 3);       // sampler II from per-marker state tables
+    constexpr int kTS = kTab ? (1 << NT) : 1, kTV = kTab ? NT * (NT + 1) / 2 + 1 : 1;
     const DevParams* P = A.P;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = A.b;
@@ -1214,6 +1348,11 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
 #pragma unroll
             for (int t = 0; t < NT; ++t) { an[t] = a0[q][t]; bn[t] = b0[q][t]; dn[t] = d0[q][t]; Dl[t] = 0.f; }
             if constexpr (METHOD == kMTBayesC1) mt1_eval<NT>(K, Q0, lpr, w0[q], dj, thr0[q], z0[q], an, bn, dn, Dl);
+            else if constexpr (kTab) {
+                double T[kTS][kTV];
+                mt2_load_tab<NT>(A.mt2_tab, p, j0 + c, T);
+                mt2_eval_tab<NT>(K, lpr, w0[q], T, thr0[q][0], z0[q], an, bn, dn, Dl);
+            }
             else if constexpr (METHOD == kMTBayesC2) mt2_eval<NT>(K, lpr, w0[q], dj, thr0[q][0], z0[q], an, bn, dn, Dl);
             else mega_eval<NT>(K, Q0, w0[q], dj, thr0[q], z0[q], an, bn, dn, Dl);
 #pragma unroll
@@ -1340,6 +1479,8 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
 #pragma unroll
             for (int t = 0; t < NT; ++t) lcm[t] = parked ? lpf[(1 + t) * B + c] : A.prep_f[(int64_t)t * p + j];
             const MtPre<NT> Qm = mt_precompute<METHOD, NT>(K, dj, lcm); // x'x-only terms, once per marker (SIMD over the sub-block)
+            double T[kTS][kTV];
+            if constexpr (kTab) mt2_load_tab<NT>(A.mt2_tab, p, j, T);
             while (true) {
                 const bool live = valid && ((pending >> lane) & 1ull);
                 float an[NT], bn[NT], dn[NT], Dl[NT];
@@ -1351,6 +1492,7 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
 #pragma unroll
                     for (int t = 0; t < NT; ++t) w[t] = rhs_lds[t * B + c] + dj * a_cur[t];           // :82
                     if constexpr (METHOD == kMTBayesC1) mt1_eval<NT>(K, Qm, lpr, w, dj, thr, z, an, bn, dn, Dl);
+                    else if constexpr (kTab) mt2_eval_tab<NT>(K, lpr, w, T, thr[0], z, an, bn, dn, Dl);
                     else if constexpr (METHOD == kMTBayesC2) mt2_eval<NT>(K, lpr, w, dj, thr[0], z, an, bn, dn, Dl);
                     else mega_eval<NT>(K, Qm, w, dj, thr, z, an, bn, dn, Dl);
 #pragma unroll
