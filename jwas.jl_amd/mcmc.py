@@ -274,7 +274,10 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         # Sparse priors: keep a second, larger block size resident and pick per sweep from the previous sweep's number
         # of effect changes (a chain quantity, so runs stay reproducible): 1024-marker blocks amortise the per-launch cost
         # once fewer than ~1.3 % of the markers change per sweep (measured crossover at 50k x 600k: 8 900 changes).
-        adaptive = (not dense) and block_size == 512 and p > 4 * 1024
+        # (single-trait only: the multi-trait samplers are bound by the serial phase, not by launches, and at 1024
+        # markers x 3 traits the per-marker draws no longer fit LDS next to the staged Gram rows -- measured 10.0 vs 8.9 ms
+        # per sweep at 20k x 100k x 3 traits)
+        adaptive = (not dense) and t == 1 and block_size == 512 and p > 4 * 1024
 
     # ---- engine (the only engine shipped is the HIP one; there is no CPU fallback)
     own_engine = engine is None
