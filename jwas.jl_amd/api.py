@@ -205,8 +205,20 @@ def build_model(model_equations, R=False, *, df=4.0, estimate_variance=True, est
     for k in unsupported:
         raise NotImplementedError(f"build_model argument '{k}' (neural-network / censored / categorical models) "
                                   "stays on the reference path")
+    if not _is_false(R):                                                                      # :50-52
+        Rm = np.atleast_2d(np.asarray(R, dtype=np.float64))
+        ok = Rm.shape[0] == Rm.shape[1] and np.allclose(Rm, Rm.T)
+        if ok:
+            try:
+                np.linalg.cholesky(Rm)
+            except np.linalg.LinAlgError:
+                ok = False
+        if not ok:
+            raise ValueError("The covariance matrix is not positive definite.")
     if not isinstance(model_equations, str) or model_equations.strip() == "":
-        raise ValueError("Model equations are wrong.\n To find an example, type ?build_model and press enter.")   # :50-52
+        raise ValueError("Model equations are wrong.\n To find an example, type ?build_model and press enter.")   # :53-56
+    if estimate_scale is not False:
+        raise ValueError("estimate scale for residual variance is not supported now.")        # :57-59
     caller = inspect.currentframe().f_back
     scope = dict(caller.f_globals)
     scope.update(caller.f_locals)
@@ -232,6 +244,8 @@ def build_model(model_equations, R=False, *, df=4.0, estimate_variance=True, est
     if len(M) > 1:
         raise NotImplementedError("one genotype category per model on the device path (reference: 'now only work for one geno')")
     nModels = len(traits)
+    if not _is_false(R) and np.atleast_2d(np.asarray(R)).shape[0] != nModels:                 # :67-69
+        raise ValueError(f"The residual covariance matrix is not a {nModels} by {nModels} matrix.")
     for Mi in M:                                                                              # :98-112
         Mi.ntraits = nModels
         Mi.trait_names = traits

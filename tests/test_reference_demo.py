@@ -1,0 +1,132 @@
+"""The reference's own short tests for this path (test/runtests.jl:199-330, 352-400), run through this package on the
+reference's demo_7animals example data (committed as data fixtures under tests/golden/demo_7animals/).
+
+CPU part: genotype loading / QC / error contracts (host logic).  GPU part: the short MCMC runs -- same calls, same
+structural assertions as the reference's test sets (it pins no sampler values there)."""
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+import jwas_jl_amd as J
+from jwas_jl_amd import api
+
+DEMO = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "demo_7animals")
+GENO = os.path.join(DEMO, "genotypes.txt")
+PHENO = os.path.join(DEMO, "phenotypes.txt")
+
+
+def _phenotypes():
+    return pd.read_csv(PHENO, sep=",", na_values=["NA"], dtype={"ID": str})
+
+
+# ---- "Genotype Loading" (runtests.jl:198-230) -------------------------------------------------------------
+def test_load_from_file_with_header():
+    geno = api.get_genotypes(GENO, 1.0, separator=",", header=True, method="BayesC")
+    assert geno.nMarkers > 0 and geno.nObs > 0
+    assert geno.centered is True
+    assert geno.method == "BayesC"
+    assert len(geno.obsID) == geno.nObs == 7
+    assert len(geno.markerID) == geno.nMarkers
+    assert list(geno.obsID) == ["a1", "a3", "a4", "a5", "a6", "a7", "a8"]
+    # centred columns; allele frequency = column mean / 2 (readgenotypes.jl:384-385)
+    raw = pd.read_csv(GENO).iloc[:, 1:].to_numpy(dtype=np.float64)
+    keep = [m in geno.markerID for m in ["m1", "m2", "m3", "m4", "m5"]]
+    np.testing.assert_allclose(np.asarray(geno.genotypes, dtype=np.float64), (raw - raw.mean(0))[:, keep], atol=1e-6)
+    np.testing.assert_allclose(np.asarray(geno.alleleFreq).ravel(), (raw.mean(0) / 2)[keep], atol=1e-6)
+
+
+@pytest.mark.parametrize("method", ["BayesA", "BayesB", "BayesC", "BayesR"])
+def test_load_with_device_methods(method):
+    geno = api.get_genotypes(GENO, 1.0, separator=",", method=method)
+    assert geno.method == method and geno.nMarkers > 0
+
+
+@pytest.mark.parametrize("method", ["RR-BLUP", "BayesL", "GBLUP"])
+def test_methods_off_the_device_path_are_refused_loudly(method):
+    """The reference loads these too (runtests.jl:213-220); they are outside the hot path built here and must not
+    silently fall back to anything."""
+    with pytest.raises(NotImplementedError, match="not on the device path"):
+        api.get_genotypes(GENO, 1.0, separator=",", method=method)
+
+
+def test_quality_control_never_adds_markers():
+    with_qc = api.get_genotypes(GENO, 1.0, separator=",", quality_control=True, MAF=0.01)
+    no_qc = api.get_genotypes(GENO, 1.0, separator=",", quality_control=False)
+    assert with_qc.nMarkers <= no_qc.nMarkers == 5
+
+
+# ---- "Edge Cases" (runtests.jl:352-366) and "Data Types" (:385-400) ----------------------------------------
+def test_invalid_residual_variance():
+    with pytest.raises(ValueError):
+        api.build_model("y = intercept", -1.0)
+
+
+def test_invalid_covariance_matrix():
+    with pytest.raises(ValueError):
+        api.build_model("y1 = intercept\ny2 = intercept", np.array([[1.0, 2.0], [2.0, 1.0]]))
+
+
+def test_single_precision_default_and_double_refused():
+    geno = api.get_genotypes(GENO, 1.0, separator=",", double_precision=False)
+    assert np.asarray(geno.genotypes).dtype == np.float32
+    with pytest.raises(NotImplementedError, match="Float32"):
+        api.get_genotypes(GENO, 1.0, separator=",", double_precision=True)
+
+
+# ---- "MCMC Functionality" (runtests.jl:258-320), "Model frequency" (:333-349) -------------------------------
+@pytest.mark.gpu
+def test_single_trait_bayesc_short_run(tmp_path):
+    geno = api.get_genotypes(GENO, 1.0, separator=",", method="BayesC")
+    model = api.build_model("y1 = intercept + geno", 1.0)
+    out = api.runMCMC(model, _phenotypes(), chain_length=50, burnin=10, output_samples_frequency=10,
+                      output_folder=str(tmp_path / "results"), seed=123)
+    assert "location parameters" in out and "residual variance" in out and "marker effects geno" in out
+    assert len(out["location parameters"]) > 0
+    me = out["marker effects geno"]
+    assert list(me.columns) == ["Trait", "Marker_ID", "Estimate", "SD", "Model_Frequency"]     # output.jl:108-147
+    assert len(me) == geno.nMarkers
+    assert ((me["Model_Frequency"] >= 0) & (me["Model_Frequency"] <= 1)).all()
+    assert np.isfinite(me["Estimate"]).all()
+    assert os.path.isfile(tmp_path / "results" / "location_parameters.txt")
+    assert os.path.isfile(tmp_path / "results" / "residual_variance.txt")
+    assert os.path.isfile(tmp_path / "results" / "MCMC_samples_marker_effects_geno_y1.txt")
+    samples = pd.read_csv(tmp_path / "results" / "MCMC_samples_marker_effects_geno_y1.txt")
+    assert samples.shape == (4, geno.nMarkers)            # (50 - 10) / 10 saved samples x markers
+    freq = (samples.to_numpy() != 0).mean(0)              # GWAS(): model frequency from the samples file
+    assert ((freq >= 0) & (freq <= 1)).all()
+
+
+@pytest.mark.gpu
+def test_reproducibility_with_seed(tmp_path):
+    outs = []
+    for tag in ("temp1", "temp2"):
+        geno = api.get_genotypes(GENO, 1.0, separator=",", method="BayesC")
+        model = api.build_model("y1 = intercept + geno", 1.0)
+        outs.append(api.runMCMC(model, _phenotypes(), chain_length=50, output_folder=str(tmp_path / tag), seed=999))
+    assert abs(outs[0]["residual variance"]["Estimate"][0] - outs[1]["residual variance"]["Estimate"][0]) <= 1e-10
+    np.testing.assert_array_equal(outs[0]["marker effects geno"]["Estimate"].to_numpy(),
+                                  outs[1]["marker effects geno"]["Estimate"].to_numpy())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", ["BayesA", "BayesB", "BayesR"])
+def test_other_single_trait_methods_short_run(tmp_path, method):
+    geno = api.get_genotypes(GENO, 1.0, separator=",", method=method)
+    model = api.build_model("y1 = intercept + geno", 1.0)
+    out = api.runMCMC(model, _phenotypes(), chain_length=50, burnin=10, output_folder=str(tmp_path / method), seed=123)
+    assert len(out["marker effects geno"]) == geno.nMarkers
+    assert np.isfinite(out["residual variance"]["Estimate"]).all()
+
+
+@pytest.mark.gpu
+def test_multi_trait_bayesc_short_run(tmp_path):
+    """y1, y2 with missing records (a5 has no y2): multi-trait BayesC on the demo data (runtests.jl multi-trait sets)."""
+    geno = api.get_genotypes(GENO, np.eye(2), separator=",", method="BayesC")
+    model = api.build_model("y1 = intercept + geno\ny2 = intercept + geno", np.eye(2))
+    ph = _phenotypes().dropna(subset=["y1", "y2"])
+    out = api.runMCMC(model, ph, chain_length=50, burnin=10, output_folder=str(tmp_path / "mt"), seed=123)
+    me = out["marker effects geno"]
+    assert len(me) == 2 * geno.nMarkers
+    assert set(me["Trait"]) == {"y1", "y2"}
