@@ -23,6 +23,10 @@
  *                              variance_components.jl:60-112,151-189
  *   jwas_hip_accumulate        output_posterior_mean_variance, marker part (output.jl:568-577)
  *   jwas_hip_mul_alpha         getEBV's X*alpha (output.jl:281-306)
+ *   jwas_hip_load_output_dense_f32 / jwas_hip_mul_alpha_output
+ *                              Mi.output_genotypes (markers/tools4genotypes.jl:290-296) and getEBV over mme.output_ID
+ *                              (output.jl:281-306; default output_ID = all genotyped individuals,
+ *                              input_data_validation.jl:150-154)
  *
  * Conventions: every entry point returns 0 on success and a negative JWAS_HIP_E* code on failure
  * (no exceptions cross the boundary; jwas_hip_last_error() returns the message -- the analogue of
@@ -209,6 +213,12 @@ int  jwas_hip_residual_from_dev(jwas_hip_ctx* ctx, int32_t trait, const void* sr
 int  jwas_hip_residual_sub_xalpha(jwas_hip_ctx* ctx, int32_t trait);
 /* out = X * alpha_k (n floats, fp64-accumulated). */
 int  jwas_hip_mul_alpha(jwas_hip_ctx* ctx, int32_t trait, float* out_host);
+/* Rows for which EBVs are reported when they are not exactly the training rows (individuals without records, a
+ * user's outputEBV(model, IDs) list): X_out is n_out x p marker-major fp32 with leading dimension ld_host, processed
+ * (imputed / centred with the training column means) like the training matrix; copied. */
+int  jwas_hip_load_output_dense_f32(jwas_hip_ctx* ctx, const float* X_out_host, int64_t n_out, int64_t p, int64_t ld_host);
+/* out = X_out * alpha_k (n_out floats, fp64-accumulated). */
+int  jwas_hip_mul_alpha_output(jwas_hip_ctx* ctx, int32_t trait, float* out_host);
 
 /* ---- the sweep ------------------------------------------------------------------------------ */
 /* Time every `stride`-th k_block_step launch of subsequent sweeps with HIP events on the

@@ -119,7 +119,7 @@ def get_genotypes(file, G=False, *, method="BayesC", Pi=0.0, estimatePi=True,
         pd = None
     if isinstance(file, str):                                                                 # :300-327
         with open(file) as fh:
-            row1 = [t for t in fh.readline().rstrip("\n").split(separator) if t != ""]
+            row1 = [t.strip().strip('"') for t in fh.readline().rstrip("\r\n").split(separator) if t != ""]
         ncol = len(row1)
         markerID = [str(t) for t in row1[1:]] if header else [str(i + 1) for i in range(ncol - 1)]
         tab = pd.read_csv(file, sep=separator, header=None, skiprows=1 if header else 0, dtype={0: str})
@@ -195,6 +195,7 @@ class Model:
         self.covVec = []
         self.MCMCinfo = None
         self.output = None
+        self.output_ID = False                 # outputEBV(model, IDs); False = all genotyped individuals
 
 
 def build_model(model_equations, R=False, *, df=4.0, estimate_variance=True, estimate_scale=False,
@@ -261,6 +262,11 @@ def build_model(model_equations, R=False, *, df=4.0, estimate_variance=True, est
         scale_R = False if _is_false(R) else np.asarray(R, dtype=np.float64) * (df - 1)
         df_R = df + nModels
     return Model(model_equations, traits, terms, M, Variance(Rv, np.float32(df_R), scale_R, estimate_variance, estimate_scale, constraint))
+
+
+def outputEBV(model, IDs):
+    """output.jl:60-70: individuals of interest for EBV output (default: all genotyped individuals)."""
+    model.output_ID = [str(i) for i in IDs]
 
 
 def set_covariate(model, *names):

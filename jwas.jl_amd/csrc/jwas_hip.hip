@@ -69,6 +69,8 @@ struct jwas_hip_ctx {
     double* prep_d = nullptr;           // [kPrepD][p] per-sweep marker constants (k_prepare)
     float*  prep_f = nullptr;           // [kPrepF][p]
     double* mt2_tab = nullptr;          // sampler II, <= 3 traits: [2^t * (t(t+1)/2 + 1)][p] state tables
+    float*  Xout = nullptr;             // output (EBV) rows: [p][ld_out] fp32, Mi.output_genotypes (tools4genotypes.jl:290-296)
+    int64_t n_out = 0, ld_out = 0;
     float*  var_vec = nullptr;
     double* pi_vec = nullptr;
     double* pi_mat = nullptr;
@@ -199,6 +201,7 @@ static void free_storage(jwas_hip_ctx* c)
     c->host_buf = nullptr;
     (void)hipFree(c->var_vec); (void)hipFree(c->pi_vec); (void)hipFree(c->pi_mat);
     c->var_vec = nullptr; c->pi_vec = c->pi_mat = nullptr;
+    (void)hipFree(c->Xout); c->Xout = nullptr; c->n_out = c->ld_out = 0;
 }
 
 void jwas_hip_destroy(jwas_hip_ctx* c)
@@ -818,6 +821,49 @@ int jwas_hip_mul_alpha(jwas_hip_ctx* c, int32_t trait, float* out)
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(tmp);
     if (e != hipSuccess) return fail(c, JWAS_HIP_EHIP, "jwas_hip_mul_alpha: %s", hipGetErrorString(e));
+    return JWAS_HIP_OK;
+}
+
+// Output rows: the reference keeps Mi.output_genotypes = Z_out * genotypes for mme.output_ID (all genotyped individuals by
+// default, input_data_validation.jl:150-154; tools4genotypes.jl:290-296) next to the training rows and forms
+// EBV = output_genotypes * alpha for every saved sample (output.jl:281-306).
+int jwas_hip_load_output_dense_f32(jwas_hip_ctx* c, const float* Xh, int64_t n_out, int64_t p, int64_t ld_host)
+{
+    NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
+    NEED(c, Xh, JWAS_HIP_EINVAL, "X_out is NULL");
+    NEED(c, HAVE_STORAGE(c), JWAS_HIP_ESTATE, "no genotype matrix loaded");
+    NEED(c, n_out >= 1, JWAS_HIP_EINVAL, "n_out must be >= 1 (got %lld)", (long long)n_out);
+    NEED(c, p == c->p, JWAS_HIP_EINVAL, "output genotypes have %lld markers, the training matrix %lld", (long long)p, (long long)c->p);
+    NEED(c, ld_host >= n_out, JWAS_HIP_EINVAL, "ld_host (%lld) must be >= n_out (%lld)", (long long)ld_host, (long long)n_out);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(c->Xout); c->Xout = nullptr; c->n_out = c->ld_out = 0;
+    const int64_t ld = (n_out + kSliceRows - 1) / kSliceRows * kSliceRows;
+    HIPCHK(c, hipMalloc(&c->Xout, (size_t)4 * ld * p));
+    c->n_out = n_out; c->ld_out = ld;
+    if (ld != n_out) HIPCHK(c, hipMemsetAsync(c->Xout, 0, (size_t)4 * ld * p, c->stream));
+    HIPCHK(c, hipMemcpy2DAsync(c->Xout, (size_t)4 * ld, Xh, (size_t)4 * ld_host, (size_t)4 * n_out, (size_t)p,
+                               hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return JWAS_HIP_OK;
+}
+
+int jwas_hip_mul_alpha_output(jwas_hip_ctx* c, int32_t trait, float* out)
+{
+    NEED(c, c && out, JWAS_HIP_EINVAL, "NULL argument");
+    NEED_TRAIT(c, trait);
+    NEED(c, c->Xout, JWAS_HIP_ESTATE, "jwas_hip_load_output_dense_f32 has not been called");
+    HIPCHK(c, hipSetDevice(c->device));
+    float* tmp = nullptr;
+    HIPCHK(c, hipMalloc(&tmp, sizeof(float) * c->ld_out));
+    DenseCols cx{c->Xout, c->ld_out, nullptr, 0};
+    hipLaunchKernelGGL((k_mul_alpha<DenseCols>), dim3((unsigned)(c->ld_out / kSliceRows)), dim3(256), 0, c->stream, cx, c->p,
+                       c->alpha + (size_t)trait * c->p, tmp);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(out, tmp, sizeof(float) * c->n_out, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return fail(c, JWAS_HIP_EHIP, "jwas_hip_mul_alpha_output: %s", hipGetErrorString(e));
     return JWAS_HIP_OK;
 }
 

@@ -269,6 +269,26 @@ class HipEngine:
         self._chk(self._L.jwas_hip_mul_alpha(self._h, int(trait), _ptr(out)))
         return out
 
+    def load_output_dense(self, X_out):
+        """Rows EBVs are reported for when they differ from the training rows (Mi.output_genotypes,
+        tools4genotypes.jl:290-296).  X_out: n_out x p float32."""
+        X_out = np.asarray(X_out)
+        if X_out.dtype != np.float32:
+            raise TypeError("the HIP path stores Float32 genotypes (double_precision=false)")
+        if X_out.ndim != 2:
+            raise ValueError("genotype matrix must be 2-D")
+        if not X_out.flags.f_contiguous:
+            X_out = np.asfortranarray(X_out)
+        n_out, p = X_out.shape
+        self._chk(self._L.jwas_hip_load_output_dense_f32(self._h, _ptr(X_out), n_out, p, n_out))
+        self.n_out = n_out
+
+    def mul_alpha_output(self, trait=0):
+        """EBV = output_genotypes * alpha (output.jl:281-306)."""
+        out = np.empty(getattr(self, "n_out", 0), dtype=np.float32)
+        self._chk(self._L.jwas_hip_mul_alpha_output(self._h, int(trait), _ptr(out)))
+        return out
+
     # -- the sweep -------------------------------------------------------------------------------
     def sweep(self, *, iteration, seed, vare, var_effect, pi=0.0, pi_classes=None, gamma=BAYESR_GAMMA,
               log_prior_states=None, var_effect_vec=None, pi_vec=None, pi_matrix=None, nreps=1,

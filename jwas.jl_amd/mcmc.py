@@ -143,8 +143,14 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
     complete = np.ones(len(ph), dtype=bool)
     for tr in model.lhsVec:
         complete &= np.isfinite(ph[tr].to_numpy(dtype=np.float64))
-    if t > 1 and not complete.all():
-        raise NotImplementedError("missing phenotypes in multi-trait analyses (residual imputation, residual.jl:15-73) stay on the reference")
+    if t > 1:
+        # individuals whose phenotypes are missing for ALL traits are removed (input_data_validation.jl:396-404);
+        # partially missing records need the reference's residual imputation (residual.jl:15-73)
+        anyobs = np.zeros(len(ph), dtype=bool)
+        for tr in model.lhsVec:
+            anyobs |= np.isfinite(ph[tr].to_numpy(dtype=np.float64))
+        if (anyobs & ~complete).any():
+            raise NotImplementedError("missing phenotypes in multi-trait analyses (residual imputation, residual.jl:15-73) stay on the reference")
     stream = getattr(Mi, "storage_mode", "dense") == "stream"
     if stream:
         # the packed payload goes from the file straight to HBM and is never re-ordered: like the reference's stream
@@ -164,6 +170,24 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         rows = np.array([geno_index[i] for i in ph[idcol]], dtype=np.int64)
         X = Mi.genotypes if (len(rows) == Mi.nObs and np.array_equal(rows, np.arange(Mi.nObs))) else np.asfortranarray(Mi.genotypes[rows, :])
         n, p = X.shape
+    # ---- individuals EBVs are reported for (check_outputID, input_data_validation.jl:143-196): all genotyped
+    # individuals unless outputEBV(model, IDs) named a list; IDs without genotypes are dropped with the reference's note
+    out_ids, out_rows, out_same = None, None, True
+    if outputEBV:
+        want = list(Mi.obsID) if getattr(model, "output_ID", False) is False else list(model.output_ID)
+        known = set(Mi.obsID)
+        if not all(i in known for i in want):
+            print("Testing individuals are not a subset of genotyped individuals (complete genomic data,non-single-step). "
+                  "Only output EBV for tesing individuals with genotypes.")
+            want = [i for i in want if i in known]
+        out_ids = want
+        out_same = out_ids == list(ph[idcol])             # exactly the training rows, same order: X itself
+        if not out_same:
+            if stream:
+                raise NotImplementedError("storage=:stream reports EBVs for the genotyped individuals in file order "
+                                          "(outputEBV(model, IDs) lists stay on the reference)")
+            gi = {g: i for i, g in enumerate(Mi.obsID)}
+            out_rows = np.array([gi[i] for i in out_ids], dtype=np.int64)
     with open(os.path.join(output_folder, "IDs_for_individuals_with_phenotypes.txt"), "w") as fh:
         fh.write("\n".join(ph[idcol]) + "\n")
     with open(os.path.join(output_folder, "IDs_for_individuals_with_genotypes.txt"), "w") as fh:
@@ -297,6 +321,8 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         engine.load_jgb2(Mi.stream_backend["prefix"])          # payload stays 2-bit packed in HBM
     else:
         engine.load_dense(X)                   # after alignment (tools4genotypes.jl:310-321)
+    if outputEBV and not out_same:             # Mi.output_genotypes = Z_out * genotypes (tools4genotypes.jl:290-296)
+        engine.load_output_dense(np.asfortranarray(Mi.genotypes[out_rows, :]))
     if invw is not None:
         engine.set_weights(invw)               # x'R^-1 x, X_b'R^-1 X_b, X_b'R^-1 r on the device (GibbsMats with Rinv)
     engine.setup_blocks(block_size, gram_mode)
@@ -336,7 +362,7 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
     run_sol, run_vare = _Running(sol), _Running(vare)
     run_varg = _Running(Gval) if method != "BayesB" else None
     run_pi = _Running(np.atleast_1d(np.asarray(pi_t if mega else pi, dtype=np.float64))) if Mi.estimatePi else None
-    ebv_run = [_Running(np.zeros(n)) for _ in range(t)] if outputEBV else None
+    ebv_run = [_Running(np.zeros(len(out_ids))) for _ in range(t)] if outputEBV else None
     name = Mi.name
     files = {}
 
@@ -462,7 +488,7 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
                     fh.write("\n")
             if outputEBV:
                 for kk in range(t):
-                    ebv_run[kk].add(engine.mul_alpha(kk), k)
+                    ebv_run[kk].add(engine.mul_alpha(kk) if out_same else engine.mul_alpha_output(kk), k)   # getEBV, output.jl:281-306
         if it % printout_frequency == 0 and it > burnin:
             print(f"\nPosterior means at iteration: {it}")
             print(f"Residual variance: {np.round(run_vare.mean, 6)}")
@@ -502,7 +528,7 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
     if outputEBV:
         for k, tr in enumerate(model.lhsVec):
             m = ebv_run[k].mean
-            out[f"EBV_{tr}"] = pd.DataFrame({"ID": list(ph[idcol]), "EBV": m, "PEV": np.abs(ebv_run[k].mean2 - m ** 2)})
+            out[f"EBV_{tr}"] = pd.DataFrame({"ID": out_ids, "EBV": m, "PEV": np.abs(ebv_run[k].mean2 - m ** 2)})
     for key, tab in out.items():                                         # JWAS.jl:480-482
         tab.to_csv(os.path.join(output_folder, key.replace(" ", "_") + ".txt"), index=False)
     out["_timing"] = {"wall_s": wall, "device_sweep_ms_total": t_sweep, "iterations": chain_length,

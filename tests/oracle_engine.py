@@ -120,6 +120,12 @@ class OracleEngine:
     def mul_alpha(self, trait=0):
         return (self.X.astype(np.float64) @ self.alpha[trait].astype(np.float64)).astype(np.float32)
 
+    def load_output_dense(self, X_out):
+        self.X_out = np.asarray(X_out, dtype=np.float32)
+
+    def mul_alpha_output(self, trait=0):
+        return (self.X_out.astype(np.float64) @ self.alpha[trait].astype(np.float64)).astype(np.float32)
+
     def sweep(self, *, iteration, seed, vare, var_effect, pi=0.0, pi_classes=None, gamma=O.GAMMA,
               log_prior_states=None, var_effect_vec=None, pi_vec=None, pi_matrix=None, nreps=1,
               marker_offset=0, independent_blocks=False):

@@ -199,3 +199,49 @@ print("NCCL_ONE_RANK_OK")
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "NCCL_ONE_RANK_OK" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
+
+
+def test_heldout_ebv_gpu_matches_oracle(tmp_path):
+    """Individuals with genotypes but no record: EBV = output_genotypes * alpha on the device
+    (jwas_hip_load_output_dense_f32 / jwas_hip_mul_alpha_output; output.jl:281-306, tools4genotypes.jl:290-296)."""
+    gdf, ph, d = _setup("BayesC", 0.95, n=330, p=700, seed=5)
+    ph = ph.copy()
+    held = np.arange(3, 330, 4)
+    ph.loc[held, "y1"] = np.nan
+    outs = {}
+    for tag, eng in (("orc", OracleEngine("lookahead")), ("hip", None)):
+        geno = api.get_genotypes(gdf, method="BayesC", Pi=0.95)
+        model = api.build_model("y1 = intercept + geno")
+        outs[tag] = api.runMCMC(model, ph, chain_length=120, burnin=20, seed=9, output_folder=str(tmp_path / tag),
+                                engine=eng, block_size=128, gram_mode="f64")
+    eo, eh = outs["orc"]["EBV_y1"], outs["hip"]["EBV_y1"]
+    assert list(eh["ID"]) == list(eo["ID"]) == list(gdf["ID"])
+    np.testing.assert_allclose(eh["EBV"], eo["EBV"], atol=1e-3)
+    np.testing.assert_allclose(eh["PEV"], eo["PEV"], atol=1e-3)
+    assert np.corrcoef(eh["EBV"].to_numpy()[held], d["y"][held])[0, 1] > 0.3
+
+
+def test_reference_cv_benchmark_heldout_accuracy(tmp_path):
+    """Statistical pin against the reference's OWN published output: its 5-fold cross-validation benchmark on its
+    packaged simulated_annotations data (benchmarks/simulated_annotations_multitrait_comparison.jl, cv mode; results in
+    benchmarks/reports/2026-04-11-simulated-annotations-cv-report.md): held-out cor(y, EBV), trait mean, BayesC_single
+    0.6424 and MT_BayesC_I 0.6397 (2 seeds x 5 folds).  Same protocol through this package, one seed here (the full
+    two-seed run: scripts/cv_simulated_annotations.py -> profiles/r01_cv_simulated_annotations.json: 0.6434 / 0.6394;
+    standard error of a fold mean ~0.015, fold partitions differ from the reference's)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "cv_sa", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "cv_simulated_annotations.py"))
+    cv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cv)
+    pheno = pd.read_csv(os.path.join(cv.DATA, "phenotypes_mt.csv"), dtype={"ID": str})
+    fold_of = cv.folds_for(list(pheno["ID"]), 5, 101)
+    rows = []
+    for case in ("BayesC_y1", "BayesC_y2", "MT_I"):
+        for fold in range(1, 6):
+            rows += cv.run_variant(case, pheno, 101, fold_of, fold, 1500, 500, 50, str(tmp_path))
+    df = pd.DataFrame(rows)
+    df["family"] = df["variant"].str.replace("_y1", "").str.replace("_y2", "")
+    got = {fam: float(g.groupby("trait")["cor"].mean().mean()) for fam, g in df.groupby("family")}
+    assert abs(got["BayesC"] - cv.REFERENCE["BayesC"]) < 0.04, got
+    assert abs(got["MT_I"] - cv.REFERENCE["MT_I"]) < 0.04, got

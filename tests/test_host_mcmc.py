@@ -119,8 +119,9 @@ def test_runmcmc_recovers_signal_and_writes_outputs(tmp_path, method, Pi):
     top = set(me.reindex(me["Estimate"].abs().sort_values(ascending=False).index)["Marker_ID"].head(8))
     assert len(top & causal_ids) >= 3
     ebv = out["EBV_y1"]
-    assert list(ebv.columns) == ["ID", "EBV", "PEV"] and list(ebv["ID"]) == ids[::-1]
-    assert np.corrcoef(ebv["EBV"], ph["y1"])[0, 1] > 0.5
+    # EBVs are reported for mme.output_ID = all genotyped individuals, in genotype order (input_data_validation.jl:150-154)
+    assert list(ebv.columns) == ["ID", "EBV", "PEV"] and list(ebv["ID"]) == ids
+    assert np.corrcoef(ebv["EBV"], d["y"])[0, 1] > 0.5
     assert 0 < float(out["residual variance"]["Estimate"][0]) < 2 * float(np.var(d["y"]))
     for f in ("marker_effects_geno.txt", "residual_variance.txt", "location_parameters.txt", "EBV_y1.txt",
               "MCMC_samples_residual_variance.txt", "MCMC_samples_marker_effects_geno_y1.txt",
@@ -332,3 +333,38 @@ def test_config1_plumbing_on_the_oracle(tmp_path, config1_data):
     h2 = 1 - float(out["residual variance"]["Estimate"][0]) / float(np.var(d["y"]))
     assert 0.25 < h2 < 0.75
     assert np.corrcoef(out["EBV_y1"]["EBV"], ph["y1"])[0, 1] > 0.6
+
+
+def test_ebv_for_individuals_without_records_and_outputEBV_list(tmp_path):
+    """Held-out prediction, the reference's standard use: individuals with genotypes but no phenotype get EBVs
+    (default output_ID = all genotyped individuals, input_data_validation.jl:150-154; Mi.output_genotypes,
+    tools4genotypes.jl:290-296); outputEBV(model, IDs) restricts the list (output.jl:60-70) and drops IDs without
+    genotypes (input_data_validation.jl:181-186)."""
+    d = make_dataset(n=300, p=200, ncausal=8, seed=77, center=False)
+    ids = [f"id{i}" for i in range(300)]
+    gdf = pd.DataFrame(d["raw"], columns=[f"snp{j}" for j in range(200)])
+    gdf.insert(0, "ID", ids)
+    y = d["y"].astype(np.float64).copy()
+    held = np.arange(0, 300, 5)
+    y_masked = y.copy()
+    y_masked[held] = np.nan
+    ph = pd.DataFrame({"ID": ids, "y1": y_masked})
+    geno = api.get_genotypes(gdf, method="BayesC", Pi=0.9)
+    model = api.build_model("y1 = intercept + geno")
+    out = api.runMCMC(model, ph, chain_length=200, burnin=40, seed=3, output_folder=str(tmp_path / "a"),
+                      engine=OracleEngine("block"), block_size=64)
+    ebv = out["EBV_y1"]
+    assert list(ebv["ID"]) == ids                                   # all genotyped individuals, genotype order
+    assert np.corrcoef(ebv["EBV"].to_numpy()[held], y[held])[0, 1] > 0.3          # held-out prediction
+    # EBV of a training individual = its row of X times the posterior mean effects (linearity)
+    me = out["marker effects geno"]["Estimate"].to_numpy(dtype=np.float64)
+    np.testing.assert_allclose(ebv["EBV"].to_numpy(), np.asarray(geno.genotypes, dtype=np.float64) @ me, atol=2e-3)
+
+    geno = api.get_genotypes(gdf, method="BayesC", Pi=0.9)
+    model = api.build_model("y1 = intercept + geno")
+    api.outputEBV(model, ["id5", "id0", "nobody", "id7"])
+    out2 = api.runMCMC(model, ph, chain_length=200, burnin=40, seed=3, output_folder=str(tmp_path / "b"),
+                       engine=OracleEngine("block"), block_size=64)
+    assert list(out2["EBV_y1"]["ID"]) == ["id5", "id0", "id7"]
+    full = ebv.set_index("ID")["EBV"]
+    np.testing.assert_allclose(out2["EBV_y1"]["EBV"].to_numpy(), full.loc[["id5", "id0", "id7"]].to_numpy(), atol=1e-5)
