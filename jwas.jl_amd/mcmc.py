@@ -104,6 +104,34 @@ def pick_block_size(n_events, p, small=512, large=1024):
     return large if n_events < ADAPTIVE_CHANGE_FRACTION * p else small
 
 
+def _impute_missing_residuals(res, observed, R0, rng):
+    """sampleMissingResiduals (residual.jl:52-73), in place on the per-trait residual vectors `res`: for every missing
+    pattern the missing residuals are drawn from their conditional distribution given the observed ones,
+    e_m | e_o ~ N(Rc Ro^-1 e_o, Rmm - Rc Ro^-1 Rc').  Returns the per-record inverse residual covariance of mkRi/getRi
+    (residual.jl:2-44): inv(R0[o, o]) embedded in a t x t matrix of zeros."""
+    n, t = observed.shape
+    Ri_rows = np.empty((n, t, t))
+    codes = observed @ (1 << np.arange(t))
+    full = (1 << t) - 1
+    for code in np.unique(codes):
+        rows = np.nonzero(codes == code)[0]
+        o = np.array([(code >> k) & 1 for k in range(t)], dtype=bool)
+        Ro_inv = np.linalg.inv(R0[np.ix_(o, o)])
+        RZ = np.zeros((t, t))
+        RZ[np.ix_(o, o)] = Ro_inv
+        Ri_rows[rows] = RZ
+        if code == full:
+            continue
+        m = ~o
+        Rc = R0[np.ix_(m, o)]
+        U = np.linalg.cholesky(R0[np.ix_(m, m)] - Rc @ Ro_inv @ Rc.T).T          # upper factor, as cholesky(...).U
+        eo = np.stack([res[k][rows] for k in np.nonzero(o)[0]], axis=1)          # rows x n_obs
+        em = eo @ Ro_inv @ Rc.T + rng.standard_normal((len(rows), int(m.sum()))) @ U
+        for c, k in enumerate(np.nonzero(m)[0]):
+            res[k][rows] = em[:, c]
+    return Ri_rows
+
+
 def _gibbs(A, x, b, rng, vare=None):
     """One sweep of the single-site Gibbs sampler on the MME (iterative_solver/solver.jl:143-162)."""
     for i in range(len(x)):
@@ -149,8 +177,13 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         anyobs = np.zeros(len(ph), dtype=bool)
         for tr in model.lhsVec:
             anyobs |= np.isfinite(ph[tr].to_numpy(dtype=np.float64))
-        if (anyobs & ~complete).any():
-            raise NotImplementedError("missing phenotypes in multi-trait analyses (residual imputation, residual.jl:15-73) stay on the reference")
+        if (anyobs & ~complete).any() and not missing_phenotypes:
+            raise ValueError("phenotypes are missing for some traits of some individuals; missing_phenotypes=false does not allow that")
+        if (anyobs & ~complete).any() and mega:
+            raise NotImplementedError("missing phenotypes with constraint=true stay on the reference")
+        usable = anyobs                          # partially observed records stay; their residuals are imputed every iteration
+    else:
+        usable = complete
     stream = getattr(Mi, "storage_mode", "dense") == "stream"
     if stream:
         # the packed payload goes from the file straight to HBM and is never re-ordered: like the reference's stream
@@ -163,7 +196,7 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         n, p = Mi.nObs, Mi.nMarkers
     else:
         geno_index = {g: i for i, g in enumerate(Mi.obsID)}
-        keep = complete & ph[idcol].isin(geno_index).to_numpy()
+        keep = usable & ph[idcol].isin(geno_index).to_numpy()
         ph = ph.loc[keep].reset_index(drop=True)
         if len(ph) == 0:
             raise ValueError("no individual has both phenotypes and genotypes")
@@ -193,6 +226,10 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
     with open(os.path.join(output_folder, "IDs_for_individuals_with_genotypes.txt"), "w") as fh:
         fh.write("\n".join(Mi.obsID) + "\n")
     Y = np.stack([ph[tr].to_numpy(dtype=np.float32) for tr in model.lhsVec])       # t x n
+    observed = np.isfinite(Y).T                                                     # n x t: mme.missingPattern (residual.jl:17-21)
+    has_missing = not observed.all()
+    phenovar = np.array([np.var(Y[k][observed[:, k]].astype(np.float64), ddof=1) for k in range(t)])
+    Y = np.where(np.isfinite(Y), Y, np.float32(0)).astype(np.float32)               # imputed before first use (residual.jl:52-73)
     invw = None
     if heterogeneous_residuals:                                           # build_MME.jl:305-310
         if "weights" not in ph.columns:
@@ -203,7 +240,6 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
     w64 = np.ones(len(ph)) if invw is None else invw.astype(np.float64)
 
     # ---- default priors (input_data_validation.jl:296-350, tools4genotypes.jl:353-478, build_MME.jl:128-141)
-    phenovar = np.array([np.var(Y[k].astype(np.float64), ddof=1) for k in range(t)])
     varg = np.diag(phenovar) * 0.5
     vare0 = np.diag(phenovar) * 0.5
     R = model.R
@@ -397,13 +433,32 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
                 r -= Xf[0] @ sol
                 engine.set_residual(r.astype(np.float32), 0)
             else:
-                Rinv = np.linalg.inv(np.asarray(vare, dtype=np.float64))
-                rr = [engine.get_residual(k).astype(np.float64) + Xf[k] @ sol[off[k]:off[k + 1]] for k in range(t)]
-                A = np.block([[Rinv[k, l] * lhs_blocks[k][l] for l in range(t)] for k in range(t)])
-                b = np.concatenate([Xf[k].T @ (w64 * sum(Rinv[k, l] * rr[l] for l in range(t))) for k in range(t)])
+                R0 = np.asarray(vare, dtype=np.float64)
+                Rinv = np.linalg.inv(R0)
+                res = [engine.get_residual(k).astype(np.float64) for k in range(t)]
+                if has_missing:
+                    # residuals of the missing records are imputed from the observed ones (sampleMissingResiduals,
+                    # residual.jl:52-73) and the location-parameter equations weight every record with the inverse
+                    # of the OBSERVED block of R only (mkRi / getRi, residual.jl:2-44)
+                    Ri_rows = _impute_missing_residuals(res, observed, R0, rng)
+                    if invw is not None:
+                        Ri_rows = Ri_rows * w64[:, None, None]
+                    rr = [res[k] + Xf[k] @ sol[off[k]:off[k + 1]] for k in range(t)]
+                    A = np.block([[Xf[k].T @ (Ri_rows[:, k, l][:, None] * Xf[l]) for l in range(t)] for k in range(t)])
+                    b = np.concatenate([Xf[k].T @ sum(Ri_rows[:, k, l] * rr[l] for l in range(t)) for k in range(t)])
+                else:
+                    rr = [res[k] + Xf[k] @ sol[off[k]:off[k + 1]] for k in range(t)]
+                    A = np.block([[Rinv[k, l] * lhs_blocks[k][l] for l in range(t)] for k in range(t)])
+                    b = np.concatenate([Xf[k].T @ (w64 * sum(Rinv[k, l] * rr[l] for l in range(t))) for k in range(t)])
                 _gibbs(A, sol, b, rng, None)
                 for k in range(t):
                     engine.set_residual((rr[k] - Xf[k] @ sol[off[k]:off[k + 1]]).astype(np.float32), k)
+
+        elif t > 1 and has_missing:                                       # no location parameters: imputation only
+            res = [engine.get_residual(k).astype(np.float64) for k in range(t)]
+            _impute_missing_residuals(res, observed, np.asarray(vare, dtype=np.float64), rng)
+            for k in range(t):
+                engine.set_residual(res[k].astype(np.float32), k)
 
         # 2. marker effects (DEVICE)
         kw = dict(iteration=it, seed=seed_int, vare=vare, nreps=nreps)

@@ -368,3 +368,73 @@ def test_ebv_for_individuals_without_records_and_outputEBV_list(tmp_path):
     assert list(out2["EBV_y1"]["ID"]) == ["id5", "id0", "id7"]
     full = ebv.set_index("ID")["EBV"]
     np.testing.assert_allclose(out2["EBV_y1"]["EBV"].to_numpy(), full.loc[["id5", "id0", "id7"]].to_numpy(), atol=1e-5)
+
+
+def test_impute_missing_residuals_conditional_moments():
+    """sampleMissingResiduals (residual.jl:52-73): E[e_m | e_o] = Rc Ro^-1 e_o, Var = Rmm - Rc Ro^-1 Rc';
+    the per-record weights are inv(R0[o,o]) embedded in zeros (getRi, residual.jl:2-11)."""
+    from jwas_jl_amd.mcmc import _impute_missing_residuals
+    rng = np.random.default_rng(0)
+    R0 = np.array([[2.0, 0.8, 0.3], [0.8, 1.5, -0.4], [0.3, -0.4, 1.0]])
+    n = 60000
+    observed = np.ones((n, 3), dtype=bool)
+    observed[: n // 2, 1] = False                    # pattern (1,0,1)
+    observed[n // 2:, 0] = False
+    observed[n // 2:, 2] = False                     # pattern (0,1,0)
+    e = [np.full(n, 0.7), np.full(n, -0.2), np.full(n, 1.1)]
+    res = [v.copy() for v in e]
+    Ri = _impute_missing_residuals(res, observed, R0, rng)
+    # observed entries untouched
+    assert np.array_equal(res[0][: n // 2], e[0][: n // 2]) and np.array_equal(res[1][n // 2:], e[1][n // 2:])
+    o = np.array([True, False, True])
+    Ro_inv = np.linalg.inv(R0[np.ix_(o, o)])
+    Rc = R0[np.ix_(~o, o)]
+    mean = (Rc @ Ro_inv @ np.array([0.7, 1.1]))[0]
+    var = (R0[1, 1] - Rc @ Ro_inv @ Rc.T)[0, 0]
+    assert abs(res[1][: n // 2].mean() - mean) < 4 * np.sqrt(var / (n // 2))
+    assert abs(res[1][: n // 2].var() - var) < 0.03 * var
+    # pattern (0,1,0): two missing traits, joint conditional covariance
+    o2 = np.array([False, True, False])
+    Rc2 = R0[np.ix_(~o2, o2)]
+    cov2 = R0[np.ix_(~o2, ~o2)] - Rc2 @ Rc2.T / R0[1, 1]
+    got = np.cov(np.stack([res[0][n // 2:], res[2][n // 2:]]))
+    np.testing.assert_allclose(got, cov2, atol=0.03)
+    want = np.zeros((3, 3)); want[np.ix_(o, o)] = Ro_inv
+    np.testing.assert_allclose(Ri[0], want)
+    want2 = np.zeros((3, 3)); want2[1, 1] = 1 / R0[1, 1]
+    np.testing.assert_allclose(Ri[-1], want2)
+
+
+def test_multitrait_with_partially_missing_records(tmp_path):
+    """The reference's multi-trait tests run on records with missing traits (demo_7animals: a5 has y1 but no y2;
+    test_multitrait_mcmc.jl:111-128): such records stay in the analysis, their missing residuals are imputed."""
+    d = make_dataset(n=260, p=150, ncausal=6, seed=12, center=False)
+    ids = [f"id{i}" for i in range(260)]
+    gdf = pd.DataFrame(d["raw"], columns=[f"snp{j}" for j in range(150)])
+    gdf.insert(0, "ID", ids)
+    rng = np.random.default_rng(5)
+    y1 = d["y"].astype(np.float64)
+    y2 = 0.6 * y1 + 0.8 * rng.standard_normal(260)
+    y1m, y2m = y1.copy(), y2.copy()
+    y2m[::3] = np.nan                        # partially missing
+    y1m[1::7] = np.nan
+    both = np.arange(5, 260, 41)
+    y1m[both] = np.nan; y2m[both] = np.nan   # no record at all: dropped from the analysis, still gets an EBV
+    ph = pd.DataFrame({"ID": ids, "y1": y1m, "y2": y2m})
+    geno = api.get_genotypes(gdf, np.eye(2) * 0.5, method="BayesC", Pi={(0.0, 0.0): 0.7, (1.0, 0.0): 0.1, (0.0, 1.0): 0.1, (1.0, 1.0): 0.1})
+    model = api.build_model("y1 = intercept + geno\ny2 = intercept + geno", np.eye(2))
+    out = api.runMCMC(model, ph, chain_length=150, burnin=30, seed=3, output_folder=str(tmp_path / "mt"),
+                      engine=OracleEngine("block"), block_size=64)
+    assert len(out["residual variance"]) == 4
+    assert np.isfinite(out["residual variance"]["Estimate"]).all()
+    n_used = len(open(tmp_path / "mt" / "IDs_for_individuals_with_phenotypes.txt").read().split())
+    assert n_used == int((~(np.isnan(y1m) & np.isnan(y2m))).sum()) < 260 - len(both) + 1
+    ebv = out["EBV_y2"]
+    assert list(ebv["ID"]) == ids
+    miss2 = np.isnan(y2m)
+    assert np.corrcoef(ebv["EBV"].to_numpy()[miss2], y2[miss2])[0, 1] > 0.2      # prediction of the hidden records
+    with pytest.raises(ValueError, match="missing_phenotypes=false"):
+        geno = api.get_genotypes(gdf, np.eye(2) * 0.5, method="BayesC")
+        model = api.build_model("y1 = intercept + geno\ny2 = intercept + geno", np.eye(2))
+        api.runMCMC(model, ph, chain_length=5, seed=3, output_folder=str(tmp_path / "mt2"), engine=OracleEngine("block"),
+                    block_size=64, missing_phenotypes=False)

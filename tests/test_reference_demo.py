@@ -121,12 +121,41 @@ def test_other_single_trait_methods_short_run(tmp_path, method):
 
 
 @pytest.mark.gpu
-def test_multi_trait_bayesc_short_run(tmp_path):
-    """y1, y2 with missing records (a5 has no y2): multi-trait BayesC on the demo data (runtests.jl multi-trait sets)."""
-    geno = api.get_genotypes(GENO, np.eye(2), separator=",", method="BayesC")
-    model = api.build_model("y1 = intercept + geno\ny2 = intercept + geno", np.eye(2))
-    ph = _phenotypes().dropna(subset=["y1", "y2"])
-    out = api.runMCMC(model, ph, chain_length=50, burnin=10, output_folder=str(tmp_path / "mt"), seed=123)
+@pytest.mark.parametrize("sampler", ["I", "II"])
+def test_multi_trait_bayesc_short_run(tmp_path, sampler):
+    """test_multitrait_mcmc.jl:111-128, 239-265: multi-trait BayesC on the demo data as it is -- a5 has y1 but no y2
+    (its missing residual is imputed every iteration, residual.jl:52-73); a2 is not genotyped, a6-a8 have no records."""
+    G = np.array([[1.0, 0.5], [0.5, 1.0]])
+    R = np.array([[1.0, 0.5], [0.5, 1.0]])
+    geno = api.get_genotypes(GENO, G, separator=",", method="BayesC", multi_trait_sampler=sampler)
+    assert geno.multi_trait_sampler == sampler
+    model = api.build_model("y1 = intercept + geno\ny2 = intercept + geno", R)
+    out = api.runMCMC(model, _phenotypes(), chain_length=100, burnin=20, output_samples_frequency=10,
+                      output_folder=str(tmp_path / "mt"), seed=123)
+    assert "location parameters" in out and "residual variance" in out and "marker effects geno" in out
+    assert len(out["residual variance"]) == 4                     # 2x2 covariance flattened
     me = out["marker effects geno"]
-    assert len(me) == 2 * geno.nMarkers
-    assert set(me["Trait"]) == {"y1", "y2"}
+    assert len(me) == 2 * geno.nMarkers and set(me["Trait"]) == {"y1", "y2"}
+    used = open(tmp_path / "mt" / "IDs_for_individuals_with_phenotypes.txt").read().split()
+    assert used == ["a1", "a3", "a4", "a5"]
+    assert list(out["EBV_y2"]["ID"]) == list(geno.obsID)           # EBVs for all 7 genotyped animals
+
+
+def test_multi_trait_sampler_default_and_auto():
+    """test_multitrait_mcmc.jl:130-138"""
+    G = np.array([[1.0, 0.5], [0.5, 1.0]])
+    assert api.get_genotypes(GENO, G, separator=",", method="BayesC").multi_trait_sampler == "I"
+    assert api.get_genotypes(GENO, G, separator=",", method="BayesC", multi_trait_sampler="auto").multi_trait_sampler == "auto"
+
+
+@pytest.mark.gpu
+def test_ebv_output_with_genotypes(tmp_path):
+    """test_output_ebv.jl:9-31"""
+    geno = api.get_genotypes(GENO, 1.0, separator=",", method="BayesC")
+    model = api.build_model("y1 = intercept + geno", 1.0)
+    api.outputEBV(model, geno.obsID)
+    out = api.runMCMC(model, _phenotypes(), chain_length=100, burnin=20, output_samples_frequency=10, outputEBV=True,
+                      output_folder=str(tmp_path / "ebv"), seed=123)
+    ebv = out["EBV_y1"]
+    assert list(ebv.columns) == ["ID", "EBV", "PEV"] and len(ebv) == 7
+    assert (ebv["PEV"] >= 0).all()
