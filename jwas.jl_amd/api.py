@@ -313,6 +313,11 @@ def runMCMC(model, df, *, heterogeneous_residuals=False, chain_length=100, start
         raise ValueError("memory_guard must be :error, :warn or :off.")
     if output_samples_frequency is None:
         output_samples_frequency = chain_length // 1000 if chain_length > 1000 else 1          # :168
+    if int(output_samples_frequency) <= 0:
+        raise ValueError("output_samples_frequency should be an integer > 0.")                # input_data_validation.jl:14-16
+    for Mi in model.M:                                                                        # :19-23
+        if Mi.method not in ("BayesL", "BayesC", "BayesB", "BayesA", "BayesR", "RR-BLUP", "GBLUP"):
+            raise ValueError(f"{Mi.method} is not available in JWAS. Please read the documentation.")
     if printout_frequency is None:
         printout_frequency = chain_length + 1
     # an existing output folder is never overwritten (JWAS.jl:255-262)

@@ -75,6 +75,22 @@ def test_single_precision_default_and_double_refused():
         api.get_genotypes(GENO, 1.0, separator=",", double_precision=True)
 
 
+# ---- "Input Validation" (test/unit/test_input_validation.jl:9-40) ---------------------------------------------
+def test_invalid_bayesian_method(tmp_path):
+    geno = api.get_genotypes(GENO, 1.0, separator=",", method="BayesC")
+    geno.method = "InvalidMethod"
+    model = api.build_model("y1 = intercept + geno", 1.0)
+    with pytest.raises(ValueError, match="is not available in JWAS"):
+        api.runMCMC(model, _phenotypes(), chain_length=10, output_folder=str(tmp_path / "x"), seed=123)
+
+
+def test_output_samples_frequency_validation(tmp_path):
+    geno = api.get_genotypes(GENO, 1.0, separator=",", method="BayesC")
+    model = api.build_model("y1 = intercept + geno", 1.0)
+    with pytest.raises(ValueError, match="output_samples_frequency should be an integer > 0"):
+        api.runMCMC(model, _phenotypes(), chain_length=10, output_samples_frequency=0, output_folder=str(tmp_path / "x"), seed=123)
+
+
 # ---- "MCMC Functionality" (runtests.jl:258-320), "Model frequency" (:333-349) -------------------------------
 @pytest.mark.gpu
 def test_single_trait_bayesc_short_run(tmp_path):
