@@ -149,10 +149,12 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
     Mi = model.M[0]
     t = model.nModels
     method = Mi.method
-    if t > 1 and method != "BayesC":
+    if t > 1 and method not in ("BayesC", "RR-BLUP"):
         raise NotImplementedError("multi-trait device path implements BayesC (Gibbs samplers I, II and the constraint=true "
                                   "megaBayesABC! path); other methods stay on the reference")
     mega = t > 1 and bool(Mi.G.constraint)                              # megaBayesABC! (MCMC_BayesianAlphabet.jl:233-234)
+    if mega and method == "RR-BLUP":
+        raise NotImplementedError("multi-trait RR-BLUP with constraint=true stays on the reference")
     if t == 1 and (Mi.G.constraint or model.R.constraint):
         raise ValueError("constraint==true is for multi-trait only")     # input_data_validation.jl:534-535,550-551
     if not isinstance(starting_value, bool) or starting_value:
@@ -270,6 +272,14 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         pi = np.array([0.95, 0.03, 0.015, 0.005])
     if method == "BayesA":                                             # input_data_validation.jl:33-36
         method, pi, Mi.estimatePi = "BayesB", 0.0, False
+    if method == "RR-BLUP":                                            # input_data_validation.jl:24-31
+        if not (np.isscalar(pi) and (pi is False or pi == 0.0)):
+            print("RR-BLUP runs with π = false.")
+        elif Mi.estimatePi:
+            print("RR-BLUP runs with estimatePi = false.")
+        # the device's BayesC update with pi = 0 (every marker included) is RR-BLUP's full conditional (api.SUPPORTED_METHODS)
+        method, Mi.estimatePi = "BayesC", False
+        pi = 0.0 if t == 1 else np.eye(1, 1 << t, (1 << t) - 1).ravel()
     if Mi.G.val is False:
         Mi.G.val = genetic2marker(Mi, pi, method, t)
         if (t == 1 and not Mi.G.val > 0) or (t > 1 and np.any(np.linalg.eigvalsh(Mi.G.val) <= 0)):

@@ -438,3 +438,23 @@ def test_multitrait_with_partially_missing_records(tmp_path):
         model = api.build_model("y1 = intercept + geno\ny2 = intercept + geno", np.eye(2))
         api.runMCMC(model, ph, chain_length=5, seed=3, output_folder=str(tmp_path / "mt2"), engine=OracleEngine("block"),
                     block_size=64, missing_phenotypes=False)
+
+
+def test_rrblup_is_bayesc_with_all_markers_in_the_model(tmp_path):
+    """RR-BLUP runs on the device's BayesC path with pi = 0 fixed (same full conditionals: BayesC0L.jl:20-47 vs
+    BayesABC.jl:24-58 with probDelta1 = 1; variance update with nloci = nMarkers, variance_components.jl:160-162)."""
+    d = make_dataset(n=200, p=120, ncausal=6, seed=8, center=False)
+    ids = [f"id{i}" for i in range(200)]
+    gdf = pd.DataFrame(d["raw"], columns=[f"snp{j}" for j in range(120)])
+    gdf.insert(0, "ID", ids)
+    ph = pd.DataFrame({"ID": ids, "y1": d["y"]})
+    outs = {}
+    for tag, kw in (("rr", dict(method="RR-BLUP")), ("c0", dict(method="BayesC", Pi=0.0, estimatePi=False))):
+        geno = api.get_genotypes(gdf, **kw)
+        model = api.build_model("y1 = intercept + geno")
+        outs[tag] = api.runMCMC(model, ph, chain_length=60, burnin=10, seed=4, output_folder=str(tmp_path / tag),
+                                engine=OracleEngine("block"), block_size=64)
+    np.testing.assert_array_equal(outs["rr"]["marker effects geno"]["Estimate"].to_numpy(),
+                                  outs["c0"]["marker effects geno"]["Estimate"].to_numpy())
+    assert (outs["rr"]["marker effects geno"]["Model_Frequency"] == 1.0).all()
+    assert "pi_geno" not in outs["rr"]

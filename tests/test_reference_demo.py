@@ -37,13 +37,13 @@ def test_load_from_file_with_header():
     np.testing.assert_allclose(np.asarray(geno.alleleFreq).ravel(), (raw.mean(0) / 2)[keep], atol=1e-6)
 
 
-@pytest.mark.parametrize("method", ["BayesA", "BayesB", "BayesC", "BayesR"])
+@pytest.mark.parametrize("method", ["BayesA", "BayesB", "BayesC", "BayesR", "RR-BLUP"])
 def test_load_with_device_methods(method):
     geno = api.get_genotypes(GENO, 1.0, separator=",", method=method)
     assert geno.method == method and geno.nMarkers > 0
 
 
-@pytest.mark.parametrize("method", ["RR-BLUP", "BayesL", "GBLUP"])
+@pytest.mark.parametrize("method", ["BayesL", "GBLUP"])
 def test_methods_off_the_device_path_are_refused_loudly(method):
     """The reference loads these too (runtests.jl:213-220); they are outside the hot path built here and must not
     silently fall back to anything."""
@@ -115,10 +115,22 @@ def test_single_trait_bayesc_short_run(tmp_path):
 
 
 @pytest.mark.gpu
+def test_output_folder_creation_rrblup(tmp_path):
+    """runtests.jl:283-297"""
+    geno = api.get_genotypes(GENO, 1.0, separator=",", method="RR-BLUP")
+    model = api.build_model("y1 = intercept + geno", 1.0)
+    folder = tmp_path / "test_results_temp"
+    out = api.runMCMC(model, _phenotypes(), chain_length=50, output_folder=str(folder), seed=123)
+    assert os.path.isdir(folder)
+    assert os.path.isfile(folder / "location_parameters.txt") and os.path.isfile(folder / "residual_variance.txt")
+    assert (out["marker effects geno"]["Model_Frequency"] == 1.0).all()        # every marker is in the model
+
+
+@pytest.mark.gpu
 def test_reproducibility_with_seed(tmp_path):
     outs = []
     for tag in ("temp1", "temp2"):
-        geno = api.get_genotypes(GENO, 1.0, separator=",", method="BayesC")
+        geno = api.get_genotypes(GENO, 1.0, separator=",", method="RR-BLUP")
         model = api.build_model("y1 = intercept + geno", 1.0)
         outs.append(api.runMCMC(model, _phenotypes(), chain_length=50, output_folder=str(tmp_path / tag), seed=999))
     assert abs(outs[0]["residual variance"]["Estimate"][0] - outs[1]["residual variance"]["Estimate"][0]) <= 1e-10
