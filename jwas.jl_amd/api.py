@@ -23,7 +23,9 @@ from .mcmc import run_chain
 # RR-BLUP: every marker is in the model with one common effect variance -- the same full conditionals as BayesC with
 # pi = 0 fixed (BayesL! with gammaArray = [1.0], BayesC0L.jl:20-47, vs bayesabc_update_marker! with probDelta1 = 1;
 # variance update with nloci = nMarkers, variance_components.jl:160-162), so it runs on the device's BayesC path
-SUPPORTED_METHODS = ("BayesA", "BayesB", "BayesC", "BayesR", "RR-BLUP")
+# BayesL (single trait): BayesL!'s update is the device's BayesB update with pi = 0 and var_j = G*gamma_j; the gamma_j
+# Metropolis-Hastings step stays on the host (mcmc.py)
+SUPPORTED_METHODS = ("BayesA", "BayesB", "BayesC", "BayesR", "RR-BLUP", "BayesL")
 BAYESR_DEFAULT_PI = np.array([0.95, 0.03, 0.015, 0.005])      # tools4genotypes.jl:375-377
 BAYESR_GAMMA = np.array([0.0, 0.01, 0.1, 1.0])                # JWAS.jl:12
 

@@ -272,6 +272,18 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         pi = np.array([0.95, 0.03, 0.015, 0.005])
     if method == "BayesA":                                             # input_data_validation.jl:33-36
         method, pi, Mi.estimatePi = "BayesB", 0.0, False
+    lasso = method == "BayesL"
+    if lasso:
+        # Bayesian LASSO (BayesL!, BayesC0L.jl:25-47): every marker in the model, effect variance G*gamma_j with the
+        # gamma_j updated by Metropolis-Hastings on the host (sampleGammaArray!, variance_components.jl:191-203).  Its full
+        # conditional lhs = x'x + (vare/G)/gamma_j is the device's BayesB update with pi = 0 and var_j = G*gamma_j.
+        if t > 1:
+            raise NotImplementedError("multi-trait BayesL stays on the reference")
+        if not (np.isscalar(pi) and (pi is False or pi == 0.0)):
+            print("BayesL runs with π = false.")                        # input_data_validation.jl:24-31
+        elif Mi.estimatePi:
+            print("BayesL runs with estimatePi = false.")
+        method, pi, Mi.estimatePi = "BayesB", 0.0, False
     if method == "RR-BLUP":                                            # input_data_validation.jl:24-31
         if not (np.isscalar(pi) and (pi is False or pi == 0.0)):
             print("RR-BLUP runs with π = false.")
@@ -395,8 +407,14 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
 
     vare = np.float32(R.val) if t == 1 else np.asarray(R.val, dtype=np.float32)
     Gval = np.float32(Mi.G.val) if t == 1 else np.asarray(Mi.G.val, dtype=np.float32)
-    if method == "BayesB":
+    if lasso:                                                           # MCMC_BayesianAlphabet.jl:70-81
+        Gval = np.float32(Gval / 8)
+        Mi.G.scale = Mi.G.scale / 8
+        gamma_l = rng.gamma(1.0, 8.0, size=p)
+        Gvec = (np.float64(Gval) * gamma_l).astype(np.float32)
+    elif method == "BayesB":
         Gvec = np.full(p, Gval, dtype=np.float32)                       # MCMC_BayesianAlphabet.jl:67-69
+    pervar = method == "BayesB" and not lasso                           # per-marker variances, no common variance to report
     if t == 1 and method in ("BayesC", "BayesB") and np.ndim(pi) == 0:
         pi = float(pi)
     if t > 1:
@@ -406,7 +424,7 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
 
     # ---- accumulators and sample files (output.jl:320-437)
     run_sol, run_vare = _Running(sol), _Running(vare)
-    run_varg = _Running(Gval) if method != "BayesB" else None
+    run_varg = _Running(Gval) if not pervar else None
     run_pi = _Running(np.atleast_1d(np.asarray(pi_t if mega else pi, dtype=np.float64))) if Mi.estimatePi else None
     ebv_run = [_Running(np.zeros(len(out_ids))) for _ in range(t)] if outputEBV else None
     name = Mi.name
@@ -419,7 +437,7 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
 
     rnames = [f"{a}_{b}" for a in model.lhsVec for b in model.lhsVec]
     _open("residual_variance", rnames if t > 1 else [model.lhsVec[0]])
-    if method != "BayesB":
+    if not pervar:
         _open(f"marker_effects_variances_{name}", rnames if t > 1 else ["1"])
     if Mi.estimatePi:
         npi = t if mega else np.size(pi)
@@ -513,6 +531,15 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
                 Gval = np.asarray(invwishart.rvs(df=Gdf + p, scale=(S + S.T) / 2, random_state=rng), dtype=np.float32).reshape(t, t)
             elif method == "BayesR":
                 Gval = np.float32((st["bayesr_ssq"] + Gdf * Mi.G.scale) / rng.chisquare(st["bayesr_nnz"] + Gdf))
+            elif lasso:                                                 # variance_components.jl:152-166,191-203
+                a64 = engine.get_state(0)[0].astype(np.float64)
+                Gval = np.float32((np.dot(a64 / gamma_l, a64) + Gdf * Mi.G.scale) / rng.chisquare(p + Gdf))
+                Q = a64 * a64 / np.float64(Gval)
+                cand = 1.0 / rng.gamma(0.5, 4.0, size=p)
+                with np.errstate(over="ignore"):
+                    accept = rng.random(p) < np.exp(Q / 4.0 * (2.0 / gamma_l - cand))
+                gamma_l[accept] = 2.0 / cand[accept]
+                Gvec = (np.float64(Gval) * gamma_l).astype(np.float32)
             elif method == "BayesB":
                 beta = engine.get_state(0)[1].astype(np.float64)
                 Gvec = ((beta * beta + Gdf * Mi.G.scale) / rng.chisquare(1.0 + Gdf, size=p)).astype(np.float32)
@@ -541,7 +568,7 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
                 run_pi.add(np.atleast_1d(pi_t if mega else pi), k)
             engine.accumulate(k)
             files["residual_variance"].write(",".join(repr(float(v)) for v in np.atleast_1d(vare).ravel()) + "\n")
-            if method != "BayesB":
+            if not pervar:
                 files[f"marker_effects_variances_{name}"].write(",".join(repr(float(v)) for v in np.atleast_1d(Gval).ravel()) + "\n")
             if Mi.estimatePi:
                 files[f"pi_{name}"].write(",".join(repr(float(v)) for v in np.atleast_1d(pi_t if mega else pi)) + "\n")

@@ -458,3 +458,26 @@ def test_rrblup_is_bayesc_with_all_markers_in_the_model(tmp_path):
                                   outs["c0"]["marker effects geno"]["Estimate"].to_numpy())
     assert (outs["rr"]["marker effects geno"]["Model_Frequency"] == 1.0).all()
     assert "pi_geno" not in outs["rr"]
+
+
+def test_bayes_lasso_runs_on_the_bayesb_device_path(tmp_path):
+    """BayesL (BayesC0L.jl:25-47; gamma_j update variance_components.jl:191-203; G/8 and Gamma(1,8) start
+    MCMC_BayesianAlphabet.jl:70-81): all markers in the model, common scale reported, signal recovered."""
+    d = make_dataset(n=300, p=250, ncausal=6, seed=19, center=False)
+    ids = [f"id{i}" for i in range(300)]
+    gdf = pd.DataFrame(d["raw"], columns=[f"snp{j}" for j in range(250)])
+    gdf.insert(0, "ID", ids)
+    ph = pd.DataFrame({"ID": ids, "y1": d["y"]})
+    geno = api.get_genotypes(gdf, method="BayesL")
+    model = api.build_model("y1 = intercept + geno")
+    out = api.runMCMC(model, ph, chain_length=300, burnin=60, seed=2, output_folder=str(tmp_path / "bl"),
+                      engine=OracleEngine("block"), block_size=64)
+    me = out["marker effects geno"]
+    assert (me["Model_Frequency"] == 1.0).all()
+    assert "marker effects variance geno" in out and float(out["marker effects variance geno"]["Estimate"][0]) > 0
+    assert "pi_geno" not in out
+    causal = {f"snp{j}" for j in d["causal"]}
+    top = set(me.reindex(me["Estimate"].abs().sort_values(ascending=False).index)["Marker_ID"].head(10))
+    assert len(top & causal) >= 3
+    assert np.corrcoef(out["EBV_y1"]["EBV"], d["y"])[0, 1] > 0.6
+    assert os.path.exists(tmp_path / "bl" / "MCMC_samples_marker_effects_variances_geno.txt")

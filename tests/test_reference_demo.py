@@ -37,13 +37,13 @@ def test_load_from_file_with_header():
     np.testing.assert_allclose(np.asarray(geno.alleleFreq).ravel(), (raw.mean(0) / 2)[keep], atol=1e-6)
 
 
-@pytest.mark.parametrize("method", ["BayesA", "BayesB", "BayesC", "BayesR", "RR-BLUP"])
+@pytest.mark.parametrize("method", ["BayesA", "BayesB", "BayesC", "BayesR", "RR-BLUP", "BayesL"])
 def test_load_with_device_methods(method):
     geno = api.get_genotypes(GENO, 1.0, separator=",", method=method)
     assert geno.method == method and geno.nMarkers > 0
 
 
-@pytest.mark.parametrize("method", ["BayesL", "GBLUP"])
+@pytest.mark.parametrize("method", ["GBLUP"])
 def test_methods_off_the_device_path_are_refused_loudly(method):
     """The reference loads these too (runtests.jl:213-220); they are outside the hot path built here and must not
     silently fall back to anything."""
@@ -139,7 +139,7 @@ def test_reproducibility_with_seed(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("method", ["BayesA", "BayesB", "BayesR"])
+@pytest.mark.parametrize("method", ["BayesA", "BayesB", "BayesR", "BayesL", "RR-BLUP"])      # test_bayesb_methods.jl:8-54
 def test_other_single_trait_methods_short_run(tmp_path, method):
     geno = api.get_genotypes(GENO, 1.0, separator=",", method=method)
     model = api.build_model("y1 = intercept + geno", 1.0)
