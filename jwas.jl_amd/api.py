@@ -61,6 +61,7 @@ class Genotypes:
         self.storage_mode = "dense"            # "dense" | "stream" (types.jl:149-150)
         self.stream_backend = None             # metadata of the 2-bit packed backend (streaming.load_streaming_backend)
         self.multi_trait_sampler = "I"
+        self.annotations = False               # annotations.MarkerAnnotations (types.jl:167-215)
 
 
 def _is_false(x):
@@ -111,8 +112,6 @@ def get_genotypes(file, G=False, *, method="BayesC", Pi=0.0, estimatePi=True,
     if double_precision:
         raise NotImplementedError("the MI355X path is Float32 (double_precision=false), like the reference's "
                                   "storage=:stream mode (readgenotypes.jl:246-248)")
-    if annotations is not False:
-        raise NotImplementedError("marker annotations stay on the reference path")
     if method not in SUPPORTED_METHODS:
         raise NotImplementedError(f"method {method} is not on the device path (supported: {SUPPORTED_METHODS}); "
                                   "GBLUP / RR-BLUP / BayesL stay on the reference")
@@ -142,6 +141,11 @@ def get_genotypes(file, G=False, *, method="BayesC", Pi=0.0, estimatePi=True,
         raise TypeError("The data type is not supported.")                                    # :346-348
 
     nObs, nMarkers = genotypes.shape
+    from . import annotations as _ann
+    annotation_matrix = _ann.validate_annotations_input(annotations, nMarkers, method)       # :56-70, one row per RAW marker
+    if annotation_matrix is not False and estimatePi is False:                                # :152-158
+        print(f"estimatePi=false is ignored when annotations are provided; Annotated {method} requires estimatePi=true.")
+        estimatePi = True
     if quality_control:                                                                       # :372-382
         mv = data_type(missing_value)
         for j in range(nMarkers):
@@ -162,6 +166,8 @@ def get_genotypes(file, G=False, *, method="BayesC", Pi=0.0, estimatePi=True,
         genotypes = np.asfortranarray(genotypes[:, select])
         p = p[select]
         markerID = [m for m, s in zip(markerID, select) if s]
+        if annotation_matrix is not False:
+            annotation_matrix = annotation_matrix[select, :]
         print(f"{int((~select).sum())} loci which are fixed or have minor allele frequency < {MAF} are removed.")
     nObs, nMarkers = genotypes.shape
     sum2pq = float((2.0 * p.astype(np.float32) * (1.0 - p.astype(np.float32))).sum(dtype=np.float32))   # :401
@@ -171,6 +177,15 @@ def get_genotypes(file, G=False, *, method="BayesC", Pi=0.0, estimatePi=True,
     g.genetic_variance = Variance(False if G_is_marker_variance else G, df, False, estimate_variance, estimate_scale, constraint)
     g.method, g.estimatePi, g.pi = method, estimatePi, Pi
     g.multi_trait_sampler = multi_trait_sampler
+    if annotation_matrix is not False:                                                        # :111-150
+        if method == "BayesC" and not isinstance(Pi, dict):
+            if np.ndim(Pi) == 1:
+                if len(Pi) != nMarkers:
+                    raise ValueError(f"Annotated BayesC starting Pi vector length {len(Pi)} must match the number of markers ({nMarkers}).")
+                g.pi = np.array(Pi, dtype=np.float64)
+            else:
+                g.pi = np.full(nMarkers, float(Pi))
+        g.annotations = _ann.build_marker_annotations(annotation_matrix, method, Pi)
     print("Genotype informatin:")
     print(f"#markers: {nMarkers}; #individuals: {nObs}")
     if not _is_false(starting_value):                                                         # :438-446

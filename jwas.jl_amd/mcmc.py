@@ -297,6 +297,17 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         if (t == 1 and not Mi.G.val > 0) or (t > 1 and np.any(np.linalg.eigvalsh(Mi.G.val) <= 0)):
             raise ValueError("Marker effects variance is negative!" if t == 1 else
                              "Marker effects covariance matrix is not postive definite! Please modify the argument: Pi.")
+    ann = getattr(Mi, "annotations", False)
+    if ann is not False:
+        from . import annotations as A_
+        if t > 1:
+            raise NotImplementedError("annotated multi-trait BayesC (a per-marker prior over the joint states) stays on the reference")
+        if stream:
+            raise NotImplementedError("marker annotations with storage=:stream stay on the reference")
+        if method == "BayesC":                                         # annotation_setup.jl:78-99
+            pi = np.array(pi, dtype=np.float64) if np.ndim(pi) == 1 else np.full(p, float(pi))
+            A_.initialize_bayesc_single_trait(ann, pi)
+        Mi.estimatePi = True
     Gdf = float(Mi.G.df)
     Mi.G.scale = (np.float64(Mi.G.val) * (Gdf - 2) / Gdf) if t == 1 else np.asarray(Mi.G.val, dtype=np.float64) * (Gdf - t - 1)   # :414-418
     Rdf = float(R.df)
@@ -439,7 +450,7 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
     _open("residual_variance", rnames if t > 1 else [model.lhsVec[0]])
     if not pervar:
         _open(f"marker_effects_variances_{name}", rnames if t > 1 else ["1"])
-    if Mi.estimatePi:
+    if Mi.estimatePi and (np.size(pi) <= 20000 or output_samples_for_all_parameters):   # (marker-level pi: p values per sample)
         npi = t if mega else np.size(pi)
         _open(f"pi_{name}", [f"pi{i + 1}" for i in range(npi)] if npi > 1 else ["pi"])
     write_marker_samples = output_samples_for_all_parameters or p <= 20000
@@ -499,10 +510,14 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
                 kw.update(var_effect=Gval, log_prior_states=np.log(np.asarray(pi, dtype=np.float64)))
         elif method == "BayesR":
             kw.update(var_effect=Gval, pi_classes=np.asarray(pi, dtype=np.float64))
+            if ann is not False:
+                kw["pi_matrix"] = ann.snp_pi                            # per-marker class priors (BayesR.jl:62-66)
             if fast_blocks is not False:                                # bayesr_block_nreps (BayesR.jl:22-25)
                 kw["nreps"] = 1 if it <= burnin else 0
         elif method == "BayesB":
             kw.update(var_effect=Gval, var_effect_vec=Gvec, pi=pi)
+        elif np.ndim(pi) == 1:                                          # marker-level pi (bayesabc_pi_vector, BayesABC.jl:16-22)
+            kw.update(var_effect=Gval, pi_vec=pi)
         else:
             kw.update(var_effect=Gval, pi=pi)
         st = engine.sweep(**kw)
@@ -516,6 +531,9 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
                 pi_t = np.array([rng.beta(p - st["sum_delta"][k] + 1.0, st["sum_delta"][k] + 1.0) for k in range(t)])
             elif t > 1:
                 pi = rng.dirichlet(st["state_counts"] + 1.0)
+            elif ann is not False:                                      # update_marker_annotation_priors! (annotation_updates.jl:328-351)
+                dlt = engine.get_state(0)[2]
+                pi = A_.update_bayesr_nested_priors(ann, dlt, rng) if method == "BayesR" else A_.update_bayesc_binary_priors(ann, dlt, rng)
             elif method == "BayesR":
                 pi = rng.dirichlet(st["class_counts"] + 1.0)
             else:
@@ -567,10 +585,12 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
             if run_pi is not None:
                 run_pi.add(np.atleast_1d(pi_t if mega else pi), k)
             engine.accumulate(k)
+            if ann is not False:
+                A_.accumulate(ann, k)
             files["residual_variance"].write(",".join(repr(float(v)) for v in np.atleast_1d(vare).ravel()) + "\n")
             if not pervar:
                 files[f"marker_effects_variances_{name}"].write(",".join(repr(float(v)) for v in np.atleast_1d(Gval).ravel()) + "\n")
-            if Mi.estimatePi:
+            if Mi.estimatePi and f"pi_{name}" in files:
                 files[f"pi_{name}"].write(",".join(repr(float(v)) for v in np.atleast_1d(pi_t if mega else pi)) + "\n")
             if write_marker_samples:
                 for kk, tr in enumerate(model.lhsVec):
@@ -614,9 +634,13 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
             lab = ["".join(str((s >> k) & 1) for k in range(t)) for s in range(1 << t)]
         elif method == "BayesR":
             lab = ["class1", "class2", "class3", "class4"]
+        elif np.size(run_pi.mean) > 1:
+            lab = list(Mi.markerID)                                      # annotated BayesC: marker-level pi
         else:
             lab = ["π"]
         out[f"pi_{name}"] = pd.DataFrame({"π": lab, "Estimate": run_pi.mean, "SD": run_pi.sd()})
+    if ann is not False:
+        out[f"annotation coefficients {name}"] = A_.coefficients_table(ann, method)
     if outputEBV:
         for k, tr in enumerate(model.lhsVec):
             m = ebv_run[k].mean

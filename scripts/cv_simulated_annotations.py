@@ -7,7 +7,7 @@ center=false; held-out cor(y, EBV) and RMSE per fold.  The reference's published
 (benchmarks/reports/2026-04-11-simulated-annotations-cv-report.md) are printed next to ours.  The fold partitions
 differ (Julia's MersenneTwister shuffle is not reproducible here), so agreement is statistical.
 
-usage: python scripts/cv_simulated_annotations.py [--variants BayesC BayesR MT_I MT_II] [--json out.json]"""
+usage: python scripts/cv_simulated_annotations.py [--variants BayesC BayesR AnnotatedBayesC AnnotatedBayesR MT_I MT_II] [--json out.json]"""
 import argparse
 import json
 import os
@@ -28,8 +28,8 @@ MT_START_PI = {(0.0, 0.0): 0.96, (1.0, 0.0): 0.015, (0.0, 1.0): 0.015, (1.0, 1.0
 ST_BAYESC_PI = 0.98
 ST_BAYESR_PI = [0.99, 0.006, 0.003, 0.001]
 # held-out cor(y, EBV), trait mean over y1 and y2 (report: "Multi-Trait Family Summary", "Single-Trait Family Summary")
-REFERENCE = {"BayesC": 0.6424, "BayesR": 0.6497, "MT_I": 0.6397, "MT_II": 0.6423}
-REFERENCE_RMSE = {"BayesC": 4.5294, "BayesR": 4.4392, "MT_I": 5.0015, "MT_II": 4.6572}
+REFERENCE = {"BayesC": 0.6424, "BayesR": 0.6497, "MT_I": 0.6397, "MT_II": 0.6423, "AnnotatedBayesC": 0.6469, "AnnotatedBayesR": 0.6484}
+REFERENCE_RMSE = {"BayesC": 4.5294, "BayesR": 4.4392, "MT_I": 5.0015, "MT_II": 4.6572, "AnnotatedBayesC": 4.6178, "AnnotatedBayesR": 4.3353}
 
 
 def folds_for(ids, nfolds, seed):
@@ -56,11 +56,15 @@ def run_variant(variant, pheno, seed, fold_of, fold, chain_length, burnin, freq,
         traits = ["y1", "y2"]
     else:
         method, trait = variant.split("_")
+        annotated = method.startswith("Annotated")
+        method = method.replace("Annotated", "")
         start_g = float(np.var(pheno[trait].to_numpy(dtype=np.float64), ddof=1)) * 0.5
         start_r = start_g
         run = pheno[["ID", trait]].copy()
         run.loc[mask, trait] = np.nan
         kw = dict(Pi=ST_BAYESC_PI) if method == "BayesC" else dict(Pi=list(ST_BAYESR_PI), G_is_marker_variance=False)
+        if annotated:                                   # annotation_mode = :real: every column of annotations_mt.csv but the id
+            kw["annotations"] = pd.read_csv(os.path.join(DATA, "annotations_mt.csv")).iloc[:, 1:].to_numpy(dtype=np.float64)
         bench_geno = api.get_genotypes(os.path.join(DATA, "genotypes.csv"), start_g, separator=",", method=method,
                                        estimatePi=True, quality_control=False, center=False, **kw)
         model = api.build_model(f"{trait} = intercept + bench_geno", start_r, genotypes={"bench_geno": bench_geno})
@@ -83,7 +87,7 @@ def run_variant(variant, pheno, seed, fold_of, fold, chain_length, burnin, freq,
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--variants", nargs="+", default=["BayesC", "BayesR", "MT_I", "MT_II"])
+    ap.add_argument("--variants", nargs="+", default=["BayesC", "BayesR", "AnnotatedBayesC", "AnnotatedBayesR", "MT_I", "MT_II"])
     ap.add_argument("--seeds", type=int, nargs="+", default=[101, 202])
     ap.add_argument("--folds", type=int, default=5)
     ap.add_argument("--chain-length", type=int, default=1500)

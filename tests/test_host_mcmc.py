@@ -481,3 +481,69 @@ def test_bayes_lasso_runs_on_the_bayesb_device_path(tmp_path):
     assert len(top & causal) >= 3
     assert np.corrcoef(out["EBV_y1"]["EBV"], d["y"])[0, 1] > 0.6
     assert os.path.exists(tmp_path / "bl" / "MCMC_samples_marker_effects_variances_geno.txt")
+
+
+def _annotated_dataset(seed=3, n=400, p=300):
+    """Causal markers are enriched among the markers carrying a binary annotation."""
+    rng = np.random.default_rng(seed)
+    f = rng.uniform(0.1, 0.4, p)
+    X = (rng.random((n, p)) < f).astype(np.float32) + (rng.random((n, p)) < f).astype(np.float32)
+    ann = np.zeros((p, 2))
+    ann[:60, 0] = 1.0                                   # informative annotation
+    ann[:, 1] = rng.standard_normal(p)                  # noise annotation
+    causal = rng.choice(60, 24, replace=False)
+    beta = np.zeros(p); beta[causal] = rng.standard_normal(24)
+    g = (X - X.mean(0)) @ beta
+    y = 1.0 + g / g.std() * np.sqrt(0.6) + rng.standard_normal(n) * np.sqrt(0.4)
+    ids = [f"id{i}" for i in range(n)]
+    gdf = pd.DataFrame(X, columns=[f"snp{j}" for j in range(p)])
+    gdf.insert(0, "ID", ids)
+    return gdf, pd.DataFrame({"ID": ids, "y1": y}), ann, causal
+
+
+@pytest.mark.parametrize("method", ["BayesC", "BayesR"])
+def test_annotated_single_trait_priors(tmp_path, method):
+    """Annotated BayesC / BayesR (annotation_updates.jl, annotation_setup.jl): the probit regression of the inclusion
+    indicators on the annotations finds the informative annotation; marker-level priors reach the device sweep
+    (pi_vec / p x 4 pi_matrix)."""
+    gdf, ph, ann, causal = _annotated_dataset()
+    kw = dict(Pi=0.9) if method == "BayesC" else dict(Pi=[0.9, 0.06, 0.03, 0.01])
+    geno = api.get_genotypes(gdf, method=method, annotations=ann, estimatePi=False, **kw)
+    assert geno.estimatePi is True                       # forced (readgenotypes.jl:152-158)
+    model = api.build_model("y1 = intercept + geno")
+    out = api.runMCMC(model, ph, chain_length=400, burnin=100, seed=7, output_folder=str(tmp_path / method),
+                      engine=OracleEngine("block"), block_size=64)
+    tab = out["annotation coefficients geno"]
+    if method == "BayesC":
+        assert list(tab.columns) == ["Annotation", "Estimate", "SD"]
+        assert list(tab["Annotation"]) == ["Intercept", "Annotation_1", "Annotation_2"]
+        slope = float(tab["Estimate"][1])
+        pi_tab = out["pi_geno"]
+        assert len(pi_tab) == geno.nMarkers
+        assert pi_tab["Estimate"][:60].mean() < pi_tab["Estimate"][60:].mean() - 0.02     # annotated markers: lower Pr(zero)
+    else:
+        assert list(tab.columns) == ["Annotation", "Step", "Estimate", "SD"] and len(tab) == 9
+        slope = float(tab[(tab["Annotation"] == "Annotation_1") & (tab["Step"] == "step1_zero_vs_nonzero")]["Estimate"].iloc[0])
+        assert len(out["pi_geno"]) == 4
+    assert slope > 0.3, tab
+    me = out["marker effects geno"]
+    assert me["Model_Frequency"][:60].mean() > me["Model_Frequency"][60:].mean()
+
+
+def test_annotation_input_errors():
+    """readgenotypes.jl:56-105"""
+    gdf, ph, ann, _ = _annotated_dataset(p=80, n=50)
+    with pytest.raises(ValueError, match="only supported with method"):
+        api.get_genotypes(gdf, method="BayesB", annotations=ann)
+    with pytest.raises(ValueError, match="must match the number of raw markers"):
+        api.get_genotypes(gdf, method="BayesC", annotations=ann[:-1])
+    bad = ann.copy(); bad[:, 0] = 2.0
+    with pytest.raises(ValueError, match=r"constant column\(s\) \[1\]"):
+        api.get_genotypes(gdf, method="BayesC", annotations=bad)
+    col = np.hstack([ann, ann[:, :1] * 2])
+    with pytest.raises(ValueError, match="collinear"):
+        api.get_genotypes(gdf, method="BayesC", annotations=col)
+    with pytest.raises(ValueError, match="positive prior mass in classes 3 or 4"):
+        api.get_genotypes(gdf, method="BayesR", annotations=ann, Pi=[0.9, 0.1, 0.0, 0.0])
+    with pytest.raises(ValueError, match="Pi vector length"):
+        api.get_genotypes(gdf, method="BayesC", annotations=ann, Pi=np.full(7, 0.9))
