@@ -160,6 +160,70 @@ def test_larger_problem_invariants_without_oracle():
     assert same > 0.999                      # identical draws; only fp32 rounding of the two Gram layouts differs
 
 
+def test_full_size_config2_invariants():
+    """BASELINE.json config 2 at its full size (50 000 x 600 000 fp32, 120 GB in HBM, genotypes generated on the
+    device): the oracle cannot run here, so parity is checked through size-independent properties -- the residual
+    identity r = y - X alpha after several sweeps, statistics = direct reductions of the state, bit-reproducibility,
+    and invariance of the chain to the block size (512 vs 1024: same draws; only the fp32 rounding of the two Gram
+    layouts differs)."""
+    import jwas_jl_amd as J
+    n, p = 50_000, 600_000
+    e = J.HipEngine(0)
+    if e.device_info()["hbm_free"] < 150e9:
+        e.close()
+        pytest.skip("needs 150 GB of free HBM")
+    e.alloc_dense(n, p); e.synth(2026, 0, True)
+    e.setup_blocks(512, "mfma"); e.add_block_size(1024, "mfma")
+    e.init_state("BayesC")
+    rng = np.random.default_rng(0)
+    a_true = np.zeros(p, dtype=np.float32); idx = rng.choice(p, 600, replace=False); a_true[idx] = rng.standard_normal(600)
+    e.set_state(alpha=a_true)
+    g = e.mul_alpha()
+    y = (g / g.std() + rng.standard_normal(n)).astype(np.float32)
+    y -= y.mean()
+    xpx = e.xpx()
+    assert xpx.min() > 0 and np.isfinite(xpx).all()
+    varg = np.float32(1.0 / (0.05 * float(xpx.astype(np.float64).sum()) / n))
+    res = {}
+    for tag, bs in (("a", 512), ("b", 1024), ("c", 512)):
+        e.select_block_size(bs)
+        e.set_state(alpha=np.zeros(p), beta=np.zeros(p), delta=np.ones(p))
+        e.set_residual(y)
+        pi = 0.95
+        for it in range(1, 7):
+            st = e.sweep(iteration=it, seed=2026, vare=np.float32(1.0), var_effect=varg, pi=pi)
+            pi = float(1 - (st["sum_delta"][0] + 1) / (p + 2))
+        a, b, dlt = e.get_state()
+        r = e.get_residual()
+        np.testing.assert_allclose(r, y - e.mul_alpha(), atol=5e-3)                              # residual identity
+        assert st["sum_delta"][0] == float(dlt.sum()) == float((a != 0).sum())
+        assert st["alpha_ss"][0, 0] == pytest.approx(float(a.astype(np.float64) @ a.astype(np.float64)), rel=1e-9)
+        assert st["resid_ss"][0, 0] == pytest.approx(float(r.astype(np.float64) @ r.astype(np.float64)), rel=1e-9)
+        res[tag] = (a, dlt, r)
+    e.close()
+    # the same genotypes kept 2-bit packed in HBM (7.5 GB instead of 120 GB): the same chain, bit for bit
+    e = J.HipEngine(0)
+    e.alloc_packed(n, p); e.synth(2026, 0, True)
+    e.setup_blocks(512, "mfma"); e.init_state("BayesC")
+    assert np.array_equal(e.xpx(), xpx)
+    e.set_state(alpha=np.zeros(p), beta=np.zeros(p), delta=np.ones(p))
+    e.set_residual(y)
+    pi = 0.95
+    for it in range(1, 7):
+        st = e.sweep(iteration=it, seed=2026, vare=np.float32(1.0), var_effect=varg, pi=pi)
+        pi = float(1 - (st["sum_delta"][0] + 1) / (p + 2))
+    res["packed"] = (e.get_state()[0], e.get_state()[2], e.get_residual())
+    e.close()
+    assert np.array_equal(res["packed"][0], res["a"][0]) and np.array_equal(res["packed"][2], res["a"][2])
+    assert np.array_equal(res["a"][0], res["c"][0]) and np.array_equal(res["a"][2], res["c"][2])    # reproducible, bit for bit
+    assert (res["a"][1] == res["b"][1]).mean() > 0.9995                                         # block-size invariant draws
+    both = (res["a"][1] != 0) & (res["b"][1] != 0)
+    assert np.abs(res["a"][0][both] - res["b"][0][both]).max() < 5e-3
+    # the simulated QTL with large effects are found
+    big = idx[np.abs(a_true[idx]) > 1.5]
+    assert (res["a"][1][big] != 0).mean() > 0.5
+
+
 def test_marker_shard_with_nccl_backend_single_rank(tmp_path):
     """The collective path (RCCL all-reduce of the residual delta and of the packed statistics) with the real
     nccl backend: one rank, collectives forced, must reproduce the plain sweep up to the fp32 rounding of
