@@ -103,6 +103,9 @@ typedef struct jwas_sweep_params {
     const float*  var_effect_vec;       /* BayesB: p per-marker variances (host), else NULL          */
     const double* pi_vec;               /* BayesC/B: p per-marker pi (host), else NULL               */
     const double* pi_matrix;            /* BayesR: p x 4 row-major per-marker class priors, else NULL */
+    const double* log_prior_states_matrix;  /* MT samplers I/II: p x 2^t row-major per-marker log pi(state) (marker-specific */
+                                        /* joint priors: the reference's annotated multi-trait BayesC, MarkerSpecificPiPrior, */
+                                        /* MTBayesABC.jl:22-47), else NULL; needs 2 traits and a block size <= 512 */
 } jwas_sweep_params;
 
 /* Reductions the host-side conjugate draws need (Pi.jl, variance_components.jl). */

@@ -45,6 +45,7 @@ class SweepParams(C.Structure):
         ("var_effect_vec", C.POINTER(C.c_float)),
         ("pi_vec", C.POINTER(C.c_double)),
         ("pi_matrix", C.POINTER(C.c_double)),
+        ("log_prior_states_matrix", C.POINTER(C.c_double)),
     ]
 
 

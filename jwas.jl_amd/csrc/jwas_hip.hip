@@ -74,6 +74,8 @@ struct jwas_hip_ctx {
     float*  var_vec = nullptr;
     double* pi_vec = nullptr;
     double* pi_mat = nullptr;
+    double* lpr_mat = nullptr;          // p x 2^t marker-specific multi-trait log priors
+    bool    lpr_active = false;         // ... in use by the current sweep
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     int timing_stride = 0;
     double last_events = -1.0;          // effect changes of the previous sweep (-1: none yet)
@@ -199,8 +201,8 @@ static void free_storage(jwas_hip_ctx* c)
     c->ev = nullptr; c->dparams = nullptr; c->counters = nullptr; c->fin_out = c->stat_out = nullptr;
     if (c->host_buf) (void)hipHostFree(c->host_buf);
     c->host_buf = nullptr;
-    (void)hipFree(c->var_vec); (void)hipFree(c->pi_vec); (void)hipFree(c->pi_mat);
-    c->var_vec = nullptr; c->pi_vec = c->pi_mat = nullptr;
+    (void)hipFree(c->var_vec); (void)hipFree(c->pi_vec); (void)hipFree(c->pi_mat); (void)hipFree(c->lpr_mat);
+    c->var_vec = nullptr; c->pi_vec = c->pi_mat = c->lpr_mat = nullptr;
     (void)hipFree(c->Xout); c->Xout = nullptr; c->n_out = c->ld_out = 0;
 }
 
@@ -876,7 +878,7 @@ static hipError_t launch_step_cx(jwas_hip_ctx* c, const CX& cx, const UpdateArgs
     UpdateArgsT<CX> U;
     static_cast<UpdateArgs&>(U) = U0;
     U.cx = cx;
-    const StepSmem SM(c->block_size, NT, is_mt_method(METHOD) ? mt_park_nd(c->block_size, NT) : (METHOD == kBayesR ? BayesRMarker::kFastD : 4), is_mt_method(METHOD) ? mt_park_nf(c->block_size, NT) : (METHOD == kBayesR ? 1 : 4));
+    const StepSmem SM(c->block_size, NT, is_mt_method(METHOD) ? mt_park_nd(c->block_size, NT) + (S.lpr_mat ? (1 << NT) : 0) : (METHOD == kBayesR ? BayesRMarker::kFastD : 4), is_mt_method(METHOD) ? mt_park_nf(c->block_size, NT) : (METHOD == kBayesR ? 1 : 4));
     static bool attr_set = false;
     if (!attr_set) {   // allow > 64 KB of dynamic LDS
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_block_step<METHOD, NT, CX>),
@@ -932,7 +934,7 @@ static hipError_t launch_indep_cx(jwas_hip_ctx* c, const CX& cx, const UpdateArg
     UpdateArgsT<CX> U;
     static_cast<UpdateArgs&>(U) = U0;
     U.cx = cx;
-    const StepSmem SM(c->block_size, NT, is_mt_method(METHOD) ? mt_park_nd(c->block_size, NT) : (METHOD == kBayesR ? BayesRMarker::kFastD : 4), is_mt_method(METHOD) ? mt_park_nf(c->block_size, NT) : (METHOD == kBayesR ? 1 : 4));
+    const StepSmem SM(c->block_size, NT, is_mt_method(METHOD) ? mt_park_nd(c->block_size, NT) + (S.lpr_mat ? (1 << NT) : 0) : (METHOD == kBayesR ? BayesRMarker::kFastD : 4), is_mt_method(METHOD) ? mt_park_nf(c->block_size, NT) : (METHOD == kBayesR ? 1 : 4));
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_indep_sample<METHOD, NT>),
@@ -982,7 +984,7 @@ static int sweep_independent(jwas_hip_ctx* c, EventList* out)
     S.P = c->dparams; S.partials = c->ipartials; S.nrg = c->nrg; S.bstride = bs;
     S.p = c->p; S.bsz = bs; S.xpx = c->xpx; S.gram = c->gram;
     S.cross_next = c->gram; S.b_next = 0; S.corr_in = c->corr; S.corr_out = c->corr + (size_t)kMaxT * bs;
-    S.prep_d = c->prep_d; S.prep_f = c->prep_f; S.mt2_tab = c->mt2_tab;
+    S.prep_d = c->prep_d; S.prep_f = c->prep_f; S.mt2_tab = c->mt2_tab; S.lpr_mat = c->lpr_active ? c->lpr_mat : nullptr;
     S.alpha = c->alpha; S.beta = c->beta; S.delta = c->delta;
     S.counters = c->counters;
     hipError_t e;
@@ -1049,6 +1051,7 @@ int jwas_hip_sweep(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_sweep_stats
     HIPCHK(c, hipSetDevice(c->device));
 
     DevParams D;
+    c->lpr_active = is_mt_method(c->method) && c->method != JWAS_HIP_MEGABAYESC && P->log_prior_states_matrix != nullptr;
     std::memset(&D, 0, sizeof D);
     D.method = c->method; D.ntraits = t; D.nreps = P->nreps;
     D.iter = P->iteration; D.seed_lo = (uint32_t)P->seed; D.seed_hi = (uint32_t)(P->seed >> 32); D.marker0 = P->marker_offset;
@@ -1058,8 +1061,14 @@ int jwas_hip_sweep(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_sweep_stats
         NEED(c, inv_small(P->var_effect, t, D.Ginv) == 0, JWAS_HIP_EINVAL, "marker effect covariance matrix is singular");
         bool any_finite = false;
         for (int i = 0; i < (1 << t); ++i) { D.log_prior[i] = P->log_prior_states[i]; any_finite = any_finite || std::isfinite(D.log_prior[i]); }
-        if (c->method == JWAS_HIP_MTBAYESC2)      // MTBayesABC.jl:190
+        if (c->method == JWAS_HIP_MTBAYESC2 && !P->log_prior_states_matrix)      // MTBayesABC.jl:190
             NEED(c, any_finite, JWAS_HIP_EINVAL, "All MTBayesABC sampler II state probabilities are zero or invalid.");
+        if (P->log_prior_states_matrix) {          // MarkerSpecificPiPrior (MTBayesABC.jl:22-47)
+            NEED(c, t == 2, JWAS_HIP_EUNSUP, "marker-specific joint priors support 2 traits (got %d)", t);
+            NEED(c, c->block_size <= 512, JWAS_HIP_EUNSUP, "marker-specific joint priors need a block size <= 512 (got %d)", c->block_size);
+            int rc = upload_vec(c, (void**)&c->lpr_mat, P->log_prior_states_matrix, sizeof(double) * (size_t)(1 << t) * c->p);
+            if (rc) return rc;
+        }
     } else if (c->method == JWAS_HIP_MEGABAYESC) {
         // megaBayesABC! (BayesABC.jl:1-8): trait k uses vare[k,k], var_effect[k,k] and its own pi (pi_classes[k])
         for (int k = 0; k < t; ++k) {
@@ -1166,7 +1175,7 @@ int jwas_hip_sweep(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_sweep_stats
             S.cross_next = c->cross + (sb + 1 < nb ? sb + 1 : sb) * (int64_t)bs * bs;
             S.corr_in = c->corr + (sb & 1) * (size_t)kMaxT * bs;
             S.corr_out = c->corr + ((sb + 1) & 1) * (size_t)kMaxT * bs;
-            S.prep_d = c->prep_d; S.prep_f = c->prep_f; S.mt2_tab = c->mt2_tab;
+            S.prep_d = c->prep_d; S.prep_f = c->prep_f; S.mt2_tab = c->mt2_tab; S.lpr_mat = c->lpr_active ? c->lpr_mat : nullptr;
             S.alpha = c->alpha; S.beta = c->beta; S.delta = c->delta;
             S.ev_out = &c->ev[(k - 1) & 1];
             S.counters = c->counters;

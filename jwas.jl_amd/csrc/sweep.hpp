@@ -241,6 +241,7 @@ struct SamplerArgs {
     float* corr_out;              // [NT][bsz] lookahead correction of the NEXT block
     const double* prep_d; const float* prep_f;
     const double* mt2_tab;        // sampler II, <= 3 traits: per-marker state tables (k_prepare_mt2), else NULL
+    const double* lpr_mat;        // multi-trait: p x 2^t marker-specific log prior of the joint states, else NULL
     float* alpha; float* beta; void* delta;
     Events* ev_out;
     unsigned long long* counters;
@@ -903,7 +904,7 @@ __device__ __forceinline__ MtPre<NT> mt_precompute(const MtConsts<NT>& K, float 
 
 // Gibbs sampler I (MTBayesABC.jl:85-120)
 template <int NT>
-__device__ __forceinline__ void mt1_eval(const MtConsts<NT>& K, const MtPre<NT>& Q, const double* lpr, const float (&w)[NT], float dj,
+__device__ __forceinline__ void mt1_eval(const MtConsts<NT>& K, const MtPre<NT>& Q, const double* lpr, int ls, const float (&w)[NT], float dj,
                                          const double (&thr)[NT], const double (&z)[NT],
                                          float (&an)[NT], float (&bn)[NT], float (&dn)[NT], float (&Dl)[NT])
 {
@@ -932,8 +933,8 @@ __device__ __forceinline__ void mt1_eval(const MtConsts<NT>& K, const MtPre<NT>&
         const unsigned s1 = s0 | (1u << k);
         const float in0 = K.lG[k] - (gHat0 * gHat0) * Ginv11;                       // :104
         const float in1 = Q.lC11[k] - (gHat1 * gHat1) * C11;                        // :105
-        const double logDelta0 = -0.5 * (double)in0 + lpr[s0];
-        const double logDelta1 = -0.5 * (double)in1 + lpr[s1];
+        const double logDelta0 = -0.5 * (double)in0 + lpr[s0 * ls];          // ls = 1: shared table; block size: this marker's
+        const double logDelta1 = -0.5 * (double)in1 + lpr[s1 * ls];
         if ((logDelta0 - logDelta1) < thr[k]) {                                     // :107-111
             dn[k] = 1.f;
             bn[k] = (float)((double)gHat1 + z[k] * (double)Q.s1[k]);
@@ -1143,7 +1144,7 @@ __device__ __forceinline__ void mt2_load_tab(const double* __restrict__ tab, int
 
 // Gibbs sampler II, one marker, from its state table (same results as mt2_eval).
 template <int NT>
-__device__ __forceinline__ void mt2_eval_tab(const MtConsts<NT>& K, const double* lpr, const float (&w)[NT],
+__device__ __forceinline__ void mt2_eval_tab(const MtConsts<NT>& K, const double* lpr, int ls, const float (&w)[NT],
                                              const double (&T)[Mt2Tab<NT>::NS][Mt2Tab<NT>::NV],
                                              double u, const double (&z)[NT],
                                              float (&an)[NT], float (&bn)[NT], float (&dn)[NT], float (&Dl)[NT])
@@ -1155,7 +1156,7 @@ __device__ __forceinline__ void mt2_eval_tab(const MtConsts<NT>& K, const double
         double inv[NT][NT], lg, q, gh[NT];
         mt2_unpack<NT>(T[s], inv, lg);
         mt2_state_post<NT>(K, (unsigned)s, w, inv, lg, q, gh);
-        ld[s] = q + lpr[s];
+        ld[s] = q + lpr[s * ls];
     }
     int which = NS - 1;
     {                                                                               // :188-198
@@ -1197,7 +1198,7 @@ __device__ __forceinline__ void mt2_eval_tab(const MtConsts<NT>& K, const double
 
 // Gibbs sampler II, one marker (MTBayesABC.jl:160-208).  u = the marker's uniform (slot 0).
 template <int NT>
-__device__ __forceinline__ void mt2_eval(const MtConsts<NT>& K, const double* lpr, const float (&w)[NT], float dj,
+__device__ __forceinline__ void mt2_eval(const MtConsts<NT>& K, const double* lpr, int ls, const float (&w)[NT], float dj,
                                          double u, const double (&z)[NT],
                                          float (&an)[NT], float (&bn)[NT], float (&dn)[NT], float (&Dl)[NT])
 {
@@ -1213,7 +1214,7 @@ __device__ __forceinline__ void mt2_eval(const MtConsts<NT>& K, const double* lp
         double q;
         mt2_state<NT>(K, st, w, dj, z, pass == NS, q, cand);
         if (pass < NS) {
-            const double v = q + lpr[pass];
+            const double v = q + lpr[pass * ls];
 #pragma unroll
             for (int s = 0; s < NS; ++s) ld[s] = (s == pass) ? v : ld[s];
         }
@@ -1251,7 +1252,8 @@ __device__ __forceinline__ void mt2_eval(const MtConsts<NT>& K, const double* lp
 template <int METHOD, int NT>
 __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A)
 {
-    const StepSmem SM(A.bsz, NT, mt_park_nd(A.bsz, NT), mt_park_nf(A.bsz, NT));
+    const bool pm = A.lpr_mat != nullptr;           // marker-specific joint priors (host: only with parked draws)
+    const StepSmem SM(A.bsz, NT, mt_park_nd(A.bsz, NT) + (pm ? (1 << NT) : 0), mt_park_nf(A.bsz, NT));
     const int B = SM.B;
     const bool parked = mt_park_nd(B, NT) != 0;
     constexpr bool kTab = (METHOD == kMTBayesC2) && (NT <= 3);       // sampler II from per-marker state tables
@@ -1317,6 +1319,11 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
             thr0[q][t] = A.prep_d[(int64_t)t * p + j]; z0[q][t] = A.prep_d[(int64_t)(NT + t) * p + j];
             lc0[q][t] = A.prep_f[(int64_t)t * p + j];
         }
+        double lpm[1 << NT];
+        if (pm) {
+#pragma unroll
+            for (int st = 0; st < (1 << NT); ++st) lpm[st] = A.lpr_mat[(int64_t)(1 << NT) * j + st];
+        }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const double sum = sum_partials(A.partials + (int64_t)t * A.nrg * A.bstride + cc, A.nrg, A.bstride);
@@ -1330,9 +1337,17 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
             a0[q][t] = a_in;
         }
         if (parked) lpf[c] = dj;
+        if (pm) {
+#pragma unroll
+            for (int st = 0; st < (1 << NT); ++st) lpd[(2 * NT + st) * B + c] = lpm[st];
+        }
     }
     if (tid < (1 << NT)) lpr[tid] = lpr_mine;
     __syncthreads();
+    // marker c's table of log prior state probabilities: the shared one (stride 1) or its own column of the parked
+    // marker-specific priors (stride B)
+    const int ls = pm ? B : 1;
+    auto lpr_of = [&](int c) -> const double* { return pm ? lpd + 2 * NT * B + c : lpr; };
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int c = tid + q * kStepThreads;
@@ -1347,13 +1362,13 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
             float an[NT], bn[NT], dn[NT], Dl[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) { an[t] = a0[q][t]; bn[t] = b0[q][t]; dn[t] = d0[q][t]; Dl[t] = 0.f; }
-            if constexpr (METHOD == kMTBayesC1) mt1_eval<NT>(K, Q0, lpr, w0[q], dj, thr0[q], z0[q], an, bn, dn, Dl);
+            if constexpr (METHOD == kMTBayesC1) mt1_eval<NT>(K, Q0, lpr_of(c), ls, w0[q], dj, thr0[q], z0[q], an, bn, dn, Dl);
             else if constexpr (kTab) {
                 double T[kTS][kTV];
                 mt2_load_tab<NT>(A.mt2_tab, p, j0 + c, T);
-                mt2_eval_tab<NT>(K, lpr, w0[q], T, thr0[q][0], z0[q], an, bn, dn, Dl);
+                mt2_eval_tab<NT>(K, lpr_of(c), ls, w0[q], T, thr0[q][0], z0[q], an, bn, dn, Dl);
             }
-            else if constexpr (METHOD == kMTBayesC2) mt2_eval<NT>(K, lpr, w0[q], dj, thr0[q][0], z0[q], an, bn, dn, Dl);
+            else if constexpr (METHOD == kMTBayesC2) mt2_eval<NT>(K, lpr_of(c), ls, w0[q], dj, thr0[q][0], z0[q], an, bn, dn, Dl);
             else mega_eval<NT>(K, Q0, w0[q], dj, thr0[q], z0[q], an, bn, dn, Dl);
 #pragma unroll
             for (int t = 0; t < NT; ++t) moves = moves || (Dl[t] != 0.f);
@@ -1426,8 +1441,8 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
                     Qm.C11[t] = bcast_f(Qq[q].C11[t], l); Qm.invLhs1[t] = bcast_f(Qq[q].invLhs1[t], l);
                     Qm.lC11[t] = bcast_f(Qq[q].lC11[t], l); Qm.s1[t] = bcast_f(Qq[q].s1[t], l);
                 }
-                if constexpr (METHOD == kMTBayesC1) mt1_eval<NT>(K, Qm, lpr, w, dj, thr, z, an, bn, dn, Dl);
-                else if constexpr (METHOD == kMTBayesC2) mt2_eval<NT>(K, lpr, w, dj, thr[0], z, an, bn, dn, Dl);
+                if constexpr (METHOD == kMTBayesC1) mt1_eval<NT>(K, Qm, lpr_of(jj), ls, w, dj, thr, z, an, bn, dn, Dl);
+                else if constexpr (METHOD == kMTBayesC2) mt2_eval<NT>(K, lpr_of(jj), ls, w, dj, thr[0], z, an, bn, dn, Dl);
                 else mega_eval<NT>(K, Qm, w, dj, thr, z, an, bn, dn, Dl);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
@@ -1491,9 +1506,9 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
                     float w[NT];
 #pragma unroll
                     for (int t = 0; t < NT; ++t) w[t] = rhs_lds[t * B + c] + dj * a_cur[t];           // :82
-                    if constexpr (METHOD == kMTBayesC1) mt1_eval<NT>(K, Qm, lpr, w, dj, thr, z, an, bn, dn, Dl);
-                    else if constexpr (kTab) mt2_eval_tab<NT>(K, lpr, w, T, thr[0], z, an, bn, dn, Dl);
-                    else if constexpr (METHOD == kMTBayesC2) mt2_eval<NT>(K, lpr, w, dj, thr[0], z, an, bn, dn, Dl);
+                    if constexpr (METHOD == kMTBayesC1) mt1_eval<NT>(K, Qm, lpr_of(c), ls, w, dj, thr, z, an, bn, dn, Dl);
+                    else if constexpr (kTab) mt2_eval_tab<NT>(K, lpr_of(c), ls, w, T, thr[0], z, an, bn, dn, Dl);
+                    else if constexpr (METHOD == kMTBayesC2) mt2_eval<NT>(K, lpr_of(c), ls, w, dj, thr[0], z, an, bn, dn, Dl);
                     else mega_eval<NT>(K, Qm, w, dj, thr, z, an, bn, dn, Dl);
 #pragma unroll
                     for (int t = 0; t < NT; ++t) is_event = is_event || (Dl[t] != 0.f);

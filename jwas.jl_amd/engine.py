@@ -360,10 +360,17 @@ class HipEngine:
                 P.pi_classes[k] = float(pt[k])
         else:
             lp = np.asarray(log_prior_states, dtype=np.float64)
-            if lp.shape != (1 << t,):
-                raise ValueError(f"log_prior_states must have {1 << t} entries")
-            for k in range(1 << t):
-                P.log_prior_states[k] = float(lp[k])
+            if lp.ndim == 2:                      # marker-specific joint priors (MarkerSpecificPiPrior, MTBayesABC.jl:22-47)
+                if lp.shape != (self.p, 1 << t):
+                    raise ValueError(f"marker-specific log_prior_states must be {self.p} x {1 << t}")
+                lpm = np.ascontiguousarray(lp)
+                keep.append(lpm)
+                P.log_prior_states_matrix = lpm.ctypes.data_as(C.POINTER(C.c_double))
+            else:
+                if lp.shape != (1 << t,):
+                    raise ValueError(f"log_prior_states must have {1 << t} entries")
+                for k in range(1 << t):
+                    P.log_prior_states[k] = float(lp[k])
         self._keep = keep
         S = SweepStats()
         self._chk(self._L.jwas_hip_sweep(self._h, C.byref(P), C.byref(S)))

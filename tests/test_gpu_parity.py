@@ -553,3 +553,48 @@ def test_state_machine_errors(hip, small_data):
     with pytest.raises(J.JwasHipError):
         e.init_state("MTBayesC", 9)
     e.close()
+
+
+@pytest.mark.parametrize("sampler,bs,nreps", [("MTBayesC", 64, 1), ("MTBayesC", 512, 1), ("MTBayesC_II", 128, 1), ("MTBayesC_II", 256, 2), ("MTBayesC", 128, 3)])
+def test_mt_marker_specific_prior_parity(hip, sampler, bs, nreps):
+    """Marker-specific joint-state priors (the reference's annotated 2-trait BayesC: MarkerSpecificPiPrior,
+    MTBayesABC.jl:22-47; p x 4 log prior matrix) against the oracle."""
+    t = 2
+    data = make_dataset(n=400, p=2 * bs + 29, ncausal=8, seed=77)
+    orc, hip = _pair(hip, data, bs, sampler, ntraits=t)
+    rng = np.random.default_rng(5)
+    Y = np.stack([data["y"] - data["y"].mean() + 0.3 * rng.standard_normal(len(data["y"])).astype(np.float32)
+                  for _ in range(t)]).astype(np.float32)
+    for k in range(t):
+        orc.set_residual(Y[k], k)
+        hip.set_residual(Y[k], k)
+        if sampler == "MTBayesC":
+            ones = np.ones(orc.p, dtype=np.float32)
+            orc.set_state(k, delta=ones)
+            hip.set_state(k, delta=ones)
+    vare = np.array([[0.6, 0.1], [0.1, 0.5]], dtype=np.float32)
+    varg = np.array([[0.003, 0.001], [0.001, 0.002]], dtype=np.float32)
+    prior = rng.dirichlet(np.array([8.0, 1.0, 1.0, 1.0]), size=orc.p)          # every marker its own prior
+    prior[::7] = [0.25, 0.25, 0.25, 0.25]
+    lp = np.log(prior)
+    for it in range(1, 11):
+        so = orc.sweep(iteration=it, seed=21, vare=vare, var_effect=varg, log_prior_states=lp, nreps=nreps)
+        sh = hip.sweep(iteration=it, seed=21, vare=vare, var_effect=varg, log_prior_states=lp, nreps=nreps)
+        assert np.array_equal(so["state_counts"], sh["state_counts"]), f"iteration {it}"
+        np.testing.assert_allclose(sh["beta_ss"], so["beta_ss"], rtol=1e-5)
+    assert so["state_counts"][1:].sum() > 0
+    for k in range(t):
+        _compare_state(orc, hip, k, atol=5e-6)
+
+
+def test_mt_marker_specific_prior_error_contracts(hip):
+    import jwas_jl_amd as J
+    data = make_dataset(n=100, p=1100, ncausal=3, seed=1)
+    hip.load_dense(data["X"]); hip.setup_blocks(1024, "f64"); hip.init_state("MTBayesC", 2)
+    lp = np.log(np.full((1100, 4), 0.25))
+    with pytest.raises(J.JwasHipError, match="block size <= 512"):
+        hip.sweep(iteration=1, seed=1, vare=np.eye(2, dtype=np.float32), var_effect=np.eye(2, dtype=np.float32) * 0.01, log_prior_states=lp)
+    hip.setup_blocks(128, "f64"); hip.init_state("MTBayesC", 3)
+    with pytest.raises(J.JwasHipError, match="support 2 traits"):
+        hip.sweep(iteration=1, seed=1, vare=np.eye(3, dtype=np.float32), var_effect=np.eye(3, dtype=np.float32) * 0.01,
+                  log_prior_states=np.log(np.full((1100, 8), 0.125)))
