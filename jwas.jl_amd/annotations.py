@@ -5,8 +5,8 @@ per-marker prior into the sweep (markers/readgenotypes.jl:56-160, markers/annota
 types.jl:167-215).  The sweep side is already per marker on the device (`pi_vec` for BayesC, the p x 4 `pi_matrix` for
 BayesR, include/jwas_hip.h); what lives here is the O(p x annotations) host update between sweeps: latent liabilities
 (truncated normals), a coordinate Gibbs pass over the annotation coefficients, their shrinkage variance, and the
-rebuilt per-marker priors.  Annotated multi-trait BayesC (a per-marker joint prior over 2^t states) stays on the
-reference."""
+rebuilt per-marker priors.  Annotated 2-trait BayesC uses the device's marker-specific joint-state prior
+(`log_prior_states_matrix`) the same way."""
 import numpy as np
 from scipy.special import ndtr, ndtri
 
@@ -152,12 +152,8 @@ def update_bayesc_binary_priors(ann, delta, rng):
     return np.clip(1.0 - ndtr(ann.mu), EPS, 1 - EPS)
 
 
-def update_bayesr_nested_priors(ann, delta, rng):
-    """annotation_updates.jl:196-285,337-351: three nested step-up probit models (delta > 1; > 2 | > 1; > 3 | > 2);
-    rebuilds ann.snp_pi (p x 4) and returns its column means."""
-    delta = np.asarray(delta)
-    z = (delta > 1, delta > 2, delta > 3)
-    active = (np.arange(delta.size), np.nonzero(z[0])[0], np.nonzero(z[1])[0])
+def _nested_probit_steps(ann, z, active, rng):
+    """sample_nested_annotation_probit_step! for steps 1..3 (annotation_updates.jl:232-268)"""
     for step in range(3):
         coeffs = ann.coefficients[:, step]
         ann.mu[:, step] = ann.design_matrix @ coeffs
@@ -173,11 +169,61 @@ def update_bayesr_nested_priors(ann, delta, rng):
         if X.shape[1] > 1:
             ann.variance[step] = sample_effect_variance(coeffs, rng)
         ann.mu[:, step] = ann.design_matrix @ coeffs
-    probs = np.clip(ndtr(ann.mu), EPS, 1 - EPS)
+    return np.clip(ndtr(ann.mu), EPS, 1 - EPS)
+
+
+def update_bayesr_nested_priors(ann, delta, rng):
+    """annotation_updates.jl:196-285,337-351: three nested step-up probit models (delta > 1; > 2 | > 1; > 3 | > 2);
+    rebuilds ann.snp_pi (p x 4) and returns its column means."""
+    delta = np.asarray(delta)
+    z = (delta > 1, delta > 2, delta > 3)
+    active = (np.arange(delta.size), np.nonzero(z[0])[0], np.nonzero(z[1])[0])
+    probs = _nested_probit_steps(ann, z, active, rng)
     ann.snp_pi[:, 0] = 1.0 - probs[:, 0]
     ann.snp_pi[:, 1] = probs[:, 0] * (1.0 - probs[:, 1])
     ann.snp_pi[:, 2] = probs[:, 0] * probs[:, 1] * (1.0 - probs[:, 2])
     ann.snp_pi[:, 3] = probs[:, 0] * probs[:, 1] * probs[:, 2]
+    return ann.snp_pi.mean(axis=0)
+
+
+# ---- annotated 2-trait BayesC: a tree over the joint states 00 / 10 / 01 / 11 -------------------------------------
+def bayesc_mt_start_row(pi):
+    """annotation_setup.jl:101-121 (+ validate_bayesc_mt_start_row :57-68).  `pi`: the 4 joint prior probabilities in
+    the order 00, 10, 01, 11 (= the device's state index sum_k delta_k << k), or 0.0 for the legacy all-active default."""
+    if np.isscalar(pi) and pi == 0.0:
+        row = np.array([0.0, 0.0, 0.0, 1.0])
+    else:
+        row = np.asarray(pi, dtype=np.float64).reshape(-1)
+        if row.size != 4:
+            raise ValueError("Annotated multi-trait BayesC v1 expects four joint prior probabilities.")
+    if not row[1] + row[3] > 0.0:
+        raise ValueError("Annotated multi-trait BayesC requires positive startup prior mass in states {10,11} for trait 1.")
+    if not row[2] + row[3] > 0.0:
+        raise ValueError("Annotated multi-trait BayesC requires positive startup prior mass in states {01,11} for trait 2.")
+    if not row[3] > 0.0:
+        raise ValueError("Annotated multi-trait BayesC requires positive startup prior mass in shared state 11.")
+    return row
+
+
+def initialize_bayesc_mt(design_matrix, start_row):
+    """annotation_setup.jl:123-133"""
+    D = np.asarray(design_matrix, dtype=np.float64)
+    return MarkerAnnotations(D, nsteps=3, nclasses=4, coefficients=np.zeros((D.shape[1], 3)),
+                             snp_pi=np.repeat(np.asarray(start_row, dtype=np.float64).reshape(1, 4), D.shape[0], axis=0))
+
+
+def update_bayesc_mt_tree_priors(ann, delta1, delta2, rng):
+    """annotation_updates.jl:287-326,353-361: step 1 zero vs active, step 2 (among active) 11 vs a single trait,
+    step 3 (among single-trait markers) 10 vs 01; rebuilds ann.snp_pi (p x 4, order 00,10,01,11), returns column means."""
+    d1, d2 = np.asarray(delta1) != 0, np.asarray(delta2) != 0
+    z = (d1 | d2, d1 & d2, d1 & ~d2)
+    active = (np.arange(d1.size), np.nonzero(z[0])[0], np.nonzero(d1 ^ d2)[0])
+    probs = _nested_probit_steps(ann, z, active, rng)
+    p1, p2, p3 = probs[:, 0], probs[:, 1], probs[:, 2]
+    ann.snp_pi[:, 0] = 1.0 - p1
+    ann.snp_pi[:, 1] = p1 * (1.0 - p2) * p3
+    ann.snp_pi[:, 2] = p1 * (1.0 - p2) * (1.0 - p3)
+    ann.snp_pi[:, 3] = p1 * p2
     return ann.snp_pi.mean(axis=0)
 
 
@@ -194,6 +240,7 @@ def coefficients_table(ann, method):
     sd = np.sqrt(np.abs(ann.mean_coefficients2 - ann.mean_coefficients ** 2))
     if ann.nsteps == 1:
         return pd.DataFrame({"Annotation": names, "Estimate": ann.mean_coefficients, "SD": sd})
-    steps = ["step1_zero_vs_nonzero", "step2_small_vs_larger", "step3_medium_vs_large"]
+    steps = (["step1_zero_vs_nonzero", "step2_small_vs_larger", "step3_medium_vs_large"] if method == "BayesR" else
+             ["step1_zero_vs_active", "step2_11_vs_singleton", "step3_10_vs_01"])
     return pd.DataFrame({"Annotation": np.repeat(names, ann.nsteps), "Step": steps[:ann.nsteps] * len(names),
                          "Estimate": ann.mean_coefficients.reshape(-1), "SD": sd.reshape(-1)})

@@ -268,6 +268,7 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
     if t > 1 and (np.isscalar(pi) and pi == 0.0):                      # tools4genotypes.jl:357-373
         pi = np.zeros(1 << t)
         pi[(1 << t) - 1] = 1.0
+        Mi._pi_was_default = True
     if method == "BayesR" and np.isscalar(pi) and pi == 0.0:           # :375-377
         pi = np.array([0.95, 0.03, 0.015, 0.005])
     if method == "BayesA":                                             # input_data_validation.jl:33-36
@@ -300,8 +301,14 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
     ann = getattr(Mi, "annotations", False)
     if ann is not False:
         from . import annotations as A_
-        if t > 1:
-            raise NotImplementedError("annotated multi-trait BayesC (a per-marker prior over the joint states) stays on the reference")
+        if t > 1:                                                      # annotation_setup.jl:101-133
+            if t != 2:
+                raise ValueError("Annotated multi-trait BayesC currently supports exactly 2 traits.")
+            if mega:
+                raise NotImplementedError("annotated multi-trait BayesC with constraint=true stays on the reference")
+            start_row = A_.bayesc_mt_start_row(0.0 if getattr(Mi, "_pi_was_default", False) else pi)
+            ann = Mi.annotations = A_.initialize_bayesc_mt(ann.design_matrix, start_row)
+            pi = start_row.copy()
         if stream:
             raise NotImplementedError("marker annotations with storage=:stream stay on the reference")
         if method == "BayesC":                                         # annotation_setup.jl:78-99
@@ -507,7 +514,7 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
             kw.update(var_effect=Gval, pi=pi_t)
         elif t > 1:
             with np.errstate(divide="ignore"):
-                kw.update(var_effect=Gval, log_prior_states=np.log(np.asarray(pi, dtype=np.float64)))
+                kw.update(var_effect=Gval, log_prior_states=np.log(ann.snp_pi if ann is not False else np.asarray(pi, dtype=np.float64)))
         elif method == "BayesR":
             kw.update(var_effect=Gval, pi_classes=np.asarray(pi, dtype=np.float64))
             if ann is not False:
@@ -529,6 +536,8 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         if Mi.estimatePi:
             if mega:                                                    # MCMC_BayesianAlphabet.jl:300-301
                 pi_t = np.array([rng.beta(p - st["sum_delta"][k] + 1.0, st["sum_delta"][k] + 1.0) for k in range(t)])
+            elif t > 1 and ann is not False:                            # annotation_updates.jl:353-361
+                pi = A_.update_bayesc_mt_tree_priors(ann, engine.get_state(0)[2], engine.get_state(1)[2], rng)
             elif t > 1:
                 pi = rng.dirichlet(st["state_counts"] + 1.0)
             elif ann is not False:                                      # update_marker_annotation_priors! (annotation_updates.jl:328-351)

@@ -28,8 +28,10 @@ MT_START_PI = {(0.0, 0.0): 0.96, (1.0, 0.0): 0.015, (0.0, 1.0): 0.015, (1.0, 1.0
 ST_BAYESC_PI = 0.98
 ST_BAYESR_PI = [0.99, 0.006, 0.003, 0.001]
 # held-out cor(y, EBV), trait mean over y1 and y2 (report: "Multi-Trait Family Summary", "Single-Trait Family Summary")
-REFERENCE = {"BayesC": 0.6424, "BayesR": 0.6497, "MT_I": 0.6397, "MT_II": 0.6423, "AnnotatedBayesC": 0.6469, "AnnotatedBayesR": 0.6484}
-REFERENCE_RMSE = {"BayesC": 4.5294, "BayesR": 4.4392, "MT_I": 5.0015, "MT_II": 4.6572, "AnnotatedBayesC": 4.6178, "AnnotatedBayesR": 4.3353}
+REFERENCE = {"BayesC": 0.6424, "BayesR": 0.6497, "MT_I": 0.6397, "MT_II": 0.6423, "AnnotatedBayesC": 0.6469, "AnnotatedBayesR": 0.6484,
+             "MT_Annotated_I": 0.6338, "MT_Annotated_II": 0.6522}
+REFERENCE_RMSE = {"BayesC": 4.5294, "BayesR": 4.4392, "MT_I": 5.0015, "MT_II": 4.6572, "AnnotatedBayesC": 4.6178, "AnnotatedBayesR": 4.3353,
+                  "MT_Annotated_I": 4.5087, "MT_Annotated_II": 4.4700}
 
 
 def folds_for(ids, nfolds, seed):
@@ -42,15 +44,18 @@ def run_variant(variant, pheno, seed, fold_of, fold, chain_length, burnin, freq,
     held = [i for i in pheno["ID"] if fold_of[i] == fold]
     mask = pheno["ID"].isin(held)
     rows = []
-    if variant in ("MT_I", "MT_II"):
+    if variant.startswith("MT_"):
         ymat = pheno[["y1", "y2"]].to_numpy(dtype=np.float64)
         start_g = np.cov(ymat.T) * 0.5
         start_r = np.cov(ymat.T) * 0.5
         run = pheno.copy()
         run.loc[mask, ["y1", "y2"]] = np.nan
+        akw = {}
+        if "Annotated" in variant:
+            akw["annotations"] = pd.read_csv(os.path.join(DATA, "annotations_mt.csv")).iloc[:, 1:].to_numpy(dtype=np.float64)
         bench_geno = api.get_genotypes(os.path.join(DATA, "genotypes.csv"), start_g, separator=",", method="BayesC",
                                        estimatePi=True, quality_control=False, center=False,
-                                       multi_trait_sampler="I" if variant == "MT_I" else "II", Pi=dict(MT_START_PI))
+                                       multi_trait_sampler="II" if variant.endswith("_II") else "I", Pi=dict(MT_START_PI), **akw)
         model = api.build_model("y1 = intercept + bench_geno\ny2 = intercept + bench_geno", start_r,
                                 genotypes={"bench_geno": bench_geno})
         traits = ["y1", "y2"]
@@ -87,7 +92,7 @@ def run_variant(variant, pheno, seed, fold_of, fold, chain_length, burnin, freq,
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--variants", nargs="+", default=["BayesC", "BayesR", "AnnotatedBayesC", "AnnotatedBayesR", "MT_I", "MT_II"])
+    ap.add_argument("--variants", nargs="+", default=["BayesC", "BayesR", "AnnotatedBayesC", "AnnotatedBayesR", "MT_I", "MT_II", "MT_Annotated_I", "MT_Annotated_II"])
     ap.add_argument("--seeds", type=int, nargs="+", default=[101, 202])
     ap.add_argument("--folds", type=int, default=5)
     ap.add_argument("--chain-length", type=int, default=1500)

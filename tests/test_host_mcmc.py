@@ -547,3 +547,31 @@ def test_annotation_input_errors():
         api.get_genotypes(gdf, method="BayesR", annotations=ann, Pi=[0.9, 0.1, 0.0, 0.0])
     with pytest.raises(ValueError, match="Pi vector length"):
         api.get_genotypes(gdf, method="BayesC", annotations=ann, Pi=np.full(7, 0.9))
+
+
+def test_annotated_two_trait_bayesc(tmp_path):
+    """Annotated 2-trait BayesC (annotation_setup.jl:101-133, annotation_updates.jl:287-326,353-361): the tree of probit
+    models over the joint states 00/10/01/11 drives a marker-specific joint prior (device: log_prior_states_matrix)."""
+    gdf, ph, ann, causal = _annotated_dataset(seed=11, n=350, p=260)
+    rng = np.random.default_rng(2)
+    y1 = ph["y1"].to_numpy()
+    ph = ph.assign(y2=0.7 * y1 + 0.7 * rng.standard_normal(len(y1)))
+    Pi = {(0.0, 0.0): 0.85, (1.0, 0.0): 0.05, (0.0, 1.0): 0.05, (1.0, 1.0): 0.05}
+    geno = api.get_genotypes(gdf, np.eye(2) * 0.5, method="BayesC", annotations=ann, Pi=Pi)
+    model = api.build_model("y1 = intercept + geno\ny2 = intercept + geno", np.eye(2))
+    out = api.runMCMC(model, ph, chain_length=300, burnin=80, seed=5, output_folder=str(tmp_path / "amt"),
+                      engine=OracleEngine("block"), block_size=64)
+    tab = out["annotation coefficients geno"]
+    assert list(tab.columns) == ["Annotation", "Step", "Estimate", "SD"] and len(tab) == 9
+    assert set(tab["Step"]) == {"step1_zero_vs_active", "step2_11_vs_singleton", "step3_10_vs_01"}
+    slope = float(tab[(tab["Annotation"] == "Annotation_1") & (tab["Step"] == "step1_zero_vs_active")]["Estimate"].iloc[0])
+    assert slope > 0.3, tab
+    assert len(out["pi_geno"]) == 4 and abs(out["pi_geno"]["Estimate"].sum() - 1.0) < 1e-6
+    me = out["marker effects geno"]
+    mf = me[me["Trait"] == "y1"]["Model_Frequency"].to_numpy()
+    assert mf[:60].mean() > mf[60:].mean()
+    with pytest.raises(ValueError, match="shared state 11"):
+        geno = api.get_genotypes(gdf, np.eye(2) * 0.5, method="BayesC", annotations=ann,
+                                 Pi={(0.0, 0.0): 0.9, (1.0, 0.0): 0.05, (0.0, 1.0): 0.05, (1.0, 1.0): 0.0})
+        model = api.build_model("y1 = intercept + geno\ny2 = intercept + geno", np.eye(2))
+        api.runMCMC(model, ph, chain_length=5, seed=5, output_folder=str(tmp_path / "amt2"), engine=OracleEngine("block"), block_size=64)
