@@ -27,6 +27,7 @@
  *                              Mi.output_genotypes (markers/tools4genotypes.jl:290-296) and getEBV over mme.output_ID
  *                              (output.jl:281-306; default output_ID = all genotyped individuals,
  *                              input_data_validation.jl:150-154)
+ *   jwas_hip_window_sums       window genomic variances of a marker-effect sample (src/3.GWAS/src/GWAS.jl:152-165)
  *
  * Conventions: every entry point returns 0 on success and a negative JWAS_HIP_E* code on failure
  * (no exceptions cross the boundary; jwas_hip_last_error() returns the message -- the analogue of
@@ -222,6 +223,14 @@ int  jwas_hip_mul_alpha(jwas_hip_ctx* ctx, int32_t trait, float* out_host);
 int  jwas_hip_load_output_dense_f32(jwas_hip_ctx* ctx, const float* X_out_host, int64_t n_out, int64_t p, int64_t ld_host);
 /* out = X_out * alpha_k (n_out floats, fp64-accumulated). */
 int  jwas_hip_mul_alpha_output(jwas_hip_ctx* ctx, int32_t trait, float* out_host);
+/* Window genomic variances of ONE saved marker-effect sample -- the inner loop of the reference's window-based GWAS
+ * (src/3.GWAS/src/GWAS.jl:152-165: genVar = var(X*alpha); per window var(X[:, w]*alpha[w])).  Window w owns the nonzero
+ * effects idx[wptr[w] .. wptr[w+1]) (marker indices, any order the caller wants summed in) with values val[..];
+ * windows may overlap (sliding windows) and window 0 is typically "all markers".  out_sum[w] = sum_i BV_w[i],
+ * out_ss[w] = sum_i BV_w[i]^2 (fp64, deterministic) over the training individuals, or over the output rows of
+ * jwas_hip_load_output_dense_f32 when use_output_rows != 0 (the reference uses Mi.output_genotypes). */
+int  jwas_hip_window_sums(jwas_hip_ctx* ctx, int32_t use_output_rows, int32_t nwin, const int32_t* wptr, const int32_t* idx,
+                          const float* val, double* out_sum, double* out_ss);
 
 /* ---- the sweep ------------------------------------------------------------------------------ */
 /* Time every `stride`-th k_block_step launch of subsequent sweeps with HIP events on the

@@ -15,6 +15,9 @@ def __getattr__(name):
     if name in ("get_genotypes", "build_model", "runMCMC", "Genotypes", "Model", "set_covariate", "outputEBV"):
         from . import api
         return getattr(api, name)
+    if name == "GWAS":
+        from . import gwas
+        return gwas.GWAS
     if name in ("prepare_streaming_genotypes", "load_streaming_backend"):
         from . import streaming
         return getattr(streaming, name)

@@ -19,6 +19,7 @@ import os
 import numpy as np
 
 from .mcmc import run_chain
+from .gwas import GWAS  # noqa: F401  (src/3.GWAS/src/GWAS.jl)
 
 # RR-BLUP: every marker is in the model with one common effect variance -- the same full conditionals as BayesC with
 # pi = 0 fixed (BayesL! with gammaArray = [1.0], BayesC0L.jl:20-47, vs bayesabc_update_marker! with probDelta1 = 1;

@@ -856,6 +856,45 @@ __global__ __launch_bounds__(256) void k_mul_alpha(CX cx, int64_t p,
     out[row] = (float)s;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Window genomic values of one marker-effect sample (GWAS.jl:152-165): window w holds the nonzero effects
+// idx[wptr[w] .. wptr[w+1]) with values val[..]; BV_w[i] = sum_j X[i, idx_j] * val_j (fp64-accumulated, fixed order).
+// grid = nslices, block = 256 (one individual per thread); partial[(w * nslices + slice) * 2 + {0,1}] = the slice's
+// sum of BV_w and of BV_w^2.  k_window_reduce then adds the slices in fixed order (deterministic, no atomics).
+// ---------------------------------------------------------------------------------------------
+template <class CX>
+__global__ __launch_bounds__(256) void k_window_partial(CX cx, int nwin, const int32_t* __restrict__ wptr,
+                                                        const int32_t* __restrict__ idx, const float* __restrict__ val,
+                                                        double* __restrict__ partial)
+{
+    __shared__ double red[2][4];
+    const int64_t row = (int64_t)blockIdx.x * kSliceRows + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int w = 0; w < nwin; ++w) {
+        double bv = 0.0;
+        for (int e = wptr[w]; e < wptr[w + 1]; ++e) bv = fma((double)val[e], (double)cx.load1(idx[e], row), bv);
+        double s = bv, q = bv * bv;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { s += __shfl_down(s, off, 64); q += __shfl_down(q, off, 64); }
+        if (lane == 0) { red[0][wave] = s; red[1][wave] = q; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            partial[((int64_t)w * gridDim.x + blockIdx.x) * 2 + 0] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+            partial[((int64_t)w * gridDim.x + blockIdx.x) * 2 + 1] = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+        }
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void k_window_reduce(int nwin, int nslices, const double* __restrict__ partial,
+                                                       double* __restrict__ out_sum, double* __restrict__ out_ss)
+{
+    const int w = blockIdx.x * 256 + threadIdx.x;
+    if (w >= nwin) return;
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < nslices; ++k) { s += partial[((int64_t)w * nslices + k) * 2]; q += partial[((int64_t)w * nslices + k) * 2 + 1]; }
+    out_sum[w] = s; out_ss[w] = q;
+}
+
 template <class CX>
 __global__ __launch_bounds__(256) void k_sub_xalpha(CX cx, int64_t p,
                                                     const float* __restrict__ alpha, float* __restrict__ r)

@@ -283,6 +283,17 @@ class HipEngine:
         self._chk(self._L.jwas_hip_load_output_dense_f32(self._h, _ptr(X_out), n_out, p, n_out))
         self.n_out = n_out
 
+    def window_sums(self, wptr, idx, val, use_output_rows=False):
+        """(sum_i BV_w[i], sum_i BV_w[i]^2) for every window of one marker-effect sample (GWAS.jl:152-165); CSR-like
+        description of the nonzero effects: window w = idx/val[wptr[w]:wptr[w+1]]."""
+        wptr = np.ascontiguousarray(wptr, dtype=np.int32)
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        val = np.ascontiguousarray(val, dtype=np.float32)
+        nwin = wptr.size - 1
+        s, q = np.empty(nwin), np.empty(nwin)
+        self._chk(self._L.jwas_hip_window_sums(self._h, 1 if use_output_rows else 0, nwin, _ptr(wptr), _ptr(idx), _ptr(val), _ptr(s), _ptr(q)))
+        return s, q
+
     def mul_alpha_output(self, trait=0):
         """EBV = output_genotypes * alpha (output.jl:281-306)."""
         out = np.empty(getattr(self, "n_out", 0), dtype=np.float32)

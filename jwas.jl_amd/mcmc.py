@@ -223,6 +223,9 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
                                           "(outputEBV(model, IDs) lists stay on the reference)")
             gi = {g: i for i, g in enumerate(Mi.obsID)}
             out_rows = np.array([gi[i] for i in out_ids], dtype=np.int64)
+    if not stream:
+        # rows of Mi.genotypes behind Mi.output_genotypes (tools4genotypes.jl:290-296); GWAS() reads them (GWAS.jl:148)
+        Mi.output_rows = out_rows if (outputEBV and not out_same) else rows
     with open(os.path.join(output_folder, "IDs_for_individuals_with_phenotypes.txt"), "w") as fh:
         fh.write("\n".join(ph[idcol]) + "\n")
     with open(os.path.join(output_folder, "IDs_for_individuals_with_genotypes.txt"), "w") as fh:

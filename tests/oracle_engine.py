@@ -120,6 +120,15 @@ class OracleEngine:
     def mul_alpha(self, trait=0):
         return (self.X.astype(np.float64) @ self.alpha[trait].astype(np.float64)).astype(np.float32)
 
+    def window_sums(self, wptr, idx, val, use_output_rows=False):
+        X = (self.X_out if use_output_rows else self.X).astype(np.float64)
+        idx = np.asarray(idx, dtype=np.int64); val = np.asarray(val, dtype=np.float64)
+        s, q = np.zeros(len(wptr) - 1), np.zeros(len(wptr) - 1)
+        for w in range(len(wptr) - 1):
+            bv = X[:, idx[wptr[w]:wptr[w + 1]]] @ val[wptr[w]:wptr[w + 1]]
+            s[w], q[w] = bv.sum(), (bv * bv).sum()
+        return s, q
+
     def load_output_dense(self, X_out):
         self.X_out = np.asarray(X_out, dtype=np.float32)
 
