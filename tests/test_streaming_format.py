@@ -100,3 +100,52 @@ def test_stream_mode_runmcmc_equals_dense_mode(tmp_path):
     model = api.build_model("y1 = intercept + geno")
     with pytest.raises(ValueError, match="requires exact genotype/phenotype ID match and order"):
         api.runMCMC(model, ph.iloc[::-1], chain_length=2, output_folder=str(tmp_path / "bad"), engine=OracleEngine("block"))
+
+
+def _write_geno_file(path, n=37, p=23, seed=4, missing=True):
+    rng = np.random.default_rng(seed)
+    f = rng.uniform(0.02, 0.5, p)
+    G = (rng.random((n, p)) < f).astype(int) + (rng.random((n, p)) < f).astype(int)
+    G[:, 5] = 1                                           # fixed marker: removed by QC
+    if missing:
+        G[rng.random((n, p)) < 0.03] = 9
+    ids = [f"a{i}" for i in range(n)]
+    tab = pd.DataFrame(G, columns=[f"m{j + 1}" for j in range(p)])
+    tab.insert(0, "ID", ids)
+    tab.to_csv(path, index=False)
+    return G, ids
+
+
+@pytest.mark.parametrize("center", [True, False])
+def test_lowmem_file_conversion_equals_dense_conversion(tmp_path, center):
+    """test_streaming_prepare_lowmem.jl:22-67,114-160: the chunked two-pass converter writes the same backend as the
+    load-everything converter (payload, sidecars, QC), and both decode to the dense get_genotypes matrix."""
+    import pandas as pd  # noqa: F811
+    path = str(tmp_path / "geno.csv")
+    G, ids = _write_geno_file(path)
+    pre_low = S.prepare_streaming_genotypes(path, str(tmp_path / "low"), conversion_mode="lowmem", chunk_rows=8, center=center)
+    pre_den = S.prepare_streaming_genotypes(path, str(tmp_path / "den"), conversion_mode="dense", center=center)
+    for ext in (".jgb2", ".obsid.txt", ".markerid.txt", ".selected.i32", ".mean.f32", ".xpRinvx.f32", ".afreq.f32"):
+        assert open(pre_low + ext, "rb").read() == open(pre_den + ext, "rb").read(), ext
+    b = S.load_streaming_backend(pre_low)
+    dense = api.get_genotypes(path, separator=",", header=True, method="BayesC", center=center)
+    assert b["markerID"] == dense.markerID and b["nObs"] == dense.nObs == 37 and b["nMarkers"] == dense.nMarkers < 23
+    Xs = S.decode_markers(b)
+    np.testing.assert_allclose(Xs, np.asarray(dense.genotypes), atol=1e-5)
+    np.testing.assert_allclose((Xs.astype(np.float64) ** 2).sum(0), b["xpRinvx"], rtol=2e-5)
+
+
+def test_auto_mode_and_guards(tmp_path, capsys):
+    """test_streaming_prepare_lowmem.jl:97-145"""
+    path = str(tmp_path / "geno.csv")
+    _write_geno_file(path, missing=False)
+    S.prepare_streaming_genotypes(path, str(tmp_path / "auto_d"), conversion_mode="auto", auto_dense_max_bytes=2 ** 30)
+    assert "Auto conversion mode selected :dense" in capsys.readouterr().out
+    S.prepare_streaming_genotypes(path, str(tmp_path / "auto_l"), conversion_mode="auto", auto_dense_max_bytes=10)
+    assert "Auto conversion mode selected :lowmem" in capsys.readouterr().out
+    assert open(str(tmp_path / "auto_d") + ".jgb2", "rb").read() == open(str(tmp_path / "auto_l") + ".jgb2", "rb").read()
+    with pytest.raises(OSError, match="Insufficient disk"):
+        S.prepare_streaming_genotypes(path, str(tmp_path / "guard"), conversion_mode="lowmem", disk_guard_ratio=0.0)
+    with pytest.raises(ValueError, match="conversion_mode"):
+        S.prepare_streaming_genotypes(path, str(tmp_path / "bad"), conversion_mode="fast")
+    assert S.prepare_streaming_genotypes(path).endswith("geno_stream")              # default prefix: <file>_stream
