@@ -806,6 +806,31 @@ int jwas_hip_residual_sub_xalpha(jwas_hip_ctx* c, int32_t trait)
     return JWAS_HIP_OK;
 }
 
+// The nonzero effects of trait `trait` as device lists (marker order); *nnz = -1: dense enough that the plain
+// loop over all markers is the better kernel.
+static hipError_t sparse_alpha(jwas_hip_ctx* c, int32_t trait, int32_t** d_idx, float** d_val, int* nnz)
+{
+    *d_idx = nullptr; *d_val = nullptr; *nnz = -1;
+    std::vector<float> a((size_t)c->p);
+    hipError_t e = hipMemcpyAsync(a.data(), c->alpha + (size_t)trait * c->p, sizeof(float) * c->p, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) return e;
+    std::vector<int32_t> idx; std::vector<float> val;
+    for (int64_t j = 0; j < c->p; ++j)
+        if (a[(size_t)j] != 0.f) {
+            idx.push_back((int32_t)j); val.push_back(a[(size_t)j]);
+            if ((int64_t)idx.size() * 4 > c->p) return hipSuccess;          // dense
+        }
+    *nnz = (int)idx.size();
+    if (*nnz == 0) return hipSuccess;
+    e = hipMalloc(d_idx, sizeof(int32_t) * idx.size());
+    if (e == hipSuccess) e = hipMalloc(d_val, sizeof(float) * val.size());
+    if (e == hipSuccess) e = hipMemcpyAsync(*d_idx, idx.data(), sizeof(int32_t) * idx.size(), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(*d_val, val.data(), sizeof(float) * val.size(), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);               // (the host vectors die with this frame)
+    return e;
+}
+
 int jwas_hip_mul_alpha(jwas_hip_ctx* c, int32_t trait, float* out)
 {
     NEED(c, c && out, JWAS_HIP_EINVAL, "NULL argument");
@@ -813,15 +838,21 @@ int jwas_hip_mul_alpha(jwas_hip_ctx* c, int32_t trait, float* out)
     HIPCHK(c, hipSetDevice(c->device));
     float* tmp = nullptr;
     HIPCHK(c, hipMalloc(&tmp, sizeof(float) * c->ld));
+    int32_t* d_idx = nullptr; float* d_val = nullptr; int nnz = -1;
+    hipError_t e0 = sparse_alpha(c, trait, &d_idx, &d_val, &nnz);
+    if (e0 != hipSuccess) { (void)hipFree(tmp); (void)hipFree(d_idx); (void)hipFree(d_val); return fail(c, JWAS_HIP_EHIP, "jwas_hip_mul_alpha: %s", hipGetErrorString(e0)); }
     with_cols(c, 0, [&](auto cx) {
-        hipLaunchKernelGGL((k_mul_alpha<decltype(cx)>), dim3(c->nslices), dim3(256), 0, c->stream, cx, c->p,
-                           c->alpha + (size_t)trait * c->p, tmp);
+        if (nnz >= 0)
+            hipLaunchKernelGGL((k_mul_alpha_list<decltype(cx)>), dim3(c->nslices), dim3(256), 0, c->stream, cx, nnz, d_idx, d_val, tmp);
+        else
+            hipLaunchKernelGGL((k_mul_alpha<decltype(cx)>), dim3(c->nslices), dim3(256), 0, c->stream, cx, c->p,
+                               c->alpha + (size_t)trait * c->p, tmp);
         return 0;
     });
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(out, tmp, sizeof(float) * c->n, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(tmp);
+    (void)hipFree(tmp); (void)hipFree(d_idx); (void)hipFree(d_val);
     if (e != hipSuccess) return fail(c, JWAS_HIP_EHIP, "jwas_hip_mul_alpha: %s", hipGetErrorString(e));
     return JWAS_HIP_OK;
 }
@@ -859,12 +890,18 @@ int jwas_hip_mul_alpha_output(jwas_hip_ctx* c, int32_t trait, float* out)
     float* tmp = nullptr;
     HIPCHK(c, hipMalloc(&tmp, sizeof(float) * c->ld_out));
     DenseCols cx{c->Xout, c->ld_out, nullptr, 0};
-    hipLaunchKernelGGL((k_mul_alpha<DenseCols>), dim3((unsigned)(c->ld_out / kSliceRows)), dim3(256), 0, c->stream, cx, c->p,
-                       c->alpha + (size_t)trait * c->p, tmp);
+    int32_t* d_idx = nullptr; float* d_val = nullptr; int nnz = -1;
+    hipError_t e0 = sparse_alpha(c, trait, &d_idx, &d_val, &nnz);
+    if (e0 != hipSuccess) { (void)hipFree(tmp); (void)hipFree(d_idx); (void)hipFree(d_val); return fail(c, JWAS_HIP_EHIP, "jwas_hip_mul_alpha_output: %s", hipGetErrorString(e0)); }
+    if (nnz >= 0)
+        hipLaunchKernelGGL((k_mul_alpha_list<DenseCols>), dim3((unsigned)(c->ld_out / kSliceRows)), dim3(256), 0, c->stream, cx, nnz, d_idx, d_val, tmp);
+    else
+        hipLaunchKernelGGL((k_mul_alpha<DenseCols>), dim3((unsigned)(c->ld_out / kSliceRows)), dim3(256), 0, c->stream, cx, c->p,
+                           c->alpha + (size_t)trait * c->p, tmp);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(out, tmp, sizeof(float) * c->n_out, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(tmp);
+    (void)hipFree(tmp); (void)hipFree(d_idx); (void)hipFree(d_val);
     if (e != hipSuccess) return fail(c, JWAS_HIP_EHIP, "jwas_hip_mul_alpha_output: %s", hipGetErrorString(e));
     return JWAS_HIP_OK;
 }
