@@ -279,8 +279,17 @@ static int alloc_storage(jwas_hip_ctx* c, int64_t n, int64_t p, bool packed = fa
     // Column groups: as many workgroups as fit in ONE scheduling round.  The step kernel's dynamic LDS (sized for the
     // sampler role) allows one workgroup per CU, and the quiet-XCD placement leaves every 8th CU idle, so 224 of the
     // 256 CUs stream; more workgroups than that run as a second round and cost up to 2x (measured: 5.5-6.1 TB/s with
-    // <= 224 workgroups, 3.8-4.1 TB/s with 235-245).  At most 8-fold update redundancy.
-    c->ncg = 224 / c->nrg; if (c->ncg < 1) c->ncg = 1; if (c->ncg > 8) c->ncg = 8;
+    // <= 224 workgroups, 3.8-4.1 TB/s with 235-245).
+    c->ncg = 224 / c->nrg; if (c->ncg < 1) c->ncg = 1;
+    {   // Cap on the column groups (every column group of a row group re-applies the previous block's changes to its
+        // copy of the residual slice, so the cap bounds that redundancy).  Short matrices have few row groups and need
+        // many column groups to put enough workgroups on the chip: measured per sweep at p = 102 400, sparse steady state,
+        // 1024-marker blocks, cap 8 -> 16 -> 32:  n = 5 000: 2.60 -> 1.92 -> 1.80 ms;  10 000: 2.67 -> 1.96 -> 1.87;
+        // 20 000: 2.84 -> 2.14 -> 2.22;  30 000: 2.99 -> 2.61 (14 groups).  n >= 50 000 reaches 200+ workgroups with <= 8.
+        const char* e = std::getenv("JWAS_HIP_MAX_NCG");                 // (experiments)
+        const int cap = e ? std::atoi(e) : (c->nrg < 8 ? 32 : 16);
+        if (c->ncg > cap) c->ncg = cap;
+    }
     size_t fb = 0, tb = 0;
     HIPCHK(c, hipMemGetInfo(&fb, &tb));
     const size_t need = packed ? (size_t)(c->ld >> 2) * p : (size_t)4 * c->ld * p;

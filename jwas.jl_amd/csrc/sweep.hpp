@@ -473,6 +473,8 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
     float* rhs_lds = reinterpret_cast<float*>(smem + SM.rhs_off);
     float* acur = reinterpret_cast<float*>(smem + SM.acur_off);
     float* astart = reinterpret_cast<float*>(smem + SM.astart_off);
+    float* bpark0 = reinterpret_cast<float*>(smem + SM.bcur_off);      // [B] beta / [B] delta of the block (single trait:
+    float* dpark0 = reinterpret_cast<float*>(smem + SM.dcur_off);      // the multi-trait slots are free)
     const long long tk0 = clock64();
 
     // ---- phase A (all threads, ONE memory latency): for its marker every thread issues, back to back, the
@@ -530,11 +532,13 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
             int cl0 = bm.evaluate_thr(rhs0, 0.f, ie, an, sure);
             if (!sure) cl0 = bm.evaluate(rhs0, 0.f, ie, an);
             cand[q] = (c < b) && ((a_in != 0.f) || (cl0 != 0));
+            dpark0[c] = 1.f;                      // a marker that stays out: class 1 (see the prefix skip below)
         } else {
             float gh;
             am.store(lpd, lpf, B, c);
             lpf[3 * B + c] = dj;
             cand[q] = (c < b) && ((a_in != 0.f) || am.evaluate(rhs0, 0.f, ie, gh));
+            bpark0[c] = am.beta_excl; dpark0[c] = 0.f;
         }
     }
     if (prestage) {
@@ -557,14 +561,27 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
     {
         int* wc = reinterpret_cast<int*>(smem + SM.wcnt_off);
         const unsigned long long mb = __ballot(cand[0] || cand[1]);
-        if (lane == 0) wc[wave] = __popcll(mb);
+        // bits 16 / 17: this wave's markers of sub-block `wave` / `8 + wave` contain a candidate
+        const int f0 = __any(cand[0]) ? 1 << 16 : 0, f1 = __any(cand[1]) ? 1 << 17 : 0;     // (votes outside the lane-0 branch)
+        if (lane == 0) wc[wave] = __popcll(mb) | f0 | f1;
     }
     __syncthreads();
     int ncand_all = 0;
+    // PREFIX SKIP: until the first candidate of the block commits, the running rhs IS the entry rhs, so the evaluation
+    // every thread just did is final for all markers before it -- they stay out of the model (beta / delta parked
+    // above) and the serial wave starts at the first sub-block that holds a candidate.  With a sparse prior that is
+    // half of the sub-blocks on average, and all of them in the blocks without a candidate.
+    int first_sub = 16;
     {
         const int* wc = reinterpret_cast<const int*>(smem + SM.wcnt_off);
+        unsigned mask = 0u;
 #pragma unroll
-        for (int q = 0; q < kStepThreads / 64; ++q) ncand_all += wc[q];
+        for (int q = 0; q < kStepThreads / 64; ++q) {
+            const int v = wc[q];
+            ncand_all += v & 0xffff;
+            mask |= ((v >> 16) & 1u) << q | ((v >> 17) & 1u) << (8 + q);
+        }
+        if (mask) first_sub = __builtin_ctz(mask);
     }
     __syncthreads();                               // (stage_rows reuses the slots)
     const long long tk1 = clock64();
@@ -664,10 +681,11 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
         }
     }
 
+    const int s_first = (lazy && !dense_done) ? (first_sub < nsub ? first_sub : nsub) : 0;      // prefix skip (single pass only)
     for (int rep = 0; rep < (dense_done ? 0 : nreps); ++rep) {
         key.rep = (uint32_t)rep;
 #pragma unroll 1
-        for (int s = 0; s < nsub; ++s) {
+        for (int s = s_first; s < nsub; ++s) {
             const int c = 64 * s + lane;
             const bool valid = c < b;
             const int64_t j = j0 + (valid ? c : 0);
@@ -809,22 +827,13 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
             bpark[c] = b_out; dpark[c] = d_out;
         }
     }
-    if (!dense_done) {
-#pragma unroll 1
-        for (int s = 0; s < nsub; ++s) {
-            const int c = 64 * s + lane;
-            if (c < b) {
-                if constexpr (METHOD == kBayesR) delta_i[j0 + c] = (int32_t)dpark[c];
-                else { A.beta[j0 + c] = bpark[c]; delta_f[j0 + c] = dpark[c]; }
-            }
-        }
-    }
+    if (lane == 0) wcnt_s[14] = dense_done ? 1 : 0;      // (the dense walk stored beta / delta itself)
 
-    // write back alpha and the net changes of this block
+    // write back alpha and the net changes of this block (nothing changed before the first candidate's sub-block)
     const long long tk4 = clock64();
     int base = 0;
 #pragma unroll 1
-    for (int s = 0; s < nsub; ++s) {
+    for (int s = s_first; s < nsub; ++s) {
         const int c = 64 * s + lane;
         const bool valid = c < b;
         const int64_t j = j0 + (valid ? c : 0);
@@ -857,6 +866,12 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
     }
     }   // wave 0
     __syncthreads();
+    if (!wcnt_s[14]) {                                       // beta / delta of the block, parked in LDS: all threads store
+        for (int c = tid; c < b; c += kStepThreads) {
+            if constexpr (METHOD == kBayesR) reinterpret_cast<int32_t*>(A.delta)[j0 + c] = (int32_t)dpark0[c];
+            else { A.beta[j0 + c] = bpark0[c]; reinterpret_cast<float*>(A.delta)[j0 + c] = dpark0[c]; }
+        }
+    }
     if (A.b_next > 0) corr_phase<1>(smem, SM, A, wcnt_s[15], cross_lds);
 }
 
