@@ -586,7 +586,8 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
     __syncthreads();                               // (stage_rows reuses the slots)
     const long long tk1 = clock64();
     const long long tk2 = clock64();
-    int nstaged = prestage ? b : stage_rows(smem, SM, A, cand);
+    // (a block without any candidate -- about a third of them with a sparse prior -- has nothing to stage or to walk)
+    int nstaged = prestage ? b : (first_sub >= 16 ? 0 : stage_rows(smem, SM, A, cand));
     const bool cross_lds = prestage && SM.has_cross;
     if (cross_lds) copy_cross_rows(smem, SM, A);         // waves 1..7, while wave 0 runs the serial phase
     else prefetch_cross_rows(smem, SM, A, nstaged);      // waves 1..7: pull the rows into L2 for corr_phase at the end
