@@ -352,12 +352,16 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
             raise NotImplementedError("explicit fast_blocks start vectors stay on the reference (device blocks are uniform)")
         if want < 1:
             raise ValueError("fast_blocks block size must be at least 1.")
-        block_size = _supported_block(want)
-        if p <= block_size:
+        if want >= p:                                                   # range(1, step=want, stop=p) has one start
             raise ValueError("fast_blocks block size must create at least two block starts.")
-        chain_length = int(np.floor(chain_length / block_size))
-        nreps = 0                                                       # = block size (BayesABC.jl:153)
-        print(f"BLOCK SIZE: {block_size}")
+        # the device partition: uniform blocks of a supported size >= the requested one (any partition is an exact block
+        # Gibbs sampler; the schedule is the reference's: as many within-block repetitions as the block is long, and the
+        # outer chain shortened by the same factor).  Fewer markers than one device block: a single block of p markers.
+        block_size = _supported_block(want)
+        eff = min(block_size, p)
+        chain_length = int(np.floor(chain_length / eff))
+        nreps = 0                                                       # = block length (BayesABC.jl:153)
+        print(f"BLOCK SIZE: {eff}" + (f" (requested {want})" if eff != want else ""))
     adaptive = False
     if block_size is None:
         # Device block size.  Sparse priors (few markers change per sweep): big blocks amortise the per-launch cost.

@@ -220,7 +220,7 @@ def test_runmcmc_contract_errors(tmp_path):
     with pytest.raises(NotImplementedError, match="single_step_analysis"):
         api.runMCMC(model, ph, single_step_analysis=True, output_folder=str(tmp_path / "e2"))
     with pytest.raises(ValueError, match="at least two block starts"):
-        api.runMCMC(model, ph, fast_blocks=True, output_folder=str(tmp_path / "e3"), engine=OracleEngine("block"))
+        api.runMCMC(model, ph, fast_blocks=4, output_folder=str(tmp_path / "e3"), engine=OracleEngine("block"))   # 4 markers: one start
     with pytest.raises(ValueError, match="Model equations are wrong"):
         api.build_model("")
     nog = api.build_model("y1 = intercept")

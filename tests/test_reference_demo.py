@@ -187,3 +187,29 @@ def test_ebv_output_with_genotypes(tmp_path):
     ebv = out["EBV_y1"]
     assert list(ebv.columns) == ["ID", "EBV", "PEV"] and len(ebv) == 7
     assert (ebv["PEV"] >= 0).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sampler,independent", [("I", False), ("II", False), ("I", True), ("II", True)])
+def test_multi_trait_fast_blocks_runs(tmp_path, sampler, independent):
+    """test_multitrait_mcmc.jl:267-322, 373-443: multi-trait BayesC with fast_blocks=true (block size floor(sqrt(nObs)) = 2
+    in the reference; 5 markers are fewer than one device block, so the device runs them as a single block with the same
+    repetition schedule) and with independent blocks, samplers I and II."""
+    G = np.array([[1.0, 0.5], [0.5, 1.0]])
+    geno = api.get_genotypes(GENO, G, separator=",", method="BayesC", quality_control=False, multi_trait_sampler=sampler)
+    model = api.build_model("y1 = intercept + geno\ny2 = intercept + geno", G)
+    out = api.runMCMC(model, _phenotypes(), chain_length=100, burnin=5, output_samples_frequency=5,
+                      output_folder=str(tmp_path / "fb"), seed=123, fast_blocks=True, independent_blocks=independent)
+    assert "marker effects geno" in out and "location parameters" in out
+    assert np.isfinite(out["marker effects geno"]["Estimate"]).all()
+    assert out["_timing"]["iterations"] == 20                     # chain_length / 5 outer iterations
+
+
+def test_fast_blocks_needs_two_block_starts(tmp_path):
+    """JWAS.jl:308-311"""
+    geno = api.get_genotypes(GENO, 1.0, separator=",", method="BayesC", quality_control=False)
+    model = api.build_model("y1 = intercept + geno", 1.0)
+    from oracle_engine import OracleEngine
+    with pytest.raises(ValueError, match="at least two block starts"):
+        api.runMCMC(model, _phenotypes(), chain_length=20, output_folder=str(tmp_path / "x"), seed=1, fast_blocks=7,
+                    engine=OracleEngine("block"))
