@@ -354,14 +354,14 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
             raise ValueError("fast_blocks block size must be at least 1.")
         if want >= p:                                                   # range(1, step=want, stop=p) has one start
             raise ValueError("fast_blocks block size must create at least two block starts.")
-        # the device partition: uniform blocks of a supported size >= the requested one (any partition is an exact block
-        # Gibbs sampler; the schedule is the reference's: as many within-block repetitions as the block is long, and the
-        # outer chain shortened by the same factor).  Fewer markers than one device block: a single block of p markers.
+        # The schedule is the reference's for the REQUESTED size: `want` within-block repetitions (BayesABC.jl:153) and
+        # chain_length / want outer iterations -- the same number of hyper-parameter updates and saved samples.  The
+        # device partition is uniform blocks of the next supported size >= want (any partition is an exact block Gibbs
+        # sampler); fewer markers than one device block run as a single block.
         block_size = _supported_block(want)
-        eff = min(block_size, p)
-        chain_length = int(np.floor(chain_length / eff))
-        nreps = 0                                                       # = block length (BayesABC.jl:153)
-        print(f"BLOCK SIZE: {eff}" + (f" (requested {want})" if eff != want else ""))
+        chain_length = int(np.floor(chain_length / want))
+        nreps = want
+        print(f"BLOCK SIZE: {want}" + (f" (device blocks of {min(block_size, p)} markers)" if min(block_size, p) != want else ""))
     adaptive = False
     if block_size is None:
         # Device block size.  Sparse priors (few markers change per sweep): big blocks amortise the per-launch cost.
@@ -527,7 +527,7 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
             if ann is not False:
                 kw["pi_matrix"] = ann.snp_pi                            # per-marker class priors (BayesR.jl:62-66)
             if fast_blocks is not False:                                # bayesr_block_nreps (BayesR.jl:22-25)
-                kw["nreps"] = 1 if it <= burnin else 0
+                kw["nreps"] = 1 if it <= burnin else nreps
         elif method == "BayesB":
             kw.update(var_effect=Gval, var_effect_vec=Gvec, pi=pi)
         elif np.ndim(pi) == 1:                                          # marker-level pi (bayesabc_pi_vector, BayesABC.jl:16-22)

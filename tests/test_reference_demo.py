@@ -193,8 +193,8 @@ def test_ebv_output_with_genotypes(tmp_path):
 @pytest.mark.parametrize("sampler,independent", [("I", False), ("II", False), ("I", True), ("II", True)])
 def test_multi_trait_fast_blocks_runs(tmp_path, sampler, independent):
     """test_multitrait_mcmc.jl:267-322, 373-443: multi-trait BayesC with fast_blocks=true (block size floor(sqrt(nObs)) = 2
-    in the reference; 5 markers are fewer than one device block, so the device runs them as a single block with the same
-    repetition schedule) and with independent blocks, samplers I and II."""
+    in the reference; 5 markers are fewer than one device block, so the device runs them as a single block with the
+    reference's repetition schedule: 2 repetitions, chain_length / 2 outer iterations) and with independent blocks, samplers I and II."""
     G = np.array([[1.0, 0.5], [0.5, 1.0]])
     geno = api.get_genotypes(GENO, G, separator=",", method="BayesC", quality_control=False, multi_trait_sampler=sampler)
     model = api.build_model("y1 = intercept + geno\ny2 = intercept + geno", G)
@@ -202,7 +202,7 @@ def test_multi_trait_fast_blocks_runs(tmp_path, sampler, independent):
                       output_folder=str(tmp_path / "fb"), seed=123, fast_blocks=True, independent_blocks=independent)
     assert "marker effects geno" in out and "location parameters" in out
     assert np.isfinite(out["marker effects geno"]["Estimate"]).all()
-    assert out["_timing"]["iterations"] == 20                     # chain_length / 5 outer iterations
+    assert out["_timing"]["iterations"] == 50                     # chain_length / floor(sqrt(4 records)) outer iterations
 
 
 def test_fast_blocks_needs_two_block_starts(tmp_path):
