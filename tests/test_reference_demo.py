@@ -213,3 +213,49 @@ def test_fast_blocks_needs_two_block_starts(tmp_path):
     with pytest.raises(ValueError, match="at least two block starts"):
         api.runMCMC(model, _phenotypes(), chain_length=20, output_folder=str(tmp_path / "x"), seed=1, fast_blocks=7,
                     engine=OracleEngine("block"))
+
+
+# ---- test/unit/test_bayesr.jl:62-140, 282-344 ---------------------------------------------------------------
+BAYESR_PI = [0.95, 0.03, 0.015, 0.005]
+
+
+def test_bayesr_genotype_loads():
+    geno = api.get_genotypes(GENO, 1.0, separator=",", method="BayesR", Pi=list(BAYESR_PI), estimatePi=True)
+    model = api.build_model("y1 = intercept + geno", 1.0)
+    assert geno.method == "BayesR" and model.nModels == 1
+
+
+def test_bayesr_rejects_bad_pi_length(tmp_path):
+    from oracle_engine import OracleEngine
+    geno = api.get_genotypes(GENO, 1.0, separator=",", method="BayesR", Pi=[0.95, 0.05, 0.0], estimatePi=True)
+    model = api.build_model("y1 = intercept + geno", 1.0)
+    with pytest.raises(ValueError, match="length 4"):
+        api.runMCMC(model, _phenotypes(), chain_length=10, output_folder=str(tmp_path / "x"), seed=1, engine=OracleEngine("block"))
+
+
+def test_bayesr_does_not_mutate_caller_pi(tmp_path):
+    from oracle_engine import OracleEngine
+    start_pi = np.array(BAYESR_PI)
+    original = start_pi.copy()
+    geno = api.get_genotypes(GENO, 1.0, separator=",", method="BayesR", Pi=start_pi, estimatePi=True)
+    model = api.build_model("y1 = intercept + geno", 1.0)
+    api.runMCMC(model, _phenotypes(), chain_length=10, burnin=0, output_samples_frequency=5, output_folder=str(tmp_path / "x"),
+                seed=123, printout_model_info=False, outputEBV=False, engine=OracleEngine("block"))
+    assert np.array_equal(start_pi, original)
+
+
+@pytest.mark.gpu
+def test_bayesr_runs_and_estimatepi_output(tmp_path):
+    geno = api.get_genotypes(GENO, 1.0, separator=",", method="BayesR", Pi=list(BAYESR_PI), estimatePi=True, estimate_variance=True)
+    model = api.build_model("y1 = intercept + geno", 1.0)
+    out = api.runMCMC(model, _phenotypes(), chain_length=30, burnin=5, output_samples_frequency=5, output_folder=str(tmp_path / "a"),
+                      seed=321, printout_model_info=False, outputEBV=False, fast_blocks=False)
+    assert len(out["pi_geno"]) == 4 and abs(out["pi_geno"]["Estimate"].sum() - 1.0) < 1e-6
+    assert out["marker effects geno"]["Model_Frequency"].between(0, 1).all()
+    # fast_blocks=true gets past validation and runs; fast_blocks=1 is the plain chain (block size 1, 1 repetition)
+    for fb in (True, 1):
+        geno = api.get_genotypes(GENO, 1.0, separator=",", method="BayesR", Pi=list(BAYESR_PI), estimatePi=False, estimate_variance=False)
+        model = api.build_model("y1 = intercept + geno", 1.0)
+        o = api.runMCMC(model, _phenotypes(), chain_length=10, burnin=0, output_samples_frequency=5, output_folder=str(tmp_path / f"fb{fb}"),
+                        seed=123, printout_model_info=False, outputEBV=False, fast_blocks=fb)
+        assert o["_timing"]["iterations"] == (5 if fb is True else 10)       # floor(sqrt(4 records)) = 2 -> 10 / 2
