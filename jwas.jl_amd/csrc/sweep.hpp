@@ -598,7 +598,6 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
 
     // wave 0: lane l owns marker c = 64*s + l of sub-block s
     float* delta_f = reinterpret_cast<float*>(A.delta);
-    int32_t* delta_i = reinterpret_cast<int32_t*>(A.delta);
     const short* slot_of = reinterpret_cast<const short*>(smem + SM.slot_off);
     const float* rows = reinterpret_cast<const float*>(smem + SM.rows_off);
     int2* evlog = reinterpret_cast<int2*>(smem + SM.log_off);
