@@ -149,3 +149,31 @@ def test_stream_mode_runmcmc_on_the_device(engines, tmp_path):
     np.testing.assert_allclose(a["Estimate"], b["Estimate"], atol=1e-4)       # test_streaming_codec.jl:100,104
     np.testing.assert_allclose(a["Model_Frequency"], b["Model_Frequency"], atol=1e-4)
     np.testing.assert_allclose(outs[0]["EBV_y1"]["EBV"], outs[1]["EBV_y1"]["EBV"], atol=1e-3)
+
+
+def test_ebv_products_and_window_sums_on_packed_storage(engines, tmp_path):
+    """X*alpha (sparse list kernel and the dense 16-deep kernel) and the GWAS window sums decode the packed payload on
+    the fly: identical to the dense path on the decoded matrix."""
+    dense, packed = engines
+    d, raw = _packed_inputs(517, 400, 8)
+    prefix = S.prepare_streaming_genotypes(raw, tmp_path / "g", quality_control=False, center=True)
+    X = S.decode_markers(S.load_streaming_backend(prefix))
+    packed.load_jgb2(prefix + ".jgb2")
+    dense.load_dense(X)
+    rng = np.random.default_rng(0)
+    a_sparse = np.zeros(400, dtype=np.float32); a_sparse[rng.choice(400, 12, replace=False)] = rng.standard_normal(12)
+    a_dense = rng.standard_normal(400).astype(np.float32)
+    for e in (dense, packed):
+        e.setup_blocks(64, "f64"); e.init_state("BayesC")
+    for a in (a_sparse, a_dense):
+        for e in (dense, packed):
+            e.set_state(alpha=a)
+        gd, gp = dense.mul_alpha(), packed.mul_alpha()
+        assert np.array_equal(gd, gp)
+        np.testing.assert_allclose(gd, X.astype(np.float64) @ a.astype(np.float64), atol=2e-4)
+    nz = np.flatnonzero(a_sparse)
+    wptr = np.array([0, nz.size, nz.size + 4, nz.size + 9], dtype=np.int32)
+    idx = np.concatenate([nz, nz[:4], nz[4:9]]).astype(np.int32)
+    sd, qd = dense.window_sums(wptr, idx, a_sparse[idx])
+    sp, qp = packed.window_sums(wptr, idx, a_sparse[idx])
+    assert np.array_equal(sd, sp) and np.array_equal(qd, qp)
