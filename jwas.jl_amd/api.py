@@ -352,7 +352,7 @@ def runMCMC(model, df, *, heterogeneous_residuals=False, chain_length=100, start
                      output_samples_frequency=int(output_samples_frequency), seed=seed,
                      starting_value=starting_value, fast_blocks=fast_blocks,
                      independent_blocks=bool(independent_blocks), heterogeneous_residuals=bool(heterogeneous_residuals),
-                     outputEBV=outputEBV,
+                     outputEBV=outputEBV, output_heritability=bool(output_heritability),
                      output_folder=output_folder, printout_frequency=printout_frequency,
                      memory_guard=memory_guard, memory_guard_ratio=memory_guard_ratio,
                      missing_phenotypes=missing_phenotypes, device=device, block_size=block_size,

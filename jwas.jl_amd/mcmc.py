@@ -142,7 +142,7 @@ def _gibbs(A, x, b, rng, vare=None):
 
 
 def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed, starting_value,
-              fast_blocks, independent_blocks=False, heterogeneous_residuals=False, outputEBV, output_folder, printout_frequency, memory_guard, memory_guard_ratio,
+              fast_blocks, independent_blocks=False, heterogeneous_residuals=False, outputEBV, output_heritability=True, output_folder, printout_frequency, memory_guard, memory_guard_ratio,
               missing_phenotypes, device, block_size, gram_mode, engine, printout_model_info,
               output_samples_for_all_parameters):
     import pandas as pd
@@ -467,6 +467,11 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
     if Mi.estimatePi and (np.size(pi) <= 20000 or output_samples_for_all_parameters):   # (marker-level pi: p values per sample)
         npi = t if mega else np.size(pi)
         _open(f"pi_{name}", [f"pi{i + 1}" for i in range(npi)] if npi > 1 else ["pi"])
+    heritability = bool(outputEBV and output_heritability)              # output.jl:358-362,426-432
+    if heritability:
+        _open("genetic_variance", rnames if t > 1 else [model.lhsVec[0]])
+        _open("heritability", list(model.lhsVec))
+        h2_samples, gv_samples = [], []
     write_marker_samples = output_samples_for_all_parameters or p <= 20000
     if write_marker_samples:
         for k, tr in enumerate(model.lhsVec):
@@ -615,8 +620,19 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
                     a.tofile(fh, sep=",", format="%.9g")          # text at C speed; 9 significant digits round-trip Float32
                     fh.write("\n")
             if outputEBV:
+                ebvs = [engine.mul_alpha(kk) if out_same else engine.mul_alpha_output(kk) for kk in range(t)]   # getEBV, output.jl:281-306
                 for kk in range(t):
-                    ebv_run[kk].add(engine.mul_alpha(kk) if out_same else engine.mul_alpha_output(kk), k)   # getEBV, output.jl:281-306
+                    ebv_run[kk].add(ebvs[kk], k)
+                if heritability:                                        # output.jl:498-512
+                    E = np.stack(ebvs, axis=1).astype(np.float64)
+                    gv = np.atleast_2d(np.cov(E, rowvar=False))
+                    if t > 1 and Mi.G.constraint:
+                        gv = np.diag(np.diag(gv))
+                    vr = np.atleast_2d(np.asarray(vare, dtype=np.float64))
+                    h2 = np.diag(gv) / (np.diag(gv) + np.diag(vr))
+                    gv_samples.append(gv.ravel()); h2_samples.append(h2)
+                    files["genetic_variance"].write(",".join(repr(float(v)) for v in gv.ravel()) + "\n")
+                    files["heritability"].write(",".join(repr(float(v)) for v in h2) + "\n")
         if it % printout_frequency == 0 and it > burnin:
             print(f"\nPosterior means at iteration: {it}")
             print(f"Residual variance: {np.round(run_vare.mean, 6)}")
@@ -661,6 +677,10 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         for k, tr in enumerate(model.lhsVec):
             m = ebv_run[k].mean
             out[f"EBV_{tr}"] = pd.DataFrame({"ID": out_ids, "EBV": m, "PEV": np.abs(ebv_run[k].mean2 - m ** 2)})
+    if heritability and gv_samples:                                      # output.jl:196-209 (mean and std of the samples)
+        for key, samples, names in (("genetic_variance", np.array(gv_samples), cov), ("heritability", np.array(h2_samples), list(model.lhsVec))):
+            out[key] = pd.DataFrame({"Covariance": names, "Estimate": samples.mean(axis=0),
+                                     "SD": samples.std(axis=0, ddof=1) if len(samples) > 1 else np.full(samples.shape[1], np.nan)})
     for key, tab in out.items():                                         # JWAS.jl:480-482
         tab.to_csv(os.path.join(output_folder, key.replace(" ", "_") + ".txt"), index=False)
     out["_timing"] = {"wall_s": wall, "device_sweep_ms_total": t_sweep, "iterations": chain_length,

@@ -575,3 +575,29 @@ def test_annotated_two_trait_bayesc(tmp_path):
                                  Pi={(0.0, 0.0): 0.9, (1.0, 0.0): 0.05, (0.0, 1.0): 0.05, (1.0, 1.0): 0.0})
         model = api.build_model("y1 = intercept + geno\ny2 = intercept + geno", np.eye(2))
         api.runMCMC(model, ph, chain_length=5, seed=5, output_folder=str(tmp_path / "amt2"), engine=OracleEngine("block"), block_size=64)
+
+
+def test_heritability_output_matches_its_definition(tmp_path):
+    """output.jl:498-512: per saved sample genetic variance = var(EBV) over the output individuals and
+    h2 = genVar / (genVar + vare); the tables are the mean / std of those samples (output.jl:196-209)."""
+    d = make_dataset(n=150, p=90, ncausal=5, seed=2, center=False)
+    ids = [f"id{i}" for i in range(150)]
+    gdf = pd.DataFrame(d["raw"], columns=[f"snp{j}" for j in range(90)]); gdf.insert(0, "ID", ids)
+    ph = pd.DataFrame({"ID": ids, "y1": d["y"]})
+    geno = api.get_genotypes(gdf, method="BayesC", Pi=0.8)
+    model = api.build_model("y1 = intercept + geno")
+    folder = tmp_path / "h"
+    out = api.runMCMC(model, ph, chain_length=60, burnin=10, output_samples_frequency=5, seed=1, output_folder=str(folder),
+                      engine=OracleEngine("block"), block_size=64)
+    a = pd.read_csv(folder / "MCMC_samples_marker_effects_geno_y1.txt").to_numpy()
+    ve = pd.read_csv(folder / "MCMC_samples_residual_variance.txt").to_numpy().ravel()
+    X = np.asarray(geno.genotypes, dtype=np.float64)
+    gv = np.array([np.var(X @ a[i], ddof=1) for i in range(len(a))])
+    np.testing.assert_allclose(pd.read_csv(folder / "MCMC_samples_genetic_variance.txt").to_numpy().ravel(), gv, rtol=1e-4)
+    np.testing.assert_allclose(pd.read_csv(folder / "MCMC_samples_heritability.txt").to_numpy().ravel(), gv / (gv + ve), rtol=1e-4)
+    assert float(out["heritability"]["Estimate"][0]) == pytest.approx(float((gv / (gv + ve)).mean()), rel=1e-4)
+    geno = api.get_genotypes(gdf, method="BayesC", Pi=0.8)
+    model = api.build_model("y1 = intercept + geno")
+    out2 = api.runMCMC(model, ph, chain_length=20, seed=1, output_folder=str(tmp_path / "h2"), engine=OracleEngine("block"),
+                       block_size=64, output_heritability=False)
+    assert "heritability" not in out2

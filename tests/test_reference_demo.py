@@ -259,3 +259,16 @@ def test_bayesr_runs_and_estimatepi_output(tmp_path):
         o = api.runMCMC(model, _phenotypes(), chain_length=10, burnin=0, output_samples_frequency=5, output_folder=str(tmp_path / f"fb{fb}"),
                         seed=123, printout_model_info=False, outputEBV=False, fast_blocks=fb)
         assert o["_timing"]["iterations"] == (5 if fb is True else 10)       # floor(sqrt(4 records)) = 2 -> 10 / 2
+
+
+@pytest.mark.gpu
+def test_ebv_output_with_heritability(tmp_path):
+    """test_output_ebv.jl:33-55 (there with RR-BLUP)"""
+    geno = api.get_genotypes(GENO, 1.0, separator=",", method="RR-BLUP")
+    model = api.build_model("y1 = intercept + geno", 1.0)
+    out = api.runMCMC(model, _phenotypes(), chain_length=100, burnin=20, output_samples_frequency=10, outputEBV=True,
+                      output_heritability=True, output_folder=str(tmp_path / "h2"), seed=123)
+    assert "EBV_y1" in out and "heritability" in out and "genetic_variance" in out
+    h2 = out["heritability"]
+    assert "Estimate" in h2.columns and h2["Estimate"].between(0, 1).all()
+    assert os.path.isfile(tmp_path / "h2" / "MCMC_samples_heritability.txt")
