@@ -61,3 +61,113 @@ def test_multi_seed_posterior_summaries_agree(tmp_path, method, Pi):
     ebv_h = np.mean([s["ebv"] for s in acc["hip"]], axis=0)
     ebv_o = np.mean([s["ebv"] for s in acc["orc"]], axis=0)
     assert np.corrcoef(ebv_h, ebv_o)[0, 1] > 0.995
+
+
+def _exact_state_posterior(X, y, vare, class_vars, class_probs):
+    """Exact posterior over the joint class assignment of p markers for y = X a + e, a_j | class k ~ N(0, class_vars[k])
+    (class_vars[0] = 0: not in the model), by enumeration: P(state | y) ~ prod_j class_probs[state_j] * N(y; 0, V_state)."""
+    import itertools
+    n, p = X.shape
+    K = len(class_vars)
+    logp = {}
+    for state in itertools.product(range(K), repeat=p):
+        V = vare * np.eye(n) + (X * np.array([class_vars[k] for k in state])) @ X.T
+        sign, logdet = np.linalg.slogdet(V)
+        logp[state] = -0.5 * (logdet + y @ np.linalg.solve(V, y)) + sum(np.log(class_probs[k]) for k in state)
+    m = max(logp.values())
+    tot = sum(np.exp(v - m) for v in logp.values())
+    return {s: np.exp(v - m) / tot for s, v in logp.items()}
+
+
+@pytest.mark.parametrize("method", ["BayesC", "BayesR"])
+def test_device_chain_samples_the_exact_posterior(method):
+    """Oracle-independent check of WHAT the device samples: with fixed hyper-parameters and three correlated markers
+    the posterior over inclusion / class states is computable exactly by enumeration (marginal likelihood of every
+    state); a long device chain must visit the states with those frequencies (Monte-Carlo error ~0.01 at 30 000 sweeps)."""
+    import jwas_jl_amd as J
+    rng = np.random.default_rng(12)
+    n, p = 40, 3
+    z = rng.standard_normal((n, 1))
+    X = (0.6 * z + rng.standard_normal((n, p))).astype(np.float32)             # correlated columns
+    X -= X.mean(0)
+    y = (0.9 * X[:, 0] + 0.5 * rng.standard_normal(n)).astype(np.float32)
+    y -= y.mean()
+    vare = 0.6
+    e = J.HipEngine(0)
+    e.load_dense(X); e.setup_blocks(64, "f64"); e.init_state(method)
+    e.set_residual(y)
+    niter, burn = 30000, 500
+    if method == "BayesC":
+        pi, varg = 0.6, 0.3
+        exact = _exact_state_posterior(X.astype(np.float64), y.astype(np.float64), vare, [0.0, varg], [pi, 1 - pi])
+        kw = dict(vare=np.float32(vare), var_effect=np.float32(varg), pi=pi)
+        e.set_state(delta=np.zeros(p, dtype=np.float32))
+    else:
+        pis, sig = np.array([0.5, 0.2, 0.2, 0.1]), 0.5
+        gam = np.array([0.0, 0.01, 0.1, 1.0])
+        exact = _exact_state_posterior(X.astype(np.float64), y.astype(np.float64), vare, list(gam * sig), list(pis))
+        kw = dict(vare=np.float32(vare), var_effect=np.float32(sig), pi_classes=pis)
+        e.set_state(delta=np.ones(p, dtype=np.int32))
+    counts = {}
+    for it in range(1, niter + 1):
+        e.sweep(iteration=it, seed=77, **kw)
+        if it > burn:
+            d = e.get_state()[2]
+            s = tuple(int(v) for v in d) if method == "BayesC" else tuple(int(v) - 1 for v in d)
+            counts[s] = counts.get(s, 0) + 1
+    e.close()
+    tot = niter - burn
+    worst = max(abs(counts.get(s, 0) / tot - pr) for s, pr in exact.items())
+    assert worst < 0.02, (worst, sorted(((pr, counts.get(s, 0) / tot, s) for s, pr in exact.items()), reverse=True)[:6])
+    # marginal inclusion probability of every marker
+    for j in range(p):
+        ex = sum(pr for s, pr in exact.items() if s[j] != 0)
+        got = sum(c for s, c in counts.items() if s[j] != 0) / tot
+        assert abs(ex - got) < 0.02, (j, ex, got)
+
+
+@pytest.mark.parametrize("sampler", ["MTBayesC", "MTBayesC_II"])
+def test_device_multitrait_chain_samples_the_exact_posterior(sampler):
+    """Same for the two-trait samplers I and II: two correlated markers, 4 joint states each (16 configurations);
+    vec(Y) ~ N(0, R (x) I + sum_j (D_j G D_j) (x) x_j x_j'), D_j = diag(delta_j)."""
+    import itertools
+    import jwas_jl_amd as J
+    rng = np.random.default_rng(3)
+    n, p, t = 30, 2, 2
+    z = rng.standard_normal((n, 1))
+    X = (0.5 * z + rng.standard_normal((n, p))).astype(np.float32)
+    X -= X.mean(0)
+    R = np.array([[0.7, 0.2], [0.2, 0.5]])
+    G = np.array([[0.4, 0.15], [0.15, 0.3]])
+    Y = np.stack([0.8 * X[:, 0] + 0.3 * rng.standard_normal(n), 0.5 * X[:, 0] - 0.4 * X[:, 1] + 0.3 * rng.standard_normal(n)]).astype(np.float32)
+    Y -= Y.mean(axis=1, keepdims=True)
+    prior = np.array([0.4, 0.2, 0.15, 0.25])                      # state index = delta_1 + 2 delta_2 (traits)
+    yv = Y.astype(np.float64).reshape(-1)                         # trait-major vec
+    X64 = X.astype(np.float64)
+    logp = {}
+    for conf in itertools.product(range(4), repeat=p):
+        V = np.kron(R, np.eye(n))
+        for j, st in enumerate(conf):
+            D = np.diag([float(st & 1), float((st >> 1) & 1)])
+            V = V + np.kron(D @ G @ D, np.outer(X64[:, j], X64[:, j]))
+        sign, logdet = np.linalg.slogdet(V)
+        logp[conf] = -0.5 * (logdet + yv @ np.linalg.solve(V, yv)) + sum(np.log(prior[s]) for s in conf)
+    m = max(logp.values())
+    tot = sum(np.exp(v - m) for v in logp.values())
+    exact = {s: np.exp(v - m) / tot for s, v in logp.items()}
+    e = J.HipEngine(0)
+    e.load_dense(X); e.setup_blocks(64, "f64"); e.init_state(sampler, t)
+    for k in range(t):
+        e.set_residual(Y[k], k)
+    niter, burn = 30000, 500
+    counts = {}
+    for it in range(1, niter + 1):
+        e.sweep(iteration=it, seed=5, vare=R.astype(np.float32), var_effect=G.astype(np.float32), log_prior_states=np.log(prior))
+        if it > burn:
+            d1, d2 = e.get_state(0)[2], e.get_state(1)[2]
+            s = tuple(int(a) + 2 * int(b) for a, b in zip(d1, d2))
+            counts[s] = counts.get(s, 0) + 1
+    e.close()
+    n_eff = niter - burn
+    worst = max(abs(counts.get(s, 0) / n_eff - pr) for s, pr in exact.items())
+    assert worst < 0.025, (worst, sorted(((pr, counts.get(s, 0) / n_eff, s) for s, pr in exact.items()), reverse=True)[:6])
