@@ -1363,6 +1363,8 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
     // marker-specific priors (stride B)
     const int ls = pm ? B : 1;
     auto lpr_of = [&](int c) -> const double* { return pm ? lpd + 2 * NT * B + c : lpr; };
+    bool stay[2] = {false, false};
+    float pb[2][NT], pd[2][NT];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int c = tid + q * kStepThreads;
@@ -1387,11 +1389,42 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
             else mega_eval<NT>(K, Q0, w0[q], dj, thr0[q], z0[q], an, bn, dn, Dl);
 #pragma unroll
             for (int t = 0; t < NT; ++t) moves = moves || (Dl[t] != 0.f);
+            if (!moves) {
+                stay[q] = true;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) { pb[q][t] = bn[t]; pd[q][t] = dn[t]; }
+            }
         }
         cand[q] = in_model || moves;
     }
+    // PREFIX SKIP (as in the single-trait sampler): until the first candidate of the block commits the running rhs is the
+    // entry rhs, so the evaluation above is final for every marker before it.  Their freshly drawn beta / delta are parked
+    // (only theirs: a later marker is re-evaluated from its OLD state) and the serial wave starts at the first sub-block
+    // that holds a candidate.  Single pass only.
+    int first_sub = 16;
+    {
+        int* wc = reinterpret_cast<int*>(smem + SM.wcnt_off);
+        const int f0 = __any(cand[0]) ? 1 : 0, f1 = __any(cand[1]) ? 2 : 0;
+        if (lane == 0) wc[wave] = f0 | f1;
+        __syncthreads();
+        unsigned mask = 0u;
+#pragma unroll
+        for (int q = 0; q < kStepThreads / 64; ++q) { const int v = wc[q]; mask |= (unsigned)(v & 1) << q | (unsigned)((v >> 1) & 1) << (8 + q); }
+        if (mask) first_sub = __builtin_ctz(mask);
+        const bool single_pass = (P->nreps > 0 ? P->nreps : b) == 1;
+        if (!single_pass) first_sub = 0;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int c = tid + q * kStepThreads;
+            if (stay[q] && c < b && (c >> 6) < first_sub) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) { bcur[t * B + c] = pb[q][t]; dcur[t * B + c] = pd[q][t]; }
+            }
+        }
+        __syncthreads();                                   // (stage_rows reuses the slots)
+    }
     const long long tk1 = clock64();
-    const int nstaged_mt = stage_rows(smem, SM, A, cand);
+    const int nstaged_mt = first_sub >= 16 ? 0 : stage_rows(smem, SM, A, cand);
     prefetch_cross_rows(smem, SM, A, nstaged_mt);
     int* wcnt_s = reinterpret_cast<int*>(smem + SM.wcnt_off);
     if (wave == 0) {
@@ -1480,10 +1513,11 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
         dense_done = true;
     }
 
+    const int s_first = (nreps == 1 && !dense_done) ? (first_sub < nsub ? first_sub : nsub) : 0;       // prefix skip (single pass only)
     for (int rep = 0; rep < (dense_done ? 0 : nreps); ++rep) {
         key.rep = (uint32_t)rep;
 #pragma unroll 1
-        for (int s = 0; s < nsub; ++s) {
+        for (int s = s_first; s < nsub; ++s) {
             const int c = 64 * s + lane;
             const bool valid = c < b;
             const int64_t j = j0 + (valid ? c : 0);
@@ -1551,7 +1585,7 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
     const long long tk4 = clock64();
     int base = 0;
 #pragma unroll 1
-    for (int s = 0; s < nsub; ++s) {
+    for (int s = s_first; s < nsub; ++s) {                    // (no change before the first candidate's sub-block)
         const int c = 64 * s + lane;
         const bool valid = c < b;
         const int64_t j = j0 + (valid ? c : 0);
@@ -1563,14 +1597,6 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
             const float a0 = astart[t * B + c];
             dd[t] = a0 - acur[t * B + c];
             changed = changed || (valid && a0 != acur[t * B + c]);
-        }
-        if (valid) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                A.alpha[(int64_t)t * p + j] = acur[t * B + c];
-                A.beta[(int64_t)t * p + j]  = bcur[t * B + c];
-                delta[(int64_t)t * p + j]   = dcur[t * B + c];
-            }
         }
         const unsigned long long cm = __ballot(changed);
         if (changed) {
@@ -1595,6 +1621,15 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
     }
     }   // wave 0
     __syncthreads();
+    for (int c = tid; c < b; c += kStepThreads) {           // the block's state, all threads (beta / delta of every marker
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {                       // are new draws; alpha changes only where an event happened)
+            const float a_fin = acur[t * B + c];
+            if (a_fin != astart[t * B + c]) A.alpha[(int64_t)t * p + j0 + c] = a_fin;
+            A.beta[(int64_t)t * p + j0 + c] = bcur[t * B + c];
+            delta[(int64_t)t * p + j0 + c]  = dcur[t * B + c];
+        }
+    }
     if (A.b_next > 0) corr_phase<NT>(smem, SM, A, wcnt_s[15]);
 }
 
