@@ -11,7 +11,11 @@
  * cannot be compared with a Julia run.  What IS pinned against the reference's own tests are
  * the deterministic / closed-form items (tests/test_oracle_kat.py): BayesR sufficient
  * statistics, bayesr_block_nreps schedule, degenerate-prior class KAT, genetic2marker,
- * 2-bit codec tables, the one-marker multi-trait posterior, memory formulas.
+ * 2-bit codec tables, the one-marker multi-trait posterior, memory formulas.  Statistically the
+ * whole stack is pinned against the reference's OWN published output: its 5-fold cross-validation
+ * benchmark on its packaged simulated_annotations data (held-out cor(y, EBV) of eight method
+ * families reproduced within 0.01), and against the exact state posterior of
+ * small models by enumeration (tests/test_gpu_statistical.py).
  *
  * Reference files restated (all under /root/reference/src/1.JWAS/src/):
  *   markers/BayesianAlphabet/BayesABC.jl:24-80    bayesabc_update_marker!, BayesABC!
@@ -19,6 +23,8 @@
  *   markers/BayesianAlphabet/BayesR.jl:1-97       BayesR!
  *   markers/BayesianAlphabet/BayesR.jl:111-193    BayesR_block!
  *   markers/BayesianAlphabet/MTBayesABC.jl:57-127 _MTBayesABC_samplerI!
+ *   markers/BayesianAlphabet/MTBayesABC.jl:129-210 _MTBayesABC_samplerII!  (+ block / independent forms :243-646)
+ *   markers/BayesianAlphabet/BayesABC.jl:1-8,190-255  megaBayesABC!, BayesABC_block_independent!
  *   markers/tools4genotypes.jl:28-36,59-78,259-267  x'x, block_rhs!, block Grams
  *   variance_components.jl:68-79                  bayesr_sigma_sufficient_statistics
  *   output.jl:568-577                             running posterior means
