@@ -231,6 +231,12 @@ int  jwas_hip_mul_alpha_output(jwas_hip_ctx* ctx, int32_t trait, float* out_host
  * jwas_hip_load_output_dense_f32 when use_output_rows != 0 (the reference uses Mi.output_genotypes). */
 int  jwas_hip_window_sums(jwas_hip_ctx* ctx, int32_t use_output_rows, int32_t nwin, const int32_t* wptr, const int32_t* idx,
                           const float* val, double* out_sum, double* out_ss);
+/* Two effect vectors over the same markers (two traits' samples of the same iteration; idx = union of their nonzero
+ * effects): additionally out_cross[w] = sum_i BV1_w[i] * BV2_w[i] -- the window genetic covariance / correlation of
+ * src/3.GWAS/src/GWAS.jl:199-217. */
+int  jwas_hip_window_sums2(jwas_hip_ctx* ctx, int32_t use_output_rows, int32_t nwin, const int32_t* wptr, const int32_t* idx,
+                           const float* val1, const float* val2, double* out_sum1, double* out_ss1, double* out_sum2,
+                           double* out_ss2, double* out_cross);
 
 /* ---- the sweep ------------------------------------------------------------------------------ */
 /* Time every `stride`-th k_block_step launch of subsequent sweeps with HIP events on the

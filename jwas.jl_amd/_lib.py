@@ -25,7 +25,7 @@ SYMBOLS = [
     "jwas_hip_set_gram", "jwas_hip_num_blocks", "jwas_hip_init_state", "jwas_hip_set_state",
     "jwas_hip_get_state", "jwas_hip_set_residual", "jwas_hip_get_residual", "jwas_hip_residual_dev",
     "jwas_hip_residual_to_dev", "jwas_hip_residual_from_dev",
-    "jwas_hip_residual_sub_xalpha", "jwas_hip_mul_alpha", "jwas_hip_load_output_dense_f32", "jwas_hip_mul_alpha_output", "jwas_hip_window_sums", "jwas_hip_set_kernel_timing", "jwas_hip_sweep",
+    "jwas_hip_residual_sub_xalpha", "jwas_hip_mul_alpha", "jwas_hip_load_output_dense_f32", "jwas_hip_mul_alpha_output", "jwas_hip_window_sums", "jwas_hip_window_sums2", "jwas_hip_set_kernel_timing", "jwas_hip_sweep",
     "jwas_hip_accumulate", "jwas_hip_get_posterior",
     "jwas_hip_load_jgb2", "jwas_hip_load_packed2bit", "jwas_hip_alloc_packed2bit", "jwas_hip_storage_info",
     "jwas_hip_set_xpx", "jwas_hip_estimate_bytes_storage", "jwas_hip_add_block_size", "jwas_hip_select_block_size",
@@ -121,6 +121,7 @@ def load():
     L.jwas_hip_load_output_dense_f32.argtypes = [vp, vp, i64, i64, i64]
     L.jwas_hip_mul_alpha_output.argtypes = [vp, i32, vp]
     L.jwas_hip_window_sums.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp]
+    L.jwas_hip_window_sums2.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.jwas_hip_sweep.argtypes = [vp, C.POINTER(SweepParams), C.POINTER(SweepStats)]
     L.jwas_hip_accumulate.argtypes = [vp, C.c_double]
     L.jwas_hip_get_posterior.argtypes = [vp, i32, vp, vp, vp]

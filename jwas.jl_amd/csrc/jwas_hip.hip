@@ -918,11 +918,13 @@ int jwas_hip_mul_alpha_output(jwas_hip_ctx* c, int32_t trait, float* out)
 // Window genomic variances of one saved marker-effect sample: the O(samples x n x p) inner loop of the reference's
 // window-based GWAS (src/3.GWAS/src/GWAS.jl:152-165: genVar = var(X*alpha), var_w = var(X[:, w] * alpha[w])) as one
 // launch over the nonzero effects only.  The caller derives var = (ss - sum^2/n) / (n - 1).
-int jwas_hip_window_sums(jwas_hip_ctx* c, int32_t use_output_rows, int32_t nwin, const int32_t* wptr, const int32_t* idx,
-                         const float* val, double* out_sum, double* out_ss)
+static int window_sums_impl(jwas_hip_ctx* c, int32_t use_output_rows, int32_t nwin, const int32_t* wptr, const int32_t* idx,
+                            const float* val, const float* val2, double* const* outs /* 2 or 5 arrays of nwin */)
 {
+    const int nv = val2 ? 5 : 2;
     NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
-    NEED(c, wptr && out_sum && out_ss, JWAS_HIP_EINVAL, "NULL argument");
+    NEED(c, wptr, JWAS_HIP_EINVAL, "NULL argument");
+    for (int v = 0; v < nv; ++v) NEED(c, outs[v], JWAS_HIP_EINVAL, "NULL output array");
     NEED(c, nwin >= 1, JWAS_HIP_EINVAL, "nwin must be >= 1 (got %d)", nwin);
     NEED(c, HAVE_STORAGE(c), JWAS_HIP_ESTATE, "no genotype matrix loaded");
     NEED(c, !use_output_rows || c->Xout, JWAS_HIP_ESTATE, "jwas_hip_load_output_dense_f32 has not been called");
@@ -933,34 +935,51 @@ int jwas_hip_window_sums(jwas_hip_ctx* c, int32_t use_output_rows, int32_t nwin,
     for (int64_t e = 0; e < nnz; ++e) NEED(c, idx[e] >= 0 && idx[e] < c->p, JWAS_HIP_EINVAL, "marker index %d out of range", idx[e]);
     HIPCHK(c, hipSetDevice(c->device));
     const int nsl = (int)(use_output_rows ? c->ld_out / kSliceRows : c->nslices);
-    int32_t *d_wptr = nullptr, *d_idx = nullptr; float* d_val = nullptr; double *d_part = nullptr, *d_out = nullptr;
+    const size_t ne = (size_t)(nnz > 0 ? nnz : 1);
+    int32_t *d_wptr = nullptr, *d_idx = nullptr; float *d_val = nullptr, *d_val2 = nullptr; double *d_part = nullptr, *d_out = nullptr;
     hipError_t e = hipMalloc(&d_wptr, sizeof(int32_t) * (nwin + 1));
-    if (e == hipSuccess) e = hipMalloc(&d_idx, sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1));
-    if (e == hipSuccess) e = hipMalloc(&d_val, sizeof(float) * (size_t)(nnz > 0 ? nnz : 1));
-    if (e == hipSuccess) e = hipMalloc(&d_part, sizeof(double) * 2 * (size_t)nwin * nsl);
-    if (e == hipSuccess) e = hipMalloc(&d_out, sizeof(double) * 2 * (size_t)nwin);
+    if (e == hipSuccess) e = hipMalloc(&d_idx, sizeof(int32_t) * ne);
+    if (e == hipSuccess) e = hipMalloc(&d_val, sizeof(float) * ne);
+    if (e == hipSuccess && val2) e = hipMalloc(&d_val2, sizeof(float) * ne);
+    if (e == hipSuccess) e = hipMalloc(&d_part, sizeof(double) * nv * (size_t)nwin * nsl);
+    if (e == hipSuccess) e = hipMalloc(&d_out, sizeof(double) * nv * (size_t)nwin);
     if (e == hipSuccess) e = hipMemcpyAsync(d_wptr, wptr, sizeof(int32_t) * (nwin + 1), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess && nnz) e = hipMemcpyAsync(d_idx, idx, sizeof(int32_t) * nnz, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess && nnz) e = hipMemcpyAsync(d_val, val, sizeof(float) * nnz, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && nnz && val2) e = hipMemcpyAsync(d_val2, val2, sizeof(float) * nnz, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
-        if (use_output_rows) {
-            DenseCols cx{c->Xout, c->ld_out, nullptr, 0};
-            hipLaunchKernelGGL((k_window_partial<DenseCols>), dim3((unsigned)nsl), dim3(256), 0, c->stream, cx, nwin, d_wptr, d_idx, d_val, d_part);
-        } else {
-            with_cols(c, 0, [&](auto cx) {
-                hipLaunchKernelGGL((k_window_partial<decltype(cx)>), dim3((unsigned)nsl), dim3(256), 0, c->stream, cx, nwin, d_wptr, d_idx, d_val, d_part);
-                return 0;
-            });
-        }
-        hipLaunchKernelGGL(k_window_reduce, dim3((unsigned)((nwin + 255) / 256)), dim3(256), 0, c->stream, nwin, nsl, d_part, d_out, d_out + nwin);
+        auto launch = [&](auto cx) {
+            if (val2) hipLaunchKernelGGL((k_window_partial<decltype(cx), 5>), dim3((unsigned)nsl), dim3(256), 0, c->stream, cx, nwin, d_wptr, d_idx, d_val, d_val2, d_part);
+            else      hipLaunchKernelGGL((k_window_partial<decltype(cx), 2>), dim3((unsigned)nsl), dim3(256), 0, c->stream, cx, nwin, d_wptr, d_idx, d_val, d_val2, d_part);
+            return 0;
+        };
+        if (use_output_rows) launch(DenseCols{c->Xout, c->ld_out, nullptr, 0});
+        else with_cols(c, 0, launch);
+        hipLaunchKernelGGL(k_window_reduce, dim3((unsigned)((nwin + 255) / 256)), dim3(256), 0, c->stream, nwin, nsl, nv, d_part, d_out);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(out_sum, d_out, sizeof(double) * nwin, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(out_ss, d_out + nwin, sizeof(double) * nwin, hipMemcpyDeviceToHost, c->stream);
+    for (int v = 0; v < nv && e == hipSuccess; ++v)
+        e = hipMemcpyAsync(outs[v], d_out + (size_t)v * nwin, sizeof(double) * nwin, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(d_wptr); (void)hipFree(d_idx); (void)hipFree(d_val); (void)hipFree(d_part); (void)hipFree(d_out);
+    (void)hipFree(d_wptr); (void)hipFree(d_idx); (void)hipFree(d_val); (void)hipFree(d_val2); (void)hipFree(d_part); (void)hipFree(d_out);
     if (e != hipSuccess) return fail(c, JWAS_HIP_EHIP, "jwas_hip_window_sums: %s", hipGetErrorString(e));
     return JWAS_HIP_OK;
+}
+
+int jwas_hip_window_sums(jwas_hip_ctx* c, int32_t use_output_rows, int32_t nwin, const int32_t* wptr, const int32_t* idx,
+                         const float* val, double* out_sum, double* out_ss)
+{
+    double* outs[2] = {out_sum, out_ss};
+    return window_sums_impl(c, use_output_rows, nwin, wptr, idx, val, nullptr, outs);
+}
+
+int jwas_hip_window_sums2(jwas_hip_ctx* c, int32_t use_output_rows, int32_t nwin, const int32_t* wptr, const int32_t* idx,
+                          const float* val1, const float* val2, double* out_sum1, double* out_ss1, double* out_sum2,
+                          double* out_ss2, double* out_cross)
+{
+    NEED(c, c && val2, JWAS_HIP_EINVAL, "NULL argument");
+    double* outs[5] = {out_sum1, out_ss1, out_sum2, out_ss2, out_cross};
+    return window_sums_impl(c, use_output_rows, nwin, wptr, idx, val1, val2, outs);
 }
 
 }  // extern "C" (templates need C++ linkage)

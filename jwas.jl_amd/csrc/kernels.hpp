@@ -870,37 +870,50 @@ __global__ __launch_bounds__(256) void k_mul_alpha(CX cx, int64_t p,
 // grid = nslices, block = 256 (one individual per thread); partial[(w * nslices + slice) * 2 + {0,1}] = the slice's
 // sum of BV_w and of BV_w^2.  k_window_reduce then adds the slices in fixed order (deterministic, no atomics).
 // ---------------------------------------------------------------------------------------------
-template <class CX>
+// NV = 2: (sum, sum of squares) of one effect vector;  NV = 5: two effect vectors over the same markers (two traits'
+// samples): (sum1, ss1, sum2, ss2, sum of products) -- the window genetic covariance / correlation of GWAS.jl:199-217.
+template <class CX, int NV>
 __global__ __launch_bounds__(256) void k_window_partial(CX cx, int nwin, const int32_t* __restrict__ wptr,
                                                         const int32_t* __restrict__ idx, const float* __restrict__ val,
-                                                        double* __restrict__ partial)
+                                                        const float* __restrict__ val2, double* __restrict__ partial)
 {
-    __shared__ double red[2][4];
+    __shared__ double red[NV][4];
     const int64_t row = (int64_t)blockIdx.x * kSliceRows + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int w = 0; w < nwin; ++w) {
-        double bv = 0.0;
-        for (int e = wptr[w]; e < wptr[w + 1]; ++e) bv = fma((double)val[e], (double)cx.load1(idx[e], row), bv);
-        double s = bv, q = bv * bv;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { s += __shfl_down(s, off, 64); q += __shfl_down(q, off, 64); }
-        if (lane == 0) { red[0][wave] = s; red[1][wave] = q; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            partial[((int64_t)w * gridDim.x + blockIdx.x) * 2 + 0] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
-            partial[((int64_t)w * gridDim.x + blockIdx.x) * 2 + 1] = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+        double bv = 0.0, bv2 = 0.0;
+        for (int e = wptr[w]; e < wptr[w + 1]; ++e) {
+            const double x = (double)cx.load1(idx[e], row);
+            bv = fma((double)val[e], x, bv);
+            if constexpr (NV == 5) bv2 = fma((double)val2[e], x, bv2);
         }
+        double v[NV];
+        v[0] = bv; v[1] = bv * bv;
+        if constexpr (NV == 5) { v[2] = bv2; v[3] = bv2 * bv2; v[4] = bv * bv2; }
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off, 64);
+            if (lane == 0) red[k][wave] = v[k];
+        }
+        __syncthreads();
+        if (threadIdx.x < NV)
+            partial[((int64_t)w * gridDim.x + blockIdx.x) * NV + threadIdx.x] =
+                ((red[threadIdx.x][0] + red[threadIdx.x][1]) + red[threadIdx.x][2]) + red[threadIdx.x][3];
         __syncthreads();
     }
 }
-__global__ __launch_bounds__(256) void k_window_reduce(int nwin, int nslices, const double* __restrict__ partial,
-                                                       double* __restrict__ out_sum, double* __restrict__ out_ss)
+// out[v * nwin + w] = sum over the slices (fixed order) of value v of window w
+__global__ __launch_bounds__(256) void k_window_reduce(int nwin, int nslices, int nv, const double* __restrict__ partial,
+                                                       double* __restrict__ out)
 {
     const int w = blockIdx.x * 256 + threadIdx.x;
     if (w >= nwin) return;
-    double s = 0.0, q = 0.0;
-    for (int k = 0; k < nslices; ++k) { s += partial[((int64_t)w * nslices + k) * 2]; q += partial[((int64_t)w * nslices + k) * 2 + 1]; }
-    out_sum[w] = s; out_ss[w] = q;
+    for (int v = 0; v < nv; ++v) {
+        double s = 0.0;
+        for (int k = 0; k < nslices; ++k) s += partial[((int64_t)w * nslices + k) * nv + v];
+        out[(int64_t)v * nwin + w] = s;
+    }
 }
 
 // X * alpha over the nonzero effects only (marker order, the same fp64 accumulation as k_mul_alpha -> identical

@@ -294,6 +294,18 @@ class HipEngine:
         self._chk(self._L.jwas_hip_window_sums(self._h, 1 if use_output_rows else 0, nwin, _ptr(wptr), _ptr(idx), _ptr(val), _ptr(s), _ptr(q)))
         return s, q
 
+    def window_sums2(self, wptr, idx, val1, val2, use_output_rows=False):
+        """Two effect vectors over the same markers: (sum1, ss1, sum2, ss2, cross) per window (GWAS.jl:199-217)."""
+        wptr = np.ascontiguousarray(wptr, dtype=np.int32)
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        v1 = np.ascontiguousarray(val1, dtype=np.float32)
+        v2 = np.ascontiguousarray(val2, dtype=np.float32)
+        nwin = wptr.size - 1
+        outs = [np.empty(nwin) for _ in range(5)]
+        self._chk(self._L.jwas_hip_window_sums2(self._h, 1 if use_output_rows else 0, nwin, _ptr(wptr), _ptr(idx), _ptr(v1), _ptr(v2),
+                                                *[_ptr(o) for o in outs]))
+        return tuple(outs)
+
     def mul_alpha_output(self, trait=0):
         """EBV = output_genotypes * alpha (output.jl:281-306)."""
         out = np.empty(getattr(self, "n_out", 0), dtype=np.float32)

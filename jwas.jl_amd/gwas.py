@@ -6,8 +6,8 @@
 (GWAS.jl:49-197).  Its cost in the reference is one dense X*alpha plus one product per window for every saved sample,
 O(samples x n x p) over the same genotype matrix the sweep streams; here every sample is one launch over its nonzero effects
 only (`jwas_hip_window_sums`: sum and sum of squares of each window's genomic values, fp64), the windows and the summary
-statistics are assembled on the host exactly as the reference does.  Genetic correlations between two traits' windows and
-local EBVs stay on the reference."""
+statistics are assembled on the host exactly as the reference does; the window genetic covariance / correlation of two
+traits (`genetic_correlation=true`, GWAS.jl:199-237) uses `jwas_hip_window_sums2`.  Local EBVs stay on the reference."""
 import os
 
 import numpy as np
@@ -67,8 +67,10 @@ def GWAS(*args, window_size="1 Mb", sliding_window=False, GWAS=True, threshold=0
     if len(args) < 3:
         raise TypeError("GWAS(model, map_file, marker_effects_file...)")
     mme, map_file, files = args[0], args[1], list(args[2:])
-    if genetic_correlation or local_EBV:
-        raise NotImplementedError("genetic_correlation / local_EBV stay on the reference")
+    if local_EBV:
+        raise NotImplementedError("local_EBV stays on the reference")
+    if genetic_correlation and len(files) != 2:
+        raise ValueError("genetic_correlation=true needs exactly two marker_effects_files (one per trait).")
     if isinstance(window_size, str):
         parts = window_size.split()
         if len(parts) != 2 or parts[1] != "Mb":
@@ -88,7 +90,6 @@ def GWAS(*args, window_size="1 Mb", sliding_window=False, GWAS=True, threshold=0
         mapfile = pd.DataFrame({"markerID": [str(i) for i in range(1, nmarkers + 1)], "chromosome": "1",
                                 "position": np.floor(1 + step * np.arange(nmarkers)).astype(np.int64)})
         window_size = "1 Mb"
-        use = np.arange(nmarkers)
     else:
         mapfile = pd.read_csv(map_file, header=0 if header else None, dtype={0: str, 1: str})
         mapfile.columns = ["markerID", "chromosome", "position"][:3] + list(mapfile.columns[3:])
@@ -100,10 +101,11 @@ def GWAS(*args, window_size="1 Mb", sliding_window=False, GWAS=True, threshold=0
     window_size_bp = int(float(window_size.split()[0]) * 1_000_000)
     win = build_windows(mapfile["chromosome"].to_numpy(), mapfile["position"].to_numpy(dtype=np.int64), window_size_bp, sliding_window)
     nwin = len(win["nsnp"])
-    if not GWAS:
+    if not GWAS and not genetic_correlation:
         return tuple()
-    print(f"Compute the posterior probability of association of the genomic window that explains more than {threshold} "
-          "of the total genetic variance.")
+    if GWAS:
+        print(f"Compute the posterior probability of association of the genomic window that explains more than {threshold} "
+              "of the total genetic variance.")
     own = engine is None
     if own:
         from .engine import HipEngine
@@ -113,7 +115,7 @@ def GWAS(*args, window_size="1 Mb", sliding_window=False, GWAS=True, threshold=0
     cs, ce = np.asarray(win["col_start"]), np.asarray(win["col_end"])
     out, props_out = [], []
     try:
-        for fi, path in enumerate(files, start=1):
+        for fi, path in enumerate(files if GWAS else [], start=1):
             samples, _ = _read_samples(path, True)
             nsamples = samples.shape[0]
             winVar = np.zeros((nsamples, nwin))
@@ -148,6 +150,33 @@ def GWAS(*args, window_size="1 Mb", sliding_window=False, GWAS=True, threshold=0
             out.append(tab)
             if output_winVarProps:
                 props_out.append(winVarProps)
+        if genetic_correlation:                                  # GWAS.jl:199-237
+            s1, _ = _read_samples(files[0], True)
+            s2, _ = _read_samples(files[1], True)
+            nsamples = s1.shape[0]
+            gcov, gcor = np.zeros((nsamples, nwin)), np.zeros((nsamples, nwin))
+            for i in range(nsamples):
+                a1, a2 = s1[i].astype(np.float32), s2[i].astype(np.float32)
+                nz = np.flatnonzero((a1 != 0) | (a2 != 0))
+                lo, hi = np.searchsorted(nz, cs), np.searchsorted(nz, ce)
+                wptr = np.concatenate([[0], np.cumsum(hi - lo)]).astype(np.int32)
+                gather = np.concatenate([nz[l:h] for l, h in zip(lo, hi) if h > l]) if wptr[-1] else nz[:0]
+                su1, q1, su2, q2, cr = engine.window_sums2(wptr, gather, a1[gather], a2[gather])
+                cov = (cr - su1 * su2 / n) / (n - 1)
+                v1, v2 = (q1 - su1 * su1 / n) / (n - 1), (q2 - su2 * su2 / n) / (n - 1)
+                gcov[i] = cov
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    gcor[i] = cov / np.sqrt(v1 * v2)
+            gcov[np.isnan(gcov)] = 0.0
+            gcor[~np.isfinite(gcor)] = 0.0
+            np.savetxt(os.path.join(output_folder, "MCMC_samples_local_genomic_covariance.txt"), gcov, delimiter=",")
+            sd = (lambda m: m.std(axis=0, ddof=1) if nsamples > 1 else np.full(nwin, np.nan))
+            tab = pd.DataFrame({
+                "trait": "cor(t1,t2)", "window": np.arange(nwin) + 1, "chr": win["chr"], "wStart": win["pos_start"],
+                "wEnd": win["pos_end"], "start_SNP": win["snp_start"], "end_SNP": win["snp_end"], "numSNP": win["nsnp"],
+                "estimate_cov": gcov.mean(axis=0), "std_cov": sd(gcov), "estimate_cor": gcor.mean(axis=0), "std_cor": sd(gcor)})
+            tab.to_csv(os.path.join(output_folder, "GWAS_" + str(files[0]).replace("/", "_") + "_" + str(files[1]).replace("/", "_")), index=False)
+            out.append(tab)
     finally:
         if own:
             engine.close()

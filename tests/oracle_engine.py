@@ -129,6 +129,18 @@ class OracleEngine:
             s[w], q[w] = bv.sum(), (bv * bv).sum()
         return s, q
 
+    def window_sums2(self, wptr, idx, val1, val2, use_output_rows=False):
+        X = (self.X_out if use_output_rows else self.X).astype(np.float64)
+        idx = np.asarray(idx, dtype=np.int64)
+        v1, v2 = np.asarray(val1, dtype=np.float64), np.asarray(val2, dtype=np.float64)
+        outs = [np.zeros(len(wptr) - 1) for _ in range(5)]
+        for w in range(len(wptr) - 1):
+            cols = X[:, idx[wptr[w]:wptr[w + 1]]]
+            b1, b2 = cols @ v1[wptr[w]:wptr[w + 1]], cols @ v2[wptr[w]:wptr[w + 1]]
+            for o, v in zip(outs, (b1.sum(), (b1 * b1).sum(), b2.sum(), (b2 * b2).sum(), (b1 * b2).sum())):
+                o[w] = v
+        return tuple(outs)
+
     def load_output_dense(self, X_out):
         self.X_out = np.asarray(X_out, dtype=np.float32)
 

@@ -133,3 +133,53 @@ def test_reference_gwas_test_sets_on_demo_data(tmp_path):
     assert len(res) >= 1 and len(props) >= 1 and props[0].shape == (8, 3)
     res = api.GWAS(model, mapfile, marker_file, window_size="1 Mb", threshold=0.01, header=True, output_folder=str(tmp_path))
     assert "WPPA" in res[0].columns
+
+
+def test_window_genetic_correlation_matches_literal_restatement(tmp_path):
+    """GWAS.jl:199-237: per sample and window cov / cor of the two traits' window genomic values."""
+    X, s1, f1, mapf, chrom, pos = _case(tmp_path, seed=5)
+    rng = np.random.default_rng(9)
+    s2 = np.where(rng.random(s1.shape) < 0.2, rng.standard_normal(s1.shape), 0.0).astype(np.float32)
+    s2[:, :5] = 0.7 * s1[:, :5]                        # some shared signal
+    f2 = str(tmp_path / "MCMC_samples_marker_effects_geno_y2.txt")
+    pd.DataFrame(s2, columns=[f"m{j + 1}" for j in range(s1.shape[1])]).to_csv(f2, index=False, float_format="%.9g")
+    res = GWAS(X, mapf, f1, f2, window_size="1 Mb", GWAS=False, genetic_correlation=True, output_folder=str(tmp_path),
+               engine=OracleEngine("dense"))
+    tab = res[-1]
+    assert list(tab.columns) == ["trait", "window", "chr", "wStart", "wEnd", "start_SNP", "end_SNP", "numSNP", "estimate_cov",
+                                 "std_cov", "estimate_cor", "std_cor"]
+    win = build_windows(chrom, pos, 1_000_000, False)
+    X64 = X.astype(np.float64)
+    ns, nw = s1.shape[0], len(win["nsnp"])
+    gcov, gcor = np.zeros((ns, nw)), np.zeros((ns, nw))
+    for i in range(ns):
+        for w in range(nw):
+            a, b = win["col_start"][w], win["col_end"][w]
+            b1, b2 = X64[:, a:b] @ s1[i, a:b].astype(np.float64), X64[:, a:b] @ s2[i, a:b].astype(np.float64)
+            gcov[i, w] = np.cov(b1, b2)[0, 1]
+            with np.errstate(divide="ignore", invalid="ignore"):
+                c = np.corrcoef(b1, b2)[0, 1]
+            gcor[i, w] = c if np.isfinite(c) else 0.0
+    np.testing.assert_allclose(tab["estimate_cov"], gcov.mean(0), atol=1e-9)
+    np.testing.assert_allclose(tab["estimate_cor"], gcor.mean(0), atol=1e-9)
+    with pytest.raises(ValueError, match="exactly two"):
+        GWAS(X, mapf, f1, genetic_correlation=True, engine=OracleEngine("dense"), output_folder=str(tmp_path))
+
+
+@pytest.mark.gpu
+def test_device_window_sums2_match_numpy():
+    import jwas_jl_amd as J
+    rng = np.random.default_rng(2)
+    n, p = 600, 200
+    X = rng.standard_normal((n, p)).astype(np.float32)
+    a1 = np.where(rng.random(p) < 0.2, rng.standard_normal(p), 0).astype(np.float32)
+    a2 = np.where(rng.random(p) < 0.2, rng.standard_normal(p), 0).astype(np.float32)
+    nz = np.flatnonzero((a1 != 0) | (a2 != 0))
+    wptr = np.array([0, 9, 9, 20, nz.size], dtype=np.int32)
+    e = J.HipEngine(0); e.load_dense(X)
+    got = e.window_sums2(wptr, nz, a1[nz], a2[nz])
+    o = OracleEngine("dense"); o.load_dense(X)
+    want = o.window_sums2(wptr, nz, a1[nz], a2[nz])
+    for g, w in zip(got, want):
+        np.testing.assert_allclose(g, w, rtol=1e-11, atol=1e-9)
+    e.close()
