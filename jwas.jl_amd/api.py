@@ -127,7 +127,10 @@ def get_genotypes(file, G=False, *, method="BayesC", Pi=0.0, estimatePi=True,
             row1 = [t.strip().strip('"') for t in fh.readline().rstrip("\r\n").split(separator) if t != ""]
         ncol = len(row1)
         markerID = [str(t) for t in row1[1:]] if header else [str(i + 1) for i in range(ncol - 1)]
-        tab = pd.read_csv(file, sep=separator, header=None, skiprows=1 if header else 0, dtype={0: str})
+        from collections import defaultdict
+        # marker columns are parsed straight to Float32 (the reference's default precision): half the transient memory
+        tab = pd.read_csv(file, sep=separator, header=None, skiprows=1 if header else 0,
+                          dtype=defaultdict(lambda: np.float32, {0: str}))
         obsID = [str(v) for v in tab.iloc[:, 0]]
         genotypes = np.asfortranarray(tab.iloc[:, 1:].to_numpy(dtype=data_type))
     elif pd is not None and isinstance(file, pd.DataFrame):                                   # :328-338
