@@ -271,9 +271,17 @@ def build_model(model_equations, R=False, *, df=4.0, estimate_variance=True, est
     nModels = len(traits)
     if not _is_false(R) and np.atleast_2d(np.asarray(R)).shape[0] != nModels:                 # :67-69
         raise ValueError(f"The residual covariance matrix is not a {nModels} by {nModels} matrix.")
-    for Mi in M:                                                                              # :98-112
+    for Mi in M:                                                                              # :98-116
         Mi.ntraits = nModels
         Mi.trait_names = traits
+        if Mi.multi_trait_sampler == "II":
+            if Mi.method != "BayesC":
+                raise ValueError("multi_trait_sampler overrides are supported for BayesC only.")
+            if nModels <= 1:
+                raise ValueError("multi_trait_sampler overrides require multi-trait BayesC.")
+        for V in (Mi.G, Mi.genetic_variance):
+            if not _is_false(V.val) and np.atleast_2d(np.asarray(V.val)).shape[0] != nModels:
+                raise ValueError(f"The genomic covariance matrix is not a {nModels} by {nModels} matrix.")
         if nModels != 1:
             Mi.G.df = Mi.G.df + nModels
             Mi.genetic_variance.df = Mi.genetic_variance.df + nModels

@@ -272,3 +272,15 @@ def test_ebv_output_with_heritability(tmp_path):
     h2 = out["heritability"]
     assert "Estimate" in h2.columns and h2["Estimate"].between(0, 1).all()
     assert os.path.isfile(tmp_path / "h2" / "MCMC_samples_heritability.txt")
+
+
+def test_build_model_genotype_contracts():
+    """build_MME.jl:104-116 (test_annotated_bayesc.jl:607-630; test_multitrait_mcmc.jl)"""
+    geno = api.get_genotypes(GENO, 1.0, separator=",", method="BayesC", multi_trait_sampler="II")
+    with pytest.raises(ValueError, match="require multi-trait BayesC"):
+        api.build_model("y1 = intercept + geno", 1.0)
+    geno = api.get_genotypes(GENO, np.eye(2), separator=",", method="BayesC")
+    with pytest.raises(ValueError, match="not a 1 by 1 matrix"):
+        api.build_model("y1 = intercept + geno", 1.0)
+    with pytest.raises(ValueError, match="multi_trait_sampler must be one of"):
+        api.get_genotypes(GENO, 1.0, separator=",", method="BayesC", multi_trait_sampler="bogus")
