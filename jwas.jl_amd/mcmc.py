@@ -338,7 +338,10 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
             raise ValueError(f"Pi must hold one value per trait or one per joint state (got {pa.size} entries for {t} traits)")
     sampler = getattr(Mi, "multi_trait_sampler", "I")                   # mt_bayesc_sampler_mode (MTBayesABC.jl:20-25)
     if t > 1 and sampler == "auto":
-        sampler = "I" if np.size(pi) == (1 << t) else "II"
+        # support-based dispatch: a Pi Dict that does not list every joint state (a restricted support, where sampler I
+        # cannot move between the listed states) selects the joint-state sampler II
+        n_states = len(Mi.pi) if isinstance(Mi.pi, dict) else (1 << t)
+        sampler = "I" if n_states == (1 << t) else "II"
     mt_method = "MegaBayesC" if mega else ("MTBayesC_II" if sampler == "II" else "MTBayesC")
 
     # ---- fast_blocks parsing (JWAS.jl:293-316); device blocks are powers of two >= 64

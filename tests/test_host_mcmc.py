@@ -601,3 +601,25 @@ def test_heritability_output_matches_its_definition(tmp_path):
     out2 = api.runMCMC(model, ph, chain_length=20, seed=1, output_folder=str(tmp_path / "h2"), engine=OracleEngine("block"),
                        block_size=64, output_heritability=False)
     assert "heritability" not in out2
+
+
+def test_auto_sampler_follows_the_support_of_pi(tmp_path):
+    """mt_bayesc_sampler_mode (MTBayesABC.jl:20-25): :auto = sampler I when Pi lists all 2^t joint states, else II."""
+    d = make_dataset(n=120, p=70, ncausal=4, seed=6, center=False)
+    ids = [f"id{i}" for i in range(120)]
+    gdf = pd.DataFrame(d["raw"], columns=[f"snp{j}" for j in range(70)]); gdf.insert(0, "ID", ids)
+    rng = np.random.default_rng(1)
+    ph = pd.DataFrame({"ID": ids, "y1": d["y"], "y2": 0.5 * d["y"] + rng.standard_normal(120)})
+    used = {}
+
+    class Spy(OracleEngine):
+        def init_state(self, method, t=1):
+            used["method"] = method
+            return super().init_state(method, t)
+
+    for Pi, want in (({(0.0, 0.0): 0.7, (1.0, 1.0): 0.3}, "MTBayesC_II"),
+                     ({(0.0, 0.0): 0.7, (1.0, 0.0): 0.1, (0.0, 1.0): 0.1, (1.0, 1.0): 0.1}, "MTBayesC")):
+        geno = api.get_genotypes(gdf, np.eye(2) * 0.5, method="BayesC", Pi=Pi, multi_trait_sampler="auto")
+        model = api.build_model("y1 = intercept + geno\ny2 = intercept + geno", np.eye(2))
+        api.runMCMC(model, ph, chain_length=6, seed=1, output_folder=str(tmp_path / want), engine=Spy("block"), block_size=64, outputEBV=False)
+        assert used["method"] == want
