@@ -181,8 +181,6 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
             anyobs |= np.isfinite(ph[tr].to_numpy(dtype=np.float64))
         if (anyobs & ~complete).any() and not missing_phenotypes:
             raise ValueError("phenotypes are missing for some traits of some individuals; missing_phenotypes=false does not allow that")
-        if (anyobs & ~complete).any() and mega:
-            raise NotImplementedError("missing phenotypes with constraint=true stay on the reference")
         usable = anyobs                          # partially observed records stay; their residuals are imputed every iteration
     else:
         usable = complete
@@ -455,6 +453,7 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
     run_varg = _Running(Gval) if not pervar else None
     run_pi = _Running(np.atleast_1d(np.asarray(pi_t if mega else pi, dtype=np.float64))) if Mi.estimatePi else None
     ebv_run = [_Running(np.zeros(len(out_ids))) for _ in range(t)] if outputEBV else None
+    run_scale = _Running(np.atleast_1d(np.float64(Mi.G.scale))) if (Mi.G.estimate_scale and t == 1) else None
     name = Mi.name
     files = {}
 
@@ -588,6 +587,11 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
             else:
                 Gval = np.float32((np.float32(st["alpha_ss"][0, 0]) + Gdf * Mi.G.scale) / rng.chisquare(st["sum_delta"][0] + Gdf))
 
+        # 4b. scale of the marker-effect variance prior (MCMC_BayesianAlphabet.jl:328-336; single trait only there too)
+        if Mi.G.estimate_scale and t == 1:
+            gv = Gvec.astype(np.float64) if pervar else np.atleast_1d(np.float64(Gval))
+            Mi.G.scale = float(rng.gamma(gv.size * Gdf / 2 + 1, 1.0 / (np.sum(Gdf / (2 * gv)) + 1)))
+
         # 5. residual variance (variance_components.jl:60-66,82-112), re-cast to Float32 (:368-370)
         if R.estimate_variance:
             if t > 1 and R.constraint:                                  # variance_components.jl:104-109
@@ -609,6 +613,8 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
             if run_pi is not None:
                 run_pi.add(np.atleast_1d(pi_t if mega else pi), k)
             engine.accumulate(k)
+            if run_scale is not None:
+                run_scale.add(np.atleast_1d(np.float64(Mi.G.scale)), k)
             if ann is not False:
                 A_.accumulate(ann, k)
             files["residual_variance"].write(",".join(repr(float(v)) for v in np.atleast_1d(vare).ravel()) + "\n")
@@ -676,6 +682,8 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         out[f"pi_{name}"] = pd.DataFrame({"π": lab, "Estimate": run_pi.mean, "SD": run_pi.sd()})
     if ann is not False:
         out[f"annotation coefficients {name}"] = A_.coefficients_table(ann, method)
+    if run_scale is not None:                                            # output.jl:148-150
+        out[f"ScaleEffectVar{name}"] = pd.DataFrame({"Covariance": [model.lhsVec[0]], "Estimate": run_scale.mean, "SD": run_scale.sd()})
     if outputEBV:
         for k, tr in enumerate(model.lhsVec):
             m = ebv_run[k].mean

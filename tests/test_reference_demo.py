@@ -284,3 +284,51 @@ def test_build_model_genotype_contracts():
         api.build_model("y1 = intercept + geno", 1.0)
     with pytest.raises(ValueError, match="multi_trait_sampler must be one of"):
         api.get_genotypes(GENO, 1.0, separator=",", method="BayesC", multi_trait_sampler="bogus")
+
+
+# ---- test/unit/test_advanced_coverage.jl:77-206 -------------------------------------------------------------
+@pytest.mark.gpu
+def test_advanced_coverage_sets_on_the_device_path(tmp_path):
+    G = np.array([[1.0, 0.5], [0.5, 1.0]])
+    I2 = np.eye(2)
+    ph = _phenotypes()
+    # mega-trait (G constraint), records with missing traits included
+    geno = api.get_genotypes(GENO, I2, separator=",", method="BayesC", constraint=True)
+    model = api.build_model("y1 = intercept + geno\ny2 = intercept + geno", I2)
+    out = api.runMCMC(model, ph, chain_length=100, burnin=20, output_samples_frequency=10, output_folder=str(tmp_path / "c"), seed=123)
+    assert "location parameters" in out and "residual variance" in out
+    # multi-trait RR-BLUP with missing phenotypes
+    geno = api.get_genotypes(GENO, G, separator=",", method="RR-BLUP")
+    model = api.build_model("y1 = intercept + geno\ny2 = intercept + geno", G)
+    out = api.runMCMC(model, ph, chain_length=100, burnin=20, output_samples_frequency=10, missing_phenotypes=True,
+                      output_folder=str(tmp_path / "m"), seed=123)
+    assert "location parameters" in out and "residual variance" in out
+    # Pi estimation in multi-trait BayesC
+    geno = api.get_genotypes(GENO, G, separator=",", method="BayesC", estimatePi=True)
+    model = api.build_model("y1 = intercept + geno\ny2 = intercept + geno", G)
+    out = api.runMCMC(model, ph, chain_length=100, burnin=20, output_samples_frequency=10, output_folder=str(tmp_path / "p"), seed=123)
+    assert "pi_geno" in out and "marker effects geno" in out
+    # single-trait BayesC with estimate_scale
+    geno = api.get_genotypes(GENO, 1.0, separator=",", method="BayesC", estimate_scale=True)
+    model = api.build_model("y1 = intercept + geno", 1.0)
+    out = api.runMCMC(model, ph, chain_length=100, burnin=20, output_samples_frequency=10, output_folder=str(tmp_path / "s"), seed=123)
+    assert "location parameters" in out and "ScaleEffectVargeno" in out and float(out["ScaleEffectVargeno"]["Estimate"][0]) > 0
+    # multi-trait EBV output with heritability
+    geno = api.get_genotypes(GENO, G, separator=",", method="BayesC")
+    model = api.build_model("y1 = intercept + geno\ny2 = intercept + geno", G)
+    api.outputEBV(model, geno.obsID)
+    out = api.runMCMC(model, ph, chain_length=100, burnin=20, output_samples_frequency=10, outputEBV=True, output_heritability=True,
+                      output_folder=str(tmp_path / "e"), seed=123)
+    assert {"EBV_y1", "EBV_y2", "genetic_variance", "heritability"} <= set(out)
+    assert len(out["genetic_variance"]) == 4 and len(out["heritability"]) == 2
+    # single-trait with weights (heterogeneous residuals): the demo file has a `weights` column
+    geno = api.get_genotypes(GENO, 1.0, separator=",", method="BayesC")
+    model = api.build_model("y1 = intercept + geno", 1.0)
+    out = api.runMCMC(model, ph, chain_length=100, burnin=20, output_samples_frequency=10, heterogeneous_residuals=True,
+                      output_folder=str(tmp_path / "w"), seed=123)
+    assert "marker effects geno" in out
+    # multi-trait BayesB / BayesL stay on the reference, loudly
+    geno = api.get_genotypes(GENO, G, separator=",", method="BayesB")
+    model = api.build_model("y1 = intercept + geno\ny2 = intercept + geno", G)
+    with pytest.raises(NotImplementedError, match="multi-trait device path"):
+        api.runMCMC(model, ph, chain_length=10, output_folder=str(tmp_path / "b"), seed=123)
