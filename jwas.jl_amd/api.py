@@ -220,6 +220,7 @@ class Model:
         self.MCMCinfo = None
         self.output = None
         self.output_ID = False                 # outputEBV(model, IDs); False = all genotyped individuals
+        self.outputSamplesVec = []             # outputMCMCsamples(model, terms...): (trait, term) pairs
 
 
 def build_model(model_equations, R=False, *, df=4.0, estimate_variance=True, estimate_scale=False,
@@ -299,6 +300,14 @@ def build_model(model_equations, R=False, *, df=4.0, estimate_variance=True, est
 def outputEBV(model, IDs):
     """output.jl:60-70: individuals of interest for EBV output (default: all genotyped individuals)."""
     model.output_ID = [str(i) for i in IDs]
+
+
+def outputMCMCsamples(model, *terms):
+    """output.jl:76-95: also save the MCMC samples of these location-parameter terms (MCMC_samples_<trait>.<term>.txt)."""
+    for trm in terms:
+        for tr, tl in zip(model.lhsVec, model.modelTerms):
+            if any(mt.name == trm for mt in tl) and (tr, trm) not in model.outputSamplesVec:
+                model.outputSamplesVec.append((tr, trm))
 
 
 def set_covariate(model, *names):

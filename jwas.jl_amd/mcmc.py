@@ -350,7 +350,22 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         elif np.isscalar(fast_blocks):
             want = int(np.floor(fast_blocks))
         else:
-            raise NotImplementedError("explicit fast_blocks start vectors stay on the reference (device blocks are uniform)")
+            try:
+                starts = [int(v) for v in fast_blocks]
+            except (TypeError, ValueError):
+                raise ValueError("fast_blocks must be false, true, a positive number, or a vector of block start positions.")
+            if any(int(v) != v for v in fast_blocks):
+                raise ValueError("fast_blocks must be false, true, a positive number, or a vector of block start positions.")
+            if len(starts) == 0:                                         # validate_fast_block_starts (JWAS.jl:73-79)
+                raise ValueError("fast_blocks block start vector cannot be empty.")
+            if starts[0] != 1:
+                raise ValueError("fast_blocks block starts must begin with 1.")
+            if not all(1 <= v <= p for v in starts):
+                raise ValueError("fast_blocks block starts must be within 1:nMarkers.")
+            if not all(b_ > a_ for a_, b_ in zip(starts, starts[1:])):
+                raise ValueError("fast_blocks block starts must be sorted and unique.")
+            raise NotImplementedError("explicit fast_blocks start vectors (a repetition count per block) stay on the reference: "
+                                      "device blocks are uniform")
         if want < 1:
             raise ValueError("fast_blocks block size must be at least 1.")
         if want >= p:                                                   # range(1, step=want, stop=p) has one start
@@ -474,6 +489,13 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         _open("genetic_variance", rnames if t > 1 else [model.lhsVec[0]])
         _open("heritability", list(model.lhsVec))
         h2_samples, gv_samples = [], []
+    term_cols = {}                                                      # outputMCMCsamples (output.jl:76-95,443-460)
+    for tr, trm in getattr(model, "outputSamplesVec", []):
+        k = model.lhsVec.index(tr)
+        cols = [off[k] + i for i, (_, eff, _) in enumerate(labels[k]) if eff == trm]
+        if cols:
+            term_cols[f"{tr}.{trm}"] = cols
+            _open(f"{tr}.{trm}", [f"{tr}:{trm}:{labels[k][c - off[k]][2]}" for c in cols])
     write_marker_samples = output_samples_for_all_parameters or p <= 20000
     if write_marker_samples:
         for k, tr in enumerate(model.lhsVec):
@@ -617,6 +639,8 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
                 run_scale.add(np.atleast_1d(np.float64(Mi.G.scale)), k)
             if ann is not False:
                 A_.accumulate(ann, k)
+            for key_, cols in term_cols.items():
+                files[key_].write(",".join(repr(float(sol[c])) for c in cols) + "\n")
             files["residual_variance"].write(",".join(repr(float(v)) for v in np.atleast_1d(vare).ravel()) + "\n")
             if not pervar:
                 files[f"marker_effects_variances_{name}"].write(",".join(repr(float(v)) for v in np.atleast_1d(Gval).ravel()) + "\n")

@@ -332,3 +332,32 @@ def test_advanced_coverage_sets_on_the_device_path(tmp_path):
     model = api.build_model("y1 = intercept + geno\ny2 = intercept + geno", G)
     with pytest.raises(NotImplementedError, match="multi-trait device path"):
         api.runMCMC(model, ph, chain_length=10, output_folder=str(tmp_path / "b"), seed=123)
+
+
+# ---- test/unit/test_misc_coverage.jl:69-91, 116-208 ---------------------------------------------------------
+def test_output_mcmc_samples_and_covariates(tmp_path):
+    from oracle_engine import OracleEngine
+    geno = api.get_genotypes(GENO, 1.0, separator=",", method="BayesC")
+    model = api.build_model("y1 = intercept + x1 + geno", 1.0)
+    api.set_covariate(model, "x1")
+    assert "x1" in model.covVec
+    api.outputMCMCsamples(model, "intercept", "x1")
+    folder = tmp_path / "test_multi_samples"
+    api.runMCMC(model, _phenotypes(), chain_length=50, output_samples_frequency=10, output_folder=str(folder), seed=123,
+                engine=OracleEngine("block"))
+    assert os.path.isfile(folder / "MCMC_samples_y1.intercept.txt") and os.path.isfile(folder / "MCMC_samples_y1.x1.txt")
+    assert pd.read_csv(folder / "MCMC_samples_y1.x1.txt").shape == (5, 1)
+
+
+@pytest.mark.parametrize("bad,msg", [([2, 4], "begin with 1"), ([1, 3, 3], "sorted and unique"), ([3, 1], "begin with 1"),
+                                     ([1, 10], "within 1:nMarkers")])
+def test_explicit_block_start_validation(tmp_path, bad, msg):
+    from oracle_engine import OracleEngine
+    geno = api.get_genotypes(GENO, 1.0, separator=",", method="BayesC")
+    model = api.build_model("y1 = intercept + geno", 1.0)
+    with pytest.raises(ValueError, match=msg):
+        api.runMCMC(model, _phenotypes(), chain_length=6, output_folder=str(tmp_path / "x"), fast_blocks=bad, engine=OracleEngine("block"))
+    geno = api.get_genotypes(GENO, 1.0, separator=",", method="BayesC")
+    model = api.build_model("y1 = intercept + geno", 1.0)
+    with pytest.raises(NotImplementedError, match="explicit fast_blocks start vectors"):
+        api.runMCMC(model, _phenotypes(), chain_length=6, output_folder=str(tmp_path / "y"), fast_blocks=[1, 3, 5], engine=OracleEngine("block"))
