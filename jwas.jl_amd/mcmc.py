@@ -345,6 +345,7 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
     # ---- fast_blocks parsing (JWAS.jl:293-316); device blocks are powers of two >= 64
     nreps = 1
     if fast_blocks is not False:
+        explicit_starts = False
         if fast_blocks is True:
             want = int(np.floor(np.sqrt(n)))
         elif np.isscalar(fast_blocks):
@@ -364,8 +365,13 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
                 raise ValueError("fast_blocks block starts must be within 1:nMarkers.")
             if not all(b_ > a_ for a_, b_ in zip(starts, starts[1:])):
                 raise ValueError("fast_blocks block starts must be sorted and unique.")
-            raise NotImplementedError("explicit fast_blocks start vectors (a repetition count per block) stay on the reference: "
-                                      "device blocks are uniform")
+            sizes = [b_ - a_ for a_, b_ in zip(starts, starts[1:])]
+            if len(starts) < 2 or len(set(sizes)) != 1 or (p - starts[-1] + 1) > sizes[0]:
+                raise NotImplementedError("non-uniform explicit fast_blocks start vectors (a repetition count per block) stay on "
+                                          "the reference: device blocks are uniform")
+            # uniform explicit starts = the numeric form, except that the reference does not rescale chain_length here
+            # (JWAS.jl:298-304: block_size = false)
+            want, explicit_starts = sizes[0], True
         if want < 1:
             raise ValueError("fast_blocks block size must be at least 1.")
         if want >= p:                                                   # range(1, step=want, stop=p) has one start
@@ -375,7 +381,8 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         # device partition is uniform blocks of the next supported size >= want (any partition is an exact block Gibbs
         # sampler); fewer markers than one device block run as a single block.
         block_size = _supported_block(want)
-        chain_length = int(np.floor(chain_length / want))
+        if not explicit_starts:
+            chain_length = int(np.floor(chain_length / want))
         nreps = want
         print(f"BLOCK SIZE: {want}" + (f" (device blocks of {min(block_size, p)} markers)" if min(block_size, p) != want else ""))
     adaptive = False

@@ -359,5 +359,18 @@ def test_explicit_block_start_validation(tmp_path, bad, msg):
         api.runMCMC(model, _phenotypes(), chain_length=6, output_folder=str(tmp_path / "x"), fast_blocks=bad, engine=OracleEngine("block"))
     geno = api.get_genotypes(GENO, 1.0, separator=",", method="BayesC")
     model = api.build_model("y1 = intercept + geno", 1.0)
-    with pytest.raises(NotImplementedError, match="explicit fast_blocks start vectors"):
-        api.runMCMC(model, _phenotypes(), chain_length=6, output_folder=str(tmp_path / "y"), fast_blocks=[1, 3, 5], engine=OracleEngine("block"))
+    with pytest.raises(NotImplementedError, match="non-uniform explicit fast_blocks"):
+        api.runMCMC(model, _phenotypes(), chain_length=6, output_folder=str(tmp_path / "y"), fast_blocks=[1, 2, 4], engine=OracleEngine("block"))
+
+
+@pytest.mark.parametrize("method", ["BayesC", "BayesR"])
+def test_independent_blocks_with_explicit_uniform_starts(tmp_path, method):
+    """test_misc_coverage.jl:161-196: fast_blocks=[1,3,5] (blocks of 2 markers) with independent_blocks=true; the chain
+    length is NOT rescaled for an explicit start vector (JWAS.jl:298-304)."""
+    from oracle_engine import OracleEngine
+    geno = api.get_genotypes(GENO, 1.0, separator=",", method=method)
+    model = api.build_model("y1 = intercept + geno", 1.0)
+    out = api.runMCMC(model, _phenotypes(), chain_length=6, output_folder=str(tmp_path / "ib"), seed=1, fast_blocks=[1, 3, 5],
+                      independent_blocks=True, engine=OracleEngine("block"))
+    assert "marker effects geno" in out and "Model_Frequency" in out["marker effects geno"].columns
+    assert out["_timing"]["iterations"] == 6
