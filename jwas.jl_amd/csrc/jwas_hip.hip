@@ -27,6 +27,7 @@ struct jwas_hip_ctx {
     int64_t n = 0, p = 0, ld = 0;
     int nslices = 0;                    // 256-row slices
     int nrg = 0, ncg = 1;               // k_update_partial grid: row groups x column groups
+    int spg = 8;                        // slices per row group
     float* X = nullptr;                 // dense fp32 storage ...
     uint8_t* Q = nullptr;               // ... or the reference's 2-bit packed storage [p][ld/4] + per-marker means
     float* qmean = nullptr;
@@ -275,20 +276,37 @@ static int alloc_storage(jwas_hip_ctx* c, int64_t n, int64_t p, bool packed = fa
     c->method = -1; c->block_size = 0; c->nblocks = 0;
     c->n = n; c->p = p; c->ld = round_up(n, kSliceRows);
     c->nslices = (int)(c->ld / kSliceRows);
-    c->nrg = (c->nslices + kRowGroupSlices - 1) / kRowGroupSlices;
-    // Column groups: as many workgroups as fit in ONE scheduling round.  The step kernel's dynamic LDS (sized for the
-    // sampler role) allows one workgroup per CU, and the quiet-XCD placement leaves every 8th CU idle, so 224 of the
-    // 256 CUs stream; more workgroups than that run as a second round and cost up to 2x (measured: 5.5-6.1 TB/s with
-    // <= 224 workgroups, 3.8-4.1 TB/s with 235-245).
-    c->ncg = 224 / c->nrg; if (c->ncg < 1) c->ncg = 1;
-    {   // Cap on the column groups (every column group of a row group re-applies the previous block's changes to its
-        // copy of the residual slice, so the cap bounds that redundancy).  Short matrices have few row groups and need
-        // many column groups to put enough workgroups on the chip: measured per sweep at p = 102 400, sparse steady state,
-        // 1024-marker blocks, cap 8 -> 16 -> 32:  n = 5 000: 2.60 -> 1.92 -> 1.80 ms;  10 000: 2.67 -> 1.96 -> 1.87;
-        // 20 000: 2.84 -> 2.14 -> 2.22;  30 000: 2.99 -> 2.61 (14 groups).  n >= 50 000 reaches 200+ workgroups with <= 8.
-        const char* e = std::getenv("JWAS_HIP_MAX_NCG");                 // (experiments)
-        const int cap = e ? std::atoi(e) : (c->nrg < 8 ? 32 : 16);
-        if (c->ncg > cap) c->ncg = cap;
+    // Update-role geometry.  A workgroup is one row group (spg slices of 256 rows, one wave each, spg <= 8) x one column
+    // group.  The step kernel's dynamic LDS (sized for the sampler role) allows one workgroup per CU and the quiet-XCD
+    // placement leaves every 8th CU idle, so 224 of the 256 CUs stream; more workgroups than that run as a second round
+    // and cost up to 2x (measured: 5.5-6.1 TB/s with <= 224 workgroups, 3.8-4.1 TB/s with 235-245).  Every column group
+    // of a row group re-applies the previous block's changes to its copy of the residual slice, so the number of column
+    // groups is capped.  Short matrices have few row groups and need many column groups to put enough workgroups on the
+    // chip (per sweep at p = 102 400, sparse steady state, 1024-marker blocks, cap 8 -> 16 -> 32: n = 5 000: 2.60 -> 1.92
+    // -> 1.80 ms; 10 000: 2.67 -> 1.96 -> 1.87; 20 000: 2.84 -> 2.14 -> 2.22; 30 000: 2.99 -> 2.61).
+    // Among spg = 4..8 the geometry with the most streaming waves (slices x column groups) wins, ties go to the one that
+    // spreads them over more CUs: at n = 50 000 (196 slices) spg 8 gives 25 x 8 = 200 workgroups, spg 7 gives 28 x 8 =
+    // 224 with the same 1568 waves -- 35.1 instead of 36.1 us per 1024-marker launch (48.0 vs 46.4-46.8 iterations/s, twice);
+    // n = 280 000: spg 5, 219 instead of 137 workgroups, 18.4 instead of 19.8 ms per 102 400-marker sweep; n = 100 000: neutral.
+    {
+        const char* e_spg = std::getenv("JWAS_HIP_SPG");                 // (experiments)
+        const char* e_cap = std::getenv("JWAS_HIP_MAX_NCG");
+        int best_spg = kRowGroupSlices, best_ncg = 1, best_nrg = (c->nslices + kRowGroupSlices - 1) / kRowGroupSlices;
+        long best_waves = -1, best_wgs = -1;
+        for (int spg = kRowGroupSlices; spg >= 4; --spg) {
+            if (e_spg && spg != std::max(1, std::min(kRowGroupSlices, std::atoi(e_spg)))) continue;
+            const int nrg = (c->nslices + spg - 1) / spg;
+            int ncg = 224 / nrg; if (ncg < 1) ncg = 1;
+            const int cap = e_cap ? std::atoi(e_cap) : (nrg < 8 ? 32 : 16);
+            if (ncg > cap) ncg = cap;
+            const long waves = (long)c->nslices * ncg, wgs = (long)nrg * ncg;
+            // (ties are only broken for tall matrices, where the launch is bound by the update role; shorter ones are
+            // bound by the sampler and measured neutral to slightly worse with 6-7 slices per group)
+            if (waves > best_waves || (waves == best_waves && wgs > best_wgs && wgs <= 224 && c->nslices >= 128)) {
+                best_waves = waves; best_wgs = wgs; best_spg = spg; best_ncg = ncg; best_nrg = nrg;
+            }
+        }
+        c->spg = best_spg; c->nrg = best_nrg; c->ncg = best_ncg;
     }
     size_t fb = 0, tb = 0;
     HIPCHK(c, hipMemGetInfo(&fb, &tb));
@@ -1090,7 +1108,7 @@ static int sweep_independent(jwas_hip_ctx* c, EventList* out)
     std::memset(&U, 0, sizeof U);
     U.r_in = c->r; U.r_out = nullptr;
     U.ev = &c->ev[0];                               // count zeroed by the caller: nothing to apply
-    U.nslices = c->nslices; U.nrg = c->nrg; U.ncg = c->ncg;
+    U.nslices = c->nslices; U.nrg = c->nrg; U.ncg = c->ncg; U.spg = c->spg;
     U.partials = c->ipartials; U.bstride = bs;
     SamplerArgs S;
     std::memset(&S, 0, sizeof S);
@@ -1261,7 +1279,7 @@ int jwas_hip_sweep(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_sweep_stats
         U.ev = &c->ev[k & 1];
         U.j0 = (k < nb) ? k * bs : 0;
         U.b = (k < nb) ? (int)((U.j0 + bs <= c->p) ? bs : c->p - U.j0) : 0;
-        U.nslices = c->nslices; U.nrg = c->nrg;
+        U.nslices = c->nslices; U.nrg = c->nrg; U.spg = c->spg;
         U.ncg = (U.b > 0 && c->ncg > U.b) ? U.b : c->ncg;
         U.partials = c->partials + (k & 1) * pstride; U.bstride = bs;
         {   // Placement heuristic (speed only): keep XCD 0 free of streaming traffic for the sampler while the sampler chain

@@ -83,13 +83,13 @@ __device__ __forceinline__ void update_role(char* smem, int rg, int g,
                                             const float* __restrict__ r_in, float* __restrict__ r_out,
                                             const Events* __restrict__ ev,
                                             int64_t j0, int b, int nslices, int nrg, int ncg,
-                                            double* __restrict__ partials, int bstride)
+                                            double* __restrict__ partials, int bstride, int spg = kRowGroupSlices)
 {
     typedef double RedT[kColChunk][NT];
     RedT* red = reinterpret_cast<RedT*>(smem);                 // [kRowGroupSlices][kColChunk][NT]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int slice = rg * kRowGroupSlices + wave;
-    const bool active = slice < nslices;
+    const int slice = rg * spg + wave;
+    const bool active = wave < spg && slice < nslices;
     // an inactive wave (slice beyond the matrix) aliases slice 0 for addressing and contributes 0
     const int64_t row = (int64_t)(active ? slice : 0) * kSliceRows + lane * 4;
     const int ncols = (b > g) ? (b - g + ncg - 1) / ncg : 0;
@@ -103,8 +103,13 @@ __device__ __forceinline__ void update_role(char* smem, int rg, int g,
     constexpr int D = CX::kDepth;                      // register batches in flight per wave
     const typename CX::Stream st = cx.stream(jc0, ncg, row);     // element i = marker jc0 + i*ncg, this lane's 4 rows
     auto load_batch = [&](Raw (&dst)[kU], int ib) {
+        if (active) {                                  // (wave-uniform; an idle wave streams nothing)
 #pragma unroll
-        for (int u = 0; u < kU; ++u) dst[u] = st.load_raw(ib + u < ncols ? ib + u : nc1);
+            for (int u = 0; u < kU; ++u) dst[u] = st.load_raw(ib + u < ncols ? ib + u : nc1);
+        } else {
+#pragma unroll
+            for (int u = 0; u < kU; ++u) dst[u] = Raw{};
+        }
     };
 
     // (1) the first batch(es) of column loads do not depend on r: issue them before the update.
@@ -1641,6 +1646,7 @@ struct UpdateArgs {
     const Events* ev;             // changes to apply (block k-2)
     int64_t j0; int b;            // block whose partial RHS is formed (b = 0: none)
     int nslices, nrg, ncg;
+    int spg;                      // slices (waves that stream) per row group: <= 8
     double* partials; int bstride;
     int quiet_xcd;                // 1: ids = 0 mod 8 (the sampler's XCD) do no update work
     int dbg_throttle;             // > 1: only every n-th update workgroup runs (timing experiments; results wrong)
@@ -1671,7 +1677,7 @@ __global__ __launch_bounds__(kStepThreads) void k_block_step(UpdateArgsT<CX> U, 
     if (w >= U.nrg * U.ncg) return;
     if (U.dbg_throttle > 1 && (w % U.dbg_throttle) != 0) return;       // timing experiments only
     update_role<NT, CX>(smem, w % U.nrg, w / U.nrg, U.cx, U.r_in, U.r_out, U.ev, U.j0, U.b,
-                        U.nslices, U.nrg, U.ncg, U.partials, U.bstride);
+                        U.nslices, U.nrg, U.ncg, U.partials, U.bstride, U.spg);
 }
 
 // Cross-Gram of consecutive blocks, exact (fp64-accumulated): C[a][c] = x_{jp+a}' x_{j0+c}.
@@ -1721,7 +1727,7 @@ __global__ __launch_bounds__(kStepThreads) void k_indep_rhs(UpdateArgsT<CX> U, i
     const int w = blockIdx.x;
     if (w >= U.nrg * ncg) return;
     update_role<NT, CX>(smem, w % U.nrg, w / U.nrg, U.cx, U.r_in, nullptr, U.ev, j0, b,
-                        U.nslices, U.nrg, ncg, U.partials + blk * pstride, U.bstride);
+                        U.nslices, U.nrg, ncg, U.partials + blk * pstride, U.bstride, U.spg);
 }
 
 // All blocks sampled concurrently.  grid = nblocks, block = 512, dynamic LDS as k_block_step.
