@@ -38,7 +38,7 @@ HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8 TB/s 
 # FETCH_SIZE x2 per the guide's gfx950 correction, checked on k_xpx which reads X exactly once).
 # Valid for the default config only (n=50000, p=600000, adaptive blocks -> 1024 in the timed region): 213.7 MB per launch
 # against 204.4 MB algorithmic (1.05x).
-TRAFFIC_BYTES_PER_LAUNCH = (103860.46 * 2 + 1006.89) * 1024          # profiles/r01_pmc_{fetch,write}_summary.csv, last rows
+TRAFFIC_BYTES_PER_LAUNCH = (101283.94 * 2 + 655.96) * 1024          # profiles/r01_pmc_{fetch,write}_summary.csv, last rows
 
 
 def parse():
