@@ -598,3 +598,42 @@ def test_mt_marker_specific_prior_error_contracts(hip):
     with pytest.raises(J.JwasHipError, match="support 2 traits"):
         hip.sweep(iteration=1, seed=1, vare=np.eye(3, dtype=np.float32), var_effect=np.eye(3, dtype=np.float32) * 0.01,
                   log_prior_states=np.log(np.full((1100, 8), 0.125)))
+
+
+@pytest.mark.parametrize("spg", [7, 5, 4])
+def test_row_group_geometry_does_not_change_the_chain(spg, monkeypatch):
+    """Tall matrices run with fewer than 8 streaming waves per row group (224 workgroups of 7 waves at n = 50 000, 5 at
+    n = 280 000; jwas_hip.hip alloc_storage).  The geometry only regroups the fp64 partial sums: forced here on a
+    small matrix (JWAS_HIP_SPG is read when the storage is allocated), the chain must still equal the oracle's."""
+    import jwas_jl_amd as J
+    monkeypatch.setenv("JWAS_HIP_SPG", str(spg))
+    data = make_dataset(n=2600, p=3 * 256 + 17, ncausal=9, seed=spg)        # 11 slices: ragged last row group
+    orc = OracleEngine("lookahead")
+    hip = J.HipEngine(0)
+    try:
+        for e in (orc, hip):
+            e.load_dense(data["X"]); e.setup_blocks(256, "f64"); e.init_state("BayesC")
+            e.set_residual(data["y"] - data["y"].mean())
+        vare, varg = _hyper(data)
+        for it in range(1, 9):
+            so = orc.sweep(iteration=it, seed=3, vare=vare, var_effect=varg, pi=0.9)
+            sh = hip.sweep(iteration=it, seed=3, vare=vare, var_effect=varg, pi=0.9)
+            assert so["sum_delta"][0] == sh["sum_delta"][0], f"iteration {it}"
+        _compare_state(orc, hip, atol=5e-6)
+        # multi-trait on the same geometry
+        for e in (orc, hip):
+            e.init_state("MTBayesC", 2)
+            for k in range(2):
+                e.set_residual((data["y"] - data["y"].mean()) * (1.0 + 0.3 * k), k)
+                e.set_state(k, delta=np.ones(e.p, dtype=np.float32))
+        lp = np.log(np.array([0.7, 0.1, 0.1, 0.1]))
+        V = np.array([[0.6, 0.1], [0.1, 0.5]], dtype=np.float32)
+        Gm = np.array([[0.003, 0.001], [0.001, 0.002]], dtype=np.float32)
+        for it in range(1, 6):
+            so = orc.sweep(iteration=it, seed=4, vare=V, var_effect=Gm, log_prior_states=lp)
+            sh = hip.sweep(iteration=it, seed=4, vare=V, var_effect=Gm, log_prior_states=lp)
+            assert np.array_equal(so["state_counts"], sh["state_counts"]), f"iteration {it}"
+        for k in range(2):
+            _compare_state(orc, hip, k, atol=5e-6)
+    finally:
+        hip.close()
