@@ -620,6 +620,11 @@ def test_row_group_geometry_does_not_change_the_chain(spg, monkeypatch):
             sh = hip.sweep(iteration=it, seed=3, vare=vare, var_effect=varg, pi=0.9)
             assert so["sum_delta"][0] == sh["sum_delta"][0], f"iteration {it}"
         _compare_state(orc, hip, atol=5e-6)
+        for it in range(9, 12):                                              # independent-block kernels on the same geometry
+            so = orc.sweep(iteration=it, seed=3, vare=vare, var_effect=varg, pi=0.9, independent_blocks=True)
+            sh = hip.sweep(iteration=it, seed=3, vare=vare, var_effect=varg, pi=0.9, independent_blocks=True)
+            assert so["sum_delta"][0] == sh["sum_delta"][0], f"independent, iteration {it}"
+        _compare_state(orc, hip, atol=5e-6)
         # multi-trait on the same geometry
         for e in (orc, hip):
             e.init_state("MTBayesC", 2)
