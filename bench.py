@@ -46,6 +46,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--burnin", type=int, default=30,
+                    help="chain iterations run as part of the SETUP (untimed, before the warm-up steps): the metric is defined "
+                         "on the steady state of the chain (SURVEY.md section 8d), which a start from alpha = 0 reaches after "
+                         "~25 sweeps; with --warmup >= 30 (the default) pass --burnin 0 for the same state")
     ap.add_argument("--n", type=int, default=N_IND)
     ap.add_argument("--p", type=int, default=P_TOTAL)
     ap.add_argument("--block-size", type=int, default=int(os.environ.get("JWAS_BLOCK_SIZE", "0")),
@@ -184,6 +188,11 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    # chain burn-in (setup): only when the warm-up alone would not reach the steady state
+    nburn = max(0, a.burnin - a.warmup)
+    for _ in range(nburn):
+        step()
+    log(f"burn-in done: {nburn} sweeps")
     for _ in range(a.warmup):
         st_ = step(); log(f"warmup step: sweep_ms={st_['sweep_ms']:.1f} events={st_['n_events']:.0f} in_model={st_['sum_delta'][0]:.0f}")
     for k in acc:
@@ -223,7 +232,8 @@ def main():
                        "storage": a.storage,
                        "n": n, "p": p_total, "block_size": bs, "block_policy": "adaptive 512/1024" if adaptive else "fixed", "parallelism": f"marker-shard x{world}" if world > 1 else "single GPU",
                        "device_sweep_ms": acc["sweep_ms"] / a.steps, "events_per_sweep": acc["events"] / a.steps,
-                       "markers_in_model": float(last["sum_delta"][0]), "setup_s": setup_s},
+                       "markers_in_model": float(last["sum_delta"][0]), "setup_s": setup_s,
+                       "chain_sweeps_before_timing": nburn + a.warmup},
             "roofline": {"bound": "hbm", "kernel": "k_block_step", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": TRAFFIC_BYTES_PER_LAUNCH if (TRAFFIC_BYTES_PER_LAUNCH and adaptive and bs == 1024 and p_total == P_TOTAL and n == N_IND and world == 1 and a.storage == "dense") else None,
                          "bytes_per_launch": bytes_per_launch, "avg_launch_us": avg_launch_us, "launches_timed": launches},
