@@ -4,21 +4,35 @@
 Metric (BASELINE.json): MCMC iters/sec (full marker sweep), 50k x 600k single-trait BayesC, fp32 dense
 genotypes, pi0 = 0.95 estimated, at 1/2/4/8 GPUs.  One "step" = one MCMC iteration = one full sweep
 over all p markers (device) + the host-side updates of MCMC_BayesianAlphabet.jl:196-220,294-370
-(intercept Gibbs step, pi ~ Beta, marker-effect variance, residual variance).
+(location parameters, pi, marker-effect variance, residual variance).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload ...]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1: markers are sharded over the ranks (jwas.jl_amd/dist.py): each rank sweeps p/N markers from the
-same residual snapshot and one all-reduce (RCCL) of the residual delta reconciles per sweep.  Total
-work is fixed (50k x 600k), so "scaling" is "strong".
+Workloads (BASELINE.json `configs`):
+    config2       single-trait BayesC, 50 000 x 600 000 fp32 dense, pi0 = 0.95 estimated  (the metric; default)
+                  --pi-fixed 0.95: estimatePi = false -- the high-turnover variant (~30 000 markers move per sweep)
+    config3       single-trait BayesR (gamma 0, .01, .1, 1; pi0 = .95, .03, .015, .005 estimated), 50 000 x 600 000
+    config4       3-trait BayesC, Gibbs sampler I, 20 000 x 100 000, R and G inverse-Wishart on the host, 8-state pi table
+                  estimated; --mt-prior default (the reference's default: all mass on the all-ones state, every marker
+                  in the model) | sparse (0.95 on the null state)
+    config5shard  one GPU's share of config 5 (single-step shaped input): BayesC, 280 000 rows (80 000 integer-coded +
+                  200 000 real-valued "imputed") x 75 000 markers = 84 GB; with --gpus N every rank holds its own 75 000
+                  markers (N = 8 is config 5 itself) -- weak scaling
+    refbench      the shape of the reference's own published benchmark (benchmarks/jwas_nonblock_benchmark.jl:34-51)
+
+N > 1 (config2/3/4: total work fixed, "strong"): markers are sharded over the ranks (jwas.jl_amd/dist.py): each rank
+sweeps its markers from the same residual snapshot and ONE all-reduce (RCCL) of the residual delta reconciles per sweep.
 
 Prints ONE JSON line (rank 0) with the contract fields plus
   "roofline":     HBM roofline of the dominant kernel (k_block_step: sampler of block k-1 || update + partial
                   RHS of block k): algorithmic bytes per launch / average launch duration, from the HIP events
-                  recorded on the sweep's stream inside the timed region;
-  "cpu_baseline": the CPU oracle's non-block BayesC sweep (the reference's per-marker sdot/saxpy
-                  order) timed on this box's host cores on a marker subsample (N = 1, rank 0 only).
+                  recorded on the sweep's stream inside the timed region; "traffic" is filled from the PMC summaries
+                  under profiles/ when they were collected for exactly this configuration (traffic_source), else null;
+  "cpu_baseline": the CPU oracle's non-block sweep of the same sampler (the reference's per-marker sdot / scalar update /
+                  saxpy order) timed on this box's host cores on a marker subsample (N = 1, rank 0 only): single thread,
+                  a 16-thread team and all cores; the fastest is `value`, all are listed in `sample`;
+  "via_api":      (config2, N = 1) the same chain driven through the package's runMCMC() -- the API path a user calls.
 """
 import argparse
 import json
@@ -31,14 +45,17 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-N_IND, P_TOTAL = 50_000, 600_000
 HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
-# HBM bytes per k_block_step launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and
-# --pmc WRITE_SIZE in separate runs of this command, averaged over the launches of the timed region's steady state;
-# FETCH_SIZE x2 per the guide's gfx950 correction, checked on k_xpx which reads X exactly once).
-# Valid for the default config only (n=50000, p=600000, adaptive blocks -> 1024 in the timed region): 213.7 MB per launch
-# against 204.4 MB algorithmic (1.05x).
-TRAFFIC_BYTES_PER_LAUNCH = (101283.94 * 2 + 655.96) * 1024          # profiles/r01_pmc_{fetch,write}_summary.csv, last rows
+BAYESR_GAMMA = np.array([0.0, 0.01, 0.1, 1.0])
+
+WORKLOADS = {
+    #                n        p        method     traits
+    "config2":      (50_000,  600_000, "BayesC",  1),
+    "config3":      (50_000,  600_000, "BayesR",  1),
+    "config4":      (20_000,  100_000, "MTBayesC", 3),
+    "config5shard": (280_000, 75_000,  "BayesC",  1),
+    "refbench":     (50_000,  100_000, "BayesC",  1),
+}
 
 
 def parse():
@@ -49,22 +66,24 @@ def parse():
     ap.add_argument("--burnin", type=int, default=30,
                     help="chain iterations run as part of the SETUP (untimed, before the warm-up steps): the metric is defined "
                          "on the steady state of the chain (SURVEY.md section 8d), which a start from alpha = 0 reaches after "
-                         "~25 sweeps; with --warmup >= 30 (the default) pass --burnin 0 for the same state")
-    ap.add_argument("--n", type=int, default=N_IND)
-    ap.add_argument("--p", type=int, default=P_TOTAL)
+                         "~25 sweeps; with --warmup >= 30 (the default) nothing extra runs")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="config2")
+    ap.add_argument("--n", type=int, default=0, help="override the workload's number of individuals")
+    ap.add_argument("--p", type=int, default=0, help="override the workload's number of markers (per GPU for config5shard)")
     ap.add_argument("--block-size", type=int, default=int(os.environ.get("JWAS_BLOCK_SIZE", "0")),
-                    help="0 (default) = the host loop's policy (jwas.jl_amd/mcmc.py): blocks of 512 markers while many effects "
-                         "change per sweep, 1024 once fewer than 1.25 %% do; or a fixed size in {64,...,1024}")
+                    help="0 (default) = the host loop's policy (jwas.jl_amd/mcmc.py); or a fixed size in {64,...,1024}")
+    ap.add_argument("--pi-fixed", type=float, default=None,
+                    help="BayesC workloads: keep pi at this value (estimatePi = false) -- the high-turnover variant")
+    ap.add_argument("--mt-prior", choices=["default", "sparse"], default="default")
     ap.add_argument("--seed", type=int, default=2026)
-    ap.add_argument("--workload", choices=["config2", "refbench"], default="config2",
-                    help="config2 = the metric's workload (default).  refbench = the shape of the reference's own published "
-                         "benchmark (benchmarks/jwas_nonblock_benchmark.jl:34-51): X ~ U[0,1) fp32 uncentred, y ~ N(0,1), Pi = 0 "
-                         "(every marker in the model, estimatePi = false), marker variance fixed; use with --p 100000 / 200000")
     ap.add_argument("--storage", choices=["dense", "packed2bit"], default="dense",
                     help="dense = the metric's fp32 dense genotypes (default); packed2bit = the reference's 2-bit packed "
                          "streaming payload kept packed in HBM (same genotypes, same chain; extra, not the headline config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-markers", type=int, default=4000)
+    ap.add_argument("--cpu-sample-markers", type=int, default=20000)
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target CPU time per thread-count leg")
+    ap.add_argument("--via-api", type=int, default=-1,
+                    help="timed iterations of the runMCMC() leg (config2, 1 GPU; default 20, 0 = skip)")
     return ap.parse_args()
 
 
@@ -74,6 +93,26 @@ _T0 = time.time()
 def log(msg):
     if os.environ.get("JWAS_BENCH_VERBOSE", "0") != "0" and int(os.environ.get("RANK", "0")) == 0:
         print(f"[bench {time.time() - _T0:8.2f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def traffic_from_profiles(workload, n, p, bs, storage, world, pi_fixed):
+    """HBM bytes per k_block_step launch from the PMC summaries committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and
+    --pmc WRITE_SIZE in separate runs of this command; FETCH_SIZE x2 per the guide's gfx950 correction, checked on k_xpx
+    which reads X exactly once).  Only returned when the summaries' recorded configuration matches this run."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(path):
+        return None, None
+    try:
+        with open(path) as fh:
+            rows = json.load(fh)
+    except (OSError, ValueError):
+        return None, None
+    for row in rows:
+        c = row.get("config", {})
+        if (c.get("workload") == workload and c.get("n") == n and c.get("p") == p and c.get("block_size") == bs
+                and c.get("storage") == storage and c.get("n_gpus") == world and c.get("pi_fixed") == pi_fixed):
+            return float(row["bytes_per_launch"]), row.get("source")
+    return None, None
 
 
 def main():
@@ -93,94 +132,154 @@ def main():
             local_rank = 0
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend, rank=rank, world_size=world)
-    if world != a.gpus:
-        if rank == 0:
-            print(f"warning: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if world != a.gpus and rank == 0:
+        print(f"warning: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     import jwas_jl_amd as J
     from jwas_jl_amd.dist import MarkerShard, shard_range
-
     from jwas_jl_amd.mcmc import pick_block_size
-    refbench = a.workload == "refbench"
-    adaptive = a.block_size == 0 and not refbench
-    n, p_total, bs = a.n, a.p, (512 if adaptive else (a.block_size or 128))      # dense prior (refbench): 128-marker blocks
+
+    wl = a.workload
+    n, p_arg, method, t = WORKLOADS[wl]
+    n = a.n or n
+    p_arg = a.p or p_arg
+    weak = wl == "config5shard"
+    p_total = p_arg * world if weak else p_arg
+    refbench = wl == "refbench"
+    bayesc = method == "BayesC"
+    estimate_pi = not refbench and a.pi_fixed is None
+    mt_dense = (t > 1 and a.mt_prior == "default")
+    dense_prior = refbench or mt_dense or (a.pi_fixed is not None and a.pi_fixed < 0.5)
+    # block policy = mcmc.run_chain's: dense priors 128; sparse single-trait priors adaptive 512/1024; multi-trait 512
+    adaptive = a.block_size == 0 and not dense_prior and t == 1
+    bs = a.block_size or (128 if dense_prior else 512)
     lo, hi = shard_range(p_total, rank, world, align=1024 if adaptive else bs)
     p_loc = hi - lo
     eng = J.HipEngine(local_rank)
     t_setup = time.time()
     log('engine created'); (eng.alloc_packed if a.storage == 'packed2bit' else eng.alloc_dense)(n, p_loc); log('alloc done')
+    n_gen = 0
     if refbench:
         eng.synth(a.seed, kind=1, center=False, marker_offset=lo)   # X ~ U[0,1), uncentred (jwas_nonblock_benchmark.jl:38,46)
+    elif weak:
+        n_gen = int(round(n * 80_000 / 280_000))                    # 80k genotyped of 280k phenotyped rows (config 5)
+        eng.synth_single_step(a.seed, n_gen, center=True, marker_offset=lo)
     else:
         eng.synth(a.seed, kind=0, center=True, marker_offset=lo)    # 0/1/2 genotypes, centred, generated on device
     log('synth done'); eng.setup_blocks(bs, "mfma")
     if adaptive:
         eng.add_block_size(1024, "mfma")
     log('setup_blocks done')
-    eng.init_state("BayesC", 1)
+    eng.init_state(method, t)
     shard = MarkerShard(eng, lo, hi, rank, world)
 
-    # ---- simulate y = 1 + X beta + e with ncausal QTL, h2 = 0.5
+    # ---- simulate y_k = 1 + X beta_k + e_k with ncausal QTL, h2 = 0.5
     rng = np.random.default_rng(a.seed)
     ncausal = max(1, p_total // 1000)
     causal = np.sort(rng.choice(p_total, size=ncausal, replace=False))
-    eff = rng.standard_normal(ncausal)
-    a_true = np.zeros(p_loc, dtype=np.float32)
     m = (causal >= lo) & (causal < hi)
-    a_true[causal[m] - lo] = eff[m]
-    eng.set_state(alpha=a_true)
-    g = shard.allreduce_sum(eng.mul_alpha().astype(np.float64)); log('mul_alpha done')
-    g *= np.sqrt(0.5 / g.var())
-    y = (1.0 + g + rng.standard_normal(n) * np.sqrt(0.5)).astype(np.float32)
-    if refbench:
-        y = rng.standard_normal(n).astype(np.float32)                # y1 = randn(Float32, n)  (:35)
-    eng.set_state(alpha=np.zeros(p_loc), beta=np.zeros(p_loc), delta=np.ones(p_loc))
+    Y = np.empty((t, n), dtype=np.float32)
+    for k in range(t):
+        eff = rng.standard_normal(ncausal)
+        a_true = np.zeros(p_loc, dtype=np.float32)
+        a_true[causal[m] - lo] = eff[m]
+        eng.set_state(0, alpha=a_true)
+        g = shard.allreduce_sum(eng.mul_alpha(0).astype(np.float64))
+        g *= np.sqrt(0.5 / g.var())
+        Y[k] = (1.0 + g + rng.standard_normal(n) * np.sqrt(0.5)).astype(np.float32)
+        if refbench:
+            Y[k] = rng.standard_normal(n).astype(np.float32)         # y1 = randn(Float32, n)  (:35)
+    log('phenotypes done')
+    dlt0 = np.ones(p_loc, dtype=np.int32 if method == "BayesR" else np.float32)
+    for k in range(t):
+        eng.set_state(k, alpha=np.zeros(p_loc), beta=np.zeros(p_loc), delta=dlt0)
 
-    # ---- priors (input_data_validation.jl:296-350, tools4genotypes.jl:353-478)
-    df_ = 4.0
-    vary = float(np.var(y.astype(np.float64), ddof=1))
-    vare = np.float32(0.5 * vary)
+    # ---- priors (input_data_validation.jl:296-350, tools4genotypes.jl:353-478, build_MME.jl:128-141)
+    vary = np.array([float(np.var(Y[k].astype(np.float64), ddof=1)) for k in range(t)])
     sum2pq = float(shard.allreduce_sum(np.array([eng.xpx().astype(np.float64).sum()]))[0]) / n   # x'x/n = 2pq (centred)
-    pi = 0.95
-    Gval = np.float32(0.5 * vary / ((1.0 - pi) * sum2pq))
-    if refbench:      # get_genotypes(X, 1.0; ...) and build_model(..., 1.0): genetic variance 1, residual variance 1, Pi = 0
-        xbar2 = 0.25                                                 # alleleFreq = mean/2 of U[0,1) columns (readgenotypes.jl:385)
-        pi, vare = 0.0, np.float32(1.0)
-        Gval = np.float32(1.0 / (p_total * 2.0 * xbar2 * (1.0 - xbar2)))
-    scale_e = float(vare) * (df_ - 2) / df_
-    scale_g = float(Gval) * (df_ - 2) / df_
+    nstates = 1 << t
+    if t == 1:
+        df_e = df_g = 4.0
+        vare = np.float32(0.5 * vary[0])
+        if method == "BayesR":
+            pi = np.array([0.95, 0.03, 0.015, 0.005])
+            Gval = np.float32(0.5 * vary[0] / (sum2pq * float((BAYESR_GAMMA * pi).sum())))
+        else:
+            pi = 0.95 if a.pi_fixed is None else float(a.pi_fixed)
+            Gval = np.float32(0.5 * vary[0] / ((1.0 - pi) * sum2pq))
+        if refbench:      # get_genotypes(X, 1.0; ...) and build_model(..., 1.0): genetic variance 1, residual variance 1, Pi = 0
+            xbar2 = 0.25                                             # alleleFreq = mean/2 of U[0,1) columns (readgenotypes.jl:385)
+            pi, vare = 0.0, np.float32(1.0)
+            Gval = np.float32(1.0 / (p_total * 2.0 * xbar2 * (1.0 - xbar2)))
+        scale_e = float(vare) * (df_e - 2) / df_e
+        scale_g = float(Gval) * (df_g - 2) / df_g
+    else:
+        df_e = df_g = 4.0 + t                                        # build_MME.jl:108-110,131-134
+        vare = np.diag(0.5 * vary).astype(np.float32)
+        pi = np.zeros(nstates)
+        if a.mt_prior == "default":
+            pi[nstates - 1] = 1.0                                    # tools4genotypes.jl:357-373
+        else:
+            pi[0] = 0.95
+            pi[1:] = 0.05 / (nstates - 1)
+        Gval = (np.diag(0.5 * vary) / (sum2pq * pi[nstates - 1])).astype(np.float32)    # :426-438
+        scale_e = np.asarray(vare, dtype=np.float64) * (df_e - t - 1)
+        scale_g = np.asarray(Gval, dtype=np.float64) * (df_g - t - 1)
     setup_s = time.time() - t_setup; log(f'setup done {setup_s:.1f}s')
 
-    state = {"r": y[None, :].copy(), "mu": 0.0, "vare": vare, "G": Gval, "pi": pi, "it": 0, "bs": bs}
-    acc = {"sweep_ms": 0.0, "k_ms": 0.0, "k_n": 0.0, "k_bytes": 0.0, "events": 0.0, "ovh_ms": 0.0, "launches": 0.0, "bytes": 0.0}
+    state = {"r": Y.copy(), "mu": np.zeros(t), "vare": vare, "G": Gval, "pi": pi, "it": 0, "bs": bs}
+    acc = {"sweep_ms": 0.0, "events": 0.0, "launches": 0.0, "bytes": 0.0}
 
     def step():
         s = state
         s["it"] += 1
-        # 1. intercept: single-site Gibbs on the 1x1 MME (solver.jl:143-151)
-        r = s["r"][0].astype(np.float64) + s["mu"]
-        s["mu"] = rng.standard_normal() * np.sqrt(float(s["vare"]) / n) + r.sum() / n
-        r -= s["mu"]
+        # 1. intercepts: single-site Gibbs on the MME (solver.jl:143-162)
+        r = s["r"].astype(np.float64) + s["mu"][:, None]
+        if t == 1:
+            s["mu"][0] = rng.standard_normal() * np.sqrt(float(s["vare"]) / n) + r[0].sum() / n
+        else:
+            Rinv = np.linalg.inv(np.asarray(s["vare"], dtype=np.float64))
+            A, b = n * Rinv, Rinv @ r.sum(axis=1)
+            for k in range(t):
+                il = 1.0 / A[k, k]
+                s["mu"][k] = rng.standard_normal() * np.sqrt(il) + il * (b[k] - A[:, k] @ s["mu"]) + s["mu"][k]
+        r -= s["mu"][:, None]
         # 2. marker sweep on the device (+ shard reconcile)
-        r_new, st = shard.sweep(r.astype(np.float32)[None, :], iteration=s["it"], seed=a.seed,
-                                vare=s["vare"], var_effect=s["G"], pi=s["pi"], nreps=1)
+        kw = dict(iteration=s["it"], seed=a.seed, vare=s["vare"], var_effect=s["G"], nreps=1)
+        if method == "BayesR":
+            kw["pi_classes"] = s["pi"]
+        elif t > 1:
+            with np.errstate(divide="ignore"):
+                kw["log_prior_states"] = np.log(s["pi"])
+        else:
+            kw["pi"] = s["pi"]
+        r_new, st = shard.sweep(r.astype(np.float32), **kw)
         s["r"] = r_new
         if adaptive:       # n_events is the all-shard total after the reconcile: every rank takes the same decision
             eng.select_block_size(pick_block_size(st["n_events"], p_total))
         acc["launches"] += -(-p_loc // s["bs"]) + 1
         acc["bytes"] += 4.0 * n * p_loc if a.storage == "dense" else 0.25 * n * p_loc
         s["bs"] = eng.block_size
-        nl = st["sum_delta"][0]
-        # 3-5. pi, marker-effect variance, residual variance (Pi.jl:7-9, variance_components.jl:60-66,151-162)
-        if not refbench:                                             # refbench: estimatePi = false, estimate_variance = false
-            s["pi"] = float(rng.beta(p_total - nl + 1.0, nl + 1.0))
-            s["G"] = np.float32((np.float32(st["alpha_ss"][0, 0]) + df_ * scale_g) / rng.chisquare(nl + df_))
-        s["vare"] = np.float32((np.float32(st["resid_ss"][0, 0]) + df_ * scale_e) / rng.chisquare(n + df_))
+        # 3-5. pi, marker-effect variance, residual variance (Pi.jl:7-42, variance_components.jl:60-112,151-189)
+        if method == "BayesR":
+            s["pi"] = rng.dirichlet(st["class_counts"] + 1.0)
+            s["G"] = np.float32((st["bayesr_ssq"] + df_g * scale_g) / rng.chisquare(st["bayesr_nnz"] + df_g))
+            s["vare"] = np.float32((np.float32(st["resid_ss"][0, 0]) + df_e * scale_e) / rng.chisquare(n + df_e))
+        elif t > 1:
+            from scipy.stats import invwishart
+            s["pi"] = rng.dirichlet(st["state_counts"] + 1.0)
+            S = scale_g + st["beta_ss"]
+            s["G"] = np.asarray(invwishart.rvs(df=df_g + p_total, scale=(S + S.T) / 2, random_state=rng), dtype=np.float32).reshape(t, t)
+            S = scale_e + st["resid_ss"]
+            s["vare"] = np.asarray(invwishart.rvs(df=df_e + n, scale=(S + S.T) / 2, random_state=rng), dtype=np.float32).reshape(t, t)
+        else:
+            nl = st["sum_delta"][0]
+            if estimate_pi:
+                s["pi"] = float(rng.beta(p_total - nl + 1.0, nl + 1.0))
+            if not refbench:                                         # refbench: estimate_variance = false for the markers
+                s["G"] = np.float32((np.float32(st["alpha_ss"][0, 0]) + df_g * scale_g) / rng.chisquare(nl + df_g))
+            s["vare"] = np.float32((np.float32(st["resid_ss"][0, 0]) + df_e * scale_e) / rng.chisquare(n + df_e))
         acc["sweep_ms"] += st["sweep_ms"]
-        acc["k_ms"] += st["update_kernel_ms"]
-        acc["k_n"] += st["update_kernel_samples"]
-        acc["k_bytes"] += st["update_kernel_bytes"]
         acc["events"] += st["n_events"]
-        acc["ovh_ms"] = st["event_overhead_ms"]
         return st
 
     def barrier():
@@ -220,26 +319,41 @@ def main():
         launches = acc["launches"]                                 # k_block_step launches of the timed sweeps (nblocks + 1 each)
         avg_launch_us = 1e3 * acc["sweep_ms"] / launches
         bytes_per_launch = acc["bytes"] / launches                 # algorithmic: 4 B (2 bits if packed) x n per marker, X read once
-        bs = state["bs"]
+        bs_now = state["bs"]
         achieved = bytes_per_launch / 1e9 / (avg_launch_us * 1e-6)
+        traffic, traffic_src = traffic_from_profiles(wl, n, p_total, bs_now, a.storage, world, a.pi_fixed)
+        if t == 1 and method == "BayesC":
+            in_model = float(last["sum_delta"][0])
+        elif method == "BayesR":
+            in_model = float(last["class_counts"][1:].sum())
+        else:
+            in_model = float(p_total - last["state_counts"][0])
+        desc = {
+            "config2": f"single-trait BayesC, {n} individuals x {p_total} SNPs, " + ("2-bit packed genotypes (decoded to fp32 on the fly)" if a.storage == "packed2bit" else "fp32 dense genotypes") + (", pi0=0.95 estimated" if a.pi_fixed is None else f", pi={a.pi_fixed} fixed (estimatePi=false)"),
+            "config3": f"single-trait BayesR (4-class mixture, gamma 0/.01/.1/1, pi estimated), {n} x {p_total}, fp32 dense genotypes",
+            "config4": f"3-trait BayesC sampler I, {n} x {p_total}, fp32 dense, R and G inverse-Wishart on host, 8-state pi estimated, start: " + ("all-ones state (reference default)" if a.mt_prior == "default" else "0.95 on the null state"),
+            "config5shard": f"single-step shaped BayesC, {n} rows ({n_gen} integer-coded + {n - n_gen} real-valued imputed) x {p_arg} SNPs per GPU ({p_total} in total), fp32 dense",
+            "refbench": f"reference benchmark shape (jwas_nonblock_benchmark.jl): BayesC, {n} x {p_total}, X~U[0,1) fp32 uncentred, y~N(0,1), Pi=0 fixed, marker variance fixed",
+        }[wl]
         out = {
             "metric": "MCMC iters/sec (full marker sweep)", "value": a.steps / elapsed, "unit": "iterations/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": (f"reference benchmark shape (jwas_nonblock_benchmark.jl): BayesC, {n} x {p_total}, X~U[0,1) fp32 uncentred, y~N(0,1), Pi=0 fixed, marker variance fixed"
-                                    if refbench else
-                                    f"single-trait BayesC, {n} individuals x {p_total} SNPs, " + ("2-bit packed genotypes (decoded to fp32 on the fly)" if a.storage == "packed2bit" else "fp32 dense genotypes") + ", pi0=0.95 estimated"),
-                       "storage": a.storage,
-                       "n": n, "p": p_total, "block_size": bs, "block_policy": "adaptive 512/1024" if adaptive else "fixed", "parallelism": f"marker-shard x{world}" if world > 1 else "single GPU",
+            "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": desc, "name": wl, "storage": a.storage,
+                       "n": n, "p": p_total, "block_size": bs_now, "block_policy": "adaptive 512/1024" if adaptive else "fixed",
+                       "parallelism": f"marker-shard x{world}" if world > 1 else "single GPU",
                        "device_sweep_ms": acc["sweep_ms"] / a.steps, "events_per_sweep": acc["events"] / a.steps,
-                       "markers_in_model": float(last["sum_delta"][0]), "setup_s": setup_s,
+                       "markers_in_model": in_model, "setup_s": setup_s,
                        "chain_sweeps_before_timing": nburn + a.warmup},
             "roofline": {"bound": "hbm", "kernel": "k_block_step", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": TRAFFIC_BYTES_PER_LAUNCH if (TRAFFIC_BYTES_PER_LAUNCH and adaptive and bs == 1024 and p_total == P_TOTAL and n == N_IND and world == 1 and a.storage == "dense") else None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "bytes_per_launch": bytes_per_launch, "avg_launch_us": avg_launch_us, "launches_timed": launches},
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(eng, n, p_total, min(a.cpu_sample_markers, p_loc), y, float(vare), float(Gval))
+            out["cpu_baseline"] = cpu_baseline(a, eng, method, t, n, p_total, min(a.cpu_sample_markers, p_loc), Y, state, refbench)
+        nvia = a.via_api if a.via_api >= 0 else (20 if (wl == "config2" and world == 1 and a.pi_fixed is None and a.storage == "dense") else 0)
+        if world == 1 and nvia > 0 and bayesc and t == 1 and not refbench:
+            out["via_api"] = via_api(eng, Y[0], n, p_total, a, nvia)
     eng.close()
     if world > 1:
         torch.distributed.barrier()
@@ -248,37 +362,77 @@ def main():
         print(json.dumps(out))
 
 
-def cpu_baseline(eng, n, p_total, p_sub, y, vare, Gval):
-    """The CPU oracle's non-block BayesC sweep (oracle/jwas_oracle.c: orc_time_bayesc_sweeps -- per marker
-    fp32 dot, scalar update, conditional fp32 axpy: the reference's operation order, BayesABC.jl:60-80) on
-    the first p_sub markers of the same matrix, scaled linearly in p (the reference's own projection
-    device, benchmarks/streaming_large_benchmark.jl:161-184).  Timed single-threaded and with the
-    dot/axpy rows split over a few threads (what a threaded BLAS does per marker; more threads than ~8
-    only add fork/join cost on 50k-element vectors); the faster one is reported with its thread count."""
+def via_api(eng, y, n, p, a, nsteps):
+    """The same workload through the package's user API: device_genotypes() (the matrix already resident on the GPU, like
+    the reference's stream_backend handle on Genotypes) -> build_model -> runMCMC; iterations/s over the last `nsteps`
+    iterations from the per-iteration timestamps runMCMC records (every iteration ends with a stream synchronisation)."""
+    import shutil
+    import tempfile
+    import pandas as pd
+    import jwas_jl_amd as J
+    warm = 30
+    geno = J.device_genotypes(eng, method="BayesC", Pi=0.95 if a.pi_fixed is None else a.pi_fixed, estimatePi=a.pi_fixed is None)
+    model = J.build_model("y = intercept + geno", genotypes={"geno": geno})
+    ph = pd.DataFrame({"ID": geno.obsID, "y": y})
+    folder = tempfile.mkdtemp(prefix="jwas_bench_")
+    try:
+        out = J.runMCMC(model, ph, chain_length=warm + nsteps, burnin=warm, seed=a.seed, outputEBV=False,
+                        output_samples_frequency=warm + nsteps + 1, output_folder=os.path.join(folder, "results"), printout_model_info=False)
+    finally:
+        shutil.rmtree(folder, ignore_errors=True)
+    ts = out["_timing"]["iteration_end_s"]
+    el = ts[-1] - ts[-1 - nsteps]
+    return {"value": nsteps / el, "unit": "iterations/s", "steps": nsteps, "warmup": warm, "ms_per_step": 1e3 * el / nsteps,
+            "what": "runMCMC(model, df; chain_length, burnin, seed) on the resident matrix: location-parameter Gibbs step, sweep, pi / "
+                    "variance draws and running means as the API does them"}
+
+
+def cpu_baseline(a, eng, method, t, n, p_total, p_sub, Y, state, refbench):
+    """The CPU oracle's NON-BLOCK sweep of the same sampler (oracle/jwas_oracle.c: orc_time_sweeps_team -- per marker fp32
+    dot, scalar update, conditional fp32 axpy: the reference's operation order, BayesABC.jl:60-80 / BayesR.jl:45-97 /
+    MTBayesABC.jl:57-127) on the first p_sub markers of the same matrix, >= 2 sweeps, scaled linearly in p (the reference's
+    own projection device, benchmarks/streaming_large_benchmark.jl:161-184).  Timed with 1 thread, a 16-thread team and all
+    logical cores (rows of every dot / axpy split over a persistent team, one spin barrier per marker -- the best a threaded
+    level-1 BLAS can do); the fastest is reported with its thread count."""
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
     X = eng.get_columns(0, p_sub)
     xpx = O.xpx(X, O.ACC_F32)
     ncores = os.cpu_count() or 1
+    kind = {"BayesC": 0, "BayesR": 1, "MTBayesC": 2}[method]
+    vare = np.atleast_2d(np.asarray(state["vare"], dtype=np.float32))
+    G = np.atleast_2d(np.asarray(state["G"], dtype=np.float32))
+    if method == "BayesR":
+        prior = np.asarray(state["pi"], dtype=np.float64)
+    elif t > 1:
+        with np.errstate(divide="ignore"):
+            prior = np.log(np.asarray(state["pi"], dtype=np.float64))
+    else:
+        prior = np.array([0.0 if refbench else 0.95])
+    R0 = np.ascontiguousarray(Y - Y.mean(axis=1, keepdims=True), dtype=np.float32)
+
+    def run(threads, sweeps, pc):
+        al = np.zeros((t, pc), dtype=np.float32)
+        be = np.zeros((t, pc), dtype=np.float32)
+        de = np.ones((t, pc), dtype=np.int32 if method == "BayesR" else np.float32)
+        Xc = X if pc == p_sub else np.asfortranarray(X[:, :pc])
+        return O.time_sweeps_team(kind, Xc, xpx[:pc].copy(), R0.copy(), al, be, de, vare, G, prior, a.seed, sweeps, threads)
+
     res = {}
-    for threads in sorted({1, min(ncores, 8)}):
-        r = (y - y.mean()).astype(np.float32)
-        al = np.zeros(p_sub, dtype=np.float32)
-        be = np.zeros(p_sub, dtype=np.float32)
-        de = np.zeros(p_sub, dtype=np.float32)
-        # one calibration sweep on a tenth of the sample, then ~6 s of timed work
-        pc = max(200, p_sub // 10)
-        t1 = O.time_bayesc_sweeps(np.asfortranarray(X[:, :pc]), xpx[:pc].copy(), r.copy(), al[:pc].copy(), be[:pc].copy(),
-                                  de[:pc].copy(), vare, Gval, 0.95, 1, 1, threads) * (p_sub / pc)
-        sweeps = int(max(1, min(10, round(6.0 / max(t1, 1e-3)))))
-        tt = O.time_bayesc_sweeps(X, xpx, r, al, be, de, vare, Gval, 0.95, 1, sweeps, threads)
+    for threads in sorted({1, min(ncores, 16), ncores}):
+        pc = max(200, p_sub // 20)
+        t1 = run(threads, 1, pc) * (p_sub / pc)                      # calibration on a twentieth of the sample
+        sweeps = int(max(2, min(20, round(a.cpu_seconds / max(t1, 1e-3)))))
+        tt = run(threads, sweeps, p_sub)
         res[threads] = (tt / sweeps, sweeps)
-        log(f"cpu baseline {threads} thread(s): {tt / sweeps:.3f} s per {p_sub}-marker sweep")
+        log(f"cpu baseline {threads} thread(s): {tt / sweeps:.3f} s per {p_sub}-marker sweep ({sweeps} sweeps)")
     best = min(res, key=lambda k: res[k][0])
     per_sweep_full = res[best][0] * p_total / p_sub
-    detail = "; ".join(f"{k} thread(s): {v[0] * p_total / p_sub:.1f} s/sweep" for k, v in sorted(res.items()))
+    detail = "; ".join(f"{k} thread(s): {v[0] * p_total / p_sub:.2f} s/sweep ({v[1]} sweeps)" for k, v in sorted(res.items()))
     return {"value": 1.0 / per_sweep_full, "unit": "iterations/s", "cores": best, "kind": "port",
-            "sample": (f"{res[best][1]} sweeps over the first {p_sub} of {p_total} markers (n={n}), scaled linearly in p; "
+            "sample": (f"non-block {method} sweeps over the first {p_sub} of {p_total} markers (n={n}), scaled linearly in p; "
                        f"{detail}; host has {ncores} logical cores; sweep only, host updates excluded")}
 
 

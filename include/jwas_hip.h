@@ -171,6 +171,10 @@ int64_t jwas_hip_estimate_bytes_storage(int64_t n, int64_t p, int32_t ntraits, i
  * marker_offset = global index of column 0, so marker shards of one matrix can be generated
  * independently on different GPUs. */
 int  jwas_hip_synth_genotypes(jwas_hip_ctx* ctx, uint64_t seed, int32_t kind, int32_t center, int64_t marker_offset);
+/* Single-step shaped input (the dense real-valued matrix impute_genotypes hands to the sweep, single_step/SSBR.jl:83-142):
+ * rows [0, n_genotyped) are 0/1/2 genotypes as above, rows [n_genotyped, n) are "imputed" -- the average of two
+ * genotyped rows drawn per ROW (the same linear map for every marker, as A_ng A_gg^-1 M_g is).  Dense storage only. */
+int  jwas_hip_synth_single_step(jwas_hip_ctx* ctx, uint64_t seed, int64_t n_genotyped, int32_t center, int64_t marker_offset);
 
 /* Residual weights R^-1 (n floats; NULL = unit weights): mme.invweights = 1 ./ df.weights (build_MME.jl:305-310).
  * With non-unit weights x'x becomes x'R^-1 x (getXpRinvX, tools4genotypes.jl:28-31), the Grams X_b'R^-1 X_b (:263-266),

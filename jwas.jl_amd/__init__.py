@@ -12,7 +12,7 @@ __all__ = ["HipEngine", "JwasHipError", "BAYESR_GAMMA", "LIB_PATH"]
 
 def __getattr__(name):
     # host-side API (imports pandas etc.) is loaded lazily
-    if name in ("get_genotypes", "build_model", "runMCMC", "Genotypes", "Model", "set_covariate", "outputEBV", "outputMCMCsamples"):
+    if name in ("get_genotypes", "build_model", "runMCMC", "Genotypes", "Model", "set_covariate", "outputEBV", "outputMCMCsamples", "device_genotypes"):
         from . import api
         return getattr(api, name)
     if name == "GWAS":

@@ -29,7 +29,7 @@ SYMBOLS = [
     "jwas_hip_accumulate", "jwas_hip_get_posterior",
     "jwas_hip_load_jgb2", "jwas_hip_load_packed2bit", "jwas_hip_alloc_packed2bit", "jwas_hip_storage_info",
     "jwas_hip_set_xpx", "jwas_hip_estimate_bytes_storage", "jwas_hip_add_block_size", "jwas_hip_select_block_size",
-    "jwas_hip_set_weights",
+    "jwas_hip_set_weights", "jwas_hip_synth_single_step",
 ]
 STORAGE_DENSE_F32, STORAGE_PACKED2BIT = 0, 1
 
@@ -102,6 +102,7 @@ def load():
     L.jwas_hip_estimate_bytes.argtypes = [i64, i64, i32, i32]
     L.jwas_hip_estimate_bytes.restype = i64
     L.jwas_hip_synth_genotypes.argtypes = [vp, u64, i32, i32, i64]
+    L.jwas_hip_synth_single_step.argtypes = [vp, u64, i64, i32, i64]
     L.jwas_hip_setup_blocks.argtypes = [vp, i32, i32]
     L.jwas_hip_get_xpx.argtypes = [vp, vp]
     L.jwas_hip_get_gram.argtypes = [vp, i64, vp]
@@ -137,7 +138,7 @@ def load():
     L.jwas_hip_estimate_bytes_storage.restype = i64
     for name in SYMBOLS:
         fn = getattr(L, name)
-        if name not in ("jwas_hip_destroy", "jwas_hip_last_error", "jwas_hip_estimate_bytes"):
+        if name not in ("jwas_hip_destroy", "jwas_hip_last_error", "jwas_hip_estimate_bytes", "jwas_hip_estimate_bytes_storage"):
             fn.restype = C.c_int
     _lib = L
     return L

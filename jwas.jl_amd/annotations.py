@@ -193,6 +193,8 @@ def bayesc_mt_start_row(pi):
     if np.isscalar(pi) and pi == 0.0:
         row = np.array([0.0, 0.0, 0.0, 1.0])
     else:
+        if np.isscalar(pi):
+            raise ValueError("Annotated multi-trait BayesC requires Pi=0.0 or a joint Pi dictionary.")   # annotation_setup.jl:118
         row = np.asarray(pi, dtype=np.float64).reshape(-1)
         if row.size != 4:
             raise ValueError("Annotated multi-trait BayesC v1 expects four joint prior probabilities.")

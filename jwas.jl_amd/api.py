@@ -200,6 +200,38 @@ def get_genotypes(file, G=False, *, method="BayesC", Pi=0.0, estimatePi=True,
     return g
 
 
+def device_genotypes(engine, G=False, *, method="BayesC", Pi=0.0, estimatePi=True, G_is_marker_variance=False, df=4.0,
+                     estimate_variance=True, estimate_scale=False, constraint=False, multi_trait_sampler="I",
+                     obsID=None, markerID=None, centered=True):
+    """A Genotypes object over a matrix that is ALREADY resident on the GPU (loaded or generated through `engine`, a
+    HipEngine) -- the device analogue of storage=:stream, where Genotypes carries a backend handle instead of the matrix
+    (types.jl:149-150, readgenotypes.jl:236-295).  Like that mode: phenotype IDs must match the genotype IDs exactly and
+    in order, Float32 only.  sum2pq is taken from the device's x'x (x'x / n = 2pq for centred 0/1/2 genotypes); block
+    configurations already resident on the engine are used as they are."""
+    if method not in SUPPORTED_METHODS:
+        raise NotImplementedError(f"method {method} is not on the device path (supported: {SUPPORTED_METHODS})")
+    if multi_trait_sampler not in ("auto", "I", "II"):
+        raise ValueError("multi_trait_sampler must be one of :auto, :I, or :II.")
+    n, p = int(engine.n), int(engine.p)
+    if n <= 0 or p <= 0:
+        raise ValueError("the engine holds no genotype matrix")
+    if engine.block_size == 0:
+        engine.setup_blocks(512 if p > 512 else 64, "mfma")
+    xpx = engine.xpx().astype(np.float64)
+    sum2pq = float(xpx.sum() / n)
+    # allele frequency from 2pq = x'x / n (the smaller root); only marker-level-pi priors read it
+    af = (0.5 * (1.0 - np.sqrt(np.clip(1.0 - 2.0 * xpx / n, 0.0, 1.0)))).astype(np.float32)
+    g = Genotypes(obsID if obsID is not None else [str(i + 1) for i in range(n)],
+                  markerID if markerID is not None else [str(j + 1) for j in range(p)], n, p, af, sum2pq, centered,
+                  np.zeros((n, 0), dtype=np.float32))
+    g.storage_mode, g.device_backend = "device", engine
+    g.G = Variance(G if G_is_marker_variance else False, df, False, estimate_variance, estimate_scale, constraint)
+    g.genetic_variance = Variance(False if G_is_marker_variance else G, df, False, estimate_variance, estimate_scale, constraint)
+    g.method, g.estimatePi, g.pi = method, estimatePi, Pi
+    g.multi_trait_sampler = multi_trait_sampler
+    return g
+
+
 class ModelTerm:
     def __init__(self, trait, name):
         self.trait, self.name = trait, name

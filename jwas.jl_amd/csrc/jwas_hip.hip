@@ -543,7 +543,21 @@ int jwas_hip_synth_genotypes(jwas_hip_ctx* c, uint64_t seed, int32_t kind, int32
                            (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)marker_offset);
     } else
     hipLaunchKernelGGL(k_synth, dim3((unsigned)c->p), dim3(256), 0, c->stream, c->X, c->n, c->ld,
-                       (uint32_t)seed, (uint32_t)(seed >> 32), (int)kind, (int)center, (uint32_t)marker_offset);
+                       (uint32_t)seed, (uint32_t)(seed >> 32), (int)kind, (int)center, (uint32_t)marker_offset, (int64_t)0);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return JWAS_HIP_OK;
+}
+
+int jwas_hip_synth_single_step(jwas_hip_ctx* c, uint64_t seed, int64_t n_genotyped, int32_t center, int64_t marker_offset)
+{
+    NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
+    NEED(c, c->X != nullptr, JWAS_HIP_ESTATE, "allocate a dense matrix first (jwas_hip_alloc_dense_f32): imputed genotypes are real-valued");
+    NEED(c, n_genotyped >= 1 && n_genotyped <= c->n, JWAS_HIP_EINVAL, "n_genotyped must lie in [1, n] (got %lld)", (long long)n_genotyped);
+    NEED(c, marker_offset >= 0 && marker_offset + c->p < (1ll << 32), JWAS_HIP_EINVAL, "marker_offset out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_synth, dim3((unsigned)c->p), dim3(256), 0, c->stream, c->X, c->n, c->ld,
+                       (uint32_t)seed, (uint32_t)(seed >> 32), 2, (int)center, (uint32_t)marker_offset, n_genotyped);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return JWAS_HIP_OK;
@@ -1018,7 +1032,12 @@ static hipError_t launch_step_cx(jwas_hip_ctx* c, const CX& cx, const UpdateArgs
         attr_set = true;
     }
     // JWAS_HIP_DEBUG_ROLE (timing experiments only; results are wrong): 1 = update role only, 2 = sampler only
+    // Development builds only (build.sh -DJWAS_HIP_DEV_KNOBS): the shipped library never reads these -- they break results.
+#ifdef JWAS_HIP_DEV_KNOBS
     static const int dbg = std::getenv("JWAS_HIP_DEBUG_ROLE") ? std::atoi(std::getenv("JWAS_HIP_DEBUG_ROLE")) : 0;
+#else
+    constexpr int dbg = 0;
+#endif
     const int nwork = c->nrg * U.ncg;
     const unsigned grid = (dbg == 2) ? 1u : (U.quiet_xcd ? (unsigned)(1 + (nwork + 6) / 7 * 8) : (unsigned)(1 + nwork));
     hipLaunchKernelGGL((k_block_step<METHOD, NT, CX>), dim3(grid), dim3(kStepThreads), SM.bytes, c->stream,
@@ -1288,7 +1307,11 @@ int jwas_hip_sweep(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_sweep_stats
             static const int qx = std::getenv("JWAS_HIP_QUIET_XCD") ? std::atoi(std::getenv("JWAS_HIP_QUIET_XCD")) : -1;
             U.quiet_xcd = qx >= 0 ? qx : (c->last_events < 0 || c->last_events > 0.0125 * (double)c->p ? 1 : 0);
         }
+#ifdef JWAS_HIP_DEV_KNOBS
         { static const int thr = std::getenv("JWAS_HIP_DEBUG_THROTTLE") ? std::atoi(std::getenv("JWAS_HIP_DEBUG_THROTTLE")) : 0; U.dbg_throttle = thr; }
+#else
+        U.dbg_throttle = 0;
+#endif
         SamplerArgs S;
         std::memset(&S, 0, sizeof S);
         const int64_t sb = k - 1;

@@ -945,8 +945,11 @@ __global__ __launch_bounds__(256) void k_sub_xalpha(CX cx, int64_t p,
 // ---------------------------------------------------------------------------------------------
 // synthetic genotypes (bench / tests).  grid = p, block = 256.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_synth(float* __restrict__ X, int64_t n, int64_t ld, uint32_t seed_lo,
-                                               uint32_t seed_hi, int kind, int center, uint32_t marker0)
+// kind 2 = single-step shaped input (the dense real-valued matrix impute_genotypes hands to the sweep, SSBR.jl:83-142):
+// rows < n_int are 0/1/2 genotypes, rows >= n_int are "imputed": the average of two genotyped rows (a, b) drawn per
+// ROW (the same linear map for every marker, as A_ng A_gg^-1 M_g is).
+__global__ __launch_bounds__(256) void k_synth(float* X, int64_t n, int64_t ld, uint32_t seed_lo,
+                                               uint32_t seed_hi, int kind, int center, uint32_t marker0, int64_t n_int = 0)
 {
     __shared__ double red[4];
     const uint32_t j = marker0 + blockIdx.x;          // global marker index keys the generator
@@ -954,9 +957,10 @@ __global__ __launch_bounds__(256) void k_synth(float* __restrict__ X, int64_t n,
     const u32x4 wf = philox4x32_10(j, 0xFFFFFFFFu, 0u, 0u, seed_lo, seed_hi);
     const float f = 0.1f + 0.3f * ((float)(wf.x >> 8) * 0x1.0p-24f);          // U(0.1, 0.4)
     double v[1] = {0.0};
+    const int64_t n_code = (kind == 2) ? n_int : n;                             // rows holding generated values
     for (int64_t i = threadIdx.x; i < ld; i += 256) {
         float val = 0.f;
-        if (i < n) {
+        if (i < n_code) {
             const u32x4 w = philox4x32_10(j, (uint32_t)i, 1u, 0u, seed_lo, seed_hi);
             if (kind == 1) val = (float)(w.x >> 8) * 0x1.0p-24f;                // U[0,1)
             else {
@@ -966,6 +970,16 @@ __global__ __launch_bounds__(256) void k_synth(float* __restrict__ X, int64_t n,
             v[0] += (double)val;
         }
         x[i] = val;
+    }
+    if (kind == 2) {
+        __syncthreads();                                                        // the genotyped rows of this column are written
+        for (int64_t i = n_int + threadIdx.x; i < n; i += 256) {
+            const u32x4 w = philox4x32_10(0xFFFFFFFEu, (uint32_t)i, 2u, 0u, seed_lo, seed_hi);   // keyed by the row only
+            const int64_t a = (int64_t)(((uint64_t)w.x * (uint64_t)n_int) >> 32), b = (int64_t)(((uint64_t)w.y * (uint64_t)n_int) >> 32);
+            const float val = 0.5f * (x[a] + x[b]);
+            v[0] += (double)val;
+            x[i] = val;
+        }
     }
     if (!center) return;
     block_sum<1>(v, red, 4);

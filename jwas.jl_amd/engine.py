@@ -146,6 +146,10 @@ class HipEngine:
     def synth(self, seed, kind=0, center=True, marker_offset=0):
         self._chk(self._L.jwas_hip_synth_genotypes(self._h, int(seed), int(kind), int(bool(center)), int(marker_offset)))
 
+    def synth_single_step(self, seed, n_genotyped, center=True, marker_offset=0):
+        """Config-5 shaped input: rows < n_genotyped are 0/1/2 genotypes, the rest real-valued 'imputed' rows."""
+        self._chk(self._L.jwas_hip_synth_single_step(self._h, int(seed), int(n_genotyped), int(bool(center)), int(marker_offset)))
+
     def layout(self):
         n, p, ld, ptr = C.c_int64(), C.c_int64(), C.c_int64(), C.c_void_p()
         self._chk(self._L.jwas_hip_dense_layout(self._h, C.byref(n), C.byref(p), C.byref(ld), C.byref(ptr)))
@@ -161,11 +165,17 @@ class HipEngine:
         mode = {"f64": _lib.GRAM_F64, "mfma": _lib.GRAM_MFMA}[gram_mode]
         self._chk(self._L.jwas_hip_setup_blocks(self._h, int(block_size), mode))
         self.block_size = int(block_size)
+        self._resident = [int(block_size)]
 
     def add_block_size(self, block_size, gram_mode="mfma"):
         """Make a second block size resident (see jwas_hip_add_block_size); select_block_size switches between sweeps."""
         mode = {"f64": _lib.GRAM_F64, "mfma": _lib.GRAM_MFMA}[gram_mode]
         self._chk(self._L.jwas_hip_add_block_size(self._h, int(block_size), mode))
+        self._resident.append(int(block_size))
+
+    def resident_block_sizes(self):
+        """Block sizes whose Grams are resident (setup_blocks / add_block_size)."""
+        return list(getattr(self, "_resident", [])) if self.block_size else []
 
     def select_block_size(self, block_size):
         self._chk(self._L.jwas_hip_select_block_size(self._h, int(block_size)))

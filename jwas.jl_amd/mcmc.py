@@ -185,7 +185,17 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
     else:
         usable = complete
     stream = getattr(Mi, "storage_mode", "dense") == "stream"
-    if stream:
+    devres = getattr(Mi, "storage_mode", "dense") == "device"          # matrix already resident on the GPU (api.device_genotypes)
+    if devres:
+        if not complete.all() or list(ph[idcol]) != list(Mi.obsID):
+            raise ValueError("device-resident genotypes require exact genotype/phenotype ID match and order "
+                             "(as storage=:stream does, JWAS.jl:388-398).")
+        if engine is not None and engine is not Mi.device_backend:
+            raise ValueError("the genotypes are resident on a different engine")
+        engine = Mi.device_backend
+        X = None
+        n, p = Mi.nObs, Mi.nMarkers
+    elif stream:
         # the packed payload goes from the file straight to HBM and is never re-ordered: like the reference's stream
         # mode, phenotype IDs must match the genotype IDs exactly and in order (JWAS.jl:388-398)
         if not complete.all() or list(ph[idcol]) != list(Mi.obsID):
@@ -216,12 +226,12 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         out_ids = want
         out_same = out_ids == list(ph[idcol])             # exactly the training rows, same order: X itself
         if not out_same:
-            if stream:
+            if stream or devres:
                 raise NotImplementedError("storage=:stream reports EBVs for the genotyped individuals in file order "
                                           "(outputEBV(model, IDs) lists stay on the reference)")
             gi = {g: i for i, g in enumerate(Mi.obsID)}
             out_rows = np.array([gi[i] for i in out_ids], dtype=np.int64)
-    if not stream:
+    if not stream and not devres:
         # rows of Mi.genotypes behind Mi.output_genotypes (tools4genotypes.jl:290-296); GWAS() reads them (GWAS.jl:148)
         Mi.output_rows = out_rows if (outputEBV and not out_same) else rows
     with open(os.path.join(output_folder, "IDs_for_individuals_with_phenotypes.txt"), "w") as fh:
@@ -266,6 +276,11 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         if abs(tab.sum() - 1.0) > 1e-6:
             raise ValueError("Summation of probabilities of Pi is not equal to one.")       # input_data_validation.jl
         pi = tab
+    if (t > 1 and getattr(Mi, "annotations", False) is not False and np.ndim(pi) == 1 and len(pi) == Mi.nMarkers
+            and len(pi) != (1 << t) and np.all(np.asarray(pi) == np.asarray(pi)[0])):
+        # get_genotypes expanded a scalar Pi to one value per marker for annotated BayesC before the number of traits was
+        # known (readgenotypes.jl:111-150); the multi-trait set-up reads the scalar (annotation_setup.jl:106-118)
+        pi = float(np.asarray(pi)[0])
     if t > 1 and (np.isscalar(pi) and pi == 0.0):                      # tools4genotypes.jl:357-373
         pi = np.zeros(1 << t)
         pi[(1 << t) - 1] = 1.0
@@ -294,9 +309,14 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         # the device's BayesC update with pi = 0 (every marker included) is RR-BLUP's full conditional (api.SUPPORTED_METHODS)
         method, Mi.estimatePi = "BayesC", False
         pi = 0.0 if t == 1 else np.eye(1, 1 << t, (1 << t) - 1).ravel()
+    if t == 2 and getattr(Mi, "annotations", False) is not False and not mega:
+        # start-row validation of the annotated 2-trait model comes first (finalize_marker_annotation_setup!,
+        # annotation_setup.jl:101-121, runs at build_model time in the reference)
+        from . import annotations as A_
+        A_.bayesc_mt_start_row(0.0 if getattr(Mi, "_pi_was_default", False) else pi)
     if Mi.G.val is False:
         Mi.G.val = genetic2marker(Mi, pi, method, t)
-        if (t == 1 and not Mi.G.val > 0) or (t > 1 and np.any(np.linalg.eigvalsh(Mi.G.val) <= 0)):
+        if (t == 1 and not Mi.G.val > 0) or (t > 1 and (not np.all(np.isfinite(Mi.G.val)) or np.any(np.linalg.eigvalsh(Mi.G.val) <= 0))):
             raise ValueError("Marker effects variance is negative!" if t == 1 else
                              "Marker effects covariance matrix is not postive definite! Please modify the argument: Pi.")
     ann = getattr(Mi, "annotations", False)
@@ -423,7 +443,9 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
                 engine.close()
                 raise MemoryError(msg)
             print("WARNING: " + msg)
-    if stream:
+    if devres:
+        pass                                   # already resident
+    elif stream:
         engine.load_jgb2(Mi.stream_backend["prefix"])          # payload stays 2-bit packed in HBM
     else:
         engine.load_dense(X)                   # after alignment (tools4genotypes.jl:310-321)
@@ -431,9 +453,17 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         engine.load_output_dense(np.asfortranarray(Mi.genotypes[out_rows, :]))
     if invw is not None:
         engine.set_weights(invw)               # x'R^-1 x, X_b'R^-1 X_b, X_b'R^-1 r on the device (GibbsMats with Rinv)
-    engine.setup_blocks(block_size, gram_mode)
-    if adaptive:
-        engine.add_block_size(1024, gram_mode)
+    if devres and invw is None and engine.block_size:
+        resident = set(engine.resident_block_sizes())
+        if block_size not in resident:
+            engine.add_block_size(block_size, gram_mode)
+        if adaptive and 1024 not in resident:
+            engine.add_block_size(1024, gram_mode)
+        engine.select_block_size(block_size)
+    else:
+        engine.setup_blocks(block_size, gram_mode)
+        if adaptive:
+            engine.add_block_size(1024, gram_mode)
     engine.init_state(mt_method if t > 1 else method, t)
 
     # ---- fixed effects
@@ -509,6 +539,7 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
             _open(f"marker_effects_{name}_{tr}", Mi.markerID)
 
     t_sweep = 0.0
+    iter_end = []                                # perf_counter at the end of every iteration (each ends synchronised with the device)
     t0 = time.time()
     # ================================ the chain =================================================
     for it in range(1, chain_length + 1):
@@ -525,11 +556,13 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
                 R0 = np.asarray(vare, dtype=np.float64)
                 Rinv = np.linalg.inv(R0)
                 res = [engine.get_residual(k).astype(np.float64) for k in range(t)]
-                if has_missing:
-                    # residuals of the missing records are imputed from the observed ones (sampleMissingResiduals,
-                    # residual.jl:52-73) and the location-parameter equations weight every record with the inverse
-                    # of the OBSERVED block of R only (mkRi / getRi, residual.jl:2-44)
-                    Ri_rows = _impute_missing_residuals(res, observed, R0, rng)
+                Ri_rows = _impute_missing_residuals(res, observed, R0, rng) if has_missing else None
+                if has_missing and (it == 1 or not R.estimate_variance):
+                    # Residuals of the missing records are imputed from the observed ones every iteration
+                    # (sampleMissingResiduals, residual.jl:52-73).  The location-parameter equations weight every record
+                    # with the inverse of the OBSERVED block of R only (mkRi / getRi, residual.jl:2-44) -- but only until
+                    # the first residual-variance draw: the reference then replaces Ri by kron(inv(R), diag(invweights))
+                    # (MCMC_BayesianAlphabet.jl:357-361) and runs plain data augmentation on the imputed residuals.
                     if invw is not None:
                         Ri_rows = Ri_rows * w64[:, None, None]
                     rr = [res[k] + Xf[k] @ sol[off[k]:off[k + 1]] for k in range(t)]
@@ -673,6 +706,7 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
                     gv_samples.append(gv.ravel()); h2_samples.append(h2)
                     files["genetic_variance"].write(",".join(repr(float(v)) for v in gv.ravel()) + "\n")
                     files["heritability"].write(",".join(repr(float(v)) for v in h2) + "\n")
+        iter_end.append(time.perf_counter())
         if it % printout_frequency == 0 and it > burnin:
             print(f"\nPosterior means at iteration: {it}")
             print(f"Residual variance: {np.round(run_vare.mean, 6)}")
@@ -726,7 +760,7 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
     for key, tab in out.items():                                         # JWAS.jl:480-482
         tab.to_csv(os.path.join(output_folder, key.replace(" ", "_") + ".txt"), index=False)
     out["_timing"] = {"wall_s": wall, "device_sweep_ms_total": t_sweep, "iterations": chain_length,
-                      "block_size": block_size, "n": n, "p": p}
-    if own_engine:
+                      "block_size": block_size, "n": n, "p": p, "iteration_end_s": iter_end}
+    if own_engine and not devres:
         engine.close()
     return out

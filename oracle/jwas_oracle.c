@@ -1029,3 +1029,108 @@ double orc_time_bayesc_sweeps(const float* X, int64_t n, int64_t p, int64_t ld, 
     clock_gettime(CLOCK_MONOTONIC, &t1);
     return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* CPU baseline timing with a PERSISTENT thread team (bench.py cpu_baseline leg).               */
+/* The reference's non-block per-marker order (fp32 dot, scalar update, conditional fp32 axpy:  */
+/* BayesABC.jl:73-79, BayesR.jl:56-96, MTBayesABC.jl:80-121) with the rows of the dot / axpy    */
+/* split over `nthreads` threads that live for the whole run and meet at ONE spin barrier per   */
+/* marker -- what a well-threaded level-1 BLAS can do at best (a fork/join per dot, as in       */
+/* orc_time_bayesc_sweeps, costs more than the 50k-element dot itself beyond ~8 threads).        */
+/* kind: 0 = BayesC, 1 = BayesR, 2 = multi-trait sampler I.                                      */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct { volatile int count; volatile int sense; char pad[56]; } team_barrier;
+
+static inline void team_wait(team_barrier* b, int nthreads, int* local_sense)
+{
+    const int s = !*local_sense;
+    *local_sense = s;
+    if (__atomic_add_fetch(&b->count, 1, __ATOMIC_ACQ_REL) == nthreads) {
+        b->count = 0;
+        __atomic_store_n(&b->sense, s, __ATOMIC_RELEASE);
+    } else {
+        while (__atomic_load_n(&b->sense, __ATOMIC_ACQUIRE) != s) __builtin_ia32_pause();
+    }
+}
+
+static inline float dot8_f32(const float* a, const float* b, int64_t n)
+{
+    float q[8] = {0};
+    int64_t i = 0;
+    for (; i + 8 <= n; i += 8)
+        for (int u = 0; u < 8; ++u) q[u] += a[i + u] * b[i + u];
+    for (; i < n; ++i) q[0] += a[i] * b[i];
+    float s = 0.0f;
+    for (int u = 0; u < 8; ++u) s += q[u];
+    return s;
+}
+
+double orc_time_sweeps_team(int kind, const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
+                            int t, float* r, int64_t ld_r, float* alpha, float* beta, void* delta,
+                            const float* vare, const float* var_effect, const double* prior, const double* gamma,
+                            uint64_t seed, int sweeps, int nthreads)
+{
+    if (nthreads < 1) nthreads = 1;
+    if (kind < 0 || kind > 2 || t < 1 || t > ORC_MAXT || (kind != 2 && t != 1)) return -1.0;
+    float Rinv[ORC_MAXT * ORC_MAXT] = {0}, Ginv[ORC_MAXT * ORC_MAXT] = {0};
+    if (kind == 2 && (inv_small(vare, t, Rinv) || inv_small(var_effect, t, Ginv))) return -1.0;
+    const float ie = 1.0f / vare[0];
+    float* partial = (float*)aligned_alloc(64, (size_t)2 * nthreads * 16 * sizeof(float));   /* [2][T][16]: one line per thread */
+    team_barrier bar; bar.count = 0; bar.sense = 0;
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nthreads)
+#endif
+    {
+#ifdef _OPENMP
+        const int tid = omp_get_thread_num(), T = omp_get_num_threads();
+#else
+        const int tid = 0, T = 1;
+#endif
+        int sense = 0;
+        const int64_t chunk = ((n + T - 1) / T + 15) / 16 * 16;
+        const int64_t lo = chunk * tid < n ? chunk * tid : n, hi = lo + chunk < n ? lo + chunk : n;
+        int64_t pend_j = -1;                                   /* thread 0: state of the previous marker, written one barrier late */
+        float pa[ORC_MAXT], pb[ORC_MAXT], pd[ORC_MAXT]; int32_t pcls = 0;
+        int64_t step = 0;
+        for (int it = 0; it < sweeps; ++it)
+            for (int64_t j = 0; j < p; ++j, ++step) {
+                const float* x = X + j * ld;
+                float* mine = partial + ((size_t)(step & 1) * T + tid) * 16;
+                for (int k = 0; k < t; ++k) mine[k] = dot8_f32(x + lo, r + k * ld_r + lo, hi - lo);
+                team_wait(&bar, T, &sense);
+                if (tid == 0 && pend_j >= 0) {                 /* every thread has finished reading the state of marker pend_j */
+                    for (int k = 0; k < t; ++k) { alpha[k * p + pend_j] = pa[k]; if (kind != 1) { beta[k * p + pend_j] = pb[k]; ((float*)delta)[k * p + pend_j] = pd[k]; } }
+                    if (kind == 1) ((int32_t*)delta)[pend_j] = pcls;
+                }
+                float s[ORC_MAXT], a[ORC_MAXT];
+                const float* all = partial + (size_t)(step & 1) * T * 16;
+                for (int k = 0; k < t; ++k) { float v = 0.0f; for (int q = 0; q < T; ++q) v += all[q * 16 + k]; s[k] = v; }
+                float la[ORC_MAXT], lb[ORC_MAXT], ldl[ORC_MAXT]; int32_t lcls = 0;
+                for (int k = 0; k < t; ++k) { la[k] = alpha[k * p + j]; if (kind != 1) { lb[k] = beta[k * p + j]; ldl[k] = ((float*)delta)[k * p + j]; } }
+                const uint32_t m = (uint32_t)j, iter = (uint32_t)it + 1u;
+                if (kind == 0) {
+                    const double u = orc_uniform(seed, m, iter, 0, 0), z = orc_normal(seed, m, iter, 0, 0);
+                    a[0] = abc_update(s[0], xpx[j], &la[0], &lb[0], &ldl[0], ie, var_effect[0], prior[0], u, z);
+                } else if (kind == 1) {
+                    const double u = orc_uniform(seed, m, iter, 0, 0), z = orc_normal(seed, m, iter, 0, 0);
+                    a[0] = bayesr_update(s[0], xpx[j], &la[0], &lcls, ie, var_effect[0], prior, gamma, u, z);
+                } else {
+                    float w[ORC_MAXT];
+                    for (int k = 0; k < t; ++k) w[k] = s[k] + xpx[j] * la[k];
+                    mt1_update(t, w, xpx[j], la, lb, ldl, 1, Rinv, Ginv, prior, seed, m, iter, 0, a);
+                }
+                if (tid == 0) { pend_j = j; pcls = lcls; for (int k = 0; k < t; ++k) { pa[k] = la[k]; pb[k] = lb[k]; pd[k] = ldl[k]; } }
+                for (int k = 0; k < t; ++k) if (a[k] != 0.0f) axpy_f32(a[k], x + lo, r + k * ld_r + lo, hi - lo);
+            }
+        team_wait(&bar, T, &sense);
+        if (tid == 0 && pend_j >= 0) {
+            for (int k = 0; k < t; ++k) { alpha[k * p + pend_j] = pa[k]; if (kind != 1) { beta[k * p + pend_j] = pb[k]; ((float*)delta)[k * p + pend_j] = pd[k]; } }
+            if (kind == 1) ((int32_t*)delta)[pend_j] = pcls;
+        }
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    free(partial);
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}

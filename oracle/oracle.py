@@ -50,6 +50,7 @@ def lib():
         L.orc_philox4x32_10.restype = None
         L.orc_philox4x32_10.argtypes = [_u32p, _u32p, _u32p]
         L.orc_time_bayesc_sweeps.restype = C.c_double
+        L.orc_time_sweeps_team.restype = C.c_double
         L.orc_bayesr_block_nreps.argtypes = [C.c_int64, C.c_int64, C.c_int64]
         _lib = L
     return _lib
@@ -290,3 +291,24 @@ def time_bayesc_sweeps(X, xpx_, r, alpha, beta, delta, vare, var_effect, pi, see
                                         _p(r, _f32p), _p(alpha, _f32p), _p(beta, _f32p), _p(delta, _f32p),
                                         C.c_float(vare), C.c_float(var_effect), C.c_double(pi),
                                         C.c_uint64(seed), C.c_int(sweeps), C.c_int(nthreads))
+
+
+def time_sweeps_team(kind, X, xpx_, r, alpha, beta, delta, vare, var_effect, prior, seed, sweeps, nthreads=1, gamma=GAMMA):
+    """kind 0 = BayesC, 1 = BayesR, 2 = multi-trait sampler I; state arrays t x p (1-D for one trait), r t x ld_r.
+    Returns elapsed seconds of `sweeps` non-block sweeps with a persistent team of `nthreads` threads."""
+    n, p, ld = _xinfo(X)
+    r2 = r.reshape(1, -1) if r.ndim == 1 else r
+    t = r2.shape[0]
+    ve = np.ascontiguousarray(vare, dtype=np.float32).reshape(-1)
+    vg = np.ascontiguousarray(var_effect, dtype=np.float32).reshape(-1)
+    pr = np.ascontiguousarray(prior, dtype=np.float64).reshape(-1)
+    g4 = np.ascontiguousarray(gamma, dtype=np.float64)
+    assert r2.dtype == np.float32 and alpha.dtype == np.float32 and r2.flags.c_contiguous
+    bt = beta if beta is not None else alpha
+    el = lib().orc_time_sweeps_team(C.c_int(kind), _p(X, _f32p), C.c_int64(n), C.c_int64(p), C.c_int64(ld), _p(xpx_, _f32p),
+                                    C.c_int(t), _p(r2, _f32p), C.c_int64(r2.shape[1]), _p(alpha, _f32p), _p(bt, _f32p),
+                                    delta.ctypes.data_as(C.c_void_p), _p(ve, _f32p), _p(vg, _f32p), _p(pr, _f64p), _p(g4, _f64p),
+                                    C.c_uint64(seed), C.c_int(sweeps), C.c_int(nthreads))
+    if el < 0:
+        raise ValueError("oracle timing helper rejected its arguments")
+    return el

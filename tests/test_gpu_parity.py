@@ -190,19 +190,31 @@ def test_bayesr_error_contracts(hip, small_data):
         hip.sweep(iteration=1, seed=1, vare=1.0, var_effect=0.2, pi_matrix=np.ones((3, 4)) / 4)
 
 
+@pytest.mark.parametrize("method", ["BayesC", "BayesR"])
 @pytest.mark.parametrize("nreps", [3, 0])
-def test_block_repetitions_parity(hip, nreps):
-    """fast_blocks semantics: nreps within-block passes (0 = block size; BayesABC.jl:153)."""
+def test_block_repetitions_parity(hip, nreps, method):
+    """fast_blocks semantics: nreps within-block passes (0 = block size; BayesABC.jl:153, BayesR.jl:146-147)."""
     data = make_dataset(n=400, p=64 * 3 + 5, ncausal=6, seed=41)
-    orc, hip = _pair(hip, data, 64, "BayesC")
+    orc, hip = _pair(hip, data, 64, method)
     r0 = data["y"] - data["y"].mean()
     orc.set_residual(r0)
     hip.set_residual(r0)
     vare, varg = _hyper(data)
+    kw = dict(var_effect=np.float32(20 * varg), pi_classes=np.array([0.9, 0.06, 0.03, 0.01])) if method == "BayesR" else dict(var_effect=varg, pi=0.9)
+    if method == "BayesR":
+        for e in (orc, hip):
+            e.set_state(delta=np.ones(e.p, dtype=np.int32))
     for it in range(1, 4):
-        orc.sweep(iteration=it, seed=5, vare=vare, var_effect=varg, pi=0.9, nreps=nreps)
-        hip.sweep(iteration=it, seed=5, vare=vare, var_effect=varg, pi=0.9, nreps=nreps)
-    _compare_state(orc, hip, atol=5e-6)
+        orc.sweep(iteration=it, seed=5, vare=vare, nreps=nreps, **kw)
+        hip.sweep(iteration=it, seed=5, vare=vare, nreps=nreps, **kw)
+    if method == "BayesR":                       # (BayesR keeps no beta)
+        ao, _, do = orc.get_state()
+        ah, _, dh = hip.get_state()
+        assert np.array_equal(do, dh) and (do > 1).sum() > 3
+        np.testing.assert_allclose(ah, ao, rtol=0, atol=5e-6)
+        np.testing.assert_allclose(hip.get_residual(), orc.get_residual(), rtol=0, atol=2e-5)
+    else:
+        _compare_state(orc, hip, atol=5e-6)
 
 
 # (3, 512): draws parked in LDS; (3, 1024), (4, 1024): too big to park -- the serial wave reads them from HBM

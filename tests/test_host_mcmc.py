@@ -577,6 +577,24 @@ def test_annotated_two_trait_bayesc(tmp_path):
         api.runMCMC(model, ph, chain_length=5, seed=5, output_folder=str(tmp_path / "amt2"), engine=OracleEngine("block"), block_size=64)
 
 
+def test_annotated_two_trait_bayesc_default_pi(tmp_path):
+    """Pi omitted (the reference's supported default, annotation_setup.jl:109-118): every marker starts in the all-active
+    state 11; a non-zero scalar Pi is the reference's error."""
+    gdf, ph, ann, causal = _annotated_dataset(seed=12, n=200, p=130)
+    rng = np.random.default_rng(3)
+    ph = ph.assign(y2=0.7 * ph["y1"].to_numpy() + 0.7 * rng.standard_normal(len(ph)))
+    geno = api.get_genotypes(gdf, np.eye(2) * 0.5, method="BayesC", annotations=ann)
+    model = api.build_model("y1 = intercept + geno\ny2 = intercept + geno", np.eye(2))
+    out = api.runMCMC(model, ph, chain_length=40, burnin=10, seed=5, output_folder=str(tmp_path / "d"),
+                      engine=OracleEngine("block"), block_size=64)
+    assert len(out["pi_geno"]) == 4 and abs(out["pi_geno"]["Estimate"].sum() - 1.0) < 1e-6
+    assert np.isfinite(out["marker effects geno"]["Estimate"]).all()
+    geno = api.get_genotypes(gdf, np.eye(2) * 0.5, method="BayesC", annotations=ann, Pi=0.5)
+    model = api.build_model("y1 = intercept + geno\ny2 = intercept + geno", np.eye(2))
+    with pytest.raises(ValueError, match="requires Pi=0.0 or a joint Pi dictionary"):
+        api.runMCMC(model, ph, chain_length=5, seed=5, output_folder=str(tmp_path / "e"), engine=OracleEngine("block"), block_size=64)
+
+
 def test_heritability_output_matches_its_definition(tmp_path):
     """output.jl:498-512: per saved sample genetic variance = var(EBV) over the output individuals and
     h2 = genVar / (genVar + vare); the tables are the mean / std of those samples (output.jl:196-209)."""
