@@ -413,26 +413,22 @@ def cpu_baseline(a, eng, method, t, n, p_total, p_sub, Y, state, refbench):
         prior = np.array([0.0 if refbench else 0.95])
     R0 = np.ascontiguousarray(Y - Y.mean(axis=1, keepdims=True), dtype=np.float32)
 
-    def run(threads, sweeps, pc):
-        al = np.zeros((t, pc), dtype=np.float32)
-        be = np.zeros((t, pc), dtype=np.float32)
-        de = np.ones((t, pc), dtype=np.int32 if method == "BayesR" else np.float32)
-        Xc = X if pc == p_sub else np.asfortranarray(X[:, :pc])
-        return O.time_sweeps_team(kind, Xc, xpx[:pc].copy(), R0.copy(), al, be, de, vare, G, prior, a.seed, sweeps, threads)
-
     res = {}
     for threads in sorted({1, min(ncores, 16), ncores}):
-        pc = max(200, p_sub // 20)
-        t1 = run(threads, 1, pc) * (p_sub / pc)                      # calibration on a twentieth of the sample
-        sweeps = int(max(2, min(20, round(a.cpu_seconds / max(t1, 1e-3)))))
-        tt = run(threads, sweeps, p_sub)
-        res[threads] = (tt / sweeps, sweeps)
-        log(f"cpu baseline {threads} thread(s): {tt / sweeps:.3f} s per {p_sub}-marker sweep ({sweeps} sweeps)")
+        al = np.zeros((t, p_sub), dtype=np.float32)
+        be = np.zeros((t, p_sub), dtype=np.float32)
+        de = np.ones((t, p_sub), dtype=np.int32 if method == "BayesR" else np.float32)
+        # up to 20 sweeps, bounded by --cpu-seconds of wall time per leg (a leg that does not finish 2 sweeps in that time
+        # -- hundreds of threads meeting at a barrier per marker -- is scaled from the marker updates it completed)
+        tt, done = O.time_sweeps_team(kind, X, xpx, R0.copy(), al, be, de, vare, G, prior, a.seed, 20, threads, max_seconds=a.cpu_seconds)
+        done = max(int(done), 1)
+        res[threads] = (tt * p_sub / done, done / p_sub)
+        log(f"cpu baseline {threads} thread(s): {res[threads][0]:.3f} s per {p_sub}-marker sweep ({res[threads][1]:.2f} sweeps in {tt:.1f} s)")
     best = min(res, key=lambda k: res[k][0])
     per_sweep_full = res[best][0] * p_total / p_sub
-    detail = "; ".join(f"{k} thread(s): {v[0] * p_total / p_sub:.2f} s/sweep ({v[1]} sweeps)" for k, v in sorted(res.items()))
+    detail = "; ".join(f"{k} thread(s): {v[0] * p_total / p_sub:.2f} s/sweep ({v[1]:.2f} sweeps of the sample timed)" for k, v in sorted(res.items()))
     return {"value": 1.0 / per_sweep_full, "unit": "iterations/s", "cores": best, "kind": "port",
-            "sample": (f"non-block {method} sweeps over the first {p_sub} of {p_total} markers (n={n}), scaled linearly in p; "
+            "sample": (f"non-block {method} sweeps over the first {p_sub} of {p_total} markers (n={n}), <= {a.cpu_seconds:.0f} s per leg, scaled linearly in p; "
                        f"{detail}; host has {ncores} logical cores; sweep only, host updates excluded")}
 
 

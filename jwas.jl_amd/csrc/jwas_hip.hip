@@ -1023,7 +1023,7 @@ static hipError_t launch_step_cx(jwas_hip_ctx* c, const CX& cx, const UpdateArgs
     UpdateArgsT<CX> U;
     static_cast<UpdateArgs&>(U) = U0;
     U.cx = cx;
-    const StepSmem SM(c->block_size, NT, is_mt_method(METHOD) ? mt_park_nd(c->block_size, NT) + (S.lpr_mat ? (1 << NT) : 0) : (METHOD == kBayesR ? BayesRMarker::kFastD : 4), is_mt_method(METHOD) ? mt_park_nf(c->block_size, NT) : (METHOD == kBayesR ? 1 : 4));
+    const StepSmem SM(c->block_size, NT, is_mt_method(METHOD) ? mt_park_nd(c->block_size, NT) + (S.lpr_mat ? (1 << NT) : 0) : st_park_nd(METHOD), is_mt_method(METHOD) ? mt_park_nf(c->block_size, NT) : st_park_nf(METHOD));
     static bool attr_set = false;
     if (!attr_set) {   // allow > 64 KB of dynamic LDS
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_block_step<METHOD, NT, CX>),
@@ -1084,7 +1084,7 @@ static hipError_t launch_indep_cx(jwas_hip_ctx* c, const CX& cx, const UpdateArg
     UpdateArgsT<CX> U;
     static_cast<UpdateArgs&>(U) = U0;
     U.cx = cx;
-    const StepSmem SM(c->block_size, NT, is_mt_method(METHOD) ? mt_park_nd(c->block_size, NT) + (S.lpr_mat ? (1 << NT) : 0) : (METHOD == kBayesR ? BayesRMarker::kFastD : 4), is_mt_method(METHOD) ? mt_park_nf(c->block_size, NT) : (METHOD == kBayesR ? 1 : 4));
+    const StepSmem SM(c->block_size, NT, is_mt_method(METHOD) ? mt_park_nd(c->block_size, NT) + (S.lpr_mat ? (1 << NT) : 0) : st_park_nd(METHOD), is_mt_method(METHOD) ? mt_park_nf(c->block_size, NT) : st_park_nf(METHOD));
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_indep_sample<METHOD, NT>),
@@ -1257,13 +1257,13 @@ int jwas_hip_sweep(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_sweep_stats
     {   // per-sweep marker constants (draws, prior logs, lhs terms) for all p markers in parallel
         const dim3 pg((unsigned)((c->p + 255) / 256)), pb(256);
         switch (c->method) {
-            case JWAS_HIP_BAYESC: hipLaunchKernelGGL((k_prepare<kBayesC, 1>), pg, pb, 0, c->stream, c->dparams, c->p, c->xpx, c->prep_d, c->prep_f); break;
-            case JWAS_HIP_BAYESB: hipLaunchKernelGGL((k_prepare<kBayesB, 1>), pg, pb, 0, c->stream, c->dparams, c->p, c->xpx, c->prep_d, c->prep_f); break;
-            case JWAS_HIP_BAYESR: hipLaunchKernelGGL((k_prepare<kBayesR, 1>), pg, pb, 0, c->stream, c->dparams, c->p, c->xpx, c->prep_d, c->prep_f); break;
+            case JWAS_HIP_BAYESC: hipLaunchKernelGGL((k_prepare<kBayesC, 1>), pg, pb, 0, c->stream, c->dparams, c->p, c->xpx, c->alpha, c->prep_d, c->prep_f); break;
+            case JWAS_HIP_BAYESB: hipLaunchKernelGGL((k_prepare<kBayesB, 1>), pg, pb, 0, c->stream, c->dparams, c->p, c->xpx, c->alpha, c->prep_d, c->prep_f); break;
+            case JWAS_HIP_BAYESR: hipLaunchKernelGGL((k_prepare<kBayesR, 1>), pg, pb, 0, c->stream, c->dparams, c->p, c->xpx, c->alpha, c->prep_d, c->prep_f); break;
 #define JW_MT_PREP(M)                                                                                                                        \
-                if (t == 2) hipLaunchKernelGGL((k_prepare<M, 2>), pg, pb, 0, c->stream, c->dparams, c->p, c->xpx, c->prep_d, c->prep_f);          \
-                else if (t == 3) hipLaunchKernelGGL((k_prepare<M, 3>), pg, pb, 0, c->stream, c->dparams, c->p, c->xpx, c->prep_d, c->prep_f);     \
-                else hipLaunchKernelGGL((k_prepare<M, 4>), pg, pb, 0, c->stream, c->dparams, c->p, c->xpx, c->prep_d, c->prep_f);                 \
+                if (t == 2) hipLaunchKernelGGL((k_prepare<M, 2>), pg, pb, 0, c->stream, c->dparams, c->p, c->xpx, c->alpha, c->prep_d, c->prep_f);          \
+                else if (t == 3) hipLaunchKernelGGL((k_prepare<M, 3>), pg, pb, 0, c->stream, c->dparams, c->p, c->xpx, c->alpha, c->prep_d, c->prep_f);     \
+                else hipLaunchKernelGGL((k_prepare<M, 4>), pg, pb, 0, c->stream, c->dparams, c->p, c->xpx, c->alpha, c->prep_d, c->prep_f);                 \
                 break;
             case JWAS_HIP_MTBAYESC2:
                 if (t == 2) hipLaunchKernelGGL((k_prepare_mt2<2>), pg, pb, 0, c->stream, c->dparams, c->p, c->xpx, c->mt2_tab);
@@ -1327,6 +1327,7 @@ int jwas_hip_sweep(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_sweep_stats
             const int64_t jn = (sb + 1) * bs;
             S.b_next = (sb + 1 < nb) ? (int)((jn + bs <= c->p) ? bs : c->p - jn) : 0;
             S.cross_next = c->cross + (sb + 1 < nb ? sb + 1 : sb) * (int64_t)bs * bs;
+            S.gram_next = (sb + 1 < nb) ? c->gram + (sb + 1) * (int64_t)bs * bs : nullptr;
             S.corr_in = c->corr + (sb & 1) * (size_t)kMaxT * bs;
             S.corr_out = c->corr + ((sb + 1) & 1) * (size_t)kMaxT * bs;
             S.prep_d = c->prep_d; S.prep_f = c->prep_f; S.mt2_tab = c->mt2_tab; S.lpr_mat = c->lpr_active ? c->lpr_mat : nullptr;
@@ -1399,8 +1400,8 @@ int jwas_hip_sweep(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_sweep_stats
     S->n_events = (double)h_cnt[0];
     c->last_events = (double)h_cnt[0];
     if (std::getenv("JWAS_HIP_DEBUG_PHASES"))
-        std::fprintf(stderr, "[jwas_hip] blocks=%lld events=%llu unstaged=%llu cycles: front=%llu cand=%llu stage=%llu serial=%llu write=%llu rounds=%llu slow_rounds=%llu\n",
-                     (long long)c->nblocks, h_cnt[0], h_cnt[1], h_cnt[2], h_cnt[3], h_cnt[4], h_cnt[5], h_cnt[6], h_cnt[7], h_cnt[8]);
+        std::fprintf(stderr, "[jwas_hip] blocks=%lld events=%llu unstaged=%llu cycles: front=%llu cand=%llu stage=%llu serial=%llu write=%llu corr=%llu rounds=%llu slow_rounds=%llu\n",
+                     (long long)c->nblocks, h_cnt[0], h_cnt[1], h_cnt[2], h_cnt[3], h_cnt[4], h_cnt[5], h_cnt[6], h_cnt[9], h_cnt[7], h_cnt[8]);
     float ms = 0.f;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev_start, c->ev_stop));
     S->sweep_ms = ms;

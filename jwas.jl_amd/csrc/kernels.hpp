@@ -324,7 +324,19 @@ __global__ __launch_bounds__(256) void k_finish(CX cx, const float* r_in,
 // sampler wave only loads them.  (Within-block repetitions > 0 recompute them in place.)
 // ---------------------------------------------------------------------------------------------
 constexpr int kPrepD = 17;
-constexpr int kPrepF = 4;
+constexpr int kPrepF = 5;
+
+// Floats as ordered integers (the bisections below walk the float number line).
+__device__ __forceinline__ uint32_t float_key(float f)
+{
+    const uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float key_float(uint32_t k)
+{
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+constexpr float kFltMax = 3.402823466e+38f;
 
 __device__ __forceinline__ float logf_via_double(float x) { return (float)log((double)x); }
 
@@ -371,7 +383,41 @@ struct AbcMarker {
     {
         return (float)((double)gHat + zs);                                  // :46
     }
+    // INCLUSION THRESHOLDS.  For a fixed alpha_old the decision of evaluate() is a monotone function of |rhs|: every
+    // operation between the block rhs x and the comparison is a correctly rounded product / sum with a fixed positive
+    // factor (monotone, sign-symmetric), so  {x : included} = {x <= lo} U {x >= hi}  for two floats (lo, hi) that depend
+    // on the marker and its draw only.  They are found once per sweep, for all markers in parallel, by bisection over
+    // the float number line with evaluate() itself as the oracle (32 steps each); the serial chain then decides with
+    // two float compares -- no double-precision arithmetic, no dependency on anything but x.
+    // always included: lo = hi = -d*alpha_old;  never: lo = -inf, hi = +inf.
+    __device__ __forceinline__ void thresholds(float a_old, float ie, float& lo, float& hi) const
+    {
+        float gh;
+        const float x0 = -(d * a_old);                       // rhs = ((x + d*a_old)*ie) = 0 here: |rhs| minimal
+        if (evaluate(x0, a_old, ie, gh)) { lo = x0; hi = x0; return; }
+        if (!evaluate(kFltMax, a_old, ie, gh)) hi = INFINITY;
+        else {
+            uint32_t a = float_key(x0), b = float_key(kFltMax);          // a: excluded, b: included
+            while (b - a > 1u) { const uint32_t m = a + ((b - a) >> 1); if (evaluate(key_float(m), a_old, ie, gh)) b = m; else a = m; }
+            hi = key_float(b);
+        }
+        if (!evaluate(-kFltMax, a_old, ie, gh)) lo = -INFINITY;
+        else {
+            uint32_t a = float_key(-kFltMax), b = float_key(x0);         // a: included, b: excluded
+            while (b - a > 1u) { const uint32_t m = a + ((b - a) >> 1); if (evaluate(key_float(m), a_old, ie, gh)) a = m; else b = m; }
+            lo = key_float(a);
+        }
+    }
 };
+
+// The committed update of a BayesA/B/C marker from its thresholds: same values as AbcMarker::evaluate + alpha_incl.
+__device__ __forceinline__ bool abc_included(float x, float lo, float hi) { return (x >= hi) || (x <= lo); }
+__device__ __forceinline__ float abc_alpha_new(float x, float a_old, float d, float ie, float invLhs, double zs, bool incl)
+{
+    const float rhs  = (x + d * a_old) * ie;                                // :36
+    const float gHat = rhs * invLhs;                                        // :39
+    return incl ? (float)((double)gHat + zs) : 0.f;                         // :46 / :55
+}
 
 // BayesR (BayesR.jl:56-96)
 struct BayesRMarker {
@@ -481,6 +527,14 @@ struct BayesRMarker {
 #pragma unroll
         for (int k = 0; k < 3; ++k) { invLhs[k + 1] = pd[k * p + j]; zs[k + 1] = pd[(3 + k) * p + j]; T[k] = pd[(6 + k) * p + j]; }
     }
+    // the same subset straight from k_prepare's global arrays (rows as written by store())
+    __device__ __forceinline__ void load_fast_global(const double* pd, int64_t p, int64_t j, float d_, float ie)
+    {
+        d = d_; die = d_ * ie;
+        invLhs[0] = 0.0; zs[0] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { invLhs[k + 1] = pd[(4 + k) * p + j]; zs[k + 1] = pd[(10 + k) * p + j]; T[k] = pd[(14 + k) * p + j]; }
+    }
     // returns class 0..3 and the candidate alpha for that class
     __device__ __forceinline__ int evaluate(float rhs_b, float a_old, float ie, float& a_new) const
     {
@@ -533,6 +587,25 @@ struct BayesRMarker {
     }
 };
 
+// BayesR candidacy threshold for a marker that is OUT of the model (alpha_old = 0): the smallest |x| at which its class
+// leaves 1.  The class is monotone in s = rhs^2 (see BayesRMarker) and rhs = x*ie is monotone in |x|, so bisection over
+// the non-negative floats with the serial chain's own decision (thresholds in s, exact formulas next to one) finds it.
+// +inf: never.  A marker that is in the model is always a candidate (its effect is redrawn or removed).
+__device__ __forceinline__ float bayesr_candidate_threshold(const BayesRMarker& bm, float ie)
+{
+    auto leaves = [&](float x) {
+        float an; bool sure;
+        int c = bm.evaluate_thr(x, 0.f, ie, an, sure);
+        if (!sure) c = bm.evaluate(x, 0.f, ie, an);
+        return c != 0;
+    };
+    if (leaves(0.f)) return 0.f;
+    if (!leaves(kFltMax)) return INFINITY;
+    uint32_t a = float_key(0.f), b = float_key(kFltMax);
+    while (b - a > 1u) { const uint32_t m = a + ((b - a) >> 1); if (leaves(key_float(m))) b = m; else a = m; }
+    return key_float(b);
+}
+
 // The serial wave's evaluation of a BayesR marker from plain scalars passed BY VALUE (an object with the constants --
 // even one with scalar members only -- is kept in scratch memory by hipcc once any sibling object is, and the
 // class-dependent selects then become scratch loads with a full memory wait inside every round).
@@ -556,7 +629,7 @@ __device__ __forceinline__ int bayesr_eval_thr(float rhs_b, float a_old, float i
 // K_P: per-sweep marker constants for repetition 0.  grid = ceil(p/256), block = 256.
 template <int METHOD, int NT>
 __global__ __launch_bounds__(256) void k_prepare(const DevParams* __restrict__ P, int64_t p,
-                                                 const float* __restrict__ xpx,
+                                                 const float* __restrict__ xpx, const float* __restrict__ alpha,
                                                  double* __restrict__ prep_d, float* __restrict__ prep_f)
 {
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -591,6 +664,7 @@ __global__ __launch_bounds__(256) void k_prepare(const DevParams* __restrict__ P
             BayesRMarker bm;
             bm.prepare(xpx[j], P->var_effect[0], pj, P->gamma, ie, u, z);
             bm.store(prep_d, prep_f, p, j);
+            prep_f[j] = (alpha[j] != 0.f) ? 0.f : bayesr_candidate_threshold(bm, ie);     // |x| >= this: a candidate
         } else {
             float var_j = P->var_effect[0];
             if constexpr (METHOD == kBayesB) var_j = P->var_vec[j];
@@ -599,6 +673,9 @@ __global__ __launch_bounds__(256) void k_prepare(const DevParams* __restrict__ P
             AbcMarker am;
             am.prepare(xpx[j], var_j, pi_j, ie, u, z);
             am.store(prep_d, prep_f, p, j);
+            float lo, hi;
+            am.thresholds(alpha[j], ie, lo, hi);             // alpha at the start of the sweep = alpha_old of repetition 0
+            prep_f[3 * p + j] = lo; prep_f[4 * p + j] = hi;
         }
     }
 }

@@ -32,7 +32,7 @@
 namespace jw {
 
 constexpr int kStepThreads = 512;
-constexpr int kRowsBytes = 96 * 1024;          // LDS budget for staged Gram rows (sampler role)
+constexpr int kRowsBytes = 128 * 1024;         // LDS budget for staged Gram rows (sampler role)
 // Dynamic-LDS carve of one step workgroup (bytes); B = block size, NT = traits, (nd, nf) = doubles /
 // floats of per-marker sampler constants staged for the serial wave (0 = none).
 constexpr int kLdsBytes = 160 * 1024;
@@ -242,6 +242,7 @@ struct SamplerArgs {
     const float* gram;            // b x b, this block
     const float* cross_next;      // b x b_next: X_this' X_next (row = marker of THIS block); b_next = 0: none
     int b_next;
+    const float* gram_next;       // b_next x b_next Gram of the NEXT block (L2 prefetch only), or NULL
     const float* corr_in;         // [NT][bsz] lookahead correction of THIS block (written by the previous sampler)
     float* corr_out;              // [NT][bsz] lookahead correction of the NEXT block
     const double* prep_d; const float* prep_f;
@@ -322,6 +323,47 @@ __device__ __forceinline__ void corr_phase(char* smem, const StepSmem& SM, const
 #pragma unroll
         for (int t = 0; t < NT; ++t) A.corr_out[t * B + c] = corr[t];
     }
+}
+
+// Waves 1..7 (after their other prefetch work, while wave 0 runs the serial phase): pull the Gram rows the NEXT block's
+// sampler will stage into this XCD's L2 -- the whole Gram block for small (dense-prior) blocks, else the rows of the
+// markers that are in the model (alpha != 0: always candidates).  A row fetch of the sampler workgroup competes with
+// ~220 streaming workgroups for HBM; here it is off the critical path, in the next launch it is an L2 hit.  Speed only.
+__device__ __forceinline__ void prefetch_next_gram(const SamplerArgs& A, bool whole_block)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bn = A.b_next;
+    if (wave == 0 || bn <= 0 || A.gram_next == nullptr) return;
+    float sink = 0.f;
+    if (whole_block) {
+        const int nlines = (bn * bn + 31) / 32;                                    // 128-byte lines of the next Gram block
+        float v[4];                                                                // (<= 4 x 448 lines: a 128 x 128 block has 512)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int l = (wave - 1) * 64 + lane + u * 7 * 64;
+            v[u] = A.gram_next[(int64_t)(l < nlines ? l : nlines - 1) * 32];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) sink += v[u];
+    } else {
+        // every lane whose marker is in the model touches the lines of ITS row: independent loads, one wait at the end
+        const int lines_per_row = (bn + 31) / 32;                                  // <= 32 for 1024-marker blocks
+        for (int c0 = (wave - 1) * 64; c0 < bn; c0 += 7 * 64) {
+            const int c = c0 + lane;
+            const float a = A.alpha[A.j0 + A.b + (c < bn ? c : 0)];
+            if (c < bn && a != 0.f) {
+                const float* row = A.gram_next + (int64_t)c * bn;
+                for (int l0 = 0; l0 < lines_per_row; l0 += 8) {
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = row[(l0 + u < lines_per_row ? l0 + u : lines_per_row - 1) * 32];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) sink += v[u];
+                }
+            }
+        }
+    }
+    asm volatile("" ::"v"(sink));
 }
 
 // Waves 1..7: touch the cross-Gram rows (X_this' X_next) of the staged candidates so that corr_phase finds
@@ -409,8 +451,33 @@ __device__ __forceinline__ int stage_rows(char* smem, const StepSmem& SM, const 
         __syncthreads();
     }
     const int ncand = base < SM.max_cand ? base : SM.max_cand;
-    // (row, 64-column chunk) tasks, kSL independent loads in flight per wave (the fetch is latency-bound: with many
-    // candidates -- BayesR, early chain -- depth is what shortens it)
+    // ALL row loads of the workgroup are issued before the first one is consumed: the fetch costs ONE memory latency
+    // (microseconds under full-rate streaming), not one per batch.  Full blocks (rows 16-byte aligned): (row, 256-column)
+    // tasks, one float4 per lane; <= kSQ tasks per wave in flight, i.e. up to 8*kSQ*256 = 49 152 floats per pass.
+    const int b4 = A.b;
+    if (b4 == B && (B & 255) == 0) {
+        constexpr int kSQ = 24;
+        const int nchunk = B / 256, ntask = ncand * nchunk;
+        for (int t0 = 0; t0 < ntask; t0 += (kStepThreads / 64) * kSQ) {
+            float4 v[kSQ];
+#pragma unroll
+            for (int u = 0; u < kSQ; ++u) {
+                const int task = t0 + u * (kStepThreads / 64) + wave;          // tasks interleaved over the waves
+                const int tk = task < ntask ? task : ntask - 1;
+                const int row = tk / nchunk, c = (tk - row * nchunk) * 256 + lane * 4;
+                v[u] = *reinterpret_cast<const float4*>(A.gram + (int64_t)cand_list[row] * B + c);
+            }
+#pragma unroll
+            for (int u = 0; u < kSQ; ++u) {
+                const int task = t0 + u * (kStepThreads / 64) + wave;
+                if (task < ntask) {
+                    const int row = task / nchunk, c = (task - row * nchunk) * 256 + lane * 4;
+                    *reinterpret_cast<float4*>(rows + row * B + c) = v[u];
+                }
+            }
+        }
+    } else {
+    // (row, 64-column chunk) tasks, kSL independent loads in flight per wave (ragged last block, 64/128-marker blocks)
     constexpr int kSL = 16;
     const int nchunk = B / 64, ntask = ncand * nchunk;
     for (int t0 = wave * kSL; t0 < ntask; t0 += (kStepThreads / 64) * kSL) {
@@ -425,6 +492,7 @@ __device__ __forceinline__ int stage_rows(char* smem, const StepSmem& SM, const 
         }
 #pragma unroll
         for (int u = 0; u < kSL; ++u) if (t0 + u < ntask) rows[dst[u]] = v[u];
+    }
     }
     __syncthreads();
     return ncand;
@@ -461,11 +529,19 @@ __device__ __forceinline__ void apply_gram_row(char* smem, const StepSmem& SM, c
 
 // ---------------------------------------------------------------------------------------------
 // SAMPLER role, single trait.  METHOD in {kBayesC, kBayesB, kBayesR}.
+//
+// Per-marker constants parked in LDS for the serial wave (rep 0):
+//   BayesA/B/C: doubles [zs]                      floats [1/lhs, beta_excl, x'x, lo, hi]   (lo/hi: AbcMarker::thresholds)
+//   BayesR    : doubles [1/lhs_k, zs_k, T_k] (9)  floats [x'x, candidate threshold]
 // ---------------------------------------------------------------------------------------------
+__host__ __device__ constexpr int st_park_nd(int method) { return method == kBayesR ? BayesRMarker::kFastD : 1; }
+__host__ __device__ constexpr int st_park_nf(int method) { return method == kBayesR ? 2 : 5; }
+
 template <int METHOD>
 __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A)
 {
-    constexpr int ND = (METHOD == kBayesR) ? BayesRMarker::kFastD : 4, NF = (METHOD == kBayesR) ? 1 : 4;
+    constexpr bool kR = (METHOD == kBayesR);
+    constexpr int ND = st_park_nd(METHOD), NF = st_park_nf(METHOD);
     const StepSmem SM(A.bsz, 1, ND, NF);
     const int B = SM.B;
     const DevParams* P = A.P;
@@ -485,8 +561,9 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
     // ---- phase A (all threads, ONE memory latency): for its marker every thread issues, back to back, the
     // loads of alpha, the sweep constants, the row-group partials and the lookahead correction; then
     //   rhs = fl32(sum of partials) + corr
-    // and decides candidacy (does the effect change if evaluated against the entry rhs?).  Under full-rate
-    // streaming by the update role a dependent global load costs microseconds, so nothing here waits twice.
+    // and decides candidacy (does the effect change if evaluated against the entry rhs?) with the marker's
+    // thresholds: two float compares.  Under full-rate streaming by the update role a dependent global load costs
+    // microseconds, so nothing here waits twice.
     // Small blocks (B <= 128: the host's choice for dense priors): the whole Gram block fits the row slots, and it does
     // not depend on anything this launch computes -- fetch it with the very first loads instead of after the candidates
     // are known (one dependent memory latency less per block).  Slot of marker c = c.
@@ -519,31 +596,31 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
         const float a0 = A.alpha[j];
         const float dj = A.xpx[j];
         const float co = A.corr_in[c];
-        AbcMarker am; BayesRMarker bm;
-        if constexpr (METHOD == kBayesR) bm.load(A.prep_d, A.prep_f, p, j, dj, ie);
-        else am.load(A.prep_d, A.prep_f, p, j, dj);
-        const double sum = sum_partials(A.partials + cc, A.nrg, A.bstride);
-        const float rhs0 = (float)sum + co;       // + lookahead correction formed by the previous block's sampler
-        rhs_lds[c] = rhs0;
-        const float a_in = (c < b) ? a0 : 0.f;
-        acur[c] = a_in;
-        astart[c] = a_in;
-        // park the constants in LDS for the serial wave
-        if constexpr (METHOD == kBayesR) {
-            float an;
-            bool sure;
+        if constexpr (kR) {
+            BayesRMarker bm;
+            bm.load_fast_global(A.prep_d, p, j, dj, ie);
+            const float thrx = A.prep_f[j];
+            const double sum = sum_partials(A.partials + cc, A.nrg, A.bstride);
+            const float rhs0 = (float)sum + co;
+            rhs_lds[c] = rhs0;
+            const float a_in = (c < b) ? a0 : 0.f;
+            acur[c] = a_in; astart[c] = a_in;
             bm.store_fast(lpd, B, c);
-            lpf[c] = dj;
-            int cl0 = bm.evaluate_thr(rhs0, 0.f, ie, an, sure);
-            if (!sure) cl0 = bm.evaluate(rhs0, 0.f, ie, an);
-            cand[q] = (c < b) && ((a_in != 0.f) || (cl0 != 0));
+            lpf[c] = dj; lpf[B + c] = thrx;
+            cand[q] = (c < b) && ((a_in != 0.f) || (fabsf(rhs0) >= thrx));
             dpark0[c] = 1.f;                      // a marker that stays out: class 1 (see the prefix skip below)
         } else {
-            float gh;
-            am.store(lpd, lpf, B, c);
-            lpf[3 * B + c] = dj;
-            cand[q] = (c < b) && ((a_in != 0.f) || am.evaluate(rhs0, 0.f, ie, gh));
-            bpark0[c] = am.beta_excl; dpark0[c] = 0.f;
+            const double zs = A.prep_d[3 * p + j];
+            const float invLhs = A.prep_f[j], bex = A.prep_f[2 * p + j], lo = A.prep_f[3 * p + j], hi = A.prep_f[4 * p + j];
+            const double sum = sum_partials(A.partials + cc, A.nrg, A.bstride);
+            const float rhs0 = (float)sum + co;       // + lookahead correction formed by the previous block's sampler
+            rhs_lds[c] = rhs0;
+            const float a_in = (c < b) ? a0 : 0.f;
+            acur[c] = a_in; astart[c] = a_in;
+            lpd[c] = zs;
+            lpf[c] = invLhs; lpf[B + c] = bex; lpf[2 * B + c] = dj; lpf[3 * B + c] = lo; lpf[4 * B + c] = hi;
+            cand[q] = (c < b) && ((a_in != 0.f) || abc_included(rhs0, lo, hi));
+            bpark0[c] = bex; dpark0[c] = 0.f;     // a marker that stays out: delta 0, beta = its excluded draw
         }
     }
     if (prestage) {
@@ -596,18 +673,19 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
     const bool cross_lds = prestage && SM.has_cross;
     if (cross_lds) copy_cross_rows(smem, SM, A);         // waves 1..7, while wave 0 runs the serial phase
     else prefetch_cross_rows(smem, SM, A, nstaged);      // waves 1..7: pull the rows into L2 for corr_phase at the end
+    prefetch_next_gram(A, prestage);                     // waves 1..7: the next block's staging becomes an L2 hit
     int* wcnt_s = reinterpret_cast<int*>(smem + SM.wcnt_off);
-    if (wave == 0) {
-    const long long tk3 = clock64();
+    long long tk3 = 0, tk4 = 0, tk5 = 0;
     int nrounds = 0, nslow = 0;
+    if (wave == 0) {
+    tk3 = clock64();
 
     // wave 0: lane l owns marker c = 64*s + l of sub-block s
-    float* delta_f = reinterpret_cast<float*>(A.delta);
     const short* slot_of = reinterpret_cast<const short*>(smem + SM.slot_off);
     const float* rows = reinterpret_cast<const float*>(smem + SM.rows_off);
     int2* evlog = reinterpret_cast<int2*>(smem + SM.log_off);
-    float* bpark = reinterpret_cast<float*>(smem + SM.bcur_off);       // [B] beta / [B] delta of the block (single trait:
-    float* dpark = reinterpret_cast<float*>(smem + SM.dcur_off);       // the multi-trait slots are free)
+    float* bpark = bpark0;
+    float* dpark = dpark0;
     const int nsub = (b + 63) / 64;
     const int nreps = P->nreps > 0 ? P->nreps : b;
     const bool lazy = (nreps == 1);     // single pass: corrections reach a sub-block when it becomes active
@@ -631,55 +709,56 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
     };
 
     // ---- DENSE blocks (most markers of the block are candidates: Pi = 0, BayesA, the reference benchmark's setting):
-    // speculation buys nothing -- every round commits exactly one marker -- so the wave walks the block sequentially
-    // instead: the running rhs of the whole block lives in two registers per lane, marker j's operands are broadcast
-    // with v_readlane, its Gram row (all rows are staged) is read from LDS while it is evaluated.  Same arithmetic,
-    // same order, same results as the speculative rounds; ~4x fewer cycles per marker.
-    // (sequential walk: ~370 cycles per marker; speculative rounds: ~1500 per 64 markers + ~500 per change)
+    // speculation buys nothing -- every round commits exactly one marker -- so the wave walks the block sequentially.
+    // Every lane evaluates ITS OWN marker against its own running rhs at every step (two float compares for the
+    // decision, six operations for the new effect: no operand is broadcast); the step's marker is lane l, whose
+    // alpha_old - alpha_new is broadcast with ONE v_readlane and applied to the running rhs of the whole block (two
+    // registers per lane) with the marker's Gram row from LDS (all rows are staged; the read is issued a step ahead).
+    // A lane's result is final at its own step: it keeps the rhs it was evaluated against and recomputes its update
+    // after the walk.  Same arithmetic, same order, same results as the speculative rounds;
+    // ~18 instructions per marker on a dependent chain of 11.
     bool dense_done = false;
-    if constexpr (METHOD != kBayesR) {
+    if constexpr (!kR) {
         if (nreps == 1 && prestage && nstaged == b && 5 * ncand_all >= 3 * b) {
-            auto bcast_f = [](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
-            auto bcast_d = [](double v, int l) {
-                return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
-            };
-            AbcMarker am[2];
-            float rhsq[2], aq[2], bo[2] = {0.f, 0.f}, dq[2] = {0.f, 0.f};
-            int slq[2];
+            float lo[2], hi[2], il[2], dj[2], ao[2], rhsq[2], rev[2], bex[2];
+            double zs[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int c = (64 * q + lane < B) ? 64 * q + lane : 0;
-                am[q].load(lpd, lpf, B, c, lpf[3 * B + c]);
-                rhsq[q] = rhs_lds[c]; aq[q] = acur[c]; slq[q] = slot_of[c];
+                il[q] = lpf[c]; bex[q] = lpf[B + c]; dj[q] = lpf[2 * B + c]; lo[q] = lpf[3 * B + c]; hi[q] = lpf[4 * B + c];
+                zs[q] = lpd[c];
+                rhsq[q] = rhs_lds[c]; ao[q] = acur[c]; rev[q] = rhsq[q];
             }
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int jend = (b < 64 * (q + 1)) ? b : 64 * (q + 1);
+                if (64 * q >= jend) break;
+                const float* grow = rows + 64 * q * B;
+                float g0 = (q == 0) ? grow[lane] : 0.f;                               // row of the first marker of the sub-block
+                float g1 = (B > 64) ? grow[64 + lane] : 0.f;
 #pragma unroll 1
                 for (int jj = 64 * q; jj < jend; ++jj) {
                     const int l = jj - 64 * q;
-                    const float* grow = rows + __builtin_amdgcn_readlane(slq[q], l) * B;
-                    const float g0 = grow[lane];
-                    const float g1 = (B > 64) ? grow[64 + lane] : 0.f;
-                    AbcMarker m;
-                    m.d = bcast_f(am[q].d, l); m.invLhs = bcast_f(am[q].invLhs, l); m.c1 = bcast_f(am[q].c1, l);
-                    m.beta_excl = bcast_f(am[q].beta_excl, l);
-                    m.lp0 = bcast_d(am[q].lp0, l); m.lp1 = bcast_d(am[q].lp1, l); m.thr = bcast_d(am[q].thr, l); m.zs = bcast_d(am[q].zs, l);
-                    const float rhs_j = bcast_f(rhsq[q], l), a_old = bcast_f(aq[q], l);
-                    float gHat;
-                    const bool incl = m.evaluate(rhs_j, a_old, ie, gHat);
-                    const float a_new = incl ? m.alpha_incl(gHat) : 0.f;
-                    const float Dl = a_old - a_new;                                  // (excluded: a_old - 0)
-                    if (lane == l) { aq[q] = a_new; bo[q] = incl ? a_new : m.beta_excl; dq[q] = incl ? 1.f : 0.f; }
-                    rhsq[0] = fmaf(Dl, g0, rhsq[0]);                                 // Dl = 0: exact no-op
-                    if (B > 64) rhsq[1] = fmaf(Dl, g1, rhsq[1]);
+                    const float x = rhsq[q];
+                    const bool inc = abc_included(x, lo[q], hi[q]);
+                    const float an = abc_alpha_new(x, ao[q], dj[q], ie, il[q], zs[q], inc);
+                    const float Dl = ao[q] - an;                                      // (excluded: alpha_old - 0)
+                    rev[q] = (lane == l) ? x : rev[q];                                // lane l: the rhs it was evaluated against
+                    const float D = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Dl), l));
+                    const float c0 = g0, c1 = g1;
+                    grow += B;                                                        // next marker's row (one past the block: the overflow row)
+                    if (q == 0) g0 = grow[lane];
+                    if (B > 64) g1 = grow[64 + lane];
+                    if (q == 0) rhsq[0] = fmaf(D, c0, rhsq[0]);                       // D = 0: exact no-op
+                    if (B > 64) rhsq[1] = fmaf(D, c1, rhsq[1]);
                 }
             }
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int c = 64 * q + lane;
-                if (c < B) { acur[c] = aq[q]; rhs_lds[c] = rhsq[q]; }
-                if (c < b) { A.beta[j0 + c] = bo[q]; delta_f[j0 + c] = dq[q]; }
+                const bool inc = abc_included(rev[q], lo[q], hi[q]);
+                const float an = abc_alpha_new(rev[q], ao[q], dj[q], ie, il[q], zs[q], inc);
+                if (c < B) { acur[c] = (c < b) ? an : 0.f; bpark0[c] = inc ? an : bex[q]; dpark0[c] = inc ? 1.f : 0.f; }
             }
             nrounds += b;
             dense_done = true;
@@ -687,19 +766,134 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
     }
 
     const int s_first = (lazy && !dense_done) ? (first_sub < nsub ? first_sub : nsub) : 0;      // prefix skip (single pass only)
-    for (int rep = 0; rep < (dense_done ? 0 : nreps); ++rep) {
+
+    // ---- SINGLE PASS (nreps = 1: the exact non-block chain; the hot path).  Everything comes from LDS; the log of
+    // committed changes {row offset, D} lives in two VGPRs (lane e = entry e, written with v_writelane, read back with
+    // v_readlane), so bringing a later sub-block up to date costs one LDS read per entry and no dependent second one.
+    if (lazy && !dense_done) {
+        int log_off = 0;            // lane e: sl*B of entry e
+        float log_D = 0.f;          // lane e: alpha_old - alpha_new of entry e
+        // apply the logged changes (in commit order) to the rhs of the sub-blocks after `s` and empty the log: needed before
+        // a change is applied eagerly (log full, or a row that only lives in the overflow slot) so that every rhs element
+        // still sees its corrections in commit order
+        auto flush_log = [&](int s) {
+            for (int s2 = s + 1; s2 < nsub; ++s2) {
+                const int c2 = 64 * s2 + lane;
+                float r2 = rhs_lds[c2];
+                for (int e = 0; e < nlog; ++e)
+                    r2 = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(log_D), e)),
+                              rows[__builtin_amdgcn_readlane(log_off, e) + c2], r2);
+                rhs_lds[c2] = r2;
+            }
+            nlog = 0;
+        };
+#pragma unroll 1
+        for (int s = s_first; s < nsub; ++s) {
+            const int c = 64 * s + lane;
+            const bool valid = c < b;
+            const int cl = valid ? c : 0;
+            const float a_cur = acur[c];                  // (fixed while the marker is pending; a committed lane leaves `pending`)
+            float rhs = rhs_lds[c];
+            const int my_slot = slot_of[c];
+            float c_lo = 0.f, c_hi = 0.f, c_il = 0.f, c_bex = 0.f, c_d = 0.f, c_thrx = 0.f;
+            double c_zs = 0.0;
+            double r_il1 = 0.0, r_il2 = 0.0, r_il3 = 0.0, r_zs1 = 0.0, r_zs2 = 0.0, r_zs3 = 0.0, r_T0 = 0.0, r_T1 = 0.0, r_T2 = 0.0;
+            if constexpr (kR) {
+                c_d = lpf[cl]; c_thrx = lpf[B + cl];
+                r_il1 = lpd[0 * B + cl]; r_il2 = lpd[1 * B + cl]; r_il3 = lpd[2 * B + cl];
+                r_zs1 = lpd[3 * B + cl]; r_zs2 = lpd[4 * B + cl]; r_zs3 = lpd[5 * B + cl];
+                r_T0 = lpd[6 * B + cl]; r_T1 = lpd[7 * B + cl]; r_T2 = lpd[8 * B + cl];
+            } else {
+                c_il = lpf[cl]; c_bex = lpf[B + cl]; c_d = lpf[2 * B + cl]; c_lo = lpf[3 * B + cl]; c_hi = lpf[4 * B + cl];
+                c_zs = lpd[cl];
+            }
+            // bring this sub-block up to date: the changes committed so far, in commit order (the same fmaf sequence
+            // per element as an immediate update); 8 independent LDS reads in flight
+            for (int e0 = 0; e0 < nlog; e0 += 8) {
+                float gv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int ee = e0 + u < nlog ? e0 + u : nlog - 1;
+                    gv[u] = rows[__builtin_amdgcn_readlane(log_off, ee) + c];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (e0 + u < nlog) rhs = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(log_D), e0 + u)), gv[u], rhs);
+            }
+            unsigned long long pending = __ballot(valid);
+            const bool nz = a_cur != 0.f;
+            // speculative rounds: every pending lane tests ITS marker against the current rhs (float compares only);
+            // the first lane whose effect changes commits, the rest are re-tested after its Gram row corrected the rhs.
+            // Lanes before the winner stay out of the model with the values parked for them; only the winner writes.
+            while (true) {
+                ++nrounds;
+                bool inc = false, ev = false;
+                if constexpr (kR) ev = nz || (fabsf(rhs) >= c_thrx);
+                else { inc = abc_included(rhs, c_lo, c_hi); ev = inc || nz; }
+                const unsigned long long m = __ballot(ev) & pending;
+                if (m == 0ull) break;                     // no further change in this sub-block
+                const int k = __builtin_amdgcn_readfirstlane(__builtin_ctzll(m));
+                float an = 0.f;
+                if constexpr (kR) {
+                    bool sure = true;
+                    int cls = bayesr_eval_thr(rhs, a_cur, ie, c_d, r_il1, r_il2, r_il3, r_zs1, r_zs2, r_zs3, r_T0, r_T1, r_T2, an, sure);
+                    if (__builtin_amdgcn_readlane(sure ? 0 : 1, k)) {       // (practically never: s within 1e-6 of a class threshold)
+                        BayesRMarker bm;
+                        bm.load(A.prep_d, A.prep_f, p, j0 + cl, c_d, ie);   // full constants from global
+                        cls = bm.evaluate(rhs, a_cur, ie, an);
+                        ++nslow;
+                    }
+                    if (cls == 0) an = 0.f;
+                    if (lane == k) { acur[c] = an; dpark[c] = (float)(cls + 1); }             // stored as class 1..4
+                } else {
+                    an = abc_alpha_new(rhs, a_cur, c_d, ie, c_il, c_zs, inc);
+                    if (lane == k) { acur[c] = an; bpark[c] = inc ? an : c_bex; dpark[c] = inc ? 1.f : 0.f; }
+                }
+                const float Dl = a_cur - an;
+                pending = (k == 63) ? 0ull : (pending & ~((2ull << k) - 1ull));
+                const float D = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Dl), k));
+                if (D != 0.f) {
+                    // rhs += D * G[ce][:] (BayesABC.jl:169,172).  The active sub-block is corrected in its register
+                    // copy -- the only value the next round waits for.
+                    int sl = __builtin_amdgcn_readlane(my_slot, k);
+                    bool overflow = false;
+                    if (sl < 0) {                                            // rare: not staged at entry
+                        if (nstaged < SM.max_cand) sl = nstaged++; else { sl = SM.max_cand; overflow = true; }
+                        fetch_row(64 * s + k, sl);
+                        if (lane == 0) atomicAdd(&A.counters[1], 1ull);      // diagnostic
+                    }
+                    const int off = sl * B;
+                    rhs = fmaf(D, rows[off + c], rhs);
+                    if (overflow || nlog >= 64) {
+                        flush_log(s);
+                        for (int s2 = s + 1; s2 < nsub; ++s2) {
+                            const int c2 = 64 * s2 + lane;
+                            rhs_lds[c2] = fmaf(D, rows[off + c2], rhs_lds[c2]);
+                        }
+                    } else {
+                        log_off = (lane == nlog) ? off : log_off;
+                        log_D = (lane == nlog) ? D : log_D;
+                        ++nlog;
+                    }
+                }
+                if (pending == 0ull) break;
+            }
+        }
+    }
+
+    for (int rep = 0; rep < ((dense_done || lazy) ? 0 : nreps); ++rep) {
         key.rep = (uint32_t)rep;
 #pragma unroll 1
         for (int s = s_first; s < nsub; ++s) {
             const int c = 64 * s + lane;
             const bool valid = c < b;
-            const int64_t j = j0 + (valid ? c : 0);
+            const int cl = valid ? c : 0;
+            const int64_t j = j0 + cl;
             const uint32_t marker = P->marker0 + (uint32_t)j;
             unsigned long long pending = __ballot(valid);
-            float a_cur = acur[c];
+            const float a_cur = acur[c];                  // (fixed while the marker is pending; a committed lane leaves `pending`)
             float rhs = rhs_lds[c];                       // register copy of the active sub-block's rhs
             const int my_slot = slot_of[c];
-            float b_out = 0.f, d_out = 0.f;
             if (lazy) {
                 // bring this sub-block up to date: the changes committed so far, in commit order
                 // (same fmaf sequence per entry as an immediate update)
@@ -716,88 +910,76 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
                 }
             }
 
-            AbcMarker am; BayesRMarker bm;
-            // BayesR: the serial chain's constants as plain scalars (see bayesr_eval_thr)
-            float r_d = 0.f;
+            // the marker's constants: parked in LDS by the parallel phase (rep 0) or recomputed for a later repetition
+            float c_lo = 0.f, c_hi = 0.f, c_il = 0.f, c_bex = 0.f, c_d = 0.f, c_thrx = 0.f;
+            double c_zs = 0.0;
+            BayesRMarker bm;
             double r_il1 = 0.0, r_il2 = 0.0, r_il3 = 0.0, r_zs1 = 0.0, r_zs2 = 0.0, r_zs3 = 0.0, r_T0 = 0.0, r_T1 = 0.0, r_T2 = 0.0;
-            if (rep == 0) {            // constants parked in LDS by the parallel phase (no global loads here)
-                const int cl = valid ? c : 0;
-                if constexpr (METHOD == kBayesR) {
-                    r_d = lpf[cl];
+            if (rep == 0) {
+                if constexpr (kR) {
+                    c_d = lpf[cl]; c_thrx = lpf[B + cl];
                     r_il1 = lpd[0 * B + cl]; r_il2 = lpd[1 * B + cl]; r_il3 = lpd[2 * B + cl];
                     r_zs1 = lpd[3 * B + cl]; r_zs2 = lpd[4 * B + cl]; r_zs3 = lpd[5 * B + cl];
                     r_T0 = lpd[6 * B + cl]; r_T1 = lpd[7 * B + cl]; r_T2 = lpd[8 * B + cl];
+                } else {
+                    c_il = lpf[cl]; c_bex = lpf[B + cl]; c_d = lpf[2 * B + cl]; c_lo = lpf[3 * B + cl]; c_hi = lpf[4 * B + cl];
+                    c_zs = lpd[cl];
                 }
-                else am.load(lpd, lpf, B, cl, lpf[3 * B + cl]);
             } else {
                 const float dj = A.xpx[j];
                 const double u = draw_uniform(key, marker, 0u);
                 const double z = draw_normal(key, marker, 0u);
-                if constexpr (METHOD == kBayesR) {
+                c_d = dj;
+                if constexpr (kR) {
                     double pj[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) pj[k] = P->pi_mat ? P->pi_mat[4 * j + k] : P->pi4[k];
                     bm.prepare(dj, P->var_effect[0], pj, P->gamma, ie, u, z);
-                    r_d = dj;
                     r_il1 = bm.invLhs[1]; r_il2 = bm.invLhs[2]; r_il3 = bm.invLhs[3];
                     r_zs1 = bm.zs[1]; r_zs2 = bm.zs[2]; r_zs3 = bm.zs[3];
                     r_T0 = bm.T[0]; r_T1 = bm.T[1]; r_T2 = bm.T[2];
+                    c_thrx = (a_cur != 0.f) ? 0.f : bayesr_candidate_threshold(bm, ie);
                 } else {
                     float var_j = P->var_effect[0];
                     if constexpr (METHOD == kBayesB) var_j = P->var_vec[j];
                     double pi_j = P->pi;
                     if (P->pi_vec) pi_j = P->pi_vec[j];
+                    AbcMarker am;
                     am.prepare(dj, var_j, pi_j, ie, u, z);
+                    am.thresholds(a_cur, ie, c_lo, c_hi);
+                    c_il = am.invLhs; c_bex = am.beta_excl; c_zs = am.zs;
                 }
+                // a marker that is not touched in this repetition gets the repetition's "out of the model" draw
+                if (valid) { if constexpr (kR) dpark[c] = 1.f; else { bpark[c] = c_bex; dpark[c] = 0.f; } }
             }
-            // speculative rounds
+            const bool nz = a_cur != 0.f;
+            // speculative rounds: every pending lane tests ITS marker against the current rhs (float compares only);
+            // the first lane whose effect changes commits, the rest are re-tested after its Gram row corrected the rhs.
+            // Lanes before the winner stay out of the model with the values parked for them; only the winner writes.
             while (true) {
                 ++nrounds;
-                bool is_event = false, incl = false;
-                float a_new = 0.f, gHat = 0.f;
-                int cls = 0;
-                const bool live = valid && ((pending >> lane) & 1ull);
-                if constexpr (METHOD == kBayesR) {
-                    // class decision from the per-sweep thresholds in s = rhs^2 (BayesRMarker); the exponentials only
-                    // when some live lane sits on a threshold (wave-uniform branch)
-                    bool sure = true;
-                    if (live) cls = bayesr_eval_thr(rhs, a_cur, ie, r_d, r_il1, r_il2, r_il3, r_zs1, r_zs2, r_zs3, r_T0, r_T1, r_T2, a_new, sure);
-                    if (__any(live && !sure)) {                     // (practically never: s within 1e-9 of a class threshold)
-                        if (rep == 0) bm.load(A.prep_d, A.prep_f, p, j, lpf[valid ? c : 0], ie);   // full constants from global
-                        if (live) cls = bm.evaluate(rhs, a_cur, ie, a_new);
-                        if (lane == 0) ++nslow;
-                    }
-                    if (live) is_event = (cls != 0) || (a_cur != 0.f);
-                }
-                if (live) {
-                    if constexpr (METHOD == kBayesR) {
-                    } else {
-                        incl = am.evaluate(rhs, a_cur, ie, gHat);
-                        is_event = incl || (a_cur != 0.f);
-                    }
-                }
-                const unsigned long long m = __ballot(is_event) & pending;
-                if (m == 0ull) {          // no further change in this sub-block: everyone pending is final
-                    if (live) {
-                        if constexpr (METHOD == kBayesR) d_out = 1.f;
-                        else { d_out = 0.f; b_out = am.beta_excl; }
-                    }
-                    break;
-                }
+                bool inc = false, ev = false;
+                if constexpr (kR) ev = nz || (fabsf(rhs) >= c_thrx);
+                else { inc = abc_included(rhs, c_lo, c_hi); ev = inc || nz; }
+                const unsigned long long m = __ballot(ev && valid) & pending;
+                if (m == 0ull) break;                     // no further change in this sub-block
                 const int k = __builtin_amdgcn_readfirstlane(__builtin_ctzll(m));
-                // lanes before k (and k itself) are final with the values just computed
-                float Dl = 0.f;
-                if (live && lane <= k) {
-                    if constexpr (METHOD == kBayesR) {
-                        d_out = (float)(cls + 1);                          // stored as class 1..4
-                        const float an = (cls == 0) ? 0.f : a_new;
-                        Dl = a_cur - an;
-                        a_cur = an;
-                    } else {
-                        if (incl) { const float an = am.alpha_incl(gHat); d_out = 1.f; b_out = an; Dl = a_cur - an; a_cur = an; }
-                        else      { d_out = 0.f; b_out = am.beta_excl; Dl = a_cur; a_cur = 0.f; }
+                float an = 0.f;
+                if constexpr (kR) {
+                    bool sure = true;
+                    int cls = bayesr_eval_thr(rhs, a_cur, ie, c_d, r_il1, r_il2, r_il3, r_zs1, r_zs2, r_zs3, r_T0, r_T1, r_T2, an, sure);
+                    if (__builtin_amdgcn_readlane(sure ? 0 : 1, k)) {       // (practically never: s within 1e-6 of a class threshold)
+                        if (rep == 0) bm.load(A.prep_d, A.prep_f, p, j, c_d, ie);          // full constants from global
+                        cls = bm.evaluate(rhs, a_cur, ie, an);
+                        ++nslow;
                     }
+                    if (cls == 0) an = 0.f;
+                    if (lane == k) { acur[c] = an; dpark[c] = (float)(cls + 1); }             // stored as class 1..4
+                } else {
+                    an = abc_alpha_new(rhs, a_cur, c_d, ie, c_il, c_zs, inc);
+                    if (lane == k) { acur[c] = an; bpark[c] = inc ? an : c_bex; dpark[c] = inc ? 1.f : 0.f; }
                 }
+                const float Dl = a_cur - an;
                 pending = (k == 63) ? 0ull : (pending & ~((2ull << k) - 1ull));
                 const float D = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Dl), k));
                 if (D != 0.f) {
@@ -825,59 +1007,57 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
                 }
                 if (pending == 0ull) break;
             }
-            acur[c] = a_cur;
             rhs_lds[c] = rhs;
-            // beta / delta are parked in LDS and written to global memory after the serial phase: a global store here
-            // would put a vector-memory wait (s_waitcnt vmcnt) on the first round of the next sub-block
-            bpark[c] = b_out; dpark[c] = d_out;
         }
     }
-    if (lane == 0) wcnt_s[14] = dense_done ? 1 : 0;      // (the dense walk stored beta / delta itself)
-
-    // write back alpha and the net changes of this block (nothing changed before the first candidate's sub-block)
-    const long long tk4 = clock64();
+    // the net changes of this block as a compact list in LDS (nothing changed before the first candidate's sub-block)
+    tk4 = clock64();
     int base = 0;
 #pragma unroll 1
     for (int s = s_first; s < nsub; ++s) {
         const int c = 64 * s + lane;
-        const bool valid = c < b;
-        const int64_t j = j0 + (valid ? c : 0);
-        const float a_start = astart[c];
-        const float a_fin = acur[c];
-        const bool changed = valid && (a_start != a_fin);
+        const bool changed = (c < b) && (astart[c] != acur[c]);
         const unsigned long long cm = __ballot(changed);
-        if (changed) {
-            const int pos = base + __popcll(cm & ((1ull << lane) - 1ull));
-            A.ev_out->idx[pos] = (int32_t)j;
-            A.ev_out->delta[0][pos] = a_start - a_fin;
-            if (pos < 7) { A.ev_out->hidx[pos] = (int32_t)j; A.ev_out->hdelta[pos] = a_start - a_fin; }
-            A.alpha[j] = a_fin;
-            reinterpret_cast<int*>(smem + SM.log_off)[pos] = c;      // compact change list for corr_phase
-        }
+        if (changed) reinterpret_cast<int*>(smem + SM.log_off)[base + __popcll(cm & ((1ull << lane) - 1ull))] = c;
         base += __popcll(cm);
     }
-    if (lane == 0) {
-        A.ev_out->count = base;
-        wcnt_s[15] = base;
-        atomicAdd(&A.counters[0], (unsigned long long)base);
-        const long long tk5 = clock64();                      // phase cycle counts (diagnostics)
-        atomicAdd(&A.counters[2], (unsigned long long)(tk1 - tk0));
+    if (lane == 0) wcnt_s[15] = base;
+    tk5 = clock64();
+    }   // wave 0
+    __syncthreads();
+    const int nfin = wcnt_s[15];
+    const long long tk6 = clock64();
+    if (A.b_next > 0) corr_phase<1>(smem, SM, A, nfin, cross_lds);
+    const long long tk7 = clock64();
+    // ---- global stores LAST (nothing in this launch waits for them; a barrier after a global store waits for the store):
+    // the change list for the next update role, alpha of the changed markers, beta / delta of the whole block
+    {
+        const int* fin = reinterpret_cast<const int*>(smem + SM.log_off);
+        for (int e = tid; e < nfin; e += kStepThreads) {
+            const int ce = fin[e];
+            const float d = astart[ce] - acur[ce];
+            A.ev_out->idx[e] = (int32_t)(j0 + ce);
+            A.ev_out->delta[0][e] = d;
+            if (e < 7) { A.ev_out->hidx[e] = (int32_t)(j0 + ce); A.ev_out->hdelta[e] = d; }
+            A.alpha[j0 + ce] = acur[ce];
+        }
+        for (int c = tid; c < b; c += kStepThreads) {
+            if constexpr (kR) reinterpret_cast<int32_t*>(A.delta)[j0 + c] = (int32_t)dpark0[c];
+            else { A.beta[j0 + c] = bpark0[c]; reinterpret_cast<float*>(A.delta)[j0 + c] = dpark0[c]; }
+        }
+    }
+    if (tid == 0) {
+        A.ev_out->count = nfin;
+        atomicAdd(&A.counters[0], (unsigned long long)nfin);
+        atomicAdd(&A.counters[2], (unsigned long long)(tk1 - tk0));      // phase cycle counts (diagnostics)
         atomicAdd(&A.counters[3], (unsigned long long)(tk2 - tk1));
         atomicAdd(&A.counters[4], (unsigned long long)(tk3 - tk2));
         atomicAdd(&A.counters[5], (unsigned long long)(tk4 - tk3));
         atomicAdd(&A.counters[6], (unsigned long long)(tk5 - tk4));
         atomicAdd(&A.counters[7], (unsigned long long)nrounds);
         if (nslow) atomicAdd(&A.counters[8], (unsigned long long)nslow);      // BayesR: rounds that needed the double-precision evaluation
+        atomicAdd(&A.counters[9], (unsigned long long)(tk7 - tk6));           // the lookahead-correction phase
     }
-    }   // wave 0
-    __syncthreads();
-    if (!wcnt_s[14]) {                                       // beta / delta of the block, parked in LDS: all threads store
-        for (int c = tid; c < b; c += kStepThreads) {
-            if constexpr (METHOD == kBayesR) reinterpret_cast<int32_t*>(A.delta)[j0 + c] = (int32_t)dpark0[c];
-            else { A.beta[j0 + c] = bpark0[c]; reinterpret_cast<float*>(A.delta)[j0 + c] = dpark0[c]; }
-        }
-    }
-    if (A.b_next > 0) corr_phase<1>(smem, SM, A, wcnt_s[15], cross_lds);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1320,6 +1500,25 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
     // everything the serial wave needs in LDS, and decides candidacy: a marker already in the model for some trait
     // (its effects always change) or one whose evaluation against the entry rhs changes an effect.  Candidates get
     // their Gram row staged in LDS; a change of a non-candidate reads its row from HBM inside the serial phase.
+    // small blocks (the host's choice for dense priors): the whole Gram block with the very first loads, as in the
+    // single-trait sampler (slot of marker c = c)
+    const bool prestage = (B <= 128) && (B <= SM.max_cand);
+    float4 gpre[8];
+    if (prestage) {
+        const int per_row = B >> 2, total = b * per_row;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = tid + u * kStepThreads;
+            const int ec = e < total ? e : 0;
+            const int row = ec / per_row, c4 = (ec - row * per_row) * 4;
+            const float* src = A.gram + (int64_t)row * b;
+            if (b == B) gpre[u] = *reinterpret_cast<const float4*>(src + c4);
+            else {
+                gpre[u].x = src[c4 < b ? c4 : 0]; gpre[u].y = src[c4 + 1 < b ? c4 + 1 : 0];
+                gpre[u].z = src[c4 + 2 < b ? c4 + 2 : 0]; gpre[u].w = src[c4 + 3 < b ? c4 + 3 : 0];
+            }
+        }
+    }
     bool cand[2] = {false, false};
     float djq_[2], a0[2][NT], b0[2][NT], d0[2][NT], w0[2][NT], lc0[2][NT];
     double thr0[2][NT], z0[2][NT];
@@ -1363,6 +1562,21 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
         }
     }
     if (tid < (1 << NT)) lpr[tid] = lpr_mine;
+    if (prestage) {
+        float* rows_p = reinterpret_cast<float*>(smem + SM.rows_off);
+        short* slot_p = reinterpret_cast<short*>(smem + SM.slot_off);
+        short* cand_p = reinterpret_cast<short*>(smem + SM.cand_off);
+        const int per_row = B >> 2, total = b * per_row;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = tid + u * kStepThreads;
+            if (e < total) {
+                const int row = e / per_row, c4 = (e - row * per_row) * 4;
+                *reinterpret_cast<float4*>(rows_p + row * B + c4) = gpre[u];
+            }
+        }
+        for (int c = tid; c < B; c += kStepThreads) { slot_p[c] = (short)(c < b ? c : -1); cand_p[c] = (short)c; }
+    }
     __syncthreads();
     // marker c's table of log prior state probabilities: the shared one (stride 1) or its own column of the parked
     // marker-specific priors (stride B)
@@ -1406,15 +1620,16 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
     // entry rhs, so the evaluation above is final for every marker before it.  Their freshly drawn beta / delta are parked
     // (only theirs: a later marker is re-evaluated from its OLD state) and the serial wave starts at the first sub-block
     // that holds a candidate.  Single pass only.
-    int first_sub = 16;
+    int first_sub = 16, ncand_all = 0;
     {
         int* wc = reinterpret_cast<int*>(smem + SM.wcnt_off);
         const int f0 = __any(cand[0]) ? 1 : 0, f1 = __any(cand[1]) ? 2 : 0;
-        if (lane == 0) wc[wave] = f0 | f1;
+        const int npop = __popcll(__ballot(cand[0])) + __popcll(__ballot(cand[1]));
+        if (lane == 0) wc[wave] = f0 | f1 | (npop << 8);
         __syncthreads();
         unsigned mask = 0u;
 #pragma unroll
-        for (int q = 0; q < kStepThreads / 64; ++q) { const int v = wc[q]; mask |= (unsigned)(v & 1) << q | (unsigned)((v >> 1) & 1) << (8 + q); }
+        for (int q = 0; q < kStepThreads / 64; ++q) { const int v = wc[q]; ncand_all += v >> 8; mask |= (unsigned)(v & 1) << q | (unsigned)((v >> 1) & 1) << (8 + q); }
         if (mask) first_sub = __builtin_ctz(mask);
         const bool single_pass = (P->nreps > 0 ? P->nreps : b) == 1;
         if (!single_pass) first_sub = 0;
@@ -1429,12 +1644,14 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
         __syncthreads();                                   // (stage_rows reuses the slots)
     }
     const long long tk1 = clock64();
-    const int nstaged_mt = first_sub >= 16 ? 0 : stage_rows(smem, SM, A, cand);
+    const int nstaged_mt = prestage ? b : (first_sub >= 16 ? 0 : stage_rows(smem, SM, A, cand));
     prefetch_cross_rows(smem, SM, A, nstaged_mt);
+    prefetch_next_gram(A, prestage);
     int* wcnt_s = reinterpret_cast<int*>(smem + SM.wcnt_off);
-    if (wave == 0) {
-    const long long tk3 = clock64();
+    long long tk3 = 0, tk4 = 0, tk5 = 0;
     int nrounds = 0;
+    if (wave == 0) {
+    tk3 = clock64();
 
 
     const int nsub = (b + 63) / 64;
@@ -1442,24 +1659,21 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
     RngKey key{P->seed_lo, P->seed_hi, P->iter, 0u};
 
     // ---- DENSE blocks (every marker of a <= 128-marker block is in the model for some trait -- the default all-ones
-    // multi-trait prior): sequential walk instead of speculative rounds, exactly as in the single-trait sampler: the
-    // block's running rhs (NT x 2 registers per lane), marker operands broadcast with v_readlane, Gram row from LDS.
+    // multi-trait prior): sequential walk instead of speculative rounds, as in the single-trait sampler.  Every lane
+    // evaluates ITS OWN marker against its own running rhs at every step -- no operand is broadcast; the step's marker
+    // is lane l, whose per-trait alpha_old - alpha_new are broadcast with NT v_readlane and applied to the running rhs of
+    // the whole block (NT x 2 registers per lane) with the marker's Gram row from LDS (read a step ahead).  A lane's
+    // result is final at its own step: it keeps the w it was evaluated with and recomputes its update after the walk.
     bool dense_done = false;
-    if (METHOD != kMTBayesC2 && nreps == 1 && B <= 128 && nstaged_mt == b) {
-        auto bcast_f = [](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
-        auto bcast_d = [](double v, int l) {
-            return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
-        };
-        const short* slot_of = reinterpret_cast<const short*>(smem + SM.slot_off);
+    if (METHOD != kMTBayesC2 && nreps == 1 && prestage && nstaged_mt == b && 5 * ncand_all >= 3 * b) {
         const float* rows = reinterpret_cast<const float*>(smem + SM.rows_off);
-        float rhsq[NT][2], aq[NT][2], bq[NT][2], dq[NT][2], djq[2];
+        float rhsq[NT][2], aq[NT][2], bq[NT][2], dq[NT][2], djq[2], wev[2][NT];
         double thrq[NT][2], zq[NT][2];
         MtPre<NT> Qq[2];
-        int slq[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int c = (64 * q + lane < b) ? 64 * q + lane : 0;
-            djq[q] = lpf[c]; slq[q] = slot_of[c];                   // (B <= 128: the draws are always parked in LDS)
+            djq[q] = lpf[c];                                        // (B <= 128: the draws are always parked in LDS)
             float lcq[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) lcq[t] = lpf[(1 + t) * B + c];
@@ -1468,52 +1682,53 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
             for (int t = 0; t < NT; ++t) {
                 rhsq[t][q] = rhs_lds[t * B + c]; aq[t][q] = acur[t * B + c]; bq[t][q] = bcur[t * B + c]; dq[t][q] = dcur[t * B + c];
                 thrq[t][q] = lpd[t * B + c]; zq[t][q] = lpd[(NT + t) * B + c];
+                wev[q][t] = 0.f;
             }
         }
+        // one marker evaluated in-lane from (w, its state at block entry, its draws)
+        auto eval_own = [&](int q, const float (&w)[NT], float (&an)[NT], float (&bn)[NT], float (&dn)[NT], float (&Dl)[NT]) {
+            const int c = (64 * q + lane < b) ? 64 * q + lane : 0;
+            double thr[NT], z[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { an[t] = aq[t][q]; bn[t] = bq[t][q]; dn[t] = dq[t][q]; Dl[t] = 0.f; thr[t] = thrq[t][q]; z[t] = zq[t][q]; }
+            if constexpr (METHOD == kMTBayesC1) mt1_eval<NT>(K, Qq[q], lpr_of(c), ls, w, djq[q], thr, z, an, bn, dn, Dl);
+            else mega_eval<NT>(K, Qq[q], w, djq[q], thr, z, an, bn, dn, Dl);
+        };
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int jend = (b < 64 * (q + 1)) ? b : 64 * (q + 1);
+            if (64 * q >= jend) break;
+            const float* grow = rows + 64 * q * B;                   // (all rows staged in marker order: slot = marker)
+            float g0 = (q == 0) ? grow[lane] : 0.f;
+            float g1 = (B > 64) ? grow[64 + lane] : 0.f;
 #pragma unroll 1
             for (int jj = 64 * q; jj < jend; ++jj) {
                 const int l = jj - 64 * q;
-                const float* grow = rows + __builtin_amdgcn_readlane(slq[q], l) * B;
-                const float g0 = grow[lane];
-                const float g1 = (B > 64) ? grow[64 + lane] : 0.f;
-                const float dj = bcast_f(djq[q], l);
                 float w[NT], an[NT], bn[NT], dn[NT], Dl[NT];
-                double thr[NT], z[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) w[t] = rhsq[t][q] + djq[q] * aq[t][q];                   // :82
+                eval_own(q, w, an, bn, dn, Dl);
+                const float c0 = g0, c1 = g1;
+                grow += B;                                           // next marker's row (one past the block: the overflow row)
+                if (q == 0) g0 = grow[lane];
+                if (B > 64) g1 = grow[64 + lane];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    an[t] = bcast_f(aq[t][q], l); bn[t] = bcast_f(bq[t][q], l); dn[t] = bcast_f(dq[t][q], l); Dl[t] = 0.f;
-                    thr[t] = bcast_d(thrq[t][q], l); z[t] = bcast_d(zq[t][q], l);
-                    w[t] = bcast_f(rhsq[t][q], l) + dj * an[t];                                         // :82
-                }
-                MtPre<NT> Qm;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    Qm.C11[t] = bcast_f(Qq[q].C11[t], l); Qm.invLhs1[t] = bcast_f(Qq[q].invLhs1[t], l);
-                    Qm.lC11[t] = bcast_f(Qq[q].lC11[t], l); Qm.s1[t] = bcast_f(Qq[q].s1[t], l);
-                }
-                if constexpr (METHOD == kMTBayesC1) mt1_eval<NT>(K, Qm, lpr_of(jj), ls, w, dj, thr, z, an, bn, dn, Dl);
-                else if constexpr (METHOD == kMTBayesC2) mt2_eval<NT>(K, lpr_of(jj), ls, w, dj, thr[0], z, an, bn, dn, Dl);
-                else mega_eval<NT>(K, Qm, w, dj, thr, z, an, bn, dn, Dl);
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    if (lane == l) { aq[t][q] = an[t]; bq[t][q] = bn[t]; dq[t][q] = dn[t]; }
-                    rhsq[t][0] = fmaf(Dl[t], g0, rhsq[t][0]);                                           // Dl = 0: exact no-op
-                    if (B > 64) rhsq[t][1] = fmaf(Dl[t], g1, rhsq[t][1]);
+                    wev[q][t] = (lane == l) ? w[t] : wev[q][t];      // lane l: what it was evaluated with
+                    const float D = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Dl[t]), l));
+                    if (q == 0) rhsq[t][0] = fmaf(D, c0, rhsq[t][0]);                                   // D = 0: exact no-op
+                    if (B > 64) rhsq[t][1] = fmaf(D, c1, rhsq[t][1]);
                 }
             }
         }
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int c = 64 * q + lane;
+            float an[NT], bn[NT], dn[NT], Dl[NT];
+            eval_own(q, wev[q], an, bn, dn, Dl);
             if (c < B)
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    acur[t * B + c] = (c < b) ? aq[t][q] : 0.f; bcur[t * B + c] = bq[t][q]; dcur[t * B + c] = dq[t][q];
-                    rhs_lds[t * B + c] = rhsq[t][q];
-                }
+                for (int t = 0; t < NT; ++t) { acur[t * B + c] = (c < b) ? an[t] : 0.f; bcur[t * B + c] = bn[t]; dcur[t * B + c] = dn[t]; }
         }
         dense_done = true;
     }
@@ -1587,55 +1802,53 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
         }
     }
 
-    const long long tk4 = clock64();
+    tk4 = clock64();
     int base = 0;
 #pragma unroll 1
     for (int s = s_first; s < nsub; ++s) {                    // (no change before the first candidate's sub-block)
         const int c = 64 * s + lane;
-        const bool valid = c < b;
-        const int64_t j = j0 + (valid ? c : 0);
         bool changed = false;
-        float dd[NT];
-        const float* astart = reinterpret_cast<const float*>(smem + SM.astart_off);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const float a0 = astart[t * B + c];
-            dd[t] = a0 - acur[t * B + c];
-            changed = changed || (valid && a0 != acur[t * B + c]);
-        }
+        for (int t = 0; t < NT; ++t) changed = changed || ((c < b) && astart[t * B + c] != acur[t * B + c]);
         const unsigned long long cm = __ballot(changed);
-        if (changed) {
-            const int pos = base + __popcll(cm & ((1ull << lane) - 1ull));
-            A.ev_out->idx[pos] = (int32_t)j;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) A.ev_out->delta[t][pos] = dd[t];
-            reinterpret_cast<int*>(smem + SM.log_off)[pos] = c;
-        }
+        if (changed) reinterpret_cast<int*>(smem + SM.log_off)[base + __popcll(cm & ((1ull << lane) - 1ull))] = c;
         base += __popcll(cm);
     }
-    if (lane == 0) {
-        A.ev_out->count = base;
-        wcnt_s[15] = base;
-        atomicAdd(&A.counters[0], (unsigned long long)base);
-        const long long tk5 = clock64();                      // phase cycle counts (diagnostics)
-        atomicAdd(&A.counters[2], (unsigned long long)(tk1 - tk0));
-        atomicAdd(&A.counters[4], (unsigned long long)(tk3 - tk1));
-        atomicAdd(&A.counters[5], (unsigned long long)(tk4 - tk3));
-        atomicAdd(&A.counters[6], (unsigned long long)(tk5 - tk4));
-        atomicAdd(&A.counters[7], (unsigned long long)nrounds);
-    }
+    if (lane == 0) wcnt_s[15] = base;
+    tk5 = clock64();
     }   // wave 0
     __syncthreads();
-    for (int c = tid; c < b; c += kStepThreads) {           // the block's state, all threads (beta / delta of every marker
+    const int nfin = wcnt_s[15];
+    if (A.b_next > 0) corr_phase<NT>(smem, SM, A, nfin);
+    // ---- global stores LAST (a barrier after a global store waits for the store): the change list for the next update
+    // role, then the block's state (beta / delta of every marker are new draws; alpha changes only where an event happened)
+    {
+        const int* fin = reinterpret_cast<const int*>(smem + SM.log_off);
+        for (int e = tid; e < nfin; e += kStepThreads) {
+            const int ce = fin[e];
+            A.ev_out->idx[e] = (int32_t)(j0 + ce);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {                       // are new draws; alpha changes only where an event happened)
+            for (int t = 0; t < NT; ++t) A.ev_out->delta[t][e] = astart[t * B + ce] - acur[t * B + ce];
+        }
+    }
+    for (int c = tid; c < b; c += kStepThreads) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
             const float a_fin = acur[t * B + c];
             if (a_fin != astart[t * B + c]) A.alpha[(int64_t)t * p + j0 + c] = a_fin;
             A.beta[(int64_t)t * p + j0 + c] = bcur[t * B + c];
             delta[(int64_t)t * p + j0 + c]  = dcur[t * B + c];
         }
     }
-    if (A.b_next > 0) corr_phase<NT>(smem, SM, A, wcnt_s[15]);
+    if (tid == 0) {
+        A.ev_out->count = nfin;
+        atomicAdd(&A.counters[0], (unsigned long long)nfin);
+        atomicAdd(&A.counters[2], (unsigned long long)(tk1 - tk0));      // phase cycle counts (diagnostics)
+        atomicAdd(&A.counters[4], (unsigned long long)(tk3 - tk1));
+        atomicAdd(&A.counters[5], (unsigned long long)(tk4 - tk3));
+        atomicAdd(&A.counters[6], (unsigned long long)(tk5 - tk4));
+        atomicAdd(&A.counters[7], (unsigned long long)nrounds);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1068,9 +1068,11 @@ static inline float dot8_f32(const float* a, const float* b, int64_t n)
 double orc_time_sweeps_team(int kind, const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
                             int t, float* r, int64_t ld_r, float* alpha, float* beta, void* delta,
                             const float* vare, const float* var_effect, const double* prior, const double* gamma,
-                            uint64_t seed, int sweeps, int nthreads)
+                            uint64_t seed, int sweeps, int nthreads, double max_seconds, int64_t* markers_done)
 {
     if (nthreads < 1) nthreads = 1;
+    volatile int stop = 0;                      /* set by thread 0 when max_seconds (> 0) have passed; read after the barrier */
+    volatile int64_t done = 0;
     if (kind < 0 || kind > 2 || t < 1 || t > ORC_MAXT || (kind != 2 && t != 1)) return -1.0;
     float Rinv[ORC_MAXT * ORC_MAXT] = {0}, Ginv[ORC_MAXT * ORC_MAXT] = {0};
     if (kind == 2 && (inv_small(vare, t, Rinv) || inv_small(var_effect, t, Ginv))) return -1.0;
@@ -1099,7 +1101,14 @@ double orc_time_sweeps_team(int kind, const float* X, int64_t n, int64_t p, int6
                 const float* x = X + j * ld;
                 float* mine = partial + ((size_t)(step & 1) * T + tid) * 16;
                 for (int k = 0; k < t; ++k) mine[k] = dot8_f32(x + lo, r + k * ld_r + lo, hi - lo);
-                team_wait(&bar, T, &sense);
+                if (tid == 0 && max_seconds > 0.0 && (step & 63) == 0) {
+                    struct timespec tn;
+                    clock_gettime(CLOCK_MONOTONIC, &tn);
+                    if ((double)(tn.tv_sec - t0.tv_sec) + 1e-9 * (double)(tn.tv_nsec - t0.tv_nsec) > max_seconds) stop = 1;
+                }
+                team_wait(&bar, T, &sense);                    /* (the flag written before the barrier is visible after it) */
+                if (stop) goto finished;
+                if (tid == 0) done = step + 1;
                 if (tid == 0 && pend_j >= 0) {                 /* every thread has finished reading the state of marker pend_j */
                     for (int k = 0; k < t; ++k) { alpha[k * p + pend_j] = pa[k]; if (kind != 1) { beta[k * p + pend_j] = pb[k]; ((float*)delta)[k * p + pend_j] = pd[k]; } }
                     if (kind == 1) ((int32_t*)delta)[pend_j] = pcls;
@@ -1125,12 +1134,14 @@ double orc_time_sweeps_team(int kind, const float* X, int64_t n, int64_t p, int6
                 for (int k = 0; k < t; ++k) if (a[k] != 0.0f) axpy_f32(a[k], x + lo, r + k * ld_r + lo, hi - lo);
             }
         team_wait(&bar, T, &sense);
+finished:
         if (tid == 0 && pend_j >= 0) {
             for (int k = 0; k < t; ++k) { alpha[k * p + pend_j] = pa[k]; if (kind != 1) { beta[k * p + pend_j] = pb[k]; ((float*)delta)[k * p + pend_j] = pd[k]; } }
             if (kind == 1) ((int32_t*)delta)[pend_j] = pcls;
         }
     }
     clock_gettime(CLOCK_MONOTONIC, &t1);
+    if (markers_done) *markers_done = done;
     free(partial);
     return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }

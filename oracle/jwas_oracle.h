@@ -217,11 +217,12 @@ double orc_time_bayesc_sweeps(const float* X, int64_t n, int64_t p, int64_t ld, 
 /* The same per-marker order for BayesC (kind 0), BayesR (1) and multi-trait sampler I (2), with the rows of
  * every dot / axpy split over a persistent team of `nthreads` threads meeting at one spin barrier per marker.
  * r: t x ld_r; alpha/beta/delta: t x p (BayesR: delta int32, beta unused); prior: &pi | pi[4] | log_prior[2^t].
- * Returns elapsed seconds (< 0: bad arguments). */
+ * max_seconds > 0 bounds the run (checked every 64 markers); *markers_done = marker updates completed (sweeps * p if
+ * it ran to the end).  Returns elapsed seconds (< 0: bad arguments). */
 double orc_time_sweeps_team(int kind, const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
                             int t, float* r, int64_t ld_r, float* alpha, float* beta, void* delta,
                             const float* vare, const float* var_effect, const double* prior, const double* gamma,
-                            uint64_t seed, int sweeps, int nthreads);
+                            uint64_t seed, int sweeps, int nthreads, double max_seconds, int64_t* markers_done);
 
 #ifdef __cplusplus
 }

@@ -293,9 +293,11 @@ def time_bayesc_sweeps(X, xpx_, r, alpha, beta, delta, vare, var_effect, pi, see
                                         C.c_uint64(seed), C.c_int(sweeps), C.c_int(nthreads))
 
 
-def time_sweeps_team(kind, X, xpx_, r, alpha, beta, delta, vare, var_effect, prior, seed, sweeps, nthreads=1, gamma=GAMMA):
+def time_sweeps_team(kind, X, xpx_, r, alpha, beta, delta, vare, var_effect, prior, seed, sweeps, nthreads=1, gamma=GAMMA,
+                     max_seconds=0.0):
     """kind 0 = BayesC, 1 = BayesR, 2 = multi-trait sampler I; state arrays t x p (1-D for one trait), r t x ld_r.
-    Returns elapsed seconds of `sweeps` non-block sweeps with a persistent team of `nthreads` threads."""
+    Runs up to `sweeps` non-block sweeps with a persistent team of `nthreads` threads (stops after max_seconds if > 0).
+    Returns (elapsed seconds, marker updates completed)."""
     n, p, ld = _xinfo(X)
     r2 = r.reshape(1, -1) if r.ndim == 1 else r
     t = r2.shape[0]
@@ -305,10 +307,11 @@ def time_sweeps_team(kind, X, xpx_, r, alpha, beta, delta, vare, var_effect, pri
     g4 = np.ascontiguousarray(gamma, dtype=np.float64)
     assert r2.dtype == np.float32 and alpha.dtype == np.float32 and r2.flags.c_contiguous
     bt = beta if beta is not None else alpha
+    done = C.c_int64(0)
     el = lib().orc_time_sweeps_team(C.c_int(kind), _p(X, _f32p), C.c_int64(n), C.c_int64(p), C.c_int64(ld), _p(xpx_, _f32p),
                                     C.c_int(t), _p(r2, _f32p), C.c_int64(r2.shape[1]), _p(alpha, _f32p), _p(bt, _f32p),
                                     delta.ctypes.data_as(C.c_void_p), _p(ve, _f32p), _p(vg, _f32p), _p(pr, _f64p), _p(g4, _f64p),
-                                    C.c_uint64(seed), C.c_int(sweeps), C.c_int(nthreads))
+                                    C.c_uint64(seed), C.c_int(sweeps), C.c_int(nthreads), C.c_double(max_seconds), C.byref(done))
     if el < 0:
         raise ValueError("oracle timing helper rejected its arguments")
-    return el
+    return el, done.value

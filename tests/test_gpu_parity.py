@@ -99,6 +99,35 @@ def test_bayesc_chain_parity(hip, bs):
     _compare_state(orc, hip)
 
 
+@pytest.mark.parametrize("method,bs,pi", [("BayesC", 256, 0.6), ("BayesC", 512, 0.5), ("BayesC", 1024, 0.7), ("BayesC", 1024, 0.3),
+                                          ("BayesR", 512, 0.5), ("BayesR", 1024, 0.6)])
+def test_many_changes_per_block_parity(hip, method, bs, pi):
+    """Hundreds of effect changes per block: more than the change log holds (64 entries: flush + eager application), more
+    candidates than Gram rows fit in LDS (rows fetched on demand, overflow slot).  Still the sequential chain, bit for bit."""
+    data = make_dataset(n=500, p=2 * bs + 37, ncausal=40, seed=900 + bs)
+    orc, hip = _pair(hip, data, bs, method)
+    r0 = data["y"] - data["y"].mean()
+    orc.set_residual(r0)
+    hip.set_residual(r0)
+    vare, varg = _hyper(data, pi=pi)
+    if method == "BayesR":
+        kw = dict(var_effect=np.float32(0.02), pi_classes=np.array([pi, (1 - pi) * 0.5, (1 - pi) * 0.3, (1 - pi) * 0.2]))
+        for e in (orc, hip):
+            e.set_state(delta=np.ones(e.p, dtype=np.int32))
+    else:
+        kw = dict(var_effect=varg, pi=pi)
+    for it in range(1, 6):
+        so = orc.sweep(iteration=it, seed=13, vare=vare, **kw)
+        sh = hip.sweep(iteration=it, seed=13, vare=vare, **kw)
+        assert so["n_events"] == sh["n_events"], f"iteration {it}"
+    assert sh["n_events"] > 0.2 * hip.p
+    ao, _, do = orc.get_state()
+    ah, _, dh = hip.get_state()
+    assert np.array_equal(do, dh), f"indicator trajectories diverged at {np.flatnonzero(do != dh)[:5]}"
+    np.testing.assert_allclose(ah, ao, rtol=0, atol=5e-6)
+    np.testing.assert_allclose(hip.get_residual(), orc.get_residual(), rtol=0, atol=5e-5)
+
+
 def test_bayesc_all_included_pi0(hip, small_data):
     """Pi = 0: every marker is in the model every sweep (the reference benchmark's setting,
     benchmarks/jwas_nonblock_benchmark.jl:34-51): the dense-event path."""
