@@ -248,6 +248,28 @@ int  jwas_hip_window_sums2(jwas_hip_ctx* ctx, int32_t use_output_rows, int32_t n
 int  jwas_hip_set_kernel_timing(jwas_hip_ctx* ctx, int32_t stride);
 int  jwas_hip_sweep(jwas_hip_ctx* ctx, const jwas_sweep_params* params, jwas_sweep_stats* stats);
 
+/* ---- marker shards over the GPUs of one node (one context per GPU / process) -------------------------------
+ * The single-site chain is sequential in the marker index; what the reference ships for parallel blocks is
+ * independent_blocks=true (BayesABC.jl:190-255): every block starts from the same residual snapshot and the residual is
+ * reconciled once per sweep by r += sum_b X_b * (alpha_old_b - alpha_new_b) (BayesABC.jl:251-253).  These entry points
+ * are that mode with one "block" per GPU: the context holds the rank's marker columns (marker_offset = global index of
+ * its first column) and a replicated residual.
+ *   jwas_hip_comm_unique_id   rank 0 creates the 128-byte RCCL id (ncclGetUniqueId) and hands it to the other ranks by
+ *                             whatever means the host has (a file, a socket, MPI, torch.distributed ...);
+ *   jwas_hip_comm_init        every rank joins (ncclCommInitRank on the context's device; collective);
+ *   jwas_hip_sweep_sharded    jwas_hip_sweep on the own markers from the snapshot, then ON THE DEVICE, on the context's
+ *                             stream: delta r = fl64(r_local) - fl64(r_snapshot) and the packed marker statistics in one
+ *                             buffer, ONE ncclAllReduce(sum, fp64) over xGMI, r = fl32(r_snapshot + sum of delta r).
+ *                             On return every rank holds the same residual (jwas_hip_get_residual) and `stats` holds the
+ *                             ALL-RANK sums (sum_delta, alpha_ss, class / state counts, n_events ...) and the residual
+ *                             statistics of the reconciled residual.  Approximate unless X_g'X_h = 0 between shards
+ *                             (docs/src/manual/block_bayesc.md:95-134); world = 1 is the exact chain.
+ * librccl.so is loaded on first use (dlopen); a single-GPU host never needs it. */
+int  jwas_hip_comm_unique_id(void* id_out_128_bytes);
+int  jwas_hip_comm_init(jwas_hip_ctx* ctx, const void* unique_id_128_bytes, int32_t rank, int32_t world);
+int  jwas_hip_comm_destroy(jwas_hip_ctx* ctx);
+int  jwas_hip_sweep_sharded(jwas_hip_ctx* ctx, const jwas_sweep_params* params, jwas_sweep_stats* stats);
+
 /* ---- posterior accumulators (output.jl:568-577) ---------------------------------------------- */
 int  jwas_hip_accumulate(jwas_hip_ctx* ctx, double nsamples);
 int  jwas_hip_get_posterior(jwas_hip_ctx* ctx, int32_t trait, float* mean_alpha, float* mean_alpha2, float* mean_delta);

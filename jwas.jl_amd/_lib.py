@@ -30,6 +30,7 @@ SYMBOLS = [
     "jwas_hip_load_jgb2", "jwas_hip_load_packed2bit", "jwas_hip_alloc_packed2bit", "jwas_hip_storage_info",
     "jwas_hip_set_xpx", "jwas_hip_estimate_bytes_storage", "jwas_hip_add_block_size", "jwas_hip_select_block_size",
     "jwas_hip_set_weights", "jwas_hip_synth_single_step",
+    "jwas_hip_comm_unique_id", "jwas_hip_comm_init", "jwas_hip_comm_destroy", "jwas_hip_sweep_sharded",
 ]
 STORAGE_DENSE_F32, STORAGE_PACKED2BIT = 0, 1
 
@@ -124,6 +125,10 @@ def load():
     L.jwas_hip_window_sums.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp]
     L.jwas_hip_window_sums2.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.jwas_hip_sweep.argtypes = [vp, C.POINTER(SweepParams), C.POINTER(SweepStats)]
+    L.jwas_hip_sweep_sharded.argtypes = [vp, C.POINTER(SweepParams), C.POINTER(SweepStats)]
+    L.jwas_hip_comm_unique_id.argtypes = [vp]
+    L.jwas_hip_comm_init.argtypes = [vp, vp, i32, i32]
+    L.jwas_hip_comm_destroy.argtypes = [vp]
     L.jwas_hip_accumulate.argtypes = [vp, C.c_double]
     L.jwas_hip_get_posterior.argtypes = [vp, i32, vp, vp, vp]
     L.jwas_hip_load_jgb2.argtypes = [vp, C.c_char_p]

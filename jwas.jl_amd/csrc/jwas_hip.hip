@@ -82,6 +82,11 @@ struct jwas_hip_ctx {
     double last_events = -1.0;          // effect changes of the previous sweep (-1: none yet)
     double event_overhead_ms = 0.0;     // mean HIP-event interval around an empty launch (calibration)
     std::vector<hipEvent_t> kev;        // pairs of events around sampled k_update_partial launches
+    // marker-shard reconcile (jwas_hip_comm_init / jwas_hip_sweep_sharded): RCCL communicator on this context's device
+    void* comm = nullptr;               // ncclComm_t
+    int comm_rank = 0, comm_world = 1;
+    float* r_snap = nullptr;            // [kMaxT][ld] residual snapshot of the running sweep
+    double* shard_buf = nullptr;        // [kMaxT*ld + kShardStats] delta r (fp64) + packed marker statistics: ONE all-reduce
 };
 
 static constexpr int kStatGrid = 128;
@@ -212,6 +217,7 @@ void jwas_hip_destroy(jwas_hip_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->comm) (void)jwas_hip_comm_destroy(c);
     free_state(c); free_blocks(c); free_storage(c);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
@@ -272,6 +278,7 @@ static int alloc_storage(jwas_hip_ctx* c, int64_t n, int64_t p, bool packed = fa
     NEED(c, p < (1ll << 31), JWAS_HIP_EUNSUP, "p=%lld exceeds the 2^31 marker limit of one context", (long long)p);
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->comm) (void)jwas_hip_comm_destroy(c);                  // (its buffers are sized by the matrix)
     free_state(c); free_blocks(c); free_storage(c);
     c->method = -1; c->block_size = 0; c->nblocks = 0;
     c->n = n; c->p = p; c->ld = round_up(n, kSliceRows);
@@ -1160,6 +1167,93 @@ static int sweep_independent(jwas_hip_ctx* c, EventList* out)
     return JWAS_HIP_OK;
 }
 
+// ---- marker-shard reconcile across GPUs (BayesABC.jl:205-253 with one "block" per GPU) -----------
+// RCCL is bound lazily (dlopen) so that a single-GPU host never needs it.
+#include <dlfcn.h>
+namespace {
+constexpr int kShardStats = kNStat + 2;           // packed marker statistics + number of effect changes
+typedef struct { char internal[128]; } jw_nccl_id;                 // ncclUniqueId (NCCL_UNIQUE_ID_BYTES = 128)
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(jw_nccl_id*) = nullptr;
+    int (*CommInitRank)(void**, int, jw_nccl_id, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::string err;
+    bool load()
+    {
+        if (lib) return true;
+        for (const char* name : {"librccl.so.1", "librccl.so"}) {               // an RCCL the process already holds (e.g. torch's)
+            lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+            if (lib) break;
+        }
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            if (lib) break;
+            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        }
+        if (!lib) { err = std::string("cannot load librccl.so: ") + dlerror(); return false; }
+        GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
+        CommInitRank = reinterpret_cast<decltype(CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
+        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+        AllReduce = reinterpret_cast<decltype(AllReduce)>(dlsym(lib, "ncclAllReduce"));
+        GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+        if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllReduce || !GetErrorString) { err = "librccl.so lacks the NCCL entry points"; lib = nullptr; return false; }
+        return true;
+    }
+};
+Rccl g_rccl;
+constexpr int kNcclFloat64 = 8, kNcclSum = 0;      // ncclDataType_t::ncclDouble, ncclRedOp_t::ncclSum (rccl.h)
+}  // namespace
+
+// buf[k*ld + i] = fl64(r_local) - fl64(r_snapshot) for the t residual vectors; the last workgroup adds this rank's marker
+// statistics (the k_marker_stats partials summed in fixed order) and its number of effect changes behind them.
+__global__ __launch_bounds__(256) void k_shard_pack(int t, int64_t ld, const float* __restrict__ r_loc, const float* __restrict__ r_snap,
+                                                    const double* __restrict__ stat_out, int nstatgrid,
+                                                    const unsigned long long* __restrict__ counters, double* __restrict__ buf)
+{
+    const int64_t total = (int64_t)t * ld;
+    if (blockIdx.x == gridDim.x - 1) {
+        for (int v = threadIdx.x; v < kNStat; v += 256) {
+            double sum = 0.0;
+            for (int g = 0; g < nstatgrid; ++g) sum += stat_out[(int64_t)g * kNStat + v];
+            buf[total + v] = sum;
+        }
+        if (threadIdx.x == 0) { buf[total + kNStat] = (double)counters[0]; buf[total + kNStat + 1] = 0.0; }
+        return;
+    }
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < total) buf[i] = (double)r_loc[i] - (double)r_snap[i];
+}
+
+// r = fl32(r_snapshot + sum over ranks of delta r)  (BayesABC.jl:251-253) and the residual statistics of the reconciled
+// residual (the k_finish reductions).  grid = nslices, block = 256: one row per thread.
+template <int NT>
+__global__ __launch_bounds__(256) void k_shard_apply(const float* __restrict__ w, int64_t ld, const float* __restrict__ r_snap,
+                                                     const double* __restrict__ buf, float* __restrict__ r_out, double* __restrict__ out)
+{
+    __shared__ double red[4 * (NT * NT + NT)];
+    const int64_t row = (int64_t)blockIdx.x * kSliceRows + threadIdx.x;
+    float rv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        rv[t] = (float)((double)r_snap[t * ld + row] + buf[t * ld + row]);
+        r_out[t * ld + row] = rv[t];
+    }
+    const double wr = (double)w[row];
+    double v[NT * NT + NT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a) {
+#pragma unroll
+        for (int c = 0; c < NT; ++c) v[a * NT + c] = ((double)rv[a] * (double)rv[c]) * wr;
+        v[NT * NT + a] = (double)rv[a] * wr;
+    }
+    block_sum<NT * NT + NT>(v, red, 4);
+    if (threadIdx.x == 0)
+#pragma unroll
+        for (int i = 0; i < NT * NT + NT; ++i) out[(int64_t)blockIdx.x * (NT * NT + NT) + i] = v[i];
+}
+
 extern "C" {
 
 int jwas_hip_set_kernel_timing(jwas_hip_ctx* c, int32_t stride)
@@ -1190,9 +1284,12 @@ int jwas_hip_set_kernel_timing(jwas_hip_ctx* c, int32_t stride)
     return JWAS_HIP_OK;
 }
 
-int jwas_hip_sweep(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_sweep_stats* S)
+}  // extern "C"
+
+// Everything of a sweep up to the marker statistics, enqueued on the context's stream (no host synchronisation).
+static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* ntimed_out, double* timed_bytes_out)
 {
-    NEED(c, c && P && S, JWAS_HIP_EINVAL, "NULL argument");
+    NEED(c, c && P, JWAS_HIP_EINVAL, "NULL argument");
     NEED(c, c->method >= 0, JWAS_HIP_ESTATE, "jwas_hip_init_state has not been called");
     NEED(c, c->block_size, JWAS_HIP_ESTATE, "jwas_hip_setup_blocks has not been called");
     NEED(c, P->method == c->method && P->ntraits == c->ntraits, JWAS_HIP_EINVAL,
@@ -1371,6 +1468,17 @@ int jwas_hip_sweep(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_sweep_stats
         default: hipLaunchKernelGGL((k_marker_stats<4>), dim3(kStatGrid), dim3(256), 0, c->stream, c->method, c->p, c->alpha, c->beta, c->delta, gamma_dev, c->stat_out);
     }
     HIPCHK(c, hipGetLastError());
+    *ntimed_out = ntimed;
+    *timed_bytes_out = timed_bytes;
+    return JWAS_HIP_OK;
+}
+
+// Copies the reductions back and fills the statistics.  packed != NULL: the marker statistics come from the all-reduced
+// shard buffer (kShardStats doubles, device) instead of this context's own partials.
+static int sweep_collect(jwas_hip_ctx* c, jwas_sweep_stats* S, size_t ntimed, double timed_bytes, const double* packed_dev)
+{
+    const int t = c->ntraits;
+    const int nfin = t * t + t;
     HIPCHK(c, hipEventRecord(c->ev_stop, c->stream));
 
     double* h_fin = c->host_buf;
@@ -1379,6 +1487,8 @@ int jwas_hip_sweep(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_sweep_stats
     HIPCHK(c, hipMemcpyAsync(h_fin, c->fin_out, sizeof(double) * c->nslices * nfin, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(h_stat, c->stat_out, sizeof(double) * kStatGrid * kNStat, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(h_cnt, c->counters, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost, c->stream));
+    if (packed_dev)       // (reuses the head of the statistics staging area: row 0 = the all-rank sums)
+        HIPCHK(c, hipMemcpyAsync(h_stat, packed_dev, sizeof(double) * kShardStats, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
 
     std::memset(S, 0, sizeof *S);
@@ -1389,7 +1499,7 @@ int jwas_hip_sweep(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_sweep_stats
             S->resid_sum[a] += f[t * t + a];
         }
     }
-    for (int g = 0; g < kStatGrid; ++g) {
+    for (int g = 0; g < (packed_dev ? 1 : kStatGrid); ++g) {
         const double* v = h_stat + (size_t)g * kNStat;
         for (int a = 0; a < t; ++a) S->sum_delta[a] += v[a];
         for (int i = 0; i < t * t; ++i) { S->alpha_ss[i] += v[4 + i]; S->beta_ss[i] += v[20 + i]; }
@@ -1397,7 +1507,7 @@ int jwas_hip_sweep(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_sweep_stats
         S->bayesr_ssq += v[40]; S->bayesr_nnz += v[41];
         for (int q = 0; q < (1 << t) && q < kMaxStates; ++q) S->state_counts[q] += v[42 + q];
     }
-    S->n_events = (double)h_cnt[0];
+    S->n_events = packed_dev ? h_stat[kNStat] : (double)h_cnt[0];
     c->last_events = (double)h_cnt[0];
     if (std::getenv("JWAS_HIP_DEBUG_PHASES"))
         std::fprintf(stderr, "[jwas_hip] blocks=%lld events=%llu unstaged=%llu cycles: front=%llu cand=%llu stage=%llu serial=%llu write=%llu corr=%llu rounds=%llu slow_rounds=%llu\n",
@@ -1414,6 +1524,93 @@ int jwas_hip_sweep(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_sweep_stats
     S->update_kernel_bytes = timed_bytes;
     S->event_overhead_ms = c->event_overhead_ms;
     return JWAS_HIP_OK;
+}
+
+extern "C" {
+
+int jwas_hip_sweep(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_sweep_stats* S)
+{
+    NEED(c, c && P && S, JWAS_HIP_EINVAL, "NULL argument");
+    size_t ntimed = 0;
+    double timed_bytes = 0.0;
+    int rc = sweep_enqueue(c, P, &ntimed, &timed_bytes);
+    if (rc) return rc;
+    return sweep_collect(c, S, ntimed, timed_bytes, nullptr);
+}
+
+// ---- marker shards over the GPUs of a node ---------------------------------------------------------------
+int jwas_hip_comm_unique_id(void* id_out_128)
+{
+    if (!id_out_128) return fail(nullptr, JWAS_HIP_EINVAL, "jwas_hip_comm_unique_id: NULL argument");
+    if (!g_rccl.load()) return fail(nullptr, JWAS_HIP_EUNSUP, "%s", g_rccl.err.c_str());
+    jw_nccl_id id;
+    const int r = g_rccl.GetUniqueId(&id);
+    if (r != 0) return fail(nullptr, JWAS_HIP_EHIP, "ncclGetUniqueId: %s", g_rccl.GetErrorString(r));
+    std::memcpy(id_out_128, &id, sizeof id);
+    return JWAS_HIP_OK;
+}
+
+int jwas_hip_comm_init(jwas_hip_ctx* c, const void* unique_id_128, int32_t rank, int32_t world)
+{
+    NEED(c, c && unique_id_128, JWAS_HIP_EINVAL, "NULL argument");
+    NEED(c, world >= 1 && rank >= 0 && rank < world, JWAS_HIP_EINVAL, "rank %d outside [0,%d)", rank, world);
+    NEED(c, HAVE_STORAGE(c), JWAS_HIP_ESTATE, "load this rank's marker columns first");
+    NEED(c, !c->comm, JWAS_HIP_ESTATE, "a communicator is already attached (jwas_hip_comm_destroy first)");
+    NEED(c, g_rccl.load(), JWAS_HIP_EUNSUP, "%s", g_rccl.err.c_str());
+    HIPCHK(c, hipSetDevice(c->device));
+    jw_nccl_id id;
+    std::memcpy(&id, unique_id_128, sizeof id);
+    const int r = g_rccl.CommInitRank(&c->comm, world, id, rank);
+    if (r != 0) { c->comm = nullptr; return fail(c, JWAS_HIP_EHIP, "ncclCommInitRank(rank %d of %d): %s", rank, world, g_rccl.GetErrorString(r)); }
+    c->comm_rank = rank; c->comm_world = world;
+    HIPCHK(c, hipMalloc(&c->r_snap, sizeof(float) * (size_t)kMaxT * c->ld));
+    HIPCHK(c, hipMalloc(&c->shard_buf, sizeof(double) * ((size_t)kMaxT * c->ld + kShardStats)));
+    return JWAS_HIP_OK;
+}
+
+int jwas_hip_comm_destroy(jwas_hip_ctx* c)
+{
+    NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
+    if (!c->comm) return JWAS_HIP_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    (void)g_rccl.CommDestroy(c->comm);
+    c->comm = nullptr; c->comm_world = 1; c->comm_rank = 0;
+    (void)hipFree(c->r_snap); (void)hipFree(c->shard_buf);
+    c->r_snap = nullptr; c->shard_buf = nullptr;
+    return JWAS_HIP_OK;
+}
+
+// One sweep of this rank's marker shard + the reconcile of BayesABC.jl:205-253 with one "block" per GPU, all on the
+// context's stream: snapshot r, sweep the own markers (exact blocked chain from the snapshot), pack
+// (fl64(r_local) - fl64(r_snapshot), marker statistics), ONE ncclAllReduce(sum, fp64), r = fl32(r_snapshot + sum).
+// On return every rank holds the same residual and the same all-rank statistics.
+int jwas_hip_sweep_sharded(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_sweep_stats* S)
+{
+    NEED(c, c && P && S, JWAS_HIP_EINVAL, "NULL argument");
+    NEED(c, c->comm, JWAS_HIP_ESTATE, "jwas_hip_comm_init has not been called");
+    NEED(c, c->method >= 0, JWAS_HIP_ESTATE, "jwas_hip_init_state has not been called");
+    const int t = c->ntraits;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(c->r_snap, c->r, sizeof(float) * (size_t)t * c->ld, hipMemcpyDeviceToDevice, c->stream));
+    size_t ntimed = 0;
+    double timed_bytes = 0.0;
+    int rc = sweep_enqueue(c, P, &ntimed, &timed_bytes);
+    if (rc) return rc;
+    const int64_t total = (int64_t)t * c->ld;
+    hipLaunchKernelGGL(k_shard_pack, dim3((unsigned)((total + 255) / 256 + 1)), dim3(256), 0, c->stream, t, c->ld, c->r, c->r_snap,
+                       c->stat_out, kStatGrid, c->counters, c->shard_buf);
+    HIPCHK(c, hipGetLastError());
+    const int r = g_rccl.AllReduce(c->shard_buf, c->shard_buf, (size_t)(total + kShardStats), kNcclFloat64, kNcclSum, c->comm, c->stream);
+    if (r != 0) return fail(c, JWAS_HIP_EHIP, "ncclAllReduce: %s", g_rccl.GetErrorString(r));
+    switch (t) {
+        case 1: hipLaunchKernelGGL((k_shard_apply<1>), dim3(c->nslices), dim3(256), 0, c->stream, c->w, c->ld, c->r_snap, c->shard_buf, c->r, c->fin_out); break;
+        case 2: hipLaunchKernelGGL((k_shard_apply<2>), dim3(c->nslices), dim3(256), 0, c->stream, c->w, c->ld, c->r_snap, c->shard_buf, c->r, c->fin_out); break;
+        case 3: hipLaunchKernelGGL((k_shard_apply<3>), dim3(c->nslices), dim3(256), 0, c->stream, c->w, c->ld, c->r_snap, c->shard_buf, c->r, c->fin_out); break;
+        default: hipLaunchKernelGGL((k_shard_apply<4>), dim3(c->nslices), dim3(256), 0, c->stream, c->w, c->ld, c->r_snap, c->shard_buf, c->r, c->fin_out);
+    }
+    HIPCHK(c, hipGetLastError());
+    return sweep_collect(c, S, ntimed, timed_bytes, c->shard_buf + total);
 }
 
 // ---- posterior accumulators ---------------------------------------------------------------------------

@@ -10,7 +10,9 @@ the residual is reconciled once per sweep by summing the blocks' X_b * delta_alp
     the residual r (n*t floats) is REPLICATED;
     per sweep: every rank sweeps its own markers exactly (blocked single-site chain, one pass)
     starting from the same r, forms  dr_g = r_local - r_snapshot,  and one all-reduce(sum) of dr
-    (RCCL over xGMI with the nccl backend; gloo on CPU for tests) gives  r = r_snapshot + sum_g dr_g.
+    gives  r = r_snapshot + sum_g dr_g.  With the nccl backend and a HipEngine all of that runs INSIDE the library
+    (jwas_hip_comm_init / jwas_hip_sweep_sharded: HIP kernels + ncclAllReduce over xGMI on the context's stream) and this
+    class only hands the RCCL id around; the numpy form below serves the CPU tests (gloo) and non-HIP engines.
     The O(p) reductions the host draws need (sum delta, alpha'alpha, class/state counts) are summed in
     the same exchange.
 
@@ -42,12 +44,20 @@ class MarkerShard:
         self._dev = None
         self._coll = world > 1 or force_collective      # force_collective: exercise the exchange with one rank (tests)
         self._stream_set = False
+        self._lib_comm = False
         if self._coll:
             import torch
             import torch.distributed as dist
             self._torch, self._dist = torch, dist
             if dist.get_backend(group) == "nccl":
                 self._dev = torch.device("cuda", torch.cuda.current_device())
+                if hasattr(engine, "comm_init"):
+                    # the reconcile runs inside the library (jwas_hip_sweep_sharded: pack kernel, ncclAllReduce on the
+                    # context's stream, apply kernel); torch.distributed only hands the 128-byte RCCL id around
+                    box = [engine.comm_unique_id() if self.rank == 0 else None]
+                    dist.broadcast_object_list(box, src=0, group=group)
+                    engine.comm_init(box[0], self.rank, self.world)
+                    self._lib_comm = True
 
     def allreduce_sum(self, arr):
         """Sum a numpy array over ranks (deterministic: every rank receives the same bits)."""
@@ -67,6 +77,11 @@ class MarkerShard:
         all-reduce that also carries the packed O(p) statistics."""
         eng = self.engine
         t = r_snapshot.shape[0]
+        if self._lib_comm:
+            for k in range(t):
+                eng.set_residual(r_snapshot[k], k)
+            st = eng.sweep_sharded(marker_offset=self.lo, **params)      # all-rank statistics, reconciled residual
+            return np.stack([eng.get_residual(k) for k in range(t)]), st
         if self._dev is not None:
             return self._sweep_device(r_snapshot, **params)
         for k in range(t):

@@ -323,9 +323,34 @@ class HipEngine:
         return out
 
     # -- the sweep -------------------------------------------------------------------------------
+    # -- marker shards over GPUs (jwas_hip_comm_* / jwas_hip_sweep_sharded) ------------------------------
+    @staticmethod
+    def comm_unique_id():
+        """128 bytes identifying a new RCCL communicator (rank 0 creates it, every rank passes it to comm_init)."""
+        buf = (C.c_char * 128)()
+        L = _lib.load()
+        rc = L.jwas_hip_comm_unique_id(C.cast(buf, C.c_void_p))
+        if rc != 0:
+            raise JwasHipError(rc, L.jwas_hip_last_error(None).decode())
+        return bytes(buf)
+
+    def comm_init(self, unique_id, rank, world):
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        self._chk(self._L.jwas_hip_comm_init(self._h, C.cast(buf, C.c_void_p), int(rank), int(world)))
+        self._comm = True
+
+    def comm_destroy(self):
+        self._chk(self._L.jwas_hip_comm_destroy(self._h))
+        self._comm = False
+
+    def sweep_sharded(self, **params):
+        """sweep() on this rank's markers + the on-device reconcile (one RCCL all-reduce of delta r and the packed
+        statistics); the returned statistics are the all-rank sums, the residual (get_residual) is the reconciled one."""
+        return self.sweep(_sharded=True, **params)
+
     def sweep(self, *, iteration, seed, vare, var_effect, pi=0.0, pi_classes=None, gamma=BAYESR_GAMMA,
               log_prior_states=None, var_effect_vec=None, pi_vec=None, pi_matrix=None, nreps=1,
-              marker_offset=0, independent_blocks=False):
+              marker_offset=0, independent_blocks=False, _sharded=False):
         """One marker sweep.  Argument meaning follows BayesABC!/BayesR!/MTBayesABC!:
         vare: residual variance (scalar or t x t); var_effect: marker effect variance (BayesC scalar,
         BayesR sigmaSq, MT t x t); pi: Pr(effect = 0) scalar, or pi_vec per marker (length p, else the
@@ -406,7 +431,7 @@ class HipEngine:
                     P.log_prior_states[k] = float(lp[k])
         self._keep = keep
         S = SweepStats()
-        self._chk(self._L.jwas_hip_sweep(self._h, C.byref(P), C.byref(S)))
+        self._chk((self._L.jwas_hip_sweep_sharded if _sharded else self._L.jwas_hip_sweep)(self._h, C.byref(P), C.byref(S)))
         return {
             "sum_delta": np.array(S.sum_delta[:t]),
             "alpha_ss": np.array(S.alpha_ss[:t * t]).reshape(t, t),

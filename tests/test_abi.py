@@ -71,3 +71,49 @@ def test_package_never_imports_the_oracle():
                 for pat in (r"#\s*include[^\n]*oracle", r"^\s*(import|from)\s+oracle", r"libjwas_oracle", r"oracle_engine",
                             r"dlopen[^\n]*oracle", r"CDLL[^\n]*oracle"):
                     assert not re.search(pat, src, flags=re.M), (f, pat)
+
+
+def test_julia_struct_layout(tmp_path):
+    """julia/JWASHip.jl mirrors jwas_sweep_params / jwas_sweep_stats as isbits structs.  Julia is absent here, so the
+    struct definitions are parsed and their C layout (natural alignment -- what an isbits Julia struct has) is compared
+    with gcc's offsetof / sizeof of the header's structs: a field-order or length slip would corrupt silently."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "julia", "JWASHip.jl")).read()
+    size = {"Int32": 4, "UInt32": 4, "UInt64": 8, "Int64": 8, "Float32": 4, "Float64": 8}
+
+    def layout(name):
+        body = re.search(r"struct %s\n(.*?)\nend" % name, src, re.S).group(1)
+        off, fields, maxal = 0, [], 1
+        for line in body.strip().splitlines():
+            fname, ftype = [v.strip() for v in line.strip().split("::")]
+            m = re.match(r"NTuple\{(\d+),(\w+)\}", ftype)
+            if m:
+                cnt, el = int(m.group(1)), size[m.group(2)]
+            elif ftype.startswith("Ptr{"):
+                cnt, el = 1, 8
+            else:
+                cnt, el = 1, size[ftype]
+            off = (off + el - 1) // el * el
+            fields.append((fname, off))
+            off += cnt * el
+            maxal = max(maxal, el)
+        return fields, (off + maxal - 1) // maxal * maxal
+
+    prog = ["#include <stdio.h>", "#include <stddef.h>", '#include "jwas_hip.h"', "int main(void){"]
+    expect = []
+    for jl, cname in (("HipSweepParams", "jwas_sweep_params"), ("HipSweepStats", "jwas_sweep_stats")):
+        fields, total = layout(jl)
+        for fname, off in fields:
+            prog.append(f'printf("%zu\\n", offsetof({cname}, {fname}));')
+            expect.append(off)
+        prog.append(f'printf("%zu\\n", sizeof({cname}));')
+        expect.append(total)
+    prog.append("return 0;}")
+    cfile = tmp_path / "layout.c"
+    cfile.write_text("\n".join(prog))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(root, "include"), str(cfile), "-o", str(exe)])
+    got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    assert got == expect

@@ -265,6 +265,49 @@ print("NCCL_ONE_RANK_OK")
     assert out.returncode == 0 and "NCCL_ONE_RANK_OK" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
 
 
+def test_library_sharded_sweep_single_rank():
+    """jwas_hip_comm_init / jwas_hip_sweep_sharded through the C ABI with a one-rank RCCL communicator: the on-device
+    reconcile (pack kernel, ncclAllReduce, apply kernel) must reproduce the plain sweep up to the fp32 rounding of
+    snapshot + (local - snapshot), with identical statistics."""
+    import jwas_jl_amd as J
+    d = make_dataset(n=700, p=900, ncausal=6, seed=18)
+    r0 = (d["y"] - d["y"].mean()).astype(np.float32)
+    outs = []
+    for sharded in (False, True):
+        e = J.HipEngine(0)
+        e.load_dense(d["X"]); e.setup_blocks(256, "f64"); e.init_state("BayesC")
+        e.set_residual(r0)
+        if sharded:
+            e.comm_init(J.HipEngine.comm_unique_id(), 0, 1)
+        for it in range(1, 5):
+            fn = e.sweep_sharded if sharded else e.sweep
+            st = fn(iteration=it, seed=3, vare=np.float32(0.5), var_effect=np.float32(0.004), pi=0.9)
+        outs.append((e.get_state()[0], e.get_residual(), st))
+        e.close()
+    (a0, r0_, s0), (a1, r1_, s1) = outs
+    assert np.abs(a0 - a1).max() <= 1e-5 and np.abs(r0_ - r1_).max() <= 1e-5
+    assert s0["sum_delta"][0] == s1["sum_delta"][0] and s0["n_events"] == s1["n_events"]
+    assert s1["alpha_ss"][0, 0] == pytest.approx(s0["alpha_ss"][0, 0], rel=1e-4)
+    assert s1["resid_ss"][0, 0] == pytest.approx(float(r1_.astype(np.float64) @ r1_.astype(np.float64)), rel=1e-9)
+
+
+def test_two_rank_sharded_sweep_over_rccl(tmp_path):
+    """Two processes, two GPUs, the library's sharded sweep over RCCL (skipped on a one-GPU box): must equal the
+    single-process emulation -- two contexts on one GPU, delta r summed in fp64 on the host (a two-term sum does not
+    depend on the order) -- bit for bit."""
+    import subprocess
+    import sys
+    import os
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", REPO=repo)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29541", os.path.join(repo, "tests", "_dist_gpu_worker.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "TWO_RANK_RCCL_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 def test_heldout_ebv_gpu_matches_oracle(tmp_path):
     """Individuals with genotypes but no record: EBV = output_genotypes * alpha on the device
     (jwas_hip_load_output_dense_f32 / jwas_hip_mul_alpha_output; output.jl:281-306, tools4genotypes.jl:290-296)."""
