@@ -160,6 +160,10 @@ int  jwas_hip_storage_info(jwas_hip_ctx* ctx, int32_t* kind, int64_t* n, int64_t
 int  jwas_hip_dense_layout(jwas_hip_ctx* ctx, int64_t* n, int64_t* p, int64_t* ld_dev, void** X_dev);
 /* Copy columns [j0, j0+count) back to the host (column-major, ld = n). */
 int  jwas_hip_get_columns(jwas_hip_ctx* ctx, int64_t j0, int64_t count, float* out_host);
+/* Overwrite columns [j0, j0+count) of an allocated dense matrix from the host (column-major, column stride ld_host >= n):
+ * a matrix that is produced in marker chunks -- impute_genotypes (single_step/SSBR.jl:112-135: 1000 markers at a time) --
+ * goes to HBM chunk by chunk and never exists on the host as a whole.  Resident block configurations are dropped. */
+int  jwas_hip_set_columns(jwas_hip_ctx* ctx, int64_t j0, int64_t count, const float* cols_host, int64_t ld_host);
 /* Memory guard (tools4genotypes.jl:99-235 analogue for HBM): bytes the dense path needs. */
 int64_t jwas_hip_estimate_bytes(int64_t n, int64_t p, int32_t ntraits, int32_t block_size);
 /* Same for a given storage kind (estimate_marker_memory(...; storage_mode), tools4genotypes.jl:99-235). */
@@ -221,6 +225,10 @@ int  jwas_hip_residual_from_dev(jwas_hip_ctx* ctx, int32_t trait, const void* sr
 int  jwas_hip_residual_sub_xalpha(jwas_hip_ctx* ctx, int32_t trait);
 /* out = X * alpha_k (n floats, fp64-accumulated). */
 int  jwas_hip_mul_alpha(jwas_hip_ctx* ctx, int32_t trait, float* out_host);
+/* The nonzero effects of trait k as (marker index, value) lists in marker order, compacted on the device: one saved
+ * marker-effect sample as a sparse record instead of the reference's dense text row of p values (output.jl:443-526).
+ * idx / val: caller arrays of `capacity` entries (capacity >= p is always enough); *nnz = number of nonzero effects. */
+int  jwas_hip_get_alpha_sparse(jwas_hip_ctx* ctx, int32_t trait, int64_t capacity, int32_t* idx, float* val, int64_t* nnz);
 /* Rows for which EBVs are reported when they are not exactly the training rows (individuals without records, a
  * user's outputEBV(model, IDs) list): X_out is n_out x p marker-major fp32 with leading dimension ld_host, processed
  * (imputed / centred with the training column means) like the training matrix; copied. */

@@ -21,4 +21,7 @@ def __getattr__(name):
     if name in ("prepare_streaming_genotypes", "load_streaming_backend"):
         from . import streaming
         return getattr(streaming, name)
+    if name in ("samples", "single_step"):
+        import importlib
+        return importlib.import_module(f"{__name__}.{name}")
     raise AttributeError(name)

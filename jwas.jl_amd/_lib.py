@@ -30,7 +30,7 @@ SYMBOLS = [
     "jwas_hip_load_jgb2", "jwas_hip_load_packed2bit", "jwas_hip_alloc_packed2bit", "jwas_hip_storage_info",
     "jwas_hip_set_xpx", "jwas_hip_estimate_bytes_storage", "jwas_hip_add_block_size", "jwas_hip_select_block_size",
     "jwas_hip_set_weights", "jwas_hip_synth_single_step",
-    "jwas_hip_comm_unique_id", "jwas_hip_comm_init", "jwas_hip_comm_destroy", "jwas_hip_sweep_sharded",
+    "jwas_hip_set_columns", "jwas_hip_get_alpha_sparse", "jwas_hip_comm_unique_id", "jwas_hip_comm_init", "jwas_hip_comm_destroy", "jwas_hip_sweep_sharded",
 ]
 STORAGE_DENSE_F32, STORAGE_PACKED2BIT = 0, 1
 
@@ -100,6 +100,8 @@ def load():
     L.jwas_hip_alloc_dense_f32.argtypes = [vp, i64, i64]
     L.jwas_hip_dense_layout.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(vp)]
     L.jwas_hip_get_columns.argtypes = [vp, i64, i64, vp]
+    L.jwas_hip_set_columns.argtypes = [vp, i64, i64, vp, i64]
+    L.jwas_hip_get_alpha_sparse.argtypes = [vp, i32, i64, vp, vp, C.POINTER(i64)]
     L.jwas_hip_estimate_bytes.argtypes = [i64, i64, i32, i32]
     L.jwas_hip_estimate_bytes.restype = i64
     L.jwas_hip_synth_genotypes.argtypes = [vp, u64, i32, i32, i64]

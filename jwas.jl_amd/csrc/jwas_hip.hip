@@ -83,6 +83,8 @@ struct jwas_hip_ctx {
     double event_overhead_ms = 0.0;     // mean HIP-event interval around an empty launch (calibration)
     std::vector<hipEvent_t> kev;        // pairs of events around sampled k_update_partial launches
     // marker-shard reconcile (jwas_hip_comm_init / jwas_hip_sweep_sharded): RCCL communicator on this context's device
+    int32_t* cmp_idx = nullptr;         // [p] + [1] compacted nonzero effects of one trait (k_compact_alpha)
+    float* cmp_val = nullptr;           // [p]
     void* comm = nullptr;               // ncclComm_t
     int comm_rank = 0, comm_world = 1;
     float* r_snap = nullptr;            // [kMaxT][ld] residual snapshot of the running sweep
@@ -185,6 +187,7 @@ static void free_state(jwas_hip_ctx* c)
     (void)hipFree(c->mean_a); (void)hipFree(c->mean_a2); (void)hipFree(c->mean_d);
     (void)hipFree(c->prep_d); (void)hipFree(c->prep_f); c->prep_d = nullptr; c->prep_f = nullptr;
     (void)hipFree(c->mt2_tab); c->mt2_tab = nullptr;
+    (void)hipFree(c->cmp_idx); (void)hipFree(c->cmp_val); c->cmp_idx = nullptr; c->cmp_val = nullptr;
     c->alpha = c->beta = nullptr; c->delta = nullptr; c->mean_a = c->mean_a2 = c->mean_d = nullptr;
 }
 
@@ -536,6 +539,24 @@ int jwas_hip_get_columns(jwas_hip_ctx* c, int64_t j0, int64_t count, float* out)
     return JWAS_HIP_OK;
 }
 
+int jwas_hip_set_columns(jwas_hip_ctx* c, int64_t j0, int64_t count, const float* in, int64_t ld_host)
+{
+    NEED(c, c && in, JWAS_HIP_EINVAL, "NULL argument");
+    NEED(c, c->X != nullptr, JWAS_HIP_ESTATE, "allocate a dense matrix first (jwas_hip_alloc_dense_f32)");
+    NEED(c, j0 >= 0 && count >= 0 && j0 + count <= c->p, JWAS_HIP_EINVAL, "column range [%lld,%lld) outside [0,%lld)",
+         (long long)j0, (long long)(j0 + count), (long long)c->p);
+    NEED(c, ld_host >= c->n, JWAS_HIP_EINVAL, "ld_host (%lld) must be >= n (%lld)", (long long)ld_host, (long long)c->n);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (count == 0) return JWAS_HIP_OK;
+    if (c->ld != c->n)          // pad rows of these columns
+        HIPCHK(c, hipMemset2DAsync(c->X + j0 * c->ld + c->n, (size_t)4 * c->ld, 0, (size_t)4 * (c->ld - c->n), (size_t)count, c->stream));
+    HIPCHK(c, hipMemcpy2DAsync(c->X + j0 * c->ld, (size_t)4 * c->ld, in, (size_t)4 * ld_host, (size_t)4 * c->n, (size_t)count,
+                               hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    free_blocks(c);                                             // x'x and the Grams depend on the matrix
+    return JWAS_HIP_OK;
+}
+
 int jwas_hip_synth_genotypes(jwas_hip_ctx* c, uint64_t seed, int32_t kind, int32_t center, int64_t marker_offset)
 {
     NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
@@ -854,28 +875,30 @@ int jwas_hip_residual_sub_xalpha(jwas_hip_ctx* c, int32_t trait)
     return JWAS_HIP_OK;
 }
 
-// The nonzero effects of trait `trait` as device lists (marker order); *nnz = -1: dense enough that the plain
-// loop over all markers is the better kernel.
+// The nonzero effects of trait `trait` as device lists (marker order), compacted on the device; *nnz = -1: dense enough
+// that the plain loop over all markers is the better kernel.  The lists live in the context (not to be freed).
+static hipError_t compact_alpha(jwas_hip_ctx* c, int32_t trait, int* nnz)
+{
+    hipError_t e = hipSuccess;
+    if (!c->cmp_idx) {
+        e = hipMalloc(&c->cmp_idx, sizeof(int32_t) * ((size_t)c->p + 1));
+        if (e == hipSuccess) e = hipMalloc(&c->cmp_val, sizeof(float) * (size_t)c->p);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_compact_alpha, dim3(1), dim3(1024), 0, c->stream, c->p, c->alpha + (size_t)trait * c->p,
+                       c->cmp_idx, c->cmp_val, c->cmp_idx + c->p);
+    e = hipGetLastError();
+    int32_t cnt = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&cnt, c->cmp_idx + c->p, sizeof cnt, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    *nnz = (int)cnt;
+    return e;
+}
 static hipError_t sparse_alpha(jwas_hip_ctx* c, int32_t trait, int32_t** d_idx, float** d_val, int* nnz)
 {
-    *d_idx = nullptr; *d_val = nullptr; *nnz = -1;
-    std::vector<float> a((size_t)c->p);
-    hipError_t e = hipMemcpyAsync(a.data(), c->alpha + (size_t)trait * c->p, sizeof(float) * c->p, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (e != hipSuccess) return e;
-    std::vector<int32_t> idx; std::vector<float> val;
-    for (int64_t j = 0; j < c->p; ++j)
-        if (a[(size_t)j] != 0.f) {
-            idx.push_back((int32_t)j); val.push_back(a[(size_t)j]);
-            if ((int64_t)idx.size() * 4 > c->p) return hipSuccess;          // dense
-        }
-    *nnz = (int)idx.size();
-    if (*nnz == 0) return hipSuccess;
-    e = hipMalloc(d_idx, sizeof(int32_t) * idx.size());
-    if (e == hipSuccess) e = hipMalloc(d_val, sizeof(float) * val.size());
-    if (e == hipSuccess) e = hipMemcpyAsync(*d_idx, idx.data(), sizeof(int32_t) * idx.size(), hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(*d_val, val.data(), sizeof(float) * val.size(), hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);               // (the host vectors die with this frame)
+    hipError_t e = compact_alpha(c, trait, nnz);
+    *d_idx = c->cmp_idx; *d_val = c->cmp_val;
+    if (e == hipSuccess && (int64_t)*nnz * 4 > c->p) *nnz = -1;          // dense
     return e;
 }
 
@@ -888,7 +911,7 @@ int jwas_hip_mul_alpha(jwas_hip_ctx* c, int32_t trait, float* out)
     HIPCHK(c, hipMalloc(&tmp, sizeof(float) * c->ld));
     int32_t* d_idx = nullptr; float* d_val = nullptr; int nnz = -1;
     hipError_t e0 = sparse_alpha(c, trait, &d_idx, &d_val, &nnz);
-    if (e0 != hipSuccess) { (void)hipFree(tmp); (void)hipFree(d_idx); (void)hipFree(d_val); return fail(c, JWAS_HIP_EHIP, "jwas_hip_mul_alpha: %s", hipGetErrorString(e0)); }
+    if (e0 != hipSuccess) { (void)hipFree(tmp); return fail(c, JWAS_HIP_EHIP, "jwas_hip_mul_alpha: %s", hipGetErrorString(e0)); }
     with_cols(c, 0, [&](auto cx) {
         if (nnz >= 0)
             hipLaunchKernelGGL((k_mul_alpha_list<decltype(cx)>), dim3(c->nslices), dim3(256), 0, c->stream, cx, nnz, d_idx, d_val, tmp);
@@ -900,7 +923,7 @@ int jwas_hip_mul_alpha(jwas_hip_ctx* c, int32_t trait, float* out)
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(out, tmp, sizeof(float) * c->n, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(tmp); (void)hipFree(d_idx); (void)hipFree(d_val);
+    (void)hipFree(tmp);
     if (e != hipSuccess) return fail(c, JWAS_HIP_EHIP, "jwas_hip_mul_alpha: %s", hipGetErrorString(e));
     return JWAS_HIP_OK;
 }
@@ -908,6 +931,26 @@ int jwas_hip_mul_alpha(jwas_hip_ctx* c, int32_t trait, float* out)
 // Output rows: the reference keeps Mi.output_genotypes = Z_out * genotypes for mme.output_ID (all genotyped individuals by
 // default, input_data_validation.jl:150-154; tools4genotypes.jl:290-296) next to the training rows and forms
 // EBV = output_genotypes * alpha for every saved sample (output.jl:281-306).
+// One saved marker-effect sample as a sparse record (output.jl:443-526 writes the dense text row; with a sparse prior a
+// sample has a few hundred nonzero effects among 600 000).  idx / val: caller arrays of `capacity` entries, marker order.
+int jwas_hip_get_alpha_sparse(jwas_hip_ctx* c, int32_t trait, int64_t capacity, int32_t* idx, float* val, int64_t* nnz_out)
+{
+    NEED(c, c && nnz_out, JWAS_HIP_EINVAL, "NULL argument");
+    NEED_TRAIT(c, trait);
+    HIPCHK(c, hipSetDevice(c->device));
+    int nnz = 0;
+    HIPCHK(c, compact_alpha(c, trait, &nnz));
+    *nnz_out = nnz;
+    NEED(c, nnz <= capacity, JWAS_HIP_EINVAL, "%d nonzero effects do not fit the caller's %lld entries", nnz, (long long)capacity);
+    if (nnz > 0) {
+        NEED(c, idx && val, JWAS_HIP_EINVAL, "idx / val is NULL");
+        HIPCHK(c, hipMemcpyAsync(idx, c->cmp_idx, sizeof(int32_t) * nnz, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(val, c->cmp_val, sizeof(float) * nnz, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return JWAS_HIP_OK;
+}
+
 int jwas_hip_load_output_dense_f32(jwas_hip_ctx* c, const float* Xh, int64_t n_out, int64_t p, int64_t ld_host)
 {
     NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
@@ -940,7 +983,7 @@ int jwas_hip_mul_alpha_output(jwas_hip_ctx* c, int32_t trait, float* out)
     DenseCols cx{c->Xout, c->ld_out, nullptr, 0};
     int32_t* d_idx = nullptr; float* d_val = nullptr; int nnz = -1;
     hipError_t e0 = sparse_alpha(c, trait, &d_idx, &d_val, &nnz);
-    if (e0 != hipSuccess) { (void)hipFree(tmp); (void)hipFree(d_idx); (void)hipFree(d_val); return fail(c, JWAS_HIP_EHIP, "jwas_hip_mul_alpha_output: %s", hipGetErrorString(e0)); }
+    if (e0 != hipSuccess) { (void)hipFree(tmp); return fail(c, JWAS_HIP_EHIP, "jwas_hip_mul_alpha_output: %s", hipGetErrorString(e0)); }
     if (nnz >= 0)
         hipLaunchKernelGGL((k_mul_alpha_list<DenseCols>), dim3((unsigned)(c->ld_out / kSliceRows)), dim3(256), 0, c->stream, cx, nnz, d_idx, d_val, tmp);
     else
@@ -949,7 +992,7 @@ int jwas_hip_mul_alpha_output(jwas_hip_ctx* c, int32_t trait, float* out)
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(out, tmp, sizeof(float) * c->n_out, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(tmp); (void)hipFree(d_idx); (void)hipFree(d_val);
+    (void)hipFree(tmp);
     if (e != hipSuccess) return fail(c, JWAS_HIP_EHIP, "jwas_hip_mul_alpha_output: %s", hipGetErrorString(e));
     return JWAS_HIP_OK;
 }

@@ -1006,6 +1006,36 @@ __global__ __launch_bounds__(256) void k_mul_alpha_list(CX cx, int nnz, const in
     out[row] = (float)s;
 }
 
+// The nonzero effects of one trait as (index, value) lists in marker order.  grid = 1, block = 1024: the workgroup walks
+// the p effects 1024 at a time with a running offset (ballot + wave prefix), ~30 us at p = 600 000.
+__global__ __launch_bounds__(1024) void k_compact_alpha(int64_t p, const float* __restrict__ alpha, int32_t* __restrict__ idx,
+                                                        float* __restrict__ val, int32_t* __restrict__ count)
+{
+    __shared__ int wsum[16];
+    __shared__ int base_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    for (int64_t j0 = 0; j0 < p; j0 += 1024) {
+        const int64_t j = j0 + tid;
+        const float a = j < p ? alpha[j] : 0.f;
+        const bool nz = a != 0.f;
+        const unsigned long long m = __ballot(nz);
+        if (lane == 0) wsum[wave] = __popcll(m);
+        __syncthreads();
+        int pre = base_s, tot = 0;
+        for (int w = 0; w < 16; ++w) { if (w < wave) pre += wsum[w]; tot += wsum[w]; }
+        if (nz) {
+            const int pos = pre + __popcll(m & ((1ull << lane) - 1ull));
+            idx[pos] = (int32_t)j; val[pos] = a;
+        }
+        __syncthreads();
+        if (tid == 0) base_s += tot;
+        __syncthreads();
+    }
+    if (tid == 0) *count = base_s;
+}
+
 template <class CX>
 __global__ __launch_bounds__(256) void k_sub_xalpha(CX cx, int64_t p,
                                                     const float* __restrict__ alpha, float* __restrict__ r)

@@ -160,6 +160,14 @@ class HipEngine:
         self._chk(self._L.jwas_hip_get_columns(self._h, int(j0), int(count), _ptr(out)))
         return out
 
+    def set_columns(self, j0, cols):
+        """Overwrite columns [j0, j0 + cols.shape[1]) of an allocated dense matrix (n x count float32, any order)."""
+        cols = np.asfortranarray(cols, dtype=np.float32)
+        if cols.ndim != 2 or cols.shape[0] != self.n:
+            raise ValueError(f"column chunk must be {self.n} x count")
+        self._chk(self._L.jwas_hip_set_columns(self._h, int(j0), int(cols.shape[1]), _ptr(cols), self.n))
+        self.block_size = 0
+
     # -- precompute ------------------------------------------------------------------------------
     def setup_blocks(self, block_size=256, gram_mode="mfma"):
         mode = {"f64": _lib.GRAM_F64, "mfma": _lib.GRAM_MFMA}[gram_mode]
@@ -278,6 +286,21 @@ class HipEngine:
         out = np.empty(self.n, dtype=np.float32)
         self._chk(self._L.jwas_hip_mul_alpha(self._h, int(trait), _ptr(out)))
         return out
+
+    def alpha_sparse(self, trait=0):
+        """(idx int32, val float32): the nonzero effects of a trait in marker order, compacted on the device."""
+        cap = getattr(self, "_sparse_cap", 4096)
+        while True:
+            idx = np.empty(cap, dtype=np.int32)
+            val = np.empty(cap, dtype=np.float32)
+            nnz = C.c_int64(0)
+            rc = self._L.jwas_hip_get_alpha_sparse(self._h, int(trait), cap, _ptr(idx), _ptr(val), C.byref(nnz))
+            if rc == 0:
+                return idx[:nnz.value].copy(), val[:nnz.value].copy()
+            if nnz.value > cap:                      # grow and retry
+                cap = self._sparse_cap = int(min(self.p, max(2 * cap, nnz.value)))
+                continue
+            self._chk(rc)
 
     def load_output_dense(self, X_out):
         """Rows EBVs are reported for when they differ from the training rows (Mi.output_genotypes,

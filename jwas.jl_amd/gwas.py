@@ -15,6 +15,9 @@ import numpy as np
 
 def _read_samples(path, header=True):
     import pandas as pd
+    if str(path).endswith(".bin"):                  # binary sparse sample records (samples.py)
+        from .samples import read_dense
+        return read_dense(path)
     tab = pd.read_csv(path, header=0 if header else None)
     ids = [str(c) for c in tab.columns] if header else list(range(1, tab.shape[1] + 1))
     return tab.to_numpy(dtype=np.float64), ids

@@ -537,6 +537,11 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
     if write_marker_samples:
         for k, tr in enumerate(model.lhsVec):
             _open(f"marker_effects_{name}_{tr}", Mi.markerID)
+    # every saved sample also goes to a binary file of sparse records -- the nonzero effects compacted on the device
+    # (samples.py); the text row of p values (output.jl:467) only for small p or on request
+    from .samples import MarkerSampleWriter
+    bin_writers = [MarkerSampleWriter(os.path.join(output_folder, f"MCMC_samples_marker_effects_{name}_{tr}.bin"), Mi.markerID)
+                   for tr in model.lhsVec]
 
     t_sweep = 0.0
     iter_end = []                                # perf_counter at the end of every iteration (each ends synchronised with the device)
@@ -686,9 +691,16 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
                 files[f"marker_effects_variances_{name}"].write(",".join(repr(float(v)) for v in np.atleast_1d(Gval).ravel()) + "\n")
             if Mi.estimatePi and f"pi_{name}" in files:
                 files[f"pi_{name}"].write(",".join(repr(float(v)) for v in np.atleast_1d(pi_t if mega else pi)) + "\n")
-            if write_marker_samples:
-                for kk, tr in enumerate(model.lhsVec):
-                    a = engine.get_state(kk)[0]
+            for kk, tr in enumerate(model.lhsVec):
+                if hasattr(engine, "alpha_sparse"):
+                    si, sv = engine.alpha_sparse(kk)              # (idx, val) compacted on the device
+                else:
+                    a_ = engine.get_state(kk)[0]
+                    si = np.flatnonzero(a_).astype(np.int32); sv = a_[si]
+                bin_writers[kk].append(si, sv)
+                if write_marker_samples:
+                    a = np.zeros(p, dtype=np.float32)
+                    a[si] = sv
                     fh = files[f"marker_effects_{name}_{tr}"]
                     a.tofile(fh, sep=",", format="%.9g")          # text at C speed; 9 significant digits round-trip Float32
                     fh.write("\n")
@@ -713,6 +725,8 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
     wall = time.time() - t0
     for fh in files.values():
         fh.close()
+    for w_ in bin_writers:
+        w_.close()
 
     # ---- results (output.jl:108-212)
     out = {}

@@ -580,6 +580,28 @@ def test_accumulate_mul_alpha_sub_xalpha(hip, small_data):
         np.testing.assert_allclose(mh, mo, rtol=0, atol=1e-6)
 
 
+def test_alpha_sparse_and_set_columns(hip, small_data):
+    """jwas_hip_get_alpha_sparse: the nonzero effects compacted on the device (marker order) -- the binary sample record;
+    jwas_hip_set_columns: a matrix uploaded in column chunks equals the one uploaded at once."""
+    X = small_data["X"]
+    n, p = X.shape
+    hip.load_dense(X); hip.setup_blocks(64, "f64"); hip.init_state("BayesC")
+    rng = np.random.default_rng(5)
+    for frac in (0.0, 0.02, 0.6, 1.0):
+        a = np.where(rng.random(p) < frac, rng.standard_normal(p), 0.0).astype(np.float32)
+        hip.set_state(alpha=a)
+        idx, val = hip.alpha_sparse()
+        assert np.array_equal(idx, np.flatnonzero(a)) and np.array_equal(val, a[a != 0])
+        np.testing.assert_allclose(hip.mul_alpha(), X.astype(np.float64) @ a.astype(np.float64), atol=2e-4)
+    xpx = hip.xpx()
+    hip.alloc_dense(n, p)
+    for j0 in range(0, p, 100):
+        hip.set_columns(j0, X[:, j0:j0 + 100])
+    assert np.array_equal(hip.get_columns(0, p), X)
+    hip.setup_blocks(64, "f64")
+    assert np.array_equal(hip.xpx(), xpx)
+
+
 def test_state_machine_errors(hip, small_data):
     import jwas_jl_amd as J
     e = J.HipEngine(0)

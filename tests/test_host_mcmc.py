@@ -641,3 +641,32 @@ def test_auto_sampler_follows_the_support_of_pi(tmp_path):
         model = api.build_model("y1 = intercept + geno\ny2 = intercept + geno", np.eye(2))
         api.runMCMC(model, ph, chain_length=6, seed=1, output_folder=str(tmp_path / want), engine=Spy("block"), block_size=64, outputEBV=False)
         assert used["method"] == want
+
+
+def test_binary_marker_effect_samples_equal_the_text_rows(tmp_path):
+    """Every saved sample is also appended as a sparse (idx, val) record to MCMC_samples_marker_effects_<geno>_<trait>.bin
+    (samples.py); converting the file back gives the reference's text layout (output.jl:443-526) value for value, and the
+    window GWAS reads either file."""
+    from jwas_jl_amd import samples as S
+    d = make_dataset(n=120, p=150, ncausal=5, seed=4, center=False)
+    ids = [f"id{i}" for i in range(120)]
+    gdf = pd.DataFrame(d["raw"], columns=[f"snp{j}" for j in range(150)]); gdf.insert(0, "ID", ids)
+    ph = pd.DataFrame({"ID": ids, "y1": d["y"]})
+    geno = api.get_genotypes(gdf, method="BayesC", Pi=0.9)
+    model = api.build_model("y1 = intercept + geno")
+    folder = tmp_path / "b"
+    api.runMCMC(model, ph, chain_length=40, burnin=10, output_samples_frequency=3, seed=1, output_folder=str(folder),
+                engine=OracleEngine("block"), block_size=64)
+    txt = folder / "MCMC_samples_marker_effects_geno_y1.txt"
+    binf = folder / "MCMC_samples_marker_effects_geno_y1.bin"
+    ref = pd.read_csv(txt)
+    dense, mids = S.read_dense(str(binf))
+    assert mids == list(ref.columns) and dense.shape == ref.shape == (10, geno.nMarkers)
+    np.testing.assert_allclose(dense, ref.to_numpy(), rtol=1e-7)                  # (the text keeps 9 significant digits)
+    assert (dense != 0).sum() < 0.5 * dense.size                                   # sparse records
+    back = S.to_text(str(binf), str(folder / "back.txt"))
+    assert open(back).read() == open(txt).read()                                   # the converter reproduces the text file
+    from jwas_jl_amd.gwas import model_frequency
+    pd.testing.assert_frame_equal(model_frequency(str(binf)), model_frequency(str(txt)))
+    with pytest.raises(ValueError, match="not a binary marker-effect sample file"):
+        S.read_dense(str(txt))
