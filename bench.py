@@ -359,7 +359,12 @@ def main():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    if _ABANDONED_THREAD:
+        os._exit(0)                                  # a CPU-baseline leg is still stuck in native code: do not wait for it
+
+
+_ABANDONED_THREAD = False
 
 
 def via_api(eng, y, n, p, a, nsteps):
@@ -413,23 +418,56 @@ def cpu_baseline(a, eng, method, t, n, p_total, p_sub, Y, state, refbench):
         prior = np.array([0.0 if refbench else 0.95])
     R0 = np.ascontiguousarray(Y - Y.mean(axis=1, keepdims=True), dtype=np.float32)
 
-    res = {}
-    for threads in sorted({1, min(ncores, 16), ncores}):
+    import threading
+    res, notes = {}, []
+    # CPUs this process may actually use: the container's CFS quota (cgroup cpu.max) caps it below the logical core count
+    # on the GPU boxes (1 600 000 / 100 000 = 16 CPUs of 256 logical); threads beyond the quota only burn it and get the
+    # whole process throttled for the rest of every 100 ms period
+    usable = ncores
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            quota = float(txt[0]) if txt[0] != "max" else -1.0
+            period = float(txt[1]) if len(txt) > 1 else float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                usable = max(1, min(ncores, int(quota // period)))
+                notes.append(f"cgroup CPU quota {quota:.0f}/{period:.0f} us = {usable} usable CPUs")
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    # legs: 1 thread; a persistent team on all USABLE CPUs (one spin barrier per marker); when no quota hides cores, also
+    # ALL logical cores with one fork/join per dot / axpy -- what the reference's setting (BLAS threads = cores,
+    # jwas_nonblock_benchmark.jl:21-22) does per call
+    team = min(usable, 64)
+    legs = [(1, 1, "team")] + ([(team, team, "team")] if team > 1 else []) + ([(ncores, -ncores, "fork-join")] if (ncores > 1 and usable == ncores) else [])
+    for threads, arg, how in legs:
         al = np.zeros((t, p_sub), dtype=np.float32)
         be = np.zeros((t, p_sub), dtype=np.float32)
         de = np.ones((t, p_sub), dtype=np.int32 if method == "BayesR" else np.float32)
-        # up to 20 sweeps, bounded by --cpu-seconds of wall time per leg (a leg that does not finish 2 sweeps in that time
-        # -- hundreds of threads meeting at a barrier per marker -- is scaled from the marker updates it completed)
-        tt, done = O.time_sweeps_team(kind, X, xpx, R0.copy(), al, be, de, vare, G, prior, a.seed, 20, threads, max_seconds=a.cpu_seconds)
+        box = {}
+
+        def leg():
+            # up to 20 sweeps, bounded by --cpu-seconds of wall time per leg (a leg that does not finish a sweep in that
+            # time is scaled from the marker updates it completed)
+            box["r"] = O.time_sweeps_team(kind, X, xpx, R0.copy(), al, be, de, vare, G, prior, a.seed, 20, arg, max_seconds=a.cpu_seconds)
+        th = threading.Thread(target=leg, daemon=True)       # (guard: a leg that does not come back is abandoned, not waited for)
+        th.start()
+        th.join(timeout=4 * a.cpu_seconds + 30)
+        if th.is_alive() or "r" not in box:
+            notes.append(f"{threads} threads ({how}): did not return within {4 * a.cpu_seconds + 30:.0f} s, abandoned")
+            global _ABANDONED_THREAD
+            _ABANDONED_THREAD = True
+            break
+        tt, done = box["r"]
         done = max(int(done), 1)
-        res[threads] = (tt * p_sub / done, done / p_sub)
-        log(f"cpu baseline {threads} thread(s): {res[threads][0]:.3f} s per {p_sub}-marker sweep ({res[threads][1]:.2f} sweeps in {tt:.1f} s)")
+        res[threads] = (tt * p_sub / done, done / p_sub, how)
+        log(f"cpu baseline {threads} thread(s) [{how}]: {res[threads][0]:.3f} s per {p_sub}-marker sweep ({res[threads][1]:.2f} sweeps in {tt:.1f} s)")
     best = min(res, key=lambda k: res[k][0])
     per_sweep_full = res[best][0] * p_total / p_sub
-    detail = "; ".join(f"{k} thread(s): {v[0] * p_total / p_sub:.2f} s/sweep ({v[1]:.2f} sweeps of the sample timed)" for k, v in sorted(res.items()))
+    detail = "; ".join([f"{k} thread(s) [{v[2]}]: {v[0] * p_total / p_sub:.2f} s/sweep ({v[1]:.2f} sweeps of the sample timed)" for k, v in sorted(res.items())] + notes)
     return {"value": 1.0 / per_sweep_full, "unit": "iterations/s", "cores": best, "kind": "port",
             "sample": (f"non-block {method} sweeps over the first {p_sub} of {p_total} markers (n={n}), <= {a.cpu_seconds:.0f} s per leg, scaled linearly in p; "
-                       f"{detail}; host has {ncores} logical cores; sweep only, host updates excluded")}
+                       f"{detail}; host has {ncores} logical cores, {usable} usable; sweep only, host updates excluded")}
 
 
 if __name__ == "__main__":

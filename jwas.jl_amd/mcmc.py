@@ -545,6 +545,18 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
 
     t_sweep = 0.0
     iter_end = []                                # perf_counter at the end of every iteration (each ends synchronised with the device)
+    # The host step between two sweeps is a handful of O(n) vector operations.  A threaded BLAS runs them on every core and
+    # its workers keep spinning afterwards: in a container with a CPU quota that burns the quota and stalls the NEXT device
+    # call until the scheduler's next 100 ms period (measured: 78-100 ms per iteration instead of 21 at 50k x 600k).
+    # JWAS_HOST_BLAS_THREADS overrides (0 = leave the BLAS alone).
+    _blas_limit = None
+    try:
+        nthr = int(os.environ.get("JWAS_HOST_BLAS_THREADS", "1"))
+        if nthr > 0:
+            from threadpoolctl import threadpool_limits
+            _blas_limit = threadpool_limits(limits=nthr, user_api="blas")
+    except Exception:                            # threadpoolctl missing: nothing to limit with
+        _blas_limit = None
     t0 = time.time()
     # ================================ the chain =================================================
     for it in range(1, chain_length + 1):
@@ -723,6 +735,8 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
             print(f"\nPosterior means at iteration: {it}")
             print(f"Residual variance: {np.round(run_vare.mean, 6)}")
     wall = time.time() - t0
+    if _blas_limit is not None:
+        _blas_limit.restore_original_limits()
     for fh in files.values():
         fh.close()
     for w_ in bin_writers:

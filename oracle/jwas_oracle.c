@@ -1070,6 +1070,8 @@ double orc_time_sweeps_team(int kind, const float* X, int64_t n, int64_t p, int6
                             const float* vare, const float* var_effect, const double* prior, const double* gamma,
                             uint64_t seed, int sweeps, int nthreads, double max_seconds, int64_t* markers_done)
 {
+    const int forkjoin = nthreads < 0;          /* nthreads < 0: |nthreads| threads, one fork/join per dot / axpy (what a */
+    if (forkjoin) nthreads = -nthreads;         /* threaded BLAS does per call) instead of a persistent team              */
     if (nthreads < 1) nthreads = 1;
     volatile int stop = 0;                      /* set by thread 0 when max_seconds (> 0) have passed; read after the barrier */
     volatile int64_t done = 0;
@@ -1077,6 +1079,38 @@ double orc_time_sweeps_team(int kind, const float* X, int64_t n, int64_t p, int6
     float Rinv[ORC_MAXT * ORC_MAXT] = {0}, Ginv[ORC_MAXT * ORC_MAXT] = {0};
     if (kind == 2 && (inv_small(vare, t, Rinv) || inv_small(var_effect, t, Ginv))) return -1.0;
     const float ie = 1.0f / vare[0];
+    if (forkjoin) {
+        struct timespec f0, f1;
+        clock_gettime(CLOCK_MONOTONIC, &f0);
+        int64_t step = 0;
+        int out_of_time = 0;
+        for (int it = 0; it < sweeps && !out_of_time; ++it)
+            for (int64_t j = 0; j < p; ++j, ++step) {
+                if (max_seconds > 0.0 && (step & 15) == 0) {
+                    clock_gettime(CLOCK_MONOTONIC, &f1);
+                    if ((double)(f1.tv_sec - f0.tv_sec) + 1e-9 * (double)(f1.tv_nsec - f0.tv_nsec) > max_seconds) { out_of_time = 1; break; }
+                }
+                const float* x = X + j * ld;
+                float s[ORC_MAXT], a[ORC_MAXT];
+                for (int k = 0; k < t; ++k) s[k] = dot_f32_mt(x, r + k * ld_r, n, nthreads);
+                const uint32_t m = (uint32_t)j, iter = (uint32_t)it + 1u;
+                if (kind == 0) {
+                    const double u = orc_uniform(seed, m, iter, 0, 0), z = orc_normal(seed, m, iter, 0, 0);
+                    a[0] = abc_update(s[0], xpx[j], &alpha[j], &beta[j], &((float*)delta)[j], ie, var_effect[0], prior[0], u, z);
+                } else if (kind == 1) {
+                    const double u = orc_uniform(seed, m, iter, 0, 0), z = orc_normal(seed, m, iter, 0, 0);
+                    a[0] = bayesr_update(s[0], xpx[j], &alpha[j], &((int32_t*)delta)[j], ie, var_effect[0], prior, gamma, u, z);
+                } else {
+                    float w[ORC_MAXT];
+                    for (int k = 0; k < t; ++k) w[k] = s[k] + xpx[j] * alpha[k * p + j];
+                    mt1_update(t, w, xpx[j], alpha + j, beta + j, (float*)delta + j, p, Rinv, Ginv, prior, seed, m, iter, 0, a);
+                }
+                for (int k = 0; k < t; ++k) if (a[k] != 0.0f) axpy_f32_mt(a[k], x, r + k * ld_r, n, nthreads);
+            }
+        clock_gettime(CLOCK_MONOTONIC, &f1);
+        if (markers_done) *markers_done = step;
+        return (double)(f1.tv_sec - f0.tv_sec) + 1e-9 * (double)(f1.tv_nsec - f0.tv_nsec);
+    }
     float* partial = (float*)aligned_alloc(64, (size_t)2 * nthreads * 16 * sizeof(float));   /* [2][T][16]: one line per thread */
     team_barrier bar; bar.count = 0; bar.sense = 0;
     struct timespec t0, t1;
