@@ -11,6 +11,8 @@ import os
 import sys
 
 root, timed_steps, pmc_steps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+wname = sys.argv[4] if len(sys.argv) > 4 else "config2"
+traffic = {}
 
 
 def find(sub, pat):
@@ -82,3 +84,21 @@ for tag, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
             fh.write(f"\"{k}\",{n},{v:.1f},{v / n:.2f}\n")
         fh.write(f"\"k_block_step: last {pmc_steps} sweeps (steady state)\",{len(last)},{sum(last):.1f},{sum(last) / max(1, len(last)):.2f}\n")
     print(tag, "steady-state per dispatch KB:", sum(last) / max(1, len(last)), "dispatches", len(last))
+    traffic[tag] = sum(last) / max(1, len(last))
+
+# HBM bytes per k_block_step launch for bench.py's roofline.traffic: FETCH_SIZE x 2 (the guide's gfx950 correction,
+# calibrated on k_xpx which reads X exactly once) + WRITE_SIZE, in KB -> bytes; keyed by the configuration it was measured on
+if "fetch" in traffic and "write" in traffic:
+    try:
+        b = json.loads(open(os.path.join(root, "bench_under_pmc_fetch.json")).read().strip().splitlines()[-1])
+        cfg = b["config"]
+        row = {"config": {"workload": cfg["name"], "n": cfg["n"], "p": cfg["p"], "block_size": cfg["block_size"], "storage": cfg["storage"],
+                          "n_gpus": b["n_gpus"], "pi_fixed": (0.95 if "fixed" in cfg["workload"] else None)},
+               "bytes_per_launch": (traffic["fetch"] * 2 + traffic["write"]) * 1024.0,
+               "fetch_KB_per_launch": traffic["fetch"], "write_KB_per_launch": traffic["write"],
+               "algorithmic_bytes_per_launch": b["roofline"]["bytes_per_launch"],
+               "source": f"profiles/<round>_{wname}_pmc_fetch_summary.csv + _pmc_write_summary.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, last {pmc_steps} sweeps)"}
+        json.dump(row, open(os.path.join(root, "traffic_row.json"), "w"), indent=1)
+        print(row)
+    except Exception as ex:                                     # noqa: BLE001
+        print("traffic row failed:", ex)
