@@ -362,7 +362,7 @@ def runMCMC(model, df, *, heterogeneous_residuals=False, chain_length=100, start
             memory_guard="error", memory_guard_ratio=0.80, output_folder="results",
             output_samples_for_all_parameters=False,
             # device options (the analogue of storage=:stream's opt-in knobs)
-            device=0, block_size=None, gram_mode="mfma", engine=None):
+            device=0, block_size=None, gram_mode="mfma", _engine=None):
     """JWAS.jl:161-511.  Returns the reference's output Dict (output.jl:108-212) as a dict of pandas
     DataFrames and writes the same text files under `output_folder`.
 
@@ -371,7 +371,8 @@ def runMCMC(model, df, *, heterogeneous_residuals=False, chain_length=100, start
     reference's fast_blocks schedule (block-size repetitions, chain_length rescaled, JWAS.jl:293-316).
     independent_blocks=True (needs fast_blocks): every block starts from the same residual snapshot and all blocks are
     sampled concurrently on the device (BayesABC.jl:190-255) -- the reference's approximate parallel mode.
-    `engine` injects a sweep engine (tests); the default and only shipped engine is HipEngine."""
+    `_engine` (private, not part of the reference's surface) lets the test-suite inject a sweep engine; the default and
+    only shipped engine is HipEngine."""
     if independent_blocks and fast_blocks is False:
         raise ValueError("independent_blocks=true requires fast_blocks != false.")             # :242-244
     for flag, name in ((single_step_analysis, "single_step_analysis"),
@@ -408,5 +409,5 @@ def runMCMC(model, df, *, heterogeneous_residuals=False, chain_length=100, start
                      output_folder=output_folder, printout_frequency=printout_frequency,
                      memory_guard=memory_guard, memory_guard_ratio=memory_guard_ratio,
                      missing_phenotypes=missing_phenotypes, device=device, block_size=block_size,
-                     gram_mode=gram_mode, engine=engine, printout_model_info=printout_model_info,
+                     gram_mode=gram_mode, engine=_engine, printout_model_info=printout_model_info,
                      output_samples_for_all_parameters=output_samples_for_all_parameters)

@@ -54,10 +54,21 @@ class MarkerShard:
                 if hasattr(engine, "comm_init"):
                     # the reconcile runs inside the library (jwas_hip_sweep_sharded: pack kernel, ncclAllReduce on the
                     # context's stream, apply kernel); torch.distributed only hands the 128-byte RCCL id around
-                    box = [engine.comm_unique_id() if self.rank == 0 else None]
-                    dist.broadcast_object_list(box, src=0, group=group)
-                    engine.comm_init(box[0], self.rank, self.world)
-                    self._lib_comm = True
+                    import os
+                    ok = 0
+                    if os.environ.get("JWAS_DIST_TORCH_RECONCILE", "0") == "0":
+                        try:
+                            box = [engine.comm_unique_id() if self.rank == 0 else None]
+                            dist.broadcast_object_list(box, src=0, group=group)
+                            engine.comm_init(box[0], self.rank, self.world)
+                            ok = 1
+                        except Exception as ex:                  # noqa: BLE001  (e.g. librccl.so not loadable)
+                            print(f"[jwas] library RCCL communicator not available on rank {self.rank} ({ex}); "
+                                  "falling back to the torch.distributed reconcile")
+                    # every rank must take the same path
+                    flag = torch.tensor([ok], device=self._dev)
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+                    self._lib_comm = bool(int(flag.item()))
 
     def allreduce_sum(self, arr):
         """Sum a numpy array over ranks (deterministic: every rank receives the same bits)."""

@@ -62,7 +62,7 @@ def build_windows(chr_, pos, window_size_bp, sliding_window):
 
 
 def GWAS(*args, window_size="1 Mb", sliding_window=False, GWAS=True, threshold=0.001, genetic_correlation=False,
-         local_EBV=False, header=True, output_winVarProps=False, output_folder=".", device=0, engine=None):
+         local_EBV=False, header=True, output_winVarProps=False, output_folder=".", device=0, _engine=None):
     """GWAS(marker_effects_file; header) or GWAS(model | genotype matrix, map_file, marker_effects_file...; ...)."""
     import pandas as pd
     if len(args) == 1:
@@ -109,6 +109,7 @@ def GWAS(*args, window_size="1 Mb", sliding_window=False, GWAS=True, threshold=0
     if GWAS:
         print(f"Compute the posterior probability of association of the genomic window that explains more than {threshold} "
               "of the total genetic variance.")
+    engine = _engine                              # (private: the test-suite injects a sweep engine)
     own = engine is None
     if own:
         from .engine import HipEngine

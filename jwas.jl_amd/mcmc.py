@@ -398,8 +398,10 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
             raise ValueError("fast_blocks block size must create at least two block starts.")
         # The schedule is the reference's for the REQUESTED size: `want` within-block repetitions (BayesABC.jl:153) and
         # chain_length / want outer iterations -- the same number of hyper-parameter updates and saved samples.  The
-        # device partition is uniform blocks of the next supported size >= want (any partition is an exact block Gibbs
-        # sampler); fewer markers than one device block run as a single block.
+        # device partition is uniform blocks of the NEAREST supported size (64 ... 1024; it may be smaller than `want`,
+        # e.g. 90 -> 64; any partition is an exact block Gibbs sampler); fewer markers than one device block run as a
+        # single block.  Deviation from the reference: every device block runs `want` repetitions, where the reference
+        # runs each block its own size (the last, shorter block fewer) -- DESIGN.md section 12.
         block_size = _supported_block(want)
         if not explicit_starts:
             chain_length = int(np.floor(chain_length / want))
@@ -434,6 +436,10 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
     if own_engine:
         from .engine import HipEngine
         need = HipEngine.estimate_bytes(n, p, t, block_size, "stream" if stream else "dense")
+        if adaptive:
+            need += 2 * 4 * 1024 * p                               # the second resident block size (Grams + cross-Grams)
+        if outputEBV and not out_same:                             # Mi.output_genotypes: a second dense matrix (n_out x p)
+            need += 4 * ((len(out_rows) + 255) // 256 * 256) * p
         engine = HipEngine(device)
         free = engine.device_info()["hbm_free"]
         if memory_guard != "off" and need > memory_guard_ratio * free:   # JWAS.jl:422-459 analogue for HBM

@@ -68,17 +68,24 @@ def _write_sidecars(prefix, n, p_all, selected, mean, afreq, xp, center, obs_ids
     return paths
 
 
-def _marker_summaries(cnt, s1, s2, n, quality_control, MAF, center):
+def _marker_summaries(cnt, s1, s2, n, quality_control, MAF, center, marker_ids=None):
     """per-marker mean / allele frequency / QC selection / x'x from the running sums (readgenotypes.jl:372-401,
     streaming_genotypes.jl:283-285)"""
-    mean = np.where(cnt > 0, s1 / np.maximum(cnt, 1), 0.0).astype(np.float32)
+    if np.any(cnt == 0):                                           # streaming_genotypes.jl:274-278
+        j = int(np.flatnonzero(cnt == 0)[0])
+        name = marker_ids[j] if marker_ids is not None else str(j + 1)
+        raise ValueError(f"Marker {name} has only missing values.")
+    mean = (s1 / cnt).astype(np.float32)
     afreq = (mean / np.float32(2.0)).astype(np.float32)
-    if quality_control:
-        var = np.where(cnt > 0, s2 / np.maximum(cnt, 1) - mean.astype(np.float64) ** 2, 0.0)
-        keep = (afreq >= MAF) & (afreq <= 1 - MAF) & (var > 0)
+    ss_centered = (s2 - mean.astype(np.float64) * s1).astype(np.float32)
+    if quality_control:                                            # strict inequalities in Float32 (:288-290)
+        maf32 = np.float32(MAF)
+        keep = (maf32 < afreq) & (afreq < np.float32(1.0) - maf32) & (ss_centered != np.float32(0.0))
     else:
         keep = np.ones(cnt.size, dtype=bool)
     selected = np.flatnonzero(keep)
+    if selected.size == 0:
+        raise ValueError("No markers remain after streaming genotype quality control.")          # :294-296
     mean, afreq = mean[selected], afreq[selected]
     mu = mean.astype(np.float64)
     xp = ((s2[selected] - mu * s1[selected]) if center else (s2[selected] + (n - cnt[selected]) * mu * mu)).astype(np.float32)
@@ -109,7 +116,7 @@ def _prepare_from_file_lowmem(path, prefix, *, separator, header, missing_value,
         _check_codes(vals)
         cnt += (~miss).sum(axis=0); s1 += vals.sum(axis=0); s2 += (vals * vals).sum(axis=0)
     n = len(obs_ids)
-    selected, mean, afreq, xp = _marker_summaries(cnt, s1, s2, n, quality_control, MAF, center)
+    selected, mean, afreq, xp = _marker_summaries(cnt, s1, s2, n, quality_control, MAF, center, marker_all)
     stride = (n + 3) // 4
     need = int(len(selected)) * stride
     free = shutil.disk_usage(os.path.dirname(prefix) or ".").free
@@ -182,18 +189,9 @@ def prepare_streaming_genotypes(genotypes, output_prefix=None, *, obs_ids=None, 
     cnt = (~miss).sum(axis=0)
     s1 = vals.sum(axis=0)
     s2 = (vals * vals).sum(axis=0)
-    mean = np.where(cnt > 0, s1 / np.maximum(cnt, 1), 0.0).astype(np.float32)
-    afreq = (mean / np.float32(2.0)).astype(np.float32)
-    if quality_control:                                             # readgenotypes.jl:388-399
-        var = np.where(cnt > 0, s2 / np.maximum(cnt, 1) - mean.astype(np.float64) ** 2, 0.0)
-        keep = (afreq >= MAF) & (afreq <= 1 - MAF) & (var > 0)
-    else:
-        keep = np.ones(p_all, dtype=bool)
-    selected = np.flatnonzero(keep)
-    mean, afreq = mean[selected], afreq[selected]
-    mu = mean.astype(np.float64)
-    # x'x of the centred, mean-imputed column: sum v^2 - mu*sum v over non-missing (streaming_genotypes.jl:283-285)
-    xp = ((s2[selected] - mu * s1[selected]) if center else (s2[selected] + (n - cnt[selected]) * mu * mu)).astype(np.float32)
+    # means, QC selection and x'x exactly as the file path computes them (x'x of the centred, mean-imputed column:
+    # sum v^2 - mu*sum v over non-missing, streaming_genotypes.jl:283-285)
+    selected, mean, afreq, xp = _marker_summaries(cnt, s1, s2, n, quality_control, MAF, center, marker_ids)
     codes = np.where(miss[:, selected], 3, vals[:, selected]).astype(np.uint8)
     payload = pack_2bit(codes)
     prefix = os.path.abspath(str(output_prefix))

@@ -30,7 +30,7 @@ def test_runmcmc_gpu_matches_oracle_chain(tmp_path, method, Pi):
         geno = api.get_genotypes(gdf, method=method, Pi=Pi)
         model = api.build_model("y1 = intercept + geno")
         outs[tag] = api.runMCMC(model, ph, chain_length=200, burnin=40, seed=2026, output_folder=str(tmp_path / tag),
-                                engine=eng, block_size=256, gram_mode="f64")
+                                _engine=eng, block_size=256, gram_mode="f64")
     eo = outs["orc"]["marker effects geno"]
     eh = outs["hip"]["marker effects geno"]
     np.testing.assert_allclose(eh["Estimate"], eo["Estimate"], atol=1e-4)
@@ -56,7 +56,7 @@ def test_config1_full_chain_gpu_vs_oracle(tmp_path, config1_data):
         geno = api.get_genotypes(gdf, method="BayesC", Pi=0.95, estimatePi=True)
         model = api.build_model("y1 = intercept + geno")
         outs[tag] = api.runMCMC(model, ph, chain_length=1000, burnin=100, seed=2026, outputEBV=False,
-                                output_folder=str(tmp_path / tag), engine=eng, block_size=256, gram_mode="f64")
+                                output_folder=str(tmp_path / tag), _engine=eng, block_size=256, gram_mode="f64")
     eo, eh = outs["orc"]["marker effects geno"], outs["hip"]["marker effects geno"]
     assert np.abs(eh["Estimate"] - eo["Estimate"]).max() <= 1e-4
     assert np.abs(eh["Model_Frequency"] - eo["Model_Frequency"]).max() <= 1e-4
@@ -84,7 +84,7 @@ def test_three_trait_chain_gpu_vs_oracle(tmp_path):
         geno = api.get_genotypes(gdf, method="BayesC", Pi=Pi, estimatePi=True)
         model = api.build_model("y1 = intercept + geno\ny2 = intercept + geno\ny3 = intercept + geno")
         outs[tag] = api.runMCMC(model, ph, chain_length=80, burnin=10, seed=11, outputEBV=False,
-                                output_folder=str(tmp_path / tag), engine=eng, block_size=128, gram_mode="f64")
+                                output_folder=str(tmp_path / tag), _engine=eng, block_size=128, gram_mode="f64")
     eo, eh = outs["orc"]["marker effects geno"], outs["hip"]["marker effects geno"]
     assert len(eh) == 3 * 450
     np.testing.assert_allclose(eh["Estimate"], eo["Estimate"], atol=1e-4)
@@ -320,7 +320,7 @@ def test_heldout_ebv_gpu_matches_oracle(tmp_path):
         geno = api.get_genotypes(gdf, method="BayesC", Pi=0.95)
         model = api.build_model("y1 = intercept + geno")
         outs[tag] = api.runMCMC(model, ph, chain_length=120, burnin=20, seed=9, output_folder=str(tmp_path / tag),
-                                engine=eng, block_size=128, gram_mode="f64")
+                                _engine=eng, block_size=128, gram_mode="f64")
     eo, eh = outs["orc"]["EBV_y1"], outs["hip"]["EBV_y1"]
     assert list(eh["ID"]) == list(eo["ID"]) == list(gdf["ID"])
     np.testing.assert_allclose(eh["EBV"], eo["EBV"], atol=1e-3)

@@ -39,7 +39,7 @@ def test_multi_seed_posterior_summaries_agree(tmp_path, method, Pi):
             geno = api.get_genotypes(gdf, method=method, Pi=Pi, estimatePi=True)
             model = api.build_model("y1 = intercept + geno")
             out = api.runMCMC(model, ph, chain_length=700, burnin=200, seed=seed + (1000 if tag == "orc" else 0),
-                              output_folder=str(tmp_path / f"{tag}{seed}"), engine=eng, **kw)
+                              output_folder=str(tmp_path / f"{tag}{seed}"), _engine=eng, **kw)
             if method == "BayesR":                      # pi_geno has 4 rows: use the null-class share
                 out["pi_geno"] = out["pi_geno"].iloc[[0]].reset_index(drop=True)
             acc[tag].append(_summaries(out))

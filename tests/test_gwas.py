@@ -56,7 +56,7 @@ def test_model_frequency_form(tmp_path):
 def test_window_gwas_matches_literal_restatement(tmp_path, sliding):
     X, samples, f, mapf, chrom, pos = _case(tmp_path, seed=3)
     res, props = GWAS(X, mapf, f, window_size="1 Mb", sliding_window=sliding, threshold=0.05, output_winVarProps=True,
-                      output_folder=str(tmp_path), engine=OracleEngine("dense"))
+                      output_folder=str(tmp_path), _engine=OracleEngine("dense"))
     tab = res[0]
     assert list(tab.columns) == ["trait", "window", "chr", "wStart", "wEnd", "start_SNP", "end_SNP", "numSNP", "estimateGenVar",
                                  "stdGenVar", "prGenVar", "WPPA", "PPA_t"]
@@ -77,8 +77,8 @@ def test_window_gwas_matches_literal_restatement(tmp_path, sliding):
 def test_window_size_format_and_fake_map(tmp_path):
     X, samples, f, mapf, _, _ = _case(tmp_path)
     with pytest.raises(ValueError, match='"1 Mb"'):
-        GWAS(X, mapf, f, window_size="1 kb", engine=OracleEngine("dense"), output_folder=str(tmp_path))
-    res = GWAS(X, False, f, window_size=8, engine=OracleEngine("dense"), output_folder=str(tmp_path))   # 8 markers per window
+        GWAS(X, mapf, f, window_size="1 kb", _engine=OracleEngine("dense"), output_folder=str(tmp_path))
+    res = GWAS(X, False, f, window_size=8, _engine=OracleEngine("dense"), output_folder=str(tmp_path))   # 8 markers per window
     assert list(res[0].sort_values("window")["numSNP"]) == [8, 8, 8, 8, 8]
 
 
@@ -144,7 +144,7 @@ def test_window_genetic_correlation_matches_literal_restatement(tmp_path):
     f2 = str(tmp_path / "MCMC_samples_marker_effects_geno_y2.txt")
     pd.DataFrame(s2, columns=[f"m{j + 1}" for j in range(s1.shape[1])]).to_csv(f2, index=False, float_format="%.9g")
     res = GWAS(X, mapf, f1, f2, window_size="1 Mb", GWAS=False, genetic_correlation=True, output_folder=str(tmp_path),
-               engine=OracleEngine("dense"))
+               _engine=OracleEngine("dense"))
     tab = res[-1]
     assert list(tab.columns) == ["trait", "window", "chr", "wStart", "wEnd", "start_SNP", "end_SNP", "numSNP", "estimate_cov",
                                  "std_cov", "estimate_cor", "std_cor"]
@@ -163,7 +163,7 @@ def test_window_genetic_correlation_matches_literal_restatement(tmp_path):
     np.testing.assert_allclose(tab["estimate_cov"], gcov.mean(0), atol=1e-9)
     np.testing.assert_allclose(tab["estimate_cor"], gcor.mean(0), atol=1e-9)
     with pytest.raises(ValueError, match="exactly two"):
-        GWAS(X, mapf, f1, genetic_correlation=True, engine=OracleEngine("dense"), output_folder=str(tmp_path))
+        GWAS(X, mapf, f1, genetic_correlation=True, _engine=OracleEngine("dense"), output_folder=str(tmp_path))
 
 
 @pytest.mark.gpu

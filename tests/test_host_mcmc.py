@@ -75,7 +75,7 @@ def _run(form, ph, geno_df, tmp, **kw):
     model = api.build_model("y1 = intercept + geno", 1.0)
     return api.runMCMC(model, ph, chain_length=40, burnin=10, output_samples_frequency=10, seed=2026,
                        output_folder=os.path.join(tmp, f"res_{form}"), outputEBV=False,
-                       engine=OracleEngine(form), block_size=64, **kw)
+                       _engine=OracleEngine(form), block_size=64, **kw)
 
 
 def test_runmcmc_dense_vs_block_same_seed(tmp_path):
@@ -111,7 +111,7 @@ def test_runmcmc_recovers_signal_and_writes_outputs(tmp_path, method, Pi):
     model = api.build_model("y1 = intercept + geno")
     folder = str(tmp_path / "out")
     out = api.runMCMC(model, ph, chain_length=150, burnin=30, seed=7, output_folder=folder,
-                      engine=OracleEngine("block"), block_size=64)
+                      _engine=OracleEngine("block"), block_size=64)
     me = out["marker effects geno"]
     assert list(me.columns) == ["Trait", "Marker_ID", "Estimate", "SD", "Model_Frequency"]
     assert len(me) == geno.nMarkers
@@ -132,7 +132,7 @@ def test_runmcmc_recovers_signal_and_writes_outputs(tmp_path, method, Pi):
     # an existing folder is never overwritten (JWAS.jl:255-262)
     geno2 = api.get_genotypes(gdf, method=method, Pi=Pi)
     model2 = api.build_model("y1 = intercept + geno2", genotypes={"geno2": geno2})
-    api.runMCMC(model2, ph, chain_length=2, seed=7, output_folder=folder, engine=OracleEngine("block"), block_size=64)
+    api.runMCMC(model2, ph, chain_length=2, seed=7, output_folder=folder, _engine=OracleEngine("block"), block_size=64)
     assert os.path.isdir(folder + "1")
 
 
@@ -151,7 +151,7 @@ def test_runmcmc_multitrait_and_fixed_effects(tmp_path):
     model = api.build_model("y1 = intercept + x1 + sex + geno\ny2 = intercept + geno")
     api.set_covariate(model, "x1")
     out = api.runMCMC(model, ph, chain_length=60, burnin=10, seed=3, output_folder=str(tmp_path / "mt"),
-                      engine=OracleEngine("block"), block_size=64)
+                      _engine=OracleEngine("block"), block_size=64)
     lp = out["location parameters"]
     assert set(lp["Trait"]) == {"y1", "y2"} and {"intercept", "x1", "sex"} <= set(lp["Effect"])
     assert float(lp[(lp.Trait == "y1") & (lp.Effect == "x1")]["Estimate"].iloc[0]) == pytest.approx(0.8, abs=0.25)
@@ -179,7 +179,7 @@ def test_runmcmc_multitrait_sampler_II(tmp_path):
     geno = api.get_genotypes(gdf, method="BayesC", Pi=Pi, estimatePi=False, multi_trait_sampler="II")
     model = api.build_model("y1 = intercept + geno\ny2 = intercept + geno")
     out = api.runMCMC(model, ph, chain_length=60, burnin=10, seed=3, output_folder=str(tmp_path / "mt2"),
-                      engine=OracleEngine("block"), block_size=64)
+                      _engine=OracleEngine("block"), block_size=64)
     me = out["marker effects geno"]
     f1 = me[me.Trait == "y1"]["Model_Frequency"].to_numpy()
     f2 = me[me.Trait == "y2"]["Model_Frequency"].to_numpy()
@@ -198,7 +198,7 @@ def test_runmcmc_constraint_true_runs_mega_path(tmp_path):
                              estimatePi=True, constraint=True)
     model = api.build_model("y1 = intercept + geno\ny2 = intercept + geno", constraint=True)
     out = api.runMCMC(model, ph, chain_length=60, burnin=10, seed=3, output_folder=str(tmp_path / "mega"),
-                      engine=OracleEngine("block"), block_size=64)
+                      _engine=OracleEngine("block"), block_size=64)
     rv = out["residual variance"]["Estimate"].to_numpy().reshape(2, 2)
     gv = out["marker effects variance geno"]["Estimate"].to_numpy().reshape(2, 2)
     assert rv[0, 1] == 0 and rv[1, 0] == 0 and gv[0, 1] == 0 and gv[1, 0] == 0
@@ -208,7 +208,7 @@ def test_runmcmc_constraint_true_runs_mega_path(tmp_path):
     single = api.get_genotypes(gdf, method="BayesC", Pi=0.5, constraint=True)
     m1 = api.build_model("y1 = intercept + single", genotypes={"single": single})
     with pytest.raises(ValueError, match="constraint==true is for multi-trait only"):
-        api.runMCMC(m1, ph, chain_length=2, output_folder=str(tmp_path / "e"), engine=OracleEngine("block"), block_size=64)
+        api.runMCMC(m1, ph, chain_length=2, output_folder=str(tmp_path / "e"), _engine=OracleEngine("block"), block_size=64)
 
 
 def test_runmcmc_contract_errors(tmp_path):
@@ -220,7 +220,7 @@ def test_runmcmc_contract_errors(tmp_path):
     with pytest.raises(NotImplementedError, match="single_step_analysis"):
         api.runMCMC(model, ph, single_step_analysis=True, output_folder=str(tmp_path / "e2"))
     with pytest.raises(ValueError, match="at least two block starts"):
-        api.runMCMC(model, ph, fast_blocks=4, output_folder=str(tmp_path / "e3"), engine=OracleEngine("block"))   # 4 markers: one start
+        api.runMCMC(model, ph, fast_blocks=4, output_folder=str(tmp_path / "e3"), _engine=OracleEngine("block"))   # 4 markers: one start
     with pytest.raises(ValueError, match="Model equations are wrong"):
         api.build_model("")
     nog = api.build_model("y1 = intercept")
@@ -238,7 +238,7 @@ def test_fast_blocks_rescales_chain_length(tmp_path):
     geno = api.get_genotypes(gdf, method="BayesC", Pi=0.9)
     model = api.build_model("y1 = intercept + geno")
     out = api.runMCMC(model, ph, chain_length=640, burnin=2, fast_blocks=64, seed=1, outputEBV=False,
-                      output_folder=str(tmp_path / "fb"), engine=OracleEngine("block"))
+                      output_folder=str(tmp_path / "fb"), _engine=OracleEngine("block"))
     assert out["_timing"]["iterations"] == 10 and out["_timing"]["block_size"] == 64
 
 
@@ -251,7 +251,7 @@ def test_independent_blocks_through_runmcmc(tmp_path):
     geno = api.get_genotypes(gdf, method="BayesC", Pi=0.9)
     model = api.build_model("y1 = intercept + geno")
     out = api.runMCMC(model, ph, chain_length=64 * 12, burnin=2, fast_blocks=64, independent_blocks=True, seed=1,
-                      output_folder=str(tmp_path / "ib"), engine=OracleEngine("block"))
+                      output_folder=str(tmp_path / "ib"), _engine=OracleEngine("block"))
     assert out["_timing"]["iterations"] == 12
     assert np.corrcoef(out["EBV_y1"]["EBV"], ph["y1"])[0, 1] > 0.4
 
@@ -281,7 +281,7 @@ def test_adaptive_block_size_policy(tmp_path):
         model = api.build_model("y1 = intercept + geno")
         spy = Spy()
         outs.append(api.runMCMC(model, ph, chain_length=12, burnin=2, seed=5, outputEBV=False,
-                                output_folder=str(tmp_path / f"ad{rep}"), engine=spy))
+                                output_folder=str(tmp_path / f"ad{rep}"), _engine=spy))
         assert spy.sizes[0] == 512 and set(spy.sizes) <= {512, 1024} and 1024 in spy.sizes
     assert np.array_equal(outs[0]["marker effects geno"]["Estimate"], outs[1]["marker effects geno"]["Estimate"])
 
@@ -301,7 +301,7 @@ def test_heterogeneous_residuals_weights(tmp_path):
         geno = api.get_genotypes(gdf, method="BayesC", Pi=0.9)
         model = api.build_model("y1 = intercept + geno")
         outs[het] = api.runMCMC(model, ph, chain_length=40, burnin=5, seed=9, heterogeneous_residuals=het,
-                                output_folder=str(tmp_path / f"w{het}"), engine=OracleEngine("block"), block_size=64)
+                                output_folder=str(tmp_path / f"w{het}"), _engine=OracleEngine("block"), block_size=64)
     a, b = outs[False]["marker effects geno"]["Estimate"], outs[True]["marker effects geno"]["Estimate"]
     assert not np.allclose(a, b)
     assert np.corrcoef(outs[True]["EBV_y1"]["EBV"], ph["y1"])[0, 1] > 0.4
@@ -309,7 +309,7 @@ def test_heterogeneous_residuals_weights(tmp_path):
         geno = api.get_genotypes(gdf, method="BayesC", Pi=0.9)
         model = api.build_model("y1 = intercept + geno")
         api.runMCMC(model, ph.drop(columns="weights"), chain_length=2, heterogeneous_residuals=True,
-                    output_folder=str(tmp_path / "w_err"), engine=OracleEngine("block"), block_size=64)
+                    output_folder=str(tmp_path / "w_err"), _engine=OracleEngine("block"), block_size=64)
 
 
 def test_config1_plumbing_on_the_oracle(tmp_path, config1_data):
@@ -324,7 +324,7 @@ def test_config1_plumbing_on_the_oracle(tmp_path, config1_data):
     geno = api.get_genotypes(gdf, method="BayesC", Pi=0.95, estimatePi=True)
     model = api.build_model("y1 = intercept + geno")
     out = api.runMCMC(model, ph, chain_length=1000, burnin=100, seed=2026, output_folder=str(tmp_path / "c1"),
-                      engine=OracleEngine("block"), block_size=256)
+                      _engine=OracleEngine("block"), block_size=256)
     me = out["marker effects geno"]
     assert len(me) == geno.nMarkers and out["_timing"]["iterations"] == 1000
     top = set(me.reindex(me["Model_Frequency"].sort_values(ascending=False).index)["Marker_ID"].head(20))
@@ -352,7 +352,7 @@ def test_ebv_for_individuals_without_records_and_outputEBV_list(tmp_path):
     geno = api.get_genotypes(gdf, method="BayesC", Pi=0.9)
     model = api.build_model("y1 = intercept + geno")
     out = api.runMCMC(model, ph, chain_length=200, burnin=40, seed=3, output_folder=str(tmp_path / "a"),
-                      engine=OracleEngine("block"), block_size=64)
+                      _engine=OracleEngine("block"), block_size=64)
     ebv = out["EBV_y1"]
     assert list(ebv["ID"]) == ids                                   # all genotyped individuals, genotype order
     assert np.corrcoef(ebv["EBV"].to_numpy()[held], y[held])[0, 1] > 0.3          # held-out prediction
@@ -364,7 +364,7 @@ def test_ebv_for_individuals_without_records_and_outputEBV_list(tmp_path):
     model = api.build_model("y1 = intercept + geno")
     api.outputEBV(model, ["id5", "id0", "nobody", "id7"])
     out2 = api.runMCMC(model, ph, chain_length=200, burnin=40, seed=3, output_folder=str(tmp_path / "b"),
-                       engine=OracleEngine("block"), block_size=64)
+                       _engine=OracleEngine("block"), block_size=64)
     assert list(out2["EBV_y1"]["ID"]) == ["id5", "id0", "id7"]
     full = ebv.set_index("ID")["EBV"]
     np.testing.assert_allclose(out2["EBV_y1"]["EBV"].to_numpy(), full.loc[["id5", "id0", "id7"]].to_numpy(), atol=1e-5)
@@ -424,7 +424,7 @@ def test_multitrait_with_partially_missing_records(tmp_path):
     geno = api.get_genotypes(gdf, np.eye(2) * 0.5, method="BayesC", Pi={(0.0, 0.0): 0.7, (1.0, 0.0): 0.1, (0.0, 1.0): 0.1, (1.0, 1.0): 0.1})
     model = api.build_model("y1 = intercept + geno\ny2 = intercept + geno", np.eye(2))
     out = api.runMCMC(model, ph, chain_length=150, burnin=30, seed=3, output_folder=str(tmp_path / "mt"),
-                      engine=OracleEngine("block"), block_size=64)
+                      _engine=OracleEngine("block"), block_size=64)
     assert len(out["residual variance"]) == 4
     assert np.isfinite(out["residual variance"]["Estimate"]).all()
     n_used = len(open(tmp_path / "mt" / "IDs_for_individuals_with_phenotypes.txt").read().split())
@@ -436,7 +436,7 @@ def test_multitrait_with_partially_missing_records(tmp_path):
     with pytest.raises(ValueError, match="missing_phenotypes=false"):
         geno = api.get_genotypes(gdf, np.eye(2) * 0.5, method="BayesC")
         model = api.build_model("y1 = intercept + geno\ny2 = intercept + geno", np.eye(2))
-        api.runMCMC(model, ph, chain_length=5, seed=3, output_folder=str(tmp_path / "mt2"), engine=OracleEngine("block"),
+        api.runMCMC(model, ph, chain_length=5, seed=3, output_folder=str(tmp_path / "mt2"), _engine=OracleEngine("block"),
                     block_size=64, missing_phenotypes=False)
 
 
@@ -453,7 +453,7 @@ def test_rrblup_is_bayesc_with_all_markers_in_the_model(tmp_path):
         geno = api.get_genotypes(gdf, **kw)
         model = api.build_model("y1 = intercept + geno")
         outs[tag] = api.runMCMC(model, ph, chain_length=60, burnin=10, seed=4, output_folder=str(tmp_path / tag),
-                                engine=OracleEngine("block"), block_size=64)
+                                _engine=OracleEngine("block"), block_size=64)
     np.testing.assert_array_equal(outs["rr"]["marker effects geno"]["Estimate"].to_numpy(),
                                   outs["c0"]["marker effects geno"]["Estimate"].to_numpy())
     assert (outs["rr"]["marker effects geno"]["Model_Frequency"] == 1.0).all()
@@ -471,7 +471,7 @@ def test_bayes_lasso_runs_on_the_bayesb_device_path(tmp_path):
     geno = api.get_genotypes(gdf, method="BayesL")
     model = api.build_model("y1 = intercept + geno")
     out = api.runMCMC(model, ph, chain_length=300, burnin=60, seed=2, output_folder=str(tmp_path / "bl"),
-                      engine=OracleEngine("block"), block_size=64)
+                      _engine=OracleEngine("block"), block_size=64)
     me = out["marker effects geno"]
     assert (me["Model_Frequency"] == 1.0).all()
     assert "marker effects variance geno" in out and float(out["marker effects variance geno"]["Estimate"][0]) > 0
@@ -512,7 +512,7 @@ def test_annotated_single_trait_priors(tmp_path, method):
     assert geno.estimatePi is True                       # forced (readgenotypes.jl:152-158)
     model = api.build_model("y1 = intercept + geno")
     out = api.runMCMC(model, ph, chain_length=400, burnin=100, seed=7, output_folder=str(tmp_path / method),
-                      engine=OracleEngine("block"), block_size=64)
+                      _engine=OracleEngine("block"), block_size=64)
     tab = out["annotation coefficients geno"]
     if method == "BayesC":
         assert list(tab.columns) == ["Annotation", "Estimate", "SD"]
@@ -560,7 +560,7 @@ def test_annotated_two_trait_bayesc(tmp_path):
     geno = api.get_genotypes(gdf, np.eye(2) * 0.5, method="BayesC", annotations=ann, Pi=Pi)
     model = api.build_model("y1 = intercept + geno\ny2 = intercept + geno", np.eye(2))
     out = api.runMCMC(model, ph, chain_length=300, burnin=80, seed=5, output_folder=str(tmp_path / "amt"),
-                      engine=OracleEngine("block"), block_size=64)
+                      _engine=OracleEngine("block"), block_size=64)
     tab = out["annotation coefficients geno"]
     assert list(tab.columns) == ["Annotation", "Step", "Estimate", "SD"] and len(tab) == 9
     assert set(tab["Step"]) == {"step1_zero_vs_active", "step2_11_vs_singleton", "step3_10_vs_01"}
@@ -574,7 +574,7 @@ def test_annotated_two_trait_bayesc(tmp_path):
         geno = api.get_genotypes(gdf, np.eye(2) * 0.5, method="BayesC", annotations=ann,
                                  Pi={(0.0, 0.0): 0.9, (1.0, 0.0): 0.05, (0.0, 1.0): 0.05, (1.0, 1.0): 0.0})
         model = api.build_model("y1 = intercept + geno\ny2 = intercept + geno", np.eye(2))
-        api.runMCMC(model, ph, chain_length=5, seed=5, output_folder=str(tmp_path / "amt2"), engine=OracleEngine("block"), block_size=64)
+        api.runMCMC(model, ph, chain_length=5, seed=5, output_folder=str(tmp_path / "amt2"), _engine=OracleEngine("block"), block_size=64)
 
 
 def test_annotated_two_trait_bayesc_default_pi(tmp_path):
@@ -586,13 +586,13 @@ def test_annotated_two_trait_bayesc_default_pi(tmp_path):
     geno = api.get_genotypes(gdf, np.eye(2) * 0.5, method="BayesC", annotations=ann)
     model = api.build_model("y1 = intercept + geno\ny2 = intercept + geno", np.eye(2))
     out = api.runMCMC(model, ph, chain_length=40, burnin=10, seed=5, output_folder=str(tmp_path / "d"),
-                      engine=OracleEngine("block"), block_size=64)
+                      _engine=OracleEngine("block"), block_size=64)
     assert len(out["pi_geno"]) == 4 and abs(out["pi_geno"]["Estimate"].sum() - 1.0) < 1e-6
     assert np.isfinite(out["marker effects geno"]["Estimate"]).all()
     geno = api.get_genotypes(gdf, np.eye(2) * 0.5, method="BayesC", annotations=ann, Pi=0.5)
     model = api.build_model("y1 = intercept + geno\ny2 = intercept + geno", np.eye(2))
     with pytest.raises(ValueError, match="requires Pi=0.0 or a joint Pi dictionary"):
-        api.runMCMC(model, ph, chain_length=5, seed=5, output_folder=str(tmp_path / "e"), engine=OracleEngine("block"), block_size=64)
+        api.runMCMC(model, ph, chain_length=5, seed=5, output_folder=str(tmp_path / "e"), _engine=OracleEngine("block"), block_size=64)
 
 
 def test_heritability_output_matches_its_definition(tmp_path):
@@ -606,7 +606,7 @@ def test_heritability_output_matches_its_definition(tmp_path):
     model = api.build_model("y1 = intercept + geno")
     folder = tmp_path / "h"
     out = api.runMCMC(model, ph, chain_length=60, burnin=10, output_samples_frequency=5, seed=1, output_folder=str(folder),
-                      engine=OracleEngine("block"), block_size=64)
+                      _engine=OracleEngine("block"), block_size=64)
     a = pd.read_csv(folder / "MCMC_samples_marker_effects_geno_y1.txt").to_numpy()
     ve = pd.read_csv(folder / "MCMC_samples_residual_variance.txt").to_numpy().ravel()
     X = np.asarray(geno.genotypes, dtype=np.float64)
@@ -616,7 +616,7 @@ def test_heritability_output_matches_its_definition(tmp_path):
     assert float(out["heritability"]["Estimate"][0]) == pytest.approx(float((gv / (gv + ve)).mean()), rel=1e-4)
     geno = api.get_genotypes(gdf, method="BayesC", Pi=0.8)
     model = api.build_model("y1 = intercept + geno")
-    out2 = api.runMCMC(model, ph, chain_length=20, seed=1, output_folder=str(tmp_path / "h2"), engine=OracleEngine("block"),
+    out2 = api.runMCMC(model, ph, chain_length=20, seed=1, output_folder=str(tmp_path / "h2"), _engine=OracleEngine("block"),
                        block_size=64, output_heritability=False)
     assert "heritability" not in out2
 
@@ -639,7 +639,7 @@ def test_auto_sampler_follows_the_support_of_pi(tmp_path):
                      ({(0.0, 0.0): 0.7, (1.0, 0.0): 0.1, (0.0, 1.0): 0.1, (1.0, 1.0): 0.1}, "MTBayesC")):
         geno = api.get_genotypes(gdf, np.eye(2) * 0.5, method="BayesC", Pi=Pi, multi_trait_sampler="auto")
         model = api.build_model("y1 = intercept + geno\ny2 = intercept + geno", np.eye(2))
-        api.runMCMC(model, ph, chain_length=6, seed=1, output_folder=str(tmp_path / want), engine=Spy("block"), block_size=64, outputEBV=False)
+        api.runMCMC(model, ph, chain_length=6, seed=1, output_folder=str(tmp_path / want), _engine=Spy("block"), block_size=64, outputEBV=False)
         assert used["method"] == want
 
 
@@ -656,7 +656,7 @@ def test_binary_marker_effect_samples_equal_the_text_rows(tmp_path):
     model = api.build_model("y1 = intercept + geno")
     folder = tmp_path / "b"
     api.runMCMC(model, ph, chain_length=40, burnin=10, output_samples_frequency=3, seed=1, output_folder=str(folder),
-                engine=OracleEngine("block"), block_size=64)
+                _engine=OracleEngine("block"), block_size=64)
     txt = folder / "MCMC_samples_marker_effects_geno_y1.txt"
     binf = folder / "MCMC_samples_marker_effects_geno_y1.bin"
     ref = pd.read_csv(txt)

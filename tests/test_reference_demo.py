@@ -212,7 +212,7 @@ def test_fast_blocks_needs_two_block_starts(tmp_path):
     from oracle_engine import OracleEngine
     with pytest.raises(ValueError, match="at least two block starts"):
         api.runMCMC(model, _phenotypes(), chain_length=20, output_folder=str(tmp_path / "x"), seed=1, fast_blocks=7,
-                    engine=OracleEngine("block"))
+                    _engine=OracleEngine("block"))
 
 
 # ---- test/unit/test_bayesr.jl:62-140, 282-344 ---------------------------------------------------------------
@@ -230,7 +230,7 @@ def test_bayesr_rejects_bad_pi_length(tmp_path):
     geno = api.get_genotypes(GENO, 1.0, separator=",", method="BayesR", Pi=[0.95, 0.05, 0.0], estimatePi=True)
     model = api.build_model("y1 = intercept + geno", 1.0)
     with pytest.raises(ValueError, match="length 4"):
-        api.runMCMC(model, _phenotypes(), chain_length=10, output_folder=str(tmp_path / "x"), seed=1, engine=OracleEngine("block"))
+        api.runMCMC(model, _phenotypes(), chain_length=10, output_folder=str(tmp_path / "x"), seed=1, _engine=OracleEngine("block"))
 
 
 def test_bayesr_does_not_mutate_caller_pi(tmp_path):
@@ -240,7 +240,7 @@ def test_bayesr_does_not_mutate_caller_pi(tmp_path):
     geno = api.get_genotypes(GENO, 1.0, separator=",", method="BayesR", Pi=start_pi, estimatePi=True)
     model = api.build_model("y1 = intercept + geno", 1.0)
     api.runMCMC(model, _phenotypes(), chain_length=10, burnin=0, output_samples_frequency=5, output_folder=str(tmp_path / "x"),
-                seed=123, printout_model_info=False, outputEBV=False, engine=OracleEngine("block"))
+                seed=123, printout_model_info=False, outputEBV=False, _engine=OracleEngine("block"))
     assert np.array_equal(start_pi, original)
 
 
@@ -344,7 +344,7 @@ def test_output_mcmc_samples_and_covariates(tmp_path):
     api.outputMCMCsamples(model, "intercept", "x1")
     folder = tmp_path / "test_multi_samples"
     api.runMCMC(model, _phenotypes(), chain_length=50, output_samples_frequency=10, output_folder=str(folder), seed=123,
-                engine=OracleEngine("block"))
+                _engine=OracleEngine("block"))
     assert os.path.isfile(folder / "MCMC_samples_y1.intercept.txt") and os.path.isfile(folder / "MCMC_samples_y1.x1.txt")
     assert pd.read_csv(folder / "MCMC_samples_y1.x1.txt").shape == (5, 1)
 
@@ -356,11 +356,11 @@ def test_explicit_block_start_validation(tmp_path, bad, msg):
     geno = api.get_genotypes(GENO, 1.0, separator=",", method="BayesC")
     model = api.build_model("y1 = intercept + geno", 1.0)
     with pytest.raises(ValueError, match=msg):
-        api.runMCMC(model, _phenotypes(), chain_length=6, output_folder=str(tmp_path / "x"), fast_blocks=bad, engine=OracleEngine("block"))
+        api.runMCMC(model, _phenotypes(), chain_length=6, output_folder=str(tmp_path / "x"), fast_blocks=bad, _engine=OracleEngine("block"))
     geno = api.get_genotypes(GENO, 1.0, separator=",", method="BayesC")
     model = api.build_model("y1 = intercept + geno", 1.0)
     with pytest.raises(NotImplementedError, match="non-uniform explicit fast_blocks"):
-        api.runMCMC(model, _phenotypes(), chain_length=6, output_folder=str(tmp_path / "y"), fast_blocks=[1, 2, 4], engine=OracleEngine("block"))
+        api.runMCMC(model, _phenotypes(), chain_length=6, output_folder=str(tmp_path / "y"), fast_blocks=[1, 2, 4], _engine=OracleEngine("block"))
 
 
 @pytest.mark.parametrize("method", ["BayesC", "BayesR"])
@@ -371,6 +371,6 @@ def test_independent_blocks_with_explicit_uniform_starts(tmp_path, method):
     geno = api.get_genotypes(GENO, 1.0, separator=",", method=method)
     model = api.build_model("y1 = intercept + geno", 1.0)
     out = api.runMCMC(model, _phenotypes(), chain_length=6, output_folder=str(tmp_path / "ib"), seed=1, fast_blocks=[1, 3, 5],
-                      independent_blocks=True, engine=OracleEngine("block"))
+                      independent_blocks=True, _engine=OracleEngine("block"))
     assert "marker effects geno" in out and "Model_Frequency" in out["marker effects geno"].columns
     assert out["_timing"]["iterations"] == 6

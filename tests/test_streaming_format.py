@@ -91,7 +91,7 @@ def test_stream_mode_runmcmc_equals_dense_mode(tmp_path):
         geno = api.get_genotypes(gdf if mode == "dense" else prefix, method="BayesC", Pi=0.9, storage=mode)
         model = api.build_model("y1 = intercept + geno")
         outs.append(api.runMCMC(model, ph, chain_length=40, burnin=5, seed=4, outputEBV=False,
-                                output_folder=str(tmp_path / mode), engine=OracleEngine("block"), block_size=64))
+                                output_folder=str(tmp_path / mode), _engine=OracleEngine("block"), block_size=64))
     a, b = (o["marker effects geno"] for o in outs)
     assert list(a["Marker_ID"]) == list(b["Marker_ID"])
     np.testing.assert_allclose(a["Estimate"], b["Estimate"], atol=1e-4)
@@ -99,7 +99,7 @@ def test_stream_mode_runmcmc_equals_dense_mode(tmp_path):
     geno = api.get_genotypes(prefix, method="BayesC", Pi=0.9, storage="stream")
     model = api.build_model("y1 = intercept + geno")
     with pytest.raises(ValueError, match="requires exact genotype/phenotype ID match and order"):
-        api.runMCMC(model, ph.iloc[::-1], chain_length=2, output_folder=str(tmp_path / "bad"), engine=OracleEngine("block"))
+        api.runMCMC(model, ph.iloc[::-1], chain_length=2, output_folder=str(tmp_path / "bad"), _engine=OracleEngine("block"))
 
 
 def _write_geno_file(path, n=37, p=23, seed=4, missing=True):
@@ -149,3 +149,22 @@ def test_auto_mode_and_guards(tmp_path, capsys):
     with pytest.raises(ValueError, match="conversion_mode"):
         S.prepare_streaming_genotypes(path, str(tmp_path / "bad"), conversion_mode="fast")
     assert S.prepare_streaming_genotypes(path).endswith("geno_stream")              # default prefix: <file>_stream
+
+
+def test_streaming_qc_matches_the_reference_rules(tmp_path):
+    """prepare_streaming_genotypes QC (streaming_genotypes.jl:274-296): a marker with only missing values is an error;
+    the MAF filter is strict in Float32 (a marker AT the threshold is dropped); fixed markers are dropped."""
+    from jwas_jl_amd.streaming import prepare_streaming_genotypes
+    rng = np.random.default_rng(0)
+    G = rng.integers(0, 3, size=(40, 6)).astype(np.float32)
+    G[:, 2] = 9.0                                            # only missing values
+    with pytest.raises(ValueError, match="Marker m3 has only missing values"):
+        prepare_streaming_genotypes(G, str(tmp_path / "a"), marker_ids=[f"m{j + 1}" for j in range(6)])
+    G[:, 2] = 1.0                                            # fixed: allele frequency 0.5 but no variance
+    G[:, 3] = 0.0; G[:4, 3] = 1.0                            # mean 0.1 -> allele frequency exactly 0.05 = MAF: dropped (strict <)
+    prefix = prepare_streaming_genotypes(G, str(tmp_path / "b"), marker_ids=[f"m{j + 1}" for j in range(6)], MAF=0.05)
+    kept = open(prefix + ".markerid.txt").read().split()
+    assert kept == ["m1", "m2", "m5", "m6"]
+    G[:] = 0.0
+    with pytest.raises(ValueError, match="No markers remain"):
+        prepare_streaming_genotypes(G, str(tmp_path / "c"))
