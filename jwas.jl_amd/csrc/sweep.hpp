@@ -1102,9 +1102,24 @@ __device__ __forceinline__ MtPre<NT> mt_precompute(const MtConsts<NT>& K, float 
     return R;
 }
 
+// Log prior probabilities of the two joint states sampler I compares for trait k (delta_k = 0 / 1, the other traits as
+// they are now).  PriorMem: a table in memory (LDS; stride ls between states: 1 = the shared table, block size = this
+// marker's column of the marker-specific priors).
+struct PriorMem {
+    const double* lpr; int ls;
+    template <int NT>
+    __device__ __forceinline__ void pair(int k, const float (&dn)[NT], double& l0, double& l1) const
+    {
+        unsigned s0 = 0u;
+#pragma unroll
+        for (int m = 0; m < NT; ++m) if (m != k && dn[m] != 0.f) s0 |= 1u << m;
+        l0 = lpr[s0 * ls];
+        l1 = lpr[(s0 | (1u << k)) * ls];
+    }
+};
 // Gibbs sampler I (MTBayesABC.jl:85-120)
-template <int NT>
-__device__ __forceinline__ void mt1_eval(const MtConsts<NT>& K, const MtPre<NT>& Q, const double* lpr, int ls, const float (&w)[NT], float dj,
+template <int NT, class LP>
+__device__ __forceinline__ void mt1_eval(const MtConsts<NT>& K, const MtPre<NT>& Q, const LP& lp, const float (&w)[NT], float dj,
                                          const double (&thr)[NT], const double (&z)[NT],
                                          float (&an)[NT], float (&bn)[NT], float (&dn)[NT], float (&Dl)[NT])
 {
@@ -1127,14 +1142,12 @@ __device__ __forceinline__ void mt1_eval(const MtConsts<NT>& K, const MtPre<NT>&
         const float invLhs1 = Q.invLhs1[k];
         const float rhs1 = wR - c12b;                                               // :96
         const float gHat1 = rhs1 * invLhs1;
-        unsigned s0 = 0u;
-#pragma unroll
-        for (int m = 0; m < NT; ++m) if (m != k && dn[m] != 0.f) s0 |= 1u << m;
-        const unsigned s1 = s0 | (1u << k);
+        double lp0, lp1;
+        lp.template pair<NT>(k, dn, lp0, lp1);
         const float in0 = K.lG[k] - (gHat0 * gHat0) * Ginv11;                       // :104
         const float in1 = Q.lC11[k] - (gHat1 * gHat1) * C11;                        // :105
-        const double logDelta0 = -0.5 * (double)in0 + lpr[s0 * ls];          // ls = 1: shared table; block size: this marker's
-        const double logDelta1 = -0.5 * (double)in1 + lpr[s1 * ls];
+        const double logDelta0 = -0.5 * (double)in0 + lp0;
+        const double logDelta1 = -0.5 * (double)in1 + lp1;
         if ((logDelta0 - logDelta1) < thr[k]) {                                     // :107-111
             dn[k] = 1.f;
             bn[k] = (float)((double)gHat1 + z[k] * (double)Q.s1[k]);
@@ -1598,7 +1611,7 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
             float an[NT], bn[NT], dn[NT], Dl[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) { an[t] = a0[q][t]; bn[t] = b0[q][t]; dn[t] = d0[q][t]; Dl[t] = 0.f; }
-            if constexpr (METHOD == kMTBayesC1) mt1_eval<NT>(K, Q0, lpr_of(c), ls, w0[q], dj, thr0[q], z0[q], an, bn, dn, Dl);
+            if constexpr (METHOD == kMTBayesC1) mt1_eval<NT>(K, Q0, PriorMem{lpr_of(c), ls}, w0[q], dj, thr0[q], z0[q], an, bn, dn, Dl);
             else if constexpr (kTab) {
                 double T[kTS][kTV];
                 mt2_load_tab<NT>(A.mt2_tab, p, j0 + c, T);
@@ -1691,7 +1704,9 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
             double thr[NT], z[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) { an[t] = aq[t][q]; bn[t] = bq[t][q]; dn[t] = dq[t][q]; Dl[t] = 0.f; thr[t] = thrq[t][q]; z[t] = zq[t][q]; }
-            if constexpr (METHOD == kMTBayesC1) mt1_eval<NT>(K, Qq[q], lpr_of(c), ls, w, djq[q], thr, z, an, bn, dn, Dl);
+            // (the shared prior table from registers -- v_cndmask trees instead of the LDS lookup -- was measured: 79 ms
+            // per sweep instead of 55 at 3 traits x 20k x 100k; the LDS read overlaps the trait's arithmetic well enough)
+            if constexpr (METHOD == kMTBayesC1) mt1_eval<NT>(K, Qq[q], PriorMem{lpr_of(c), ls}, w, djq[q], thr, z, an, bn, dn, Dl);
             else mega_eval<NT>(K, Qq[q], w, djq[q], thr, z, an, bn, dn, Dl);
         };
 #pragma unroll
@@ -1775,7 +1790,7 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
                     float w[NT];
 #pragma unroll
                     for (int t = 0; t < NT; ++t) w[t] = rhs_lds[t * B + c] + dj * a_cur[t];           // :82
-                    if constexpr (METHOD == kMTBayesC1) mt1_eval<NT>(K, Qm, lpr_of(c), ls, w, dj, thr, z, an, bn, dn, Dl);
+                    if constexpr (METHOD == kMTBayesC1) mt1_eval<NT>(K, Qm, PriorMem{lpr_of(c), ls}, w, dj, thr, z, an, bn, dn, Dl);
                     else if constexpr (kTab) mt2_eval_tab<NT>(K, lpr_of(c), ls, w, T, thr[0], z, an, bn, dn, Dl);
                     else if constexpr (METHOD == kMTBayesC2) mt2_eval<NT>(K, lpr_of(c), ls, w, dj, thr[0], z, an, bn, dn, Dl);
                     else mega_eval<NT>(K, Qm, w, dj, thr, z, an, bn, dn, Dl);
