@@ -83,7 +83,14 @@ struct DenseCols {
     // column stream of the update role: element i = rows row..row+3 of marker j0 + i*jstride
     struct Stream {
         const float* p; int64_t stride;
-        __device__ __forceinline__ SRaw load_raw(int i) const { return *reinterpret_cast<const float4*>(p + (int64_t)i * stride); }
+        // non-temporal: every element of X is read exactly once per sweep, keeping it out of the caches' replacement
+        // order is worth 3-5 % of streaming bandwidth (scripts/micro/read_bw.hip: 6.37 -> 6.69 TB/s)
+        __device__ __forceinline__ SRaw load_raw(int i) const
+        {
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            const f4 t = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p + (int64_t)i * stride));
+            return float4{t.x, t.y, t.z, t.w};
+        }
         __device__ __forceinline__ float load_mean(int) const { return 0.f; }
         static __device__ __forceinline__ unsigned flags(const SRaw&) { return 0u; }
         __device__ __forceinline__ float4 decode_fast(const SRaw& r, float) const { return r; }
