@@ -9,7 +9,7 @@ TAG=${1:-r02}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-python -m pytest tests -m gpu -q 2>&1 | tail -5 > "$OUT/gpu_tests.log"
+python -m pytest tests -m gpu -q 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" | tail -6 > "$OUT/gpu_tests.log"
 python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
 run() {   # name, timed steps, bench args...
     local W=$1 K=$2; shift 2
