@@ -1553,8 +1553,8 @@ static int sweep_collect(jwas_hip_ctx* c, jwas_sweep_stats* S, size_t ntimed, do
     S->n_events = packed_dev ? h_stat[kNStat] : (double)h_cnt[0];
     c->last_events = (double)h_cnt[0];
     if (std::getenv("JWAS_HIP_DEBUG_PHASES"))
-        std::fprintf(stderr, "[jwas_hip] blocks=%lld events=%llu unstaged=%llu cycles: front=%llu cand=%llu stage=%llu serial=%llu write=%llu corr=%llu rounds=%llu slow_rounds=%llu\n",
-                     (long long)c->nblocks, h_cnt[0], h_cnt[1], h_cnt[2], h_cnt[3], h_cnt[4], h_cnt[5], h_cnt[6], h_cnt[9], h_cnt[7], h_cnt[8]);
+        std::fprintf(stderr, "[jwas_hip] blocks=%lld events=%llu unstaged=%llu cycles: front=%llu cand=%llu stage=%llu serial=%llu write=%llu corr=%llu rounds=%llu slow_rounds=%llu stage: assign=%llu issue=%llu store=%llu\n",
+                     (long long)c->nblocks, h_cnt[0], h_cnt[1], h_cnt[2], h_cnt[3], h_cnt[4], h_cnt[5], h_cnt[6], h_cnt[9], h_cnt[7], h_cnt[8], h_cnt[10], h_cnt[11], h_cnt[12]);
     float ms = 0.f;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev_start, c->ev_stop));
     S->sweep_ms = ms;

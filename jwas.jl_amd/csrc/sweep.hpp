@@ -325,22 +325,79 @@ __device__ __forceinline__ void corr_phase(char* smem, const StepSmem& SM, const
     }
 }
 
+// Waves 1..4 of the sampler workgroup in single-pass sweeps: the lookahead correction of the NEXT block,
+//   corr[c] = fmaf(d_e, C[e][c], corr[c])  from 0 over the changed markers e in marker order  (C = X_this' X_next),
+// accumulated WHILE the serial wave runs.  The serial wave commits in marker order and publishes every change
+// {local column, alpha_old - alpha_new} to a log in LDS (counter wc[12], release / acquire at workgroup scope; wc[13] is
+// set after the last one); each helper lane owns four columns of the next block and consumes the log as it grows -- the
+// cross-Gram rows come from L2 (prefetch_cross_rows) or HBM, off the critical path.  When the serial wave is done the
+// correction is (nearly) done too: no dependent fetch of the changed markers' rows at the end of the block.
+// Spinning on LDS inside one workgroup is safe: all its waves are resident.
+// The helpers are waves 1..4 (keeping wave 4 -- the serial wave's SIMD -- idle instead was measured: no difference);
+// waves 5..7 prefetch.
+__device__ __forceinline__ bool is_corr_helper(int wave) { return wave >= 1 && wave <= 4; }
+__device__ __forceinline__ int corr_helper_index(int wave) { return wave - 1; }
+__device__ __forceinline__ float4 stream_corr_role(char* smem, const StepSmem& SM, const SamplerArgs& A)
+{
+    const int B = SM.B, bn = A.b_next;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int* wc = reinterpret_cast<int*>(smem + SM.wcnt_off);
+    const int2* plog = reinterpret_cast<const int2*>(smem + SM.log_off);
+    const int col = (corr_helper_index(wave) * 64 + lane) * 4;
+    const bool vec = (bn & 3) == 0;                         // full next block: rows 16-byte aligned
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+    int done = 0;
+    while (true) {
+        const int fin = __hip_atomic_load(&wc[13], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const int n = __hip_atomic_load(&wc[12], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (n > done) {
+            if (col < bn) {
+                for (int e0 = done; e0 < n; e0 += 8) {
+                    int2 le[8];
+                    float4 g[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) le[u] = plog[e0 + u < n ? e0 + u : n - 1];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const float* src = A.cross_next + (int64_t)le[u].x * bn + col;
+                        if (vec) g[u] = *reinterpret_cast<const float4*>(src);
+                        else { g[u].x = src[0]; g[u].y = src[col + 1 < bn ? 1 : 0]; g[u].z = src[col + 2 < bn ? 2 : 0]; g[u].w = src[col + 3 < bn ? 3 : 0]; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (e0 + u < n) {
+                            const float d = __int_as_float(le[u].y);
+                            c0 = fmaf(d, g[u].x, c0); c1 = fmaf(d, g[u].y, c1); c2 = fmaf(d, g[u].z, c2); c3 = fmaf(d, g[u].w, c3);
+                        }
+                }
+            }
+            done = n;
+        } else if (fin) break;
+        else __builtin_amdgcn_s_sleep(8);                  // ~500 cycles between polls
+    }
+    return float4{c0, c1, c2, c3};      // stored by the caller with the role's other global stores (after the barrier)
+}
+
 // Waves 1..7 (after their other prefetch work, while wave 0 runs the serial phase): pull the Gram rows the NEXT block's
 // sampler will stage into this XCD's L2 -- the whole Gram block for small (dense-prior) blocks, else the rows of the
 // markers that are in the model (alpha != 0: always candidates).  A row fetch of the sampler workgroup competes with
 // ~220 streaming workgroups for HBM; here it is off the critical path, in the next launch it is an L2 hit.  Speed only.
-__device__ __forceinline__ void prefetch_next_gram(const SamplerArgs& A, bool whole_block)
+// stop (LDS, may be NULL): set by the serial wave when it is done -- prefetching is optional work and must never hold the
+// workgroup's barrier back.
+__device__ __forceinline__ void prefetch_next_gram(const SamplerArgs& A, bool whole_block, int w0 = 1, const int* stop = nullptr)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
     const int bn = A.b_next;
-    if (wave == 0 || bn <= 0 || A.gram_next == nullptr) return;
+    const int nw = kStepThreads / 64 - w0;                 // waves w0 .. 7 do the work
+    if ((int)(threadIdx.x >> 6) < w0 || bn <= 0 || A.gram_next == nullptr) return;
+    const int wave = (int)(threadIdx.x >> 6) - w0 + 1;     // 1 .. nw
     float sink = 0.f;
     if (whole_block) {
         const int nlines = (bn * bn + 31) / 32;                                    // 128-byte lines of the next Gram block
         float v[4];                                                                // (<= 4 x 448 lines: a 128 x 128 block has 512)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int l = (wave - 1) * 64 + lane + u * 7 * 64;
+            const int l = (wave - 1) * 64 + lane + u * nw * 64;
             v[u] = A.gram_next[(int64_t)(l < nlines ? l : nlines - 1) * 32];
         }
 #pragma unroll
@@ -348,7 +405,8 @@ __device__ __forceinline__ void prefetch_next_gram(const SamplerArgs& A, bool wh
     } else {
         // every lane whose marker is in the model touches the lines of ITS row: independent loads, one wait at the end
         const int lines_per_row = (bn + 31) / 32;                                  // <= 32 for 1024-marker blocks
-        for (int c0 = (wave - 1) * 64; c0 < bn; c0 += 7 * 64) {
+        for (int c0 = (wave - 1) * 64; c0 < bn; c0 += nw * 64) {
+            if (stop && __hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
             const int c = c0 + lane;
             const float a = A.alpha[A.j0 + A.b + (c < bn ? c : 0)];
             if (c < bn && a != 0.f) {
@@ -368,15 +426,18 @@ __device__ __forceinline__ void prefetch_next_gram(const SamplerArgs& A, bool wh
 
 // Waves 1..7: touch the cross-Gram rows (X_this' X_next) of the staged candidates so that corr_phase finds
 // them in L2 instead of paying an HBM round trip at the end of the chain.
-__device__ __forceinline__ void prefetch_cross_rows(char* smem, const StepSmem& SM, const SamplerArgs& A, int ncand)
+__device__ __forceinline__ void prefetch_cross_rows(char* smem, const StepSmem& SM, const SamplerArgs& A, int ncand, int w0 = 1, const int* stop = nullptr)
 {
     const short* cand_list = reinterpret_cast<const short*>(smem + SM.cand_off);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
     const int bn = A.b_next;
-    if (wave == 0 || bn <= 0) return;
+    const int nw = kStepThreads / 64 - w0;                 // waves w0 .. 7 do the work
+    if ((int)(threadIdx.x >> 6) < w0 || bn <= 0) return;
+    const int wave = (int)(threadIdx.x >> 6) - w0 + 1;     // 1 .. nw
     const int nchunk = (bn + 63) / 64, ntask = ncand * nchunk;
     float sink = 0.f;
-    for (int t0 = (wave - 1) * 8; t0 < ntask; t0 += (kStepThreads / 64 - 1) * 8) {
+    for (int t0 = (wave - 1) * 8; t0 < ntask; t0 += nw * 8) {
+        if (stop && __hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
         float v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -420,7 +481,7 @@ __device__ __forceinline__ void copy_cross_rows(char* smem, const StepSmem& SM, 
 }
 
 // Stage the Gram rows of the candidate markers (cand[q] for marker c = tid + q*kStepThreads) in LDS.
-__device__ __forceinline__ int stage_rows(char* smem, const StepSmem& SM, const SamplerArgs& A, const bool (&cand)[2])
+__device__ __forceinline__ int stage_rows(char* smem, const StepSmem& SM, const SamplerArgs& A, const bool (&cand)[2], long long* ts = nullptr)
 {
     const int B = SM.B;
     short* slot_of = reinterpret_cast<short*>(smem + SM.slot_off);
@@ -451,31 +512,35 @@ __device__ __forceinline__ int stage_rows(char* smem, const StepSmem& SM, const 
         __syncthreads();
     }
     const int ncand = base < SM.max_cand ? base : SM.max_cand;
+    if (ts) ts[0] = clock64();
     // ALL row loads of the workgroup are issued before the first one is consumed: the fetch costs ONE memory latency
-    // (microseconds under full-rate streaming), not one per batch.  Full blocks (rows 16-byte aligned): (row, 256-column)
-    // tasks, one float4 per lane; <= kSQ tasks per wave in flight, i.e. up to 8*kSQ*256 = 49 152 floats per pass.
+    // (microseconds under full-rate streaming), not one per batch.  Full blocks of 256 / 512 / 1024 markers (rows 16-byte
+    // aligned): (row, 256-column) tasks, one float4 per lane, task = u*8 + wave.  The task -> (row, chunk) mapping uses
+    // shifts only and the candidates' row indices are fetched from LDS in one batch first: measured, the address
+    // arithmetic (a runtime division and a dependent LDS read per task, 24 tasks per wave whatever the count) cost more
+    // than the memory latency itself -- 20 k of the 21 k cycles this function took per 512-marker block.
     const int b4 = A.b;
-    if (b4 == B && (B & 255) == 0) {
-        constexpr int kSQ = 24;
-        const int nchunk = B / 256, ntask = ncand * nchunk;
-        for (int t0 = 0; t0 < ntask; t0 += (kStepThreads / 64) * kSQ) {
-            float4 v[kSQ];
-#pragma unroll
-            for (int u = 0; u < kSQ; ++u) {
-                const int task = t0 + u * (kStepThreads / 64) + wave;          // tasks interleaved over the waves
-                const int tk = task < ntask ? task : ntask - 1;
-                const int row = tk / nchunk, c = (tk - row * nchunk) * 256 + lane * 4;
-                v[u] = *reinterpret_cast<const float4*>(A.gram + (int64_t)cand_list[row] * B + c);
-            }
-#pragma unroll
-            for (int u = 0; u < kSQ; ++u) {
-                const int task = t0 + u * (kStepThreads / 64) + wave;
-                if (task < ntask) {
-                    const int row = task / nchunk, c = (task - row * nchunk) * 256 + lane * 4;
-                    *reinterpret_cast<float4*>(rows + row * B + c) = v[u];
-                }
-            }
+    if (b4 == B && (B == 256 || B == 512 || B == 1024)) {
+        // Direct global -> LDS loads (global_load_lds_dwordx4: each lane's 16 bytes land at M0 + lane*16, i.e. one task =
+        // 1 KB of a row straight into its slot): no staging registers, a ROLLED loop of a few instructions with every load
+        // in flight, one wait at the end.  (The unrolled register version spent 14 k cycles per block just issuing: cold
+        // straight-line code is fetched at memory latency.)
+        typedef __attribute__((address_space(3))) void lds_void;
+        const int sh = (B == 1024) ? 2 : (B == 512 ? 1 : 0);             // log2(256-column chunks per row)
+        const int ntask = ncand << sh;
+        // lane u of the wave holds the marker of its u-th task (task = wave + 8u)
+        const int tmine = wave + 8 * lane;
+        const int mycand = (int)cand_list[(tmine < ntask ? tmine : 0) >> sh];
+        int u = 0;
+        for (int task = wave; task < ntask; task += kStepThreads / 64, ++u) {
+            const int crow = __builtin_amdgcn_readlane(mycand, u);
+            const int ch = (task & ((1 << sh) - 1)) << 8;
+            __builtin_amdgcn_global_load_lds(A.gram + (crow * B + ch + lane * 4),
+                                             (lds_void*)(rows + ((task >> sh) * B + ch)), 16, 0, 0);
         }
+        if (ts) ts[1] = clock64();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (ts) ts[2] = clock64();
     } else {
     // (row, 64-column chunk) tasks, kSL independent loads in flight per wave (ragged last block, 64/128-marker blocks)
     constexpr int kSL = 16;
@@ -665,15 +730,29 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
         }
         if (mask) first_sub = __builtin_ctz(mask);
     }
+    // single-pass sweeps with a next block: waves 1..4 accumulate its lookahead correction while the serial wave runs
+    const bool stream_corr = ((P->nreps > 0 ? P->nreps : b) == 1) && !prestage && A.b_next > 0;
+    if (tid == 0) { int* wc0 = reinterpret_cast<int*>(smem + SM.wcnt_off); wc0[12] = 0; wc0[13] = 0; }
     __syncthreads();                               // (stage_rows reuses the slots)
     const long long tk1 = clock64();
     const long long tk2 = clock64();
     // (a block without any candidate -- about a third of them with a sparse prior -- has nothing to stage or to walk)
-    int nstaged = prestage ? b : (first_sub >= 16 ? 0 : stage_rows(smem, SM, A, cand));
+    long long tss[3] = {tk2, tk2, tk2};
+    int nstaged = prestage ? b : (first_sub >= 16 ? 0 : stage_rows(smem, SM, A, cand, tss));
     const bool cross_lds = prestage && SM.has_cross;
-    if (cross_lds) copy_cross_rows(smem, SM, A);         // waves 1..7, while wave 0 runs the serial phase
-    else prefetch_cross_rows(smem, SM, A, nstaged);      // waves 1..7: pull the rows into L2 for corr_phase at the end
-    prefetch_next_gram(A, prestage);                     // waves 1..7: the next block's staging becomes an L2 hit
+    float4 corr_mine{0.f, 0.f, 0.f, 0.f};
+    if (stream_corr) {
+        if (is_corr_helper(wave)) corr_mine = stream_corr_role(smem, SM, A);      // returns when the serial wave is done
+        else if (wave >= 5) {                                           // waves 5, 6, 7
+            const int* stop = reinterpret_cast<const int*>(smem + SM.wcnt_off) + 13;
+            prefetch_cross_rows(smem, SM, A, nstaged, 5, stop);         // the helpers' loads become L2 hits
+            prefetch_next_gram(A, prestage, 5, stop);
+        }
+    } else {
+        if (cross_lds) copy_cross_rows(smem, SM, A);         // waves 1..7, while wave 0 runs the serial phase
+        else prefetch_cross_rows(smem, SM, A, nstaged);      // waves 1..7: pull the rows into L2 for corr_phase at the end
+        prefetch_next_gram(A, prestage);                     // waves 1..7: the next block's staging becomes an L2 hit
+    }
     int* wcnt_s = reinterpret_cast<int*>(smem + SM.wcnt_off);
     long long tk3 = 0, tk4 = 0, tk5 = 0;
     int nrounds = 0, nslow = 0;
@@ -771,6 +850,8 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
     // committed changes {row offset, D} lives in two VGPRs (lane e = entry e, written with v_writelane, read back with
     // v_readlane), so bringing a later sub-block up to date costs one LDS read per entry and no dependent second one.
     if (lazy && !dense_done) {
+        int2* plog = reinterpret_cast<int2*>(smem + SM.log_off);
+        int npub = 0;
         int log_off = 0;            // lane e: sl*B of entry e
         float log_D = 0.f;          // lane e: alpha_old - alpha_new of entry e
         // apply the logged changes (in commit order) to the rhs of the sub-blocks after `s` and empty the log: needed before
@@ -853,6 +934,13 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
                 pending = (k == 63) ? 0ull : (pending & ~((2ull << k) - 1ull));
                 const float D = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Dl), k));
                 if (D != 0.f) {
+                    // the block's change list {local column, alpha_old - alpha_new}: marker order = commit order; read by
+                    // the correction helpers while it grows and by the final stores
+                    if (lane == 0) {
+                        plog[npub] = make_int2(64 * s + k, __float_as_int(D));
+                        __hip_atomic_store(&wcnt_s[12], npub + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    ++npub;
                     // rhs += D * G[ce][:] (BayesABC.jl:169,172).  The active sub-block is corrected in its register
                     // copy -- the only value the next round waits for.
                     int sl = __builtin_amdgcn_readlane(my_slot, k);
@@ -878,6 +966,10 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
                 }
                 if (pending == 0ull) break;
             }
+        }
+        if (lane == 0) {
+            wcnt_s[11] = npub;                                              // (read after the barrier)
+            __hip_atomic_store(&wcnt_s[13], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);     // the helpers may finish
         }
     }
 
@@ -1010,31 +1102,54 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
             rhs_lds[c] = rhs;
         }
     }
-    // the net changes of this block as a compact list in LDS (nothing changed before the first candidate's sub-block)
+    // the net changes of this block as a compact list in LDS (nothing changed before the first candidate's sub-block);
+    // single-pass sweeps: the published change log IS that list
     tk4 = clock64();
-    int base = 0;
+    if (!(lazy && !dense_done)) {
+        int base = 0;
 #pragma unroll 1
-    for (int s = s_first; s < nsub; ++s) {
-        const int c = 64 * s + lane;
-        const bool changed = (c < b) && (astart[c] != acur[c]);
-        const unsigned long long cm = __ballot(changed);
-        if (changed) reinterpret_cast<int*>(smem + SM.log_off)[base + __popcll(cm & ((1ull << lane) - 1ull))] = c;
-        base += __popcll(cm);
+        for (int s = s_first; s < nsub; ++s) {
+            const int c = 64 * s + lane;
+            const bool changed = (c < b) && (astart[c] != acur[c]);
+            const unsigned long long cm = __ballot(changed);
+            if (changed) reinterpret_cast<int*>(smem + SM.log_off)[base + __popcll(cm & ((1ull << lane) - 1ull))] = c;
+            base += __popcll(cm);
+        }
+        if (lane == 0) { wcnt_s[15] = base; wcnt_s[11] = -1; }
     }
-    if (lane == 0) wcnt_s[15] = base;
     tk5 = clock64();
     }   // wave 0
     __syncthreads();
-    const int nfin = wcnt_s[15];
+    const bool from_log = wcnt_s[11] >= 0;                  // single pass: {column, d} pairs published by the serial wave
+    const int nfin = from_log ? wcnt_s[11] : wcnt_s[15];
     const long long tk6 = clock64();
-    if (A.b_next > 0) corr_phase<1>(smem, SM, A, nfin, cross_lds);
+    if (A.b_next > 0 && !stream_corr) {
+        if (from_log) {                                     // (small blocks with a sparse prior: corr_phase wants plain columns)
+            const int2* plog = reinterpret_cast<const int2*>(smem + SM.log_off);
+            int cols[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) cols[q] = (tid + q * kStepThreads < nfin) ? plog[tid + q * kStepThreads].x : 0;
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 2; ++q) if (tid + q * kStepThreads < nfin) reinterpret_cast<int*>(smem + SM.log_off)[tid + q * kStepThreads] = cols[q];
+            __syncthreads();
+        }
+        corr_phase<1>(smem, SM, A, nfin, cross_lds);
+    }
     const long long tk7 = clock64();
     // ---- global stores LAST (nothing in this launch waits for them; a barrier after a global store waits for the store):
     // the change list for the next update role, alpha of the changed markers, beta / delta of the whole block
+    if (stream_corr && is_corr_helper(wave)) {              // the lookahead correction accumulated by this helper lane
+        const int col = (corr_helper_index(wave) * 64 + lane) * 4, bn = A.b_next;
+        const float cv[4] = {corr_mine.x, corr_mine.y, corr_mine.z, corr_mine.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (col + i < B) A.corr_out[col + i] = (col + i < bn) ? cv[i] : 0.f;
+    }
     {
         const int* fin = reinterpret_cast<const int*>(smem + SM.log_off);
+        const bool pairs = from_log && (stream_corr || A.b_next <= 0);          // (else the list was turned into plain columns)
         for (int e = tid; e < nfin; e += kStepThreads) {
-            const int ce = fin[e];
+            const int ce = pairs ? fin[2 * e] : fin[e];
             const float d = astart[ce] - acur[ce];
             A.ev_out->idx[e] = (int32_t)(j0 + ce);
             A.ev_out->delta[0][e] = d;
@@ -1057,6 +1172,9 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
         atomicAdd(&A.counters[7], (unsigned long long)nrounds);
         if (nslow) atomicAdd(&A.counters[8], (unsigned long long)nslow);      // BayesR: rounds that needed the double-precision evaluation
         atomicAdd(&A.counters[9], (unsigned long long)(tk7 - tk6));           // the lookahead-correction phase
+        atomicAdd(&A.counters[10], (unsigned long long)(tss[0] - tk2));       // staging: slot assignment | load issue | LDS stores
+        atomicAdd(&A.counters[11], (unsigned long long)(tss[1] - tss[0]));
+        atomicAdd(&A.counters[12], (unsigned long long)(tss[2] - tss[1]));
     }
 }
 

@@ -1,4 +1,6 @@
 cd $GRAFT_REPO_ROOT
-python bench.py --no-cpu-baseline --via-api 0 | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('config2', d['value'], d['ms_per_step'], d['config']['device_sweep_ms'], d['roofline']['frac'])"
-python bench.py --no-cpu-baseline --via-api 0 --workload config5shard | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('config5', d['value'], d['ms_per_step'], d['config']['device_sweep_ms'], d['roofline']['frac'])"
-python bench.py --no-cpu-baseline --via-api 0 --steps 10 --warmup 10 --burnin 0 --pi-fixed 0.95 | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('pifixed', d['value'], d['ms_per_step'], d['config']['device_sweep_ms'], d['roofline']['frac'])"
+python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "bayesc_chain or bayesr_chain or many_changes or fuzz" 2>&1 | grep -v "RCCL\|HIP ver\|ROCm ver\|Hostname\|Librccl" | tail -2
+B="--no-cpu-baseline --via-api 0 --steps 10 --warmup 10 --burnin 0"
+for w in "--pi-fixed 0.95" "--workload config3"; do
+JWAS_HIP_DEBUG_PHASES=1 python bench.py $B $w 2> /tmp/err.txt | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['config']['name'], d['value'], d['ms_per_step'], d['config']['device_sweep_ms'])"; grep jwas_hip /tmp/err.txt | tail -1
+done
