@@ -480,6 +480,16 @@ __device__ __forceinline__ void copy_cross_rows(char* smem, const StepSmem& SM, 
     }
 }
 
+// Linear copy global -> LDS with direct loads (global_load_lds_dwordx4: 1 KB per wave instruction), all 8 waves, rolled
+// loop, no registers; nfloats a multiple of 256.  The caller waits (s_waitcnt vmcnt(0)) and synchronises.
+__device__ __forceinline__ void dma_copy_to_lds(const float* __restrict__ src, float* lds_dst, int nfloats)
+{
+    typedef __attribute__((address_space(3))) void lds_void;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = wave * 256; k < nfloats; k += (kStepThreads / 64) * 256)
+        __builtin_amdgcn_global_load_lds(src + k + lane * 4, (lds_void*)(lds_dst + k), 16, 0, 0);
+}
+
 // Stage the Gram rows of the candidate markers (cand[q] for marker c = tid + q*kStepThreads) in LDS.
 __device__ __forceinline__ int stage_rows(char* smem, const StepSmem& SM, const SamplerArgs& A, const bool (&cand)[2], long long* ts = nullptr)
 {
@@ -633,8 +643,15 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
     // not depend on anything this launch computes -- fetch it with the very first loads instead of after the candidates
     // are known (one dependent memory latency less per block).  Slot of marker c = c.
     const bool prestage = (B <= 128) && (B <= SM.max_cand);
+    // full blocks: the Gram block (and the cross-Gram rows X_this'X_next, when they have their own LDS room and the next
+    // block is full too) go straight to LDS with direct loads issued before anything else: a handful of instructions
+    // instead of ~200 lines of cold unrolled code (instruction fetch after a dispatch runs at memory latency)
+    const bool gram_dma = prestage && b == B;
+    const bool cross_dma = gram_dma && SM.has_cross && A.b_next == B;
+    if (gram_dma) dma_copy_to_lds(A.gram, reinterpret_cast<float*>(smem + SM.rows_off), B * B);
+    if (cross_dma) dma_copy_to_lds(A.cross_next, reinterpret_cast<float*>(smem + SM.cross_off), B * B);
     float4 gpre[8];
-    if (prestage) {
+    if (prestage && !gram_dma) {
         // B*B/4 float4 elements over 512 threads: <= 8 per thread; element e -> row e / (B/4), float4 column e % (B/4)
         const int per_row = B >> 2, total = b * per_row;
 #pragma unroll
@@ -692,15 +709,17 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
         float* rows_p = reinterpret_cast<float*>(smem + SM.rows_off);
         short* slot_p = reinterpret_cast<short*>(smem + SM.slot_off);
         short* cand_p = reinterpret_cast<short*>(smem + SM.cand_off);
-        const int per_row = B >> 2, total = b * per_row;
+        if (!gram_dma) {
+            const int per_row = B >> 2, total = b * per_row;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int e = tid + u * kStepThreads;
-            if (e < total) {
-                const int row = e / per_row, c4 = (e - row * per_row) * 4;
-                *reinterpret_cast<float4*>(rows_p + row * B + c4) = gpre[u];
+            for (int u = 0; u < 8; ++u) {
+                const int e = tid + u * kStepThreads;
+                if (e < total) {
+                    const int row = e / per_row, c4 = (e - row * per_row) * 4;
+                    *reinterpret_cast<float4*>(rows_p + row * B + c4) = gpre[u];
+                }
             }
-        }
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the direct loads have landed (barrier below)
         for (int c = tid; c < B; c += kStepThreads) { slot_p[c] = (short)(c < b ? c : -1); cand_p[c] = (short)c; }
     }
     // number of markers whose effect changes against the entry rhs (block-wide count through the wave-count slots;
@@ -749,7 +768,7 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
             prefetch_next_gram(A, prestage, 5, stop);
         }
     } else {
-        if (cross_lds) copy_cross_rows(smem, SM, A);         // waves 1..7, while wave 0 runs the serial phase
+        if (cross_lds) { if (!cross_dma) copy_cross_rows(smem, SM, A); }     // waves 1..7, while wave 0 runs the serial phase
         else prefetch_cross_rows(smem, SM, A, nstaged);      // waves 1..7: pull the rows into L2 for corr_phase at the end
         prefetch_next_gram(A, prestage);                     // waves 1..7: the next block's staging becomes an L2 hit
     }
@@ -1634,8 +1653,10 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
     // small blocks (the host's choice for dense priors): the whole Gram block with the very first loads, as in the
     // single-trait sampler (slot of marker c = c)
     const bool prestage = (B <= 128) && (B <= SM.max_cand);
+    const bool gram_dma = prestage && b == B;              // full block: direct global -> LDS loads (see sampler_role_st)
+    if (gram_dma) dma_copy_to_lds(A.gram, reinterpret_cast<float*>(smem + SM.rows_off), B * B);
     float4 gpre[8];
-    if (prestage) {
+    if (prestage && !gram_dma) {
         const int per_row = B >> 2, total = b * per_row;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -1697,15 +1718,17 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
         float* rows_p = reinterpret_cast<float*>(smem + SM.rows_off);
         short* slot_p = reinterpret_cast<short*>(smem + SM.slot_off);
         short* cand_p = reinterpret_cast<short*>(smem + SM.cand_off);
-        const int per_row = B >> 2, total = b * per_row;
+        if (!gram_dma) {
+            const int per_row = B >> 2, total = b * per_row;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int e = tid + u * kStepThreads;
-            if (e < total) {
-                const int row = e / per_row, c4 = (e - row * per_row) * 4;
-                *reinterpret_cast<float4*>(rows_p + row * B + c4) = gpre[u];
+            for (int u = 0; u < 8; ++u) {
+                const int e = tid + u * kStepThreads;
+                if (e < total) {
+                    const int row = e / per_row, c4 = (e - row * per_row) * 4;
+                    *reinterpret_cast<float4*>(rows_p + row * B + c4) = gpre[u];
+                }
             }
-        }
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         for (int c = tid; c < B; c += kStepThreads) { slot_p[c] = (short)(c < b ? c : -1); cand_p[c] = (short)c; }
     }
     __syncthreads();
