@@ -328,7 +328,7 @@ __device__ __forceinline__ void corr_phase(char* smem, const StepSmem& SM, const
 // Waves 1..4 of the sampler workgroup in single-pass sweeps: the lookahead correction of the NEXT block,
 //   corr[c] = fmaf(d_e, C[e][c], corr[c])  from 0 over the changed markers e in marker order  (C = X_this' X_next),
 // accumulated WHILE the serial wave runs.  The serial wave commits in marker order and publishes every change
-// {local column, alpha_old - alpha_new} to a log in LDS (counter wc[12], release / acquire at workgroup scope; wc[13] is
+// {local column, alpha_old - alpha_new} to a log in LDS with one 8-byte write (entries are pre-set to column -1; wc[13] is
 // set after the last one); each helper lane owns four columns of the next block and consumes the log as it grows -- the
 // cross-Gram rows come from L2 (prefetch_cross_rows) or HBM, off the critical path.  When the serial wave is done the
 // correction is (nearly) done too: no dependent fetch of the changed markers' rows at the end of the block.
@@ -347,9 +347,14 @@ __device__ __forceinline__ float4 stream_corr_role(char* smem, const StepSmem& S
     const bool vec = (bn & 3) == 0;                         // full next block: rows 16-byte aligned
     float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
     int done = 0;
+    const volatile int* vcol = reinterpret_cast<const volatile int*>(plog);       // entry e: {column, bits(d)}; column -1 = not written yet
     while (true) {
         const int fin = __hip_atomic_load(&wc[13], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const int n = __hip_atomic_load(&wc[12], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // the serial wave publishes an entry with ONE 8-byte LDS write (no counter, no wait on its side): count the
+        // valid entries after `done` (at most 8 per visit)
+        int n = done;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (n == done + u && n < B && vcol[2 * n] >= 0) ++n;
         if (n > done) {
             if (col < bn) {
                 for (int e0 = done; e0 < n; e0 += 8) {
@@ -752,6 +757,7 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
     // single-pass sweeps with a next block: waves 1..4 accumulate its lookahead correction while the serial wave runs
     const bool stream_corr = ((P->nreps > 0 ? P->nreps : b) == 1) && !prestage && A.b_next > 0;
     if (tid == 0) { int* wc0 = reinterpret_cast<int*>(smem + SM.wcnt_off); wc0[12] = 0; wc0[13] = 0; }
+    if (stream_corr) for (int c = tid; c < B; c += kStepThreads) reinterpret_cast<int2*>(smem + SM.log_off)[c] = make_int2(-1, 0);
     __syncthreads();                               // (stage_rows reuses the slots)
     const long long tk1 = clock64();
     const long long tk2 = clock64();
@@ -947,7 +953,7 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
                     if (lane == k) { acur[c] = an; dpark[c] = (float)(cls + 1); }             // stored as class 1..4
                 } else {
                     an = abc_alpha_new(rhs, a_cur, c_d, ie, c_il, c_zs, inc);
-                    if (lane == k) { acur[c] = an; bpark[c] = inc ? an : c_bex; dpark[c] = inc ? 1.f : 0.f; }
+                    if (lane == k) acur[c] = an;          // (beta / delta follow from alpha at the end: derive_bd)
                 }
                 const float Dl = a_cur - an;
                 pending = (k == 63) ? 0ull : (pending & ~((2ull << k) - 1ull));
@@ -955,10 +961,7 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
                 if (D != 0.f) {
                     // the block's change list {local column, alpha_old - alpha_new}: marker order = commit order; read by
                     // the correction helpers while it grows and by the final stores
-                    if (lane == 0) {
-                        plog[npub] = make_int2(64 * s + k, __float_as_int(D));
-                        __hip_atomic_store(&wcnt_s[12], npub + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
+                    if (lane == 0) plog[npub] = make_int2(64 * s + k, __float_as_int(D));
                     ++npub;
                     // rhs += D * G[ce][:] (BayesABC.jl:169,172).  The active sub-block is corrected in its register
                     // copy -- the only value the next round waits for.
@@ -1175,8 +1178,16 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
             if (e < 7) { A.ev_out->hidx[e] = (int32_t)(j0 + ce); A.ev_out->hdelta[e] = d; }
             A.alpha[j0 + ce] = acur[ce];
         }
+        // single-pass BayesA/B/C: a marker is in the model iff its effect is nonzero, beta = the effect, else its
+        // "excluded" draw (parked at entry) -- the serial wave only wrote alpha
+        const bool derive_bd = !kR && from_log;
         for (int c = tid; c < b; c += kStepThreads) {
             if constexpr (kR) reinterpret_cast<int32_t*>(A.delta)[j0 + c] = (int32_t)dpark0[c];
+            else if (derive_bd) {
+                const float a = acur[c];
+                A.beta[j0 + c] = (a != 0.f) ? a : bpark0[c];
+                reinterpret_cast<float*>(A.delta)[j0 + c] = (a != 0.f) ? 1.f : 0.f;
+            }
             else { A.beta[j0 + c] = bpark0[c]; reinterpret_cast<float*>(A.delta)[j0 + c] = dpark0[c]; }
         }
     }
