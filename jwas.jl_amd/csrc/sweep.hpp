@@ -614,6 +614,55 @@ __device__ __forceinline__ void apply_gram_row(char* smem, const StepSmem& SM, c
 //   BayesA/B/C: doubles [zs]                      floats [1/lhs, beta_excl, x'x, lo, hi]   (lo/hi: AbcMarker::thresholds)
 //   BayesR    : doubles [1/lhs_k, zs_k, T_k] (9)  floats [x'x, candidate threshold]
 // ---------------------------------------------------------------------------------------------
+// ---- DENSE blocks: one 64-marker section of the in-lane walk (see sampler_role_st).  Lane l owns marker l of the section
+// (Q = 0: running rhs r0; Q = 1: r1); at step l lane l's alpha_old - alpha_new is broadcast with one v_readlane and applied
+// to the running rhs of the section's own markers (Q = 0) and of the next section's (TWO) with the marker's Gram row
+// (grow: LDS, row stride B; read a batch of eight rows ahead).  rev = the rhs the lane's own marker was evaluated
+// against.  ALLINC: every marker is included whatever its rhs (no compare / select on the chain).  No branch inside
+// a batch; the dependent chain per step is add, mul, mul, cvt, add(f64), cvt, sub, readlane, fma.
+__device__ __forceinline__ float dense_alpha_new(float x, float da, float ie, float invLhs, double zs, bool incl)
+{
+    const float rhs  = (x + da) * ie;                                       // BayesABC.jl:36  (da = d * alpha_old)
+    const float gHat = rhs * invLhs;                                        // :39
+    return incl ? (float)((double)gHat + zs) : 0.f;                         // :46 / :55
+}
+template <int Q, bool TWO, bool ALLINC>
+__device__ __forceinline__ void dense_section(const float* grow, int B, int nsteps, int lane, float ie, float lo, float hi,
+                                              float il, float da, float ao, double zs, float& r0, float& r1, float& rev)
+{
+    auto step = [&](int l, float c0, float c1) {
+        const float x = (Q == 0) ? r0 : r1;
+        const float an = dense_alpha_new(x, da, ie, il, zs, ALLINC ? true : abc_included(x, lo, hi));
+        const float Dl = ao - an;                                           // (excluded: alpha_old - 0)
+        rev = (lane == l) ? x : rev;
+        const float D = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Dl), l));
+        if (Q == 0) r0 = fmaf(D, c0, r0);                                   // D = 0: exact no-op
+        if (TWO) r1 = fmaf(D, c1, r1);
+    };
+    constexpr int kBatch = 8;
+    float n0[kBatch], n1[kBatch];
+    auto load = [&](int l0) {
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            n0[u] = (Q == 0) ? grow[(l0 + u) * B + lane] : 0.f;
+            n1[u] = TWO ? grow[(l0 + u) * B + 64 + lane] : 0.f;
+        }
+    };
+    int l = 0;
+    if (nsteps >= kBatch) load(0);
+#pragma unroll 1
+    for (; l + kBatch <= nsteps; l += kBatch) {
+        float c0[kBatch], c1[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) { c0[u] = n0[u]; c1[u] = n1[u]; }
+        if (l + 2 * kBatch <= nsteps) load(l + kBatch);                    // the next batch's rows: in flight during this one
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) step(l + u, c0[u], c1[u]);
+    }
+#pragma unroll 1
+    for (; l < nsteps; ++l) step(l, (Q == 0) ? grow[l * B + lane] : 0.f, TWO ? grow[l * B + 64 + lane] : 0.f);
+}
+
 __host__ __device__ constexpr int st_park_nd(int method) { return method == kBayesR ? BayesRMarker::kFastD : 1; }
 __host__ __device__ constexpr int st_park_nf(int method) { return method == kBayesR ? 2 : 5; }
 
@@ -756,7 +805,7 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
     }
     // single-pass sweeps with a next block: waves 1..4 accumulate its lookahead correction while the serial wave runs
     const bool stream_corr = ((P->nreps > 0 ? P->nreps : b) == 1) && !prestage && A.b_next > 0;
-    if (tid == 0) { int* wc0 = reinterpret_cast<int*>(smem + SM.wcnt_off); wc0[12] = 0; wc0[13] = 0; }
+    if (tid == 0) { int* wc0 = reinterpret_cast<int*>(smem + SM.wcnt_off); wc0[12] = 0; wc0[13] = 0; wc0[14] = 0; }
     if (stream_corr) for (int c = tid; c < B; c += kStepThreads) reinterpret_cast<int2*>(smem + SM.log_off)[c] = make_int2(-1, 0);
     __syncthreads();                               // (stage_rows reuses the slots)
     const long long tk1 = clock64();
@@ -824,46 +873,43 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
     bool dense_done = false;
     if constexpr (!kR) {
         if (nreps == 1 && prestage && nstaged == b && 5 * ncand_all >= 3 * b) {
-            float lo[2], hi[2], il[2], dj[2], ao[2], rhsq[2], rev[2], bex[2];
+            float lo[2], hi[2], il[2], da[2], ao[2], rhsq[2], rev[2], bex[2];
             double zs[2];
+            bool always = true;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int c = (64 * q + lane < B) ? 64 * q + lane : 0;
-                il[q] = lpf[c]; bex[q] = lpf[B + c]; dj[q] = lpf[2 * B + c]; lo[q] = lpf[3 * B + c]; hi[q] = lpf[4 * B + c];
+                il[q] = lpf[c]; bex[q] = lpf[B + c]; lo[q] = lpf[3 * B + c]; hi[q] = lpf[4 * B + c];
                 zs[q] = lpd[c];
                 rhsq[q] = rhs_lds[c]; ao[q] = acur[c]; rev[q] = rhsq[q];
+                da[q] = lpf[2 * B + c] * ao[q];                                       // d * alpha_old (BayesABC.jl:36)
+                always = always && (lo[q] == hi[q]);                                  // thresholds(): lo = hi <=> always included
             }
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int jend = (b < 64 * (q + 1)) ? b : 64 * (q + 1);
-                if (64 * q >= jend) break;
-                const float* grow = rows + 64 * q * B;
-                float g0 = (q == 0) ? grow[lane] : 0.f;                               // row of the first marker of the sub-block
-                float g1 = (B > 64) ? grow[64 + lane] : 0.f;
-#pragma unroll 1
-                for (int jj = 64 * q; jj < jend; ++jj) {
-                    const int l = jj - 64 * q;
-                    const float x = rhsq[q];
-                    const bool inc = abc_included(x, lo[q], hi[q]);
-                    const float an = abc_alpha_new(x, ao[q], dj[q], ie, il[q], zs[q], inc);
-                    const float Dl = ao[q] - an;                                      // (excluded: alpha_old - 0)
-                    rev[q] = (lane == l) ? x : rev[q];                                // lane l: the rhs it was evaluated against
-                    const float D = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Dl), l));
-                    const float c0 = g0, c1 = g1;
-                    grow += B;                                                        // next marker's row (one past the block: the overflow row)
-                    if (q == 0) g0 = grow[lane];
-                    if (B > 64) g1 = grow[64 + lane];
-                    if (q == 0) rhsq[0] = fmaf(D, c0, rhsq[0]);                       // D = 0: exact no-op
-                    if (B > 64) rhsq[1] = fmaf(D, c1, rhsq[1]);
+            // Pi = 0 / BayesA / RR-BLUP: every marker of the block is included whatever its rhs -- no decision on the chain
+            const bool all_in = __all(always);
+            if (B > 64) {
+                if (all_in) {
+                    dense_section<0, true, true>(rows, B, b < 64 ? b : 64, lane, ie, lo[0], hi[0], il[0], da[0], ao[0], zs[0], rhsq[0], rhsq[1], rev[0]);
+                    if (b > 64) dense_section<1, true, true>(rows + 64 * B, B, b - 64, lane, ie, lo[1], hi[1], il[1], da[1], ao[1], zs[1], rhsq[0], rhsq[1], rev[1]);
+                } else {
+                    dense_section<0, true, false>(rows, B, b < 64 ? b : 64, lane, ie, lo[0], hi[0], il[0], da[0], ao[0], zs[0], rhsq[0], rhsq[1], rev[0]);
+                    if (b > 64) dense_section<1, true, false>(rows + 64 * B, B, b - 64, lane, ie, lo[1], hi[1], il[1], da[1], ao[1], zs[1], rhsq[0], rhsq[1], rev[1]);
                 }
+            } else {
+                if (all_in) dense_section<0, false, true>(rows, B, b, lane, ie, lo[0], hi[0], il[0], da[0], ao[0], zs[0], rhsq[0], rhsq[1], rev[0]);
+                else dense_section<0, false, false>(rows, B, b, lane, ie, lo[0], hi[0], il[0], da[0], ao[0], zs[0], rhsq[0], rhsq[1], rev[0]);
             }
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int c = 64 * q + lane;
                 const bool inc = abc_included(rev[q], lo[q], hi[q]);
-                const float an = abc_alpha_new(rev[q], ao[q], dj[q], ie, il[q], zs[q], inc);
-                if (c < B) { acur[c] = (c < b) ? an : 0.f; bpark0[c] = inc ? an : bex[q]; dpark0[c] = inc ? 1.f : 0.f; }
+                const float an = dense_alpha_new(rev[q], da[q], ie, il[q], zs[q], inc);
+                if (c < B) {
+                    acur[c] = (c < b) ? an : 0.f; bpark0[c] = inc ? an : bex[q]; dpark0[c] = inc ? 1.f : 0.f;
+                    rhs_lds[c] = (c < b) ? ao[q] - an : 0.f;                          // alpha_old - alpha_new, for the dense correction
+                }
             }
+            if (lane == 0) wcnt_s[14] = 1;
             nrounds += b;
             dense_done = true;
         }
@@ -1145,7 +1191,29 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
     const bool from_log = wcnt_s[11] >= 0;                  // single pass: {column, d} pairs published by the serial wave
     const int nfin = from_log ? wcnt_s[11] : wcnt_s[15];
     const long long tk6 = clock64();
-    if (A.b_next > 0 && !stream_corr) {
+    if (A.b_next > 0 && !stream_corr && cross_lds && wcnt_s[14] != 0) {
+        // dense walk: every marker of the block is an entry (alpha_old - alpha_new left in rhs_lds; 0 = exact no-op), the
+        // cross-Gram rows are in LDS: one thread per column of the next block, a chain of b fused multiply-adds in marker
+        // order fed by broadcast reads of four changes and conflict-free reads of the rows
+        const float* crossL = reinterpret_cast<const float*>(smem + SM.cross_off);
+        if (tid < B) {
+            float corr = 0.f;
+            if (tid < A.b_next) {
+                int e = 0;
+#pragma unroll 1
+                for (; e + 8 <= b; e += 8) {
+                    const float4 d0 = *reinterpret_cast<const float4*>(rhs_lds + e), d1 = *reinterpret_cast<const float4*>(rhs_lds + e + 4);
+                    float g[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) g[u] = crossL[(e + u) * B + tid];
+                    corr = fmaf(d0.x, g[0], corr); corr = fmaf(d0.y, g[1], corr); corr = fmaf(d0.z, g[2], corr); corr = fmaf(d0.w, g[3], corr);
+                    corr = fmaf(d1.x, g[4], corr); corr = fmaf(d1.y, g[5], corr); corr = fmaf(d1.z, g[6], corr); corr = fmaf(d1.w, g[7], corr);
+                }
+                for (; e < b; ++e) corr = fmaf(rhs_lds[e], crossL[e * B + tid], corr);
+            }
+            A.corr_out[tid] = corr;
+        }
+    } else if (A.b_next > 0 && !stream_corr) {
         if (from_log) {                                     // (small blocks with a sparse prior: corr_phase wants plain columns)
             const int2* plog = reinterpret_cast<const int2*>(smem + SM.log_off);
             int cols[2];
