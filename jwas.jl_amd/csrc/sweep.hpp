@@ -1733,7 +1733,9 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
     // single-trait sampler (slot of marker c = c)
     const bool prestage = (B <= 128) && (B <= SM.max_cand);
     const bool gram_dma = prestage && b == B;              // full block: direct global -> LDS loads (see sampler_role_st)
+    const bool cross_dma = gram_dma && SM.has_cross && A.b_next == B;
     if (gram_dma) dma_copy_to_lds(A.gram, reinterpret_cast<float*>(smem + SM.rows_off), B * B);
+    if (cross_dma) dma_copy_to_lds(A.cross_next, reinterpret_cast<float*>(smem + SM.cross_off), B * B);
     float4 gpre[8];
     if (prestage && !gram_dma) {
         const int per_row = B >> 2, total = b * per_row;
@@ -1793,6 +1795,7 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
         }
     }
     if (tid < (1 << NT)) lpr[tid] = lpr_mine;
+    if (tid == 0) reinterpret_cast<int*>(smem + SM.wcnt_off)[14] = 0;      // set by the dense walk
     if (prestage) {
         float* rows_p = reinterpret_cast<float*>(smem + SM.rows_off);
         short* slot_p = reinterpret_cast<short*>(smem + SM.slot_off);
@@ -1898,11 +1901,20 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
     // the whole block (NT x 2 registers per lane) with the marker's Gram row from LDS (read a step ahead).  A lane's
     // result is final at its own step: it keeps the w it was evaluated with and recomputes its update after the walk.
     bool dense_done = false;
+    // Sampler I, every marker of the block in the model for every trait at entry (the reference's default prior keeps it
+    // that way: the states with a trait missing have probability ~0): the walk SPECULATES that every delta stays 1.  Then a
+    // marker's three conditionals need neither the two log-weights nor the prior lookup -- what is left of mt1_eval (same
+    // operations, same order) is  wR - C12'beta -> * 1/C11 -> + z*sqrt(1/C11) (fp64) -> alpha_old - alpha_new,  a
+    // dependent chain of ~26 operations per three-trait marker instead of ~100.  After a 64-marker section ONE full
+    // mt1_eval per lane (all 64 markers at once, each with the w it was walked with) both verifies the speculation and
+    // yields the final state; if any marker left the model for a trait the section is walked again the general way from
+    // its saved rhs (same results, by construction: the speculative numbers are only kept when they are the exact ones).
     if (METHOD != kMTBayesC2 && nreps == 1 && prestage && nstaged_mt == b && 5 * ncand_all >= 3 * b) {
         const float* rows = reinterpret_cast<const float*>(smem + SM.rows_off);
         float rhsq[NT][2], aq[NT][2], bq[NT][2], dq[NT][2], djq[2], wev[2][NT];
         double thrq[NT][2], zq[NT][2];
         MtPre<NT> Qq[2];
+        bool mine = true;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int c = (64 * q + lane < b) ? 64 * q + lane : 0;
@@ -1916,8 +1928,10 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
                 rhsq[t][q] = rhs_lds[t * B + c]; aq[t][q] = acur[t * B + c]; bq[t][q] = bcur[t * B + c]; dq[t][q] = dcur[t * B + c];
                 thrq[t][q] = lpd[t * B + c]; zq[t][q] = lpd[(NT + t) * B + c];
                 wev[q][t] = 0.f;
+                mine = mine && (dq[t][q] == 1.f);
             }
         }
+        bool speculate = (METHOD == kMTBayesC1) && __all(mine);
         // one marker evaluated in-lane from (w, its state at block entry, its draws)
         auto eval_own = [&](int q, const float (&w)[NT], float (&an)[NT], float (&bn)[NT], float (&dn)[NT], float (&Dl)[NT]) {
             const int c = (64 * q + lane < b) ? 64 * q + lane : 0;
@@ -1929,44 +1943,115 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
             if constexpr (METHOD == kMTBayesC1) mt1_eval<NT>(K, Qq[q], PriorMem{lpr_of(c), ls}, w, djq[q], thr, z, an, bn, dn, Dl);
             else mega_eval<NT>(K, Qq[q], w, djq[q], thr, z, an, bn, dn, Dl);
         };
+        // the speculative conditionals: in bn = the marker's beta at block entry, out the new ones; Dl = alpha_old - alpha_new
+        auto eval_fast = [&](int q, const float (&w)[NT], const float (&C12)[NT][NT], const double (&zs1)[NT], float (&bn)[NT], float (&Dl)[NT]) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int jend = (b < 64 * (q + 1)) ? b : 64 * (q + 1);
-            if (64 * q >= jend) break;
-            const float* grow = rows + 64 * q * B;                   // (all rows staged in marker order: slot = marker)
-            float g0 = (q == 0) ? grow[lane] : 0.f;
-            float g1 = (B > 64) ? grow[64 + lane] : 0.f;
-#pragma unroll 1
-            for (int jj = 64 * q; jj < jend; ++jj) {
-                const int l = jj - 64 * q;
+            for (int k = 0; k < NT; ++k) {
+                float c12b = 0.f, wR = 0.f;
+#pragma unroll
+                for (int m = 0; m < NT; ++m) {
+                    wR = wR + w[m] * K.Rinv[m][k];
+                    if (m == k) continue;
+                    c12b = c12b + C12[k][m] * bn[m];
+                }
+                const float rhs1 = wR - c12b;                                                       // :96
+                const float gHat1 = rhs1 * Qq[q].invLhs1[k];
+                bn[k] = (float)((double)gHat1 + zs1[k]);                                            // :109
+                Dl[k] = aq[k][q] - bn[k];
+            }
+        };
+        // 64-marker section q: eight steps per batch without a branch, the Gram rows read a batch ahead
+        auto section = [&](auto qc, auto fastc, const float* grow, int nsteps) {
+            constexpr int Q = decltype(qc)::value;
+            constexpr bool FAST = decltype(fastc)::value;
+            float C12[NT][NT], da[NT];
+            double zs1[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                da[t] = djq[Q] * aq[t][Q];                                                          // :82
+                zs1[t] = zq[t][Q] * (double)Qq[Q].s1[t];
+#pragma unroll
+                for (int m = 0; m < NT; ++m) C12[t][m] = K.Ginv[t][m] + (djq[Q] * 1.f) * K.Rinv[t][m];      // :90 with delta_m = 1
+            }
+            auto step = [&](int l, float c0, float c1) {
                 float w[NT], an[NT], bn[NT], dn[NT], Dl[NT];
 #pragma unroll
-                for (int t = 0; t < NT; ++t) w[t] = rhsq[t][q] + djq[q] * aq[t][q];                   // :82
-                eval_own(q, w, an, bn, dn, Dl);
-                const float c0 = g0, c1 = g1;
-                grow += B;                                           // next marker's row (one past the block: the overflow row)
-                if (q == 0) g0 = grow[lane];
-                if (B > 64) g1 = grow[64 + lane];
+                for (int t = 0; t < NT; ++t) w[t] = rhsq[t][Q] + da[t];
+                if constexpr (FAST) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) bn[t] = bq[t][Q];
+                    eval_fast(Q, w, C12, zs1, bn, Dl);
+                } else eval_own(Q, w, an, bn, dn, Dl);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    wev[q][t] = (lane == l) ? w[t] : wev[q][t];      // lane l: what it was evaluated with
+                    wev[Q][t] = (lane == l) ? w[t] : wev[Q][t];      // lane l: what it was evaluated with
                     const float D = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Dl[t]), l));
-                    if (q == 0) rhsq[t][0] = fmaf(D, c0, rhsq[t][0]);                                   // D = 0: exact no-op
+                    if (Q == 0) rhsq[t][0] = fmaf(D, c0, rhsq[t][0]);                                   // D = 0: exact no-op
                     if (B > 64) rhsq[t][1] = fmaf(D, c1, rhsq[t][1]);
                 }
-            }
-        }
+            };
+            constexpr int kBatch = FAST ? 8 : 2;
+            float n0[kBatch], n1[kBatch];
+            auto load = [&](int l0) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int c = 64 * q + lane;
+                for (int u = 0; u < kBatch; ++u) {
+                    n0[u] = (Q == 0) ? grow[(l0 + u) * B + lane] : 0.f;
+                    n1[u] = (B > 64) ? grow[(l0 + u) * B + 64 + lane] : 0.f;
+                }
+            };
+            int l = 0;
+            if (nsteps >= kBatch) load(0);
+#pragma unroll 1
+            for (; l + kBatch <= nsteps; l += kBatch) {
+                float c0[kBatch], c1[kBatch];
+#pragma unroll
+                for (int u = 0; u < kBatch; ++u) { c0[u] = n0[u]; c1[u] = n1[u]; }
+                if (l + 2 * kBatch <= nsteps) load(l + kBatch);
+#pragma unroll
+                for (int u = 0; u < kBatch; ++u) step(l + u, c0[u], c1[u]);
+            }
+#pragma unroll 1
+            for (; l < nsteps; ++l) step(l, (Q == 0) ? grow[l * B + lane] : 0.f, (B > 64) ? grow[l * B + 64 + lane] : 0.f);
+        };
+        using std::integral_constant;
+        auto run_section = [&](auto qc) {
+            constexpr int Q = decltype(qc)::value;
+            const int nsteps = (b < 64 * (Q + 1) ? b : 64 * (Q + 1)) - 64 * Q;
+            if (nsteps <= 0) return;
+            const float* grow = rows + 64 * Q * B;                   // (all rows staged in marker order: slot = marker)
+            const int c = 64 * Q + lane;
             float an[NT], bn[NT], dn[NT], Dl[NT];
-            eval_own(q, wev[q], an, bn, dn, Dl);
+            bool done = false;
+            if (speculate) {
+                float rs[NT][2];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) { rs[t][0] = rhsq[t][0]; rs[t][1] = rhsq[t][1]; }
+                section(qc, integral_constant<bool, true>{}, grow, nsteps);
+                eval_own(Q, wev[Q], an, bn, dn, Dl);                 // the exact evaluation of every marker of the section
+                bool ok = true;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) ok = ok && (dn[t] == 1.f);
+                if (__all(ok || c >= b)) done = true;
+                else {
+                    speculate = false;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) { rhsq[t][0] = rs[t][0]; rhsq[t][1] = rs[t][1]; }
+                    ++nrounds;                                       // (diagnostics: sections walked twice)
+                }
+            }
+            if (!done) {
+                section(qc, integral_constant<bool, false>{}, grow, nsteps);
+                eval_own(Q, wev[Q], an, bn, dn, Dl);
+            }
             if (c < B)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) { acur[t * B + c] = (c < b) ? an[t] : 0.f; bcur[t * B + c] = bn[t]; dcur[t * B + c] = dn[t]; }
-        }
+        };
+        run_section(integral_constant<int, 0>{});
+        run_section(integral_constant<int, 1>{});
         dense_done = true;
     }
+    if (dense_done && lane == 0) wcnt_s[14] = 1;
 
     const int s_first = (nreps == 1 && !dense_done) ? (first_sub < nsub ? first_sub : nsub) : 0;       // prefix skip (single pass only)
     for (int rep = 0; rep < (dense_done ? 0 : nreps); ++rep) {
@@ -2054,7 +2139,30 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
     }   // wave 0
     __syncthreads();
     const int nfin = wcnt_s[15];
-    if (A.b_next > 0) corr_phase<NT>(smem, SM, A, nfin);
+    if (A.b_next > 0 && cross_dma && wcnt_s[14] != 0) {
+        // dense walk with the cross-Gram rows in LDS: every marker is an entry (alpha_old - alpha_new = 0: exact no-op); one
+        // thread per (trait, column of the next block), the chain in marker order as in corr_phase
+        const float* crossL = reinterpret_cast<const float*>(smem + SM.cross_off);
+        for (int i = tid; i < NT * B; i += kStepThreads) rhs_lds[i] = astart[i] - acur[i];
+        __syncthreads();
+        for (int i = tid; i < NT * B; i += kStepThreads) {
+            const int t = i / B, c = i - t * B;
+            const float* dl = rhs_lds + t * B;
+            float corr = 0.f;
+            int e = 0;
+#pragma unroll 1
+            for (; e + 8 <= b; e += 8) {
+                const float4 d0 = *reinterpret_cast<const float4*>(dl + e), d1 = *reinterpret_cast<const float4*>(dl + e + 4);
+                float g[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) g[u] = crossL[(e + u) * B + c];
+                corr = fmaf(d0.x, g[0], corr); corr = fmaf(d0.y, g[1], corr); corr = fmaf(d0.z, g[2], corr); corr = fmaf(d0.w, g[3], corr);
+                corr = fmaf(d1.x, g[4], corr); corr = fmaf(d1.y, g[5], corr); corr = fmaf(d1.z, g[6], corr); corr = fmaf(d1.w, g[7], corr);
+            }
+            for (; e < b; ++e) corr = fmaf(dl[e], crossL[e * B + c], corr);
+            A.corr_out[i] = corr;
+        }
+    } else if (A.b_next > 0) corr_phase<NT>(smem, SM, A, nfin);
     // ---- global stores LAST (a barrier after a global store waits for the store): the change list for the next update
     // role, then the block's state (beta / delta of every marker are new draws; alpha changes only where an event happened)
     {

@@ -526,10 +526,14 @@ def test_residual_weights_parity(hip, method, bs, gram):
         hip.sweep(iteration=1, seed=1, **kw)
 
 
-@pytest.mark.parametrize("method,t,bs", [("MTBayesC", 3, 128), ("MTBayesC", 2, 64), ("MTBayesC_II", 2, 128), ("MegaBayesC", 3, 64)])
-def test_multitrait_dense_blocks_parity(hip, method, t, bs):
+@pytest.mark.parametrize("method,t,bs,zero", [("MTBayesC", 3, 128, False), ("MTBayesC", 2, 64, False), ("MTBayesC_II", 2, 128, False),
+                                              ("MegaBayesC", 3, 64, False), ("MTBayesC", 3, 128, True), ("MTBayesC", 2, 64, True),
+                                              ("MTBayesC", 4, 128, True), ("MTBayesC_II", 2, 128, True)])
+def test_multitrait_dense_blocks_parity(hip, method, t, bs, zero):
     """The default multi-trait prior puts all mass on the all-ones state (tools4genotypes.jl:357-373): every marker stays
-    in the model and every block is dense -- the sampler walks such blocks sequentially; results must not change."""
+    in the model and every block is dense -- the sampler walks such blocks sequentially; results must not change.
+    zero: the other states have probability exactly 0 (log prior -inf, the reference's literal default) -- sampler I then
+    takes the walk that skips the decision; else 1e-12 (the general dense walk)."""
     data = make_dataset(n=380, p=2 * bs + 41, ncausal=10, seed=800 + t)
     orc, hip = _pair(hip, data, bs, method, ntraits=t)
     rng = np.random.default_rng(t)
@@ -548,8 +552,9 @@ def test_multitrait_dense_blocks_parity(hip, method, t, bs):
     if method == "MegaBayesC":
         kw = dict(vare=np.diag(np.diag(vare)), var_effect=np.diag(np.diag(varg)), pi=np.zeros(t))
     else:
-        prior = np.full(1 << t, 1e-12); prior[-1] = 1.0; prior /= prior.sum()
-        kw = dict(vare=vare, var_effect=varg, log_prior_states=np.log(prior))
+        prior = np.full(1 << t, 0.0 if zero else 1e-12); prior[-1] = 1.0; prior /= prior.sum()
+        with np.errstate(divide="ignore"):
+            kw = dict(vare=vare, var_effect=varg, log_prior_states=np.log(prior))
     for it in range(1, 9):
         so = orc.sweep(iteration=it, seed=21, **kw)
         sh = hip.sweep(iteration=it, seed=21, **kw)
