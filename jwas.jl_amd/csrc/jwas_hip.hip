@@ -65,6 +65,7 @@ struct jwas_hip_ctx {
     DevParams* dparams = nullptr;
     unsigned long long* counters = nullptr;
     double* fin_out = nullptr;          // [nslices][kMaxT*kMaxT + kMaxT]
+    int* sync_cnt = nullptr;            // [2][nrg] arrival counters of the update role's cooperative dense apply
     double* stat_out = nullptr;         // [kStatGrid][kNStat]
     double* host_buf = nullptr;         // pinned staging for fin_out + stat_out + counters
     double* prep_d = nullptr;           // [kPrepD][p] per-sweep marker constants (k_prepare)
@@ -206,8 +207,8 @@ static void free_storage(jwas_hip_ctx* c)
 {
     (void)hipFree(c->X); (void)hipFree(c->r); (void)hipFree(c->Q); (void)hipFree(c->qmean); (void)hipFree(c->w);
     c->X = c->r = nullptr; c->Q = nullptr; c->qmean = nullptr; c->packed = false; c->w = nullptr; c->weighted = false;
-    (void)hipFree(c->ev); (void)hipFree(c->dparams); (void)hipFree(c->counters); (void)hipFree(c->fin_out); (void)hipFree(c->stat_out);
-    c->ev = nullptr; c->dparams = nullptr; c->counters = nullptr; c->fin_out = c->stat_out = nullptr;
+    (void)hipFree(c->ev); (void)hipFree(c->dparams); (void)hipFree(c->counters); (void)hipFree(c->fin_out); (void)hipFree(c->stat_out); (void)hipFree(c->sync_cnt);
+    c->sync_cnt = nullptr; c->ev = nullptr; c->dparams = nullptr; c->counters = nullptr; c->fin_out = c->stat_out = nullptr;
     if (c->host_buf) (void)hipHostFree(c->host_buf);
     c->host_buf = nullptr;
     (void)hipFree(c->var_vec); (void)hipFree(c->pi_vec); (void)hipFree(c->pi_mat); (void)hipFree(c->lpr_mat);
@@ -341,6 +342,8 @@ static int alloc_storage(jwas_hip_ctx* c, int64_t n, int64_t p, bool packed = fa
     HIPCHK(c, hipMalloc(&c->dparams, sizeof(DevParams)));
     HIPCHK(c, hipMalloc(&c->counters, sizeof(unsigned long long) * 16));
     HIPCHK(c, hipMalloc(&c->fin_out, sizeof(double) * c->nslices * (kMaxT * kMaxT + kMaxT)));
+    HIPCHK(c, hipMalloc(&c->sync_cnt, sizeof(int) * 2 * c->nrg));
+    HIPCHK(c, hipMemsetAsync(c->sync_cnt, 0, sizeof(int) * 2 * c->nrg, c->stream));
     HIPCHK(c, hipMalloc(&c->stat_out, sizeof(double) * kStatGrid * kNStat));
     HIPCHK(c, hipHostMalloc(&c->host_buf, sizeof(double) * ((size_t)c->nslices * (kMaxT * kMaxT + kMaxT) + kStatGrid * kNStat + 32)));
     return JWAS_HIP_OK;
@@ -1076,9 +1079,14 @@ static hipError_t launch_step_cx(jwas_hip_ctx* c, const CX& cx, const UpdateArgs
     const StepSmem SM(c->block_size, NT, is_mt_method(METHOD) ? mt_park_nd(c->block_size, NT) + (S.lpr_mat ? (1 << NT) : 0) : st_park_nd(METHOD), is_mt_method(METHOD) ? mt_park_nf(c->block_size, NT) : st_park_nf(METHOD));
     static bool attr_set = false;
     if (!attr_set) {   // allow > 64 KB of dynamic LDS
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_block_step<METHOD, NT, CX>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_block_step<METHOD, NT, CX, false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
+        if constexpr (CX::kCoopApply) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_block_step<METHOD, NT, CX, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+        }
         attr_set = true;
     }
     // JWAS_HIP_DEBUG_ROLE (timing experiments only; results are wrong): 1 = update role only, 2 = sampler only
@@ -1090,7 +1098,14 @@ static hipError_t launch_step_cx(jwas_hip_ctx* c, const CX& cx, const UpdateArgs
 #endif
     const int nwork = c->nrg * U.ncg;
     const unsigned grid = (dbg == 2) ? 1u : (U.quiet_xcd ? (unsigned)(1 + (nwork + 6) / 7 * 8) : (unsigned)(1 + nwork));
-    hipLaunchKernelGGL((k_block_step<METHOD, NT, CX>), dim3(grid), dim3(kStepThreads), SM.bytes, c->stream,
+    if constexpr (CX::kCoopApply) {
+        if (U.sync_now != nullptr) {     // dense sweep: the instantiation whose update role shares the apply work
+            hipLaunchKernelGGL((k_block_step<METHOD, NT, CX, true>), dim3(grid), dim3(kStepThreads), SM.bytes, c->stream,
+                               U, S, (dbg == 1) ? 0 : do_sample);
+            return hipSuccess;
+        }
+    }
+    hipLaunchKernelGGL((k_block_step<METHOD, NT, CX, false>), dim3(grid), dim3(kStepThreads), SM.bytes, c->stream,
                        U, S, (dbg == 1) ? 0 : do_sample);
     return hipSuccess;
 }
@@ -1431,6 +1446,7 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
     // one-block lookahead pipeline (sweep.hpp): launch k = sampler(block k-1) || update/partial(block k)
     HIPCHK(c, hipMemcpyAsync(c->r + rstride, c->r, sizeof(float) * (size_t)t * c->ld, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(&c->ev[1].count, 0, sizeof(int32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->sync_cnt, 0, sizeof(int) * 2 * c->nrg, c->stream));      // (launch parity restarts with the sweep)
     HIPCHK(c, hipMemsetAsync(c->corr, 0, sizeof(float) * 2 * kMaxT * (size_t)bs, c->stream));   // block 0 has no predecessor
     for (int64_t k = 0; k <= nb; ++k) {
         UpdateArgs U;
@@ -1441,6 +1457,16 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
         U.nslices = c->nslices; U.nrg = c->nrg; U.spg = c->spg;
         U.ncg = (U.b > 0 && c->ncg > U.b) ? U.b : c->ncg;
         U.partials = c->partials + (k & 1) * pstride; U.bstride = bs;
+        U.dbg = c->counters;
+        // dense sweeps (a quarter of the markers or more changed in the previous one; JWAS_HIP_COOP_APPLY=0|1 overrides):
+        // the update role's column groups share the work of applying a block's changes (update_role)
+        {
+            const char* efc = std::getenv("JWAS_HIP_COOP_APPLY");        // (read per launch: the tests switch it inside one process)
+            const int fc = efc ? std::atoi(efc) : -1;
+            const bool coop = c->sync_cnt != nullptr && (fc >= 0 ? fc != 0 : c->last_events > 0.25 * (double)c->p);
+            U.sync_now = coop ? c->sync_cnt + (k & 1) * c->nrg : nullptr;
+            U.sync_next = coop ? c->sync_cnt + ((k + 1) & 1) * c->nrg : nullptr;
+        }
         {   // Placement heuristic (speed only): keep XCD 0 free of streaming traffic for the sampler while the sampler chain
             // is the critical path (many changes per sweep); in the steady state the sampler has slack and all 8 XCDs
             // stream (+4-5 % bandwidth).  Decided from the previous sweep's change count; JWAS_HIP_QUIET_XCD=0|1 overrides.
@@ -1553,8 +1579,8 @@ static int sweep_collect(jwas_hip_ctx* c, jwas_sweep_stats* S, size_t ntimed, do
     S->n_events = packed_dev ? h_stat[kNStat] : (double)h_cnt[0];
     c->last_events = (double)h_cnt[0];
     if (std::getenv("JWAS_HIP_DEBUG_PHASES"))
-        std::fprintf(stderr, "[jwas_hip] blocks=%lld events=%llu unstaged=%llu cycles: front=%llu cand=%llu stage=%llu serial=%llu write=%llu corr=%llu rounds=%llu slow_rounds=%llu stage: assign=%llu issue=%llu store=%llu\n",
-                     (long long)c->nblocks, h_cnt[0], h_cnt[1], h_cnt[2], h_cnt[3], h_cnt[4], h_cnt[5], h_cnt[6], h_cnt[9], h_cnt[7], h_cnt[8], h_cnt[10], h_cnt[11], h_cnt[12]);
+        std::fprintf(stderr, "[jwas_hip] blocks=%lld events=%llu unstaged=%llu cycles: front=%llu cand=%llu stage=%llu serial=%llu write=%llu corr=%llu rounds=%llu slow_rounds=%llu stage: assign=%llu issue=%llu store=%llu update wg0: share=%llu wait=%llu rest=%llu\n",
+                     (long long)c->nblocks, h_cnt[0], h_cnt[1], h_cnt[2], h_cnt[3], h_cnt[4], h_cnt[5], h_cnt[6], h_cnt[9], h_cnt[7], h_cnt[8], h_cnt[10], h_cnt[11], h_cnt[12], h_cnt[13], h_cnt[14], h_cnt[15]);
     float ms = 0.f;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev_start, c->ev_stop));
     S->sweep_ms = ms;

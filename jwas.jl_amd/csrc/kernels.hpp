@@ -80,6 +80,7 @@ struct DenseCols {
     typedef float4 Raw;
     typedef float4 SRaw;
     static constexpr int kDepth = 1;
+    static constexpr bool kCoopApply = true;          // update role: the cooperative dense apply is available (load1 is one dword)
     // column stream of the update role: element i = rows row..row+3 of marker j0 + i*jstride
     struct Stream {
         const float* p; int64_t stride;
@@ -120,6 +121,7 @@ struct PackedCols {
     // the streaming loop is latency-bound, not bandwidth-bound, and wants depth
     struct Raw { unsigned byte; float mu; };
     static constexpr int kDepth = 8;
+    static constexpr bool kCoopApply = false;
     __device__ __forceinline__ Raw load_raw(int64_t j, int64_t row) const
     {
         return Raw{Q[j * (ld >> 2) + (row >> 2)], mean[j]};

@@ -77,14 +77,22 @@ __host__ __device__ constexpr int mt_park_nf(int B, int NT) { return (B * NT <= 
 // ---------------------------------------------------------------------------------------------
 // UPDATE/PARTIAL role
 // ---------------------------------------------------------------------------------------------
-template <int NT, class CX>
+template <int NT, class CX, bool COOP = false>
 __device__ __forceinline__ void update_role(char* smem, int rg, int g,
                                             const CX& cx,
                                             const float* __restrict__ r_in, float* __restrict__ r_out,
                                             const Events* __restrict__ ev,
                                             int64_t j0, int b, int nslices, int nrg, int ncg,
-                                            double* __restrict__ partials, int bstride, int spg = kRowGroupSlices)
+                                            double* __restrict__ partials, int bstride, int spg = kRowGroupSlices,
+                                            int* sync_now = nullptr, int* sync_next = nullptr, unsigned long long* dbg = nullptr)
 {
+#ifdef JWAS_HIP_DEV_KNOBS
+#define JW_UPD_CLOCK(v) v = clock64()
+#else
+#define JW_UPD_CLOCK(v) (void)0
+#endif
+    long long tu0 = 0, tu1 = 0, tu3 = 0;
+    JW_UPD_CLOCK(tu0);
     typedef double RedT[kColChunk][NT];
     RedT* red = reinterpret_cast<RedT*>(smem);                 // [kRowGroupSlices][kColChunk][NT]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -131,6 +139,83 @@ __device__ __forceinline__ void update_role(char* smem, int rg, int g,
     // stays in list order)
     const int ne = ev->count;
     constexpr int kEB = 16;
+    // ---- COOPERATIVE DENSE APPLY.  With a dense prior every launch applies a whole block of changes (ne ~ b), and every
+    // column group of a row group re-reading the same ne columns makes the update role the bottleneck of the launch (8 x
+    // 25.6 MB at n = 50 000, b = 128).  Here the ncg workgroups of a row group SPLIT the rows of every slice: wave w of
+    // group g updates rows [g*R, (g+1)*R) of its slice (R = ceil(256 / ncg) <= 64, one row per lane, dword loads, 64 of
+    // them in flight per lane), the fused multiply-add chain per row in list order -- the same operations as the float4
+    // path, bit for bit.  The shares go to r_out, a counter per row group (agent scope, zeroed by the previous launch)
+    // tells when all ncg shares have landed, and every group then reads its slices' new residual back.  The wait is
+    // BOUNDED: if the peers do not show up (workgroups not co-resident) the group falls back to applying everything
+    // itself -- same values either way, so the fallback is only slower.
+    bool applied = false;
+    if constexpr (COOP && CX::kCoopApply) {
+        const int R = (kSliceRows + ncg - 1) / ncg;
+        if (sync_now != nullptr && r_out != nullptr && ne >= 32 && ncg >= 4 && R <= 64) {
+            const int rloc = g * R + lane;                                // row of the slice
+            const bool mine = active && lane < R && rloc < kSliceRows;
+            const int64_t grow = (int64_t)(active ? slice : 0) * kSliceRows + (mine ? rloc : 0);
+            float rs[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) rs[t] = r_in[t * ld + grow];
+            // 64 changes per chunk: lane l fetches entry e0 + l of the list (index and coefficients: coalesced), every
+            // lane then loads its row of the 64 columns back to back (addresses from v_readlane: no scalar memory access,
+            // no branch, one memory latency) and runs the chain in list order; entries past the end have coefficient 0 (an
+            // exact no-op on a valid column).  (128 per pass was measured: slower, and it spills with three traits.)
+            for (int e0 = 0; e0 < ne; e0 += 64) {
+                const int el = e0 + lane, ec = el < ne ? el : ne - 1;
+                const int iv = ev->idx[ec];
+                float dv[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) { const float d = ev->delta[t][ec]; dv[t] = (el < ne) ? d : 0.f; }
+                float x[64];
+#pragma unroll
+                for (int u = 0; u < 64; ++u) x[u] = cx.load1(__builtin_amdgcn_readlane(iv, u), grow);
+#pragma unroll
+                for (int u = 0; u < 64; ++u) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        rs[t] = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(dv[t]), u)), x[u], rs[t]);
+                }
+            }
+            // the shares and the counter travel as agent-scope accesses (write-through / coherent reads): no L2 write-back or
+            // invalidate, which would cost every other workgroup of the XCD its cached columns
+            if (mine)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    __hip_atomic_store(reinterpret_cast<int*>(r_out + t * ld + grow), __float_as_int(rs[t]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's share has been written ...
+            JW_UPD_CLOCK(tu1);
+            int* flag = reinterpret_cast<int*>(smem);                     // (the reduction scratch is not in use yet)
+            __syncthreads();
+            if (tid == 0) {
+                __hip_atomic_fetch_add(&sync_now[rg], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ... before the count
+                int ok = 0;
+                for (int spin = 0; spin < 4000; ++spin) {                 // bounded: ~0.5 ms
+                    if (__hip_atomic_load(&sync_now[rg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= ncg) { ok = 1; break; }
+                    __builtin_amdgcn_s_sleep(4);
+                }
+                *flag = ok;
+            }
+            __syncthreads();
+            const int ok = *flag;
+            __syncthreads();                                              // (flag's bytes are reused below)
+            if (ok) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int* src = reinterpret_cast<const int*>(r_out + t * ld + row);
+                    rv[t].x = __int_as_float(__hip_atomic_load(src + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    rv[t].y = __int_as_float(__hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    rv[t].z = __int_as_float(__hip_atomic_load(src + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    rv[t].w = __int_as_float(__hip_atomic_load(src + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                }
+                applied = true;
+            }
+            JW_UPD_CLOCK(tu3);
+        }
+    }
+    if (applied) {
+    } else
     if (NT == 1 && ne <= 7) {
         // header path: indices and coefficients arrived with the count (one 64-byte line)
         float4 x[7];
@@ -161,9 +246,12 @@ __device__ __forceinline__ void update_role(char* smem, int rg, int g,
             }
         }
     }
-    if (active && g == 0 && r_out != nullptr)
+    if (active && g == 0 && r_out != nullptr && !applied)
 #pragma unroll
         for (int t = 0; t < NT; ++t) *reinterpret_cast<float4*>(r_out + t * ld + row) = rv[t];
+    // the next launch's arrival counter (its previous user is done).  Stores and loads share vmcnt: issued here, after the
+    // last wait of the apply phase that is on a dependent path, the store delays nothing.
+    if constexpr (COOP) { if (sync_next != nullptr && g == 0 && tid == 0) sync_next[rg] = 0; }
     if (ncols == 0) return;
     // the RHS is X_b' R^-1 r (block_rhs!, tools4genotypes.jl:59-78): the weights go onto r once per launch (weights = 1
     // when unweighted: exact), the streaming loop is untouched
@@ -225,6 +313,16 @@ __device__ __forceinline__ void update_role(char* smem, int rg, int g,
         }
         __syncthreads();
     }
+#ifdef JWAS_HIP_DEV_KNOBS
+    if (dbg != nullptr && rg == 0 && g == 0 && tid == 0) {               // development builds: one workgroup's phases
+        const long long tu4 = clock64();
+        atomicAdd(&dbg[13], (unsigned long long)(tu1 - tu0));            // cooperative apply: own share
+        atomicAdd(&dbg[14], (unsigned long long)(tu3 - tu1));            //   wait for the peers + read back
+        atomicAdd(&dbg[15], (unsigned long long)(tu4 - (applied ? tu3 : tu0)));    // the rest (float4 apply if any, partial RHS)
+    }
+#else
+    (void)dbg; (void)tu0; (void)tu1; (void)tu3;
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2205,6 +2303,8 @@ struct UpdateArgs {
     int spg;                      // slices (waves that stream) per row group: <= 8
     double* partials; int bstride;
     int quiet_xcd;                // 1: ids = 0 mod 8 (the sampler's XCD) do no update work
+    unsigned long long* dbg;      // phase cycle counters (diagnostics) or NULL
+    int* sync_now; int* sync_next; // [nrg] arrival counters of the cooperative dense apply: this launch's / the next one's (or NULL)
     int dbg_throttle;             // > 1: only every n-th update workgroup runs (timing experiments; results wrong)
 };
 template <class CX>
@@ -2212,7 +2312,9 @@ struct UpdateArgsT : UpdateArgs {
     CX cx;                        // genotype storage accessor
 };
 
-template <int METHOD, int NT, class CX>
+// COOP: the update role may split a dense change list among the column groups of a row group (see update_role); a separate
+// instantiation so that the steady-state kernel's code is exactly the one without it (its presence alone cost 1 %).
+template <int METHOD, int NT, class CX, bool COOP = false>
 __global__ __launch_bounds__(kStepThreads) void k_block_step(UpdateArgsT<CX> U, SamplerArgs S, int do_sample)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -2232,8 +2334,8 @@ __global__ __launch_bounds__(kStepThreads) void k_block_step(UpdateArgsT<CX> U, 
     }
     if (w >= U.nrg * U.ncg) return;
     if (U.dbg_throttle > 1 && (w % U.dbg_throttle) != 0) return;       // timing experiments only
-    update_role<NT, CX>(smem, w % U.nrg, w / U.nrg, U.cx, U.r_in, U.r_out, U.ev, U.j0, U.b,
-                        U.nslices, U.nrg, U.ncg, U.partials, U.bstride, U.spg);
+    update_role<NT, CX, COOP>(smem, w % U.nrg, w / U.nrg, U.cx, U.r_in, U.r_out, U.ev, U.j0, U.b,
+                              U.nslices, U.nrg, U.ncg, U.partials, U.bstride, U.spg, U.sync_now, U.sync_next, U.dbg);
 }
 
 // Cross-Gram of consecutive blocks, exact (fp64-accumulated): C[a][c] = x_{jp+a}' x_{j0+c}.

@@ -710,3 +710,52 @@ def test_row_group_geometry_does_not_change_the_chain(spg, monkeypatch):
             _compare_state(orc, hip, k, atol=5e-6)
     finally:
         hip.close()
+
+
+@pytest.mark.parametrize("method,t,bs,pi", [("BayesC", 1, 128, 0.0), ("BayesC", 1, 256, 0.5), ("MTBayesC", 3, 128, None), ("BayesR", 1, 64, None)])
+def test_cooperative_dense_apply_is_bit_identical(method, t, bs, pi, monkeypatch):
+    """Dense sweeps let the column groups of a row group split the rows when a block's changes are applied to the residual
+    (update_role, cooperative dense apply: shares through r_out, an arrival counter per row group, bounded wait with a
+    fall-back).  Forced on and off (JWAS_HIP_COOP_APPLY) on a matrix with several row groups and a ragged last slice: the
+    chain must be the same BIT FOR BIT either way, and equal the oracle's."""
+    import jwas_jl_amd as J
+    monkeypatch.setenv("JWAS_HIP_SPG", "4")
+    data = make_dataset(n=2300, p=4 * bs + 19, ncausal=12, seed=5 + t)       # 9 slices -> 3 row groups of <= 4 waves
+    y = data["y"] - data["y"].mean()
+    rng = np.random.default_rng(8)
+    vare1, varg1 = _hyper(data)
+    if t == 1:
+        kw = dict(vare=vare1, var_effect=varg1)
+        if method == "BayesR":
+            kw["pi_classes"] = np.array([0.3, 0.3, 0.2, 0.2])
+        else:
+            kw["pi"] = pi
+    else:
+        A = rng.standard_normal((t, t))
+        prior = np.full(1 << t, 1e-3); prior[-1] = 1.0; prior /= prior.sum()
+        kw = dict(vare=(A @ A.T / t + np.eye(t)).astype(np.float32) * 0.5, var_effect=(np.eye(t) * 0.002).astype(np.float32),
+                  log_prior_states=np.log(prior))
+    results = {}
+    for tag, env in (("oracle", None), ("coop", "1"), ("plain", "0")):
+        if env is not None:
+            monkeypatch.setenv("JWAS_HIP_COOP_APPLY", env)
+        e = OracleEngine("lookahead") if env is None else J.HipEngine(0)
+        try:
+            e.load_dense(data["X"]); e.setup_blocks(bs, "f64"); e.init_state(method, t)
+            for k in range(t):
+                e.set_residual(((1 + 0.25 * k) * y).astype(np.float32), k)
+            ev = []
+            for it in range(1, 7):
+                ev.append(e.sweep(iteration=it, seed=77, **kw)["n_events"])
+            results[tag] = ([e.get_state(k) for k in range(t)], [e.get_residual(k) for k in range(t)], ev)
+        finally:
+            if env is not None:
+                e.close()
+    assert results["coop"][2] == results["plain"][2] == results["oracle"][2]
+    assert min(results["coop"][2]) >= 32 * 4                                 # dense enough for the cooperative path in every block
+    for k in range(t):
+        for q in range(3):
+            assert np.array_equal(results["coop"][0][k][q], results["plain"][0][k][q])
+        assert np.array_equal(results["coop"][1][k], results["plain"][1][k])
+        np.testing.assert_allclose(results["coop"][1][k], results["oracle"][1][k], atol=2e-4)
+        np.testing.assert_allclose(results["coop"][0][k][0], results["oracle"][0][k][0], atol=5e-6)
