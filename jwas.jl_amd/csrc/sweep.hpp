@@ -162,12 +162,20 @@ __device__ __forceinline__ void update_role(char* smem, int rg, int g,
             // lane then loads its row of the 64 columns back to back (addresses from v_readlane: no scalar memory access,
             // no branch, one memory latency) and runs the chain in list order; entries past the end have coefficient 0 (an
             // exact no-op on a valid column).  (128 per pass was measured: slower, and it spills with three traits.)
-            for (int e0 = 0; e0 < ne; e0 += 64) {
+            int iv_n; float dv_n[NT];
+            auto load_list = [&](int e0) {
                 const int el = e0 + lane, ec = el < ne ? el : ne - 1;
-                const int iv = ev->idx[ec];
+                iv_n = ev->idx[ec];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) { const float d = ev->delta[t][ec]; dv_n[t] = (el < ne) ? d : 0.f; }
+            };
+            load_list(0);
+            for (int e0 = 0; e0 < ne; e0 += 64) {
+                const int iv = iv_n;
                 float dv[NT];
 #pragma unroll
-                for (int t = 0; t < NT; ++t) { const float d = ev->delta[t][ec]; dv[t] = (el < ne) ? d : 0.f; }
+                for (int t = 0; t < NT; ++t) dv[t] = dv_n[t];
+                if (e0 + 64 < ne) load_list(e0 + 64);                   // the next chunk's list: in flight behind this chunk's columns
                 float x[64];
 #pragma unroll
                 for (int u = 0; u < 64; ++u) x[u] = cx.load1(__builtin_amdgcn_readlane(iv, u), grow);
@@ -585,11 +593,12 @@ __device__ __forceinline__ void copy_cross_rows(char* smem, const StepSmem& SM, 
 
 // Linear copy global -> LDS with direct loads (global_load_lds_dwordx4: 1 KB per wave instruction), all 8 waves, rolled
 // loop, no registers; nfloats a multiple of 256.  The caller waits (s_waitcnt vmcnt(0)) and synchronises.
-__device__ __forceinline__ void dma_copy_to_lds(const float* __restrict__ src, float* lds_dst, int nfloats)
+__device__ __forceinline__ void dma_copy_to_lds(const float* __restrict__ src, float* lds_dst, int nfloats, int w0 = 0)
 {
     typedef __attribute__((address_space(3))) void lds_void;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int k = wave * 256; k < nfloats; k += (kStepThreads / 64) * 256)
+    if (wave < w0) return;                                   // (waves w0..7 share the copy)
+    for (int k = (wave - w0) * 256; k < nfloats; k += (kStepThreads / 64 - w0) * 256)
         __builtin_amdgcn_global_load_lds(src + k + lane * 4, (lds_void*)(lds_dst + k), 16, 0, 0);
 }
 
@@ -801,7 +810,7 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
     const bool gram_dma = prestage && b == B;
     const bool cross_dma = gram_dma && SM.has_cross && A.b_next == B;
     if (gram_dma) dma_copy_to_lds(A.gram, reinterpret_cast<float*>(smem + SM.rows_off), B * B);
-    if (cross_dma) dma_copy_to_lds(A.cross_next, reinterpret_cast<float*>(smem + SM.cross_off), B * B);
+    // (the cross-Gram rows are only needed after the walk: waves 1..7 fetch them while wave 0 walks)
     float4 gpre[8];
     if (prestage && !gram_dma) {
         // B*B/4 float4 elements over 512 threads: <= 8 per thread; element e -> row e / (B/4), float4 column e % (B/4)
@@ -921,7 +930,12 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
             prefetch_next_gram(A, prestage, 5, stop);
         }
     } else {
-        if (cross_lds) { if (!cross_dma) copy_cross_rows(smem, SM, A); }     // waves 1..7, while wave 0 runs the serial phase
+        if (cross_lds) {                                     // waves 1..7, while wave 0 runs the serial phase
+            if (cross_dma) {
+                dma_copy_to_lds(A.cross_next, reinterpret_cast<float*>(smem + SM.cross_off), B * B, 1);
+                if (wave != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // landed before the barrier after the walk
+            } else copy_cross_rows(smem, SM, A);
+        }
         else prefetch_cross_rows(smem, SM, A, nstaged);      // waves 1..7: pull the rows into L2 for corr_phase at the end
         prefetch_next_gram(A, prestage);                     // waves 1..7: the next block's staging becomes an L2 hit
     }
@@ -1833,7 +1847,6 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
     const bool gram_dma = prestage && b == B;              // full block: direct global -> LDS loads (see sampler_role_st)
     const bool cross_dma = gram_dma && SM.has_cross && A.b_next == B;
     if (gram_dma) dma_copy_to_lds(A.gram, reinterpret_cast<float*>(smem + SM.rows_off), B * B);
-    if (cross_dma) dma_copy_to_lds(A.cross_next, reinterpret_cast<float*>(smem + SM.cross_off), B * B);
     float4 gpre[8];
     if (prestage && !gram_dma) {
         const int per_row = B >> 2, total = b * per_row;
@@ -1979,7 +1992,10 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
     }
     const long long tk1 = clock64();
     const int nstaged_mt = prestage ? b : (first_sub >= 16 ? 0 : stage_rows(smem, SM, A, cand));
-    prefetch_cross_rows(smem, SM, A, nstaged_mt);
+    if (cross_dma) {                                       // waves 1..7: the cross-Gram rows to LDS while wave 0 walks the block
+        dma_copy_to_lds(A.cross_next, reinterpret_cast<float*>(smem + SM.cross_off), B * B, 1);
+        if (wave != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else prefetch_cross_rows(smem, SM, A, nstaged_mt);
     prefetch_next_gram(A, prestage);
     int* wcnt_s = reinterpret_cast<int*>(smem + SM.wcnt_off);
     long long tk3 = 0, tk4 = 0, tk5 = 0;
