@@ -2028,7 +2028,6 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
         float rhsq[NT][2], aq[NT][2], bq[NT][2], dq[NT][2], djq[2], wev[2][NT];
         double thrq[NT][2], zq[NT][2];
         MtPre<NT> Qq[2];
-        bool mine = true;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int c = (64 * q + lane < b) ? 64 * q + lane : 0;
@@ -2042,10 +2041,9 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
                 rhsq[t][q] = rhs_lds[t * B + c]; aq[t][q] = acur[t * B + c]; bq[t][q] = bcur[t * B + c]; dq[t][q] = dcur[t * B + c];
                 thrq[t][q] = lpd[t * B + c]; zq[t][q] = lpd[(NT + t) * B + c];
                 wev[q][t] = 0.f;
-                mine = mine && (dq[t][q] == 1.f);
             }
         }
-        bool speculate = (METHOD == kMTBayesC1) && __all(mine);
+        const bool speculate = (METHOD == kMTBayesC1);
         // one marker evaluated in-lane from (w, its state at block entry, its draws)
         auto eval_own = [&](int q, const float (&w)[NT], float (&an)[NT], float (&bn)[NT], float (&dn)[NT], float (&Dl)[NT]) {
             const int c = (64 * q + lane < b) ? 64 * q + lane : 0;
@@ -2128,6 +2126,45 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
             for (; l < nsteps; ++l) step(l, (Q == 0) ? grow[l * B + lane] : 0.f, (B > 64) ? grow[l * B + 64 + lane] : 0.f);
         };
         using std::integral_constant;
+        // the same section with some markers (bit l of `slow`) evaluated the general way and the others speculatively: one
+        // step per loop trip (used when the speculation missed, or when a marker is not in the model for every trait at entry)
+        auto section_mixed = [&](auto qc, const float* grow, int nsteps, unsigned long long slow) {
+            constexpr int Q = decltype(qc)::value;
+            float C12[NT][NT], da[NT];
+            double zs1[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                da[t] = djq[Q] * aq[t][Q];
+                zs1[t] = zq[t][Q] * (double)Qq[Q].s1[t];
+#pragma unroll
+                for (int m = 0; m < NT; ++m) C12[t][m] = K.Ginv[t][m] + (djq[Q] * 1.f) * K.Rinv[t][m];
+            }
+            float g0 = (Q == 0) ? grow[lane] : 0.f;
+            float g1 = (B > 64) ? grow[64 + lane] : 0.f;
+#pragma unroll 1
+            for (int l = 0; l < nsteps; ++l) {
+                float w[NT], an[NT], bn[NT], dn[NT], Dl[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) w[t] = rhsq[t][Q] + da[t];
+                if ((slow >> l) & 1ull) eval_own(Q, w, an, bn, dn, Dl);                               // (wave-uniform)
+                else {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) bn[t] = bq[t][Q];
+                    eval_fast(Q, w, C12, zs1, bn, Dl);
+                }
+                const float c0 = g0, c1 = g1;
+                grow += B;                                           // next marker's row (one past the block: the overflow row)
+                if (Q == 0) g0 = grow[lane];
+                if (B > 64) g1 = grow[64 + lane];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    wev[Q][t] = (lane == l) ? w[t] : wev[Q][t];
+                    const float D = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Dl[t]), l));
+                    if (Q == 0) rhsq[t][0] = fmaf(D, c0, rhsq[t][0]);
+                    if (B > 64) rhsq[t][1] = fmaf(D, c1, rhsq[t][1]);
+                }
+            }
+        };
         auto run_section = [&](auto qc) {
             constexpr int Q = decltype(qc)::value;
             const int nsteps = (b < 64 * (Q + 1) ? b : 64 * (Q + 1)) - 64 * Q;
@@ -2135,25 +2172,35 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
             const float* grow = rows + 64 * Q * B;                   // (all rows staged in marker order: slot = marker)
             const int c = 64 * Q + lane;
             float an[NT], bn[NT], dn[NT], Dl[NT];
-            bool done = false;
             if (speculate) {
                 float rs[NT][2];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) { rs[t][0] = rhsq[t][0]; rs[t][1] = rhsq[t][1]; }
-                section(qc, integral_constant<bool, true>{}, grow, nsteps);
-                eval_own(Q, wev[Q], an, bn, dn, Dl);                 // the exact evaluation of every marker of the section
-                bool ok = true;
+                // markers that are not in the model for every trait at entry cannot be speculated on
+                bool in_all = true;
 #pragma unroll
-                for (int t = 0; t < NT; ++t) ok = ok && (dn[t] == 1.f);
-                if (__all(ok || c >= b)) done = true;
-                else {
-                    speculate = false;
+                for (int t = 0; t < NT; ++t) in_all = in_all && (dq[t][Q] == 1.f);
+                unsigned long long slow = __ballot(!in_all && c < b);
+                if (__popcll(slow) * 4 > nsteps) slow = ~0ull;       // not a block to speculate on: everything the general way
+                if (slow == 0ull) section(qc, integral_constant<bool, true>{}, grow, nsteps);
+                else section_mixed(qc, grow, nsteps, slow);
+                for (int pass = 0; pass < 64; ++pass) {
+                    eval_own(Q, wev[Q], an, bn, dn, Dl);             // the exact evaluation of every marker of the section
+                    bool ok = true;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) ok = ok && (dn[t] == 1.f);
+                    // a speculated marker that leaves the model for a trait: its broadcast changes were wrong -- evaluate it
+                    // (and whatever else looks wrong now) the general way and walk the section again from its saved rhs
+                    const unsigned long long bad = __ballot(!ok && c < b) & ~slow;
+                    if (bad == 0ull) break;
+                    slow |= bad;
+                    if (__popcll(slow) * 4 > nsteps) slow = ~0ull;   // (misses are not rare here: stop speculating)
 #pragma unroll
                     for (int t = 0; t < NT; ++t) { rhsq[t][0] = rs[t][0]; rhsq[t][1] = rs[t][1]; }
-                    ++nrounds;                                       // (diagnostics: sections walked twice)
+                    section_mixed(qc, grow, nsteps, slow);
+                    ++nrounds;                                       // (diagnostics: sections walked again)
                 }
-            }
-            if (!done) {
+            } else {
                 section(qc, integral_constant<bool, false>{}, grow, nsteps);
                 eval_own(Q, wev[Q], an, bn, dn, Dl);
             }
