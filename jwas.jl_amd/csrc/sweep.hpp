@@ -1113,12 +1113,18 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
             while (true) {
                 ++nrounds;
                 bool inc = false, ev = false;
+                float an = 0.f;
                 if constexpr (kR) ev = nz || (fabsf(rhs) >= c_thrx);
-                else { inc = abc_included(rhs, c_lo, c_hi); ev = inc || nz; }
-                const unsigned long long m = __ballot(ev) & pending;
+                else {
+                    inc = abc_included(rhs, c_lo, c_hi); ev = inc || nz;
+                    // every lane's new effect BEFORE the vote: the six dependent operations run beside the vote's
+                    // compare / ballot / find-first chain instead of after it (wasted only in a sub-block's last round)
+                    an = abc_alpha_new(rhs, a_cur, c_d, ie, c_il, c_zs, inc);
+                    asm volatile("" : "+v"(an));         // (keeps the compiler from sinking it below the vote's branch)
+                }
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(ev) & pending;
                 if (m == 0ull) break;                     // no further change in this sub-block
                 const int k = __builtin_amdgcn_readfirstlane(__builtin_ctzll(m));
-                float an = 0.f;
                 if constexpr (kR) {
                     bool sure = true;
                     int cls = bayesr_eval_thr(rhs, a_cur, ie, c_d, r_il1, r_il2, r_il3, r_zs1, r_zs2, r_zs3, r_T0, r_T1, r_T2, an, sure);
@@ -1131,7 +1137,6 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
                     if (cls == 0) an = 0.f;
                     if (lane == k) { acur[c] = an; dpark[c] = (float)(cls + 1); }             // stored as class 1..4
                 } else {
-                    an = abc_alpha_new(rhs, a_cur, c_d, ie, c_il, c_zs, inc);
                     if (lane == k) acur[c] = an;          // (beta / delta follow from alpha at the end: derive_bd)
                 }
                 const float Dl = a_cur - an;
