@@ -63,8 +63,12 @@ enum {
     JWAS_HIP_MTBAYESC1 = 3,    /* multi-trait BayesC, Gibbs sampler I  (MTBayesABC.jl:57-127)    */
     JWAS_HIP_MTBAYESC2 = 4,    /* multi-trait BayesC, Gibbs sampler II (MTBayesABC.jl:129-210):  */
                                /* joint indicator state; candidate states in bitmask order       */
-    JWAS_HIP_MEGABAYESC = 5    /* megaBayesABC! (BayesABC.jl:1-8, G.constraint = true): t         */
+    JWAS_HIP_MEGABAYESC = 5,   /* megaBayesABC! (BayesABC.jl:1-8, G.constraint = true): t         */
                                /* independent single-trait BayesC chains sharing one pass over X */
+    JWAS_HIP_MTBAYESB1 = 6     /* multi-trait BayesA/B, Gibbs sampler I with ONE t x t effect      */
+                               /* covariance PER MARKER (locus_effect_variances[marker],           */
+                               /* MTBayesABC.jl:66,86-90; drawn per marker on the host,             */
+                               /* variance_components.jl:181-186): jwas_sweep_params.var_effect_matrix */
 };
 
 /* Genotype storage kinds (Genotypes.storage_mode in the reference, types.jl:149-150). */
@@ -107,6 +111,8 @@ typedef struct jwas_sweep_params {
     const double* log_prior_states_matrix;  /* MT samplers I/II: p x 2^t row-major per-marker log pi(state) (marker-specific */
                                         /* joint priors: the reference's annotated multi-trait BayesC, MarkerSpecificPiPrior, */
                                         /* MTBayesABC.jl:22-47), else NULL; needs 2 traits and a block size <= 512 */
+    const float*  var_effect_matrix;    /* MTBAYESB1: p x t x t row-major per-marker effect covariances (host); inverted on the   */
+                                        /* device once per sweep; needs block_size * ntraits <= 2048                               */
 } jwas_sweep_params;
 
 /* Reductions the host-side conjugate draws need (Pi.jl, variance_components.jl). */

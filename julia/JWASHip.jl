@@ -10,12 +10,12 @@ module JWASHip
 
 export HipBackend, HipSweepParams, HipSweepStats, hip_sweep!, hip_sweep_sharded!, hip_comm_unique_id, hip_comm_init!,
        hip_set_residual!, hip_get_residual!, hip_accumulate!, hip_posterior, hip_mul_alpha, JWAS_HIP_BAYESC,
-       JWAS_HIP_BAYESB, JWAS_HIP_BAYESR, JWAS_HIP_MTBAYESC1, JWAS_HIP_MTBAYESC2, JWAS_HIP_MEGABAYESC
+       JWAS_HIP_BAYESB, JWAS_HIP_BAYESR, JWAS_HIP_MTBAYESC1, JWAS_HIP_MTBAYESC2, JWAS_HIP_MEGABAYESC, JWAS_HIP_MTBAYESB1
 
 const LIBJWAS_HIP = get(ENV, "JWAS_HIP_LIB", "libjwas_hip.so")
 
 const JWAS_HIP_BAYESC, JWAS_HIP_BAYESB, JWAS_HIP_BAYESR = Int32(0), Int32(1), Int32(2)
-const JWAS_HIP_MTBAYESC1, JWAS_HIP_MTBAYESC2, JWAS_HIP_MEGABAYESC = Int32(3), Int32(4), Int32(5)
+const JWAS_HIP_MTBAYESC1, JWAS_HIP_MTBAYESC2, JWAS_HIP_MEGABAYESC, JWAS_HIP_MTBAYESB1 = Int32(3), Int32(4), Int32(5), Int32(6)
 const JWAS_HIP_GRAM_F64, JWAS_HIP_GRAM_MFMA = Int32(0), Int32(1)
 
 # mirrors of struct jwas_sweep_params / jwas_sweep_stats (isbits, same field order; JWAS_HIP_MAX_TRAITS = 4)
@@ -37,6 +37,7 @@ struct HipSweepParams
     pi_vec::Ptr{Float64}
     pi_matrix::Ptr{Float64}
     log_prior_states_matrix::Ptr{Float64}
+    var_effect_matrix::Ptr{Float32}
 end
 
 struct HipSweepStats
@@ -104,7 +105,8 @@ function HipSweepParams(method::Integer, iter::Integer, seed::Integer; vare::Rea
     HipSweepParams(Int32(method), Int32(1), Int32(nreps), UInt32(iter), UInt64(seed), UInt32(marker_offset),
                    UInt32(independent_blocks), Base.setindex(_z16(Float32), Float32(vare), 1),
                    Base.setindex(_z16(Float32), Float32(var_effect), 1), Float64(pi), NTuple{4,Float64}(pi_classes),
-                   NTuple{4,Float64}(gamma), _z16(Float64), var_effect_vec, pi_vec, pi_matrix, Ptr{Float64}(C_NULL))
+                   NTuple{4,Float64}(gamma), _z16(Float64), var_effect_vec, pi_vec, pi_matrix, Ptr{Float64}(C_NULL),
+                   Ptr{Float32}(C_NULL))
 end
 
 "One marker sweep = one call of BayesABC! / BayesR! / MTBayesABC! (BayesABC.jl:60-80, BayesR.jl:45-97, MTBayesABC.jl:57-127)."

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libjwas_hip.so")
 MAX_TRAITS = 4
 MAX_STATES = 16
 
-BAYESC, BAYESB, BAYESR, MTBAYESC1, MTBAYESC2, MEGABAYESC = 0, 1, 2, 3, 4, 5
+BAYESC, BAYESB, BAYESR, MTBAYESC1, MTBAYESC2, MEGABAYESC, MTBAYESB1 = 0, 1, 2, 3, 4, 5, 6
 GRAM_F64, GRAM_MFMA = 0, 1
 
 # every symbol include/jwas_hip.h declares (checked by tests/test_abi.py)
@@ -47,6 +47,7 @@ class SweepParams(C.Structure):
         ("pi_vec", C.POINTER(C.c_double)),
         ("pi_matrix", C.POINTER(C.c_double)),
         ("log_prior_states_matrix", C.POINTER(C.c_double)),
+        ("var_effect_matrix", C.POINTER(C.c_float)),
     ]
 
 

@@ -74,6 +74,8 @@ struct jwas_hip_ctx {
     float*  Xout = nullptr;             // output (EBV) rows: [p][ld_out] fp32, Mi.output_genotypes (tools4genotypes.jl:290-296)
     int64_t n_out = 0, ld_out = 0;
     float*  var_vec = nullptr;
+    float*  var_mat = nullptr;          // p x t x t per-marker effect covariances (multi-trait BayesA/B), uploaded per sweep
+    float*  ginv_mat = nullptr;         // their inverses (k_prepare)
     double* pi_vec = nullptr;
     double* pi_mat = nullptr;
     double* lpr_mat = nullptr;          // p x 2^t marker-specific multi-trait log priors
@@ -212,6 +214,7 @@ static void free_storage(jwas_hip_ctx* c)
     if (c->host_buf) (void)hipHostFree(c->host_buf);
     c->host_buf = nullptr;
     (void)hipFree(c->var_vec); (void)hipFree(c->pi_vec); (void)hipFree(c->pi_mat); (void)hipFree(c->lpr_mat);
+    (void)hipFree(c->var_mat); (void)hipFree(c->ginv_mat); c->var_mat = c->ginv_mat = nullptr;
     c->var_vec = nullptr; c->pi_vec = c->pi_mat = c->lpr_mat = nullptr;
     (void)hipFree(c->Xout); c->Xout = nullptr; c->n_out = c->ld_out = 0;
 }
@@ -757,7 +760,7 @@ int jwas_hip_init_state(jwas_hip_ctx* c, int32_t method, int32_t nt)
 {
     NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
     NEED(c, HAVE_STORAGE(c), JWAS_HIP_ESTATE, "no genotype matrix loaded");
-    NEED(c, method >= JWAS_HIP_BAYESC && method <= JWAS_HIP_MEGABAYESC, JWAS_HIP_EINVAL, "unknown method %d", method);
+    NEED(c, method >= JWAS_HIP_BAYESC && method <= JWAS_HIP_MTBAYESB1, JWAS_HIP_EINVAL, "unknown method %d", method);
     if (method >= JWAS_HIP_MTBAYESC1) NEED(c, nt >= 2 && nt <= kMaxT, JWAS_HIP_EUNSUP, "multi-trait samplers support 2..%d traits (got %d)", kMaxT, nt);
     else NEED(c, nt == 1, JWAS_HIP_EINVAL, "single-trait method requires ntraits == 1 (got %d)", nt);
     HIPCHK(c, hipSetDevice(c->device));
@@ -1076,7 +1079,7 @@ static hipError_t launch_step_cx(jwas_hip_ctx* c, const CX& cx, const UpdateArgs
     UpdateArgsT<CX> U;
     static_cast<UpdateArgs&>(U) = U0;
     U.cx = cx;
-    const StepSmem SM(c->block_size, NT, is_mt_method(METHOD) ? mt_park_nd(c->block_size, NT) + (S.lpr_mat ? (1 << NT) : 0) : st_park_nd(METHOD), is_mt_method(METHOD) ? mt_park_nf(c->block_size, NT) : st_park_nf(METHOD));
+    const StepSmem SM(c->block_size, NT, is_mt_method(METHOD) ? mt_park_nd(c->block_size, NT) + (S.lpr_mat ? (1 << NT) : 0) : st_park_nd(METHOD), is_mt_method(METHOD) ? mt_park_nf(c->block_size, NT) + (METHOD == kMTBayesB1 ? NT * NT : 0) : st_park_nf(METHOD));
     static bool attr_set = false;
     if (!attr_set) {   // allow > 64 KB of dynamic LDS
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_block_step<METHOD, NT, CX, false>),
@@ -1128,6 +1131,7 @@ static hipError_t launch_step_any(jwas_hip_ctx* c, const UpdateArgs& U, const Sa
             return launch_step<M, 4>(c, U, S, do_sample);
         case JWAS_HIP_MTBAYESC2: JW_MT_STEP(kMTBayesC2)
         case JWAS_HIP_MEGABAYESC: JW_MT_STEP(kMegaBayesC)
+        case JWAS_HIP_MTBAYESB1: JW_MT_STEP(kMTBayesB1)
         default: JW_MT_STEP(kMTBayesC1)
 #undef JW_MT_STEP
     }
@@ -1149,7 +1153,7 @@ static hipError_t launch_indep_cx(jwas_hip_ctx* c, const CX& cx, const UpdateArg
     UpdateArgsT<CX> U;
     static_cast<UpdateArgs&>(U) = U0;
     U.cx = cx;
-    const StepSmem SM(c->block_size, NT, is_mt_method(METHOD) ? mt_park_nd(c->block_size, NT) + (S.lpr_mat ? (1 << NT) : 0) : st_park_nd(METHOD), is_mt_method(METHOD) ? mt_park_nf(c->block_size, NT) : st_park_nf(METHOD));
+    const StepSmem SM(c->block_size, NT, is_mt_method(METHOD) ? mt_park_nd(c->block_size, NT) + (S.lpr_mat ? (1 << NT) : 0) : st_park_nd(METHOD), is_mt_method(METHOD) ? mt_park_nf(c->block_size, NT) + (METHOD == kMTBayesB1 ? NT * NT : 0) : st_park_nf(METHOD));
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_indep_sample<METHOD, NT>),
@@ -1200,6 +1204,7 @@ static int sweep_independent(jwas_hip_ctx* c, EventList* out)
     S.p = c->p; S.bsz = bs; S.xpx = c->xpx; S.gram = c->gram;
     S.cross_next = c->gram; S.b_next = 0; S.corr_in = c->corr; S.corr_out = c->corr + (size_t)kMaxT * bs;
     S.prep_d = c->prep_d; S.prep_f = c->prep_f; S.mt2_tab = c->mt2_tab; S.lpr_mat = c->lpr_active ? c->lpr_mat : nullptr;
+    S.ginv_mat = c->method == JWAS_HIP_MTBAYESB1 ? c->ginv_mat : nullptr;
     S.alpha = c->alpha; S.beta = c->beta; S.delta = c->delta;
     S.counters = c->counters;
     hipError_t e;
@@ -1356,13 +1361,26 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
     HIPCHK(c, hipSetDevice(c->device));
 
     DevParams D;
-    c->lpr_active = is_mt_method(c->method) && c->method != JWAS_HIP_MEGABAYESC && P->log_prior_states_matrix != nullptr;
+    c->lpr_active = is_mt_method(c->method) && c->method != JWAS_HIP_MEGABAYESC && c->method != JWAS_HIP_MTBAYESB1 && P->log_prior_states_matrix != nullptr;
     std::memset(&D, 0, sizeof D);
     D.method = c->method; D.ntraits = t; D.nreps = P->nreps;
     D.iter = P->iteration; D.seed_lo = (uint32_t)P->seed; D.seed_hi = (uint32_t)(P->seed >> 32); D.marker0 = P->marker_offset;
     for (int i = 0; i < t * t; ++i) { D.vare[i] = P->vare[i]; D.var_effect[i] = P->var_effect[i]; }
-    if (c->method == JWAS_HIP_MTBAYESC1 || c->method == JWAS_HIP_MTBAYESC2) {
+    if (c->method == JWAS_HIP_MTBAYESC1 || c->method == JWAS_HIP_MTBAYESC2 || c->method == JWAS_HIP_MTBAYESB1) {
         NEED(c, inv_small(P->vare, t, D.Rinv) == 0, JWAS_HIP_EINVAL, "residual covariance matrix is singular");
+        if (c->method == JWAS_HIP_MTBAYESB1) {
+            // multi-trait BayesA/B: one effect covariance per marker (locus_effect_variances, MTBayesABC.jl:66); inverted on
+            // the device by k_prepare, parked in LDS beside the marker's draws
+            NEED(c, P->var_effect_matrix, JWAS_HIP_EINVAL, "multi-trait BayesA/B needs per-marker effect covariances (var_effect_matrix)");
+            NEED(c, !P->independent_blocks, JWAS_HIP_EUNSUP, "independent_blocks is not available with per-marker effect covariances");
+            NEED(c, !P->log_prior_states_matrix, JWAS_HIP_EUNSUP, "marker-specific joint priors are not available with per-marker effect covariances");
+            NEED(c, mt_park_nf(c->block_size, t) != 0, JWAS_HIP_EUNSUP, "per-marker effect covariances need block_size * ntraits <= 2048 (got %d x %d)", c->block_size, t);
+            const size_t mb = sizeof(float) * (size_t)t * t * c->p;
+            int rc = upload_vec(c, (void**)&c->var_mat, P->var_effect_matrix, mb); if (rc) return rc;
+            if (!c->ginv_mat) HIPCHK(c, hipMalloc(&c->ginv_mat, mb));
+            D.var_mat = c->var_mat; D.ginv_mat = c->ginv_mat;
+            for (int i = 0; i < t * t; ++i) D.Ginv[i] = (i / t == i % t) ? 1.f : 0.f;       // (unused)
+        } else
         NEED(c, inv_small(P->var_effect, t, D.Ginv) == 0, JWAS_HIP_EINVAL, "marker effect covariance matrix is singular");
         bool any_finite = false;
         for (int i = 0; i < (1 << t); ++i) { D.log_prior[i] = P->log_prior_states[i]; any_finite = any_finite || std::isfinite(D.log_prior[i]); }
@@ -1425,6 +1443,7 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
                 else if (t == 3) hipLaunchKernelGGL((k_prepare_mt2<3>), pg, pb, 0, c->stream, c->dparams, c->p, c->xpx, c->mt2_tab);
                 JW_MT_PREP(kMTBayesC2)
             case JWAS_HIP_MEGABAYESC: JW_MT_PREP(kMegaBayesC)
+            case JWAS_HIP_MTBAYESB1: JW_MT_PREP(kMTBayesB1)
             default: JW_MT_PREP(kMTBayesC1)
 #undef JW_MT_PREP
         }
@@ -1497,6 +1516,7 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
             S.corr_in = c->corr + (sb & 1) * (size_t)kMaxT * bs;
             S.corr_out = c->corr + ((sb + 1) & 1) * (size_t)kMaxT * bs;
             S.prep_d = c->prep_d; S.prep_f = c->prep_f; S.mt2_tab = c->mt2_tab; S.lpr_mat = c->lpr_active ? c->lpr_mat : nullptr;
+    S.ginv_mat = c->method == JWAS_HIP_MTBAYESB1 ? c->ginv_mat : nullptr;
             S.alpha = c->alpha; S.beta = c->beta; S.delta = c->delta;
             S.ev_out = &c->ev[(k - 1) & 1];
             S.counters = c->counters;

@@ -34,8 +34,11 @@ constexpr int kMaxBlock  = 1024;     // largest marker block
 constexpr int kMaxT      = 4;        // traits
 constexpr int kMaxStates = 16;
 
-enum Method { kBayesC = 0, kBayesB = 1, kBayesR = 2, kMTBayesC1 = 3, kMTBayesC2 = 4, kMegaBayesC = 5 };
+enum Method { kBayesC = 0, kBayesB = 1, kBayesR = 2, kMTBayesC1 = 3, kMTBayesC2 = 4, kMegaBayesC = 5, kMTBayesB1 = 6 };
 __host__ __device__ constexpr bool is_mt_method(int m) { return m >= kMTBayesC1; }
+// Gibbs sampler I; kMTBayesB1 = the same sampler with a t x t effect covariance PER MARKER (multi-trait BayesA/B:
+// locus_effect_variances[marker], MTBayesABC.jl:66,86-90)
+__host__ __device__ constexpr bool is_sampler1(int m) { return m == kMTBayesC1 || m == kMTBayesB1; }
 
 // Effect changes of one marker block, consumed by the next k_update_partial.
 struct Events {
@@ -58,6 +61,8 @@ struct DevParams {
     double   pi4[4], gamma[4];
     double   log_prior[kMaxStates];
     const float*  var_vec;                  // p, BayesB
+    const float*  var_mat;                  // p x t x t, multi-trait BayesA/B: per-marker effect covariances
+    float*        ginv_mat;                 // p x t x t, their inverses (written by k_prepare, read by the sampler)
     const double* pi_vec;                   // p
     const double* pi_mat;                   // p x 4
 };
@@ -635,6 +640,49 @@ __device__ __forceinline__ int bayesr_eval_thr(float rhs_b, float a_old, float i
     return cls;
 }
 
+// t x t inverse on the device: the host's inv_small (double Gauss-Jordan with partial pivoting, rounded to float), the same
+// operation sequence -- multi-trait BayesA/B inverts one covariance matrix per marker (Ginv = inv.(varEffects),
+// MTBayesABC.jl:66).  A singular matrix yields NaNs.
+template <int NT>
+__device__ __forceinline__ void inv_small_dev(const float* A, float* Ainv)
+{
+    double M[NT][2 * NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) { M[i][j] = A[i * NT + j]; M[i][NT + j] = (i == j) ? 1.0 : 0.0; }
+    bool bad = false;
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+        int piv = c;
+        double best = fabs(M[c][c]);                                 // (= fabs(M[piv][c]): no indexing by a run-time row)
+#pragma unroll
+        for (int i = c + 1; i < NT; ++i) { const double v = fabs(M[i][c]); if (v > best) { best = v; piv = i; } }
+#pragma unroll
+        for (int i = c + 1; i < NT; ++i)
+            if (i == piv) {
+#pragma unroll
+                for (int j = 0; j < 2 * NT; ++j) { const double tmp = M[c][j]; M[c][j] = M[i][j]; M[i][j] = tmp; }
+            }
+        if (M[c][c] == 0.0) bad = true;
+        const double d = M[c][c];
+#pragma unroll
+        for (int j = 0; j < 2 * NT; ++j) M[c][j] /= d;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) if (i != c) {
+            const double f = M[i][c];
+            if (f != 0.0) {
+#pragma unroll
+                for (int j = 0; j < 2 * NT; ++j) M[i][j] -= f * M[c][j];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) Ainv[i * NT + j] = bad ? NAN : (float)M[i][NT + j];
+}
+
 // K_P: per-sweep marker constants for repetition 0.  grid = ceil(p/256), block = 256.
 template <int METHOD, int NT>
 __global__ __launch_bounds__(256) void k_prepare(const DevParams* __restrict__ P, int64_t p,
@@ -646,6 +694,18 @@ __global__ __launch_bounds__(256) void k_prepare(const DevParams* __restrict__ P
     const RngKey key{P->seed_lo, P->seed_hi, P->iter, 0u};
     const uint32_t marker = P->marker0 + (uint32_t)j;
     if constexpr (is_mt_method(METHOD)) {
+        float Gi[NT * NT];
+        if constexpr (METHOD == kMTBayesB1) {                       // this marker's own covariance: invert it once per sweep
+            float Gj[NT * NT];
+#pragma unroll
+            for (int i = 0; i < NT * NT; ++i) Gj[i] = P->var_mat[j * (NT * NT) + i];
+            inv_small_dev<NT>(Gj, Gi);
+#pragma unroll
+            for (int i = 0; i < NT * NT; ++i) P->ginv_mat[j * (NT * NT) + i] = Gi[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < NT * NT; ++i) Gi[i] = P->Ginv[i];
+        }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const double u = draw_uniform(key, marker, (uint32_t)t);
@@ -659,7 +719,7 @@ __global__ __launch_bounds__(256) void k_prepare(const DevParams* __restrict__ P
                 const float lhs = dj * (1.0f / P->vare[t * NT + t]) + 1.0f / var;                     // BayesABC.jl:37
                 prep_f[(int64_t)t * p + j] = logf_via_double(lhs) + logf_via_double(var);
             } else {
-                prep_f[(int64_t)t * p + j] = logf_via_double(P->Ginv[t * NT + t] + P->Rinv[t * NT + t] * dj);   // MTBayesABC.jl:89
+                prep_f[(int64_t)t * p + j] = logf_via_double(Gi[t * NT + t] + P->Rinv[t * NT + t] * dj);         // MTBayesABC.jl:89
             }
         }
     } else {

@@ -354,6 +354,7 @@ struct SamplerArgs {
     const double* prep_d; const float* prep_f;
     const double* mt2_tab;        // sampler II, <= 3 traits: per-marker state tables (k_prepare_mt2), else NULL
     const double* lpr_mat;        // multi-trait: p x 2^t marker-specific log prior of the joint states, else NULL
+    const float* ginv_mat;        // multi-trait BayesA/B (kMTBayesB1): p x t x t per-marker G^-1 (k_prepare), else NULL
     float* alpha; float* beta; void* delta;
     Events* ev_out;
     unsigned long long* counters;
@@ -1820,7 +1821,8 @@ template <int METHOD, int NT>
 __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A)
 {
     const bool pm = A.lpr_mat != nullptr;           // marker-specific joint priors (host: only with parked draws)
-    const StepSmem SM(A.bsz, NT, mt_park_nd(A.bsz, NT) + (pm ? (1 << NT) : 0), mt_park_nf(A.bsz, NT));
+    constexpr bool kPG = (METHOD == kMTBayesB1);    // a t x t effect covariance per marker (host: only with parked draws)
+    const StepSmem SM(A.bsz, NT, mt_park_nd(A.bsz, NT) + (pm ? (1 << NT) : 0), mt_park_nf(A.bsz, NT) + (kPG ? NT * NT : 0));
     const int B = SM.B;
     const bool parked = mt_park_nd(B, NT) != 0;
     constexpr bool kTab = (METHOD == kMTBayesC2) && (NT <= 3);       // sampler II from per-marker state tables
@@ -1836,6 +1838,7 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
     float* dcur = reinterpret_cast<float*>(smem + SM.dcur_off);
     double* lpd = reinterpret_cast<double*>(smem + SM.prepd_off);     // [2 NT][B] thresholds, normals (if parked)
     float* lpf = reinterpret_cast<float*>(smem + SM.prepf_off);       // [B] x'x (if parked)
+    float* lpg = lpf + (1 + NT) * B;                                  // [NT*NT][B] the marker's own G^-1 (kPG)
     float* delta = reinterpret_cast<float*>(A.delta);
     const long long tk0 = clock64();
 
@@ -1857,6 +1860,27 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
             K.lp1[a] = log(1.0 - P->pi4[a]);                        // logPiComp          :68
         }
     }
+    // multi-trait BayesA/B: the constants that depend on G are the marker's own (its inverse was formed by k_prepare)
+    auto with_ginv = [&](const float (&g)[NT * NT]) {
+        MtConsts<NT> Kj = K;
+#pragma unroll
+        for (int a = 0; a < NT; ++a) {
+#pragma unroll
+            for (int c2 = 0; c2 < NT; ++c2) Kj.Ginv[a][c2] = g[a * NT + c2];
+            Kj.invG[a] = 1.0f / Kj.Ginv[a][a];                      // MTBayesABC.jl:92
+            Kj.lG[a] = logf_via_double(Kj.Ginv[a][a]);
+            Kj.sG[a] = sqrtf(Kj.invG[a]);
+        }
+        return Kj;
+    };
+    auto consts_of = [&](int c) {                                     // marker c of the block (after the front's barrier)
+        if constexpr (kPG) {
+            float g[NT * NT];
+#pragma unroll
+            for (int i = 0; i < NT * NT; ++i) g[i] = lpg[i * B + c];
+            return with_ginv(g);
+        } else { (void)c; return K; }
+    };
     // the 2^NT log prior state probabilities are indexed by the running state inside every evaluation: a global load
     // there would put a memory latency (microseconds under full-rate streaming) on each trait of each round -- LDS copy
     double* lpr = reinterpret_cast<double*>(smem + SM.lpr_off);
@@ -1890,7 +1914,7 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
         }
     }
     bool cand[2] = {false, false};
-    float djq_[2], a0[2][NT], b0[2][NT], d0[2][NT], w0[2][NT], lc0[2][NT];
+    float djq_[2], a0[2][NT], b0[2][NT], d0[2][NT], w0[2][NT], lc0[2][NT], gq_[2][kPG ? NT * NT : 1];
     double thr0[2][NT], z0[2][NT];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -1907,6 +1931,10 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
             co[t] = A.corr_in[t * B + c];
             thr0[q][t] = A.prep_d[(int64_t)t * p + j]; z0[q][t] = A.prep_d[(int64_t)(NT + t) * p + j];
             lc0[q][t] = A.prep_f[(int64_t)t * p + j];
+        }
+        if constexpr (kPG) {
+#pragma unroll
+            for (int i = 0; i < NT * NT; ++i) gq_[q][i] = A.ginv_mat[j * (NT * NT) + i];
         }
         double lpm[1 << NT];
         if (pm) {
@@ -1928,6 +1956,10 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
             a0[q][t] = a_in;
         }
         if (parked) lpf[c] = dj;
+        if constexpr (kPG) {
+#pragma unroll
+            for (int i = 0; i < NT * NT; ++i) lpg[i * B + c] = gq_[q][i];
+        }
         if (pm) {
 #pragma unroll
             for (int st = 0; st < (1 << NT); ++st) lpd[(2 * NT + st) * B + c] = lpm[st];
@@ -1969,11 +2001,13 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
         bool moves = false;
         if (!in_model) {
             const float dj = djq_[q];
-            const MtPre<NT> Q0 = mt_precompute<METHOD, NT>(K, dj, lc0[q]);
+            MtConsts<NT> Kc = K;
+            if constexpr (kPG) Kc = with_ginv(gq_[q]);
+            const MtPre<NT> Q0 = mt_precompute<METHOD, NT>(Kc, dj, lc0[q]);
             float an[NT], bn[NT], dn[NT], Dl[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) { an[t] = a0[q][t]; bn[t] = b0[q][t]; dn[t] = d0[q][t]; Dl[t] = 0.f; }
-            if constexpr (METHOD == kMTBayesC1) mt1_eval<NT>(K, Q0, PriorMem{lpr_of(c), ls}, w0[q], dj, thr0[q], z0[q], an, bn, dn, Dl);
+            if constexpr (is_sampler1(METHOD)) mt1_eval<NT>(Kc, Q0, PriorMem{lpr_of(c), ls}, w0[q], dj, thr0[q], z0[q], an, bn, dn, Dl);
             else if constexpr (kTab) {
                 double T[kTS][kTV];
                 mt2_load_tab<NT>(A.mt2_tab, p, j0 + c, T);
@@ -2056,6 +2090,8 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
         float rhsq[NT][2], aq[NT][2], bq[NT][2], dq[NT][2], djq[2], wev[2][NT];
         double thrq[NT][2], zq[NT][2];
         MtPre<NT> Qq[2];
+        MtConsts<NT> Kq[kPG ? 2 : 1];                               // (kPG: the two markers' own constants)
+        auto KQ = [&](int q) -> const MtConsts<NT>& { if constexpr (kPG) return Kq[q]; else { (void)q; return K; } };
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int c = (64 * q + lane < b) ? 64 * q + lane : 0;
@@ -2063,7 +2099,8 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
             float lcq[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) lcq[t] = lpf[(1 + t) * B + c];
-            Qq[q] = mt_precompute<METHOD, NT>(K, djq[q], lcq);
+            if constexpr (kPG) Kq[q] = consts_of(c);
+            Qq[q] = mt_precompute<METHOD, NT>(KQ(q), djq[q], lcq);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 rhsq[t][q] = rhs_lds[t * B + c]; aq[t][q] = acur[t * B + c]; bq[t][q] = bcur[t * B + c]; dq[t][q] = dcur[t * B + c];
@@ -2071,7 +2108,7 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
                 wev[q][t] = 0.f;
             }
         }
-        const bool speculate = (METHOD == kMTBayesC1);
+        const bool speculate = is_sampler1(METHOD);
         // one marker evaluated in-lane from (w, its state at block entry, its draws)
         auto eval_own = [&](int q, const float (&w)[NT], float (&an)[NT], float (&bn)[NT], float (&dn)[NT], float (&Dl)[NT]) {
             const int c = (64 * q + lane < b) ? 64 * q + lane : 0;
@@ -2080,7 +2117,7 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
             for (int t = 0; t < NT; ++t) { an[t] = aq[t][q]; bn[t] = bq[t][q]; dn[t] = dq[t][q]; Dl[t] = 0.f; thr[t] = thrq[t][q]; z[t] = zq[t][q]; }
             // (the shared prior table from registers -- v_cndmask trees instead of the LDS lookup -- was measured: 79 ms
             // per sweep instead of 55 at 3 traits x 20k x 100k; the LDS read overlaps the trait's arithmetic well enough)
-            if constexpr (METHOD == kMTBayesC1) mt1_eval<NT>(K, Qq[q], PriorMem{lpr_of(c), ls}, w, djq[q], thr, z, an, bn, dn, Dl);
+            if constexpr (is_sampler1(METHOD)) mt1_eval<NT>(KQ(q), Qq[q], PriorMem{lpr_of(c), ls}, w, djq[q], thr, z, an, bn, dn, Dl);
             else mega_eval<NT>(K, Qq[q], w, djq[q], thr, z, an, bn, dn, Dl);
         };
         // the speculative conditionals: in bn = the marker's beta at block entry, out the new ones; Dl = alpha_old - alpha_new
@@ -2111,7 +2148,7 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
                 da[t] = djq[Q] * aq[t][Q];                                                          // :82
                 zs1[t] = zq[t][Q] * (double)Qq[Q].s1[t];
 #pragma unroll
-                for (int m = 0; m < NT; ++m) C12[t][m] = K.Ginv[t][m] + (djq[Q] * 1.f) * K.Rinv[t][m];      // :90 with delta_m = 1
+                for (int m = 0; m < NT; ++m) C12[t][m] = KQ(Q).Ginv[t][m] + (djq[Q] * 1.f) * K.Rinv[t][m];      // :90 with delta_m = 1
             }
             auto step = [&](int l, float c0, float c1) {
                 float w[NT], an[NT], bn[NT], dn[NT], Dl[NT];
@@ -2165,7 +2202,7 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
                 da[t] = djq[Q] * aq[t][Q];
                 zs1[t] = zq[t][Q] * (double)Qq[Q].s1[t];
 #pragma unroll
-                for (int m = 0; m < NT; ++m) C12[t][m] = K.Ginv[t][m] + (djq[Q] * 1.f) * K.Rinv[t][m];
+                for (int m = 0; m < NT; ++m) C12[t][m] = KQ(Q).Ginv[t][m] + (djq[Q] * 1.f) * K.Rinv[t][m];
             }
             float g0 = (Q == 0) ? grow[lane] : 0.f;
             float g1 = (B > 64) ? grow[64 + lane] : 0.f;
@@ -2271,7 +2308,8 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
             float lcm[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) lcm[t] = parked ? lpf[(1 + t) * B + c] : A.prep_f[(int64_t)t * p + j];
-            const MtPre<NT> Qm = mt_precompute<METHOD, NT>(K, dj, lcm); // x'x-only terms, once per marker (SIMD over the sub-block)
+            const MtConsts<NT> Km = consts_of(valid ? c : 0);          // (kPG: this marker's own G-dependent constants)
+            const MtPre<NT> Qm = mt_precompute<METHOD, NT>(Km, dj, lcm); // x'x-only terms, once per marker (SIMD over the sub-block)
             double T[kTS][kTV];
             if constexpr (kTab) mt2_load_tab<NT>(A.mt2_tab, p, j, T);
             while (true) {
@@ -2284,7 +2322,7 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
                     float w[NT];
 #pragma unroll
                     for (int t = 0; t < NT; ++t) w[t] = rhs_lds[t * B + c] + dj * a_cur[t];           // :82
-                    if constexpr (METHOD == kMTBayesC1) mt1_eval<NT>(K, Qm, PriorMem{lpr_of(c), ls}, w, dj, thr, z, an, bn, dn, Dl);
+                    if constexpr (is_sampler1(METHOD)) mt1_eval<NT>(Km, Qm, PriorMem{lpr_of(c), ls}, w, dj, thr, z, an, bn, dn, Dl);
                     else if constexpr (kTab) mt2_eval_tab<NT>(K, lpr_of(c), ls, w, T, thr[0], z, an, bn, dn, Dl);
                     else if constexpr (METHOD == kMTBayesC2) mt2_eval<NT>(K, lpr_of(c), ls, w, dj, thr[0], z, an, bn, dn, Dl);
                     else mega_eval<NT>(K, Qm, w, dj, thr, z, an, bn, dn, Dl);

@@ -22,7 +22,7 @@ from ._lib import JwasHipError, SweepParams, SweepStats
 
 METHOD_CODES = {"BayesC": _lib.BAYESC, "BayesB": _lib.BAYESB, "BayesA": _lib.BAYESB,
                 "BayesR": _lib.BAYESR, "MTBayesC": _lib.MTBAYESC1, "MTBayesC_II": _lib.MTBAYESC2,
-                "MegaBayesC": _lib.MEGABAYESC}
+                "MegaBayesC": _lib.MEGABAYESC, "MTBayesB": _lib.MTBAYESB1}
 BAYESR_GAMMA = np.array([0.0, 0.01, 0.1, 1.0], dtype=np.float64)   # JWAS.jl:12
 
 
@@ -372,7 +372,7 @@ class HipEngine:
         return self.sweep(_sharded=True, **params)
 
     def sweep(self, *, iteration, seed, vare, var_effect, pi=0.0, pi_classes=None, gamma=BAYESR_GAMMA,
-              log_prior_states=None, var_effect_vec=None, pi_vec=None, pi_matrix=None, nreps=1,
+              log_prior_states=None, var_effect_vec=None, var_effect_matrix=None, pi_vec=None, pi_matrix=None, nreps=1,
               marker_offset=0, independent_blocks=False, _sharded=False):
         """One marker sweep.  Argument meaning follows BayesABC!/BayesR!/MTBayesABC!:
         vare: residual variance (scalar or t x t); var_effect: marker effect variance (BayesC scalar,
@@ -440,6 +440,14 @@ class HipEngine:
             for k in range(t):
                 P.pi_classes[k] = float(pt[k])
         else:
+            if self.method == _lib.MTBAYESB1:     # multi-trait BayesA/B: one t x t effect covariance per marker
+                if var_effect_matrix is None:
+                    raise ValueError("multi-trait BayesA/B needs var_effect_matrix (p x t x t)")
+                vm = np.ascontiguousarray(var_effect_matrix, dtype=np.float32)
+                if vm.shape != (self.p, t, t):
+                    raise ValueError(f"var_effect_matrix must be {self.p} x {t} x {t}")
+                keep.append(vm)
+                P.var_effect_matrix = vm.ctypes.data_as(C.POINTER(C.c_float))
             lp = np.asarray(log_prior_states, dtype=np.float64)
             if lp.ndim == 2:                      # marker-specific joint priors (MarkerSpecificPiPrior, MTBayesABC.jl:22-47)
                 if lp.shape != (self.p, 1 << t):

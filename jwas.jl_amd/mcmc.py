@@ -132,6 +132,23 @@ def _impute_missing_residuals(res, observed, R0, rng):
     return Ri_rows
 
 
+def _inverse_wishart_batch(rng, df, scale):
+    """One InverseWishart(df, scale_j) draw per matrix of the batch (m x t x t), Bartlett's decomposition: with
+    scale_j^-1 = L L' and A lower-triangular (A_ii = sqrt(chi2(df - i)), A_ik ~ N(0,1) below the diagonal),
+    W = L A A' L' ~ Wishart(df, scale_j^-1) and G = W^-1 (the reference draws each marker's matrix with
+    rand(InverseWishart(df, scale)), variance_components.jl:181-186)."""
+    m, t, _ = scale.shape
+    L = np.linalg.cholesky(np.linalg.inv(scale))
+    A = np.zeros((m, t, t))
+    for i in range(t):
+        A[:, i, i] = np.sqrt(rng.chisquare(df - i, size=m))
+        for k in range(i):
+            A[:, i, k] = rng.standard_normal(m)
+    Minv = np.linalg.inv(L @ A)
+    G = Minv.transpose(0, 2, 1) @ Minv
+    return (G + G.transpose(0, 2, 1)) / 2
+
+
 def _gibbs(A, x, b, rng, vare=None):
     """One sweep of the single-site Gibbs sampler on the MME (iterative_solver/solver.jl:143-162)."""
     for i in range(len(x)):
@@ -149,10 +166,12 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
     Mi = model.M[0]
     t = model.nModels
     method = Mi.method
-    if t > 1 and method not in ("BayesC", "RR-BLUP"):
+    if t > 1 and method not in ("BayesC", "RR-BLUP", "BayesB", "BayesA"):
         raise NotImplementedError("multi-trait device path implements BayesC (Gibbs samplers I, II and the constraint=true "
-                                  "megaBayesABC! path); other methods stay on the reference")
+                                  "megaBayesABC! path) and BayesA/B (sampler I); other methods stay on the reference")
     mega = t > 1 and bool(Mi.G.constraint)                              # megaBayesABC! (MCMC_BayesianAlphabet.jl:233-234)
+    if mega and method in ("BayesB", "BayesA"):
+        raise NotImplementedError("multi-trait BayesA/B with constraint=true stays on the reference")
     if mega and method == "RR-BLUP":
         raise NotImplementedError("multi-trait RR-BLUP with constraint=true stays on the reference")
     if t == 1 and (Mi.G.constraint or model.R.constraint):
@@ -288,7 +307,8 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
     if method == "BayesR" and np.isscalar(pi) and pi == 0.0:           # :375-377
         pi = np.array([0.95, 0.03, 0.015, 0.005])
     if method == "BayesA":                                             # input_data_validation.jl:33-36
-        method, pi, Mi.estimatePi = "BayesB", 0.0, False
+        method, Mi.estimatePi = "BayesB", False
+        pi = 0.0 if t == 1 else np.eye(1, 1 << t, (1 << t) - 1).ravel()  # every marker in the model for every trait
     lasso = method == "BayesL"
     if lasso:
         # Bayesian LASSO (BayesL!, BayesC0L.jl:25-47): every marker in the model, effect variance G*gamma_j with the
@@ -361,6 +381,13 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         n_states = len(Mi.pi) if isinstance(Mi.pi, dict) else (1 << t)
         sampler = "I" if n_states == (1 << t) else "II"
     mt_method = "MegaBayesC" if mega else ("MTBayesC_II" if sampler == "II" else "MTBayesC")
+    mt_pervar = t > 1 and method == "BayesB"        # multi-trait BayesA/B: one t x t effect covariance per marker
+    if mt_pervar:
+        if sampler == "II":
+            raise NotImplementedError("multi-trait BayesA/B runs with Gibbs sampler I on the device (multi_trait_sampler=:I)")
+        if getattr(Mi, "annotations", False) is not False:
+            raise NotImplementedError("annotated multi-trait BayesB stays on the reference")
+        mt_method = "MTBayesB"
 
     # ---- fast_blocks parsing (JWAS.jl:293-316); device blocks are powers of two >= 64
     nreps = 1
@@ -422,6 +449,8 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
             dense = float(np.mean(pi)) < 0.5
         block_size = 128 if dense else 512
         while block_size > 64 and p <= block_size:
+            block_size //= 2
+        while mt_pervar and block_size * t > 2048:                      # the markers' own constants are parked in LDS
             block_size //= 2
         # Sparse priors: keep a second, larger block size resident and pick per sweep from the previous sweep's number
         # of effect changes (a chain quantity, so runs stay reproducible): 1024-marker blocks amortise the per-launch cost
@@ -496,6 +525,8 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         Mi.G.scale = Mi.G.scale / 8
         gamma_l = rng.gamma(1.0, 8.0, size=p)
         Gvec = (np.float64(Gval) * gamma_l).astype(np.float32)
+    elif mt_pervar:
+        Gmat = np.tile(np.asarray(Gval, dtype=np.float32), (p, 1, 1))   # MCMC_BayesianAlphabet.jl:67-69 (fill(G, nMarkers))
     elif method == "BayesB":
         Gvec = np.full(p, Gval, dtype=np.float32)                       # MCMC_BayesianAlphabet.jl:67-69
     pervar = method == "BayesB" and not lasso                           # per-marker variances, no common variance to report
@@ -614,6 +645,8 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         elif t > 1:
             with np.errstate(divide="ignore"):
                 kw.update(var_effect=Gval, log_prior_states=np.log(ann.snp_pi if ann is not False else np.asarray(pi, dtype=np.float64)))
+            if mt_pervar:
+                kw["var_effect_matrix"] = Gmat
         elif method == "BayesR":
             kw.update(var_effect=Gval, pi_classes=np.asarray(pi, dtype=np.float64))
             if ann is not False:
@@ -651,6 +684,9 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         if Mi.G.estimate_variance:
             if mega:                                                    # diagonal only (variance_components.jl:104-109)
                 Gval = np.diag([(st["beta_ss"][k, k] + Gdf * Mi.G.scale[k, k]) / rng.chisquare(p + Gdf) for k in range(t)]).astype(np.float32)
+            elif mt_pervar:                                             # variance_components.jl:181-186: one draw per marker,
+                B = np.stack([engine.get_state(k)[1] for k in range(t)], axis=1).astype(np.float64)     # IW(df + 1, scale + b_j b_j')
+                Gmat = _inverse_wishart_batch(rng, Gdf + 1.0, np.asarray(Mi.G.scale, dtype=np.float64)[None] + B[:, :, None] * B[:, None, :]).astype(np.float32)
             elif t > 1:
                 from scipy.stats import invwishart
                 S = np.asarray(Mi.G.scale, dtype=np.float64) + st["beta_ss"]

@@ -399,6 +399,18 @@ static int inv_small(const float* A, int t, float* Ainv)
     return 0;
 }
 
+/* Multi-trait BayesA/B (MTBayesABC.jl:66  Ginv = inv.(varEffects),  :86-90  Ginv[marker]): one t x t effect covariance per
+ * marker.  Test-harness state: when set (p x t x t, row-major per marker), every multi-trait sweep inverts marker j's own
+ * matrix instead of using the sweep-wide var_effect. */
+static const float* g_var_effect_mat = NULL;
+void orc_set_var_effect_matrix(const float* mat) { g_var_effect_mat = mat; }
+static inline const float* marker_ginv(int64_t j, int t, const float* Ginv_all, float* tmp)
+{
+    if (!g_var_effect_mat) return Ginv_all;
+    if (inv_small(g_var_effect_mat + j * t * t, t, tmp)) for (int i = 0; i < t * t; ++i) tmp[i] = NAN;
+    return tmp;
+}
+
 /* One marker.  w[k] = x'r_k + d*alpha_old_k already formed.  Writes axpy coefficients a[k]. */
 static inline void mt1_update(int t, const float* w, float d, float* alpha, float* beta, float* delta,
                               int64_t stride, const float* Rinv, const float* Ginv,
@@ -605,7 +617,8 @@ int orc_mt_sweep(int kind, const float* X, int64_t n, int64_t p, int64_t ld, con
                          uint64_t seed, uint32_t iter, uint32_t marker0, int acc)
 {
     if (t < 1 || t > ORC_MAXT || n <= 0 || ld < n || ld_r < n) return -1;
-    float Rinv[ORC_MAXT * ORC_MAXT], Ginv[ORC_MAXT * ORC_MAXT];
+    float Rinv[ORC_MAXT * ORC_MAXT], Ginv[ORC_MAXT * ORC_MAXT], Gtmp_[ORC_MAXT * ORC_MAXT];
+    (void)Gtmp_;
     if (kind < MT_SAMPLER_I || kind > MT_MEGA) return -1;
     if (inv_small(vare, t, Rinv) || inv_small(var_effect, t, Ginv)) return -2;
     const int nstates = 1 << t;
@@ -613,7 +626,7 @@ int orc_mt_sweep(int kind, const float* X, int64_t n, int64_t p, int64_t ld, con
         const float* x = X + j * ld;
         float w[ORC_MAXT], a[ORC_MAXT];
         for (int k = 0; k < t; ++k) w[k] = dot_acc(x, r + k * ld_r, n, acc);     /* :82 */
-        mt_update(kind, t, w, xpx[j], alpha + j, beta + j, delta + j, p, Rinv, Ginv, vare, var_effect,
+        mt_update(kind, t, w, xpx[j], alpha + j, beta + j, delta + j, p, Rinv, marker_ginv(j, t, Ginv, Gtmp_), vare, var_effect,
                   prior_is_matrix ? log_prior + (int64_t)nstates * j : log_prior,
                   seed, marker0 + (uint32_t)j, iter, 0, a);
         for (int k = 0; k < t; ++k) if (a[k] != 0.0f) axpy_f32(a[k], x, r + k * ld_r, n);
@@ -629,7 +642,8 @@ static int mt_block_sweep_impl(int kind, const float* X, int64_t n, int64_t p, i
                                uint64_t seed, uint32_t iter, uint32_t marker0, int acc, int independent)
 {
     if (t < 1 || t > ORC_MAXT || n <= 0 || ld < n || ld_r < n || !blocks_ok(block_starts, nblocks, p)) return -1;
-    float Rinv[ORC_MAXT * ORC_MAXT], Ginv[ORC_MAXT * ORC_MAXT];
+    float Rinv[ORC_MAXT * ORC_MAXT], Ginv[ORC_MAXT * ORC_MAXT], Gtmp_[ORC_MAXT * ORC_MAXT];
+    (void)Gtmp_;
     if (kind < MT_SAMPLER_I || kind > MT_MEGA) return -1;
     if (inv_small(vare, t, Rinv) || inv_small(var_effect, t, Ginv)) return -2;
     const int nstates = 1 << t;
@@ -651,7 +665,7 @@ static int mt_block_sweep_impl(int kind, const float* X, int64_t n, int64_t p, i
                 const int64_t j = j0 + c;
                 float w[ORC_MAXT], a[ORC_MAXT];
                 for (int k = 0; k < t; ++k) w[k] = rhs_b[k * b + c];
-                mt_update(kind, t, w, xpx[j], alpha + j, beta + j, delta + j, p, Rinv, Ginv, vare, var_effect,
+                mt_update(kind, t, w, xpx[j], alpha + j, beta + j, delta + j, p, Rinv, marker_ginv(j, t, Ginv, Gtmp_), vare, var_effect,
                           prior_is_matrix ? log_prior + (int64_t)nstates * j : log_prior,
                           seed, marker0 + (uint32_t)j, iter, (uint32_t)rep, a);
                 for (int k = 0; k < t; ++k)
@@ -810,7 +824,8 @@ int orc_mt_lookahead_sweep(int kind, const float* X, int64_t n, int64_t p, int64
                                    uint64_t seed, uint32_t iter, uint32_t marker0, int acc)
 {
     if (t < 1 || t > ORC_MAXT || n <= 0 || ld < n || ld_r < n || !blocks_ok(block_starts, nblocks, p)) return -1;
-    float Rinv[ORC_MAXT * ORC_MAXT], Ginv[ORC_MAXT * ORC_MAXT];
+    float Rinv[ORC_MAXT * ORC_MAXT], Ginv[ORC_MAXT * ORC_MAXT], Gtmp_[ORC_MAXT * ORC_MAXT];
+    (void)Gtmp_;
     if (kind < MT_SAMPLER_I || kind > MT_MEGA) return -1;
     if (inv_small(vare, t, Rinv) || inv_small(var_effect, t, Ginv)) return -2;
     const int nstates = 1 << t;
@@ -830,7 +845,7 @@ int orc_mt_lookahead_sweep(int kind, const float* X, int64_t n, int64_t p, int64
                 const int64_t j = j0 + c;
                 float w[ORC_MAXT], a[ORC_MAXT];
                 for (int k = 0; k < t; ++k) w[k] = rhs_b[k * b + c];
-                mt_update(kind, t, w, xpx[j], alpha + j, beta + j, delta + j, p, Rinv, Ginv, vare, var_effect,
+                mt_update(kind, t, w, xpx[j], alpha + j, beta + j, delta + j, p, Rinv, marker_ginv(j, t, Ginv, Gtmp_), vare, var_effect,
                           prior_is_matrix ? log_prior + (int64_t)nstates * j : log_prior,
                           seed, marker0 + (uint32_t)j, iter, (uint32_t)rep, a);
                 for (int k = 0; k < t; ++k) if (a[k] != 0.0f) axpy_f32(a[k], G + c * b, rhs_b + k * b, b);

@@ -153,6 +153,9 @@ int orc_mtbayesc_I_lookahead_sweep(const float* X, int64_t n, int64_t p, int64_t
 #define ORC_MT_SAMPLER_I  1
 #define ORC_MT_SAMPLER_II 2
 #define ORC_MT_MEGA       3
+/* Multi-trait BayesA/B: per-marker effect covariances (p x t x t row-major; MTBayesABC.jl:66,86-90) used by every
+ * multi-trait sweep until reset with NULL (harness state; sampler I). */
+void orc_set_var_effect_matrix(const float* mat);
 int orc_mt_sweep(int kind, const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
                  int t, float* r, int64_t ld_r, float* alpha, float* beta, float* delta,
                  const float* vare, const float* var_effect, const double* log_prior, int prior_is_matrix,

@@ -251,6 +251,20 @@ def mt_sweep(kind, X, xpx_, r, alpha, beta, delta, vare, var_effect, log_prior, 
         raise ValueError(f"oracle multi-trait sweep (kind {kind}) rejected its arguments (rc={rc})")
 
 
+def set_var_effect_matrix(mat):
+    """Per-marker effect covariances (p x t x t float32) for the multi-trait sweeps (multi-trait BayesA/B), or None."""
+    global _VEM
+    if mat is None:
+        _VEM = None
+        lib().orc_set_var_effect_matrix(None)
+    else:
+        _VEM = np.ascontiguousarray(mat, dtype=np.float32)
+        lib().orc_set_var_effect_matrix(_p(_VEM, _f32p))
+
+
+_VEM = None
+
+
 def mtbayesc_I_sweep(X, xpx_, r, alpha, beta, delta, vare, var_effect, log_prior, seed, it, **kw):
     mt_sweep(MT_SAMPLER_I, X, xpx_, r, alpha, beta, delta, vare, var_effect, log_prior, seed, it, **kw)
 

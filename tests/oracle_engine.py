@@ -10,9 +10,9 @@ import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
 import oracle as O  # noqa: E402
 
-BAYESC, BAYESB, BAYESR, MTBAYESC1, MTBAYESC2, MEGABAYESC = 0, 1, 2, 3, 4, 5
+BAYESC, BAYESB, BAYESR, MTBAYESC1, MTBAYESC2, MEGABAYESC, MTBAYESB1 = 0, 1, 2, 3, 4, 5, 6
 METHOD_CODES = {"BayesC": BAYESC, "BayesB": BAYESB, "BayesA": BAYESB, "BayesR": BAYESR, "MTBayesC": MTBAYESC1,
-                "MTBayesC_II": MTBAYESC2, "MegaBayesC": MEGABAYESC}
+                "MTBayesC_II": MTBAYESC2, "MegaBayesC": MEGABAYESC, "MTBayesB": MTBAYESB1}
 
 
 class OracleEngine:
@@ -148,7 +148,7 @@ class OracleEngine:
         return (self.X_out.astype(np.float64) @ self.alpha[trait].astype(np.float64)).astype(np.float32)
 
     def sweep(self, *, iteration, seed, vare, var_effect, pi=0.0, pi_classes=None, gamma=O.GAMMA,
-              log_prior_states=None, var_effect_vec=None, pi_vec=None, pi_matrix=None, nreps=1,
+              log_prior_states=None, var_effect_vec=None, var_effect_matrix=None, pi_vec=None, pi_matrix=None, nreps=1,
               marker_offset=0, independent_blocks=False):
         t = self.ntraits
         blk = (dict(block_starts=self._bs, grams=self._grams, nreps=nreps, lookahead=(self.form == "lookahead"),
@@ -158,11 +158,17 @@ class OracleEngine:
             raise ValueError("independent blocks need a block form")
         a_before = self.alpha.copy()
         self._w()
+        if self.method == MTBAYESB1:                  # multi-trait BayesA/B: one effect covariance per marker
+            vm = np.ascontiguousarray(var_effect_matrix, dtype=np.float32)
+            assert vm.shape == (self.p, t, t)
+            O.set_var_effect_matrix(vm)
+            var_effect = np.eye(t, dtype=np.float32)  # (unused)
         try:
             self._sweep_inner(t, blk, iteration, seed, vare, var_effect, pi, pi_classes, gamma, log_prior_states,
                               var_effect_vec, pi_vec, pi_matrix, marker_offset)
         finally:
             O.set_weights(None)
+            O.set_var_effect_matrix(None)
         return self._stats(a_before, gamma)
 
     def _sweep_inner(self, t, blk, iteration, seed, vare, var_effect, pi, pi_classes, gamma, log_prior_states,
@@ -181,7 +187,7 @@ class OracleEngine:
                            float(np.asarray(vare).reshape(-1)[0]), float(np.asarray(var_effect).reshape(-1)[0]),
                            pc, seed, iteration, gamma=gamma, marker0=marker_offset, acc=self.acc, **blk)
         else:
-            kind = {MTBAYESC1: O.MT_SAMPLER_I, MTBAYESC2: O.MT_SAMPLER_II, MEGABAYESC: O.MT_MEGA}[self.method]
+            kind = {MTBAYESC1: O.MT_SAMPLER_I, MTBAYESB1: O.MT_SAMPLER_I, MTBAYESC2: O.MT_SAMPLER_II, MEGABAYESC: O.MT_MEGA}[self.method]
             prior = np.asarray(pi, dtype=np.float64).reshape(-1) if self.method == MEGABAYESC else log_prior_states
             O.mt_sweep(kind, self.X, self._xpx, self.r, self.alpha, self.beta, self.delta,
                        np.asarray(vare, dtype=np.float32).reshape(t, t),

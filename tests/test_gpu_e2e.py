@@ -92,6 +92,30 @@ def test_three_trait_chain_gpu_vs_oracle(tmp_path):
     np.testing.assert_allclose(outs["hip"]["residual variance"]["Estimate"], outs["orc"]["residual variance"]["Estimate"], rtol=1e-3)
 
 
+@pytest.mark.parametrize("method", ["BayesB", "BayesA"])
+def test_three_trait_bayesb_chain_gpu_vs_oracle(tmp_path, method):
+    """Multi-trait BayesA/B through runMCMC: every marker's 3 x 3 effect covariance is redrawn on the host each iteration
+    (variance_components.jl:181-186) and inverted on the device; the whole chain against the CPU oracle engine."""
+    d = make_dataset(n=280, p=400, ncausal=6, seed=78, center=False)
+    rng = np.random.default_rng(5)
+    ids = [f"i{i}" for i in range(280)]
+    gdf = pd.DataFrame(d["raw"], columns=[f"m{j}" for j in range(400)])
+    gdf.insert(0, "ID", ids)
+    ph = pd.DataFrame({"ID": ids, "y1": d["y"], "y2": (0.7 * d["y"] + 0.5 * rng.standard_normal(280)).astype(np.float32),
+                       "y3": (-0.4 * d["y"] + 0.8 * rng.standard_normal(280)).astype(np.float32)})
+    outs = {}
+    for tag, eng in (("orc", OracleEngine("lookahead")), ("hip", None)):
+        geno = api.get_genotypes(gdf, method=method)
+        model = api.build_model("y1 = intercept + geno\ny2 = intercept + geno\ny3 = intercept + geno")
+        outs[tag] = api.runMCMC(model, ph, chain_length=60, burnin=10, seed=12, outputEBV=False,
+                                output_folder=str(tmp_path / tag), _engine=eng, block_size=128, gram_mode="f64")
+    eo, eh = outs["orc"]["marker effects geno"], outs["hip"]["marker effects geno"]
+    assert len(eh) == 3 * 400
+    np.testing.assert_allclose(eh["Estimate"], eo["Estimate"], atol=1e-4)
+    np.testing.assert_allclose(eh["Model_Frequency"], eo["Model_Frequency"], atol=1e-4)
+    np.testing.assert_allclose(outs["hip"]["residual variance"]["Estimate"], outs["orc"]["residual variance"]["Estimate"], rtol=1e-3)
+
+
 def test_runmcmc_gpu_mfma_gram_statistically_equivalent(tmp_path):
     """With the production (fp32 MFMA) Gram the chain may round differently from the oracle; the
     posterior summaries still agree within Monte-Carlo noise of a short chain."""

@@ -759,3 +759,61 @@ def test_cooperative_dense_apply_is_bit_identical(method, t, bs, pi, monkeypatch
         assert np.array_equal(results["coop"][1][k], results["plain"][1][k])
         np.testing.assert_allclose(results["coop"][1][k], results["oracle"][1][k], atol=2e-4)
         np.testing.assert_allclose(results["coop"][0][k][0], results["oracle"][0][k][0], atol=5e-6)
+
+
+@pytest.mark.parametrize("t,bs,dense,nreps", [(2, 64, False, 1), (3, 128, False, 1), (3, 512, False, 1), (4, 256, False, 1),
+                                              (3, 128, True, 1), (2, 64, True, 1), (3, 64, False, 3)])
+def test_mt_bayesb_per_marker_covariance_parity(hip, t, bs, dense, nreps):
+    """Multi-trait BayesA/B: Gibbs sampler I with ONE t x t effect covariance PER MARKER (Ginv = inv.(varEffects),
+    MTBayesABC.jl:66,86-90).  The device inverts every marker's matrix in k_prepare (the host's Gauss-Jordan, operation for
+    operation) and the sampler uses the marker's own constants; sparse rounds, the dense walk (every marker in the model,
+    speculative and general) and within-block repetitions against the oracle."""
+    import jwas_jl_amd as J
+    data = make_dataset(n=420, p=2 * bs + 29, ncausal=10, seed=900 + t)
+    orc, hip = _pair(hip, data, bs, "MTBayesB", ntraits=t)
+    rng = np.random.default_rng(40 + t)
+    p = orc.p
+    Y = np.stack([data["y"] - data["y"].mean() + 0.3 * rng.standard_normal(len(data["y"])).astype(np.float32)
+                  for _ in range(t)]).astype(np.float32)
+    for k in range(t):
+        orc.set_residual(Y[k], k); hip.set_residual(Y[k], k)
+        ones = np.ones(p, dtype=np.float32)
+        if dense:
+            a0 = (0.01 * rng.standard_normal(p)).astype(np.float32)
+            orc.set_state(k, alpha=a0, beta=a0, delta=ones); hip.set_state(k, alpha=a0, beta=a0, delta=ones)
+            orc.sub_xalpha(k); hip.sub_xalpha(k)
+        else:
+            orc.set_state(k, delta=ones); hip.set_state(k, delta=ones)
+    A = rng.standard_normal((t, t))
+    vare = (A @ A.T / t + np.eye(t)).astype(np.float32) * 0.5
+    # a different SPD matrix for every marker (scales over two orders of magnitude)
+    Bm = rng.standard_normal((p, t, t))
+    Gm = ((Bm @ Bm.transpose(0, 2, 1) / t + np.eye(t)) * (0.002 * np.exp(rng.uniform(-2, 2, p)))[:, None, None]).astype(np.float32)
+    if dense:
+        prior = np.full(1 << t, 1e-4); prior[-1] = 1.0; prior /= prior.sum()
+    else:
+        prior = rng.dirichlet(np.ones(1 << t))
+    kw = dict(vare=vare, var_effect=np.eye(t, dtype=np.float32), var_effect_matrix=Gm, log_prior_states=np.log(prior), nreps=nreps)
+    for it in range(1, 13):
+        so = orc.sweep(iteration=it, seed=13, **kw)
+        sh = hip.sweep(iteration=it, seed=13, **kw)
+        assert np.array_equal(so["state_counts"], sh["state_counts"]), f"iteration {it}"
+        np.testing.assert_allclose(sh["beta_ss"], so["beta_ss"], rtol=1e-5)
+        np.testing.assert_allclose(sh["resid_ss"], so["resid_ss"], rtol=1e-5, atol=1e-6 * float(np.max(np.abs(so["resid_ss"]))))
+    for k in range(t):
+        _compare_state(orc, hip, k, atol=5e-6)
+    # error contracts
+    with pytest.raises(ValueError, match="var_effect_matrix"):
+        hip.sweep(iteration=1, seed=1, vare=vare, var_effect=np.eye(t, dtype=np.float32), log_prior_states=np.log(prior))
+    with pytest.raises(J.JwasHipError, match="independent_blocks"):
+        hip.sweep(iteration=1, seed=1, independent_blocks=True, **kw)
+
+
+def test_mt_bayesb_needs_parked_draws(hip):
+    import jwas_jl_amd as J
+    data = make_dataset(n=100, p=1100, ncausal=3, seed=1)
+    hip.load_dense(data["X"]); hip.setup_blocks(1024, "f64"); hip.init_state("MTBayesB", 3)
+    Gm = np.tile(np.eye(3, dtype=np.float32) * 0.01, (1100, 1, 1))
+    with pytest.raises(J.JwasHipError, match="block_size \\* ntraits <= 2048"):
+        hip.sweep(iteration=1, seed=1, vare=np.eye(3, dtype=np.float32), var_effect=np.eye(3, dtype=np.float32),
+                  var_effect_matrix=Gm, log_prior_states=np.log(np.full(8, 0.125)))
