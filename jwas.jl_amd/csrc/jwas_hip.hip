@@ -1516,7 +1516,7 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
             S.corr_in = c->corr + (sb & 1) * (size_t)kMaxT * bs;
             S.corr_out = c->corr + ((sb + 1) & 1) * (size_t)kMaxT * bs;
             S.prep_d = c->prep_d; S.prep_f = c->prep_f; S.mt2_tab = c->mt2_tab; S.lpr_mat = c->lpr_active ? c->lpr_mat : nullptr;
-    S.ginv_mat = c->method == JWAS_HIP_MTBAYESB1 ? c->ginv_mat : nullptr;
+            S.ginv_mat = c->method == JWAS_HIP_MTBAYESB1 ? c->ginv_mat : nullptr;
             S.alpha = c->alpha; S.beta = c->beta; S.delta = c->delta;
             S.ev_out = &c->ev[(k - 1) & 1];
             S.counters = c->counters;
