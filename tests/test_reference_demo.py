@@ -327,11 +327,15 @@ def test_advanced_coverage_sets_on_the_device_path(tmp_path):
     out = api.runMCMC(model, ph, chain_length=100, burnin=20, output_samples_frequency=10, heterogeneous_residuals=True,
                       output_folder=str(tmp_path / "w"), seed=123)
     assert "marker effects geno" in out
-    # multi-trait BayesB / BayesL stay on the reference, loudly
+    # multi-trait BayesB runs on the device (one effect covariance per marker); multi-trait BayesL stays on the reference, loudly
     geno = api.get_genotypes(GENO, G, separator=",", method="BayesB")
     model = api.build_model("y1 = intercept + geno\ny2 = intercept + geno", G)
-    with pytest.raises(NotImplementedError, match="multi-trait device path"):
-        api.runMCMC(model, ph, chain_length=10, output_folder=str(tmp_path / "b"), seed=123)
+    out = api.runMCMC(model, ph, chain_length=40, burnin=10, output_folder=str(tmp_path / "b"), seed=123)
+    assert np.isfinite(out["marker effects geno"]["Estimate"]).all() and np.isfinite(out["residual variance"]["Estimate"]).all()
+    geno = api.get_genotypes(GENO, G, separator=",", method="BayesL")
+    model = api.build_model("y1 = intercept + geno\ny2 = intercept + geno", G)
+    with pytest.raises(NotImplementedError, match="multi-trait"):
+        api.runMCMC(model, ph, chain_length=10, output_folder=str(tmp_path / "l"), seed=123)
 
 
 # ---- test/unit/test_misc_coverage.jl:69-91, 116-208 ---------------------------------------------------------
