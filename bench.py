@@ -75,6 +75,8 @@ def parse():
     ap.add_argument("--pi-fixed", type=float, default=None,
                     help="BayesC workloads: keep pi at this value (estimatePi = false) -- the high-turnover variant")
     ap.add_argument("--mt-prior", choices=["default", "sparse"], default="default")
+    ap.add_argument("--mt-method", choices=["BayesC", "BayesB"], default="BayesC",
+                    help="config4: BayesB = multi-trait BayesA/B, one effect covariance per marker (redrawn on the host each iteration)")
     ap.add_argument("--seed", type=int, default=2026)
     ap.add_argument("--storage", choices=["dense", "packed2bit"], default="dense",
                     help="dense = the metric's fp32 dense genotypes (default); packed2bit = the reference's 2-bit packed "
@@ -169,7 +171,10 @@ def main():
     if adaptive:
         eng.add_block_size(1024, "mfma")
     log('setup_blocks done')
-    eng.init_state(method, t)
+    mt_pervar = t > 1 and a.mt_method == "BayesB"
+    if mt_pervar and world > 1:
+        raise SystemExit("--mt-method BayesB runs on one GPU")
+    eng.init_state("MTBayesB" if mt_pervar else method, t)
     shard = MarkerShard(eng, lo, hi, rank, world)
 
     # ---- simulate y_k = 1 + X beta_k + e_k with ncausal QTL, h2 = 0.5
@@ -227,6 +232,8 @@ def main():
     setup_s = time.time() - t_setup; log(f'setup done {setup_s:.1f}s')
 
     state = {"r": Y.copy(), "mu": np.zeros(t), "vare": vare, "G": Gval, "pi": pi, "it": 0, "bs": bs}
+    if t > 1 and a.mt_method == "BayesB":
+        state["Gmat"] = np.tile(np.asarray(Gval, dtype=np.float32), (p_loc, 1, 1))      # MCMC_BayesianAlphabet.jl:67-69
     acc = {"sweep_ms": 0.0, "events": 0.0, "launches": 0.0, "bytes": 0.0}
 
     def step():
@@ -250,6 +257,8 @@ def main():
         elif t > 1:
             with np.errstate(divide="ignore"):
                 kw["log_prior_states"] = np.log(s["pi"])
+            if mt_pervar:
+                kw["var_effect_matrix"] = s["Gmat"]
         else:
             kw["pi"] = s["pi"]
         r_new, st = shard.sweep(r.astype(np.float32), **kw)
@@ -267,8 +276,13 @@ def main():
         elif t > 1:
             from scipy.stats import invwishart
             s["pi"] = rng.dirichlet(st["state_counts"] + 1.0)
-            S = scale_g + st["beta_ss"]
-            s["G"] = np.asarray(invwishart.rvs(df=df_g + p_total, scale=(S + S.T) / 2, random_state=rng), dtype=np.float32).reshape(t, t)
+            if mt_pervar:                    # one InverseWishart(df + 1, scale + b_j b_j') draw per marker (variance_components.jl:181-186)
+                from jwas_jl_amd.mcmc import _inverse_wishart_batch
+                Bm = np.stack([eng.get_state(k)[1] for k in range(t)], axis=1).astype(np.float64)
+                s["Gmat"] = _inverse_wishart_batch(rng, df_g + 1.0, scale_g[None] + Bm[:, :, None] * Bm[:, None, :]).astype(np.float32)
+            else:
+                S = scale_g + st["beta_ss"]
+                s["G"] = np.asarray(invwishart.rvs(df=df_g + p_total, scale=(S + S.T) / 2, random_state=rng), dtype=np.float32).reshape(t, t)
             S = scale_e + st["resid_ss"]
             s["vare"] = np.asarray(invwishart.rvs(df=df_e + n, scale=(S + S.T) / 2, random_state=rng), dtype=np.float32).reshape(t, t)
         else:
@@ -331,7 +345,7 @@ def main():
         desc = {
             "config2": f"single-trait BayesC, {n} individuals x {p_total} SNPs, " + ("2-bit packed genotypes (decoded to fp32 on the fly)" if a.storage == "packed2bit" else "fp32 dense genotypes") + (", pi0=0.95 estimated" if a.pi_fixed is None else f", pi={a.pi_fixed} fixed (estimatePi=false)"),
             "config3": f"single-trait BayesR (4-class mixture, gamma 0/.01/.1/1, pi estimated), {n} x {p_total}, fp32 dense genotypes",
-            "config4": f"3-trait BayesC sampler I, {n} x {p_total}, fp32 dense, R and G inverse-Wishart on host, 8-state pi estimated, start: " + ("all-ones state (reference default)" if a.mt_prior == "default" else "0.95 on the null state"),
+            "config4": f"3-trait {'BayesB (one effect covariance per marker, drawn on the host each iteration)' if a.mt_method == 'BayesB' else 'BayesC'} sampler I, {n} x {p_total}, fp32 dense, R and G inverse-Wishart on host, 8-state pi estimated, start: " + ("all-ones state (reference default)" if a.mt_prior == "default" else "0.95 on the null state"),
             "config5shard": f"single-step shaped BayesC, {n} rows ({n_gen} integer-coded + {n - n_gen} real-valued imputed) x {p_arg} SNPs per GPU ({p_total} in total), fp32 dense",
             "refbench": f"reference benchmark shape (jwas_nonblock_benchmark.jl): BayesC, {n} x {p_total}, X~U[0,1) fp32 uncentred, y~N(0,1), Pi=0 fixed, marker variance fixed",
         }[wl]
