@@ -208,6 +208,12 @@ int  jwas_hip_num_blocks(jwas_hip_ctx* ctx, int64_t* nblocks, int32_t* block_siz
  * a free tuning knob too: fast_blocks=<number>, JWAS.jl:293-316).  get/set_gram and num_blocks act on the selected size. */
 int  jwas_hip_add_block_size(jwas_hip_ctx* ctx, int32_t block_size, int32_t gram_mode);
 int  jwas_hip_select_block_size(jwas_hip_ctx* ctx, int32_t block_size);
+/* Explicit, possibly non-uniform block partition: fast_blocks = a vector of block starts (JWAS.jl:298-304,
+ * validate_fast_block_starts JWAS.jl:73-79).  starts: nblocks 0-based first markers, starts[0] = 0, strictly increasing;
+ * block k = [starts[k], starts[k+1]) (the last one ends at p); at most 1024 markers per block and 32768 blocks.  With
+ * jwas_sweep_params.nreps <= 0 every block runs its own size as repetition count (BayesABC.jl:153).  Replaces any resident
+ * block configuration; independent_blocks and a second resident block size are not available on it. */
+int  jwas_hip_setup_blocks_explicit(jwas_hip_ctx* ctx, const int64_t* starts, int64_t nblocks, int32_t gram_mode);
 
 /* ---- chain state ---------------------------------------------------------------------------- */
 /* Declare the sampler so state buffers can be sized: method + ntraits (delta is int32 classes for

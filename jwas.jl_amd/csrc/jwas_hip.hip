@@ -40,6 +40,8 @@ struct jwas_hip_ctx {
     // can pick per sweep: big blocks when few markers change, smaller ones when many do).
     struct BlockSet { int bs; int64_t nblocks; float *gram, *cross, *corr; double* partials; };
     std::vector<BlockSet> sets;
+    std::vector<int64_t> starts;        // explicit block starts (nblocks + 1 entries, last = p), empty = uniform blocks
+    int64_t* d_starts = nullptr;        // ... on the device
     int block_size = 0;
     int64_t nblocks = 0;
     float* xpx = nullptr;
@@ -201,6 +203,7 @@ static void free_blocks(jwas_hip_ctx* c)
     c->sets.clear();
     c->xpx = c->gram = c->cross = c->corr = nullptr; c->partials = nullptr;
     c->block_size = 0; c->nblocks = 0;
+    c->starts.clear(); (void)hipFree(c->d_starts); c->d_starts = nullptr;
     (void)hipFree(c->ipartials); (void)hipFree(c->ev_all); (void)hipFree(c->ev_offs); (void)hipFree(c->idx_all); (void)hipFree(c->delta_all);
     c->ipartials = nullptr; c->ev_all = nullptr; c->ev_offs = nullptr; c->idx_all = nullptr; c->delta_all = nullptr; c->ind_traits = 0;
 }
@@ -598,6 +601,16 @@ int jwas_hip_synth_single_step(jwas_hip_ctx* c, uint64_t seed, int64_t n_genotyp
 }
 
 // ---- precompute ---------------------------------------------------------------------------------
+// first marker / size of block k of the current partition (uniform blocks, or the explicit starts of
+// jwas_hip_setup_blocks_explicit)
+static inline int64_t blk_j0(const jwas_hip_ctx* c, int64_t k) { return c->starts.empty() ? k * c->block_size : c->starts[(size_t)k]; }
+static inline int blk_b(const jwas_hip_ctx* c, int64_t k)
+{
+    if (!c->starts.empty()) return (int)(c->starts[(size_t)k + 1] - c->starts[(size_t)k]);
+    const int64_t j0 = k * c->block_size;
+    return (int)((j0 + c->block_size <= c->p) ? c->block_size : c->p - j0);
+}
+
 static void select_set(jwas_hip_ctx* c, size_t i)
 {
     const auto& b = c->sets[i];
@@ -608,12 +621,12 @@ static void select_set(jwas_hip_ctx* c, size_t i)
     c->ipartials = nullptr; c->ev_all = nullptr; c->ev_offs = nullptr; c->idx_all = nullptr; c->delta_all = nullptr; c->ind_traits = 0;
 }
 
-// Grams and cross-Grams of one block size (x'x must exist).
+// Grams and cross-Grams of one block size (x'x must exist); c->starts non-empty: of the explicit partition (bs >= every block).
 static int build_block_set(jwas_hip_ctx* c, int32_t bs, int32_t gram_mode)
 {
     jwas_hip_ctx::BlockSet B{};
     B.bs = bs;
-    B.nblocks = (c->p + bs - 1) / bs;
+    B.nblocks = c->starts.empty() ? (c->p + bs - 1) / bs : (int64_t)c->starts.size() - 1;
     HIPCHK(c, hipMalloc(&B.gram, sizeof(float) * (size_t)B.nblocks * bs * bs));
     HIPCHK(c, hipMalloc(&B.cross, sizeof(float) * (size_t)B.nblocks * bs * bs));
     HIPCHK(c, hipMalloc(&B.corr, sizeof(float) * 2 * kMaxT * (size_t)bs));
@@ -627,15 +640,16 @@ static int build_block_set(jwas_hip_ctx* c, int32_t bs, int32_t gram_mode)
         const int64_t pc = c->p - y0 * bs;
         float* Cc = B.cross + y0 * (int64_t)bs * bs;
         const int64_t nyc = (y0 + ny < B.nblocks) ? ny : ny - 1;      // cross blocks y0+1 .. (last block has none after it)
-        with_cols(c, y0 * bs, [&](auto Xc) {
+        const int64_t* ds = c->d_starts;                  // explicit starts: absolute marker indices, one launch (<= 32768 blocks)
+        with_cols(c, ds ? 0 : y0 * bs, [&](auto Xc) {
             using CX = decltype(Xc);
             if (gram_mode == JWAS_HIP_GRAM_F64) {
-                hipLaunchKernelGGL((k_gram_f64<CX>), dim3(bs, (unsigned)ny), dim3(256), 0, c->stream, Xc, pc, (int)bs, Gc);
-                if (nyc > 0) hipLaunchKernelGGL((k_cross_f64<CX>), dim3(bs, (unsigned)nyc), dim3(256), 0, c->stream, Xc, pc, (int)bs, Cc);
+                hipLaunchKernelGGL((k_gram_f64<CX>), dim3(bs, (unsigned)ny), dim3(256), 0, c->stream, Xc, pc, (int)bs, Gc, ds);
+                if (nyc > 0) hipLaunchKernelGGL((k_cross_f64<CX>), dim3(bs, (unsigned)nyc), dim3(256), 0, c->stream, Xc, pc, (int)bs, Cc, ds);
             } else {
                 const int nt = bs / 64;
-                hipLaunchKernelGGL((k_gram_mfma<CX>), dim3(nt * (nt + 1) / 2, (unsigned)ny), dim3(256), 0, c->stream, Xc, pc, (int)bs, Gc, 0);
-                if (nyc > 0) hipLaunchKernelGGL((k_gram_mfma<CX>), dim3(nt * nt, (unsigned)nyc), dim3(256), 0, c->stream, Xc, pc, (int)bs, Cc, 1);
+                hipLaunchKernelGGL((k_gram_mfma<CX>), dim3(nt * (nt + 1) / 2, (unsigned)ny), dim3(256), 0, c->stream, Xc, pc, (int)bs, Gc, 0, ds);
+                if (nyc > 0) hipLaunchKernelGGL((k_gram_mfma<CX>), dim3(nt * nt, (unsigned)nyc), dim3(256), 0, c->stream, Xc, pc, (int)bs, Cc, 1, ds);
             }
             return 0;
         });
@@ -673,12 +687,48 @@ int jwas_hip_setup_blocks(jwas_hip_ctx* c, int32_t bs, int32_t gram_mode)
     return JWAS_HIP_OK;
 }
 
+int jwas_hip_setup_blocks_explicit(jwas_hip_ctx* c, const int64_t* starts, int64_t nblocks, int32_t gram_mode)
+{
+    NEED(c, c && starts, JWAS_HIP_EINVAL, "NULL argument");
+    NEED(c, HAVE_STORAGE(c), JWAS_HIP_ESTATE, "no genotype matrix loaded");
+    NEED(c, gram_mode == JWAS_HIP_GRAM_F64 || gram_mode == JWAS_HIP_GRAM_MFMA, JWAS_HIP_EINVAL, "unknown gram_mode %d", gram_mode);
+    NEED(c, nblocks >= 1 && nblocks <= 32768, JWAS_HIP_EUNSUP, "explicit block partitions hold 1..32768 blocks (got %lld)", (long long)nblocks);
+    NEED(c, starts[0] == 0, JWAS_HIP_EINVAL, "block starts must begin with marker 0");
+    int64_t bmax = 0;
+    for (int64_t k = 0; k < nblocks; ++k) {
+        const int64_t e = (k + 1 < nblocks) ? starts[k + 1] : c->p;
+        NEED(c, e > starts[k] && e <= c->p, JWAS_HIP_EINVAL, "block starts must be sorted, unique and below the number of markers");
+        bmax = std::max(bmax, e - starts[k]);
+    }
+    NEED(c, bmax <= 1024, JWAS_HIP_EUNSUP, "a block holds at most 1024 markers (got %lld)", (long long)bmax);
+    int32_t bs = 64;
+    while (bs < bmax) bs *= 2;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    free_blocks(c);
+    c->starts.assign(starts, starts + nblocks);
+    c->starts.push_back(c->p);
+    HIPCHK(c, hipMalloc(&c->d_starts, sizeof(int64_t) * c->starts.size()));
+    HIPCHK(c, hipMemcpy(c->d_starts, c->starts.data(), sizeof(int64_t) * c->starts.size(), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMalloc(&c->xpx, sizeof(float) * c->p));
+    with_cols(c, 0, [&](auto cx) {
+        hipLaunchKernelGGL((k_xpx<decltype(cx)>), dim3((unsigned)c->p), dim3(256), 0, c->stream, cx, c->xpx);
+        return 0;
+    });
+    HIPCHK(c, hipGetLastError());
+    int rc = build_block_set(c, bs, gram_mode);
+    if (rc) return rc;
+    select_set(c, 0);
+    return JWAS_HIP_OK;
+}
+
 int jwas_hip_add_block_size(jwas_hip_ctx* c, int32_t bs, int32_t gram_mode)
 {
     NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
     int rc = check_block_args(c, bs, gram_mode);
     if (rc) return rc;
     NEED(c, !c->sets.empty(), JWAS_HIP_ESTATE, "jwas_hip_setup_blocks has not been called");
+    NEED(c, c->starts.empty(), JWAS_HIP_EUNSUP, "a second block size cannot be added to an explicit block partition");
     for (auto& b : c->sets) NEED(c, b.bs != bs, JWAS_HIP_EINVAL, "block size %d is already resident", bs);
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -728,8 +778,7 @@ static int block_dims(jwas_hip_ctx* c, int64_t blk, int* b)
 {
     NEED(c, c->gram, JWAS_HIP_ESTATE, "jwas_hip_setup_blocks has not been called");
     NEED(c, blk >= 0 && blk < c->nblocks, JWAS_HIP_EINVAL, "block %lld outside [0,%lld)", (long long)blk, (long long)c->nblocks);
-    const int64_t j0 = blk * c->block_size;
-    *b = (int)((j0 + c->block_size <= c->p) ? c->block_size : c->p - j0);
+    *b = blk_b(c, blk);
     return JWAS_HIP_OK;
 }
 
@@ -1180,6 +1229,7 @@ static int sweep_independent(jwas_hip_ctx* c, EventList* out)
     const int t = c->ntraits, bs = c->block_size;
     const int64_t nb = c->nblocks;
     NEED(c, nb <= 65535, JWAS_HIP_EUNSUP, "independent blocks: at most 65535 blocks (got %lld)", (long long)nb);
+    NEED(c, c->starts.empty(), JWAS_HIP_EUNSUP, "independent blocks run on uniform block partitions (not on explicit block starts)");
     const int64_t pstride = (int64_t)t * c->nrg * bs;
     if (!c->ev_all || c->ind_traits != t) {
         (void)hipFree(c->ipartials); (void)hipFree(c->ev_all); (void)hipFree(c->ev_offs); (void)hipFree(c->idx_all); (void)hipFree(c->delta_all);
@@ -1471,8 +1521,8 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
         UpdateArgs U;
         U.r_in = c->r + ((k + 1) & 1) * rstride; U.r_out = c->r + (k & 1) * rstride;
         U.ev = &c->ev[k & 1];
-        U.j0 = (k < nb) ? k * bs : 0;
-        U.b = (k < nb) ? (int)((U.j0 + bs <= c->p) ? bs : c->p - U.j0) : 0;
+        U.j0 = (k < nb) ? blk_j0(c, k) : 0;
+        U.b = (k < nb) ? blk_b(c, k) : 0;
         U.nslices = c->nslices; U.nrg = c->nrg; U.spg = c->spg;
         U.ncg = (U.b > 0 && c->ncg > U.b) ? U.b : c->ncg;
         U.partials = c->partials + (k & 1) * pstride; U.bstride = bs;
@@ -1503,14 +1553,13 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
         if (sb >= 0) {
             S.P = c->dparams;
             S.partials = c->partials + (sb & 1) * pstride; S.nrg = c->nrg; S.bstride = bs;
-            S.j0 = sb * bs; S.b = (int)((S.j0 + bs <= c->p) ? bs : c->p - S.j0); S.p = c->p;
+            S.j0 = blk_j0(c, sb); S.b = blk_b(c, sb); S.p = c->p;
             S.bsz = bs;
             S.xpx = c->xpx;
             S.gram = c->gram + sb * (int64_t)bs * bs;
             // the correction of block sb was written by the sampler of block sb-1 (launch k-1) into corr[sb&1];
             // this sampler writes the one of block sb+1 into corr[(sb+1)&1]
-            const int64_t jn = (sb + 1) * bs;
-            S.b_next = (sb + 1 < nb) ? (int)((jn + bs <= c->p) ? bs : c->p - jn) : 0;
+            S.b_next = (sb + 1 < nb) ? blk_b(c, sb + 1) : 0;
             S.cross_next = c->cross + (sb + 1 < nb ? sb + 1 : sb) * (int64_t)bs * bs;
             S.gram_next = (sb + 1 < nb) ? c->gram + (sb + 1) * (int64_t)bs * bs : nullptr;
             S.corr_in = c->corr + (sb & 1) * (size_t)kMaxT * bs;

@@ -844,12 +844,14 @@ __global__ __launch_bounds__(256) void k_xpx(CX cx, float* __restrict__ xpx)
 // writes row a: G[a][c], c <= a, and mirrors.  Test-size path; O(p*b*n/2) VALU work.
 template <class CX>
 __global__ __launch_bounds__(256) void k_gram_f64(CX cx, int64_t p, int bsize,
-                                                  float* __restrict__ gram)
+                                                  float* __restrict__ gram, const int64_t* __restrict__ starts = nullptr)
 {
+    // starts (nblocks + 1 entries, or NULL): explicit, possibly non-uniform block starts (fast_blocks = a vector of starts,
+    // JWAS.jl:298-304); blocks stay stored at stride bsize^2, bsize >= every block
     const int64_t ld = cx.ld;
     const int64_t blk = blockIdx.y;
-    const int64_t j0 = blk * bsize;
-    const int b = (int)((j0 + bsize <= p) ? bsize : (p - j0));
+    const int64_t j0 = starts ? starts[blk] : blk * bsize;
+    const int b = starts ? (int)(starts[blk + 1] - j0) : (int)((j0 + bsize <= p) ? bsize : (p - j0));
     const int a = blockIdx.x;
     if (a >= b) return;
     float* G = gram + blk * (int64_t)bsize * bsize;   // blocks are stored at stride bsize^2, each b x b packed
@@ -884,16 +886,16 @@ constexpr int kGramChunk = 64;       // rows per fp32 accumulation chunk (then f
 // nt x nt tiles, rows = markers of the previous block, row stride = size of block blk).
 template <class CX>
 __global__ __launch_bounds__(256) void k_gram_mfma(CX cx, int64_t p, int bsize,
-                                                   float* __restrict__ gram, int cross)
+                                                   float* __restrict__ gram, int cross, const int64_t* __restrict__ starts = nullptr)
 {
     const int64_t ld = cx.ld;
     __shared__ __attribute__((aligned(16))) float As[64 * kGramLd];
     __shared__ __attribute__((aligned(16))) float Bs[64 * kGramLd];
     const int64_t blk = cross ? (int64_t)blockIdx.y + 1 : (int64_t)blockIdx.y;
-    const int64_t j0 = blk * bsize;                        // block of the B operand (columns of the output)
-    const int b = (int)((j0 + bsize <= p) ? bsize : (p - j0));
-    const int64_t jA = cross ? j0 - bsize : j0;            // block of the A operand (rows of the output)
-    const int bA = cross ? bsize : b;
+    const int64_t j0 = starts ? starts[blk] : blk * bsize;                        // block of the B operand (columns of the output)
+    const int b = starts ? (int)(starts[blk + 1] - j0) : (int)((j0 + bsize <= p) ? bsize : (p - j0));
+    const int64_t jA = cross ? (starts ? starts[blk - 1] : j0 - bsize) : j0;      // block of the A operand (rows of the output)
+    const int bA = cross ? (int)(j0 - jA) : b;
     int ti = 0, tj = 0;
     if (cross) { const int nt = bsize / 64; ti = blockIdx.x / nt; tj = blockIdx.x % nt; }
     else {   // tile index -> (ti, tj), ti >= tj, over nt = ceil(bsize/64) tiles per side

@@ -2471,13 +2471,14 @@ __global__ __launch_bounds__(kStepThreads) void k_block_step(UpdateArgsT<CX> U, 
 // grid = (bsize, nblocks-1), block = 256; workgroup (a, i) writes row a of cross block i+1.
 template <class CX>
 __global__ __launch_bounds__(256) void k_cross_f64(CX cx, int64_t p, int bsize,
-                                                   float* __restrict__ cross)
+                                                   float* __restrict__ cross, const int64_t* __restrict__ starts = nullptr)
 {
     const int64_t ld = cx.ld;
     const int64_t blk = (int64_t)blockIdx.y + 1;
-    const int64_t j0 = blk * bsize, jp = j0 - bsize;
-    const int b = (int)((j0 + bsize <= p) ? bsize : (p - j0));
+    const int64_t j0 = starts ? starts[blk] : blk * bsize, jp = starts ? starts[blk - 1] : j0 - bsize;
+    const int b = starts ? (int)(starts[blk + 1] - j0) : (int)((j0 + bsize <= p) ? bsize : (p - j0));
     const int a = blockIdx.x;
+    if (a >= (int)(j0 - jp)) return;                   // (explicit starts: the previous block may be shorter than bsize)
     float* C = cross + blk * (int64_t)bsize * bsize;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int c = wave; c < b; c += 4) {

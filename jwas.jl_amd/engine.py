@@ -174,6 +174,19 @@ class HipEngine:
         self._chk(self._L.jwas_hip_setup_blocks(self._h, int(block_size), mode))
         self.block_size = int(block_size)
         self._resident = [int(block_size)]
+        self._explicit_starts = None
+
+    def setup_blocks_explicit(self, starts, gram_mode="mfma"):
+        """Explicit, possibly non-uniform block partition (fast_blocks = a vector of block starts, JWAS.jl:298-304):
+        `starts` = 0-based first marker of every block, starts[0] = 0, strictly increasing, blocks of <= 1024 markers."""
+        mode = {"f64": _lib.GRAM_F64, "mfma": _lib.GRAM_MFMA}[gram_mode]
+        st = np.ascontiguousarray(starts, dtype=np.int64)
+        self._chk(self._L.jwas_hip_setup_blocks_explicit(self._h, st.ctypes.data_as(C.POINTER(C.c_int64)), len(st), mode))
+        nb, bs = C.c_int64(0), C.c_int32(0)
+        self._chk(self._L.jwas_hip_num_blocks(self._h, C.byref(nb), C.byref(bs)))
+        self.block_size = int(bs.value)
+        self._resident = [self.block_size]
+        self._explicit_starts = st.copy()
 
     def add_block_size(self, block_size, gram_mode="mfma"):
         """Make a second block size resident (see jwas_hip_add_block_size); select_block_size switches between sweeps."""
@@ -196,9 +209,14 @@ class HipEngine:
         return nb.value
 
     def block_starts(self):
+        if getattr(self, "_explicit_starts", None) is not None:
+            return self._explicit_starts.copy()
         return np.arange(0, self.p, self.block_size, dtype=np.int64)
 
     def _bsize(self, i):
+        if getattr(self, "_explicit_starts", None) is not None:
+            st = self._explicit_starts
+            return int((st[i + 1] if i + 1 < len(st) else self.p) - st[i])
         j0 = i * self.block_size
         return min(self.block_size, self.p - j0)
 

@@ -391,6 +391,7 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
 
     # ---- fast_blocks parsing (JWAS.jl:293-316); device blocks are powers of two >= 64
     nreps = 1
+    explicit_partition = None                                          # 0-based starts of a non-uniform explicit partition
     if fast_blocks is not False:
         explicit_starts = False
         if fast_blocks is True:
@@ -412,13 +413,20 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
                 raise ValueError("fast_blocks block starts must be within 1:nMarkers.")
             if not all(b_ > a_ for a_, b_ in zip(starts, starts[1:])):
                 raise ValueError("fast_blocks block starts must be sorted and unique.")
-            sizes = [b_ - a_ for a_, b_ in zip(starts, starts[1:])]
-            if len(starts) < 2 or len(set(sizes)) != 1 or (p - starts[-1] + 1) > sizes[0]:
-                raise NotImplementedError("non-uniform explicit fast_blocks start vectors (a repetition count per block) stay on "
-                                          "the reference: device blocks are uniform")
-            # uniform explicit starts = the numeric form, except that the reference does not rescale chain_length here
-            # (JWAS.jl:298-304: block_size = false)
-            want, explicit_starts = sizes[0], True
+            sizes = [b_ - a_ for a_, b_ in zip(starts, starts[1:])] + [p - starts[-1] + 1]
+            if len(starts) < 2:
+                raise ValueError("fast_blocks block size must create at least two block starts.")
+            # the reference does not rescale chain_length for explicit starts (JWAS.jl:298-304: block_size = false)
+            explicit_starts = True
+            if len(set(sizes[:-1])) != 1 or sizes[-1] > sizes[0]:
+                # NON-UNIFORM partition: the device runs exactly these blocks, each with its own size as repetition count
+                # (BayesABC.jl:153); jwas_hip_setup_blocks_explicit
+                if max(sizes) > 1024:
+                    raise NotImplementedError("explicit fast_blocks blocks hold at most 1024 markers on the device")
+                if independent_blocks:
+                    raise NotImplementedError("independent_blocks with non-uniform explicit block starts stays on the reference")
+                explicit_partition = np.asarray(starts, dtype=np.int64) - 1
+            want = max(sizes) if explicit_partition is not None else sizes[0]
         if want < 1:
             raise ValueError("fast_blocks block size must be at least 1.")
         if want >= p:                                                   # range(1, step=want, stop=p) has one start
@@ -433,7 +441,13 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         if not explicit_starts:
             chain_length = int(np.floor(chain_length / want))
         nreps = want
-        print(f"BLOCK SIZE: {want}" + (f" (device blocks of {min(block_size, p)} markers)" if min(block_size, p) != want else ""))
+        if explicit_partition is not None:
+            nreps = 0                                                   # every block its own size (jwas_sweep_params.nreps <= 0)
+            while block_size < want:
+                block_size *= 2
+            print(f"BLOCK STARTS: {len(explicit_partition)} blocks of {min(sizes)}..{max(sizes)} markers")
+        else:
+            print(f"BLOCK SIZE: {want}" + (f" (device blocks of {min(block_size, p)} markers)" if min(block_size, p) != want else ""))
     adaptive = False
     if block_size is None:
         # Device block size.  Sparse priors (few markers change per sweep): big blocks amortise the per-launch cost.
@@ -488,7 +502,9 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         engine.load_output_dense(np.asfortranarray(Mi.genotypes[out_rows, :]))
     if invw is not None:
         engine.set_weights(invw)               # x'R^-1 x, X_b'R^-1 X_b, X_b'R^-1 r on the device (GibbsMats with Rinv)
-    if devres and invw is None and engine.block_size:
+    if explicit_partition is not None:
+        engine.setup_blocks_explicit(explicit_partition, gram_mode)
+    elif devres and invw is None and engine.block_size:
         resident = set(engine.resident_block_sizes())
         if block_size not in resident:
             engine.add_block_size(block_size, gram_mode)

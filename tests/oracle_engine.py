@@ -59,6 +59,16 @@ class OracleEngine:
         self._sets = {self.block_size: (self._bs, self._grams)}
         O.set_weights(None)
 
+    def setup_blocks_explicit(self, starts, gram_mode="f64"):
+        self._w()
+        self._xpx = O.xpx(self.X, self.acc)
+        self._bs = np.ascontiguousarray(starts, dtype=np.int64)
+        self._grams = O.grams_for(self.X, self._bs, self.acc)
+        sizes = np.diff(np.append(self._bs, self.p))
+        self.block_size = int(sizes.max())
+        self._sets = {self.block_size: (self._bs, self._grams)}
+        O.set_weights(None)
+
     def add_block_size(self, block_size, gram_mode="f64"):
         self._w()
         bs = O.block_starts_for(self.p, int(block_size))

@@ -116,6 +116,31 @@ def test_three_trait_bayesb_chain_gpu_vs_oracle(tmp_path, method):
     np.testing.assert_allclose(outs["hip"]["residual variance"]["Estimate"], outs["orc"]["residual variance"]["Estimate"], rtol=1e-3)
 
 
+@pytest.mark.parametrize("method,Pi", [("BayesC", 0.9), ("BayesR", 0.0)])
+def test_runmcmc_non_uniform_fast_blocks_gpu_vs_oracle(tmp_path, method, Pi):
+    """fast_blocks = a vector of block starts with blocks of different sizes (JWAS.jl:298-304): the device runs exactly that
+    partition (jwas_hip_setup_blocks_explicit), every block its own size as repetition count; chain_length is not rescaled."""
+    d = make_dataset(n=300, p=520, ncausal=8, seed=31, center=False)
+    ids = [f"i{i}" for i in range(300)]
+    gdf = pd.DataFrame(d["raw"], columns=[f"m{j}" for j in range(520)])
+    gdf.insert(0, "ID", ids)
+    ph = pd.DataFrame({"ID": ids, "y": d["y"]})
+    # 1-based, as in the reference; blocks of 1..40 markers (a block runs its own size as repetition count, so the chain
+    # makes up to 40 x chain_length passes over a marker: kept short, the comparison is float-for-float)
+    starts = [1, 31, 32, 70, 110, 150, 185, 225, 260, 300, 340, 380, 420, 460, 500]
+    outs = {}
+    for tag, eng in (("orc", OracleEngine("lookahead")), ("hip", None)):
+        geno = api.get_genotypes(gdf, method=method, Pi=Pi, estimatePi=True)
+        model = api.build_model("y = intercept + geno")
+        outs[tag] = api.runMCMC(model, ph, chain_length=10, burnin=2, seed=5, outputEBV=False, fast_blocks=starts,
+                                output_folder=str(tmp_path / tag), _engine=eng, gram_mode="f64")
+        assert outs[tag]["_timing"]["iterations"] == 10
+    eo, eh = outs["orc"]["marker effects geno"], outs["hip"]["marker effects geno"]
+    np.testing.assert_allclose(eh["Estimate"], eo["Estimate"], atol=1e-4)
+    np.testing.assert_allclose(eh["Model_Frequency"], eo["Model_Frequency"], atol=1e-4)
+    np.testing.assert_allclose(outs["hip"]["residual variance"]["Estimate"], outs["orc"]["residual variance"]["Estimate"], rtol=1e-3)
+
+
 def test_runmcmc_gpu_mfma_gram_statistically_equivalent(tmp_path):
     """With the production (fp32 MFMA) Gram the chain may round differently from the oracle; the
     posterior summaries still agree within Monte-Carlo noise of a short chain."""

@@ -817,3 +817,59 @@ def test_mt_bayesb_needs_parked_draws(hip):
     with pytest.raises(J.JwasHipError, match="block_size \\* ntraits <= 2048"):
         hip.sweep(iteration=1, seed=1, vare=np.eye(3, dtype=np.float32), var_effect=np.eye(3, dtype=np.float32),
                   var_effect_matrix=Gm, log_prior_states=np.log(np.full(8, 0.125)))
+
+
+@pytest.mark.parametrize("method,t,nreps,gram", [("BayesC", 1, 0, "f64"), ("BayesC", 1, 1, "mfma"), ("BayesR", 1, 0, "f64"),
+                                                 ("MTBayesC", 2, 0, "f64"), ("MTBayesC_II", 2, 1, "f64"), ("BayesC", 1, 3, "f64")])
+def test_explicit_non_uniform_block_starts_parity(hip, method, t, nreps, gram):
+    """fast_blocks = a vector of block starts (JWAS.jl:298-304): blocks of different sizes (here 1 ... 200 markers, some
+    larger than one 64-marker sub-block, a single-marker block, a short last block), every block running its own size as
+    repetition count when nreps <= 0 (BayesABC.jl:153).  Grams / cross-Grams of the ragged partition and the whole chain
+    against the oracle on the same partition."""
+    import jwas_jl_amd as J
+    data = make_dataset(n=360, p=700, ncausal=10, seed=61)
+    starts = np.array([0, 70, 71, 200, 400, 430, 560, 690], dtype=np.int64)
+    orc = OracleEngine("lookahead")
+    orc.load_dense(data["X"]); orc.setup_blocks_explicit(starts); orc.init_state(method, t)
+    hip.load_dense(data["X"]); hip.setup_blocks_explicit(starts, gram); hip.init_state(method, t)
+    assert hip.block_size == 256 and hip.nblocks == len(starts)
+    sizes = np.diff(np.append(starts, 700))
+    for k in (0, 1, 3, 7):
+        g = hip.gram(k)
+        assert g.shape == (sizes[k], sizes[k])
+        np.testing.assert_allclose(g, orc._grams[int((sizes[:k] ** 2).sum()):int((sizes[:k + 1] ** 2).sum())].reshape(sizes[k], sizes[k]),
+                                   rtol=(1e-6 if gram == "f64" else 2e-5), atol=(1e-6 if gram == "f64" else 2e-3))
+    y = data["y"] - data["y"].mean()
+    rng = np.random.default_rng(6)
+    for k in range(t):
+        yk = ((1 + 0.3 * k) * y + 0.1 * k * rng.standard_normal(len(y))).astype(np.float32)
+        orc.set_residual(yk, k); hip.set_residual(yk, k)
+        if t > 1:
+            ones = np.ones(700, dtype=np.float32)
+            orc.set_state(k, delta=ones); hip.set_state(k, delta=ones)
+    vare1, varg1 = _hyper(data)
+    if method == "BayesR":
+        kw = dict(vare=vare1, var_effect=np.float32(varg1 * 5), pi_classes=np.array([0.9, 0.05, 0.03, 0.02]))
+    elif t == 1:
+        kw = dict(vare=vare1, var_effect=varg1, pi=0.9)
+    else:
+        kw = dict(vare=(np.eye(t) * 0.5 + 0.1).astype(np.float32), var_effect=(np.eye(t) * 0.004).astype(np.float32),
+                  log_prior_states=np.log(np.array([0.7, 0.1, 0.1, 0.1])))
+    for it in range(1, 9):
+        so = orc.sweep(iteration=it, seed=9, nreps=nreps, **kw)
+        sh = hip.sweep(iteration=it, seed=9, nreps=nreps, **kw)
+        assert so["n_events"] == sh["n_events"], f"iteration {it}"
+    tol = 5e-6 if gram == "f64" else 5e-4
+    for k in range(t):
+        if gram == "f64":
+            _compare_state(orc, hip, k, atol=tol)
+        else:
+            np.testing.assert_allclose(hip.get_state(k)[0], orc.get_state(k)[0], atol=tol)
+    with pytest.raises(J.JwasHipError, match="uniform block partitions"):
+        hip.sweep(iteration=1, seed=1, independent_blocks=True, **kw)
+    with pytest.raises(J.JwasHipError, match="explicit block partition"):
+        hip.add_block_size(512, "f64")
+    with pytest.raises(J.JwasHipError, match="sorted, unique"):
+        hip.setup_blocks_explicit(np.array([0, 50, 50, 100]), "f64")
+    with pytest.raises(J.JwasHipError, match="at most 1024 markers"):
+        hip.load_dense(np.zeros((8, 1300), dtype=np.float32)); hip.setup_blocks_explicit(np.array([0, 1100]), "f64")

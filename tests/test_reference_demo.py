@@ -363,8 +363,10 @@ def test_explicit_block_start_validation(tmp_path, bad, msg):
         api.runMCMC(model, _phenotypes(), chain_length=6, output_folder=str(tmp_path / "x"), fast_blocks=bad, _engine=OracleEngine("block"))
     geno = api.get_genotypes(GENO, 1.0, separator=",", method="BayesC")
     model = api.build_model("y1 = intercept + geno", 1.0)
-    with pytest.raises(NotImplementedError, match="non-uniform explicit fast_blocks"):
-        api.runMCMC(model, _phenotypes(), chain_length=6, output_folder=str(tmp_path / "y"), fast_blocks=[1, 2, 4], _engine=OracleEngine("block"))
+    # a NON-uniform start vector runs as given: blocks of 1, 2 and 2 markers, each with its own size as repetition count
+    out = api.runMCMC(model, _phenotypes(), chain_length=6, output_folder=str(tmp_path / "y"), fast_blocks=[1, 2, 4], seed=3,
+                      _engine=OracleEngine("block"))
+    assert out["_timing"]["iterations"] == 6 and np.isfinite(out["marker effects geno"]["Estimate"]).all()
 
 
 @pytest.mark.parametrize("method", ["BayesC", "BayesR"])
