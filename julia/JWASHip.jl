@@ -9,7 +9,7 @@
 module JWASHip
 
 export HipBackend, HipSweepParams, HipSweepStats, hip_sweep!, hip_sweep_sharded!, hip_comm_unique_id, hip_comm_init!,
-       hip_set_residual!, hip_get_residual!, hip_accumulate!, hip_posterior, hip_mul_alpha, JWAS_HIP_BAYESC,
+       hip_setup_blocks!, hip_set_residual!, hip_get_residual!, hip_accumulate!, hip_posterior, hip_mul_alpha, JWAS_HIP_BAYESC,
        JWAS_HIP_BAYESB, JWAS_HIP_BAYESR, JWAS_HIP_MTBAYESC1, JWAS_HIP_MTBAYESC2, JWAS_HIP_MEGABAYESC, JWAS_HIP_MTBAYESB1
 
 const LIBJWAS_HIP = get(ENV, "JWAS_HIP_LIB", "libjwas_hip.so")
@@ -86,6 +86,14 @@ function HipBackend(X::Matrix{Float32}; device::Integer=0, block_size::Integer=5
     hip_check(b.ctx, ccall((:jwas_hip_setup_blocks, LIBJWAS_HIP), Cint, (Ptr{Cvoid}, Int32, Int32),
                            b.ctx, block_size, JWAS_HIP_GRAM_MFMA))
     hip_check(b.ctx, ccall((:jwas_hip_init_state, LIBJWAS_HIP), Cint, (Ptr{Cvoid}, Int32, Int32), b.ctx, method, ntraits))
+    return b
+end
+
+"fast_blocks = a vector of 1-based block starts, possibly non-uniform (JWAS.jl:298-304): the device runs exactly that partition."
+function hip_setup_blocks!(b::HipBackend, starts::AbstractVector{<:Integer})
+    s0 = Int64.(starts) .- 1
+    hip_check(b.ctx, ccall((:jwas_hip_setup_blocks_explicit, LIBJWAS_HIP), Cint, (Ptr{Cvoid}, Ptr{Int64}, Int64, Int32),
+                           b.ctx, s0, length(s0), JWAS_HIP_GRAM_MFMA))
     return b
 end
 
