@@ -631,6 +631,13 @@ static int build_block_set(jwas_hip_ctx* c, int32_t bs, int32_t gram_mode)
     HIPCHK(c, hipMalloc(&B.cross, sizeof(float) * (size_t)B.nblocks * bs * bs));
     HIPCHK(c, hipMalloc(&B.corr, sizeof(float) * 2 * kMaxT * (size_t)bs));
     HIPCHK(c, hipMalloc(&B.partials, sizeof(double) * 2 * (size_t)bs * c->nrg * kMaxT));   // ping-pong
+#ifdef JWAS_HIP_DEV_KNOBS
+    if (std::getenv("JWAS_HIP_DEBUG_POISON")) {          // development builds: NaN-fill what the setup kernels do not write
+        HIPCHK(c, hipMemset(B.gram, 0xFF, sizeof(float) * (size_t)B.nblocks * bs * bs));
+        HIPCHK(c, hipMemset(B.cross, 0xFF, sizeof(float) * (size_t)B.nblocks * bs * bs));
+        HIPCHK(c, hipMemset(B.partials, 0xFF, sizeof(double) * 2 * (size_t)bs * c->nrg * kMaxT));
+    }
+#endif
     c->sets.push_back(B);
     // Gram launches are chunked over blocks so grid.y stays below 65536
     const int64_t ychunk = 32768;

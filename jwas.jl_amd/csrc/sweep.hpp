@@ -941,7 +941,11 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
     const long long tk2 = clock64();
     // (a block without any candidate -- about a third of them with a sparse prior -- has nothing to stage or to walk)
     long long tss[3] = {tk2, tk2, tk2};
-    int nstaged = prestage ? b : (first_sub >= 16 ? 0 : stage_rows(smem, SM, A, cand, tss));
+    // (a block without any candidate has nothing to stage or to walk -- in a SINGLE pass.  With within-block repetitions a
+    // later repetition draws anew and may move a marker that was no candidate at entry: stage_rows must then have marked
+    // every marker "not staged" (slot -1), or the winner's row would be looked up through a stale slot.)
+    const bool single_pass_st = (P->nreps > 0 ? P->nreps : b) == 1;
+    int nstaged = prestage ? b : ((first_sub >= 16 && single_pass_st) ? 0 : stage_rows(smem, SM, A, cand, tss));
     const bool cross_lds = prestage && SM.has_cross;
     float4 corr_mine{0.f, 0.f, 0.f, 0.f};
     if (stream_corr) {

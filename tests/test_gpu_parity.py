@@ -873,3 +873,31 @@ def test_explicit_non_uniform_block_starts_parity(hip, method, t, nreps, gram):
         hip.setup_blocks_explicit(np.array([0, 50, 50, 100]), "f64")
     with pytest.raises(J.JwasHipError, match="at most 1024 markers"):
         hip.load_dense(np.zeros((8, 1300), dtype=np.float32)); hip.setup_blocks_explicit(np.array([0, 1100]), "f64")
+
+
+@pytest.mark.parametrize("method", ["BayesC", "BayesR"])
+def test_block_repetitions_with_blocks_that_start_without_candidates(hip, method):
+    """Within-block repetitions on a sparse chain: most 64-marker blocks hold no candidate at entry (the single-pass sampler
+    skips such blocks entirely), but a later repetition draws anew and may move a marker -- whose Gram row must then be
+    fetched, not looked up through a slot left over from an earlier block.  Many blocks, many repetitions, several block
+    sizes alternating in one process (stale LDS from the previous configuration is the hazard)."""
+    data = make_dataset(n=300, p=64 * 14 + 9, ncausal=4, seed=71)
+    vare, varg = _hyper(data)
+    for bs, nreps in ((256, 1), (64, 12), (128, 0), (64, 24)):
+        orc, hip = _pair(hip, data, bs, method)
+        r0 = data["y"] - data["y"].mean()
+        orc.set_residual(r0); hip.set_residual(r0)
+        if method == "BayesR":
+            kw = dict(var_effect=np.float32(20 * varg), pi_classes=np.array([0.992, 0.004, 0.003, 0.001]))
+            for e in (orc, hip):
+                e.set_state(delta=np.ones(e.p, dtype=np.int32))
+        else:
+            kw = dict(var_effect=np.float32(8 * varg), pi=0.992)
+        for it in range(1, 5):
+            so = orc.sweep(iteration=it, seed=17, vare=vare, nreps=nreps, **kw)
+            sh = hip.sweep(iteration=it, seed=17, vare=vare, nreps=nreps, **kw)
+            assert so["n_events"] == sh["n_events"], f"bs={bs} nreps={nreps} iteration {it}"
+        ao, _, do = orc.get_state()
+        ah, _, dh = hip.get_state()
+        assert np.array_equal(do, dh)
+        np.testing.assert_allclose(ah, ao, rtol=0, atol=5e-6)
