@@ -2453,6 +2453,12 @@ __global__ __launch_bounds__(kStepThreads) void k_block_step(UpdateArgsT<CX> U, 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (blockIdx.x == 0) {
         if (!do_sample) return;
+#ifdef JWAS_HIP_POISON_LDS
+        // development builds (-DJWAS_HIP_POISON_LDS=0x11111111): the sampler starts from a known-bad LDS image instead of
+        // whatever the previous kernel left there -- a read of something this launch did not write shows up as a parity failure
+        for (int i = threadIdx.x; i < 150000 / 4; i += kStepThreads) reinterpret_cast<unsigned*>(smem)[i] = (unsigned)(JWAS_HIP_POISON_LDS);
+        __syncthreads();
+#endif
         if constexpr (is_mt_method(METHOD)) sampler_role_mt<METHOD, NT>(smem, S);
         else sampler_role_st<METHOD>(smem, S);
         return;
