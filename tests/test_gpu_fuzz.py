@@ -67,3 +67,88 @@ def test_ragged_shapes(hip, n, p, bs, method):
         np.testing.assert_allclose(ah, ao, rtol=0, atol=1e-5)
         np.testing.assert_allclose(hip.get_residual(k), orc.get_residual(k), rtol=0, atol=5e-5)
     np.testing.assert_allclose(sh["resid_ss"], so["resid_ss"], rtol=1e-5, atol=1e-6)
+
+
+def _random_case(seed):
+    """One random configuration of the sweep: shape, block partition (uniform size or explicit ragged starts), sampler,
+    prior sparsity (dense ... very sparse), repetitions (1, a few, 0 = block size), traits."""
+    rng = np.random.default_rng(seed)
+    method = rng.choice(["BayesC", "BayesC", "BayesR", "BayesB", "MTBayesC", "MTBayesC_II", "MegaBayesC", "MTBayesB"])
+    t = 1 if method in ("BayesC", "BayesR", "BayesB") else int(rng.integers(2, 4))
+    n = int(rng.integers(40, 700))
+    p = int(rng.integers(30, 900))
+    explicit = rng.random() < 0.4
+    if explicit:
+        cuts = np.unique(rng.integers(1, p, size=int(rng.integers(1, 12))))
+        starts = np.concatenate([[0], cuts]).astype(np.int64)
+        while np.diff(np.append(starts, p)).max() > 300:                # keep blocks small enough for the oracle's patience
+            big = int(np.argmax(np.diff(np.append(starts, p))))
+            starts = np.sort(np.append(starts, starts[big] + np.diff(np.append(starts, p))[big] // 2))
+        part = ("explicit", starts)
+    else:
+        part = ("uniform", int(rng.choice([64, 128, 256, 512])))
+    nreps = int(rng.choice([1, 1, 1, 2, 5, 0]))
+    if method == "MTBayesB" and not explicit and part[1] * t > 2048:
+        part = ("uniform", 256)
+    sparsity = float(rng.choice([0.0, 0.3, 0.9, 0.99]))
+    return dict(method=method, t=t, n=n, p=p, part=part, nreps=nreps, sparsity=sparsity, seed=int(seed))
+
+
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("JWAS_FUZZ_CASES", "40")))))     # JWAS_FUZZ_CASES=1000 for a long run
+def test_random_configurations_against_the_oracle(hip, seed):
+    """Differential fuzzing of the whole configuration space (a seeded, reproducible sample of it): whatever the shape,
+    partition, sampler, prior and repetition count, the device chain equals the oracle's."""
+    c = _random_case(1000 + seed)
+    rng = np.random.default_rng(c["seed"])
+    method, t, n, p = c["method"], c["t"], c["n"], c["p"]
+    d = make_dataset(n=n, p=p, ncausal=min(6, p), seed=c["seed"] % 1000)
+    y = (d["y"] - d["y"].mean()).astype(np.float32)
+    orc = OracleEngine("lookahead")
+    for e in (orc, hip):
+        e.load_dense(d["X"])
+        if c["part"][0] == "explicit":
+            e.setup_blocks_explicit(c["part"][1], "f64")
+        else:
+            e.setup_blocks(c["part"][1], "f64")
+        e.init_state(method, t)
+        for k in range(t):
+            e.set_residual(((1 + 0.3 * k) * y).astype(np.float32), k)
+        if method == "BayesR":
+            e.set_state(0, delta=np.ones(p, dtype=np.int32))
+        elif t > 1:
+            for k in range(t):
+                e.set_state(k, delta=np.ones(p, dtype=np.float32))
+    v = np.float32(max(float(np.var(y)), 0.1))
+    g = np.float32(0.02)
+    sp = c["sparsity"]
+    A = rng.standard_normal((t, t)); Rm = ((A @ A.T / t + np.eye(t)) * v).astype(np.float32)
+    Bm = rng.standard_normal((t, t)); Gm = ((Bm @ Bm.T / t + np.eye(t)) * g).astype(np.float32)
+    if method == "BayesC":
+        kw = dict(vare=v, var_effect=g, pi=sp)
+    elif method == "BayesB":
+        kw = dict(vare=v, var_effect=g, var_effect_vec=rng.uniform(0.005, 0.04, p).astype(np.float32), pi=sp)
+    elif method == "BayesR":
+        rest = np.array([0.5, 0.3, 0.2]) * (1 - sp)
+        kw = dict(vare=v, var_effect=np.float32(0.1), pi_classes=np.concatenate([[sp], rest]))
+    elif method == "MegaBayesC":
+        kw = dict(vare=np.diag(np.diag(Rm)), var_effect=np.diag(np.diag(Gm)), pi=np.full(t, sp))
+    else:
+        prior = np.full(1 << t, (1 - sp) / ((1 << t) - 1)); prior[0] = sp
+        if sp == 0.0:
+            prior = np.full(1 << t, 1e-3); prior[-1] = 1.0
+        prior /= prior.sum()
+        kw = dict(vare=Rm, var_effect=Gm, log_prior_states=np.log(prior))
+        if method == "MTBayesB":
+            Wm = rng.standard_normal((p, t, t))
+            kw["var_effect_matrix"] = ((Wm @ Wm.transpose(0, 2, 1) / t + np.eye(t)) * (g * np.exp(rng.uniform(-1, 1, p)))[:, None, None]).astype(np.float32)
+    nreps = c["nreps"] if method != "MTBayesC_II" or c["nreps"] in (1, 2) else 1
+    for it in range(1, 5):
+        so = orc.sweep(iteration=it, seed=c["seed"], nreps=nreps, **kw)
+        sh = hip.sweep(iteration=it, seed=c["seed"], nreps=nreps, **kw)
+        assert so["n_events"] == sh["n_events"], f"{c} iteration {it}"
+    for k in range(t):
+        ao, bo, do = orc.get_state(k)
+        ah, bh, dh = hip.get_state(k)
+        assert np.array_equal(do, dh), f"{c}"
+        np.testing.assert_allclose(ah, ao, rtol=0, atol=2e-5, err_msg=str(c))
+        np.testing.assert_allclose(hip.get_residual(k), orc.get_residual(k), rtol=0, atol=1e-4, err_msg=str(c))
