@@ -91,21 +91,30 @@ def _random_case(seed):
     if method == "MTBayesB" and not explicit and part[1] * t > 2048:
         part = ("uniform", 256)
     sparsity = float(rng.choice([0.0, 0.3, 0.9, 0.99]))
-    return dict(method=method, t=t, n=n, p=p, part=part, nreps=nreps, sparsity=sparsity, seed=int(seed))
+    weights = rng.random() < 0.25                                       # heterogeneous residuals (x'R^-1 x, X_b'R^-1 r)
+    indep = (not explicit) and method != "MTBayesB" and rng.random() < 0.2      # independent_blocks=true
+    marker_prior = method in ("BayesC", "BayesR") and rng.random() < 0.25       # per-marker pi (annotation priors)
+    coop = rng.random() < 0.3                                           # cooperative dense apply forced on
+    return dict(method=method, t=t, n=n, p=p, part=part, nreps=nreps, sparsity=sparsity, seed=int(seed),
+                weights=weights, indep=indep, marker_prior=marker_prior, coop=coop)
 
 
 @pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("JWAS_FUZZ_CASES", "40")))))     # JWAS_FUZZ_CASES=1000 for a long run
-def test_random_configurations_against_the_oracle(hip, seed):
+def test_random_configurations_against_the_oracle(hip, seed, monkeypatch):
     """Differential fuzzing of the whole configuration space (a seeded, reproducible sample of it): whatever the shape,
-    partition, sampler, prior and repetition count, the device chain equals the oracle's."""
+    partition, sampler, prior, repetition count, residual weights, independent blocks, per-marker priors and update-role
+    variant, the device chain equals the oracle's."""
     c = _random_case(1000 + seed)
+    monkeypatch.setenv("JWAS_HIP_COOP_APPLY", "1" if c["coop"] else "0")
     rng = np.random.default_rng(c["seed"])
     method, t, n, p = c["method"], c["t"], c["n"], c["p"]
     d = make_dataset(n=n, p=p, ncausal=min(6, p), seed=c["seed"] % 1000)
     y = (d["y"] - d["y"].mean()).astype(np.float32)
     orc = OracleEngine("lookahead")
+    w = rng.uniform(0.3, 3.0, n).astype(np.float32) if c["weights"] else None
     for e in (orc, hip):
         e.load_dense(d["X"])
+        e.set_weights(w)
         if c["part"][0] == "explicit":
             e.setup_blocks_explicit(c["part"][1], "f64")
         else:
@@ -125,11 +134,16 @@ def test_random_configurations_against_the_oracle(hip, seed):
     Bm = rng.standard_normal((t, t)); Gm = ((Bm @ Bm.T / t + np.eye(t)) * g).astype(np.float32)
     if method == "BayesC":
         kw = dict(vare=v, var_effect=g, pi=sp)
+        if c["marker_prior"]:
+            kw = dict(vare=v, var_effect=g, pi_vec=np.clip(sp + rng.uniform(-0.2, 0.2, p), 0.0, 0.999))
     elif method == "BayesB":
         kw = dict(vare=v, var_effect=g, var_effect_vec=rng.uniform(0.005, 0.04, p).astype(np.float32), pi=sp)
     elif method == "BayesR":
         rest = np.array([0.5, 0.3, 0.2]) * (1 - sp)
         kw = dict(vare=v, var_effect=np.float32(0.1), pi_classes=np.concatenate([[sp], rest]))
+        if c["marker_prior"]:
+            pm = rng.dirichlet(np.ones(4), size=p) * 0.5 + 0.5 * kw["pi_classes"]
+            kw["pi_matrix"] = pm / pm.sum(axis=1, keepdims=True)
     elif method == "MegaBayesC":
         kw = dict(vare=np.diag(np.diag(Rm)), var_effect=np.diag(np.diag(Gm)), pi=np.full(t, sp))
     else:
@@ -142,6 +156,8 @@ def test_random_configurations_against_the_oracle(hip, seed):
             Wm = rng.standard_normal((p, t, t))
             kw["var_effect_matrix"] = ((Wm @ Wm.transpose(0, 2, 1) / t + np.eye(t)) * (g * np.exp(rng.uniform(-1, 1, p)))[:, None, None]).astype(np.float32)
     nreps = c["nreps"] if method != "MTBayesC_II" or c["nreps"] in (1, 2) else 1
+    if c["indep"]:
+        kw["independent_blocks"] = True
     for it in range(1, 5):
         so = orc.sweep(iteration=it, seed=c["seed"], nreps=nreps, **kw)
         sh = hip.sweep(iteration=it, seed=c["seed"], nreps=nreps, **kw)
