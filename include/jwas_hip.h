@@ -289,6 +289,17 @@ int  jwas_hip_comm_unique_id(void* id_out_128_bytes);
 int  jwas_hip_comm_init(jwas_hip_ctx* ctx, const void* unique_id_128_bytes, int32_t rank, int32_t world);
 int  jwas_hip_comm_destroy(jwas_hip_ctx* ctx);
 int  jwas_hip_sweep_sharded(jwas_hip_ctx* ctx, const jwas_sweep_params* params, jwas_sweep_stats* stats);
+/* ---- exact ROW shards (SURVEY 8e "exact alternative"): every rank holds a slice of the individuals and ALL markers.
+ * jwas_hip_comm_row_shards(ctx, 1) after jwas_hip_comm_init and BEFORE jwas_hip_setup_blocks: x'x, the block Grams and the
+ * cross-Grams are summed over the ranks at setup, every block's partial right-hand side X_b'r is summed over the ranks
+ * (one small all-reduce per block launch, on the context's stream) before its sampler runs -- replicated, on identical
+ * inputs, so every rank holds the same effects and its own slice of the residual.  jwas_hip_sweep then IS the exact chain
+ * of the pooled data (the sums are formed in a different order than on one GPU, nothing else); r'r / sum r come back summed
+ * over the ranks.  Needs the same number of 256-row groups on every rank (pad with zero rows) and the same markers.
+ * jwas_hip_comm_init_loopback: test transport -- the ranks are contexts of ONE process driven by different host threads,
+ * the exchange goes through host memory (slot 0..3 = one group of ranks). */
+int  jwas_hip_comm_row_shards(jwas_hip_ctx* ctx, int32_t enable);
+int  jwas_hip_comm_init_loopback(jwas_hip_ctx* ctx, int32_t slot, int32_t rank, int32_t world);
 
 /* ---- posterior accumulators (output.jl:568-577) ---------------------------------------------- */
 int  jwas_hip_accumulate(jwas_hip_ctx* ctx, double nsamples);

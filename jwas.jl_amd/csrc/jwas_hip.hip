@@ -12,6 +12,9 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <mutex>
+#include <condition_variable>
+#include <chrono>
 
 using namespace jw;
 
@@ -94,9 +97,15 @@ struct jwas_hip_ctx {
     int comm_rank = 0, comm_world = 1;
     float* r_snap = nullptr;            // [kMaxT][ld] residual snapshot of the running sweep
     double* shard_buf = nullptr;        // [kMaxT*ld + kShardStats] delta r (fp64) + packed marker statistics: ONE all-reduce
+    // exact ROW shards (jwas_hip_comm_row_shards): this context holds a slice of the individuals and ALL markers; x'x, the
+    // Grams and every block's partial RHS are summed over the ranks, the sampler then runs replicated
+    bool row_mode = false;
+    int loop_slot = -1;                 // >= 0: loopback transport (ranks = contexts of one process on different host threads)
+    double* row_buf = nullptr;          // [32] small exchanges
 };
 
 static constexpr int kStatGrid = 128;
+static int row_allreduce(jwas_hip_ctx* c, void* dev, size_t count, bool f64);      // exact row shards: sum over the ranks
 static thread_local std::string g_create_error;
 
 static int fail(jwas_hip_ctx* ctx, int code, const char* fmt, ...)
@@ -288,7 +297,7 @@ static int alloc_storage(jwas_hip_ctx* c, int64_t n, int64_t p, bool packed = fa
     NEED(c, p < (1ll << 31), JWAS_HIP_EUNSUP, "p=%lld exceeds the 2^31 marker limit of one context", (long long)p);
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->comm) (void)jwas_hip_comm_destroy(c);                  // (its buffers are sized by the matrix)
+    if (c->comm || c->loop_slot >= 0) (void)jwas_hip_comm_destroy(c);     // (its buffers are sized by the matrix)
     free_state(c); free_blocks(c); free_storage(c);
     c->method = -1; c->block_size = 0; c->nblocks = 0;
     c->n = n; c->p = p; c->ld = round_up(n, kSliceRows);
@@ -662,6 +671,10 @@ static int build_block_set(jwas_hip_ctx* c, int32_t bs, int32_t gram_mode)
         });
         HIPCHK(c, hipGetLastError());
     }
+    if (c->row_mode) {      // exact row shards: X_b'X_b and the cross-Grams are sums over the ranks' individuals (fp32, once)
+        int rc = row_allreduce(c, B.gram, (size_t)B.nblocks * bs * bs, false); if (rc) return rc;
+        rc = row_allreduce(c, B.cross, (size_t)B.nblocks * bs * bs, false); if (rc) return rc;
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return JWAS_HIP_OK;
 }
@@ -688,6 +701,7 @@ int jwas_hip_setup_blocks(jwas_hip_ctx* c, int32_t bs, int32_t gram_mode)
         return 0;
     });
     HIPCHK(c, hipGetLastError());
+    if (c->row_mode) { rc = row_allreduce(c, c->xpx, (size_t)c->p, false); if (rc) return rc; }     // x'x over all individuals
     rc = build_block_set(c, bs, gram_mode);
     if (rc) return rc;
     select_set(c, 0);
@@ -723,6 +737,7 @@ int jwas_hip_setup_blocks_explicit(jwas_hip_ctx* c, const int64_t* starts, int64
         return 0;
     });
     HIPCHK(c, hipGetLastError());
+    if (c->row_mode) { int rr = row_allreduce(c, c->xpx, (size_t)c->p, false); if (rr) return rr; }
     int rc = build_block_set(c, bs, gram_mode);
     if (rc) return rc;
     select_set(c, 0);
@@ -1237,6 +1252,7 @@ static int sweep_independent(jwas_hip_ctx* c, EventList* out)
     const int64_t nb = c->nblocks;
     NEED(c, nb <= 65535, JWAS_HIP_EUNSUP, "independent blocks: at most 65535 blocks (got %lld)", (long long)nb);
     NEED(c, c->starts.empty(), JWAS_HIP_EUNSUP, "independent blocks run on uniform block partitions (not on explicit block starts)");
+    NEED(c, !c->row_mode, JWAS_HIP_EUNSUP, "independent blocks are not available on row shards");
     const int64_t pstride = (int64_t)t * c->nrg * bs;
     if (!c->ev_all || c->ind_traits != t) {
         (void)hipFree(c->ipartials); (void)hipFree(c->ev_all); (void)hipFree(c->ev_offs); (void)hipFree(c->idx_all); (void)hipFree(c->delta_all);
@@ -1323,8 +1339,67 @@ struct Rccl {
     }
 };
 Rccl g_rccl;
-constexpr int kNcclFloat64 = 8, kNcclSum = 0;      // ncclDataType_t::ncclDouble, ncclRedOp_t::ncclSum (rccl.h)
+constexpr int kNcclFloat64 = 8, kNcclFloat32 = 7, kNcclSum = 0;      // ncclDataType_t, ncclRedOp_t::ncclSum (rccl.h)
+
+// Loopback transport (tests, single-GPU development): the "ranks" are contexts of ONE process driven by different host
+// threads; an all-reduce goes through host memory, summed in rank order.  Same call sites as the RCCL one.
+struct Loopback {
+    std::mutex m;
+    std::condition_variable cv;
+    int world = 0, arrived = 0;
+    uint64_t gen = 0;
+    std::vector<std::vector<double>> part;      // per rank
+    std::vector<double> sum;
+};
+Loopback g_loop[4];
 }  // namespace
+
+// Sum `count` elements (fp64 or fp32) over the ranks, in place, on the context's stream (RCCL) or through the host
+// (loopback).  Every rank receives the same bits.
+static int row_allreduce(jwas_hip_ctx* c, void* dev, size_t count, bool f64)
+{
+    if (c->loop_slot >= 0) {
+        Loopback& L = g_loop[c->loop_slot];
+        std::vector<double> mine(count);
+        if (f64) { HIPCHK(c, hipMemcpyAsync(mine.data(), dev, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); }
+        else {
+            std::vector<float> tmp(count);
+            HIPCHK(c, hipMemcpyAsync(tmp.data(), dev, sizeof(float) * count, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            for (size_t i = 0; i < count; ++i) mine[i] = tmp[i];
+        }
+        std::vector<double> total;
+        {
+            std::unique_lock<std::mutex> lk(L.m);
+            const uint64_t g0 = L.gen;
+            L.part[(size_t)c->comm_rank] = std::move(mine);
+            if (++L.arrived == L.world) {
+                L.sum.assign(count, 0.0);
+                for (int r = 0; r < L.world; ++r) {
+                    if (L.part[(size_t)r].size() != count) { L.arrived = 0; ++L.gen; L.cv.notify_all(); return fail(c, JWAS_HIP_ESTATE, "loopback all-reduce: the ranks disagree on the element count"); }
+                    if (f64) for (size_t i = 0; i < count; ++i) L.sum[i] += L.part[(size_t)r][i];
+                    else for (size_t i = 0; i < count; ++i) L.sum[i] = (double)((float)L.sum[i] + (float)L.part[(size_t)r][i]);      // fp32 sums, rank order
+                }
+                L.arrived = 0; ++L.gen;
+                L.cv.notify_all();
+            } else if (!L.cv.wait_for(lk, std::chrono::seconds(60), [&] { return L.gen != g0; }))
+                return fail(c, JWAS_HIP_ESTATE, "loopback all-reduce: the other rank did not arrive within 60 s");
+            total = L.sum;
+        }
+        if (total.size() != count) return fail(c, JWAS_HIP_ESTATE, "loopback all-reduce: the ranks disagree on the element count");
+        if (f64) HIPCHK(c, hipMemcpy(dev, total.data(), sizeof(double) * count, hipMemcpyHostToDevice));
+        else {
+            std::vector<float> tmp(count);
+            for (size_t i = 0; i < count; ++i) tmp[i] = (float)total[i];
+            HIPCHK(c, hipMemcpy(dev, tmp.data(), sizeof(float) * count, hipMemcpyHostToDevice));
+        }
+        return JWAS_HIP_OK;
+    }
+    NEED(c, c->comm, JWAS_HIP_ESTATE, "no communicator attached");
+    const int r = g_rccl.AllReduce(dev, dev, count, f64 ? kNcclFloat64 : kNcclFloat32, kNcclSum, c->comm, c->stream);
+    NEED(c, r == 0, JWAS_HIP_EHIP, "ncclAllReduce: %s", g_rccl.GetErrorString(r));
+    return JWAS_HIP_OK;
+}
 
 // buf[k*ld + i] = fl64(r_local) - fl64(r_snapshot) for the t residual vectors; the last workgroup adds this rank's marker
 // statistics (the k_marker_stats partials summed in fixed order) and its number of effect changes behind them.
@@ -1583,6 +1658,10 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
             HIPCHK(c, hipEventRecord(c->kev[2 * ntimed], c->stream));
         }
         HIPCHK(c, launch_step_any(c, U, S, sb >= 0));
+        if (c->row_mode && U.b > 0) {          // the block's partial RHS summed over the ranks' individuals, before its sampler runs
+            int rc = row_allreduce(c, U.partials, (size_t)t * c->nrg * bs, true);
+            if (rc) return rc;
+        }
         if (timed) {
             HIPCHK(c, hipEventRecord(c->kev[2 * ntimed + 1], c->stream));
             ++ntimed;
@@ -1652,6 +1731,18 @@ static int sweep_collect(jwas_hip_ctx* c, jwas_sweep_stats* S, size_t ntimed, do
         S->bayesr_ssq += v[40]; S->bayesr_nnz += v[41];
         for (int q = 0; q < (1 << t) && q < kMaxStates; ++q) S->state_counts[q] += v[42 + q];
     }
+    if (c->row_mode) {       // r'r and sum(r) are sums over the ranks' individuals (the marker statistics are replicated)
+        double h[kMaxT * kMaxT + kMaxT];
+        for (int i = 0; i < t * t; ++i) h[i] = S->resid_ss[i];
+        for (int a = 0; a < t; ++a) h[t * t + a] = S->resid_sum[a];
+        HIPCHK(c, hipMemcpy(c->row_buf, h, sizeof(double) * (size_t)nfin, hipMemcpyHostToDevice));
+        int rc = row_allreduce(c, c->row_buf, (size_t)nfin, true);
+        if (rc) return rc;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipMemcpy(h, c->row_buf, sizeof(double) * (size_t)nfin, hipMemcpyDeviceToHost));
+        for (int i = 0; i < t * t; ++i) S->resid_ss[i] = h[i];
+        for (int a = 0; a < t; ++a) S->resid_sum[a] = h[t * t + a];
+    }
     S->n_events = packed_dev ? h_stat[kNStat] : (double)h_cnt[0];
     c->last_events = (double)h_cnt[0];
     if (std::getenv("JWAS_HIP_DEBUG_PHASES"))
@@ -1716,13 +1807,54 @@ int jwas_hip_comm_init(jwas_hip_ctx* c, const void* unique_id_128, int32_t rank,
 int jwas_hip_comm_destroy(jwas_hip_ctx* c)
 {
     NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
-    if (!c->comm) return JWAS_HIP_OK;
+    if (!c->comm && c->loop_slot < 0) return JWAS_HIP_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    (void)g_rccl.CommDestroy(c->comm);
+    if (c->comm) (void)g_rccl.CommDestroy(c->comm);
     c->comm = nullptr; c->comm_world = 1; c->comm_rank = 0;
     (void)hipFree(c->r_snap); (void)hipFree(c->shard_buf);
     c->r_snap = nullptr; c->shard_buf = nullptr;
+    c->row_mode = false; c->loop_slot = -1;
+    (void)hipFree(c->row_buf); c->row_buf = nullptr;
+    return JWAS_HIP_OK;
+}
+
+int jwas_hip_comm_init_loopback(jwas_hip_ctx* c, int32_t slot, int32_t rank, int32_t world)
+{
+    NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
+    NEED(c, slot >= 0 && slot < 4, JWAS_HIP_EINVAL, "loopback slot %d outside [0,4)", slot);
+    NEED(c, world >= 1 && world <= 8 && rank >= 0 && rank < world, JWAS_HIP_EINVAL, "rank %d outside [0,%d)", rank, world);
+    NEED(c, !c->comm && c->loop_slot < 0, JWAS_HIP_ESTATE, "a communicator is already attached (jwas_hip_comm_destroy first)");
+    {
+        std::lock_guard<std::mutex> lk(g_loop[slot].m);
+        if (g_loop[slot].world != world) { g_loop[slot].world = world; g_loop[slot].part.assign((size_t)world, {}); g_loop[slot].arrived = 0; }
+    }
+    c->loop_slot = slot; c->comm_rank = rank; c->comm_world = world;
+    return JWAS_HIP_OK;
+}
+
+int jwas_hip_comm_row_shards(jwas_hip_ctx* c, int32_t enable)
+{
+    NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
+    NEED(c, c->comm || c->loop_slot >= 0, JWAS_HIP_ESTATE, "attach a communicator first (jwas_hip_comm_init)");
+    NEED(c, c->sets.empty(), JWAS_HIP_ESTATE, "switch the sharding mode before jwas_hip_setup_blocks (x'x and the Grams are summed over the ranks there)");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!enable) { c->row_mode = false; return JWAS_HIP_OK; }
+    if (!c->row_buf) HIPCHK(c, hipMalloc(&c->row_buf, sizeof(double) * 32));
+    // every rank must run the same update-role geometry (the partial RHS are summed row group by row group) and hold the
+    // same markers: world * sum(x^2) == (sum x)^2  <=>  all x equal
+    double h[6] = {(double)c->nrg, (double)c->nrg * c->nrg, (double)c->p, (double)c->p * (double)c->p, (double)c->packed, 1.0};
+    HIPCHK(c, hipMemcpy(c->row_buf, h, sizeof h, hipMemcpyHostToDevice));
+    int rc = row_allreduce(c, c->row_buf, 6, true);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(h, c->row_buf, sizeof h, hipMemcpyDeviceToHost));
+    const double w = h[5];
+    NEED(c, (int)w == c->comm_world, JWAS_HIP_ESTATE, "row shards: %d of %d ranks answered", (int)w, c->comm_world);
+    NEED(c, w * h[1] == h[0] * h[0], JWAS_HIP_EINVAL, "row shards need the same number of row groups on every rank (this rank: %d; pad the shorter shards with zero rows)", c->nrg);
+    NEED(c, w * h[3] == h[2] * h[2], JWAS_HIP_EINVAL, "row shards need the same markers on every rank (this rank: %lld)", (long long)c->p);
+    NEED(c, h[4] == 0.0 || h[4] == w, JWAS_HIP_EINVAL, "row shards need the same storage on every rank");
+    c->row_mode = true;
     return JWAS_HIP_OK;
 }
 
@@ -1734,6 +1866,7 @@ int jwas_hip_sweep_sharded(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_swe
 {
     NEED(c, c && P && S, JWAS_HIP_EINVAL, "NULL argument");
     NEED(c, c->comm, JWAS_HIP_ESTATE, "jwas_hip_comm_init has not been called");
+    NEED(c, !c->row_mode, JWAS_HIP_ESTATE, "this communicator runs exact row shards: use jwas_hip_sweep");
     NEED(c, c->method >= 0, JWAS_HIP_ESTATE, "jwas_hip_init_state has not been called");
     const int t = c->ntraits;
     HIPCHK(c, hipSetDevice(c->device));

@@ -380,6 +380,15 @@ class HipEngine:
         self._chk(self._L.jwas_hip_comm_init(self._h, C.cast(buf, C.c_void_p), int(rank), int(world)))
         self._comm = True
 
+    def comm_row_shards(self, enable=True):
+        """Exact ROW shards (jwas_hip_comm_row_shards): this rank holds a slice of the individuals and all markers; call
+        after comm_init (or comm_init_loopback) and before setup_blocks.  sweep() is then the exact chain of the pooled data."""
+        self._chk(self._L.jwas_hip_comm_row_shards(self._h, 1 if enable else 0))
+
+    def comm_init_loopback(self, slot, rank, world):
+        """Test transport: the ranks are engines of ONE process driven by different host threads (exchange through host memory)."""
+        self._chk(self._L.jwas_hip_comm_init_loopback(self._h, int(slot), int(rank), int(world)))
+
     def comm_destroy(self):
         self._chk(self._L.jwas_hip_comm_destroy(self._h))
         self._comm = False

@@ -357,6 +357,22 @@ def test_two_rank_sharded_sweep_over_rccl(tmp_path):
     assert out.returncode == 0 and "TWO_RANK_RCCL_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
+def test_two_rank_row_shards_over_rccl(tmp_path):
+    """Two processes, two GPUs, exact row shards over RCCL (skipped on a one-GPU box): the same chain, bit for bit, as the
+    same two shards over the loopback transport on one GPU."""
+    import subprocess
+    import sys
+    import os
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", REPO=repo)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29543", os.path.join(repo, "tests", "_dist_gpu_rows_worker.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "TWO_RANK_ROWS_RCCL_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 def test_heldout_ebv_gpu_matches_oracle(tmp_path):
     """Individuals with genotypes but no record: EBV = output_genotypes * alpha on the device
     (jwas_hip_load_output_dense_f32 / jwas_hip_mul_alpha_output; output.jl:281-306, tools4genotypes.jl:290-296)."""
@@ -439,3 +455,107 @@ def test_impute_genotypes_on_device_and_sweep_parity():
     assert np.array_equal(do, dh) and do.sum() > 3
     np.testing.assert_allclose(ah, ao, rtol=0, atol=5e-6)
     e.close()
+
+
+@pytest.mark.parametrize("method,t,bs,nranks", [("BayesC", 1, 128, 2), ("BayesR", 1, 256, 2), ("MTBayesC", 2, 128, 3), ("BayesC", 1, 64, 4)])
+def test_exact_row_shards_over_the_loopback_transport(method, t, bs, nranks):
+    """Exact ROW shards (jwas_hip_comm_row_shards): every rank holds a slice of the individuals and all markers; x'x, the Grams
+    and each block's partial RHS are summed over the ranks, the sampler runs replicated.  The ranks here are engines of one
+    process on different host threads (loopback transport: the all-reduces go through host memory), which exercises the same
+    call sites the RCCL transport uses.  The pooled chain must equal the oracle's on the full data (the sums are formed in
+    a different order, nothing else), every rank must hold the same effects bit for bit, and r'r must be the pooled one."""
+    import threading
+    import jwas_jl_amd as J
+    rows_per = 512                                       # two 256-row slices per rank: the same row groups everywhere
+    n = rows_per * nranks
+    d = make_dataset(n=n, p=3 * bs + 21, ncausal=8, seed=50 + nranks)
+    p = d["X"].shape[1]
+    y = (d["y"] - d["y"].mean()).astype(np.float32)
+    vare, varg = np.float32(0.5 * d["y"].var()), np.float32(0.004)
+    if method == "BayesR":
+        kw = dict(vare=vare, var_effect=np.float32(0.05), pi_classes=np.array([0.9, 0.05, 0.03, 0.02]))
+    elif t == 1:
+        kw = dict(vare=vare, var_effect=varg, pi=0.9)
+    else:
+        kw = dict(vare=(np.eye(t) * 0.5 + 0.1).astype(np.float32) * vare, var_effect=(np.eye(t) * 0.004).astype(np.float32),
+                  log_prior_states=np.log(np.array([0.7, 0.1, 0.1, 0.1])))
+    nsweeps = 6
+    orc = OracleEngine("lookahead")
+    orc.load_dense(d["X"]); orc.setup_blocks(bs); orc.init_state(method, t)
+    for k in range(t):
+        orc.set_residual(((1 + 0.3 * k) * y).astype(np.float32), k)
+        if t > 1:
+            orc.set_state(k, delta=np.ones(p, dtype=np.float32))
+    so = [orc.sweep(iteration=it, seed=23, **kw) for it in range(1, nsweeps + 1)]
+    out, errs = [None] * nranks, []
+
+    def run(rank):
+        try:
+            e = J.HipEngine(0)
+            sl = slice(rank * rows_per, (rank + 1) * rows_per)
+            e.load_dense(np.asfortranarray(d["X"][sl]))
+            e.comm_init_loopback(1, rank, nranks)
+            e.comm_row_shards(True)
+            e.setup_blocks(bs, "f64"); e.init_state(method, t)
+            for k in range(t):
+                e.set_residual(((1 + 0.3 * k) * y[sl]).astype(np.float32), k)
+                if t > 1:
+                    e.set_state(k, delta=np.ones(p, dtype=np.float32))
+            st = [e.sweep(iteration=it, seed=23, **kw) for it in range(1, nsweeps + 1)]
+            out[rank] = ([e.get_state(k) for k in range(t)], [e.get_residual(k) for k in range(t)], st, e.xpx())
+            e.close()
+        except Exception as ex:                          # noqa: BLE001
+            errs.append((rank, repr(ex)))
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(nranks)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join(timeout=300)
+    assert not errs, errs
+    assert all(o is not None for o in out)
+    np.testing.assert_allclose(out[0][3], orc.xpx(), rtol=2e-6)                      # x'x of the pooled individuals
+    for it in range(nsweeps):
+        for r in range(nranks):
+            assert out[r][2][it]["n_events"] == so[it]["n_events"], f"sweep {it + 1}, rank {r}"
+            np.testing.assert_allclose(out[r][2][it]["resid_ss"], so[it]["resid_ss"], rtol=2e-5)      # pooled r'r on every rank
+    for k in range(t):
+        ao, bo, do = orc.get_state(k)
+        for r in range(nranks):
+            a, b_, dl = out[r][0][k]
+            assert np.array_equal(a, out[0][0][k][0]) and np.array_equal(dl, out[0][0][k][2])      # replicated bit for bit
+            assert np.array_equal(dl, do)
+            np.testing.assert_allclose(a, ao, rtol=0, atol=2e-5)
+        r_all = np.concatenate([out[r][1][k] for r in range(nranks)])
+        np.testing.assert_allclose(r_all, orc.get_residual(k), rtol=0, atol=1e-4)
+
+
+def test_row_shards_single_rank_is_the_plain_sweep_and_contract_errors():
+    import jwas_jl_amd as J
+    d = make_dataset(n=300, p=200, ncausal=5, seed=8)
+    y = (d["y"] - d["y"].mean()).astype(np.float32)
+    kw = dict(vare=np.float32(0.5), var_effect=np.float32(0.004), pi=0.9)
+    res = []
+    for row in (False, True, "rccl"):
+        e = J.HipEngine(0)
+        e.load_dense(d["X"])
+        if row == "rccl":                                # the RCCL transport with one rank: same call sites, real ncclAllReduce
+            e.comm_init(e.comm_unique_id(), 0, 1)
+            e.comm_row_shards(True)
+        elif row:
+            with pytest.raises(J.JwasHipError, match="attach a communicator first"):
+                e.comm_row_shards(True)
+            e.comm_init_loopback(2, 0, 1)
+            e.comm_row_shards(True)
+        e.setup_blocks(64, "f64"); e.init_state("BayesC"); e.set_residual(y)
+        st = [e.sweep(iteration=it, seed=4, **kw) for it in range(1, 5)]
+        res.append((e.get_state(), e.get_residual(), st[-1]["resid_ss"]))
+        if row is True:
+            with pytest.raises(J.JwasHipError, match="before jwas_hip_setup_blocks"):
+                e.comm_row_shards(False)
+            with pytest.raises(J.JwasHipError, match="not available on row shards"):
+                e.sweep(iteration=9, seed=4, independent_blocks=True, **kw)
+        e.close()
+    for q in (1, 2):
+        assert all(np.array_equal(x, y_) for x, y_ in zip(res[0][0], res[q][0])) and np.array_equal(res[0][1], res[q][1])
+        assert np.array_equal(res[0][2], res[q][2])
