@@ -134,18 +134,25 @@ def _impute_missing_residuals(res, observed, R0, rng):
 
 def _inverse_wishart_batch(rng, df, scale):
     """One InverseWishart(df, scale_j) draw per matrix of the batch (m x t x t), Bartlett's decomposition: with
-    scale_j^-1 = L L' and A lower-triangular (A_ii = sqrt(chi2(df - i)), A_ik ~ N(0,1) below the diagonal),
-    W = L A A' L' ~ Wishart(df, scale_j^-1) and G = W^-1 (the reference draws each marker's matrix with
-    rand(InverseWishart(df, scale)), variance_components.jl:181-186)."""
+    scale_j = C C' (Cholesky) and A lower-triangular (A_ii = sqrt(chi2(df - i)), A_ik ~ N(0,1) below the diagonal),
+    W = C'^-1 A A' C^-1 ~ Wishart(df, scale_j^-1) and G = W^-1 = K K' with K' = A^-1 C' (one batched Cholesky and a forward
+    substitution vectorised over the batch; the reference draws each marker's matrix with rand(InverseWishart(df, scale)),
+    variance_components.jl:181-186)."""
     m, t, _ = scale.shape
-    L = np.linalg.cholesky(np.linalg.inv(scale))
+    C = np.linalg.cholesky(scale)
     A = np.zeros((m, t, t))
     for i in range(t):
         A[:, i, i] = np.sqrt(rng.chisquare(df - i, size=m))
         for k in range(i):
             A[:, i, k] = rng.standard_normal(m)
-    Minv = np.linalg.inv(L @ A)
-    G = Minv.transpose(0, 2, 1) @ Minv
+    Kt = np.empty((m, t, t))
+    Ct = C.transpose(0, 2, 1)
+    for i in range(t):
+        acc = Ct[:, i, :].copy()
+        for k in range(i):
+            acc -= A[:, i, k, None] * Kt[:, k, :]
+        Kt[:, i, :] = acc / A[:, i, i, None]
+    G = Kt.transpose(0, 2, 1) @ Kt
     return (G + G.transpose(0, 2, 1)) / 2
 
 
