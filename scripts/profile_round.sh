@@ -9,8 +9,11 @@ TAG=${1:-r02}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
+ONLY=${2:-all}          # "dense": only the dense-regime workloads (refbench, config4) -- bash scripts/profile_round.sh r02 dense
+if [ "$ONLY" = all ]; then
 python -m pytest tests -m gpu -q 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" | tail -6 > "$OUT/gpu_tests.log"
 python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
+fi
 run() {   # name, timed steps, bench args...
     local W=$1 K=$2; shift 2
     mkdir -p "$OUT/$W"
@@ -23,7 +26,12 @@ run() {   # name, timed steps, bench args...
     find "$OUT/$W" -name "*counter_collection.csv" -size +5M -delete
     find "$OUT/$W" -name "*.db" -delete
 }
+if [ "$ONLY" = all ]; then
 run config2 30
 run config3 10 --workload config3 --warmup 20
 run config2_pifixed 10 --pi-fixed 0.95 --warmup 20
+else
+run refbench 10 --workload refbench --warmup 10 --burnin 0
+run config4 10 --workload config4 --warmup 10 --burnin 0
+fi
 ls -la "$OUT" "$OUT"/*
