@@ -202,6 +202,13 @@ int  jwas_hip_set_xpx(jwas_hip_ctx* ctx, const float* in_p);
 int  jwas_hip_get_gram(jwas_hip_ctx* ctx, int64_t block, float* out_bxb);        /* row-major b x b */
 int  jwas_hip_set_gram(jwas_hip_ctx* ctx, int64_t block, const float* in_bxb);
 int  jwas_hip_num_blocks(jwas_hip_ctx* ctx, int64_t* nblocks, int32_t* block_size);
+/* Overwrite the cross-Gram X_{block-1}' X_block (row-major b_{block-1} x b_block; block >= 1) -- with jwas_hip_set_xpx /
+ * jwas_hip_set_gram this lets a host (or the test oracle) supply every precomputed inner product. */
+int  jwas_hip_set_cross_gram(jwas_hip_ctx* ctx, int64_t block, const float* in);
+/* Geometry of the streaming (update) role chosen for this matrix: slices (256 rows, one wave each) per row group, row
+ * groups, column groups.  The order in which a block's x'r is summed follows from it (fp64; slices of a row group in
+ * order, then the row groups in order): the test oracle reproduces it to compare chains bit for bit. */
+int  jwas_hip_update_geometry(jwas_hip_ctx* ctx, int32_t* slices_per_row_group, int32_t* row_groups, int32_t* column_groups);
 /* Several block sizes can be resident (Grams + cross-Grams each: 8*p*block_size bytes).  The random draws do not depend
  * on the block size, so a host may switch between sweeps: large blocks amortise the per-launch cost when few markers
  * change per sweep, smaller ones keep the serial within-block chain short when many do (the reference's block size is

@@ -30,7 +30,7 @@ SYMBOLS = [
     "jwas_hip_load_jgb2", "jwas_hip_load_packed2bit", "jwas_hip_alloc_packed2bit", "jwas_hip_storage_info",
     "jwas_hip_set_xpx", "jwas_hip_estimate_bytes_storage", "jwas_hip_add_block_size", "jwas_hip_select_block_size",
     "jwas_hip_set_weights", "jwas_hip_synth_single_step", "jwas_hip_setup_blocks_explicit",
-    "jwas_hip_comm_row_shards", "jwas_hip_comm_init_loopback",
+    "jwas_hip_comm_row_shards", "jwas_hip_comm_init_loopback", "jwas_hip_update_geometry", "jwas_hip_set_cross_gram",
     "jwas_hip_set_columns", "jwas_hip_get_alpha_sparse", "jwas_hip_comm_unique_id", "jwas_hip_comm_init", "jwas_hip_comm_destroy", "jwas_hip_sweep_sharded",
 ]
 STORAGE_DENSE_F32, STORAGE_PACKED2BIT = 0, 1
@@ -144,6 +144,8 @@ def load():
     L.jwas_hip_add_block_size.argtypes = [vp, i32, i32]
     L.jwas_hip_setup_blocks_explicit.argtypes = [vp, C.POINTER(C.c_int64), i64, i32]
     L.jwas_hip_comm_row_shards.argtypes = [vp, i32]
+    L.jwas_hip_update_geometry.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    L.jwas_hip_set_cross_gram.argtypes = [vp, i64, vp]
     L.jwas_hip_comm_init_loopback.argtypes = [vp, i32, i32, i32]
     L.jwas_hip_select_block_size.argtypes = [vp, i32]
     L.jwas_hip_estimate_bytes_storage.argtypes = [i64, i64, i32, i32, i32]

@@ -815,6 +815,29 @@ int jwas_hip_get_gram(jwas_hip_ctx* c, int64_t blk, float* out)
     return JWAS_HIP_OK;
 }
 
+int jwas_hip_update_geometry(jwas_hip_ctx* c, int32_t* spg, int32_t* nrg, int32_t* ncg)
+{
+    NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
+    NEED(c, HAVE_STORAGE(c), JWAS_HIP_ESTATE, "no genotype matrix loaded");
+    if (spg) *spg = c->spg;
+    if (nrg) *nrg = c->nrg;
+    if (ncg) *ncg = c->ncg;
+    return JWAS_HIP_OK;
+}
+
+int jwas_hip_set_cross_gram(jwas_hip_ctx* c, int64_t blk, const float* in)
+{
+    NEED(c, c && in, JWAS_HIP_EINVAL, "NULL argument");
+    int b = 0, rc = block_dims(c, blk, &b);
+    if (rc) return rc;
+    NEED(c, blk >= 1, JWAS_HIP_EINVAL, "block 0 has no predecessor");
+    const int bp = blk_b(c, blk - 1);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(c->cross + blk * (int64_t)c->block_size * c->block_size, in, sizeof(float) * (size_t)bp * b, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return JWAS_HIP_OK;
+}
+
 int jwas_hip_set_gram(jwas_hip_ctx* c, int64_t blk, const float* in)
 {
     NEED(c, c && in, JWAS_HIP_EINVAL, "NULL argument");

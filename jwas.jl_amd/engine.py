@@ -238,6 +238,19 @@ class HipEngine:
             raise ValueError(f"Gram block {i} must be {b} x {b}")
         self._chk(self._L.jwas_hip_set_gram(self._h, int(i), _ptr(G)))
 
+    def set_cross_gram(self, i, C_):
+        """Overwrite X_{i-1}' X_i (rows = markers of block i-1), i >= 1."""
+        Cc = np.ascontiguousarray(C_, dtype=np.float32)
+        if Cc.shape != (self._bsize(i - 1), self._bsize(i)):
+            raise ValueError(f"cross-Gram of block {i} must be {self._bsize(i - 1)} x {self._bsize(i)}")
+        self._chk(self._L.jwas_hip_set_cross_gram(self._h, int(i), _ptr(Cc)))
+
+    def update_geometry(self):
+        """(slices per row group, row groups, column groups) of the streaming role for this matrix."""
+        a, b, c_ = C.c_int32(), C.c_int32(), C.c_int32()
+        self._chk(self._L.jwas_hip_update_geometry(self._h, C.byref(a), C.byref(b), C.byref(c_)))
+        return a.value, b.value, c_.value
+
     def set_grams_packed(self, grams):
         """grams: concatenated row-major b_i x b_i blocks (the oracle's packing)."""
         off = 0

@@ -71,8 +71,50 @@ double orc_normal(uint64_t seed, uint32_t marker, uint32_t iter, uint32_t rep, u
 static const float* g_rinv = NULL;
 void orc_set_weights(const float* rinv) { g_rinv = rinv; }
 
+/* ORC_ACC_DEVICE: the block right-hand side x'r summed in the ORDER the device sums it (jwas.jl_amd/csrc/sweep.hpp
+ * update_role): 256-row slices; in a slice lane l holds rows 4l..4l+3 (product, then three fused multiply-adds, fp64);
+ * the 64 lane values are folded pairwise at distances 32, 16, 8, 4, 2, 1 (butterfly8); the slices of a row group (spg of
+ * them) are added in order, then the row groups in order; rounded to fp32 once.  The values are the same exact fp32
+ * products as ORC_ACC_F64 -- only the association of the fp64 additions differs -- so with this mode the oracle's chain
+ * and the device's agree in EVERY bit.  orc_set_device_order(spg) (harness state): spg = slices per row group of the
+ * device context (jwas_hip_update_geometry). */
+static int g_dev_spg = 8;
+void orc_set_device_order(int spg) { g_dev_spg = spg > 0 ? spg : 8; }
+static float dot_device_order(const float* x, const float* r, int64_t n, const float* w)
+{
+    const int64_t nsl = (n + 255) / 256, nrg = (nsl + g_dev_spg - 1) / g_dev_spg;
+    double total = 0.0;
+    for (int64_t rg = 0; rg < nrg; ++rg) {
+        double P = 0.0;
+        for (int wv = 0; wv < 8; ++wv) {
+            double T = 0.0;
+            const int64_t sl = rg * g_dev_spg + wv;
+            if (wv < g_dev_spg && sl < nsl) {
+                double L[64];
+                for (int l = 0; l < 64; ++l) {
+                    const int64_t i0 = sl * 256 + 4 * l;
+                    double acc = 0.0;
+                    for (int q = 0; q < 4; ++q) {
+                        const int64_t i = i0 + q;
+                        const float xv = i < n ? x[i] : 0.0f;
+                        const float rw = i < n ? (w ? r[i] * w[i] : r[i]) : 0.0f;
+                        acc = (q == 0) ? (double)xv * (double)rw : fma((double)xv, (double)rw, acc);
+                    }
+                    L[l] = acc;
+                }
+                for (int d = 32; d >= 1; d >>= 1) for (int i = 0; i < d; ++i) L[i] = L[i] + L[i + d];
+                T = L[0];
+            }
+            P += T;
+        }
+        total += P;
+    }
+    return (float)total;
+}
+
 static float dot_acc(const float* a, const float* b, int64_t n, int acc)
 {
+    if (acc == ORC_ACC_DEVICE) return dot_device_order(a, b, n, g_rinv);
     if (g_rinv) {
         double s = 0.0;
         for (int64_t i = 0; i < n; ++i) s += (double)a[i] * (double)(b[i] * g_rinv[i]);
@@ -96,6 +138,13 @@ static void axpy_f32(float a, const float* x, float* y, int64_t n)
 void orc_xpx(const float* X, int64_t n, int64_t p, int64_t ld, float* xpx, int acc)
 {
     for (int64_t j = 0; j < p; ++j) xpx[j] = dot_acc(X + j * ld, X + j * ld, n, acc);
+}
+
+/* Cross-Gram X_prev' X_this as the lookahead correction uses it (la_block_rhs): out[a * b + c] = x_{jp+a}' x_{j0+c}. */
+void orc_cross_gram(const float* X, int64_t n, int64_t ld, int64_t jp, int64_t bp, int64_t j0, int64_t b, float* out, int acc)
+{
+    for (int64_t a = 0; a < bp; ++a)
+        for (int64_t c = 0; c < b; ++c) out[a * b + c] = dot_acc(X + (jp + a) * ld, X + (j0 + c) * ld, n, acc);
 }
 
 void orc_gram(const float* X, int64_t n, int64_t ld, int64_t j0, int64_t b, float* G, int acc)

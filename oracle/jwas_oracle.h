@@ -50,7 +50,11 @@
 extern "C" {
 #endif
 
-enum { ORC_ACC_F64 = 0, ORC_ACC_F32 = 1 };
+enum { ORC_ACC_F64 = 0, ORC_ACC_F32 = 1, ORC_ACC_DEVICE = 2 };
+/* ORC_ACC_DEVICE: x'r summed in the device's association order (see jwas_oracle.c dot_device_order); spg = the device
+ * context's slices per row group. */
+void orc_set_device_order(int spg);
+void orc_cross_gram(const float* X, int64_t n, int64_t ld, int64_t jp, int64_t bp, int64_t j0, int64_t b, float* out, int acc);
 
 /* ---- random numbers -------------------------------------------------------------------- */
 void   orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);

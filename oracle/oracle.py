@@ -14,6 +14,7 @@ _LIB_PATH = os.path.join(_HERE, "libjwas_oracle.so")
 
 ACC_F64 = 0
 ACC_F32 = 1
+ACC_DEVICE = 2      # x'r summed in the device's association order (set_device_order(spg) first)
 GAMMA = np.array([0.0, 0.01, 0.1, 1.0], dtype=np.float64)  # JWAS.jl:12
 
 
@@ -106,6 +107,15 @@ def gram(X, j0, b, acc=ACC_F64):
 
 def block_starts_for(p, block_size):
     return np.arange(0, p, block_size, dtype=np.int64)
+
+
+def cross_gram(X, jp, bp, j0, b, acc=ACC_F64):
+    """X_prev' X_this (bp x b) with the inner products the lookahead correction uses."""
+    n, p, ld = _xinfo(X)
+    out = np.empty((bp, b), dtype=np.float32)
+    lib().orc_cross_gram(_p(X, _f32p), C.c_int64(n), C.c_int64(ld), C.c_int64(jp), C.c_int64(bp), C.c_int64(j0), C.c_int64(b),
+                         _p(out, _f32p), C.c_int(acc))
+    return out
 
 
 def grams_for(X, block_starts, acc=ACC_F64):
@@ -249,6 +259,11 @@ def mt_sweep(kind, X, xpx_, r, alpha, beta, delta, vare, var_effect, log_prior, 
                 C.c_uint64(seed), C.c_uint32(it), C.c_uint32(marker0), C.c_int(acc))
     if rc != 0:
         raise ValueError(f"oracle multi-trait sweep (kind {kind}) rejected its arguments (rc={rc})")
+
+
+def set_device_order(spg):
+    """Slices per row group of the device context whose summation order ACC_DEVICE mirrors (HipEngine.update_geometry())."""
+    lib().orc_set_device_order(C.c_int(int(spg)))
 
 
 def set_var_effect_matrix(mat):

@@ -901,3 +901,62 @@ def test_block_repetitions_with_blocks_that_start_without_candidates(hip, method
         ah, _, dh = hip.get_state()
         assert np.array_equal(do, dh)
         np.testing.assert_allclose(ah, ao, rtol=0, atol=5e-6)
+
+
+@pytest.mark.parametrize("method,t,bs,nreps,n,weights", [("BayesC", 1, 64, 1, 700, False), ("BayesC", 1, 512, 0, 664, False), ("BayesR", 1, 256, 1, 1500, True),
+                                                         ("MTBayesC", 3, 128, 1, 900, False), ("BayesC", 1, 256, 300, 2600, False),
+                                                         ("MTBayesC_II", 2, 64, 2, 500, False)])
+def test_every_bit_equal_when_the_oracle_sums_in_the_device_order(hip, method, t, bs, nreps, n, weights):
+    """The device and the oracle perform the same operations on the same numbers with ONE exception: the association of the
+    fp64 additions in a block's x'r (row groups on the device, row by row in the oracle).  With the oracle summing in the
+    device's order (ORC_ACC_DEVICE, the geometry from jwas_hip_update_geometry) and the same precomputed inner products
+    on both sides (x'x, Grams, cross-Grams handed to the device), every effect, every indicator and every residual element
+    must be equal bit for bit -- also after hundreds of within-block repetitions, where last-bit differences would be
+    amplified (the case the fuzz run found: 512 repetitions, n = 664, p = 704)."""
+    import oracle as O
+    p = 704 if bs == 512 else 3 * bs + 37
+    d = make_dataset(n=n, p=p, ncausal=8, seed=2319 % 1000 if bs == 512 else 5)
+    y = (d["y"] - d["y"].mean()).astype(np.float32)
+    rng = np.random.default_rng(3)
+    w = rng.uniform(0.4, 2.5, n).astype(np.float32) if weights else None
+    hip.load_dense(d["X"]); hip.set_weights(w); hip.setup_blocks(bs, "f64"); hip.init_state(method, t)
+    spg, nrg, ncg = hip.update_geometry()
+    O.set_device_order(spg)
+    orc = OracleEngine("lookahead", acc=O.ACC_DEVICE)
+    orc.load_dense(d["X"]); orc.set_weights(w); orc.setup_blocks(bs); orc.init_state(method, t)
+    # the same precomputed inner products on both sides
+    hip.set_xpx(orc._xpx)
+    hip.set_grams_packed(orc._grams)
+    orc._w()
+    starts = list(orc._bs) + [p]
+    for k in range(1, len(starts) - 1):
+        hip.set_cross_gram(k, O.cross_gram(d["X"], starts[k - 1], starts[k] - starts[k - 1], starts[k], starts[k + 1] - starts[k], O.ACC_DEVICE))
+    O.set_weights(None)
+    for k in range(t):
+        yk = ((1 + 0.3 * k) * y).astype(np.float32)
+        orc.set_residual(yk, k); hip.set_residual(yk, k)
+        if method == "BayesR":
+            orc.set_state(0, delta=np.ones(p, dtype=np.int32)); hip.set_state(0, delta=np.ones(p, dtype=np.int32))
+        elif t > 1:
+            orc.set_state(k, delta=np.ones(p, dtype=np.float32)); hip.set_state(k, delta=np.ones(p, dtype=np.float32))
+    v = np.float32(max(float(np.var(y)), 0.1))
+    if method == "BayesR":
+        kw = dict(vare=v, var_effect=np.float32(0.1), pi_classes=np.array([0.6, 0.2, 0.1, 0.1]))
+    elif t == 1:
+        kw = dict(vare=v, var_effect=np.float32(0.02), pi=0.3)
+    else:
+        A = rng.standard_normal((t, t)); B = rng.standard_normal((t, t))
+        kw = dict(vare=((A @ A.T / t + np.eye(t)) * v).astype(np.float32), var_effect=((B @ B.T / t + np.eye(t)) * 0.02).astype(np.float32),
+                  log_prior_states=np.log(rng.dirichlet(np.ones(1 << t))))
+    try:
+        for it in range(1, 7):
+            so = orc.sweep(iteration=it, seed=2319, nreps=nreps, **kw)
+            sh = hip.sweep(iteration=it, seed=2319, nreps=nreps, **kw)
+            assert so["n_events"] == sh["n_events"], f"iteration {it}"
+            for k in range(t):
+                for q, (xo, xh) in enumerate(zip(orc.get_state(k), hip.get_state(k))):
+                    assert np.array_equal(xo, xh), f"iteration {it}, trait {k}, field {q}: max diff {np.abs(xo.astype(np.float64) - xh).max()}"
+                assert np.array_equal(orc.get_residual(k), hip.get_residual(k)), f"iteration {it}: residual of trait {k}"
+    finally:
+        O.set_device_order(8)
+        hip.set_weights(None)
