@@ -75,7 +75,7 @@ def _random_case(seed):
     rng = np.random.default_rng(seed)
     method = rng.choice(["BayesC", "BayesC", "BayesR", "BayesB", "MTBayesC", "MTBayesC_II", "MegaBayesC", "MTBayesB"])
     t = 1 if method in ("BayesC", "BayesR", "BayesB") else int(rng.integers(2, 4))
-    n = int(rng.integers(40, 700))
+    n = int(rng.integers(40, 700)) if rng.random() < 0.85 else int(rng.integers(1500, 4200))      # (the tall ones: several row groups)
     p = int(rng.integers(30, 900))
     explicit = rng.random() < 0.4
     if explicit:
