@@ -21,8 +21,15 @@ Workloads (BASELINE.json `configs`):
                   markers (N = 8 is config 5 itself) -- weak scaling
     refbench      the shape of the reference's own published benchmark (benchmarks/jwas_nonblock_benchmark.jl:34-51)
 
-N > 1 (config2/3/4: total work fixed, "strong"): markers are sharded over the ranks (jwas.jl_amd/dist.py): each rank
-sweeps its markers from the same residual snapshot and ONE all-reduce (RCCL) of the residual delta reconciles per sweep.
+N > 1 (config2/3/4: total work fixed, "strong"): one process per GPU.  Under torch.distributed.run (RANK / WORLD_SIZE in
+the environment) this process is one rank; run plainly with --gpus N > 1 it SPAWNS the N ranks itself (re-executes
+under torch.distributed.run on 127.0.0.1) and fails -- exit code 2, no JSON line -- when the box has fewer GPUs than N.
+  --shard markers (default): markers are sharded over the ranks (jwas.jl_amd/dist.py MarkerShard): each rank sweeps its markers
+                  from the same residual snapshot and ONE ncclAllReduce of the residual delta + the packed marker
+                  statistics reconciles per sweep, inside the library (jwas_hip_sweep_sharded), residual resident in HBM;
+  --shard rows:   exact row shards (dist.RowShard / jwas_hip_comm_row_shards): every rank holds n / N individuals and all
+                  markers, one small all-reduce of the block's partial right-hand side per block launch, sampler replicated.
+The line's n_gpus is the rank count the RCCL communicator itself reports (ncclCommCount); a mismatch with --gpus is an error.
 
 Prints ONE JSON line (rank 0) with the contract fields plus
   "roofline":     HBM roofline of the dominant kernel (k_block_step: sampler of block k-1 || update + partial
@@ -37,6 +44,8 @@ Prints ONE JSON line (rank 0) with the contract fields plus
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -77,6 +86,9 @@ def parse():
     ap.add_argument("--mt-prior", choices=["default", "sparse"], default="default")
     ap.add_argument("--mt-method", choices=["BayesC", "BayesB"], default="BayesC",
                     help="config4: BayesB = multi-trait BayesA/B, one effect covariance per marker (redrawn on the host each iteration)")
+    ap.add_argument("--shard", choices=["markers", "rows"], default="markers",
+                    help="N > 1: markers = marker shards + one all-reduce of the residual delta per sweep (the metric's mode); "
+                         "rows = exact row shards (one small all-reduce per block launch, replicated sampler)")
     ap.add_argument("--seed", type=int, default=2026)
     ap.add_argument("--storage", choices=["dense", "packed2bit"], default="dense",
                     help="dense = the metric's fp32 dense genotypes (default); packed2bit = the reference's 2-bit packed "
@@ -117,11 +129,38 @@ def traffic_from_profiles(workload, n, p, bs, storage, world, pi_fixed):
     return None, None
 
 
+def spawn_ranks(a):
+    """`python bench.py --gpus N` run plainly (no RANK in the environment): become the launcher of N ranks, one per GPU,
+    the same way the driver's torch.distributed.run command line does.  Never measures fewer GPUs than asked for."""
+    import torch
+    ndev = torch.cuda.device_count()
+    if ndev < a.gpus and not os.environ.get("JWAS_BENCH_ONE_DEVICE"):
+        print(f"bench.py: --gpus {a.gpus} needs {a.gpus} GPUs, this box has {ndev}; refusing to report a {ndev}-GPU number "
+              f"as a {a.gpus}-GPU one", file=sys.stderr)
+        sys.exit(2)
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // max(1, a.gpus))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     a = parse()
+    if "RANK" not in os.environ and a.gpus > 1:
+        spawn_ranks(a)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {a.gpus} but the launcher started {world} rank(s); refusing to print a line whose n_gpus "
+                  "is not the number of ranks", file=sys.stderr)
+        sys.exit(2)
     import torch
     if world > 1:
         import torch.distributed as dist
@@ -132,12 +171,13 @@ def main():
         backend = os.environ.get("JWAS_BENCH_BACKEND", "nccl")
         if os.environ.get("JWAS_BENCH_ONE_DEVICE"):
             local_rank = 0
+        elif torch.cuda.device_count() <= local_rank:
+            print(f"bench.py: rank {rank} has no GPU {local_rank} (the box has {torch.cuda.device_count()})", file=sys.stderr)
+            sys.exit(2)
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend, rank=rank, world_size=world)
-    if world != a.gpus and rank == 0:
-        print(f"warning: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     import jwas_jl_amd as J
-    from jwas_jl_amd.dist import MarkerShard, shard_range
+    from jwas_jl_amd.dist import MarkerShard, RowShard, shard_range
     from jwas_jl_amd.mcmc import pick_block_size
 
     wl = a.workload
@@ -154,53 +194,86 @@ def main():
     # block policy = mcmc.run_chain's: dense priors 128; sparse single-trait priors adaptive 512/1024; multi-trait 512
     adaptive = a.block_size == 0 and not dense_prior and t == 1
     bs = a.block_size or (128 if dense_prior else 512)
-    lo, hi = shard_range(p_total, rank, world, align=1024 if adaptive else bs)
+    rows_mode = a.shard == "rows"
+    if rows_mode and (weak or a.storage != "dense"):
+        raise SystemExit("--shard rows runs the dense strong-scaling workloads (config2 / config3 / config4 / refbench)")
+    if rows_mode:
+        # exact row shards: every rank holds n / N individuals and ALL markers (the same number of 256-row groups on every rank)
+        lo, hi = 0, p_total
+        n_loc = -(-n // world)
+        n_loc = min(n_loc, n - rank * n_loc) if rank == world - 1 else n_loc
+        if -(-n_loc // 256) != -(-(-(-n // world)) // 256):
+            raise SystemExit(f"--shard rows: {n} individuals do not split into {world} slices with the same number of 256-row groups")
+        synth_seed = a.seed + 1_000_003 * rank      # every rank generates its OWN individuals (centred within the slice: the pooled columns sum to zero too)
+    else:
+        lo, hi = shard_range(p_total, rank, world, align=1024 if adaptive else bs)
+        n_loc, synth_seed = n, a.seed
     p_loc = hi - lo
     eng = J.HipEngine(local_rank)
     t_setup = time.time()
-    log('engine created'); (eng.alloc_packed if a.storage == 'packed2bit' else eng.alloc_dense)(n, p_loc); log('alloc done')
+    log('engine created'); (eng.alloc_packed if a.storage == 'packed2bit' else eng.alloc_dense)(n_loc, p_loc); log('alloc done')
     n_gen = 0
     if refbench:
-        eng.synth(a.seed, kind=1, center=False, marker_offset=lo)   # X ~ U[0,1), uncentred (jwas_nonblock_benchmark.jl:38,46)
+        eng.synth(synth_seed, kind=1, center=False, marker_offset=lo)   # X ~ U[0,1), uncentred (jwas_nonblock_benchmark.jl:38,46)
     elif weak:
         n_gen = int(round(n * 80_000 / 280_000))                    # 80k genotyped of 280k phenotyped rows (config 5)
         eng.synth_single_step(a.seed, n_gen, center=True, marker_offset=lo)
     else:
-        eng.synth(a.seed, kind=0, center=True, marker_offset=lo)    # 0/1/2 genotypes, centred, generated on device
-    log('synth done'); eng.setup_blocks(bs, "mfma")
-    if adaptive:
-        eng.add_block_size(1024, "mfma")
-    log('setup_blocks done')
+        eng.synth(synth_seed, kind=0, center=True, marker_offset=lo)    # 0/1/2 genotypes, centred, generated on device
+    log('synth done')
     mt_pervar = t > 1 and a.mt_method == "BayesB"
     if mt_pervar and world > 1:
         raise SystemExit("--mt-method BayesB runs on one GPU")
+    if rows_mode:
+        shard = RowShard(eng, rank, world)           # before setup_blocks: x'x and the Grams are summed over the ranks there
+    eng.setup_blocks(bs, "mfma")
+    if adaptive:
+        eng.add_block_size(1024, "mfma")
+    log('setup_blocks done')
     eng.init_state("MTBayesB" if mt_pervar else method, t)
-    shard = MarkerShard(eng, lo, hi, rank, world)
+    if not rows_mode:
+        shard = MarkerShard(eng, lo, hi, rank, world)
+    comm_world = shard.comm_world()
+    if comm_world != world:
+        raise SystemExit(f"bench.py: the communicator reports {comm_world} rank(s), the launcher started {world}")
 
     # ---- simulate y_k = 1 + X beta_k + e_k with ncausal QTL, h2 = 0.5
     rng = np.random.default_rng(a.seed)
+    rng_e = np.random.default_rng(a.seed + 17 + (rank if rows_mode else 0))      # residuals: per individual (rows mode: per rank)
     ncausal = max(1, p_total // 1000)
     causal = np.sort(rng.choice(p_total, size=ncausal, replace=False))
     m = (causal >= lo) & (causal < hi)
-    Y = np.empty((t, n), dtype=np.float32)
+    Y = np.empty((t, n_loc), dtype=np.float32)
     for k in range(t):
         eff = rng.standard_normal(ncausal)
         a_true = np.zeros(p_loc, dtype=np.float32)
         a_true[causal[m] - lo] = eff[m]
         eng.set_state(0, alpha=a_true)
-        g = shard.allreduce_sum(eng.mul_alpha(0).astype(np.float64))
-        g *= np.sqrt(0.5 / g.var())
-        Y[k] = (1.0 + g + rng.standard_normal(n) * np.sqrt(0.5)).astype(np.float32)
+        g = eng.mul_alpha(0).astype(np.float64)
+        if rows_mode:       # own individuals, all markers: pooled variance of g over the ranks
+            mom = shard.allreduce_sum(np.array([g.sum(), (g * g).sum()]))
+            gvar = mom[1] / n - (mom[0] / n) ** 2
+        else:               # own markers, all individuals
+            g = shard.allreduce_sum(g)
+            gvar = g.var()
+        g *= np.sqrt(0.5 / gvar)
+        Y[k] = (1.0 + g + rng_e.standard_normal(n_loc) * np.sqrt(0.5)).astype(np.float32)
         if refbench:
-            Y[k] = rng.standard_normal(n).astype(np.float32)         # y1 = randn(Float32, n)  (:35)
+            Y[k] = rng_e.standard_normal(n_loc).astype(np.float32)     # y1 = randn(Float32, n)  (:35)
     log('phenotypes done')
     dlt0 = np.ones(p_loc, dtype=np.int32 if method == "BayesR" else np.float32)
     for k in range(t):
         eng.set_state(k, alpha=np.zeros(p_loc), beta=np.zeros(p_loc), delta=dlt0)
 
     # ---- priors (input_data_validation.jl:296-350, tools4genotypes.jl:353-478, build_MME.jl:128-141)
-    vary = np.array([float(np.var(Y[k].astype(np.float64), ddof=1)) for k in range(t)])
-    sum2pq = float(shard.allreduce_sum(np.array([eng.xpx().astype(np.float64).sum()]))[0]) / n   # x'x/n = 2pq (centred)
+    Y64 = Y.astype(np.float64)
+    if rows_mode:
+        mom = shard.allreduce_sum(np.concatenate([Y64.sum(axis=1), (Y64 * Y64).sum(axis=1)]))
+        vary = (mom[t:] - mom[:t] ** 2 / n) / (n - 1)
+        sum2pq = float(eng.xpx().astype(np.float64).sum()) / n                      # (x'x is already the pooled one)
+    else:
+        vary = np.array([float(np.var(Y64[k], ddof=1)) for k in range(t)])
+        sum2pq = float(shard.allreduce_sum(np.array([eng.xpx().astype(np.float64).sum()]))[0]) / n   # x'x/n = 2pq (centred)
     nstates = 1 << t
     if t == 1:
         df_e = df_g = 4.0
@@ -231,7 +304,15 @@ def main():
         scale_g = np.asarray(Gval, dtype=np.float64) * (df_g - t - 1)
     setup_s = time.time() - t_setup; log(f'setup done {setup_s:.1f}s')
 
-    state = {"r": Y.copy(), "mu": np.zeros(t), "vare": vare, "G": Gval, "pi": pi, "it": 0, "bs": bs}
+    # The residual lives on the device for the whole chain: the host's location step is the intercept, whose Gibbs update
+    # needs sum(r) (returned with every sweep's statistics) and whose residual correction is a scalar shift
+    # (jwas_hip_residual_add_scalar).  No O(n) host traffic per iteration.
+    for k in range(t):
+        eng.set_residual(Y[k], k)
+    rsum0 = Y64.sum(axis=1)
+    if rows_mode:
+        rsum0 = shard.allreduce_sum(rsum0)
+    state = {"rsum": rsum0, "mu": np.zeros(t), "vare": vare, "G": Gval, "pi": pi, "it": 0, "bs": bs}
     if t > 1 and a.mt_method == "BayesB":
         state["Gmat"] = np.tile(np.asarray(Gval, dtype=np.float32), (p_loc, 1, 1))      # MCMC_BayesianAlphabet.jl:67-69
     acc = {"sweep_ms": 0.0, "events": 0.0, "launches": 0.0, "bytes": 0.0}
@@ -239,17 +320,19 @@ def main():
     def step():
         s = state
         s["it"] += 1
-        # 1. intercepts: single-site Gibbs on the MME (solver.jl:143-162)
-        r = s["r"].astype(np.float64) + s["mu"][:, None]
+        # 1. intercepts: single-site Gibbs on the MME (solver.jl:143-162); sum(r adjusted for mu) = sum(r) + n mu
+        mu_old = s["mu"].copy()
+        rs = s["rsum"] + n * mu_old
         if t == 1:
-            s["mu"][0] = rng.standard_normal() * np.sqrt(float(s["vare"]) / n) + r[0].sum() / n
+            s["mu"][0] = rng.standard_normal() * np.sqrt(float(s["vare"]) / n) + rs[0] / n
         else:
             Rinv = np.linalg.inv(np.asarray(s["vare"], dtype=np.float64))
-            A, b = n * Rinv, Rinv @ r.sum(axis=1)
+            A, b = n * Rinv, Rinv @ rs
             for k in range(t):
                 il = 1.0 / A[k, k]
                 s["mu"][k] = rng.standard_normal() * np.sqrt(il) + il * (b[k] - A[:, k] @ s["mu"]) + s["mu"][k]
-        r -= s["mu"][:, None]
+        for k in range(t):
+            eng.residual_add_scalar(mu_old[k] - s["mu"][k], k)
         # 2. marker sweep on the device (+ shard reconcile)
         kw = dict(iteration=s["it"], seed=a.seed, vare=s["vare"], var_effect=s["G"], nreps=1)
         if method == "BayesR":
@@ -261,12 +344,12 @@ def main():
                 kw["var_effect_matrix"] = s["Gmat"]
         else:
             kw["pi"] = s["pi"]
-        r_new, st = shard.sweep(r.astype(np.float32), **kw)
-        s["r"] = r_new
+        st = shard.sweep_resident(**kw)
+        s["rsum"] = np.asarray(st["resid_sum"], dtype=np.float64).copy()
         if adaptive:       # n_events is the all-shard total after the reconcile: every rank takes the same decision
             eng.select_block_size(pick_block_size(st["n_events"], p_total))
         acc["launches"] += -(-p_loc // s["bs"]) + 1
-        acc["bytes"] += 4.0 * n * p_loc if a.storage == "dense" else 0.25 * n * p_loc
+        acc["bytes"] += 4.0 * n_loc * p_loc if a.storage == "dense" else 0.25 * n_loc * p_loc
         s["bs"] = eng.block_size
         # 3-5. pi, marker-effect variance, residual variance (Pi.jl:7-42, variance_components.jl:60-112,151-189)
         if method == "BayesR":
@@ -322,6 +405,11 @@ def main():
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    per_rank_sweep_ms = [acc["sweep_ms"] / a.steps]
+    if world > 1:
+        box = [None] * world
+        torch.distributed.all_gather_object(box, per_rank_sweep_ms[0])
+        per_rank_sweep_ms = [float(v) for v in box]
     out = None
     if rank == 0:
         ms_per_step = 1e3 * elapsed / a.steps
@@ -351,12 +439,13 @@ def main():
         }[wl]
         out = {
             "metric": "MCMC iters/sec (full marker sweep)", "value": a.steps / elapsed, "unit": "iterations/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
+            "n_gpus": comm_world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "name": wl, "storage": a.storage,
                        "n": n, "p": p_total, "block_size": bs_now, "block_policy": "adaptive 512/1024" if adaptive else "fixed",
-                       "parallelism": f"marker-shard x{world}" if world > 1 else "single GPU",
-                       "device_sweep_ms": acc["sweep_ms"] / a.steps, "events_per_sweep": acc["events"] / a.steps,
+                       "parallelism": (f"{'row' if rows_mode else 'marker'}-shard x{world}" + (" (exact chain of the pooled data; one all-reduce of the block RHS per block launch)" if rows_mode else " (one all-reduce of the residual delta per sweep; residual resident in HBM)")) if world > 1 else "single GPU",
+                       "ranks_reported_by_communicator": comm_world,
+                       "device_sweep_ms": acc["sweep_ms"] / a.steps, "per_rank_device_sweep_ms": per_rank_sweep_ms, "events_per_sweep": acc["events"] / a.steps,
                        "markers_in_model": in_model, "setup_s": setup_s,
                        "chain_sweeps_before_timing": nburn + a.warmup},
             "roofline": {"bound": "hbm", "kernel": "k_block_step", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

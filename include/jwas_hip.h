@@ -240,6 +240,11 @@ int  jwas_hip_residual_dev(jwas_hip_ctx* ctx, void** r_dev, int64_t* ld_dev);
  * all-reduce of the residual delta. */
 int  jwas_hip_residual_to_dev(jwas_hip_ctx* ctx, int32_t trait, void* dst_dev);
 int  jwas_hip_residual_from_dev(jwas_hip_ctx* ctx, int32_t trait, const void* src_dev);
+/* r_k[i] = fl32(fl64(r_k[i]) + shift) for the n individuals: the residual correction of a location parameter whose design
+ * column is all ones (the intercept step of the host's single-site Gibbs pass, solver.jl:143-162) without a host copy of
+ * the residual -- with jwas_sweep_stats.resid_sum the intercept update needs no O(n) host traffic at all.  Asynchronous
+ * (ordered on the context's stream). */
+int  jwas_hip_residual_add_scalar(jwas_hip_ctx* ctx, int32_t trait, double shift);
 /* r_k -= X * alpha_k for the current device alpha (initial ycorr; sequential fmaf in marker order). */
 int  jwas_hip_residual_sub_xalpha(jwas_hip_ctx* ctx, int32_t trait);
 /* out = X * alpha_k (n floats, fp64-accumulated). */
@@ -295,6 +300,9 @@ int  jwas_hip_sweep(jwas_hip_ctx* ctx, const jwas_sweep_params* params, jwas_swe
 int  jwas_hip_comm_unique_id(void* id_out_128_bytes);
 int  jwas_hip_comm_init(jwas_hip_ctx* ctx, const void* unique_id_128_bytes, int32_t rank, int32_t world);
 int  jwas_hip_comm_destroy(jwas_hip_ctx* ctx);
+/* Rank and size of the attached communicator as the TRANSPORT reports them (ncclCommUserRank / ncclCommCount): what a
+ * host must report as its GPU count.  Without a communicator: rank 0 of 1. */
+int  jwas_hip_comm_info(jwas_hip_ctx* ctx, int32_t* rank, int32_t* world);
 int  jwas_hip_sweep_sharded(jwas_hip_ctx* ctx, const jwas_sweep_params* params, jwas_sweep_stats* stats);
 /* ---- exact ROW shards (SURVEY 8e "exact alternative"): every rank holds a slice of the individuals and ALL markers.
  * jwas_hip_comm_row_shards(ctx, 1) after jwas_hip_comm_init and BEFORE jwas_hip_setup_blocks: x'x, the block Grams and the

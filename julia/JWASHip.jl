@@ -8,7 +8,7 @@
 # jwas_sweep_params / jwas_sweep_stats.
 module JWASHip
 
-export HipBackend, HipSweepParams, HipSweepStats, hip_sweep!, hip_sweep_sharded!, hip_comm_unique_id, hip_comm_init!,
+export HipBackend, HipSweepParams, HipSweepStats, hip_sweep!, hip_sweep_sharded!, hip_comm_unique_id, hip_comm_init!, hip_comm_info, hip_residual_add_scalar!,
        hip_setup_blocks!, hip_set_residual!, hip_get_residual!, hip_accumulate!, hip_posterior, hip_mul_alpha, JWAS_HIP_BAYESC,
        JWAS_HIP_BAYESB, JWAS_HIP_BAYESR, JWAS_HIP_MTBAYESC1, JWAS_HIP_MTBAYESC2, JWAS_HIP_MEGABAYESC, JWAS_HIP_MTBAYESB1
 
@@ -102,6 +102,10 @@ hip_set_residual!(b::HipBackend, trait::Integer, r::Vector{Float32}) =
 hip_get_residual!(b::HipBackend, trait::Integer, r::Vector{Float32}) =
     hip_check(b.ctx, ccall((:jwas_hip_get_residual, LIBJWAS_HIP), Cint, (Ptr{Cvoid}, Int32, Ptr{Float32}), b.ctx, trait, r))
 
+"ycorr .+= shift on the device: the residual correction of an all-ones design column (intercept step, solver.jl:143-162)."
+hip_residual_add_scalar!(b::HipBackend, trait::Integer, shift::Real) =
+    hip_check(b.ctx, ccall((:jwas_hip_residual_add_scalar, LIBJWAS_HIP), Cint, (Ptr{Cvoid}, Int32, Cdouble), b.ctx, trait, shift))
+
 _z16(::Type{T}) where {T} = ntuple(_ -> zero(T), 16)
 
 "Parameters of a single-trait BayesC / BayesR sweep (the multi-trait samplers fill vare / var_effect / log_prior_states row-major)."
@@ -134,6 +138,13 @@ function hip_comm_unique_id()
 end
 hip_comm_init!(b::HipBackend, id::Vector{UInt8}, rank::Integer, world::Integer) =
     hip_check(b.ctx, ccall((:jwas_hip_comm_init, LIBJWAS_HIP), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Int32, Int32), b.ctx, id, rank, world))
+
+"(rank, world) of the attached communicator as RCCL reports them (ncclCommUserRank / ncclCommCount)."
+function hip_comm_info(b::HipBackend)
+    r, w = Ref{Int32}(0), Ref{Int32}(1)
+    hip_check(b.ctx, ccall((:jwas_hip_comm_info, LIBJWAS_HIP), Cint, (Ptr{Cvoid}, Ref{Int32}, Ref{Int32}), b.ctx, r, w))
+    return Int(r[]), Int(w[])
+end
 
 "Sweep of this rank's markers + on-device reconcile (one ncclAllReduce of delta r and the packed statistics, BayesABC.jl:205-253)."
 function hip_sweep_sharded!(b::HipBackend, P::HipSweepParams)

@@ -202,12 +202,15 @@ def get_genotypes(file, G=False, *, method="BayesC", Pi=0.0, estimatePi=True,
 
 def device_genotypes(engine, G=False, *, method="BayesC", Pi=0.0, estimatePi=True, G_is_marker_variance=False, df=4.0,
                      estimate_variance=True, estimate_scale=False, constraint=False, multi_trait_sampler="I",
-                     obsID=None, markerID=None, centered=True):
+                     obsID=None, markerID=None, centered=True, alleleFreq=None, sum2pq=None):
     """A Genotypes object over a matrix that is ALREADY resident on the GPU (loaded or generated through `engine`, a
     HipEngine) -- the device analogue of storage=:stream, where Genotypes carries a backend handle instead of the matrix
     (types.jl:149-150, readgenotypes.jl:236-295).  Like that mode: phenotype IDs must match the genotype IDs exactly and
-    in order, Float32 only.  sum2pq is taken from the device's x'x (x'x / n = 2pq for centred 0/1/2 genotypes); block
-    configurations already resident on the engine are used as they are."""
+    in order, Float32 only.  sum2pq / alleleFreq: pass them when they are known (impute_genotypes does; the reference
+    computes sum(2p(1-p)) from the column means before centring, readgenotypes.jl:385-402); otherwise they are derived from
+    the device's x'x, which is exact only for CENTRED 0/1/2 genotypes with unit residual weights (x'x / n = 2pq) -- an
+    uncentred or weighted resident matrix without explicit values is an error, not a silently wrong variance conversion.
+    Block configurations already resident on the engine are used as they are."""
     if method not in SUPPORTED_METHODS:
         raise NotImplementedError(f"method {method} is not on the device path (supported: {SUPPORTED_METHODS})")
     if multi_trait_sampler not in ("auto", "I", "II"):
@@ -217,10 +220,22 @@ def device_genotypes(engine, G=False, *, method="BayesC", Pi=0.0, estimatePi=Tru
         raise ValueError("the engine holds no genotype matrix")
     if engine.block_size == 0:
         engine.setup_blocks(512 if p > 512 else 64, "mfma")
-    xpx = engine.xpx().astype(np.float64)
-    sum2pq = float(xpx.sum() / n)
-    # allele frequency from 2pq = x'x / n (the smaller root); only marker-level-pi priors read it
-    af = (0.5 * (1.0 - np.sqrt(np.clip(1.0 - 2.0 * xpx / n, 0.0, 1.0)))).astype(np.float32)
+    if sum2pq is None or alleleFreq is None:
+        if not centered:
+            raise ValueError("device_genotypes(centered=False): x'x / n is 2pq + 4p^2 for an uncentred matrix; pass alleleFreq "
+                             "and sum2pq explicitly")
+        if getattr(engine, "_weighted", False):
+            raise ValueError("device_genotypes: the engine holds residual weights (x'x is x'R^-1 x); pass alleleFreq and "
+                             "sum2pq explicitly")
+        xpx = engine.xpx().astype(np.float64)
+        if sum2pq is None:
+            sum2pq = float(xpx.sum() / n)
+        if alleleFreq is None:      # allele frequency from 2pq = x'x / n (the smaller root); only marker-level-pi priors read it
+            alleleFreq = 0.5 * (1.0 - np.sqrt(np.clip(1.0 - 2.0 * xpx / n, 0.0, 1.0)))
+    af = np.asarray(alleleFreq, dtype=np.float32).reshape(-1)
+    if af.shape != (p,):
+        raise ValueError(f"alleleFreq must have one entry per marker ({p})")
+    sum2pq = float(sum2pq)
     g = Genotypes(obsID if obsID is not None else [str(i + 1) for i in range(n)],
                   markerID if markerID is not None else [str(j + 1) for j in range(p)], n, p, af, sum2pq, centered,
                   np.zeros((n, 0), dtype=np.float32))

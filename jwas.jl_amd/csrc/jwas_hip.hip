@@ -960,6 +960,26 @@ int jwas_hip_residual_from_dev(jwas_hip_ctx* c, int32_t trait, const void* src)
     return JWAS_HIP_OK;
 }
 
+// r_k[i] = fl32(fl64(r_k[i]) + shift) for the n individuals (pad rows stay zero): the residual correction of a location
+// parameter whose design column is all ones -- the intercept step of the host's Gibbs pass (solver.jl:143-162) without a
+// host copy of the residual.
+__global__ __launch_bounds__(256) void k_residual_add_scalar(float* __restrict__ r, int64_t n, double shift)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) r[i] = (float)((double)r[i] + shift);
+}
+
+int jwas_hip_residual_add_scalar(jwas_hip_ctx* c, int32_t trait, double shift)
+{
+    NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
+    NEED_TRAIT(c, trait);
+    HIPCHK(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_residual_add_scalar, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream,
+                       c->r + (size_t)trait * c->ld, c->n, shift);
+    HIPCHK(c, hipGetLastError());
+    return JWAS_HIP_OK;
+}
+
 int jwas_hip_residual_sub_xalpha(jwas_hip_ctx* c, int32_t trait)
 {
     NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
@@ -1174,8 +1194,9 @@ static hipError_t launch_step_cx(jwas_hip_ctx* c, const CX& cx, const UpdateArgs
     static_cast<UpdateArgs&>(U) = U0;
     U.cx = cx;
     const StepSmem SM(c->block_size, NT, is_mt_method(METHOD) ? mt_park_nd(c->block_size, NT) + (S.lpr_mat ? (1 << NT) : 0) : st_park_nd(METHOD), is_mt_method(METHOD) ? mt_park_nf(c->block_size, NT) + (METHOD == kMTBayesB1 ? NT * NT : 0) : st_park_nf(METHOD));
-    static bool attr_set = false;
-    if (!attr_set) {   // allow > 64 KB of dynamic LDS
+    static unsigned long long attr_set = 0ull;       // one bit per device: the attribute belongs to the device's code object
+    const unsigned long long dev_bit = 1ull << (c->device & 63);
+    if (!(attr_set & dev_bit)) {   // allow > 64 KB of dynamic LDS
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_block_step<METHOD, NT, CX, false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
@@ -1184,7 +1205,7 @@ static hipError_t launch_step_cx(jwas_hip_ctx* c, const CX& cx, const UpdateArgs
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
         }
-        attr_set = true;
+        attr_set |= dev_bit;
     }
     // JWAS_HIP_DEBUG_ROLE (timing experiments only; results are wrong): 1 = update role only, 2 = sampler only
     // Development builds only (build.sh -DJWAS_HIP_DEV_KNOBS): the shipped library never reads these -- they break results.
@@ -1248,12 +1269,13 @@ static hipError_t launch_indep_cx(jwas_hip_ctx* c, const CX& cx, const UpdateArg
     static_cast<UpdateArgs&>(U) = U0;
     U.cx = cx;
     const StepSmem SM(c->block_size, NT, is_mt_method(METHOD) ? mt_park_nd(c->block_size, NT) + (S.lpr_mat ? (1 << NT) : 0) : st_park_nd(METHOD), is_mt_method(METHOD) ? mt_park_nf(c->block_size, NT) + (METHOD == kMTBayesB1 ? NT * NT : 0) : st_park_nf(METHOD));
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_set = 0ull;       // one bit per device
+    const unsigned long long dev_bit = 1ull << (c->device & 63);
+    if (!(attr_set & dev_bit)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_indep_sample<METHOD, NT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set |= dev_bit;
     }
     const size_t red = sizeof(double) * kRowGroupSlices * kColChunk * NT;
     hipLaunchKernelGGL((k_indep_rhs<NT, CX>), dim3((unsigned)(U.nrg * U.ncg), (unsigned)c->nblocks), dim3(kStepThreads), red, c->stream,
@@ -1339,6 +1361,8 @@ struct Rccl {
     int (*CommDestroy)(void*) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
+    int (*CommCount)(void*, int*) = nullptr;
+    int (*CommUserRank)(void*, int*) = nullptr;
     std::string err;
     bool load()
     {
@@ -1357,7 +1381,9 @@ struct Rccl {
         CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
         AllReduce = reinterpret_cast<decltype(AllReduce)>(dlsym(lib, "ncclAllReduce"));
         GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
-        if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllReduce || !GetErrorString) { err = "librccl.so lacks the NCCL entry points"; lib = nullptr; return false; }
+        CommCount = reinterpret_cast<decltype(CommCount)>(dlsym(lib, "ncclCommCount"));
+        CommUserRank = reinterpret_cast<decltype(CommUserRank)>(dlsym(lib, "ncclCommUserRank"));
+        if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllReduce || !GetErrorString || !CommCount || !CommUserRank) { err = "librccl.so lacks the NCCL entry points"; lib = nullptr; return false; }
         return true;
     }
 };
@@ -1622,6 +1648,12 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
     HIPCHK(c, hipMemsetAsync(&c->ev[1].count, 0, sizeof(int32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(c->sync_cnt, 0, sizeof(int) * 2 * c->nrg, c->stream));      // (launch parity restarts with the sweep)
     HIPCHK(c, hipMemsetAsync(c->corr, 0, sizeof(float) * 2 * kMaxT * (size_t)bs, c->stream));   // block 0 has no predecessor
+    // dense sweeps (a quarter of the markers or more changed in the previous one; JWAS_HIP_COOP_APPLY=0|1 overrides):
+    // the update role's column groups share the work of applying a block's changes (update_role).  The knob is read
+    // once per sweep (the tests switch it between sweeps of one process).
+    const char* efc = std::getenv("JWAS_HIP_COOP_APPLY");
+    const int fc = efc ? std::atoi(efc) : -1;
+    const bool coop = c->sync_cnt != nullptr && (fc >= 0 ? fc != 0 : c->last_events > 0.25 * (double)c->p);
     for (int64_t k = 0; k <= nb; ++k) {
         UpdateArgs U;
         U.r_in = c->r + ((k + 1) & 1) * rstride; U.r_out = c->r + (k & 1) * rstride;
@@ -1632,15 +1664,8 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
         U.ncg = (U.b > 0 && c->ncg > U.b) ? U.b : c->ncg;
         U.partials = c->partials + (k & 1) * pstride; U.bstride = bs;
         U.dbg = c->counters;
-        // dense sweeps (a quarter of the markers or more changed in the previous one; JWAS_HIP_COOP_APPLY=0|1 overrides):
-        // the update role's column groups share the work of applying a block's changes (update_role)
-        {
-            const char* efc = std::getenv("JWAS_HIP_COOP_APPLY");        // (read per launch: the tests switch it inside one process)
-            const int fc = efc ? std::atoi(efc) : -1;
-            const bool coop = c->sync_cnt != nullptr && (fc >= 0 ? fc != 0 : c->last_events > 0.25 * (double)c->p);
-            U.sync_now = coop ? c->sync_cnt + (k & 1) * c->nrg : nullptr;
-            U.sync_next = coop ? c->sync_cnt + ((k + 1) & 1) * c->nrg : nullptr;
-        }
+        U.sync_now = coop ? c->sync_cnt + (k & 1) * c->nrg : nullptr;
+        U.sync_next = coop ? c->sync_cnt + ((k + 1) & 1) * c->nrg : nullptr;
         {   // Placement heuristic (speed only): keep XCD 0 free of streaming traffic for the sampler while the sampler chain
             // is the critical path (many changes per sweep); in the steady state the sampler has slack and all 8 XCDs
             // stream (+4-5 % bandwidth).  Decided from the previous sweep's change count; JWAS_HIP_QUIET_XCD=0|1 overrides.
@@ -1824,6 +1849,24 @@ int jwas_hip_comm_init(jwas_hip_ctx* c, const void* unique_id_128, int32_t rank,
     c->comm_rank = rank; c->comm_world = world;
     HIPCHK(c, hipMalloc(&c->r_snap, sizeof(float) * (size_t)kMaxT * c->ld));
     HIPCHK(c, hipMalloc(&c->shard_buf, sizeof(double) * ((size_t)kMaxT * c->ld + kShardStats)));
+    return JWAS_HIP_OK;
+}
+
+// Rank and size of the attached communicator AS THE TRANSPORT REPORTS THEM (ncclCommUserRank / ncclCommCount; the loopback
+// transport reports what it was created with): a host that prints "N GPUs" checks it against this, not against its own
+// launch arguments.  No communicator: rank 0 of 1.
+int jwas_hip_comm_info(jwas_hip_ctx* c, int32_t* rank, int32_t* world)
+{
+    NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
+    int r = 0, w = 1;
+    if (c->comm) {
+        int e = g_rccl.CommCount(c->comm, &w);
+        NEED(c, e == 0, JWAS_HIP_EHIP, "ncclCommCount: %s", g_rccl.GetErrorString(e));
+        e = g_rccl.CommUserRank(c->comm, &r);
+        NEED(c, e == 0, JWAS_HIP_EHIP, "ncclCommUserRank: %s", g_rccl.GetErrorString(e));
+    } else if (c->loop_slot >= 0) { r = c->comm_rank; w = c->comm_world; }
+    if (rank) *rank = r;
+    if (world) *world = w;
     return JWAS_HIP_OK;
 }
 

@@ -34,6 +34,35 @@ def shard_range(p_total, rank, world, align=1):
     return min(lo_u * align, p_total), min(hi_u * align, p_total)
 
 
+def _attach_library_comm(engine, rank, world, group, dev):
+    """Create the library's RCCL communicator on every rank, or on none.  ncclCommInitRank is collective, so the ranks
+    first agree on a NON-collective probe (can this rank bind librccl at all: jwas_hip_comm_unique_id does the dlopen and
+    a local ncclGetUniqueId) and only enter comm_init when every rank can; a rank that fails afterwards raises (a hang
+    would be the alternative).  JWAS_DIST_TORCH_RECONCILE=1 forces the torch.distributed reconcile."""
+    import os
+    import torch
+    import torch.distributed as dist
+    ok = 0
+    if os.environ.get("JWAS_DIST_TORCH_RECONCILE", "0") == "0":
+        try:
+            engine.comm_unique_id()
+            ok = 1
+        except Exception as ex:                  # noqa: BLE001  (e.g. librccl.so not loadable)
+            print(f"[jwas] library RCCL communicator not available on rank {rank} ({ex}); "
+                  "falling back to the torch.distributed reconcile")
+    flag = torch.tensor([ok], device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    if not int(flag.item()):
+        return False
+    box = [engine.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    engine.comm_init(box[0], rank, world)
+    r, w = engine.comm_info()
+    if (r, w) != (rank, world):
+        raise RuntimeError(f"RCCL communicator reports rank {r} of {w}, expected rank {rank} of {world}")
+    return True
+
+
 class MarkerShard:
     """Wraps one rank's sweep engine (its marker shard already loaded) and reconciles after a sweep."""
 
@@ -54,21 +83,7 @@ class MarkerShard:
                 if hasattr(engine, "comm_init"):
                     # the reconcile runs inside the library (jwas_hip_sweep_sharded: pack kernel, ncclAllReduce on the
                     # context's stream, apply kernel); torch.distributed only hands the 128-byte RCCL id around
-                    import os
-                    ok = 0
-                    if os.environ.get("JWAS_DIST_TORCH_RECONCILE", "0") == "0":
-                        try:
-                            box = [engine.comm_unique_id() if self.rank == 0 else None]
-                            dist.broadcast_object_list(box, src=0, group=group)
-                            engine.comm_init(box[0], self.rank, self.world)
-                            ok = 1
-                        except Exception as ex:                  # noqa: BLE001  (e.g. librccl.so not loadable)
-                            print(f"[jwas] library RCCL communicator not available on rank {self.rank} ({ex}); "
-                                  "falling back to the torch.distributed reconcile")
-                    # every rank must take the same path
-                    flag = torch.tensor([ok], device=self._dev)
-                    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-                    self._lib_comm = bool(int(flag.item()))
+                    self._lib_comm = _attach_library_comm(engine, self.rank, self.world, group, self._dev)
 
     def allreduce_sum(self, arr):
         """Sum a numpy array over ranks (deterministic: every rank receives the same bits)."""
@@ -79,6 +94,25 @@ class MarkerShard:
             t = t.to(self._dev)
         self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group)
         return t.cpu().numpy()
+
+    def sweep_resident(self, **params):
+        """One sweep + reconcile with the residual RESIDENT on the device: the engine's current residual is the replicated
+        snapshot, and on return it holds the reconciled one (jwas_hip_sweep_sharded does all of it on the context's
+        stream).  Returns the all-rank statistics (resid_sum / resid_ss of the reconciled residual included), which is all
+        a host with an intercept-only location step needs (engine.residual_add_scalar applies its correction)."""
+        eng = self.engine
+        if self._lib_comm:
+            return eng.sweep_sharded(marker_offset=self.lo, **params)
+        if not self._coll:
+            return eng.sweep(marker_offset=self.lo, **params)
+        snap = np.stack([eng.get_residual(k) for k in range(eng.ntraits)])      # (gloo / torch reconcile: through the host)
+        return self.sweep(snap, **params)[1]
+
+    def comm_world(self):
+        """Number of ranks the transport itself reports (ncclCommCount for the library communicator)."""
+        if self._lib_comm:
+            return self.engine.comm_info()[1]
+        return self._dist.get_world_size(self.group) if self._coll else 1
 
     def sweep(self, r_snapshot, **params):
         """r_snapshot: t x n float32 (replicated).  Returns (r_new t x n, stats) after reconcile.
@@ -151,3 +185,51 @@ class MarkerShard:
         r_new = r_dev.cpu().numpy()
         self._unpack(st, buf[t * n:].cpu().numpy(), r_new)
         return r_new, st
+
+
+class RowShard:
+    """Exact row shards (the "exact alternative"; jwas_hip_comm_row_shards): rank g holds a slice
+    of the INDIVIDUALS and all markers.  x'x, the block Grams and the cross-Grams are summed over the ranks at setup, every
+    block's partial right-hand side X_b'r is summed over the ranks (one small ncclAllReduce per block launch on the
+    context's stream) before its sampler runs -- replicated, on identical inputs -- so every rank holds the same effects
+    and its own slice of the residual: engine.sweep IS the exact chain of the pooled data.
+
+    Create it AFTER the rank's rows are loaded and BEFORE setup_blocks; every rank needs the same number of 256-row
+    groups (pad the shorter slices with zero rows).  torch.distributed only hands the 128-byte RCCL id around."""
+
+    def __init__(self, engine, rank, world, group=None):
+        import torch
+        import torch.distributed as dist
+        self.engine, self.rank, self.world, self.group = engine, int(rank), int(world), group
+        self._torch, self._dist = torch, dist
+        self._dev = None
+        if dist.is_initialized():
+            if dist.get_backend(group) != "nccl":
+                raise RuntimeError("row shards exchange every block's right-hand side through RCCL on the device: they need the nccl backend")
+            self._dev = torch.device("cuda", torch.cuda.current_device())
+            box = [engine.comm_unique_id() if self.rank == 0 else None]
+            dist.broadcast_object_list(box, src=0, group=group)
+            uid = box[0]
+        else:
+            if self.world != 1:
+                raise RuntimeError("row shards over more than one rank need an initialised torch.distributed process group")
+            uid = engine.comm_unique_id()
+        engine.comm_init(uid, self.rank, self.world)
+        r, w = engine.comm_info()
+        if (r, w) != (self.rank, self.world):
+            raise RuntimeError(f"RCCL communicator reports rank {r} of {w}, expected rank {self.rank} of {self.world}")
+        engine.comm_row_shards(True)
+
+    def comm_world(self):
+        return self.engine.comm_info()[1]
+
+    def allreduce_sum(self, arr):
+        if self._dev is None:
+            return arr
+        t = self._torch.from_numpy(np.ascontiguousarray(arr)).to(self._dev)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group)
+        return t.cpu().numpy()
+
+    def sweep_resident(self, **params):
+        """engine.sweep on the pooled data: marker statistics replicated, r'r and sum(r) pooled over the ranks."""
+        return self.engine.sweep(**params)

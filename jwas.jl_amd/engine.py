@@ -44,6 +44,8 @@ class HipEngine:
         self.ntraits = 0
         self.block_size = 0
         self._keep = []   # host arrays referenced by the last sweep call
+        self._weighted = False          # non-unit residual weights on the device (set_weights)
+        self._explicit_starts = None    # explicit block partition resident (setup_blocks_explicit)
 
     # -- plumbing --------------------------------------------------------------------------------
     def _chk(self, rc):
@@ -141,6 +143,7 @@ class HipEngine:
             if w.shape != (self.n,):
                 raise ValueError(f"one weight per individual is required ({self.n}), got {w.shape}")
             self._chk(self._L.jwas_hip_set_weights(self._h, _ptr(w)))
+        self._weighted = rinv is not None
         self.block_size = 0
 
     def synth(self, seed, kind=0, center=True, marker_offset=0):
@@ -307,6 +310,10 @@ class HipEngine:
     def residual_from_dev(self, src_ptr, trait=0):
         self._chk(self._L.jwas_hip_residual_from_dev(self._h, int(trait), C.c_void_p(int(src_ptr))))
 
+    def residual_add_scalar(self, shift, trait=0):
+        """r_trait += shift on the device (the intercept's residual correction; no host copy of the residual)."""
+        self._chk(self._L.jwas_hip_residual_add_scalar(self._h, int(trait), float(shift)))
+
     def set_kernel_timing(self, stride):
         self._chk(self._L.jwas_hip_set_kernel_timing(self._h, int(stride)))
 
@@ -392,6 +399,12 @@ class HipEngine:
         buf = C.create_string_buffer(bytes(unique_id), 128)
         self._chk(self._L.jwas_hip_comm_init(self._h, C.cast(buf, C.c_void_p), int(rank), int(world)))
         self._comm = True
+
+    def comm_info(self):
+        """(rank, world) of the attached communicator as RCCL reports them (ncclCommUserRank / ncclCommCount)."""
+        r, w = C.c_int32(0), C.c_int32(1)
+        self._chk(self._L.jwas_hip_comm_info(self._h, C.byref(r), C.byref(w)))
+        return r.value, w.value
 
     def comm_row_shards(self, enable=True):
         """Exact ROW shards (jwas_hip_comm_row_shards): this rank holds a slice of the individuals and all markers; call

@@ -438,18 +438,25 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
             raise ValueError("fast_blocks block size must be at least 1.")
         if want >= p:                                                   # range(1, step=want, stop=p) has one start
             raise ValueError("fast_blocks block size must create at least two block starts.")
-        # The schedule is the reference's for the REQUESTED size: `want` within-block repetitions (BayesABC.jl:153) and
-        # chain_length / want outer iterations -- the same number of hyper-parameter updates and saved samples.  The
-        # device partition is uniform blocks of the NEAREST supported size (64 ... 1024; it may be smaller than `want`,
-        # e.g. 90 -> 64; any partition is an exact block Gibbs sampler); fewer markers than one device block run as a
-        # single block.  Deviation from the reference: every device block runs `want` repetitions, where the reference
-        # runs each block its own size (the last, shorter block fewer) -- DESIGN.md section 12.
-        block_size = _supported_block(want)
+        # The schedule AND the partition are the reference's (JWAS.jl:308-312): block starts collect(range(1, step=want,
+        # stop=p)), every block repeated its own size (BayesABC.jl:153: the last, shorter block fewer times), and
+        # chain_length / want outer iterations -- the same number of hyper-parameter updates and saved samples.
+        #   * `want` is one of the device's uniform block sizes (64 ... 1024): the uniform layout IS that partition
+        #     (nreps <= 0 = every block its own size);
+        #   * any other size <= 1024: the ragged-partition form (jwas_hip_setup_blocks_explicit) with those starts;
+        #   * more than 1024 markers per block do not fit the sampler's LDS plan: an explicit error;
+        #   * independent_blocks on a size that is not a device size: uniform device blocks of the nearest supported size
+        #     with `want` repetitions each (independent blocks are the reference's own approximation).
         if not explicit_starts:
             chain_length = int(np.floor(chain_length / want))
-        nreps = want
+        if want > max(DEVICE_BLOCK_SIZES) and not (explicit_partition is None and independent_blocks):
+            raise NotImplementedError(f"fast_blocks blocks hold at most {max(DEVICE_BLOCK_SIZES)} markers on the device (got {want})")
+        if explicit_partition is None and want not in DEVICE_BLOCK_SIZES and not independent_blocks:
+            explicit_partition = np.arange(0, p, want, dtype=np.int64)          # = collect(range(1, step=want, stop=p)) - 1
+            sizes = [want] * (len(explicit_partition) - 1) + [p - int(explicit_partition[-1])]
+        block_size = _supported_block(want)
+        nreps = want if (explicit_partition is None and want not in DEVICE_BLOCK_SIZES) else 0   # 0: every block its own size
         if explicit_partition is not None:
-            nreps = 0                                                   # every block its own size (jwas_sweep_params.nreps <= 0)
             while block_size < want:
                 block_size *= 2
             print(f"BLOCK STARTS: {len(explicit_partition)} blocks of {min(sizes)}..{max(sizes)} markers")
@@ -507,11 +514,14 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         engine.load_dense(X)                   # after alignment (tools4genotypes.jl:310-321)
     if outputEBV and not out_same:             # Mi.output_genotypes = Z_out * genotypes (tools4genotypes.jl:290-296)
         engine.load_output_dense(np.asfortranarray(Mi.genotypes[out_rows, :]))
-    if invw is not None:
+    # A device-resident engine may come from an earlier run: its weights, Grams and block partition must be THIS run's.
+    # set_weights(None) restores unit weights (and drops the resident Grams, which were X_b'R^-1 X_b); an explicit
+    # partition left by the previous run is rebuilt as uniform blocks below.
+    if invw is not None or getattr(engine, "_weighted", False):
         engine.set_weights(invw)               # x'R^-1 x, X_b'R^-1 X_b, X_b'R^-1 r on the device (GibbsMats with Rinv)
     if explicit_partition is not None:
         engine.setup_blocks_explicit(explicit_partition, gram_mode)
-    elif devres and invw is None and engine.block_size:
+    elif devres and invw is None and engine.block_size and getattr(engine, "_explicit_starts", None) is None:
         resident = set(engine.resident_block_sizes())
         if block_size not in resident:
             engine.add_block_size(block_size, gram_mode)
@@ -619,193 +629,196 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         _blas_limit = None
     t0 = time.time()
     # ================================ the chain =================================================
-    for it in range(1, chain_length + 1):
-        # 1. location parameters (host)
-        if sum(q):
-            if t == 1:
-                r = engine.get_residual(0).astype(np.float64)
-                r += Xf[0] @ sol
-                rhs = Xf[0].T @ (w64 * r)                               # MCMC_BayesianAlphabet.jl:211
-                _gibbs(lhs, sol, rhs, rng, float(vare))
-                r -= Xf[0] @ sol
-                engine.set_residual(r.astype(np.float32), 0)
-            else:
-                R0 = np.asarray(vare, dtype=np.float64)
-                Rinv = np.linalg.inv(R0)
+    try:
+        for it in range(1, chain_length + 1):
+            # 1. location parameters (host)
+            if sum(q):
+                if t == 1:
+                    r = engine.get_residual(0).astype(np.float64)
+                    r += Xf[0] @ sol
+                    rhs = Xf[0].T @ (w64 * r)                               # MCMC_BayesianAlphabet.jl:211
+                    _gibbs(lhs, sol, rhs, rng, float(vare))
+                    r -= Xf[0] @ sol
+                    engine.set_residual(r.astype(np.float32), 0)
+                else:
+                    R0 = np.asarray(vare, dtype=np.float64)
+                    Rinv = np.linalg.inv(R0)
+                    res = [engine.get_residual(k).astype(np.float64) for k in range(t)]
+                    Ri_rows = _impute_missing_residuals(res, observed, R0, rng) if has_missing else None
+                    if has_missing and (it == 1 or not R.estimate_variance):
+                        # Residuals of the missing records are imputed from the observed ones every iteration
+                        # (sampleMissingResiduals, residual.jl:52-73).  The location-parameter equations weight every record
+                        # with the inverse of the OBSERVED block of R only (mkRi / getRi, residual.jl:2-44) -- but only until
+                        # the first residual-variance draw: the reference then replaces Ri by kron(inv(R), diag(invweights))
+                        # (MCMC_BayesianAlphabet.jl:357-361) and runs plain data augmentation on the imputed residuals.
+                        if invw is not None:
+                            Ri_rows = Ri_rows * w64[:, None, None]
+                        rr = [res[k] + Xf[k] @ sol[off[k]:off[k + 1]] for k in range(t)]
+                        A = np.block([[Xf[k].T @ (Ri_rows[:, k, l][:, None] * Xf[l]) for l in range(t)] for k in range(t)])
+                        b = np.concatenate([Xf[k].T @ sum(Ri_rows[:, k, l] * rr[l] for l in range(t)) for k in range(t)])
+                    else:
+                        rr = [res[k] + Xf[k] @ sol[off[k]:off[k + 1]] for k in range(t)]
+                        A = np.block([[Rinv[k, l] * lhs_blocks[k][l] for l in range(t)] for k in range(t)])
+                        b = np.concatenate([Xf[k].T @ (w64 * sum(Rinv[k, l] * rr[l] for l in range(t))) for k in range(t)])
+                    _gibbs(A, sol, b, rng, None)
+                    for k in range(t):
+                        engine.set_residual((rr[k] - Xf[k] @ sol[off[k]:off[k + 1]]).astype(np.float32), k)
+
+            elif t > 1 and has_missing:                                       # no location parameters: imputation only
                 res = [engine.get_residual(k).astype(np.float64) for k in range(t)]
-                Ri_rows = _impute_missing_residuals(res, observed, R0, rng) if has_missing else None
-                if has_missing and (it == 1 or not R.estimate_variance):
-                    # Residuals of the missing records are imputed from the observed ones every iteration
-                    # (sampleMissingResiduals, residual.jl:52-73).  The location-parameter equations weight every record
-                    # with the inverse of the OBSERVED block of R only (mkRi / getRi, residual.jl:2-44) -- but only until
-                    # the first residual-variance draw: the reference then replaces Ri by kron(inv(R), diag(invweights))
-                    # (MCMC_BayesianAlphabet.jl:357-361) and runs plain data augmentation on the imputed residuals.
-                    if invw is not None:
-                        Ri_rows = Ri_rows * w64[:, None, None]
-                    rr = [res[k] + Xf[k] @ sol[off[k]:off[k + 1]] for k in range(t)]
-                    A = np.block([[Xf[k].T @ (Ri_rows[:, k, l][:, None] * Xf[l]) for l in range(t)] for k in range(t)])
-                    b = np.concatenate([Xf[k].T @ sum(Ri_rows[:, k, l] * rr[l] for l in range(t)) for k in range(t)])
-                else:
-                    rr = [res[k] + Xf[k] @ sol[off[k]:off[k + 1]] for k in range(t)]
-                    A = np.block([[Rinv[k, l] * lhs_blocks[k][l] for l in range(t)] for k in range(t)])
-                    b = np.concatenate([Xf[k].T @ (w64 * sum(Rinv[k, l] * rr[l] for l in range(t))) for k in range(t)])
-                _gibbs(A, sol, b, rng, None)
+                _impute_missing_residuals(res, observed, np.asarray(vare, dtype=np.float64), rng)
                 for k in range(t):
-                    engine.set_residual((rr[k] - Xf[k] @ sol[off[k]:off[k + 1]]).astype(np.float32), k)
+                    engine.set_residual(res[k].astype(np.float32), k)
 
-        elif t > 1 and has_missing:                                       # no location parameters: imputation only
-            res = [engine.get_residual(k).astype(np.float64) for k in range(t)]
-            _impute_missing_residuals(res, observed, np.asarray(vare, dtype=np.float64), rng)
-            for k in range(t):
-                engine.set_residual(res[k].astype(np.float32), k)
-
-        # 2. marker effects (DEVICE)
-        kw = dict(iteration=it, seed=seed_int, vare=vare, nreps=nreps)
-        if independent_blocks:
-            kw["independent_blocks"] = True
-        if mega:
-            kw.update(var_effect=Gval, pi=pi_t)
-        elif t > 1:
-            with np.errstate(divide="ignore"):
-                kw.update(var_effect=Gval, log_prior_states=np.log(ann.snp_pi if ann is not False else np.asarray(pi, dtype=np.float64)))
-            if mt_pervar:
-                kw["var_effect_matrix"] = Gmat
-        elif method == "BayesR":
-            kw.update(var_effect=Gval, pi_classes=np.asarray(pi, dtype=np.float64))
-            if ann is not False:
-                kw["pi_matrix"] = ann.snp_pi                            # per-marker class priors (BayesR.jl:62-66)
-            if fast_blocks is not False:                                # bayesr_block_nreps (BayesR.jl:22-25)
-                kw["nreps"] = 1 if it <= burnin else nreps
-        elif method == "BayesB":
-            kw.update(var_effect=Gval, var_effect_vec=Gvec, pi=pi)
-        elif np.ndim(pi) == 1:                                          # marker-level pi (bayesabc_pi_vector, BayesABC.jl:16-22)
-            kw.update(var_effect=Gval, pi_vec=pi)
-        else:
-            kw.update(var_effect=Gval, pi=pi)
-        st = engine.sweep(**kw)
-        t_sweep += st["sweep_ms"]
-        if adaptive:
-            engine.select_block_size(pick_block_size(st["n_events"], p))
-
-        # 3. pi (Pi.jl:7-42)
-        if Mi.estimatePi:
-            if mega:                                                    # MCMC_BayesianAlphabet.jl:300-301
-                pi_t = np.array([rng.beta(p - st["sum_delta"][k] + 1.0, st["sum_delta"][k] + 1.0) for k in range(t)])
-            elif t > 1 and ann is not False:                            # annotation_updates.jl:353-361
-                pi = A_.update_bayesc_mt_tree_priors(ann, engine.get_state(0)[2], engine.get_state(1)[2], rng)
+            # 2. marker effects (DEVICE)
+            kw = dict(iteration=it, seed=seed_int, vare=vare, nreps=nreps)
+            if independent_blocks:
+                kw["independent_blocks"] = True
+            if mega:
+                kw.update(var_effect=Gval, pi=pi_t)
             elif t > 1:
-                pi = rng.dirichlet(st["state_counts"] + 1.0)
-            elif ann is not False:                                      # update_marker_annotation_priors! (annotation_updates.jl:328-351)
-                dlt = engine.get_state(0)[2]
-                pi = A_.update_bayesr_nested_priors(ann, dlt, rng) if method == "BayesR" else A_.update_bayesc_binary_priors(ann, dlt, rng)
+                with np.errstate(divide="ignore"):
+                    kw.update(var_effect=Gval, log_prior_states=np.log(ann.snp_pi if ann is not False else np.asarray(pi, dtype=np.float64)))
+                if mt_pervar:
+                    kw["var_effect_matrix"] = Gmat
             elif method == "BayesR":
-                pi = rng.dirichlet(st["class_counts"] + 1.0)
-            else:
-                pi = float(rng.beta(p - st["sum_delta"][0] + 1.0, st["sum_delta"][0] + 1.0))
-
-        # 4. marker effect variance (variance_components.jl:151-189), re-cast to Float32 (:323-325)
-        if Mi.G.estimate_variance:
-            if mega:                                                    # diagonal only (variance_components.jl:104-109)
-                Gval = np.diag([(st["beta_ss"][k, k] + Gdf * Mi.G.scale[k, k]) / rng.chisquare(p + Gdf) for k in range(t)]).astype(np.float32)
-            elif mt_pervar:                                             # variance_components.jl:181-186: one draw per marker,
-                B = np.stack([engine.get_state(k)[1] for k in range(t)], axis=1).astype(np.float64)     # IW(df + 1, scale + b_j b_j')
-                Gmat = _inverse_wishart_batch(rng, Gdf + 1.0, np.asarray(Mi.G.scale, dtype=np.float64)[None] + B[:, :, None] * B[:, None, :]).astype(np.float32)
-            elif t > 1:
-                from scipy.stats import invwishart
-                S = np.asarray(Mi.G.scale, dtype=np.float64) + st["beta_ss"]
-                Gval = np.asarray(invwishart.rvs(df=Gdf + p, scale=(S + S.T) / 2, random_state=rng), dtype=np.float32).reshape(t, t)
-            elif method == "BayesR":
-                Gval = np.float32((st["bayesr_ssq"] + Gdf * Mi.G.scale) / rng.chisquare(st["bayesr_nnz"] + Gdf))
-            elif lasso:                                                 # variance_components.jl:152-166,191-203
-                a64 = engine.get_state(0)[0].astype(np.float64)
-                Gval = np.float32((np.dot(a64 / gamma_l, a64) + Gdf * Mi.G.scale) / rng.chisquare(p + Gdf))
-                Q = a64 * a64 / np.float64(Gval)
-                cand = 1.0 / rng.gamma(0.5, 4.0, size=p)
-                with np.errstate(over="ignore"):
-                    accept = rng.random(p) < np.exp(Q / 4.0 * (2.0 / gamma_l - cand))
-                gamma_l[accept] = 2.0 / cand[accept]
-                Gvec = (np.float64(Gval) * gamma_l).astype(np.float32)
+                kw.update(var_effect=Gval, pi_classes=np.asarray(pi, dtype=np.float64))
+                if ann is not False:
+                    kw["pi_matrix"] = ann.snp_pi                            # per-marker class priors (BayesR.jl:62-66)
+                if fast_blocks is not False:                                # bayesr_block_nreps (BayesR.jl:22-25)
+                    kw["nreps"] = 1 if it <= burnin else nreps
             elif method == "BayesB":
-                beta = engine.get_state(0)[1].astype(np.float64)
-                Gvec = ((beta * beta + Gdf * Mi.G.scale) / rng.chisquare(1.0 + Gdf, size=p)).astype(np.float32)
+                kw.update(var_effect=Gval, var_effect_vec=Gvec, pi=pi)
+            elif np.ndim(pi) == 1:                                          # marker-level pi (bayesabc_pi_vector, BayesABC.jl:16-22)
+                kw.update(var_effect=Gval, pi_vec=pi)
             else:
-                Gval = np.float32((np.float32(st["alpha_ss"][0, 0]) + Gdf * Mi.G.scale) / rng.chisquare(st["sum_delta"][0] + Gdf))
+                kw.update(var_effect=Gval, pi=pi)
+            st = engine.sweep(**kw)
+            t_sweep += st["sweep_ms"]
+            if adaptive:
+                engine.select_block_size(pick_block_size(st["n_events"], p))
 
-        # 4b. scale of the marker-effect variance prior (MCMC_BayesianAlphabet.jl:328-336; single trait only there too)
-        if Mi.G.estimate_scale and t == 1:
-            gv = Gvec.astype(np.float64) if pervar else np.atleast_1d(np.float64(Gval))
-            Mi.G.scale = float(rng.gamma(gv.size * Gdf / 2 + 1, 1.0 / (np.sum(Gdf / (2 * gv)) + 1)))
-
-        # 5. residual variance (variance_components.jl:60-66,82-112), re-cast to Float32 (:368-370)
-        if R.estimate_variance:
-            if t > 1 and R.constraint:                                  # variance_components.jl:104-109
-                vare = np.diag([(st["resid_ss"][k, k] + Rdf * R.scale[k, k]) / rng.chisquare(n + Rdf) for k in range(t)]).astype(np.float32)
-            elif t > 1:
-                from scipy.stats import invwishart
-                S = np.asarray(R.scale, dtype=np.float64) + st["resid_ss"]
-                vare = np.asarray(invwishart.rvs(df=Rdf + n, scale=(S + S.T) / 2, random_state=rng), dtype=np.float32).reshape(t, t)
-            else:
-                vare = np.float32((np.float32(st["resid_ss"][0, 0]) + Rdf * R.scale) / rng.chisquare(n + Rdf))
-
-        # 6. save (MCMC_BayesianAlphabet.jl:399-413, output.jl:443-604)
-        if it > burnin and (it - burnin) % output_samples_frequency == 0:
-            k = (it - burnin) / output_samples_frequency
-            run_sol.add(sol, k)
-            run_vare.add(vare, k)
-            if run_varg is not None:
-                run_varg.add(Gval, k)
-            if run_pi is not None:
-                run_pi.add(np.atleast_1d(pi_t if mega else pi), k)
-            engine.accumulate(k)
-            if run_scale is not None:
-                run_scale.add(np.atleast_1d(np.float64(Mi.G.scale)), k)
-            if ann is not False:
-                A_.accumulate(ann, k)
-            for key_, cols in term_cols.items():
-                files[key_].write(",".join(repr(float(sol[c])) for c in cols) + "\n")
-            files["residual_variance"].write(",".join(repr(float(v)) for v in np.atleast_1d(vare).ravel()) + "\n")
-            if not pervar:
-                files[f"marker_effects_variances_{name}"].write(",".join(repr(float(v)) for v in np.atleast_1d(Gval).ravel()) + "\n")
-            if Mi.estimatePi and f"pi_{name}" in files:
-                files[f"pi_{name}"].write(",".join(repr(float(v)) for v in np.atleast_1d(pi_t if mega else pi)) + "\n")
-            for kk, tr in enumerate(model.lhsVec):
-                if hasattr(engine, "alpha_sparse"):
-                    si, sv = engine.alpha_sparse(kk)              # (idx, val) compacted on the device
+            # 3. pi (Pi.jl:7-42)
+            if Mi.estimatePi:
+                if mega:                                                    # MCMC_BayesianAlphabet.jl:300-301
+                    pi_t = np.array([rng.beta(p - st["sum_delta"][k] + 1.0, st["sum_delta"][k] + 1.0) for k in range(t)])
+                elif t > 1 and ann is not False:                            # annotation_updates.jl:353-361
+                    pi = A_.update_bayesc_mt_tree_priors(ann, engine.get_state(0)[2], engine.get_state(1)[2], rng)
+                elif t > 1:
+                    pi = rng.dirichlet(st["state_counts"] + 1.0)
+                elif ann is not False:                                      # update_marker_annotation_priors! (annotation_updates.jl:328-351)
+                    dlt = engine.get_state(0)[2]
+                    pi = A_.update_bayesr_nested_priors(ann, dlt, rng) if method == "BayesR" else A_.update_bayesc_binary_priors(ann, dlt, rng)
+                elif method == "BayesR":
+                    pi = rng.dirichlet(st["class_counts"] + 1.0)
                 else:
-                    a_ = engine.get_state(kk)[0]
-                    si = np.flatnonzero(a_).astype(np.int32); sv = a_[si]
-                bin_writers[kk].append(si, sv)
-                if write_marker_samples:
-                    a = np.zeros(p, dtype=np.float32)
-                    a[si] = sv
-                    fh = files[f"marker_effects_{name}_{tr}"]
-                    a.tofile(fh, sep=",", format="%.9g")          # text at C speed; 9 significant digits round-trip Float32
-                    fh.write("\n")
-            if outputEBV:
-                ebvs = [engine.mul_alpha(kk) if out_same else engine.mul_alpha_output(kk) for kk in range(t)]   # getEBV, output.jl:281-306
-                for kk in range(t):
-                    ebv_run[kk].add(ebvs[kk], k)
-                if heritability:                                        # output.jl:498-512
-                    E = np.stack(ebvs, axis=1).astype(np.float64)
-                    gv = np.atleast_2d(np.cov(E, rowvar=False))
-                    if t > 1 and Mi.G.constraint:
-                        gv = np.diag(np.diag(gv))
-                    vr = np.atleast_2d(np.asarray(vare, dtype=np.float64))
-                    h2 = np.diag(gv) / (np.diag(gv) + np.diag(vr))
-                    gv_samples.append(gv.ravel()); h2_samples.append(h2)
-                    files["genetic_variance"].write(",".join(repr(float(v)) for v in gv.ravel()) + "\n")
-                    files["heritability"].write(",".join(repr(float(v)) for v in h2) + "\n")
-        iter_end.append(time.perf_counter())
-        if it % printout_frequency == 0 and it > burnin:
-            print(f"\nPosterior means at iteration: {it}")
-            print(f"Residual variance: {np.round(run_vare.mean, 6)}")
-    wall = time.time() - t0
-    if _blas_limit is not None:
-        _blas_limit.restore_original_limits()
-    for fh in files.values():
-        fh.close()
-    for w_ in bin_writers:
-        w_.close()
+                    pi = float(rng.beta(p - st["sum_delta"][0] + 1.0, st["sum_delta"][0] + 1.0))
+
+            # 4. marker effect variance (variance_components.jl:151-189), re-cast to Float32 (:323-325)
+            if Mi.G.estimate_variance:
+                if mega:                                                    # diagonal only (variance_components.jl:104-109)
+                    Gval = np.diag([(st["beta_ss"][k, k] + Gdf * Mi.G.scale[k, k]) / rng.chisquare(p + Gdf) for k in range(t)]).astype(np.float32)
+                elif mt_pervar:                                             # variance_components.jl:181-186: one draw per marker,
+                    B = np.stack([engine.get_state(k)[1] for k in range(t)], axis=1).astype(np.float64)     # IW(df + 1, scale + b_j b_j')
+                    Gmat = _inverse_wishart_batch(rng, Gdf + 1.0, np.asarray(Mi.G.scale, dtype=np.float64)[None] + B[:, :, None] * B[:, None, :]).astype(np.float32)
+                elif t > 1:
+                    from scipy.stats import invwishart
+                    S = np.asarray(Mi.G.scale, dtype=np.float64) + st["beta_ss"]
+                    Gval = np.asarray(invwishart.rvs(df=Gdf + p, scale=(S + S.T) / 2, random_state=rng), dtype=np.float32).reshape(t, t)
+                elif method == "BayesR":
+                    Gval = np.float32((st["bayesr_ssq"] + Gdf * Mi.G.scale) / rng.chisquare(st["bayesr_nnz"] + Gdf))
+                elif lasso:                                                 # variance_components.jl:152-166,191-203
+                    a64 = engine.get_state(0)[0].astype(np.float64)
+                    Gval = np.float32((np.dot(a64 / gamma_l, a64) + Gdf * Mi.G.scale) / rng.chisquare(p + Gdf))
+                    Q = a64 * a64 / np.float64(Gval)
+                    cand = 1.0 / rng.gamma(0.5, 4.0, size=p)
+                    with np.errstate(over="ignore"):
+                        accept = rng.random(p) < np.exp(Q / 4.0 * (2.0 / gamma_l - cand))
+                    gamma_l[accept] = 2.0 / cand[accept]
+                    Gvec = (np.float64(Gval) * gamma_l).astype(np.float32)
+                elif method == "BayesB":
+                    beta = engine.get_state(0)[1].astype(np.float64)
+                    Gvec = ((beta * beta + Gdf * Mi.G.scale) / rng.chisquare(1.0 + Gdf, size=p)).astype(np.float32)
+                else:
+                    Gval = np.float32((np.float32(st["alpha_ss"][0, 0]) + Gdf * Mi.G.scale) / rng.chisquare(st["sum_delta"][0] + Gdf))
+
+            # 4b. scale of the marker-effect variance prior (MCMC_BayesianAlphabet.jl:328-336; single trait only there too)
+            if Mi.G.estimate_scale and t == 1:
+                gv = Gvec.astype(np.float64) if pervar else np.atleast_1d(np.float64(Gval))
+                Mi.G.scale = float(rng.gamma(gv.size * Gdf / 2 + 1, 1.0 / (np.sum(Gdf / (2 * gv)) + 1)))
+
+            # 5. residual variance (variance_components.jl:60-66,82-112), re-cast to Float32 (:368-370)
+            if R.estimate_variance:
+                if t > 1 and R.constraint:                                  # variance_components.jl:104-109
+                    vare = np.diag([(st["resid_ss"][k, k] + Rdf * R.scale[k, k]) / rng.chisquare(n + Rdf) for k in range(t)]).astype(np.float32)
+                elif t > 1:
+                    from scipy.stats import invwishart
+                    S = np.asarray(R.scale, dtype=np.float64) + st["resid_ss"]
+                    vare = np.asarray(invwishart.rvs(df=Rdf + n, scale=(S + S.T) / 2, random_state=rng), dtype=np.float32).reshape(t, t)
+                else:
+                    vare = np.float32((np.float32(st["resid_ss"][0, 0]) + Rdf * R.scale) / rng.chisquare(n + Rdf))
+
+            # 6. save (MCMC_BayesianAlphabet.jl:399-413, output.jl:443-604)
+            if it > burnin and (it - burnin) % output_samples_frequency == 0:
+                k = (it - burnin) / output_samples_frequency
+                run_sol.add(sol, k)
+                run_vare.add(vare, k)
+                if run_varg is not None:
+                    run_varg.add(Gval, k)
+                if run_pi is not None:
+                    run_pi.add(np.atleast_1d(pi_t if mega else pi), k)
+                engine.accumulate(k)
+                if run_scale is not None:
+                    run_scale.add(np.atleast_1d(np.float64(Mi.G.scale)), k)
+                if ann is not False:
+                    A_.accumulate(ann, k)
+                for key_, cols in term_cols.items():
+                    files[key_].write(",".join(repr(float(sol[c])) for c in cols) + "\n")
+                files["residual_variance"].write(",".join(repr(float(v)) for v in np.atleast_1d(vare).ravel()) + "\n")
+                if not pervar:
+                    files[f"marker_effects_variances_{name}"].write(",".join(repr(float(v)) for v in np.atleast_1d(Gval).ravel()) + "\n")
+                if Mi.estimatePi and f"pi_{name}" in files:
+                    files[f"pi_{name}"].write(",".join(repr(float(v)) for v in np.atleast_1d(pi_t if mega else pi)) + "\n")
+                for kk, tr in enumerate(model.lhsVec):
+                    if hasattr(engine, "alpha_sparse"):
+                        si, sv = engine.alpha_sparse(kk)              # (idx, val) compacted on the device
+                    else:
+                        a_ = engine.get_state(kk)[0]
+                        si = np.flatnonzero(a_).astype(np.int32); sv = a_[si]
+                    bin_writers[kk].append(si, sv)
+                    if write_marker_samples:
+                        a = np.zeros(p, dtype=np.float32)
+                        a[si] = sv
+                        fh = files[f"marker_effects_{name}_{tr}"]
+                        a.tofile(fh, sep=",", format="%.9g")          # text at C speed; 9 significant digits round-trip Float32
+                        fh.write("\n")
+                if outputEBV:
+                    ebvs = [engine.mul_alpha(kk) if out_same else engine.mul_alpha_output(kk) for kk in range(t)]   # getEBV, output.jl:281-306
+                    for kk in range(t):
+                        ebv_run[kk].add(ebvs[kk], k)
+                    if heritability:                                        # output.jl:498-512
+                        E = np.stack(ebvs, axis=1).astype(np.float64)
+                        gv = np.atleast_2d(np.cov(E, rowvar=False))
+                        if t > 1 and Mi.G.constraint:
+                            gv = np.diag(np.diag(gv))
+                        vr = np.atleast_2d(np.asarray(vare, dtype=np.float64))
+                        h2 = np.diag(gv) / (np.diag(gv) + np.diag(vr))
+                        gv_samples.append(gv.ravel()); h2_samples.append(h2)
+                        files["genetic_variance"].write(",".join(repr(float(v)) for v in gv.ravel()) + "\n")
+                        files["heritability"].write(",".join(repr(float(v)) for v in h2) + "\n")
+            iter_end.append(time.perf_counter())
+            if it % printout_frequency == 0 and it > burnin:
+                print(f"\nPosterior means at iteration: {it}")
+                print(f"Residual variance: {np.round(run_vare.mean, 6)}")
+    finally:                                     # also on an exception inside the chain: give the BLAS its threads back, close the files
+        wall = time.time() - t0
+        if _blas_limit is not None:
+            _blas_limit.restore_original_limits()
+        for fh in files.values():
+            fh.close()
+        for w_ in bin_writers:
+            w_.close()
+
 
     # ---- results (output.jl:108-212)
     out = {}
@@ -853,7 +866,9 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
     for key, tab in out.items():                                         # JWAS.jl:480-482
         tab.to_csv(os.path.join(output_folder, key.replace(" ", "_") + ".txt"), index=False)
     out["_timing"] = {"wall_s": wall, "device_sweep_ms_total": t_sweep, "iterations": chain_length,
-                      "block_size": block_size, "n": n, "p": p, "iteration_end_s": iter_end}
+                      "block_size": block_size, "n": n, "p": p, "iteration_end_s": iter_end,
+                      "block_starts": (np.asarray(engine.block_starts(), dtype=np.int64) + 1).tolist() if fast_blocks is not False else None,
+                      "block_repetitions": int(nreps)}
     if own_engine and not devres:
         engine.close()
     return out

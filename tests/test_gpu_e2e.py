@@ -559,3 +559,51 @@ def test_row_shards_single_rank_is_the_plain_sweep_and_contract_errors():
     for q in (1, 2):
         assert all(np.array_equal(x, y_) for x, y_ in zip(res[0][0], res[q][0])) and np.array_equal(res[0][1], res[q][1])
         assert np.array_equal(res[0][2], res[q][2])
+
+
+def test_device_resident_engine_is_reset_between_runs(tmp_path):
+    """A device-resident engine (api.device_genotypes) reused across runMCMC calls: a WEIGHTED run followed by an
+    unweighted one, and a run on an explicit block partition followed by a plain one, must give exactly what a fresh
+    engine gives -- the previous run's R^-1, its weighted Grams and its partition may not leak into the next run."""
+    from jwas_jl_amd.engine import HipEngine
+    d = make_dataset(n=300, p=900, ncausal=6, seed=77)
+    ids = [str(i + 1) for i in range(300)]
+    rng = np.random.default_rng(5)
+    wts = rng.uniform(0.5, 2.0, 300)
+    ph = pd.DataFrame({"ID": ids, "y1": d["y"], "weights": wts})
+
+    def run(eng, tag, **kw):
+        geno = api.device_genotypes(eng, method="BayesC", Pi=0.9, estimatePi=True, obsID=ids)
+        model = api.build_model("y1 = intercept + geno", genotypes={"geno": geno})
+        return api.runMCMC(model, ph, chain_length=30, burnin=5, seed=4, outputEBV=False, output_folder=str(tmp_path / tag),
+                           printout_model_info=False, **kw)["marker effects geno"]
+
+    fresh = HipEngine(0)
+    fresh.load_dense(d["X"])
+    ref = run(fresh, "fresh")
+    fresh.close()
+
+    eng = HipEngine(0)
+    eng.load_dense(d["X"])
+    run(eng, "weighted", heterogeneous_residuals=True)
+    assert eng._weighted
+    again = run(eng, "after_weighted")
+    assert not eng._weighted
+    np.testing.assert_array_equal(again["Estimate"].to_numpy(), ref["Estimate"].to_numpy())
+    np.testing.assert_array_equal(again["Model_Frequency"].to_numpy(), ref["Model_Frequency"].to_numpy())
+
+    run(eng, "explicit", fast_blocks=[1, 101, 401, 650])
+    assert eng._explicit_starts is not None
+    again = run(eng, "after_explicit")
+    assert eng._explicit_starts is None
+    np.testing.assert_array_equal(again["Estimate"].to_numpy(), ref["Estimate"].to_numpy())
+    eng.close()
+
+    with pytest.raises(ValueError, match="centered=False"):
+        api.device_genotypes(HipEngine(0) if False else _Dummy(300, 900), centered=False)
+
+
+class _Dummy:
+    """Stand-in with the attributes device_genotypes reads before it touches the device."""
+    def __init__(self, n, p):
+        self.n, self.p, self.block_size, self._weighted = n, p, 64, False

@@ -705,3 +705,34 @@ def test_runmcmc_multitrait_bayesb_per_marker_covariances(tmp_path, method):
         geno = api.get_genotypes(gdf, np.eye(2) * 0.5, method="BayesB", multi_trait_sampler="II")
         model = api.build_model("y1 = intercept + geno\ny2 = intercept + geno", np.eye(2))
         api.runMCMC(model, ph, chain_length=5, seed=4, output_folder=str(tmp_path / "x"), _engine=OracleEngine("lookahead"), block_size=64)
+
+
+@pytest.mark.parametrize("fb,p", [(64, 200), (50, 230), (True, 300), (7, 100)])
+def test_fast_blocks_numeric_runs_the_reference_partition(tmp_path, fb, p):
+    """JWAS.jl:308-312: fast_blocks = true | number cuts the markers at collect(range(1, step=block_size, stop=p)), and
+    BayesABC.jl:153 repeats every block its own size (the last, shorter block fewer times): the host hands the device
+    exactly that partition (uniform device blocks when the size is a device size, the ragged-partition form otherwise)."""
+    n = 200
+    d = make_dataset(n=n, p=p, ncausal=3, seed=9, center=False)
+    ids = [str(i) for i in range(n)]
+    gdf = pd.DataFrame(d["raw"]); gdf.insert(0, "ID", ids)
+    ph = pd.DataFrame({"ID": ids, "y1": d["y"]})
+    geno = api.get_genotypes(gdf, method="BayesC", Pi=0.9, quality_control=False)
+    model = api.build_model("y1 = intercept + geno")
+    s = int(np.floor(np.sqrt(n))) if fb is True else int(fb)
+    out = api.runMCMC(model, ph, chain_length=6 * s, burnin=1, fast_blocks=fb, seed=1, outputEBV=False,
+                      output_folder=str(tmp_path / "fb"), _engine=OracleEngine("block"))
+    assert out["_timing"]["block_starts"] == list(range(1, p + 1, s))         # collect(range(1, step=s, stop=p))
+    assert out["_timing"]["block_repetitions"] == 0                            # every block its own size
+    assert out["_timing"]["iterations"] == 6                                   # chain_length / block_size
+
+
+def test_fast_blocks_above_the_device_limit_is_an_explicit_error(tmp_path):
+    d = make_dataset(n=100, p=2500, ncausal=3, seed=9, center=False)
+    ids = [str(i) for i in range(100)]
+    gdf = pd.DataFrame(d["raw"]); gdf.insert(0, "ID", ids)
+    ph = pd.DataFrame({"ID": ids, "y1": d["y"]})
+    geno = api.get_genotypes(gdf, method="BayesC", Pi=0.9, quality_control=False)
+    model = api.build_model("y1 = intercept + geno")
+    with pytest.raises(NotImplementedError, match="at most 1024 markers"):
+        api.runMCMC(model, ph, chain_length=4000, fast_blocks=1200, output_folder=str(tmp_path / "x"), _engine=OracleEngine("block"))
