@@ -98,6 +98,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target CPU time per thread-count leg")
     ap.add_argument("--via-api", type=int, default=-1,
                     help="timed iterations of the runMCMC() leg (config2, 1 GPU; default 20, 0 = skip)")
+    if "JWAS_BENCH_ARGV" in os.environ and "RANK" in os.environ and len(sys.argv) == 1:      # a rank started by spawn_ranks()
+        return ap.parse_args(json.loads(os.environ["JWAS_BENCH_ARGV"]))
     return ap.parse_args()
 
 
@@ -144,8 +146,11 @@ def spawn_ranks(a):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // max(1, a.gpus))))
+    # the ranks read this process's own argument list from the environment: torch.distributed.run's parser would try to
+    # match options placed after the script name against its own abbreviations (--n ...)
+    env["JWAS_BENCH_ARGV"] = json.dumps(sys.argv[1:])
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)]
     sys.exit(subprocess.call(cmd, env=env))
 
 
@@ -193,7 +198,10 @@ def main():
     dense_prior = refbench or mt_dense or (a.pi_fixed is not None and a.pi_fixed < 0.5)
     # block policy = mcmc.run_chain's: dense priors 128; sparse single-trait priors adaptive 512/1024; multi-trait 512
     adaptive = a.block_size == 0 and not dense_prior and t == 1
-    bs = a.block_size or (128 if dense_prior else 512)
+    # (single-trait priors that include every marker whatever its rhs -- refbench's Pi = 0 -- run 512-marker blocks through
+    # the sampler's dense_big_st path; the multi-trait default prior keeps 128)
+    all_in = refbench or (t == 1 and bayesc and a.pi_fixed == 0.0)
+    bs = a.block_size or ((512 if all_in else 128) if dense_prior else 512)
     rows_mode = a.shard == "rows"
     if rows_mode and (weak or a.storage != "dense"):
         raise SystemExit("--shard rows runs the dense strong-scaling workloads (config2 / config3 / config4 / refbench)")
@@ -359,10 +367,9 @@ def main():
         elif t > 1:
             from scipy.stats import invwishart
             s["pi"] = rng.dirichlet(st["state_counts"] + 1.0)
-            if mt_pervar:                    # one InverseWishart(df + 1, scale + b_j b_j') draw per marker (variance_components.jl:181-186)
-                from jwas_jl_amd.mcmc import _inverse_wishart_batch
-                Bm = np.stack([eng.get_state(k)[1] for k in range(t)], axis=1).astype(np.float64)
-                s["Gmat"] = _inverse_wishart_batch(rng, df_g + 1.0, scale_g[None] + Bm[:, :, None] * Bm[:, None, :]).astype(np.float32)
+            if mt_pervar:                    # one InverseWishart(df + 1, scale + b_j b_j') draw per marker (variance_components.jl:181-186):
+                eng.sample_marker_covariances(df_g + 1.0, scale_g, seed=a.seed, iteration=s["it"], marker_offset=lo)   # on the device, from the resident beta
+                s["Gmat"] = None             # (the next sweep uses the resident covariances)
             else:
                 S = scale_g + st["beta_ss"]
                 s["G"] = np.asarray(invwishart.rvs(df=df_g + p_total, scale=(S + S.T) / 2, random_state=rng), dtype=np.float32).reshape(t, t)
@@ -433,7 +440,7 @@ def main():
         desc = {
             "config2": f"single-trait BayesC, {n} individuals x {p_total} SNPs, " + ("2-bit packed genotypes (decoded to fp32 on the fly)" if a.storage == "packed2bit" else "fp32 dense genotypes") + (", pi0=0.95 estimated" if a.pi_fixed is None else f", pi={a.pi_fixed} fixed (estimatePi=false)"),
             "config3": f"single-trait BayesR (4-class mixture, gamma 0/.01/.1/1, pi estimated), {n} x {p_total}, fp32 dense genotypes",
-            "config4": f"3-trait {'BayesB (one effect covariance per marker, drawn on the host each iteration)' if a.mt_method == 'BayesB' else 'BayesC'} sampler I, {n} x {p_total}, fp32 dense, R and G inverse-Wishart on host, 8-state pi estimated, start: " + ("all-ones state (reference default)" if a.mt_prior == "default" else "0.95 on the null state"),
+            "config4": f"3-trait {'BayesB (one effect covariance per marker, redrawn on the device each iteration)' if a.mt_method == 'BayesB' else 'BayesC'} sampler I, {n} x {p_total}, fp32 dense, R and G inverse-Wishart on host, 8-state pi estimated, start: " + ("all-ones state (reference default)" if a.mt_prior == "default" else "0.95 on the null state"),
             "config5shard": f"single-step shaped BayesC, {n} rows ({n_gen} integer-coded + {n - n_gen} real-valued imputed) x {p_arg} SNPs per GPU ({p_total} in total), fp32 dense",
             "refbench": f"reference benchmark shape (jwas_nonblock_benchmark.jl): BayesC, {n} x {p_total}, X~U[0,1) fp32 uncentred, y~N(0,1), Pi=0 fixed, marker variance fixed",
         }[wl]

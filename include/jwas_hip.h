@@ -112,7 +112,8 @@ typedef struct jwas_sweep_params {
                                         /* joint priors: the reference's annotated multi-trait BayesC, MarkerSpecificPiPrior, */
                                         /* MTBayesABC.jl:22-47), else NULL; needs 2 traits and a block size <= 512 */
     const float*  var_effect_matrix;    /* MTBAYESB1: p x t x t row-major per-marker effect covariances (host); inverted on the   */
-                                        /* device once per sweep; needs block_size * ntraits <= 2048                               */
+                                        /* device once per sweep; needs block_size * ntraits <= 2048.  NULL = the covariances     */
+                                        /* resident on the device (an earlier sweep's, or jwas_hip_sample_marker_covariances)     */
 } jwas_sweep_params;
 
 /* Reductions the host-side conjugate draws need (Pi.jl, variance_components.jl). */
@@ -315,6 +316,17 @@ int  jwas_hip_sweep_sharded(jwas_hip_ctx* ctx, const jwas_sweep_params* params, 
  * the exchange goes through host memory (slot 0..3 = one group of ranks). */
 int  jwas_hip_comm_row_shards(jwas_hip_ctx* ctx, int32_t enable);
 int  jwas_hip_comm_init_loopback(jwas_hip_ctx* ctx, int32_t slot, int32_t rank, int32_t world);
+
+/* ---- multi-trait BayesA/B: the per-marker effect covariances on the device ------------------------------------------------
+ * The reference redraws every marker's t x t effect covariance each iteration, G_j ~ InverseWishart(df + 1, scale + b_j b_j')
+ * (sample_variance(data, 1, df, scale) per marker, variance_components.jl:181-186): O(p) small matrix draws that would
+ * otherwise make the host the bottleneck.  jwas_hip_sample_marker_covariances draws all p of them on the device from the
+ * CURRENT beta (Bartlett's decomposition on the counter RNG, keyed by (seed, iteration, global marker)); `df` is the
+ * inverse-Wishart's degrees of freedom as passed to the distribution (the reference's df + 1), `scale` its t x t row-major
+ * scale matrix.  The next jwas_hip_sweep with jwas_sweep_params.var_effect_matrix == NULL uses them in place.  Asynchronous. */
+int  jwas_hip_sample_marker_covariances(jwas_hip_ctx* ctx, double df, const double* scale_txt, uint64_t seed,
+                                        uint32_t iteration, uint32_t marker_offset);
+int  jwas_hip_get_marker_covariances(jwas_hip_ctx* ctx, float* out_p_t_t);      /* p x t x t row-major */
 
 /* ---- posterior accumulators (output.jl:568-577) ---------------------------------------------- */
 int  jwas_hip_accumulate(jwas_hip_ctx* ctx, double nsamples);

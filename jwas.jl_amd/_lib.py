@@ -32,7 +32,7 @@ SYMBOLS = [
     "jwas_hip_set_weights", "jwas_hip_synth_single_step", "jwas_hip_setup_blocks_explicit",
     "jwas_hip_comm_row_shards", "jwas_hip_comm_init_loopback", "jwas_hip_update_geometry", "jwas_hip_set_cross_gram",
     "jwas_hip_set_columns", "jwas_hip_get_alpha_sparse", "jwas_hip_comm_unique_id", "jwas_hip_comm_init", "jwas_hip_comm_destroy", "jwas_hip_sweep_sharded",
-    "jwas_hip_residual_add_scalar", "jwas_hip_comm_info",
+    "jwas_hip_residual_add_scalar", "jwas_hip_comm_info", "jwas_hip_sample_marker_covariances", "jwas_hip_get_marker_covariances",
 ]
 STORAGE_DENSE_F32, STORAGE_PACKED2BIT = 0, 1
 
@@ -136,6 +136,8 @@ def load():
     L.jwas_hip_comm_destroy.argtypes = [vp]
     L.jwas_hip_comm_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     L.jwas_hip_residual_add_scalar.argtypes = [vp, i32, C.c_double]
+    L.jwas_hip_sample_marker_covariances.argtypes = [vp, C.c_double, f64p, u64, C.c_uint32, C.c_uint32]
+    L.jwas_hip_get_marker_covariances.argtypes = [vp, vp]
     L.jwas_hip_accumulate.argtypes = [vp, C.c_double]
     L.jwas_hip_get_posterior.argtypes = [vp, i32, vp, vp, vp]
     L.jwas_hip_load_jgb2.argtypes = [vp, C.c_char_p]

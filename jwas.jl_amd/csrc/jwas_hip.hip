@@ -42,6 +42,7 @@ struct jwas_hip_ctx {
     // Active block configuration (a view of one entry of `sets`; several block sizes can be resident so the host
     // can pick per sweep: big blocks when few markers change, smaller ones when many do).
     struct BlockSet { int bs; int64_t nblocks; float *gram, *cross, *corr; double* partials; };
+    int set_index = 0;                  // entry of `sets` that is selected
     std::vector<BlockSet> sets;
     std::vector<int64_t> starts;        // explicit block starts (nblocks + 1 entries, last = p), empty = uniform blocks
     int64_t* d_starts = nullptr;        // ... on the device
@@ -81,6 +82,7 @@ struct jwas_hip_ctx {
     float*  var_vec = nullptr;
     float*  var_mat = nullptr;          // p x t x t per-marker effect covariances (multi-trait BayesA/B), uploaded per sweep
     float*  ginv_mat = nullptr;         // their inverses (k_prepare)
+    bool    var_mat_resident = false;   // var_mat holds this chain's per-marker covariances (uploaded or drawn on the device)
     double* pi_vec = nullptr;
     double* pi_mat = nullptr;
     double* lpr_mat = nullptr;          // p x 2^t marker-specific multi-trait log priors
@@ -203,6 +205,7 @@ static void free_state(jwas_hip_ctx* c)
     (void)hipFree(c->mt2_tab); c->mt2_tab = nullptr;
     (void)hipFree(c->cmp_idx); (void)hipFree(c->cmp_val); c->cmp_idx = nullptr; c->cmp_val = nullptr;
     c->alpha = c->beta = nullptr; c->delta = nullptr; c->mean_a = c->mean_a2 = c->mean_d = nullptr;
+    (void)hipFree(c->var_mat); (void)hipFree(c->ginv_mat); c->var_mat = nullptr; c->ginv_mat = nullptr; c->var_mat_resident = false;
 }
 
 static void free_blocks(jwas_hip_ctx* c)
@@ -623,6 +626,7 @@ static inline int blk_b(const jwas_hip_ctx* c, int64_t k)
 static void select_set(jwas_hip_ctx* c, size_t i)
 {
     const auto& b = c->sets[i];
+    c->set_index = (int)i;
     c->block_size = b.bs; c->nblocks = b.nblocks;
     c->gram = b.gram; c->cross = b.cross; c->corr = b.corr; c->partials = b.partials;
     // independent-mode buffers are sized by the block configuration: rebuild them on next use
@@ -1188,12 +1192,13 @@ int jwas_hip_window_sums2(jwas_hip_ctx* c, int32_t use_output_rows, int32_t nwin
 
 // ---- the sweep --------------------------------------------------------------------------------------
 template <int METHOD, int NT, class CX>
-static hipError_t launch_step_cx(jwas_hip_ctx* c, const CX& cx, const UpdateArgs& U0, const SamplerArgs& S, int do_sample)
+static hipError_t launch_step_cx(jwas_hip_ctx* c, const CX& cx, const UpdateArgs& U0, const SamplerArgs& S, int do_sample, bool dense)
 {
     UpdateArgsT<CX> U;
     static_cast<UpdateArgs&>(U) = U0;
     U.cx = cx;
     const StepSmem SM(c->block_size, NT, is_mt_method(METHOD) ? mt_park_nd(c->block_size, NT) + (S.lpr_mat ? (1 << NT) : 0) : st_park_nd(METHOD), is_mt_method(METHOD) ? mt_park_nf(c->block_size, NT) + (METHOD == kMTBayesB1 ? NT * NT : 0) : st_park_nf(METHOD));
+    constexpr bool kHasDense = CX::kCoopApply && (METHOD == kBayesC || METHOD == kBayesB) && NT == 1;
     static unsigned long long attr_set = 0ull;       // one bit per device: the attribute belongs to the device's code object
     const unsigned long long dev_bit = 1ull << (c->device & 63);
     if (!(attr_set & dev_bit)) {   // allow > 64 KB of dynamic LDS
@@ -1202,6 +1207,11 @@ static hipError_t launch_step_cx(jwas_hip_ctx* c, const CX& cx, const UpdateArgs
         if (e != hipSuccess) return e;
         if constexpr (CX::kCoopApply) {
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_block_step<METHOD, NT, CX, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+        }
+        if constexpr (kHasDense) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_block_step<METHOD, NT, CX, true, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
         }
@@ -1216,6 +1226,13 @@ static hipError_t launch_step_cx(jwas_hip_ctx* c, const CX& cx, const UpdateArgs
 #endif
     const int nwork = c->nrg * U.ncg;
     const unsigned grid = (dbg == 2) ? 1u : (U.quiet_xcd ? (unsigned)(1 + (nwork + 6) / 7 * 8) : (unsigned)(1 + nwork));
+    if constexpr (kHasDense) {
+        if (dense && U.sync_now != nullptr) {   // every marker always included, 256- / 512-marker blocks: the sampler with dense_big_st
+            hipLaunchKernelGGL((k_block_step<METHOD, NT, CX, true, true>), dim3(grid), dim3(kStepThreads), SM.bytes, c->stream,
+                               U, S, (dbg == 1) ? 0 : do_sample);
+            return hipSuccess;
+        }
+    }
     if constexpr (CX::kCoopApply) {
         if (U.sync_now != nullptr) {     // dense sweep: the instantiation whose update role shares the apply work
             hipLaunchKernelGGL((k_block_step<METHOD, NT, CX, true>), dim3(grid), dim3(kStepThreads), SM.bytes, c->stream,
@@ -1229,16 +1246,16 @@ static hipError_t launch_step_cx(jwas_hip_ctx* c, const CX& cx, const UpdateArgs
 }
 
 template <int METHOD, int NT>
-static hipError_t launch_step(jwas_hip_ctx* c, const UpdateArgs& U, const SamplerArgs& S, int do_sample)
+static hipError_t launch_step(jwas_hip_ctx* c, const UpdateArgs& U, const SamplerArgs& S, int do_sample, bool dense = false)
 {
-    return with_cols(c, 0, [&](auto cx) { return launch_step_cx<METHOD, NT, decltype(cx)>(c, cx, U, S, do_sample); });
+    return with_cols(c, 0, [&](auto cx) { return launch_step_cx<METHOD, NT, decltype(cx)>(c, cx, U, S, do_sample, dense); });
 }
 
-static hipError_t launch_step_any(jwas_hip_ctx* c, const UpdateArgs& U, const SamplerArgs& S, int do_sample)
+static hipError_t launch_step_any(jwas_hip_ctx* c, const UpdateArgs& U, const SamplerArgs& S, int do_sample, bool dense)
 {
     switch (c->method) {
-        case JWAS_HIP_BAYESC: return launch_step<kBayesC, 1>(c, U, S, do_sample);
-        case JWAS_HIP_BAYESB: return launch_step<kBayesB, 1>(c, U, S, do_sample);
+        case JWAS_HIP_BAYESC: return launch_step<kBayesC, 1>(c, U, S, do_sample, dense);
+        case JWAS_HIP_BAYESB: return launch_step<kBayesB, 1>(c, U, S, do_sample, dense);
         case JWAS_HIP_BAYESR: return launch_step<kBayesR, 1>(c, U, S, do_sample);
 #define JW_MT_STEP(M)                                                            \
             if (c->ntraits == 2) return launch_step<M, 2>(c, U, S, do_sample);       \
@@ -1552,12 +1569,12 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
         if (c->method == JWAS_HIP_MTBAYESB1) {
             // multi-trait BayesA/B: one effect covariance per marker (locus_effect_variances, MTBayesABC.jl:66); inverted on
             // the device by k_prepare, parked in LDS beside the marker's draws
-            NEED(c, P->var_effect_matrix, JWAS_HIP_EINVAL, "multi-trait BayesA/B needs per-marker effect covariances (var_effect_matrix)");
+            NEED(c, P->var_effect_matrix || c->var_mat_resident, JWAS_HIP_EINVAL, "multi-trait BayesA/B needs per-marker effect covariances (var_effect_matrix, or jwas_hip_sample_marker_covariances)");
             NEED(c, !P->independent_blocks, JWAS_HIP_EUNSUP, "independent_blocks is not available with per-marker effect covariances");
             NEED(c, !P->log_prior_states_matrix, JWAS_HIP_EUNSUP, "marker-specific joint priors are not available with per-marker effect covariances");
             NEED(c, mt_park_nf(c->block_size, t) != 0, JWAS_HIP_EUNSUP, "per-marker effect covariances need block_size * ntraits <= 2048 (got %d x %d)", c->block_size, t);
             const size_t mb = sizeof(float) * (size_t)t * t * c->p;
-            int rc = upload_vec(c, (void**)&c->var_mat, P->var_effect_matrix, mb); if (rc) return rc;
+            if (P->var_effect_matrix) { int rc = upload_vec(c, (void**)&c->var_mat, P->var_effect_matrix, mb); if (rc) return rc; c->var_mat_resident = true; }
             if (!c->ginv_mat) HIPCHK(c, hipMalloc(&c->ginv_mat, mb));
             D.var_mat = c->var_mat; D.ginv_mat = c->ginv_mat;
             for (int i = 0; i < t * t; ++i) D.Ginv[i] = (i / t == i % t) ? 1.f : 0.f;       // (unused)
@@ -1653,7 +1670,13 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
     // once per sweep (the tests switch it between sweeps of one process).
     const char* efc = std::getenv("JWAS_HIP_COOP_APPLY");
     const int fc = efc ? std::atoi(efc) : -1;
-    const bool coop = c->sync_cnt != nullptr && (fc >= 0 ? fc != 0 : c->last_events > 0.25 * (double)c->p);
+    // Priors that include every marker whatever its rhs (Pi = 0 without per-marker pi: RR-BLUP, BayesA, the reference's own
+    // benchmark setting) on 256- / 512-marker blocks, single pass: the kernel whose sampler carries dense_big_st (sweep.hpp);
+    // it always runs with the cooperative apply (every marker of every block changes).
+    const bool dense_big = c->sync_cnt != nullptr && fc != 0 && (c->method == JWAS_HIP_BAYESC || c->method == JWAS_HIP_BAYESB) &&
+                           (bs == 256 || bs == 512) && c->starts.empty() && P->nreps == 1 && P->pi == 0.0 && P->pi_vec == nullptr &&
+                           std::getenv("JWAS_HIP_DENSE_BIG_OFF") == nullptr;
+    const bool coop = c->sync_cnt != nullptr && (dense_big || (fc >= 0 ? fc != 0 : c->last_events > 0.25 * (double)c->p));
     for (int64_t k = 0; k <= nb; ++k) {
         UpdateArgs U;
         U.r_in = c->r + ((k + 1) & 1) * rstride; U.r_out = c->r + (k & 1) * rstride;
@@ -1692,6 +1715,8 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
             S.b_next = (sb + 1 < nb) ? blk_b(c, sb + 1) : 0;
             S.cross_next = c->cross + (sb + 1 < nb ? sb + 1 : sb) * (int64_t)bs * bs;
             S.gram_next = (sb + 1 < nb) ? c->gram + (sb + 1) * (int64_t)bs * bs : nullptr;
+            S.cross_after = (sb + 2 < nb) ? c->cross + (sb + 2) * (int64_t)bs * bs : nullptr;
+            S.lines_after = (sb + 2 < nb) ? (int)(((int64_t)blk_b(c, sb + 1) * blk_b(c, sb + 2) + 31) / 32) : 0;
             S.corr_in = c->corr + (sb & 1) * (size_t)kMaxT * bs;
             S.corr_out = c->corr + ((sb + 1) & 1) * (size_t)kMaxT * bs;
             S.prep_d = c->prep_d; S.prep_f = c->prep_f; S.mt2_tab = c->mt2_tab; S.lpr_mat = c->lpr_active ? c->lpr_mat : nullptr;
@@ -1705,7 +1730,7 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
             while (c->kev.size() < 2 * (ntimed + 1)) { hipEvent_t e; HIPCHK(c, hipEventCreate(&e)); c->kev.push_back(e); }
             HIPCHK(c, hipEventRecord(c->kev[2 * ntimed], c->stream));
         }
-        HIPCHK(c, launch_step_any(c, U, S, sb >= 0));
+        HIPCHK(c, launch_step_any(c, U, S, sb >= 0, dense_big));
         if (c->row_mode && U.b > 0) {          // the block's partial RHS summed over the ranks' individuals, before its sampler runs
             int rc = row_allreduce(c, U.partials, (size_t)t * c->nrg * bs, true);
             if (rc) return rc;
@@ -1955,6 +1980,40 @@ int jwas_hip_sweep_sharded(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_swe
     }
     HIPCHK(c, hipGetLastError());
     return sweep_collect(c, S, ntimed, timed_bytes, c->shard_buf + total);
+}
+
+// ---- multi-trait BayesA/B: the per-marker effect covariances drawn on the device -------------------------------
+int jwas_hip_sample_marker_covariances(jwas_hip_ctx* c, double df, const double* scale, uint64_t seed, uint32_t iteration, uint32_t marker_offset)
+{
+    NEED(c, c && scale, JWAS_HIP_EINVAL, "NULL argument");
+    NEED(c, c->method == JWAS_HIP_MTBAYESB1, JWAS_HIP_ESTATE, "jwas_hip_sample_marker_covariances needs init_state(JWAS_HIP_MTBAYESB1, t)");
+    const int t = c->ntraits;
+    NEED(c, df > (double)(t - 1), JWAS_HIP_EINVAL, "inverse-Wishart degrees of freedom must exceed ntraits - 1 (got %g)", df);
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t mb = sizeof(float) * (size_t)t * t * c->p;
+    if (!c->var_mat) HIPCHK(c, hipMalloc(&c->var_mat, mb));
+    IwParams Q;
+    std::memset(&Q, 0, sizeof Q);
+    Q.df = df;
+    for (int i = 0; i < t * t; ++i) Q.scale[i] = scale[i];
+    Q.seed_lo = (uint32_t)seed; Q.seed_hi = (uint32_t)(seed >> 32); Q.iter = iteration; Q.marker0 = marker_offset;
+    const dim3 g((unsigned)((c->p + 255) / 256)), b(256);
+    if (t == 2) hipLaunchKernelGGL((k_sample_marker_covariances<2>), g, b, 0, c->stream, Q, c->p, c->beta, c->var_mat);
+    else if (t == 3) hipLaunchKernelGGL((k_sample_marker_covariances<3>), g, b, 0, c->stream, Q, c->p, c->beta, c->var_mat);
+    else hipLaunchKernelGGL((k_sample_marker_covariances<4>), g, b, 0, c->stream, Q, c->p, c->beta, c->var_mat);
+    HIPCHK(c, hipGetLastError());
+    c->var_mat_resident = true;
+    return JWAS_HIP_OK;
+}
+
+int jwas_hip_get_marker_covariances(jwas_hip_ctx* c, float* out)
+{
+    NEED(c, c && out, JWAS_HIP_EINVAL, "NULL argument");
+    NEED(c, c->var_mat && c->var_mat_resident, JWAS_HIP_ESTATE, "no per-marker effect covariances are resident");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(out, c->var_mat, sizeof(float) * (size_t)c->ntraits * c->ntraits * c->p, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return JWAS_HIP_OK;
 }
 
 // ---- posterior accumulators ---------------------------------------------------------------------------

@@ -349,6 +349,8 @@ struct SamplerArgs {
     const float* cross_next;      // b x b_next: X_this' X_next (row = marker of THIS block); b_next = 0: none
     int b_next;
     const float* gram_next;       // b_next x b_next Gram of the NEXT block (L2 prefetch only), or NULL
+    const float* cross_after;     // cross-Gram X_next' X_(next+1) the NEXT launch's sampler reads (L2 prefetch only), or NULL
+    int lines_after;              // ... its size in 128-byte lines
     const float* corr_in;         // [NT][bsz] lookahead correction of THIS block (written by the previous sampler)
     float* corr_out;              // [NT][bsz] lookahead correction of the NEXT block
     const double* prep_d; const float* prep_f;
@@ -792,10 +794,138 @@ __device__ __forceinline__ void dense_section(const float* grow, int B, int nste
     for (; l < nsteps; ++l) step(l, (Q == 0) ? grow[l * B + lane] : 0.f, TWO ? grow[l * B + 64 + lane] : 0.f);
 }
 
+// ---- DENSE blocks of 256 / 512 markers (every marker of the block is included whatever its rhs: Pi = 0, RR-BLUP, BayesA,
+// the reference's own benchmark setting).  The block chain is a forward substitution: marker c needs the changes of all
+// markers before it.  Section s (64 markers) is walked by wave s exactly as dense_section walks a small block -- same
+// operations, same order, bit-identical to the sequential chain -- with its 64 x 64 DIAGONAL Gram tile from LDS (all
+// tiles are fetched with direct loads at the very start of the launch); everything off the diagonal runs in parallel:
+// thread c owns row c (its running rhs in a register) and column c of the next block's lookahead correction, and after
+// section s is done applies its 64 changes from Gram / cross-Gram values it prefetched into registers while the section
+// was being walked (rhs = fmaf(D_k, G[k][c], rhs) in marker order: the sequential chain's own fmaf sequence).
+// One barrier per section; the serial part per marker is dense_section's chain and nothing else.
+template <int METHOD>
+__device__ __forceinline__ void dense_big_st(char* smem, const StepSmem& SM, const SamplerArgs& A, float ie, long long tk0)
+{
+    const int B = SM.B, b = A.b, bn = A.b_next;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t j0 = A.j0;
+    float* rhs_lds = reinterpret_cast<float*>(smem + SM.rhs_off);      // entry rhs; reused as D[c] = alpha_old - alpha_new once c is done
+    float* acur = reinterpret_cast<float*>(smem + SM.acur_off);
+    const float* astart = reinterpret_cast<const float*>(smem + SM.astart_off);
+    const double* lpd = reinterpret_cast<const double*>(smem + SM.prepd_off);
+    const float* lpf = reinterpret_cast<const float*>(smem + SM.prepf_off);
+    const float* tiles = reinterpret_cast<const float*>(smem + SM.rows_off);      // [B/64][64][64] diagonal Gram tiles
+    int* wcnt = reinterpret_cast<int*>(smem + SM.wcnt_off);
+    const int c = tid;
+    const bool own = c < b;
+    const int cl = own ? c : 0;
+    float rr = rhs_lds[cl];
+    const float il = lpf[cl], dj = lpf[2 * B + cl];
+    const double zs = lpd[cl];
+    const float ao = acur[cl];
+    const float da = dj * ao;                                           // d * alpha_old (BayesABC.jl:36)
+    float an_own = 0.f;
+    const int nsec = b >> 6;
+    const bool has_col = tid < bn;
+    float corr = 0.f;
+    float gq[64], cq[64];
+    // thread c reads column c of the Gram rows / cross-Gram rows of a section: one dword per lane, coalesced (256 bytes = two
+    // lines per wave instruction).  (Reading the thread's own ROW instead -- G is symmetric -- as 16 dwordx4 loads was
+    // measured 3x slower: 64 different lines per wave instruction keep the texture addresser busy ~360 cycles each.)
+    const float* gcol = A.gram + cl;                                    // G[k][c] = gram[k * b + c]
+    const float* ccol = A.cross_next + (has_col ? tid : 0);             // C[k][c'] = cross[k * bn + c']
+    auto load_g = [&](int s) {
+#pragma unroll
+        for (int u = 0; u < 64; ++u) gq[u] = gcol[(64 * s + u) * b];
+    };
+    auto load_c = [&](int s) {
+#pragma unroll
+        for (int u = 0; u < 64; ++u) cq[u] = ccol[(64 * s + u) * bn];
+    };
+    // Barrier of the section loop: LDS traffic only.  (__syncthreads() also waits for every outstanding GLOBAL load -- the
+    // prefetches below are meant to stay in flight across it.)
+    auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    auto prefetch = [&](int sec) {
+        if (wave > sec && own) load_g(sec);
+        if (has_col) load_c(sec);
+    };
+    prefetch(0);
+#pragma unroll 1
+    for (int s = 0; s < nsec; ++s) {
+        if (wave == s) {
+            float r0 = rr, r1 = 0.f, rev = rr;
+            dense_section<0, false, true>(tiles + s * 4096, 64, 64, lane, ie, 0.f, 0.f, il, da, ao, zs, r0, r1, rev);
+            an_own = dense_alpha_new(rev, da, ie, il, zs, true);
+            acur[c] = an_own;
+            rhs_lds[c] = ao - an_own;                                   // D of this marker, read by everybody after the barrier
+        }
+        lds_barrier();
+        // (Keep this body simple: a variant in which the next walker skipped the correction and caught up in a loop after its
+        // walk made the register allocator keep several copies of the prefetch arrays alive -- 218 spilled VGPRs.)
+        // The section's 64 changes first (16 broadcast reads back to back: one LDS latency instead of one per group of four),
+        // then the two fmaf chains in marker order, interleaved
+        float dv[64];
+        {
+            const float4* Dv4 = reinterpret_cast<const float4*>(rhs_lds + 64 * s);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { const float4 d = Dv4[u]; dv[4 * u] = d.x; dv[4 * u + 1] = d.y; dv[4 * u + 2] = d.z; dv[4 * u + 3] = d.w; }
+        }
+        // the wave that just walked did not prefetch its cross-Gram values (the issue sat between the barrier and its walk,
+        // on the critical path): it fetches them now -- its rows are done, nobody waits for it
+        if (wave == s && has_col && s > 0) load_c(s);
+        const bool do_r = wave > s && own;
+        if (do_r && has_col) {
+#pragma unroll
+            for (int u = 0; u < 64; ++u) { rr = fmaf(dv[u], gq[u], rr); corr = fmaf(dv[u], cq[u], corr); }
+        } else if (do_r) {
+#pragma unroll
+            for (int u = 0; u < 64; ++u) rr = fmaf(dv[u], gq[u], rr);
+        } else if (has_col) {
+#pragma unroll
+            for (int u = 0; u < 64; ++u) corr = fmaf(dv[u], cq[u], corr);
+        }
+        if (s + 1 < nsec) {
+            if (wave > s + 1 && own) load_g(s + 1);
+            if (has_col && wave != s + 1) load_c(s + 1);                // (the next walker: see above)
+        }
+    }
+    __syncthreads();
+    const long long tk4 = clock64();
+    // the block's change list in marker order (an effect that came out bit-equal to the old one is no change)
+    const bool changed = own && (ao != an_own);
+    const unsigned long long cm = __ballot(changed);
+    __syncthreads();                                                    // (the candidate counts of the front are no longer read)
+    if (lane == 0) wcnt[wave] = __popcll(cm);
+    __syncthreads();
+    int base = 0, nfin = 0;
+#pragma unroll
+    for (int q = 0; q < kStepThreads / 64; ++q) { const int v = wcnt[q]; base += (q < wave) ? v : 0; nfin += v; }
+    // ---- global stores last
+    if (tid < B && bn > 0) A.corr_out[tid] = has_col ? corr : 0.f;
+    if (changed) {
+        const int e = base + __popcll(cm & ((1ull << lane) - 1ull));
+        const float d = ao - an_own;
+        A.ev_out->idx[e] = (int32_t)(j0 + c);
+        A.ev_out->delta[0][e] = d;
+        if (e < 7) { A.ev_out->hidx[e] = (int32_t)(j0 + c); A.ev_out->hdelta[e] = d; }
+        A.alpha[j0 + c] = an_own;
+    }
+    if (own) { A.beta[j0 + c] = an_own; reinterpret_cast<float*>(A.delta)[j0 + c] = 1.f; }
+    if (tid == 0) {
+        A.ev_out->count = nfin;
+        atomicAdd(&A.counters[0], (unsigned long long)nfin);
+        atomicAdd(&A.counters[5], (unsigned long long)(tk4 - tk0));      // (diagnostics: front + walk)
+        atomicAdd(&A.counters[7], (unsigned long long)b);
+    }
+    (void)astart;
+}
+
 __host__ __device__ constexpr int st_park_nd(int method) { return method == kBayesR ? BayesRMarker::kFastD : 1; }
 __host__ __device__ constexpr int st_park_nf(int method) { return method == kBayesR ? 2 : 5; }
 
-template <int METHOD>
+// DENSE: the instantiation that carries dense_big_st (selected by the host for sweeps whose prior includes every marker);
+// the steady-state kernel is compiled without it.
+template <int METHOD, bool DENSE = false>
 __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A)
 {
     constexpr bool kR = (METHOD == kBayesR);
@@ -832,6 +962,24 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
     const bool gram_dma = prestage && b == B;
     const bool cross_dma = gram_dma && SM.has_cross && A.b_next == B;
     if (gram_dma) dma_copy_to_lds(A.gram, reinterpret_cast<float*>(smem + SM.rows_off), B * B);
+    // 256- / 512-marker blocks under a prior that includes every marker (Pi = 0 without per-marker pi: known before any
+    // load): dense_big_st.  Its diagonal Gram tiles (64 x 64 floats per 64-marker section: wave w fetches tile w) go to
+    // LDS with direct loads issued before anything else; whether every marker really is "always included" (thresholds
+    // lo = hi) is voted below, and a block that fails the vote runs the general path (which re-stages the row slots).
+    bool dense_big_try = false;
+    if constexpr (!kR && DENSE) {
+        dense_big_try = (B == 256 || B == 512) && b == B && (A.b_next == 0 || A.b_next == B) &&
+                        (P->nreps == 1) && P->pi == 0.0 && P->pi_vec == nullptr;
+        if (dense_big_try && wave < (B >> 6)) {
+            typedef __attribute__((address_space(3))) void lds_void;
+            float* tile = reinterpret_cast<float*>(smem + SM.rows_off) + wave * 4096;
+            const float* src = A.gram + (int64_t)(64 * wave + (lane >> 4)) * b + 64 * wave + (lane & 15) * 4;
+#pragma unroll 1
+            for (int r4 = 0; r4 < 16; ++r4)       // 4 rows of 64 floats per instruction: lane -> row lane / 16, float4 column lane % 16
+                __builtin_amdgcn_global_load_lds(src + (int64_t)(4 * r4) * b, (lds_void*)(tile + r4 * 256), 16, 0, 0);
+        }
+    }
+    bool always_mine = true;
     // (the cross-Gram rows are only needed after the walk: waves 1..7 fetch them while wave 0 walks)
     float4 gpre[8];
     if (prestage && !gram_dma) {
@@ -885,6 +1033,7 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
             lpd[c] = zs;
             lpf[c] = invLhs; lpf[B + c] = bex; lpf[2 * B + c] = dj; lpf[3 * B + c] = lo; lpf[4 * B + c] = hi;
             cand[q] = (c < b) && ((a_in != 0.f) || abc_included(rhs0, lo, hi));
+            always_mine = always_mine && ((c >= b) || (lo == hi));           // thresholds(): lo = hi <=> always included
             bpark0[c] = bex; dpark0[c] = 0.f;     // a marker that stays out: delta 0, beta = its excluded draw
         }
     }
@@ -912,8 +1061,10 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
         const unsigned long long mb = __ballot(cand[0] || cand[1]);
         // bits 16 / 17: this wave's markers of sub-block `wave` / `8 + wave` contain a candidate
         const int f0 = __any(cand[0]) ? 1 << 16 : 0, f1 = __any(cand[1]) ? 1 << 17 : 0;     // (votes outside the lane-0 branch)
-        if (lane == 0) wc[wave] = __popcll(mb) | f0 | f1;
+        const int f2 = __all(always_mine) ? 1 << 18 : 0;                 // bit 18: every marker of this wave is always included
+        if (lane == 0) wc[wave] = __popcll(mb) | f0 | f1 | f2;
     }
+    if (dense_big_try) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the diagonal tiles have landed (barrier below)
     __syncthreads();
     int ncand_all = 0;
     // PREFIX SKIP: until the first candidate of the block commits, the running rhs IS the entry rhs, so the evaluation
@@ -931,6 +1082,15 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
             mask |= ((v >> 16) & 1u) << q | ((v >> 17) & 1u) << (8 + q);
         }
         if (mask) first_sub = __builtin_ctz(mask);
+    }
+    if constexpr (!kR && DENSE) {
+        if (dense_big_try) {
+            const int* wc = reinterpret_cast<const int*>(smem + SM.wcnt_off);
+            bool all_in = true;
+#pragma unroll
+            for (int q = 0; q < kStepThreads / 64; ++q) all_in = all_in && ((wc[q] >> 18) & 1);
+            if (all_in) { dense_big_st<METHOD>(smem, SM, A, ie, tk0); return; }
+        }
     }
     // single-pass sweeps with a next block: waves 1..4 accumulate its lookahead correction while the serial wave runs
     const bool stream_corr = ((P->nreps > 0 ? P->nreps : b) == 1) && !prestage && A.b_next > 0;
@@ -1567,6 +1727,89 @@ __device__ __forceinline__ void chol_lower(const double (&A)[NT][NT], double (&L
             L[i][j] = v / L[j][j];
         }
     }
+}
+
+// ---- multi-trait BayesA/B: one InverseWishart(df, scale + b_j b_j') draw per marker (variance_components.jl:181-186:
+// sample_variance(data, 1, df, scale) per marker -- the host's 100 000 draws per iteration were ~35 ms of numpy and made
+// the multi-trait BayesB iteration host-bound).  One thread per marker, Bartlett's decomposition on the counter RNG:
+//   S = scale + b b' = C C' (chol_lower);  A lower-triangular, A_ii = sqrt(chi2(df - i)), A_ik ~ N(0,1) (k < i);
+//   K' = A^-1 C' (forward substitution);  G = K K', symmetrised, rounded to float.
+// W = C'^-1 A A' C^-1 ~ Wishart(df, S^-1) and G = W^-1.  Counter of a draw: (global marker, iteration, 0x80000000 | attempt,
+// slot): slot 32 + 2i (+1) the chi-square of row i (Marsaglia-Tsang gamma: one normal + one uniform per attempt), slot
+// 64 + 4i + k the normal A_ik -- disjoint from the sweep's own draws (repetition index < 2^31, slots 0 / 1 + 16 trait).
+// Operation for operation the oracle's orc_sample_marker_covariances.
+__device__ __forceinline__ double iw_chi2(uint32_t marker, uint32_t iter, uint32_t slot, uint32_t k0, uint32_t k1, double nu)
+{
+    double a = 0.5 * nu, boost = 1.0;
+    if (a < 1.0) {                                   // gamma(a) = gamma(a + 1) * u^(1/a)
+        const u32x4 w = philox4x32_10(marker, iter, 0x80000000u | 0xFFFFu, slot, k0, k1);
+        boost = exp(log(u52(w.x, w.y)) / a);
+        a = a + 1.0;
+    }
+    const double d = a - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
+    double g = d;
+    for (uint32_t attempt = 0; attempt < 64u; ++attempt) {
+        const u32x4 w = philox4x32_10(marker, iter, 0x80000000u | attempt, slot, k0, k1);
+        const u32x4 w2 = philox4x32_10(marker, iter, 0x80000000u | attempt, slot + 1u, k0, k1);
+        const double x = sqrt(-2.0 * log(u52(w.x, w.y))) * cos(6.283185307179586476925286766559 * u52(w.z, w.w));
+        const double u = u52(w2.x, w2.y);
+        double v = 1.0 + c * x;
+        if (v <= 0.0) continue;
+        v = v * v * v;
+        g = d * v;
+        if (log(u) < 0.5 * x * x + d - d * v + d * log(v)) break;
+    }
+    return 2.0 * g * boost;
+}
+
+struct IwParams { double df; double scale[kMaxT * kMaxT]; uint32_t seed_lo, seed_hi, iter, marker0; };
+
+template <int NT>
+__global__ __launch_bounds__(256) void k_sample_marker_covariances(IwParams Q, int64_t p, const float* __restrict__ beta, float* __restrict__ var_mat)
+{
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= p) return;
+    const uint32_t marker = Q.marker0 + (uint32_t)j;
+    double b[NT], S[NT][NT], C[NT][NT], A[NT][NT], Kt[NT][NT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a) b[a] = (double)beta[(int64_t)a * p + j];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int c = 0; c < NT; ++c) { S[a][c] = Q.scale[a * NT + c] + b[a] * b[c]; C[a][c] = 0.0; A[a][c] = 0.0; }
+    chol_lower<NT>(S, C);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        A[i][i] = sqrt(iw_chi2(marker, Q.iter, 32u + 2u * (uint32_t)i, Q.seed_lo, Q.seed_hi, Q.df - (double)i));
+#pragma unroll
+        for (int k = 0; k < i; ++k) {
+            const u32x4 w = philox4x32_10(marker, Q.iter, 0x80000000u, 64u + 4u * (uint32_t)i + (uint32_t)k, Q.seed_lo, Q.seed_hi);
+            A[i][k] = sqrt(-2.0 * log(u52(w.x, w.y))) * cos(6.283185307179586476925286766559 * u52(w.z, w.w));
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+            double acc = C[c][i];                                       // C'[i][c]
+#pragma unroll
+            for (int k = 0; k < i; ++k) acc = acc - A[i][k] * Kt[k][c];
+            Kt[i][c] = acc / A[i][i];
+        }
+    double G[NT][NT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) s = s + Kt[i][a] * Kt[i][c];
+            G[a][c] = s;
+        }
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int c = 0; c < NT; ++c) var_mat[(j * NT + a) * NT + c] = (float)(0.5 * (G[a][c] + G[c][a]));
 }
 
 // Gibbs sampler II, one candidate state (MTBayesABC.jl:178-185).  st: bit k = trait k in the model.
@@ -2447,7 +2690,7 @@ struct UpdateArgsT : UpdateArgs {
 
 // COOP: the update role may split a dense change list among the column groups of a row group (see update_role); a separate
 // instantiation so that the steady-state kernel's code is exactly the one without it (its presence alone cost 1 %).
-template <int METHOD, int NT, class CX, bool COOP = false>
+template <int METHOD, int NT, class CX, bool COOP = false, bool DENSE = false>
 __global__ __launch_bounds__(kStepThreads) void k_block_step(UpdateArgsT<CX> U, SamplerArgs S, int do_sample)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -2460,7 +2703,7 @@ __global__ __launch_bounds__(kStepThreads) void k_block_step(UpdateArgsT<CX> U, 
         __syncthreads();
 #endif
         if constexpr (is_mt_method(METHOD)) sampler_role_mt<METHOD, NT>(smem, S);
-        else sampler_role_st<METHOD>(smem, S);
+        else sampler_role_st<METHOD, DENSE>(smem, S);
         return;
     }
     int w = blockIdx.x - 1;
@@ -2468,6 +2711,29 @@ __global__ __launch_bounds__(kStepThreads) void k_block_step(UpdateArgsT<CX> U, 
         // Speed heuristic only (never correctness): workgroup ids are observed to round-robin over the 8 XCDs,
         // so ids = 0 mod 8 share the sampler's XCD/L2.  Leaving them idle keeps that L2 free of the streaming
         // traffic, which shortens every dependent load of the sampler chain.
+        if constexpr (DENSE) {
+            // ... and ONE of them (id 8) pulls what the NEXT launch's sampler will read -- the next block's Gram and its
+            // cross-Gram, 2 MB at 512 markers -- into that L2: dense_big_st moves ~1.5 MB per block through one CU, and with
+            // HBM latency under the update role's streaming (~5 us) a CU's 63 loads in flight per wave cap it at ~25 GB/s.
+            if (blockIdx.x == 8 && do_sample) {
+                const int nl_g = (S.gram_next != nullptr) ? (S.b_next * S.b_next + 31) / 32 : 0;
+                const int nl_c = (S.cross_after != nullptr) ? S.lines_after : 0;
+                float sink = 0.f;
+                for (int l0 = 0; l0 < nl_g + nl_c; l0 += 8 * kStepThreads) {
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        int l = l0 + u * kStepThreads + (int)threadIdx.x;
+                        l = l < nl_g + nl_c ? l : nl_g + nl_c - 1;
+                        v[u] = (l < nl_g) ? S.gram_next[(int64_t)l * 32] : S.cross_after[(int64_t)(l - nl_g) * 32];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) sink += v[u];
+                }
+                asm volatile("" ::"v"(sink));
+                return;
+            }
+        }
         if ((blockIdx.x & 7) == 0) return;
         w = (int)(blockIdx.x - 1) - (int)((blockIdx.x - 1) >> 3);
     }

@@ -494,13 +494,12 @@ class HipEngine:
                 P.pi_classes[k] = float(pt[k])
         else:
             if self.method == _lib.MTBAYESB1:     # multi-trait BayesA/B: one t x t effect covariance per marker
-                if var_effect_matrix is None:
-                    raise ValueError("multi-trait BayesA/B needs var_effect_matrix (p x t x t)")
-                vm = np.ascontiguousarray(var_effect_matrix, dtype=np.float32)
-                if vm.shape != (self.p, t, t):
-                    raise ValueError(f"var_effect_matrix must be {self.p} x {t} x {t}")
-                keep.append(vm)
-                P.var_effect_matrix = vm.ctypes.data_as(C.POINTER(C.c_float))
+                if var_effect_matrix is not None:     # (None: the covariances resident on the device -- sample_marker_covariances)
+                    vm = np.ascontiguousarray(var_effect_matrix, dtype=np.float32)
+                    if vm.shape != (self.p, t, t):
+                        raise ValueError(f"var_effect_matrix must be {self.p} x {t} x {t}")
+                    keep.append(vm)
+                    P.var_effect_matrix = vm.ctypes.data_as(C.POINTER(C.c_float))
             lp = np.asarray(log_prior_states, dtype=np.float64)
             if lp.ndim == 2:                      # marker-specific joint priors (MarkerSpecificPiPrior, MTBayesABC.jl:22-47)
                 if lp.shape != (self.p, 1 << t):
@@ -529,6 +528,21 @@ class HipEngine:
             "update_kernel_ms": S.update_kernel_ms, "update_kernel_samples": S.update_kernel_samples,
             "update_kernel_bytes": S.update_kernel_bytes, "event_overhead_ms": S.event_overhead_ms,
         }
+
+    # -- multi-trait BayesA/B: per-marker effect covariances drawn on the device --------------------
+    def sample_marker_covariances(self, df, scale, *, seed, iteration, marker_offset=0):
+        """G_j ~ InverseWishart(df, scale + b_j b_j') for every marker from the current beta (variance_components.jl:181-186,
+        df = the reference's df + 1); the next sweep(var_effect_matrix=None) uses them in place."""
+        sc = np.ascontiguousarray(scale, dtype=np.float64).reshape(-1)
+        if sc.size != self.ntraits * self.ntraits:
+            raise ValueError(f"scale must be {self.ntraits} x {self.ntraits}")
+        self._chk(self._L.jwas_hip_sample_marker_covariances(self._h, float(df), sc.ctypes.data_as(C.POINTER(C.c_double)), int(seed),
+                                                             int(iteration), int(marker_offset)))
+
+    def marker_covariances(self):
+        out = np.empty((self.p, self.ntraits, self.ntraits), dtype=np.float32)
+        self._chk(self._L.jwas_hip_get_marker_covariances(self._h, _ptr(out)))
+        return out
 
     # -- posterior accumulators --------------------------------------------------------------------
     def accumulate(self, nsamples):

@@ -475,7 +475,12 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
             dense = float(np.asarray(pi, dtype=np.float64)[0]) < 0.5
         else:
             dense = float(np.mean(pi)) < 0.5
-        block_size = 128 if dense else 512
+        # ... except when the prior includes every marker whatever its rhs (single-trait BayesA / B / C with Pi = 0, RR-BLUP,
+        # BayesL): the sampler's dense_big_st path walks 512-marker blocks section by section (diagonal Gram tiles in LDS,
+        # the rest applied in parallel) -- four times fewer launches of the streaming role.
+        all_in = (t == 1 and method in ("BayesC", "BayesB") and np.ndim(pi) == 0 and float(pi) == 0.0 and not Mi.estimatePi
+                  and getattr(Mi, "annotations", False) is False)
+        block_size = (512 if all_in else 128) if dense else 512
         while block_size > 64 and p <= block_size:
             block_size //= 2
         while mt_pervar and block_size * t > 2048:                      # the markers' own constants are parked in LDS
@@ -719,8 +724,13 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
                 if mega:                                                    # diagonal only (variance_components.jl:104-109)
                     Gval = np.diag([(st["beta_ss"][k, k] + Gdf * Mi.G.scale[k, k]) / rng.chisquare(p + Gdf) for k in range(t)]).astype(np.float32)
                 elif mt_pervar:                                             # variance_components.jl:181-186: one draw per marker,
-                    B = np.stack([engine.get_state(k)[1] for k in range(t)], axis=1).astype(np.float64)     # IW(df + 1, scale + b_j b_j')
-                    Gmat = _inverse_wishart_batch(rng, Gdf + 1.0, np.asarray(Mi.G.scale, dtype=np.float64)[None] + B[:, :, None] * B[:, None, :]).astype(np.float32)
+                    if hasattr(engine, "sample_marker_covariances"):        # IW(df + 1, scale + b_j b_j') -- on the device, from the
+                        # resident beta (jwas_hip_sample_marker_covariances: Bartlett on the counter RNG); the next sweep uses them in place
+                        engine.sample_marker_covariances(Gdf + 1.0, np.asarray(Mi.G.scale, dtype=np.float64), seed=seed_int, iteration=it)
+                        Gmat = None
+                    else:
+                        B = np.stack([engine.get_state(k)[1] for k in range(t)], axis=1).astype(np.float64)
+                        Gmat = _inverse_wishart_batch(rng, Gdf + 1.0, np.asarray(Mi.G.scale, dtype=np.float64)[None] + B[:, :, None] * B[:, None, :]).astype(np.float32)
                 elif t > 1:
                     from scipy.stats import invwishart
                     S = np.asarray(Mi.G.scale, dtype=np.float64) + st["beta_ss"]

@@ -453,6 +453,80 @@ static int inv_small(const float* A, int t, float* Ainv)
  * matrix instead of using the sweep-wide var_effect. */
 static const float* g_var_effect_mat = NULL;
 void orc_set_var_effect_matrix(const float* mat) { g_var_effect_mat = mat; }
+
+/* ------------------------------------------------------------------------------------------ */
+/* Multi-trait BayesA/B: one InverseWishart(df, scale + b_j b_j') draw per marker                 */
+/* (sample_variance(data, 1, df, scale) per marker, variance_components.jl:181-186; the caller's  */
+/* df is the reference's df + 1).  Bartlett's decomposition on the counter RNG, operation for     */
+/* operation the device's k_sample_marker_covariances (csrc/sweep.hpp):                            */
+/*   S = scale + b b' = C C';  A lower-triangular, A_ii = sqrt(chi2(df - i)), A_ik ~ N(0,1);       */
+/*   K' = A^-1 C' (forward substitution);  G = K K', symmetrised, rounded to float.                */
+/* Counter of a draw: (global marker, iteration, 0x80000000 | attempt, slot).                      */
+/* ------------------------------------------------------------------------------------------ */
+static void chol_lower(int t, const double* A, double* L);
+static double iw_chi2(uint64_t seed, uint32_t marker, uint32_t iter, uint32_t slot, double nu)
+{
+    uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) }, w[4], w2[4];
+    double a = 0.5 * nu, boost = 1.0;
+    if (a < 1.0) {
+        uint32_t ctr[4] = { marker, iter, 0x80000000u | 0xFFFFu, slot };
+        orc_philox4x32_10(ctr, key, w);
+        boost = exp(log(u52(w[0], w[1])) / a);
+        a = a + 1.0;
+    }
+    const double d = a - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
+    double g = d;
+    for (uint32_t attempt = 0; attempt < 64u; ++attempt) {
+        uint32_t ctr[4] = { marker, iter, 0x80000000u | attempt, slot }, ctr2[4] = { marker, iter, 0x80000000u | attempt, slot + 1u };
+        orc_philox4x32_10(ctr, key, w);
+        orc_philox4x32_10(ctr2, key, w2);
+        const double x = sqrt(-2.0 * log(u52(w[0], w[1]))) * cos(6.283185307179586476925286766559 * u52(w[2], w[3]));
+        const double u = u52(w2[0], w2[1]);
+        double v = 1.0 + c * x;
+        if (v <= 0.0) continue;
+        v = v * v * v;
+        g = d * v;
+        if (log(u) < 0.5 * x * x + d - d * v + d * log(v)) break;
+    }
+    return 2.0 * g * boost;
+}
+
+void orc_sample_marker_covariances(int t, int64_t p, const float* beta /* [t][p] */, double df, const double* scale /* t x t */,
+                                   uint64_t seed, uint32_t iter, uint32_t marker0, float* var_mat /* [p][t][t] */)
+{
+    uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) }, w[4];
+    for (int64_t j = 0; j < p; ++j) {
+        const uint32_t marker = marker0 + (uint32_t)j;
+        double b[ORC_MAXT], S[ORC_MAXT * ORC_MAXT], C[ORC_MAXT * ORC_MAXT], A[ORC_MAXT * ORC_MAXT], Kt[ORC_MAXT * ORC_MAXT], G[ORC_MAXT * ORC_MAXT];
+        for (int a = 0; a < t; ++a) b[a] = (double)beta[(int64_t)a * p + j];
+        for (int a = 0; a < t; ++a)
+            for (int c = 0; c < t; ++c) { S[a * t + c] = scale[a * t + c] + b[a] * b[c]; A[a * t + c] = 0.0; }
+        chol_lower(t, S, C);
+        for (int i = 0; i < t; ++i) {
+            A[i * t + i] = sqrt(iw_chi2(seed, marker, iter, 32u + 2u * (uint32_t)i, df - (double)i));
+            for (int k = 0; k < i; ++k) {
+                uint32_t ctr[4] = { marker, iter, 0x80000000u, 64u + 4u * (uint32_t)i + (uint32_t)k };
+                orc_philox4x32_10(ctr, key, w);
+                A[i * t + k] = sqrt(-2.0 * log(u52(w[0], w[1]))) * cos(6.283185307179586476925286766559 * u52(w[2], w[3]));
+            }
+        }
+        for (int i = 0; i < t; ++i)
+            for (int c = 0; c < t; ++c) {
+                double acc = C[c * t + i];                                        /* C'[i][c] */
+                for (int k = 0; k < i; ++k) acc = acc - A[i * t + k] * Kt[k * t + c];
+                Kt[i * t + c] = acc / A[i * t + i];
+            }
+        for (int a = 0; a < t; ++a)
+            for (int c = 0; c < t; ++c) {
+                double s = 0.0;
+                for (int i = 0; i < t; ++i) s = s + Kt[i * t + a] * Kt[i * t + c];
+                G[a * t + c] = s;
+            }
+        for (int a = 0; a < t; ++a)
+            for (int c = 0; c < t; ++c) var_mat[(j * t + a) * t + c] = (float)(0.5 * (G[a * t + c] + G[c * t + a]));
+    }
+}
+
 static inline const float* marker_ginv(int64_t j, int t, const float* Ginv_all, float* tmp)
 {
     if (!g_var_effect_mat) return Ginv_all;

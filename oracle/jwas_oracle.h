@@ -160,6 +160,10 @@ int orc_mtbayesc_I_lookahead_sweep(const float* X, int64_t n, int64_t p, int64_t
 /* Multi-trait BayesA/B: per-marker effect covariances (p x t x t row-major; MTBayesABC.jl:66,86-90) used by every
  * multi-trait sweep until reset with NULL (harness state; sampler I). */
 void orc_set_var_effect_matrix(const float* mat);
+/* One InverseWishart(df, scale + b_j b_j') draw per marker (variance_components.jl:181-186; df = the reference's df + 1),
+ * Bartlett on the counter RNG: the restatement the device's k_sample_marker_covariances is compared with. */
+void orc_sample_marker_covariances(int t, int64_t p, const float* beta, double df, const double* scale,
+                                   uint64_t seed, uint32_t iter, uint32_t marker0, float* var_mat);
 int orc_mt_sweep(int kind, const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
                  int t, float* r, int64_t ld_r, float* alpha, float* beta, float* delta,
                  const float* vare, const float* var_effect, const double* log_prior, int prior_is_matrix,

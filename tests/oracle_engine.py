@@ -169,7 +169,10 @@ class OracleEngine:
         a_before = self.alpha.copy()
         self._w()
         if self.method == MTBAYESB1:                  # multi-trait BayesA/B: one effect covariance per marker
-            vm = np.ascontiguousarray(var_effect_matrix, dtype=np.float32)
+            if var_effect_matrix is None:             # (None: the resident ones -- an earlier sweep's or sample_marker_covariances')
+                var_effect_matrix = self._var_mat
+            self._var_mat = np.ascontiguousarray(var_effect_matrix, dtype=np.float32)
+            vm = self._var_mat
             assert vm.shape == (self.p, t, t)
             O.set_var_effect_matrix(vm)
             var_effect = np.eye(t, dtype=np.float32)  # (unused)
@@ -227,6 +230,13 @@ class OracleEngine:
                 state |= (d[k] != 0).astype(np.int64) << k
             out["state_counts"] = np.bincount(state, minlength=1 << t).astype(np.float64)
         return out
+
+    def sample_marker_covariances(self, df, scale, *, seed, iteration, marker_offset=0):
+        """The oracle's restatement of jwas_hip_sample_marker_covariances (same counter RNG, same operations)."""
+        self._var_mat = O.sample_marker_covariances(self.beta, df, scale, seed, iteration, marker_offset)
+
+    def marker_covariances(self):
+        return self._var_mat.copy()
 
     def accumulate(self, nsamples):
         for k in range(self.ntraits):

@@ -572,8 +572,12 @@ def test_device_resident_engine_is_reset_between_runs(tmp_path):
     wts = rng.uniform(0.5, 2.0, 300)
     ph = pd.DataFrame({"ID": ids, "y1": d["y"], "weights": wts})
 
+    info = {}
+
     def run(eng, tag, **kw):
-        geno = api.device_genotypes(eng, method="BayesC", Pi=0.9, estimatePi=True, obsID=ids)
+        # (allele frequencies / sum 2pq come from the unweighted x'x of the first call; a weighted engine refuses to derive them)
+        geno = api.device_genotypes(eng, method="BayesC", Pi=0.9, estimatePi=True, obsID=ids, **info)
+        info.update(alleleFreq=geno.alleleFreq, sum2pq=geno.sum2pq)
         model = api.build_model("y1 = intercept + geno", genotypes={"geno": geno})
         return api.runMCMC(model, ph, chain_length=30, burnin=5, seed=4, outputEBV=False, output_folder=str(tmp_path / tag),
                            printout_model_info=False, **kw)["marker effects geno"]
@@ -600,7 +604,11 @@ def test_device_resident_engine_is_reset_between_runs(tmp_path):
     eng.close()
 
     with pytest.raises(ValueError, match="centered=False"):
-        api.device_genotypes(HipEngine(0) if False else _Dummy(300, 900), centered=False)
+        api.device_genotypes(_Dummy(300, 900), centered=False)
+    weighted = _Dummy(300, 900)
+    weighted._weighted = True
+    with pytest.raises(ValueError, match="residual weights"):
+        api.device_genotypes(weighted)
 
 
 class _Dummy:

@@ -803,10 +803,20 @@ def test_mt_bayesb_per_marker_covariance_parity(hip, t, bs, dense, nreps):
     for k in range(t):
         _compare_state(orc, hip, k, atol=5e-6)
     # error contracts
-    with pytest.raises(ValueError, match="var_effect_matrix"):
-        hip.sweep(iteration=1, seed=1, vare=vare, var_effect=np.eye(t, dtype=np.float32), log_prior_states=np.log(prior))
     with pytest.raises(J.JwasHipError, match="independent_blocks"):
         hip.sweep(iteration=1, seed=1, independent_blocks=True, **kw)
+    # var_effect_matrix=None means "the covariances resident on the device" (an earlier sweep's, or those drawn by
+    # jwas_hip_sample_marker_covariances): same chain as handing the same matrices over again ...
+    a_before = [hip.get_state(k)[0].copy() for k in range(t)]
+    kw_res = dict(kw); kw_res["var_effect_matrix"] = None
+    orc.sweep(iteration=13, seed=13, **kw); hip.sweep(iteration=13, seed=13, **kw_res)
+    for k in range(t):
+        _compare_state(orc, hip, k, atol=5e-6)
+    assert any(not np.array_equal(a_before[k], hip.get_state(k)[0]) for k in range(t))
+    # ... and an error while none are resident (a fresh state)
+    hip.init_state("MTBayesB", t)
+    with pytest.raises(J.JwasHipError, match="per-marker effect covariances"):
+        hip.sweep(iteration=1, seed=1, **kw_res)
 
 
 def test_mt_bayesb_needs_parked_draws(hip):
@@ -960,3 +970,159 @@ def test_every_bit_equal_when_the_oracle_sums_in_the_device_order(hip, method, t
     finally:
         O.set_device_order(8)
         hip.set_weights(None)
+
+
+def test_cooperative_dense_apply_stress_at_production_geometry(monkeypatch):
+    """Stress run of the cooperative dense apply (sweep.hpp update_role<COOP>): the protocol publishes a row group's shares
+    with relaxed agent-scope stores + s_waitcnt, counts arrivals in a relaxed counter and reads the peers' shares with
+    relaxed agent-scope loads -- it relies on the hardware's ordering of a wave's own stores, so a stale read would be a
+    silently wrong residual.  >= 10 000 cooperative launches at the production geometry (n = 50 000: 28 row groups x 8
+    column groups, every CU busy, Pi = 0 so every marker of every block changes), residual and effects compared BIT FOR
+    BIT with the redundant apply (JWAS_HIP_COOP_APPLY=0) every ten sweeps."""
+    import os
+    import jwas_jl_amd as J
+    n, p, bs, sweeps = 50_000, 12_800, 128, 100
+    engs = {}
+    try:
+        for tag in ("coop", "plain"):
+            e = J.HipEngine(0)
+            e.alloc_dense(n, p)
+            e.synth(11, kind=0, center=True)
+            e.setup_blocks(bs, "mfma")
+            e.init_state("BayesC", 1)
+            engs[tag] = e
+        rng = np.random.default_rng(3)
+        y = rng.standard_normal(n).astype(np.float32)
+        for e in engs.values():
+            e.set_residual(y)
+        launches = 0
+        for it in range(1, sweeps + 1):
+            for tag, e in engs.items():
+                monkeypatch.setenv("JWAS_HIP_COOP_APPLY", "1" if tag == "coop" else "0")      # (read once per sweep)
+                st = e.sweep(iteration=it, seed=5, vare=np.float32(1.0), var_effect=np.float32(1e-4), pi=0.0)
+                assert st["n_events"] == p
+            launches += p // bs + 1
+            if it % 10 == 0:
+                assert np.array_equal(engs["coop"].get_residual(), engs["plain"].get_residual()), f"residuals differ after sweep {it}"
+                assert np.array_equal(engs["coop"].get_state()[0], engs["plain"].get_state()[0]), f"effects differ after sweep {it}"
+        assert launches >= 10_000
+        # and the residual still is y - X alpha (what a stale share would break first)
+        e = engs["coop"]
+        r = e.get_residual().astype(np.float64)
+        xa = e.mul_alpha(0).astype(np.float64)
+        assert np.abs((y.astype(np.float64) - xa) - r).max() < 5e-3
+    finally:
+        for e in engs.values():
+            e.close()
+
+
+@pytest.mark.parametrize("method,bs,n,p", [("BayesC", 256, 900, 256 * 4 + 77), ("BayesC", 512, 2300, 512 * 3 + 130),
+                                           ("BayesA", 512, 700, 512 * 2), ("BayesC", 256, 300, 256 * 3)])
+def test_dense_big_blocks_parity(method, bs, n, p, monkeypatch):
+    """Pi = 0 on 256- / 512-marker blocks: the sampler's dense_big_st path (sweep.hpp) -- 64-marker sections walked by one
+    wave each from LDS-resident diagonal Gram tiles, everything off the diagonal applied in parallel from prefetched
+    registers, the lookahead correction accumulated section by section.  It performs the sequential chain's own fmaf
+    sequence, so the chain must equal the oracle's lookahead form (indicators exactly, effects to the rounding of x'r) and
+    must equal BIT FOR BIT what the general path gives (JWAS_HIP_DENSE_BIG_OFF=1); the ragged last block runs the general
+    path inside the same sweep."""
+    import jwas_jl_amd as J
+    monkeypatch.setenv("JWAS_HIP_SPG", "4")                                  # several row groups also on short matrices
+    data = make_dataset(n=n, p=p, ncausal=10, seed=41)
+    y = (data["y"] - data["y"].mean()).astype(np.float32)
+    rng = np.random.default_rng(2)
+    kw = dict(vare=np.float32(0.7), var_effect=np.float32(0.003), pi=0.0)
+    code = "BayesB" if method == "BayesA" else method
+    if method == "BayesA":
+        kw["var_effect_vec"] = rng.uniform(0.001, 0.01, size=p).astype(np.float32)
+    res = {}
+    for tag in ("oracle", "big", "general"):
+        if tag == "general":
+            monkeypatch.setenv("JWAS_HIP_DENSE_BIG_OFF", "1")
+        e = OracleEngine("lookahead") if tag == "oracle" else J.HipEngine(0)
+        try:
+            e.load_dense(data["X"]); e.setup_blocks(bs, "f64"); e.init_state(code, 1)
+            e.set_residual(y)
+            ev = [e.sweep(iteration=it, seed=21, **kw)["n_events"] for it in range(1, 6)]
+            res[tag] = (e.get_state(0), e.get_residual(0), ev)
+        finally:
+            if tag != "oracle":
+                e.close()
+    assert res["big"][2] == res["general"][2] == res["oracle"][2] == [float(p)] * 5
+    for q in range(3):
+        assert np.array_equal(res["big"][0][q], res["general"][0][q])
+    assert np.array_equal(res["big"][1], res["general"][1])
+    assert np.array_equal(res["big"][0][2], res["oracle"][0][2])
+    np.testing.assert_allclose(res["big"][0][0], res["oracle"][0][0], atol=5e-6)
+    np.testing.assert_allclose(res["big"][1], res["oracle"][1], atol=2e-4)
+
+
+def test_dense_big_blocks_every_bit_equal_the_oracle(hip):
+    """dense_big_st against the oracle with the oracle summing x'r in the device's order and the device using the oracle's
+    inner products: every effect and residual element equal bit for bit (the same standard as
+    test_every_bit_equal_when_the_oracle_sums_in_the_device_order), BayesC Pi = 0 on 512-marker blocks, two full blocks."""
+    import oracle as O
+    n, p, bs = 1100, 512 * 2, 512
+    d = make_dataset(n=n, p=p, ncausal=10, seed=43)
+    y = (d["y"] - d["y"].mean()).astype(np.float32)
+    hip.load_dense(d["X"]); hip.setup_blocks(bs, "f64"); hip.init_state("BayesC", 1)
+    spg, nrg, ncg = hip.update_geometry()
+    O.set_device_order(spg)
+    orc = OracleEngine("lookahead", acc=O.ACC_DEVICE)
+    orc.load_dense(d["X"]); orc.setup_blocks(bs); orc.init_state("BayesC", 1)
+    hip.set_xpx(orc._xpx)
+    hip.set_grams_packed(orc._grams)
+    starts = list(orc._bs) + [p]
+    for k in range(1, len(starts) - 1):
+        hip.set_cross_gram(k, O.cross_gram(d["X"], starts[k - 1], starts[k] - starts[k - 1], starts[k], starts[k + 1] - starts[k], O.ACC_DEVICE))
+    orc.set_residual(y); hip.set_residual(y)
+    for it in range(1, 6):
+        kw = dict(iteration=it, seed=8, vare=np.float32(0.6), var_effect=np.float32(0.002), pi=0.0)
+        so = orc.sweep(**kw); sh = hip.sweep(**kw)
+        assert so["n_events"] == sh["n_events"] == p
+        assert np.array_equal(hip.get_state(0)[0], orc.get_state(0)[0]), f"iteration {it}"
+        assert np.array_equal(hip.get_residual(0), orc.get_residual(0)), f"iteration {it}"
+
+
+@pytest.mark.parametrize("t", [2, 3, 4])
+def test_marker_covariance_draws_device_vs_oracle(hip, t):
+    """jwas_hip_sample_marker_covariances: one InverseWishart(df, scale + b_j b_j') draw per marker from the resident beta
+    (variance_components.jl:181-186; Bartlett's decomposition on the counter RNG, keyed by the global marker index) against
+    the oracle's restatement -- same counters, same operations, double arithmetic rounded to float once: equal to the last
+    bit except where libm and the device's log / cos / sqrt differ in their last place -- and against the distribution's
+    mean E[G] = (scale + b b') / (df - t - 1)."""
+    import oracle as O
+    n, p = 300, 6000
+    d = make_dataset(n=n, p=p, ncausal=5, seed=17)
+    hip.load_dense(d["X"]); hip.setup_blocks(64, "f64"); hip.init_state("MTBayesB", t)
+    rng = np.random.default_rng(t)
+    beta = (0.05 * rng.standard_normal((t, p))).astype(np.float32)
+    for k in range(t):
+        hip.set_state(k, alpha=beta[k], beta=beta[k], delta=np.ones(p, dtype=np.float32))
+    A = rng.standard_normal((t, t))
+    scale = (A @ A.T / t + np.eye(t)) * 0.01
+    df = t + 5.0
+    hip.sample_marker_covariances(df, scale, seed=11, iteration=4, marker_offset=1000)
+    Gh = hip.marker_covariances()
+    Go = O.sample_marker_covariances(beta, df, scale, 11, 4, 1000)
+    assert np.isfinite(Gh).all()
+    np.testing.assert_allclose(Gh, Go, rtol=2e-6, atol=0)
+    assert (Gh == Go).mean() > 0.98
+    assert np.array_equal(Gh, Gh.transpose(0, 2, 1))
+    # a different iteration / marker offset gives different draws; the same call the same draws
+    hip.sample_marker_covariances(df, scale, seed=11, iteration=4, marker_offset=1000)
+    assert np.array_equal(hip.marker_covariances(), Gh)
+    hip.sample_marker_covariances(df, scale, seed=11, iteration=5, marker_offset=1000)
+    assert not np.array_equal(hip.marker_covariances(), Gh)
+    # mean of the draws (b = 0: E[G] = scale / (df - t - 1))
+    for k in range(t):
+        hip.set_state(k, beta=np.zeros(p, dtype=np.float32))
+    hip.sample_marker_covariances(df, scale, seed=3, iteration=1)
+    np.testing.assert_allclose(hip.marker_covariances().mean(axis=0), scale / (df - t - 1), rtol=0.15, atol=2e-4)
+    # the next sweep uses the resident draws (no matrix handed over)
+    y = (d["y"] - d["y"].mean()).astype(np.float32)
+    for k in range(t):
+        hip.set_residual(y, k)
+    prior = np.full(1 << t, 0.5 / ((1 << t) - 1)); prior[0] = 0.5
+    st = hip.sweep(iteration=1, seed=3, vare=np.eye(t, dtype=np.float32) * 0.5, var_effect=np.eye(t, dtype=np.float32),
+                   log_prior_states=np.log(prior))
+    assert st["state_counts"].sum() == p
