@@ -114,6 +114,11 @@ typedef struct jwas_sweep_params {
     const float*  var_effect_matrix;    /* MTBAYESB1: p x t x t row-major per-marker effect covariances (host); inverted on the   */
                                         /* device once per sweep; needs block_size * ntraits <= 2048.  NULL = the covariances     */
                                         /* resident on the device (an earlier sweep's, or jwas_hip_sample_marker_covariances)     */
+    /* Float64 contexts (jwas_hip_set_precision(ctx, 64); runMCMC(double_precision=true)) read these instead of vare /     */
+    /* var_effect / var_effect_vec -- the same quantities as Float64, as the reference holds them in that mode:           */
+    double   vare_f64[JWAS_HIP_MAX_TRAITS * JWAS_HIP_MAX_TRAITS];
+    double   var_effect_f64[JWAS_HIP_MAX_TRAITS * JWAS_HIP_MAX_TRAITS];
+    const double* var_effect_vec_f64;   /* BayesB: p per-marker variances (host), else NULL                                */
 } jwas_sweep_params;
 
 /* Reductions the host-side conjugate draws need (Pi.jl, variance_components.jl). */
@@ -327,6 +332,24 @@ int  jwas_hip_comm_init_loopback(jwas_hip_ctx* ctx, int32_t slot, int32_t rank, 
 int  jwas_hip_sample_marker_covariances(jwas_hip_ctx* ctx, double df, const double* scale_txt, uint64_t seed,
                                         uint32_t iteration, uint32_t marker_offset);
 int  jwas_hip_get_marker_covariances(jwas_hip_ctx* ctx, float* out_p_t_t);      /* p x t x t row-major */
+
+/* ---- Float64 mode: runMCMC(double_precision=true) (JWAS.jl:349-366; genotypes read as Float64, readgenotypes.jl:298,345) ----
+ * In that mode the reference holds EVERYTHING as Float64 -- genotypes, ycorr, alpha / beta / delta, x'x -- and its scalar
+ * kernels run in Float64.  jwas_hip_set_precision(ctx, 64) BEFORE genotypes are loaded makes the context a Float64 context:
+ * the data entry points below replace their Float32 namesakes (same meaning, double host arrays; delta is double 0/1, or
+ * int32 classes for BayesR); jwas_hip_setup_blocks (block_size 64 or 128), jwas_hip_init_state, jwas_hip_sweep (reading
+ * jwas_sweep_params.vare_f64 / var_effect_f64 / var_effect_vec_f64), jwas_hip_residual_sub_xalpha, jwas_hip_accumulate and
+ * jwas_hip_num_blocks are shared.  Samplers: single-trait BayesA/B/C, BayesR, multi-trait sampler I; dense storage;
+ * within-block repetitions.  Everything else of the Float32 surface returns JWAS_HIP_EUNSUP on a Float64 context. */
+int  jwas_hip_set_precision(jwas_hip_ctx* ctx, int32_t bits);                     /* 32 (default) or 64 */
+int  jwas_hip_load_dense_f64(jwas_hip_ctx* ctx, const double* X_host, int64_t n, int64_t p, int64_t ld_host);
+int  jwas_hip_get_xpx_f64(jwas_hip_ctx* ctx, double* out_p);
+int  jwas_hip_set_state_f64(jwas_hip_ctx* ctx, int32_t trait, const double* alpha, const double* beta, const void* delta);
+int  jwas_hip_get_state_f64(jwas_hip_ctx* ctx, int32_t trait, double* alpha, double* beta, void* delta);
+int  jwas_hip_set_residual_f64(jwas_hip_ctx* ctx, int32_t trait, const double* r_host);
+int  jwas_hip_get_residual_f64(jwas_hip_ctx* ctx, int32_t trait, double* r_host);
+int  jwas_hip_mul_alpha_f64(jwas_hip_ctx* ctx, int32_t trait, double* out_host);
+int  jwas_hip_get_posterior_f64(jwas_hip_ctx* ctx, int32_t trait, double* mean_alpha, double* mean_alpha2, double* mean_delta);
 
 /* ---- posterior accumulators (output.jl:568-577) ---------------------------------------------- */
 int  jwas_hip_accumulate(jwas_hip_ctx* ctx, double nsamples);

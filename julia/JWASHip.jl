@@ -38,6 +38,9 @@ struct HipSweepParams
     pi_matrix::Ptr{Float64}
     log_prior_states_matrix::Ptr{Float64}
     var_effect_matrix::Ptr{Float32}
+    vare_f64::NTuple{16,Float64}
+    var_effect_f64::NTuple{16,Float64}
+    var_effect_vec_f64::Ptr{Float64}
 end
 
 struct HipSweepStats
@@ -102,6 +105,11 @@ hip_set_residual!(b::HipBackend, trait::Integer, r::Vector{Float32}) =
 hip_get_residual!(b::HipBackend, trait::Integer, r::Vector{Float32}) =
     hip_check(b.ctx, ccall((:jwas_hip_get_residual, LIBJWAS_HIP), Cint, (Ptr{Cvoid}, Int32, Ptr{Float32}), b.ctx, trait, r))
 
+"Float64 context (runMCMC(double_precision=true), JWAS.jl:349-366): call before loading genotypes; the data entry points are then
+jwas_hip_load_dense_f64 / _set_state_f64 / _get_state_f64 / _set_residual_f64 / _get_residual_f64 / _get_posterior_f64 (Ptr{Float64})."
+hip_set_precision!(ctx::Ptr{Cvoid}, bits::Integer) =
+    hip_check(ctx, ccall((:jwas_hip_set_precision, LIBJWAS_HIP), Cint, (Ptr{Cvoid}, Int32), ctx, bits))
+
 "ycorr .+= shift on the device: the residual correction of an all-ones design column (intercept step, solver.jl:143-162)."
 hip_residual_add_scalar!(b::HipBackend, trait::Integer, shift::Real) =
     hip_check(b.ctx, ccall((:jwas_hip_residual_add_scalar, LIBJWAS_HIP), Cint, (Ptr{Cvoid}, Int32, Cdouble), b.ctx, trait, shift))
@@ -118,7 +126,8 @@ function HipSweepParams(method::Integer, iter::Integer, seed::Integer; vare::Rea
                    UInt32(independent_blocks), Base.setindex(_z16(Float32), Float32(vare), 1),
                    Base.setindex(_z16(Float32), Float32(var_effect), 1), Float64(pi), NTuple{4,Float64}(pi_classes),
                    NTuple{4,Float64}(gamma), _z16(Float64), var_effect_vec, pi_vec, pi_matrix, Ptr{Float64}(C_NULL),
-                   Ptr{Float32}(C_NULL))
+                   Ptr{Float32}(C_NULL), Base.setindex(_z16(Float64), Float64(vare), 1),
+                   Base.setindex(_z16(Float64), Float64(var_effect), 1), Ptr{Float64}(C_NULL))      # (the Float64 context's copies)
 end
 
 "One marker sweep = one call of BayesABC! / BayesR! / MTBayesABC! (BayesABC.jl:60-80, BayesR.jl:45-97, MTBayesABC.jl:57-127)."

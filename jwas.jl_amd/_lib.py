@@ -33,6 +33,8 @@ SYMBOLS = [
     "jwas_hip_comm_row_shards", "jwas_hip_comm_init_loopback", "jwas_hip_update_geometry", "jwas_hip_set_cross_gram",
     "jwas_hip_set_columns", "jwas_hip_get_alpha_sparse", "jwas_hip_comm_unique_id", "jwas_hip_comm_init", "jwas_hip_comm_destroy", "jwas_hip_sweep_sharded",
     "jwas_hip_residual_add_scalar", "jwas_hip_comm_info", "jwas_hip_sample_marker_covariances", "jwas_hip_get_marker_covariances",
+    "jwas_hip_set_precision", "jwas_hip_load_dense_f64", "jwas_hip_get_xpx_f64", "jwas_hip_set_state_f64", "jwas_hip_get_state_f64",
+    "jwas_hip_set_residual_f64", "jwas_hip_get_residual_f64", "jwas_hip_mul_alpha_f64", "jwas_hip_get_posterior_f64",
 ]
 STORAGE_DENSE_F32, STORAGE_PACKED2BIT = 0, 1
 
@@ -50,6 +52,9 @@ class SweepParams(C.Structure):
         ("pi_matrix", C.POINTER(C.c_double)),
         ("log_prior_states_matrix", C.POINTER(C.c_double)),
         ("var_effect_matrix", C.POINTER(C.c_float)),
+        ("vare_f64", C.c_double * (MAX_TRAITS * MAX_TRAITS)),
+        ("var_effect_f64", C.c_double * (MAX_TRAITS * MAX_TRAITS)),
+        ("var_effect_vec_f64", C.POINTER(C.c_double)),
     ]
 
 
@@ -138,6 +143,15 @@ def load():
     L.jwas_hip_residual_add_scalar.argtypes = [vp, i32, C.c_double]
     L.jwas_hip_sample_marker_covariances.argtypes = [vp, C.c_double, f64p, u64, C.c_uint32, C.c_uint32]
     L.jwas_hip_get_marker_covariances.argtypes = [vp, vp]
+    L.jwas_hip_set_precision.argtypes = [vp, i32]
+    L.jwas_hip_load_dense_f64.argtypes = [vp, vp, i64, i64, i64]
+    L.jwas_hip_get_xpx_f64.argtypes = [vp, vp]
+    L.jwas_hip_set_state_f64.argtypes = [vp, i32, vp, vp, vp]
+    L.jwas_hip_get_state_f64.argtypes = [vp, i32, vp, vp, vp]
+    L.jwas_hip_set_residual_f64.argtypes = [vp, i32, vp]
+    L.jwas_hip_get_residual_f64.argtypes = [vp, i32, vp]
+    L.jwas_hip_mul_alpha_f64.argtypes = [vp, i32, vp]
+    L.jwas_hip_get_posterior_f64.argtypes = [vp, i32, vp, vp, vp]
     L.jwas_hip_accumulate.argtypes = [vp, C.c_double]
     L.jwas_hip_get_posterior.argtypes = [vp, i32, vp, vp, vp]
     L.jwas_hip_load_jgb2.argtypes = [vp, C.c_char_p]

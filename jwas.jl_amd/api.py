@@ -110,14 +110,11 @@ def get_genotypes(file, G=False, *, method="BayesC", Pi=0.0, estimatePi=True,
                 raise ValueError("length of starting values is wrong.")
             g.alpha = sv
         return g
-    if double_precision:
-        raise NotImplementedError("the MI355X path is Float32 (double_precision=false), like the reference's "
-                                  "storage=:stream mode (readgenotypes.jl:246-248)")
     if method not in SUPPORTED_METHODS:
         raise NotImplementedError(f"method {method} is not on the device path (supported: {SUPPORTED_METHODS}); "
                                   "GBLUP / RR-BLUP / BayesL stay on the reference")
 
-    data_type = np.float32
+    data_type = np.float64 if double_precision else np.float32           # readgenotypes.jl:298: Float64 genotypes on request
     try:
         import pandas as pd
     except ImportError:                                              # pragma: no cover
@@ -130,7 +127,7 @@ def get_genotypes(file, G=False, *, method="BayesC", Pi=0.0, estimatePi=True,
         from collections import defaultdict
         # marker columns are parsed straight to Float32 (the reference's default precision): half the transient memory
         tab = pd.read_csv(file, sep=separator, header=None, skiprows=1 if header else 0,
-                          dtype=defaultdict(lambda: np.float32, {0: str}))
+                          dtype=defaultdict(lambda: data_type, {0: str}))
         obsID = [str(v) for v in tab.iloc[:, 0]]
         genotypes = np.asfortranarray(tab.iloc[:, 1:].to_numpy(dtype=data_type))
     elif pd is not None and isinstance(file, pd.DataFrame):                                   # :328-338
@@ -156,13 +153,13 @@ def get_genotypes(file, G=False, *, method="BayesC", Pi=0.0, estimatePi=True,
             col = genotypes[:, j]
             miss = col == mv
             if miss.any():
-                col[miss] = col[~miss].mean(dtype=np.float32)
+                col[miss] = col[~miss].mean(dtype=data_type)
     if center:                                                                                # :384
-        markerMeans = genotypes.mean(axis=0, dtype=np.float32).astype(np.float32)
+        markerMeans = genotypes.mean(axis=0, dtype=data_type).astype(data_type)
         genotypes -= markerMeans[None, :]
     else:
-        markerMeans = genotypes.mean(axis=0, dtype=np.float32).astype(np.float32)
-    p = (markerMeans / data_type(2.0)).astype(np.float32)                                     # :385
+        markerMeans = genotypes.mean(axis=0, dtype=data_type).astype(data_type)
+    p = (markerMeans / data_type(2.0)).astype(data_type)                                      # :385
     if quality_control:                                                                       # :388-399
         select1 = (MAF < p) & (p < 1 - MAF)
         select2 = genotypes.var(axis=0, ddof=1) != 0
@@ -174,7 +171,7 @@ def get_genotypes(file, G=False, *, method="BayesC", Pi=0.0, estimatePi=True,
             annotation_matrix = annotation_matrix[select, :]
         print(f"{int((~select).sum())} loci which are fixed or have minor allele frequency < {MAF} are removed.")
     nObs, nMarkers = genotypes.shape
-    sum2pq = float((2.0 * p.astype(np.float32) * (1.0 - p.astype(np.float32))).sum(dtype=np.float32))   # :401
+    sum2pq = float((2.0 * p.astype(data_type) * (1.0 - p.astype(data_type))).sum(dtype=data_type))   # :401
 
     g = Genotypes(obsID, markerID, nObs, nMarkers, p, sum2pq, center, genotypes)
     g.G = Variance(G if G_is_marker_variance else False, df, False, estimate_variance, estimate_scale, constraint)   # :424
@@ -193,7 +190,7 @@ def get_genotypes(file, G=False, *, method="BayesC", Pi=0.0, estimatePi=True,
     print("Genotype informatin:")
     print(f"#markers: {nMarkers}; #individuals: {nObs}")
     if not _is_false(starting_value):                                                         # :438-446
-        sv = np.asarray(starting_value, dtype=np.float32).reshape(-1)
+        sv = np.asarray(starting_value, dtype=data_type).reshape(-1)
         if sv.size % nMarkers != 0:
             raise ValueError("length of starting values is wrong.")
         g.alpha = sv
@@ -387,11 +384,15 @@ def runMCMC(model, df, *, heterogeneous_residuals=False, chain_length=100, start
     independent_blocks=True (needs fast_blocks): every block starts from the same residual snapshot and all blocks are
     sampled concurrently on the device (BayesABC.jl:190-255) -- the reference's approximate parallel mode.
     `_engine` (private, not part of the reference's surface) lets the test-suite inject a sweep engine; the default and
-    only shipped engine is HipEngine."""
+    only shipped engine is HipEngine.
+
+    double_precision=True (JWAS.jl:349-366): genotypes, residual, effects and the samplers' arithmetic all Float64 -- a
+    Float64 device context (jwas_hip_set_precision; csrc/f64_path.hpp): single-trait BayesA/B/C, RR-BLUP, BayesL, BayesR and
+    multi-trait BayesC sampler I on dense storage; fast_blocks = 64 | 128."""
     if independent_blocks and fast_blocks is False:
         raise ValueError("independent_blocks=true requires fast_blocks != false.")             # :242-244
     for flag, name in ((single_step_analysis, "single_step_analysis"),
-                       (causal_structure, "causal_structure"), (RRM, "RRM"), (double_precision, "double_precision"),
+                       (causal_structure, "causal_structure"), (RRM, "RRM"),
                        (update_priors_frequency, "update_priors_frequency"),
                        (prediction_equation, "prediction_equation")):
         if not _is_false(flag) and flag != 0:
@@ -420,6 +421,7 @@ def runMCMC(model, df, *, heterogeneous_residuals=False, chain_length=100, start
                      output_samples_frequency=int(output_samples_frequency), seed=seed,
                      starting_value=starting_value, fast_blocks=fast_blocks,
                      independent_blocks=bool(independent_blocks), heterogeneous_residuals=bool(heterogeneous_residuals),
+                     double_precision=bool(double_precision),
                      outputEBV=outputEBV, output_heritability=bool(output_heritability),
                      output_folder=output_folder, printout_frequency=printout_frequency,
                      memory_guard=memory_guard, memory_guard_ratio=memory_guard_ratio,

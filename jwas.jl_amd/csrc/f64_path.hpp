@@ -1,0 +1,454 @@
+// f64_path.hpp -- the Float64 marker sweep (runMCMC(double_precision=true), JWAS.jl:349-366, readgenotypes.jl:298,345).
+//
+// In the reference double_precision=true makes EVERYTHING Float64: genotypes, residual, effects, x'x, the scalar kernels'
+// arithmetic.  This file is that mode on the device: the same exact block form of the single-site chain as the Float32 path
+// (x_j'(r - x_k D_k) = rhs_j - G_jk D_k; BayesABC.jl:118-188, BayesR.jl:111-193, MTBayesABC.jl:243-333) with every
+// quantity in double, written for clarity first:
+//
+//   per block k (b <= 128 markers), two stream-ordered launches:
+//     k64_update_partial   grid = 256-row slices: apply block k-1's changes to the slice of r (registers), then the slice's
+//                          partial right-hand side X_k[rows,:]' r  -- X is read once per sweep (+ once per changed column);
+//     k64_sample           one workgroup: rhs = sum of the slice partials (fixed order), the block's Gram (<= 128 KB of
+//                          doubles) staged in LDS, then one wave runs the block's single-site chain by speculative
+//                          parallel evaluation (all 64 lanes test their marker against the current rhs; the first lane
+//                          whose effect changes commits, its Gram row corrects the rhs, the rest are re-tested), the draws
+//                          fixed by the counter RNG -- the Float32 path's scheme without its fast paths.
+//
+// There is no lookahead here (launch k+1 starts when block k's sampler is done): the Float64 mode is the reference's
+// "more digits" switch, not its throughput mode -- ~2 launches of a few microseconds per 128 markers on top of streaming
+// 8 n p bytes.  Methods: single-trait BayesA/B/C (RR-BLUP, BayesL via the host), BayesR, multi-trait sampler I; dense
+// storage; within-block repetitions (fast_blocks).  Arithmetic: operation for operation the scalar kernels of the
+// reference with T = Float64 (bayesabc_update_marker! BayesABC.jl:24-58, BayesR! :56-96, _MTBayesABC_samplerI! :57-127);
+// inner products are plain double sums (order: 4 x 64 lanes per slice, slices in order), so the chain agrees with a
+// sequential double chain to ~1e-13 relative, not bit for bit.  Oracle: oracle/jwas_oracle_f64.c.
+#pragma once
+#include "kernels.hpp"
+
+namespace jw64 {
+using namespace jw;
+
+constexpr int kMaxBlock64 = 128;
+
+struct Events64 {
+    int32_t count;
+    int32_t idx[kMaxBlock64];               // global marker index
+    double  delta[kMaxT][kMaxBlock64];      // alpha_old - alpha_new per trait
+};
+
+struct Params64 {
+    int32_t method, ntraits, nreps;
+    uint32_t iter, seed_lo, seed_hi, marker0, pad0;
+    double vare[16], var_effect[16], Rinv[16], Ginv[16];
+    double pi, pi4[4], gamma[4], log_prior[kMaxStates];
+    const double* var_vec;      // p (BayesB)
+    const double* pi_vec;       // p
+    const double* pi_mat;       // p x 4
+};
+
+// ---- x'x --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k64_xpx(const double* __restrict__ X, int64_t ld, double* __restrict__ xpx)
+{
+    __shared__ double red[4];
+    const double* x = X + (int64_t)blockIdx.x * ld;
+    double v[1] = {0.0};
+    for (int64_t i = threadIdx.x; i < ld; i += 256) v[0] += x[i] * x[i];
+    block_sum<1>(v, red, 4);
+    if (threadIdx.x == 0) xpx[blockIdx.x] = v[0];
+}
+
+// ---- block Grams: G[blk][a][c] = x_a' x_c.  grid = (bs, nblocks), block = 256: workgroup (a, blk) writes row a. --------
+__global__ __launch_bounds__(256) void k64_gram(const double* __restrict__ X, int64_t ld, int64_t p, int bs, double* __restrict__ G)
+{
+    __shared__ double red[4];
+    const int64_t j0 = (int64_t)blockIdx.y * bs;
+    const int b = (int)((j0 + bs <= p) ? bs : p - j0);
+    const int a = blockIdx.x;
+    if (a >= b) return;
+    const double* xa = X + (j0 + a) * ld;
+    double* out = G + (int64_t)blockIdx.y * bs * bs + (int64_t)a * b;
+    for (int c = 0; c < b; ++c) {
+        const double* xc = X + (j0 + c) * ld;
+        double v[1] = {0.0};
+        for (int64_t i = threadIdx.x; i < ld; i += 256) v[0] += xa[i] * xc[i];
+        block_sum<1>(v, red, 4);
+        if (threadIdx.x == 0) out[c] = v[0];
+        __syncthreads();
+    }
+}
+
+// ---- update / partial: one 256-row slice per workgroup, one row per thread ----------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void k64_update_partial(const double* __restrict__ X, int64_t ld, double* __restrict__ r /* [NT][ld] */,
+                                                          const Events64* __restrict__ ev, int64_t j0, int b,
+                                                          double* __restrict__ partials /* [NT][nslices][kMaxBlock64] */)
+{
+    __shared__ double red[4][8 * NT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t row = (int64_t)blockIdx.x * 256 + tid;
+    const int nslices = gridDim.x;
+    double rv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) rv[t] = r[(int64_t)t * ld + row];
+    const int nev = ev ? ev->count : 0;
+    if (nev > 0) {
+        for (int e = 0; e < nev; ++e) {
+            const double x = X[(int64_t)ev->idx[e] * ld + row];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) rv[t] = fma(ev->delta[t][e], x, rv[t]);        // axpy!(oldAlpha - alpha, x, yCorr)
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) r[(int64_t)t * ld + row] = rv[t];
+    }
+    // partial right-hand sides, 8 columns at a time (transposed butterfly: 8 wave sums for ~10 shuffle-adds)
+    for (int c0 = 0; c0 < b; c0 += 8) {
+        double xv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) xv[u] = (c0 + u < b) ? X[(j0 + c0 + u) * ld + row] : 0.0;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = xv[u] * rv[t];
+            const double s = butterfly8(v, lane);                 // lane l: column ((l>>5)&1)*4 + ((l>>4)&1)*2 + ((l>>3)&1)
+            if ((lane & 7) == 0) red[wave][(lane >> 3) * NT + t] = s;
+        }
+        __syncthreads();
+        if (tid < 8 * NT) {
+            const int u = tid / NT, t = tid - u * NT;
+            if (c0 + u < b)
+                partials[((int64_t)t * nslices + blockIdx.x) * kMaxBlock64 + c0 + u] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+        }
+        __syncthreads();
+    }
+}
+
+// ---- per-marker evaluation, all double.  Each returns the new effect(s); "changed" = the effect differs from the old one.
+// BayesA/B/C: bayesabc_update_marker! (BayesABC.jl:24-58) with T = Float64.
+struct Abc64 {
+    double d, ie, iv, lv, sv, lp0, lp1, u, z;     // x'x, 1/vare, 1/var_j, log var_j, sqrt var_j, log pi, log(1-pi), draws
+    __device__ __forceinline__ void eval(double x, double a_old, double& a_new, double& b_new, double& d_new) const
+    {
+        const double rhs = (x + d * a_old) * ie;                                  // :36
+        const double lhs = d * ie + iv;                                           // :37
+        const double invLhs = 1.0 / lhs;                                          // :38
+        const double gHat = rhs * invLhs;                                         // :39
+        const double logDelta1 = -0.5 * (log(lhs) + lv - gHat * rhs) + lp1;       // :40
+        const double probDelta1 = 1.0 / (1.0 + exp(lp0 - logDelta1));             // :41
+        if (u < probDelta1) { d_new = 1.0; b_new = gHat + z * sqrt(invLhs); a_new = b_new; }      // :44-48
+        else { d_new = 0.0; b_new = z * sv; a_new = 0.0; }                        // :50-56
+    }
+};
+
+// BayesR: BayesR! (BayesR.jl:56-96) with T = Float64; classes 1..4 (delta as stored), class 1 = zero effect.
+struct R64 {
+    double d, ie, sigma_sq, lpi[4], gamma[4], u, z;
+    __device__ __forceinline__ void eval(double x, double a_old, double& a_new, int& cls_new) const
+    {
+        const double rhs = (x + d * a_old) * ie;                                  // :60
+        double lp[4], probs[4];
+        lp[0] = lpi[0];                                                           // :64
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {                                             // :65-72
+            const double varEffect = gamma[k] * sigma_sq;
+            const double invVarEffect = 1.0 / varEffect;
+            const double lhs = d * ie + invVarEffect;
+            const double invLhs = 1.0 / lhs;
+            const double betaHat = invLhs * rhs;
+            lp[k] = 0.5 * (log(invLhs) - log(varEffect) + betaHat * rhs) + lpi[k];
+        }
+        double mx = lp[0];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) mx = lp[k] > mx ? lp[k] : mx;
+        double se = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) se += exp(lp[k] - mx);
+        const double log_norm = mx + log(se);                                     // bayesr_logsumexp :1-4
+#pragma unroll
+        for (int k = 0; k < 4; ++k) probs[k] = exp(lp[k] - log_norm);             // :75-77
+        int cls = 0;                                                              // rand(Categorical(probs)) :79: CDF walk while cp <= u
+        double cp = probs[0];
+        while (cp <= u && cls < 3) { ++cls; cp += probs[cls]; }
+        cls_new = cls + 1;
+        if (cls == 0) { a_new = 0.0; return; }                                    // :82-86
+        const double varEffect = gamma[cls] * sigma_sq;                           // :88-94
+        const double lhs = d * ie + 1.0 / varEffect;
+        const double invLhs = 1.0 / lhs;
+        a_new = invLhs * rhs + z * sqrt(invLhs);
+    }
+};
+
+// ---- sampler: one workgroup of 256 threads; wave 0 runs the chain -----------------------------------------------------
+// LDS: gram [b][b] doubles, rhs [NT][128], then small per-marker state.
+struct Smem64 {
+    int gram_off, rhs_off, bytes;
+    __host__ __device__ Smem64(int bs, int NT) { gram_off = 0; rhs_off = bs * bs * 8; bytes = rhs_off + NT * kMaxBlock64 * 8; }
+};
+
+template <int METHOD, int NT>
+__global__ __launch_bounds__(256) void k64_sample(const Params64* __restrict__ P, const double* __restrict__ gram /* b x b */,
+                                                  const double* __restrict__ partials, int nslices, int64_t j0, int b, int64_t p,
+                                                  const double* __restrict__ xpx, double* __restrict__ alpha, double* __restrict__ beta,
+                                                  void* __restrict__ delta, Events64* __restrict__ ev_out, unsigned long long* __restrict__ counters)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const Smem64 SM(b, NT);
+    double* G = reinterpret_cast<double*>(smem + SM.gram_off);       // [b][b]
+    double* rhs = reinterpret_cast<double*>(smem + SM.rhs_off);      // [NT][128]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < b * b; i += 256) G[i] = gram[i];
+    for (int i = tid; i < NT * b; i += 256) {
+        const int t = i / b, c = i - t * b;
+        double s = 0.0;
+        for (int sl = 0; sl < nslices; ++sl) s += partials[((int64_t)t * nslices + sl) * kMaxBlock64 + c];      // fixed order
+        rhs[t * kMaxBlock64 + c] = s;
+    }
+    __syncthreads();
+    if (wave != 0) return;
+
+    const int nreps = P->nreps > 0 ? P->nreps : b;
+    const int nsub = (b + 63) / 64;
+    RngKey key{P->seed_lo, P->seed_hi, P->iter, 0u};
+    double a_start[2][NT];                                            // effects at block entry (lane's markers of the <= 2 sub-blocks)
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { const int c = 64 * s + lane; a_start[s][t] = (c < b) ? alpha[(int64_t)t * p + j0 + c] : 0.0; }
+    double a_cur[2][NT], b_cur[2][NT], d_cur[2][NT];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int c = 64 * s + lane;
+            a_cur[s][t] = a_start[s][t];
+            b_cur[s][t] = (c < b && METHOD != kBayesR) ? beta[(int64_t)t * p + j0 + c] : 0.0;
+            if (METHOD == kBayesR) d_cur[s][t] = (c < b) ? (double)reinterpret_cast<const int32_t*>(delta)[j0 + c] : 1.0;
+            else d_cur[s][t] = (c < b) ? reinterpret_cast<const double*>(delta)[(int64_t)t * p + j0 + c] : 0.0;
+        }
+    const double ie = 1.0 / P->vare[0];
+
+    for (int rep = 0; rep < nreps; ++rep) {
+        key.rep = (uint32_t)rep;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (s >= nsub) break;
+            const int c = 64 * s + lane;
+            const bool valid = c < b;
+            const int cl = valid ? c : 0;
+            const int64_t j = j0 + cl;
+            const uint32_t marker = P->marker0 + (uint32_t)j;
+            const double dj = xpx[j];
+            unsigned long long pending = __ballot(valid);
+            // the marker's sweep constants and draws (fixed for this repetition)
+            Abc64 am;
+            R64 rm;
+            double u_t[NT], z_t[NT];
+            if constexpr (METHOD == kBayesC || METHOD == kBayesB) {
+                const double var_j = (METHOD == kBayesB) ? P->var_vec[j] : P->var_effect[0];
+                const double pi_j = P->pi_vec ? P->pi_vec[j] : P->pi;
+                am.d = dj; am.ie = ie; am.iv = 1.0 / var_j; am.lv = log(var_j); am.sv = sqrt(var_j);
+                am.lp0 = log(pi_j); am.lp1 = log(1.0 - pi_j);
+                am.u = draw_uniform(key, marker, 0u); am.z = draw_normal(key, marker, 0u);
+            } else if constexpr (METHOD == kBayesR) {
+                rm.d = dj; rm.ie = ie; rm.sigma_sq = P->var_effect[0];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { rm.lpi[k] = log(P->pi_mat ? P->pi_mat[4 * j + k] : P->pi4[k]); rm.gamma[k] = P->gamma[k]; }
+                rm.u = draw_uniform(key, marker, 0u); rm.z = draw_normal(key, marker, 0u);
+            } else {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) { u_t[t] = draw_uniform(key, marker, (uint32_t)t); z_t[t] = draw_normal(key, marker, (uint32_t)t); }
+            }
+            while (pending) {
+                // every pending lane evaluates ITS marker against the current rhs
+                double an[NT], bn[NT], dn[NT];
+                bool ev = false;
+                if constexpr (METHOD == kBayesC || METHOD == kBayesB) {
+                    am.eval(rhs[c & 127], a_cur[s][0], an[0], bn[0], dn[0]);
+                    ev = an[0] != a_cur[s][0];
+                } else if constexpr (METHOD == kBayesR) {
+                    int cls;
+                    rm.eval(rhs[c & 127], a_cur[s][0], an[0], cls);
+                    bn[0] = 0.0; dn[0] = (double)cls;
+                    ev = an[0] != a_cur[s][0];
+                } else {
+                    // _MTBayesABC_samplerI! (MTBayesABC.jl:76-121), T = Float64
+                    double w[NT], bb[NT], dl[NT];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) { w[t] = rhs[t * kMaxBlock64 + (c & 127)] + dj * a_cur[s][t]; bb[t] = b_cur[s][t]; dl[t] = d_cur[s][t]; an[t] = a_cur[s][t]; }
+#pragma unroll
+                    for (int k = 0; k < NT; ++k) {
+                        const double Ginv11 = P->Ginv[k * NT + k];                               // :86
+                        const double C11 = Ginv11 + P->Rinv[k * NT + k] * dj;                    // :89
+                        double rhs0 = 0.0, c12b = 0.0, wR = 0.0;
+#pragma unroll
+                        for (int m = 0; m < NT; ++m) {
+                            wR = wR + w[m] * P->Rinv[m * NT + k];                                // :96
+                            if (m == k) continue;
+                            const double C12m = P->Ginv[k * NT + m] + (dj * dl[m]) * P->Rinv[k * NT + m];      // :90
+                            rhs0 = rhs0 + P->Ginv[k * NT + m] * bb[m];                           // :93
+                            c12b = c12b + C12m * bb[m];
+                        }
+                        rhs0 = -rhs0;
+                        const double invLhs0 = 1.0 / Ginv11, gHat0 = rhs0 * invLhs0;             // :92,:94
+                        const double invLhs1 = 1.0 / C11, rhs1 = wR - c12b, gHat1 = rhs1 * invLhs1;       // :95-97
+                        unsigned s0 = 0u;
+#pragma unroll
+                        for (int m = 0; m < NT; ++m) if (m != k && dl[m] != 0.0) s0 |= 1u << m;
+                        const unsigned s1 = s0 | (1u << k);
+                        const double logDelta0 = -0.5 * (log(Ginv11) - gHat0 * gHat0 * Ginv11) + P->log_prior[s0];      // :104
+                        const double logDelta1 = -0.5 * (log(C11) - gHat1 * gHat1 * C11) + P->log_prior[s1];            // :105
+                        const double probDelta1 = 1.0 / (1.0 + exp(logDelta0 - logDelta1));                          // :107
+                        if (u_t[k] < probDelta1) { dl[k] = 1.0; bb[k] = gHat1 + z_t[k] * sqrt(invLhs1); an[k] = bb[k]; }      // :108-111
+                        else { bb[k] = gHat0 + z_t[k] * sqrt(invLhs0); dl[k] = 0.0; an[k] = 0.0; }                         // :112-119
+                    }
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) { bn[t] = bb[t]; dn[t] = dl[t]; ev = ev || (an[t] != a_cur[s][t]); }
+                }
+                // a lane whose effect does not change still takes its new beta / delta when it becomes final (below)
+                const unsigned long long m = __ballot(ev && valid) & pending;
+                const int k = m ? (int)__builtin_ctzll(m) : 64;
+                // lanes before the winner are final with what they just evaluated (their effect is unchanged)
+                const unsigned long long done = (k >= 64) ? pending : (pending & ((k == 63) ? ~0ull : ((2ull << k) - 1ull)));
+                if ((done >> lane) & 1ull) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) { b_cur[s][t] = bn[t]; d_cur[s][t] = dn[t]; }
+                }
+                if (k >= 64) break;
+                // the winner commits; its Gram row corrects the rhs of the whole block (BayesABC.jl:169,172)
+                const int ce = 64 * s + k;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const double Dl = a_cur[s][t] - an[t];
+                    const double D = __shfl(Dl, k, 64);
+                    if (lane == k) a_cur[s][t] = an[t];
+                    if (D != 0.0) {
+                        for (int c2 = lane; c2 < b; c2 += 64) rhs[t * kMaxBlock64 + c2] = fma(D, G[ce * b + c2], rhs[t * kMaxBlock64 + c2]);
+                    }
+                }
+                pending &= ~done;
+            }
+        }
+    }
+    // write back + the block's change list (marker order)
+    int base = 0;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        if (s >= nsub) break;
+        const int c = 64 * s + lane;
+        const bool valid = c < b;
+        bool changed = false;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) changed = changed || (a_cur[s][t] != a_start[s][t]);
+        changed = changed && valid;
+        const unsigned long long cm = __ballot(changed);
+        if (changed) {
+            const int e = base + __popcll(cm & ((1ull << lane) - 1ull));
+            ev_out->idx[e] = (int32_t)(j0 + c);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) ev_out->delta[t][e] = a_start[s][t] - a_cur[s][t];
+        }
+        base += __popcll(cm);
+        if (valid) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                alpha[(int64_t)t * p + j0 + c] = a_cur[s][t];
+                if (METHOD == kBayesR) reinterpret_cast<int32_t*>(delta)[j0 + c] = (int32_t)d_cur[s][0];
+                else { beta[(int64_t)t * p + j0 + c] = b_cur[s][t]; reinterpret_cast<double*>(delta)[(int64_t)t * p + j0 + c] = d_cur[s][t]; }
+            }
+        }
+    }
+    if (lane == 0) { ev_out->count = base; atomicAdd(&counters[0], (unsigned long long)base); }
+}
+
+// ---- epilogue: apply the last block's changes, r'r and sum(r) per slice -------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void k64_finish(const double* __restrict__ X, int64_t ld, int64_t n, double* __restrict__ r,
+                                                  const Events64* __restrict__ ev, double* __restrict__ out /* [nslices][NT*NT+NT] */)
+{
+    __shared__ double red[4 * (NT * NT + NT)];
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double rv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) rv[t] = r[(int64_t)t * ld + row];
+    const int nev = ev ? ev->count : 0;
+    for (int e = 0; e < nev; ++e) {
+        const double x = X[(int64_t)ev->idx[e] * ld + row];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) rv[t] = fma(ev->delta[t][e], x, rv[t]);
+    }
+    if (nev > 0)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) r[(int64_t)t * ld + row] = rv[t];
+    double v[NT * NT + NT];
+    const double live = row < n ? 1.0 : 0.0;
+#pragma unroll
+    for (int a = 0; a < NT; ++a) {
+#pragma unroll
+        for (int c = 0; c < NT; ++c) v[a * NT + c] = rv[a] * rv[c] * live;
+        v[NT * NT + a] = rv[a] * live;
+    }
+    block_sum<NT * NT + NT>(v, red, 4);
+    if (threadIdx.x == 0)
+#pragma unroll
+        for (int i = 0; i < NT * NT + NT; ++i) out[(int64_t)blockIdx.x * (NT * NT + NT) + i] = v[i];
+}
+
+// ---- marker statistics (one workgroup per kStat slot, fixed order) ------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void k64_marker_stats(int method, int64_t p, const double* __restrict__ alpha, const double* __restrict__ beta,
+                                                        const void* __restrict__ delta, const double* __restrict__ gamma, double* __restrict__ out)
+{
+    __shared__ double red[4 * kNStat];
+    double v[kNStat];
+#pragma unroll
+    for (int i = 0; i < kNStat; ++i) v[i] = 0.0;
+    for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < p; j += (int64_t)gridDim.x * 256) {
+        double a[NT], b[NT];
+        unsigned st = 0u;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { a[t] = alpha[(int64_t)t * p + j]; b[t] = beta[(int64_t)t * p + j]; }
+        if (method == kBayesR) {
+            const int cls = reinterpret_cast<const int32_t*>(delta)[j];
+            v[36 + (cls - 1)] += 1.0;
+            if (cls > 1) { v[40] += (a[0] * a[0]) / gamma[cls - 1]; v[41] += 1.0; }
+        } else {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { const double d = reinterpret_cast<const double*>(delta)[(int64_t)t * p + j]; v[t] += d; if (d != 0.0) st |= 1u << t; }
+            v[42 + st] += 1.0;
+        }
+#pragma unroll
+        for (int x = 0; x < NT; ++x)
+#pragma unroll
+            for (int y = 0; y < NT; ++y) { v[4 + x * NT + y] += a[x] * a[y]; v[20 + x * NT + y] += b[x] * b[y]; }
+    }
+    block_sum<kNStat>(v, red, 4);
+    if (threadIdx.x == 0)
+        for (int i = 0; i < kNStat; ++i) out[(int64_t)blockIdx.x * kNStat + i] = v[i];
+}
+
+// ---- running posterior means (output.jl:556-560) -----------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k64_accumulate(int64_t count, int delta_is_class, double k, const double* __restrict__ alpha,
+                                                      const void* __restrict__ delta, double* __restrict__ ma, double* __restrict__ ma2, double* __restrict__ md)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    const double a = alpha[i];
+    const double d = delta_is_class ? (reinterpret_cast<const int32_t*>(delta)[i] > 1 ? 1.0 : 0.0) : reinterpret_cast<const double*>(delta)[i];
+    ma[i] += (a - ma[i]) / k;
+    ma2[i] += (a * a - ma2[i]) / k;
+    md[i] += (d - md[i]) / k;
+}
+
+// ---- out = X alpha (getEBV, output.jl:281-306); r -= X alpha (initial ycorr) ---------------------------------------------
+__global__ __launch_bounds__(256) void k64_mul_alpha(const double* __restrict__ X, int64_t ld, int64_t p, const double* __restrict__ alpha,
+                                                     double* __restrict__ out, double sign, const double* __restrict__ base)
+{
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double acc = base ? base[row] : 0.0;
+    for (int64_t j = 0; j < p; ++j) {
+        const double a = alpha[j];
+        if (a != 0.0) acc = fma(sign * a, X[j * ld + row], acc);
+    }
+    out[row] = acc;
+}
+
+}  // namespace jw64

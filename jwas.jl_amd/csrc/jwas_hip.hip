@@ -2,6 +2,7 @@
 // gfx950 only.  No CPU fallback: every entry point either runs the HIP path or returns an error.
 #include "../../include/jwas_hip.h"
 #include "sweep.hpp"
+#include "f64_path.hpp"
 
 #include <hip/hip_runtime.h>
 #include <cmath>
@@ -104,6 +105,21 @@ struct jwas_hip_ctx {
     bool row_mode = false;
     int loop_slot = -1;                 // >= 0: loopback transport (ranks = contexts of one process on different host threads)
     double* row_buf = nullptr;          // [32] small exchanges
+    // Float64 mode (runMCMC(double_precision=true); csrc/f64_path.hpp): its own storage / state, created by jwas_hip_set_precision
+    struct F64 {
+        double* X = nullptr;                // [p][ld]
+        double* r = nullptr;                // [kMaxT][ld]
+        double* xpx = nullptr;              // [p]
+        double* gram = nullptr;             // [nblocks][bs][bs]
+        double *alpha = nullptr, *beta = nullptr;      // [t][p]
+        void* delta = nullptr;              // double [t][p], or int32 [p] (BayesR classes)
+        double *mean_a = nullptr, *mean_a2 = nullptr, *mean_d = nullptr;
+        double* partials = nullptr;         // [kMaxT][nslices][128]
+        jw64::Events64* ev = nullptr;       // [2]
+        jw64::Params64* dparams = nullptr;
+        double* var_vec = nullptr;          // [p] BayesB
+    };
+    F64* f64 = nullptr;
 };
 
 static constexpr int kStatGrid = 128;
@@ -165,6 +181,11 @@ static auto with_cols(jwas_hip_ctx* c, int64_t j_off, F&& f)
     return f(DenseCols{c->X + j_off * c->ld, c->ld, c->w, (int32_t)c->weighted});
 }
 #define HAVE_STORAGE(c) ((c)->X != nullptr || (c)->Q != nullptr)
+#define IS_F64(c) ((c)->f64 != nullptr)
+#define NOT_F64(c, what) NEED(c, !IS_F64(c), JWAS_HIP_EUNSUP, "%s is not available in a Float64 context (double_precision=true)", what)
+#define ONLY_F64(c) NEED(c, IS_F64(c), JWAS_HIP_ESTATE, "this entry point needs a Float64 context (jwas_hip_set_precision(ctx, 64))")
+static int f64_setup_blocks(jwas_hip_ctx* c, int32_t bs);
+static int f64_init_state(jwas_hip_ctx* c, int32_t method, int32_t nt);
 
 
 extern "C" {
@@ -241,6 +262,13 @@ void jwas_hip_destroy(jwas_hip_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     if (c->comm) (void)jwas_hip_comm_destroy(c);
     free_state(c); free_blocks(c); free_storage(c);
+    if (c->f64) {
+        auto* F = c->f64;
+        for (void* q : {(void*)F->X, (void*)F->r, (void*)F->xpx, (void*)F->gram, (void*)F->alpha, (void*)F->beta, F->delta, (void*)F->mean_a,
+                        (void*)F->mean_a2, (void*)F->mean_d, (void*)F->partials, (void*)F->ev, (void*)F->dparams, (void*)F->var_vec}) (void)hipFree(q);
+        delete F;
+        c->f64 = nullptr;
+    }
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
     for (hipEvent_t e : c->kev) (void)hipEventDestroy(e);
@@ -369,6 +397,7 @@ static int alloc_storage(jwas_hip_ctx* c, int64_t n, int64_t p, bool packed = fa
 
 int jwas_hip_load_dense_f32(jwas_hip_ctx* c, const float* Xh, int64_t n, int64_t p, int64_t ld_host)
 {
+    if (c) NOT_F64(c, "jwas_hip_load_dense_f32 (use jwas_hip_load_dense_f64)");
     NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
     NEED(c, Xh, JWAS_HIP_EINVAL, "X_host is NULL");
     NEED(c, ld_host >= n, JWAS_HIP_EINVAL, "ld_host (%lld) must be >= n (%lld)", (long long)ld_host, (long long)n);
@@ -383,12 +412,14 @@ int jwas_hip_load_dense_f32(jwas_hip_ctx* c, const float* Xh, int64_t n, int64_t
 
 int jwas_hip_alloc_dense_f32(jwas_hip_ctx* c, int64_t n, int64_t p)
 {
+    if (c) NOT_F64(c, "jwas_hip_alloc_dense_f32");
     NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
     return alloc_storage(c, n, p);
 }
 
 int jwas_hip_alloc_packed2bit(jwas_hip_ctx* c, int64_t n, int64_t p, int32_t centered)
 {
+    if (c) NOT_F64(c, "2-bit packed storage");
     NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
     int rc = alloc_storage(c, n, p, true);
     if (rc) return rc;
@@ -399,6 +430,7 @@ int jwas_hip_alloc_packed2bit(jwas_hip_ctx* c, int64_t n, int64_t p, int32_t cen
 int jwas_hip_load_packed2bit(jwas_hip_ctx* c, const uint8_t* payload, int64_t n, int64_t p, int64_t stride_bytes,
                              const float* means, int32_t centered)
 {
+    if (c) NOT_F64(c, "2-bit packed storage");
     NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
     NEED(c, payload && means, JWAS_HIP_EINVAL, "payload / means is NULL");
     NEED(c, stride_bytes >= (n + 3) / 4, JWAS_HIP_EINVAL, "stride_bytes (%lld) must be >= cld(n,4) = %lld", (long long)stride_bytes, (long long)((n + 3) / 4));
@@ -431,6 +463,7 @@ static bool read_manifest(const std::string& path, std::vector<std::pair<std::st
 
 int jwas_hip_load_jgb2(jwas_hip_ctx* c, const char* path)
 {
+    if (c) NOT_F64(c, "2-bit packed storage");
     NEED(c, c && path, JWAS_HIP_EINVAL, "NULL argument");
     std::string prefix(path);                                   // _resolve_streaming_prefix (:97-105)
     for (const char* ext : {".meta", ".jgb2"}) {
@@ -487,6 +520,7 @@ int jwas_hip_load_jgb2(jwas_hip_ctx* c, const char* path)
 
 int jwas_hip_set_weights(jwas_hip_ctx* c, const float* rinv)
 {
+    if (c) NOT_F64(c, "residual weights");
     NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
     NEED(c, HAVE_STORAGE(c), JWAS_HIP_ESTATE, "no genotype matrix loaded");
     HIPCHK(c, hipSetDevice(c->device));
@@ -693,6 +727,7 @@ static int check_block_args(jwas_hip_ctx* c, int32_t bs, int32_t gram_mode)
 
 int jwas_hip_setup_blocks(jwas_hip_ctx* c, int32_t bs, int32_t gram_mode)
 {
+    if (c && IS_F64(c)) return f64_setup_blocks(c, bs);
     NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
     int rc = check_block_args(c, bs, gram_mode);
     if (rc) return rc;
@@ -714,6 +749,7 @@ int jwas_hip_setup_blocks(jwas_hip_ctx* c, int32_t bs, int32_t gram_mode)
 
 int jwas_hip_setup_blocks_explicit(jwas_hip_ctx* c, const int64_t* starts, int64_t nblocks, int32_t gram_mode)
 {
+    if (c) NOT_F64(c, "an explicit block partition");
     NEED(c, c && starts, JWAS_HIP_EINVAL, "NULL argument");
     NEED(c, HAVE_STORAGE(c), JWAS_HIP_ESTATE, "no genotype matrix loaded");
     NEED(c, gram_mode == JWAS_HIP_GRAM_F64 || gram_mode == JWAS_HIP_GRAM_MFMA, JWAS_HIP_EINVAL, "unknown gram_mode %d", gram_mode);
@@ -750,6 +786,7 @@ int jwas_hip_setup_blocks_explicit(jwas_hip_ctx* c, const int64_t* starts, int64
 
 int jwas_hip_add_block_size(jwas_hip_ctx* c, int32_t bs, int32_t gram_mode)
 {
+    if (c) NOT_F64(c, "a second block size");
     NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
     int rc = check_block_args(c, bs, gram_mode);
     if (rc) return rc;
@@ -782,6 +819,7 @@ int jwas_hip_num_blocks(jwas_hip_ctx* c, int64_t* nb, int32_t* bs)
 
 int jwas_hip_get_xpx(jwas_hip_ctx* c, float* out)
 {
+    if (c) NOT_F64(c, "jwas_hip_get_xpx (use jwas_hip_get_xpx_f64)");
     NEED(c, c && out, JWAS_HIP_EINVAL, "NULL argument");
     NEED(c, c->xpx, JWAS_HIP_ESTATE, "jwas_hip_setup_blocks has not been called");
     HIPCHK(c, hipSetDevice(c->device));
@@ -856,6 +894,7 @@ int jwas_hip_set_gram(jwas_hip_ctx* c, int64_t blk, const float* in)
 // ---- chain state ----------------------------------------------------------------------------------
 int jwas_hip_init_state(jwas_hip_ctx* c, int32_t method, int32_t nt)
 {
+    if (c && IS_F64(c)) return f64_init_state(c, method, nt);
     NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
     NEED(c, HAVE_STORAGE(c), JWAS_HIP_ESTATE, "no genotype matrix loaded");
     NEED(c, method >= JWAS_HIP_BAYESC && method <= JWAS_HIP_MTBAYESB1, JWAS_HIP_EINVAL, "unknown method %d", method);
@@ -893,6 +932,7 @@ int jwas_hip_init_state(jwas_hip_ctx* c, int32_t method, int32_t nt)
 
 int jwas_hip_set_state(jwas_hip_ctx* c, int32_t trait, const float* a, const float* b, const void* d)
 {
+    if (c) NOT_F64(c, "jwas_hip_set_state (use jwas_hip_set_state_f64)");
     NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
     NEED_TRAIT(c, trait);
     HIPCHK(c, hipSetDevice(c->device));
@@ -906,6 +946,7 @@ int jwas_hip_set_state(jwas_hip_ctx* c, int32_t trait, const float* a, const flo
 
 int jwas_hip_get_state(jwas_hip_ctx* c, int32_t trait, float* a, float* b, void* d)
 {
+    if (c) NOT_F64(c, "jwas_hip_get_state (use jwas_hip_get_state_f64)");
     NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
     NEED_TRAIT(c, trait);
     HIPCHK(c, hipSetDevice(c->device));
@@ -919,6 +960,7 @@ int jwas_hip_get_state(jwas_hip_ctx* c, int32_t trait, float* a, float* b, void*
 
 int jwas_hip_set_residual(jwas_hip_ctx* c, int32_t trait, const float* rh)
 {
+    if (c) NOT_F64(c, "jwas_hip_set_residual (use jwas_hip_set_residual_f64)");
     NEED(c, c && rh, JWAS_HIP_EINVAL, "NULL argument");
     NEED_TRAIT(c, trait);
     HIPCHK(c, hipSetDevice(c->device));
@@ -929,6 +971,7 @@ int jwas_hip_set_residual(jwas_hip_ctx* c, int32_t trait, const float* rh)
 
 int jwas_hip_get_residual(jwas_hip_ctx* c, int32_t trait, float* rh)
 {
+    if (c) NOT_F64(c, "jwas_hip_get_residual (use jwas_hip_get_residual_f64)");
     NEED(c, c && rh, JWAS_HIP_EINVAL, "NULL argument");
     NEED_TRAIT(c, trait);
     HIPCHK(c, hipSetDevice(c->device));
@@ -975,6 +1018,7 @@ __global__ __launch_bounds__(256) void k_residual_add_scalar(float* __restrict__
 
 int jwas_hip_residual_add_scalar(jwas_hip_ctx* c, int32_t trait, double shift)
 {
+    if (c) NOT_F64(c, "jwas_hip_residual_add_scalar");
     NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
     NEED_TRAIT(c, trait);
     HIPCHK(c, hipSetDevice(c->device));
@@ -986,6 +1030,15 @@ int jwas_hip_residual_add_scalar(jwas_hip_ctx* c, int32_t trait, double shift)
 
 int jwas_hip_residual_sub_xalpha(jwas_hip_ctx* c, int32_t trait)
 {
+    if (c && IS_F64(c)) {
+        NEED_TRAIT(c, trait);
+        HIPCHK(c, hipSetDevice(c->device));
+        double* rk = c->f64->r + (size_t)trait * c->ld;
+        hipLaunchKernelGGL(jw64::k64_mul_alpha, dim3((unsigned)c->nslices), dim3(256), 0, c->stream, c->f64->X, c->ld, c->p,
+                           c->f64->alpha + (size_t)trait * c->p, rk, -1.0, (const double*)rk);
+        HIPCHK(c, hipGetLastError());
+        return JWAS_HIP_OK;
+    }
     NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
     NEED_TRAIT(c, trait);
     HIPCHK(c, hipSetDevice(c->device));
@@ -1028,6 +1081,7 @@ static hipError_t sparse_alpha(jwas_hip_ctx* c, int32_t trait, int32_t** d_idx, 
 
 int jwas_hip_mul_alpha(jwas_hip_ctx* c, int32_t trait, float* out)
 {
+    if (c) NOT_F64(c, "jwas_hip_mul_alpha (use jwas_hip_mul_alpha_f64)");
     NEED(c, c && out, JWAS_HIP_EINVAL, "NULL argument");
     NEED_TRAIT(c, trait);
     HIPCHK(c, hipSetDevice(c->device));
@@ -1835,11 +1889,346 @@ static int sweep_collect(jwas_hip_ctx* c, jwas_sweep_stats* S, size_t ntimed, do
     return JWAS_HIP_OK;
 }
 
+
+// =====================================================================================================================
+// Float64 mode: runMCMC(double_precision=true) (JWAS.jl:349-366, readgenotypes.jl:298,345).  Kernels: csrc/f64_path.hpp.
+// A context becomes a Float64 context with jwas_hip_set_precision(ctx, 64) BEFORE genotypes are loaded; it then takes the
+// *_f64 data entry points (double host arrays) and the shared control entry points (setup_blocks, init_state, sweep,
+// accumulate, residual_sub_xalpha, num_blocks); everything else of the Float32 surface (packed storage, weights, explicit
+// partitions, output rows, window sums, shards) answers "not available in a Float64 context".
+// =====================================================================================================================
+
+static void f64_free_state(jwas_hip_ctx* c)
+{
+    auto* F = c->f64;
+    for (void* q : {(void*)F->alpha, (void*)F->beta, F->delta, (void*)F->mean_a, (void*)F->mean_a2, (void*)F->mean_d, (void*)F->var_vec}) (void)hipFree(q);
+    F->alpha = F->beta = F->mean_a = F->mean_a2 = F->mean_d = F->var_vec = nullptr; F->delta = nullptr;
+}
+
+static int f64_setup_blocks(jwas_hip_ctx* c, int32_t bs)
+{
+    auto* F = c->f64;
+    NEED(c, F->X, JWAS_HIP_ESTATE, "no genotype matrix loaded");
+    NEED(c, bs == 64 || bs == 128, JWAS_HIP_EINVAL, "Float64 contexts run blocks of 64 or 128 markers (got %d)", bs);
+    HIPCHK(c, hipSetDevice(c->device));
+    (void)hipFree(F->xpx); (void)hipFree(F->gram); F->xpx = F->gram = nullptr;
+    c->block_size = bs; c->nblocks = (c->p + bs - 1) / bs;
+    HIPCHK(c, hipMalloc(&F->xpx, sizeof(double) * c->p));
+    HIPCHK(c, hipMalloc(&F->gram, sizeof(double) * (size_t)c->nblocks * bs * bs));
+    hipLaunchKernelGGL(jw64::k64_xpx, dim3((unsigned)c->p), dim3(256), 0, c->stream, F->X, c->ld, F->xpx);
+    for (int64_t y0 = 0; y0 < c->nblocks; y0 += 32768) {
+        const int64_t ny = std::min<int64_t>(32768, c->nblocks - y0);
+        hipLaunchKernelGGL(jw64::k64_gram, dim3((unsigned)bs, (unsigned)ny), dim3(256), 0, c->stream, F->X + y0 * bs * c->ld, c->ld, c->p - y0 * bs, (int)bs,
+                           F->gram + y0 * (int64_t)bs * bs);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return JWAS_HIP_OK;
+}
+
+static int f64_init_state(jwas_hip_ctx* c, int32_t method, int32_t nt)
+{
+    auto* F = c->f64;
+    NEED(c, F->X, JWAS_HIP_ESTATE, "no genotype matrix loaded");
+    NEED(c, method == JWAS_HIP_BAYESC || method == JWAS_HIP_BAYESB || method == JWAS_HIP_BAYESR || method == JWAS_HIP_MTBAYESC1, JWAS_HIP_EUNSUP,
+         "Float64 contexts run single-trait BayesA/B/C, BayesR and multi-trait sampler I (got method %d)", method);
+    if (method == JWAS_HIP_MTBAYESC1) NEED(c, nt >= 2 && nt <= kMaxT, JWAS_HIP_EUNSUP, "multi-trait samplers support 2..%d traits (got %d)", kMaxT, nt);
+    else NEED(c, nt == 1, JWAS_HIP_EINVAL, "single-trait method requires ntraits == 1 (got %d)", nt);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    f64_free_state(c);
+    c->method = method; c->ntraits = nt;
+    const size_t db = sizeof(double) * (size_t)nt * c->p;
+    const size_t delb = method == JWAS_HIP_BAYESR ? sizeof(int32_t) * (size_t)c->p : db;
+    HIPCHK(c, hipMalloc(&F->alpha, db)); HIPCHK(c, hipMalloc(&F->beta, db)); HIPCHK(c, hipMalloc(&F->delta, delb));
+    HIPCHK(c, hipMalloc(&F->mean_a, db)); HIPCHK(c, hipMalloc(&F->mean_a2, db)); HIPCHK(c, hipMalloc(&F->mean_d, db));
+    for (void* q : {(void*)F->alpha, (void*)F->beta, (void*)F->mean_a, (void*)F->mean_a2, (void*)F->mean_d}) HIPCHK(c, hipMemsetAsync(q, 0, db, c->stream));
+    HIPCHK(c, hipMemsetAsync(F->delta, 0, delb, c->stream));
+    HIPCHK(c, hipMemsetAsync(F->r, 0, sizeof(double) * kMaxT * c->ld, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return JWAS_HIP_OK;
+}
+
+template <int NT>
+static void f64_launch_block(jwas_hip_ctx* c, const jw64::Events64* ev_prev, int64_t k, jw64::Events64* ev_out)
+{
+    auto* F = c->f64;
+    const int bs = c->block_size;
+    const int64_t j0 = k * bs;
+    const int b = (int)((j0 + bs <= c->p) ? bs : c->p - j0);
+    hipLaunchKernelGGL((jw64::k64_update_partial<NT>), dim3((unsigned)c->nslices), dim3(256), 0, c->stream, F->X, c->ld, F->r, ev_prev, j0, b, F->partials);
+    const jw64::Smem64 SM(b, NT);
+    const double* G = F->gram + k * (int64_t)bs * bs;
+#define JW64_SAMPLE(M)                                                                                                                  \
+    hipLaunchKernelGGL((jw64::k64_sample<M, NT>), dim3(1), dim3(256), SM.bytes, c->stream, F->dparams, G, F->partials, c->nslices, j0, b, c->p, \
+                       F->xpx, F->alpha, F->beta, F->delta, ev_out, c->counters)
+    if constexpr (NT == 1) {
+        if (c->method == JWAS_HIP_BAYESC) JW64_SAMPLE(kBayesC);
+        else if (c->method == JWAS_HIP_BAYESB) JW64_SAMPLE(kBayesB);
+        else JW64_SAMPLE(kBayesR);
+    } else JW64_SAMPLE(kMTBayesC1);
+#undef JW64_SAMPLE
+}
+
+template <int NT>
+static hipError_t f64_set_lds_attr()
+{
+    hipError_t e = hipSuccess;
+    if constexpr (NT == 1) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&jw64::k64_sample<kBayesC, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&jw64::k64_sample<kBayesB, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&jw64::k64_sample<kBayesR, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    } else e = hipFuncSetAttribute(reinterpret_cast<const void*>(&jw64::k64_sample<kMTBayesC1, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return e;
+}
+
+static int f64_sweep(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_sweep_stats* S)
+{
+    auto* F = c->f64;
+    NEED(c, c->method >= 0, JWAS_HIP_ESTATE, "jwas_hip_init_state has not been called");
+    NEED(c, c->block_size && F->gram, JWAS_HIP_ESTATE, "jwas_hip_setup_blocks has not been called");
+    NEED(c, P->method == c->method && P->ntraits == c->ntraits, JWAS_HIP_EINVAL, "sweep method/ntraits (%d/%d) differ from init_state (%d/%d)", P->method, P->ntraits, c->method, c->ntraits);
+    NEED(c, !P->independent_blocks, JWAS_HIP_EUNSUP, "independent_blocks is not available in a Float64 context");
+    NEED(c, !P->log_prior_states_matrix && !P->var_effect_matrix, JWAS_HIP_EUNSUP, "marker-specific multi-trait priors / covariances are not available in a Float64 context");
+    const int t = c->ntraits;
+    HIPCHK(c, hipSetDevice(c->device));
+    {   // > 64 KB of dynamic LDS (the block's Gram in doubles)
+        static unsigned long long attr_set = 0ull;
+        const unsigned long long bit = 1ull << (c->device & 63);
+        if (!(attr_set & bit)) {
+            HIPCHK(c, f64_set_lds_attr<1>()); HIPCHK(c, f64_set_lds_attr<2>()); HIPCHK(c, f64_set_lds_attr<3>()); HIPCHK(c, f64_set_lds_attr<4>());
+            attr_set |= bit;
+        }
+    }
+    jw64::Params64 D;
+    std::memset(&D, 0, sizeof D);
+    D.method = c->method; D.ntraits = t; D.nreps = P->nreps;
+    D.iter = P->iteration; D.seed_lo = (uint32_t)P->seed; D.seed_hi = (uint32_t)(P->seed >> 32); D.marker0 = P->marker_offset;
+    for (int i = 0; i < t * t; ++i) { D.vare[i] = P->vare_f64[i]; D.var_effect[i] = P->var_effect_f64[i]; }
+    if (c->method == JWAS_HIP_MTBAYESC1) {
+        // inv(vare), inv(G) (MTBayesABC.jl:66-67) in double: Gauss-Jordan with partial pivoting (the oracle's operation order)
+        auto inv_d = [&](const double* A, double* Ainv) -> int {
+            double M[kMaxT][2 * kMaxT];
+            for (int i = 0; i < t; ++i) for (int j = 0; j < t; ++j) { M[i][j] = A[i * t + j]; M[i][t + j] = (i == j); }
+            for (int cc = 0; cc < t; ++cc) {
+                int piv = cc;
+                for (int i = cc + 1; i < t; ++i) if (std::fabs(M[i][cc]) > std::fabs(M[piv][cc])) piv = i;
+                if (M[piv][cc] == 0.0) return -1;
+                if (piv != cc) for (int j = 0; j < 2 * t; ++j) std::swap(M[cc][j], M[piv][j]);
+                const double d = M[cc][cc];
+                for (int j = 0; j < 2 * t; ++j) M[cc][j] /= d;
+                for (int i = 0; i < t; ++i) if (i != cc) { const double f = M[i][cc]; if (f != 0.0) for (int j = 0; j < 2 * t; ++j) M[i][j] -= f * M[cc][j]; }
+            }
+            for (int i = 0; i < t; ++i) for (int j = 0; j < t; ++j) Ainv[i * t + j] = M[i][t + j];
+            return 0;
+        };
+        NEED(c, inv_d(D.vare, D.Rinv) == 0, JWAS_HIP_EINVAL, "residual covariance matrix is singular");
+        NEED(c, inv_d(D.var_effect, D.Ginv) == 0, JWAS_HIP_EINVAL, "marker effect covariance matrix is singular");
+        for (int i = 0; i < (1 << t); ++i) D.log_prior[i] = P->log_prior_states[i];
+    } else NEED(c, D.vare[0] > 0.0, JWAS_HIP_EINVAL, "residual variance must be positive");
+    if (c->method == JWAS_HIP_BAYESR) {
+        NEED(c, D.var_effect[0] > 0.0, JWAS_HIP_EINVAL, "BayesR sigmaSq must be positive.");
+        if (!P->pi_matrix) {
+            double sum = 0.0;
+            for (int k = 0; k < 4; ++k) { NEED(c, P->pi_classes[k] >= 0.0, JWAS_HIP_EINVAL, "BayesR pi entries must be nonnegative."); sum += P->pi_classes[k]; }
+            NEED(c, std::fabs(sum - 1.0) <= 1e-8, JWAS_HIP_EINVAL, "BayesR pi must sum to 1.");
+        }
+        for (int k = 0; k < 4; ++k) { D.pi4[k] = P->pi_classes[k]; D.gamma[k] = P->gamma[k]; }
+        if (P->pi_matrix) { int rc = upload_vec(c, (void**)&c->pi_mat, P->pi_matrix, sizeof(double) * 4 * c->p); if (rc) return rc; D.pi_mat = c->pi_mat; }
+    } else if (c->method == JWAS_HIP_BAYESC || c->method == JWAS_HIP_BAYESB) {
+        D.pi = P->pi;
+        if (P->pi_vec) { int rc = upload_vec(c, (void**)&c->pi_vec, P->pi_vec, sizeof(double) * c->p); if (rc) return rc; D.pi_vec = c->pi_vec; }
+        if (c->method == JWAS_HIP_BAYESB) {
+            NEED(c, P->var_effect_vec_f64, JWAS_HIP_EINVAL, "BayesB needs per-marker effect variances (var_effect_vec_f64)");
+            int rc = upload_vec(c, (void**)&F->var_vec, P->var_effect_vec_f64, sizeof(double) * c->p); if (rc) return rc;
+            D.var_vec = F->var_vec;
+        } else NEED(c, D.var_effect[0] > 0.0, JWAS_HIP_EINVAL, "marker effect variance must be positive");
+    }
+    HIPCHK(c, hipMemcpyAsync(F->dparams, &D, sizeof D, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->counters, 0, sizeof(unsigned long long) * 16, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev_start, c->stream));
+    const int64_t nb = c->nblocks;
+    for (int64_t k = 0; k < nb; ++k) {
+        const jw64::Events64* prev = k > 0 ? &F->ev[(k - 1) & 1] : nullptr;
+        switch (t) {
+            case 1: f64_launch_block<1>(c, prev, k, &F->ev[k & 1]); break;
+            case 2: f64_launch_block<2>(c, prev, k, &F->ev[k & 1]); break;
+            case 3: f64_launch_block<3>(c, prev, k, &F->ev[k & 1]); break;
+            default: f64_launch_block<4>(c, prev, k, &F->ev[k & 1]);
+        }
+    }
+    const jw64::Events64* last = &F->ev[(nb - 1) & 1];
+    const double* gamma_dev = reinterpret_cast<const double*>(reinterpret_cast<const char*>(F->dparams) + offsetof(jw64::Params64, gamma));
+    switch (t) {
+        case 1: hipLaunchKernelGGL((jw64::k64_finish<1>), dim3(c->nslices), dim3(256), 0, c->stream, F->X, c->ld, c->n, F->r, last, c->fin_out);
+                hipLaunchKernelGGL((jw64::k64_marker_stats<1>), dim3(kStatGrid), dim3(256), 0, c->stream, c->method, c->p, F->alpha, F->beta, F->delta, gamma_dev, c->stat_out); break;
+        case 2: hipLaunchKernelGGL((jw64::k64_finish<2>), dim3(c->nslices), dim3(256), 0, c->stream, F->X, c->ld, c->n, F->r, last, c->fin_out);
+                hipLaunchKernelGGL((jw64::k64_marker_stats<2>), dim3(kStatGrid), dim3(256), 0, c->stream, c->method, c->p, F->alpha, F->beta, F->delta, gamma_dev, c->stat_out); break;
+        case 3: hipLaunchKernelGGL((jw64::k64_finish<3>), dim3(c->nslices), dim3(256), 0, c->stream, F->X, c->ld, c->n, F->r, last, c->fin_out);
+                hipLaunchKernelGGL((jw64::k64_marker_stats<3>), dim3(kStatGrid), dim3(256), 0, c->stream, c->method, c->p, F->alpha, F->beta, F->delta, gamma_dev, c->stat_out); break;
+        default: hipLaunchKernelGGL((jw64::k64_finish<4>), dim3(c->nslices), dim3(256), 0, c->stream, F->X, c->ld, c->n, F->r, last, c->fin_out);
+                hipLaunchKernelGGL((jw64::k64_marker_stats<4>), dim3(kStatGrid), dim3(256), 0, c->stream, c->method, c->p, F->alpha, F->beta, F->delta, gamma_dev, c->stat_out);
+    }
+    HIPCHK(c, hipGetLastError());
+    return sweep_collect(c, S, 0, 0.0, nullptr);
+}
+
+extern "C" {
+
+int jwas_hip_set_precision(jwas_hip_ctx* c, int32_t bits)
+{
+    NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
+    NEED(c, bits == 32 || bits == 64, JWAS_HIP_EINVAL, "precision must be 32 or 64 bits (got %d)", bits);
+    NEED(c, !HAVE_STORAGE(c) && !(c->f64 && c->f64->X), JWAS_HIP_ESTATE, "choose the precision before genotypes are loaded");
+    if (bits == 64 && !c->f64) c->f64 = new jwas_hip_ctx::F64();
+    if (bits == 32 && c->f64) { delete c->f64; c->f64 = nullptr; }
+    return JWAS_HIP_OK;
+}
+
+int jwas_hip_load_dense_f64(jwas_hip_ctx* c, const double* Xh, int64_t n, int64_t p, int64_t ld_host)
+{
+    NEED(c, c && Xh, JWAS_HIP_EINVAL, "NULL argument");
+    ONLY_F64(c);
+    NEED(c, n > 0 && p > 0, JWAS_HIP_EINVAL, "genotype matrix must be non-empty (n=%lld, p=%lld)", (long long)n, (long long)p);
+    NEED(c, p < (1ll << 31), JWAS_HIP_EUNSUP, "p=%lld exceeds the 2^31 marker limit of one context", (long long)p);
+    NEED(c, ld_host >= n, JWAS_HIP_EINVAL, "ld_host (%lld) < n (%lld)", (long long)ld_host, (long long)n);
+    auto* F = c->f64;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    f64_free_state(c);
+    for (void* q : {(void*)F->X, (void*)F->r, (void*)F->xpx, (void*)F->gram, (void*)F->partials, (void*)F->ev, (void*)F->dparams}) (void)hipFree(q);
+    F->X = F->r = F->xpx = F->gram = F->partials = nullptr; F->ev = nullptr; F->dparams = nullptr;
+    (void)hipFree(c->counters); (void)hipFree(c->fin_out); (void)hipFree(c->stat_out); if (c->host_buf) (void)hipHostFree(c->host_buf);
+    c->counters = nullptr; c->fin_out = c->stat_out = nullptr; c->host_buf = nullptr;
+    c->method = -1; c->ntraits = 0; c->block_size = 0; c->nblocks = 0;
+    c->n = n; c->p = p; c->ld = round_up(n, kSliceRows); c->nslices = (int)(c->ld / kSliceRows);
+    HIPCHK(c, hipMalloc(&F->X, sizeof(double) * (size_t)c->ld * p));
+    HIPCHK(c, hipMalloc(&F->r, sizeof(double) * (size_t)kMaxT * c->ld));
+    HIPCHK(c, hipMalloc(&F->partials, sizeof(double) * (size_t)kMaxT * c->nslices * jw64::kMaxBlock64));
+    HIPCHK(c, hipMalloc(&F->ev, sizeof(jw64::Events64) * 2));
+    HIPCHK(c, hipMalloc(&F->dparams, sizeof(jw64::Params64)));
+    HIPCHK(c, hipMalloc(&c->counters, sizeof(unsigned long long) * 16));
+    const int nfin = kMaxT * kMaxT + kMaxT;
+    HIPCHK(c, hipMalloc(&c->fin_out, sizeof(double) * (size_t)c->nslices * nfin));
+    HIPCHK(c, hipMalloc(&c->stat_out, sizeof(double) * (size_t)kStatGrid * kNStat));
+    HIPCHK(c, hipHostMalloc(&c->host_buf, sizeof(double) * ((size_t)c->nslices * nfin + (size_t)kStatGrid * kNStat) + sizeof(unsigned long long) * 16));
+    HIPCHK(c, hipMemsetAsync(F->X, 0, sizeof(double) * (size_t)c->ld * p, c->stream));       // pad rows zero
+    HIPCHK(c, hipMemsetAsync(F->ev, 0, sizeof(jw64::Events64) * 2, c->stream));
+    HIPCHK(c, hipMemcpy2DAsync(F->X, sizeof(double) * c->ld, Xh, sizeof(double) * ld_host, sizeof(double) * n, (size_t)p, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return JWAS_HIP_OK;
+}
+
+int jwas_hip_get_xpx_f64(jwas_hip_ctx* c, double* out)
+{
+    NEED(c, c && out, JWAS_HIP_EINVAL, "NULL argument");
+    ONLY_F64(c);
+    NEED(c, c->f64->xpx, JWAS_HIP_ESTATE, "jwas_hip_setup_blocks has not been called");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(out, c->f64->xpx, sizeof(double) * c->p, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return JWAS_HIP_OK;
+}
+
+int jwas_hip_set_state_f64(jwas_hip_ctx* c, int32_t trait, const double* a, const double* b, const void* d)
+{
+    NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
+    ONLY_F64(c);
+    NEED_TRAIT(c, trait);
+    auto* F = c->f64;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t nb = sizeof(double) * c->p, off = (size_t)trait * c->p;
+    if (a) HIPCHK(c, hipMemcpyAsync(F->alpha + off, a, nb, hipMemcpyHostToDevice, c->stream));
+    if (b) HIPCHK(c, hipMemcpyAsync(F->beta + off, b, nb, hipMemcpyHostToDevice, c->stream));
+    if (d) {
+        if (c->method == JWAS_HIP_BAYESR) HIPCHK(c, hipMemcpyAsync(F->delta, d, sizeof(int32_t) * c->p, hipMemcpyHostToDevice, c->stream));
+        else HIPCHK(c, hipMemcpyAsync((double*)F->delta + off, d, nb, hipMemcpyHostToDevice, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return JWAS_HIP_OK;
+}
+
+int jwas_hip_get_state_f64(jwas_hip_ctx* c, int32_t trait, double* a, double* b, void* d)
+{
+    NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
+    ONLY_F64(c);
+    NEED_TRAIT(c, trait);
+    auto* F = c->f64;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t nb = sizeof(double) * c->p, off = (size_t)trait * c->p;
+    if (a) HIPCHK(c, hipMemcpyAsync(a, F->alpha + off, nb, hipMemcpyDeviceToHost, c->stream));
+    if (b) HIPCHK(c, hipMemcpyAsync(b, F->beta + off, nb, hipMemcpyDeviceToHost, c->stream));
+    if (d) {
+        if (c->method == JWAS_HIP_BAYESR) HIPCHK(c, hipMemcpyAsync(d, F->delta, sizeof(int32_t) * c->p, hipMemcpyDeviceToHost, c->stream));
+        else HIPCHK(c, hipMemcpyAsync(d, (double*)F->delta + off, nb, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return JWAS_HIP_OK;
+}
+
+int jwas_hip_set_residual_f64(jwas_hip_ctx* c, int32_t trait, const double* rh)
+{
+    NEED(c, c && rh, JWAS_HIP_EINVAL, "NULL argument");
+    ONLY_F64(c);
+    NEED_TRAIT(c, trait);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(c->f64->r + (size_t)trait * c->ld, rh, sizeof(double) * c->n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return JWAS_HIP_OK;
+}
+
+int jwas_hip_get_residual_f64(jwas_hip_ctx* c, int32_t trait, double* rh)
+{
+    NEED(c, c && rh, JWAS_HIP_EINVAL, "NULL argument");
+    ONLY_F64(c);
+    NEED_TRAIT(c, trait);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(rh, c->f64->r + (size_t)trait * c->ld, sizeof(double) * c->n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return JWAS_HIP_OK;
+}
+
+int jwas_hip_mul_alpha_f64(jwas_hip_ctx* c, int32_t trait, double* out)
+{
+    NEED(c, c && out, JWAS_HIP_EINVAL, "NULL argument");
+    ONLY_F64(c);
+    NEED_TRAIT(c, trait);
+    auto* F = c->f64;
+    HIPCHK(c, hipSetDevice(c->device));
+    double* tmp = nullptr;
+    HIPCHK(c, hipMalloc(&tmp, sizeof(double) * c->ld));
+    hipLaunchKernelGGL(jw64::k64_mul_alpha, dim3((unsigned)c->nslices), dim3(256), 0, c->stream, F->X, c->ld, c->p, F->alpha + (size_t)trait * c->p, tmp, 1.0,
+                       (const double*)nullptr);
+    hipError_t e = hipMemcpyAsync(out, tmp, sizeof(double) * c->n, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(tmp);
+    HIPCHK(c, e);
+    return JWAS_HIP_OK;
+}
+
+int jwas_hip_get_posterior_f64(jwas_hip_ctx* c, int32_t trait, double* ma, double* ma2, double* md)
+{
+    NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
+    ONLY_F64(c);
+    NEED_TRAIT(c, trait);
+    auto* F = c->f64;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t nb = sizeof(double) * c->p, off = (size_t)trait * c->p;
+    if (ma) HIPCHK(c, hipMemcpyAsync(ma, F->mean_a + off, nb, hipMemcpyDeviceToHost, c->stream));
+    if (ma2) HIPCHK(c, hipMemcpyAsync(ma2, F->mean_a2 + off, nb, hipMemcpyDeviceToHost, c->stream));
+    if (md) HIPCHK(c, hipMemcpyAsync(md, F->mean_d + off, nb, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return JWAS_HIP_OK;
+}
+
+}  // extern "C"
+
 extern "C" {
 
 int jwas_hip_sweep(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_sweep_stats* S)
 {
     NEED(c, c && P && S, JWAS_HIP_EINVAL, "NULL argument");
+    if (c->f64) return f64_sweep(c, P, S);
     size_t ntimed = 0;
     double timed_bytes = 0.0;
     int rc = sweep_enqueue(c, P, &ntimed, &timed_bytes);
@@ -1861,6 +2250,7 @@ int jwas_hip_comm_unique_id(void* id_out_128)
 
 int jwas_hip_comm_init(jwas_hip_ctx* c, const void* unique_id_128, int32_t rank, int32_t world)
 {
+    if (c) NOT_F64(c, "a shard communicator");
     NEED(c, c && unique_id_128, JWAS_HIP_EINVAL, "NULL argument");
     NEED(c, world >= 1 && rank >= 0 && rank < world, JWAS_HIP_EINVAL, "rank %d outside [0,%d)", rank, world);
     NEED(c, HAVE_STORAGE(c), JWAS_HIP_ESTATE, "load this rank's marker columns first");
@@ -1912,6 +2302,7 @@ int jwas_hip_comm_destroy(jwas_hip_ctx* c)
 
 int jwas_hip_comm_init_loopback(jwas_hip_ctx* c, int32_t slot, int32_t rank, int32_t world)
 {
+    if (c) NOT_F64(c, "a shard communicator");
     NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
     NEED(c, slot >= 0 && slot < 4, JWAS_HIP_EINVAL, "loopback slot %d outside [0,4)", slot);
     NEED(c, world >= 1 && world <= 8 && rank >= 0 && rank < world, JWAS_HIP_EINVAL, "rank %d outside [0,%d)", rank, world);
@@ -1955,6 +2346,7 @@ int jwas_hip_comm_row_shards(jwas_hip_ctx* c, int32_t enable)
 // On return every rank holds the same residual and the same all-rank statistics.
 int jwas_hip_sweep_sharded(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_sweep_stats* S)
 {
+    if (c) NOT_F64(c, "a sharded sweep");
     NEED(c, c && P && S, JWAS_HIP_EINVAL, "NULL argument");
     NEED(c, c->comm, JWAS_HIP_ESTATE, "jwas_hip_comm_init has not been called");
     NEED(c, !c->row_mode, JWAS_HIP_ESTATE, "this communicator runs exact row shards: use jwas_hip_sweep");
@@ -1985,6 +2377,7 @@ int jwas_hip_sweep_sharded(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_swe
 // ---- multi-trait BayesA/B: the per-marker effect covariances drawn on the device -------------------------------
 int jwas_hip_sample_marker_covariances(jwas_hip_ctx* c, double df, const double* scale, uint64_t seed, uint32_t iteration, uint32_t marker_offset)
 {
+    if (c) NOT_F64(c, "per-marker effect covariances");
     NEED(c, c && scale, JWAS_HIP_EINVAL, "NULL argument");
     NEED(c, c->method == JWAS_HIP_MTBAYESB1, JWAS_HIP_ESTATE, "jwas_hip_sample_marker_covariances needs init_state(JWAS_HIP_MTBAYESB1, t)");
     const int t = c->ntraits;
@@ -2019,6 +2412,16 @@ int jwas_hip_get_marker_covariances(jwas_hip_ctx* c, float* out)
 // ---- posterior accumulators ---------------------------------------------------------------------------
 int jwas_hip_accumulate(jwas_hip_ctx* c, double k)
 {
+    if (c && IS_F64(c)) {
+        NEED(c, c->method >= 0, JWAS_HIP_ESTATE, "jwas_hip_init_state has not been called");
+        NEED(c, k >= 1.0, JWAS_HIP_EINVAL, "nsamples must be >= 1");
+        HIPCHK(c, hipSetDevice(c->device));
+        const int64_t count = (int64_t)c->ntraits * c->p;
+        hipLaunchKernelGGL(jw64::k64_accumulate, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream, count, (int)(c->method == JWAS_HIP_BAYESR), k,
+                           c->f64->alpha, c->f64->delta, c->f64->mean_a, c->f64->mean_a2, c->f64->mean_d);
+        HIPCHK(c, hipGetLastError());
+        return JWAS_HIP_OK;
+    }
     NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
     NEED(c, c->method >= 0, JWAS_HIP_ESTATE, "jwas_hip_init_state has not been called");
     NEED(c, k >= 1.0, JWAS_HIP_EINVAL, "nsamples must be >= 1");
@@ -2032,6 +2435,7 @@ int jwas_hip_accumulate(jwas_hip_ctx* c, double k)
 
 int jwas_hip_get_posterior(jwas_hip_ctx* c, int32_t trait, float* ma, float* ma2, float* md)
 {
+    if (c) NOT_F64(c, "jwas_hip_get_posterior (use jwas_hip_get_posterior_f64)");
     NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
     NEED_TRAIT(c, trait);
     HIPCHK(c, hipSetDevice(c->device));

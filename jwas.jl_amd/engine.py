@@ -31,13 +31,23 @@ def _ptr(a):
 
 
 class HipEngine:
-    def __init__(self, device=0):
+    def __init__(self, device=0, precision=32):
+        """precision: 32 (the reference's default Float32 path) or 64 (runMCMC(double_precision=true): a Float64 context --
+        genotypes, residual, effects and the samplers' arithmetic all in double; jwas_hip_set_precision)."""
+        if precision not in (32, 64):
+            raise ValueError("precision must be 32 or 64")
         self._L = _lib.load()
         h = C.c_void_p()
         rc = self._L.jwas_hip_create(int(device), C.byref(h))
         if rc != 0:
             raise JwasHipError(rc, self._L.jwas_hip_last_error(None).decode())
         self._h = h
+        self.precision = int(precision)
+        self.dtype = np.float64 if precision == 64 else np.float32
+        if precision == 64:
+            rc = self._L.jwas_hip_set_precision(h, 64)
+            if rc != 0:
+                raise JwasHipError(rc, self._L.jwas_hip_last_error(h).decode())
         self.device = int(device)
         self.n = self.p = 0
         self.method = None
@@ -80,14 +90,14 @@ class HipEngine:
     def load_dense(self, X):
         """X: n x p float32.  Fortran order is uploaded as is (marker-major, zero re-layout)."""
         X = np.asarray(X)
-        if X.dtype != np.float32:
-            raise TypeError("the HIP path stores Float32 genotypes (double_precision=false)")
+        if X.dtype != self.dtype:
+            raise TypeError(f"this engine stores {np.dtype(self.dtype).name} genotypes (double_precision={'true' if self.precision == 64 else 'false'})")
         if X.ndim != 2:
             raise ValueError("genotype matrix must be 2-D")
         if not X.flags.f_contiguous:
             X = np.asfortranarray(X)
         n, p = X.shape
-        self._chk(self._L.jwas_hip_load_dense_f32(self._h, _ptr(X), n, p, n))
+        self._chk((self._L.jwas_hip_load_dense_f64 if self.precision == 64 else self._L.jwas_hip_load_dense_f32)(self._h, _ptr(X), n, p, n))
         self.n, self.p = n, p
         self.method, self.block_size = None, 0
 
@@ -224,8 +234,8 @@ class HipEngine:
         return min(self.block_size, self.p - j0)
 
     def xpx(self):
-        out = np.empty(self.p, dtype=np.float32)
-        self._chk(self._L.jwas_hip_get_xpx(self._h, _ptr(out)))
+        out = np.empty(self.p, dtype=self.dtype)
+        self._chk((self._L.jwas_hip_get_xpx_f64 if self.precision == 64 else self._L.jwas_hip_get_xpx)(self._h, _ptr(out)))
         return out
 
     def gram(self, i):
@@ -270,33 +280,37 @@ class HipEngine:
         self.method, self.ntraits = code, int(ntraits)
 
     def _delta_dtype(self):
-        return np.int32 if self.method == _lib.BAYESR else np.float32
+        return np.int32 if self.method == _lib.BAYESR else self.dtype
+
+    def _f(self, name):
+        """The entry point `name`, or its _f64 namesake in a Float64 context."""
+        return getattr(self._L, name + "_f64" if self.precision == 64 else name)
 
     def set_state(self, trait=0, alpha=None, beta=None, delta=None):
-        a = None if alpha is None else np.ascontiguousarray(alpha, dtype=np.float32)
-        b = None if beta is None else np.ascontiguousarray(beta, dtype=np.float32)
+        a = None if alpha is None else np.ascontiguousarray(alpha, dtype=self.dtype)
+        b = None if beta is None else np.ascontiguousarray(beta, dtype=self.dtype)
         d = None if delta is None else np.ascontiguousarray(delta, dtype=self._delta_dtype())
         for v in (a, b, d):
             if v is not None and v.shape != (self.p,):
                 raise ValueError(f"state vectors must have length {self.p}")
-        self._chk(self._L.jwas_hip_set_state(self._h, int(trait), _ptr(a), _ptr(b), _ptr(d)))
+        self._chk(self._f("jwas_hip_set_state")(self._h, int(trait), _ptr(a), _ptr(b), _ptr(d)))
 
     def get_state(self, trait=0):
-        a = np.empty(self.p, dtype=np.float32)
-        b = np.empty(self.p, dtype=np.float32)
+        a = np.empty(self.p, dtype=self.dtype)
+        b = np.empty(self.p, dtype=self.dtype)
         d = np.empty(self.p, dtype=self._delta_dtype())
-        self._chk(self._L.jwas_hip_get_state(self._h, int(trait), _ptr(a), _ptr(b), _ptr(d)))
+        self._chk(self._f("jwas_hip_get_state")(self._h, int(trait), _ptr(a), _ptr(b), _ptr(d)))
         return a, b, d
 
     def set_residual(self, r, trait=0):
-        r = np.ascontiguousarray(r, dtype=np.float32)
+        r = np.ascontiguousarray(r, dtype=self.dtype)
         if r.shape != (self.n,):
             raise ValueError(f"residual must have length {self.n}")
-        self._chk(self._L.jwas_hip_set_residual(self._h, int(trait), _ptr(r)))
+        self._chk(self._f("jwas_hip_set_residual")(self._h, int(trait), _ptr(r)))
 
     def get_residual(self, trait=0):
-        r = np.empty(self.n, dtype=np.float32)
-        self._chk(self._L.jwas_hip_get_residual(self._h, int(trait), _ptr(r)))
+        r = np.empty(self.n, dtype=self.dtype)
+        self._chk(self._f("jwas_hip_get_residual")(self._h, int(trait), _ptr(r)))
         return r
 
     def residual_dev(self):
@@ -321,8 +335,8 @@ class HipEngine:
         self._chk(self._L.jwas_hip_residual_sub_xalpha(self._h, int(trait)))
 
     def mul_alpha(self, trait=0):
-        out = np.empty(self.n, dtype=np.float32)
-        self._chk(self._L.jwas_hip_mul_alpha(self._h, int(trait), _ptr(out)))
+        out = np.empty(self.n, dtype=self.dtype)
+        self._chk(self._f("jwas_hip_mul_alpha")(self._h, int(trait), _ptr(out)))
         return out
 
     def alpha_sparse(self, trait=0):
@@ -440,9 +454,13 @@ class HipEngine:
         vg = np.asarray(var_effect, dtype=np.float32).reshape(-1)
         if ve.size != t * t or vg.size != t * t:
             raise ValueError(f"vare / var_effect must have {t}x{t} entries")
+        ve64 = np.asarray(vare, dtype=np.float64).reshape(-1)
+        vg64 = np.asarray(var_effect, dtype=np.float64).reshape(-1)
         for i in range(t * t):
             P.vare[i] = float(ve[i])
             P.var_effect[i] = float(vg[i])
+            P.vare_f64[i] = float(ve64[i])              # (read by Float64 contexts: the variances as the reference holds them there)
+            P.var_effect_f64[i] = float(vg64[i])
         P.pi = float(pi) if np.ndim(pi) == 0 else 0.0      # (vector pi: per marker, or per trait for megaBayesABC)
         keep = []
         if self.method in (_lib.BAYESC, _lib.BAYESB):
@@ -458,10 +476,13 @@ class HipEngine:
             if self.method == _lib.BAYESB:
                 if var_effect_vec is None:
                     raise ValueError("BayesB needs per-marker effect variances")
-                vv = np.ascontiguousarray(var_effect_vec, dtype=np.float32)
+                vv = np.ascontiguousarray(var_effect_vec, dtype=self.dtype)
                 if vv.shape != (self.p,):
                     raise ValueError(f"BayesB variance vector must have length {self.p}")
-                P.var_effect_vec = vv.ctypes.data_as(C.POINTER(C.c_float))
+                if self.precision == 64:
+                    P.var_effect_vec_f64 = vv.ctypes.data_as(C.POINTER(C.c_double))
+                else:
+                    P.var_effect_vec = vv.ctypes.data_as(C.POINTER(C.c_float))
                 keep.append(vv)
         elif self.method == _lib.BAYESR:
             g = np.asarray(gamma, dtype=np.float64)
@@ -549,8 +570,8 @@ class HipEngine:
         self._chk(self._L.jwas_hip_accumulate(self._h, float(nsamples)))
 
     def posterior(self, trait=0):
-        ma = np.empty(self.p, dtype=np.float32)
-        ma2 = np.empty(self.p, dtype=np.float32)
-        md = np.empty(self.p, dtype=np.float32)
-        self._chk(self._L.jwas_hip_get_posterior(self._h, int(trait), _ptr(ma), _ptr(ma2), _ptr(md)))
+        ma = np.empty(self.p, dtype=self.dtype)
+        ma2 = np.empty(self.p, dtype=self.dtype)
+        md = np.empty(self.p, dtype=self.dtype)
+        self._chk(self._f("jwas_hip_get_posterior")(self._h, int(trait), _ptr(ma), _ptr(ma2), _ptr(md)))
         return ma, ma2, md

@@ -168,11 +168,17 @@ def _gibbs(A, x, b, rng, vare=None):
 def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed, starting_value,
               fast_blocks, independent_blocks=False, heterogeneous_residuals=False, outputEBV, output_heritability=True, output_folder, printout_frequency, memory_guard, memory_guard_ratio,
               missing_phenotypes, device, block_size, gram_mode, engine, printout_model_info,
-              output_samples_for_all_parameters):
+              output_samples_for_all_parameters, double_precision=False):
     import pandas as pd
     Mi = model.M[0]
     t = model.nModels
     method = Mi.method
+    # runMCMC(double_precision=true) (JWAS.jl:349-366): genotypes, G, alpha -> Float64; everything the chain holds follows.
+    # ftype is the element type of the run (the reference's Float32 default, or Float64).
+    ftype = np.float64 if double_precision else np.float32
+    if not double_precision and getattr(Mi, "genotypes", None) is not None and getattr(Mi.genotypes, "dtype", None) == np.float64:
+        raise NotImplementedError("Float64 genotypes (get_genotypes(double_precision=true)) run with runMCMC(double_precision=true); "
+                                  "the mixed Float64 / Float32 chain stays on the reference")
     if t > 1 and method not in ("BayesC", "RR-BLUP", "BayesB", "BayesA"):
         raise NotImplementedError("multi-trait device path implements BayesC (Gibbs samplers I, II and the constraint=true "
                                   "megaBayesABC! path) and BayesA/B (sampler I); other methods stay on the reference")
@@ -264,16 +270,16 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         fh.write("\n".join(ph[idcol]) + "\n")
     with open(os.path.join(output_folder, "IDs_for_individuals_with_genotypes.txt"), "w") as fh:
         fh.write("\n".join(Mi.obsID) + "\n")
-    Y = np.stack([ph[tr].to_numpy(dtype=np.float32) for tr in model.lhsVec])       # t x n
+    Y = np.stack([ph[tr].to_numpy(dtype=ftype) for tr in model.lhsVec])       # t x n
     observed = np.isfinite(Y).T                                                     # n x t: mme.missingPattern (residual.jl:17-21)
     has_missing = not observed.all()
     phenovar = np.array([np.var(Y[k][observed[:, k]].astype(np.float64), ddof=1) for k in range(t)])
-    Y = np.where(np.isfinite(Y), Y, np.float32(0)).astype(np.float32)               # imputed before first use (residual.jl:52-73)
+    Y = np.where(np.isfinite(Y), Y, ftype(0)).astype(ftype)               # imputed before first use (residual.jl:52-73)
     invw = None
     if heterogeneous_residuals:                                           # build_MME.jl:305-310
         if "weights" not in ph.columns:
             raise ValueError("heterogeneous_residuals=true requires a column named weights in the phenotype data.")
-        invw = (1.0 / ph["weights"].to_numpy(dtype=np.float64)).astype(np.float32)
+        invw = (1.0 / ph["weights"].to_numpy(dtype=np.float64)).astype(ftype)
         if not np.all(np.isfinite(invw) & (invw > 0)):
             raise ValueError("weights must be positive and finite.")
     w64 = np.ones(len(ph)) if invw is None else invw.astype(np.float64)
@@ -283,7 +289,7 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
     vare0 = np.diag(phenovar) * 0.5
     R = model.R
     if R.val is False:
-        R.val = np.float32(vare0[0, 0]) if t == 1 else vare0.astype(np.float32)
+        R.val = ftype(vare0[0, 0]) if t == 1 else vare0.astype(ftype)
         R.scale = float(R.val) * (float(R.df) - 2) / float(R.df) if t == 1 else np.asarray(R.val, dtype=np.float64) * (float(R.df) - t - 1)
     if Mi.G.val is False and Mi.genetic_variance.val is False:
         Mi.genetic_variance.val = varg[0, 0] if t == 1 else varg
@@ -369,12 +375,12 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
     if t > 1 and R.constraint:                                         # R_constraint! (input_data_validation.jl:530-540)
         Rdf -= t
         R.scale = np.diag(np.diag(np.asarray(R.scale, dtype=np.float64)) / (Rdf - 1)) * (Rdf - 2) / Rdf
-        R.val = np.diag(np.diag(np.asarray(R.val, dtype=np.float32)))
+        R.val = np.diag(np.diag(np.asarray(R.val, dtype=ftype)))
     pi_t = None
     if mega:                                                           # G_constraint! (input_data_validation.jl:543-559)
         Gdf -= t
         Mi.G.scale = np.diag(np.diag(np.asarray(Mi.G.scale, dtype=np.float64)) / (Gdf - 1)) * (Gdf - 2) / Gdf
-        Mi.G.val = np.diag(np.diag(np.asarray(Mi.G.val, dtype=np.float32)))
+        Mi.G.val = np.diag(np.diag(np.asarray(Mi.G.val, dtype=ftype)))
         # megaBayesABC! reads one pi per trait (genotypes.pi[i], BayesABC.jl:5).  The reference only holds the joint
         # 2^t table before the first samplePi; the per-trait value used here is its marginal Pr(delta_k = 0).
         pa = np.asarray(pi, dtype=np.float64)
@@ -493,16 +499,32 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         # per sweep at 20k x 100k x 3 traits)
         adaptive = (not dense) and t == 1 and block_size == 512 and p > 4 * 1024
 
+    if double_precision:
+        # the Float64 device context (csrc/f64_path.hpp): dense storage, blocks of 64 / 128 markers, single-trait
+        # BayesA/B/C (+ RR-BLUP, BayesL through them), BayesR, multi-trait BayesC sampler I
+        if stream or devres:
+            raise NotImplementedError("double_precision=true needs dense host genotypes (the streaming backend is Float32 only, readgenotypes.jl:246-248)")
+        if invw is not None or independent_blocks or mega or mt_pervar or explicit_partition is not None or (t > 1 and mt_method != "MTBayesC"):
+            raise NotImplementedError("double_precision=true runs unit residual weights, the sequential block sweep, multi-trait BayesC "
+                                      "sampler I and uniform blocks; the other combinations stay on the reference")
+        if fast_blocks is not False:
+            if want not in (64, 128):
+                raise NotImplementedError("double_precision=true runs fast_blocks = 64 or 128 on the device")
+            block_size = want
+        else:
+            block_size = 128 if p > 64 else 64
+        adaptive = False
+
     # ---- engine (the only engine shipped is the HIP one; there is no CPU fallback)
     own_engine = engine is None
     if own_engine:
         from .engine import HipEngine
-        need = HipEngine.estimate_bytes(n, p, t, block_size, "stream" if stream else "dense")
+        need = HipEngine.estimate_bytes(n, p, t, block_size, "stream" if stream else "dense") * (2 if double_precision else 1)
         if adaptive:
             need += 2 * 4 * 1024 * p                               # the second resident block size (Grams + cross-Grams)
         if outputEBV and not out_same:                             # Mi.output_genotypes: a second dense matrix (n_out x p)
             need += 4 * ((len(out_rows) + 255) // 256 * 256) * p
-        engine = HipEngine(device)
+        engine = HipEngine(device, precision=64 if double_precision else 32)
         free = engine.device_info()["hbm_free"]
         if memory_guard != "off" and need > memory_guard_ratio * free:   # JWAS.jl:422-459 analogue for HBM
             msg = (f"marker path needs {need / 1e9:.2f} GB of HBM, more than {memory_guard_ratio:.2f} x free "
@@ -516,9 +538,13 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
     elif stream:
         engine.load_jgb2(Mi.stream_backend["prefix"])          # payload stays 2-bit packed in HBM
     else:
-        engine.load_dense(X)                   # after alignment (tools4genotypes.jl:310-321)
+        engine.load_dense(np.asfortranarray(X, dtype=ftype))      # after alignment (tools4genotypes.jl:310-321); Float64 on request (JWAS.jl:353)
+    X_out_host = None
     if outputEBV and not out_same:             # Mi.output_genotypes = Z_out * genotypes (tools4genotypes.jl:290-296)
-        engine.load_output_dense(np.asfortranarray(Mi.genotypes[out_rows, :]))
+        if double_precision:                   # (the Float64 context has no second resident matrix: the EBV product runs on the host)
+            X_out_host = np.asarray(Mi.genotypes[out_rows, :], dtype=np.float64)
+        else:
+            engine.load_output_dense(np.asfortranarray(Mi.genotypes[out_rows, :]))
     # A device-resident engine may come from an earlier run: its weights, Grams and block partition must be THIS run's.
     # set_weights(None) restores unit weights (and drops the resident Grams, which were X_b'R^-1 X_b); an explicit
     # partition left by the previous run is rebuilt as uniform blocks below.
@@ -546,27 +572,27 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
     off = np.cumsum([0] + q)
 
     # ---- starting state (MCMC_BayesianAlphabet.jl:85-147)
-    alpha0 = np.zeros((t, p), dtype=np.float32)
+    alpha0 = np.zeros((t, p), dtype=ftype)
     if Mi.alpha is not False:
-        alpha0[:] = np.asarray(Mi.alpha, dtype=np.float32).reshape(t, p)
+        alpha0[:] = np.asarray(Mi.alpha, dtype=ftype).reshape(t, p)
     for k in range(t):
         engine.set_state(k, alpha=alpha0[k], beta=alpha0[k],
-                         delta=np.ones(p, dtype=np.int32 if method == "BayesR" else np.float32))
+                         delta=np.ones(p, dtype=np.int32 if method == "BayesR" else ftype))
         engine.set_residual(Y[k], k)           # sol = 0
         if alpha0[k].any():
             engine.sub_xalpha(k)
 
-    vare = np.float32(R.val) if t == 1 else np.asarray(R.val, dtype=np.float32)
-    Gval = np.float32(Mi.G.val) if t == 1 else np.asarray(Mi.G.val, dtype=np.float32)
+    vare = ftype(R.val) if t == 1 else np.asarray(R.val, dtype=ftype)
+    Gval = ftype(Mi.G.val) if t == 1 else np.asarray(Mi.G.val, dtype=ftype)
     if lasso:                                                           # MCMC_BayesianAlphabet.jl:70-81
-        Gval = np.float32(Gval / 8)
+        Gval = ftype(Gval / 8)
         Mi.G.scale = Mi.G.scale / 8
         gamma_l = rng.gamma(1.0, 8.0, size=p)
-        Gvec = (np.float64(Gval) * gamma_l).astype(np.float32)
+        Gvec = (np.float64(Gval) * gamma_l).astype(ftype)
     elif mt_pervar:
-        Gmat = np.tile(np.asarray(Gval, dtype=np.float32), (p, 1, 1))   # MCMC_BayesianAlphabet.jl:67-69 (fill(G, nMarkers))
+        Gmat = np.tile(np.asarray(Gval, dtype=ftype), (p, 1, 1))   # MCMC_BayesianAlphabet.jl:67-69 (fill(G, nMarkers))
     elif method == "BayesB":
-        Gvec = np.full(p, Gval, dtype=np.float32)                       # MCMC_BayesianAlphabet.jl:67-69
+        Gvec = np.full(p, Gval, dtype=ftype)                       # MCMC_BayesianAlphabet.jl:67-69
     pervar = method == "BayesB" and not lasso                           # per-marker variances, no common variance to report
     if t == 1 and method in ("BayesC", "BayesB") and np.ndim(pi) == 0:
         pi = float(pi)
@@ -644,7 +670,7 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
                     rhs = Xf[0].T @ (w64 * r)                               # MCMC_BayesianAlphabet.jl:211
                     _gibbs(lhs, sol, rhs, rng, float(vare))
                     r -= Xf[0] @ sol
-                    engine.set_residual(r.astype(np.float32), 0)
+                    engine.set_residual(r.astype(ftype), 0)
                 else:
                     R0 = np.asarray(vare, dtype=np.float64)
                     Rinv = np.linalg.inv(R0)
@@ -667,13 +693,13 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
                         b = np.concatenate([Xf[k].T @ (w64 * sum(Rinv[k, l] * rr[l] for l in range(t))) for k in range(t)])
                     _gibbs(A, sol, b, rng, None)
                     for k in range(t):
-                        engine.set_residual((rr[k] - Xf[k] @ sol[off[k]:off[k + 1]]).astype(np.float32), k)
+                        engine.set_residual((rr[k] - Xf[k] @ sol[off[k]:off[k + 1]]).astype(ftype), k)
 
             elif t > 1 and has_missing:                                       # no location parameters: imputation only
                 res = [engine.get_residual(k).astype(np.float64) for k in range(t)]
                 _impute_missing_residuals(res, observed, np.asarray(vare, dtype=np.float64), rng)
                 for k in range(t):
-                    engine.set_residual(res[k].astype(np.float32), k)
+                    engine.set_residual(res[k].astype(ftype), k)
 
             # 2. marker effects (DEVICE)
             kw = dict(iteration=it, seed=seed_int, vare=vare, nreps=nreps)
@@ -722,7 +748,7 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
             # 4. marker effect variance (variance_components.jl:151-189), re-cast to Float32 (:323-325)
             if Mi.G.estimate_variance:
                 if mega:                                                    # diagonal only (variance_components.jl:104-109)
-                    Gval = np.diag([(st["beta_ss"][k, k] + Gdf * Mi.G.scale[k, k]) / rng.chisquare(p + Gdf) for k in range(t)]).astype(np.float32)
+                    Gval = np.diag([(st["beta_ss"][k, k] + Gdf * Mi.G.scale[k, k]) / rng.chisquare(p + Gdf) for k in range(t)]).astype(ftype)
                 elif mt_pervar:                                             # variance_components.jl:181-186: one draw per marker,
                     if hasattr(engine, "sample_marker_covariances"):        # IW(df + 1, scale + b_j b_j') -- on the device, from the
                         # resident beta (jwas_hip_sample_marker_covariances: Bartlett on the counter RNG); the next sweep uses them in place
@@ -730,27 +756,27 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
                         Gmat = None
                     else:
                         B = np.stack([engine.get_state(k)[1] for k in range(t)], axis=1).astype(np.float64)
-                        Gmat = _inverse_wishart_batch(rng, Gdf + 1.0, np.asarray(Mi.G.scale, dtype=np.float64)[None] + B[:, :, None] * B[:, None, :]).astype(np.float32)
+                        Gmat = _inverse_wishart_batch(rng, Gdf + 1.0, np.asarray(Mi.G.scale, dtype=np.float64)[None] + B[:, :, None] * B[:, None, :]).astype(ftype)
                 elif t > 1:
                     from scipy.stats import invwishart
                     S = np.asarray(Mi.G.scale, dtype=np.float64) + st["beta_ss"]
-                    Gval = np.asarray(invwishart.rvs(df=Gdf + p, scale=(S + S.T) / 2, random_state=rng), dtype=np.float32).reshape(t, t)
+                    Gval = np.asarray(invwishart.rvs(df=Gdf + p, scale=(S + S.T) / 2, random_state=rng), dtype=ftype).reshape(t, t)
                 elif method == "BayesR":
-                    Gval = np.float32((st["bayesr_ssq"] + Gdf * Mi.G.scale) / rng.chisquare(st["bayesr_nnz"] + Gdf))
+                    Gval = ftype((st["bayesr_ssq"] + Gdf * Mi.G.scale) / rng.chisquare(st["bayesr_nnz"] + Gdf))
                 elif lasso:                                                 # variance_components.jl:152-166,191-203
                     a64 = engine.get_state(0)[0].astype(np.float64)
-                    Gval = np.float32((np.dot(a64 / gamma_l, a64) + Gdf * Mi.G.scale) / rng.chisquare(p + Gdf))
+                    Gval = ftype((np.dot(a64 / gamma_l, a64) + Gdf * Mi.G.scale) / rng.chisquare(p + Gdf))
                     Q = a64 * a64 / np.float64(Gval)
                     cand = 1.0 / rng.gamma(0.5, 4.0, size=p)
                     with np.errstate(over="ignore"):
                         accept = rng.random(p) < np.exp(Q / 4.0 * (2.0 / gamma_l - cand))
                     gamma_l[accept] = 2.0 / cand[accept]
-                    Gvec = (np.float64(Gval) * gamma_l).astype(np.float32)
+                    Gvec = (np.float64(Gval) * gamma_l).astype(ftype)
                 elif method == "BayesB":
                     beta = engine.get_state(0)[1].astype(np.float64)
-                    Gvec = ((beta * beta + Gdf * Mi.G.scale) / rng.chisquare(1.0 + Gdf, size=p)).astype(np.float32)
+                    Gvec = ((beta * beta + Gdf * Mi.G.scale) / rng.chisquare(1.0 + Gdf, size=p)).astype(ftype)
                 else:
-                    Gval = np.float32((np.float32(st["alpha_ss"][0, 0]) + Gdf * Mi.G.scale) / rng.chisquare(st["sum_delta"][0] + Gdf))
+                    Gval = ftype((ftype(st["alpha_ss"][0, 0]) + Gdf * Mi.G.scale) / rng.chisquare(st["sum_delta"][0] + Gdf))
 
             # 4b. scale of the marker-effect variance prior (MCMC_BayesianAlphabet.jl:328-336; single trait only there too)
             if Mi.G.estimate_scale and t == 1:
@@ -760,13 +786,13 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
             # 5. residual variance (variance_components.jl:60-66,82-112), re-cast to Float32 (:368-370)
             if R.estimate_variance:
                 if t > 1 and R.constraint:                                  # variance_components.jl:104-109
-                    vare = np.diag([(st["resid_ss"][k, k] + Rdf * R.scale[k, k]) / rng.chisquare(n + Rdf) for k in range(t)]).astype(np.float32)
+                    vare = np.diag([(st["resid_ss"][k, k] + Rdf * R.scale[k, k]) / rng.chisquare(n + Rdf) for k in range(t)]).astype(ftype)
                 elif t > 1:
                     from scipy.stats import invwishart
                     S = np.asarray(R.scale, dtype=np.float64) + st["resid_ss"]
-                    vare = np.asarray(invwishart.rvs(df=Rdf + n, scale=(S + S.T) / 2, random_state=rng), dtype=np.float32).reshape(t, t)
+                    vare = np.asarray(invwishart.rvs(df=Rdf + n, scale=(S + S.T) / 2, random_state=rng), dtype=ftype).reshape(t, t)
                 else:
-                    vare = np.float32((np.float32(st["resid_ss"][0, 0]) + Rdf * R.scale) / rng.chisquare(n + Rdf))
+                    vare = ftype((ftype(st["resid_ss"][0, 0]) + Rdf * R.scale) / rng.chisquare(n + Rdf))
 
             # 6. save (MCMC_BayesianAlphabet.jl:399-413, output.jl:443-604)
             if it > burnin and (it - burnin) % output_samples_frequency == 0:
@@ -790,20 +816,23 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
                 if Mi.estimatePi and f"pi_{name}" in files:
                     files[f"pi_{name}"].write(",".join(repr(float(v)) for v in np.atleast_1d(pi_t if mega else pi)) + "\n")
                 for kk, tr in enumerate(model.lhsVec):
-                    if hasattr(engine, "alpha_sparse"):
+                    if hasattr(engine, "alpha_sparse") and not double_precision:
                         si, sv = engine.alpha_sparse(kk)              # (idx, val) compacted on the device
                     else:
                         a_ = engine.get_state(kk)[0]
                         si = np.flatnonzero(a_).astype(np.int32); sv = a_[si]
                     bin_writers[kk].append(si, sv)
                     if write_marker_samples:
-                        a = np.zeros(p, dtype=np.float32)
+                        a = np.zeros(p, dtype=ftype)
                         a[si] = sv
                         fh = files[f"marker_effects_{name}_{tr}"]
                         a.tofile(fh, sep=",", format="%.9g")          # text at C speed; 9 significant digits round-trip Float32
                         fh.write("\n")
                 if outputEBV:
-                    ebvs = [engine.mul_alpha(kk) if out_same else engine.mul_alpha_output(kk) for kk in range(t)]   # getEBV, output.jl:281-306
+                    if X_out_host is not None:
+                        ebvs = [(X_out_host @ engine.get_state(kk)[0].astype(np.float64)).astype(ftype) for kk in range(t)]
+                    else:
+                        ebvs = [engine.mul_alpha(kk) if out_same else engine.mul_alpha_output(kk) for kk in range(t)]   # getEBV, output.jl:281-306
                     for kk in range(t):
                         ebv_run[kk].add(ebvs[kk], k)
                     if heritability:                                        # output.jl:498-512

@@ -235,6 +235,26 @@ double orc_time_sweeps_team(int kind, const float* X, int64_t n, int64_t p, int6
                             const float* vare, const float* var_effect, const double* prior, const double* gamma,
                             uint64_t seed, int sweeps, int nthreads, double max_seconds, int64_t* markers_done);
 
+/* ---- Float64 mode (runMCMC(double_precision=true)): oracle/jwas_oracle_f64.c -- the reference's scalar kernels with
+ * T = Float64 in the literal non-block order (and BayesABC_block! with repetitions); same counter RNG. */
+void orc64_xpx(const double* X, int64_t n, int64_t p, int64_t ld, double* out);
+int  orc64_bayesabc_sweep(const double* X, int64_t n, int64_t p, int64_t ld, const double* xpx,
+                          double* r, double* alpha, double* beta, double* delta,
+                          double vare, const double* var_effects, const double* pi,
+                          uint64_t seed, uint32_t iter, uint32_t marker0);
+int  orc64_bayesabc_block_sweep(const double* X, int64_t n, int64_t p, int64_t ld, const double* xpx, int64_t bs, int nreps,
+                                double* r, double* alpha, double* beta, double* delta,
+                                double vare, const double* var_effects, const double* pi,
+                                uint64_t seed, uint32_t iter, uint32_t marker0);
+int  orc64_bayesr_sweep(const double* X, int64_t n, int64_t p, int64_t ld, const double* xpx,
+                        double* r, double* alpha, int32_t* delta,
+                        double vare, double sigma_sq, const double* pi, int pi_is_matrix, const double* gamma,
+                        uint64_t seed, uint32_t iter, uint32_t marker0);
+int  orc64_mt1_sweep(int t, const double* X, int64_t n, int64_t p, int64_t ld, const double* xpx,
+                     double* r, int64_t ldr, double* alpha, double* beta, double* delta,
+                     const double* vare, const double* var_effect, const double* log_prior,
+                     uint64_t seed, uint32_t iter, uint32_t marker0);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,9 +20,10 @@ GAMMA = np.array([0.0, 0.01, 0.1, 1.0], dtype=np.float64)  # JWAS.jl:12
 
 def build(force=False):
     src = os.path.join(_HERE, "jwas_oracle.c")
+    src64 = os.path.join(_HERE, "jwas_oracle_f64.c")
     hdr = os.path.join(_HERE, "jwas_oracle.h")
     stale = (not os.path.exists(_LIB_PATH)) or any(
-        os.path.exists(f) and os.path.getmtime(f) > os.path.getmtime(_LIB_PATH) for f in (src, hdr))
+        os.path.exists(f) and os.path.getmtime(f) > os.path.getmtime(_LIB_PATH) for f in (src, src64, hdr))
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "-B", "libjwas_oracle.so"],
                               stdout=subprocess.DEVNULL)
@@ -358,3 +359,58 @@ def time_sweeps_team(kind, X, xpx_, r, alpha, beta, delta, vare, var_effect, pri
     if el < 0:
         raise ValueError("oracle timing helper rejected its arguments")
     return el, done.value
+
+
+# ---- Float64 mode (runMCMC(double_precision=true)): oracle/jwas_oracle_f64.c ------------------------------------------
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def xpx64(X):
+    X = np.asfortranarray(X, dtype=np.float64)
+    n, p = X.shape
+    out = np.empty(p)
+    L = lib()
+    L.orc64_xpx.restype = None
+    L.orc64_xpx.argtypes = [_f64p, C.c_int64, C.c_int64, C.c_int64, _f64p]
+    L.orc64_xpx(_p(X, _f64p), n, p, n, _p(out, _f64p))
+    return out
+
+
+def bayesabc_sweep64(X, xpx_, r, alpha, beta, delta, vare, var_effects, pi, seed, it, marker0=0, block_size=0, nreps=1):
+    """BayesABC! with T = Float64, in place; block_size > 0: BayesABC_block! with `nreps` repetitions."""
+    n, p = X.shape
+    ve = np.broadcast_to(np.asarray(var_effects, dtype=np.float64), (p,)).copy()
+    pv = np.broadcast_to(np.asarray(pi, dtype=np.float64), (p,)).copy()
+    L = lib()
+    common = [_p(r, _f64p), _p(alpha, _f64p), _p(beta, _f64p), _p(delta, _f64p), C.c_double(float(vare)), _p(ve, _f64p), _p(pv, _f64p),
+              C.c_uint64(int(seed)), C.c_uint32(int(it)), C.c_uint32(int(marker0))]
+    if block_size:
+        rc = L.orc64_bayesabc_block_sweep(_p(X, _f64p), C.c_int64(n), C.c_int64(p), C.c_int64(n), _p(xpx_, _f64p), C.c_int64(int(block_size)),
+                                          C.c_int(int(nreps)), *common)
+    else:
+        rc = L.orc64_bayesabc_sweep(_p(X, _f64p), C.c_int64(n), C.c_int64(p), C.c_int64(n), _p(xpx_, _f64p), *common)
+    if rc:
+        raise ValueError(f"orc64_bayesabc_sweep: {rc}")
+
+
+def bayesr_sweep64(X, xpx_, r, alpha, delta, vare, sigma_sq, pi, seed, it, gamma=GAMMA, marker0=0):
+    n, p = X.shape
+    pm = _f64(pi)
+    g = _f64(gamma)
+    rc = lib().orc64_bayesr_sweep(_p(X, _f64p), C.c_int64(n), C.c_int64(p), C.c_int64(n), _p(xpx_, _f64p), _p(r, _f64p), _p(alpha, _f64p),
+                                  _p(delta, _i32p), C.c_double(float(vare)), C.c_double(float(sigma_sq)), _p(pm, _f64p), C.c_int(int(pm.ndim == 2)),
+                                  _p(g, _f64p), C.c_uint64(int(seed)), C.c_uint32(int(it)), C.c_uint32(int(marker0)))
+    if rc:
+        raise ValueError(f"orc64_bayesr_sweep: {rc}")
+
+
+def mt1_sweep64(X, xpx_, r, alpha, beta, delta, vare, var_effect, log_prior, seed, it, marker0=0):
+    """_MTBayesABC_samplerI! with T = Float64; r: t x n, alpha / beta / delta: t x p (all C-contiguous float64, in place)."""
+    n, p = X.shape
+    t = r.shape[0]
+    rc = lib().orc64_mt1_sweep(C.c_int(t), _p(X, _f64p), C.c_int64(n), C.c_int64(p), C.c_int64(n), _p(xpx_, _f64p), _p(r, _f64p), C.c_int64(n),
+                               _p(alpha, _f64p), _p(beta, _f64p), _p(delta, _f64p), _p(_f64(vare), _f64p), _p(_f64(var_effect), _f64p),
+                               _p(_f64(log_prior), _f64p), C.c_uint64(int(seed)), C.c_uint32(int(it)), C.c_uint32(int(marker0)))
+    if rc:
+        raise ValueError(f"orc64_mt1_sweep: {rc}")

@@ -244,3 +244,110 @@ class OracleEngine:
 
     def posterior(self, trait=0):
         return self.mean_a[trait].copy(), self.mean_a2[trait].copy(), self.mean_d[trait].copy()
+
+
+class OracleEngine64:
+    """The sweep-engine protocol on the Float64 oracle (oracle/jwas_oracle_f64.c): runMCMC(double_precision=true) on the CPU.
+    The literal non-block chain (block form with repetitions for single-trait BayesA/B/C when nreps != 1)."""
+    precision = 64
+    dtype = np.float64
+
+    def __init__(self):
+        self.n = self.p = 0
+        self.method = None
+        self.ntraits = 0
+        self.block_size = 0
+
+    def close(self):
+        pass
+
+    def load_dense(self, X):
+        self.X = np.asfortranarray(np.asarray(X, dtype=np.float64))
+        self.n, self.p = self.X.shape
+
+    def setup_blocks(self, block_size=128, gram_mode="f64"):
+        self.block_size = int(block_size)
+        self._xpx = O.xpx64(self.X)
+
+    def block_starts(self):
+        return np.arange(0, self.p, self.block_size, dtype=np.int64)
+
+    def xpx(self):
+        return self._xpx.copy()
+
+    def init_state(self, method, ntraits=1):
+        self.method = METHOD_CODES[method] if isinstance(method, str) else int(method)
+        assert self.method in (BAYESC, BAYESB, BAYESR, MTBAYESC1)
+        self.ntraits = t = int(ntraits)
+        self.alpha = np.zeros((t, self.p)); self.beta = np.zeros((t, self.p))
+        self.delta = np.zeros(self.p, dtype=np.int32)[None] if self.method == BAYESR else np.zeros((t, self.p))
+        self.r = np.zeros((t, self.n))
+        self.mean_a = np.zeros((t, self.p)); self.mean_a2 = np.zeros((t, self.p)); self.mean_d = np.zeros((t, self.p))
+
+    def set_state(self, trait=0, alpha=None, beta=None, delta=None):
+        if alpha is not None: self.alpha[trait] = alpha
+        if beta is not None: self.beta[trait] = beta
+        if delta is not None: self.delta[trait] = delta
+
+    def get_state(self, trait=0):
+        return self.alpha[trait].copy(), self.beta[trait].copy(), self.delta[trait].copy()
+
+    def set_residual(self, r, trait=0):
+        self.r[trait] = np.asarray(r, dtype=np.float64)
+
+    def get_residual(self, trait=0):
+        return self.r[trait].copy()
+
+    def sub_xalpha(self, trait=0):
+        self.r[trait] -= self.X @ self.alpha[trait]
+
+    def mul_alpha(self, trait=0):
+        return self.X @ self.alpha[trait]
+
+    def sweep(self, *, iteration, seed, vare, var_effect, pi=0.0, pi_classes=None, gamma=O.GAMMA, log_prior_states=None,
+              var_effect_vec=None, pi_vec=None, pi_matrix=None, nreps=1, marker_offset=0, **_):
+        t = self.ntraits
+        a_before = self.alpha.copy()
+        if self.method in (BAYESC, BAYESB):
+            if np.ndim(pi) == 1:
+                pi_vec = pi
+            pv = pi_vec if pi_vec is not None else float(pi)
+            ve = var_effect_vec if self.method == BAYESB else float(np.asarray(var_effect).reshape(-1)[0])
+            O.bayesabc_sweep64(self.X, self._xpx, self.r[0], self.alpha[0], self.beta[0], self.delta[0],
+                               float(np.asarray(vare).reshape(-1)[0]), ve, pv, seed, iteration, marker0=marker_offset,
+                               block_size=0 if nreps == 1 else self.block_size, nreps=nreps)
+        elif self.method == BAYESR:
+            assert nreps == 1
+            pc = pi_matrix if pi_matrix is not None else pi_classes
+            O.bayesr_sweep64(self.X, self._xpx, self.r[0], self.alpha[0], self.delta[0], float(np.asarray(vare).reshape(-1)[0]),
+                             float(np.asarray(var_effect).reshape(-1)[0]), pc, seed, iteration, gamma=gamma, marker0=marker_offset)
+        else:
+            assert nreps == 1
+            O.mt1_sweep64(self.X, self._xpx, self.r, self.alpha, self.beta, self.delta, np.asarray(vare, dtype=np.float64).reshape(t, t),
+                          np.asarray(var_effect, dtype=np.float64).reshape(t, t), log_prior_states, seed, iteration, marker0=marker_offset)
+        out = {"alpha_ss": self.alpha @ self.alpha.T, "beta_ss": self.beta @ self.beta.T, "resid_ss": self.r @ self.r.T,
+               "resid_sum": self.r.sum(axis=1), "n_events": float(np.any(a_before != self.alpha, axis=0).sum()), "sweep_ms": 0.0,
+               "class_counts": np.zeros(4), "bayesr_ssq": 0.0, "bayesr_nnz": 0.0, "sum_delta": np.zeros(t), "state_counts": np.zeros(1 << t)}
+        if self.method == BAYESR:
+            d = self.delta[0]
+            out["class_counts"] = np.array([(d == k + 1).sum() for k in range(4)], dtype=np.float64)
+            nz = d > 1
+            out["bayesr_ssq"] = float((self.alpha[0][nz] ** 2 / np.asarray(gamma)[d[nz] - 1]).sum())
+            out["bayesr_nnz"] = float(nz.sum())
+        else:
+            out["sum_delta"] = self.delta.sum(axis=1)
+            state = np.zeros(self.p, dtype=np.int64)
+            for k in range(t):
+                state |= (self.delta[k] != 0).astype(np.int64) << k
+            out["state_counts"] = np.bincount(state, minlength=1 << t).astype(np.float64)
+        return out
+
+    def accumulate(self, nsamples):
+        k = float(nsamples)
+        d = (self.delta > 1).astype(np.float64) if self.method == BAYESR else self.delta
+        self.mean_a += (self.alpha - self.mean_a) / k
+        self.mean_a2 += (self.alpha ** 2 - self.mean_a2) / k
+        self.mean_d += (d - self.mean_d) / k
+
+    def posterior(self, trait=0):
+        return self.mean_a[trait].copy(), self.mean_a2[trait].copy(), self.mean_d[trait].copy()

@@ -41,8 +41,9 @@ def test_get_genotypes_maf_filter_and_errors(tmp_path):
     assert g.nMarkers == 2 and g.markerID == ["2", "3"]
     with pytest.raises(ValueError, match="storage must be"):
         api.get_genotypes(X, 1.0, storage="disk")
-    with pytest.raises(NotImplementedError, match="Float32"):
-        api.get_genotypes(X, 1.0, double_precision=True)
+    g64 = api.get_genotypes(X, 1.0, double_precision=True)                              # readgenotypes.jl:298: Float64 on request
+    assert g64.genotypes.dtype == np.float64 and g.genotypes.dtype == np.float32
+    np.testing.assert_allclose(g64.genotypes, g.genotypes, atol=1e-6)
     with pytest.raises(NotImplementedError, match="GBLUP"):
         api.get_genotypes(X, 1.0, method="GBLUP")
     with pytest.raises(ValueError, match="starting values"):
@@ -736,3 +737,35 @@ def test_fast_blocks_above_the_device_limit_is_an_explicit_error(tmp_path):
     model = api.build_model("y1 = intercept + geno")
     with pytest.raises(NotImplementedError, match="at most 1024 markers"):
         api.runMCMC(model, ph, chain_length=4000, fast_blocks=1200, output_folder=str(tmp_path / "x"), _engine=OracleEngine("block"))
+
+
+def test_runmcmc_double_precision_host_loop(tmp_path):
+    """runMCMC(double_precision=true) (JWAS.jl:349-366): genotypes, residual, effects and variances stay Float64 through the
+    host loop (here on the Float64 CPU oracle engine); single- and two-trait chains run and recover the signal; combinations
+    the Float64 device context does not run are explicit errors."""
+    from oracle_engine import OracleEngine64
+    d = make_dataset(n=220, p=260, ncausal=5, seed=8, center=False)
+    ids = [str(i) for i in range(220)]
+    gdf = pd.DataFrame(d["raw"]); gdf.insert(0, "ID", ids)
+    rng = np.random.default_rng(1)
+    ph = pd.DataFrame({"ID": ids, "y1": d["y"], "y2": 0.6 * d["y"] + 0.8 * rng.standard_normal(220)})
+    geno = api.get_genotypes(gdf, method="BayesC", Pi=0.9, double_precision=True)
+    assert geno.genotypes.dtype == np.float64
+    model = api.build_model("y1 = intercept + geno")
+    out = api.runMCMC(model, ph, chain_length=80, burnin=10, seed=2, double_precision=True, output_folder=str(tmp_path / "st"),
+                      _engine=OracleEngine64())
+    assert out["marker effects geno"]["Estimate"].dtype == np.float64
+    assert np.corrcoef(out["EBV_y1"]["EBV"], ph["y1"])[0, 1] > 0.5
+    geno = api.get_genotypes(gdf, np.eye(2) * 0.5, method="BayesC", double_precision=True)      # (build_model resolves `geno` by name)
+    model2 = api.build_model("y1 = intercept + geno\ny2 = intercept + geno", np.eye(2))
+    out2 = api.runMCMC(model2, ph, chain_length=60, burnin=10, seed=2, double_precision=True, output_folder=str(tmp_path / "mt"),
+                       _engine=OracleEngine64())
+    assert np.isfinite(out2["residual variance"]["Estimate"]).all()
+    with pytest.raises(NotImplementedError, match="double_precision=true"):
+        api.runMCMC(model, ph, chain_length=10, double_precision=True, fast_blocks=50, output_folder=str(tmp_path / "e1"), _engine=OracleEngine64())
+    ph_w = ph.assign(weights=1.0 + rng.uniform(0, 1, 220))
+    with pytest.raises(NotImplementedError, match="double_precision=true"):
+        api.runMCMC(model, ph_w, chain_length=10, double_precision=True, heterogeneous_residuals=True, output_folder=str(tmp_path / "e2"),
+                    _engine=OracleEngine64())
+    with pytest.raises(NotImplementedError, match="runMCMC\\(double_precision=true\\)"):
+        api.runMCMC(model, ph, chain_length=10, output_folder=str(tmp_path / "e3"), _engine=OracleEngine64())      # Float64 genotypes, Float32 run

@@ -488,3 +488,35 @@ def test_per_marker_covariance_oracle_reduces_to_the_shared_one():
                 assert all(np.array_equal(x, y) for x, y in zip(a, b)), form
             else:
                 assert np.array_equal(a, b), form
+
+
+@pytest.mark.parametrize("method", ["BayesC", "BayesR", "MTBayesC"])
+def test_float64_oracle_tracks_the_float32_oracle(method):
+    """The Float64 restatement (oracle/jwas_oracle_f64.c: the reference's kernels with T = Float64, runMCMC(double_precision=
+    true)) and the Float32 oracle use the same counter RNG: on a small well-conditioned problem their chains make the same
+    inclusion / class decisions and the effects agree to Float32 rounding -- the Float64 oracle is pinned to the pinned one."""
+    from oracle_engine import OracleEngine, OracleEngine64
+    d = make_dataset(n=260, p=420, ncausal=6, seed=12)
+    y = d["y"] - d["y"].mean()
+    t = 2 if method == "MTBayesC" else 1
+    rng = np.random.default_rng(1)
+    if method == "BayesC":
+        kw = dict(vare=0.5, var_effect=0.004, pi=0.9)
+    elif method == "BayesR":
+        kw = dict(vare=0.5, var_effect=0.05, pi_classes=np.array([0.9, 0.05, 0.03, 0.02]))
+    else:
+        kw = dict(vare=np.array([[0.6, 0.1], [0.1, 0.5]]), var_effect=np.array([[0.004, 0.001], [0.001, 0.003]]),
+                  log_prior_states=np.log(np.array([0.7, 0.1, 0.1, 0.1])))
+    res = {}
+    for tag, e, dt in (("f32", OracleEngine("dense"), np.float32), ("f64", OracleEngine64(), np.float64)):
+        e.load_dense(d["X"].astype(dt)); e.setup_blocks(64); e.init_state(method, t)
+        for k in range(t):
+            e.set_residual(((1 + 0.2 * k) * y).astype(dt), k)
+            e.set_state(k, delta=np.ones(e.p, dtype=np.int32 if method == "BayesR" else dt))
+        kws = {k_: (np.asarray(v, dtype=dt) if k_ in ("vare", "var_effect") else v) for k_, v in kw.items()}
+        for it in range(1, 16):
+            e.sweep(iteration=it, seed=5, **kws)
+        res[tag] = [e.get_state(k) for k in range(t)]
+    for k in range(t):
+        assert np.array_equal(res["f32"][k][2], res["f64"][k][2])
+        np.testing.assert_allclose(res["f32"][k][0], res["f64"][k][0], atol=5e-6)

@@ -68,11 +68,13 @@ def test_invalid_covariance_matrix():
         api.build_model("y1 = intercept\ny2 = intercept", np.array([[1.0, 2.0], [2.0, 1.0]]))
 
 
-def test_single_precision_default_and_double_refused():
+def test_single_precision_default_and_double_on_request():
+    """test/runtests.jl: genotypes are Float32 unless double_precision=true asks for Float64 (readgenotypes.jl:298)."""
     geno = api.get_genotypes(GENO, 1.0, separator=",", double_precision=False)
     assert np.asarray(geno.genotypes).dtype == np.float32
-    with pytest.raises(NotImplementedError, match="Float32"):
-        api.get_genotypes(GENO, 1.0, separator=",", double_precision=True)
+    geno64 = api.get_genotypes(GENO, 1.0, separator=",", double_precision=True)
+    assert np.asarray(geno64.genotypes).dtype == np.float64
+    np.testing.assert_allclose(geno64.genotypes, geno.genotypes, atol=1e-6)
 
 
 # ---- "Input Validation" (test/unit/test_input_validation.jl:9-40) ---------------------------------------------
