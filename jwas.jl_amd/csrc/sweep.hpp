@@ -1636,12 +1636,74 @@ struct PriorMem {
         l1 = lpr[(s0 | (1u << k)) * ls];
     }
 };
-// Gibbs sampler I (MTBayesABC.jl:85-120)
-template <int NT, class LP>
+// ---- Rule L (sampler I): the LINEAR FORM of a marker that is in the model for every trait and stays there.
+// With every delta = 1 before and after, the marker's NT conditionals are one small triangular system:
+//     beta_k = 1/C11_k * ( sum_m Rinv[m][k] w_m - sum_{m<k} C12[k][m] beta_m - sum_{m>k} C12[k][m] beta_old_m ) + z_k sqrt(1/C11_k)
+// i.e.  beta = A w + c  with A (NT x NT) and c (NT) functions of the marker's constants, its old beta and its draws only --
+// NOT of the running rhs.  The dense walk (every marker in the model: the reference's default all-ones prior) precomputes
+// A, c for all 64 markers of a section in parallel and is left with NT^2 fused multiply-adds per marker on the serial
+// chain instead of the ~26 dependent operations of the conditional-by-conditional order (430 -> ~110 cycles per 3-trait
+// marker).  So that every path (dense walk, speculative rounds, the oracle) produces the SAME numbers, the rule is part
+// of the sampler's definition: whenever the exact evaluation (below, the reference's operation order) says that a marker
+// which entered with every delta = 1 leaves with every delta = 1, its new effects are the linear form's
+//     beta_k = fmaf(A[k][NT-1], w[NT-1], ... fmaf(A[k][0], w[0], c[k]))      (A, c: double recurrence, rounded to float)
+// -- the same conditional means and the same draws, another association: <= a few ulp from the reference's order.  Every
+// other marker keeps the exact order's values.  The oracle applies the same rule (orc mt1_update; the literal order stays
+// available there: orc_set_mt_linear_form(0), compared in tests/test_oracle_kat.py).
+template <int NT>
+__device__ __forceinline__ void mt1_linear_coeffs(const MtConsts<NT>& K, const MtPre<NT>& Q, float dj, const float (&b_old)[NT],
+                                                  const double (&z)[NT], float (&A)[NT][NT], float (&cc)[NT])
+{
+    double Ad[NT][NT], cd[NT];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+        const double il = (double)Q.invLhs1[k];
+        double C12[NT];
+#pragma unroll
+        for (int m = 0; m < NT; ++m) C12[m] = (double)(K.Ginv[k][m] + (dj * 1.f) * K.Rinv[k][m]);       // MTBayesABC.jl:90 with delta_m = 1
+#pragma unroll
+        for (int m = 0; m < NT; ++m) {
+            double acc = (double)K.Rinv[m][k];
+#pragma unroll
+            for (int j = 0; j < k; ++j) acc = acc - C12[j] * Ad[j][m];
+            Ad[k][m] = il * acc;
+        }
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < k; ++j) acc = acc - C12[j] * cd[j];
+#pragma unroll
+        for (int j = k + 1; j < NT; ++j) acc = acc - C12[j] * (double)b_old[j];
+        cd[k] = il * acc + z[k] * (double)Q.s1[k];
+    }
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+        cc[k] = (float)cd[k];
+#pragma unroll
+        for (int m = 0; m < NT; ++m) A[k][m] = (float)Ad[k][m];
+    }
+}
+template <int NT>
+__device__ __forceinline__ void mt1_linear_beta(const float (&A)[NT][NT], const float (&cc)[NT], const float (&w)[NT], float (&b)[NT])
+{
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+        float v = cc[k];
+#pragma unroll
+        for (int m = 0; m < NT; ++m) v = fmaf(A[k][m], w[m], v);
+        b[k] = v;
+    }
+}
+
+// Gibbs sampler I (MTBayesABC.jl:85-120); LIN: apply Rule L to the result (off only where the result's VALUES are not kept).
+template <int NT, bool LIN = true, class LP>
 __device__ __forceinline__ void mt1_eval(const MtConsts<NT>& K, const MtPre<NT>& Q, const LP& lp, const float (&w)[NT], float dj,
                                          const double (&thr)[NT], const double (&z)[NT],
                                          float (&an)[NT], float (&bn)[NT], float (&dn)[NT], float (&Dl)[NT])
 {
+    float a_in[NT], b_in[NT];
+    bool all1 = LIN;
+#pragma unroll
+    for (int k = 0; k < NT; ++k) { a_in[k] = an[k]; b_in[k] = bn[k]; all1 = all1 && (dn[k] == 1.f); }
 #pragma unroll
     for (int k = 0; k < NT; ++k) {                                                  // :85
         const float Ginv11 = K.Ginv[k][k];
@@ -1677,6 +1739,17 @@ __device__ __forceinline__ void mt1_eval(const MtConsts<NT>& K, const MtPre<NT>&
             dn[k] = 0.f;
             Dl[k] = an[k];
             an[k] = 0.f;
+        }
+    }
+    if constexpr (LIN) {
+#pragma unroll
+        for (int k = 0; k < NT; ++k) all1 = all1 && (dn[k] == 1.f);
+        if (all1) {                                                                 // Rule L
+            float A[NT][NT], cc[NT];
+            mt1_linear_coeffs<NT>(K, Q, dj, b_in, z, A, cc);
+            mt1_linear_beta<NT>(A, cc, w, bn);
+#pragma unroll
+            for (int k = 0; k < NT; ++k) { an[k] = bn[k]; Dl[k] = a_in[k] - bn[k]; }
         }
     }
 }
@@ -2254,7 +2327,7 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
             float an[NT], bn[NT], dn[NT], Dl[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) { an[t] = a0[q][t]; bn[t] = b0[q][t]; dn[t] = d0[q][t]; Dl[t] = 0.f; }
-            if constexpr (is_sampler1(METHOD)) mt1_eval<NT>(Kc, Q0, PriorMem{lpr_of(c), ls}, w0[q], dj, thr0[q], z0[q], an, bn, dn, Dl);
+            if constexpr (is_sampler1(METHOD)) mt1_eval<NT, false>(Kc, Q0, PriorMem{lpr_of(c), ls}, w0[q], dj, thr0[q], z0[q], an, bn, dn, Dl);
             else if constexpr (kTab) {
                 double T[kTS][kTV];
                 mt2_load_tab<NT>(A.mt2_tab, p, j0 + c, T);
@@ -2325,13 +2398,12 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
     // result is final at its own step: it keeps the w it was evaluated with and recomputes its update after the walk.
     bool dense_done = false;
     // Sampler I, every marker of the block in the model for every trait at entry (the reference's default prior keeps it
-    // that way: the states with a trait missing have probability ~0): the walk SPECULATES that every delta stays 1.  Then a
-    // marker's three conditionals need neither the two log-weights nor the prior lookup -- what is left of mt1_eval (same
-    // operations, same order) is  wR - C12'beta -> * 1/C11 -> + z*sqrt(1/C11) (fp64) -> alpha_old - alpha_new,  a
-    // dependent chain of ~26 operations per three-trait marker instead of ~100.  After a 64-marker section ONE full
-    // mt1_eval per lane (all 64 markers at once, each with the w it was walked with) both verifies the speculation and
-    // yields the final state; if any marker left the model for a trait the section is walked again the general way from
-    // its saved rhs (same results, by construction: the speculative numbers are only kept when they are the exact ones).
+    // that way: the states with a trait missing have probability ~0): the walk SPECULATES that every delta stays 1 and
+    // evaluates a marker with Rule L's linear form (mt1_linear_coeffs: A, c of all 64 markers of a section formed in
+    // parallel, NT^2 fused multiply-adds per marker on the chain).  After a 64-marker section ONE full mt1_eval per lane
+    // (all 64 markers at once, each with the w it was walked with) both verifies the speculation and yields the final
+    // state -- by Rule L the linear form's own numbers whenever the speculation held; if any marker left the model for a
+    // trait the section is walked again from its saved rhs with those markers evaluated the general way.
     if (METHOD != kMTBayesC2 && nreps == 1 && prestage && nstaged_mt == b && 5 * ncand_all >= 3 * b) {
         const float* rows = reinterpret_cast<const float*>(smem + SM.rows_off);
         float rhsq[NT][2], aq[NT][2], bq[NT][2], dq[NT][2], djq[2], wev[2][NT];
@@ -2367,45 +2439,34 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
             if constexpr (is_sampler1(METHOD)) mt1_eval<NT>(KQ(q), Qq[q], PriorMem{lpr_of(c), ls}, w, djq[q], thr, z, an, bn, dn, Dl);
             else mega_eval<NT>(K, Qq[q], w, djq[q], thr, z, an, bn, dn, Dl);
         };
-        // the speculative conditionals: in bn = the marker's beta at block entry, out the new ones; Dl = alpha_old - alpha_new
-        auto eval_fast = [&](int q, const float (&w)[NT], const float (&C12)[NT][NT], const double (&zs1)[NT], float (&bn)[NT], float (&Dl)[NT]) {
+        // the speculative conditionals = Rule L's linear form (mt1_linear_coeffs): A, c of the lane's own marker are formed once
+        // per section; a step is NT^2 fused multiply-adds.  Dl = alpha_old - alpha_new
+        auto eval_fast = [&](int q, const float (&w)[NT], const float (&Al)[NT][NT], const float (&cl)[NT], float (&bn)[NT], float (&Dl)[NT]) {
+            mt1_linear_beta<NT>(Al, cl, w, bn);
 #pragma unroll
-            for (int k = 0; k < NT; ++k) {
-                float c12b = 0.f, wR = 0.f;
+            for (int k = 0; k < NT; ++k) Dl[k] = aq[k][q] - bn[k];
+        };
+        auto linear_of = [&](int q, float (&Al)[NT][NT], float (&cl)[NT]) {
+            float b_old[NT];
+            double zz[NT];
 #pragma unroll
-                for (int m = 0; m < NT; ++m) {
-                    wR = wR + w[m] * K.Rinv[m][k];
-                    if (m == k) continue;
-                    c12b = c12b + C12[k][m] * bn[m];
-                }
-                const float rhs1 = wR - c12b;                                                       // :96
-                const float gHat1 = rhs1 * Qq[q].invLhs1[k];
-                bn[k] = (float)((double)gHat1 + zs1[k]);                                            // :109
-                Dl[k] = aq[k][q] - bn[k];
-            }
+            for (int t = 0; t < NT; ++t) { b_old[t] = bq[t][q]; zz[t] = zq[t][q]; }
+            mt1_linear_coeffs<NT>(KQ(q), Qq[q], djq[q], b_old, zz, Al, cl);
         };
         // 64-marker section q: eight steps per batch without a branch, the Gram rows read a batch ahead
         auto section = [&](auto qc, auto fastc, const float* grow, int nsteps) {
             constexpr int Q = decltype(qc)::value;
             constexpr bool FAST = decltype(fastc)::value;
-            float C12[NT][NT], da[NT];
-            double zs1[NT];
+            float Al[NT][NT], cl[NT], da[NT];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                da[t] = djq[Q] * aq[t][Q];                                                          // :82
-                zs1[t] = zq[t][Q] * (double)Qq[Q].s1[t];
-#pragma unroll
-                for (int m = 0; m < NT; ++m) C12[t][m] = KQ(Q).Ginv[t][m] + (djq[Q] * 1.f) * K.Rinv[t][m];      // :90 with delta_m = 1
-            }
+            for (int t = 0; t < NT; ++t) da[t] = djq[Q] * aq[t][Q];                                 // :82
+            if constexpr (FAST) linear_of(Q, Al, cl);
             auto step = [&](int l, float c0, float c1) {
                 float w[NT], an[NT], bn[NT], dn[NT], Dl[NT];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) w[t] = rhsq[t][Q] + da[t];
-                if constexpr (FAST) {
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) bn[t] = bq[t][Q];
-                    eval_fast(Q, w, C12, zs1, bn, Dl);
-                } else eval_own(Q, w, an, bn, dn, Dl);
+                if constexpr (FAST) eval_fast(Q, w, Al, cl, bn, Dl);
+                else eval_own(Q, w, an, bn, dn, Dl);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     wev[Q][t] = (lane == l) ? w[t] : wev[Q][t];      // lane l: what it was evaluated with
@@ -2442,15 +2503,10 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
         // step per loop trip (used when the speculation missed, or when a marker is not in the model for every trait at entry)
         auto section_mixed = [&](auto qc, const float* grow, int nsteps, unsigned long long slow) {
             constexpr int Q = decltype(qc)::value;
-            float C12[NT][NT], da[NT];
-            double zs1[NT];
+            float Al[NT][NT], cl[NT], da[NT];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                da[t] = djq[Q] * aq[t][Q];
-                zs1[t] = zq[t][Q] * (double)Qq[Q].s1[t];
-#pragma unroll
-                for (int m = 0; m < NT; ++m) C12[t][m] = KQ(Q).Ginv[t][m] + (djq[Q] * 1.f) * K.Rinv[t][m];
-            }
+            for (int t = 0; t < NT; ++t) da[t] = djq[Q] * aq[t][Q];
+            linear_of(Q, Al, cl);
             float g0 = (Q == 0) ? grow[lane] : 0.f;
             float g1 = (B > 64) ? grow[64 + lane] : 0.f;
 #pragma unroll 1
@@ -2459,11 +2515,7 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
 #pragma unroll
                 for (int t = 0; t < NT; ++t) w[t] = rhsq[t][Q] + da[t];
                 if ((slow >> l) & 1ull) eval_own(Q, w, an, bn, dn, Dl);                               // (wave-uniform)
-                else {
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) bn[t] = bq[t][Q];
-                    eval_fast(Q, w, C12, zs1, bn, Dl);
-                }
+                else eval_fast(Q, w, Al, cl, bn, Dl);
                 const float c0 = g0, c1 = g1;
                 grow += B;                                           // next marker's row (one past the block: the overflow row)
                 if (Q == 0) g0 = grow[lane];

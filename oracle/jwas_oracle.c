@@ -534,14 +534,52 @@ static inline const float* marker_ginv(int64_t j, int t, const float* Ginv_all, 
     return tmp;
 }
 
+/* Rule L (the device's sampler-I definition, csrc/sweep.hpp): a marker that enters with every delta = 1 and -- by the exact
+ * evaluation below, the reference's operation order -- leaves with every delta = 1 takes its new effects from the LINEAR
+ * FORM of its t conditionals,  beta = A w + c  (A, c from the marker's constants, its old beta and its draws by the double
+ * recurrence below, rounded to float; beta_k = fmaf(A[k][t-1], w[t-1], ... fmaf(A[k][0], w[0], c[k]))): the same
+ * conditional means and draws in another association, a few ulp from the literal order.  orc_set_mt_linear_form(0)
+ * switches the rule off (the literal restatement; tests/test_oracle_kat.py compares the two). */
+static int g_mt_linear = 1;
+void orc_set_mt_linear_form(int on) { g_mt_linear = on; }
+
+static inline void mt1_linear(int t, const float* w, float d, const float* Rinv, const float* Ginv, const float* b_old,
+                              const double* z, float* b_new)
+{
+    double Ad[ORC_MAXT][ORC_MAXT], cd[ORC_MAXT];
+    for (int k = 0; k < t; ++k) {
+        const float C11 = Ginv[k * t + k] + Rinv[k * t + k] * d;                 /* :89 */
+        const float invLhs1 = 1.0f / C11;                                        /* :95 */
+        const double il = (double)invLhs1;
+        double C12[ORC_MAXT];
+        for (int m = 0; m < t; ++m) C12[m] = (double)(Ginv[k * t + m] + (d * 1.0f) * Rinv[k * t + m]);      /* :90, delta_m = 1 */
+        for (int m = 0; m < t; ++m) {
+            double acc = (double)Rinv[m * t + k];
+            for (int j = 0; j < k; ++j) acc = acc - C12[j] * Ad[j][m];
+            Ad[k][m] = il * acc;
+        }
+        double acc = 0.0;
+        for (int j = 0; j < k; ++j) acc = acc - C12[j] * cd[j];
+        for (int j = k + 1; j < t; ++j) acc = acc - C12[j] * (double)b_old[j];
+        cd[k] = il * acc + z[k] * (double)sqrtf(invLhs1);
+    }
+    for (int k = 0; k < t; ++k) {
+        float v = (float)cd[k];
+        for (int m = 0; m < t; ++m) v = fmaf((float)Ad[k][m], w[m], v);
+        b_new[k] = v;
+    }
+}
+
 /* One marker.  w[k] = x'r_k + d*alpha_old_k already formed.  Writes axpy coefficients a[k]. */
 static inline void mt1_update(int t, const float* w, float d, float* alpha, float* beta, float* delta,
                               int64_t stride, const float* Rinv, const float* Ginv,
                               const double* log_prior, uint64_t seed, uint32_t marker, uint32_t iter,
                               uint32_t rep, float* a_out)
 {
-    float b[ORC_MAXT], dl[ORC_MAXT];
-    for (int k = 0; k < t; ++k) { b[k] = beta[k * stride]; dl[k] = delta[k * stride]; }
+    float b[ORC_MAXT], dl[ORC_MAXT], b_in[ORC_MAXT], a_in[ORC_MAXT];
+    double zz[ORC_MAXT];
+    int all1 = g_mt_linear;
+    for (int k = 0; k < t; ++k) { b[k] = beta[k * stride]; dl[k] = delta[k * stride]; b_in[k] = b[k]; a_in[k] = alpha[k * stride]; all1 = all1 && (dl[k] == 1.0f); }
     for (int k = 0; k < t; ++k) {                                                /* :85 */
         const float a_old = alpha[k * stride];
         const float Ginv11 = Ginv[k * t + k];                                    /* :86 */
@@ -573,6 +611,7 @@ static inline void mt1_update(int t, const float* w, float d, float* alpha, floa
         const double probDelta1 = 1.0 / (1.0 + exp(logDelta0 - logDelta1));      /* :107 */
         const double u = orc_uniform(seed, marker, iter, rep, (uint32_t)k);
         const double z = orc_normal(seed, marker, iter, rep, (uint32_t)k);
+        zz[k] = z;
         if (u < probDelta1) {                                                    /* :108-111 */
             dl[k] = 1.0f;
             b[k] = (float)((double)gHat1 + z * (double)sqrtf(invLhs1));
@@ -584,6 +623,11 @@ static inline void mt1_update(int t, const float* w, float d, float* alpha, floa
             alpha[k * stride] = 0.0f;
             a_out[k] = a_old;
         }
+    }
+    for (int k = 0; k < t; ++k) all1 = all1 && (dl[k] == 1.0f);
+    if (all1) {                                                                  /* Rule L */
+        mt1_linear(t, w, d, Rinv, Ginv, b_in, zz, b);
+        for (int k = 0; k < t; ++k) { alpha[k * stride] = b[k]; a_out[k] = a_in[k] - b[k]; }
     }
     for (int k = 0; k < t; ++k) { beta[k * stride] = b[k]; delta[k * stride] = dl[k]; }
 }

@@ -520,3 +520,42 @@ def test_float64_oracle_tracks_the_float32_oracle(method):
     for k in range(t):
         assert np.array_equal(res["f32"][k][2], res["f64"][k][2])
         np.testing.assert_allclose(res["f32"][k][0], res["f64"][k][0], atol=5e-6)
+
+
+def test_sampler1_linear_form_stays_within_a_few_ulp_of_the_literal_order():
+    """Rule L (csrc/sweep.hpp, oracle mt1_update): a marker that is and stays in the model for every trait takes its new
+    effects from the linear form beta = A w + c of its t conditionals instead of the conditional-by-conditional order --
+    the same conditional means and draws, another association.  With the rule switched off the oracle is the literal
+    restatement of _MTBayesABC_samplerI! (MTBayesABC.jl:85-120); both chains must make the same inclusion decisions and
+    their effects may differ only at Float32 rounding level."""
+    import oracle as O
+    from oracle_engine import OracleEngine
+    d = make_dataset(n=300, p=260, ncausal=6, seed=4)
+    y = d["y"] - d["y"].mean()
+    t = 3
+    rng = np.random.default_rng(2)
+    A = rng.standard_normal((t, t)); B = rng.standard_normal((t, t))
+    prior = np.full(1 << t, 1e-3); prior[-1] = 1.0; prior /= prior.sum()             # (nearly) every marker in the model
+    kw = dict(vare=((A @ A.T / t + np.eye(t)) * 0.5).astype(np.float32), var_effect=((B @ B.T / t + np.eye(t)) * 0.003).astype(np.float32),
+              log_prior_states=np.log(prior))
+    res = {}
+    try:
+        for on in (1, 0):
+            O.lib().orc_set_mt_linear_form(on)
+            e = OracleEngine("dense")
+            e.load_dense(d["X"]); e.setup_blocks(64); e.init_state("MTBayesC", t)
+            for k in range(t):
+                e.set_residual(((1 + 0.2 * k) * y).astype(np.float32), k)
+                e.set_state(k, delta=np.ones(e.p, dtype=np.float32))
+            for it in range(1, 9):
+                e.sweep(iteration=it, seed=3, **kw)
+            res[on] = [e.get_state(k) for k in range(t)]
+    finally:
+        O.lib().orc_set_mt_linear_form(1)
+    changed = 0
+    for k in range(t):
+        assert np.array_equal(res[1][k][2], res[0][k][2])
+        scale = np.abs(res[0][k][0]).max()
+        np.testing.assert_allclose(res[1][k][0], res[0][k][0], atol=2e-5 * scale)
+        changed += int((res[1][k][0] != res[0][k][0]).sum())
+    assert changed > 0                       # the rule did apply (the two orders round differently somewhere)
