@@ -1251,8 +1251,9 @@ static hipError_t launch_step_cx(jwas_hip_ctx* c, const CX& cx, const UpdateArgs
     UpdateArgsT<CX> U;
     static_cast<UpdateArgs&>(U) = U0;
     U.cx = cx;
-    const StepSmem SM(c->block_size, NT, is_mt_method(METHOD) ? mt_park_nd(c->block_size, NT) + (S.lpr_mat ? (1 << NT) : 0) : st_park_nd(METHOD), is_mt_method(METHOD) ? mt_park_nf(c->block_size, NT) + (METHOD == kMTBayesB1 ? NT * NT : 0) : st_park_nf(METHOD));
-    constexpr bool kHasDense = CX::kCoopApply && (METHOD == kBayesC || METHOD == kBayesB) && NT == 1;
+    constexpr bool kHasDense = (METHOD == kBayesC || METHOD == kBayesB) && NT == 1;       // sweeps under a uniform pi = 0 (Rule D)
+    const bool dn = kHasDense && dense;
+    const StepSmem SM(c->block_size, NT, is_mt_method(METHOD) ? mt_park_nd(c->block_size, NT) + (S.lpr_mat ? (1 << NT) : 0) : st_park_nd(METHOD), is_mt_method(METHOD) ? mt_park_nf(c->block_size, NT) + (METHOD == kMTBayesB1 ? NT * NT : 0) : st_park_nf(METHOD, dn));
     static unsigned long long attr_set = 0ull;       // one bit per device: the attribute belongs to the device's code object
     const unsigned long long dev_bit = 1ull << (c->device & 63);
     if (!(attr_set & dev_bit)) {   // allow > 64 KB of dynamic LDS
@@ -1265,9 +1266,14 @@ static hipError_t launch_step_cx(jwas_hip_ctx* c, const CX& cx, const UpdateArgs
             if (e != hipSuccess) return e;
         }
         if constexpr (kHasDense) {
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_block_step<METHOD, NT, CX, true, true>),
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_block_step<METHOD, NT, CX, false, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
+            if constexpr (CX::kCoopApply) {
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_block_step<METHOD, NT, CX, true, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) return e;
+            }
         }
         attr_set |= dev_bit;
     }
@@ -1280,22 +1286,26 @@ static hipError_t launch_step_cx(jwas_hip_ctx* c, const CX& cx, const UpdateArgs
 #endif
     const int nwork = c->nrg * U.ncg;
     const unsigned grid = (dbg == 2) ? 1u : (U.quiet_xcd ? (unsigned)(1 + (nwork + 6) / 7 * 8) : (unsigned)(1 + nwork));
+    const int ds = (dbg == 1) ? 0 : do_sample;
     if constexpr (kHasDense) {
-        if (dense && U.sync_now != nullptr) {   // every marker always included, 256- / 512-marker blocks: the sampler with dense_big_st
-            hipLaunchKernelGGL((k_block_step<METHOD, NT, CX, true, true>), dim3(grid), dim3(kStepThreads), SM.bytes, c->stream,
-                               U, S, (dbg == 1) ? 0 : do_sample);
+        if (dn) {       // uniform pi = 0: the sampler that follows Rule D (and takes dense_big_st on full 256- / 512-marker blocks)
+            if constexpr (CX::kCoopApply) {
+                if (U.sync_now != nullptr) {
+                    hipLaunchKernelGGL((k_block_step<METHOD, NT, CX, true, true>), dim3(grid), dim3(kStepThreads), SM.bytes, c->stream, U, S, ds);
+                    return hipSuccess;
+                }
+            }
+            hipLaunchKernelGGL((k_block_step<METHOD, NT, CX, false, true>), dim3(grid), dim3(kStepThreads), SM.bytes, c->stream, U, S, ds);
             return hipSuccess;
         }
     }
     if constexpr (CX::kCoopApply) {
         if (U.sync_now != nullptr) {     // dense sweep: the instantiation whose update role shares the apply work
-            hipLaunchKernelGGL((k_block_step<METHOD, NT, CX, true>), dim3(grid), dim3(kStepThreads), SM.bytes, c->stream,
-                               U, S, (dbg == 1) ? 0 : do_sample);
+            hipLaunchKernelGGL((k_block_step<METHOD, NT, CX, true>), dim3(grid), dim3(kStepThreads), SM.bytes, c->stream, U, S, ds);
             return hipSuccess;
         }
     }
-    hipLaunchKernelGGL((k_block_step<METHOD, NT, CX, false>), dim3(grid), dim3(kStepThreads), SM.bytes, c->stream,
-                       U, S, (dbg == 1) ? 0 : do_sample);
+    hipLaunchKernelGGL((k_block_step<METHOD, NT, CX, false>), dim3(grid), dim3(kStepThreads), SM.bytes, c->stream, U, S, ds);
     return hipSuccess;
 }
 
@@ -1334,35 +1344,48 @@ static int upload_vec(jwas_hip_ctx* c, void** dev, const void* host, size_t byte
 // snapshot (one pass over X), all blocks sampled concurrently, change lists compacted in (block, marker) order;
 // the caller's k_finish applies them to the residual.
 template <int METHOD, int NT, class CX>
-static hipError_t launch_indep_cx(jwas_hip_ctx* c, const CX& cx, const UpdateArgs& U0, const SamplerArgs& S, int64_t pstride)
+static hipError_t launch_indep_cx(jwas_hip_ctx* c, const CX& cx, const UpdateArgs& U0, const SamplerArgs& S, int64_t pstride, bool dense)
 {
     UpdateArgsT<CX> U;
     static_cast<UpdateArgs&>(U) = U0;
     U.cx = cx;
-    const StepSmem SM(c->block_size, NT, is_mt_method(METHOD) ? mt_park_nd(c->block_size, NT) + (S.lpr_mat ? (1 << NT) : 0) : st_park_nd(METHOD), is_mt_method(METHOD) ? mt_park_nf(c->block_size, NT) + (METHOD == kMTBayesB1 ? NT * NT : 0) : st_park_nf(METHOD));
+    constexpr bool kHasDense = (METHOD == kBayesC || METHOD == kBayesB) && NT == 1;       // sweeps under a uniform pi = 0 (Rule D)
+    const bool dn = kHasDense && dense;
+    const StepSmem SM(c->block_size, NT, is_mt_method(METHOD) ? mt_park_nd(c->block_size, NT) + (S.lpr_mat ? (1 << NT) : 0) : st_park_nd(METHOD), is_mt_method(METHOD) ? mt_park_nf(c->block_size, NT) + (METHOD == kMTBayesB1 ? NT * NT : 0) : st_park_nf(METHOD, dn));
     static unsigned long long attr_set = 0ull;       // one bit per device
     const unsigned long long dev_bit = 1ull << (c->device & 63);
     if (!(attr_set & dev_bit)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_indep_sample<METHOD, NT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
+        if constexpr (kHasDense) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_indep_sample<METHOD, NT, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+        }
         attr_set |= dev_bit;
     }
     const size_t red = sizeof(double) * kRowGroupSlices * kColChunk * NT;
     hipLaunchKernelGGL((k_indep_rhs<NT, CX>), dim3((unsigned)(U.nrg * U.ncg), (unsigned)c->nblocks), dim3(kStepThreads), red, c->stream,
                        U, c->p, c->block_size, pstride);
+    if constexpr (kHasDense) {
+        if (dn) {
+            hipLaunchKernelGGL((k_indep_sample<METHOD, NT, true>), dim3((unsigned)c->nblocks), dim3(kStepThreads), SM.bytes, c->stream, S, pstride, c->ev_all);
+            return hipGetLastError();
+        }
+    }
     hipLaunchKernelGGL((k_indep_sample<METHOD, NT>), dim3((unsigned)c->nblocks), dim3(kStepThreads), SM.bytes, c->stream,
                        S, pstride, c->ev_all);
     return hipGetLastError();
 }
 
 template <int METHOD, int NT>
-static hipError_t launch_indep(jwas_hip_ctx* c, const UpdateArgs& U, const SamplerArgs& S, int64_t pstride)
+static hipError_t launch_indep(jwas_hip_ctx* c, const UpdateArgs& U, const SamplerArgs& S, int64_t pstride, bool dense = false)
 {
-    return with_cols(c, 0, [&](auto cx) { return launch_indep_cx<METHOD, NT, decltype(cx)>(c, cx, U, S, pstride); });
+    return with_cols(c, 0, [&](auto cx) { return launch_indep_cx<METHOD, NT, decltype(cx)>(c, cx, U, S, pstride, dense); });
 }
 
-static int sweep_independent(jwas_hip_ctx* c, EventList* out)
+static int sweep_independent(jwas_hip_ctx* c, EventList* out, bool dense, int dense_big_off)
 {
     const int t = c->ntraits, bs = c->block_size;
     const int64_t nb = c->nblocks;
@@ -1396,10 +1419,11 @@ static int sweep_independent(jwas_hip_ctx* c, EventList* out)
     S.ginv_mat = c->method == JWAS_HIP_MTBAYESB1 ? c->ginv_mat : nullptr;
     S.alpha = c->alpha; S.beta = c->beta; S.delta = c->delta;
     S.counters = c->counters;
+    S.dense_big_off = dense_big_off;
     hipError_t e;
     switch (c->method) {
-        case JWAS_HIP_BAYESC: e = launch_indep<kBayesC, 1>(c, U, S, pstride); break;
-        case JWAS_HIP_BAYESB: e = launch_indep<kBayesB, 1>(c, U, S, pstride); break;
+        case JWAS_HIP_BAYESC: e = launch_indep<kBayesC, 1>(c, U, S, pstride, dense); break;
+        case JWAS_HIP_BAYESB: e = launch_indep<kBayesB, 1>(c, U, S, pstride, dense); break;
         case JWAS_HIP_BAYESR: e = launch_indep<kBayesR, 1>(c, U, S, pstride); break;
 #define JW_MT_IND(M)                                                              \
             if (t == 2) e = launch_indep<M, 2>(c, U, S, pstride);                 \
@@ -1710,8 +1734,13 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
     const bool independent = P->independent_blocks != 0;
     EventList ev_list{nullptr, nullptr, nullptr, 0};
     const float* r_last = c->r;
+    // A uniform prior pi = 0 (single-trait BayesA/B/C: RR-BLUP, BayesA, BayesL, the reference's own benchmark setting): the
+    // kernel instantiation whose sampler follows Rule D on every path and takes dense_big_st on full 256- / 512-marker blocks
+    // (sweep.hpp).  Every marker of every block changes, so the update role shares the apply work (COOP) unless told not to.
+    const bool dense_big = (c->method == JWAS_HIP_BAYESC || c->method == JWAS_HIP_BAYESB) && P->pi == 0.0 && P->pi_vec == nullptr;
+    const int dense_big_off = std::getenv("JWAS_HIP_DENSE_BIG_OFF") != nullptr ? 1 : 0;      // (tests: the same chain through the general path)
     if (independent) {
-        int rc = sweep_independent(c, &ev_list);
+        int rc = sweep_independent(c, &ev_list, dense_big, dense_big_off);
         if (rc) return rc;
     } else {
     // one-block lookahead pipeline (sweep.hpp): launch k = sampler(block k-1) || update/partial(block k)
@@ -1724,13 +1753,7 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
     // once per sweep (the tests switch it between sweeps of one process).
     const char* efc = std::getenv("JWAS_HIP_COOP_APPLY");
     const int fc = efc ? std::atoi(efc) : -1;
-    // Priors that include every marker whatever its rhs (Pi = 0 without per-marker pi: RR-BLUP, BayesA, the reference's own
-    // benchmark setting) on 256- / 512-marker blocks, single pass: the kernel whose sampler carries dense_big_st (sweep.hpp);
-    // it always runs with the cooperative apply (every marker of every block changes).
-    const bool dense_big = c->sync_cnt != nullptr && fc != 0 && (c->method == JWAS_HIP_BAYESC || c->method == JWAS_HIP_BAYESB) &&
-                           (bs == 256 || bs == 512) && c->starts.empty() && P->nreps == 1 && P->pi == 0.0 && P->pi_vec == nullptr &&
-                           std::getenv("JWAS_HIP_DENSE_BIG_OFF") == nullptr;
-    const bool coop = c->sync_cnt != nullptr && (dense_big || (fc >= 0 ? fc != 0 : c->last_events > 0.25 * (double)c->p));
+    const bool coop = c->sync_cnt != nullptr && (fc >= 0 ? fc != 0 : (dense_big || c->last_events > 0.25 * (double)c->p));
     for (int64_t k = 0; k <= nb; ++k) {
         UpdateArgs U;
         U.r_in = c->r + ((k + 1) & 1) * rstride; U.r_out = c->r + (k & 1) * rstride;
@@ -1770,6 +1793,7 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
             S.cross_next = c->cross + (sb + 1 < nb ? sb + 1 : sb) * (int64_t)bs * bs;
             S.gram_next = (sb + 1 < nb) ? c->gram + (sb + 1) * (int64_t)bs * bs : nullptr;
             S.cross_after = (sb + 2 < nb) ? c->cross + (sb + 2) * (int64_t)bs * bs : nullptr;
+            S.dense_big_off = dense_big_off;
             S.lines_after = (sb + 2 < nb) ? (int)(((int64_t)blk_b(c, sb + 1) * blk_b(c, sb + 2) + 31) / 32) : 0;
             S.corr_in = c->corr + (sb & 1) * (size_t)kMaxT * bs;
             S.corr_out = c->corr + ((sb + 1) & 1) * (size_t)kMaxT * bs;

@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256) void k_finish(CX cx, const float* r_in,
 // sampler wave only loads them.  (Within-block repetitions > 0 recompute them in place.)
 // ---------------------------------------------------------------------------------------------
 constexpr int kPrepD = 17;
-constexpr int kPrepF = 5;
+constexpr int kPrepF = 7;          // (rows 5, 6: Rule D's c1, c0 -- sweeps with a uniform pi = 0 only)
 
 // Floats as ordered integers (the bisections below walk the float number line).
 __device__ __forceinline__ uint32_t float_key(float f)
@@ -373,6 +373,19 @@ struct AbcMarker {
         zs  = z * (double)sqrtf(invLhs);
         thr = log((1.0 - u) / u);
         beta_excl = (float)(z * (double)sqrtf(var_));       // :54
+    }
+    // RULE D (single-trait BayesA/B/C under a uniform prior pi = 0: RR-BLUP, BayesA, BayesL, the reference's own benchmark
+    // setting): every marker is included whatever its rhs, so the scalar kernel's chain rhs -> gHat -> alpha (:36,:39,:46)
+    // is one affine map of the block rhs x.  Its two coefficients depend on the marker, its old effect and its draw only,
+    //     c1 = fl32( fl64(1/vare) * fl64(1/lhs) ),   c0 = fl32( fl64(1/vare) * fl64(1/lhs) * (fl64(d) * fl64(alpha_old)) + z sqrt(1/lhs) ),
+    // and the new effect is  alpha = fmaf(c1, x, c0)  -- the same conditional mean and draw in one rounding instead of
+    // four: the serial chain of a dense block is fma -> subtract -> broadcast -> fma per marker (~45 cycles instead of
+    // ~100).  Part of the sampler's definition for such sweeps on every path; the oracle applies it too (orc abc_update).
+    __device__ __forceinline__ void rule_d(float a_old, float ie, float& c1D, float& c0D) const
+    {
+        const double k1 = (double)ie * (double)invLhs;
+        c1D = (float)k1;
+        c0D = (float)(k1 * ((double)d * (double)a_old) + zs);
     }
     __device__ __forceinline__ void store(double* pd, float* pf, int64_t p, int64_t j) const
     {
@@ -745,6 +758,11 @@ __global__ __launch_bounds__(256) void k_prepare(const DevParams* __restrict__ P
             float lo, hi;
             am.thresholds(alpha[j], ie, lo, hi);             // alpha at the start of the sweep = alpha_old of repetition 0
             prep_f[3 * p + j] = lo; prep_f[4 * p + j] = hi;
+            if (P->pi == 0.0 && P->pi_vec == nullptr) {      // Rule D (uniform pi = 0)
+                float c1D, c0D;
+                am.rule_d(alpha[j], ie, c1D, c0D);
+                prep_f[5 * p + j] = c1D; prep_f[6 * p + j] = c0D;
+            }
         }
     }
 }

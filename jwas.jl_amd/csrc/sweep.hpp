@@ -152,16 +152,23 @@ __device__ __forceinline__ void update_role(char* smem, int rg, int g,
     if constexpr (COOP && CX::kCoopApply) {
         const int R = (kSliceRows + ncg - 1) / ncg;
         if (sync_now != nullptr && r_out != nullptr && ne >= 32 && ncg >= 4 && R <= 64) {
-            const int rloc = g * R + lane;                                // row of the slice
-            const bool mine = active && lane < R && rloc < kSliceRows;
-            const int64_t grow = (int64_t)(active ? slice : 0) * kSliceRows + (mine ? rloc : 0);
+            // Rows of this group: [g*R, (g+1)*R) of every slice of the row group.  When R divides 64 (ncg = 8: R = 32) a wave
+            // takes the share of 64 / R slices at once, so that all 64 lanes carry a row: the phase is bound by instruction
+            // issue (one readlane + address + load and one readlane + fma per entry and row), and seven half-empty waves on
+            // four SIMDs cost twice what four full ones do.
+            const int pack = (64 % R == 0) ? 64 / R : 1;
+            const int sl_w = wave * pack + lane / R;                      // slice of the row group this lane works for
+            const int rloc = g * R + (pack > 1 ? lane % R : lane);        // row of the slice
+            const int slice_l = rg * spg + sl_w;
+            const bool mine = sl_w < spg && slice_l < nslices && (pack > 1 || lane < R) && rloc < kSliceRows;
+            const int64_t grow = (int64_t)(mine ? slice_l : 0) * kSliceRows + (mine ? rloc : 0);
             float rs[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) rs[t] = r_in[t * ld + grow];
             // 64 changes per chunk: lane l fetches entry e0 + l of the list (index and coefficients: coalesced), every
             // lane then loads its row of the 64 columns back to back (addresses from v_readlane: no scalar memory access,
             // no branch, one memory latency) and runs the chain in list order; entries past the end have coefficient 0 (an
-            // exact no-op on a valid column).  (128 per pass was measured: slower, and it spills with three traits.)
+            // exact no-op on a valid column).  (128 per pass, and two chunks in flight, were measured: not faster.)
             int iv_n; float dv_n[NT];
             auto load_list = [&](int e0) {
                 const int el = e0 + lane, ec = el < ne ? el : ne - 1;
@@ -169,6 +176,7 @@ __device__ __forceinline__ void update_role(char* smem, int rg, int g,
 #pragma unroll
                 for (int t = 0; t < NT; ++t) { const float d = ev->delta[t][ec]; dv_n[t] = (el < ne) ? d : 0.f; }
             };
+            if (wave * pack < spg) {                                      // (wave-uniform: the waves beyond the packed slices have no share)
             load_list(0);
             for (int e0 = 0; e0 < ne; e0 += 64) {
                 const int iv = iv_n;
@@ -185,6 +193,7 @@ __device__ __forceinline__ void update_role(char* smem, int rg, int g,
                     for (int t = 0; t < NT; ++t)
                         rs[t] = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(dv[t]), u)), x[u], rs[t]);
                 }
+            }
             }
             // the shares and the counter travel as agent-scope accesses (write-through / coherent reads): no L2 write-back or
             // invalidate, which would cost every other workgroup of the XCD its cached columns
@@ -351,6 +360,7 @@ struct SamplerArgs {
     const float* gram_next;       // b_next x b_next Gram of the NEXT block (L2 prefetch only), or NULL
     const float* cross_after;     // cross-Gram X_next' X_(next+1) the NEXT launch's sampler reads (L2 prefetch only), or NULL
     int lines_after;              // ... its size in 128-byte lines
+    int dense_big_off;            // != 0: never take dense_big_st (tests: the same chain through the general path)
     const float* corr_in;         // [NT][bsz] lookahead correction of THIS block (written by the previous sampler)
     float* corr_out;              // [NT][bsz] lookahead correction of the NEXT block
     const double* prep_d; const float* prep_f;
@@ -757,13 +767,15 @@ __device__ __forceinline__ float dense_alpha_new(float x, float da, float ie, fl
     const float gHat = rhs * invLhs;                                        // :39
     return incl ? (float)((double)gHat + zs) : 0.f;                         // :46 / :55
 }
-template <int Q, bool TWO, bool ALLINC>
+// RULED: the sweep runs under Rule D (uniform pi = 0): alpha_new = fmaf(kc1, x, kc0) -- the chain is fma, sub, readlane, fma.
+template <int Q, bool TWO, bool ALLINC, bool RULED = false>
 __device__ __forceinline__ void dense_section(const float* grow, int B, int nsteps, int lane, float ie, float lo, float hi,
-                                              float il, float da, float ao, double zs, float& r0, float& r1, float& rev)
+                                              float il, float da, float ao, double zs, float& r0, float& r1, float& rev,
+                                              float kc1 = 0.f, float kc0 = 0.f)
 {
     auto step = [&](int l, float c0, float c1) {
         const float x = (Q == 0) ? r0 : r1;
-        const float an = dense_alpha_new(x, da, ie, il, zs, ALLINC ? true : abc_included(x, lo, hi));
+        const float an = RULED ? fmaf(kc1, x, kc0) : dense_alpha_new(x, da, ie, il, zs, ALLINC ? true : abc_included(x, lo, hi));
         const float Dl = ao - an;                                           // (excluded: alpha_old - 0)
         rev = (lane == l) ? x : rev;
         const float D = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Dl), l));
@@ -821,6 +833,7 @@ __device__ __forceinline__ void dense_big_st(char* smem, const StepSmem& SM, con
     const int cl = own ? c : 0;
     float rr = rhs_lds[cl];
     const float il = lpf[cl], dj = lpf[2 * B + cl];
+    const float kc1 = lpf[B + cl], kc0 = lpf[3 * B + cl];               // Rule D: alpha_new = fmaf(kc1, x, kc0)  (see the front)
     const double zs = lpd[cl];
     const float ao = acur[cl];
     const float da = dj * ao;                                           // d * alpha_old (BayesABC.jl:36)
@@ -854,8 +867,8 @@ __device__ __forceinline__ void dense_big_st(char* smem, const StepSmem& SM, con
     for (int s = 0; s < nsec; ++s) {
         if (wave == s) {
             float r0 = rr, r1 = 0.f, rev = rr;
-            dense_section<0, false, true>(tiles + s * 4096, 64, 64, lane, ie, 0.f, 0.f, il, da, ao, zs, r0, r1, rev);
-            an_own = dense_alpha_new(rev, da, ie, il, zs, true);
+            dense_section<0, false, true, true>(tiles + s * 4096, 64, 64, lane, ie, 0.f, 0.f, il, da, ao, zs, r0, r1, rev, kc1, kc0);
+            an_own = fmaf(kc1, rev, kc0);
             acur[c] = an_own;
             rhs_lds[c] = ao - an_own;                                   // D of this marker, read by everybody after the barrier
         }
@@ -921,15 +934,16 @@ __device__ __forceinline__ void dense_big_st(char* smem, const StepSmem& SM, con
 }
 
 __host__ __device__ constexpr int st_park_nd(int method) { return method == kBayesR ? BayesRMarker::kFastD : 1; }
-__host__ __device__ constexpr int st_park_nf(int method) { return method == kBayesR ? 2 : 5; }
+__host__ __device__ constexpr int st_park_nf(int method, bool dense = false) { (void)dense; return method == kBayesR ? 2 : 5; }
 
-// DENSE: the instantiation that carries dense_big_st (selected by the host for sweeps whose prior includes every marker);
-// the steady-state kernel is compiled without it.
+// DENSE: the instantiation for sweeps under a UNIFORM PRIOR pi = 0 (single-trait BayesA/B/C: RR-BLUP, BayesA, BayesL, the
+// reference's benchmark setting), selected by the host: every marker follows Rule D (AbcMarker::rule_d) on every path of
+// it, and full 256- / 512-marker blocks take dense_big_st.  The steady-state kernel is compiled without any of it.
 template <int METHOD, bool DENSE = false>
 __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A)
 {
     constexpr bool kR = (METHOD == kBayesR);
-    constexpr int ND = st_park_nd(METHOD), NF = st_park_nf(METHOD);
+    constexpr int ND = st_park_nd(METHOD), NF = st_park_nf(METHOD, DENSE);
     const StepSmem SM(A.bsz, 1, ND, NF);
     const int B = SM.B;
     const DevParams* P = A.P;
@@ -969,7 +983,7 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
     bool dense_big_try = false;
     if constexpr (!kR && DENSE) {
         dense_big_try = (B == 256 || B == 512) && b == B && (A.b_next == 0 || A.b_next == B) &&
-                        (P->nreps == 1) && P->pi == 0.0 && P->pi_vec == nullptr;
+                        (P->nreps == 1) && P->pi == 0.0 && P->pi_vec == nullptr && !A.dense_big_off;
         if (dense_big_try && wave < (B >> 6)) {
             typedef __attribute__((address_space(3))) void lds_void;
             float* tile = reinterpret_cast<float*>(smem + SM.rows_off) + wave * 4096;
@@ -1032,6 +1046,9 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
             acur[c] = a_in; astart[c] = a_in;
             lpd[c] = zs;
             lpf[c] = invLhs; lpf[B + c] = bex; lpf[2 * B + c] = dj; lpf[3 * B + c] = lo; lpf[4 * B + c] = hi;
+            // Rule D sweeps: nothing is ever excluded, so the slots of the "excluded" draw and of the lower threshold carry
+            // c1 and c0 instead (512-marker blocks leave no LDS for two more rows next to dense_big_st's 128 KB of tiles)
+            if constexpr (DENSE) { lpf[B + c] = A.prep_f[5 * p + j]; lpf[3 * B + c] = A.prep_f[6 * p + j]; }
             cand[q] = (c < b) && ((a_in != 0.f) || abc_included(rhs0, lo, hi));
             always_mine = always_mine && ((c >= b) || (lo == hi));           // thresholds(): lo = hi <=> always included
             bpark0[c] = bex; dpark0[c] = 0.f;     // a marker that stays out: delta 0, beta = its excluded draw
@@ -1171,20 +1188,28 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
     bool dense_done = false;
     if constexpr (!kR) {
         if (nreps == 1 && prestage && nstaged == b && 5 * ncand_all >= 3 * b) {
-            float lo[2], hi[2], il[2], da[2], ao[2], rhsq[2], rev[2], bex[2];
+            float lo[2], hi[2], il[2], da[2], ao[2], rhsq[2], rev[2], bex[2], kc1[2] = {0.f, 0.f}, kc0[2] = {0.f, 0.f};
             double zs[2];
             bool always = true;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int c = (64 * q + lane < B) ? 64 * q + lane : 0;
                 il[q] = lpf[c]; bex[q] = lpf[B + c]; lo[q] = lpf[3 * B + c]; hi[q] = lpf[4 * B + c];
+                if constexpr (DENSE) { kc1[q] = lpf[B + c]; kc0[q] = lpf[3 * B + c]; }
                 zs[q] = lpd[c];
                 rhsq[q] = rhs_lds[c]; ao[q] = acur[c]; rev[q] = rhsq[q];
                 da[q] = lpf[2 * B + c] * ao[q];                                       // d * alpha_old (BayesABC.jl:36)
-                always = always && (lo[q] == hi[q]);                                  // thresholds(): lo = hi <=> always included
+                always = always && (DENSE || lo[q] == hi[q]);                         // thresholds(): lo = hi <=> always included
             }
             // Pi = 0 / BayesA / RR-BLUP: every marker of the block is included whatever its rhs -- no decision on the chain
             const bool all_in = __all(always);
+            if constexpr (DENSE) {
+                // Rule D (uniform pi = 0): every marker is always included and its new effect is fmaf(kc1, x, kc0)
+                if (B > 64) {
+                    dense_section<0, true, true, true>(rows, B, b < 64 ? b : 64, lane, ie, lo[0], hi[0], il[0], da[0], ao[0], zs[0], rhsq[0], rhsq[1], rev[0], kc1[0], kc0[0]);
+                    if (b > 64) dense_section<1, true, true, true>(rows + 64 * B, B, b - 64, lane, ie, lo[1], hi[1], il[1], da[1], ao[1], zs[1], rhsq[0], rhsq[1], rev[1], kc1[1], kc0[1]);
+                } else dense_section<0, false, true, true>(rows, B, b, lane, ie, lo[0], hi[0], il[0], da[0], ao[0], zs[0], rhsq[0], rhsq[1], rev[0], kc1[0], kc0[0]);
+            } else
             if (B > 64) {
                 if (all_in) {
                     dense_section<0, true, true>(rows, B, b < 64 ? b : 64, lane, ie, lo[0], hi[0], il[0], da[0], ao[0], zs[0], rhsq[0], rhsq[1], rev[0]);
@@ -1200,8 +1225,8 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int c = 64 * q + lane;
-                const bool inc = abc_included(rev[q], lo[q], hi[q]);
-                const float an = dense_alpha_new(rev[q], da[q], ie, il[q], zs[q], inc);
+                const bool inc = DENSE ? true : abc_included(rev[q], lo[q], hi[q]);
+                const float an = DENSE ? fmaf(kc1[q], rev[q], kc0[q]) : dense_alpha_new(rev[q], da[q], ie, il[q], zs[q], inc);
                 if (c < B) {
                     acur[c] = (c < b) ? an : 0.f; bpark0[c] = inc ? an : bex[q]; dpark0[c] = inc ? 1.f : 0.f;
                     rhs_lds[c] = (c < b) ? ao[q] - an : 0.f;                          // alpha_old - alpha_new, for the dense correction
@@ -1245,7 +1270,7 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
             const float a_cur = acur[c];                  // (fixed while the marker is pending; a committed lane leaves `pending`)
             float rhs = rhs_lds[c];
             const int my_slot = slot_of[c];
-            float c_lo = 0.f, c_hi = 0.f, c_il = 0.f, c_bex = 0.f, c_d = 0.f, c_thrx = 0.f;
+            float c_lo = 0.f, c_hi = 0.f, c_il = 0.f, c_bex = 0.f, c_d = 0.f, c_thrx = 0.f, c_k1 = 0.f, c_k0 = 0.f;
             double c_zs = 0.0;
             double r_il1 = 0.0, r_il2 = 0.0, r_il3 = 0.0, r_zs1 = 0.0, r_zs2 = 0.0, r_zs3 = 0.0, r_T0 = 0.0, r_T1 = 0.0, r_T2 = 0.0;
             if constexpr (kR) {
@@ -1256,6 +1281,7 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
             } else {
                 c_il = lpf[cl]; c_bex = lpf[B + cl]; c_d = lpf[2 * B + cl]; c_lo = lpf[3 * B + cl]; c_hi = lpf[4 * B + cl];
                 c_zs = lpd[cl];
+                if constexpr (DENSE) { c_k1 = lpf[B + cl]; c_k0 = lpf[3 * B + cl]; }
             }
             // bring this sub-block up to date: the changes committed so far, in commit order (the same fmaf sequence
             // per element as an immediate update); 8 independent LDS reads in flight
@@ -1281,10 +1307,11 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
                 float an = 0.f;
                 if constexpr (kR) ev = nz || (fabsf(rhs) >= c_thrx);
                 else {
-                    inc = abc_included(rhs, c_lo, c_hi); ev = inc || nz;
+                    inc = DENSE ? true : abc_included(rhs, c_lo, c_hi); ev = inc || nz;
                     // every lane's new effect BEFORE the vote: the six dependent operations run beside the vote's
                     // compare / ballot / find-first chain instead of after it (wasted only in a sub-block's last round)
-                    an = abc_alpha_new(rhs, a_cur, c_d, ie, c_il, c_zs, inc);
+                    if constexpr (DENSE) an = fmaf(c_k1, rhs, c_k0);         // Rule D (uniform pi = 0: inc is always true)
+                    else an = abc_alpha_new(rhs, a_cur, c_d, ie, c_il, c_zs, inc);
                     asm volatile("" : "+v"(an));         // (keeps the compiler from sinking it below the vote's branch)
                 }
                 const unsigned long long m = __builtin_amdgcn_ballot_w64(ev) & pending;
@@ -1374,7 +1401,7 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
             }
 
             // the marker's constants: parked in LDS by the parallel phase (rep 0) or recomputed for a later repetition
-            float c_lo = 0.f, c_hi = 0.f, c_il = 0.f, c_bex = 0.f, c_d = 0.f, c_thrx = 0.f;
+            float c_lo = 0.f, c_hi = 0.f, c_il = 0.f, c_bex = 0.f, c_d = 0.f, c_thrx = 0.f, c_k1 = 0.f, c_k0 = 0.f;
             double c_zs = 0.0;
             BayesRMarker bm;
             double r_il1 = 0.0, r_il2 = 0.0, r_il3 = 0.0, r_zs1 = 0.0, r_zs2 = 0.0, r_zs3 = 0.0, r_T0 = 0.0, r_T1 = 0.0, r_T2 = 0.0;
@@ -1387,6 +1414,7 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
                 } else {
                     c_il = lpf[cl]; c_bex = lpf[B + cl]; c_d = lpf[2 * B + cl]; c_lo = lpf[3 * B + cl]; c_hi = lpf[4 * B + cl];
                     c_zs = lpd[cl];
+                    if constexpr (DENSE) { c_k1 = lpf[B + cl]; c_k0 = lpf[3 * B + cl]; }
                 }
             } else {
                 const float dj = A.xpx[j];
@@ -1411,6 +1439,7 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
                     am.prepare(dj, var_j, pi_j, ie, u, z);
                     am.thresholds(a_cur, ie, c_lo, c_hi);
                     c_il = am.invLhs; c_bex = am.beta_excl; c_zs = am.zs;
+                    if constexpr (DENSE) am.rule_d(a_cur, ie, c_k1, c_k0);       // Rule D with this repetition's alpha_old and draw
                 }
                 // a marker that is not touched in this repetition gets the repetition's "out of the model" draw
                 if (valid) { if constexpr (kR) dpark[c] = 1.f; else { bpark[c] = c_bex; dpark[c] = 0.f; } }
@@ -1423,7 +1452,7 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
                 ++nrounds;
                 bool inc = false, ev = false;
                 if constexpr (kR) ev = nz || (fabsf(rhs) >= c_thrx);
-                else { inc = abc_included(rhs, c_lo, c_hi); ev = inc || nz; }
+                else { inc = DENSE ? true : abc_included(rhs, c_lo, c_hi); ev = inc || nz; }
                 const unsigned long long m = __ballot(ev && valid) & pending;
                 if (m == 0ull) break;                     // no further change in this sub-block
                 const int k = __builtin_amdgcn_readfirstlane(__builtin_ctzll(m));
@@ -1439,7 +1468,8 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
                     if (cls == 0) an = 0.f;
                     if (lane == k) { acur[c] = an; dpark[c] = (float)(cls + 1); }             // stored as class 1..4
                 } else {
-                    an = abc_alpha_new(rhs, a_cur, c_d, ie, c_il, c_zs, inc);
+                    if constexpr (DENSE) an = fmaf(c_k1, rhs, c_k0);         // Rule D (inc is always true)
+                    else an = abc_alpha_new(rhs, a_cur, c_d, ie, c_il, c_zs, inc);
                     if (lane == k) { acur[c] = an; bpark[c] = inc ? an : c_bex; dpark[c] = inc ? 1.f : 0.f; }
                 }
                 const float Dl = a_cur - an;
@@ -2767,7 +2797,7 @@ __global__ __launch_bounds__(kStepThreads) void k_block_step(UpdateArgsT<CX> U, 
             // ... and ONE of them (id 8) pulls what the NEXT launch's sampler will read -- the next block's Gram and its
             // cross-Gram, 2 MB at 512 markers -- into that L2: dense_big_st moves ~1.5 MB per block through one CU, and with
             // HBM latency under the update role's streaming (~5 us) a CU's 63 loads in flight per wave cap it at ~25 GB/s.
-            if (blockIdx.x == 8 && do_sample) {
+            if (blockIdx.x == 8 && do_sample && (S.bsz == 256 || S.bsz == 512) && !S.dense_big_off) {
                 const int nl_g = (S.gram_next != nullptr) ? (S.b_next * S.b_next + 31) / 32 : 0;
                 const int nl_c = (S.cross_after != nullptr) ? S.lines_after : 0;
                 float sink = 0.f;
@@ -2847,7 +2877,7 @@ __global__ __launch_bounds__(kStepThreads) void k_indep_rhs(UpdateArgsT<CX> U, i
 }
 
 // All blocks sampled concurrently.  grid = nblocks, block = 512, dynamic LDS as k_block_step.
-template <int METHOD, int NT>
+template <int METHOD, int NT, bool DENSE = false>
 __global__ __launch_bounds__(kStepThreads) void k_indep_sample(SamplerArgs S, int64_t pstride, Events* ev_all)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -2859,7 +2889,7 @@ __global__ __launch_bounds__(kStepThreads) void k_indep_sample(SamplerArgs S, in
     S.ev_out = ev_all + blk;
     S.b_next = 0;                                   // no lookahead correction in this mode
     if constexpr (is_mt_method(METHOD)) sampler_role_mt<METHOD, NT>(smem, S);
-    else sampler_role_st<METHOD>(smem, S);
+    else sampler_role_st<METHOD, DENSE>(smem, S);
 }
 
 // Exclusive scan of the per-block change counts.  grid = 1, block = 1024.

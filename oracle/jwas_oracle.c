@@ -174,9 +174,30 @@ typedef struct {
     float  ie;        /* invVarRes = 1/vare                  (BayesABC.jl:69)                  */
 } abc_sweep_consts;
 
+/* Rule D (the device's definition for sweeps under a UNIFORM prior pi = 0 -- RR-BLUP, BayesA, BayesL, the reference's own
+ * benchmark setting; csrc/kernels.hpp AbcMarker::rule_d): every marker is included whatever its rhs, and its new effect is
+ * ONE fused multiply-add of the block rhs,  alpha = fmaf(c1, s, c0),  c1 = fl32(fl64(ie) fl64(1/lhs)),
+ * c0 = fl32(fl64(ie) fl64(1/lhs) (fl64(d) fl64(alpha_old)) + z sqrt(1/lhs))  -- the same conditional mean and draw as
+ * :36,:39,:46 in one rounding instead of four.  The caller (oracle.py) switches it on exactly for such sweeps;
+ * orc_set_abc_rule_d(0) is the literal operation order (compared in tests/test_oracle_kat.py). */
+static int g_abc_rule_d = 0;
+void orc_set_abc_rule_d(int on) { g_abc_rule_d = on; }
+
 static inline float abc_update(float s, float d, float* alpha, float* beta, float* delta,
                                float ie, float var_j, double pi_j, double u, double z)
 {
+    if (g_abc_rule_d && pi_j == 0.0) {
+        const float a_old = *alpha;
+        const float lhs = d * ie + 1.0f / var_j;                       /* :37 */
+        const float invLhs = 1.0f / lhs;                               /* :38 */
+        const double k1 = (double)ie * (double)invLhs;
+        const float c1 = (float)k1;
+        const float c0 = (float)(k1 * ((double)d * (double)a_old) + z * (double)sqrtf(invLhs));
+        *delta = 1.0f;
+        *beta = fmaf(c1, s, c0);
+        *alpha = *beta;
+        return a_old - *alpha;
+    }
     /* per-sweep vectors of BayesABC.jl:66-71, evaluated per marker (same values) */
     const double lp0 = log(pi_j);                 /* logPi[j]      (Float64)                    */
     const double lp1 = log(1.0 - pi_j);           /* logPiComp[j]  (Float64)                    */

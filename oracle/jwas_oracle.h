@@ -162,6 +162,8 @@ int orc_mtbayesc_I_lookahead_sweep(const float* X, int64_t n, int64_t p, int64_t
 void orc_set_var_effect_matrix(const float* mat);
 /* Rule L of sampler I (see mt1_update): 1 = on (the device's definition; default), 0 = the literal operation order. */
 void orc_set_mt_linear_form(int on);
+/* Rule D of single-trait BayesA/B/C sweeps under a uniform pi = 0 (see abc_update): 1 = on, 0 = the literal order (default). */
+void orc_set_abc_rule_d(int on);
 /* One InverseWishart(df, scale + b_j b_j') draw per marker (variance_components.jl:181-186; df = the reference's df + 1),
  * Bartlett on the counter RNG: the restatement the device's k_sample_marker_covariances is compared with. */
 void orc_sample_marker_covariances(int t, int64_t p, const float* beta, double df, const double* scale,

@@ -139,6 +139,9 @@ def _vec_or_fill(v, p, dtype):
     return np.ascontiguousarray(v)
 
 
+RULE_D = True        # (tests switch the rule off to compare with the literal operation order)
+
+
 def bayesabc_sweep(X, xpx_, r, alpha, beta, delta, vare, var_effects, pi, seed, it,
                    marker0=0, acc=ACC_F64, block_starts=None, grams=None, nreps=1, lookahead=False, independent=False):
     """In-place sweep.  block_starts=None -> non-block form (BayesABC.jl:60-80); lookahead=True ->
@@ -146,6 +149,9 @@ def bayesabc_sweep(X, xpx_, r, alpha, beta, delta, vare, var_effects, pi, seed, 
     n, p, ld = _xinfo(X)
     ve = _vec_or_fill(var_effects, p, np.float32)
     pv = np.asarray(pi, dtype=np.float64)
+    # Rule D (jwas_oracle.c abc_update; the device's definition for sweeps under a UNIFORM prior pi = 0): on exactly when the
+    # sweep's pi is the scalar 0 -- a per-marker pi vector never triggers it, as on the device; RULE_D = False = literal order
+    lib().orc_set_abc_rule_d(1 if (RULE_D and pv.ndim == 0 and float(pv) == 0.0) else 0)
     if pv.ndim == 1 and pv.shape[0] != p:
         # bayesabc_pi_vector (BayesABC.jl:16-22)
         raise ValueError(f"BayesABC pi vector length {pv.shape[0]} must match the number of markers ({p}).")
@@ -166,6 +172,7 @@ def bayesabc_sweep(X, xpx_, r, alpha, beta, delta, vare, var_effects, pi, seed, 
                                             _p(r, _f32p), _p(alpha, _f32p), _p(beta, _f32p), _p(delta, _f32p),
                                             C.c_float(vare), _p(ve, _f32p), _p(pv, _f64p), C.c_int(nreps),
                                             C.c_uint64(seed), C.c_uint32(it), C.c_uint32(marker0), C.c_int(acc))
+    lib().orc_set_abc_rule_d(0)
     if rc != 0:
         raise ValueError(f"oracle BayesABC sweep rejected its arguments (rc={rc})")
 

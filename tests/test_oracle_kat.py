@@ -559,3 +559,43 @@ def test_sampler1_linear_form_stays_within_a_few_ulp_of_the_literal_order():
         np.testing.assert_allclose(res[1][k][0], res[0][k][0], atol=2e-5 * scale)
         changed += int((res[1][k][0] != res[0][k][0]).sum())
     assert changed > 0                       # the rule did apply (the two orders round differently somewhere)
+
+
+def test_rule_d_stays_within_float32_rounding_of_the_literal_order():
+    """Rule D (csrc/kernels.hpp AbcMarker::rule_d, oracle abc_update): under a uniform prior pi = 0 every marker is included
+    whatever its rhs and its new effect is one fused multiply-add of the block rhs, alpha = fmaf(c1, x, c0), instead of the
+    chain rhs -> gHat -> alpha of bayesabc_update_marker! (BayesABC.jl:36,39,46).  With the rule switched off the oracle is
+    the literal restatement; the two chains (RR-BLUP and BayesA settings, every marker in the model every sweep) agree to
+    Float32 rounding -- the chain is a contraction there, rounding differences do not grow."""
+    import oracle as O
+    from oracle_engine import OracleEngine
+    d = make_dataset(n=300, p=280, ncausal=6, seed=9)
+    y = (d["y"] - d["y"].mean()).astype(np.float32)
+    rng = np.random.default_rng(0)
+    for method, kw in (("BayesC", dict(vare=np.float32(0.6), var_effect=np.float32(0.002), pi=0.0)),
+                       ("BayesB", dict(vare=np.float32(0.6), var_effect=np.float32(0.002), pi=0.0,
+                                       var_effect_vec=rng.uniform(0.001, 0.01, 280).astype(np.float32)))):
+        res = {}
+        try:
+            for on in (True, False):
+                O.RULE_D = on
+                e = OracleEngine("dense")
+                e.load_dense(d["X"]); e.setup_blocks(64); e.init_state(method, 1); e.set_residual(y)
+                for it in range(1, 13):
+                    st = e.sweep(iteration=it, seed=3, **kw)
+                    assert st["sum_delta"][0] == e.p
+                res[on] = (e.get_state(0)[0], e.get_residual(0))
+        finally:
+            O.RULE_D = True
+        scale = np.abs(res[False][0]).max()
+        np.testing.assert_allclose(res[True][0], res[False][0], atol=3e-6 * max(scale, 1.0))
+        np.testing.assert_allclose(res[True][1], res[False][1], atol=2e-4)
+        assert (res[True][0] != res[False][0]).any()             # the rule did apply
+    # a per-marker pi vector of zeros does NOT trigger the rule (nor does it on the device: pi_vec sweeps run the general kernel)
+    e1, e2 = OracleEngine("dense"), OracleEngine("dense")
+    out = []
+    for e, pi in ((e1, 0.0), (e2, np.zeros(280))):
+        e.load_dense(d["X"]); e.setup_blocks(64); e.init_state("BayesC", 1); e.set_residual(y)
+        e.sweep(iteration=1, seed=3, vare=np.float32(0.6), var_effect=np.float32(0.002), pi=pi)
+        out.append(e.get_state(0)[0])
+    assert (out[0] != out[1]).any() and np.abs(out[0] - out[1]).max() < 1e-5
