@@ -1,0 +1,1150 @@
+// sampler_mt.hpp -- SAMPLER role, multi-trait: per-marker evaluations of samplers I (with Rule L) / II / megaBayesABC, the per-marker
+// inverse-Wishart draws of multi-trait BayesA/B, k_prepare_mt2 and sampler_role_mt.  Included by sweep.hpp.
+#pragma once
+#include "kernels.hpp"
+
+namespace jw {
+
+// ---------------------------------------------------------------------------------------------
+// Per-marker evaluation of the multi-trait samplers.  Inputs: w[k] = rhs_k + d*alpha_k (fp32), the
+// marker's current (alpha, beta, delta), its draws.  Outputs: new (an, bn, dn) and the axpy
+// coefficients Dl[k] (alpha_old - alpha_new; 0 = no change).  Operation for operation the oracle's
+// mt1_update / mt2_update / mega_update.
+// ---------------------------------------------------------------------------------------------
+template <int NT>
+struct MtConsts {
+    float Rinv[NT][NT], Ginv[NT][NT];
+    float invG[NT], lG[NT], sG[NT];                   // sampler I: 1/Ginv_kk, log Ginv_kk, sqrt(1/Ginv_kk)
+    // mega (constraint = true): per-trait single-trait BayesC constants
+    float ie[NT], var[NT], iv[NT], lv[NT], sv[NT];   // sv = sqrt(var)
+    double lp0[NT], lp1[NT];
+};
+
+// Per-marker quantities that depend only on x'x (not on the running rhs): computed once per marker, SIMD across the
+// markers of a sub-block, instead of inside every evaluation (each holds a double-precision log).
+template <int NT>
+struct MtPre {
+    float C11[NT], invLhs1[NT], lC11[NT], s1[NT];     // sampler I: C11, 1/C11, log C11, sqrt(1/C11)
+                                                      // mega:      lhs, 1/lhs, log(lhs) + log(var), sqrt(1/lhs)
+};
+// lc = the logs k_prepare took for this marker (prep_f rows 0..NT-1)
+template <int METHOD, int NT>
+__device__ __forceinline__ MtPre<NT> mt_precompute(const MtConsts<NT>& K, float dj, const float (&lc)[NT])
+{
+    MtPre<NT> R;
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+        if constexpr (METHOD == kMegaBayesC) {
+            R.C11[k] = dj * K.ie[k] + K.iv[k];                                     // BayesABC.jl:37
+            R.invLhs1[k] = 1.0f / R.C11[k];                                        // :38
+        } else {
+            R.C11[k] = K.Ginv[k][k] + K.Rinv[k][k] * dj;                           // MTBayesABC.jl:89
+            R.invLhs1[k] = 1.0f / R.C11[k];                                        // :95
+        }
+        R.lC11[k] = lc[k];
+        R.s1[k] = sqrtf(R.invLhs1[k]);
+    }
+    return R;
+}
+
+// Log prior probabilities of the two joint states sampler I compares for trait k (delta_k = 0 / 1, the other traits as
+// they are now).  PriorMem: a table in memory (LDS; stride ls between states: 1 = the shared table, block size = this
+// marker's column of the marker-specific priors).
+struct PriorMem {
+    const double* lpr; int ls;
+    template <int NT>
+    __device__ __forceinline__ void pair(int k, const float (&dn)[NT], double& l0, double& l1) const
+    {
+        unsigned s0 = 0u;
+#pragma unroll
+        for (int m = 0; m < NT; ++m) if (m != k && dn[m] != 0.f) s0 |= 1u << m;
+        l0 = lpr[s0 * ls];
+        l1 = lpr[(s0 | (1u << k)) * ls];
+    }
+};
+// ---- Rule L (sampler I): the LINEAR FORM of a marker that is in the model for every trait and stays there.
+// With every delta = 1 before and after, the marker's NT conditionals are one small triangular system:
+//     beta_k = 1/C11_k * ( sum_m Rinv[m][k] w_m - sum_{m<k} C12[k][m] beta_m - sum_{m>k} C12[k][m] beta_old_m ) + z_k sqrt(1/C11_k)
+// i.e.  beta = A w + c  with A (NT x NT) and c (NT) functions of the marker's constants, its old beta and its draws only --
+// NOT of the running rhs.  The dense walk (every marker in the model: the reference's default all-ones prior) precomputes
+// A, c for all 64 markers of a section in parallel and is left with NT^2 fused multiply-adds per marker on the serial
+// chain instead of the ~26 dependent operations of the conditional-by-conditional order (430 -> ~110 cycles per 3-trait
+// marker).  So that every path (dense walk, speculative rounds, the oracle) produces the SAME numbers, the rule is part
+// of the sampler's definition: whenever the exact evaluation (below, the reference's operation order) says that a marker
+// which entered with every delta = 1 leaves with every delta = 1, its new effects are the linear form's
+//     beta_k = fmaf(A[k][NT-1], w[NT-1], ... fmaf(A[k][0], w[0], c[k]))      (A, c: double recurrence, rounded to float)
+// -- the same conditional means and the same draws, another association: <= a few ulp from the reference's order.  Every
+// other marker keeps the exact order's values.  The oracle applies the same rule (orc mt1_update; the literal order stays
+// available there: orc_set_mt_linear_form(0), compared in tests/test_oracle_kat.py).
+template <int NT>
+__device__ __forceinline__ void mt1_linear_coeffs(const MtConsts<NT>& K, const MtPre<NT>& Q, float dj, const float (&b_old)[NT],
+                                                  const double (&z)[NT], float (&A)[NT][NT], float (&cc)[NT])
+{
+    double Ad[NT][NT], cd[NT];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+        const double il = (double)Q.invLhs1[k];
+        double C12[NT];
+#pragma unroll
+        for (int m = 0; m < NT; ++m) C12[m] = (double)(K.Ginv[k][m] + (dj * 1.f) * K.Rinv[k][m]);       // MTBayesABC.jl:90 with delta_m = 1
+#pragma unroll
+        for (int m = 0; m < NT; ++m) {
+            double acc = (double)K.Rinv[m][k];
+#pragma unroll
+            for (int j = 0; j < k; ++j) acc = acc - C12[j] * Ad[j][m];
+            Ad[k][m] = il * acc;
+        }
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < k; ++j) acc = acc - C12[j] * cd[j];
+#pragma unroll
+        for (int j = k + 1; j < NT; ++j) acc = acc - C12[j] * (double)b_old[j];
+        cd[k] = il * acc + z[k] * (double)Q.s1[k];
+    }
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+        cc[k] = (float)cd[k];
+#pragma unroll
+        for (int m = 0; m < NT; ++m) A[k][m] = (float)Ad[k][m];
+    }
+}
+template <int NT>
+__device__ __forceinline__ void mt1_linear_beta(const float (&A)[NT][NT], const float (&cc)[NT], const float (&w)[NT], float (&b)[NT])
+{
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+        float v = cc[k];
+#pragma unroll
+        for (int m = 0; m < NT; ++m) v = fmaf(A[k][m], w[m], v);
+        b[k] = v;
+    }
+}
+
+// Gibbs sampler I (MTBayesABC.jl:85-120); LIN: apply Rule L to the result (off only where the result's VALUES are not kept).
+template <int NT, bool LIN = true, class LP>
+__device__ __forceinline__ void mt1_eval(const MtConsts<NT>& K, const MtPre<NT>& Q, const LP& lp, const float (&w)[NT], float dj,
+                                         const double (&thr)[NT], const double (&z)[NT],
+                                         float (&an)[NT], float (&bn)[NT], float (&dn)[NT], float (&Dl)[NT])
+{
+    float a_in[NT], b_in[NT];
+    bool all1 = LIN;
+#pragma unroll
+    for (int k = 0; k < NT; ++k) { a_in[k] = an[k]; b_in[k] = bn[k]; all1 = all1 && (dn[k] == 1.f); }
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {                                                  // :85
+        const float Ginv11 = K.Ginv[k][k];
+        const float C11 = Q.C11[k];                                                 // :89
+        float rhs0 = 0.f, c12b = 0.f, wR = 0.f;
+#pragma unroll
+        for (int m = 0; m < NT; ++m) {
+            wR = wR + w[m] * K.Rinv[m][k];
+            if (m == k) continue;
+            const float C12m = K.Ginv[k][m] + (dj * dn[m]) * K.Rinv[k][m];          // :90
+            rhs0 = rhs0 + K.Ginv[k][m] * bn[m];
+            c12b = c12b + C12m * bn[m];
+        }
+        rhs0 = -rhs0;                                                               // :93
+        const float invLhs0 = K.invG[k];
+        const float gHat0 = rhs0 * invLhs0;
+        const float invLhs1 = Q.invLhs1[k];
+        const float rhs1 = wR - c12b;                                               // :96
+        const float gHat1 = rhs1 * invLhs1;
+        double lp0, lp1;
+        lp.template pair<NT>(k, dn, lp0, lp1);
+        const float in0 = K.lG[k] - (gHat0 * gHat0) * Ginv11;                       // :104
+        const float in1 = Q.lC11[k] - (gHat1 * gHat1) * C11;                        // :105
+        const double logDelta0 = -0.5 * (double)in0 + lp0;
+        const double logDelta1 = -0.5 * (double)in1 + lp1;
+        if ((logDelta0 - logDelta1) < thr[k]) {                                     // :107-111
+            dn[k] = 1.f;
+            bn[k] = (float)((double)gHat1 + z[k] * (double)Q.s1[k]);
+            Dl[k] = an[k] - bn[k];
+            an[k] = bn[k];
+        } else {                                                                    // :112-119
+            bn[k] = (float)((double)gHat0 + z[k] * (double)K.sG[k]);
+            dn[k] = 0.f;
+            Dl[k] = an[k];
+            an[k] = 0.f;
+        }
+    }
+    if constexpr (LIN) {
+#pragma unroll
+        for (int k = 0; k < NT; ++k) all1 = all1 && (dn[k] == 1.f);
+        if (all1) {                                                                 // Rule L
+            float A[NT][NT], cc[NT];
+            mt1_linear_coeffs<NT>(K, Q, dj, b_in, z, A, cc);
+            mt1_linear_beta<NT>(A, cc, w, bn);
+#pragma unroll
+            for (int k = 0; k < NT; ++k) { an[k] = bn[k]; Dl[k] = a_in[k] - bn[k]; }
+        }
+    }
+}
+
+// megaBayesABC! (BayesABC.jl:1-8): trait k is an independent single-trait BayesC update (BayesABC.jl:24-58)
+template <int NT>
+__device__ __forceinline__ void mega_eval(const MtConsts<NT>& K, const MtPre<NT>& Q, const float (&w)[NT], float dj,
+                                          const double (&thr)[NT], const double (&z)[NT],
+                                          float (&an)[NT], float (&bn)[NT], float (&dn)[NT], float (&Dl)[NT])
+{
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+        const float rhs    = w[k] * K.ie[k];                                        // :36
+        const float invLhs = Q.invLhs1[k];                                          // :37-38
+        const float gHat   = rhs * invLhs;                                          // :39
+        const float inner  = Q.lC11[k] - gHat * rhs;                                // (log lhs + log var) - gHat*rhs
+        const double l1    = -0.5 * (double)inner + K.lp1[k];                       // :40
+        if ((K.lp0[k] - l1) < thr[k]) {                                             // :41,:44
+            dn[k] = 1.f;
+            bn[k] = (float)((double)gHat + z[k] * (double)Q.s1[k]);                 // :46
+            Dl[k] = an[k] - bn[k];
+            an[k] = bn[k];
+        } else {
+            dn[k] = 0.f;
+            bn[k] = (float)(z[k] * (double)K.sv[k]);                                // :54
+            Dl[k] = an[k];
+            an[k] = 0.f;
+        }
+    }
+    (void)dj;
+}
+
+// lower Cholesky factor of an SPD NT x NT matrix (fixed operation order, shared with the oracle's chol_lower)
+template <int NT>
+__device__ __forceinline__ void chol_lower(const double (&A)[NT][NT], double (&L)[NT][NT])
+{
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        double s = A[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) s = s - L[j][k] * L[j][k];
+        L[j][j] = sqrt(s);
+#pragma unroll
+        for (int i = j + 1; i < NT; ++i) {
+            double v = A[i][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) v = v - L[i][k] * L[j][k];
+            L[i][j] = v / L[j][j];
+        }
+    }
+}
+
+// ---- multi-trait BayesA/B: one InverseWishart(df, scale + b_j b_j') draw per marker (variance_components.jl:181-186:
+// sample_variance(data, 1, df, scale) per marker -- the host's 100 000 draws per iteration were ~35 ms of numpy and made
+// the multi-trait BayesB iteration host-bound).  One thread per marker, Bartlett's decomposition on the counter RNG:
+//   S = scale + b b' = C C' (chol_lower);  A lower-triangular, A_ii = sqrt(chi2(df - i)), A_ik ~ N(0,1) (k < i);
+//   K' = A^-1 C' (forward substitution);  G = K K', symmetrised, rounded to float.
+// W = C'^-1 A A' C^-1 ~ Wishart(df, S^-1) and G = W^-1.  Counter of a draw: (global marker, iteration, 0x80000000 | attempt,
+// slot): slot 32 + 2i (+1) the chi-square of row i (Marsaglia-Tsang gamma: one normal + one uniform per attempt), slot
+// 64 + 4i + k the normal A_ik -- disjoint from the sweep's own draws (repetition index < 2^31, slots 0 / 1 + 16 trait).
+// Operation for operation the oracle's orc_sample_marker_covariances.
+__device__ __forceinline__ double iw_chi2(uint32_t marker, uint32_t iter, uint32_t slot, uint32_t k0, uint32_t k1, double nu)
+{
+    double a = 0.5 * nu, boost = 1.0;
+    if (a < 1.0) {                                   // gamma(a) = gamma(a + 1) * u^(1/a)
+        const u32x4 w = philox4x32_10(marker, iter, 0x80000000u | 0xFFFFu, slot, k0, k1);
+        boost = exp(log(u52(w.x, w.y)) / a);
+        a = a + 1.0;
+    }
+    const double d = a - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
+    double g = d;
+    for (uint32_t attempt = 0; attempt < 64u; ++attempt) {
+        const u32x4 w = philox4x32_10(marker, iter, 0x80000000u | attempt, slot, k0, k1);
+        const u32x4 w2 = philox4x32_10(marker, iter, 0x80000000u | attempt, slot + 1u, k0, k1);
+        const double x = sqrt(-2.0 * log(u52(w.x, w.y))) * cos(6.283185307179586476925286766559 * u52(w.z, w.w));
+        const double u = u52(w2.x, w2.y);
+        double v = 1.0 + c * x;
+        if (v <= 0.0) continue;
+        v = v * v * v;
+        g = d * v;
+        if (log(u) < 0.5 * x * x + d - d * v + d * log(v)) break;
+    }
+    return 2.0 * g * boost;
+}
+
+struct IwParams { double df; double scale[kMaxT * kMaxT]; uint32_t seed_lo, seed_hi, iter, marker0; };
+
+template <int NT>
+__global__ __launch_bounds__(256) void k_sample_marker_covariances(IwParams Q, int64_t p, const float* __restrict__ beta, float* __restrict__ var_mat)
+{
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= p) return;
+    const uint32_t marker = Q.marker0 + (uint32_t)j;
+    double b[NT], S[NT][NT], C[NT][NT], A[NT][NT], Kt[NT][NT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a) b[a] = (double)beta[(int64_t)a * p + j];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int c = 0; c < NT; ++c) { S[a][c] = Q.scale[a * NT + c] + b[a] * b[c]; C[a][c] = 0.0; A[a][c] = 0.0; }
+    chol_lower<NT>(S, C);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        A[i][i] = sqrt(iw_chi2(marker, Q.iter, 32u + 2u * (uint32_t)i, Q.seed_lo, Q.seed_hi, Q.df - (double)i));
+#pragma unroll
+        for (int k = 0; k < i; ++k) {
+            const u32x4 w = philox4x32_10(marker, Q.iter, 0x80000000u, 64u + 4u * (uint32_t)i + (uint32_t)k, Q.seed_lo, Q.seed_hi);
+            A[i][k] = sqrt(-2.0 * log(u52(w.x, w.y))) * cos(6.283185307179586476925286766559 * u52(w.z, w.w));
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+            double acc = C[c][i];                                       // C'[i][c]
+#pragma unroll
+            for (int k = 0; k < i; ++k) acc = acc - A[i][k] * Kt[k][c];
+            Kt[i][c] = acc / A[i][i];
+        }
+    double G[NT][NT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) s = s + Kt[i][a] * Kt[i][c];
+            G[a][c] = s;
+        }
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int c = 0; c < NT; ++c) var_mat[(j * NT + a) * NT + c] = (float)(0.5 * (G[a][c] + G[c][a]));
+}
+
+// Gibbs sampler II, one candidate state (MTBayesABC.jl:178-185).  st: bit k = trait k in the model.
+// q = -0.5*(log det lhs - rhs'gHat); cand = gHat + chol(lhs^-1)*z only when want_cand.
+// The evaluation of one state is split in three: the part that depends on the marker's x'x and the sweep's variances
+// only (lhs, its inverse and log determinant -- both Cholesky factorisations' worth of divisions and square roots),
+// the part that depends on the running rhs (a handful of multiply-adds), and the candidate effects of the chosen state.
+// mt2_state = pre + post (+ cand): one operation order, shared with the oracle's mt2_state.
+template <int NT>
+__device__ __forceinline__ void mt2_state_pre(const MtConsts<NT>& K, unsigned st, float dj, double (&inv)[NT][NT], double& logdet)
+{
+    double lhs[NT][NT], L[NT][NT], M[NT][NT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a) {
+        const double Da = ((st >> a) & 1u) ? 1.0 : 0.0;
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+            const double Dc = ((st >> c) & 1u) ? 1.0 : 0.0;
+            const double rl = (Da * (double)K.Rinv[a][c]) * Dc;                     // D*Rinv*D  :159
+            lhs[a][c] = rl * (double)dj + (double)K.Ginv[a][c];                     // :179
+        }
+    }
+    chol_lower<NT>(lhs, L);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {                                                  // M = L^-1
+        M[j][j] = 1.0 / L[j][j];
+#pragma unroll
+        for (int i = j + 1; i < NT; ++i) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = j; k < i; ++k) s = s + L[i][k] * M[k][j];
+            M[i][j] = -s / L[i][i];
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < NT; ++a)                                                    // inv(lhs) = M'M  :181
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = (a > c ? a : c); k < NT; ++k) s = s + M[k][a] * M[k][c];
+            inv[a][c] = s;                                                          // (bitwise symmetric: products commute)
+        }
+    double det = 1.0;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) det = det * (L[j][j] * L[j][j]);
+    logdet = log(det);
+}
+template <int NT>
+__device__ __forceinline__ void mt2_state_post(const MtConsts<NT>& K, unsigned st, const float (&w)[NT],
+                                               const double (&inv)[NT][NT], double logdet, double& q, double (&gHat)[NT])
+{
+    double rhs[NT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a) {
+        const double Da = ((st >> a) & 1u) ? 1.0 : 0.0;
+        double s = 0.0;
+#pragma unroll
+        for (int m = 0; m < NT; ++m) s = s + ((double)K.Rinv[m][a] * Da) * (double)w[m];   // (Rinv*D)'w :180
+        rhs[a] = s;
+    }
+    double quad = 0.0;
+#pragma unroll
+    for (int a = 0; a < NT; ++a) {                                                  // gHat = invLhs*rhs :183
+        double s = 0.0;
+#pragma unroll
+        for (int c = 0; c < NT; ++c) s = s + inv[a][c] * rhs[c];
+        gHat[a] = s;
+        quad = quad + rhs[a] * s;
+    }
+    q = -0.5 * (logdet - quad);                                                     // :184
+}
+template <int NT>
+__device__ __forceinline__ void mt2_state_cand(const double (&inv)[NT][NT], const double (&gHat)[NT], const double (&z)[NT],
+                                               double (&cand)[NT])
+{
+    double C[NT][NT];
+    chol_lower<NT>(inv, C);                                                         // cholesky(Hermitian(invLhs)).L :182
+#pragma unroll
+    for (int a = 0; a < NT; ++a) {                                                  // gHat + L*z  :185
+        double s = gHat[a];
+#pragma unroll
+        for (int c = 0; c <= a; ++c) s = s + C[a][c] * z[c];
+        cand[a] = s;
+    }
+}
+template <int NT>
+__device__ __forceinline__ void mt2_state(const MtConsts<NT>& K, unsigned st, const float (&w)[NT], float dj,
+                                          const double (&z)[NT], bool want_cand, double& q, double (&cand)[NT])
+{
+    double inv[NT][NT], gHat[NT], logdet;
+    mt2_state_pre<NT>(K, st, dj, inv, logdet);
+    mt2_state_post<NT>(K, st, w, inv, logdet, q, gHat);
+    if (want_cand) mt2_state_cand<NT>(inv, gHat, z, cand);
+}
+
+// Per-marker table of the state-dependent, rhs-independent quantities (sampler II, NT <= 3): for each of the 2^NT
+// states the NT(NT+1)/2 unique entries of inv(lhs) (row-major upper triangle) and log det lhs.  Filled once per sweep
+// for all markers in parallel (k_prepare_mt2); layout [state][value][p].
+template <int NT>
+struct Mt2Tab {
+    static constexpr int NS = 1 << NT, NV = NT * (NT + 1) / 2 + 1, kRows = NS * NV;
+};
+template <int NT>
+__device__ __forceinline__ void mt2_unpack(const double (&row)[Mt2Tab<NT>::NV], double (&inv)[NT][NT], double& logdet)
+{
+    int v = 0;
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int c = a; c < NT; ++c) { inv[a][c] = row[v]; inv[c][a] = row[v]; ++v; }
+    logdet = row[v];
+}
+template <int NT>
+__global__ __launch_bounds__(256) void k_prepare_mt2(const DevParams* __restrict__ P, int64_t p, const float* __restrict__ xpx,
+                                                     double* __restrict__ tab)
+{
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= p) return;
+    MtConsts<NT> K;
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int c = 0; c < NT; ++c) { K.Rinv[a][c] = P->Rinv[a * NT + c]; K.Ginv[a][c] = P->Ginv[a * NT + c]; }
+    const float dj = xpx[j];
+#pragma unroll 1
+    for (int st = 0; st < Mt2Tab<NT>::NS; ++st) {
+        double inv[NT][NT], logdet;
+        mt2_state_pre<NT>(K, (unsigned)st, dj, inv, logdet);
+        int v = 0;
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+            for (int c = a; c < NT; ++c) { tab[((int64_t)st * Mt2Tab<NT>::NV + v) * p + j] = inv[a][c]; ++v; }
+        tab[((int64_t)st * Mt2Tab<NT>::NV + v) * p + j] = logdet;
+    }
+}
+template <int NT>
+__device__ __forceinline__ void mt2_load_tab(const double* __restrict__ tab, int64_t p, int64_t j,
+                                             double (&T)[Mt2Tab<NT>::NS][Mt2Tab<NT>::NV])
+{
+#pragma unroll
+    for (int st = 0; st < Mt2Tab<NT>::NS; ++st)
+#pragma unroll
+        for (int v = 0; v < Mt2Tab<NT>::NV; ++v) T[st][v] = tab[((int64_t)st * Mt2Tab<NT>::NV + v) * p + j];
+}
+
+// Gibbs sampler II, one marker, from its state table (same results as mt2_eval).
+template <int NT>
+__device__ __forceinline__ void mt2_eval_tab(const MtConsts<NT>& K, const double* lpr, int ls, const float (&w)[NT],
+                                             const double (&T)[Mt2Tab<NT>::NS][Mt2Tab<NT>::NV],
+                                             double u, const double (&z)[NT],
+                                             float (&an)[NT], float (&bn)[NT], float (&dn)[NT], float (&Dl)[NT])
+{
+    constexpr int NS = Mt2Tab<NT>::NS, NV = Mt2Tab<NT>::NV;
+    double ld[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        double inv[NT][NT], lg, q, gh[NT];
+        mt2_unpack<NT>(T[s], inv, lg);
+        mt2_state_post<NT>(K, (unsigned)s, w, inv, lg, q, gh);
+        ld[s] = q + lpr[s * ls];
+    }
+    int which = NS - 1;
+    {                                                                               // :188-198
+        double mx = -INFINITY;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) if (ld[s] > mx) mx = ld[s];
+        double den = 0.0;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { ld[s] = exp(ld[s] - mx); den += ld[s]; }
+        double cp = 0.0;
+        bool found = false;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            cp += ld[s] / den;
+            if (!found && u < cp) { which = s; found = true; }
+        }
+    }
+    double row[NV];                                                                 // the chosen state's row: select chain
+#pragma unroll
+    for (int v = 0; v < NV; ++v) row[v] = T[0][v];
+#pragma unroll
+    for (int s = 1; s < NS; ++s)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) row[v] = (which == s) ? T[s][v] : row[v];
+    double inv[NT][NT], lg, q, gh[NT], cand[NT];
+    mt2_unpack<NT>(row, inv, lg);
+    mt2_state_post<NT>(K, (unsigned)which, w, inv, lg, q, gh);
+    mt2_state_cand<NT>(inv, gh, z, cand);
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+        const double dk = ((which >> k) & 1) ? 1.0 : 0.0;
+        const double a_new = dk * cand[k];                                          // diagm(delta)*beta :201
+        Dl[k] = (float)((double)an[k] - a_new);                                     // oldα-newα -> axpy :204
+        bn[k] = (float)cand[k];
+        dn[k] = (float)dk;
+        an[k] = (float)a_new;
+    }
+}
+
+// Gibbs sampler II, one marker (MTBayesABC.jl:160-208).  u = the marker's uniform (slot 0).
+template <int NT>
+__device__ __forceinline__ void mt2_eval(const MtConsts<NT>& K, const double* lpr, int ls, const float (&w)[NT], float dj,
+                                         double u, const double (&z)[NT],
+                                         float (&an)[NT], float (&bn)[NT], float (&dn)[NT], float (&Dl)[NT])
+{
+    constexpr int NS = 1 << NT;
+    double ld[NS], cand[NT];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) ld[s] = 0.0;
+    int which = NS - 1;
+    // passes 0..NS-1 evaluate the states; pass NS re-evaluates the chosen one for its candidate effects
+#pragma unroll 1
+    for (int pass = 0; pass <= NS; ++pass) {
+        const unsigned st = pass < NS ? (unsigned)pass : (unsigned)which;
+        double q;
+        mt2_state<NT>(K, st, w, dj, z, pass == NS, q, cand);
+        if (pass < NS) {
+            const double v = q + lpr[pass * ls];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) ld[s] = (s == pass) ? v : ld[s];
+        }
+        if (pass == NS - 1) {                                                       // :188-198
+            double mx = -INFINITY;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) if (ld[s] > mx) mx = ld[s];
+            double den = 0.0;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) { ld[s] = exp(ld[s] - mx); den += ld[s]; }
+            double cp = 0.0;
+            bool found = false;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                cp += ld[s] / den;
+                if (!found && u < cp) { which = s; found = true; }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+        const double dk = ((which >> k) & 1) ? 1.0 : 0.0;
+        const double a_new = dk * cand[k];                                          // diagm(delta)*beta :201
+        Dl[k] = (float)((double)an[k] - a_new);                                     // oldα-newα -> axpy :204
+        bn[k] = (float)cand[k];
+        dn[k] = (float)dk;
+        an[k] = (float)a_new;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// SAMPLER role, multi-trait: Gibbs sampler I (MTBayesABC.jl:57-127, block form :243-333), sampler II
+// (:129-210) and megaBayesABC! (BayesABC.jl:1-8) share the schedule; only the per-marker evaluation differs.
+// ---------------------------------------------------------------------------------------------
+template <int METHOD, int NT>
+__device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A)
+{
+    const bool pm = A.lpr_mat != nullptr;           // marker-specific joint priors (host: only with parked draws)
+    constexpr bool kPG = (METHOD == kMTBayesB1);    // a t x t effect covariance per marker (host: only with parked draws)
+    const StepSmem SM(A.bsz, NT, mt_park_nd(A.bsz, NT) + (pm ? (1 << NT) : 0), mt_park_nf(A.bsz, NT) + (kPG ? NT * NT : 0));
+    const int B = SM.B;
+    const bool parked = mt_park_nd(B, NT) != 0;
+    constexpr bool kTab = (METHOD == kMTBayesC2) && (NT <= 3);       // sampler II from per-marker state tables
+    constexpr int kTS = kTab ? (1 << NT) : 1, kTV = kTab ? NT * (NT + 1) / 2 + 1 : 1;
+    const DevParams* P = A.P;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = A.b;
+    const int64_t j0 = A.j0, p = A.p;
+    float* rhs_lds = reinterpret_cast<float*>(smem + SM.rhs_off);
+    float* acur = reinterpret_cast<float*>(smem + SM.acur_off);
+    float* astart = reinterpret_cast<float*>(smem + SM.astart_off);
+    float* bcur = reinterpret_cast<float*>(smem + SM.bcur_off);
+    float* dcur = reinterpret_cast<float*>(smem + SM.dcur_off);
+    double* lpd = reinterpret_cast<double*>(smem + SM.prepd_off);     // [2 NT][B] thresholds, normals (if parked)
+    float* lpf = reinterpret_cast<float*>(smem + SM.prepf_off);       // [B] x'x (if parked)
+    float* lpg = lpf + (1 + NT) * B;                                  // [NT*NT][B] the marker's own G^-1 (kPG)
+    float* delta = reinterpret_cast<float*>(A.delta);
+    const long long tk0 = clock64();
+
+    MtConsts<NT> K;
+#pragma unroll
+    for (int a = 0; a < NT; ++a) {
+#pragma unroll
+        for (int c = 0; c < NT; ++c) { K.Rinv[a][c] = P->Rinv[a * NT + c]; K.Ginv[a][c] = P->Ginv[a * NT + c]; }
+        K.invG[a] = 1.0f / K.Ginv[a][a];                            // MTBayesABC.jl:92
+        K.lG[a] = logf_via_double(K.Ginv[a][a]);
+        K.sG[a] = sqrtf(K.invG[a]);
+        if constexpr (METHOD == kMegaBayesC) {
+            K.ie[a]  = 1.0f / P->vare[a * NT + a];                  // invVarRes          BayesABC.jl:69
+            K.var[a] = P->var_effect[a * NT + a];
+            K.iv[a]  = 1.0f / K.var[a];                             // invVarEffects[j]   :70
+            K.lv[a]  = logf_via_double(K.var[a]);                   // logVarEffects[j]   :71
+            K.sv[a]  = sqrtf(K.var[a]);
+            K.lp0[a] = log(P->pi4[a]);                              // logPi              :67
+            K.lp1[a] = log(1.0 - P->pi4[a]);                        // logPiComp          :68
+        }
+    }
+    // multi-trait BayesA/B: the constants that depend on G are the marker's own (its inverse was formed by k_prepare)
+    auto with_ginv = [&](const float (&g)[NT * NT]) {
+        MtConsts<NT> Kj = K;
+#pragma unroll
+        for (int a = 0; a < NT; ++a) {
+#pragma unroll
+            for (int c2 = 0; c2 < NT; ++c2) Kj.Ginv[a][c2] = g[a * NT + c2];
+            Kj.invG[a] = 1.0f / Kj.Ginv[a][a];                      // MTBayesABC.jl:92
+            Kj.lG[a] = logf_via_double(Kj.Ginv[a][a]);
+            Kj.sG[a] = sqrtf(Kj.invG[a]);
+        }
+        return Kj;
+    };
+    auto consts_of = [&](int c) {                                     // marker c of the block (after the front's barrier)
+        if constexpr (kPG) {
+            float g[NT * NT];
+#pragma unroll
+            for (int i = 0; i < NT * NT; ++i) g[i] = lpg[i * B + c];
+            return with_ginv(g);
+        } else { (void)c; return K; }
+    };
+    // the 2^NT log prior state probabilities are indexed by the running state inside every evaluation: a global load
+    // there would put a memory latency (microseconds under full-rate streaming) on each trait of each round -- LDS copy
+    double* lpr = reinterpret_cast<double*>(smem + SM.lpr_off);
+    const double lpr_mine = P->log_prior[tid < (1 << NT) ? tid : 0];
+
+    // ---- front (all threads, ONE memory latency): every thread issues the loads of its marker's state, draws, x'x,
+    // lookahead correction and row-group partials back to back, forms  rhs = fl32(sum of partials) + corr,  parks
+    // everything the serial wave needs in LDS, and decides candidacy: a marker already in the model for some trait
+    // (its effects always change) or one whose evaluation against the entry rhs changes an effect.  Candidates get
+    // their Gram row staged in LDS; a change of a non-candidate reads its row from HBM inside the serial phase.
+    // small blocks (the host's choice for dense priors): the whole Gram block with the very first loads, as in the
+    // single-trait sampler (slot of marker c = c)
+    const bool prestage = (B <= 128) && (B <= SM.max_cand);
+    const bool gram_dma = prestage && b == B;              // full block: direct global -> LDS loads (see sampler_role_st)
+    const bool cross_dma = gram_dma && SM.has_cross && A.b_next == B;
+    if (gram_dma) dma_copy_to_lds(A.gram, reinterpret_cast<float*>(smem + SM.rows_off), B * B);
+    float4 gpre[8];
+    if (prestage && !gram_dma) {
+        const int per_row = B >> 2, total = b * per_row;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = tid + u * kStepThreads;
+            const int ec = e < total ? e : 0;
+            const int row = ec / per_row, c4 = (ec - row * per_row) * 4;
+            const float* src = A.gram + (int64_t)row * b;
+            if (b == B) gpre[u] = *reinterpret_cast<const float4*>(src + c4);
+            else {
+                gpre[u].x = src[c4 < b ? c4 : 0]; gpre[u].y = src[c4 + 1 < b ? c4 + 1 : 0];
+                gpre[u].z = src[c4 + 2 < b ? c4 + 2 : 0]; gpre[u].w = src[c4 + 3 < b ? c4 + 3 : 0];
+            }
+        }
+    }
+    bool cand[2] = {false, false};
+    float djq_[2], a0[2][NT], b0[2][NT], d0[2][NT], w0[2][NT], lc0[2][NT], gq_[2][kPG ? NT * NT : 1];
+    double thr0[2][NT], z0[2][NT];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int c = tid + q * kStepThreads;
+        if (c >= B) continue;
+        const int cc = c < b ? c : 0;
+        const int64_t j = j0 + cc;
+        const float dj = A.xpx[j];
+        float co[NT];
+        djq_[q] = dj;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            a0[q][t] = A.alpha[(int64_t)t * p + j]; b0[q][t] = A.beta[(int64_t)t * p + j]; d0[q][t] = delta[(int64_t)t * p + j];
+            co[t] = A.corr_in[t * B + c];
+            thr0[q][t] = A.prep_d[(int64_t)t * p + j]; z0[q][t] = A.prep_d[(int64_t)(NT + t) * p + j];
+            lc0[q][t] = A.prep_f[(int64_t)t * p + j];
+        }
+        if constexpr (kPG) {
+#pragma unroll
+            for (int i = 0; i < NT * NT; ++i) gq_[q][i] = A.ginv_mat[j * (NT * NT) + i];
+        }
+        double lpm[1 << NT];
+        if (pm) {
+#pragma unroll
+            for (int st = 0; st < (1 << NT); ++st) lpm[st] = A.lpr_mat[(int64_t)(1 << NT) * j + st];
+        }
+        double psum[NT];
+        sum_partials_traits<NT>(A.partials + cc, (int64_t)A.nrg * A.bstride, A.nrg, A.bstride, psum);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const double sum = psum[t];
+            const float rhs0 = (float)sum + co[t];
+            const float a_in = (c < b) ? a0[q][t] : 0.f;
+            rhs_lds[t * B + c] = rhs0;
+            acur[t * B + c] = a_in; astart[t * B + c] = a_in;
+            bcur[t * B + c] = b0[q][t]; dcur[t * B + c] = d0[q][t];
+            w0[q][t] = rhs0 + dj * a_in;                                                             // :82
+            if (parked) { lpd[t * B + c] = thr0[q][t]; lpd[(NT + t) * B + c] = z0[q][t]; lpf[(1 + t) * B + c] = lc0[q][t]; }
+            a0[q][t] = a_in;
+        }
+        if (parked) lpf[c] = dj;
+        if constexpr (kPG) {
+#pragma unroll
+            for (int i = 0; i < NT * NT; ++i) lpg[i * B + c] = gq_[q][i];
+        }
+        if (pm) {
+#pragma unroll
+            for (int st = 0; st < (1 << NT); ++st) lpd[(2 * NT + st) * B + c] = lpm[st];
+        }
+    }
+    if (tid < (1 << NT)) lpr[tid] = lpr_mine;
+    if (tid == 0) reinterpret_cast<int*>(smem + SM.wcnt_off)[14] = 0;      // set by the dense walk
+    if (prestage) {
+        float* rows_p = reinterpret_cast<float*>(smem + SM.rows_off);
+        short* slot_p = reinterpret_cast<short*>(smem + SM.slot_off);
+        short* cand_p = reinterpret_cast<short*>(smem + SM.cand_off);
+        if (!gram_dma) {
+            const int per_row = B >> 2, total = b * per_row;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = tid + u * kStepThreads;
+                if (e < total) {
+                    const int row = e / per_row, c4 = (e - row * per_row) * 4;
+                    *reinterpret_cast<float4*>(rows_p + row * B + c4) = gpre[u];
+                }
+            }
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int c = tid; c < B; c += kStepThreads) { slot_p[c] = (short)(c < b ? c : -1); cand_p[c] = (short)c; }
+    }
+    __syncthreads();
+    // marker c's table of log prior state probabilities: the shared one (stride 1) or its own column of the parked
+    // marker-specific priors (stride B)
+    const int ls = pm ? B : 1;
+    auto lpr_of = [&](int c) -> const double* { return pm ? lpd + 2 * NT * B + c : lpr; };
+    bool stay[2] = {false, false};
+    float pb[2][NT], pd[2][NT];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int c = tid + q * kStepThreads;
+        if (c >= b) continue;
+        bool in_model = false;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) in_model = in_model || (a0[q][t] != 0.f);
+        bool moves = false;
+        if (!in_model) {
+            const float dj = djq_[q];
+            MtConsts<NT> Kc = K;
+            if constexpr (kPG) Kc = with_ginv(gq_[q]);
+            const MtPre<NT> Q0 = mt_precompute<METHOD, NT>(Kc, dj, lc0[q]);
+            float an[NT], bn[NT], dn[NT], Dl[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { an[t] = a0[q][t]; bn[t] = b0[q][t]; dn[t] = d0[q][t]; Dl[t] = 0.f; }
+            if constexpr (is_sampler1(METHOD)) mt1_eval<NT, false>(Kc, Q0, PriorMem{lpr_of(c), ls}, w0[q], dj, thr0[q], z0[q], an, bn, dn, Dl);
+            else if constexpr (kTab) {
+                double T[kTS][kTV];
+                mt2_load_tab<NT>(A.mt2_tab, p, j0 + c, T);
+                mt2_eval_tab<NT>(K, lpr_of(c), ls, w0[q], T, thr0[q][0], z0[q], an, bn, dn, Dl);
+            }
+            else if constexpr (METHOD == kMTBayesC2) mt2_eval<NT>(K, lpr_of(c), ls, w0[q], dj, thr0[q][0], z0[q], an, bn, dn, Dl);
+            else mega_eval<NT>(K, Q0, w0[q], dj, thr0[q], z0[q], an, bn, dn, Dl);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) moves = moves || (Dl[t] != 0.f);
+            if (!moves) {
+                stay[q] = true;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) { pb[q][t] = bn[t]; pd[q][t] = dn[t]; }
+            }
+        }
+        cand[q] = in_model || moves;
+    }
+    // PREFIX SKIP (as in the single-trait sampler): until the first candidate of the block commits the running rhs is the
+    // entry rhs, so the evaluation above is final for every marker before it.  Their freshly drawn beta / delta are parked
+    // (only theirs: a later marker is re-evaluated from its OLD state) and the serial wave starts at the first sub-block
+    // that holds a candidate.  Single pass only.
+    int first_sub = 16, ncand_all = 0;
+    {
+        int* wc = reinterpret_cast<int*>(smem + SM.wcnt_off);
+        const int f0 = __any(cand[0]) ? 1 : 0, f1 = __any(cand[1]) ? 2 : 0;
+        const int npop = __popcll(__ballot(cand[0])) + __popcll(__ballot(cand[1]));
+        if (lane == 0) wc[wave] = f0 | f1 | (npop << 8);
+        __syncthreads();
+        unsigned mask = 0u;
+#pragma unroll
+        for (int q = 0; q < kStepThreads / 64; ++q) { const int v = wc[q]; ncand_all += v >> 8; mask |= (unsigned)(v & 1) << q | (unsigned)((v >> 1) & 1) << (8 + q); }
+        if (mask) first_sub = __builtin_ctz(mask);
+        const bool single_pass = (P->nreps > 0 ? P->nreps : b) == 1;
+        if (!single_pass) first_sub = 0;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int c = tid + q * kStepThreads;
+            if (stay[q] && c < b && (c >> 6) < first_sub) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) { bcur[t * B + c] = pb[q][t]; dcur[t * B + c] = pd[q][t]; }
+            }
+        }
+        __syncthreads();                                   // (stage_rows reuses the slots)
+    }
+    const long long tk1 = clock64();
+    const int nstaged_mt = prestage ? b : (first_sub >= 16 ? 0 : stage_rows(smem, SM, A, cand));
+    if (cross_dma) {                                       // waves 1..7: the cross-Gram rows to LDS while wave 0 walks the block
+        dma_copy_to_lds(A.cross_next, reinterpret_cast<float*>(smem + SM.cross_off), B * B, 1);
+        if (wave != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else prefetch_cross_rows(smem, SM, A, nstaged_mt);
+    prefetch_next_gram(A, prestage);
+    int* wcnt_s = reinterpret_cast<int*>(smem + SM.wcnt_off);
+    long long tk3 = 0, tk4 = 0, tk5 = 0;
+    int nrounds = 0;
+    if (wave == 0) {
+    tk3 = clock64();
+
+
+    const int nsub = (b + 63) / 64;
+    const int nreps = P->nreps > 0 ? P->nreps : b;
+    RngKey key{P->seed_lo, P->seed_hi, P->iter, 0u};
+
+    // ---- DENSE blocks (every marker of a <= 128-marker block is in the model for some trait -- the default all-ones
+    // multi-trait prior): sequential walk instead of speculative rounds, as in the single-trait sampler.  Every lane
+    // evaluates ITS OWN marker against its own running rhs at every step -- no operand is broadcast; the step's marker
+    // is lane l, whose per-trait alpha_old - alpha_new are broadcast with NT v_readlane and applied to the running rhs of
+    // the whole block (NT x 2 registers per lane) with the marker's Gram row from LDS (read a step ahead).  A lane's
+    // result is final at its own step: it keeps the w it was evaluated with and recomputes its update after the walk.
+    bool dense_done = false;
+    // Sampler I, every marker of the block in the model for every trait at entry (the reference's default prior keeps it
+    // that way: the states with a trait missing have probability ~0): the walk SPECULATES that every delta stays 1 and
+    // evaluates a marker with Rule L's linear form (mt1_linear_coeffs: A, c of all 64 markers of a section formed in
+    // parallel, NT^2 fused multiply-adds per marker on the chain).  After a 64-marker section ONE full mt1_eval per lane
+    // (all 64 markers at once, each with the w it was walked with) both verifies the speculation and yields the final
+    // state -- by Rule L the linear form's own numbers whenever the speculation held; if any marker left the model for a
+    // trait the section is walked again from its saved rhs with those markers evaluated the general way.
+    if (METHOD != kMTBayesC2 && nreps == 1 && prestage && nstaged_mt == b && 5 * ncand_all >= 3 * b) {
+        const float* rows = reinterpret_cast<const float*>(smem + SM.rows_off);
+        float rhsq[NT][2], aq[NT][2], bq[NT][2], dq[NT][2], djq[2], wev[2][NT];
+        double thrq[NT][2], zq[NT][2];
+        MtPre<NT> Qq[2];
+        MtConsts<NT> Kq[kPG ? 2 : 1];                               // (kPG: the two markers' own constants)
+        auto KQ = [&](int q) -> const MtConsts<NT>& { if constexpr (kPG) return Kq[q]; else { (void)q; return K; } };
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int c = (64 * q + lane < b) ? 64 * q + lane : 0;
+            djq[q] = lpf[c];                                        // (B <= 128: the draws are always parked in LDS)
+            float lcq[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) lcq[t] = lpf[(1 + t) * B + c];
+            if constexpr (kPG) Kq[q] = consts_of(c);
+            Qq[q] = mt_precompute<METHOD, NT>(KQ(q), djq[q], lcq);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                rhsq[t][q] = rhs_lds[t * B + c]; aq[t][q] = acur[t * B + c]; bq[t][q] = bcur[t * B + c]; dq[t][q] = dcur[t * B + c];
+                thrq[t][q] = lpd[t * B + c]; zq[t][q] = lpd[(NT + t) * B + c];
+                wev[q][t] = 0.f;
+            }
+        }
+        const bool speculate = is_sampler1(METHOD);
+        // one marker evaluated in-lane from (w, its state at block entry, its draws)
+        auto eval_own = [&](int q, const float (&w)[NT], float (&an)[NT], float (&bn)[NT], float (&dn)[NT], float (&Dl)[NT]) {
+            const int c = (64 * q + lane < b) ? 64 * q + lane : 0;
+            double thr[NT], z[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { an[t] = aq[t][q]; bn[t] = bq[t][q]; dn[t] = dq[t][q]; Dl[t] = 0.f; thr[t] = thrq[t][q]; z[t] = zq[t][q]; }
+            // (the shared prior table from registers -- v_cndmask trees instead of the LDS lookup -- was measured: 79 ms
+            // per sweep instead of 55 at 3 traits x 20k x 100k; the LDS read overlaps the trait's arithmetic well enough)
+            if constexpr (is_sampler1(METHOD)) mt1_eval<NT>(KQ(q), Qq[q], PriorMem{lpr_of(c), ls}, w, djq[q], thr, z, an, bn, dn, Dl);
+            else mega_eval<NT>(K, Qq[q], w, djq[q], thr, z, an, bn, dn, Dl);
+        };
+        // the speculative conditionals = Rule L's linear form (mt1_linear_coeffs): A, c of the lane's own marker are formed once
+        // per section; a step is NT^2 fused multiply-adds.  Dl = alpha_old - alpha_new
+        auto eval_fast = [&](int q, const float (&w)[NT], const float (&Al)[NT][NT], const float (&cl)[NT], float (&bn)[NT], float (&Dl)[NT]) {
+            mt1_linear_beta<NT>(Al, cl, w, bn);
+#pragma unroll
+            for (int k = 0; k < NT; ++k) Dl[k] = aq[k][q] - bn[k];
+        };
+        auto linear_of = [&](int q, float (&Al)[NT][NT], float (&cl)[NT]) {
+            float b_old[NT];
+            double zz[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { b_old[t] = bq[t][q]; zz[t] = zq[t][q]; }
+            mt1_linear_coeffs<NT>(KQ(q), Qq[q], djq[q], b_old, zz, Al, cl);
+        };
+        // 64-marker section q: eight steps per batch without a branch, the Gram rows read a batch ahead
+        auto section = [&](auto qc, auto fastc, const float* grow, int nsteps) {
+            constexpr int Q = decltype(qc)::value;
+            constexpr bool FAST = decltype(fastc)::value;
+            float Al[NT][NT], cl[NT], da[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) da[t] = djq[Q] * aq[t][Q];                                 // :82
+            if constexpr (FAST) linear_of(Q, Al, cl);
+            auto step = [&](int l, float c0, float c1) {
+                float w[NT], an[NT], bn[NT], dn[NT], Dl[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) w[t] = rhsq[t][Q] + da[t];
+                if constexpr (FAST) eval_fast(Q, w, Al, cl, bn, Dl);
+                else eval_own(Q, w, an, bn, dn, Dl);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    wev[Q][t] = (lane == l) ? w[t] : wev[Q][t];      // lane l: what it was evaluated with
+                    const float D = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Dl[t]), l));
+                    if (Q == 0) rhsq[t][0] = fmaf(D, c0, rhsq[t][0]);                                   // D = 0: exact no-op
+                    if (B > 64) rhsq[t][1] = fmaf(D, c1, rhsq[t][1]);
+                }
+            };
+            constexpr int kBatch = FAST ? 8 : 2;
+            float n0[kBatch], n1[kBatch];
+            auto load = [&](int l0) {
+#pragma unroll
+                for (int u = 0; u < kBatch; ++u) {
+                    n0[u] = (Q == 0) ? grow[(l0 + u) * B + lane] : 0.f;
+                    n1[u] = (B > 64) ? grow[(l0 + u) * B + 64 + lane] : 0.f;
+                }
+            };
+            int l = 0;
+            if (nsteps >= kBatch) load(0);
+#pragma unroll 1
+            for (; l + kBatch <= nsteps; l += kBatch) {
+                float c0[kBatch], c1[kBatch];
+#pragma unroll
+                for (int u = 0; u < kBatch; ++u) { c0[u] = n0[u]; c1[u] = n1[u]; }
+                if (l + 2 * kBatch <= nsteps) load(l + kBatch);
+#pragma unroll
+                for (int u = 0; u < kBatch; ++u) step(l + u, c0[u], c1[u]);
+            }
+#pragma unroll 1
+            for (; l < nsteps; ++l) step(l, (Q == 0) ? grow[l * B + lane] : 0.f, (B > 64) ? grow[l * B + 64 + lane] : 0.f);
+        };
+        using std::integral_constant;
+        // the same section with some markers (bit l of `slow`) evaluated the general way and the others speculatively: one
+        // step per loop trip (used when the speculation missed, or when a marker is not in the model for every trait at entry)
+        auto section_mixed = [&](auto qc, const float* grow, int nsteps, unsigned long long slow) {
+            constexpr int Q = decltype(qc)::value;
+            float Al[NT][NT], cl[NT], da[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) da[t] = djq[Q] * aq[t][Q];
+            linear_of(Q, Al, cl);
+            float g0 = (Q == 0) ? grow[lane] : 0.f;
+            float g1 = (B > 64) ? grow[64 + lane] : 0.f;
+#pragma unroll 1
+            for (int l = 0; l < nsteps; ++l) {
+                float w[NT], an[NT], bn[NT], dn[NT], Dl[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) w[t] = rhsq[t][Q] + da[t];
+                if ((slow >> l) & 1ull) eval_own(Q, w, an, bn, dn, Dl);                               // (wave-uniform)
+                else eval_fast(Q, w, Al, cl, bn, Dl);
+                const float c0 = g0, c1 = g1;
+                grow += B;                                           // next marker's row (one past the block: the overflow row)
+                if (Q == 0) g0 = grow[lane];
+                if (B > 64) g1 = grow[64 + lane];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    wev[Q][t] = (lane == l) ? w[t] : wev[Q][t];
+                    const float D = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Dl[t]), l));
+                    if (Q == 0) rhsq[t][0] = fmaf(D, c0, rhsq[t][0]);
+                    if (B > 64) rhsq[t][1] = fmaf(D, c1, rhsq[t][1]);
+                }
+            }
+        };
+        auto run_section = [&](auto qc) {
+            constexpr int Q = decltype(qc)::value;
+            const int nsteps = (b < 64 * (Q + 1) ? b : 64 * (Q + 1)) - 64 * Q;
+            if (nsteps <= 0) return;
+            const float* grow = rows + 64 * Q * B;                   // (all rows staged in marker order: slot = marker)
+            const int c = 64 * Q + lane;
+            float an[NT], bn[NT], dn[NT], Dl[NT];
+            if (speculate) {
+                float rs[NT][2];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) { rs[t][0] = rhsq[t][0]; rs[t][1] = rhsq[t][1]; }
+                // markers that are not in the model for every trait at entry cannot be speculated on
+                bool in_all = true;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) in_all = in_all && (dq[t][Q] == 1.f);
+                unsigned long long slow = __ballot(!in_all && c < b);
+                if (__popcll(slow) * 4 > nsteps) slow = ~0ull;       // not a block to speculate on: everything the general way
+                if (slow == 0ull) section(qc, integral_constant<bool, true>{}, grow, nsteps);
+                else section_mixed(qc, grow, nsteps, slow);
+                for (int pass = 0; pass < 64; ++pass) {
+                    eval_own(Q, wev[Q], an, bn, dn, Dl);             // the exact evaluation of every marker of the section
+                    bool ok = true;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) ok = ok && (dn[t] == 1.f);
+                    // a speculated marker that leaves the model for a trait: its broadcast changes were wrong -- evaluate it
+                    // (and whatever else looks wrong now) the general way and walk the section again from its saved rhs
+                    const unsigned long long bad = __ballot(!ok && c < b) & ~slow;
+                    if (bad == 0ull) break;
+                    slow |= bad;
+                    if (__popcll(slow) * 4 > nsteps) slow = ~0ull;   // (misses are not rare here: stop speculating)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) { rhsq[t][0] = rs[t][0]; rhsq[t][1] = rs[t][1]; }
+                    section_mixed(qc, grow, nsteps, slow);
+                    ++nrounds;                                       // (diagnostics: sections walked again)
+                }
+            } else {
+                section(qc, integral_constant<bool, false>{}, grow, nsteps);
+                eval_own(Q, wev[Q], an, bn, dn, Dl);
+            }
+            if (c < B)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) { acur[t * B + c] = (c < b) ? an[t] : 0.f; bcur[t * B + c] = bn[t]; dcur[t * B + c] = dn[t]; }
+        };
+        run_section(integral_constant<int, 0>{});
+        run_section(integral_constant<int, 1>{});
+        dense_done = true;
+    }
+    if (dense_done && lane == 0) wcnt_s[14] = 1;
+
+    const int s_first = (nreps == 1 && !dense_done) ? (first_sub < nsub ? first_sub : nsub) : 0;       // prefix skip (single pass only)
+    for (int rep = 0; rep < (dense_done ? 0 : nreps); ++rep) {
+        key.rep = (uint32_t)rep;
+#pragma unroll 1
+        for (int s = s_first; s < nsub; ++s) {
+            const int c = 64 * s + lane;
+            const bool valid = c < b;
+            const int64_t j = j0 + (valid ? c : 0);
+            const uint32_t marker = P->marker0 + (uint32_t)j;
+            unsigned long long pending = __ballot(valid);
+            const float dj = parked ? lpf[c] : A.xpx[j];
+            double thr[NT], z[NT];
+            float a_cur[NT], b_cur[NT], d_cur[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                a_cur[t] = acur[t * B + c]; b_cur[t] = bcur[t * B + c]; d_cur[t] = dcur[t * B + c];
+                if (rep == 0) {
+                    if (parked) { thr[t] = lpd[t * B + c]; z[t] = lpd[(NT + t) * B + c]; }
+                    else { thr[t] = A.prep_d[(int64_t)t * p + j]; z[t] = A.prep_d[(int64_t)(NT + t) * p + j]; }
+                }
+                else {
+                    const double u = draw_uniform(key, marker, (uint32_t)t);
+                    thr[t] = (METHOD == kMTBayesC2) ? u : log((1.0 - u) / u);
+                    z[t] = draw_normal(key, marker, (uint32_t)t);
+                }
+            }
+            float lcm[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) lcm[t] = parked ? lpf[(1 + t) * B + c] : A.prep_f[(int64_t)t * p + j];
+            const MtConsts<NT> Km = consts_of(valid ? c : 0);          // (kPG: this marker's own G-dependent constants)
+            const MtPre<NT> Qm = mt_precompute<METHOD, NT>(Km, dj, lcm); // x'x-only terms, once per marker (SIMD over the sub-block)
+            double T[kTS][kTV];
+            if constexpr (kTab) mt2_load_tab<NT>(A.mt2_tab, p, j, T);
+            while (true) {
+                const bool live = valid && ((pending >> lane) & 1ull);
+                float an[NT], bn[NT], dn[NT], Dl[NT];
+                bool is_event = false;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) { an[t] = a_cur[t]; bn[t] = b_cur[t]; dn[t] = d_cur[t]; Dl[t] = 0.f; }
+                if (live) {
+                    float w[NT];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) w[t] = rhs_lds[t * B + c] + dj * a_cur[t];           // :82
+                    if constexpr (is_sampler1(METHOD)) mt1_eval<NT>(Km, Qm, PriorMem{lpr_of(c), ls}, w, dj, thr, z, an, bn, dn, Dl);
+                    else if constexpr (kTab) mt2_eval_tab<NT>(K, lpr_of(c), ls, w, T, thr[0], z, an, bn, dn, Dl);
+                    else if constexpr (METHOD == kMTBayesC2) mt2_eval<NT>(K, lpr_of(c), ls, w, dj, thr[0], z, an, bn, dn, Dl);
+                    else mega_eval<NT>(K, Qm, w, dj, thr, z, an, bn, dn, Dl);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) is_event = is_event || (Dl[t] != 0.f);
+                }
+                ++nrounds;
+                const unsigned long long m = __ballot(is_event) & pending;
+                const int k = m ? __builtin_ctzll(m) : 64;
+                if (live && lane <= k) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) { a_cur[t] = an[t]; b_cur[t] = bn[t]; d_cur[t] = dn[t]; }
+                }
+                if (k == 64) break;
+                pending = (k == 63) ? 0ull : (pending & ~((2ull << k) - 1ull));
+                float D[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) D[t] = __shfl(Dl[t], k, 64);
+                apply_gram_row<NT>(smem, SM, A, 64 * s + k, D, lane);                               // :311,317
+                if (pending == 0ull) break;
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { acur[t * B + c] = a_cur[t]; bcur[t * B + c] = b_cur[t]; dcur[t * B + c] = d_cur[t]; }
+        }
+    }
+
+    tk4 = clock64();
+    int base = 0;
+#pragma unroll 1
+    for (int s = s_first; s < nsub; ++s) {                    // (no change before the first candidate's sub-block)
+        const int c = 64 * s + lane;
+        bool changed = false;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) changed = changed || ((c < b) && astart[t * B + c] != acur[t * B + c]);
+        const unsigned long long cm = __ballot(changed);
+        if (changed) reinterpret_cast<int*>(smem + SM.log_off)[base + __popcll(cm & ((1ull << lane) - 1ull))] = c;
+        base += __popcll(cm);
+    }
+    if (lane == 0) wcnt_s[15] = base;
+    tk5 = clock64();
+    }   // wave 0
+    __syncthreads();
+    const int nfin = wcnt_s[15];
+    if (A.b_next > 0 && cross_dma && wcnt_s[14] != 0) {
+        // dense walk with the cross-Gram rows in LDS: every marker is an entry (alpha_old - alpha_new = 0: exact no-op); one
+        // thread per (trait, column of the next block), the chain in marker order as in corr_phase
+        const float* crossL = reinterpret_cast<const float*>(smem + SM.cross_off);
+        for (int i = tid; i < NT * B; i += kStepThreads) rhs_lds[i] = astart[i] - acur[i];
+        __syncthreads();
+        for (int i = tid; i < NT * B; i += kStepThreads) {
+            const int t = i / B, c = i - t * B;
+            const float* dl = rhs_lds + t * B;
+            float corr = 0.f;
+            int e = 0;
+#pragma unroll 1
+            for (; e + 8 <= b; e += 8) {
+                const float4 d0 = *reinterpret_cast<const float4*>(dl + e), d1 = *reinterpret_cast<const float4*>(dl + e + 4);
+                float g[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) g[u] = crossL[(e + u) * B + c];
+                corr = fmaf(d0.x, g[0], corr); corr = fmaf(d0.y, g[1], corr); corr = fmaf(d0.z, g[2], corr); corr = fmaf(d0.w, g[3], corr);
+                corr = fmaf(d1.x, g[4], corr); corr = fmaf(d1.y, g[5], corr); corr = fmaf(d1.z, g[6], corr); corr = fmaf(d1.w, g[7], corr);
+            }
+            for (; e < b; ++e) corr = fmaf(dl[e], crossL[e * B + c], corr);
+            A.corr_out[i] = corr;
+        }
+    } else if (A.b_next > 0) corr_phase<NT>(smem, SM, A, nfin);
+    // ---- global stores LAST (a barrier after a global store waits for the store): the change list for the next update
+    // role, then the block's state (beta / delta of every marker are new draws; alpha changes only where an event happened)
+    {
+        const int* fin = reinterpret_cast<const int*>(smem + SM.log_off);
+        for (int e = tid; e < nfin; e += kStepThreads) {
+            const int ce = fin[e];
+            A.ev_out->idx[e] = (int32_t)(j0 + ce);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) A.ev_out->delta[t][e] = astart[t * B + ce] - acur[t * B + ce];
+        }
+    }
+    for (int c = tid; c < b; c += kStepThreads) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float a_fin = acur[t * B + c];
+            if (a_fin != astart[t * B + c]) A.alpha[(int64_t)t * p + j0 + c] = a_fin;
+            A.beta[(int64_t)t * p + j0 + c] = bcur[t * B + c];
+            delta[(int64_t)t * p + j0 + c]  = dcur[t * B + c];
+        }
+    }
+    if (tid == 0) {
+        A.ev_out->count = nfin;
+        atomicAdd(&A.counters[0], (unsigned long long)nfin);
+        atomicAdd(&A.counters[2], (unsigned long long)(tk1 - tk0));      // phase cycle counts (diagnostics)
+        atomicAdd(&A.counters[4], (unsigned long long)(tk3 - tk1));
+        atomicAdd(&A.counters[5], (unsigned long long)(tk4 - tk3));
+        atomicAdd(&A.counters[6], (unsigned long long)(tk5 - tk4));
+        atomicAdd(&A.counters[7], (unsigned long long)nrounds);
+    }
+}
+
+
+}  // namespace jw

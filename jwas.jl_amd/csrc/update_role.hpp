@@ -1,0 +1,283 @@
+// update_role.hpp -- UPDATE / PARTIAL role of the fused step kernel (apply a block's changes to the residual -- sparse exit update, or the
+// cooperative dense apply -- then the block's partial right-hand side).  Included by sweep.hpp.
+#pragma once
+#include "kernels.hpp"
+
+namespace jw {
+
+// ---------------------------------------------------------------------------------------------
+// UPDATE/PARTIAL role
+// ---------------------------------------------------------------------------------------------
+template <int NT, class CX, bool COOP = false>
+__device__ __forceinline__ void update_role(char* smem, int rg, int g,
+                                            const CX& cx,
+                                            const float* __restrict__ r_in, float* __restrict__ r_out,
+                                            const Events* __restrict__ ev,
+                                            int64_t j0, int b, int nslices, int nrg, int ncg,
+                                            double* __restrict__ partials, int bstride, int spg = kRowGroupSlices,
+                                            int* sync_now = nullptr, int* sync_next = nullptr, unsigned long long* dbg = nullptr)
+{
+#ifdef JWAS_HIP_DEV_KNOBS
+#define JW_UPD_CLOCK(v) v = clock64()
+#else
+#define JW_UPD_CLOCK(v) (void)0
+#endif
+    long long tu0 = 0, tu1 = 0, tu3 = 0;
+    JW_UPD_CLOCK(tu0);
+    typedef double RedT[kColChunk][NT];
+    RedT* red = reinterpret_cast<RedT*>(smem);                 // [kRowGroupSlices][kColChunk][NT]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int slice = rg * spg + wave;
+    const bool active = wave < spg && slice < nslices;
+    // an inactive wave (slice beyond the matrix) aliases slice 0 for addressing and contributes 0
+    const int64_t row = (int64_t)(active ? slice : 0) * kSliceRows + lane * 4;
+    const int ncols = (b > g) ? (b - g + ncg - 1) / ncg : 0;
+    const int64_t ld = cx.ld;
+
+    // Loads are unconditional from clamped, always-valid addresses: a select between a load and a
+    // constant makes hipcc pick between pointers and emit flat/scratch accesses.
+    const int64_t jc0 = j0 + (ncols > 0 ? g : 0);
+    const int nc1 = ncols > 0 ? ncols - 1 : 0;
+    typedef typename CX::SRaw Raw;
+    constexpr int D = CX::kDepth;                      // register batches in flight per wave
+    const typename CX::Stream st = cx.stream(jc0, ncg, row);     // element i = marker jc0 + i*ncg, this lane's 4 rows
+    auto load_batch = [&](Raw (&dst)[kU], int ib) {
+        if (active) {                                  // (wave-uniform; an idle wave streams nothing)
+#pragma unroll
+            for (int u = 0; u < kU; ++u) dst[u] = st.load_raw(ib + u < ncols ? ib + u : nc1);
+        } else {
+#pragma unroll
+            for (int u = 0; u < kU; ++u) dst[u] = Raw{};
+        }
+    };
+
+    // (1) the first batch(es) of column loads do not depend on r: issue them before the update.
+    //     Dense: in-flight depth is ONE batch per wave (8 KB): with ~1600 waves streaming that is ~13 MB outstanding,
+    //     enough for full HBM rate; doubling it only lengthens the memory queues (Little's law) and with them
+    //     the latency of every dependent load of the concurrently running sampler role.
+    //     2-bit packed: a batch is 8 x 64 B per wave, so the loop is latency-bound and keeps D batches in flight.
+    float mnext = st.load_mean(lane < ncols ? lane : nc1);     // packed storage: marker means of the first 64 stream elements
+    Raw xr[D][kU];
+#pragma unroll
+    for (int s = 0; s < D; ++s) load_batch(xr[s], s * kU);
+
+    // (2) sparse exit update: sequential fmaf in marker order, bit-identical to the oracle's per-marker
+    //     axpy sequence.  Every column group recomputes it (reads r_in only); group 0 stores r_out.
+    float4 rv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) rv[t] = *reinterpret_cast<const float4*>(r_in + t * ld + row);
+    // (dense priors apply a whole block of changes here: 16 column loads in flight per wave, the fmaf chain per row
+    // stays in list order)
+    const int ne = ev->count;
+    constexpr int kEB = 16;
+    // ---- COOPERATIVE DENSE APPLY.  With a dense prior every launch applies a whole block of changes (ne ~ b), and every
+    // column group of a row group re-reading the same ne columns makes the update role the bottleneck of the launch (8 x
+    // 25.6 MB at n = 50 000, b = 128).  Here the ncg workgroups of a row group SPLIT the rows of every slice: wave w of
+    // group g updates rows [g*R, (g+1)*R) of its slice (R = ceil(256 / ncg) <= 64, one row per lane, dword loads, 64 of
+    // them in flight per lane), the fused multiply-add chain per row in list order -- the same operations as the float4
+    // path, bit for bit.  The shares go to r_out, a counter per row group (agent scope, zeroed by the previous launch)
+    // tells when all ncg shares have landed, and every group then reads its slices' new residual back.  The wait is
+    // BOUNDED: if the peers do not show up (workgroups not co-resident) the group falls back to applying everything
+    // itself -- same values either way, so the fallback is only slower.
+    bool applied = false;
+    if constexpr (COOP && CX::kCoopApply) {
+        const int R = (kSliceRows + ncg - 1) / ncg;
+        if (sync_now != nullptr && r_out != nullptr && ne >= 32 && ncg >= 4 && R <= 64) {
+            // Rows of this group: [g*R, (g+1)*R) of every slice of the row group.  When R divides 64 (ncg = 8: R = 32) a wave
+            // takes the share of 64 / R slices at once, so that all 64 lanes carry a row: the phase is bound by instruction
+            // issue (one readlane + address + load and one readlane + fma per entry and row), and seven half-empty waves on
+            // four SIMDs cost twice what four full ones do.
+            // With at least as many column groups as slices (the usual geometry: 7-8 slices, 8-16 groups) group g takes slice g
+            // of the row group WHOLE (waves 0..3: 64 consecutive rows each): 256 contiguous bytes per wave load and 1 KB per
+            // column and workgroup, instead of 128-byte (or, with 16 groups, 64-byte: every line fetched by two XCDs) pieces
+            // of every slice -- 9.65 -> 9.2 ms per sweep on the reference benchmark shape.  Otherwise the row-fraction split.
+            const bool slice_map = ncg >= spg;
+            const int pack = slice_map ? 1 : ((64 % R == 0) ? 64 / R : 1);
+            const int sl_w = slice_map ? g : wave * pack + lane / R;      // slice of the row group this lane works for
+            const int rloc = slice_map ? wave * 64 + lane : g * R + (pack > 1 ? lane % R : lane);        // row of the slice
+            const int slice_l = rg * spg + sl_w;
+            const bool mine = slice_map ? (g < spg && slice_l < nslices && wave < 4)
+                                        : (sl_w < spg && slice_l < nslices && (pack > 1 || lane < R) && rloc < kSliceRows);
+            const int64_t grow = (int64_t)(mine ? slice_l : 0) * kSliceRows + (mine ? rloc : 0);
+            float rs[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) rs[t] = r_in[t * ld + grow];
+            // 64 changes per chunk: lane l fetches entry e0 + l of the list (index and coefficients: coalesced), every
+            // lane then loads its row of the 64 columns back to back (addresses from v_readlane: no scalar memory access,
+            // no branch, one memory latency) and runs the chain in list order; entries past the end have coefficient 0 (an
+            // exact no-op on a valid column).  (128 per pass, and two chunks in flight, were measured: not faster.)
+            int iv_n; float dv_n[NT];
+            auto load_list = [&](int e0) {
+                const int el = e0 + lane, ec = el < ne ? el : ne - 1;
+                iv_n = ev->idx[ec];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) { const float d = ev->delta[t][ec]; dv_n[t] = (el < ne) ? d : 0.f; }
+            };
+            if (slice_map ? (wave < 4 && g < spg) : (wave * pack < spg)) {   // (wave-uniform: the other waves have no share)
+            load_list(0);
+            for (int e0 = 0; e0 < ne; e0 += 64) {
+                const int iv = iv_n;
+                float dv[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) dv[t] = dv_n[t];
+                if (e0 + 64 < ne) load_list(e0 + 64);                   // the next chunk's list: in flight behind this chunk's columns
+                float x[64];
+#pragma unroll
+                for (int u = 0; u < 64; ++u) x[u] = cx.load1(__builtin_amdgcn_readlane(iv, u), grow);
+#pragma unroll
+                for (int u = 0; u < 64; ++u) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        rs[t] = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(dv[t]), u)), x[u], rs[t]);
+                }
+            }
+            }
+            // the shares and the counter travel as agent-scope accesses (write-through / coherent reads): no L2 write-back or
+            // invalidate, which would cost every other workgroup of the XCD its cached columns
+            if (mine)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    __hip_atomic_store(reinterpret_cast<int*>(r_out + t * ld + grow), __float_as_int(rs[t]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's share has been written ...
+            JW_UPD_CLOCK(tu1);
+            int* flag = reinterpret_cast<int*>(smem);                     // (the reduction scratch is not in use yet)
+            __syncthreads();
+            if (tid == 0) {
+                __hip_atomic_fetch_add(&sync_now[rg], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ... before the count
+                int ok = 0;
+                for (int spin = 0; spin < 4000; ++spin) {                 // bounded: ~0.5 ms
+                    if (__hip_atomic_load(&sync_now[rg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= ncg) { ok = 1; break; }
+                    __builtin_amdgcn_s_sleep(4);
+                }
+                *flag = ok;
+            }
+            __syncthreads();
+            const int ok = *flag;
+            __syncthreads();                                              // (flag's bytes are reused below)
+            if (ok) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int* src = reinterpret_cast<const int*>(r_out + t * ld + row);
+                    rv[t].x = __int_as_float(__hip_atomic_load(src + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    rv[t].y = __int_as_float(__hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    rv[t].z = __int_as_float(__hip_atomic_load(src + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    rv[t].w = __int_as_float(__hip_atomic_load(src + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                }
+                applied = true;
+            }
+            JW_UPD_CLOCK(tu3);
+        }
+    }
+    if (applied) {
+    } else
+    if (NT == 1 && ne <= 7) {
+        // header path: indices and coefficients arrived with the count (one 64-byte line)
+        float4 x[7];
+#pragma unroll
+        for (int u = 0; u < 7; ++u) x[u] = cx.load4(u < ne ? ev->hidx[u] : 0, row);     // (unused slots: column 0, always valid)
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+            if (u < ne) {
+                const float d = ev->hdelta[u];
+                rv[0].x = fmaf(d, x[u].x, rv[0].x); rv[0].y = fmaf(d, x[u].y, rv[0].y);
+                rv[0].z = fmaf(d, x[u].z, rv[0].z); rv[0].w = fmaf(d, x[u].w, rv[0].w);
+            }
+        }
+    } else
+    for (int e0 = 0; e0 < ne; e0 += kEB) {
+        float4 x[kEB];
+#pragma unroll
+        for (int u = 0; u < kEB; ++u) x[u] = cx.load4(ev->idx[e0 + u < ne ? e0 + u : ne - 1], row);
+#pragma unroll
+        for (int u = 0; u < kEB; ++u) {
+            if (e0 + u < ne) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const float d = ev->delta[t][e0 + u];
+                    rv[t].x = fmaf(d, x[u].x, rv[t].x); rv[t].y = fmaf(d, x[u].y, rv[t].y);
+                    rv[t].z = fmaf(d, x[u].z, rv[t].z); rv[t].w = fmaf(d, x[u].w, rv[t].w);
+                }
+            }
+        }
+    }
+    if (active && g == 0 && r_out != nullptr && !applied)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) *reinterpret_cast<float4*>(r_out + t * ld + row) = rv[t];
+    // the next launch's arrival counter (its previous user is done).  Stores and loads share vmcnt: issued here, after the
+    // last wait of the apply phase that is on a dependent path, the store delays nothing.
+    if constexpr (COOP) { if (sync_next != nullptr && g == 0 && tid == 0) sync_next[rg] = 0; }
+    if (ncols == 0) return;
+    // the RHS is X_b' R^-1 r (block_rhs!, tools4genotypes.jl:59-78): the weights go onto r once per launch (weights = 1
+    // when unweighted: exact), the streaming loop is untouched
+    float4 wv = *reinterpret_cast<const float4*>(cx.w + row);
+    if (!active) wv = float4{0.f, 0.f, 0.f, 0.f};
+    double rd[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        rd[t][0] = rv[t].x * wv.x; rd[t][1] = rv[t].y * wv.y; rd[t][2] = rv[t].z * wv.z; rd[t][3] = rv[t].w * wv.w;
+    }
+
+    // (3) partial block RHS.  (kColChunk / kU batches per chunk is a multiple of D, so ring slot = batch % D.)
+    for (int i0 = 0; i0 < ncols; i0 += kColChunk) {
+        const int iend = (i0 + kColChunk < ncols) ? i0 + kColChunk : ncols;
+        const float mcur = mnext;                                // lane i: mean of stream element i0 + i
+        if (i0 + kColChunk < ncols) mnext = st.load_mean(i0 + kColChunk + lane < ncols ? i0 + kColChunk + lane : nc1);
+        for (int ib0 = i0; ib0 < iend; ib0 += kU * D) {
+#pragma unroll
+            for (int s = 0; s < D; ++s) {
+                const int ib = ib0 + s * kU;
+                if (ib >= iend) break;
+                double acc[NT][kU];
+                auto products = [&](auto dec) {
+#pragma unroll
+                    for (int u = 0; u < kU; ++u) {
+                        const float mu = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mcur), ib + u - i0));
+                        const float4 xa = dec(xr[s][u], mu);
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            acc[t][u] = (double)xa.x * rd[t][0];
+                            acc[t][u] = fma((double)xa.y, rd[t][1], acc[t][u]);
+                            acc[t][u] = fma((double)xa.z, rd[t][2], acc[t][u]);
+                            acc[t][u] = fma((double)xa.w, rd[t][3], acc[t][u]);
+                        }
+                    }
+                };
+                unsigned fl = 0u;                              // packed storage: does any byte of the batch hold a missing code?
+#pragma unroll
+                for (int u = 0; u < kU; ++u) fl |= CX::Stream::flags(xr[s][u]);
+                if (__any(fl != 0u)) products([&](const Raw& r, float mu) { return st.decode_patch(r, mu); });   // wave-uniform branch
+                else products([&](const Raw& r, float mu) { return st.decode_fast(r, mu); });
+                if (ib + kU * D < ncols) load_batch(xr[s], ib + kU * D);   // registers are free again: refill the slot
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const double sum = butterfly8(acc[t], lane);
+                    const int u = lane >> 3;                   // column of this 8-lane group
+                    if ((lane & 7) == 0 && ib + u < ncols) red[wave][ib + u - i0][t] = sum;
+                }
+            }
+        }
+        __syncthreads();
+        for (int q = tid; q < (iend - i0) * NT; q += kStepThreads) {
+            const int i = q / NT, t = q - i * NT;
+            double s = 0.0;
+#pragma unroll
+            for (int w = 0; w < kRowGroupSlices; ++w) s += red[w][i][t];
+            const int c = g + (i0 + i) * ncg;
+            partials[((int64_t)t * nrg + rg) * bstride + c] = s;
+        }
+        __syncthreads();
+    }
+#ifdef JWAS_HIP_DEV_KNOBS
+    if (dbg != nullptr && rg == 0 && g == 0 && tid == 0) {               // development builds: one workgroup's phases
+        const long long tu4 = clock64();
+        atomicAdd(&dbg[13], (unsigned long long)(tu1 - tu0));            // cooperative apply: own share
+        atomicAdd(&dbg[14], (unsigned long long)(tu3 - tu1));            //   wait for the peers + read back
+        atomicAdd(&dbg[15], (unsigned long long)(tu4 - (applied ? tu3 : tu0)));    // the rest (float4 apply if any, partial RHS)
+    }
+#else
+    (void)dbg; (void)tu0; (void)tu1; (void)tu3;
+#endif
+}
+
+
+}  // namespace jw
