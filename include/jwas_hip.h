@@ -317,7 +317,7 @@ int  jwas_hip_sweep_sharded(jwas_hip_ctx* ctx, const jwas_sweep_params* params, 
  * inputs, so every rank holds the same effects and its own slice of the residual.  jwas_hip_sweep then IS the exact chain
  * of the pooled data (the sums are formed in a different order than on one GPU, nothing else); r'r / sum r come back summed
  * over the ranks.  Needs the same number of 256-row groups on every rank (pad with zero rows) and the same markers.
- * jwas_hip_comm_init_loopback: test transport -- the ranks are contexts of ONE process driven by different host threads,
+ * jwas_hip_comm_init_loopback: test transport (both sharding modes: jwas_hip_sweep_sharded and the row shards) -- the ranks are contexts of ONE process driven by different host threads,
  * the exchange goes through host memory (slot 0..3 = one group of ranks). */
 int  jwas_hip_comm_row_shards(jwas_hip_ctx* ctx, int32_t enable);
 int  jwas_hip_comm_init_loopback(jwas_hip_ctx* ctx, int32_t slot, int32_t rank, int32_t world);

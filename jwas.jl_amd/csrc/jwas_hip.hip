@@ -2336,6 +2336,11 @@ int jwas_hip_comm_init_loopback(jwas_hip_ctx* c, int32_t slot, int32_t rank, int
         if (g_loop[slot].world != world) { g_loop[slot].world = world; g_loop[slot].part.assign((size_t)world, {}); g_loop[slot].arrived = 0; }
     }
     c->loop_slot = slot; c->comm_rank = rank; c->comm_world = world;
+    if (HAVE_STORAGE(c)) {          // (marker shards through this transport: the reconcile's buffers, as jwas_hip_comm_init makes them)
+        HIPCHK(c, hipSetDevice(c->device));
+        if (!c->r_snap) HIPCHK(c, hipMalloc(&c->r_snap, sizeof(float) * (size_t)kMaxT * c->ld));
+        if (!c->shard_buf) HIPCHK(c, hipMalloc(&c->shard_buf, sizeof(double) * ((size_t)kMaxT * c->ld + kShardStats)));
+    }
     return JWAS_HIP_OK;
 }
 
@@ -2372,7 +2377,8 @@ int jwas_hip_sweep_sharded(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_swe
 {
     if (c) NOT_F64(c, "a sharded sweep");
     NEED(c, c && P && S, JWAS_HIP_EINVAL, "NULL argument");
-    NEED(c, c->comm, JWAS_HIP_ESTATE, "jwas_hip_comm_init has not been called");
+    NEED(c, c->comm || c->loop_slot >= 0, JWAS_HIP_ESTATE, "jwas_hip_comm_init has not been called");
+    NEED(c, c->r_snap && c->shard_buf, JWAS_HIP_ESTATE, "attach the communicator after the rank's marker columns are loaded");
     NEED(c, !c->row_mode, JWAS_HIP_ESTATE, "this communicator runs exact row shards: use jwas_hip_sweep");
     NEED(c, c->method >= 0, JWAS_HIP_ESTATE, "jwas_hip_init_state has not been called");
     const int t = c->ntraits;
@@ -2386,8 +2392,8 @@ int jwas_hip_sweep_sharded(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_swe
     hipLaunchKernelGGL(k_shard_pack, dim3((unsigned)((total + 255) / 256 + 1)), dim3(256), 0, c->stream, t, c->ld, c->r, c->r_snap,
                        c->stat_out, kStatGrid, c->counters, c->shard_buf);
     HIPCHK(c, hipGetLastError());
-    const int r = g_rccl.AllReduce(c->shard_buf, c->shard_buf, (size_t)(total + kShardStats), kNcclFloat64, kNcclSum, c->comm, c->stream);
-    if (r != 0) return fail(c, JWAS_HIP_EHIP, "ncclAllReduce: %s", g_rccl.GetErrorString(r));
+    rc = row_allreduce(c, c->shard_buf, (size_t)(total + kShardStats), true);      // ncclAllReduce(sum, fp64) on the stream, or the loopback transport
+    if (rc) return rc;
     switch (t) {
         case 1: hipLaunchKernelGGL((k_shard_apply<1>), dim3(c->nslices), dim3(256), 0, c->stream, c->w, c->ld, c->r_snap, c->shard_buf, c->r, c->fin_out); break;
         case 2: hipLaunchKernelGGL((k_shard_apply<2>), dim3(c->nslices), dim3(256), 0, c->stream, c->w, c->ld, c->r_snap, c->shard_buf, c->r, c->fin_out); break;

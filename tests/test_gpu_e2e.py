@@ -615,3 +615,87 @@ class _Dummy:
     """Stand-in with the attributes device_genotypes reads before it touches the device."""
     def __init__(self, n, p):
         self.n, self.p, self.block_size, self._weighted = n, p, 64, False
+
+
+@pytest.mark.parametrize("method,nranks", [("BayesC", 2), ("BayesR", 3), ("BayesC", 4)])
+def test_library_sharded_sweep_with_several_ranks_over_the_loopback_transport(method, nranks):
+    """jwas_hip_sweep_sharded with MORE THAN ONE rank: marker shards, one context per rank (here engines of one process on
+    different host threads; the all-reduce goes through the loopback transport, the same call site RCCL uses).  Per sweep
+    every rank sweeps its own markers from the same residual snapshot, packs (fl64(r_local) - fl64(r_snapshot), its marker
+    statistics), ONE all-reduce, r = fl32(r_snapshot + sum): the reference's independent-block reconcile (BayesABC.jl:205-253)
+    with one block per rank.  Against a single-process emulation on the oracle: the reconciled residual is the same on every
+    rank bit for bit, the shards' chains equal the oracle's (indicators exactly), the statistics are the all-rank sums."""
+    import threading
+    import jwas_jl_amd as J
+    from jwas_jl_amd.dist import shard_range
+    bs = 64
+    d = make_dataset(n=700, p=64 * 7 + 30, ncausal=8, seed=60 + nranks)
+    X, p = d["X"], d["X"].shape[1]
+    y = (d["y"] - d["y"].mean()).astype(np.float32)
+    if method == "BayesR":
+        kw = dict(vare=np.float32(0.5), var_effect=np.float32(0.05), pi_classes=np.array([0.9, 0.05, 0.03, 0.02]))
+    else:
+        kw = dict(vare=np.float32(0.5), var_effect=np.float32(0.004), pi=0.9)
+    shards = [shard_range(p, r, nranks, bs) for r in range(nranks)]
+    nsweeps = 5
+    # ---- emulation on the oracle: every shard from the same snapshot, then the reconcile
+    orcs = []
+    for lo, hi in shards:
+        o = OracleEngine("lookahead")
+        o.load_dense(np.asfortranarray(X[:, lo:hi])); o.setup_blocks(bs); o.init_state(method, 1)
+        if method == "BayesR":
+            o.set_state(0, delta=np.ones(hi - lo, dtype=np.int32))
+        orcs.append(o)
+    r = y.copy()
+    ref_stats = []
+    for it in range(1, nsweeps + 1):
+        snap = r.copy()
+        tot = np.zeros(len(r), dtype=np.float64)
+        nev, sd = 0.0, 0.0
+        for o, (lo, hi) in zip(orcs, shards):
+            o.set_residual(snap)
+            st = o.sweep(iteration=it, seed=31, marker_offset=lo, **kw)
+            tot += o.get_residual().astype(np.float64) - snap.astype(np.float64)
+            nev += st["n_events"]; sd += st["sum_delta"][0] if method != "BayesR" else st["class_counts"][1:].sum()
+        r = (snap.astype(np.float64) + tot).astype(np.float32)
+        ref_stats.append((nev, sd, float(r.astype(np.float64) @ r.astype(np.float64))))
+    # ---- the library, one thread per rank
+    out, errs = [None] * nranks, []
+
+    def run(rank):
+        try:
+            lo, hi = shards[rank]
+            e = J.HipEngine(0)
+            e.load_dense(np.asfortranarray(X[:, lo:hi]))
+            e.comm_init_loopback(2, rank, nranks)
+            assert e.comm_info() == (rank, nranks)
+            e.setup_blocks(bs, "f64"); e.init_state(method, 1)
+            if method == "BayesR":
+                e.set_state(0, delta=np.ones(hi - lo, dtype=np.int32))
+            e.set_residual(y)
+            sts = [e.sweep_sharded(iteration=it, seed=31, marker_offset=lo, **kw) for it in range(1, nsweeps + 1)]
+            out[rank] = (e.get_state(0), e.get_residual(0), sts)
+            e.close()
+        except Exception as ex:                          # noqa: BLE001
+            errs.append((rank, repr(ex)))
+
+    th = [threading.Thread(target=run, args=(rk,)) for rk in range(nranks)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join(timeout=300)
+    assert not errs, errs
+    assert all(o is not None for o in out)
+    for rk in range(nranks):
+        assert np.array_equal(out[rk][1], out[0][1])                                  # the same reconciled residual everywhere
+        ao, bo, do = orcs[rk].get_state(0)
+        a, b_, dl = out[rk][0]
+        assert np.array_equal(dl, do)
+        np.testing.assert_allclose(a, ao, rtol=0, atol=5e-6)
+        for it in range(nsweeps):
+            st = out[rk][2][it]
+            assert st["n_events"] == ref_stats[it][0]                                 # all-rank sums on every rank
+            got_sd = st["sum_delta"][0] if method != "BayesR" else st["class_counts"][1:].sum()
+            assert got_sd == ref_stats[it][1]
+            assert st["resid_ss"][0, 0] == pytest.approx(ref_stats[it][2], rel=2e-5)
+    np.testing.assert_allclose(out[0][1], r, rtol=0, atol=1e-4)
