@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void k64_update_partial(const double* __restri
                                                           const Events64* __restrict__ ev, int64_t j0, int b,
                                                           double* __restrict__ partials /* [NT][nslices][kMaxBlock64] */)
 {
-    __shared__ double red[4][8 * NT];
+    __shared__ double red[2][4][8 * NT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t row = (int64_t)blockIdx.x * 256 + tid;
     const int nslices = gridDim.x;
@@ -99,26 +99,35 @@ __global__ __launch_bounds__(256) void k64_update_partial(const double* __restri
 #pragma unroll
         for (int t = 0; t < NT; ++t) r[(int64_t)t * ld + row] = rv[t];
     }
-    // partial right-hand sides, 8 columns at a time (transposed butterfly: 8 wave sums for ~10 shuffle-adds)
-    for (int c0 = 0; c0 < b; c0 += 8) {
+    // partial right-hand sides, 8 columns at a time (transposed butterfly: 8 wave sums for ~10 shuffle-adds); the next
+    // batch's loads are in flight while this one is reduced, and the cross-wave scratch is double-buffered (one barrier per
+    // batch)
+    double xn[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) xn[u] = (u < b) ? X[(j0 + u) * ld + row] : 0.0;
+    int ph = 0;
+    for (int c0 = 0; c0 < b; c0 += 8, ph ^= 1) {
         double xv[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) xv[u] = (c0 + u < b) ? X[(j0 + c0 + u) * ld + row] : 0.0;
+        for (int u = 0; u < 8; ++u) xv[u] = xn[u];
+        if (c0 + 8 < b) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xn[u] = (c0 + 8 + u < b) ? X[(j0 + c0 + 8 + u) * ld + row] : 0.0;
+        }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             double v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) v[u] = xv[u] * rv[t];
             const double s = butterfly8(v, lane);                 // lane l: column ((l>>5)&1)*4 + ((l>>4)&1)*2 + ((l>>3)&1)
-            if ((lane & 7) == 0) red[wave][(lane >> 3) * NT + t] = s;
+            if ((lane & 7) == 0) red[ph][wave][(lane >> 3) * NT + t] = s;
         }
         __syncthreads();
         if (tid < 8 * NT) {
             const int u = tid / NT, t = tid - u * NT;
             if (c0 + u < b)
-                partials[((int64_t)t * nslices + blockIdx.x) * kMaxBlock64 + c0 + u] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+                partials[((int64_t)t * nslices + blockIdx.x) * kMaxBlock64 + c0 + u] = (red[ph][0][tid] + red[ph][1][tid]) + (red[ph][2][tid] + red[ph][3][tid]);
         }
-        __syncthreads();
     }
 }
 
@@ -198,8 +207,15 @@ __global__ __launch_bounds__(256) void k64_sample(const Params64* __restrict__ P
     for (int i = tid; i < b * b; i += 256) G[i] = gram[i];
     for (int i = tid; i < NT * b; i += 256) {
         const int t = i / b, c = i - t * b;
+        const double* pp = partials + (int64_t)t * nslices * kMaxBlock64 + c;
         double s = 0.0;
-        for (int sl = 0; sl < nslices; ++sl) s += partials[((int64_t)t * nslices + sl) * kMaxBlock64 + c];      // fixed order
+        for (int sl0 = 0; sl0 < nslices; sl0 += 16) {          // 16 independent loads in flight, summed in slice order (fixed order)
+            double v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = pp[(int64_t)(sl0 + u < nslices ? sl0 + u : nslices - 1) * kMaxBlock64];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) if (sl0 + u < nslices) s += v[u];
+        }
         rhs[t * kMaxBlock64 + c] = s;
     }
     __syncthreads();

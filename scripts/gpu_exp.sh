@@ -1,2 +1,4 @@
 #!/bin/bash
-timeout 1500 python -m pytest tests/test_gpu_e2e.py -q -x -k "loopback or sharded or shard" 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl\|bringing" | tail -15
+mkdir -p gpurun_out/r03f64
+timeout 600 python -m pytest tests/test_gpu_f64.py -q -x 2>&1 | tail -2
+timeout 1200 python scripts/f64_bench.py 20000 20000 2>/dev/null | tail -1 | tee gpurun_out/r03f64/f64_bench.json
