@@ -65,10 +65,18 @@ enum {
                                /* joint indicator state; candidate states in bitmask order       */
     JWAS_HIP_MEGABAYESC = 5,   /* megaBayesABC! (BayesABC.jl:1-8, G.constraint = true): t         */
                                /* independent single-trait BayesC chains sharing one pass over X */
-    JWAS_HIP_MTBAYESB1 = 6     /* multi-trait BayesA/B, Gibbs sampler I with ONE t x t effect      */
+    JWAS_HIP_MTBAYESB1 = 6,    /* multi-trait BayesA/B, Gibbs sampler I with ONE t x t effect      */
                                /* covariance PER MARKER (locus_effect_variances[marker],           */
-                               /* MTBayesABC.jl:66,86-90; drawn per marker on the host,             */
-                               /* variance_components.jl:181-186): jwas_sweep_params.var_effect_matrix */
+                               /* MTBayesABC.jl:66,86-90; variance_components.jl:181-186):          */
+                               /* jwas_sweep_params.var_effect_matrix, or drawn on the device by    */
+                               /* jwas_hip_sample_marker_covariances                                 */
+    JWAS_HIP_MTBAYESB2 = 7,    /* multi-trait BayesA/B under Gibbs sampler II (a Pi that lists fewer */
+                               /* than 2^t states with multi_trait_sampler = :auto, MTBayesABC.jl:   */
+                               /* 20-25,129-210 with Ginv[marker]); covariances as for MTBAYESB1     */
+    JWAS_HIP_MEGABAYESB = 8    /* megaBayesABC! with BayesA/B (BayesABC.jl:1-8, G.constraint = true): */
+                               /* t independent single-trait chains, trait k of marker j with        */
+                               /* variance var_effect_matrix[j][k][k] (off-diagonals ignored);       */
+                               /* jwas_hip_sample_marker_covariances then draws the diagonal only    */
 };
 
 /* Genotype storage kinds (Genotypes.storage_mode in the reference, types.jl:149-150). */

@@ -10,12 +10,14 @@ module JWASHip
 
 export HipBackend, HipSweepParams, HipSweepStats, hip_sweep!, hip_sweep_sharded!, hip_comm_unique_id, hip_comm_init!, hip_comm_info, hip_residual_add_scalar!,
        hip_setup_blocks!, hip_set_residual!, hip_get_residual!, hip_accumulate!, hip_posterior, hip_mul_alpha, JWAS_HIP_BAYESC,
-       JWAS_HIP_BAYESB, JWAS_HIP_BAYESR, JWAS_HIP_MTBAYESC1, JWAS_HIP_MTBAYESC2, JWAS_HIP_MEGABAYESC, JWAS_HIP_MTBAYESB1
+       JWAS_HIP_BAYESB, JWAS_HIP_BAYESR, JWAS_HIP_MTBAYESC1, JWAS_HIP_MTBAYESC2, JWAS_HIP_MEGABAYESC, JWAS_HIP_MTBAYESB1,
+       JWAS_HIP_MTBAYESB2, JWAS_HIP_MEGABAYESB
 
 const LIBJWAS_HIP = get(ENV, "JWAS_HIP_LIB", "libjwas_hip.so")
 
 const JWAS_HIP_BAYESC, JWAS_HIP_BAYESB, JWAS_HIP_BAYESR = Int32(0), Int32(1), Int32(2)
 const JWAS_HIP_MTBAYESC1, JWAS_HIP_MTBAYESC2, JWAS_HIP_MEGABAYESC, JWAS_HIP_MTBAYESB1 = Int32(3), Int32(4), Int32(5), Int32(6)
+const JWAS_HIP_MTBAYESB2, JWAS_HIP_MEGABAYESB = Int32(7), Int32(8)     # BayesA/B under sampler II / constraint = true
 const JWAS_HIP_GRAM_F64, JWAS_HIP_GRAM_MFMA = Int32(0), Int32(1)
 
 # mirrors of struct jwas_sweep_params / jwas_sweep_stats (isbits, same field order; JWAS_HIP_MAX_TRAITS = 4)

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libjwas_hip.so")
 MAX_TRAITS = 4
 MAX_STATES = 16
 
-BAYESC, BAYESB, BAYESR, MTBAYESC1, MTBAYESC2, MEGABAYESC, MTBAYESB1 = 0, 1, 2, 3, 4, 5, 6
+BAYESC, BAYESB, BAYESR, MTBAYESC1, MTBAYESC2, MEGABAYESC, MTBAYESB1, MTBAYESB2, MEGABAYESB = 0, 1, 2, 3, 4, 5, 6, 7, 8
 GRAM_F64, GRAM_MFMA = 0, 1
 
 # every symbol include/jwas_hip.h declares (checked by tests/test_abi.py)

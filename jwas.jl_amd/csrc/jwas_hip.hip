@@ -897,7 +897,7 @@ int jwas_hip_init_state(jwas_hip_ctx* c, int32_t method, int32_t nt)
     if (c && IS_F64(c)) return f64_init_state(c, method, nt);
     NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
     NEED(c, HAVE_STORAGE(c), JWAS_HIP_ESTATE, "no genotype matrix loaded");
-    NEED(c, method >= JWAS_HIP_BAYESC && method <= JWAS_HIP_MTBAYESB1, JWAS_HIP_EINVAL, "unknown method %d", method);
+    NEED(c, method >= JWAS_HIP_BAYESC && method <= JWAS_HIP_MEGABAYESB, JWAS_HIP_EINVAL, "unknown method %d", method);
     if (method >= JWAS_HIP_MTBAYESC1) NEED(c, nt >= 2 && nt <= kMaxT, JWAS_HIP_EUNSUP, "multi-trait samplers support 2..%d traits (got %d)", kMaxT, nt);
     else NEED(c, nt == 1, JWAS_HIP_EINVAL, "single-trait method requires ntraits == 1 (got %d)", nt);
     HIPCHK(c, hipSetDevice(c->device));
@@ -1253,7 +1253,7 @@ static hipError_t launch_step_cx(jwas_hip_ctx* c, const CX& cx, const UpdateArgs
     U.cx = cx;
     constexpr bool kHasDense = (METHOD == kBayesC || METHOD == kBayesB) && NT == 1;       // sweeps under a uniform pi = 0 (Rule D)
     const bool dn = kHasDense && dense;
-    const StepSmem SM(c->block_size, NT, is_mt_method(METHOD) ? mt_park_nd(c->block_size, NT) + (S.lpr_mat ? (1 << NT) : 0) : st_park_nd(METHOD), is_mt_method(METHOD) ? mt_park_nf(c->block_size, NT) + (METHOD == kMTBayesB1 ? NT * NT : 0) : st_park_nf(METHOD, dn));
+    const StepSmem SM(c->block_size, NT, is_mt_method(METHOD) ? mt_park_nd(c->block_size, NT) + (S.lpr_mat ? (1 << NT) : 0) : st_park_nd(METHOD), is_mt_method(METHOD) ? mt_park_nf(c->block_size, NT) + (has_marker_cov(METHOD) ? NT * NT : 0) : st_park_nf(METHOD, dn));
     static unsigned long long attr_set = 0ull;       // one bit per device: the attribute belongs to the device's code object
     const unsigned long long dev_bit = 1ull << (c->device & 63);
     if (!(attr_set & dev_bit)) {   // allow > 64 KB of dynamic LDS
@@ -1328,6 +1328,8 @@ static hipError_t launch_step_any(jwas_hip_ctx* c, const UpdateArgs& U, const Sa
         case JWAS_HIP_MTBAYESC2: JW_MT_STEP(kMTBayesC2)
         case JWAS_HIP_MEGABAYESC: JW_MT_STEP(kMegaBayesC)
         case JWAS_HIP_MTBAYESB1: JW_MT_STEP(kMTBayesB1)
+        case JWAS_HIP_MTBAYESB2: JW_MT_STEP(kMTBayesB2)
+        case JWAS_HIP_MEGABAYESB: JW_MT_STEP(kMegaBayesB)
         default: JW_MT_STEP(kMTBayesC1)
 #undef JW_MT_STEP
     }
@@ -1351,7 +1353,7 @@ static hipError_t launch_indep_cx(jwas_hip_ctx* c, const CX& cx, const UpdateArg
     U.cx = cx;
     constexpr bool kHasDense = (METHOD == kBayesC || METHOD == kBayesB) && NT == 1;       // sweeps under a uniform pi = 0 (Rule D)
     const bool dn = kHasDense && dense;
-    const StepSmem SM(c->block_size, NT, is_mt_method(METHOD) ? mt_park_nd(c->block_size, NT) + (S.lpr_mat ? (1 << NT) : 0) : st_park_nd(METHOD), is_mt_method(METHOD) ? mt_park_nf(c->block_size, NT) + (METHOD == kMTBayesB1 ? NT * NT : 0) : st_park_nf(METHOD, dn));
+    const StepSmem SM(c->block_size, NT, is_mt_method(METHOD) ? mt_park_nd(c->block_size, NT) + (S.lpr_mat ? (1 << NT) : 0) : st_park_nd(METHOD), is_mt_method(METHOD) ? mt_park_nf(c->block_size, NT) + (has_marker_cov(METHOD) ? NT * NT : 0) : st_park_nf(METHOD, dn));
     static unsigned long long attr_set = 0ull;       // one bit per device
     const unsigned long long dev_bit = 1ull << (c->device & 63);
     if (!(attr_set & dev_bit)) {
@@ -1416,7 +1418,7 @@ static int sweep_independent(jwas_hip_ctx* c, EventList* out, bool dense, int de
     S.p = c->p; S.bsz = bs; S.xpx = c->xpx; S.gram = c->gram;
     S.cross_next = c->gram; S.b_next = 0; S.corr_in = c->corr; S.corr_out = c->corr + (size_t)kMaxT * bs;
     S.prep_d = c->prep_d; S.prep_f = c->prep_f; S.mt2_tab = c->mt2_tab; S.lpr_mat = c->lpr_active ? c->lpr_mat : nullptr;
-    S.ginv_mat = c->method == JWAS_HIP_MTBAYESB1 ? c->ginv_mat : nullptr;
+    S.ginv_mat = has_marker_cov(c->method) ? c->ginv_mat : nullptr;
     S.alpha = c->alpha; S.beta = c->beta; S.delta = c->delta;
     S.counters = c->counters;
     S.dense_big_off = dense_big_off;
@@ -1637,30 +1639,33 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
     HIPCHK(c, hipSetDevice(c->device));
 
     DevParams D;
-    c->lpr_active = is_mt_method(c->method) && c->method != JWAS_HIP_MEGABAYESC && c->method != JWAS_HIP_MTBAYESB1 && P->log_prior_states_matrix != nullptr;
+    c->lpr_active = is_mt_method(c->method) && !is_mega(c->method) && !has_marker_cov(c->method) && P->log_prior_states_matrix != nullptr;
     std::memset(&D, 0, sizeof D);
     D.method = c->method; D.ntraits = t; D.nreps = P->nreps;
     D.iter = P->iteration; D.seed_lo = (uint32_t)P->seed; D.seed_hi = (uint32_t)(P->seed >> 32); D.marker0 = P->marker_offset;
     for (int i = 0; i < t * t; ++i) { D.vare[i] = P->vare[i]; D.var_effect[i] = P->var_effect[i]; }
-    if (c->method == JWAS_HIP_MTBAYESC1 || c->method == JWAS_HIP_MTBAYESC2 || c->method == JWAS_HIP_MTBAYESB1) {
+    const bool marker_cov = has_marker_cov(c->method);
+    if (marker_cov) {
+        // multi-trait BayesA/B: one effect covariance per marker (locus_effect_variances, MTBayesABC.jl:66; with
+        // constraint = true its diagonal, BayesABC.jl:5); inverted on the device by k_prepare (the constrained form keeps the
+        // variances), parked in LDS beside the marker's draws
+        NEED(c, P->var_effect_matrix || c->var_mat_resident, JWAS_HIP_EINVAL, "multi-trait BayesA/B needs per-marker effect covariances (var_effect_matrix, or jwas_hip_sample_marker_covariances)");
+        NEED(c, !P->independent_blocks, JWAS_HIP_EUNSUP, "independent_blocks is not available with per-marker effect covariances");
+        NEED(c, !P->log_prior_states_matrix, JWAS_HIP_EUNSUP, "marker-specific joint priors are not available with per-marker effect covariances");
+        NEED(c, mt_park_nf(c->block_size, t) != 0, JWAS_HIP_EUNSUP, "per-marker effect covariances need block_size * ntraits <= 2048 (got %d x %d)", c->block_size, t);
+        const size_t mb = sizeof(float) * (size_t)t * t * c->p;
+        if (P->var_effect_matrix) { int rc = upload_vec(c, (void**)&c->var_mat, P->var_effect_matrix, mb); if (rc) return rc; c->var_mat_resident = true; }
+        if (!c->ginv_mat) HIPCHK(c, hipMalloc(&c->ginv_mat, mb));
+        D.var_mat = c->var_mat; D.ginv_mat = c->ginv_mat;
+        for (int i = 0; i < t * t; ++i) D.Ginv[i] = (i / t == i % t) ? 1.f : 0.f;       // (unused)
+    }
+    if (is_mt_method(c->method) && !is_mega(c->method)) {
         NEED(c, inv_small(P->vare, t, D.Rinv) == 0, JWAS_HIP_EINVAL, "residual covariance matrix is singular");
-        if (c->method == JWAS_HIP_MTBAYESB1) {
-            // multi-trait BayesA/B: one effect covariance per marker (locus_effect_variances, MTBayesABC.jl:66); inverted on
-            // the device by k_prepare, parked in LDS beside the marker's draws
-            NEED(c, P->var_effect_matrix || c->var_mat_resident, JWAS_HIP_EINVAL, "multi-trait BayesA/B needs per-marker effect covariances (var_effect_matrix, or jwas_hip_sample_marker_covariances)");
-            NEED(c, !P->independent_blocks, JWAS_HIP_EUNSUP, "independent_blocks is not available with per-marker effect covariances");
-            NEED(c, !P->log_prior_states_matrix, JWAS_HIP_EUNSUP, "marker-specific joint priors are not available with per-marker effect covariances");
-            NEED(c, mt_park_nf(c->block_size, t) != 0, JWAS_HIP_EUNSUP, "per-marker effect covariances need block_size * ntraits <= 2048 (got %d x %d)", c->block_size, t);
-            const size_t mb = sizeof(float) * (size_t)t * t * c->p;
-            if (P->var_effect_matrix) { int rc = upload_vec(c, (void**)&c->var_mat, P->var_effect_matrix, mb); if (rc) return rc; c->var_mat_resident = true; }
-            if (!c->ginv_mat) HIPCHK(c, hipMalloc(&c->ginv_mat, mb));
-            D.var_mat = c->var_mat; D.ginv_mat = c->ginv_mat;
-            for (int i = 0; i < t * t; ++i) D.Ginv[i] = (i / t == i % t) ? 1.f : 0.f;       // (unused)
-        } else
-        NEED(c, inv_small(P->var_effect, t, D.Ginv) == 0, JWAS_HIP_EINVAL, "marker effect covariance matrix is singular");
+        if (!marker_cov)
+            NEED(c, inv_small(P->var_effect, t, D.Ginv) == 0, JWAS_HIP_EINVAL, "marker effect covariance matrix is singular");
         bool any_finite = false;
         for (int i = 0; i < (1 << t); ++i) { D.log_prior[i] = P->log_prior_states[i]; any_finite = any_finite || std::isfinite(D.log_prior[i]); }
-        if (c->method == JWAS_HIP_MTBAYESC2 && !P->log_prior_states_matrix)      // MTBayesABC.jl:190
+        if ((c->method == JWAS_HIP_MTBAYESC2 || c->method == JWAS_HIP_MTBAYESB2) && !P->log_prior_states_matrix)      // MTBayesABC.jl:190
             NEED(c, any_finite, JWAS_HIP_EINVAL, "All MTBayesABC sampler II state probabilities are zero or invalid.");
         if (P->log_prior_states_matrix) {          // MarkerSpecificPiPrior (MTBayesABC.jl:22-47)
             NEED(c, t == 2, JWAS_HIP_EUNSUP, "marker-specific joint priors support 2 traits (got %d)", t);
@@ -1668,11 +1673,11 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
             int rc = upload_vec(c, (void**)&c->lpr_mat, P->log_prior_states_matrix, sizeof(double) * (size_t)(1 << t) * c->p);
             if (rc) return rc;
         }
-    } else if (c->method == JWAS_HIP_MEGABAYESC) {
-        // megaBayesABC! (BayesABC.jl:1-8): trait k uses vare[k,k], var_effect[k,k] and its own pi (pi_classes[k])
+    } else if (is_mega(c->method)) {
+        // megaBayesABC! (BayesABC.jl:1-8): trait k uses vare[k,k], var_effect[k,k] (BayesA/B: the marker's own) and its own pi (pi_classes[k])
         for (int k = 0; k < t; ++k) {
             NEED(c, P->vare[k * t + k] > 0.f, JWAS_HIP_EINVAL, "residual variance must be positive");
-            NEED(c, P->var_effect[k * t + k] > 0.f, JWAS_HIP_EINVAL, "marker effect variance must be positive");
+            NEED(c, marker_cov || P->var_effect[k * t + k] > 0.f, JWAS_HIP_EINVAL, "marker effect variance must be positive");
             NEED(c, P->pi_classes[k] >= 0.0 && P->pi_classes[k] <= 1.0, JWAS_HIP_EINVAL, "pi must lie in [0,1]");
             D.pi4[k] = P->pi_classes[k];
         }
@@ -1720,6 +1725,8 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
                 JW_MT_PREP(kMTBayesC2)
             case JWAS_HIP_MEGABAYESC: JW_MT_PREP(kMegaBayesC)
             case JWAS_HIP_MTBAYESB1: JW_MT_PREP(kMTBayesB1)
+            case JWAS_HIP_MTBAYESB2: JW_MT_PREP(kMTBayesB2)
+            case JWAS_HIP_MEGABAYESB: JW_MT_PREP(kMegaBayesB)
             default: JW_MT_PREP(kMTBayesC1)
 #undef JW_MT_PREP
         }
@@ -1798,7 +1805,7 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
             S.corr_in = c->corr + (sb & 1) * (size_t)kMaxT * bs;
             S.corr_out = c->corr + ((sb + 1) & 1) * (size_t)kMaxT * bs;
             S.prep_d = c->prep_d; S.prep_f = c->prep_f; S.mt2_tab = c->mt2_tab; S.lpr_mat = c->lpr_active ? c->lpr_mat : nullptr;
-            S.ginv_mat = c->method == JWAS_HIP_MTBAYESB1 ? c->ginv_mat : nullptr;
+            S.ginv_mat = has_marker_cov(c->method) ? c->ginv_mat : nullptr;
             S.alpha = c->alpha; S.beta = c->beta; S.delta = c->delta;
             S.ev_out = &c->ev[(k - 1) & 1];
             S.counters = c->counters;
@@ -2409,15 +2416,16 @@ int jwas_hip_sample_marker_covariances(jwas_hip_ctx* c, double df, const double*
 {
     if (c) NOT_F64(c, "per-marker effect covariances");
     NEED(c, c && scale, JWAS_HIP_EINVAL, "NULL argument");
-    NEED(c, c->method == JWAS_HIP_MTBAYESB1, JWAS_HIP_ESTATE, "jwas_hip_sample_marker_covariances needs init_state(JWAS_HIP_MTBAYESB1, t)");
+    NEED(c, has_marker_cov(c->method), JWAS_HIP_ESTATE, "jwas_hip_sample_marker_covariances needs init_state(JWAS_HIP_MTBAYESB1 | JWAS_HIP_MTBAYESB2 | JWAS_HIP_MEGABAYESB, t)");
     const int t = c->ntraits;
-    NEED(c, df > (double)(t - 1), JWAS_HIP_EINVAL, "inverse-Wishart degrees of freedom must exceed ntraits - 1 (got %g)", df);
+    const bool diag = is_mega(c->method);           // constraint = true: scaled inverse chi-square draws of the diagonal only
+    NEED(c, df > (diag ? 0.0 : (double)(t - 1)), JWAS_HIP_EINVAL, "inverse-Wishart degrees of freedom must exceed ntraits - 1 (got %g)", df);
     HIPCHK(c, hipSetDevice(c->device));
     const size_t mb = sizeof(float) * (size_t)t * t * c->p;
     if (!c->var_mat) HIPCHK(c, hipMalloc(&c->var_mat, mb));
     IwParams Q;
     std::memset(&Q, 0, sizeof Q);
-    Q.df = df;
+    Q.df = df; Q.diagonal = diag ? 1 : 0;
     for (int i = 0; i < t * t; ++i) Q.scale[i] = scale[i];
     Q.seed_lo = (uint32_t)seed; Q.seed_hi = (uint32_t)(seed >> 32); Q.iter = iteration; Q.marker0 = marker_offset;
     const dim3 g((unsigned)((c->p + 255) / 256)), b(256);

@@ -34,11 +34,16 @@ constexpr int kMaxBlock  = 1024;     // largest marker block
 constexpr int kMaxT      = 4;        // traits
 constexpr int kMaxStates = 16;
 
-enum Method { kBayesC = 0, kBayesB = 1, kBayesR = 2, kMTBayesC1 = 3, kMTBayesC2 = 4, kMegaBayesC = 5, kMTBayesB1 = 6 };
+enum Method { kBayesC = 0, kBayesB = 1, kBayesR = 2, kMTBayesC1 = 3, kMTBayesC2 = 4, kMegaBayesC = 5, kMTBayesB1 = 6, kMTBayesB2 = 7, kMegaBayesB = 8 };
 __host__ __device__ constexpr bool is_mt_method(int m) { return m >= kMTBayesC1; }
 // Gibbs sampler I; kMTBayesB1 = the same sampler with a t x t effect covariance PER MARKER (multi-trait BayesA/B:
 // locus_effect_variances[marker], MTBayesABC.jl:66,86-90)
 __host__ __device__ constexpr bool is_sampler1(int m) { return m == kMTBayesC1 || m == kMTBayesB1; }
+// sampler II (joint state); kMTBayesB2 = sampler II with a t x t effect covariance per marker (multi-trait BayesA/B, multi_trait_sampler = :II)
+__host__ __device__ constexpr bool is_sampler2(int m) { return m == kMTBayesC2 || m == kMTBayesB2; }
+__host__ __device__ constexpr bool has_marker_cov(int m) { return m == kMTBayesB1 || m == kMTBayesB2 || m == kMegaBayesB; }
+// megaBayesABC! (t independent single-trait chains); kMegaBayesB: with every marker's own diagonal variances (BayesA/B)
+__host__ __device__ constexpr bool is_mega(int m) { return m == kMegaBayesC || m == kMegaBayesB; }
 
 // Effect changes of one marker block, consumed by the next k_update_partial.
 struct Events {
@@ -708,10 +713,14 @@ __global__ __launch_bounds__(256) void k_prepare(const DevParams* __restrict__ P
     const uint32_t marker = P->marker0 + (uint32_t)j;
     if constexpr (is_mt_method(METHOD)) {
         float Gi[NT * NT];
-        if constexpr (METHOD == kMTBayesB1) {                       // this marker's own covariance: invert it once per sweep
+        if constexpr (has_marker_cov(METHOD)) {                     // this marker's own covariance: invert it once per sweep
             float Gj[NT * NT];
 #pragma unroll
             for (int i = 0; i < NT * NT; ++i) Gj[i] = P->var_mat[j * (NT * NT) + i];
+            if constexpr (is_mega(METHOD)) {                        // constraint = true: the sampler reads the diagonal variances themselves
+#pragma unroll
+                for (int i = 0; i < NT * NT; ++i) Gi[i] = Gj[i];
+            } else
             inv_small_dev<NT>(Gj, Gi);
 #pragma unroll
             for (int i = 0; i < NT * NT; ++i) P->ginv_mat[j * (NT * NT) + i] = Gi[i];
@@ -722,13 +731,13 @@ __global__ __launch_bounds__(256) void k_prepare(const DevParams* __restrict__ P
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const double u = draw_uniform(key, marker, (uint32_t)t);
-            prep_d[(int64_t)t * p + j] = (METHOD == kMTBayesC2) ? u : log((1.0 - u) / u);   // sampler II keeps the raw uniform
+            prep_d[(int64_t)t * p + j] = is_sampler2(METHOD) ? u : log((1.0 - u) / u);   // sampler II keeps the raw uniform
             prep_d[(int64_t)(NT + t) * p + j] = draw_normal(key, marker, (uint32_t)t);
             // log of the marker's "in the model" left-hand side (depends on x'x and this sweep's variances only): the
             // double-precision log is taken here, for all markers in parallel, not inside the serial sampler
             const float dj = xpx[j];
-            if constexpr (METHOD == kMegaBayesC) {
-                const float var = P->var_effect[t * NT + t];
+            if constexpr (is_mega(METHOD)) {
+                const float var = (METHOD == kMegaBayesB) ? Gi[t * NT + t] : P->var_effect[t * NT + t];
                 const float lhs = dj * (1.0f / P->vare[t * NT + t]) + 1.0f / var;                     // BayesABC.jl:37
                 prep_f[(int64_t)t * p + j] = logf_via_double(lhs) + logf_via_double(var);
             } else {

@@ -34,7 +34,7 @@ __device__ __forceinline__ MtPre<NT> mt_precompute(const MtConsts<NT>& K, float 
     MtPre<NT> R;
 #pragma unroll
     for (int k = 0; k < NT; ++k) {
-        if constexpr (METHOD == kMegaBayesC) {
+        if constexpr (is_mega(METHOD)) {
             R.C11[k] = dj * K.ie[k] + K.iv[k];                                     // BayesABC.jl:37
             R.invLhs1[k] = 1.0f / R.C11[k];                                        // :38
         } else {
@@ -261,7 +261,7 @@ __device__ __forceinline__ double iw_chi2(uint32_t marker, uint32_t iter, uint32
     return 2.0 * g * boost;
 }
 
-struct IwParams { double df; double scale[kMaxT * kMaxT]; uint32_t seed_lo, seed_hi, iter, marker0; };
+struct IwParams { double df; double scale[kMaxT * kMaxT]; uint32_t seed_lo, seed_hi, iter, marker0; int diagonal; };
 
 template <int NT>
 __global__ __launch_bounds__(256) void k_sample_marker_covariances(IwParams Q, int64_t p, const float* __restrict__ beta, float* __restrict__ var_mat)
@@ -272,6 +272,15 @@ __global__ __launch_bounds__(256) void k_sample_marker_covariances(IwParams Q, i
     double b[NT], S[NT][NT], C[NT][NT], A[NT][NT], Kt[NT][NT];
 #pragma unroll
     for (int a = 0; a < NT; ++a) b[a] = (double)beta[(int64_t)a * p + j];
+    if (Q.diagonal) {       // constraint = true (variance_components.jl:112-117): G_kk = (scale_kk + b_k^2) / chi2(df), zeros elsewhere
+#pragma unroll
+        for (int a = 0; a < NT; ++a) {
+            const double g = (Q.scale[a * NT + a] + b[a] * b[a]) / iw_chi2(marker, Q.iter, 32u + 2u * (uint32_t)a, Q.seed_lo, Q.seed_hi, Q.df);
+#pragma unroll
+            for (int c = 0; c < NT; ++c) var_mat[(j * NT + a) * NT + c] = (c == a) ? (float)g : 0.0f;
+        }
+        return;
+    }
 #pragma unroll
     for (int a = 0; a < NT; ++a)
 #pragma unroll
@@ -567,7 +576,7 @@ template <int METHOD, int NT>
 __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A)
 {
     const bool pm = A.lpr_mat != nullptr;           // marker-specific joint priors (host: only with parked draws)
-    constexpr bool kPG = (METHOD == kMTBayesB1);    // a t x t effect covariance per marker (host: only with parked draws)
+    constexpr bool kPG = has_marker_cov(METHOD);   // a t x t effect covariance per marker (host: only with parked draws)
     const StepSmem SM(A.bsz, NT, mt_park_nd(A.bsz, NT) + (pm ? (1 << NT) : 0), mt_park_nf(A.bsz, NT) + (kPG ? NT * NT : 0));
     const int B = SM.B;
     const bool parked = mt_park_nd(B, NT) != 0;
@@ -596,7 +605,7 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
         K.invG[a] = 1.0f / K.Ginv[a][a];                            // MTBayesABC.jl:92
         K.lG[a] = logf_via_double(K.Ginv[a][a]);
         K.sG[a] = sqrtf(K.invG[a]);
-        if constexpr (METHOD == kMegaBayesC) {
+        if constexpr (is_mega(METHOD)) {
             K.ie[a]  = 1.0f / P->vare[a * NT + a];                  // invVarRes          BayesABC.jl:69
             K.var[a] = P->var_effect[a * NT + a];
             K.iv[a]  = 1.0f / K.var[a];                             // invVarEffects[j]   :70
@@ -609,6 +618,15 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
     // multi-trait BayesA/B: the constants that depend on G are the marker's own (its inverse was formed by k_prepare)
     auto with_ginv = [&](const float (&g)[NT * NT]) {
         MtConsts<NT> Kj = K;
+        if constexpr (is_mega(METHOD)) {                                // (the parked matrix is the marker's variances)
+#pragma unroll
+            for (int a = 0; a < NT; ++a) {
+                Kj.var[a] = g[a * NT + a];
+                Kj.iv[a]  = 1.0f / Kj.var[a];                           // invVarEffects[j]   BayesABC.jl:70
+                Kj.sv[a]  = sqrtf(Kj.var[a]);
+            }
+            return Kj;
+        }
 #pragma unroll
         for (int a = 0; a < NT; ++a) {
 #pragma unroll
@@ -759,8 +777,8 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
                 mt2_load_tab<NT>(A.mt2_tab, p, j0 + c, T);
                 mt2_eval_tab<NT>(K, lpr_of(c), ls, w0[q], T, thr0[q][0], z0[q], an, bn, dn, Dl);
             }
-            else if constexpr (METHOD == kMTBayesC2) mt2_eval<NT>(K, lpr_of(c), ls, w0[q], dj, thr0[q][0], z0[q], an, bn, dn, Dl);
-            else mega_eval<NT>(K, Q0, w0[q], dj, thr0[q], z0[q], an, bn, dn, Dl);
+            else if constexpr (is_sampler2(METHOD)) mt2_eval<NT>(Kc, lpr_of(c), ls, w0[q], dj, thr0[q][0], z0[q], an, bn, dn, Dl);
+            else mega_eval<NT>(Kc, Q0, w0[q], dj, thr0[q], z0[q], an, bn, dn, Dl);
 #pragma unroll
             for (int t = 0; t < NT; ++t) moves = moves || (Dl[t] != 0.f);
             if (!moves) {
@@ -830,7 +848,7 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
     // (all 64 markers at once, each with the w it was walked with) both verifies the speculation and yields the final
     // state -- by Rule L the linear form's own numbers whenever the speculation held; if any marker left the model for a
     // trait the section is walked again from its saved rhs with those markers evaluated the general way.
-    if (METHOD != kMTBayesC2 && nreps == 1 && prestage && nstaged_mt == b && 5 * ncand_all >= 3 * b) {
+    if (!is_sampler2(METHOD) && nreps == 1 && prestage && nstaged_mt == b && 5 * ncand_all >= 3 * b) {
         const float* rows = reinterpret_cast<const float*>(smem + SM.rows_off);
         float rhsq[NT][2], aq[NT][2], bq[NT][2], dq[NT][2], djq[2], wev[2][NT];
         double thrq[NT][2], zq[NT][2];
@@ -863,7 +881,7 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
             // (the shared prior table from registers -- v_cndmask trees instead of the LDS lookup -- was measured: 79 ms
             // per sweep instead of 55 at 3 traits x 20k x 100k; the LDS read overlaps the trait's arithmetic well enough)
             if constexpr (is_sampler1(METHOD)) mt1_eval<NT>(KQ(q), Qq[q], PriorMem{lpr_of(c), ls}, w, djq[q], thr, z, an, bn, dn, Dl);
-            else mega_eval<NT>(K, Qq[q], w, djq[q], thr, z, an, bn, dn, Dl);
+            else mega_eval<NT>(KQ(q), Qq[q], w, djq[q], thr, z, an, bn, dn, Dl);
         };
         // the speculative conditionals = Rule L's linear form (mt1_linear_coeffs): A, c of the lane's own marker are formed once
         // per section; a step is NT^2 fused multiply-adds.  Dl = alpha_old - alpha_new
@@ -1026,7 +1044,7 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
                 }
                 else {
                     const double u = draw_uniform(key, marker, (uint32_t)t);
-                    thr[t] = (METHOD == kMTBayesC2) ? u : log((1.0 - u) / u);
+                    thr[t] = is_sampler2(METHOD) ? u : log((1.0 - u) / u);
                     z[t] = draw_normal(key, marker, (uint32_t)t);
                 }
             }
@@ -1049,8 +1067,8 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
                     for (int t = 0; t < NT; ++t) w[t] = rhs_lds[t * B + c] + dj * a_cur[t];           // :82
                     if constexpr (is_sampler1(METHOD)) mt1_eval<NT>(Km, Qm, PriorMem{lpr_of(c), ls}, w, dj, thr, z, an, bn, dn, Dl);
                     else if constexpr (kTab) mt2_eval_tab<NT>(K, lpr_of(c), ls, w, T, thr[0], z, an, bn, dn, Dl);
-                    else if constexpr (METHOD == kMTBayesC2) mt2_eval<NT>(K, lpr_of(c), ls, w, dj, thr[0], z, an, bn, dn, Dl);
-                    else mega_eval<NT>(K, Qm, w, dj, thr, z, an, bn, dn, Dl);
+                    else if constexpr (is_sampler2(METHOD)) mt2_eval<NT>(Km, lpr_of(c), ls, w, dj, thr[0], z, an, bn, dn, Dl);
+                    else mega_eval<NT>(Km, Qm, w, dj, thr, z, an, bn, dn, Dl);
 #pragma unroll
                     for (int t = 0; t < NT; ++t) is_event = is_event || (Dl[t] != 0.f);
                 }

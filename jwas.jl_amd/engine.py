@@ -22,7 +22,7 @@ from ._lib import JwasHipError, SweepParams, SweepStats
 
 METHOD_CODES = {"BayesC": _lib.BAYESC, "BayesB": _lib.BAYESB, "BayesA": _lib.BAYESB,
                 "BayesR": _lib.BAYESR, "MTBayesC": _lib.MTBAYESC1, "MTBayesC_II": _lib.MTBAYESC2,
-                "MegaBayesC": _lib.MEGABAYESC, "MTBayesB": _lib.MTBAYESB1}
+                "MegaBayesC": _lib.MEGABAYESC, "MTBayesB": _lib.MTBAYESB1, "MTBayesB_II": _lib.MTBAYESB2, "MegaBayesB": _lib.MEGABAYESB}
 BAYESR_GAMMA = np.array([0.0, 0.01, 0.1, 1.0], dtype=np.float64)   # JWAS.jl:12
 
 
@@ -463,6 +463,13 @@ class HipEngine:
             P.var_effect_f64[i] = float(vg64[i])
         P.pi = float(pi) if np.ndim(pi) == 0 else 0.0      # (vector pi: per marker, or per trait for megaBayesABC)
         keep = []
+        if self.method in (_lib.MTBAYESB1, _lib.MTBAYESB2, _lib.MEGABAYESB):     # multi-trait BayesA/B: one t x t effect covariance per marker
+            if var_effect_matrix is not None:     # (None: the covariances resident on the device -- sample_marker_covariances)
+                vm = np.ascontiguousarray(var_effect_matrix, dtype=np.float32)
+                if vm.shape != (self.p, t, t):
+                    raise ValueError(f"var_effect_matrix must be {self.p} x {t} x {t}")
+                keep.append(vm)
+                P.var_effect_matrix = vm.ctypes.data_as(C.POINTER(C.c_float))
         if self.method in (_lib.BAYESC, _lib.BAYESB):
             if np.ndim(pi) == 1:
                 pi_vec = pi
@@ -506,7 +513,7 @@ class HipEngine:
                     raise ValueError(f"BayesR pi vector length {pc.size} must match the number of mixture classes (4).")
                 for k in range(4):
                     P.pi_classes[k] = float(pc[k])
-        elif self.method == _lib.MEGABAYESC:
+        elif self.method in (_lib.MEGABAYESC, _lib.MEGABAYESB):
             # megaBayesABC! (BayesABC.jl:1-8): one pi per trait (genotypes.pi[i])
             pt = np.asarray(pi, dtype=np.float64).reshape(-1)
             if pt.shape != (t,):
@@ -514,13 +521,6 @@ class HipEngine:
             for k in range(t):
                 P.pi_classes[k] = float(pt[k])
         else:
-            if self.method == _lib.MTBAYESB1:     # multi-trait BayesA/B: one t x t effect covariance per marker
-                if var_effect_matrix is not None:     # (None: the covariances resident on the device -- sample_marker_covariances)
-                    vm = np.ascontiguousarray(var_effect_matrix, dtype=np.float32)
-                    if vm.shape != (self.p, t, t):
-                        raise ValueError(f"var_effect_matrix must be {self.p} x {t} x {t}")
-                    keep.append(vm)
-                    P.var_effect_matrix = vm.ctypes.data_as(C.POINTER(C.c_float))
             lp = np.asarray(log_prior_states, dtype=np.float64)
             if lp.ndim == 2:                      # marker-specific joint priors (MarkerSpecificPiPrior, MTBayesABC.jl:22-47)
                 if lp.shape != (self.p, 1 << t):

@@ -181,10 +181,8 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
                                   "the mixed Float64 / Float32 chain stays on the reference")
     if t > 1 and method not in ("BayesC", "RR-BLUP", "BayesB", "BayesA"):
         raise NotImplementedError("multi-trait device path implements BayesC (Gibbs samplers I, II and the constraint=true "
-                                  "megaBayesABC! path) and BayesA/B (sampler I); other methods stay on the reference")
+                                  "megaBayesABC! path) and BayesA/B (the same three); other methods stay on the reference")
     mega = t > 1 and bool(Mi.G.constraint)                              # megaBayesABC! (MCMC_BayesianAlphabet.jl:233-234)
-    if mega and method in ("BayesB", "BayesA"):
-        raise NotImplementedError("multi-trait BayesA/B with constraint=true stays on the reference")
     if mega and method == "RR-BLUP":
         raise NotImplementedError("multi-trait RR-BLUP with constraint=true stays on the reference")
     if t == 1 and (Mi.G.constraint or model.R.constraint):
@@ -396,11 +394,10 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
     mt_method = "MegaBayesC" if mega else ("MTBayesC_II" if sampler == "II" else "MTBayesC")
     mt_pervar = t > 1 and method == "BayesB"        # multi-trait BayesA/B: one t x t effect covariance per marker
     if mt_pervar:
-        if sampler == "II":
-            raise NotImplementedError("multi-trait BayesA/B runs with Gibbs sampler I on the device (multi_trait_sampler=:I)")
         if getattr(Mi, "annotations", False) is not False:
             raise NotImplementedError("annotated multi-trait BayesB stays on the reference")
-        mt_method = "MTBayesB"
+        # constraint = true: megaBayesABC! reads every marker's own diagonal (BayesABC.jl:5)
+        mt_method = "MegaBayesB" if mega else ("MTBayesB_II" if sampler == "II" else "MTBayesB")
 
     # ---- fast_blocks parsing (JWAS.jl:293-316); device blocks are powers of two >= 64
     nreps = 1
@@ -707,6 +704,8 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
                 kw["independent_blocks"] = True
             if mega:
                 kw.update(var_effect=Gval, pi=pi_t)
+                if mt_pervar:
+                    kw["var_effect_matrix"] = Gmat
             elif t > 1:
                 with np.errstate(divide="ignore"):
                     kw.update(var_effect=Gval, log_prior_states=np.log(ann.snp_pi if ann is not False else np.asarray(pi, dtype=np.float64)))
@@ -747,7 +746,17 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
 
             # 4. marker effect variance (variance_components.jl:151-189), re-cast to Float32 (:323-325)
             if Mi.G.estimate_variance:
-                if mega:                                                    # diagonal only (variance_components.jl:104-109)
+                if mega and mt_pervar:                                      # one scaled inverse chi-square per marker and trait
+                    sc = np.diag(Gdf * np.diag(np.asarray(Mi.G.scale, dtype=np.float64)))      # (variance_components.jl:112-117,181-186)
+                    if hasattr(engine, "sample_marker_covariances"):        # on the device, from the resident beta
+                        engine.sample_marker_covariances(Gdf + 1.0, sc, seed=seed_int, iteration=it)
+                        Gmat = None
+                    else:
+                        B = np.stack([engine.get_state(k)[1] for k in range(t)], axis=1).astype(np.float64)
+                        Gmat = np.zeros((p, t, t), dtype=ftype)
+                        for k in range(t):
+                            Gmat[:, k, k] = (B[:, k] ** 2 + sc[k, k]) / rng.chisquare(Gdf + 1.0, size=p)
+                elif mega:                                                  # diagonal only (variance_components.jl:104-109)
                     Gval = np.diag([(st["beta_ss"][k, k] + Gdf * Mi.G.scale[k, k]) / rng.chisquare(p + Gdf) for k in range(t)]).astype(ftype)
                 elif mt_pervar:                                             # variance_components.jl:181-186: one draw per marker,
                     if hasattr(engine, "sample_marker_covariances"):        # IW(df + 1, scale + b_j b_j') -- on the device, from the

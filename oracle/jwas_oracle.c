@@ -548,6 +548,28 @@ void orc_sample_marker_covariances(int t, int64_t p, const float* beta /* [t][p]
     }
 }
 
+/* constraint = true (variance_components.jl:112-117 through :184: sample_variance(data, 1, df, scale, false, true)): only the
+ * diagonal is drawn, G_kk = (scale_kk + b_jk^2) / chi2(df), scale = the reference's df * scale and df = its df + 1; the
+ * chi-square of trait k on the same counters as row k of the full draw (slot 32 + 2k); off-diagonals are zero. */
+void orc_sample_marker_variances_diag(int t, int64_t p, const float* beta /* [t][p] */, double df, const double* scale /* t x t */,
+                                      uint64_t seed, uint32_t iter, uint32_t marker0, float* var_mat /* [p][t][t] */)
+{
+    for (int64_t j = 0; j < p; ++j) {
+        const uint32_t marker = marker0 + (uint32_t)j;
+        for (int a = 0; a < t; ++a) {
+            const double b = (double)beta[(int64_t)a * p + j];
+            const double g = (scale[a * t + a] + b * b) / iw_chi2(seed, marker, iter, 32u + 2u * (uint32_t)a, df);
+            for (int c = 0; c < t; ++c) var_mat[(j * t + a) * t + c] = (c == a) ? (float)g : 0.0f;
+        }
+    }
+}
+
+/* megaBayesABC! with BayesA/B (BayesABC.jl:1-8: [vari[i,i] for vari in locus_effect_variances]): the marker's own diagonal */
+static inline const float* marker_var(int64_t j, int t, const float* var_all)
+{
+    return g_var_effect_mat ? g_var_effect_mat + j * t * t : var_all;
+}
+
 static inline const float* marker_ginv(int64_t j, int t, const float* Ginv_all, float* tmp)
 {
     if (!g_var_effect_mat) return Ginv_all;
@@ -814,7 +836,7 @@ int orc_mt_sweep(int kind, const float* X, int64_t n, int64_t p, int64_t ld, con
         const float* x = X + j * ld;
         float w[ORC_MAXT], a[ORC_MAXT];
         for (int k = 0; k < t; ++k) w[k] = dot_acc(x, r + k * ld_r, n, acc);     /* :82 */
-        mt_update(kind, t, w, xpx[j], alpha + j, beta + j, delta + j, p, Rinv, marker_ginv(j, t, Ginv, Gtmp_), vare, var_effect,
+        mt_update(kind, t, w, xpx[j], alpha + j, beta + j, delta + j, p, Rinv, marker_ginv(j, t, Ginv, Gtmp_), vare, marker_var(j, t, var_effect),
                   prior_is_matrix ? log_prior + (int64_t)nstates * j : log_prior,
                   seed, marker0 + (uint32_t)j, iter, 0, a);
         for (int k = 0; k < t; ++k) if (a[k] != 0.0f) axpy_f32(a[k], x, r + k * ld_r, n);
@@ -853,7 +875,7 @@ static int mt_block_sweep_impl(int kind, const float* X, int64_t n, int64_t p, i
                 const int64_t j = j0 + c;
                 float w[ORC_MAXT], a[ORC_MAXT];
                 for (int k = 0; k < t; ++k) w[k] = rhs_b[k * b + c];
-                mt_update(kind, t, w, xpx[j], alpha + j, beta + j, delta + j, p, Rinv, marker_ginv(j, t, Ginv, Gtmp_), vare, var_effect,
+                mt_update(kind, t, w, xpx[j], alpha + j, beta + j, delta + j, p, Rinv, marker_ginv(j, t, Ginv, Gtmp_), vare, marker_var(j, t, var_effect),
                           prior_is_matrix ? log_prior + (int64_t)nstates * j : log_prior,
                           seed, marker0 + (uint32_t)j, iter, (uint32_t)rep, a);
                 for (int k = 0; k < t; ++k)
@@ -1033,7 +1055,7 @@ int orc_mt_lookahead_sweep(int kind, const float* X, int64_t n, int64_t p, int64
                 const int64_t j = j0 + c;
                 float w[ORC_MAXT], a[ORC_MAXT];
                 for (int k = 0; k < t; ++k) w[k] = rhs_b[k * b + c];
-                mt_update(kind, t, w, xpx[j], alpha + j, beta + j, delta + j, p, Rinv, marker_ginv(j, t, Ginv, Gtmp_), vare, var_effect,
+                mt_update(kind, t, w, xpx[j], alpha + j, beta + j, delta + j, p, Rinv, marker_ginv(j, t, Ginv, Gtmp_), vare, marker_var(j, t, var_effect),
                           prior_is_matrix ? log_prior + (int64_t)nstates * j : log_prior,
                           seed, marker0 + (uint32_t)j, iter, (uint32_t)rep, a);
                 for (int k = 0; k < t; ++k) if (a[k] != 0.0f) axpy_f32(a[k], G + c * b, rhs_b + k * b, b);

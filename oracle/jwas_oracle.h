@@ -168,6 +168,9 @@ void orc_set_abc_rule_d(int on);
  * Bartlett on the counter RNG: the restatement the device's k_sample_marker_covariances is compared with. */
 void orc_sample_marker_covariances(int t, int64_t p, const float* beta, double df, const double* scale,
                                    uint64_t seed, uint32_t iter, uint32_t marker0, float* var_mat);
+/* constraint = true: diagonal only, G_kk = (scale_kk + b_jk^2) / chi2(df) (variance_components.jl:112-117) */
+void orc_sample_marker_variances_diag(int t, int64_t p, const float* beta, double df, const double* scale,
+                                      uint64_t seed, uint32_t iter, uint32_t marker0, float* var_mat);
 int orc_mt_sweep(int kind, const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
                  int t, float* r, int64_t ld_r, float* alpha, float* beta, float* delta,
                  const float* vare, const float* var_effect, const double* log_prior, int prior_is_matrix,

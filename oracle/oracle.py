@@ -288,17 +288,19 @@ def set_var_effect_matrix(mat):
 _VEM = None
 
 
-def sample_marker_covariances(beta, df, scale, seed, it, marker0=0):
+def sample_marker_covariances(beta, df, scale, seed, it, marker0=0, diagonal=False):
     """One InverseWishart(df, scale + b_j b_j') draw per marker (variance_components.jl:181-186; df = the reference's
-    df + 1): beta t x p float32, scale t x t -> p x t x t float32 (orc_sample_marker_covariances)."""
+    df + 1): beta t x p float32, scale t x t -> p x t x t float32 (orc_sample_marker_covariances).  diagonal=True
+    (constraint = true, :112-117): G_kk = (scale_kk + b_jk^2) / chi2(df) and zero off-diagonals."""
     b = np.ascontiguousarray(beta, dtype=np.float32)
     t, p = b.shape
     sc = np.ascontiguousarray(scale, dtype=np.float64).reshape(t, t)
     out = np.empty((p, t, t), dtype=np.float32)
     L = lib()
-    L.orc_sample_marker_covariances.restype = None
-    L.orc_sample_marker_covariances.argtypes = [C.c_int, C.c_int64, _f32p, C.c_double, _f64p, C.c_uint64, C.c_uint32, C.c_uint32, _f32p]
-    L.orc_sample_marker_covariances(t, p, _p(b, _f32p), float(df), _p(sc, _f64p), int(seed), int(it), int(marker0), _p(out, _f32p))
+    fn = L.orc_sample_marker_variances_diag if diagonal else L.orc_sample_marker_covariances
+    fn.restype = None
+    fn.argtypes = [C.c_int, C.c_int64, _f32p, C.c_double, _f64p, C.c_uint64, C.c_uint32, C.c_uint32, _f32p]
+    fn(t, p, _p(b, _f32p), float(df), _p(sc, _f64p), int(seed), int(it), int(marker0), _p(out, _f32p))
     return out
 
 

@@ -10,9 +10,9 @@ import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
 import oracle as O  # noqa: E402
 
-BAYESC, BAYESB, BAYESR, MTBAYESC1, MTBAYESC2, MEGABAYESC, MTBAYESB1 = 0, 1, 2, 3, 4, 5, 6
+BAYESC, BAYESB, BAYESR, MTBAYESC1, MTBAYESC2, MEGABAYESC, MTBAYESB1, MTBAYESB2, MEGABAYESB = 0, 1, 2, 3, 4, 5, 6, 7, 8
 METHOD_CODES = {"BayesC": BAYESC, "BayesB": BAYESB, "BayesA": BAYESB, "BayesR": BAYESR, "MTBayesC": MTBAYESC1,
-                "MTBayesC_II": MTBAYESC2, "MegaBayesC": MEGABAYESC, "MTBayesB": MTBAYESB1}
+                "MTBayesC_II": MTBAYESC2, "MegaBayesC": MEGABAYESC, "MTBayesB": MTBAYESB1, "MTBayesB_II": MTBAYESB2, "MegaBayesB": MEGABAYESB}
 
 
 class OracleEngine:
@@ -168,7 +168,7 @@ class OracleEngine:
             raise ValueError("independent blocks need a block form")
         a_before = self.alpha.copy()
         self._w()
-        if self.method == MTBAYESB1:                  # multi-trait BayesA/B: one effect covariance per marker
+        if self.method in (MTBAYESB1, MTBAYESB2, MEGABAYESB):     # multi-trait BayesA/B: one effect covariance per marker
             if var_effect_matrix is None:             # (None: the resident ones -- an earlier sweep's or sample_marker_covariances')
                 var_effect_matrix = self._var_mat
             self._var_mat = np.ascontiguousarray(var_effect_matrix, dtype=np.float32)
@@ -200,8 +200,8 @@ class OracleEngine:
                            float(np.asarray(vare).reshape(-1)[0]), float(np.asarray(var_effect).reshape(-1)[0]),
                            pc, seed, iteration, gamma=gamma, marker0=marker_offset, acc=self.acc, **blk)
         else:
-            kind = {MTBAYESC1: O.MT_SAMPLER_I, MTBAYESB1: O.MT_SAMPLER_I, MTBAYESC2: O.MT_SAMPLER_II, MEGABAYESC: O.MT_MEGA}[self.method]
-            prior = np.asarray(pi, dtype=np.float64).reshape(-1) if self.method == MEGABAYESC else log_prior_states
+            kind = {MTBAYESC1: O.MT_SAMPLER_I, MTBAYESB1: O.MT_SAMPLER_I, MTBAYESC2: O.MT_SAMPLER_II, MTBAYESB2: O.MT_SAMPLER_II, MEGABAYESC: O.MT_MEGA, MEGABAYESB: O.MT_MEGA}[self.method]
+            prior = np.asarray(pi, dtype=np.float64).reshape(-1) if self.method in (MEGABAYESC, MEGABAYESB) else log_prior_states
             O.mt_sweep(kind, self.X, self._xpx, self.r, self.alpha, self.beta, self.delta,
                        np.asarray(vare, dtype=np.float32).reshape(t, t),
                        np.asarray(var_effect, dtype=np.float32).reshape(t, t),
@@ -233,7 +233,8 @@ class OracleEngine:
 
     def sample_marker_covariances(self, df, scale, *, seed, iteration, marker_offset=0):
         """The oracle's restatement of jwas_hip_sample_marker_covariances (same counter RNG, same operations)."""
-        self._var_mat = O.sample_marker_covariances(self.beta, df, scale, seed, iteration, marker_offset)
+        self._var_mat = O.sample_marker_covariances(self.beta, df, scale, seed, iteration, marker_offset,
+                                                    diagonal=(self.method == MEGABAYESB))
 
     def marker_covariances(self):
         return self._var_mat.copy()

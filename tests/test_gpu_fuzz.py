@@ -75,6 +75,9 @@ def _random_case(seed):
     rng = np.random.default_rng(seed)
     method = rng.choice(["BayesC", "BayesC", "BayesR", "BayesB", "MTBayesC", "MTBayesC_II", "MegaBayesC", "MTBayesB"])
     t = 1 if method in ("BayesC", "BayesR", "BayesB") else int(rng.integers(2, 4))
+    pervar = method == "MTBayesB"                                       # multi-trait BayesA/B: a covariance per marker ...
+    if pervar:                                                          # ... under either Gibbs sampler, or constrained
+        method = ("MTBayesB", "MTBayesB_II", "MegaBayesB")[int(seed) % 3]
     n = int(rng.integers(40, 700)) if rng.random() < 0.85 else int(rng.integers(1500, 4200))      # (the tall ones: several row groups)
     p = int(rng.integers(30, 900))
     explicit = rng.random() < 0.4
@@ -99,11 +102,11 @@ def _random_case(seed):
                 big = int(np.argmax(np.diff(np.append(starts, p))))
                 starts = np.sort(np.append(starts, starts[big] + np.diff(np.append(starts, p))[big] // 2))
             part = ("explicit", starts)
-    if method == "MTBayesB" and not explicit and part[1] * t > 2048:
+    if pervar and not explicit and part[1] * t > 2048:
         part = ("uniform", 256)
     sparsity = float(rng.choice([0.0, 0.3, 0.9, 0.99]))
     weights = rng.random() < 0.25                                       # heterogeneous residuals (x'R^-1 x, X_b'R^-1 r)
-    indep = (not explicit) and method != "MTBayesB" and rng.random() < 0.2      # independent_blocks=true
+    indep = (not explicit) and not pervar and rng.random() < 0.2      # independent_blocks=true
     marker_prior = method in ("BayesC", "BayesR") and rng.random() < 0.25       # per-marker pi (annotation priors)
     coop = rng.random() < 0.3                                           # cooperative dense apply forced on
     return dict(method=method, t=t, n=n, p=p, part=part, nreps=nreps, sparsity=sparsity, seed=int(seed),
@@ -168,16 +171,21 @@ def test_random_configurations_against_the_oracle(hip, seed, monkeypatch):
             kw["pi_matrix"] = pm / pm.sum(axis=1, keepdims=True)
     elif method == "MegaBayesC":
         kw = dict(vare=np.diag(np.diag(Rm)), var_effect=np.diag(np.diag(Gm)), pi=np.full(t, sp))
+    elif method == "MegaBayesB":                                        # (the marker's own diagonal variances)
+        Vm = np.zeros((p, t, t), dtype=np.float32)
+        for k in range(t):
+            Vm[:, k, k] = g * np.exp(rng.uniform(-1, 1, p))
+        kw = dict(vare=np.diag(np.diag(Rm)), var_effect=np.eye(t, dtype=np.float32), pi=np.full(t, sp), var_effect_matrix=Vm)
     else:
         prior = np.full(1 << t, (1 - sp) / ((1 << t) - 1)); prior[0] = sp
         if sp == 0.0:
             prior = np.full(1 << t, 1e-3); prior[-1] = 1.0
         prior /= prior.sum()
         kw = dict(vare=Rm, var_effect=Gm, log_prior_states=np.log(prior))
-        if method == "MTBayesB":
+        if method in ("MTBayesB", "MTBayesB_II"):
             Wm = rng.standard_normal((p, t, t))
             kw["var_effect_matrix"] = ((Wm @ Wm.transpose(0, 2, 1) / t + np.eye(t)) * (g * np.exp(rng.uniform(-1, 1, p)))[:, None, None]).astype(np.float32)
-    nreps = c["nreps"] if method != "MTBayesC_II" or c["nreps"] in (1, 2) else 1
+    nreps = c["nreps"] if method not in ("MTBayesC_II", "MTBayesB_II") or c["nreps"] in (1, 2) else 1
     if c["indep"]:
         kw["independent_blocks"] = True
     for it in range(1, 5):

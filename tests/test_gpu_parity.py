@@ -761,16 +761,17 @@ def test_cooperative_dense_apply_is_bit_identical(method, t, bs, pi, monkeypatch
         np.testing.assert_allclose(results["coop"][0][k][0], results["oracle"][0][k][0], atol=5e-6)
 
 
+@pytest.mark.parametrize("method", ["MTBayesB", "MTBayesB_II"])
 @pytest.mark.parametrize("t,bs,dense,nreps", [(2, 64, False, 1), (3, 128, False, 1), (3, 512, False, 1), (4, 256, False, 1),
                                               (3, 128, True, 1), (2, 64, True, 1), (3, 64, False, 3)])
-def test_mt_bayesb_per_marker_covariance_parity(hip, t, bs, dense, nreps):
-    """Multi-trait BayesA/B: Gibbs sampler I with ONE t x t effect covariance PER MARKER (Ginv = inv.(varEffects),
-    MTBayesABC.jl:66,86-90).  The device inverts every marker's matrix in k_prepare (the host's Gauss-Jordan, operation for
+def test_mt_bayesb_per_marker_covariance_parity(hip, t, bs, dense, nreps, method):
+    """Multi-trait BayesA/B: Gibbs sampler I (MTBayesABC.jl:66,86-90) or the joint-state sampler II (MTBayesABC.jl:129-210)
+    with ONE t x t effect covariance PER MARKER (Ginv = inv.(varEffects)).  The device inverts every marker's matrix in k_prepare (the host's Gauss-Jordan, operation for
     operation) and the sampler uses the marker's own constants; sparse rounds, the dense walk (every marker in the model,
     speculative and general) and within-block repetitions against the oracle."""
     import jwas_jl_amd as J
     data = make_dataset(n=420, p=2 * bs + 29, ncausal=10, seed=900 + t)
-    orc, hip = _pair(hip, data, bs, "MTBayesB", ntraits=t)
+    orc, hip = _pair(hip, data, bs, method, ntraits=t)
     rng = np.random.default_rng(40 + t)
     p = orc.p
     Y = np.stack([data["y"] - data["y"].mean() + 0.3 * rng.standard_normal(len(data["y"])).astype(np.float32)
@@ -814,9 +815,53 @@ def test_mt_bayesb_per_marker_covariance_parity(hip, t, bs, dense, nreps):
         _compare_state(orc, hip, k, atol=5e-6)
     assert any(not np.array_equal(a_before[k], hip.get_state(k)[0]) for k in range(t))
     # ... and an error while none are resident (a fresh state)
-    hip.init_state("MTBayesB", t)
+    hip.init_state(method, t)
     with pytest.raises(J.JwasHipError, match="per-marker effect covariances"):
         hip.sweep(iteration=1, seed=1, **kw_res)
+
+
+@pytest.mark.parametrize("t,bs,pi,nreps", [(2, 64, 0.9, 1), (3, 128, 0.5, 1), (4, 256, 0.95, 1), (3, 128, 0.0, 1), (2, 64, 0.7, 3)])
+def test_mega_bayesb_per_marker_variances_parity(hip, t, bs, pi, nreps):
+    """megaBayesABC! with BayesA/B (BayesABC.jl:1-8: [vari[i,i] for vari in locus_effect_variances]; G.constraint = true): t
+    independent single-trait chains, trait k of marker j under its own variance.  Sparse and dense (pi = 0: BayesA) against
+    the oracle; the off-diagonal entries of the matrices handed over are ignored; and the constrained draw of the next
+    iteration's variances, G_kk = (scale_kk + b_jk^2) / chi2(df) (variance_components.jl:112-117), on the device."""
+    import oracle as O
+    data = make_dataset(n=380, p=2 * bs + 17, ncausal=8, seed=700 + t)
+    orc, hip = _pair(hip, data, bs, "MegaBayesB", ntraits=t)
+    rng = np.random.default_rng(70 + t)
+    p = orc.p
+    for k in range(t):
+        y = (data["y"] - data["y"].mean() + 0.3 * rng.standard_normal(len(data["y"]))).astype(np.float32)
+        orc.set_residual(y, k); hip.set_residual(y, k)
+        ones = np.ones(p, dtype=np.float32)
+        orc.set_state(k, delta=ones); hip.set_state(k, delta=ones)
+    vare = np.diag(rng.uniform(0.3, 0.8, t)).astype(np.float32)
+    Vm = np.zeros((p, t, t), dtype=np.float32)
+    for k in range(t):
+        Vm[:, k, k] = 0.003 * np.exp(rng.uniform(-2, 2, p))
+    Vh = Vm.copy()
+    Vh[:, 0, t - 1] = 7.0; Vh[:, t - 1, 0] = -3.0                       # (ignored: only the diagonal is read)
+    kw = dict(vare=vare, var_effect=np.eye(t, dtype=np.float32), pi=np.full(t, pi), nreps=nreps)
+    for it in range(1, 9):
+        so = orc.sweep(iteration=it, seed=5, var_effect_matrix=Vm, **kw)
+        sh = hip.sweep(iteration=it, seed=5, var_effect_matrix=Vh if it % 2 else Vm, **kw)
+        assert np.array_equal(so["sum_delta"], sh["sum_delta"]), f"iteration {it}"
+        np.testing.assert_allclose(sh["resid_ss"], so["resid_ss"], rtol=1e-5, atol=1e-6 * float(np.max(np.abs(so["resid_ss"]))))
+    for k in range(t):
+        _compare_state(orc, hip, k, atol=5e-6)
+    # the constrained draw: diagonal only, same counters as the oracle's
+    scale = np.diag(rng.uniform(0.01, 0.05, t))
+    hip.sample_marker_covariances(5.5, scale, seed=9, iteration=9, marker_offset=11)
+    Gh = hip.marker_covariances()
+    beta = np.stack([hip.get_state(k)[1] for k in range(t)])
+    Go = O.sample_marker_covariances(beta, 5.5, scale, 9, 9, 11, diagonal=True)
+    np.testing.assert_allclose(Gh, Go, rtol=2e-6, atol=0)
+    off = ~np.eye(t, dtype=bool)
+    assert (Gh[:, off] == 0).all() and (Gh[:, ~off] > 0).all()
+    orc._var_mat = Gh                                                    # (the device's own draws: libm's last place aside)
+    so = orc.sweep(iteration=9, seed=5, **kw); sh = hip.sweep(iteration=9, seed=5, **kw)      # the resident draws
+    assert np.array_equal(so["sum_delta"], sh["sum_delta"])
 
 
 def test_mt_bayesb_needs_parked_draws(hip):

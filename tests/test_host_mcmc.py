@@ -708,6 +708,73 @@ def test_runmcmc_multitrait_bayesb_per_marker_covariances(tmp_path, method):
         api.runMCMC(model, ph, chain_length=5, seed=4, output_folder=str(tmp_path / "x"), _engine=OracleEngine("lookahead"), block_size=64)
 
 
+@pytest.mark.parametrize("method", ["BayesB", "BayesA"])
+def test_multitrait_bayesb_constraint_runs_mega_path_with_marker_variances(tmp_path, method):
+    """constraint = true with BayesA/B: megaBayesABC! takes [vari[i,i] for vari in locus_effect_variances] (BayesABC.jl:5) and
+    sample_variance(..., constraint = true) redraws only the diagonal of every marker's matrix (variance_components.jl:
+    112-117,181-186): t independent single-trait BayesB chains, each marker with its own variance per trait."""
+    d = make_dataset(n=240, p=140, ncausal=6, seed=21, center=False)
+    ids = [f"id{i}" for i in range(240)]
+    gdf = pd.DataFrame(d["raw"], columns=[f"snp{j}" for j in range(140)]); gdf.insert(0, "ID", ids)
+    rng = np.random.default_rng(2)
+    y1 = d["y"].astype(np.float64)
+    y2 = 0.7 * y1 + 0.7 * rng.standard_normal(240)
+    ph = pd.DataFrame({"ID": ids, "y1": y1, "y2": y2})
+    used = {"draws": 0}
+
+    class Spy(OracleEngine):
+        def init_state(self, m, t=1):
+            used["method"] = m
+            return super().init_state(m, t)
+
+        def sample_marker_covariances(self, *a, **k):
+            super().sample_marker_covariances(*a, **k)
+            G = self.marker_covariances()
+            off = ~np.eye(2, dtype=bool)
+            assert (G[:, off] == 0).all() and (G[:, ~off] > 0).all()          # diagonal draws only
+            used["draws"] += 1
+
+    geno = api.get_genotypes(gdf, np.eye(2) * 0.5, method=method, constraint=True)
+    model = api.build_model("y1 = intercept + geno\ny2 = intercept + geno", np.eye(2), constraint=True)
+    out = api.runMCMC(model, ph, chain_length=120, burnin=30, seed=4, output_folder=str(tmp_path / method),
+                      _engine=Spy("lookahead"), block_size=64)
+    assert used["method"] == "MegaBayesB" and used["draws"] == 120
+    for tr, y in (("y1", y1), ("y2", y2)):
+        assert np.corrcoef(out[f"EBV_{tr}"]["EBV"].to_numpy(), y)[0, 1] > 0.5
+    if method == "BayesA":
+        assert (out["marker effects geno"]["Model_Frequency"].to_numpy() == 1.0).all()
+
+
+def test_multitrait_bayesb_restricted_support_runs_sampler_II(tmp_path):
+    """mt_bayesc_sampler_mode (MTBayesABC.jl:20-25) under :auto sends a BayesB analysis whose Pi lists fewer than 2^t states
+    to Gibbs sampler II (MTBayesABC.jl:129-210) with locus_effect_variances = one matrix per marker: a locus then affects
+    both traits or none, and the effects follow the causal markers."""
+    d = make_dataset(n=240, p=140, ncausal=6, seed=21, center=False)
+    ids = [f"id{i}" for i in range(240)]
+    gdf = pd.DataFrame(d["raw"], columns=[f"snp{j}" for j in range(140)]); gdf.insert(0, "ID", ids)
+    rng = np.random.default_rng(2)
+    y1 = d["y"].astype(np.float64)
+    ph = pd.DataFrame({"ID": ids, "y1": y1, "y2": 0.7 * y1 + 0.7 * rng.standard_normal(240)})
+    used = {}
+
+    class Spy(OracleEngine):
+        def init_state(self, method, t=1):
+            used["method"] = method
+            return super().init_state(method, t)
+
+    geno = api.get_genotypes(gdf, np.eye(2) * 0.5, method="BayesB", Pi={(0.0, 0.0): 0.8, (1.0, 1.0): 0.2},
+                             estimatePi=False, multi_trait_sampler="auto")
+    model = api.build_model("y1 = intercept + geno\ny2 = intercept + geno", np.eye(2))
+    out = api.runMCMC(model, ph, chain_length=120, burnin=30, seed=4, output_folder=str(tmp_path / "b2"),
+                      _engine=Spy("lookahead"), block_size=64)
+    assert used["method"] == "MTBayesB_II"
+    me = out["marker effects geno"]
+    f1 = me[me.Trait == "y1"]["Model_Frequency"].to_numpy()
+    f2 = me[me.Trait == "y2"]["Model_Frequency"].to_numpy()
+    assert np.array_equal(f1, f2) and 0 < f1.mean() < 1
+    assert np.corrcoef(out["EBV_y1"]["EBV"].to_numpy(), y1)[0, 1] > 0.5
+
+
 @pytest.mark.parametrize("fb,p", [(64, 200), (50, 230), (True, 300), (7, 100)])
 def test_fast_blocks_numeric_runs_the_reference_partition(tmp_path, fb, p):
     """JWAS.jl:308-312: fast_blocks = true | number cuts the markers at collect(range(1, step=block_size, stop=p)), and
