@@ -1369,15 +1369,15 @@ static hipError_t launch_indep_cx(jwas_hip_ctx* c, const CX& cx, const UpdateArg
     }
     const size_t red = sizeof(double) * kRowGroupSlices * kColChunk * NT;
     hipLaunchKernelGGL((k_indep_rhs<NT, CX>), dim3((unsigned)(U.nrg * U.ncg), (unsigned)c->nblocks), dim3(kStepThreads), red, c->stream,
-                       U, c->p, c->block_size, pstride);
+                       U, c->p, c->block_size, pstride, (const int64_t*)c->d_starts);
     if constexpr (kHasDense) {
         if (dn) {
-            hipLaunchKernelGGL((k_indep_sample<METHOD, NT, true>), dim3((unsigned)c->nblocks), dim3(kStepThreads), SM.bytes, c->stream, S, pstride, c->ev_all);
+            hipLaunchKernelGGL((k_indep_sample<METHOD, NT, true>), dim3((unsigned)c->nblocks), dim3(kStepThreads), SM.bytes, c->stream, S, pstride, c->ev_all, (const int64_t*)c->d_starts);
             return hipGetLastError();
         }
     }
     hipLaunchKernelGGL((k_indep_sample<METHOD, NT>), dim3((unsigned)c->nblocks), dim3(kStepThreads), SM.bytes, c->stream,
-                       S, pstride, c->ev_all);
+                       S, pstride, c->ev_all, (const int64_t*)c->d_starts);
     return hipGetLastError();
 }
 
@@ -1392,7 +1392,6 @@ static int sweep_independent(jwas_hip_ctx* c, EventList* out, bool dense, int de
     const int t = c->ntraits, bs = c->block_size;
     const int64_t nb = c->nblocks;
     NEED(c, nb <= 65535, JWAS_HIP_EUNSUP, "independent blocks: at most 65535 blocks (got %lld)", (long long)nb);
-    NEED(c, c->starts.empty(), JWAS_HIP_EUNSUP, "independent blocks run on uniform block partitions (not on explicit block starts)");
     NEED(c, !c->row_mode, JWAS_HIP_EUNSUP, "independent blocks are not available on row shards");
     const int64_t pstride = (int64_t)t * c->nrg * bs;
     if (!c->ev_all || c->ind_traits != t) {

@@ -201,12 +201,13 @@ __global__ __launch_bounds__(256) void k_cross_f64(CX cx, int64_t p, int bsize,
 // ---------------------------------------------------------------------------------------------
 // Block RHS of ALL blocks from the snapshot.  grid = (nrg*ncg, nblocks), block = 512.
 template <int NT, class CX>
-__global__ __launch_bounds__(kStepThreads) void k_indep_rhs(UpdateArgsT<CX> U, int64_t p, int bsz, int64_t pstride)
+__global__ __launch_bounds__(kStepThreads) void k_indep_rhs(UpdateArgsT<CX> U, int64_t p, int bsz, int64_t pstride,
+                                                            const int64_t* __restrict__ starts /* explicit partition (nblocks + 1), or NULL */)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int64_t blk = blockIdx.y;
-    const int64_t j0 = blk * bsz;
-    const int b = (int)((j0 + bsz <= p) ? bsz : p - j0);
+    const int64_t j0 = starts ? starts[blk] : blk * bsz;
+    const int b = starts ? (int)(starts[blk + 1] - j0) : (int)((j0 + bsz <= p) ? bsz : p - j0);
     const int ncg = U.ncg < b ? U.ncg : b;
     const int w = blockIdx.x;
     if (w >= U.nrg * ncg) return;
@@ -216,12 +217,13 @@ __global__ __launch_bounds__(kStepThreads) void k_indep_rhs(UpdateArgsT<CX> U, i
 
 // All blocks sampled concurrently.  grid = nblocks, block = 512, dynamic LDS as k_block_step.
 template <int METHOD, int NT, bool DENSE = false>
-__global__ __launch_bounds__(kStepThreads) void k_indep_sample(SamplerArgs S, int64_t pstride, Events* ev_all)
+__global__ __launch_bounds__(kStepThreads) void k_indep_sample(SamplerArgs S, int64_t pstride, Events* ev_all,
+                                                               const int64_t* __restrict__ starts)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int64_t blk = blockIdx.x;
-    S.j0 = blk * S.bsz;
-    S.b = (int)((S.j0 + S.bsz <= S.p) ? S.bsz : S.p - S.j0);
+    S.j0 = starts ? starts[blk] : blk * S.bsz;
+    S.b = starts ? (int)(starts[blk + 1] - S.j0) : (int)((S.j0 + S.bsz <= S.p) ? S.bsz : S.p - S.j0);
     S.partials += blk * pstride;
     S.gram += blk * (int64_t)S.bsz * S.bsz;
     S.ev_out = ev_all + blk;

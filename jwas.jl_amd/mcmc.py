@@ -433,8 +433,6 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
                 # (BayesABC.jl:153); jwas_hip_setup_blocks_explicit
                 if max(sizes) > 1024:
                     raise NotImplementedError("explicit fast_blocks blocks hold at most 1024 markers on the device")
-                if independent_blocks:
-                    raise NotImplementedError("independent_blocks with non-uniform explicit block starts stays on the reference")
                 explicit_partition = np.asarray(starts, dtype=np.int64) - 1
             want = max(sizes) if explicit_partition is not None else sizes[0]
         if want < 1:
@@ -448,13 +446,13 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         #     (nreps <= 0 = every block its own size);
         #   * any other size <= 1024: the ragged-partition form (jwas_hip_setup_blocks_explicit) with those starts;
         #   * more than 1024 markers per block do not fit the sampler's LDS plan: an explicit error;
-        #   * independent_blocks on a size that is not a device size: uniform device blocks of the nearest supported size
-        #     with `want` repetitions each (independent blocks are the reference's own approximation).
+        #     (independent_blocks alone may ask for more: uniform device blocks of 1024 markers with `want` repetitions
+        #     each -- independent blocks are the reference's own approximation).
         if not explicit_starts:
             chain_length = int(np.floor(chain_length / want))
         if want > max(DEVICE_BLOCK_SIZES) and not (explicit_partition is None and independent_blocks):
             raise NotImplementedError(f"fast_blocks blocks hold at most {max(DEVICE_BLOCK_SIZES)} markers on the device (got {want})")
-        if explicit_partition is None and want not in DEVICE_BLOCK_SIZES and not independent_blocks:
+        if explicit_partition is None and want not in DEVICE_BLOCK_SIZES and want <= max(DEVICE_BLOCK_SIZES):
             explicit_partition = np.arange(0, p, want, dtype=np.int64)          # = collect(range(1, step=want, stop=p)) - 1
             sizes = [want] * (len(explicit_partition) - 1) + [p - int(explicit_partition[-1])]
         block_size = _supported_block(want)

@@ -106,7 +106,8 @@ def _random_case(seed):
         part = ("uniform", 256)
     sparsity = float(rng.choice([0.0, 0.3, 0.9, 0.99]))
     weights = rng.random() < 0.25                                       # heterogeneous residuals (x'R^-1 x, X_b'R^-1 r)
-    indep = (not explicit) and not pervar and rng.random() < 0.2      # independent_blocks=true
+    # independent_blocks=true (on explicit partitions: every fifth seed -- no extra draw, so the other cases keep their configuration)
+    indep = (not pervar) and ((int(seed) % 5 == 0) if explicit else rng.random() < 0.2)
     marker_prior = method in ("BayesC", "BayesR") and rng.random() < 0.25       # per-marker pi (annotation priors)
     coop = rng.random() < 0.3                                           # cooperative dense apply forced on
     return dict(method=method, t=t, n=n, p=p, part=part, nreps=nreps, sparsity=sparsity, seed=int(seed),

@@ -920,8 +920,18 @@ def test_explicit_non_uniform_block_starts_parity(hip, method, t, nreps, gram):
             _compare_state(orc, hip, k, atol=tol)
         else:
             np.testing.assert_allclose(hip.get_state(k)[0], orc.get_state(k)[0], atol=tol)
-    with pytest.raises(J.JwasHipError, match="uniform block partitions"):
-        hip.sweep(iteration=1, seed=1, independent_blocks=True, **kw)
+    # independent blocks on the same ragged partition (BayesABC_block_independent!, BayesABC.jl:190-255, under explicit starts):
+    # every block's rhs from the residual snapshot, blocks of 1 ... 200 markers sampled concurrently
+    for it in range(9, 14):
+        so = orc.sweep(iteration=it, seed=9, nreps=nreps, independent_blocks=True, **kw)
+        sh = hip.sweep(iteration=it, seed=9, nreps=nreps, independent_blocks=True, **kw)
+        assert so["n_events"] == sh["n_events"], f"independent iteration {it}"
+    for k in range(t):
+        if gram == "f64":
+            _compare_state(orc, hip, k, atol=tol)
+            np.testing.assert_allclose(hip.get_residual(k), orc.get_residual(k), atol=2e-4)
+        else:
+            np.testing.assert_allclose(hip.get_state(k)[0], orc.get_state(k)[0], atol=tol)
     with pytest.raises(J.JwasHipError, match="explicit block partition"):
         hip.add_block_size(512, "f64")
     with pytest.raises(J.JwasHipError, match="sorted, unique"):

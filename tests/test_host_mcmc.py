@@ -775,6 +775,24 @@ def test_multitrait_bayesb_restricted_support_runs_sampler_II(tmp_path):
     assert np.corrcoef(out["EBV_y1"]["EBV"].to_numpy(), y1)[0, 1] > 0.5
 
 
+@pytest.mark.parametrize("fb", [50, [1, 40, 41, 150]])
+def test_independent_blocks_run_the_reference_partition_too(tmp_path, fb):
+    """independent_blocks = true with a block size that is not a device size, or with explicit ragged starts
+    (BayesABC_block_independent!, BayesABC.jl:190-255, under JWAS.jl:298-312): the same partition as the sequential sweep."""
+    n, p = 200, 230
+    d = make_dataset(n=n, p=p, ncausal=3, seed=9, center=False)
+    ids = [str(i) for i in range(n)]
+    gdf = pd.DataFrame(d["raw"]); gdf.insert(0, "ID", ids)
+    ph = pd.DataFrame({"ID": ids, "y1": d["y"]})
+    geno = api.get_genotypes(gdf, method="BayesC", Pi=0.9, quality_control=False)
+    model = api.build_model("y1 = intercept + geno")
+    out = api.runMCMC(model, ph, chain_length=300 if np.isscalar(fb) else 6, burnin=1, fast_blocks=fb, independent_blocks=True, seed=1,
+                      outputEBV=False, output_folder=str(tmp_path / "fbi"), _engine=OracleEngine("block"))
+    want = list(range(1, p + 1, 50)) if np.isscalar(fb) else fb
+    assert out["_timing"]["block_starts"] == want
+    assert out["_timing"]["iterations"] == 6
+
+
 @pytest.mark.parametrize("fb,p", [(64, 200), (50, 230), (True, 300), (7, 100)])
 def test_fast_blocks_numeric_runs_the_reference_partition(tmp_path, fb, p):
     """JWAS.jl:308-312: fast_blocks = true | number cuts the markers at collect(range(1, step=block_size, stop=p)), and
