@@ -183,8 +183,6 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         raise NotImplementedError("multi-trait device path implements BayesC (Gibbs samplers I, II and the constraint=true "
                                   "megaBayesABC! path) and BayesA/B (the same three); other methods stay on the reference")
     mega = t > 1 and bool(Mi.G.constraint)                              # megaBayesABC! (MCMC_BayesianAlphabet.jl:233-234)
-    if mega and method == "RR-BLUP":
-        raise NotImplementedError("multi-trait RR-BLUP with constraint=true stays on the reference")
     if t == 1 and (Mi.G.constraint or model.R.constraint):
         raise ValueError("constraint==true is for multi-trait only")     # input_data_validation.jl:534-535,550-551
     if not isinstance(starting_value, bool) or starting_value:

@@ -212,6 +212,30 @@ def test_runmcmc_constraint_true_runs_mega_path(tmp_path):
         api.runMCMC(m1, ph, chain_length=2, output_folder=str(tmp_path / "e"), _engine=OracleEngine("block"), block_size=64)
 
 
+def test_runmcmc_rrblup_constraint_true_runs_mega_path(tmp_path):
+    """Multi-trait RR-BLUP with constraint = true: megaBayesC0! (MCMC_BayesianAlphabet.jl:260-262) = the constrained chains
+    with every marker in the model for every trait (pi_k = 0), diagonal variance draws."""
+    d, ph, gdf = _two_trait()
+    geno = api.get_genotypes(gdf, method="RR-BLUP", constraint=True)
+    model = api.build_model("y1 = intercept + geno\ny2 = intercept + geno", constraint=True)
+    used = {}
+
+    class Spy(OracleEngine):
+        def init_state(self, m, t=1):
+            used["method"] = m
+            return super().init_state(m, t)
+
+        def sweep(self, **kw):
+            used["pi"] = np.asarray(kw["pi"]).copy()
+            return super().sweep(**kw)
+
+    out = api.runMCMC(model, ph, chain_length=40, burnin=10, seed=3, output_folder=str(tmp_path / "rr"), _engine=Spy("block"), block_size=64)
+    assert used["method"] == "MegaBayesC" and np.array_equal(used["pi"], [0.0, 0.0])
+    gv = out["marker effects variance geno"]["Estimate"].to_numpy().reshape(2, 2)
+    assert gv[0, 1] == 0 and gv[1, 0] == 0 and gv[0, 0] > 0 and gv[1, 1] > 0
+    assert (out["marker effects geno"]["Model_Frequency"].to_numpy() == 1.0).all()
+
+
 def test_runmcmc_contract_errors(tmp_path):
     geno_df, ph = _six_animals()
     geno = api.get_genotypes(geno_df, 1.0, quality_control=False)
