@@ -794,6 +794,7 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
     // (only theirs: a later marker is re-evaluated from its OLD state) and the serial wave starts at the first sub-block
     // that holds a candidate.  Single pass only.
     int first_sub = 16, ncand_all = 0;
+    bool dense_walk = false;
     {
         int* wc = reinterpret_cast<int*>(smem + SM.wcnt_off);
         const int f0 = __any(cand[0]) ? 1 : 0, f1 = __any(cand[1]) ? 2 : 0;
@@ -812,6 +813,21 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
             if (stay[q] && c < b && (c >> 6) < first_sub) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) { bcur[t * B + c] = pb[q][t]; dcur[t * B + c] = pd[q][t]; }
+            }
+        }
+        // The dense walk (below) runs on STRICTLY UPPER diagonal tiles: G[l][c] = 0 for c <= l inside a 64-marker section, so
+        // that a lane's running rhs stops moving at its own step -- after the section it still holds the value the lane's
+        // marker was evaluated with (no per-step copy of it), and the later steps' updates are exact no-ops on it.  The rows
+        // are not read again after the walk (single pass).
+        dense_walk = !is_sampler2(METHOD) && single_pass && prestage && 5 * ncand_all >= 3 * b;
+        if (dense_walk) {
+            // one float4 column group per thread and pass: whole groups left of the diagonal with one store
+            float* rows_m = reinterpret_cast<float*>(smem + SM.rows_off);
+            for (int e = tid; e < (B >> 6) * 64 * 16; e += kStepThreads) {
+                const int q = e >> 10, l = (e >> 4) & 63, c4 = (e & 15) * 4;
+                float* dst = rows_m + (64 * q + l) * B + 64 * q + c4;
+                if (c4 + 3 <= l) *reinterpret_cast<float4*>(dst) = float4{0.f, 0.f, 0.f, 0.f};
+                else if (c4 <= l) { dst[0] = 0.f; if (c4 + 1 <= l) dst[1] = 0.f; if (c4 + 2 <= l) dst[2] = 0.f; }
             }
         }
         __syncthreads();                                   // (stage_rows reuses the slots)
@@ -848,7 +864,7 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
     // (all 64 markers at once, each with the w it was walked with) both verifies the speculation and yields the final
     // state -- by Rule L the linear form's own numbers whenever the speculation held; if any marker left the model for a
     // trait the section is walked again from its saved rhs with those markers evaluated the general way.
-    if (!is_sampler2(METHOD) && nreps == 1 && prestage && nstaged_mt == b && 5 * ncand_all >= 3 * b) {
+    if (dense_walk) {
         const float* rows = reinterpret_cast<const float*>(smem + SM.rows_off);
         float rhsq[NT][2], aq[NT][2], bq[NT][2], dq[NT][2], djq[2], wev[2][NT];
         double thrq[NT][2], zq[NT][2];
@@ -898,9 +914,11 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
             mt1_linear_coeffs<NT>(KQ(q), Qq[q], djq[q], b_old, zz, Al, cl);
         };
         // 64-marker section q: eight steps per batch without a branch, the Gram rows read a batch ahead
-        auto section = [&](auto qc, auto fastc, const float* grow, int nsteps) {
+        // (TWO: blocks of 128 markers -- the second half's running rhs follows too; a compile-time property of the loop body)
+        auto section = [&](auto qc, auto fastc, auto twoc, const float* grow, int nsteps) {
             constexpr int Q = decltype(qc)::value;
             constexpr bool FAST = decltype(fastc)::value;
+            constexpr bool TWO = decltype(twoc)::value;
             float Al[NT][NT], cl[NT], da[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) da[t] = djq[Q] * aq[t][Q];                                 // :82
@@ -913,10 +931,10 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
                 else eval_own(Q, w, an, bn, dn, Dl);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    wev[Q][t] = (lane == l) ? w[t] : wev[Q][t];      // lane l: what it was evaluated with
+                    // (the diagonal tiles are strictly upper: lanes <= l are not moved -- a lane keeps the rhs of its own step)
                     const float D = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Dl[t]), l));
                     if (Q == 0) rhsq[t][0] = fmaf(D, c0, rhsq[t][0]);                                   // D = 0: exact no-op
-                    if (B > 64) rhsq[t][1] = fmaf(D, c1, rhsq[t][1]);
+                    if (TWO) rhsq[t][1] = fmaf(D, c1, rhsq[t][1]);
                 }
             };
             constexpr int kBatch = FAST ? 8 : 2;
@@ -925,7 +943,7 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
 #pragma unroll
                 for (int u = 0; u < kBatch; ++u) {
                     n0[u] = (Q == 0) ? grow[(l0 + u) * B + lane] : 0.f;
-                    n1[u] = (B > 64) ? grow[(l0 + u) * B + 64 + lane] : 0.f;
+                    n1[u] = TWO ? grow[(l0 + u) * B + 64 + lane] : 0.f;
                 }
             };
             int l = 0;
@@ -940,19 +958,22 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
                 for (int u = 0; u < kBatch; ++u) step(l + u, c0[u], c1[u]);
             }
 #pragma unroll 1
-            for (; l < nsteps; ++l) step(l, (Q == 0) ? grow[l * B + lane] : 0.f, (B > 64) ? grow[l * B + 64 + lane] : 0.f);
+            for (; l < nsteps; ++l) step(l, (Q == 0) ? grow[l * B + lane] : 0.f, TWO ? grow[l * B + 64 + lane] : 0.f);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) wev[Q][t] = rhsq[t][Q] + da[t];     // every lane: what its marker was evaluated with
         };
         using std::integral_constant;
         // the same section with some markers (bit l of `slow`) evaluated the general way and the others speculatively: one
         // step per loop trip (used when the speculation missed, or when a marker is not in the model for every trait at entry)
-        auto section_mixed = [&](auto qc, const float* grow, int nsteps, unsigned long long slow) {
+        auto section_mixed = [&](auto qc, auto twoc, const float* grow, int nsteps, unsigned long long slow) {
             constexpr int Q = decltype(qc)::value;
+            constexpr bool TWO = decltype(twoc)::value;
             float Al[NT][NT], cl[NT], da[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) da[t] = djq[Q] * aq[t][Q];
             linear_of(Q, Al, cl);
             float g0 = (Q == 0) ? grow[lane] : 0.f;
-            float g1 = (B > 64) ? grow[64 + lane] : 0.f;
+            float g1 = TWO ? grow[64 + lane] : 0.f;
 #pragma unroll 1
             for (int l = 0; l < nsteps; ++l) {
                 float w[NT], an[NT], bn[NT], dn[NT], Dl[NT];
@@ -963,17 +984,18 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
                 const float c0 = g0, c1 = g1;
                 grow += B;                                           // next marker's row (one past the block: the overflow row)
                 if (Q == 0) g0 = grow[lane];
-                if (B > 64) g1 = grow[64 + lane];
+                if (TWO) g1 = grow[64 + lane];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    wev[Q][t] = (lane == l) ? w[t] : wev[Q][t];
                     const float D = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Dl[t]), l));
                     if (Q == 0) rhsq[t][0] = fmaf(D, c0, rhsq[t][0]);
-                    if (B > 64) rhsq[t][1] = fmaf(D, c1, rhsq[t][1]);
+                    if (TWO) rhsq[t][1] = fmaf(D, c1, rhsq[t][1]);
                 }
             }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) wev[Q][t] = rhsq[t][Q] + da[t];
         };
-        auto run_section = [&](auto qc) {
+        auto run_section = [&](auto qc, auto twoc) {
             constexpr int Q = decltype(qc)::value;
             const int nsteps = (b < 64 * (Q + 1) ? b : 64 * (Q + 1)) - 64 * Q;
             if (nsteps <= 0) return;
@@ -990,8 +1012,8 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
                 for (int t = 0; t < NT; ++t) in_all = in_all && (dq[t][Q] == 1.f);
                 unsigned long long slow = __ballot(!in_all && c < b);
                 if (__popcll(slow) * 4 > nsteps) slow = ~0ull;       // not a block to speculate on: everything the general way
-                if (slow == 0ull) section(qc, integral_constant<bool, true>{}, grow, nsteps);
-                else section_mixed(qc, grow, nsteps, slow);
+                if (slow == 0ull) section(qc, integral_constant<bool, true>{}, twoc, grow, nsteps);
+                else section_mixed(qc, twoc, grow, nsteps, slow);
                 for (int pass = 0; pass < 64; ++pass) {
                     eval_own(Q, wev[Q], an, bn, dn, Dl);             // the exact evaluation of every marker of the section
                     bool ok = true;
@@ -1005,19 +1027,21 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
                     if (__popcll(slow) * 4 > nsteps) slow = ~0ull;   // (misses are not rare here: stop speculating)
 #pragma unroll
                     for (int t = 0; t < NT; ++t) { rhsq[t][0] = rs[t][0]; rhsq[t][1] = rs[t][1]; }
-                    section_mixed(qc, grow, nsteps, slow);
+                    section_mixed(qc, twoc, grow, nsteps, slow);
                     ++nrounds;                                       // (diagnostics: sections walked again)
                 }
             } else {
-                section(qc, integral_constant<bool, false>{}, grow, nsteps);
+                section(qc, integral_constant<bool, false>{}, twoc, grow, nsteps);
                 eval_own(Q, wev[Q], an, bn, dn, Dl);
             }
             if (c < B)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) { acur[t * B + c] = (c < b) ? an[t] : 0.f; bcur[t * B + c] = bn[t]; dcur[t * B + c] = dn[t]; }
         };
-        run_section(integral_constant<int, 0>{});
-        run_section(integral_constant<int, 1>{});
+        if (B > 64) {
+            run_section(integral_constant<int, 0>{}, integral_constant<bool, true>{});
+            run_section(integral_constant<int, 1>{}, integral_constant<bool, true>{});
+        } else run_section(integral_constant<int, 0>{}, integral_constant<bool, false>{});
         dense_done = true;
     }
     if (dense_done && lane == 0) wcnt_s[14] = 1;

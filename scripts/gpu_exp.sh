@@ -1,4 +1,8 @@
 #!/bin/bash
-mkdir -p gpurun_out/r03f64
-timeout 600 python -m pytest tests/test_gpu_f64.py -q -x 2>&1 | tail -2
-timeout 1200 python scripts/f64_bench.py 20000 20000 2>/dev/null | tail -1 | tee gpurun_out/r03f64/f64_bench.json
+# scratch
+python -m pytest tests/test_gpu_parity.py -q -m gpu -x -k "mt or mega or dense" 2>&1 | tail -2
+python -m pytest tests/test_gpu_fuzz.py -q -m gpu -x 2>&1 | tail -2
+for w in "config4" "config4 --mt-method BayesB"; do
+  echo "== $w"
+  JWAS_HIP_DEBUG_PHASES=1 timeout 900 python bench.py --workload $w --steps 5 --warmup 2 --burnin 30 --no-cpu-baseline 2>&1 | grep -E "jwas_hip\]|ms_per_step" | tail -2 | cut -c1-330
+done
