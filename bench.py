@@ -111,7 +111,7 @@ def log(msg):
         print(f"[bench {time.time() - _T0:8.2f}s] {msg}", file=sys.stderr, flush=True)
 
 
-def traffic_from_profiles(workload, n, p, bs, storage, world, pi_fixed):
+def traffic_from_profiles(workload, n, p, bs, storage, world, pi_fixed, variant=None):
     """HBM bytes per k_block_step launch from the PMC summaries committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and
     --pmc WRITE_SIZE in separate runs of this command; FETCH_SIZE x2 per the guide's gfx950 correction, checked on k_xpx
     which reads X exactly once).  Only returned when the summaries' recorded configuration matches this run."""
@@ -126,7 +126,8 @@ def traffic_from_profiles(workload, n, p, bs, storage, world, pi_fixed):
     for row in rows:
         c = row.get("config", {})
         if (c.get("workload") == workload and c.get("n") == n and c.get("p") == p and c.get("block_size") == bs
-                and c.get("storage") == storage and c.get("n_gpus") == world and c.get("pi_fixed") == pi_fixed):
+                and c.get("storage") == storage and c.get("n_gpus") == world and c.get("pi_fixed") == pi_fixed
+                and c.get("variant") == variant):
             return float(row["bytes_per_launch"]), row.get("source")
     return None, None
 
@@ -430,7 +431,8 @@ def main():
         bytes_per_launch = acc["bytes"] / launches                 # algorithmic: 4 B (2 bits if packed) x n per marker, X read once
         bs_now = state["bs"]
         achieved = bytes_per_launch / 1e9 / (avg_launch_us * 1e-6)
-        traffic, traffic_src = traffic_from_profiles(wl, n, p_total, bs_now, a.storage, world, a.pi_fixed)
+        variant = f"{a.mt_method}/{a.mt_prior}" if t > 1 else None          # (config 4: sampler family and prior of the run)
+        traffic, traffic_src = traffic_from_profiles(wl, n, p_total, bs_now, a.storage, world, a.pi_fixed, variant)
         if t == 1 and method == "BayesC":
             in_model = float(last["sum_delta"][0])
         elif method == "BayesR":
@@ -448,7 +450,7 @@ def main():
             "metric": "MCMC iters/sec (full marker sweep)", "value": a.steps / elapsed, "unit": "iterations/s",
             "n_gpus": comm_world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": desc, "name": wl, "storage": a.storage,
+            "config": {"workload": desc, "name": wl, "variant": (f"{a.mt_method}/{a.mt_prior}" if t > 1 else None), "storage": a.storage,
                        "n": n, "p": p_total, "block_size": bs_now, "block_policy": "adaptive 512/1024" if adaptive else "fixed",
                        "parallelism": (f"{'row' if rows_mode else 'marker'}-shard x{world}" + (" (exact chain of the pooled data; one all-reduce of the block RHS per block launch)" if rows_mode else " (one all-reduce of the residual delta per sweep; residual resident in HBM)")) if world > 1 else "single GPU",
                        "ranks_reported_by_communicator": comm_world,

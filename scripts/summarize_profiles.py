@@ -93,7 +93,7 @@ if "fetch" in traffic and "write" in traffic:
         b = json.loads(open(os.path.join(root, "bench_under_pmc_fetch.json")).read().strip().splitlines()[-1])
         cfg = b["config"]
         row = {"config": {"workload": cfg["name"], "n": cfg["n"], "p": cfg["p"], "block_size": cfg["block_size"], "storage": cfg["storage"],
-                          "n_gpus": b["n_gpus"], "pi_fixed": (0.95 if "pifixed" in wname else None)},
+                          "n_gpus": b["n_gpus"], "pi_fixed": (0.95 if "pifixed" in wname else None), "variant": cfg.get("variant")},
                "bytes_per_launch": (traffic["fetch"] * 2 + traffic["write"]) * 1024.0,
                "fetch_KB_per_launch": traffic["fetch"], "write_KB_per_launch": traffic["write"],
                "algorithmic_bytes_per_launch": b["roofline"]["bytes_per_launch"],
