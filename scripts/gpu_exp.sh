@@ -1,7 +1,9 @@
 #!/bin/bash
-# scratch: the config-4 bench lines again, now that profiles/traffic.json holds their measured traffic
-mkdir -p gpurun_out/r03b
-python bench.py --via-api 0 --workload config4 --warmup 10 --burnin 0 > gpurun_out/r03b/bench_config4.json 2>/dev/null
-python bench.py --via-api 0 --workload config4 --mt-prior sparse > gpurun_out/r03b/bench_config4_sparse.json 2>/dev/null
-python bench.py --via-api 0 --workload config4 --mt-method BayesB --warmup 10 --burnin 0 > gpurun_out/r03b/bench_config4_bayesb.json 2>/dev/null
-tail -c 700 gpurun_out/r03b/bench_config4.json
+# scratch
+JWAS_HIP_PRESUM=1 python -m pytest tests/test_gpu_parity.py -q -m gpu -x -n 4 2>&1 | tail -2
+JWAS_HIP_PRESUM=1 python -m pytest tests/test_gpu_fuzz.py -q -m gpu -x 2>&1 | tail -2
+python -m pytest tests/test_gpu_fuzz.py -q -m gpu -x 2>&1 | tail -1
+for w in "config3" "config2 --pi-fixed 0.95" "config2 --storage packed2bit" "refbench" "config4" "config2"; do
+  echo "== $w"
+  JWAS_HIP_DEBUG_PHASES=1 timeout 900 python bench.py --workload $w --steps 5 --warmup 3 --burnin 30 --no-cpu-baseline 2>&1 | grep -E "jwas_hip\]|ms_per_step" | tail -2 | cut -c1-300
+done
