@@ -3,6 +3,10 @@
 #pragma once
 #include "kernels.hpp"
 
+// v_writelane_b32 (lane `lane` of `old` := the uniform value v; the other lanes keep theirs): this clang has no builtin for it --
+// the LLVM intrinsic by its own name (the compiler then places the required wait states itself)
+extern "C" __device__ int jw_llvm_amdgcn_writelane_i32(int v, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
+
 namespace jw {
 
 // ---------------------------------------------------------------------------------------------

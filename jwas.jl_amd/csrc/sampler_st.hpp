@@ -34,7 +34,6 @@ __device__ __forceinline__ void dense_section(const float* grow, int B, int nste
         const float x = (Q == 0) ? r0 : r1;
         const float an = RULED ? fmaf(kc1, x, kc0) : dense_alpha_new(x, da, ie, il, zs, ALLINC ? true : abc_included(x, lo, hi));
         const float Dl = ao - an;                                           // (excluded: alpha_old - 0)
-        rev = (lane == l) ? x : rev;
         const float D = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Dl), l));
         if (Q == 0) r0 = fmaf(D, c0, r0);                                   // D = 0: exact no-op
         if (TWO) r1 = fmaf(D, c1, r1);
@@ -61,6 +60,22 @@ __device__ __forceinline__ void dense_section(const float* grow, int B, int nste
     }
 #pragma unroll 1
     for (; l < nsteps; ++l) step(l, (Q == 0) ? grow[l * B + lane] : 0.f, TWO ? grow[l * B + 64 + lane] : 0.f);
+    rev = (Q == 0) ? r0 : r1;       // strictly upper diagonal tile: the lane's rhs has not moved since its own step
+}
+
+// The dense walks run on STRICTLY UPPER diagonal Gram tiles: G[l][c] = 0 for c <= l inside a 64-marker section, so that a
+// lane's running rhs stops moving at its own step (the later steps' updates are exact no-ops on it) and the walk needs no
+// per-step "remember what I was evaluated with" (a compare and a select of the ~10 issue slots of a step -- a lone wave
+// issues one instruction every ~8 cycles, scripts/micro/dep_latency.hip, so the walk is bound by its instruction COUNT).
+// One 64 x 64 tile with leading dimension ld, by the calling threads (nthr of them, thread index t).
+__device__ __forceinline__ void mask_diagonal_tile(float* tile, int ld, int t, int nthr)
+{
+    for (int e = t; e < 64 * 16; e += nthr) {                  // one float4 column group per thread and pass
+        const int l = e >> 4, c4 = (e & 15) * 4;
+        float* dst = tile + l * ld + c4;
+        if (c4 + 3 <= l) *reinterpret_cast<float4*>(dst) = float4{0.f, 0.f, 0.f, 0.f};
+        else if (c4 <= l) { dst[0] = 0.f; if (c4 + 1 <= l) dst[1] = 0.f; if (c4 + 2 <= l) dst[2] = 0.f; }
+    }
 }
 
 // ---- DENSE blocks of 256 / 512 markers (every marker of the block is included whatever its rhs: Pi = 0, RR-BLUP, BayesA,
@@ -120,6 +135,8 @@ __device__ __forceinline__ void dense_big_st(char* smem, const StepSmem& SM, con
         if (has_col) load_c(sec);
     };
     prefetch(0);
+    // (wave w walks tile w and nobody else reads it: it masks the tile itself -- LDS operations of one wave are in order)
+    if (wave < nsec) mask_diagonal_tile(reinterpret_cast<float*>(smem + SM.rows_off) + wave * 4096, 64, lane, 64);
 #pragma unroll 1
     for (int s = 0; s < nsec; ++s) {
         if (wave == s) {
@@ -370,6 +387,13 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
     const bool stream_corr = ((P->nreps > 0 ? P->nreps : b) == 1) && !prestage && A.b_next > 0;
     if (tid == 0) { int* wc0 = reinterpret_cast<int*>(smem + SM.wcnt_off); wc0[12] = 0; wc0[13] = 0; wc0[14] = 0; }
     if (stream_corr) for (int c = tid; c < B; c += kStepThreads) reinterpret_cast<int2*>(smem + SM.log_off)[c] = make_int2(-1, 0);
+    // small dense blocks (most markers are candidates): the serial wave walks them section by section (below) -- on strictly
+    // upper diagonal tiles (mask_diagonal_tile); the rows are not read again after the walk (single pass)
+    const bool dense_walk = !kR && ((P->nreps > 0 ? P->nreps : b) == 1) && prestage && 5 * ncand_all >= 3 * b;
+    if (dense_walk) {
+        float* rows_m = reinterpret_cast<float*>(smem + SM.rows_off);
+        for (int q = 0; q < (B >> 6); ++q) mask_diagonal_tile(rows_m + (64 * q) * B + 64 * q, B, tid, kStepThreads);
+    }
     __syncthreads();                               // (stage_rows reuses the slots)
     const long long tk1 = clock64();
     const long long tk2 = clock64();
@@ -444,7 +468,7 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
     // ~18 instructions per marker on a dependent chain of 11.
     bool dense_done = false;
     if constexpr (!kR) {
-        if (nreps == 1 && prestage && nstaged == b && 5 * ncand_all >= 3 * b) {
+        if (dense_walk) {
             float lo[2], hi[2], il[2], da[2], ao[2], rhsq[2], rev[2], bex[2], kc1[2] = {0.f, 0.f}, kc0[2] = {0.f, 0.f};
             double zs[2];
             bool always = true;
@@ -555,6 +579,12 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
             }
             unsigned long long pending = __ballot(valid);
             const bool nz = a_cur != 0.f;
+            // this sub-block's entries of the block's change list {local column, alpha_old - alpha_new} (marker order = commit
+            // order; read by the correction helpers while it grows and by the final stores) collect in two VGPRs -- lane e =
+            // the sub-block's e-th change, a lane wins at most once -- and go to LDS with ONE write when the sub-block is done
+            // (a round is ~70 instructions of one wave at ~8 cycles each: the per-change LDS write under a lane mask was 8 of them)
+            const int npub0 = npub;
+            int pub_col = 0, pub_D = 0;
             // speculative rounds: every pending lane tests ITS marker against the current rhs (float compares only);
             // the first lane whose effect changes commits, the rest are re-tested after its Gram row corrected the rhs.
             // Lanes before the winner stay out of the model with the values parked for them; only the winner writes.
@@ -592,9 +622,8 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
                 pending = (k == 63) ? 0ull : (pending & ~((2ull << k) - 1ull));
                 const float D = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Dl), k));
                 if (D != 0.f) {
-                    // the block's change list {local column, alpha_old - alpha_new}: marker order = commit order; read by
-                    // the correction helpers while it grows and by the final stores
-                    if (lane == 0) plog[npub] = make_int2(64 * s + k, __float_as_int(D));
+                    pub_col = jw_llvm_amdgcn_writelane_i32(64 * s + k, npub - npub0, pub_col);
+                    pub_D = jw_llvm_amdgcn_writelane_i32(__float_as_int(D), npub - npub0, pub_D);
                     ++npub;
                     // rhs += D * G[ce][:] (BayesABC.jl:169,172).  The active sub-block is corrected in its register
                     // copy -- the only value the next round waits for.
@@ -614,13 +643,14 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
                             rhs_lds[c2] = fmaf(D, rows[off + c2], rhs_lds[c2]);
                         }
                     } else {
-                        log_off = (lane == nlog) ? off : log_off;
-                        log_D = (lane == nlog) ? D : log_D;
+                        log_off = jw_llvm_amdgcn_writelane_i32(off, nlog, log_off);
+                        log_D = __int_as_float(jw_llvm_amdgcn_writelane_i32(__float_as_int(D), nlog, __float_as_int(log_D)));
                         ++nlog;
                     }
                 }
                 if (pending == 0ull) break;
             }
+            if (lane < npub - npub0) plog[npub0 + lane] = make_int2(pub_col, pub_D);
         }
         if (lane == 0) {
             wcnt_s[11] = npub;                                              // (read after the barrier)
