@@ -117,15 +117,20 @@ __device__ __forceinline__ void dense_big_st(char* smem, const StepSmem& SM, con
     // thread c reads column c of the Gram rows / cross-Gram rows of a section: one dword per lane, coalesced (256 bytes = two
     // lines per wave instruction).  (Reading the thread's own ROW instead -- G is symmetric -- as 16 dwordx4 loads was
     // measured 3x slower: 64 different lines per wave instruction keep the texture addresser busy ~360 cycles each.)
-    const float* gcol = A.gram + cl;                                    // G[k][c] = gram[k * b + c]
-    const float* ccol = A.cross_next + (has_col ? tid : 0);             // C[k][c'] = cross[k * bn + c']
+    // (address = UNIFORM row pointer + the lane's column: the load takes the row pointer from scalar registers and needs no
+    // vector address arithmetic -- 128 loads per thread and section, and the seven waves doing this share the walker's CU)
+    const int ccl = has_col ? tid : 0;
     auto load_g = [&](int s) {
+        const char* base = reinterpret_cast<const char*>(A.gram + (int64_t)(64 * s) * b);      // G[k][c] = gram[k * b + c]
+        unsigned off = 4u * (unsigned)cl;                               // (32-bit byte offset: one v_add per load)
 #pragma unroll
-        for (int u = 0; u < 64; ++u) gq[u] = gcol[(64 * s + u) * b];
+        for (int u = 0; u < 64; ++u) { gq[u] = *reinterpret_cast<const float*>(base + off); off += 4u * (unsigned)b; asm volatile("" : "+v"(off)); }
     };
     auto load_c = [&](int s) {
+        const char* base = reinterpret_cast<const char*>(A.cross_next + (int64_t)(64 * s) * bn);   // C[k][c'] = cross[k * bn + c']
+        unsigned off = 4u * (unsigned)ccl;
 #pragma unroll
-        for (int u = 0; u < 64; ++u) cq[u] = ccol[(64 * s + u) * bn];
+        for (int u = 0; u < 64; ++u) { cq[u] = *reinterpret_cast<const float*>(base + off); off += 4u * (unsigned)bn; asm volatile("" : "+v"(off)); }
     };
     // Barrier of the section loop: LDS traffic only.  (__syncthreads() also waits for every outstanding GLOBAL load -- the
     // prefetches below are meant to stay in flight across it.)
