@@ -1251,7 +1251,8 @@ static hipError_t launch_step_cx(jwas_hip_ctx* c, const CX& cx, const UpdateArgs
     UpdateArgsT<CX> U;
     static_cast<UpdateArgs&>(U) = U0;
     U.cx = cx;
-    constexpr bool kHasDense = (METHOD == kBayesC || METHOD == kBayesB) && NT == 1;       // sweeps under a uniform pi = 0 (Rule D)
+    // DENSE instantiations: single-trait sweeps under a uniform pi = 0 (Rule D), and the multi-trait samplers' dense-walk-only form
+    constexpr bool kHasDense = ((METHOD == kBayesC || METHOD == kBayesB) && NT == 1) || (is_mt_method(METHOD) && !is_sampler2(METHOD));
     const bool dn = kHasDense && dense;
     const StepSmem SM(c->block_size, NT, is_mt_method(METHOD) ? mt_park_nd(c->block_size, NT) + (S.lpr_mat ? (1 << NT) : 0) : st_park_nd(METHOD), is_mt_method(METHOD) ? mt_park_nf(c->block_size, NT) + (has_marker_cov(METHOD) ? NT * NT : 0) : st_park_nf(METHOD, dn));
     static unsigned long long attr_set = 0ull;       // one bit per device: the attribute belongs to the device's code object
@@ -1322,9 +1323,9 @@ static hipError_t launch_step_any(jwas_hip_ctx* c, const UpdateArgs& U, const Sa
         case JWAS_HIP_BAYESB: return launch_step<kBayesB, 1>(c, U, S, do_sample, dense);
         case JWAS_HIP_BAYESR: return launch_step<kBayesR, 1>(c, U, S, do_sample);
 #define JW_MT_STEP(M)                                                            \
-            if (c->ntraits == 2) return launch_step<M, 2>(c, U, S, do_sample);       \
-            if (c->ntraits == 3) return launch_step<M, 3>(c, U, S, do_sample);       \
-            return launch_step<M, 4>(c, U, S, do_sample);
+            if (c->ntraits == 2) return launch_step<M, 2>(c, U, S, do_sample, dense);       \
+            if (c->ntraits == 3) return launch_step<M, 3>(c, U, S, do_sample, dense);       \
+            return launch_step<M, 4>(c, U, S, do_sample, dense);
         case JWAS_HIP_MTBAYESC2: JW_MT_STEP(kMTBayesC2)
         case JWAS_HIP_MEGABAYESC: JW_MT_STEP(kMegaBayesC)
         case JWAS_HIP_MTBAYESB1: JW_MT_STEP(kMTBayesB1)
@@ -1744,6 +1745,12 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
     // kernel instantiation whose sampler follows Rule D on every path and takes dense_big_st on full 256- / 512-marker blocks
     // (sweep.hpp).  Every marker of every block changes, so the update role shares the apply work (COOP) unless told not to.
     const bool dense_big = (c->method == JWAS_HIP_BAYESC || c->method == JWAS_HIP_BAYESB) && P->pi == 0.0 && P->pi_vec == nullptr;
+    // multi-trait sweeps in which most markers changed last time (the reference's default prior: every marker in the model),
+    // single pass over <= 128-marker blocks: the dense-walk-only instantiation of the sampler (sampler_role_mt<.., DW>: the same
+    // chain, a fraction of the code).  JWAS_HIP_DENSE_MT=0|1 overrides (tests: both instantiations give the same bits).
+    const char* edm = std::getenv("JWAS_HIP_DENSE_MT");
+    const bool dense_mt = is_mt_method(c->method) && !is_sampler2(c->method) && c->block_size <= 128 && P->nreps == 1 && !P->independent_blocks &&
+                          (edm ? std::atoi(edm) != 0 : c->last_events >= 0.6 * (double)c->p);
     const int dense_big_off = std::getenv("JWAS_HIP_DENSE_BIG_OFF") != nullptr ? 1 : 0;      // (tests: the same chain through the general path)
     if (independent) {
         int rc = sweep_independent(c, &ev_list, dense_big, dense_big_off);
@@ -1814,7 +1821,7 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
             while (c->kev.size() < 2 * (ntimed + 1)) { hipEvent_t e; HIPCHK(c, hipEventCreate(&e)); c->kev.push_back(e); }
             HIPCHK(c, hipEventRecord(c->kev[2 * ntimed], c->stream));
         }
-        HIPCHK(c, launch_step_any(c, U, S, sb >= 0, dense_big));
+        HIPCHK(c, launch_step_any(c, U, S, sb >= 0, dense_big || dense_mt));
         if (c->row_mode && U.b > 0) {          // the block's partial RHS summed over the ranks' individuals, before its sampler runs
             int rc = row_allreduce(c, U.partials, (size_t)t * c->nrg * bs, true);
             if (rc) return rc;

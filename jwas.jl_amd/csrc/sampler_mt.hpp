@@ -572,9 +572,16 @@ __device__ __forceinline__ void mt2_eval(const MtConsts<NT>& K, const double* lp
 // SAMPLER role, multi-trait: Gibbs sampler I (MTBayesABC.jl:57-127, block form :243-333), sampler II
 // (:129-210) and megaBayesABC! (BayesABC.jl:1-8) share the schedule; only the per-marker evaluation differs.
 // ---------------------------------------------------------------------------------------------
-template <int METHOD, int NT>
+// DW: the instantiation for sweeps in which (nearly) every marker is in the model (selected by the host from the previous
+// sweep's change count, for single-pass sweeps over <= 128-marker blocks): EVERY block takes the dense walk -- which is exact
+// for any state, markers outside the model are simply evaluated the general way at their step -- so the candidacy evaluation
+// of the front, the prefix skip, row staging and the speculative rounds are compiled out.  Same results as the general
+// instantiation, bit for bit (the walk and the rounds are the same chain); the point is the CODE SIZE: the front is ~3 000
+// cold instructions per launch, fetched at memory latency.
+template <int METHOD, int NT, bool DW = false>
 __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A)
 {
+    constexpr bool kDW = DW && !is_sampler2(METHOD);
     const bool pm = A.lpr_mat != nullptr;           // marker-specific joint priors (host: only with parked draws)
     constexpr bool kPG = has_marker_cov(METHOD);   // a t x t effect covariance per marker (host: only with parked draws)
     const StepSmem SM(A.bsz, NT, mt_park_nd(A.bsz, NT) + (pm ? (1 << NT) : 0), mt_park_nf(A.bsz, NT) + (kPG ? NT * NT : 0));
@@ -763,7 +770,8 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
 #pragma unroll
         for (int t = 0; t < NT; ++t) in_model = in_model || (a0[q][t] != 0.f);
         bool moves = false;
-        if (!in_model) {
+        if constexpr (kDW) { in_model = true; }
+        else if (!in_model) {
             const float dj = djq_[q];
             MtConsts<NT> Kc = K;
             if constexpr (kPG) Kc = with_ginv(gq_[q]);
@@ -795,7 +803,17 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
     // that holds a candidate.  Single pass only.
     int first_sub = 16, ncand_all = 0;
     bool dense_walk = false;
-    {
+    if constexpr (kDW) {
+        first_sub = 0; ncand_all = b; dense_walk = true;
+        float* rows_m = reinterpret_cast<float*>(smem + SM.rows_off);
+        for (int e = tid; e < (B >> 6) * 64 * 16; e += kStepThreads) {     // strictly upper diagonal tiles (see below)
+            const int q = e >> 10, l = (e >> 4) & 63, c4 = (e & 15) * 4;
+            float* dst = rows_m + (64 * q + l) * B + 64 * q + c4;
+            if (c4 + 3 <= l) *reinterpret_cast<float4*>(dst) = float4{0.f, 0.f, 0.f, 0.f};
+            else if (c4 <= l) { dst[0] = 0.f; if (c4 + 1 <= l) dst[1] = 0.f; if (c4 + 2 <= l) dst[2] = 0.f; }
+        }
+        __syncthreads();
+    } else {
         int* wc = reinterpret_cast<int*>(smem + SM.wcnt_off);
         const int f0 = __any(cand[0]) ? 1 : 0, f1 = __any(cand[1]) ? 2 : 0;
         const int npop = __popcll(__ballot(cand[0])) + __popcll(__ballot(cand[1]));
@@ -833,7 +851,7 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
         __syncthreads();                                   // (stage_rows reuses the slots)
     }
     const long long tk1 = clock64();
-    const int nstaged_mt = prestage ? b : (first_sub >= 16 ? 0 : stage_rows(smem, SM, A, cand));
+    const int nstaged_mt = (kDW || prestage) ? b : (first_sub >= 16 ? 0 : stage_rows(smem, SM, A, cand));
     if (cross_dma) {                                       // waves 1..7: the cross-Gram rows to LDS while wave 0 walks the block
         dma_copy_to_lds(A.cross_next, reinterpret_cast<float*>(smem + SM.cross_off), B * B, 1);
         if (wave != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1047,6 +1065,7 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
     if (dense_done && lane == 0) wcnt_s[14] = 1;
 
     const int s_first = (nreps == 1 && !dense_done) ? (first_sub < nsub ? first_sub : nsub) : 0;       // prefix skip (single pass only)
+    if constexpr (!kDW)
     for (int rep = 0; rep < (dense_done ? 0 : nreps); ++rep) {
         key.rep = (uint32_t)rep;
 #pragma unroll 1

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(kStepThreads) void k_block_step(UpdateArgsT<CX> U, 
         for (int i = threadIdx.x; i < 150000 / 4; i += kStepThreads) reinterpret_cast<unsigned*>(smem)[i] = (unsigned)(JWAS_HIP_POISON_LDS);
         __syncthreads();
 #endif
-        if constexpr (is_mt_method(METHOD)) sampler_role_mt<METHOD, NT>(smem, S);
+        if constexpr (is_mt_method(METHOD)) sampler_role_mt<METHOD, NT, DENSE>(smem, S);
         else sampler_role_st<METHOD, DENSE>(smem, S);
         return;
     }

@@ -712,6 +712,59 @@ def test_row_group_geometry_does_not_change_the_chain(spg, monkeypatch):
         hip.close()
 
 
+@pytest.mark.parametrize("method,t,bs,sparse", [("MTBayesC", 3, 128, False), ("MTBayesC", 2, 64, True), ("MegaBayesC", 3, 128, False),
+                                                ("MTBayesB", 3, 128, False), ("MegaBayesB", 2, 64, True)])
+def test_dense_walk_only_multitrait_instantiation_is_bit_identical(method, t, bs, sparse, monkeypatch):
+    """The multi-trait sampler's dense-walk-only instantiation (sampler_role_mt<.., DW>: every block walked marker by marker,
+    candidacy evaluation / prefix skip / row staging / speculative rounds compiled out; the host picks it after a sweep in which
+    most markers changed) against the general instantiation, forced on and off (JWAS_HIP_DENSE_MT): the same chain BIT FOR
+    BIT -- also from a sparse state, where the general instantiation runs speculative rounds and the walk evaluates the markers
+    outside the model the general way -- with a ragged last block, and against the oracle."""
+    import jwas_jl_amd as J
+    data = make_dataset(n=700, p=3 * bs + 37, ncausal=9, seed=31 + t)
+    y = data["y"] - data["y"].mean()
+    rng = np.random.default_rng(3)
+    p = data["X"].shape[1]
+    A = rng.standard_normal((t, t))
+    vare = ((A @ A.T / t + np.eye(t)) * 0.5).astype(np.float32)
+    mega = method.startswith("Mega")
+    if mega:
+        vare = np.diag(np.diag(vare))
+        kw = dict(vare=vare, var_effect=(np.eye(t) * 0.003).astype(np.float32), pi=np.full(t, 0.9 if sparse else 0.02))
+    else:
+        prior = np.full(1 << t, 0.1 / ((1 << t) - 1)) if sparse else np.full(1 << t, 1e-3)
+        prior[0 if sparse else -1] = 0.9 if sparse else 1.0
+        prior /= prior.sum()
+        kw = dict(vare=vare, var_effect=(np.eye(t) * 0.003).astype(np.float32), log_prior_states=np.log(prior))
+    if method in ("MTBayesB", "MegaBayesB"):
+        Vm = np.zeros((p, t, t), dtype=np.float32)
+        for k in range(t):
+            Vm[:, k, k] = 0.003 * np.exp(rng.uniform(-1, 1, p))
+        kw["var_effect_matrix"] = Vm
+    results = {}
+    for tag, env in (("oracle", None), ("walk", "1"), ("general", "0")):
+        if env is not None:
+            monkeypatch.setenv("JWAS_HIP_DENSE_MT", env)
+        e = OracleEngine("lookahead") if env is None else J.HipEngine(0)
+        try:
+            e.load_dense(data["X"]); e.setup_blocks(bs, "f64"); e.init_state(method, t)
+            for k in range(t):
+                e.set_residual(((1 + 0.25 * k) * y).astype(np.float32), k)
+                e.set_state(k, delta=np.ones(p, dtype=np.float32))
+            ev = [e.sweep(iteration=it, seed=19, **kw)["n_events"] for it in range(1, 8)]
+            results[tag] = ([e.get_state(k) for k in range(t)], [e.get_residual(k) for k in range(t)], ev)
+        finally:
+            if env is not None:
+                e.close()
+    assert results["walk"][2] == results["general"][2] == results["oracle"][2]
+    for k in range(t):
+        for q in range(3):
+            assert np.array_equal(results["walk"][0][k][q], results["general"][0][k][q])
+        assert np.array_equal(results["walk"][1][k], results["general"][1][k])
+        np.testing.assert_allclose(results["walk"][0][k][0], results["oracle"][0][k][0], atol=5e-6)
+        assert np.array_equal(results["walk"][0][k][2], results["oracle"][0][k][2])
+
+
 @pytest.mark.parametrize("method,t,bs,pi", [("BayesC", 1, 128, 0.0), ("BayesC", 1, 256, 0.5), ("MTBayesC", 3, 128, None), ("BayesR", 1, 64, None)])
 def test_cooperative_dense_apply_is_bit_identical(method, t, bs, pi, monkeypatch):
     """Dense sweeps let the column groups of a row group split the rows when a block's changes are applied to the residual
