@@ -121,10 +121,13 @@ __device__ __forceinline__ void mt1_linear_beta(const float (&A)[NT][NT], const 
 }
 
 // Gibbs sampler I (MTBayesABC.jl:85-120); LIN: apply Rule L to the result (off only where the result's VALUES are not kept).
+// Apre / cpre: Rule L's coefficients of this marker when the caller has formed them already (the dense walk: once per
+// section) -- the same numbers mt1_linear_coeffs would give here (same constants, entry beta and draws).
 template <int NT, bool LIN = true, class LP>
 __device__ __forceinline__ void mt1_eval(const MtConsts<NT>& K, const MtPre<NT>& Q, const LP& lp, const float (&w)[NT], float dj,
                                          const double (&thr)[NT], const double (&z)[NT],
-                                         float (&an)[NT], float (&bn)[NT], float (&dn)[NT], float (&Dl)[NT])
+                                         float (&an)[NT], float (&bn)[NT], float (&dn)[NT], float (&Dl)[NT],
+                                         const float (*Apre)[NT] = nullptr, const float* cpre = nullptr)
 {
     float a_in[NT], b_in[NT];
     bool all1 = LIN;
@@ -172,7 +175,14 @@ __device__ __forceinline__ void mt1_eval(const MtConsts<NT>& K, const MtPre<NT>&
         for (int k = 0; k < NT; ++k) all1 = all1 && (dn[k] == 1.f);
         if (all1) {                                                                 // Rule L
             float A[NT][NT], cc[NT];
-            mt1_linear_coeffs<NT>(K, Q, dj, b_in, z, A, cc);
+            if (Apre != nullptr) {
+#pragma unroll
+                for (int k = 0; k < NT; ++k) {
+                    cc[k] = cpre[k];
+#pragma unroll
+                    for (int m = 0; m < NT; ++m) A[k][m] = Apre[k][m];
+                }
+            } else mt1_linear_coeffs<NT>(K, Q, dj, b_in, z, A, cc);
             mt1_linear_beta<NT>(A, cc, w, bn);
 #pragma unroll
             for (int k = 0; k < NT; ++k) { an[k] = bn[k]; Dl[k] = a_in[k] - bn[k]; }
@@ -907,15 +917,16 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
         }
         const bool speculate = is_sampler1(METHOD);
         // one marker evaluated in-lane from (w, its state at block entry, its draws)
-        auto eval_own = [&](int q, const float (&w)[NT], float (&an)[NT], float (&bn)[NT], float (&dn)[NT], float (&Dl)[NT]) {
+        auto eval_own = [&](int q, const float (&w)[NT], float (&an)[NT], float (&bn)[NT], float (&dn)[NT], float (&Dl)[NT],
+                            const float (*Apre)[NT] = nullptr, const float* cpre = nullptr) {
             const int c = (64 * q + lane < b) ? 64 * q + lane : 0;
             double thr[NT], z[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) { an[t] = aq[t][q]; bn[t] = bq[t][q]; dn[t] = dq[t][q]; Dl[t] = 0.f; thr[t] = thrq[t][q]; z[t] = zq[t][q]; }
             // (the shared prior table from registers -- v_cndmask trees instead of the LDS lookup -- was measured: 79 ms
             // per sweep instead of 55 at 3 traits x 20k x 100k; the LDS read overlaps the trait's arithmetic well enough)
-            if constexpr (is_sampler1(METHOD)) mt1_eval<NT>(KQ(q), Qq[q], PriorMem{lpr_of(c), ls}, w, djq[q], thr, z, an, bn, dn, Dl);
-            else mega_eval<NT>(KQ(q), Qq[q], w, djq[q], thr, z, an, bn, dn, Dl);
+            if constexpr (is_sampler1(METHOD)) mt1_eval<NT>(KQ(q), Qq[q], PriorMem{lpr_of(c), ls}, w, djq[q], thr, z, an, bn, dn, Dl, Apre, cpre);
+            else { (void)Apre; (void)cpre; mega_eval<NT>(KQ(q), Qq[q], w, djq[q], thr, z, an, bn, dn, Dl); }
         };
         // the speculative conditionals = Rule L's linear form (mt1_linear_coeffs): A, c of the lane's own marker are formed once
         // per section; a step is NT^2 fused multiply-adds.  Dl = alpha_old - alpha_new
@@ -933,14 +944,13 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
         };
         // 64-marker section q: eight steps per batch without a branch, the Gram rows read a batch ahead
         // (TWO: blocks of 128 markers -- the second half's running rhs follows too; a compile-time property of the loop body)
-        auto section = [&](auto qc, auto fastc, auto twoc, const float* grow, int nsteps) {
+        auto section = [&](auto qc, auto fastc, auto twoc, const float* grow, int nsteps, const float (&Al)[NT][NT], const float (&cl)[NT]) {
             constexpr int Q = decltype(qc)::value;
             constexpr bool FAST = decltype(fastc)::value;
             constexpr bool TWO = decltype(twoc)::value;
-            float Al[NT][NT], cl[NT], da[NT];
+            float da[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) da[t] = djq[Q] * aq[t][Q];                                 // :82
-            if constexpr (FAST) linear_of(Q, Al, cl);
             auto step = [&](int l, float c0, float c1) {
                 float w[NT], an[NT], bn[NT], dn[NT], Dl[NT];
 #pragma unroll
@@ -983,13 +993,12 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
         using std::integral_constant;
         // the same section with some markers (bit l of `slow`) evaluated the general way and the others speculatively: one
         // step per loop trip (used when the speculation missed, or when a marker is not in the model for every trait at entry)
-        auto section_mixed = [&](auto qc, auto twoc, const float* grow, int nsteps, unsigned long long slow) {
+        auto section_mixed = [&](auto qc, auto twoc, const float* grow, int nsteps, unsigned long long slow, const float (&Al)[NT][NT], const float (&cl)[NT]) {
             constexpr int Q = decltype(qc)::value;
             constexpr bool TWO = decltype(twoc)::value;
-            float Al[NT][NT], cl[NT], da[NT];
+            float da[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) da[t] = djq[Q] * aq[t][Q];
-            linear_of(Q, Al, cl);
             float g0 = (Q == 0) ? grow[lane] : 0.f;
             float g1 = TWO ? grow[64 + lane] : 0.f;
 #pragma unroll 1
@@ -997,7 +1006,7 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
                 float w[NT], an[NT], bn[NT], dn[NT], Dl[NT];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) w[t] = rhsq[t][Q] + da[t];
-                if ((slow >> l) & 1ull) eval_own(Q, w, an, bn, dn, Dl);                               // (wave-uniform)
+                if ((slow >> l) & 1ull) eval_own(Q, w, an, bn, dn, Dl, Al, cl);                       // (wave-uniform)
                 else eval_fast(Q, w, Al, cl, bn, Dl);
                 const float c0 = g0, c1 = g1;
                 grow += B;                                           // next marker's row (one past the block: the overflow row)
@@ -1020,7 +1029,9 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
             const float* grow = rows + 64 * Q * B;                   // (all rows staged in marker order: slot = marker)
             const int c = 64 * Q + lane;
             float an[NT], bn[NT], dn[NT], Dl[NT];
+            float Alq[NT][NT], clq[NT];                              // Rule L's coefficients of the section's markers: formed ONCE
             if (speculate) {
+                linear_of(Q, Alq, clq);
                 float rs[NT][2];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) { rs[t][0] = rhsq[t][0]; rs[t][1] = rhsq[t][1]; }
@@ -1030,10 +1041,10 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
                 for (int t = 0; t < NT; ++t) in_all = in_all && (dq[t][Q] == 1.f);
                 unsigned long long slow = __ballot(!in_all && c < b);
                 if (__popcll(slow) * 4 > nsteps) slow = ~0ull;       // not a block to speculate on: everything the general way
-                if (slow == 0ull) section(qc, integral_constant<bool, true>{}, twoc, grow, nsteps);
-                else section_mixed(qc, twoc, grow, nsteps, slow);
+                if (slow == 0ull) section(qc, integral_constant<bool, true>{}, twoc, grow, nsteps, Alq, clq);
+                else section_mixed(qc, twoc, grow, nsteps, slow, Alq, clq);
                 for (int pass = 0; pass < 64; ++pass) {
-                    eval_own(Q, wev[Q], an, bn, dn, Dl);             // the exact evaluation of every marker of the section
+                    eval_own(Q, wev[Q], an, bn, dn, Dl, Alq, clq);   // the exact evaluation of every marker of the section
                     bool ok = true;
 #pragma unroll
                     for (int t = 0; t < NT; ++t) ok = ok && (dn[t] == 1.f);
@@ -1045,11 +1056,11 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
                     if (__popcll(slow) * 4 > nsteps) slow = ~0ull;   // (misses are not rare here: stop speculating)
 #pragma unroll
                     for (int t = 0; t < NT; ++t) { rhsq[t][0] = rs[t][0]; rhsq[t][1] = rs[t][1]; }
-                    section_mixed(qc, twoc, grow, nsteps, slow);
+                    section_mixed(qc, twoc, grow, nsteps, slow, Alq, clq);
                     ++nrounds;                                       // (diagnostics: sections walked again)
                 }
             } else {
-                section(qc, integral_constant<bool, false>{}, twoc, grow, nsteps);
+                section(qc, integral_constant<bool, false>{}, twoc, grow, nsteps, Alq, clq);
                 eval_own(Q, wev[Q], an, bn, dn, Dl);
             }
             if (c < B)
