@@ -698,7 +698,7 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
     float djq_[2], a0[2][NT], b0[2][NT], d0[2][NT], w0[2][NT], lc0[2][NT], gq_[2][kPG ? NT * NT : 1];
     double thr0[2][NT], z0[2][NT];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < (kDW ? 1 : 2); ++q) {
         const int c = tid + q * kStepThreads;
         if (c >= B) continue;
         const int cc = c < b ? c : 0;
@@ -773,7 +773,7 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
     bool stay[2] = {false, false};
     float pb[2][NT], pd[2][NT];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < (kDW ? 1 : 2); ++q) {
         const int c = tid + q * kStepThreads;
         if (c >= b) continue;
         bool in_model = false;
