@@ -27,6 +27,12 @@
 #include <stdint.h>
 #include "rng.hpp"
 
+// non-template kernels live in this header: the translation unit that owns them (jwas_hip.hip) leaves this empty, any other one
+// (resident_launch.hip) defines it `static` so that the two object files do not both export them
+#ifndef JW_PLAIN_KERNEL
+#define JW_PLAIN_KERNEL
+#endif
+
 namespace jw {
 
 constexpr int kSliceRows = 256;      // rows of r owned by one workgroup of k_update_partial
@@ -829,7 +835,7 @@ __global__ __launch_bounds__(256) void k_marker_stats(int method, int64_t p, con
 }
 
 // running posterior means (output.jl:568-577)
-__global__ __launch_bounds__(256) void k_accumulate(int64_t count, int delta_is_class, double k,
+JW_PLAIN_KERNEL __global__ __launch_bounds__(256) void k_accumulate(int64_t count, int delta_is_class, double k,
                                                     const float* __restrict__ alpha, const void* __restrict__ delta_v,
                                                     float* __restrict__ mean_a, float* __restrict__ mean_a2,
                                                     float* __restrict__ mean_d)
@@ -1079,7 +1085,7 @@ __global__ __launch_bounds__(256) void k_window_partial(CX cx, int nwin, const i
     }
 }
 // out[v * nwin + w] = sum over the slices (fixed order) of value v of window w
-__global__ __launch_bounds__(256) void k_window_reduce(int nwin, int nslices, int nv, const double* __restrict__ partial,
+JW_PLAIN_KERNEL __global__ __launch_bounds__(256) void k_window_reduce(int nwin, int nslices, int nv, const double* __restrict__ partial,
                                                        double* __restrict__ out)
 {
     const int w = blockIdx.x * 256 + threadIdx.x;
@@ -1106,7 +1112,7 @@ __global__ __launch_bounds__(256) void k_mul_alpha_list(CX cx, int nnz, const in
 
 // The nonzero effects of one trait as (index, value) lists in marker order.  grid = 1, block = 1024: the workgroup walks
 // the p effects 1024 at a time with a running offset (ballot + wave prefix), ~30 us at p = 600 000.
-__global__ __launch_bounds__(1024) void k_compact_alpha(int64_t p, const float* __restrict__ alpha, int32_t* __restrict__ idx,
+JW_PLAIN_KERNEL __global__ __launch_bounds__(1024) void k_compact_alpha(int64_t p, const float* __restrict__ alpha, int32_t* __restrict__ idx,
                                                         float* __restrict__ val, int32_t* __restrict__ count)
 {
     __shared__ int wsum[16];
@@ -1153,7 +1159,7 @@ __global__ __launch_bounds__(256) void k_sub_xalpha(CX cx, int64_t p,
 // kind 2 = single-step shaped input (the dense real-valued matrix impute_genotypes hands to the sweep, SSBR.jl:83-142):
 // rows < n_int are 0/1/2 genotypes, rows >= n_int are "imputed": the average of two genotyped rows (a, b) drawn per
 // ROW (the same linear map for every marker, as A_ng A_gg^-1 M_g is).
-__global__ __launch_bounds__(256) void k_synth(float* X, int64_t n, int64_t ld, uint32_t seed_lo,
+JW_PLAIN_KERNEL __global__ __launch_bounds__(256) void k_synth(float* X, int64_t n, int64_t ld, uint32_t seed_lo,
                                                uint32_t seed_hi, int kind, int center, uint32_t marker0, int64_t n_int = 0)
 {
     __shared__ double red[4];
@@ -1195,7 +1201,7 @@ __global__ __launch_bounds__(256) void k_synth(float* X, int64_t n, int64_t ld, 
 
 // Same generator, written as the reference's 2-bit codes + per-marker mean (kind 0 only: 0/1/2 genotypes).
 // Q: [p][sb] bytes, sb = ld/4.  The decoded matrix equals k_synth's output bit for bit.
-__global__ __launch_bounds__(256) void k_synth_packed(uint8_t* __restrict__ Q, float* __restrict__ mean, int64_t n, int64_t ld,
+JW_PLAIN_KERNEL __global__ __launch_bounds__(256) void k_synth_packed(uint8_t* __restrict__ Q, float* __restrict__ mean, int64_t n, int64_t ld,
                                                       uint32_t seed_lo, uint32_t seed_hi, uint32_t marker0)
 {
     __shared__ double red[4];
@@ -1232,6 +1238,6 @@ __global__ __launch_bounds__(256) void k_get_columns(CX cx, int64_t j0, int64_t 
 }
 
 // empty kernel: calibrates what a HIP-event pair around ONE launch measures beyond the kernel itself
-__global__ void k_null() {}
+JW_PLAIN_KERNEL __global__ void k_null() {}
 
 }  // namespace jw

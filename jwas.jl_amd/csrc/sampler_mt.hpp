@@ -588,7 +588,7 @@ __device__ __forceinline__ void mt2_eval(const MtConsts<NT>& K, const double* lp
 // of the front, the prefix skip, row staging and the speculative rounds are compiled out.  Same results as the general
 // instantiation, bit for bit (the walk and the rounds are the same chain); the point is the CODE SIZE: the front is ~3 000
 // cold instructions per launch, fetched at memory latency.
-template <int METHOD, int NT, bool DW = false>
+template <int METHOD, int NT, bool DW = false, bool RES = false>       // RES: inside the resident sampler kernel (see sampler_role_st)
 __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A)
 {
     constexpr bool kDW = DW && !is_sampler2(METHOD);
@@ -723,7 +723,7 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
             for (int st = 0; st < (1 << NT); ++st) lpm[st] = A.lpr_mat[(int64_t)(1 << NT) * j + st];
         }
         double psum[NT];
-        sum_partials_traits<NT>(A.partials + cc, (int64_t)A.nrg * A.bstride, A.nrg, A.bstride, psum);
+        sum_partials_traits<NT, RES>(A.partials + cc, (int64_t)A.nrg * A.bstride, A.nrg, A.bstride, psum);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const double sum = psum[t];
@@ -1193,9 +1193,9 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
         const int* fin = reinterpret_cast<const int*>(smem + SM.log_off);
         for (int e = tid; e < nfin; e += kStepThreads) {
             const int ce = fin[e];
-            A.ev_out->idx[e] = (int32_t)(j0 + ce);
+            st_coh<RES>(&A.ev_out->idx[e], (int32_t)(j0 + ce));
 #pragma unroll
-            for (int t = 0; t < NT; ++t) A.ev_out->delta[t][e] = astart[t * B + ce] - acur[t * B + ce];
+            for (int t = 0; t < NT; ++t) st_coh<RES>(&A.ev_out->delta[t][e], astart[t * B + ce] - acur[t * B + ce]);
         }
     }
     for (int c = tid; c < b; c += kStepThreads) {
@@ -1208,7 +1208,7 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
         }
     }
     if (tid == 0) {
-        A.ev_out->count = nfin;
+        st_coh<RES>(&A.ev_out->count, (int32_t)nfin);
         atomicAdd(&A.counters[0], (unsigned long long)nfin);
         atomicAdd(&A.counters[2], (unsigned long long)(tk1 - tk0));      // phase cycle counts (diagnostics)
         atomicAdd(&A.counters[4], (unsigned long long)(tk3 - tk1));

@@ -233,7 +233,7 @@ __global__ __launch_bounds__(kStepThreads) void k_indep_sample(SamplerArgs S, in
 }
 
 // Exclusive scan of the per-block change counts.  grid = 1, block = 1024.
-__global__ __launch_bounds__(1024) void k_indep_scan(const Events* __restrict__ ev_all, int nblocks,
+JW_PLAIN_KERNEL __global__ __launch_bounds__(1024) void k_indep_scan(const Events* __restrict__ ev_all, int nblocks,
                                                      int32_t* __restrict__ offs, int32_t* __restrict__ total)
 {
     __shared__ int wsum[16];
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(1024) void k_indep_scan(const Events* __restrict__ 
 }
 
 // Compact the per-block change lists into one list in (block, marker) order.  grid = nblocks, block = 256.
-__global__ __launch_bounds__(256) void k_indep_gather(const Events* __restrict__ ev_all, const int32_t* __restrict__ offs,
+JW_PLAIN_KERNEL __global__ __launch_bounds__(256) void k_indep_gather(const Events* __restrict__ ev_all, const int32_t* __restrict__ offs,
                                                       int nt, int32_t* __restrict__ idx_all, float* __restrict__ delta_all,
                                                       int64_t dstride)
 {

@@ -2,20 +2,33 @@
 // cooperative dense apply -- then the block's partial right-hand side).  Included by sweep.hpp.
 #pragma once
 #include "kernels.hpp"
+#include "coherent.hpp"
 
 namespace jw {
 
 // ---------------------------------------------------------------------------------------------
 // UPDATE/PARTIAL role
 // ---------------------------------------------------------------------------------------------
-template <int NT, class CX, bool COOP = false>
+// RES (resident-sampler sweeps, resident.hpp): the change list `ev` is published by a sampler kernel that runs CONCURRENTLY --
+// the workgroup waits (bounded) until res.done says so, reads the list with coherent loads, stores its partial sums with
+// coherent (write-through) stores and reports them with one arrival per workgroup.
+struct ResidentLink {
+    int* done;          // number of blocks whose change list has been published (monotonic within a sweep)
+    int need_done;      // this launch may read its list once *done >= need_done (0: nothing to wait for)
+    int* abort;         // set by whoever gave up waiting: the host re-runs the sweep through the launch-per-block path
+    int* arrive;        // this block's arrival counter (one increment per workgroup whose partial sums are stored), or NULL
+    int* ticket;        // this launch's {work ticket, helper claim} counters (quiet sweeps: resident.hpp)
+};
+constexpr long long kResidentUpdateTimeout = 20000000ll;      // wall_clock64 ticks (100 MHz): 200 ms
+template <int NT, class CX, bool COOP = false, bool RES = false>
 __device__ __forceinline__ void update_role(char* smem, int rg, int g,
                                             const CX& cx,
                                             const float* __restrict__ r_in, float* __restrict__ r_out,
                                             const Events* __restrict__ ev,
                                             int64_t j0, int b, int nslices, int nrg, int ncg,
                                             double* __restrict__ partials, int bstride, int spg = kRowGroupSlices,
-                                            int* sync_now = nullptr, int* sync_next = nullptr, unsigned long long* dbg = nullptr)
+                                            int* sync_now = nullptr, int* sync_next = nullptr, unsigned long long* dbg = nullptr,
+                                            ResidentLink res = ResidentLink{nullptr, 0, nullptr, nullptr, nullptr})
 {
 #ifdef JWAS_HIP_DEV_KNOBS
 #define JW_UPD_CLOCK(v) v = clock64()
@@ -66,9 +79,38 @@ __device__ __forceinline__ void update_role(char* smem, int rg, int g,
     float4 rv[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) rv[t] = *reinterpret_cast<const float4*>(r_in + t * ld + row);
+    if constexpr (RES) {
+        // the list is published by the resident sampler: wait for it (the column loads above are already in flight).  The wait
+        // is BOUNDED; giving up marks the sweep aborted and the host re-runs it through the launch-per-block path.
+        if (res.need_done > 0) {
+            int* flag = reinterpret_cast<int*>(smem);                    // (the reduction scratch is not in use yet)
+            if (tid == 0) {
+                int ok = 0;
+                const long long t0 = wall_clock64();
+                const long long tc0 = clock64();
+                while (true) {
+                    if (__hip_atomic_load(res.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= res.need_done) { ok = 1; break; }
+                    if (__hip_atomic_load(res.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                    if (wall_clock64() - t0 > kResidentUpdateTimeout) {
+                        if (__hip_atomic_exchange(res.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {      // (diagnostics: who gave up first)
+                            res.abort[1] = 1; res.abort[2] = res.need_done; res.abort[3] = __hip_atomic_load(res.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                *flag = ok;
+                if (dbg != nullptr && rg == 0 && g == 0) atomicAdd(&dbg[15], (unsigned long long)(clock64() - tc0));      // diagnostics: one workgroup's wait
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // (LDS only: the column loads stay in flight)
+            const int ok = *flag;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (!ok) return;
+        } else if (__hip_atomic_load(res.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+    }
     // (dense priors apply a whole block of changes here: 16 column loads in flight per wave, the fmaf chain per row
     // stays in list order)
-    const int ne = ev->count;
+    const int ne = ld_coh<RES>(&ev->count);
     constexpr int kEB = 16;
     // ---- COOPERATIVE DENSE APPLY.  With a dense prior every launch applies a whole block of changes (ne ~ b), and every
     // column group of a row group re-reading the same ne columns makes the update role the bottleneck of the launch (8 x
@@ -109,9 +151,9 @@ __device__ __forceinline__ void update_role(char* smem, int rg, int g,
             int iv_n; float dv_n[NT];
             auto load_list = [&](int e0) {
                 const int el = e0 + lane, ec = el < ne ? el : ne - 1;
-                iv_n = ev->idx[ec];
+                iv_n = ld_coh<RES>(&ev->idx[ec]);
 #pragma unroll
-                for (int t = 0; t < NT; ++t) { const float d = ev->delta[t][ec]; dv_n[t] = (el < ne) ? d : 0.f; }
+                for (int t = 0; t < NT; ++t) { const float d = ld_coh<RES>(&ev->delta[t][ec]); dv_n[t] = (el < ne) ? d : 0.f; }
             };
             if (slice_map ? (wave < 4 && g < spg) : (wave * pack < spg)) {   // (wave-uniform: the other waves have no share)
             load_list(0);
@@ -174,11 +216,11 @@ __device__ __forceinline__ void update_role(char* smem, int rg, int g,
         // header path: indices and coefficients arrived with the count (one 64-byte line)
         float4 x[7];
 #pragma unroll
-        for (int u = 0; u < 7; ++u) x[u] = cx.load4(u < ne ? ev->hidx[u] : 0, row);     // (unused slots: column 0, always valid)
+        for (int u = 0; u < 7; ++u) x[u] = cx.load4(u < ne ? ld_coh<RES>(&ev->hidx[u]) : 0, row);     // (unused slots: column 0, always valid)
 #pragma unroll
         for (int u = 0; u < 7; ++u) {
             if (u < ne) {
-                const float d = ev->hdelta[u];
+                const float d = ld_coh<RES>(&ev->hdelta[u]);
                 rv[0].x = fmaf(d, x[u].x, rv[0].x); rv[0].y = fmaf(d, x[u].y, rv[0].y);
                 rv[0].z = fmaf(d, x[u].z, rv[0].z); rv[0].w = fmaf(d, x[u].w, rv[0].w);
             }
@@ -187,13 +229,13 @@ __device__ __forceinline__ void update_role(char* smem, int rg, int g,
     for (int e0 = 0; e0 < ne; e0 += kEB) {
         float4 x[kEB];
 #pragma unroll
-        for (int u = 0; u < kEB; ++u) x[u] = cx.load4(ev->idx[e0 + u < ne ? e0 + u : ne - 1], row);
+        for (int u = 0; u < kEB; ++u) x[u] = cx.load4(ld_coh<RES>(&ev->idx[e0 + u < ne ? e0 + u : ne - 1]), row);
 #pragma unroll
         for (int u = 0; u < kEB; ++u) {
             if (e0 + u < ne) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    const float d = ev->delta[t][e0 + u];
+                    const float d = ld_coh<RES>(&ev->delta[t][e0 + u]);
                     rv[t].x = fmaf(d, x[u].x, rv[t].x); rv[t].y = fmaf(d, x[u].y, rv[t].y);
                     rv[t].z = fmaf(d, x[u].z, rv[t].z); rv[t].w = fmaf(d, x[u].w, rv[t].w);
                 }
@@ -263,9 +305,17 @@ __device__ __forceinline__ void update_role(char* smem, int rg, int g,
 #pragma unroll
             for (int w = 0; w < kRowGroupSlices; ++w) s += red[w][i][t];
             const int c = g + (i0 + i) * ncg;
-            partials[((int64_t)t * nrg + rg) * bstride + c] = s;
+            st_coh<RES>(&partials[((int64_t)t * nrg + rg) * bstride + c], s);
         }
         __syncthreads();
+    }
+    if constexpr (RES) {
+        // every wave's partial sums are written through (s_waitcnt vmcnt(0) = acknowledged) before the workgroup's one arrival
+        if (res.arrive != nullptr) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(res.arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 #ifdef JWAS_HIP_DEV_KNOBS
     if (dbg != nullptr && rg == 0 && g == 0 && tid == 0) {               // development builds: one workgroup's phases

@@ -183,6 +183,10 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         raise NotImplementedError("multi-trait device path implements BayesC (Gibbs samplers I, II and the constraint=true "
                                   "megaBayesABC! path) and BayesA/B (the same three); other methods stay on the reference")
     mega = t > 1 and bool(Mi.G.constraint)                              # megaBayesABC! (MCMC_BayesianAlphabet.jl:233-234)
+    # Methods the reference never runs block-wise: megaBayesABC! / megaBayesC0! (constraint = true), BayesC0! / MTBayesC0!
+    # (RR-BLUP) and BayesL! are ONE plain pass over the markers per outer iteration whatever fast_blocks says -- although
+    # chain_length has already been divided by the block size (MCMC_BayesianAlphabet.jl:233-262, JWAS.jl:308-316).
+    plain_pass = mega or method in ("RR-BLUP", "BayesL")
     if t == 1 and (Mi.G.constraint or model.R.constraint):
         raise ValueError("constraint==true is for multi-trait only")     # input_data_validation.jl:534-535,550-551
     if not isinstance(starting_value, bool) or starting_value:
@@ -396,6 +400,8 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
             raise NotImplementedError("annotated multi-trait BayesB stays on the reference")
         # constraint = true: megaBayesABC! reads every marker's own diagonal (BayesABC.jl:5)
         mt_method = "MegaBayesB" if mega else ("MTBayesB_II" if sampler == "II" else "MTBayesB")
+        if independent_blocks:
+            raise NotImplementedError("independent_blocks with multi-trait BayesA/B (one effect covariance per marker) stays on the reference")
 
     # ---- fast_blocks parsing (JWAS.jl:293-316); device blocks are powers of two >= 64
     nreps = 1
@@ -455,12 +461,17 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
             sizes = [want] * (len(explicit_partition) - 1) + [p - int(explicit_partition[-1])]
         block_size = _supported_block(want)
         nreps = want if (explicit_partition is None and want not in DEVICE_BLOCK_SIZES) else 0   # 0: every block its own size
+        if plain_pass:
+            nreps = 1            # the reference's schedule for these methods: chain_length / block size plain passes
         if explicit_partition is not None:
             while block_size < want:
                 block_size *= 2
             print(f"BLOCK STARTS: {len(explicit_partition)} blocks of {min(sizes)}..{max(sizes)} markers")
         else:
             print(f"BLOCK SIZE: {want}" + (f" (device blocks of {min(block_size, p)} markers)" if min(block_size, p) != want else ""))
+    if mt_pervar and block_size is not None and block_size * t > 2048:
+        # the markers' own covariances are parked in LDS beside their draws (sampler_mt.hpp): known before anything is loaded
+        raise NotImplementedError(f"multi-trait BayesA/B needs fast_blocks * traits <= 2048 on the device (got {block_size} x {t})")
     adaptive = False
     if block_size is None:
         # Device block size.  Sparse priors (few markers change per sweep): big blocks amortise the per-launch cost.

@@ -80,7 +80,37 @@ def test_julia_struct_layout(tmp_path):
     import re
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    src = open(os.path.join(root, "julia", "JWASHip.jl")).read()
+    _check_julia_struct_layout(open(os.path.join(root, "julia", "JWASHip.jl")).read(), tmp_path)
+
+
+def test_integration_md_struct_excerpt_matches_the_header(tmp_path):
+    """INTEGRATION.md section 1 prints the struct mirrors a maintainer would paste: the excerpt must be the text of
+    julia/JWASHip.jl (round 3's copy had drifted four fields short) and must itself match the header's layout."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    md = open(os.path.join(root, "INTEGRATION.md")).read()
+    jl = open(os.path.join(root, "julia", "JWASHip.jl")).read()
+    blocks = "\n".join(re.findall(r"```julia\n(.*?)```", md, re.S))
+    for name in ("HipSweepParams", "HipSweepStats"):
+        pat = r"struct %s\n.*?\nend" % name
+        assert re.search(pat, blocks, re.S).group(0) == re.search(pat, jl, re.S).group(0), name
+    # the positional constructor call of the excerpt has one argument per field
+    nfields = len(re.search(r"struct HipSweepParams\n(.*?)\nend", blocks, re.S).group(1).strip().splitlines())
+    ctor = re.search(r"function HipSweepParams\(.*?\n    (HipSweepParams\(.*?)\nend", blocks, re.S).group(1)
+    ctor = re.sub(r"#.*", "", ctor)
+    depth, nargs = 0, 1
+    for ch in ctor[ctor.index("(") + 1:ctor.rindex(")")]:
+        depth += ch in "({[" 
+        depth -= ch in ")}]"
+        nargs += (ch == "," and depth == 0)
+    assert nargs == nfields, (nargs, nfields)
+    _check_julia_struct_layout(blocks, tmp_path)
+
+
+def _check_julia_struct_layout(src, tmp_path):
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     size = {"Int32": 4, "UInt32": 4, "UInt64": 8, "Int64": 8, "Float32": 4, "Float64": 8}
 
     def layout(name):

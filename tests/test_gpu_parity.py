@@ -143,6 +143,79 @@ def test_bayesc_all_included_pi0(hip, small_data):
     _compare_state(orc, hip, atol=5e-6)
 
 
+@pytest.mark.parametrize("method,bs", [("BayesC", 512), ("BayesC", 128), ("BayesB", 256)])
+def test_rule_d_device_against_the_literal_oracle(hip, method, bs):
+    """The device (Rule D: alpha = fmaf(c1, x, c0) under a uniform pi = 0, csrc/kernels.hpp AbcMarker::rule_d; dense_big_st on
+    full 256- / 512-marker blocks, the in-lane walk on 128-marker ones) against the oracle in the reference's LITERAL operation
+    order (bayesabc_update_marker!, BayesABC.jl:36-46: rhs -> gHat -> alpha, RULE_D off) on the reference benchmark's shape
+    (Pi = 0, every marker in the model, benchmarks/jwas_nonblock_benchmark.jl:34-51).  Not bit for bit -- the two associate
+    differently -- but within the stated floating-point tolerance: every marker included every sweep on both sides, effects
+    and posterior means within 1e-4 of the effects' scale, the residual within 2e-4."""
+    data = make_dataset(n=1100, p=2 * bs + 77, ncausal=30, seed=4100 + bs)
+    rng = np.random.default_rng(bs)
+    kw = dict(vare=np.float32(0.6), var_effect=np.float32(0.002), pi=0.0)
+    if method == "BayesB":
+        kw["var_effect_vec"] = rng.uniform(0.001, 0.01, data["X"].shape[1]).astype(np.float32)
+    r0 = data["y"] - data["y"].mean()
+    try:
+        O.RULE_D = False
+        orc, hip = _pair(hip, data, bs, method)
+        orc.set_residual(r0); hip.set_residual(r0)
+        mean_o = np.zeros(orc.p); mean_h = np.zeros(orc.p)
+        nit = 20
+        for it in range(1, nit + 1):
+            so = orc.sweep(iteration=it, seed=17, **kw)
+            sh = hip.sweep(iteration=it, seed=17, **kw)
+            assert so["sum_delta"][0] == sh["sum_delta"][0] == orc.p, f"iteration {it}"
+            mean_o += orc.get_state(0)[0]; mean_h += hip.get_state(0)[0]
+    finally:
+        O.RULE_D = True
+    ao, ah = orc.get_state(0)[0], hip.get_state(0)[0]
+    scale = max(float(np.abs(ao).max()), 1.0)
+    assert (ao != ah).any()                  # the two orders do round differently somewhere: the comparison is not vacuous
+    np.testing.assert_allclose(ah, ao, rtol=0, atol=1e-4 * scale)
+    np.testing.assert_allclose(mean_h / nit, mean_o / nit, rtol=0, atol=1e-4 * scale)
+    np.testing.assert_allclose(hip.get_residual(0), orc.get_residual(0), rtol=0, atol=2e-4)
+
+
+@pytest.mark.parametrize("t,bs", [(3, 128), (2, 64)])
+def test_rule_l_device_against_the_literal_oracle(hip, t, bs):
+    """The device (Rule L: the linear form beta = A w + c of a marker that is and stays in the model for every trait,
+    sampler_mt.hpp mt1_linear_coeffs) against the oracle in the reference's LITERAL conditional-by-conditional order
+    (_MTBayesABC_samplerI!, MTBayesABC.jl:85-120; orc_set_mt_linear_form(0)) under the reference's default all-ones prior
+    (config 4's regime): identical inclusion trajectories in every sweep, effects within 1e-4 of their scale."""
+    data = make_dataset(n=900, p=4 * bs + 29, ncausal=12, seed=4200 + t)
+    rng = np.random.default_rng(40 + t)
+    Y = np.stack([(1 + 0.2 * k) * (data["y"] - data["y"].mean()) + 0.3 * rng.standard_normal(len(data["y"])).astype(np.float32)
+                  for k in range(t)]).astype(np.float32)
+    A = rng.standard_normal((t, t)); B = rng.standard_normal((t, t))
+    vare = ((A @ A.T / t + np.eye(t)) * 0.5).astype(np.float32)
+    varg = ((B @ B.T / t + np.eye(t)) * 0.003).astype(np.float32)
+    prior = np.full(1 << t, 1e-3); prior[-1] = 1.0; prior /= prior.sum()              # (nearly) every marker in the model
+    try:
+        O.lib().orc_set_mt_linear_form(0)
+        orc, hip = _pair(hip, data, bs, "MTBayesC", ntraits=t)
+        for k in range(t):
+            orc.set_residual(Y[k], k); hip.set_residual(Y[k], k)
+            ones = np.ones(orc.p, dtype=np.float32)
+            orc.set_state(k, delta=ones); hip.set_state(k, delta=ones)
+        for it in range(1, 13):
+            so = orc.sweep(iteration=it, seed=23, vare=vare, var_effect=varg, log_prior_states=np.log(prior))
+            sh = hip.sweep(iteration=it, seed=23, vare=vare, var_effect=varg, log_prior_states=np.log(prior))
+            assert np.array_equal(so["state_counts"], sh["state_counts"]), f"iteration {it}"
+            for k in range(t):
+                assert np.array_equal(orc.get_state(k)[2], hip.get_state(k)[2]), f"iteration {it}, trait {k}"
+    finally:
+        O.lib().orc_set_mt_linear_form(1)
+    differ = 0
+    for k in range(t):
+        ao, ah = orc.get_state(k)[0], hip.get_state(k)[0]
+        scale = max(float(np.abs(ao).max()), 1e-3)
+        np.testing.assert_allclose(ah, ao, rtol=0, atol=1e-4 * scale)
+        differ += int((ao != ah).sum())
+    assert differ > 0                        # the linear form did apply on the device
+
+
 def test_bayesc_pi_vector_and_bayesb(hip, small_data):
     p = small_data["X"].shape[1]
     rng = np.random.default_rng(0)
