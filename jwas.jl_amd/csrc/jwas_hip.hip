@@ -404,12 +404,12 @@ static int alloc_storage(jwas_hip_ctx* c, int64_t n, int64_t p, bool packed = fa
     HIPCHK(c, hipMalloc(&c->ev, sizeof(Events) * 2));
     HIPCHK(c, hipMemsetAsync(c->ev, 0, sizeof(Events) * 2, c->stream));
     HIPCHK(c, hipMalloc(&c->dparams, sizeof(DevParams)));
-    HIPCHK(c, hipMalloc(&c->counters, sizeof(unsigned long long) * 16));
+    HIPCHK(c, hipMalloc(&c->counters, sizeof(unsigned long long) * kNCounters));
     HIPCHK(c, hipMalloc(&c->fin_out, sizeof(double) * c->nslices * (kMaxT * kMaxT + kMaxT)));
     HIPCHK(c, hipMalloc(&c->sync_cnt, sizeof(int) * 2 * c->nrg));
     HIPCHK(c, hipMemsetAsync(c->sync_cnt, 0, sizeof(int) * 2 * c->nrg, c->stream));
     HIPCHK(c, hipMalloc(&c->stat_out, sizeof(double) * kStatGrid * kNStat));
-    HIPCHK(c, hipHostMalloc(&c->host_buf, sizeof(double) * ((size_t)c->nslices * (kMaxT * kMaxT + kMaxT) + kStatGrid * kNStat + 32)));
+    HIPCHK(c, hipHostMalloc(&c->host_buf, sizeof(double) * ((size_t)c->nslices * (kMaxT * kMaxT + kMaxT) + kStatGrid * kNStat + 64)));
     return JWAS_HIP_OK;
 }
 
@@ -1406,7 +1406,7 @@ static hipError_t launch_indep(jwas_hip_ctx* c, const UpdateArgs& U, const Sampl
     return with_cols(c, 0, [&](auto cx) { return launch_indep_cx<METHOD, NT, decltype(cx)>(c, cx, U, S, pstride, dense); });
 }
 
-static int sweep_independent(jwas_hip_ctx* c, EventList* out, bool dense, int dense_big_off)
+static int sweep_independent(jwas_hip_ctx* c, EventList* out, bool dense, int dense_big_off, int compact_off)
 {
     const int t = c->ntraits, bs = c->block_size;
     const int64_t nb = c->nblocks;
@@ -1440,6 +1440,7 @@ static int sweep_independent(jwas_hip_ctx* c, EventList* out, bool dense, int de
     S.alpha = c->alpha; S.beta = c->beta; S.delta = c->delta;
     S.counters = c->counters;
     S.dense_big_off = dense_big_off;
+    S.compact_off = compact_off;
     hipError_t e;
     switch (c->method) {
         case JWAS_HIP_BAYESC: e = launch_indep<kBayesC, 1>(c, U, S, pstride, dense); break;
@@ -1773,7 +1774,7 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
     }
     HIPCHK(c, hipMemcpyAsync(c->dparams, &D, sizeof D, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(&c->ev[0].count, 0, sizeof(int32_t), c->stream));
-    HIPCHK(c, hipMemsetAsync(c->counters, 0, sizeof(unsigned long long) * 16, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->counters, 0, sizeof(unsigned long long) * kNCounters, c->stream));
     HIPCHK(c, hipEventRecord(c->ev_start, c->stream));
 
     {   // per-sweep marker constants (draws, prior logs, lhs terms) for all p markers in parallel
@@ -1820,6 +1821,7 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
     const bool dense_mt = is_mt_method(c->method) && !is_sampler2(c->method) && c->block_size <= 128 && P->nreps == 1 && !P->independent_blocks &&
                           (edm ? std::atoi(edm) != 0 : c->last_events >= 0.6 * (double)c->p);
     const int dense_big_off = std::getenv("JWAS_HIP_DENSE_BIG_OFF") != nullptr ? 1 : 0;      // (tests: the same chain through the general path)
+    const int compact_off = std::getenv("JWAS_HIP_COMPACT_OFF") != nullptr ? std::atoi(std::getenv("JWAS_HIP_COMPACT_OFF")) : 0;          // (tests: the speculative rounds instead of the compact chain)
     const bool resident = resident_wanted(c, P, dense_big, dense_mt);
     c->resident_active = resident;
     if (resident) {
@@ -1828,7 +1830,7 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
         HIPCHK(c, hipMemsetAsync(c->res_sync, 0, sizeof(int) * (size_t)(kResArrive + 4 * (nb + 1)), c->stream));
     }
     if (independent) {
-        int rc = sweep_independent(c, &ev_list, dense_big, dense_big_off);
+        int rc = sweep_independent(c, &ev_list, dense_big, dense_big_off, compact_off);
         if (rc) return rc;
     } else {
     // one-block lookahead pipeline (sweep.hpp): launch k = sampler(block k-1) || update/partial(block k)
@@ -1848,6 +1850,7 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
         std::memset(&R, 0, sizeof R);
         R.S.P = c->dparams; R.S.nrg = c->nrg; R.S.bstride = bs; R.S.p = c->p; R.S.bsz = bs; R.S.xpx = c->xpx;
         R.S.dense_big_off = dense_big_off;
+        R.S.compact_off = compact_off;
         R.S.prep_d = c->prep_d; R.S.prep_f = c->prep_f; R.S.mt2_tab = c->mt2_tab; R.S.lpr_mat = c->lpr_active ? c->lpr_mat : nullptr;
         R.S.ginv_mat = has_marker_cov(c->method) ? c->ginv_mat : nullptr;
         R.S.alpha = c->alpha; R.S.beta = c->beta; R.S.delta = c->delta; R.S.counters = c->counters;
@@ -1899,6 +1902,7 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
             S.gram_next = (sb + 1 < nb) ? c->gram + (sb + 1) * (int64_t)bs * bs : nullptr;
             S.cross_after = (sb + 2 < nb) ? c->cross + (sb + 2) * (int64_t)bs * bs : nullptr;
             S.dense_big_off = dense_big_off;
+            S.compact_off = compact_off;
             S.lines_after = (sb + 2 < nb) ? (int)(((int64_t)blk_b(c, sb + 1) * blk_b(c, sb + 2) + 31) / 32) : 0;
             S.corr_in = c->corr + (sb & 1) * (size_t)kMaxT * bs;
             S.corr_out = c->corr + ((sb + 1) & 1) * (size_t)kMaxT * bs;
@@ -2009,8 +2013,8 @@ static int sweep_collect(jwas_hip_ctx* c, jwas_sweep_stats* S, size_t ntimed, do
     unsigned long long* h_cnt = reinterpret_cast<unsigned long long*>(h_stat + (size_t)kStatGrid * kNStat);
     HIPCHK(c, hipMemcpyAsync(h_fin, c->fin_out, sizeof(double) * c->nslices * nfin, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(h_stat, c->stat_out, sizeof(double) * kStatGrid * kNStat, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(h_cnt, c->counters, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost, c->stream));
-    int* h_abort = reinterpret_cast<int*>(h_cnt + 16);
+    HIPCHK(c, hipMemcpyAsync(h_cnt, c->counters, sizeof(unsigned long long) * kNCounters, hipMemcpyDeviceToHost, c->stream));
+    int* h_abort = reinterpret_cast<int*>(h_cnt + kNCounters);
     *h_abort = 0;
     if (c->resident_active) HIPCHK(c, hipMemcpyAsync(h_abort, c->res_sync + kResAbort, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     if (packed_dev)       // (reuses the head of the statistics staging area: row 0 = the all-rank sums)
@@ -2049,8 +2053,8 @@ static int sweep_collect(jwas_hip_ctx* c, jwas_sweep_stats* S, size_t ntimed, do
     S->n_events = packed_dev ? h_stat[kNStat] : (double)h_cnt[0];
     c->last_events = (double)h_cnt[0];
     if (std::getenv("JWAS_HIP_DEBUG_PHASES"))
-        std::fprintf(stderr, "[jwas_hip] blocks=%lld events=%llu unstaged=%llu cycles: front=%llu cand=%llu stage=%llu serial=%llu write=%llu corr=%llu rounds=%llu slow_rounds=%llu stage: assign=%llu issue=%llu store=%llu update wg0: share=%llu wait=%llu rest=%llu (resident sweeps: sampler wait=share, sampler drain=wait, update wg0 wait=rest) resident=%d\n",
-                     (long long)c->nblocks, h_cnt[0], h_cnt[1], h_cnt[2], h_cnt[3], h_cnt[4], h_cnt[5], h_cnt[6], h_cnt[9], h_cnt[7], h_cnt[8], h_cnt[10], h_cnt[11], h_cnt[12], h_cnt[13], h_cnt[14], h_cnt[15], (int)c->resident_active);
+        std::fprintf(stderr, "[jwas_hip] blocks=%lld events=%llu unstaged=%llu cycles: front=%llu cand=%llu stage=%llu serial=%llu write=%llu corr=%llu rounds=%llu slow_rounds=%llu stage: assign=%llu issue=%llu wait=%llu update wg0: share=%llu wait=%llu rest=%llu (resident sweeps: sampler wait=share, sampler drain=wait, update wg0 wait=rest) resident=%d compact: blocks=%llu fallback=%llu walk=%llu verify=%llu role=%llu tailwait=%llu\n",
+                     (long long)c->nblocks, h_cnt[0], h_cnt[1], h_cnt[2], h_cnt[3], h_cnt[4], h_cnt[5], h_cnt[6], h_cnt[9], h_cnt[7], h_cnt[8], h_cnt[10], h_cnt[11], h_cnt[12], h_cnt[13], h_cnt[14], h_cnt[15], (int)c->resident_active, h_cnt[16], h_cnt[17], h_cnt[18], h_cnt[19], h_cnt[20], h_cnt[21]);
     float ms = 0.f;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev_start, c->ev_stop));
     S->sweep_ms = ms;
@@ -2221,7 +2225,7 @@ static int f64_sweep(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_sweep_sta
         } else NEED(c, D.var_effect[0] > 0.0, JWAS_HIP_EINVAL, "marker effect variance must be positive");
     }
     HIPCHK(c, hipMemcpyAsync(F->dparams, &D, sizeof D, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->counters, 0, sizeof(unsigned long long) * 16, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->counters, 0, sizeof(unsigned long long) * kNCounters, c->stream));
     HIPCHK(c, hipEventRecord(c->ev_start, c->stream));
     const int64_t nb = c->nblocks;
     for (int64_t k = 0; k < nb; ++k) {
@@ -2283,11 +2287,11 @@ int jwas_hip_load_dense_f64(jwas_hip_ctx* c, const double* Xh, int64_t n, int64_
     HIPCHK(c, hipMalloc(&F->partials, sizeof(double) * (size_t)kMaxT * c->nslices * jw64::kMaxBlock64));
     HIPCHK(c, hipMalloc(&F->ev, sizeof(jw64::Events64) * 2));
     HIPCHK(c, hipMalloc(&F->dparams, sizeof(jw64::Params64)));
-    HIPCHK(c, hipMalloc(&c->counters, sizeof(unsigned long long) * 16));
+    HIPCHK(c, hipMalloc(&c->counters, sizeof(unsigned long long) * kNCounters));
     const int nfin = kMaxT * kMaxT + kMaxT;
     HIPCHK(c, hipMalloc(&c->fin_out, sizeof(double) * (size_t)c->nslices * nfin));
     HIPCHK(c, hipMalloc(&c->stat_out, sizeof(double) * (size_t)kStatGrid * kNStat));
-    HIPCHK(c, hipHostMalloc(&c->host_buf, sizeof(double) * ((size_t)c->nslices * nfin + (size_t)kStatGrid * kNStat) + sizeof(unsigned long long) * 16));
+    HIPCHK(c, hipHostMalloc(&c->host_buf, sizeof(double) * ((size_t)c->nslices * nfin + (size_t)kStatGrid * kNStat) + sizeof(unsigned long long) * kNCounters + 64));
     HIPCHK(c, hipMemsetAsync(F->X, 0, sizeof(double) * (size_t)c->ld * p, c->stream));       // pad rows zero
     HIPCHK(c, hipMemsetAsync(F->ev, 0, sizeof(jw64::Events64) * 2, c->stream));
     HIPCHK(c, hipMemcpy2DAsync(F->X, sizeof(double) * c->ld, Xh, sizeof(double) * ld_host, sizeof(double) * n, (size_t)p, hipMemcpyHostToDevice, c->stream));
@@ -2548,7 +2552,7 @@ int jwas_hip_sweep_sharded(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_swe
     if (rc) return rc;
     if (c->resident_active) {
         // the reconcile must not run on an aborted sweep: look at the flag before the pack (one host synchronisation)
-        int* h_abort = reinterpret_cast<int*>(c->host_buf + (size_t)c->nslices * (t * t + t) + (size_t)kStatGrid * kNStat) + 2 * 16;
+        int* h_abort = reinterpret_cast<int*>(c->host_buf + (size_t)c->nslices * (t * t + t) + (size_t)kStatGrid * kNStat) + 2 * kNCounters;
         *h_abort = 0;
         HIPCHK(c, hipMemcpyAsync(h_abort, c->res_sync + kResAbort, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -29,6 +29,7 @@ struct SamplerArgs {
     const float* cross_after;     // cross-Gram X_next' X_(next+1) the NEXT launch's sampler reads (L2 prefetch only), or NULL
     int lines_after;              // ... its size in 128-byte lines
     int dense_big_off;            // != 0: never take dense_big_st (tests: the same chain through the general path)
+    int compact_off;              // != 0: never take the compact chain (tests: the same chain through the speculative rounds)
     const float* corr_in;         // [NT][bsz] lookahead correction of THIS block (written by the previous sampler)
     float* corr_out;              // [NT][bsz] lookahead correction of the NEXT block
     const double* prep_d; const float* prep_f;
@@ -306,15 +307,18 @@ __device__ __forceinline__ void dma_copy_to_lds(const float* __restrict__ src, f
 }
 
 // Stage the Gram rows of the candidate markers (cand[q] for marker c = tid + q*kStepThreads) in LDS.
-__device__ __forceinline__ int stage_rows(char* smem, const StepSmem& SM, const SamplerArgs& A, const bool (&cand)[2], long long* ts = nullptr)
+// Stage the Gram rows of the candidate markers (cand[q] for marker c = tid + q*kStepThreads) in LDS.  Two steps, so that a
+// caller can issue loads of its own between them that share the rows' memory latency (sampler_st.hpp: the cross-Gram rows of
+// the compact chain): stage_assign (slots in marker order, candidate list; returns the number of rows that will be staged,
+// total = all candidates) and stage_load.
+__device__ __forceinline__ int stage_assign(char* smem, const StepSmem& SM, const SamplerArgs& A, const bool (&cand)[2], int& total)
 {
     const int B = SM.B;
     short* slot_of = reinterpret_cast<short*>(smem + SM.slot_off);
     short* cand_list = reinterpret_cast<short*>(smem + SM.cand_off);
     int* wcnt = reinterpret_cast<int*>(smem + SM.wcnt_off);
-    float* rows = reinterpret_cast<float*>(smem + SM.rows_off);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = A.b;
+    (void)A;
     int base = 0;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -336,7 +340,16 @@ __device__ __forceinline__ int stage_rows(char* smem, const StepSmem& SM, const 
         base = tot;
         __syncthreads();
     }
-    const int ncand = base < SM.max_cand ? base : SM.max_cand;
+    total = base;
+    return base < SM.max_cand ? base : SM.max_cand;
+}
+__device__ __forceinline__ void stage_load(char* smem, const StepSmem& SM, const SamplerArgs& A, int ncand, long long* ts = nullptr)
+{
+    const int B = SM.B;
+    const short* cand_list = reinterpret_cast<const short*>(smem + SM.cand_off);
+    float* rows = reinterpret_cast<float*>(smem + SM.rows_off);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = A.b;
     if (ts) ts[0] = clock64();
     // ALL row loads of the workgroup are issued before the first one is consumed: the fetch costs ONE memory latency
     // (microseconds under full-rate streaming), not one per batch.  Full blocks of 256 / 512 / 1024 markers (rows 16-byte
@@ -385,6 +398,12 @@ __device__ __forceinline__ int stage_rows(char* smem, const StepSmem& SM, const 
     }
     }
     __syncthreads();
+}
+__device__ __forceinline__ int stage_rows(char* smem, const StepSmem& SM, const SamplerArgs& A, const bool (&cand)[2], long long* ts = nullptr)
+{
+    int total = 0;
+    const int ncand = stage_assign(smem, SM, A, cand, total);
+    stage_load(smem, SM, A, ncand, ts);
     return ncand;
 }
 

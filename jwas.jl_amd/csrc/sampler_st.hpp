@@ -212,6 +212,164 @@ __device__ __forceinline__ void dense_big_st(char* smem, const StepSmem& SM, con
     (void)astart;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// COMPACT CHAIN (round 4).  Single-pass sweeps of 256- / 512- / 1024-marker blocks with a sparse prior and MANY markers in the
+// model (BayesR, a fixed pi, the first sweeps of a chain): the speculative rounds cost ~850 cycles per committed change plus
+// ~1.8 k per 64-marker sub-block, and almost every change is a marker that was a candidate at block entry (it is in the
+// model, or its entry rhs already passes its threshold).  When all nc <= 64 candidates have their Gram rows staged
+// (slot i = the i-th candidate in marker order), wave 0 walks THE CANDIDATES ONLY, dense-walk style: lane i owns candidate
+// i and evaluates it against its own running rhs at every step; at step i lane i's alpha_old - alpha_new is broadcast with
+// one v_readlane and applied to the running rhs of the candidates after it with G[cand_i][cand_l] from the staged rows --
+// per element the sequential chain's own fmaf sequence in commit order.  That is the exact chain PROVIDED no other marker
+// of the block changes; so afterwards all threads bring the rhs of every non-candidate up to the value it has when the
+// chain reaches it (entry rhs + the changes of the candidates before it, same fmaf sequence) and test it against its
+// threshold.  Nobody crosses (the usual case: a few percent of the blocks hold a "surprise"): the walk's results are the
+// chain's, bit for bit, and are committed -- effects, classes and the change log, all at once.  Somebody crosses: nothing
+// has been written, the block runs through the speculative rounds from its untouched entry state.
+// Reference chain: BayesABC.jl:153-179, BayesR.jl:150-189.
+// ---------------------------------------------------------------------------------------------
+// Candidates at block entry: markers in the model, markers whose entry rhs passes their threshold -- and markers whose entry
+// rhs comes within 1/16 of it: the changes committed inside the block move a later marker's rhs by a few percent of its
+// threshold, and a marker that crosses it without having been a candidate ("surprise") costs the compact chain its block
+// (fixed pi = 0.95: 17 % of the blocks without the margin).  A candidate that does not move is an exact no-op everywhere
+// (its row is staged, it is walked, its change is 0): the margin changes speed only.
+constexpr float kCandMargin = 0.9375f;
+constexpr int kCompactMin = 6;          // fewer candidates: the speculative rounds are as fast
+constexpr int kCompactMax = 64;         // one lane per candidate
+
+// scratch of the compact chain: the overflow Gram-row slot (B >= 256 floats; rewritten by the general path before it reads it)
+struct CompactScratch {
+    int2* log;        // [64] {local column, bits(alpha_old - alpha_new)} of candidate i
+    float* an;        // [64] its new effect
+    int* cls;         // [64] BayesR: its class 0..3
+    __device__ __forceinline__ CompactScratch(char* smem, const StepSmem& SM)
+    {
+        float* base = reinterpret_cast<float*>(smem + SM.rows_off) + SM.max_cand * SM.B;
+        log = reinterpret_cast<int2*>(base); an = base + 128; cls = reinterpret_cast<int*>(base + 192);
+    }
+};
+
+// wave 0.  Returns false when a BayesR evaluation lay too close to a class threshold to be decided from the thresholds
+// (practically never): the caller falls back.
+template <int METHOD>
+__device__ __forceinline__ bool compact_walk(char* smem, const StepSmem& SM, int nc, float ie, int lane)
+{
+    constexpr bool kR = (METHOD == kBayesR);
+    const int B = SM.B;
+    const short* cand_list = reinterpret_cast<const short*>(smem + SM.cand_off);
+    const float* rows = reinterpret_cast<const float*>(smem + SM.rows_off);
+    const float* rhs_lds = reinterpret_cast<const float*>(smem + SM.rhs_off);
+    const float* acur = reinterpret_cast<const float*>(smem + SM.acur_off);
+    const double* lpd = reinterpret_cast<const double*>(smem + SM.prepd_off);
+    const float* lpf = reinterpret_cast<const float*>(smem + SM.prepf_off);
+    const CompactScratch CS(smem, SM);
+    const bool act = lane < nc;
+    const int col = (int)cand_list[act ? lane : 0];
+    float rhs = rhs_lds[col];
+    const float a_cur = acur[col];
+    float c_lo = 0.f, c_hi = 0.f, c_il = 0.f, c_d = 0.f;
+    double c_zs = 0.0;
+    double r_il1 = 0.0, r_il2 = 0.0, r_il3 = 0.0, r_zs1 = 0.0, r_zs2 = 0.0, r_zs3 = 0.0, r_T0 = 0.0, r_T1 = 0.0, r_T2 = 0.0;
+    if constexpr (kR) {
+        c_d = lpf[col];
+        r_il1 = lpd[0 * B + col]; r_il2 = lpd[1 * B + col]; r_il3 = lpd[2 * B + col];
+        r_zs1 = lpd[3 * B + col]; r_zs2 = lpd[4 * B + col]; r_zs3 = lpd[5 * B + col];
+        r_T0 = lpd[6 * B + col]; r_T1 = lpd[7 * B + col]; r_T2 = lpd[8 * B + col];
+    } else {
+        c_il = lpf[col]; c_d = lpf[2 * B + col]; c_lo = lpf[3 * B + col]; c_hi = lpf[4 * B + col];
+        c_zs = lpd[col];
+    }
+    int cls = 0;
+    bool sure = true;
+    auto eval = [&](float x) -> float {
+        float an;
+        if constexpr (kR) cls = bayesr_eval_thr(x, a_cur, ie, c_d, r_il1, r_il2, r_il3, r_zs1, r_zs2, r_zs3, r_T0, r_T1, r_T2, an, sure);
+        else an = abc_alpha_new(x, a_cur, c_d, ie, c_il, c_zs, abc_included(x, c_lo, c_hi));
+        return an;
+    };
+    // G[cand_i][cand_lane] = rows[i * B + col]; lane l takes the changes of the candidates BEFORE it only (i < l), so its
+    // running rhs stops moving at its own step and its last evaluation is the one of its own step
+    const float* gcol = rows + col;
+    auto step = [&](int i, float g) {
+        const float Dl = a_cur - eval(rhs);
+        const float D = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Dl), i));
+        rhs = fmaf(D, (i < lane) ? g : 0.f, rhs);
+    };
+    constexpr int kBatch = 8;
+    float gn[kBatch];
+    int i = 0;
+    if (nc >= kBatch) {
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) gn[u] = gcol[u * B];
+    }
+#pragma unroll 1
+    for (; i + kBatch <= nc; i += kBatch) {
+        float g[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) g[u] = gn[u];
+        if (i + 2 * kBatch <= nc) {
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u) gn[u] = gcol[(i + kBatch + u) * B];
+        }
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) step(i + u, g[u]);
+    }
+#pragma unroll 1
+    for (; i < nc; ++i) step(i, gcol[i * B]);
+    const float an = eval(rhs);                            // the evaluation of the lane's own step (its rhs is final)
+    if (act) {
+        CS.log[lane] = make_int2(col, __float_as_int(a_cur - an));
+        CS.an[lane] = an;
+        CS.cls[lane] = cls;
+    }
+    return __all(sure || !act);
+}
+
+// all threads, after the walk: does a marker that was NO candidate at block entry change when the chain reaches it?
+// cand[q]: marker c = tid + q * kStepThreads was a candidate (walked).
+template <int METHOD>
+__device__ __forceinline__ bool compact_surprise(char* smem, const StepSmem& SM, int nc, int b, const bool (&cand)[2])
+{
+    constexpr bool kR = (METHOD == kBayesR);
+    const int B = SM.B;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const float* rows = reinterpret_cast<const float*>(smem + SM.rows_off);
+    const float* rhs_lds = reinterpret_cast<const float*>(smem + SM.rhs_off);
+    const float* lpf = reinterpret_cast<const float*>(smem + SM.prepf_off);
+    const CompactScratch CS(smem, SM);
+    bool surprise = false;
+    const int mycol = CS.log[lane < nc ? lane : 0].x;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        if (q * kStepThreads >= B) break;
+        const int c = tid + q * kStepThreads;
+        if ((c & ~63) >= b) continue;                       // (wave-uniform: none of the wave's columns is a marker)
+        const int cmax = (c | 63) + 1;                      // the wave's columns are [cmax - 64, cmax)
+        // candidates before the wave's last column (the list is in marker order): wave-uniform loop bound
+        const int nlim = __popcll(__ballot(lane < nc && mycol < cmax));
+        float r = rhs_lds[c < B ? c : 0];
+        for (int i0 = 0; i0 < nlim; i0 += 8) {
+            int2 e[8];
+            float g[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u < nlim ? i0 + u : nlim - 1;
+                e[u] = CS.log[i];
+                g[u] = rows[i * B + (c < B ? c : 0)];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (i0 + u < nlim) r = fmaf((e[u].x < c) ? __int_as_float(e[u].y) : 0.f, g[u], r);
+        }
+        bool ev;
+        if constexpr (kR) ev = fabsf(r) >= lpf[B + (c < B ? c : 0)];
+        else ev = abc_included(r, lpf[3 * B + (c < B ? c : 0)], lpf[4 * B + (c < B ? c : 0)]);
+        surprise = surprise || (ev && c < b && !cand[q]);
+    }
+    return surprise;
+}
+
 __host__ __device__ constexpr int st_park_nd(int method) { return method == kBayesR ? BayesRMarker::kFastD : 1; }
 __host__ __device__ constexpr int st_park_nf(int method, bool dense = false) { (void)dense; return method == kBayesR ? 2 : 5; }
 
@@ -315,7 +473,7 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
             acur[c] = a_in; astart[c] = a_in;
             bm.store_fast(lpd, B, c);
             lpf[c] = dj; lpf[B + c] = thrx;
-            cand[q] = (c < b) && ((a_in != 0.f) || (fabsf(rhs0) >= thrx));
+            cand[q] = (c < b) && ((a_in != 0.f) || (fabsf(rhs0) >= thrx * kCandMargin));
             dpark0[c] = 1.f;                      // a marker that stays out: class 1 (see the prefix skip below)
         } else {
             const double zs = A.prep_d[3 * p + j];
@@ -330,7 +488,7 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
             // Rule D sweeps: nothing is ever excluded, so the slots of the "excluded" draw and of the lower threshold carry
             // c1 and c0 instead (512-marker blocks leave no LDS for two more rows next to dense_big_st's 128 KB of tiles)
             if constexpr (DENSE) { lpf[B + c] = A.prep_f[5 * p + j]; lpf[3 * B + c] = A.prep_f[6 * p + j]; }
-            cand[q] = (c < b) && ((a_in != 0.f) || abc_included(rhs0, lo, hi));
+            cand[q] = (c < b) && ((a_in != 0.f) || abc_included(rhs0, lo * kCandMargin, hi * kCandMargin));      // (alpha = 0: lo <= 0 <= hi)
             always_mine = always_mine && ((c >= b) || (lo == hi));           // thresholds(): lo = hi <=> always included
             bpark0[c] = bex; dpark0[c] = 0.f;     // a marker that stays out: delta 0, beta = its excluded draw
         }
@@ -392,7 +550,7 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
     }
     // single-pass sweeps with a next block: waves 1..4 accumulate its lookahead correction while the serial wave runs
     const bool stream_corr = ((P->nreps > 0 ? P->nreps : b) == 1) && !prestage && A.b_next > 0;
-    if (tid == 0) { int* wc0 = reinterpret_cast<int*>(smem + SM.wcnt_off); wc0[12] = 0; wc0[13] = 0; wc0[14] = 0; }
+    if (tid == 0) { int* wc0 = reinterpret_cast<int*>(smem + SM.wcnt_off); wc0[8] = 0; wc0[9] = 0; wc0[12] = 0; wc0[13] = 0; wc0[14] = 0; }
     if (stream_corr) for (int c = tid; c < B; c += kStepThreads) reinterpret_cast<int2*>(smem + SM.log_off)[c] = make_int2(-1, 0);
     // small dense blocks (most markers are candidates): the serial wave walks them section by section (below) -- on strictly
     // upper diagonal tiles (mask_diagonal_tile); the rows are not read again after the walk (single pass)
@@ -410,10 +568,100 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
     // later repetition draws anew and may move a marker that was no candidate at entry: stage_rows must then have marked
     // every marker "not staged" (slot -1), or the winner's row would be looked up through a stale slot.)
     const bool single_pass_st = (P->nreps > 0 ? P->nreps : b) == 1;
-    int nstaged = prestage ? b : ((first_sub >= 16 && single_pass_st) ? 0 : stage_rows(smem, SM, A, cand, tss));
+    int ncand_total = 0;
+    // COMPACT CHAIN (below): the lookahead correction of the NEXT block needs the cross-Gram rows of the markers that moved --
+    // candidates all.  With a full next block waves 1..7 fetch the candidates' rows into REGISTERS (float4 pieces, task
+    // T = k * 448 + (wave - 1) * 64 + lane -> row T / (B/4), piece T % (B/4): <= 19 per lane), issued together with the Gram
+    // rows' own loads (one memory latency for both); once the walk is verified the staged Gram rows are dead and the pieces
+    // take their place in LDS, so the correction is a chain of LDS reads -- no global access after the walk.  (Left to the
+    // log-consuming helper waves it was 21 k cycles of L2 / HBM round trips per block behind the walk.)
+    constexpr int kXR = 19, kXL = kStepThreads - 64;
+    const bool xreg_geom = !DENSE && single_pass_st && !prestage && !(A.compact_off & 1) &&
+                           (A.b_next == B) && (b == B) && (B == 256 || B == 512 || B == 1024);
+    const int xsh = (B == 1024) ? 8 : (B == 512 ? 7 : 6);
+    const int xlid = tid - 64;
+    typedef float xr_v4f __attribute__((ext_vector_type(4)));      // (a native vector: an array of HIP's float4 struct stayed in scratch memory)
+    xr_v4f xr[kXR];
+    bool xreg = false;
+    int nstaged = prestage ? b : 0;
+    if (!prestage && !(first_sub >= 16 && single_pass_st)) {
+        nstaged = stage_assign(smem, SM, A, cand, ncand_total);
+        xreg = xreg_geom && ncand_total >= kCompactMin && ncand_total <= kCompactMax && ncand_total <= SM.max_cand;
+        if (xreg && wave != 0) {
+            const short* cl = reinterpret_cast<const short*>(smem + SM.cand_off);
+            const int xtask = ncand_total << xsh;
+#pragma unroll
+            for (int k = 0; k < kXR; ++k) {
+                const int T = k * kXL + xlid, Tc = T < xtask ? T : xtask - 1;
+                xr[k] = *reinterpret_cast<const xr_v4f*>(A.cross_next + ((int64_t)cl[Tc >> xsh] * B + 4 * (Tc & ((1 << xsh) - 1))));
+            }
+        }
+        stage_load(smem, SM, A, nstaged, tss);
+    }
+    // ---- COMPACT CHAIN (see compact_walk): all candidates staged, one lane each
+    bool compact_done = false, compact_corr = false;      // compact_corr: ... and the next block's lookahead correction is in corr_cd
+    float corr_cd[2] = {0.f, 0.f};
+    long long tkc[3] = {0, 0, 0};
+    if constexpr (!DENSE) {
+        const bool compact_try = single_pass_st && !prestage && !(A.compact_off & 1) && ncand_total >= kCompactMin &&
+                                 ncand_total <= kCompactMax && ncand_total <= SM.max_cand;
+        if (compact_try) {
+            int* wc = reinterpret_cast<int*>(smem + SM.wcnt_off);
+            tkc[0] = clock64();
+            const int nc = ncand_total;
+            const int xtask = nc << xsh;
+            if (wave == 0) {
+                const bool ok = compact_walk<METHOD>(smem, SM, nc, ie, lane);
+                if (lane == 0) { wc[8] = ok ? 1 : 0; __hip_atomic_store(&wc[12], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+            } else {
+                if (!xreg && A.b_next > 0) prefetch_cross_rows(smem, SM, A, nstaged, 1, wc + 12);     // (ragged next block: L2 only)
+                if (!(A.compact_off & 2)) prefetch_next_gram(A, false, 1, wc + 12);             // the next block's staging becomes an L2 hit
+            }
+            __syncthreads();
+            tkc[1] = clock64();
+            const bool surprise = compact_surprise<METHOD>(smem, SM, nc, b, cand);
+            if (__any(surprise) && lane == 0) wc[9] = 1;
+            __syncthreads();
+            compact_done = (wc[8] != 0) && (wc[9] == 0);
+            tkc[2] = clock64();
+            if (compact_done && xreg) {
+                float* crossL = reinterpret_cast<float*>(smem + SM.rows_off);        // rows 0 .. nc-1 (the scratch row lies behind them)
+                if (wave != 0) {
+#pragma unroll
+                    for (int k = 0; k < kXR; ++k) {
+                        const int T = k * kXL + xlid;
+                        if (T < xtask) *reinterpret_cast<xr_v4f*>(crossL + (T >> xsh) * B + 4 * (T & ((1 << xsh) - 1))) = xr[k];
+                    }
+                }
+                __syncthreads();
+                const CompactScratch CS(smem, SM);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int c = tid + q * kStepThreads;
+                    if (c >= B) break;
+                    float corr = 0.f;
+                    for (int e0 = 0; e0 < nc; e0 += 8) {
+                        float dd[8], g[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int e = e0 + u < nc ? e0 + u : nc - 1;
+                            dd[u] = __int_as_float(CS.log[e].y);
+                            g[u] = crossL[e * B + c];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) if (e0 + u < nc) corr = fmaf(dd[u], g[u], corr);     // (a marker that did not move: d = 0, an exact no-op)
+                    }
+                    corr_cd[q] = corr;
+                }
+                compact_corr = true;
+            }
+        }
+    }
     const bool cross_lds = prestage && SM.has_cross;
     float4 corr_mine{0.f, 0.f, 0.f, 0.f};
-    if (stream_corr) {
+    if (compact_corr) {
+        // (nothing left for the other waves: the correction is done, the prefetches went out during the walk)
+    } else if (stream_corr) {
         if (is_corr_helper(wave)) corr_mine = stream_corr_role(smem, SM, A);      // returns when the serial wave is done
         else if (wave >= 5) {                                           // waves 5, 6, 7
             const int* stop = reinterpret_cast<const int*>(smem + SM.wcnt_off) + 13;
@@ -531,6 +779,26 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
     // ---- SINGLE PASS (nreps = 1: the exact non-block chain; the hot path).  Everything comes from LDS; the log of
     // committed changes {row offset, D} lives in two VGPRs (lane e = entry e, written with v_writelane, read back with
     // v_readlane), so bringing a later sub-block up to date costs one LDS read per entry and no dependent second one.
+    if (lazy && !dense_done && compact_done) {
+        // the compact chain's results ARE the block's: effects, classes, and the change log {column, alpha_old - alpha_new} of
+        // the effects that moved, in marker order -- published at once (the correction helpers consume it from here)
+        int2* plog = reinterpret_cast<int2*>(smem + SM.log_off);
+        const CompactScratch CS(smem, SM);
+        const bool act = lane < ncand_total;
+        const int2 e = CS.log[act ? lane : 0];
+        const bool moved = act && (__int_as_float(e.y) != 0.f);
+        const unsigned long long mm = __ballot(moved);
+        if (act) {
+            acur[e.x] = CS.an[lane];
+            if constexpr (kR) dpark0[e.x] = (float)(CS.cls[lane] + 1);
+        }
+        if (moved) plog[__popcll(mm & ((1ull << lane) - 1ull))] = e;
+        nrounds += ncand_total;
+        if (lane == 0) {
+            wcnt_s[11] = __popcll(mm);
+            __hip_atomic_store(&wcnt_s[13], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    } else
     if (lazy && !dense_done) {
         int2* plog = reinterpret_cast<int2*>(smem + SM.log_off);
         int npub = 0;
@@ -814,6 +1082,7 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
     }
     tk5 = clock64();
     }   // wave 0
+    const long long tk5w = clock64();
     __syncthreads();
     const bool from_log = wcnt_s[11] >= 0;                  // single pass: {column, d} pairs published by the serial wave
     const int nfin = from_log ? wcnt_s[11] : wcnt_s[15];
@@ -856,6 +1125,10 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
     const long long tk7 = clock64();
     // ---- global stores LAST (nothing in this launch waits for them; a barrier after a global store waits for the store):
     // the change list for the next update role, alpha of the changed markers, beta / delta of the whole block
+    if (compact_corr) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) if (tid + q * kStepThreads < B) A.corr_out[tid + q * kStepThreads] = corr_cd[q];
+    } else
     if (stream_corr && is_corr_helper(wave)) {              // the lookahead correction accumulated by this helper lane
         const int col = (corr_helper_index(wave) * 64 + lane) * 4, bn = A.b_next;
         const float cv[4] = {corr_mine.x, corr_mine.y, corr_mine.z, corr_mine.w};
@@ -900,6 +1173,14 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
         atomicAdd(&A.counters[10], (unsigned long long)(tss[0] - tk2));       // staging: slot assignment | load issue | LDS stores
         atomicAdd(&A.counters[11], (unsigned long long)(tss[1] - tss[0]));
         atomicAdd(&A.counters[12], (unsigned long long)(tss[2] - tss[1]));
+        atomicAdd(&A.counters[20], (unsigned long long)(clock64() - tk0));    // the whole role
+        atomicAdd(&A.counters[21], (unsigned long long)(tk6 - tk5w));         // serial wave done -> every helper wave done
+        if (tkc[0] != 0) {                                                    // compact chain: blocks tried / fallen back, walk / verification cycles
+            atomicAdd(&A.counters[16], 1ull);
+            if (!compact_done) atomicAdd(&A.counters[17], 1ull);
+            atomicAdd(&A.counters[18], (unsigned long long)(tkc[1] - tkc[0]));
+            atomicAdd(&A.counters[19], (unsigned long long)(tkc[2] - tkc[1]));
+        }
     }
 }
 

@@ -1,6 +1,7 @@
 // update_role.hpp -- UPDATE / PARTIAL role of the fused step kernel (apply a block's changes to the residual -- sparse exit update, or the
 // cooperative dense apply -- then the block's partial right-hand side).  Included by sweep.hpp.
 #pragma once
+#include <type_traits>
 #include "kernels.hpp"
 #include "coherent.hpp"
 
@@ -79,6 +80,9 @@ __device__ __forceinline__ void update_role(char* smem, int rg, int g,
     float4 rv[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) rv[t] = *reinterpret_cast<const float4*>(r_in + t * ld + row);
+    // (the residual weights: fetched here, with the role's first loads -- behind the apply they were one more dependent
+    // memory round trip before the stream could start)
+    float4 wv = *reinterpret_cast<const float4*>(cx.w + row);
     if constexpr (RES) {
         // the list is published by the resident sampler: wait for it (the column loads above are already in flight).  The wait
         // is BOUNDED; giving up marks the sweep aborted and the host re-runs it through the launch-per-block path.
@@ -111,7 +115,15 @@ __device__ __forceinline__ void update_role(char* smem, int rg, int g,
     // (dense priors apply a whole block of changes here: 16 column loads in flight per wave, the fmaf chain per row
     // stays in list order)
     const int ne = ld_coh<RES>(&ev->count);
-    constexpr int kEB = 16;
+    // the head of the list, one entry per lane, issued with the count (not after it: the arrays are always there, what lies
+    // beyond the count is never used as an address or a coefficient) -- the general apply below then needs ONE further
+    // memory latency per 32 changes instead of two per 16 (a scalar index load, then the columns: with 30-40 changes per
+    // 512-marker block -- BayesR, a fixed pi, the first sweeps of a chain -- that was 4-6 dependent round trips, ~12 us of a
+    // 29 us launch)
+    int liv_n = ld_coh<RES>(&ev->idx[lane]);
+    float ldv_n[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) ldv_n[t] = ld_coh<RES>(&ev->delta[t][lane]);
     // ---- COOPERATIVE DENSE APPLY.  With a dense prior every launch applies a whole block of changes (ne ~ b), and every
     // column group of a row group re-reading the same ne columns makes the update role the bottleneck of the launch (8 x
     // 25.6 MB at n = 50 000, b = 128).  Here the ncg workgroups of a row group SPLIT the rows of every slice: wave w of
@@ -226,22 +238,44 @@ __device__ __forceinline__ void update_role(char* smem, int rg, int g,
             }
         }
     } else
-    for (int e0 = 0; e0 < ne; e0 += kEB) {
-        float4 x[kEB];
+    for (int e0 = 0; e0 < ne; e0 += 64) {
+        // lane l: entry e0 + l of the list; the next 64 entries are fetched behind this chunk's columns
+        const int liv = liv_n;
+        float ldv[NT];
 #pragma unroll
-        for (int u = 0; u < kEB; ++u) x[u] = cx.load4(ld_coh<RES>(&ev->idx[e0 + u < ne ? e0 + u : ne - 1]), row);
+        for (int t = 0; t < NT; ++t) ldv[t] = ldv_n[t];
+        if (e0 + 64 < ne) {
+            const int el = e0 + 64 + lane, ec = el < ne ? el : ne - 1;
+            liv_n = ld_coh<RES>(&ev->idx[ec]);
 #pragma unroll
-        for (int u = 0; u < kEB; ++u) {
-            if (e0 + u < ne) {
+            for (int t = 0; t < NT; ++t) ldv_n[t] = ld_coh<RES>(&ev->delta[t][ec]);
+        }
+        // K columns in flight per lane (addresses from v_readlane: no scalar memory access), the fused multiply-add chain per
+        // row in list order; entries past the end re-read the last valid column and are skipped
+        auto chunk = [&](auto kc, int h, int rem) {
+            constexpr int K = decltype(kc)::value;
+            float4 x[K];
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const float d = ld_coh<RES>(&ev->delta[t][e0 + u]);
-                    rv[t].x = fmaf(d, x[u].x, rv[t].x); rv[t].y = fmaf(d, x[u].y, rv[t].y);
-                    rv[t].z = fmaf(d, x[u].z, rv[t].z); rv[t].w = fmaf(d, x[u].w, rv[t].w);
+            for (int u = 0; u < K; ++u) x[u] = cx.load4(__builtin_amdgcn_readlane(liv, h + (u < rem ? u : rem - 1)), row);
+#pragma unroll
+            for (int u = 0; u < K; ++u) {
+                if (u < rem) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ldv[t]), h + u));
+                        rv[t].x = fmaf(d, x[u].x, rv[t].x); rv[t].y = fmaf(d, x[u].y, rv[t].y);
+                        rv[t].z = fmaf(d, x[u].z, rv[t].z); rv[t].w = fmaf(d, x[u].w, rv[t].w);
+                    }
                 }
             }
+        };
+        for (int h = 0; h < 64 && e0 + h < ne; h += 32) {
+            const int rem = ne - (e0 + h);                     // >= 1 entries left from here
+            if (rem <= 16) chunk(std::integral_constant<int, 16>{}, h, rem);
+            else chunk(std::integral_constant<int, 32>{}, h, rem);
         }
     }
+    if (!applied) { JW_UPD_CLOCK(tu1); tu3 = tu1; }               // (development builds: entry + apply | partial sums)
     if (active && g == 0 && r_out != nullptr && !applied)
 #pragma unroll
         for (int t = 0; t < NT; ++t) *reinterpret_cast<float4*>(r_out + t * ld + row) = rv[t];
@@ -251,7 +285,6 @@ __device__ __forceinline__ void update_role(char* smem, int rg, int g,
     if (ncols == 0) return;
     // the RHS is X_b' R^-1 r (block_rhs!, tools4genotypes.jl:59-78): the weights go onto r once per launch (weights = 1
     // when unweighted: exact), the streaming loop is untouched
-    float4 wv = *reinterpret_cast<const float4*>(cx.w + row);
     if (!active) wv = float4{0.f, 0.f, 0.f, 0.f};
     double rd[NT][4];
 #pragma unroll
@@ -322,7 +355,7 @@ __device__ __forceinline__ void update_role(char* smem, int rg, int g,
         const long long tu4 = clock64();
         atomicAdd(&dbg[13], (unsigned long long)(tu1 - tu0));            // cooperative apply: own share
         atomicAdd(&dbg[14], (unsigned long long)(tu3 - tu1));            //   wait for the peers + read back
-        atomicAdd(&dbg[15], (unsigned long long)(tu4 - (applied ? tu3 : tu0)));    // the rest (float4 apply if any, partial RHS)
+        atomicAdd(&dbg[15], (unsigned long long)(tu4 - tu3));            // the rest (partial RHS)
     }
 #else
     (void)dbg; (void)tu0; (void)tu1; (void)tu3;
