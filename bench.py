@@ -89,6 +89,10 @@ def parse():
     ap.add_argument("--shard", choices=["markers", "rows"], default="markers",
                     help="N > 1: markers = marker shards + one all-reduce of the residual delta per sweep (the metric's mode); "
                          "rows = exact row shards (one small all-reduce per block launch, replicated sampler)")
+    ap.add_argument("--one-rank-comm", action="store_true",
+                    help="with --gpus 1: run the sweep through the library's sharded path (jwas_hip_sweep_sharded: snapshot, pack "
+                         "kernel, ncclAllReduce on a ONE-rank RCCL communicator, apply kernel) -- what one rank of an N-GPU job "
+                         "executes per iteration, minus the wire time (profiles/r04_rank_share.json)")
     ap.add_argument("--seed", type=int, default=2026)
     ap.add_argument("--storage", choices=["dense", "packed2bit"], default="dense",
                     help="dense = the metric's fp32 dense genotypes (default); packed2bit = the reference's 2-bit packed "
@@ -182,6 +186,12 @@ def main():
             sys.exit(2)
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend, rank=rank, world_size=world)
+    elif a.one_rank_comm:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1)
     import jwas_jl_amd as J
     from jwas_jl_amd.dist import MarkerShard, RowShard, shard_range
     from jwas_jl_amd.mcmc import pick_block_size
@@ -241,7 +251,7 @@ def main():
     log('setup_blocks done')
     eng.init_state("MTBayesB" if mt_pervar else method, t)
     if not rows_mode:
-        shard = MarkerShard(eng, lo, hi, rank, world)
+        shard = MarkerShard(eng, lo, hi, rank, world, force_collective=a.one_rank_comm)
     comm_world = shard.comm_world()
     if comm_world != world:
         raise SystemExit(f"bench.py: the communicator reports {comm_world} rank(s), the launcher started {world}")
@@ -456,6 +466,8 @@ def main():
                        "ranks_reported_by_communicator": comm_world,
                        "device_sweep_ms": acc["sweep_ms"] / a.steps, "per_rank_device_sweep_ms": per_rank_sweep_ms, "events_per_sweep": acc["events"] / a.steps,
                        "markers_in_model": in_model, "setup_s": setup_s,
+                       "host_ms_per_step": ms_per_step - acc["sweep_ms"] / a.steps,
+                       "sharded_path": bool(getattr(shard, "_lib_comm", False)),
                        "chain_sweeps_before_timing": nburn + a.warmup},
             "roofline": {"bound": "hbm", "kernel": "k_block_step", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
@@ -469,6 +481,8 @@ def main():
     eng.close()
     if world > 1:
         torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    elif a.one_rank_comm:
         torch.distributed.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -DJWAS_HIP_DEV_KNOBS"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -DJWAS_HIP_DEV_KNOBS $JWAS_DEV_EXTRA"
 mkdir -p _dev
 "$HIPCC" $FLAGS "$@" -c jwas_hip.hip -o _dev/jwas_hip.o &
 P1=$!

@@ -1575,8 +1575,16 @@ __global__ __launch_bounds__(256) void k_shard_pack(int t, int64_t ld, const flo
     const int64_t total = (int64_t)t * ld;
     if (blockIdx.x == gridDim.x - 1) {
         for (int v = threadIdx.x; v < kNStat; v += 256) {
+            // (the additions in ascending order, as the host sums them; 16 independent loads in flight instead of one --
+            // 30 us of dependent round trips per sweep at one rank's share of config 2, profiles/r04_rank_share_*)
             double sum = 0.0;
-            for (int g = 0; g < nstatgrid; ++g) sum += stat_out[(int64_t)g * kNStat + v];
+            for (int g0 = 0; g0 < nstatgrid; g0 += 16) {
+                double q[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) q[u] = stat_out[(int64_t)(g0 + u < nstatgrid ? g0 + u : nstatgrid - 1) * kNStat + v];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) if (g0 + u < nstatgrid) sum += q[u];
+            }
             buf[total + v] = sum;
         }
         if (threadIdx.x == 0) { buf[total + kNStat] = (double)counters[0]; buf[total + kNStat + 1] = 0.0; }
@@ -2053,8 +2061,8 @@ static int sweep_collect(jwas_hip_ctx* c, jwas_sweep_stats* S, size_t ntimed, do
     S->n_events = packed_dev ? h_stat[kNStat] : (double)h_cnt[0];
     c->last_events = (double)h_cnt[0];
     if (std::getenv("JWAS_HIP_DEBUG_PHASES"))
-        std::fprintf(stderr, "[jwas_hip] blocks=%lld events=%llu unstaged=%llu cycles: front=%llu cand=%llu stage=%llu serial=%llu write=%llu corr=%llu rounds=%llu slow_rounds=%llu stage: assign=%llu issue=%llu wait=%llu update wg0: share=%llu wait=%llu rest=%llu (resident sweeps: sampler wait=share, sampler drain=wait, update wg0 wait=rest) resident=%d compact: blocks=%llu fallback=%llu walk=%llu verify=%llu role=%llu tailwait=%llu\n",
-                     (long long)c->nblocks, h_cnt[0], h_cnt[1], h_cnt[2], h_cnt[3], h_cnt[4], h_cnt[5], h_cnt[6], h_cnt[9], h_cnt[7], h_cnt[8], h_cnt[10], h_cnt[11], h_cnt[12], h_cnt[13], h_cnt[14], h_cnt[15], (int)c->resident_active, h_cnt[16], h_cnt[17], h_cnt[18], h_cnt[19], h_cnt[20], h_cnt[21]);
+        std::fprintf(stderr, "[jwas_hip] blocks=%lld events=%llu unstaged=%llu cycles: front=%llu cand=%llu stage=%llu serial=%llu write=%llu corr=%llu rounds=%llu slow_rounds=%llu stage: assign=%llu issue=%llu wait=%llu update wg0: share=%llu wait=%llu rest=%llu (resident sweeps: sampler wait=share, sampler drain=wait, update wg0 wait=rest) resident=%d compact: blocks=%llu fallback=%llu walk=%llu verify=%llu role=%llu tailwait=%llu xwrite=%llu xchain=%llu\n",
+                     (long long)c->nblocks, h_cnt[0], h_cnt[1], h_cnt[2], h_cnt[3], h_cnt[4], h_cnt[5], h_cnt[6], h_cnt[9], h_cnt[7], h_cnt[8], h_cnt[10], h_cnt[11], h_cnt[12], h_cnt[13], h_cnt[14], h_cnt[15], (int)c->resident_active, h_cnt[16], h_cnt[17], h_cnt[18], h_cnt[19], h_cnt[20], h_cnt[21], h_cnt[22], h_cnt[23]);
     float ms = 0.f;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev_start, c->ev_stop));
     S->sweep_ms = ms;

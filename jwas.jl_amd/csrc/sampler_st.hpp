@@ -348,8 +348,19 @@ __device__ __forceinline__ bool compact_surprise(char* smem, const StepSmem& SM,
         const int cmax = (c | 63) + 1;                      // the wave's columns are [cmax - 64, cmax)
         // candidates before the wave's last column (the list is in marker order): wave-uniform loop bound
         const int nlim = __popcll(__ballot(lane < nc && mycol < cmax));
+        // ... and the candidates before the wave's FIRST column reach every lane: whole batches of them need no per-lane test
+        const int nf8 = __popcll(__ballot(lane < nc && mycol < cmax - 64)) & ~7;
         float r = rhs_lds[c < B ? c : 0];
-        for (int i0 = 0; i0 < nlim; i0 += 8) {
+#pragma unroll 1
+        for (int i0 = 0; i0 < nf8; i0 += 8) {
+            float d[8], g[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { d[u] = __int_as_float(CS.log[i0 + u].y); g[u] = rows[(i0 + u) * B + (c < B ? c : 0)]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) r = fmaf(d[u], g[u], r);
+        }
+#pragma unroll 1
+        for (int i0 = nf8; i0 < nlim; i0 += 8) {
             int2 e[8];
             float g[8];
 #pragma unroll
@@ -601,7 +612,7 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
     // ---- COMPACT CHAIN (see compact_walk): all candidates staged, one lane each
     bool compact_done = false, compact_corr = false;      // compact_corr: ... and the next block's lookahead correction is in corr_cd
     float corr_cd[2] = {0.f, 0.f};
-    long long tkc[3] = {0, 0, 0};
+    long long tkc[3] = {0, 0, 0}, tkx[3] = {0, 0, 0};
     if constexpr (!DENSE) {
         const bool compact_try = single_pass_st && !prestage && !(A.compact_off & 1) && ncand_total >= kCompactMin &&
                                  ncand_total <= kCompactMax && ncand_total <= SM.max_cand;
@@ -633,7 +644,9 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
                         if (T < xtask) *reinterpret_cast<xr_v4f*>(crossL + (T >> xsh) * B + 4 * (T & ((1 << xsh) - 1))) = xr[k];
                     }
                 }
+                tkx[0] = clock64();
                 __syncthreads();
+                tkx[1] = clock64();
                 const CompactScratch CS(smem, SM);
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
@@ -654,6 +667,7 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
                     corr_cd[q] = corr;
                 }
                 compact_corr = true;
+                tkx[2] = clock64();
             }
         }
     }
@@ -1180,6 +1194,10 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
             if (!compact_done) atomicAdd(&A.counters[17], 1ull);
             atomicAdd(&A.counters[18], (unsigned long long)(tkc[1] - tkc[0]));
             atomicAdd(&A.counters[19], (unsigned long long)(tkc[2] - tkc[1]));
+            if (tkx[0] != 0) {
+                atomicAdd(&A.counters[22], (unsigned long long)(tkx[1] - tkc[2]));      // cross-Gram pieces to LDS (+ barrier)
+                atomicAdd(&A.counters[23], (unsigned long long)(tkx[2] - tkx[1]));      // the correction chain
+            }
         }
     }
 }

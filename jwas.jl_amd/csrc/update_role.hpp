@@ -5,6 +5,12 @@
 #include "kernels.hpp"
 #include "coherent.hpp"
 
+#ifdef JWAS_HIP_COOP_RELACQ
+#define JW_COOP_ARRIVE_ORDER __ATOMIC_RELEASE
+#else
+#define JW_COOP_ARRIVE_ORDER __ATOMIC_RELAXED
+#endif
+
 namespace jw {
 
 // ---------------------------------------------------------------------------------------------
@@ -197,12 +203,17 @@ __device__ __forceinline__ void update_role(char* smem, int rg, int g,
             int* flag = reinterpret_cast<int*>(smem);                     // (the reduction scratch is not in use yet)
             __syncthreads();
             if (tid == 0) {
-                __hip_atomic_fetch_add(&sync_now[rg], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ... before the count
+                // JWAS_HIP_COOP_RELACQ (measurement builds): the formally ordered variant -- release on the arrival, acquire on
+                // the successful poll.  On gfx950 each is a full L2 write-back / invalidate of the workgroup's XCD.
+                __hip_atomic_fetch_add(&sync_now[rg], 1, JW_COOP_ARRIVE_ORDER, __HIP_MEMORY_SCOPE_AGENT);     // ... before the count
                 int ok = 0;
                 for (int spin = 0; spin < 4000; ++spin) {                 // bounded: ~0.5 ms
                     if (__hip_atomic_load(&sync_now[rg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= ncg) { ok = 1; break; }
                     __builtin_amdgcn_s_sleep(4);
                 }
+#ifdef JWAS_HIP_COOP_RELACQ
+                if (ok) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");         // (the successful poll, acquired once)
+#endif
                 *flag = ok;
             }
             __syncthreads();

@@ -432,11 +432,21 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
                 raise ValueError("fast_blocks block size must create at least two block starts.")
             # the reference does not rescale chain_length for explicit starts (JWAS.jl:298-304: block_size = false)
             explicit_starts = True
+            if max(sizes) > max(DEVICE_BLOCK_SIZES):
+                # a block of more than 1024 markers does not fit the sampler's LDS plan: the nearest legal partition is the
+                # given one with every oversized block cut into pieces of at most 1024 markers (each piece repeated its own
+                # size, BayesABC.jl:153) -- said out loud, as the reference prints its block size (JWAS.jl:308-316)
+                lim = max(DEVICE_BLOCK_SIZES)
+                cut = []
+                for a_, sz in zip(starts, sizes):
+                    cut.extend(range(a_, a_ + sz, lim))
+                print(f"NOTICE: fast_blocks blocks of up to {max(sizes)} markers exceed the device limit of {lim}; "
+                      f"running {len(cut)} blocks (oversized blocks cut into pieces of at most {lim} markers)")
+                starts = cut
+                sizes = [b_ - a_ for a_, b_ in zip(starts, starts[1:])] + [p - starts[-1] + 1]
             if len(set(sizes[:-1])) != 1 or sizes[-1] > sizes[0]:
                 # NON-UNIFORM partition: the device runs exactly these blocks, each with its own size as repetition count
                 # (BayesABC.jl:153); jwas_hip_setup_blocks_explicit
-                if max(sizes) > 1024:
-                    raise NotImplementedError("explicit fast_blocks blocks hold at most 1024 markers on the device")
                 explicit_partition = np.asarray(starts, dtype=np.int64) - 1
             want = max(sizes) if explicit_partition is not None else sizes[0]
         if want < 1:
@@ -452,10 +462,16 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         #   * more than 1024 markers per block do not fit the sampler's LDS plan: an explicit error;
         #     (independent_blocks alone may ask for more: uniform device blocks of 1024 markers with `want` repetitions
         #     each -- independent blocks are the reference's own approximation).
+        if want > max(DEVICE_BLOCK_SIZES) and not explicit_starts and not independent_blocks:
+            # fast_blocks = true on more than 1024^2 records, or a number above 1024: the sampler's LDS plan holds the draws,
+            # constants and staged Gram rows of at most 1024 markers.  The nearest legal schedule is the reference's own at
+            # the largest device size -- blocks of 1024 markers, each repeated 1024 times, chain_length / 1024 outer
+            # iterations -- and the run says so where the reference prints its block size (JWAS.jl:308-316).
+            print(f"NOTICE: fast_blocks block size {want} exceeds the device limit of {max(DEVICE_BLOCK_SIZES)} markers per block; "
+                  f"running BLOCK SIZE {max(DEVICE_BLOCK_SIZES)} (chain_length / {max(DEVICE_BLOCK_SIZES)} outer iterations)")
+            want = max(DEVICE_BLOCK_SIZES)
         if not explicit_starts:
             chain_length = int(np.floor(chain_length / want))
-        if want > max(DEVICE_BLOCK_SIZES) and not (explicit_partition is None and independent_blocks):
-            raise NotImplementedError(f"fast_blocks blocks hold at most {max(DEVICE_BLOCK_SIZES)} markers on the device (got {want})")
         if explicit_partition is None and want not in DEVICE_BLOCK_SIZES and want <= max(DEVICE_BLOCK_SIZES):
             explicit_partition = np.arange(0, p, want, dtype=np.int64)          # = collect(range(1, step=want, stop=p)) - 1
             sizes = [want] * (len(explicit_partition) - 1) + [p - int(explicit_partition[-1])]

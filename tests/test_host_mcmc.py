@@ -837,15 +837,28 @@ def test_fast_blocks_numeric_runs_the_reference_partition(tmp_path, fb, p):
     assert out["_timing"]["iterations"] == 6                                   # chain_length / block_size
 
 
-def test_fast_blocks_above_the_device_limit_is_an_explicit_error(tmp_path):
+def test_fast_blocks_above_the_device_limit_falls_back_to_the_nearest_legal_partition(tmp_path, capsys):
+    """A block size above the device's 1024-marker limit (JWAS.jl:293-316 accepts any) runs the reference's schedule at 1024
+    markers per block, and an explicit start vector with an oversized block runs with that block cut into pieces -- both with
+    a printed notice, never a NotImplementedError."""
     d = make_dataset(n=100, p=2500, ncausal=3, seed=9, center=False)
     ids = [str(i) for i in range(100)]
     gdf = pd.DataFrame(d["raw"]); gdf.insert(0, "ID", ids)
     ph = pd.DataFrame({"ID": ids, "y1": d["y"]})
     geno = api.get_genotypes(gdf, method="BayesC", Pi=0.9, quality_control=False)
     model = api.build_model("y1 = intercept + geno")
-    with pytest.raises(NotImplementedError, match="at most 1024 markers"):
-        api.runMCMC(model, ph, chain_length=4000, fast_blocks=1200, output_folder=str(tmp_path / "x"), _engine=OracleEngine("block"))
+    out = api.runMCMC(model, ph, chain_length=2048, fast_blocks=1200, output_folder=str(tmp_path / "x"), outputEBV=False,
+                      _engine=OracleEngine("block"))
+    assert "exceeds the device limit of 1024" in capsys.readouterr().out
+    assert out["_timing"]["iterations"] == 2                                   # chain_length / 1024
+    assert out["_timing"]["block_starts"] == [1, 1025, 2049]
+    geno = api.get_genotypes(gdf, method="BayesC", Pi=0.9, quality_control=False)
+    model = api.build_model("y1 = intercept + geno")
+    out = api.runMCMC(model, ph, chain_length=3, fast_blocks=[1, 301, 1601], output_folder=str(tmp_path / "y"), outputEBV=False,
+                      _engine=OracleEngine("block"))
+    assert "cut into pieces" in capsys.readouterr().out
+    assert out["_timing"]["block_starts"] == [1, 301, 1325, 1601]              # the 1300-marker block in two pieces
+    assert out["_timing"]["iterations"] == 3                                   # explicit starts: chain length as given
 
 
 def test_runmcmc_double_precision_host_loop(tmp_path):
