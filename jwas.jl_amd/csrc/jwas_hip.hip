@@ -127,10 +127,17 @@ struct jwas_hip_ctx {
         double *alpha = nullptr, *beta = nullptr;      // [t][p]
         void* delta = nullptr;              // double [t][p], or int32 [p] (BayesR classes)
         double *mean_a = nullptr, *mean_a2 = nullptr, *mean_d = nullptr;
-        double* partials = nullptr;         // [kMaxT][nslices][128]
-        jw64::Events64* ev = nullptr;       // [2]
+        double* partials = nullptr;         // [kMaxT][nslices][bstride]  (independent blocks: one such set per block)
+        size_t partials_cap = 0;            // ... in doubles
+        jw64::Events64* ev = nullptr;       // [2]  (independent blocks: ev_all, one per block)
+        jw64::Events64* ev_all = nullptr;
+        int64_t ev_all_cap = 0;
         jw64::Params64* dparams = nullptr;
         double* var_vec = nullptr;          // [p] BayesB
+        double* w = nullptr;                // [ld] residual weights R^-1 (pad rows 0; ones when unweighted)
+        std::vector<int64_t> starts;        // block starts (nblocks + 1 entries, 0-based): uniform or explicit partition
+        int bstride = 0;                    // largest block of the partition, rounded up to a multiple of 8
+        bool explicit_part = false;
     };
     F64* f64 = nullptr;
 };
@@ -198,6 +205,8 @@ static auto with_cols(jwas_hip_ctx* c, int64_t j_off, F&& f)
 #define NOT_F64(c, what) NEED(c, !IS_F64(c), JWAS_HIP_EUNSUP, "%s is not available in a Float64 context (double_precision=true)", what)
 #define ONLY_F64(c) NEED(c, IS_F64(c), JWAS_HIP_ESTATE, "this entry point needs a Float64 context (jwas_hip_set_precision(ctx, 64))")
 static int f64_setup_blocks(jwas_hip_ctx* c, int32_t bs);
+static int f64_setup_blocks_explicit(jwas_hip_ctx* c, const int64_t* starts, int64_t nblocks);
+static int f64_set_weights(jwas_hip_ctx* c, const float* rinv);
 static int f64_init_state(jwas_hip_ctx* c, int32_t method, int32_t nt);
 
 
@@ -279,7 +288,7 @@ void jwas_hip_destroy(jwas_hip_ctx* c)
     if (c->f64) {
         auto* F = c->f64;
         for (void* q : {(void*)F->X, (void*)F->r, (void*)F->xpx, (void*)F->gram, (void*)F->alpha, (void*)F->beta, F->delta, (void*)F->mean_a,
-                        (void*)F->mean_a2, (void*)F->mean_d, (void*)F->partials, (void*)F->ev, (void*)F->dparams, (void*)F->var_vec}) (void)hipFree(q);
+                        (void*)F->mean_a2, (void*)F->mean_d, (void*)F->partials, (void*)F->ev, (void*)F->dparams, (void*)F->var_vec, (void*)F->w, (void*)F->ev_all}) (void)hipFree(q);
         delete F;
         c->f64 = nullptr;
     }
@@ -538,7 +547,7 @@ int jwas_hip_load_jgb2(jwas_hip_ctx* c, const char* path)
 
 int jwas_hip_set_weights(jwas_hip_ctx* c, const float* rinv)
 {
-    if (c) NOT_F64(c, "residual weights");
+    if (c && IS_F64(c)) return f64_set_weights(c, rinv);
     NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
     NEED(c, HAVE_STORAGE(c), JWAS_HIP_ESTATE, "no genotype matrix loaded");
     HIPCHK(c, hipSetDevice(c->device));
@@ -767,7 +776,7 @@ int jwas_hip_setup_blocks(jwas_hip_ctx* c, int32_t bs, int32_t gram_mode)
 
 int jwas_hip_setup_blocks_explicit(jwas_hip_ctx* c, const int64_t* starts, int64_t nblocks, int32_t gram_mode)
 {
-    if (c) NOT_F64(c, "an explicit block partition");
+    if (c && IS_F64(c)) return f64_setup_blocks_explicit(c, starts, nblocks);
     NEED(c, c && starts, JWAS_HIP_EINVAL, "NULL argument");
     NEED(c, HAVE_STORAGE(c), JWAS_HIP_ESTATE, "no genotype matrix loaded");
     NEED(c, gram_mode == JWAS_HIP_GRAM_F64 || gram_mode == JWAS_HIP_GRAM_MFMA, JWAS_HIP_EINVAL, "unknown gram_mode %d", gram_mode);
@@ -2093,25 +2102,65 @@ static void f64_free_state(jwas_hip_ctx* c)
     F->alpha = F->beta = F->mean_a = F->mean_a2 = F->mean_d = F->var_vec = nullptr; F->delta = nullptr;
 }
 
-static int f64_setup_blocks(jwas_hip_ctx* c, int32_t bs)
+// x'R^-1 x, the Grams X_b'R^-1 X_b of the partition in F->starts (block k at k * bstride^2, row stride = the block's size) and
+// the partial-sum buffer.
+static int f64_build_blocks(jwas_hip_ctx* c)
 {
     auto* F = c->f64;
-    NEED(c, F->X, JWAS_HIP_ESTATE, "no genotype matrix loaded");
-    NEED(c, bs == 64 || bs == 128, JWAS_HIP_EINVAL, "Float64 contexts run blocks of 64 or 128 markers (got %d)", bs);
     HIPCHK(c, hipSetDevice(c->device));
-    (void)hipFree(F->xpx); (void)hipFree(F->gram); F->xpx = F->gram = nullptr;
-    c->block_size = bs; c->nblocks = (c->p + bs - 1) / bs;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(F->xpx); (void)hipFree(F->gram); (void)hipFree(F->partials); F->xpx = F->gram = F->partials = nullptr; F->partials_cap = 0;
+    const int64_t nb = (int64_t)F->starts.size() - 1;
+    int mx = 0;
+    for (int64_t k = 0; k < nb; ++k) mx = std::max<int>(mx, (int)(F->starts[(size_t)k + 1] - F->starts[(size_t)k]));
+    F->bstride = (mx + 7) / 8 * 8;
+    c->nblocks = nb;
     HIPCHK(c, hipMalloc(&F->xpx, sizeof(double) * c->p));
-    HIPCHK(c, hipMalloc(&F->gram, sizeof(double) * (size_t)c->nblocks * bs * bs));
-    hipLaunchKernelGGL(jw64::k64_xpx, dim3((unsigned)c->p), dim3(256), 0, c->stream, F->X, c->ld, F->xpx);
-    for (int64_t y0 = 0; y0 < c->nblocks; y0 += 32768) {
-        const int64_t ny = std::min<int64_t>(32768, c->nblocks - y0);
-        hipLaunchKernelGGL(jw64::k64_gram, dim3((unsigned)bs, (unsigned)ny), dim3(256), 0, c->stream, F->X + y0 * bs * c->ld, c->ld, c->p - y0 * bs, (int)bs,
-                           F->gram + y0 * (int64_t)bs * bs);
+    HIPCHK(c, hipMalloc(&F->gram, sizeof(double) * (size_t)nb * F->bstride * F->bstride));
+    F->partials_cap = (size_t)kMaxT * c->nslices * F->bstride;
+    HIPCHK(c, hipMalloc(&F->partials, sizeof(double) * F->partials_cap));
+    hipLaunchKernelGGL(jw64::k64_xpx, dim3((unsigned)c->p), dim3(256), 0, c->stream, F->X, c->ld, F->w, F->xpx);
+    for (int64_t k = 0; k < nb; ++k) {
+        const int64_t j0 = F->starts[(size_t)k];
+        const int b = (int)(F->starts[(size_t)k + 1] - j0);
+        hipLaunchKernelGGL(jw64::k64_gram, dim3((unsigned)b), dim3(256), 0, c->stream, F->X, c->ld, F->w, j0, b, F->gram + k * (int64_t)F->bstride * F->bstride);
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return JWAS_HIP_OK;
+}
+
+static int f64_setup_blocks(jwas_hip_ctx* c, int32_t bs)
+{
+    auto* F = c->f64;
+    NEED(c, F->X, JWAS_HIP_ESTATE, "no genotype matrix loaded");
+    NEED(c, bs >= 1 && bs <= jw64::kMaxBlock64, JWAS_HIP_EINVAL, "Float64 contexts run blocks of 1 to %d markers (got %d)", jw64::kMaxBlock64, bs);
+    F->starts.clear();
+    for (int64_t j = 0; j < c->p; j += bs) F->starts.push_back(j);
+    F->starts.push_back(c->p);
+    F->explicit_part = false;
+    c->block_size = bs;
+    return f64_build_blocks(c);
+}
+
+static int f64_setup_blocks_explicit(jwas_hip_ctx* c, const int64_t* starts, int64_t nblocks)
+{
+    auto* F = c->f64;
+    NEED(c, F->X, JWAS_HIP_ESTATE, "no genotype matrix loaded");
+    NEED(c, starts && nblocks >= 1, JWAS_HIP_EINVAL, "block starts: NULL or empty");
+    NEED(c, starts[0] == 0, JWAS_HIP_EINVAL, "block starts must begin with marker 0");
+    int mx = 0;
+    for (int64_t k = 0; k < nblocks; ++k) {
+        const int64_t hi = (k + 1 < nblocks) ? starts[k + 1] : c->p;
+        NEED(c, hi > starts[k] && hi <= c->p, JWAS_HIP_EINVAL, "block starts must be sorted, unique and within the markers (block %lld)", (long long)k);
+        NEED(c, hi - starts[k] <= jw64::kMaxBlock64, JWAS_HIP_EINVAL, "block %lld holds %lld markers; blocks hold at most %d markers", (long long)k, (long long)(hi - starts[k]), jw64::kMaxBlock64);
+        mx = std::max<int>(mx, (int)(hi - starts[k]));
+    }
+    F->starts.assign(starts, starts + nblocks);
+    F->starts.push_back(c->p);
+    F->explicit_part = true;
+    c->block_size = mx;
+    return f64_build_blocks(c);
 }
 
 static int f64_init_state(jwas_hip_ctx* c, int32_t method, int32_t nt)
@@ -2132,24 +2181,56 @@ static int f64_init_state(jwas_hip_ctx* c, int32_t method, int32_t nt)
     HIPCHK(c, hipMalloc(&F->mean_a, db)); HIPCHK(c, hipMalloc(&F->mean_a2, db)); HIPCHK(c, hipMalloc(&F->mean_d, db));
     for (void* q : {(void*)F->alpha, (void*)F->beta, (void*)F->mean_a, (void*)F->mean_a2, (void*)F->mean_d}) HIPCHK(c, hipMemsetAsync(q, 0, db, c->stream));
     HIPCHK(c, hipMemsetAsync(F->delta, 0, delb, c->stream));
-    HIPCHK(c, hipMemsetAsync(F->r, 0, sizeof(double) * kMaxT * c->ld, c->stream));
+    HIPCHK(c, hipMemsetAsync(F->r, 0, sizeof(double) * 2 * kMaxT * c->ld, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return JWAS_HIP_OK;
 }
 
-template <int NT>
-static void f64_launch_block(jwas_hip_ctx* c, const jw64::Events64* ev_prev, int64_t k, jw64::Events64* ev_out)
+// Residual weights of a Float64 context: taken as the Float32 values the C ABI carries, widened (the reference casts whatever
+// it is given, JWAS.jl:349-366); x'R^-1 x and the Grams depend on them, so the blocks are rebuilt.
+static int f64_set_weights(jwas_hip_ctx* c, const float* rinv)
 {
     auto* F = c->f64;
-    const int bs = c->block_size;
-    const int64_t j0 = k * bs;
-    const int b = (int)((j0 + bs <= c->p) ? bs : c->p - j0);
-    hipLaunchKernelGGL((jw64::k64_update_partial<NT>), dim3((unsigned)c->nslices), dim3(256), 0, c->stream, F->X, c->ld, F->r, ev_prev, j0, b, F->partials);
-    const jw64::Smem64 SM(b, NT);
-    const double* G = F->gram + k * (int64_t)bs * bs;
+    NEED(c, F->X, JWAS_HIP_ESTATE, "no genotype matrix loaded");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<double> wv((size_t)c->ld, 0.0);
+    for (int64_t i = 0; i < c->n; ++i) {
+        const float v = rinv ? rinv[i] : 1.f;
+        NEED(c, std::isfinite(v) && v > 0.f, JWAS_HIP_EINVAL, "residual weights must be positive and finite (row %lld: %g)", (long long)i, (double)v);
+        wv[(size_t)i] = (double)v;
+    }
+    HIPCHK(c, hipMemcpy(F->w, wv.data(), sizeof(double) * (size_t)c->ld, hipMemcpyHostToDevice));
+    if (!F->starts.empty()) return f64_build_blocks(c);
+    return JWAS_HIP_OK;
+}
+
+// One block: its partial sums (r_in -> r_out with the previous block's changes; r_out = NULL, ev_prev = NULL: none), then its
+// sampler.  part: the partial-sum buffer of this block.
+template <int NT>
+static void f64_launch_block(jwas_hip_ctx* c, const double* r_in, double* r_out, const jw64::Events64* ev_prev, int64_t k,
+                             double* part, jw64::Events64* ev_out)
+{
+    auto* F = c->f64;
+    const int64_t j0 = F->starts[(size_t)k];
+    const int b = (int)(F->starts[(size_t)k + 1] - j0);
+    const int bsz = F->bstride;
+    // column groups: enough workgroups to fill the chip (one slice = 256 rows), whole batches of 8 columns each
+    int ncg = (int)std::max<int64_t>(1, std::min<int64_t>((b + 7) / 8, (512 + c->nslices - 1) / c->nslices));
+    const int cpg = (((b + ncg - 1) / ncg) + 7) / 8 * 8;
+    ncg = (b + cpg - 1) / cpg;
+    hipLaunchKernelGGL((jw64::k64_update_partial<NT>), dim3((unsigned)c->nslices, (unsigned)ncg), dim3(256), 0, c->stream, F->X, c->ld, F->w,
+                       r_in, r_out, ev_prev, j0, b, cpg, part, bsz);
+    const bool glds = b <= jw64::kGramLds64;
+    const jw64::Smem64 SM(b, bsz, NT, glds);
+    const double* G = F->gram + k * (int64_t)bsz * bsz;
 #define JW64_SAMPLE(M)                                                                                                                  \
-    hipLaunchKernelGGL((jw64::k64_sample<M, NT>), dim3(1), dim3(256), SM.bytes, c->stream, F->dparams, G, F->partials, c->nslices, j0, b, c->p, \
-                       F->xpx, F->alpha, F->beta, F->delta, ev_out, c->counters)
+    do {                                                                                                                                \
+        if (glds) hipLaunchKernelGGL((jw64::k64_sample<M, NT, true>), dim3(1), dim3(256), SM.bytes, c->stream, F->dparams, G, part, c->nslices, bsz, j0, b, c->p, \
+                                     F->xpx, F->alpha, F->beta, F->delta, ev_out, c->counters);                                       \
+        else hipLaunchKernelGGL((jw64::k64_sample<M, NT, false>), dim3(1), dim3(256), SM.bytes, c->stream, F->dparams, G, part, c->nslices, bsz, j0, b, c->p, \
+                                F->xpx, F->alpha, F->beta, F->delta, ev_out, c->counters);                                            \
+    } while (0)
     if constexpr (NT == 1) {
         if (c->method == JWAS_HIP_BAYESC) JW64_SAMPLE(kBayesC);
         else if (c->method == JWAS_HIP_BAYESB) JW64_SAMPLE(kBayesB);
@@ -2162,11 +2243,14 @@ template <int NT>
 static hipError_t f64_set_lds_attr()
 {
     hipError_t e = hipSuccess;
-    if constexpr (NT == 1) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&jw64::k64_sample<kBayesC, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&jw64::k64_sample<kBayesB, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&jw64::k64_sample<kBayesR, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    } else e = hipFuncSetAttribute(reinterpret_cast<const void*>(&jw64::k64_sample<kMTBayesC1, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define JW64_ATTR(M)                                                                                                                                   \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&jw64::k64_sample<M, NT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  \
+    if (e != hipSuccess) return e;                                                                                                                     \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&jw64::k64_sample<M, NT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    if (e != hipSuccess) return e;
+    if constexpr (NT == 1) { JW64_ATTR(kBayesC) JW64_ATTR(kBayesB) JW64_ATTR(kBayesR) }
+    else { JW64_ATTR(kMTBayesC1) }
+#undef JW64_ATTR
     return e;
 }
 
@@ -2176,9 +2260,9 @@ static int f64_sweep(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_sweep_sta
     NEED(c, c->method >= 0, JWAS_HIP_ESTATE, "jwas_hip_init_state has not been called");
     NEED(c, c->block_size && F->gram, JWAS_HIP_ESTATE, "jwas_hip_setup_blocks has not been called");
     NEED(c, P->method == c->method && P->ntraits == c->ntraits, JWAS_HIP_EINVAL, "sweep method/ntraits (%d/%d) differ from init_state (%d/%d)", P->method, P->ntraits, c->method, c->ntraits);
-    NEED(c, !P->independent_blocks, JWAS_HIP_EUNSUP, "independent_blocks is not available in a Float64 context");
     NEED(c, !P->log_prior_states_matrix && !P->var_effect_matrix, JWAS_HIP_EUNSUP, "marker-specific multi-trait priors / covariances are not available in a Float64 context");
     const int t = c->ntraits;
+    NEED(c, F->bstride * t <= 2048, JWAS_HIP_EUNSUP, "Float64 contexts need block size x traits <= 2048 (got %d x %d)", F->bstride, t);
     HIPCHK(c, hipSetDevice(c->device));
     {   // > 64 KB of dynamic LDS (the block's Gram in doubles)
         static std::atomic<unsigned long long> attr_set{0ull};
@@ -2236,25 +2320,55 @@ static int f64_sweep(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_sweep_sta
     HIPCHK(c, hipMemsetAsync(c->counters, 0, sizeof(unsigned long long) * kNCounters, c->stream));
     HIPCHK(c, hipEventRecord(c->ev_start, c->stream));
     const int64_t nb = c->nblocks;
-    for (int64_t k = 0; k < nb; ++k) {
-        const jw64::Events64* prev = k > 0 ? &F->ev[(k - 1) & 1] : nullptr;
-        switch (t) {
-            case 1: f64_launch_block<1>(c, prev, k, &F->ev[k & 1]); break;
-            case 2: f64_launch_block<2>(c, prev, k, &F->ev[k & 1]); break;
-            case 3: f64_launch_block<3>(c, prev, k, &F->ev[k & 1]); break;
-            default: f64_launch_block<4>(c, prev, k, &F->ev[k & 1]);
+    const size_t rbuf = (size_t)kMaxT * c->ld;
+    auto rb = [&](int64_t parity) { return F->r + (size_t)(parity & 1) * rbuf; };
+    const jw64::Events64* fin_lists = nullptr;
+    int64_t fin_nlists = 0, fin_parity = 0;
+    if (!P->independent_blocks) {
+        // launch k reads r(k & 1), applies block k-1's changes and writes r((k + 1) & 1)
+        for (int64_t k = 0; k < nb; ++k) {
+            const jw64::Events64* prev = k > 0 ? &F->ev[(k - 1) & 1] : nullptr;
+            switch (t) {
+                case 1: f64_launch_block<1>(c, rb(k), rb(k + 1), prev, k, F->partials, &F->ev[k & 1]); break;
+                case 2: f64_launch_block<2>(c, rb(k), rb(k + 1), prev, k, F->partials, &F->ev[k & 1]); break;
+                case 3: f64_launch_block<3>(c, rb(k), rb(k + 1), prev, k, F->partials, &F->ev[k & 1]); break;
+                default: f64_launch_block<4>(c, rb(k), rb(k + 1), prev, k, F->partials, &F->ev[k & 1]);
+            }
         }
+        fin_lists = &F->ev[(nb - 1) & 1]; fin_nlists = 1; fin_parity = nb;
+    } else {
+        // BayesABC_block_independent! (BayesABC.jl:190-255): every block from the SAME residual, reconciled afterwards
+        if (F->ev_all_cap < nb) {
+            (void)hipFree(F->ev_all); F->ev_all = nullptr; F->ev_all_cap = 0;
+            HIPCHK(c, hipMalloc(&F->ev_all, sizeof(jw64::Events64) * (size_t)nb));
+            F->ev_all_cap = nb;
+        }
+        const size_t one = (size_t)kMaxT * c->nslices * F->bstride;
+        if (F->partials_cap < one * (size_t)nb) {
+            (void)hipFree(F->partials); F->partials = nullptr; F->partials_cap = 0;
+            HIPCHK(c, hipMalloc(&F->partials, sizeof(double) * one * (size_t)nb));
+            F->partials_cap = one * (size_t)nb;
+        }
+        for (int64_t k = 0; k < nb; ++k) {
+            double* part = F->partials + one * (size_t)k;
+            switch (t) {
+                case 1: f64_launch_block<1>(c, rb(0), nullptr, nullptr, k, part, F->ev_all + k); break;
+                case 2: f64_launch_block<2>(c, rb(0), nullptr, nullptr, k, part, F->ev_all + k); break;
+                case 3: f64_launch_block<3>(c, rb(0), nullptr, nullptr, k, part, F->ev_all + k); break;
+                default: f64_launch_block<4>(c, rb(0), nullptr, nullptr, k, part, F->ev_all + k);
+            }
+        }
+        fin_lists = F->ev_all; fin_nlists = nb; fin_parity = 0;
     }
-    const jw64::Events64* last = &F->ev[(nb - 1) & 1];
     const double* gamma_dev = reinterpret_cast<const double*>(reinterpret_cast<const char*>(F->dparams) + offsetof(jw64::Params64, gamma));
     switch (t) {
-        case 1: hipLaunchKernelGGL((jw64::k64_finish<1>), dim3(c->nslices), dim3(256), 0, c->stream, F->X, c->ld, c->n, F->r, last, c->fin_out);
+        case 1: hipLaunchKernelGGL((jw64::k64_finish<1>), dim3(c->nslices), dim3(256), 0, c->stream, F->X, c->ld, c->n, F->w, rb(fin_parity), rb(0), fin_lists, fin_nlists, c->fin_out);
                 hipLaunchKernelGGL((jw64::k64_marker_stats<1>), dim3(kStatGrid), dim3(256), 0, c->stream, c->method, c->p, F->alpha, F->beta, F->delta, gamma_dev, c->stat_out); break;
-        case 2: hipLaunchKernelGGL((jw64::k64_finish<2>), dim3(c->nslices), dim3(256), 0, c->stream, F->X, c->ld, c->n, F->r, last, c->fin_out);
+        case 2: hipLaunchKernelGGL((jw64::k64_finish<2>), dim3(c->nslices), dim3(256), 0, c->stream, F->X, c->ld, c->n, F->w, rb(fin_parity), rb(0), fin_lists, fin_nlists, c->fin_out);
                 hipLaunchKernelGGL((jw64::k64_marker_stats<2>), dim3(kStatGrid), dim3(256), 0, c->stream, c->method, c->p, F->alpha, F->beta, F->delta, gamma_dev, c->stat_out); break;
-        case 3: hipLaunchKernelGGL((jw64::k64_finish<3>), dim3(c->nslices), dim3(256), 0, c->stream, F->X, c->ld, c->n, F->r, last, c->fin_out);
+        case 3: hipLaunchKernelGGL((jw64::k64_finish<3>), dim3(c->nslices), dim3(256), 0, c->stream, F->X, c->ld, c->n, F->w, rb(fin_parity), rb(0), fin_lists, fin_nlists, c->fin_out);
                 hipLaunchKernelGGL((jw64::k64_marker_stats<3>), dim3(kStatGrid), dim3(256), 0, c->stream, c->method, c->p, F->alpha, F->beta, F->delta, gamma_dev, c->stat_out); break;
-        default: hipLaunchKernelGGL((jw64::k64_finish<4>), dim3(c->nslices), dim3(256), 0, c->stream, F->X, c->ld, c->n, F->r, last, c->fin_out);
+        default: hipLaunchKernelGGL((jw64::k64_finish<4>), dim3(c->nslices), dim3(256), 0, c->stream, F->X, c->ld, c->n, F->w, rb(fin_parity), rb(0), fin_lists, fin_nlists, c->fin_out);
                 hipLaunchKernelGGL((jw64::k64_marker_stats<4>), dim3(kStatGrid), dim3(256), 0, c->stream, c->method, c->p, F->alpha, F->beta, F->delta, gamma_dev, c->stat_out);
     }
     HIPCHK(c, hipGetLastError());
@@ -2284,15 +2398,22 @@ int jwas_hip_load_dense_f64(jwas_hip_ctx* c, const double* Xh, int64_t n, int64_
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     f64_free_state(c);
-    for (void* q : {(void*)F->X, (void*)F->r, (void*)F->xpx, (void*)F->gram, (void*)F->partials, (void*)F->ev, (void*)F->dparams}) (void)hipFree(q);
-    F->X = F->r = F->xpx = F->gram = F->partials = nullptr; F->ev = nullptr; F->dparams = nullptr;
+    for (void* q : {(void*)F->X, (void*)F->r, (void*)F->xpx, (void*)F->gram, (void*)F->partials, (void*)F->ev, (void*)F->dparams, (void*)F->w, (void*)F->ev_all}) (void)hipFree(q);
+    F->X = F->r = F->xpx = F->gram = F->partials = F->w = nullptr; F->ev = F->ev_all = nullptr; F->dparams = nullptr;
+    F->partials_cap = 0; F->ev_all_cap = 0; F->starts.clear(); F->bstride = 0;
     (void)hipFree(c->counters); (void)hipFree(c->fin_out); (void)hipFree(c->stat_out); if (c->host_buf) (void)hipHostFree(c->host_buf);
     c->counters = nullptr; c->fin_out = c->stat_out = nullptr; c->host_buf = nullptr;
     c->method = -1; c->ntraits = 0; c->block_size = 0; c->nblocks = 0;
     c->n = n; c->p = p; c->ld = round_up(n, kSliceRows); c->nslices = (int)(c->ld / kSliceRows);
     HIPCHK(c, hipMalloc(&F->X, sizeof(double) * (size_t)c->ld * p));
-    HIPCHK(c, hipMalloc(&F->r, sizeof(double) * (size_t)kMaxT * c->ld));
-    HIPCHK(c, hipMalloc(&F->partials, sizeof(double) * (size_t)kMaxT * c->nslices * jw64::kMaxBlock64));
+    HIPCHK(c, hipMalloc(&F->r, sizeof(double) * 2 * (size_t)kMaxT * c->ld));                // two buffers: a sweep's launches alternate
+    HIPCHK(c, hipMalloc(&F->w, sizeof(double) * (size_t)c->ld));
+    {
+        std::vector<double> ones((size_t)c->ld, 0.0);
+        for (int64_t i = 0; i < n; ++i) ones[(size_t)i] = 1.0;
+        HIPCHK(c, hipMemcpy(F->w, ones.data(), sizeof(double) * (size_t)c->ld, hipMemcpyHostToDevice));
+    }
+    F->partials = nullptr; F->partials_cap = 0;
     HIPCHK(c, hipMalloc(&F->ev, sizeof(jw64::Events64) * 2));
     HIPCHK(c, hipMalloc(&F->dparams, sizeof(jw64::Params64)));
     HIPCHK(c, hipMalloc(&c->counters, sizeof(unsigned long long) * kNCounters));

@@ -520,19 +520,25 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         adaptive = (not dense) and t == 1 and block_size == 512 and p > 4 * 1024
 
     if double_precision:
-        # the Float64 device context (csrc/f64_path.hpp): dense storage, blocks of 64 / 128 markers, single-trait
-        # BayesA/B/C (+ RR-BLUP, BayesL through them), BayesR, multi-trait BayesC sampler I
+        # the Float64 device context (csrc/f64_path.hpp): dense storage; single-trait BayesA/B/C (+ RR-BLUP, BayesL through
+        # them), BayesR, multi-trait BayesC sampler I; any fast_blocks partition with blocks of <= 1024 markers (uniform or
+        # explicit starts), independent_blocks, residual weights; block size x traits <= 2048
         if stream or devres:
             raise NotImplementedError("double_precision=true needs dense host genotypes (the streaming backend is Float32 only, readgenotypes.jl:246-248)")
-        if invw is not None or independent_blocks or mega or mt_pervar or explicit_partition is not None or (t > 1 and mt_method != "MTBayesC"):
-            raise NotImplementedError("double_precision=true runs unit residual weights, the sequential block sweep, multi-trait BayesC "
-                                      "sampler I and uniform blocks; the other combinations stay on the reference")
+        if mega or mt_pervar or (t > 1 and mt_method != "MTBayesC"):
+            raise NotImplementedError("double_precision=true runs the single-trait samplers and multi-trait BayesC sampler I on the device; "
+                                      "sampler II, constraint=true and multi-trait BayesA/B stay on the reference in Float64 mode")
         if fast_blocks is not False:
-            if want not in (64, 128):
-                raise NotImplementedError("double_precision=true runs fast_blocks = 64 or 128 on the device")
-            block_size = want
+            if explicit_partition is None:
+                block_size = want                      # (the Float64 context runs uniform blocks of ANY size <= 1024 as they are)
         else:
-            block_size = 128 if p > 64 else 64
+            # two stream-ordered launches per block, no lookahead: big blocks amortise them (20k x 20k BayesC: 6.8 ms per sweep
+            # at 128 markers per block, 2.1 ms at 512 -- scripts/f64_bench.py); the chain is the same whatever the size
+            block_size = 512
+            while block_size > 64 and p <= block_size:
+                block_size //= 2
+        if block_size * t > 2048:
+            raise NotImplementedError(f"double_precision=true needs fast_blocks * traits <= 2048 on the device (got {block_size} x {t})")
         adaptive = False
 
     # ---- engine (the only engine shipped is the HIP one; there is no CPU fallback)

@@ -253,6 +253,12 @@ int  orc64_bayesabc_block_sweep(const double* X, int64_t n, int64_t p, int64_t l
                                 double* r, double* alpha, double* beta, double* delta,
                                 double vare, const double* var_effects, const double* pi,
                                 uint64_t seed, uint32_t iter, uint32_t marker0);
+void orc64_xpx_w(const double* X, int64_t n, int64_t p, int64_t ld, const double* w, double* out);
+int  orc64_bayesabc_block_sweep_ex(const double* X, int64_t n, int64_t p, int64_t ld, const double* xpx, const double* w,
+                                   const int64_t* starts, int64_t nb, int nreps, int independent,
+                                   double* r, double* alpha, double* beta, double* delta,
+                                   double vare, const double* var_effects, const double* pi,
+                                   uint64_t seed, uint32_t iter, uint32_t marker0);
 int  orc64_bayesr_sweep(const double* X, int64_t n, int64_t p, int64_t ld, const double* xpx,
                         double* r, double* alpha, int32_t* delta,
                         double vare, double sigma_sq, const double* pi, int pi_is_matrix, const double* gamma,

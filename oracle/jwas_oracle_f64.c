@@ -241,3 +241,78 @@ int orc64_bayesabc_block_sweep(const double* X, int64_t n, int64_t p, int64_t ld
     free(G); free(rhs_b); free(a_old);
     return 0;
 }
+
+
+/* The general Float64 block form of BayesABC! (BayesABC_block!, BayesABC.jl:118-188; BayesABC_block_independent!, :190-255):
+ * any partition `starts` (nb + 1 entries, 0-based, starts[nb] = p), residual weights w (NULL = unit: X_b'R^-1 X_b, X_b'R^-1 r and
+ * x'R^-1 x with R^-1 = diag(w), tools4genotypes.jl:59-78,237-275), nreps <= 0 = every block its own size (:153),
+ * independent != 0: every block's right-hand side from the residual at the START of the sweep, the residual reconciled
+ * afterwards in (block, marker) order (:251-253).  xpx: x'R^-1 x (orc64_xpx_w). */
+void orc64_xpx_w(const double* X, int64_t n, int64_t p, int64_t ld, const double* w, double* out)
+{
+    for (int64_t j = 0; j < p; ++j) {
+        const double* x = X + j * ld;
+        double s = 0.0;
+        for (int64_t i = 0; i < n; ++i) s += (x[i] * x[i]) * (w ? w[i] : 1.0);
+        out[j] = s;
+    }
+}
+
+int orc64_bayesabc_block_sweep_ex(const double* X, int64_t n, int64_t p, int64_t ld, const double* xpx, const double* w,
+                                  const int64_t* starts, int64_t nb, int nreps_arg, int independent,
+                                  double* r, double* alpha, double* beta, double* delta,
+                                  double vare, const double* var_effects, const double* pi,
+                                  uint64_t seed, uint32_t iter, uint32_t marker0)
+{
+    if (n <= 0 || p <= 0 || ld < n || !(vare > 0.0) || nb < 1 || !starts) return -1;
+    const double invVarRes = 1.0 / vare;
+    int64_t bmax = 0;
+    for (int64_t k = 0; k < nb; ++k) if (starts[k + 1] - starts[k] > bmax) bmax = starts[k + 1] - starts[k];
+    double* G = (double*)malloc(sizeof(double) * (size_t)bmax * bmax);
+    double* rhs_b = (double*)malloc(sizeof(double) * (size_t)bmax);
+    double* a_old = (double*)malloc(sizeof(double) * (size_t)p);
+    double* rw = (double*)malloc(sizeof(double) * (size_t)n);
+    for (int64_t j = 0; j < p; ++j) a_old[j] = alpha[j];
+    if (independent) for (int64_t i = 0; i < n; ++i) rw[i] = r[i] * (w ? w[i] : 1.0);      /* the snapshot, weighted once */
+    for (int64_t blk = 0; blk < nb; ++blk) {
+        const int64_t j0 = starts[blk], b = starts[blk + 1] - j0;
+        for (int64_t a = 0; a < b; ++a)
+            for (int64_t c = 0; c < b; ++c) {
+                const double *xa = X + (j0 + a) * ld, *xc = X + (j0 + c) * ld;
+                double sum = 0.0;
+                for (int64_t i = 0; i < n; ++i) sum += (xa[i] * xc[i]) * (w ? w[i] : 1.0);
+                G[a * b + c] = sum;
+            }
+        if (!independent) for (int64_t i = 0; i < n; ++i) rw[i] = r[i] * (w ? w[i] : 1.0);
+        for (int64_t k = 0; k < b; ++k) rhs_b[k] = dot64(X + (j0 + k) * ld, rw, n);                             /* block_rhs! */
+        const int nreps = nreps_arg > 0 ? nreps_arg : (int)b;                                                   /* :153 */
+        for (int rep = 0; rep < nreps; ++rep)
+            for (int64_t k = 0; k < b; ++k) {                                                                   /* :155-178 */
+                const int64_t j = j0 + k;
+                const uint32_t m = marker0 + (uint32_t)j;
+                const double rhs = (rhs_b[k] + xpx[j] * alpha[j]) * invVarRes;
+                const double lhs = xpx[j] * invVarRes + 1.0 / var_effects[j];
+                const double invLhs = 1.0 / lhs, gHat = rhs * invLhs;
+                const double logDelta1 = -0.5 * (log(lhs) + log(var_effects[j]) - gHat * rhs) + log(1.0 - pi[j]);
+                const double probDelta1 = 1.0 / (1.0 + exp(log(pi[j]) - logDelta1));
+                const double oldAlpha = alpha[j];
+                const double u = orc_uniform(seed, m, iter, (uint32_t)rep, 0), z = orc_normal(seed, m, iter, (uint32_t)rep, 0);
+                double coef;
+                if (u < probDelta1) { delta[j] = 1.0; beta[j] = gHat + z * sqrt(invLhs); alpha[j] = beta[j]; coef = oldAlpha - alpha[j]; }
+                else { delta[j] = 0.0; beta[j] = z * sqrt(var_effects[j]); alpha[j] = 0.0; coef = oldAlpha; }
+                if (coef != 0.0) axpy64(coef, G + k * b, rhs_b, b);                                             /* :169,172 */
+            }
+        if (!independent)
+            for (int64_t k = 0; k < b; ++k) {                                                                   /* :181-185 */
+                const double d = a_old[j0 + k] - alpha[j0 + k];
+                if (d != 0.0) axpy64(d, X + (j0 + k) * ld, r, n);
+            }
+    }
+    if (independent)
+        for (int64_t j = 0; j < p; ++j) {                                                                       /* :251-253 */
+            const double d = a_old[j] - alpha[j];
+            if (d != 0.0) axpy64(d, X + j * ld, r, n);
+        }
+    free(G); free(rhs_b); free(a_old); free(rw);
+    return 0;
+}

@@ -403,6 +403,36 @@ def bayesabc_sweep64(X, xpx_, r, alpha, beta, delta, vare, var_effects, pi, seed
         raise ValueError(f"orc64_bayesabc_sweep: {rc}")
 
 
+def xpx64_w(X, w=None):
+    """x'R^-1 x in Float64 (w = None: unit weights)."""
+    X = np.asfortranarray(X, dtype=np.float64)
+    n, p = X.shape
+    out = np.empty(p)
+    L = lib()
+    L.orc64_xpx_w.restype = None
+    wv = None if w is None else _f64(w)
+    L.orc64_xpx_w(_p(X, _f64p), C.c_int64(n), C.c_int64(p), C.c_int64(n), None if wv is None else _p(wv, _f64p), _p(out, _f64p))
+    return out
+
+
+def bayesabc_block_sweep64_ex(X, xpx_, r, alpha, beta, delta, vare, var_effects, pi, seed, it, starts, nreps=1, independent=False,
+                              w=None, marker0=0):
+    """BayesABC_block! / BayesABC_block_independent! with T = Float64 on the partition `starts` (0-based block starts; the
+    end p is appended here), residual weights w, in place."""
+    n, p = X.shape
+    ve = np.broadcast_to(np.asarray(var_effects, dtype=np.float64), (p,)).copy()
+    pv = np.broadcast_to(np.asarray(pi, dtype=np.float64), (p,)).copy()
+    st = np.ascontiguousarray(list(starts) + [p], dtype=np.int64)
+    wv = None if w is None else _f64(w)
+    rc = lib().orc64_bayesabc_block_sweep_ex(_p(X, _f64p), C.c_int64(n), C.c_int64(p), C.c_int64(n), _p(xpx_, _f64p),
+                                             None if wv is None else _p(wv, _f64p), st.ctypes.data_as(C.POINTER(C.c_int64)), C.c_int64(len(st) - 1),
+                                             C.c_int(int(nreps)), C.c_int(1 if independent else 0),
+                                             _p(r, _f64p), _p(alpha, _f64p), _p(beta, _f64p), _p(delta, _f64p), C.c_double(float(vare)),
+                                             _p(ve, _f64p), _p(pv, _f64p), C.c_uint64(int(seed)), C.c_uint32(int(it)), C.c_uint32(int(marker0)))
+    if rc:
+        raise ValueError(f"orc64_bayesabc_block_sweep_ex: {rc}")
+
+
 def bayesr_sweep64(X, xpx_, r, alpha, delta, vare, sigma_sq, pi, seed, it, gamma=GAMMA, marker0=0):
     n, p = X.shape
     pm = _f64(pi)

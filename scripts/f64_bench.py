@@ -1,6 +1,7 @@
 """Throughput of the Float64 context (runMCMC(double_precision=true)) on one MI355X: BayesC sweeps over a synthetic
 n x p matrix of doubles.  python scripts/f64_bench.py [n] [p]"""
 import json
+import os
 import sys
 import time
 
@@ -26,7 +27,7 @@ for prec in (64, 32):
     e = J.HipEngine(0, precision=prec)
     dt = np.float64 if prec == 64 else np.float32
     e.load_dense(np.asfortranarray(X, dtype=dt))
-    t0 = time.time(); e.setup_blocks(128 if prec == 64 else 512, "mfma"); setup = time.time() - t0
+    t0 = time.time(); e.setup_blocks(int(os.environ.get("JWAS_F64_BLOCK", "512")) if prec == 64 else 512, "mfma"); setup = time.time() - t0
     e.init_state("BayesC", 1); e.set_residual((y - y.mean()).astype(dt))
     pi, ms = 0.95, []
     for it in range(1, 41):

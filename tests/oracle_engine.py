@@ -268,9 +268,23 @@ class OracleEngine64:
 
     def setup_blocks(self, block_size=128, gram_mode="f64"):
         self.block_size = int(block_size)
-        self._xpx = O.xpx64(self.X)
+        self._starts = None
+        self._xpx = O.xpx64_w(self.X, getattr(self, "_w", None))
+
+    def setup_blocks_explicit(self, starts, gram_mode="f64"):
+        self._starts = np.asarray(starts, dtype=np.int64)
+        sizes = np.diff(np.append(self._starts, self.p))
+        self.block_size = int(sizes.max())
+        self._xpx = O.xpx64_w(self.X, getattr(self, "_w", None))
+
+    def set_weights(self, rinv):
+        self._w = None if rinv is None else np.asarray(np.asarray(rinv, dtype=np.float32), dtype=np.float64)      # (the C ABI carries Float32 weights)
+        if getattr(self, "_xpx", None) is not None:
+            self._xpx = O.xpx64_w(self.X, self._w)
 
     def block_starts(self):
+        if getattr(self, "_starts", None) is not None:
+            return self._starts.copy()
         return np.arange(0, self.p, self.block_size, dtype=np.int64)
 
     def xpx(self):
@@ -306,28 +320,36 @@ class OracleEngine64:
         return self.X @ self.alpha[trait]
 
     def sweep(self, *, iteration, seed, vare, var_effect, pi=0.0, pi_classes=None, gamma=O.GAMMA, log_prior_states=None,
-              var_effect_vec=None, pi_vec=None, pi_matrix=None, nreps=1, marker_offset=0, **_):
+              var_effect_vec=None, pi_vec=None, pi_matrix=None, nreps=1, marker_offset=0, independent_blocks=False, **_):
         t = self.ntraits
         a_before = self.alpha.copy()
+        w = getattr(self, "_w", None)
+        general = independent_blocks or w is not None or getattr(self, "_starts", None) is not None
         if self.method in (BAYESC, BAYESB):
             if np.ndim(pi) == 1:
                 pi_vec = pi
             pv = pi_vec if pi_vec is not None else float(pi)
             ve = var_effect_vec if self.method == BAYESB else float(np.asarray(var_effect).reshape(-1)[0])
-            O.bayesabc_sweep64(self.X, self._xpx, self.r[0], self.alpha[0], self.beta[0], self.delta[0],
-                               float(np.asarray(vare).reshape(-1)[0]), ve, pv, seed, iteration, marker0=marker_offset,
-                               block_size=0 if nreps == 1 else self.block_size, nreps=nreps)
+            if general:
+                O.bayesabc_block_sweep64_ex(self.X, self._xpx, self.r[0], self.alpha[0], self.beta[0], self.delta[0],
+                                            float(np.asarray(vare).reshape(-1)[0]), ve, pv, seed, iteration, self.block_starts(),
+                                            nreps=nreps, independent=independent_blocks, w=w, marker0=marker_offset)
+            else:
+                O.bayesabc_sweep64(self.X, self._xpx, self.r[0], self.alpha[0], self.beta[0], self.delta[0],
+                                   float(np.asarray(vare).reshape(-1)[0]), ve, pv, seed, iteration, marker0=marker_offset,
+                                   block_size=0 if nreps == 1 else self.block_size, nreps=nreps)
         elif self.method == BAYESR:
-            assert nreps == 1
+            assert nreps == 1 and not general
             pc = pi_matrix if pi_matrix is not None else pi_classes
             O.bayesr_sweep64(self.X, self._xpx, self.r[0], self.alpha[0], self.delta[0], float(np.asarray(vare).reshape(-1)[0]),
                              float(np.asarray(var_effect).reshape(-1)[0]), pc, seed, iteration, gamma=gamma, marker0=marker_offset)
         else:
-            assert nreps == 1
+            assert nreps == 1 and not general
             O.mt1_sweep64(self.X, self._xpx, self.r, self.alpha, self.beta, self.delta, np.asarray(vare, dtype=np.float64).reshape(t, t),
                           np.asarray(var_effect, dtype=np.float64).reshape(t, t), log_prior_states, seed, iteration, marker0=marker_offset)
-        out = {"alpha_ss": self.alpha @ self.alpha.T, "beta_ss": self.beta @ self.beta.T, "resid_ss": self.r @ self.r.T,
-               "resid_sum": self.r.sum(axis=1), "n_events": float(np.any(a_before != self.alpha, axis=0).sum()), "sweep_ms": 0.0,
+        ww = np.ones(self.n) if w is None else w
+        out = {"alpha_ss": self.alpha @ self.alpha.T, "beta_ss": self.beta @ self.beta.T, "resid_ss": (self.r * ww) @ self.r.T,
+               "resid_sum": (self.r * ww).sum(axis=1), "n_events": float(np.any(a_before != self.alpha, axis=0).sum()), "sweep_ms": 0.0,
                "class_counts": np.zeros(4), "bayesr_ssq": 0.0, "bayesr_nnz": 0.0, "sum_delta": np.zeros(t), "state_counts": np.zeros(1 << t)}
         if self.method == BAYESR:
             d = self.delta[0]

@@ -42,10 +42,10 @@ def test_f64_xpx_and_dtype_contract():
         np.testing.assert_allclose(hip.xpx(), (X * X).sum(axis=0), rtol=1e-13)
         with pytest.raises(TypeError, match="float64"):
             hip.load_dense(X.astype(np.float32))
+        with pytest.raises(J.JwasHipError, match="1 to 1024 markers"):
+            hip.setup_blocks(2048)
         with pytest.raises(J.JwasHipError, match="Float64 context"):
-            hip.set_weights(np.ones(300, dtype=np.float32))
-        with pytest.raises(J.JwasHipError, match="64 or 128"):
-            hip.setup_blocks(256)
+            hip.add_block_size(512)
         f32 = J.HipEngine(0)
         try:
             with pytest.raises(TypeError, match="float32"):
@@ -175,3 +175,95 @@ def test_runmcmc_double_precision_gpu_vs_oracle(tmp_path, method, Pi):
     np.testing.assert_allclose(eh["Model_Frequency"], eo["Model_Frequency"], atol=1e-12)
     np.testing.assert_allclose(outs["hip"]["EBV_y1"]["EBV"], outs["orc"]["EBV_y1"]["EBV"], atol=1e-7)
     assert float(outs["hip"]["residual variance"]["Estimate"][0]) == pytest.approx(float(outs["orc"]["residual variance"]["Estimate"][0]), rel=1e-9)
+
+
+# ---- round 4: the Float64 context beyond uniform 64- / 128-marker blocks -------------------
+@pytest.mark.parametrize("method,bs,n,p,t", [("BayesC", 223, 600, 223 * 2 + 90, 1), ("BayesR", 512, 520, 512 + 300, 1),
+                                             ("BayesB", 1024, 300, 1024 + 77, 1), ("MTBayesC", 256, 400, 256 * 2 + 31, 2)])
+def test_f64_any_block_size_parity(method, bs, n, p, t):
+    """Uniform blocks of ANY size <= 1024 (the reference default fast_blocks = true is floor(sqrt(n)): 223 at n = 50 000): blocks
+    above 128 markers read their Gram rows from L2 and walk up to 16 sub-blocks.  Single pass = the literal chain."""
+    d, X, orc, hip = _pair(n, p, bs, method, t=t, seed=41)
+    try:
+        rng = np.random.default_rng(5)
+        y = d["y"] - d["y"].mean()
+        for k in range(t):
+            for e in (orc, hip):
+                e.set_residual((1 + 0.4 * k) * y, k)
+                if method == "MTBayesC":
+                    e.set_state(k, delta=np.ones(e.p))
+        if method == "BayesR":
+            kw = dict(vare=0.5, var_effect=0.05, pi_classes=np.array([0.9, 0.05, 0.03, 0.02]))
+        elif method == "MTBayesC":
+            kw = dict(vare=np.array([[0.5, 0.1], [0.1, 0.6]]), var_effect=np.array([[0.004, 0.001], [0.001, 0.003]]),
+                      log_prior_states=np.log(np.array([0.7, 0.1, 0.1, 0.1])))
+        elif method == "BayesB":
+            kw = dict(vare=0.5, var_effect=0.004, var_effect_vec=rng.uniform(0.002, 0.006, p), pi=0.9)
+        else:
+            kw = dict(vare=0.5, var_effect=0.004, pi=0.9)
+        for it in range(1, 7):
+            orc.sweep(iteration=it, seed=6, **kw)
+            hip.sweep(iteration=it, seed=6, **kw)
+        _compare(orc, hip, t)
+    finally:
+        hip.close()
+
+
+@pytest.mark.parametrize("bs,nreps,independent", [(128, 1, False), (300, 0, False), (96, 3, True), (223, 0, True)])
+def test_f64_weights_and_independent_blocks_parity(bs, nreps, independent):
+    """Residual weights (x'R^-1 x, X_b'R^-1 X_b, X_b'R^-1 r, r'R^-1 r: tools4genotypes.jl:59-78,237-275) and
+    independent_blocks (BayesABC.jl:190-255) in the Float64 context, against the general Float64 block oracle."""
+    d, X, orc, hip = _pair(450, bs * 2 + 57, bs, "BayesC", seed=43)
+    try:
+        w = (1.0 + np.random.default_rng(2).uniform(0, 1.5, 450)).astype(np.float32)
+        for e in (orc, hip):
+            e.set_weights(w); e.setup_blocks(bs); e.init_state("BayesC", 1)
+            e.set_residual(d["y"] - d["y"].mean())
+        np.testing.assert_allclose(hip.xpx(), (X * X * w.astype(np.float64)[:, None]).sum(axis=0), rtol=1e-13)
+        for it in range(1, 6):
+            so = orc.sweep(iteration=it, seed=8, vare=0.5, var_effect=0.004, pi=0.9, nreps=nreps, independent_blocks=independent)
+            sh = hip.sweep(iteration=it, seed=8, vare=0.5, var_effect=0.004, pi=0.9, nreps=nreps, independent_blocks=independent)
+            assert so["sum_delta"][0] == sh["sum_delta"][0], f"iteration {it}"
+            np.testing.assert_allclose(sh["resid_ss"], so["resid_ss"], rtol=1e-9)
+            np.testing.assert_allclose(sh["resid_sum"], so["resid_sum"], rtol=0, atol=1e-8)
+        _compare(orc, hip, 1)
+    finally:
+        hip.close()
+
+
+def test_f64_explicit_partition_parity():
+    """fast_blocks = a vector of block starts (JWAS.jl:298-304) in the Float64 context: ragged blocks, each repeated its own size."""
+    d, X, orc, hip = _pair(380, 700, 128, "BayesC", seed=47)
+    try:
+        starts = np.array([0, 5, 140, 141, 400, 655])
+        for e in (orc, hip):
+            e.setup_blocks_explicit(starts); e.init_state("BayesC", 1)
+            e.set_residual(d["y"] - d["y"].mean())
+        for it in range(1, 4):
+            so = orc.sweep(iteration=it, seed=9, vare=0.5, var_effect=0.004, pi=0.9, nreps=0)
+            sh = hip.sweep(iteration=it, seed=9, vare=0.5, var_effect=0.004, pi=0.9, nreps=0)
+            assert so["sum_delta"][0] == sh["sum_delta"][0], f"iteration {it}"
+        _compare(orc, hip, 1)
+    finally:
+        hip.close()
+
+
+def test_runmcmc_double_precision_default_fast_blocks_at_50000_records(tmp_path):
+    """runMCMC(double_precision=true, fast_blocks=true) at n = 50 000: the reference's default block size floor(sqrt(n)) = 223
+    (JWAS.jl:308-312) runs on the device (it was an error through round 3)."""
+    n, p = 50_000, 1_200
+    rng = np.random.default_rng(3)
+    raw = rng.integers(0, 3, size=(n, p)).astype(np.float64)
+    beta = np.zeros(p); beta[rng.choice(p, 10, replace=False)] = rng.standard_normal(10)
+    g = (raw - raw.mean(axis=0)) @ beta
+    y = 1.0 + g + rng.standard_normal(n) * g.std()
+    ids = [str(i + 1) for i in range(n)]                    # (a matrix gets the individual IDs "1" .. "n", readgenotypes.jl:339-345)
+    geno = api.get_genotypes(raw, method="BayesC", Pi=0.95, double_precision=True, quality_control=False)
+    model = api.build_model("y1 = intercept + geno")
+    ph = pd.DataFrame({"ID": ids, "y1": y})
+    out = api.runMCMC(model, ph, chain_length=223 * 3, burnin=1, seed=1, double_precision=True, fast_blocks=True, outputEBV=False,
+                      output_folder=str(tmp_path / "fb"))
+    assert out["_timing"]["iterations"] == 3
+    assert out["_timing"]["block_starts"][:3] == [1, 224, 447]
+    est = np.asarray(out["marker effects geno"]["Estimate"])
+    assert est.dtype == np.float64 and np.corrcoef(est, beta)[0, 1] > 0.9

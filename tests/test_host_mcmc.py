@@ -883,11 +883,23 @@ def test_runmcmc_double_precision_host_loop(tmp_path):
     out2 = api.runMCMC(model2, ph, chain_length=60, burnin=10, seed=2, double_precision=True, output_folder=str(tmp_path / "mt"),
                        _engine=OracleEngine64())
     assert np.isfinite(out2["residual variance"]["Estimate"]).all()
-    with pytest.raises(NotImplementedError, match="double_precision=true"):
-        api.runMCMC(model, ph, chain_length=10, double_precision=True, fast_blocks=50, output_folder=str(tmp_path / "e1"), _engine=OracleEngine64())
+    # round 4: any fast_blocks partition, independent blocks and residual weights run in Float64 mode too (JWAS.jl:349-366 casts
+    # everything and every mode keeps working); what stays an explicit error is sampler II / constraint / multi-trait BayesA/B
+    out3 = api.runMCMC(model, ph, chain_length=100, double_precision=True, fast_blocks=50, seed=2, output_folder=str(tmp_path / "e1"),
+                       _engine=OracleEngine64())
+    assert out3["_timing"]["iterations"] == 2 and out3["marker effects geno"]["Estimate"].dtype == np.float64
+    out4 = api.runMCMC(model, ph, chain_length=100, double_precision=True, fast_blocks=True, independent_blocks=True, seed=2,
+                       output_folder=str(tmp_path / "e1b"), _engine=OracleEngine64())
+    assert out4["_timing"]["block_starts"] == list(range(1, 261, 14))                       # floor(sqrt(220)) = 14
     ph_w = ph.assign(weights=1.0 + rng.uniform(0, 1, 220))
+    out5 = api.runMCMC(model, ph_w, chain_length=30, double_precision=True, heterogeneous_residuals=True, seed=2,
+                       output_folder=str(tmp_path / "e2"), _engine=OracleEngine64())
+    assert np.isfinite(out5["residual variance"]["Estimate"]).all()
+    geno = api.get_genotypes(gdf, np.eye(2) * 0.5, method="BayesC", double_precision=True, constraint=True)
+    model2c = api.build_model("y1 = intercept + geno\ny2 = intercept + geno", np.eye(2))
     with pytest.raises(NotImplementedError, match="double_precision=true"):
-        api.runMCMC(model, ph_w, chain_length=10, double_precision=True, heterogeneous_residuals=True, output_folder=str(tmp_path / "e2"),
-                    _engine=OracleEngine64())
+        api.runMCMC(model2c, ph, chain_length=10, double_precision=True, output_folder=str(tmp_path / "e2c"), _engine=OracleEngine64())
+    geno = api.get_genotypes(gdf, method="BayesC", Pi=0.9, double_precision=True)
+    model = api.build_model("y1 = intercept + geno")
     with pytest.raises(NotImplementedError, match="runMCMC\\(double_precision=true\\)"):
         api.runMCMC(model, ph, chain_length=10, output_folder=str(tmp_path / "e3"), _engine=OracleEngine64())      # Float64 genotypes, Float32 run
