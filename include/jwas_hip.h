@@ -345,10 +345,13 @@ int  jwas_hip_get_marker_covariances(jwas_hip_ctx* ctx, float* out_p_t_t);      
  * In that mode the reference holds EVERYTHING as Float64 -- genotypes, ycorr, alpha / beta / delta, x'x -- and its scalar
  * kernels run in Float64.  jwas_hip_set_precision(ctx, 64) BEFORE genotypes are loaded makes the context a Float64 context:
  * the data entry points below replace their Float32 namesakes (same meaning, double host arrays; delta is double 0/1, or
- * int32 classes for BayesR); jwas_hip_setup_blocks (block_size 64 or 128), jwas_hip_init_state, jwas_hip_sweep (reading
- * jwas_sweep_params.vare_f64 / var_effect_f64 / var_effect_vec_f64), jwas_hip_residual_sub_xalpha, jwas_hip_accumulate and
- * jwas_hip_num_blocks are shared.  Samplers: single-trait BayesA/B/C, BayesR, multi-trait sampler I; dense storage;
- * within-block repetitions.  Everything else of the Float32 surface returns JWAS_HIP_EUNSUP on a Float64 context. */
+ * int32 classes for BayesR); jwas_hip_setup_blocks (any block size 1 .. 1024), jwas_hip_setup_blocks_explicit (blocks of at
+ * most 1024 markers), jwas_hip_set_weights (the Float32 values, widened), jwas_hip_init_state, jwas_hip_sweep (reading
+ * jwas_sweep_params.vare_f64 / var_effect_f64 / var_effect_vec_f64; nreps and independent_blocks as in a Float32 context),
+ * jwas_hip_residual_sub_xalpha, jwas_hip_accumulate and jwas_hip_num_blocks are shared.  Samplers: single-trait BayesA/B/C,
+ * BayesR, multi-trait sampler I; dense storage; block size x traits <= 2048.  Everything else of the Float32 surface (packed
+ * storage, a second block size, output rows, window sums, shards, samplers II / constrained / per-marker covariances)
+ * returns JWAS_HIP_EUNSUP on a Float64 context. */
 int  jwas_hip_set_precision(jwas_hip_ctx* ctx, int32_t bits);                     /* 32 (default) or 64 */
 int  jwas_hip_load_dense_f64(jwas_hip_ctx* ctx, const double* X_host, int64_t n, int64_t p, int64_t ld_host);
 int  jwas_hip_get_xpx_f64(jwas_hip_ctx* ctx, double* out_p);
