@@ -99,6 +99,51 @@ def test_bayesc_chain_parity(hip, bs):
     _compare_state(orc, hip)
 
 
+@pytest.mark.parametrize("method,bs", [("BayesC", 512), ("BayesR", 512), ("BayesC", 256), ("BayesC", 1024)])
+def test_compact_candidate_chain_and_its_fallback(hip, method, bs, capfd, monkeypatch):
+    """Round 4: the compact candidate chain (sampler_st.hpp: compact_walk / compact_surprise) -- 6..64 candidates per block,
+    wave 0 walks the candidates only, every other marker is verified afterwards, and a block in which a NON-candidate crosses
+    its threshold ("surprise") is thrown away and re-run through the speculative rounds from its untouched entry state.
+    Strong LD (near-duplicate neighbouring markers: a committed change moves its neighbour's rhs by much more than the 1/16
+    candidate margin) makes surprises frequent; the chain must equal the oracle's either way, and the library's phase counters
+    must show that both the compact chain and its fallback actually ran."""
+    import re
+    rng = np.random.default_rng(77)
+    n, p = 1500, 3 * bs + 40
+    base = make_dataset(n=n, p=p, ncausal=12, seed=78)
+    X = base["X"].copy()
+    for j in range(1, p, 2):                                   # marker j ~ marker j-1 (r^2 ~ 0.9)
+        flip = rng.random(n) < 0.05
+        X[:, j] = np.where(flip, X[:, j], X[:, j - 1])
+    X -= X.mean(axis=0, dtype=np.float64).astype(np.float32)
+    data = dict(base); data["X"] = np.asfortranarray(X.astype(np.float32))
+    orc, hip = _pair(hip, data, bs, method)
+    y = (data["y"] - data["y"].mean()).astype(np.float32)
+    for e in (orc, hip):
+        e.set_residual(y)
+    monkeypatch.setenv("JWAS_HIP_DEBUG_PHASES", "1")
+    vare = np.float32(0.5 * y.var())
+    if method == "BayesR":
+        kw = dict(vare=vare, var_effect=np.float32(0.02), pi_classes=np.array([0.9, 0.05, 0.03, 0.02]))
+    else:
+        kw = dict(vare=vare, var_effect=np.float32(0.004), pi=0.93)
+    tried = fell = 0
+    for it in range(1, 41):
+        so = orc.sweep(iteration=it, seed=5, **kw)
+        sh = hip.sweep(iteration=it, seed=5, **kw)
+        if method == "BayesR":
+            assert np.array_equal(so["class_counts"], sh["class_counts"]), f"iteration {it}"
+        else:
+            assert so["sum_delta"][0] == sh["sum_delta"][0], f"iteration {it}"
+        m = re.findall(r"compact: blocks=(\d+) fallback=(\d+)", capfd.readouterr().err)
+        assert m, "the library did not print its phase counters"
+        tried += int(m[-1][0]); fell += int(m[-1][1])
+    _compare_state(orc, hip, atol=5e-6)
+    assert tried > (20 if bs < 1024 else 4), f"the compact chain ran in {tried} blocks only"      # (1024-marker blocks stage 31 rows at most)
+    if bs <= 512 and method == "BayesC":
+        assert fell > 0, "no block took the fallback: the test no longer exercises it"
+
+
 @pytest.mark.parametrize("method,bs,pi", [("BayesC", 256, 0.6), ("BayesC", 512, 0.5), ("BayesC", 1024, 0.7), ("BayesC", 1024, 0.3),
                                           ("BayesR", 512, 0.5), ("BayesR", 1024, 0.6)])
 def test_many_changes_per_block_parity(hip, method, bs, pi):
