@@ -343,7 +343,13 @@ __device__ __forceinline__ int stage_assign(char* smem, const StepSmem& SM, cons
     total = base;
     return base < SM.max_cand ? base : SM.max_cand;
 }
-__device__ __forceinline__ void stage_load(char* smem, const StepSmem& SM, const SamplerArgs& A, int ncand, long long* ts = nullptr)
+// phase: 0 = issue + wait (the whole thing); 1 = issue only (full blocks: the direct loads; returns true -- otherwise nothing
+// is done and false comes back: call phase 0 instead); 2 = wait for the direct loads of phase 1 and synchronise.
+// keep_younger (phase 2): the caller issued exactly kStageYounger vector loads AFTER phase 1 on the waves != 0 and wants them
+// to stay in flight -- the wait is for the direct loads only (vmcnt counts in order) and the barrier is LDS-only.
+constexpr int kStageYounger = 19;
+__device__ __forceinline__ bool stage_load(char* smem, const StepSmem& SM, const SamplerArgs& A, int ncand, long long* ts = nullptr,
+                                           int phase = 0, bool keep_younger = false)
 {
     const int B = SM.B;
     const short* cand_list = reinterpret_cast<const short*>(smem + SM.cand_off);
@@ -358,7 +364,18 @@ __device__ __forceinline__ void stage_load(char* smem, const StepSmem& SM, const
     // arithmetic (a runtime division and a dependent LDS read per task, 24 tasks per wave whatever the count) cost more
     // than the memory latency itself -- 20 k of the 21 k cycles this function took per 512-marker block.
     const int b4 = A.b;
-    if (b4 == B && (B == 256 || B == 512 || B == 1024)) {
+    const bool direct = b4 == B && (B == 256 || B == 512 || B == 1024);
+    if (phase == 1 && !direct) return false;
+    if (phase == 2) {
+        if (ts) ts[1] = clock64();
+        if (keep_younger && wave != 0) asm volatile("s_waitcnt vmcnt(19)" ::: "memory");      // kStageYounger
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (ts) ts[2] = clock64();
+        if (keep_younger) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // (__syncthreads would wait for every load)
+        else __syncthreads();
+        return true;
+    }
+    if (direct) {
         // Direct global -> LDS loads (global_load_lds_dwordx4: each lane's 16 bytes land at M0 + lane*16, i.e. one task =
         // 1 KB of a row straight into its slot): no staging registers, a ROLLED loop of a few instructions with every load
         // in flight, one wait at the end.  (The unrolled register version spent 14 k cycles per block just issuing: cold
@@ -376,6 +393,7 @@ __device__ __forceinline__ void stage_load(char* smem, const StepSmem& SM, const
             __builtin_amdgcn_global_load_lds(A.gram + (crow * B + ch + lane * 4),
                                              (lds_void*)(rows + ((task >> sh) * B + ch)), 16, 0, 0);
         }
+        if (phase == 1) return true;
         if (ts) ts[1] = clock64();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (ts) ts[2] = clock64();
@@ -398,7 +416,9 @@ __device__ __forceinline__ void stage_load(char* smem, const StepSmem& SM, const
     }
     }
     __syncthreads();
+    return direct;
 }
+static_assert(kStageYounger == 19, "stage_load's s_waitcnt immediate");
 __device__ __forceinline__ int stage_rows(char* smem, const StepSmem& SM, const SamplerArgs& A, const bool (&cand)[2], long long* ts = nullptr)
 {
     int total = 0;

@@ -598,6 +598,10 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
     if (!prestage && !(first_sub >= 16 && single_pass_st)) {
         nstaged = stage_assign(smem, SM, A, cand, ncand_total);
         xreg = xreg_geom && ncand_total >= kCompactMin && ncand_total <= kCompactMax && ncand_total <= SM.max_cand;
+        // the Gram rows' direct loads FIRST, the cross-Gram pieces behind them: the walk needs the rows, the pieces are needed
+        // after it -- the wait below is for the rows only (vmcnt counts in order), the pieces arrive while wave 0 walks
+        // (waiting for both cost 5.8 k cycles per block: ~190 KB through one CU's memory pipe under the stream's load)
+        const bool split = xreg && stage_load(smem, SM, A, nstaged, tss, 1);
         if (xreg && wave != 0) {
             const short* cl = reinterpret_cast<const short*>(smem + SM.cand_off);
             const int xtask = ncand_total << xsh;
@@ -607,7 +611,9 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
                 xr[k] = *reinterpret_cast<const xr_v4f*>(A.cross_next + ((int64_t)cl[Tc >> xsh] * B + 4 * (Tc & ((1 << xsh) - 1))));
             }
         }
-        stage_load(smem, SM, A, nstaged, tss);
+        static_assert(kXR == kStageYounger, "the number of loads stage_load leaves in flight");
+        if (split) stage_load(smem, SM, A, nstaged, tss, 2, true);
+        else stage_load(smem, SM, A, nstaged, tss);
     }
     // ---- COMPACT CHAIN (see compact_walk): all candidates staged, one lane each
     bool compact_done = false, compact_corr = false;      // compact_corr: ... and the next block's lookahead correction is in corr_cd

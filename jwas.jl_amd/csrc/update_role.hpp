@@ -27,7 +27,9 @@ struct ResidentLink {
     int* ticket;        // this launch's {work ticket, helper claim} counters (quiet sweeps: resident.hpp)
 };
 constexpr long long kResidentUpdateTimeout = 20000000ll;      // wall_clock64 ticks (100 MHz): 200 ms
-template <int NT, class CX, bool COOP = false, bool RES = false>
+// ROLL: the rolling-window apply for 33..64 changes (below) -- only where the kernel's register budget carries it (the
+// instantiation's sampler role decides: single-trait BayesA/B/C; with BayesR's or the multi-trait samplers' it spilled)
+template <int NT, class CX, bool COOP = false, bool RES = false, bool ROLL = false>
 __device__ __forceinline__ void update_role(char* smem, int rg, int g,
                                             const CX& cx,
                                             const float* __restrict__ r_in, float* __restrict__ r_out,
@@ -280,10 +282,44 @@ __device__ __forceinline__ void update_role(char* smem, int rg, int g,
                 }
             }
         };
-        for (int h = 0; h < 64 && e0 + h < ne; h += 32) {
-            const int rem = ne - (e0 + h);                     // >= 1 entries left from here
-            if (rem <= 16) chunk(std::integral_constant<int, 16>{}, h, rem);
-            else chunk(std::integral_constant<int, 32>{}, h, rem);
+        const int rem0 = ne - e0;                              // >= 1 entries of this list chunk (lanes 0 .. min(rem0, 64) - 1)
+        if (rem0 <= 16) chunk(std::integral_constant<int, 16>{}, 0, rem0);
+        else if (rem0 <= 32) chunk(std::integral_constant<int, 32>{}, 0, rem0);
+        else if constexpr (!ROLL) {
+            for (int h = 0; h < 64 && e0 + h < ne; h += 32) {
+                const int rem = ne - (e0 + h);
+                if (rem <= 16) chunk(std::integral_constant<int, 16>{}, h, rem);
+                else chunk(std::integral_constant<int, 32>{}, h, rem);
+            }
+        } else {
+            // 33 .. 64 changes: a ROLLING window of 32 columns -- as soon as a column has been applied its registers take the
+            // column 32 entries further on, so the second half's loads are in flight behind the first half's arithmetic
+            // instead of one more dependent round trip later (fixed pi = 0.95: ~37 changes per 512-marker block)
+            const int rem = rem0 < 64 ? rem0 : 64;
+            float4 x[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) x[u] = cx.load4(__builtin_amdgcn_readlane(liv, u), row);
+#pragma unroll
+            for (int u = 0; u < 32; ++u) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ldv[t]), u));
+                    rv[t].x = fmaf(d, x[u].x, rv[t].x); rv[t].y = fmaf(d, x[u].y, rv[t].y);
+                    rv[t].z = fmaf(d, x[u].z, rv[t].z); rv[t].w = fmaf(d, x[u].w, rv[t].w);
+                }
+                x[u] = cx.load4(__builtin_amdgcn_readlane(liv, 32 + u < rem ? 32 + u : rem - 1), row);
+            }
+#pragma unroll
+            for (int u = 0; u < 32; ++u) {
+                if (32 + u < rem) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ldv[t]), 32 + u));
+                        rv[t].x = fmaf(d, x[u].x, rv[t].x); rv[t].y = fmaf(d, x[u].y, rv[t].y);
+                        rv[t].z = fmaf(d, x[u].z, rv[t].z); rv[t].w = fmaf(d, x[u].w, rv[t].w);
+                    }
+                }
+            }
         }
     }
     if (!applied) { JW_UPD_CLOCK(tu1); tu3 = tu1; }               // (development builds: entry + apply | partial sums)
