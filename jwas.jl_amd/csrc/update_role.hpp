@@ -284,6 +284,10 @@ __device__ __forceinline__ void update_role(char* smem, int rg, int g,
         };
         const int rem0 = ne - e0;                              // >= 1 entries of this list chunk (lanes 0 .. min(rem0, 64) - 1)
         if (rem0 <= 16) chunk(std::integral_constant<int, 16>{}, 0, rem0);
+        else if constexpr (CX::kDepth != 1) {
+            // (2-bit packed storage: the stream keeps 8 batches of bytes in registers -- 16 columns at a time here)
+            for (int h = 0; h < 64 && e0 + h < ne; h += 16) chunk(std::integral_constant<int, 16>{}, h, ne - (e0 + h));
+        }
         else if (rem0 <= 32) chunk(std::integral_constant<int, 32>{}, 0, rem0);
         else if constexpr (!ROLL) {
             for (int h = 0; h < 64 && e0 + h < ne; h += 32) {
