@@ -1835,7 +1835,9 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
     // single pass over <= 128-marker blocks: the dense-walk-only instantiation of the sampler (sampler_role_mt<.., DW>: the same
     // chain, a fraction of the code).  JWAS_HIP_DENSE_MT=0|1 overrides (tests: both instantiations give the same bits).
     const char* edm = std::getenv("JWAS_HIP_DENSE_MT");
-    const bool dense_mt = is_mt_method(c->method) && !is_sampler2(c->method) && c->block_size <= 128 && P->nreps == 1 && !P->independent_blocks &&
+    // ... and full 256-marker blocks of sampler I with one shared covariance (dense_big_mt: decided per launch below)
+    const bool dense_mt256 = c->block_size == 256 && c->method == JWAS_HIP_MTBAYESC1 && !P->log_prior_states_matrix;
+    const bool dense_mt = is_mt_method(c->method) && !is_sampler2(c->method) && (c->block_size <= 128 || dense_mt256) && P->nreps == 1 && !P->independent_blocks &&
                           (edm ? std::atoi(edm) != 0 : c->last_events >= 0.6 * (double)c->p);
     const int dense_big_off = std::getenv("JWAS_HIP_DENSE_BIG_OFF") != nullptr ? 1 : 0;      // (tests: the same chain through the general path)
     const int compact_off = std::getenv("JWAS_HIP_COMPACT_OFF") != nullptr ? std::atoi(std::getenv("JWAS_HIP_COMPACT_OFF")) : 0;          // (tests: the speculative rounds instead of the compact chain)
@@ -1876,7 +1878,7 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
         R.gram = c->gram; R.cross = c->cross; R.corr = c->corr; R.ev = c->ev; R.sync = c->res_sync; R.ncg = c->ncg;
         HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
         HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-        HIPCHK(c, launch_sampler_resident(c->device, c->method, t, dense_big || dense_mt, R, c->stream2));
+        HIPCHK(c, launch_sampler_resident(c->device, c->method, t, dense_big || (dense_mt && c->block_size <= 128), R, c->stream2));
         HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
     }
     for (int64_t k = 0; k <= nb; ++k) {
@@ -1955,7 +1957,13 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
             }
             HIPCHK(c, le);
         } else
-        HIPCHK(c, launch_step_any(c, U, S, sb >= 0, dense_big || dense_mt));
+        {
+            // (256-marker multi-trait blocks: the dense-walk-only instantiation serves FULL blocks; a ragged last one goes through
+            // the general instantiation)
+            bool dmt = dense_mt;
+            if (dmt && c->block_size == 256 && sb >= 0) dmt = !dense_big_off && S.b == 256;
+            HIPCHK(c, launch_step_any(c, U, S, sb >= 0, dense_big || dmt));
+        }
         if (c->row_mode && U.b > 0) {          // the block's partial RHS summed over the ranks' individuals, before its sampler runs
             int rc = row_allreduce(c, U.partials, (size_t)t * c->nrg * bs, true);
             if (rc) return rc;

@@ -588,6 +588,239 @@ __device__ __forceinline__ void mt2_eval(const MtConsts<NT>& K, const double* lp
 // of the front, the prefix skip, row staging and the speculative rounds are compiled out.  Same results as the general
 // instantiation, bit for bit (the walk and the rounds are the same chain); the point is the CODE SIZE: the front is ~3 000
 // cold instructions per launch, fetched at memory latency.
+// ---- DENSE blocks of 256 markers, sampler I with one shared effect covariance (the reference's default multi-trait prior: every
+// marker in the model for every trait).  As dense_big_st: the block chain is a forward substitution; 64-marker SECTION s is
+// walked by wave s from its strictly-upper DIAGONAL Gram tile in LDS exactly as the 128-marker dense walk walks a section --
+// Rule L's linear form speculatively, one full evaluation per lane afterwards that verifies the speculation and yields the
+// final state, the section walked again from its saved rhs with the offending markers evaluated the general way on a miss --
+// and everything off the diagonal runs in parallel: thread c (waves 0..3) owns marker c and its running rhs of every trait
+// in registers, thread 256 + c' (waves 4..7) owns column c' of the NEXT block's lookahead correction, and after section s is
+// done both apply its 64 changes per trait from Gram / cross-Gram values they prefetched into registers while the section was
+// being walked (fmaf in marker order: the sequential chain's own sequence -- bit-identical to the general path).  Half the
+// launches (and fronts) of the 128-marker blocks, and the walking wave updates its own section only.
+// Reference: MTBayesABC.jl:243-333 (block form of _MTBayesABC_samplerI!).
+template <int METHOD, int NT, bool RES>
+__device__ __forceinline__ void dense_big_mt(char* smem, const StepSmem& SM, const SamplerArgs& A, const MtConsts<NT>& K,
+                                             const double* lpr, long long tk0, long long tk1)
+{
+    static_assert(is_sampler1(METHOD) && !has_marker_cov(METHOD), "shared-G sampler I only");
+    constexpr int kB = 256, kSec = kB / 64;
+    static_assert(kStepThreads == 2 * kB, "waves 0..3: markers, waves 4..7: columns of the next block");
+    const int B = SM.B, b = A.b, bn = A.b_next;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t j0 = A.j0, p = A.p;
+    float* rhs_lds = reinterpret_cast<float*>(smem + SM.rhs_off);       // entry rhs; reused as D[t][c] = alpha_old - alpha_new
+    float* acur = reinterpret_cast<float*>(smem + SM.acur_off);
+    const float* astart = reinterpret_cast<const float*>(smem + SM.astart_off);
+    float* bcur = reinterpret_cast<float*>(smem + SM.bcur_off);
+    float* dcur = reinterpret_cast<float*>(smem + SM.dcur_off);
+    const double* lpd = reinterpret_cast<const double*>(smem + SM.prepd_off);
+    const float* lpf = reinterpret_cast<const float*>(smem + SM.prepf_off);
+    const float* tiles = reinterpret_cast<const float*>(smem + SM.rows_off);      // [4][64][64], strictly upper
+    int* wcnt = reinterpret_cast<int*>(smem + SM.wcnt_off);
+    float* delta = reinterpret_cast<float*>(A.delta);
+    const bool rowthr = tid < kB;                       // marker c = tid
+    const bool colthr = !rowthr && (tid - kB) < bn;     // column c' = tid - 256 of the next block
+    const int c = rowthr ? tid : 0;
+    const int cn = colthr ? tid - kB : 0;
+    // the marker's state, draws and constants (parked in LDS by the front)
+    float rhs[NT], a[NT], bb[NT], dd[NT], lc[NT], corr[NT];
+    double thr[NT], z[NT];
+    const float dj = lpf[c];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        rhs[t] = rhs_lds[t * B + c]; a[t] = acur[t * B + c]; bb[t] = bcur[t * B + c]; dd[t] = dcur[t * B + c];
+        thr[t] = lpd[t * B + c]; z[t] = lpd[(NT + t) * B + c]; lc[t] = lpf[(1 + t) * B + c];
+        corr[t] = 0.f;
+    }
+    const MtPre<NT> Q = mt_precompute<METHOD, NT>(K, dj, lc);
+    float an[NT], bnw[NT], dn[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { an[t] = a[t]; bnw[t] = bb[t]; dn[t] = dd[t]; }
+    int nredo = 0;
+    float pq[64];
+    // thread c reads column c of the Gram rows (waves after the section) / column c' of the cross-Gram rows of a section: one
+    // dword per lane, coalesced; the row pointer is uniform
+    auto load_g = [&](int s) {
+        const char* base = reinterpret_cast<const char*>(A.gram + (int64_t)(64 * s) * b);
+        unsigned off = 4u * (unsigned)c;
+#pragma unroll
+        for (int u = 0; u < 64; ++u) { pq[u] = *reinterpret_cast<const float*>(base + off); off += 4u * (unsigned)b; asm volatile("" : "+v"(off)); }
+    };
+    auto load_c = [&](int s) {
+        const char* base = reinterpret_cast<const char*>(A.cross_next + (int64_t)(64 * s) * bn);
+        unsigned off = 4u * (unsigned)cn;
+#pragma unroll
+        for (int u = 0; u < 64; ++u) { pq[u] = *reinterpret_cast<const float*>(base + off); off += 4u * (unsigned)bn; asm volatile("" : "+v"(off)); }
+    };
+    auto prefetch = [&](int s) {
+        if (rowthr && wave > s) load_g(s);
+        else if (colthr) load_c(s);
+    };
+    auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    prefetch(0);
+#pragma unroll 1
+    for (int s = 0; s < kSec; ++s) {
+        if (wave == s) {
+            // ---- walk section s (lane = marker 64 s + lane), diagonal tile s: stride 64
+            const float* tile = tiles + s * 4096;
+            float Al[NT][NT], cl[NT], da[NT], rs[NT], wev[NT];
+            mt1_linear_coeffs<NT>(K, Q, dj, bb, z, Al, cl);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { da[t] = dj * a[t]; rs[t] = rhs[t]; }                       // MTBayesABC.jl:82
+            auto eval_own = [&](const float (&w)[NT], float (&ao)[NT], float (&bo)[NT], float (&d_o)[NT], float (&Dl)[NT]) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) { ao[t] = a[t]; bo[t] = bb[t]; d_o[t] = dd[t]; Dl[t] = 0.f; }
+                mt1_eval<NT>(K, Q, PriorMem{lpr, 1}, w, dj, thr, z, ao, bo, d_o, Dl, Al, cl);
+            };
+            auto bcast = [&](int l, const float (&Dl)[NT], float g) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const float D = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Dl[t]), l));
+                    rhs[t] = fmaf(D, g, rhs[t]);                                // (strictly upper tile: lanes <= l are not moved)
+                }
+            };
+            auto step_fast = [&](int l, float g) {
+                float w[NT], bo[NT], Dl[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) w[t] = rhs[t] + da[t];
+                mt1_linear_beta<NT>(Al, cl, w, bo);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) Dl[t] = a[t] - bo[t];
+                bcast(l, Dl, g);
+            };
+            auto walk_fast = [&]() {
+                float gn[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) gn[u] = tile[u * 64 + lane];
+#pragma unroll 1
+                for (int l = 0; l < 64; l += 8) {
+                    float g[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) g[u] = gn[u];
+                    if (l + 8 < 64) {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) gn[u] = tile[(l + 8 + u) * 64 + lane];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) step_fast(l + u, g[u]);
+                }
+            };
+            auto walk_mixed = [&](unsigned long long slow) {
+                float g = tile[lane];
+#pragma unroll 1
+                for (int l = 0; l < 64; ++l) {
+                    float w[NT], ao[NT], bo[NT], d_o[NT], Dl[NT];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) w[t] = rhs[t] + da[t];
+                    if ((slow >> l) & 1ull) eval_own(w, ao, bo, d_o, Dl);                             // (wave-uniform)
+                    else {
+                        mt1_linear_beta<NT>(Al, cl, w, bo);
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) Dl[t] = a[t] - bo[t];
+                    }
+                    const float gl = g;
+                    g = tile[(l + 1 < 64 ? l + 1 : 63) * 64 + lane];
+                    bcast(l, Dl, gl);
+                }
+            };
+            bool in_all = true;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) in_all = in_all && (dd[t] == 1.f);
+            unsigned long long slow = __ballot(!in_all);
+            if (__popcll(slow) * 4 > 64) slow = ~0ull;
+            if (slow == 0ull) walk_fast(); else walk_mixed(slow);
+            float Dl[NT];
+            for (int pass = 0; pass < 64; ++pass) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) wev[t] = rhs[t] + da[t];                                 // what the lane's marker was evaluated with
+                eval_own(wev, an, bnw, dn, Dl);
+                bool ok = true;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) ok = ok && (dn[t] == 1.f);
+                const unsigned long long bad = __ballot(!ok) & ~slow;
+                if (bad == 0ull) break;
+                slow |= bad;
+                if (__popcll(slow) * 4 > 64) slow = ~0ull;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) rhs[t] = rs[t];
+                walk_mixed(slow);
+                ++nredo;
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                acur[t * B + c] = an[t]; bcur[t * B + c] = bnw[t]; dcur[t * B + c] = dn[t];
+                rhs_lds[t * B + c] = a[t] - an[t];                              // D of this marker, read by everybody after the barrier
+            }
+        }
+        lds_barrier();
+        // the section's changes: fmaf chains in marker order, traits interleaved; 8 broadcast reads per trait and batch
+        const bool do_r = rowthr && wave > s;
+        if (do_r || colthr) {
+#pragma unroll
+            for (int k0 = 0; k0 < 64; k0 += 8) {
+                float dv[NT][8];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const float4 d0 = *reinterpret_cast<const float4*>(rhs_lds + t * B + 64 * s + k0);
+                    const float4 d1 = *reinterpret_cast<const float4*>(rhs_lds + t * B + 64 * s + k0 + 4);
+                    dv[t][0] = d0.x; dv[t][1] = d0.y; dv[t][2] = d0.z; dv[t][3] = d0.w; dv[t][4] = d1.x; dv[t][5] = d1.y; dv[t][6] = d1.z; dv[t][7] = d1.w;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        if (do_r) rhs[t] = fmaf(dv[t][u], pq[k0 + u], rhs[t]);
+                        else corr[t] = fmaf(dv[t][u], pq[k0 + u], corr[t]);
+                    }
+                }
+            }
+        }
+        if (s + 1 < kSec) prefetch(s + 1);
+    }
+    __syncthreads();
+    const long long tk4 = clock64();
+    // the block's change list in marker order
+    bool changed = false;
+    if (rowthr) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) changed = changed || (astart[t * B + c] != acur[t * B + c]);
+    }
+    const unsigned long long cm = __ballot(changed);
+    if (lane == 0) wcnt[wave] = __popcll(cm);
+    __syncthreads();
+    int base = 0, nfin = 0;
+#pragma unroll
+    for (int q = 0; q < kStepThreads / 64; ++q) { const int v = wcnt[q]; base += (q < wave) ? v : 0; nfin += v; }
+    // ---- global stores last
+    if (!rowthr && bn > 0) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) A.corr_out[t * B + (tid - kB)] = colthr ? corr[t] : 0.f;
+    }
+    if (changed) {
+        const int e = base + __popcll(cm & ((1ull << lane) - 1ull));
+        st_coh<RES>(&A.ev_out->idx[e], (int32_t)(j0 + c));
+#pragma unroll
+        for (int t = 0; t < NT; ++t) st_coh<RES>(&A.ev_out->delta[t][e], astart[t * B + c] - acur[t * B + c]);
+    }
+    if (rowthr) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float a_fin = acur[t * B + c];
+            if (a_fin != astart[t * B + c]) A.alpha[(int64_t)t * p + j0 + c] = a_fin;
+            A.beta[(int64_t)t * p + j0 + c] = bcur[t * B + c];
+            delta[(int64_t)t * p + j0 + c] = dcur[t * B + c];
+        }
+    }
+    if (tid == 0) {
+        st_coh<RES>(&A.ev_out->count, (int32_t)nfin);
+        atomicAdd(&A.counters[0], (unsigned long long)nfin);
+        atomicAdd(&A.counters[2], (unsigned long long)(tk1 - tk0));      // front
+        atomicAdd(&A.counters[5], (unsigned long long)(tk4 - tk1));      // sections (walks + off-diagonal applies)
+    }
+    if (lane == 0 && nredo) atomicAdd(&A.counters[7], (unsigned long long)nredo);      // sections walked again
+}
+
 template <int METHOD, int NT, bool DW = false, bool RES = false>       // RES: inside the resident sampler kernel (see sampler_role_st)
 __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A)
 {
@@ -678,6 +911,30 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
     const bool gram_dma = prestage && b == B;              // full block: direct global -> LDS loads (see sampler_role_st)
     const bool cross_dma = gram_dma && SM.has_cross && A.b_next == B;
     if (gram_dma) dma_copy_to_lds(A.gram, reinterpret_cast<float*>(smem + SM.rows_off), B * B);
+    // full 256-marker blocks of sampler I with one shared covariance, single pass: dense_big_mt (diagonal Gram tiles in LDS, the
+    // rest in parallel) when (nearly) every marker changes.  The dense-walk-only instantiation knows that before any load and
+    // fetches the tiles with the launch's first loads (the host selects it for full blocks only); the general instantiation
+    // decides after the candidates have been counted.
+    bool big_try = false;
+    auto fetch_tiles = [&]() {
+        if (wave < 4) {
+            typedef __attribute__((address_space(3))) void lds_void;
+            float* tile = reinterpret_cast<float*>(smem + SM.rows_off) + wave * 4096;
+            const float* src = A.gram + (int64_t)(64 * wave + (lane >> 4)) * b + 64 * wave + (lane & 15) * 4;
+#pragma unroll 1
+            for (int r4 = 0; r4 < 16; ++r4)       // 4 rows of 64 floats per instruction: lane -> row lane / 16, float4 column lane % 16
+                __builtin_amdgcn_global_load_lds(src + (int64_t)(4 * r4) * b, (lds_void*)(tile + r4 * 256), 16, 0, 0);
+        }
+    };
+    auto finish_tiles = [&]() {                            // landed, strictly upper (each wave its own tile), visible to everybody
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (wave < 4) mask_diagonal_tile(reinterpret_cast<float*>(smem + SM.rows_off) + wave * 4096, 64, lane, 64);
+        __syncthreads();
+    };
+    if constexpr (is_sampler1(METHOD) && !kPG) {
+        big_try = (B == 256) && (b == B) && !pm && parked && (P->nreps == 1) && !A.dense_big_off;      // (any next block: its columns are threads 256 .. 256 + b_next - 1)
+        if constexpr (kDW) { if (big_try) fetch_tiles(); }
+    }
     float4 gpre[8];
     if (prestage && !gram_dma) {
         const int per_row = B >> 2, total = b * per_row;
@@ -815,6 +1072,13 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
     bool dense_walk = false;
     if constexpr (kDW) {
         first_sub = 0; ncand_all = b; dense_walk = true;
+        if constexpr (is_sampler1(METHOD) && !kPG) {
+            if (big_try) {
+                finish_tiles();
+                dense_big_mt<METHOD, NT, RES>(smem, SM, A, K, lpr, tk0, clock64());
+                return;
+            }
+        }
         float* rows_m = reinterpret_cast<float*>(smem + SM.rows_off);
         for (int e = tid; e < (B >> 6) * 64 * 16; e += kStepThreads) {     // strictly upper diagonal tiles (see below)
             const int q = e >> 10, l = (e >> 4) & 63, c4 = (e & 15) * 4;
@@ -847,6 +1111,15 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
         // that a lane's running rhs stops moving at its own step -- after the section it still holds the value the lane's
         // marker was evaluated with (no per-step copy of it), and the later steps' updates are exact no-ops on it.  The rows
         // are not read again after the walk (single pass).
+        if constexpr (is_sampler1(METHOD) && !kPG) {
+            // (first_sub == 0: nothing was parked by the prefix skip -- the walk starts from every marker's OLD state)
+            if (big_try && single_pass && first_sub == 0 && 5 * ncand_all >= 3 * b) {
+                fetch_tiles();
+                finish_tiles();
+                dense_big_mt<METHOD, NT, RES>(smem, SM, A, K, lpr, tk0, clock64());
+                return;
+            }
+        }
         dense_walk = !is_sampler2(METHOD) && single_pass && prestage && 5 * ncand_all >= 3 * b;
         if (dense_walk) {
             // one float4 column group per thread and pass: whole groups left of the diagonal with one store

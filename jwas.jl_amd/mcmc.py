@@ -506,7 +506,10 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         # the rest applied in parallel) -- four times fewer launches of the streaming role.
         all_in = (t == 1 and method in ("BayesC", "BayesB") and np.ndim(pi) == 0 and float(pi) == 0.0 and not Mi.estimatePi
                   and getattr(Mi, "annotations", False) is False)
-        block_size = (512 if all_in else 128) if dense else 512
+        # ... and multi-trait BayesC sampler I with one shared covariance and the shared prior table (the reference's default
+        # all-ones prior): 256-marker blocks through dense_big_mt (round 4)
+        mt_big = (t > 1 and not mega and not mt_pervar and mt_method == "MTBayesC" and getattr(Mi, "annotations", False) is False)
+        block_size = (512 if all_in else (256 if mt_big else 128)) if dense else 512
         while block_size > 64 and p <= block_size:
             block_size //= 2
         while mt_pervar and block_size * t > 2048:                      # the markers' own constants are parked in LDS

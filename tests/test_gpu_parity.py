@@ -645,6 +645,7 @@ def test_residual_weights_parity(hip, method, bs, gram):
 
 
 @pytest.mark.parametrize("method,t,bs,zero", [("MTBayesC", 3, 128, False), ("MTBayesC", 2, 64, False), ("MTBayesC_II", 2, 128, False),
+                                              ("MTBayesC", 3, 256, False), ("MTBayesC", 2, 256, True), ("MTBayesC", 4, 256, False),      # (dense_big_mt)
                                               ("MegaBayesC", 3, 64, False), ("MTBayesC", 3, 128, True), ("MTBayesC", 2, 64, True),
                                               ("MTBayesC", 4, 128, True), ("MTBayesC_II", 2, 128, True)])
 def test_multitrait_dense_blocks_parity(hip, method, t, bs, zero):
@@ -831,6 +832,7 @@ def test_row_group_geometry_does_not_change_the_chain(spg, monkeypatch):
 
 
 @pytest.mark.parametrize("method,t,bs,sparse", [("MTBayesC", 3, 128, False), ("MTBayesC", 2, 64, True), ("MegaBayesC", 3, 128, False),
+                                                ("MTBayesC", 3, 256, False), ("MTBayesC", 2, 256, True),      # (256-marker blocks: dense_big_mt)
                                                 ("MTBayesB", 3, 128, False), ("MegaBayesB", 2, 64, True)])
 def test_dense_walk_only_multitrait_instantiation_is_bit_identical(method, t, bs, sparse, monkeypatch):
     """The multi-trait sampler's dense-walk-only instantiation (sampler_role_mt<.., DW>: every block walked marker by marker,
@@ -881,6 +883,48 @@ def test_dense_walk_only_multitrait_instantiation_is_bit_identical(method, t, bs
         assert np.array_equal(results["walk"][1][k], results["general"][1][k])
         np.testing.assert_allclose(results["walk"][0][k][0], results["oracle"][0][k][0], atol=5e-6)
         assert np.array_equal(results["walk"][0][k][2], results["oracle"][0][k][2])
+
+
+@pytest.mark.parametrize("t,mixed", [(3, False), (2, True), (4, False)])
+def test_dense_big_multitrait_blocks_equal_the_general_path(t, mixed, monkeypatch):
+    """Round 4: full 256-marker blocks of sampler I under a dense prior take dense_big_mt (diagonal Gram tiles in LDS, one wave per
+    64-marker section, the rest applied in parallel) -- against the same chain through the general path (JWAS_HIP_DENSE_BIG_OFF)
+    BIT FOR BIT, and against the oracle.  mixed: a third of the markers start outside the model for a trait and the prior gives the
+    other states real mass, so sections are walked with markers evaluated the general way and speculation misses happen."""
+    import jwas_jl_amd as J
+    data = make_dataset(n=900, p=4 * 256, ncausal=12, seed=60 + t)
+    y = data["y"] - data["y"].mean()
+    rng = np.random.default_rng(8)
+    p = data["X"].shape[1]
+    A = rng.standard_normal((t, t))
+    vare = ((A @ A.T / t + np.eye(t)) * 0.5).astype(np.float32)
+    prior = np.full(1 << t, 0.02 if mixed else 1e-9); prior[-1] = 1.0; prior /= prior.sum()
+    kw = dict(vare=vare, var_effect=(np.eye(t) * 0.003).astype(np.float32), log_prior_states=np.log(prior))
+    d0 = np.ones((t, p), dtype=np.float32)
+    if mixed:
+        d0[rng.integers(0, t, p // 3), rng.choice(p, p // 3, replace=False)] = 0.0
+    results = {}
+    for tag in ("oracle", "big", "general"):
+        if tag == "general":
+            monkeypatch.setenv("JWAS_HIP_DENSE_BIG_OFF", "1")
+        e = OracleEngine("lookahead") if tag == "oracle" else J.HipEngine(0)
+        try:
+            e.load_dense(data["X"]); e.setup_blocks(256, "f64"); e.init_state("MTBayesC", t)
+            for k in range(t):
+                e.set_residual(((1 + 0.25 * k) * y).astype(np.float32), k)
+                e.set_state(k, delta=d0[k])
+            ev = [e.sweep(iteration=it, seed=23, **kw)["n_events"] for it in range(1, 10)]
+            results[tag] = ([e.get_state(k) for k in range(t)], [e.get_residual(k) for k in range(t)], ev)
+        finally:
+            if tag != "oracle":
+                e.close()
+    assert results["big"][2] == results["general"][2] == results["oracle"][2]
+    for k in range(t):
+        for q in range(3):
+            assert np.array_equal(results["big"][0][k][q], results["general"][0][k][q])
+        assert np.array_equal(results["big"][1][k], results["general"][1][k])
+        np.testing.assert_allclose(results["big"][0][k][0], results["oracle"][0][k][0], atol=5e-6)
+        assert np.array_equal(results["big"][0][k][2], results["oracle"][0][k][2])
 
 
 @pytest.mark.parametrize("method,t,bs,pi", [("BayesC", 1, 128, 0.0), ("BayesC", 1, 256, 0.5), ("MTBayesC", 3, 128, None), ("BayesR", 1, 64, None)])
