@@ -212,7 +212,7 @@ def main():
     # (single-trait priors that include every marker whatever its rhs -- refbench's Pi = 0 -- run 512-marker blocks through
     # the sampler's dense_big_st path; the multi-trait default prior keeps 128)
     all_in = refbench or (t == 1 and bayesc and a.pi_fixed == 0.0)
-    mt_big = mt_dense and a.mt_method == "BayesC"       # (sampler I, one shared covariance: 256-marker blocks through dense_big_mt)
+    mt_big = mt_dense                                   # (sampler I, shared or per-marker covariance: 256-marker blocks through dense_big_mt)
     bs = a.block_size or ((512 if all_in else (256 if mt_big else 128)) if dense_prior else 512)
     rows_mode = a.shard == "rows"
     if rows_mode and (weak or a.storage != "dense"):

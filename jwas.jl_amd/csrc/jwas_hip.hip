@@ -1836,7 +1836,7 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
     // chain, a fraction of the code).  JWAS_HIP_DENSE_MT=0|1 overrides (tests: both instantiations give the same bits).
     const char* edm = std::getenv("JWAS_HIP_DENSE_MT");
     // ... and full 256-marker blocks of sampler I with one shared covariance (dense_big_mt: decided per launch below)
-    const bool dense_mt256 = c->block_size == 256 && c->method == JWAS_HIP_MTBAYESC1 && !P->log_prior_states_matrix;
+    const bool dense_mt256 = c->block_size == 256 && (c->method == JWAS_HIP_MTBAYESC1 || c->method == JWAS_HIP_MTBAYESB1) && !P->log_prior_states_matrix;
     const bool dense_mt = is_mt_method(c->method) && !is_sampler2(c->method) && (c->block_size <= 128 || dense_mt256) && P->nreps == 1 && !P->independent_blocks &&
                           (edm ? std::atoi(edm) != 0 : c->last_events >= 0.6 * (double)c->p);
     const int dense_big_off = std::getenv("JWAS_HIP_DENSE_BIG_OFF") != nullptr ? 1 : 0;      // (tests: the same chain through the general path)

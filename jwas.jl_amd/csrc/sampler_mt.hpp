@@ -588,8 +588,8 @@ __device__ __forceinline__ void mt2_eval(const MtConsts<NT>& K, const double* lp
 // of the front, the prefix skip, row staging and the speculative rounds are compiled out.  Same results as the general
 // instantiation, bit for bit (the walk and the rounds are the same chain); the point is the CODE SIZE: the front is ~3 000
 // cold instructions per launch, fetched at memory latency.
-// ---- DENSE blocks of 256 markers, sampler I with one shared effect covariance (the reference's default multi-trait prior: every
-// marker in the model for every trait).  As dense_big_st: the block chain is a forward substitution; 64-marker SECTION s is
+// ---- DENSE blocks of 256 markers, sampler I (one shared effect covariance, or one per marker: multi-trait BayesA/B) under a
+// prior that keeps (nearly) every marker in the model for every trait -- the reference's default multi-trait prior.  As dense_big_st: the block chain is a forward substitution; 64-marker SECTION s is
 // walked by wave s from its strictly-upper DIAGONAL Gram tile in LDS exactly as the 128-marker dense walk walks a section --
 // Rule L's linear form speculatively, one full evaluation per lane afterwards that verifies the speculation and yields the
 // final state, the section walked again from its saved rhs with the offending markers evaluated the general way on a miss --
@@ -603,7 +603,7 @@ template <int METHOD, int NT, bool RES>
 __device__ __forceinline__ void dense_big_mt(char* smem, const StepSmem& SM, const SamplerArgs& A, const MtConsts<NT>& K,
                                              const double* lpr, long long tk0, long long tk1)
 {
-    static_assert(is_sampler1(METHOD) && !has_marker_cov(METHOD), "shared-G sampler I only");
+    static_assert(is_sampler1(METHOD), "sampler I (K: the constants of THIS thread's marker -- the shared ones, or the marker's own under multi-trait BayesA/B)");
     constexpr int kB = 256, kSec = kB / 64;
     static_assert(kStepThreads == 2 * kB, "waves 0..3: markers, waves 4..7: columns of the next block");
     const int B = SM.B, b = A.b, bn = A.b_next;
@@ -931,7 +931,7 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
         if (wave < 4) mask_diagonal_tile(reinterpret_cast<float*>(smem + SM.rows_off) + wave * 4096, 64, lane, 64);
         __syncthreads();
     };
-    if constexpr (is_sampler1(METHOD) && !kPG) {
+    if constexpr (is_sampler1(METHOD)) {
         big_try = (B == 256) && (b == B) && !pm && parked && (P->nreps == 1) && !A.dense_big_off;      // (any next block: its columns are threads 256 .. 256 + b_next - 1)
         if constexpr (kDW) { if (big_try) fetch_tiles(); }
     }
@@ -1072,10 +1072,10 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
     bool dense_walk = false;
     if constexpr (kDW) {
         first_sub = 0; ncand_all = b; dense_walk = true;
-        if constexpr (is_sampler1(METHOD) && !kPG) {
+        if constexpr (is_sampler1(METHOD)) {
             if (big_try) {
                 finish_tiles();
-                dense_big_mt<METHOD, NT, RES>(smem, SM, A, K, lpr, tk0, clock64());
+                dense_big_mt<METHOD, NT, RES>(smem, SM, A, consts_of(tid < 256 ? tid : 0), lpr, tk0, clock64());
                 return;
             }
         }
@@ -1111,12 +1111,12 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
         // that a lane's running rhs stops moving at its own step -- after the section it still holds the value the lane's
         // marker was evaluated with (no per-step copy of it), and the later steps' updates are exact no-ops on it.  The rows
         // are not read again after the walk (single pass).
-        if constexpr (is_sampler1(METHOD) && !kPG) {
+        if constexpr (is_sampler1(METHOD)) {
             // (first_sub == 0: nothing was parked by the prefix skip -- the walk starts from every marker's OLD state)
             if (big_try && single_pass && first_sub == 0 && 5 * ncand_all >= 3 * b) {
                 fetch_tiles();
                 finish_tiles();
-                dense_big_mt<METHOD, NT, RES>(smem, SM, A, K, lpr, tk0, clock64());
+                dense_big_mt<METHOD, NT, RES>(smem, SM, A, consts_of(tid < 256 ? tid : 0), lpr, tk0, clock64());
                 return;
             }
         }

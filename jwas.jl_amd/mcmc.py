@@ -508,7 +508,7 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
                   and getattr(Mi, "annotations", False) is False)
         # ... and multi-trait BayesC sampler I with one shared covariance and the shared prior table (the reference's default
         # all-ones prior): 256-marker blocks through dense_big_mt (round 4)
-        mt_big = (t > 1 and not mega and not mt_pervar and mt_method == "MTBayesC" and getattr(Mi, "annotations", False) is False)
+        mt_big = (t > 1 and not mega and mt_method in ("MTBayesC", "MTBayesB") and getattr(Mi, "annotations", False) is False)
         block_size = (512 if all_in else (256 if mt_big else 128)) if dense else 512
         while block_size > 64 and p <= block_size:
             block_size //= 2

@@ -978,7 +978,8 @@ def test_cooperative_dense_apply_is_bit_identical(method, t, bs, pi, monkeypatch
 
 @pytest.mark.parametrize("method", ["MTBayesB", "MTBayesB_II"])
 @pytest.mark.parametrize("t,bs,dense,nreps", [(2, 64, False, 1), (3, 128, False, 1), (3, 512, False, 1), (4, 256, False, 1),
-                                              (3, 128, True, 1), (2, 64, True, 1), (3, 64, False, 3)])
+                                              (3, 128, True, 1), (2, 64, True, 1), (3, 64, False, 3),
+                                              (3, 256, True, 1), (2, 256, True, 1)])      # (dense 256-marker blocks: dense_big_mt with the markers' own constants)
 def test_mt_bayesb_per_marker_covariance_parity(hip, t, bs, dense, nreps, method):
     """Multi-trait BayesA/B: Gibbs sampler I (MTBayesABC.jl:66,86-90) or the joint-state sampler II (MTBayesABC.jl:129-210)
     with ONE t x t effect covariance PER MARKER (Ginv = inv.(varEffects)).  The device inverts every marker's matrix in k_prepare (the host's Gauss-Jordan, operation for
