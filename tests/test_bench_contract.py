@@ -59,3 +59,20 @@ def test_bench_row_shards_single_rank_equals_the_plain_chain():
         outs.append(json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]))
     assert outs[0]["config"]["markers_in_model"] == outs[1]["config"]["markers_in_model"]
     assert outs[0]["config"]["events_per_sweep"] == outs[1]["config"]["events_per_sweep"]
+
+
+@pytest.mark.gpu
+def test_bench_one_rank_communicator_runs_the_library_sharded_path():
+    """--one-rank-comm (round 4: what one rank of an N-GPU job executes per iteration, profiles/r04_rank_share.json): the sweep goes
+    through jwas_hip_sweep_sharded on a ONE-rank RCCL communicator -- snapshot, pack kernel, ncclAllReduce, apply kernel -- and
+    yields the plain run's chain (a one-term sum changes nothing)."""
+    import json
+    outs = []
+    for extra in ([], ["--one-rank-comm"]):
+        r = _run(["--steps", "3", "--warmup", "3", "--burnin", "0", "--n", "3000", "--p", "8192", "--no-cpu-baseline", "--via-api", "0"] + extra, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs.append(json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')][-1]))
+    assert outs[1]["config"]["sharded_path"] is True and outs[0]["config"]["sharded_path"] is False
+    assert outs[0]["config"]["markers_in_model"] == outs[1]["config"]["markers_in_model"]
+    assert outs[0]["config"]["events_per_sweep"] == outs[1]["config"]["events_per_sweep"]
+    assert "host_ms_per_step" in outs[1]["config"]
