@@ -1749,15 +1749,6 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
         NEED(c, inv_small(P->vare, t, D.Rinv) == 0, JWAS_HIP_EINVAL, "residual covariance matrix is singular");
         if (!marker_cov)
             NEED(c, inv_small(P->var_effect, t, D.Ginv) == 0, JWAS_HIP_EINVAL, "marker effect covariance matrix is singular");
-        // the per-trait constants of the shared covariance, once per sweep instead of once per thread and block (three double
-        // logarithms in every sampler front); the same operations the device did: float division, log in double rounded to float,
-        // float sqrt
-        for (int a = 0; a < t; ++a) {
-            const float g = D.Ginv[a * t + a];
-            D.mt_invG[a] = 1.0f / g;
-            D.mt_lG[a] = (float)std::log((double)g);
-            D.mt_sG[a] = std::sqrt(D.mt_invG[a]);
-        }
         bool any_finite = false;
         for (int i = 0; i < (1 << t); ++i) { D.log_prior[i] = P->log_prior_states[i]; any_finite = any_finite || std::isfinite(D.log_prior[i]); }
         if ((c->method == JWAS_HIP_MTBAYESC2 || c->method == JWAS_HIP_MTBAYESB2) && !P->log_prior_states_matrix)      // MTBayesABC.jl:190

@@ -68,7 +68,6 @@ struct DevParams {
     uint32_t iter, seed_lo, seed_hi, marker0, pad0;
     float    vare[16], var_effect[16];
     float    Rinv[16], Ginv[16];            // t x t inverses (host: double Gauss-Jordan -> float)
-    float    mt_invG[4], mt_lG[4], mt_sG[4]; // sampler I with one shared covariance: 1/Ginv_kk, log Ginv_kk, sqrt(1/Ginv_kk) (host; MTBayesABC.jl:92)
     double   pi;
     double   pi4[4], gamma[4];
     double   log_prior[kMaxStates];

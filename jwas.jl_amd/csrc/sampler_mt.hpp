@@ -852,11 +852,9 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
     for (int a = 0; a < NT; ++a) {
 #pragma unroll
         for (int c = 0; c < NT; ++c) { K.Rinv[a][c] = P->Rinv[a * NT + c]; K.Ginv[a][c] = P->Ginv[a * NT + c]; }
-        if constexpr (is_mega(METHOD) || kPG) {
-            K.invG[a] = 1.0f / K.Ginv[a][a];                        // MTBayesABC.jl:92
-            K.lG[a] = logf_via_double(K.Ginv[a][a]);
-            K.sG[a] = sqrtf(K.invG[a]);
-        } else { K.invG[a] = P->mt_invG[a]; K.lG[a] = P->mt_lG[a]; K.sG[a] = P->mt_sG[a]; }      // (formed once per sweep by the host)
+        K.invG[a] = 1.0f / K.Ginv[a][a];                            // MTBayesABC.jl:92
+        K.lG[a] = logf_via_double(K.Ginv[a][a]);
+        K.sG[a] = sqrtf(K.invG[a]);
         if constexpr (is_mega(METHOD)) {
             K.ie[a]  = 1.0f / P->vare[a * NT + a];                  // invVarRes          BayesABC.jl:69
             K.var[a] = P->var_effect[a * NT + a];
