@@ -3,7 +3,7 @@
 #include "../../include/jwas_hip.h"
 #include "sweep.hpp"
 #include "f64_path.hpp"
-#include "resident_api.hpp"
+#include "step_launch.hpp"
 
 #include <hip/hip_runtime.h>
 #include <cmath>
@@ -107,17 +107,6 @@ struct jwas_hip_ctx {
     bool row_mode = false;
     int loop_slot = -1;                 // >= 0: loopback transport (ranks = contexts of one process on different host threads)
     double* row_buf = nullptr;          // [32] small exchanges
-    // resident-sampler sweeps (csrc/resident.hpp): the sampler kernel's stream, fork / join events, the synchronisation block,
-    // and the snapshot (alpha, beta, delta, r) the sweep is re-run from if a bounded wait gave up
-    hipStream_t stream2 = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    int* res_sync = nullptr;            // [kResArrive + res_sync_blocks + 1]
-    int64_t res_sync_blocks = 0;
-    float* res_snap = nullptr;          // [3][t][p] + [kMaxT][ld]
-    size_t res_snap_floats = 0;
-    bool resident_active = false;       // the sweep that is being collected ran with the resident sampler
-    bool resident_off = false;          // a resident sweep gave up once: this context stays on the launch-per-block path
-    int resident_aborts = 0;
     // Float64 mode (runMCMC(double_precision=true); csrc/f64_path.hpp): its own storage / state, created by jwas_hip_set_precision
     struct F64 {
         double* X = nullptr;                // [p][ld]
@@ -295,10 +284,6 @@ void jwas_hip_destroy(jwas_hip_ctx* c)
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
     for (hipEvent_t e : c->kev) (void)hipEventDestroy(e);
-    if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
-    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-    (void)hipFree(c->res_sync); (void)hipFree(c->res_snap);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1272,94 +1257,28 @@ int jwas_hip_window_sums2(jwas_hip_ctx* c, int32_t use_output_rows, int32_t nwin
 }  // extern "C" (templates need C++ linkage)
 
 // ---- the sweep --------------------------------------------------------------------------------------
-template <int METHOD, int NT, class CX>
-static hipError_t launch_step_cx(jwas_hip_ctx* c, const CX& cx, const UpdateArgs& U0, const SamplerArgs& S, int do_sample, bool dense)
+// The step kernel's instantiations live in one translation unit per sampler family (step_launch.hpp).
+static StepLaunch step_launch_of(const jwas_hip_ctx* c)
 {
-    UpdateArgsT<CX> U;
-    static_cast<UpdateArgs&>(U) = U0;
-    U.cx = cx;
-    // DENSE instantiations: single-trait sweeps under a uniform pi = 0 (Rule D), and the multi-trait samplers' dense-walk-only form
-    constexpr bool kHasDense = ((METHOD == kBayesC || METHOD == kBayesB) && NT == 1) || (is_mt_method(METHOD) && !is_sampler2(METHOD));
-    const bool dn = kHasDense && dense;
-    const StepSmem SM(c->block_size, NT, is_mt_method(METHOD) ? mt_park_nd(c->block_size, NT) + (S.lpr_mat ? (1 << NT) : 0) : st_park_nd(METHOD), is_mt_method(METHOD) ? mt_park_nf(c->block_size, NT) + (has_marker_cov(METHOD) ? NT * NT : 0) : st_park_nf(METHOD, dn));
-    static std::atomic<unsigned long long> attr_set{0ull};       // one bit per device: the attribute belongs to the device's code object
-    const unsigned long long dev_bit = 1ull << (c->device & 63);
-    if (!(attr_set.load(std::memory_order_acquire) & dev_bit)) {   // allow > 64 KB of dynamic LDS
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_block_step<METHOD, NT, CX, false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        if constexpr (CX::kCoopApply) {
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_block_step<METHOD, NT, CX, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return e;
-        }
-        if constexpr (kHasDense) {
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_block_step<METHOD, NT, CX, false, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return e;
-            if constexpr (CX::kCoopApply) {
-                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_block_step<METHOD, NT, CX, true, true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                if (e != hipSuccess) return e;
-            }
-        }
-        attr_set.fetch_or(dev_bit, std::memory_order_release);
-    }
-    // JWAS_HIP_DEBUG_ROLE (timing experiments only; results are wrong): 1 = update role only, 2 = sampler only
-    // Development builds only (build.sh -DJWAS_HIP_DEV_KNOBS): the shipped library never reads these -- they break results.
-#ifdef JWAS_HIP_DEV_KNOBS
-    static const int dbg = std::getenv("JWAS_HIP_DEBUG_ROLE") ? std::atoi(std::getenv("JWAS_HIP_DEBUG_ROLE")) : 0;
-#else
-    constexpr int dbg = 0;
-#endif
-    const int nwork = c->nrg * U.ncg;
-    const unsigned grid = (dbg == 2) ? 1u : (U.quiet_xcd ? (unsigned)(1 + (nwork + 6) / 7 * 8) : (unsigned)(1 + nwork));
-    const int ds = (dbg == 1) ? 0 : do_sample;
-    if constexpr (kHasDense) {
-        if (dn) {       // uniform pi = 0: the sampler that follows Rule D (and takes dense_big_st on full 256- / 512-marker blocks)
-            if constexpr (CX::kCoopApply) {
-                if (U.sync_now != nullptr) {
-                    hipLaunchKernelGGL((k_block_step<METHOD, NT, CX, true, true>), dim3(grid), dim3(kStepThreads), SM.bytes, c->stream, U, S, ds);
-                    return hipSuccess;
-                }
-            }
-            hipLaunchKernelGGL((k_block_step<METHOD, NT, CX, false, true>), dim3(grid), dim3(kStepThreads), SM.bytes, c->stream, U, S, ds);
-            return hipSuccess;
-        }
-    }
-    if constexpr (CX::kCoopApply) {
-        if (U.sync_now != nullptr) {     // dense sweep: the instantiation whose update role shares the apply work
-            hipLaunchKernelGGL((k_block_step<METHOD, NT, CX, true>), dim3(grid), dim3(kStepThreads), SM.bytes, c->stream, U, S, ds);
-            return hipSuccess;
-        }
-    }
-    hipLaunchKernelGGL((k_block_step<METHOD, NT, CX, false>), dim3(grid), dim3(kStepThreads), SM.bytes, c->stream, U, S, ds);
-    return hipSuccess;
-}
-
-template <int METHOD, int NT>
-static hipError_t launch_step(jwas_hip_ctx* c, const UpdateArgs& U, const SamplerArgs& S, int do_sample, bool dense = false)
-{
-    return with_cols(c, 0, [&](auto cx) { return launch_step_cx<METHOD, NT, decltype(cx)>(c, cx, U, S, do_sample, dense); });
+    StepLaunch L;
+    L.device = c->device; L.block_size = c->block_size; L.nrg = c->nrg;
+    L.nblocks = c->nblocks; L.p = c->p; L.stream = c->stream;
+    L.d_starts = (const int64_t*)c->d_starts; L.ev_all = c->ev_all;
+    L.packed = c->packed;
+    L.dc = DenseCols{c->X, c->ld, c->w, (int32_t)c->weighted};
+    L.pc = PackedCols{c->Q, c->ld, c->qmean, c->n, c->centered, c->w, (int32_t)c->weighted};
+    return L;
 }
 
 static hipError_t launch_step_any(jwas_hip_ctx* c, const UpdateArgs& U, const SamplerArgs& S, int do_sample, bool dense)
 {
+    const StepLaunch L = step_launch_of(c);
     switch (c->method) {
-        case JWAS_HIP_BAYESC: return launch_step<kBayesC, 1>(c, U, S, do_sample, dense);
-        case JWAS_HIP_BAYESB: return launch_step<kBayesB, 1>(c, U, S, do_sample, dense);
-        case JWAS_HIP_BAYESR: return launch_step<kBayesR, 1>(c, U, S, do_sample);
-#define JW_MT_STEP(M)                                                            \
-            if (c->ntraits == 2) return launch_step<M, 2>(c, U, S, do_sample, dense);       \
-            if (c->ntraits == 3) return launch_step<M, 3>(c, U, S, do_sample, dense);       \
-            return launch_step<M, 4>(c, U, S, do_sample, dense);
-        case JWAS_HIP_MTBAYESC2: JW_MT_STEP(kMTBayesC2)
-        case JWAS_HIP_MEGABAYESC: JW_MT_STEP(kMegaBayesC)
-        case JWAS_HIP_MTBAYESB1: JW_MT_STEP(kMTBayesB1)
-        case JWAS_HIP_MTBAYESB2: JW_MT_STEP(kMTBayesB2)
-        case JWAS_HIP_MEGABAYESB: JW_MT_STEP(kMegaBayesB)
-        default: JW_MT_STEP(kMTBayesC1)
-#undef JW_MT_STEP
+        case JWAS_HIP_BAYESC: case JWAS_HIP_BAYESB: case JWAS_HIP_BAYESR: return launch_step_st(L, c->method, U, S, do_sample, dense);
+        case JWAS_HIP_MTBAYESC2: case JWAS_HIP_MTBAYESB2: return launch_step_mt2(L, c->method, c->ntraits, U, S, do_sample, dense);
+        case JWAS_HIP_MEGABAYESC: case JWAS_HIP_MEGABAYESB: return launch_step_mega(L, c->method, c->ntraits, U, S, do_sample, dense);
+        case JWAS_HIP_MTBAYESB1: return launch_step_mtb1(L, c->ntraits, U, S, do_sample, dense);
+        default: return launch_step_mtc1(L, c->ntraits, U, S, do_sample, dense);
     }
 }
 
@@ -1373,48 +1292,6 @@ static int upload_vec(jwas_hip_ctx* c, void** dev, const void* host, size_t byte
 // Independent-block sweep (BayesABC_block_independent!, BayesABC.jl:190-255): all block RHS from the residual
 // snapshot (one pass over X), all blocks sampled concurrently, change lists compacted in (block, marker) order;
 // the caller's k_finish applies them to the residual.
-template <int METHOD, int NT, class CX>
-static hipError_t launch_indep_cx(jwas_hip_ctx* c, const CX& cx, const UpdateArgs& U0, const SamplerArgs& S, int64_t pstride, bool dense)
-{
-    UpdateArgsT<CX> U;
-    static_cast<UpdateArgs&>(U) = U0;
-    U.cx = cx;
-    constexpr bool kHasDense = (METHOD == kBayesC || METHOD == kBayesB) && NT == 1;       // sweeps under a uniform pi = 0 (Rule D)
-    const bool dn = kHasDense && dense;
-    const StepSmem SM(c->block_size, NT, is_mt_method(METHOD) ? mt_park_nd(c->block_size, NT) + (S.lpr_mat ? (1 << NT) : 0) : st_park_nd(METHOD), is_mt_method(METHOD) ? mt_park_nf(c->block_size, NT) + (has_marker_cov(METHOD) ? NT * NT : 0) : st_park_nf(METHOD, dn));
-    static std::atomic<unsigned long long> attr_set{0ull};       // one bit per device
-    const unsigned long long dev_bit = 1ull << (c->device & 63);
-    if (!(attr_set.load(std::memory_order_acquire) & dev_bit)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_indep_sample<METHOD, NT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        if constexpr (kHasDense) {
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_indep_sample<METHOD, NT, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return e;
-        }
-        attr_set.fetch_or(dev_bit, std::memory_order_release);
-    }
-    const size_t red = sizeof(double) * kRowGroupSlices * kColChunk * NT;
-    hipLaunchKernelGGL((k_indep_rhs<NT, CX>), dim3((unsigned)(U.nrg * U.ncg), (unsigned)c->nblocks), dim3(kStepThreads), red, c->stream,
-                       U, c->p, c->block_size, pstride, (const int64_t*)c->d_starts);
-    if constexpr (kHasDense) {
-        if (dn) {
-            hipLaunchKernelGGL((k_indep_sample<METHOD, NT, true>), dim3((unsigned)c->nblocks), dim3(kStepThreads), SM.bytes, c->stream, S, pstride, c->ev_all, (const int64_t*)c->d_starts);
-            return hipGetLastError();
-        }
-    }
-    hipLaunchKernelGGL((k_indep_sample<METHOD, NT>), dim3((unsigned)c->nblocks), dim3(kStepThreads), SM.bytes, c->stream,
-                       S, pstride, c->ev_all, (const int64_t*)c->d_starts);
-    return hipGetLastError();
-}
-
-template <int METHOD, int NT>
-static hipError_t launch_indep(jwas_hip_ctx* c, const UpdateArgs& U, const SamplerArgs& S, int64_t pstride, bool dense = false)
-{
-    return with_cols(c, 0, [&](auto cx) { return launch_indep_cx<METHOD, NT, decltype(cx)>(c, cx, U, S, pstride, dense); });
-}
-
 static int sweep_independent(jwas_hip_ctx* c, EventList* out, bool dense, int dense_big_off, int compact_off)
 {
     const int t = c->ntraits, bs = c->block_size;
@@ -1451,19 +1328,12 @@ static int sweep_independent(jwas_hip_ctx* c, EventList* out, bool dense, int de
     S.dense_big_off = dense_big_off;
     S.compact_off = compact_off;
     hipError_t e;
+    const StepLaunch L = step_launch_of(c);
     switch (c->method) {
-        case JWAS_HIP_BAYESC: e = launch_indep<kBayesC, 1>(c, U, S, pstride, dense); break;
-        case JWAS_HIP_BAYESB: e = launch_indep<kBayesB, 1>(c, U, S, pstride, dense); break;
-        case JWAS_HIP_BAYESR: e = launch_indep<kBayesR, 1>(c, U, S, pstride); break;
-#define JW_MT_IND(M)                                                              \
-            if (t == 2) e = launch_indep<M, 2>(c, U, S, pstride);                 \
-            else if (t == 3) e = launch_indep<M, 3>(c, U, S, pstride);            \
-            else e = launch_indep<M, 4>(c, U, S, pstride);                        \
-            break;
-        case JWAS_HIP_MTBAYESC2: JW_MT_IND(kMTBayesC2)
-        case JWAS_HIP_MEGABAYESC: JW_MT_IND(kMegaBayesC)
-        default: JW_MT_IND(kMTBayesC1)
-#undef JW_MT_IND
+        case JWAS_HIP_BAYESC: case JWAS_HIP_BAYESB: case JWAS_HIP_BAYESR: e = launch_indep_st(L, c->method, U, S, pstride, dense); break;
+        case JWAS_HIP_MTBAYESC2: e = launch_indep_mt2(L, t, U, S, pstride); break;
+        case JWAS_HIP_MEGABAYESC: e = launch_indep_mega(L, t, U, S, pstride); break;
+        default: e = launch_indep_mtc1(L, t, U, S, pstride);
     }
     HIPCHK(c, e);
     hipLaunchKernelGGL(k_indep_scan, dim3(1), dim3(1024), 0, c->stream, c->ev_all, (int)nb, c->ev_offs, c->ev_offs + nb);
@@ -1664,56 +1534,6 @@ int jwas_hip_set_kernel_timing(jwas_hip_ctx* c, int32_t stride)
 }  // extern "C"
 
 // Everything of a sweep up to the marker statistics, enqueued on the context's stream (no host synchronisation).
-// Resident-sampler sweeps (csrc/resident.hpp) are OPT-IN: JWAS_HIP_RESIDENT=1 (read once per sweep: the tests switch it
-// between sweeps of one process).  Measured on every bench workload (profiles/r04_resident_ab.txt) the
-// mode is correct and bit-identical but never faster than the launch-per-block sweep, so nothing selects it by default.
-static bool resident_wanted(jwas_hip_ctx* c, const jwas_sweep_params* P, bool dense_big, bool dense_mt)
-{
-    (void)dense_big; (void)dense_mt;
-    if (c->resident_off || c->row_mode || P->independent_blocks || c->nblocks < 3) return false;
-    if (!resident_supported(c->method, c->ntraits)) return false;
-    const char* e = std::getenv("JWAS_HIP_RESIDENT");
-    return e != nullptr && std::atoi(e) != 0;
-}
-
-// Allocations of the resident mode (first use / after a change of geometry).
-static int resident_prepare(jwas_hip_ctx* c)
-{
-    const int t = c->ntraits;
-    if (!c->stream2) HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-    if (!c->ev_fork) HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-    if (!c->ev_join) HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-    if (!c->res_sync || c->res_sync_blocks < c->nblocks) {
-        (void)hipFree(c->res_sync); c->res_sync = nullptr;
-        HIPCHK(c, hipMalloc(&c->res_sync, sizeof(int) * (size_t)(kResArrive + 4 * (c->nblocks + 1))));
-        c->res_sync_blocks = c->nblocks;
-    }
-    const size_t need = (size_t)3 * t * c->p + (size_t)kMaxT * c->ld;
-    if (!c->res_snap || c->res_snap_floats < need) {
-        (void)hipFree(c->res_snap); c->res_snap = nullptr;
-        HIPCHK(c, hipMalloc(&c->res_snap, sizeof(float) * need));
-        c->res_snap_floats = need;
-    }
-    return JWAS_HIP_OK;
-}
-
-// delta is int32 classes (BayesR) or float indicators: four bytes per marker and trait either way
-static int resident_snapshot(jwas_hip_ctx* c, bool restore)
-{
-    const int t = c->ntraits;
-    const size_t tp = (size_t)t * c->p;
-    float* sa = c->res_snap; float* sb = sa + tp; float* sd = sb + tp; float* sr = sd + tp;
-    auto cp = [&](void* live, void* snap, size_t bytes) {
-        return restore ? hipMemcpyAsync(live, snap, bytes, hipMemcpyDeviceToDevice, c->stream)
-                       : hipMemcpyAsync(snap, live, bytes, hipMemcpyDeviceToDevice, c->stream);
-    };
-    HIPCHK(c, cp(c->alpha, sa, sizeof(float) * tp));
-    HIPCHK(c, cp(c->beta, sb, sizeof(float) * tp));
-    HIPCHK(c, cp(c->delta, sd, sizeof(float) * tp));
-    HIPCHK(c, cp(c->r, sr, sizeof(float) * (size_t)t * c->ld));
-    return JWAS_HIP_OK;
-}
-
 static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* ntimed_out, double* timed_bytes_out)
 {
     NEED(c, c && P, JWAS_HIP_EINVAL, "NULL argument");
@@ -1841,13 +1661,6 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
                           (edm ? std::atoi(edm) != 0 : c->last_events >= 0.6 * (double)c->p);
     const int dense_big_off = std::getenv("JWAS_HIP_DENSE_BIG_OFF") != nullptr ? 1 : 0;      // (tests: the same chain through the general path)
     const int compact_off = std::getenv("JWAS_HIP_COMPACT_OFF") != nullptr ? std::atoi(std::getenv("JWAS_HIP_COMPACT_OFF")) : 0;          // (tests: the speculative rounds instead of the compact chain)
-    const bool resident = resident_wanted(c, P, dense_big, dense_mt);
-    c->resident_active = resident;
-    if (resident) {
-        int rc = resident_prepare(c); if (rc) return rc;
-        rc = resident_snapshot(c, false); if (rc) return rc;
-        HIPCHK(c, hipMemsetAsync(c->res_sync, 0, sizeof(int) * (size_t)(kResArrive + 4 * (nb + 1)), c->stream));
-    }
     if (independent) {
         int rc = sweep_independent(c, &ev_list, dense_big, dense_big_off, compact_off);
         if (rc) return rc;
@@ -1863,24 +1676,6 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
     const char* efc = std::getenv("JWAS_HIP_COOP_APPLY");
     const int fc = efc ? std::atoi(efc) : -1;
     const bool coop = c->sync_cnt != nullptr && (fc >= 0 ? fc != 0 : (dense_big || c->last_events > 0.25 * (double)c->p));
-    if (resident) {
-        // ---- the sampler kernel of the whole sweep, on its own stream behind everything enqueued so far
-        ResidentArgs R;
-        std::memset(&R, 0, sizeof R);
-        R.S.P = c->dparams; R.S.nrg = c->nrg; R.S.bstride = bs; R.S.p = c->p; R.S.bsz = bs; R.S.xpx = c->xpx;
-        R.S.dense_big_off = dense_big_off;
-        R.S.compact_off = compact_off;
-        R.S.prep_d = c->prep_d; R.S.prep_f = c->prep_f; R.S.mt2_tab = c->mt2_tab; R.S.lpr_mat = c->lpr_active ? c->lpr_mat : nullptr;
-        R.S.ginv_mat = has_marker_cov(c->method) ? c->ginv_mat : nullptr;
-        R.S.alpha = c->alpha; R.S.beta = c->beta; R.S.delta = c->delta; R.S.counters = c->counters;
-        R.nb = nb; R.starts = c->starts.empty() ? nullptr : (const int64_t*)c->d_starts;
-        R.partials = c->partials; R.pstride = (int64_t)pstride;
-        R.gram = c->gram; R.cross = c->cross; R.corr = c->corr; R.ev = c->ev; R.sync = c->res_sync; R.ncg = c->ncg;
-        HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
-        HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-        HIPCHK(c, launch_sampler_resident(c->device, c->method, t, dense_big || (dense_mt && c->block_size <= 128), R, c->stream2));
-        HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
-    }
     for (int64_t k = 0; k <= nb; ++k) {
         UpdateArgs U;
         U.r_in = c->r + ((k + 1) & 1) * rstride; U.r_out = c->r + (k & 1) * rstride;
@@ -1936,27 +1731,6 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
             while (c->kev.size() < 2 * (ntimed + 1)) { hipEvent_t e; HIPCHK(c, hipEventCreate(&e)); c->kev.push_back(e); }
             HIPCHK(c, hipEventRecord(c->kev[2 * ntimed], c->stream));
         }
-        if (resident) {
-            // launch k applies block k-2's changes: it may read that list once `done` >= k-1; its partial sums are block k's
-            int* blk_sync = c->res_sync + kResArrive + 4 * k;         // {arrivals, work tickets, helper claim, -} of launch k
-            ResidentLink L{c->res_sync + kResDone, k >= 2 ? (int)(k - 1) : 0, c->res_sync + kResAbort, k < nb ? blk_sync : nullptr, blk_sync + 1};
-            ResidentHelp H{nullptr, 0, nullptr, 0};
-            if (dense_big && U.quiet_xcd && sb >= 0 && (bs == 256 || bs == 512) && !dense_big_off) {
-                H.gram_next = S.gram_next; H.nl_g = S.gram_next ? (S.b_next * S.b_next + 31) / 32 : 0;
-                H.cross_after = S.cross_after; H.nl_c = S.cross_after ? S.lines_after : 0;
-            }
-            const int nwork = c->nrg * U.ncg;
-            const unsigned grid = U.quiet_xcd ? (unsigned)((nwork + 6) / 7 * 8 + 16) : (unsigned)nwork;      // (quiet: 1/8 of them idle + slack)
-            hipError_t le;
-            if (c->packed) {
-                const PackedCols pc{c->Q, c->ld, c->qmean, c->n, c->centered, c->w, (int32_t)c->weighted};
-                le = launch_update_step(c->device, t, coop, U, nullptr, &pc, L, H, grid, c->stream);
-            } else {
-                const DenseCols dc{c->X, c->ld, c->w, (int32_t)c->weighted};
-                le = launch_update_step(c->device, t, coop, U, &dc, nullptr, L, H, grid, c->stream);
-            }
-            HIPCHK(c, le);
-        } else
         {
             // (256-marker multi-trait blocks: the dense-walk-only instantiation serves FULL blocks; a ragged last one goes through
             // the general instantiation)
@@ -1978,7 +1752,6 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
     if (!independent) {
         ev_list = event_list(&c->ev[(nb - 1) & 1]);
         r_last = c->r + (nb & 1) * rstride;                   // r(nb-2), written by the last step
-        if (resident) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));      // the last block's list: the sampler kernel is done
     }
     const int nfin = t * t + t;
     with_cols(c, 0, [&](auto cx) {
@@ -2004,27 +1777,6 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
     return JWAS_HIP_OK;
 }
 
-// A resident sweep gave up a bounded wait (resident.hpp): back to the state before the sweep; this context stays on the
-// launch-per-block path from now on (the next sweep_enqueue re-runs the sweep there: same chain, same bits).
-constexpr int JWAS_HIP_RESIDENT_ABORTED = -1000;
-static int resident_fallback(jwas_hip_ctx* c)
-{
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream2));
-    int rc = resident_snapshot(c, true); if (rc) return rc;
-    c->resident_off = true;
-    ++c->resident_aborts;
-    int h[kResArrive + 16];
-    HIPCHK(c, hipMemcpy(h, c->res_sync, sizeof h, hipMemcpyDeviceToHost));
-    std::fprintf(stderr, "[jwas_hip] resident-sampler sweep gave up a bounded wait (%s, block %d: saw %d, needed %d; blocks published: %d of %lld; arrivals of the first blocks: %d %d %d %d); "
-                 "re-running the sweep launch per block (the mode is off for this context)\n",
-                 h[kResAbort + 1] == 2 ? "sampler waiting for partial sums" : "update kernel waiting for a change list", h[kResAbort + 2], h[kResAbort + 3],
-                 h[kResAbort + 1] == 2 ? h[kResAbort + 4] : h[kResAbort + 2], h[kResDone], (long long)c->nblocks,
-                 h[kResArrive], h[kResArrive + 4], h[kResArrive + 8], h[kResArrive + 12]);
-    std::fprintf(stderr, "[jwas_hip]   sampler claimed on XCC %d: %s\n", h[kResAbort + 8], h[kResClaim] ? "yes" : "NO (no workgroup of its launch reached the XCC, or it never started)");
-    return JWAS_HIP_OK;
-}
-
 // Copies the reductions back and fills the statistics.  packed != NULL: the marker statistics come from the all-reduced
 // shard buffer (kShardStats doubles, device) instead of this context's own partials.
 static int sweep_collect(jwas_hip_ctx* c, jwas_sweep_stats* S, size_t ntimed, double timed_bytes, const double* packed_dev)
@@ -2039,13 +1791,9 @@ static int sweep_collect(jwas_hip_ctx* c, jwas_sweep_stats* S, size_t ntimed, do
     HIPCHK(c, hipMemcpyAsync(h_fin, c->fin_out, sizeof(double) * c->nslices * nfin, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(h_stat, c->stat_out, sizeof(double) * kStatGrid * kNStat, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(h_cnt, c->counters, sizeof(unsigned long long) * kNCounters, hipMemcpyDeviceToHost, c->stream));
-    int* h_abort = reinterpret_cast<int*>(h_cnt + kNCounters);
-    *h_abort = 0;
-    if (c->resident_active) HIPCHK(c, hipMemcpyAsync(h_abort, c->res_sync + kResAbort, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     if (packed_dev)       // (reuses the head of the statistics staging area: row 0 = the all-rank sums)
         HIPCHK(c, hipMemcpyAsync(h_stat, packed_dev, sizeof(double) * kShardStats, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->resident_active && *h_abort != 0) return JWAS_HIP_RESIDENT_ABORTED;      // (internal: the caller re-runs the sweep)
 
     std::memset(S, 0, sizeof *S);
     for (int s = 0; s < c->nslices; ++s) {
@@ -2078,8 +1826,8 @@ static int sweep_collect(jwas_hip_ctx* c, jwas_sweep_stats* S, size_t ntimed, do
     S->n_events = packed_dev ? h_stat[kNStat] : (double)h_cnt[0];
     c->last_events = (double)h_cnt[0];
     if (std::getenv("JWAS_HIP_DEBUG_PHASES"))
-        std::fprintf(stderr, "[jwas_hip] blocks=%lld events=%llu unstaged=%llu cycles: front=%llu cand=%llu stage=%llu serial=%llu write=%llu corr=%llu rounds=%llu slow_rounds=%llu stage: assign=%llu issue=%llu wait=%llu update wg0: share=%llu wait=%llu rest=%llu (resident sweeps: sampler wait=share, sampler drain=wait, update wg0 wait=rest) resident=%d compact: blocks=%llu fallback=%llu walk=%llu verify=%llu role=%llu tailwait=%llu xwrite=%llu xchain=%llu\n",
-                     (long long)c->nblocks, h_cnt[0], h_cnt[1], h_cnt[2], h_cnt[3], h_cnt[4], h_cnt[5], h_cnt[6], h_cnt[9], h_cnt[7], h_cnt[8], h_cnt[10], h_cnt[11], h_cnt[12], h_cnt[13], h_cnt[14], h_cnt[15], (int)c->resident_active, h_cnt[16], h_cnt[17], h_cnt[18], h_cnt[19], h_cnt[20], h_cnt[21], h_cnt[22], h_cnt[23]);
+        std::fprintf(stderr, "[jwas_hip] blocks=%lld events=%llu unstaged=%llu cycles: front=%llu cand=%llu stage=%llu serial=%llu write=%llu corr=%llu rounds=%llu slow_rounds=%llu stage: assign=%llu issue=%llu wait=%llu update wg0: share=%llu wait=%llu rest=%llu compact: blocks=%llu fallback=%llu walk=%llu verify=%llu role=%llu tailwait=%llu xwrite=%llu xchain=%llu\n",
+                     (long long)c->nblocks, h_cnt[0], h_cnt[1], h_cnt[2], h_cnt[3], h_cnt[4], h_cnt[5], h_cnt[6], h_cnt[9], h_cnt[7], h_cnt[8], h_cnt[10], h_cnt[11], h_cnt[12], h_cnt[13], h_cnt[14], h_cnt[15], h_cnt[16], h_cnt[17], h_cnt[18], h_cnt[19], h_cnt[20], h_cnt[21], h_cnt[22], h_cnt[23]);
     float ms = 0.f;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev_start, c->ev_stop));
     S->sweep_ms = ms;
@@ -2229,7 +1977,9 @@ static void f64_launch_block(jwas_hip_ctx* c, const double* r_in, double* r_out,
     ncg = (b + cpg - 1) / cpg;
     hipLaunchKernelGGL((jw64::k64_update_partial<NT>), dim3((unsigned)c->nslices, (unsigned)ncg), dim3(256), 0, c->stream, F->X, c->ld, F->w,
                        r_in, r_out, ev_prev, j0, b, cpg, part, bsz);
-    const bool glds = b <= jw64::kGramLds64;
+    // the block's Gram in LDS only when it FITS beside the per-marker arrays (their stride is the partition's largest block:
+    // b = 128 next to a 512-marker block with two traits would ask for 168 KB); otherwise the rows come from L2
+    const bool glds = b <= jw64::kGramLds64 && jw64::Smem64(b, bsz, NT, true).bytes <= 160 * 1024;
     const jw64::Smem64 SM(b, bsz, NT, glds);
     const double* G = F->gram + k * (int64_t)bsz * bsz;
 #define JW64_SAMPLE(M)                                                                                                                  \
@@ -2551,11 +2301,6 @@ int jwas_hip_sweep(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_sweep_stats
     int rc = sweep_enqueue(c, P, &ntimed, &timed_bytes);
     if (rc) return rc;
     rc = sweep_collect(c, S, ntimed, timed_bytes, nullptr);
-    if (rc == JWAS_HIP_RESIDENT_ABORTED) {
-        rc = resident_fallback(c); if (rc) return rc;
-        rc = sweep_enqueue(c, P, &ntimed, &timed_bytes); if (rc) return rc;
-        rc = sweep_collect(c, S, ntimed, timed_bytes, nullptr);
-    }
     return rc;
 }
 
@@ -2687,17 +2432,6 @@ int jwas_hip_sweep_sharded(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_swe
     double timed_bytes = 0.0;
     int rc = sweep_enqueue(c, P, &ntimed, &timed_bytes);
     if (rc) return rc;
-    if (c->resident_active) {
-        // the reconcile must not run on an aborted sweep: look at the flag before the pack (one host synchronisation)
-        int* h_abort = reinterpret_cast<int*>(c->host_buf + (size_t)c->nslices * (t * t + t) + (size_t)kStatGrid * kNStat) + 2 * kNCounters;
-        *h_abort = 0;
-        HIPCHK(c, hipMemcpyAsync(h_abort, c->res_sync + kResAbort, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (*h_abort != 0) {
-            rc = resident_fallback(c); if (rc) return rc;
-            rc = sweep_enqueue(c, P, &ntimed, &timed_bytes); if (rc) return rc;
-        }
-    }
     const int64_t total = (int64_t)t * c->ld;
     hipLaunchKernelGGL(k_shard_pack, dim3((unsigned)((total + 255) / 256 + 1)), dim3(256), 0, c->stream, t, c->ld, c->r, c->r_snap,
                        c->stat_out, kStatGrid, c->counters, c->shard_buf);

@@ -2,7 +2,6 @@
 // the L2 prefetch helpers.  Included by sweep.hpp.
 #pragma once
 #include "kernels.hpp"
-#include "coherent.hpp"
 
 // v_writelane_b32 (lane `lane` of `old` := the uniform value v; the other lanes keep theirs): this clang has no builtin for it --
 // the LLVM intrinsic by its own name (the compiler then places the required wait states itself)
@@ -43,35 +42,34 @@ struct SamplerArgs {
 
 // fp64 sum of one column's row-group partials in fixed (ascending row group) order; the first N loads are issued
 // back to back from clamped addresses (no load depends on another).
-template <int N, bool COH = false>
+template <int N>
 __device__ __forceinline__ double sum_partials_n(const double* pp, int nrg, int64_t stride)
 {
     double v[N];
 #pragma unroll
-    for (int u = 0; u < N; ++u) v[u] = ld_coh<COH>(pp + (int64_t)(u < nrg ? u : nrg - 1) * stride);
+    for (int u = 0; u < N; ++u) v[u] = *(pp + (int64_t)(u < nrg ? u : nrg - 1) * stride);
     double sum = 0.0;
 #pragma unroll
     for (int u = 0; u < N; ++u) if (u < nrg) sum += v[u];
     for (int rg = N; rg < nrg; rg += 16) {                        // very tall matrices only
         double w[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) w[u] = ld_coh<COH>(pp + (int64_t)(rg + u < nrg ? rg + u : nrg - 1) * stride);
+        for (int u = 0; u < 16; ++u) w[u] = *(pp + (int64_t)(rg + u < nrg ? rg + u : nrg - 1) * stride);
 #pragma unroll
         for (int u = 0; u < 16; ++u) if (rg + u < nrg) sum += w[u];
     }
     return sum;
 }
-template <bool COH = false>
 __device__ __forceinline__ double sum_partials(const double* pp, int nrg, int64_t stride)
 {
-    if (nrg <= 8) return sum_partials_n<8, COH>(pp, nrg, stride);      // (uniform branches: nrg is a launch constant)
-    if (nrg <= 16) return sum_partials_n<16, COH>(pp, nrg, stride);
-    return sum_partials_n<32, COH>(pp, nrg, stride);
+    if (nrg <= 8) return sum_partials_n<8>(pp, nrg, stride);      // (uniform branches: nrg is a launch constant)
+    if (nrg <= 16) return sum_partials_n<16>(pp, nrg, stride);
+    return sum_partials_n<32>(pp, nrg, stride);
 }
 
 // All NT traits of one column at once: the loads of a chunk of row groups are issued back to back for every trait (one
 // memory latency per chunk instead of one per trait), the sums per trait in the same ascending order as sum_partials.
-template <int NT, bool COH = false>
+template <int NT>
 __device__ __forceinline__ void sum_partials_traits(const double* pp, int64_t tstride, int nrg, int64_t stride, double (&sum)[NT])
 {
     constexpr int kC = (NT <= 2) ? 16 : (NT == 3 ? 12 : 8);
@@ -82,7 +80,7 @@ __device__ __forceinline__ void sum_partials_traits(const double* pp, int64_t ts
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int u = 0; u < kC; ++u) v[t][u] = ld_coh<COH>(pp + t * tstride + (int64_t)(rg + u < nrg ? rg + u : nrg - 1) * stride);
+            for (int u = 0; u < kC; ++u) v[t][u] = *(pp + t * tstride + (int64_t)(rg + u < nrg ? rg + u : nrg - 1) * stride);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll

@@ -599,7 +599,7 @@ __device__ __forceinline__ void mt2_eval(const MtConsts<NT>& K, const double* lp
 // being walked (fmaf in marker order: the sequential chain's own sequence -- bit-identical to the general path).  Half the
 // launches (and fronts) of the 128-marker blocks, and the walking wave updates its own section only.
 // Reference: MTBayesABC.jl:243-333 (block form of _MTBayesABC_samplerI!).
-template <int METHOD, int NT, bool RES>
+template <int METHOD, int NT>
 __device__ __forceinline__ void dense_big_mt(char* smem, const StepSmem& SM, const SamplerArgs& A, const MtConsts<NT>& K,
                                              const double* lpr, long long tk0, long long tk1)
 {
@@ -799,9 +799,9 @@ __device__ __forceinline__ void dense_big_mt(char* smem, const StepSmem& SM, con
     }
     if (changed) {
         const int e = base + __popcll(cm & ((1ull << lane) - 1ull));
-        st_coh<RES>(&A.ev_out->idx[e], (int32_t)(j0 + c));
+        A.ev_out->idx[e] = (int32_t)(j0 + c);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) st_coh<RES>(&A.ev_out->delta[t][e], astart[t * B + c] - acur[t * B + c]);
+        for (int t = 0; t < NT; ++t) A.ev_out->delta[t][e] = astart[t * B + c] - acur[t * B + c];
     }
     if (rowthr) {
 #pragma unroll
@@ -813,7 +813,7 @@ __device__ __forceinline__ void dense_big_mt(char* smem, const StepSmem& SM, con
         }
     }
     if (tid == 0) {
-        st_coh<RES>(&A.ev_out->count, (int32_t)nfin);
+        A.ev_out->count = (int32_t)nfin;
         atomicAdd(&A.counters[0], (unsigned long long)nfin);
         atomicAdd(&A.counters[2], (unsigned long long)(tk1 - tk0));      // front
         atomicAdd(&A.counters[5], (unsigned long long)(tk4 - tk1));      // sections (walks + off-diagonal applies)
@@ -821,7 +821,7 @@ __device__ __forceinline__ void dense_big_mt(char* smem, const StepSmem& SM, con
     if (lane == 0 && nredo) atomicAdd(&A.counters[7], (unsigned long long)nredo);      // sections walked again
 }
 
-template <int METHOD, int NT, bool DW = false, bool RES = false>       // RES: inside the resident sampler kernel (see sampler_role_st)
+template <int METHOD, int NT, bool DW = false>
 __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A)
 {
     constexpr bool kDW = DW && !is_sampler2(METHOD);
@@ -980,7 +980,7 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
             for (int st = 0; st < (1 << NT); ++st) lpm[st] = A.lpr_mat[(int64_t)(1 << NT) * j + st];
         }
         double psum[NT];
-        sum_partials_traits<NT, RES>(A.partials + cc, (int64_t)A.nrg * A.bstride, A.nrg, A.bstride, psum);
+        sum_partials_traits<NT>(A.partials + cc, (int64_t)A.nrg * A.bstride, A.nrg, A.bstride, psum);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const double sum = psum[t];
@@ -1075,7 +1075,7 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
         if constexpr (is_sampler1(METHOD)) {
             if (big_try) {
                 finish_tiles();
-                dense_big_mt<METHOD, NT, RES>(smem, SM, A, consts_of(tid < 256 ? tid : 0), lpr, tk0, clock64());
+                dense_big_mt<METHOD, NT>(smem, SM, A, consts_of(tid < 256 ? tid : 0), lpr, tk0, clock64());
                 return;
             }
         }
@@ -1116,7 +1116,7 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
             if (big_try && single_pass && first_sub == 0 && 5 * ncand_all >= 3 * b) {
                 fetch_tiles();
                 finish_tiles();
-                dense_big_mt<METHOD, NT, RES>(smem, SM, A, consts_of(tid < 256 ? tid : 0), lpr, tk0, clock64());
+                dense_big_mt<METHOD, NT>(smem, SM, A, consts_of(tid < 256 ? tid : 0), lpr, tk0, clock64());
                 return;
             }
         }
@@ -1466,9 +1466,9 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
         const int* fin = reinterpret_cast<const int*>(smem + SM.log_off);
         for (int e = tid; e < nfin; e += kStepThreads) {
             const int ce = fin[e];
-            st_coh<RES>(&A.ev_out->idx[e], (int32_t)(j0 + ce));
+            A.ev_out->idx[e] = (int32_t)(j0 + ce);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) st_coh<RES>(&A.ev_out->delta[t][e], astart[t * B + ce] - acur[t * B + ce]);
+            for (int t = 0; t < NT; ++t) A.ev_out->delta[t][e] = astart[t * B + ce] - acur[t * B + ce];
         }
     }
     for (int c = tid; c < b; c += kStepThreads) {
@@ -1481,7 +1481,7 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
         }
     }
     if (tid == 0) {
-        st_coh<RES>(&A.ev_out->count, (int32_t)nfin);
+        A.ev_out->count = (int32_t)nfin;
         atomicAdd(&A.counters[0], (unsigned long long)nfin);
         atomicAdd(&A.counters[2], (unsigned long long)(tk1 - tk0));      // phase cycle counts (diagnostics)
         atomicAdd(&A.counters[4], (unsigned long long)(tk3 - tk1));

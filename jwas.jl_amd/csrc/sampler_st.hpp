@@ -87,7 +87,7 @@ __device__ __forceinline__ void mask_diagonal_tile(float* tile, int ld, int t, i
 // section s is done applies its 64 changes from Gram / cross-Gram values it prefetched into registers while the section
 // was being walked (rhs = fmaf(D_k, G[k][c], rhs) in marker order: the sequential chain's own fmaf sequence).
 // One barrier per section; the serial part per marker is dense_section's chain and nothing else.
-template <int METHOD, bool RES = false>
+template <int METHOD>
 __device__ __forceinline__ void dense_big_st(char* smem, const StepSmem& SM, const SamplerArgs& A, float ie, long long tk0)
 {
     const int B = SM.B, b = A.b, bn = A.b_next;
@@ -197,14 +197,14 @@ __device__ __forceinline__ void dense_big_st(char* smem, const StepSmem& SM, con
     if (changed) {
         const int e = base + __popcll(cm & ((1ull << lane) - 1ull));
         const float d = ao - an_own;
-        st_coh<RES>(&A.ev_out->idx[e], (int32_t)(j0 + c));
-        st_coh<RES>(&A.ev_out->delta[0][e], d);
-        if (e < 7) { st_coh<RES>(&A.ev_out->hidx[e], (int32_t)(j0 + c)); st_coh<RES>(&A.ev_out->hdelta[e], d); }
+        A.ev_out->idx[e] = (int32_t)(j0 + c);
+        A.ev_out->delta[0][e] = d;
+        if (e < 7) { A.ev_out->hidx[e] = (int32_t)(j0 + c); A.ev_out->hdelta[e] = d; }
         A.alpha[j0 + c] = an_own;
     }
     if (own) { A.beta[j0 + c] = an_own; reinterpret_cast<float*>(A.delta)[j0 + c] = 1.f; }
     if (tid == 0) {
-        st_coh<RES>(&A.ev_out->count, (int32_t)nfin);
+        A.ev_out->count = (int32_t)nfin;
         atomicAdd(&A.counters[0], (unsigned long long)nfin);
         atomicAdd(&A.counters[5], (unsigned long long)(tk4 - tk0));      // (diagnostics: front + walk)
         atomicAdd(&A.counters[7], (unsigned long long)b);
@@ -387,9 +387,7 @@ __host__ __device__ constexpr int st_park_nf(int method, bool dense = false) { (
 // DENSE: the instantiation for sweeps under a UNIFORM PRIOR pi = 0 (single-trait BayesA/B/C: RR-BLUP, BayesA, BayesL, the
 // reference's benchmark setting), selected by the host: every marker follows Rule D (AbcMarker::rule_d) on every path of
 // it, and full 256- / 512-marker blocks take dense_big_st.  The steady-state kernel is compiled without any of it.
-// RES: the role runs inside the resident sampler kernel (resident.hpp): the row-group partials come from, and the change list
-// goes to, update kernels that run concurrently -- coherent accesses for exactly those (ld_coh / st_coh); nothing else differs.
-template <int METHOD, bool DENSE = false, bool RES = false>
+template <int METHOD, bool DENSE = false>
 __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A)
 {
     constexpr bool kR = (METHOD == kBayesR);
@@ -480,7 +478,7 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
             BayesRMarker bm;
             bm.load_fast_global(A.prep_d, p, j, dj, ie);
             const float thrx = A.prep_f[j];
-            const double sum = sum_partials<RES>(A.partials + cc, A.nrg, A.bstride);
+            const double sum = sum_partials(A.partials + cc, A.nrg, A.bstride);
             const float rhs0 = (float)sum + co;
             rhs_lds[c] = rhs0;
             const float a_in = (c < b) ? a0 : 0.f;
@@ -492,7 +490,7 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
         } else {
             const double zs = A.prep_d[3 * p + j];
             const float invLhs = A.prep_f[j], bex = A.prep_f[2 * p + j], lo = A.prep_f[3 * p + j], hi = A.prep_f[4 * p + j];
-            const double sum = sum_partials<RES>(A.partials + cc, A.nrg, A.bstride);
+            const double sum = sum_partials(A.partials + cc, A.nrg, A.bstride);
             const float rhs0 = (float)sum + co;       // + lookahead correction formed by the previous block's sampler
             rhs_lds[c] = rhs0;
             const float a_in = (c < b) ? a0 : 0.f;
@@ -559,7 +557,7 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
             bool all_in = true;
 #pragma unroll
             for (int q = 0; q < kStepThreads / 64; ++q) all_in = all_in && ((wc[q] >> 18) & 1);
-            if (all_in) { dense_big_st<METHOD, RES>(smem, SM, A, ie, tk0); return; }
+            if (all_in) { dense_big_st<METHOD>(smem, SM, A, ie, tk0); return; }
         }
     }
     // single-pass sweeps with a next block: waves 1..4 accumulate its lookahead correction while the serial wave runs
@@ -1164,9 +1162,9 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
         for (int e = tid; e < nfin; e += kStepThreads) {
             const int ce = pairs ? fin[2 * e] : fin[e];
             const float d = astart[ce] - acur[ce];
-            st_coh<RES>(&A.ev_out->idx[e], (int32_t)(j0 + ce));
-            st_coh<RES>(&A.ev_out->delta[0][e], d);
-            if (e < 7) { st_coh<RES>(&A.ev_out->hidx[e], (int32_t)(j0 + ce)); st_coh<RES>(&A.ev_out->hdelta[e], d); }
+            A.ev_out->idx[e] = (int32_t)(j0 + ce);
+            A.ev_out->delta[0][e] = d;
+            if (e < 7) { A.ev_out->hidx[e] = (int32_t)(j0 + ce); A.ev_out->hdelta[e] = d; }
             A.alpha[j0 + ce] = acur[ce];
         }
         // single-pass BayesA/B/C: a marker is in the model iff its effect is nonzero, beta = the effect, else its
@@ -1183,7 +1181,7 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
         }
     }
     if (tid == 0) {
-        st_coh<RES>(&A.ev_out->count, (int32_t)nfin);
+        A.ev_out->count = (int32_t)nfin;
         atomicAdd(&A.counters[0], (unsigned long long)nfin);
         atomicAdd(&A.counters[2], (unsigned long long)(tk1 - tk0));      // phase cycle counts (diagnostics)
         atomicAdd(&A.counters[3], (unsigned long long)(tk2 - tk1));

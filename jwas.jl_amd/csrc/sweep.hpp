@@ -160,7 +160,7 @@ __global__ __launch_bounds__(kStepThreads) void k_block_step(UpdateArgsT<CX> U, 
     if (w >= U.nrg * U.ncg) return;
     if (U.dbg_throttle > 1 && (w % U.dbg_throttle) != 0) return;       // timing experiments only
     constexpr bool kRoll = (METHOD == kBayesC || METHOD == kBayesB) && NT == 1 && !DENSE && CX::kDepth == 1;      // (see update_role; dense storage: the packed stream keeps 8 batches in registers)
-    update_role<NT, CX, COOP, false, kRoll>(smem, w % U.nrg, w / U.nrg, U.cx, U.r_in, U.r_out, U.ev, U.j0, U.b,
+    update_role<NT, CX, COOP, kRoll>(smem, w % U.nrg, w / U.nrg, U.cx, U.r_in, U.r_out, U.ev, U.j0, U.b,
                                             U.nslices, U.nrg, U.ncg, U.partials, U.bstride, U.spg, U.sync_now, U.sync_next, U.dbg);
 }
 

@@ -3,7 +3,6 @@
 #pragma once
 #include <type_traits>
 #include "kernels.hpp"
-#include "coherent.hpp"
 
 #ifdef JWAS_HIP_COOP_RELACQ
 #define JW_COOP_ARRIVE_ORDER __ATOMIC_RELEASE
@@ -16,28 +15,16 @@ namespace jw {
 // ---------------------------------------------------------------------------------------------
 // UPDATE/PARTIAL role
 // ---------------------------------------------------------------------------------------------
-// RES (resident-sampler sweeps, resident.hpp): the change list `ev` is published by a sampler kernel that runs CONCURRENTLY --
-// the workgroup waits (bounded) until res.done says so, reads the list with coherent loads, stores its partial sums with
-// coherent (write-through) stores and reports them with one arrival per workgroup.
-struct ResidentLink {
-    int* done;          // number of blocks whose change list has been published (monotonic within a sweep)
-    int need_done;      // this launch may read its list once *done >= need_done (0: nothing to wait for)
-    int* abort;         // set by whoever gave up waiting: the host re-runs the sweep through the launch-per-block path
-    int* arrive;        // this block's arrival counter (one increment per workgroup whose partial sums are stored), or NULL
-    int* ticket;        // this launch's {work ticket, helper claim} counters (quiet sweeps: resident.hpp)
-};
-constexpr long long kResidentUpdateTimeout = 20000000ll;      // wall_clock64 ticks (100 MHz): 200 ms
 // ROLL: the rolling-window apply for 33..64 changes (below) -- only where the kernel's register budget carries it (the
 // instantiation's sampler role decides: single-trait BayesA/B/C; with BayesR's or the multi-trait samplers' it spilled)
-template <int NT, class CX, bool COOP = false, bool RES = false, bool ROLL = false>
+template <int NT, class CX, bool COOP = false, bool ROLL = false>
 __device__ __forceinline__ void update_role(char* smem, int rg, int g,
                                             const CX& cx,
                                             const float* __restrict__ r_in, float* __restrict__ r_out,
                                             const Events* __restrict__ ev,
                                             int64_t j0, int b, int nslices, int nrg, int ncg,
                                             double* __restrict__ partials, int bstride, int spg = kRowGroupSlices,
-                                            int* sync_now = nullptr, int* sync_next = nullptr, unsigned long long* dbg = nullptr,
-                                            ResidentLink res = ResidentLink{nullptr, 0, nullptr, nullptr, nullptr})
+                                            int* sync_now = nullptr, int* sync_next = nullptr, unsigned long long* dbg = nullptr)
 {
 #ifdef JWAS_HIP_DEV_KNOBS
 #define JW_UPD_CLOCK(v) v = clock64()
@@ -91,47 +78,18 @@ __device__ __forceinline__ void update_role(char* smem, int rg, int g,
     // (the residual weights: fetched here, with the role's first loads -- behind the apply they were one more dependent
     // memory round trip before the stream could start)
     float4 wv = *reinterpret_cast<const float4*>(cx.w + row);
-    if constexpr (RES) {
-        // the list is published by the resident sampler: wait for it (the column loads above are already in flight).  The wait
-        // is BOUNDED; giving up marks the sweep aborted and the host re-runs it through the launch-per-block path.
-        if (res.need_done > 0) {
-            int* flag = reinterpret_cast<int*>(smem);                    // (the reduction scratch is not in use yet)
-            if (tid == 0) {
-                int ok = 0;
-                const long long t0 = wall_clock64();
-                const long long tc0 = clock64();
-                while (true) {
-                    if (__hip_atomic_load(res.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= res.need_done) { ok = 1; break; }
-                    if (__hip_atomic_load(res.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-                    if (wall_clock64() - t0 > kResidentUpdateTimeout) {
-                        if (__hip_atomic_exchange(res.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {      // (diagnostics: who gave up first)
-                            res.abort[1] = 1; res.abort[2] = res.need_done; res.abort[3] = __hip_atomic_load(res.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(2);
-                }
-                *flag = ok;
-                if (dbg != nullptr && rg == 0 && g == 0) atomicAdd(&dbg[15], (unsigned long long)(clock64() - tc0));      // diagnostics: one workgroup's wait
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // (LDS only: the column loads stay in flight)
-            const int ok = *flag;
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (!ok) return;
-        } else if (__hip_atomic_load(res.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
-    }
     // (dense priors apply a whole block of changes here: 16 column loads in flight per wave, the fmaf chain per row
     // stays in list order)
-    const int ne = ld_coh<RES>(&ev->count);
+    const int ne = ev->count;
     // the head of the list, one entry per lane, issued with the count (not after it: the arrays are always there, what lies
     // beyond the count is never used as an address or a coefficient) -- the general apply below then needs ONE further
     // memory latency per 32 changes instead of two per 16 (a scalar index load, then the columns: with 30-40 changes per
     // 512-marker block -- BayesR, a fixed pi, the first sweeps of a chain -- that was 4-6 dependent round trips, ~12 us of a
     // 29 us launch)
-    int liv_n = ld_coh<RES>(&ev->idx[lane]);
+    int liv_n = ev->idx[lane];
     float ldv_n[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) ldv_n[t] = ld_coh<RES>(&ev->delta[t][lane]);
+    for (int t = 0; t < NT; ++t) ldv_n[t] = ev->delta[t][lane];
     // ---- COOPERATIVE DENSE APPLY.  With a dense prior every launch applies a whole block of changes (ne ~ b), and every
     // column group of a row group re-reading the same ne columns makes the update role the bottleneck of the launch (8 x
     // 25.6 MB at n = 50 000, b = 128).  Here the ncg workgroups of a row group SPLIT the rows of every slice: wave w of
@@ -171,9 +129,9 @@ __device__ __forceinline__ void update_role(char* smem, int rg, int g,
             int iv_n; float dv_n[NT];
             auto load_list = [&](int e0) {
                 const int el = e0 + lane, ec = el < ne ? el : ne - 1;
-                iv_n = ld_coh<RES>(&ev->idx[ec]);
+                iv_n = ev->idx[ec];
 #pragma unroll
-                for (int t = 0; t < NT; ++t) { const float d = ld_coh<RES>(&ev->delta[t][ec]); dv_n[t] = (el < ne) ? d : 0.f; }
+                for (int t = 0; t < NT; ++t) { const float d = ev->delta[t][ec]; dv_n[t] = (el < ne) ? d : 0.f; }
             };
             if (slice_map ? (wave < 4 && g < spg) : (wave * pack < spg)) {   // (wave-uniform: the other waves have no share)
             load_list(0);
@@ -241,11 +199,11 @@ __device__ __forceinline__ void update_role(char* smem, int rg, int g,
         // header path: indices and coefficients arrived with the count (one 64-byte line)
         float4 x[7];
 #pragma unroll
-        for (int u = 0; u < 7; ++u) x[u] = cx.load4(u < ne ? ld_coh<RES>(&ev->hidx[u]) : 0, row);     // (unused slots: column 0, always valid)
+        for (int u = 0; u < 7; ++u) x[u] = cx.load4(u < ne ? ev->hidx[u] : 0, row);     // (unused slots: column 0, always valid)
 #pragma unroll
         for (int u = 0; u < 7; ++u) {
             if (u < ne) {
-                const float d = ld_coh<RES>(&ev->hdelta[u]);
+                const float d = ev->hdelta[u];
                 rv[0].x = fmaf(d, x[u].x, rv[0].x); rv[0].y = fmaf(d, x[u].y, rv[0].y);
                 rv[0].z = fmaf(d, x[u].z, rv[0].z); rv[0].w = fmaf(d, x[u].w, rv[0].w);
             }
@@ -259,9 +217,9 @@ __device__ __forceinline__ void update_role(char* smem, int rg, int g,
         for (int t = 0; t < NT; ++t) ldv[t] = ldv_n[t];
         if (e0 + 64 < ne) {
             const int el = e0 + 64 + lane, ec = el < ne ? el : ne - 1;
-            liv_n = ld_coh<RES>(&ev->idx[ec]);
+            liv_n = ev->idx[ec];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) ldv_n[t] = ld_coh<RES>(&ev->delta[t][ec]);
+            for (int t = 0; t < NT; ++t) ldv_n[t] = ev->delta[t][ec];
         }
         // K columns in flight per lane (addresses from v_readlane: no scalar memory access), the fused multiply-add chain per
         // row in list order; entries past the end re-read the last valid column and are skipped
@@ -389,17 +347,9 @@ __device__ __forceinline__ void update_role(char* smem, int rg, int g,
 #pragma unroll
             for (int w = 0; w < kRowGroupSlices; ++w) s += red[w][i][t];
             const int c = g + (i0 + i) * ncg;
-            st_coh<RES>(&partials[((int64_t)t * nrg + rg) * bstride + c], s);
+            partials[((int64_t)t * nrg + rg) * bstride + c] = s;
         }
         __syncthreads();
-    }
-    if constexpr (RES) {
-        // every wave's partial sums are written through (s_waitcnt vmcnt(0) = acknowledged) before the workgroup's one arrival
-        if (res.arrive != nullptr) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) __hip_atomic_fetch_add(res.arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
     }
 #ifdef JWAS_HIP_DEV_KNOBS
     if (dbg != nullptr && rg == 0 && g == 0 && tid == 0) {               // development builds: one workgroup's phases

@@ -231,6 +231,30 @@ def test_f64_weights_and_independent_blocks_parity(bs, nreps, independent):
         hip.close()
 
 
+@pytest.mark.parametrize("t,bs,tail", [(2, 512, 126), (3, 512, 120), (2, 1024, 128)])
+def test_f64_small_tail_block_beside_a_big_one(t, bs, tail):
+    """A 102..128-marker tail block in a partition whose largest block is 512 / 1024 markers (p % block size; also what cutting
+    an oversized block produces): the tail's Gram in LDS PLUS the per-marker arrays at the big block's stride would exceed the
+    160 KB dynamic-LDS cap (b = 126, stride 512, two traits: 168 KB) -- the launch must take the Gram rows from L2 instead
+    (round-4 advisor finding: the launch failed)."""
+    d, X, orc, hip = _pair(260, bs + tail, bs, "MTBayesC", t=t, seed=53)
+    try:
+        y = d["y"] - d["y"].mean()
+        for k in range(t):
+            for e in (orc, hip):
+                e.set_residual((1 + 0.3 * k) * y, k)
+                e.set_state(k, delta=np.ones(e.p))
+        R = 0.5 * np.eye(t) + 0.1
+        G = 0.003 * np.eye(t) + 0.001
+        lp = np.log(np.full(1 << t, 0.3 / ((1 << t) - 1))); lp[-1] = np.log(0.7)
+        for it in range(1, 4):
+            orc.sweep(iteration=it, seed=12, vare=R, var_effect=G, log_prior_states=lp)
+            hip.sweep(iteration=it, seed=12, vare=R, var_effect=G, log_prior_states=lp)
+        _compare(orc, hip, t)
+    finally:
+        hip.close()
+
+
 def test_f64_explicit_partition_parity():
     """fast_blocks = a vector of block starts (JWAS.jl:298-304) in the Float64 context: ragged blocks, each repeated its own size."""
     d, X, orc, hip = _pair(380, 700, 128, "BayesC", seed=47)

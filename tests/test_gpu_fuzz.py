@@ -121,9 +121,6 @@ def test_random_configurations_against_the_oracle(hip, seed, monkeypatch):
     variant, the device chain equals the oracle's BIT FOR BIT (effects, indicators, residuals)."""
     c = _random_case(1000 + seed)
     monkeypatch.setenv("JWAS_HIP_COOP_APPLY", "1" if c["coop"] else "0")
-    # every other case through the resident-sampler sweep (csrc/resident.hpp; a function of the seed, not a draw: the other
-    # dimensions of a case do not depend on it), the rest launch per block -- the same chain, the same bits
-    monkeypatch.setenv("JWAS_HIP_RESIDENT", "1" if seed % 2 else "0")
     rng = np.random.default_rng(c["seed"])
     method, t, n, p = c["method"], c["t"], c["n"], c["p"]
     d = make_dataset(n=n, p=p, ncausal=min(6, p), seed=c["seed"] % 1000)
