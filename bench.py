@@ -84,6 +84,8 @@ def parse():
     ap.add_argument("--pi-fixed", type=float, default=None,
                     help="BayesC workloads: keep pi at this value (estimatePi = false) -- the high-turnover variant")
     ap.add_argument("--mt-prior", choices=["default", "sparse"], default="default")
+    ap.add_argument("--no-section-solve", action="store_true",
+                    help="dense priors: the sequential walk instead of Rule T (jwas_sweep_params.section_solve) -- A/B")
     ap.add_argument("--mt-method", choices=["BayesC", "BayesB"], default="BayesC",
                     help="config4: BayesB = multi-trait BayesA/B, one effect covariance per marker (redrawn on the host each iteration)")
     ap.add_argument("--shard", choices=["markers", "rows"], default="markers",
@@ -214,6 +216,8 @@ def main():
     all_in = refbench or (t == 1 and bayesc and a.pi_fixed == 0.0)
     mt_big = mt_dense                                   # (sampler I, shared or per-marker covariance: 256-marker blocks through dense_big_mt)
     bs = a.block_size or ((512 if all_in else (256 if mt_big else 128)) if dense_prior else 512)
+    # Rule T (mcmc.run_chain's policy): the dense 256-marker blocks of sampler I as triangular solves; --no-section-solve = the walk
+    section_solve = bool(mt_big and t <= 3 and bs == 256 and not a.no_section_solve)
     rows_mode = a.shard == "rows"
     if rows_mode and (weak or a.storage != "dense"):
         raise SystemExit("--shard rows runs the dense strong-scaling workloads (config2 / config3 / config4 / refbench)")
@@ -355,6 +359,8 @@ def main():
             eng.residual_add_scalar(mu_old[k] - s["mu"][k], k)
         # 2. marker sweep on the device (+ shard reconcile)
         kw = dict(iteration=s["it"], seed=a.seed, vare=s["vare"], var_effect=s["G"], nreps=1)
+        if section_solve:
+            kw["section_solve"] = True
         if method == "BayesR":
             kw["pi_classes"] = s["pi"]
         elif t > 1:

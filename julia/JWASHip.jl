@@ -43,6 +43,8 @@ struct HipSweepParams
     vare_f64::NTuple{16,Float64}
     var_effect_f64::NTuple{16,Float64}
     var_effect_vec_f64::Ptr{Float64}
+    section_solve::Int32
+    reserved0::Int32
 end
 
 struct HipSweepStats
@@ -123,13 +125,14 @@ function HipSweepParams(method::Integer, iter::Integer, seed::Integer; vare::Rea
                         pi_classes=(0.0, 0.0, 0.0, 0.0), gamma=(0.0, 0.01, 0.1, 1.0), nreps::Integer=1,
                         marker_offset::Integer=0, independent_blocks::Bool=false,
                         pi_vec::Ptr{Float64}=Ptr{Float64}(C_NULL), pi_matrix::Ptr{Float64}=Ptr{Float64}(C_NULL),
-                        var_effect_vec::Ptr{Float32}=Ptr{Float32}(C_NULL))
+                        var_effect_vec::Ptr{Float32}=Ptr{Float32}(C_NULL), section_solve::Bool=false)
     HipSweepParams(Int32(method), Int32(1), Int32(nreps), UInt32(iter), UInt64(seed), UInt32(marker_offset),
                    UInt32(independent_blocks), Base.setindex(_z16(Float32), Float32(vare), 1),
                    Base.setindex(_z16(Float32), Float32(var_effect), 1), Float64(pi), NTuple{4,Float64}(pi_classes),
                    NTuple{4,Float64}(gamma), _z16(Float64), var_effect_vec, pi_vec, pi_matrix, Ptr{Float64}(C_NULL),
                    Ptr{Float32}(C_NULL), Base.setindex(_z16(Float64), Float64(vare), 1),
-                   Base.setindex(_z16(Float64), Float64(var_effect), 1), Ptr{Float64}(C_NULL))      # (the Float64 context's copies)
+                   Base.setindex(_z16(Float64), Float64(var_effect), 1), Ptr{Float64}(C_NULL),      # (the Float64 context's copies)
+                   Int32(section_solve), Int32(0))                                                   # Rule T (dense priors, pi = 0)
 end
 
 "One marker sweep = one call of BayesABC! / BayesR! / MTBayesABC! (BayesABC.jl:60-80, BayesR.jl:45-97, MTBayesABC.jl:57-127)."

@@ -25,7 +25,7 @@ SYMBOLS = [
     "jwas_hip_set_gram", "jwas_hip_num_blocks", "jwas_hip_init_state", "jwas_hip_set_state",
     "jwas_hip_get_state", "jwas_hip_set_residual", "jwas_hip_get_residual", "jwas_hip_residual_dev",
     "jwas_hip_residual_to_dev", "jwas_hip_residual_from_dev",
-    "jwas_hip_residual_sub_xalpha", "jwas_hip_mul_alpha", "jwas_hip_load_output_dense_f32", "jwas_hip_mul_alpha_output", "jwas_hip_window_sums", "jwas_hip_window_sums2", "jwas_hip_set_kernel_timing", "jwas_hip_sweep",
+    "jwas_hip_residual_sub_xalpha", "jwas_hip_mul_alpha", "jwas_hip_load_output_dense_f32", "jwas_hip_mul_alpha_output", "jwas_hip_window_sums", "jwas_hip_window_sums2", "jwas_hip_set_kernel_timing", "jwas_hip_sweep", "jwas_hip_last_sweep_counters",
     "jwas_hip_accumulate", "jwas_hip_get_posterior",
     "jwas_hip_load_jgb2", "jwas_hip_load_packed2bit", "jwas_hip_alloc_packed2bit", "jwas_hip_storage_info",
     "jwas_hip_set_xpx", "jwas_hip_estimate_bytes_storage", "jwas_hip_add_block_size", "jwas_hip_select_block_size",
@@ -55,6 +55,8 @@ class SweepParams(C.Structure):
         ("vare_f64", C.c_double * (MAX_TRAITS * MAX_TRAITS)),
         ("var_effect_f64", C.c_double * (MAX_TRAITS * MAX_TRAITS)),
         ("var_effect_vec_f64", C.POINTER(C.c_double)),
+        ("section_solve", C.c_int32),
+        ("reserved0", C.c_int32),
     ]
 
 
@@ -128,6 +130,7 @@ def load():
     L.jwas_hip_residual_to_dev.argtypes = [vp, i32, vp]
     L.jwas_hip_residual_from_dev.argtypes = [vp, i32, vp]
     L.jwas_hip_set_kernel_timing.argtypes = [vp, i32]
+    L.jwas_hip_last_sweep_counters.argtypes = [vp, C.POINTER(C.c_uint64), i32]
     L.jwas_hip_residual_sub_xalpha.argtypes = [vp, i32]
     L.jwas_hip_mul_alpha.argtypes = [vp, i32, vp]
     L.jwas_hip_load_output_dense_f32.argtypes = [vp, vp, i64, i64, i64]

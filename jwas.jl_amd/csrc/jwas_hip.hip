@@ -80,6 +80,10 @@ struct jwas_hip_ctx {
     double* prep_d = nullptr;           // [kPrepD][p] per-sweep marker constants (k_prepare)
     float*  prep_f = nullptr;           // [kPrepF][p]
     double* mt2_tab = nullptr;          // sampler II, <= 3 traits: [2^t * (t(t+1)/2 + 1)][p] state tables
+    float*  tsec = nullptr;             // Rule T (section_solve): the section inverses of the current sweep, [sections][(64 t)^2]
+    size_t  tsec_cap = 0;               // ... capacity in floats
+    float*  xch = nullptr;              // Rule T: [kMaxT][256] floats + the flag: the sampler workgroup's hand-over to the helper workgroup
+    int     xch_epoch = 0;              // ... grows by 8 per launch
     float*  Xout = nullptr;             // output (EBV) rows: [p][ld_out] fp32, Mi.output_genotypes (tools4genotypes.jl:290-296)
     int64_t n_out = 0, ld_out = 0;
     float*  var_vec = nullptr;
@@ -93,6 +97,7 @@ struct jwas_hip_ctx {
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     int timing_stride = 0;
     double last_events = -1.0;          // effect changes of the previous sweep (-1: none yet)
+    unsigned long long last_counters[kNCounters] = {};      // the sampler's diagnostics counters of the previous sweep
     double event_overhead_ms = 0.0;     // mean HIP-event interval around an empty launch (calibration)
     std::vector<hipEvent_t> kev;        // pairs of events around sampled k_update_partial launches
     // marker-shard reconcile (jwas_hip_comm_init / jwas_hip_sweep_sharded): RCCL communicator on this context's device
@@ -236,6 +241,8 @@ static void free_state(jwas_hip_ctx* c)
     (void)hipFree(c->mean_a); (void)hipFree(c->mean_a2); (void)hipFree(c->mean_d);
     (void)hipFree(c->prep_d); (void)hipFree(c->prep_f); c->prep_d = nullptr; c->prep_f = nullptr;
     (void)hipFree(c->mt2_tab); c->mt2_tab = nullptr;
+    (void)hipFree(c->tsec); c->tsec = nullptr; c->tsec_cap = 0;
+    (void)hipFree(c->xch); c->xch = nullptr;
     (void)hipFree(c->cmp_idx); (void)hipFree(c->cmp_val); c->cmp_idx = nullptr; c->cmp_val = nullptr;
     c->alpha = c->beta = nullptr; c->delta = nullptr; c->mean_a = c->mean_a2 = c->mean_d = nullptr;
     (void)hipFree(c->var_mat); (void)hipFree(c->ginv_mat); c->var_mat = nullptr; c->ginv_mat = nullptr; c->var_mat_resident = false;
@@ -1660,6 +1667,27 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
     const bool dense_mt = is_mt_method(c->method) && !is_sampler2(c->method) && (c->block_size <= 128 || dense_mt256) && P->nreps == 1 && !P->independent_blocks &&
                           (edm ? std::atoi(edm) != 0 : c->last_events >= 0.6 * (double)c->p);
     const int dense_big_off = std::getenv("JWAS_HIP_DENSE_BIG_OFF") != nullptr ? 1 : 0;      // (tests: the same chain through the general path)
+    // Rule T (jwas_sweep_params.section_solve): the dense chain of a 64-marker section as a mat-vec with the section's inverse,
+    // formed here for all sections of the full blocks in parallel (sampler_mt.hpp).  Multi-trait sampler I on uniform 256-marker blocks.
+    const int64_t solve_blocks = (P->section_solve && dense_mt256 && P->nreps == 1 && !independent && c->starts.empty() && !c->row_mode && !dense_big_off)
+                                     ? c->p / 256 : 0;
+    const size_t tsf = (size_t)(64 * t) * (size_t)(64 * t);
+    if (solve_blocks > 0) {
+        const size_t need = (size_t)solve_blocks * 4 * tsf;
+        if (c->tsec_cap < need) {
+            (void)hipFree(c->tsec); c->tsec = nullptr; c->tsec_cap = 0;
+    (void)hipFree(c->xch); c->xch = nullptr;
+            HIPCHK(c, hipMalloc(&c->tsec, sizeof(float) * need));
+            c->tsec_cap = need;
+        }
+        if (!c->xch) {
+            HIPCHK(c, hipMalloc(&c->xch, sizeof(float) * (kMaxT * 256 + 64)));
+            HIPCHK(c, hipMemsetAsync(c->xch, 0, sizeof(float) * (kMaxT * 256 + 64), c->stream));
+        }
+        const StepLaunch L = step_launch_of(c);
+        if (c->method == JWAS_HIP_MTBAYESB1) HIPCHK(c, launch_section_inverse_mtb1(L, t, c->dparams, c->xpx, c->gram, c->ginv_mat, solve_blocks * 4, c->tsec));
+        else HIPCHK(c, launch_section_inverse_mtc1(L, t, c->dparams, c->xpx, c->gram, solve_blocks * 4, c->tsec));
+    }
     const int compact_off = std::getenv("JWAS_HIP_COMPACT_OFF") != nullptr ? std::atoi(std::getenv("JWAS_HIP_COMPACT_OFF")) : 0;          // (tests: the speculative rounds instead of the compact chain)
     if (independent) {
         int rc = sweep_independent(c, &ev_list, dense_big, dense_big_off, compact_off);
@@ -1717,6 +1745,13 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
             S.cross_after = (sb + 2 < nb) ? c->cross + (sb + 2) * (int64_t)bs * bs : nullptr;
             S.dense_big_off = dense_big_off;
             S.compact_off = compact_off;
+            S.tsec = (sb < solve_blocks) ? c->tsec + (size_t)sb * 4 * tsf : nullptr;
+            S.tsec_next = (sb + 1 < solve_blocks) ? c->tsec + (size_t)(sb + 1) * 4 * tsf : nullptr;
+            S.tsec_lines = (int)(4 * tsf / 32);
+            if (S.tsec != nullptr) {       // (the helper workgroup lives on the quiet XCD: ids = 0 mod 8 do no streaming)
+                S.xch = c->xch; S.xch_flag = reinterpret_cast<int*>(c->xch + kMaxT * 256); c->xch_epoch += 8; S.xch_epoch = c->xch_epoch;
+                U.quiet_xcd = 1;
+            }
             S.lines_after = (sb + 2 < nb) ? (int)(((int64_t)blk_b(c, sb + 1) * blk_b(c, sb + 2) + 31) / 32) : 0;
             S.corr_in = c->corr + (sb & 1) * (size_t)kMaxT * bs;
             S.corr_out = c->corr + ((sb + 1) & 1) * (size_t)kMaxT * bs;
@@ -1736,6 +1771,7 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
             // the general instantiation)
             bool dmt = dense_mt;
             if (dmt && c->block_size == 256 && sb >= 0) dmt = !dense_big_off && S.b == 256;
+            if (sb >= 0 && S.tsec != nullptr) dmt = true;          // Rule T lives in dense_big_mt: the dense-walk-only instantiation, whatever the last sweep did
             HIPCHK(c, launch_step_any(c, U, S, sb >= 0, dense_big || dmt));
         }
         if (c->row_mode && U.b > 0) {          // the block's partial RHS summed over the ranks' individuals, before its sampler runs
@@ -1825,6 +1861,7 @@ static int sweep_collect(jwas_hip_ctx* c, jwas_sweep_stats* S, size_t ntimed, do
     }
     S->n_events = packed_dev ? h_stat[kNStat] : (double)h_cnt[0];
     c->last_events = (double)h_cnt[0];
+    for (int i = 0; i < kNCounters; ++i) c->last_counters[i] = h_cnt[i];
     if (std::getenv("JWAS_HIP_DEBUG_PHASES"))
         std::fprintf(stderr, "[jwas_hip] blocks=%lld events=%llu unstaged=%llu cycles: front=%llu cand=%llu stage=%llu serial=%llu write=%llu corr=%llu rounds=%llu slow_rounds=%llu stage: assign=%llu issue=%llu wait=%llu update wg0: share=%llu wait=%llu rest=%llu compact: blocks=%llu fallback=%llu walk=%llu verify=%llu role=%llu tailwait=%llu xwrite=%llu xchain=%llu\n",
                      (long long)c->nblocks, h_cnt[0], h_cnt[1], h_cnt[2], h_cnt[3], h_cnt[4], h_cnt[5], h_cnt[6], h_cnt[9], h_cnt[7], h_cnt[8], h_cnt[10], h_cnt[11], h_cnt[12], h_cnt[13], h_cnt[14], h_cnt[15], h_cnt[16], h_cnt[17], h_cnt[18], h_cnt[19], h_cnt[20], h_cnt[21], h_cnt[22], h_cnt[23]);
@@ -2291,6 +2328,13 @@ int jwas_hip_get_posterior_f64(jwas_hip_ctx* c, int32_t trait, double* ma, doubl
 }  // extern "C"
 
 extern "C" {
+
+int jwas_hip_last_sweep_counters(jwas_hip_ctx* c, uint64_t* out, int32_t n)
+{
+    NEED(c, c && out && n >= 0, JWAS_HIP_EINVAL, "NULL argument");
+    for (int i = 0; i < n; ++i) out[i] = i < kNCounters ? (uint64_t)c->last_counters[i] : 0u;
+    return JWAS_HIP_OK;
+}
 
 int jwas_hip_sweep(jwas_hip_ctx* c, const jwas_sweep_params* P, jwas_sweep_stats* S)
 {

@@ -29,6 +29,13 @@ struct SamplerArgs {
     int lines_after;              // ... its size in 128-byte lines
     int dense_big_off;            // != 0: never take dense_big_st (tests: the same chain through the general path)
     int compact_off;              // != 0: never take the compact chain (tests: the same chain through the speculative rounds)
+    const float* tsec;            // Rule T (jwas_sweep_params.section_solve): the inverses of THIS block's 64-marker sections (see sampler_mt.hpp /
+                                  // sampler_st.hpp), or NULL = the sequential chain
+    const float* tsec_next;       // ... of the NEXT block (L2 prefetch only), or NULL
+    int tsec_lines;               // ... its size in 128-byte lines
+    float* xch;                   // Rule T: [kMaxT][256] the changes of the block's sections, published by the sampler workgroup for the
+    int* xch_flag;                // helper workgroup (corr_helper_mt); *xch_flag = xch_epoch + (sections published so far)
+    int xch_epoch;                // ... of THIS launch (grows by 8 per launch: no reset between launches)
     const float* corr_in;         // [NT][bsz] lookahead correction of THIS block (written by the previous sampler)
     float* corr_out;              // [NT][bsz] lookahead correction of the NEXT block
     const double* prep_d; const float* prep_f;

@@ -14,6 +14,7 @@ namespace jw {
 template <int NT>
 struct MtConsts {
     float Rinv[NT][NT], Ginv[NT][NT];
+    float Rm[NT][NT];                                 // the residual covariance itself (Rule T: the rhs a solved effect implies)
     float invG[NT], lG[NT], sG[NT];                   // sampler I: 1/Ginv_kk, log Ginv_kk, sqrt(1/Ginv_kk)
     // mega (constraint = true): per-trait single-trait BayesC constants
     float ie[NT], var[NT], iv[NT], lv[NT], sv[NT];   // sv = sqrt(var)
@@ -119,6 +120,137 @@ __device__ __forceinline__ void mt1_linear_beta(const float (&A)[NT][NT], const 
         b[k] = v;
     }
 }
+
+// The matrix A of Rule L alone (the part of mt1_linear_coeffs that does not depend on the marker's old effects or draws --
+// only on its x'x and the sweep's covariances): the same operations, the same floats.
+template <int NT>
+__device__ __forceinline__ void mt1_linear_A(const MtConsts<NT>& K, float dj, float (&A)[NT][NT])
+{
+    double Ad[NT][NT];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+        const float C11 = K.Ginv[k][k] + K.Rinv[k][k] * dj;                                     // MTBayesABC.jl:89
+        const double il = (double)(1.0f / C11);                                                 // :95
+        double C12[NT];
+#pragma unroll
+        for (int m = 0; m < NT; ++m) C12[m] = (double)(K.Ginv[k][m] + (dj * 1.f) * K.Rinv[k][m]);
+#pragma unroll
+        for (int m = 0; m < NT; ++m) {
+            double acc = (double)K.Rinv[m][k];
+#pragma unroll
+            for (int j = 0; j < k; ++j) acc = acc - C12[j] * Ad[j][m];
+            Ad[k][m] = il * acc;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NT; ++k)
+#pragma unroll
+        for (int m = 0; m < NT; ++m) A[k][m] = (float)Ad[k][m];
+}
+
+// ---------------------------------------------------------------------------------------------
+// RULE T (round 5): the dense block chain as the TRIANGULAR SOLVE it is.
+// With every marker of a 64-marker section in the model for every trait, Rule L makes the section's chain linear in the
+// changes D_l = alpha_old_l - alpha_new_l (NT-vectors):
+//     D_l = y_l - A_l * sum_{j<l} G_lj D_j ,      y_l = alpha_old_l - (A_l (rhs_l + d_l alpha_old_l) + c_l)
+// (rhs_l: the section-entry right-hand side; G: the section's diagonal Gram tile) -- i.e. (I + L) D = y with the strictly
+// lower block matrix L[(l,k),(j,m)] = A_l[k][m] G_lj.  A_l depends on the marker's x'x and the sweep's covariances only, so
+// T_s = (I + L)^-1 (64 NT x 64 NT, lower block triangular) is formed ONCE PER SWEEP for all sections in parallel
+// (k_section_inverse_mt: one workgroup per section, one thread per column, forward substitution) and a section's chain is
+// one mat-vec  D~ = T_s y  spread over 2 NT waves instead of a 64-step walk of one wave.  The new effects are
+// alpha_new = alpha_old - D~ (the linear form's own values up to rounding: the same conditional means and draws); the
+// literal evaluation (MTBayesABC.jl:85-120) at the right-hand side those effects imply,
+//     rhs~_l = rhs_l + R Lc_l (y_l - D~_l)      (Lc_l: the marker's lower-triangular C11 / C12 matrix, R: residual covariance),
+// verifies that every indicator stays 1; if one does not, the section runs through the sequential chain (the walk) from its
+// saved state.  Part of the sampler's definition when jwas_sweep_params.section_solve is set (the oracle restates it
+// operation for operation: orc mt1_section_solve); off = the sequential chain everywhere, bit for bit as before.
+// Layout of T_s in HBM: float [16 NT][64 NT][4] -- column group cg (columns 4 cg .. 4 cg + 3; column = m * 64 + j for trait m
+// of marker j), row r = k * 64 + l, the row's four values of the group: one float4 per lane, 1 KB per wave load.
+// Summation order of D~[(l,k)]: two fmaf chains from 0 over the columns [0, 32 NT) and [32 NT, 64 NT) in ascending order, added.
+// ---------------------------------------------------------------------------------------------
+template <int NT> __host__ __device__ constexpr int64_t tsec_floats() { return (int64_t)(64 * NT) * (64 * NT); }
+
+// One section's inverse.  grid = sections (4 per full 256-marker block), block = 64 NT threads (thread = column).
+// LDS: the tile's G (16 KB), A of the 64 markers, the inverse in packed lower-block-triangular form (NT^2 * 2080 floats).
+template <int METHOD, int NT>
+__global__ __launch_bounds__(64 * NT) void k_section_inverse_mt(const DevParams* __restrict__ P, const float* __restrict__ xpx,
+                                                               const float* __restrict__ gram /* blocks at stride 256*256 */,
+                                                               const float* __restrict__ ginv_mat, float* __restrict__ tsec)
+{
+    static_assert(is_sampler1(METHOD), "sampler I");
+    constexpr int NR = 64 * NT;
+    extern __shared__ __attribute__((aligned(16))) char smem_ti[];
+    float* Gt = reinterpret_cast<float*>(smem_ti);                  // [64][64] the section's diagonal Gram tile
+    float* Al = Gt + 4096;                                          // [64][NT*NT]
+    float* Xp = Al + 64 * NT * NT;                                  // packed inverse: row (l,k), columns of markers <= l
+    const int tid = threadIdx.x;
+    const int64_t sec = blockIdx.x, blk = sec >> 2;
+    const int s = (int)(sec & 3);
+    const float* G = gram + blk * (int64_t)(256 * 256) + (int64_t)(64 * s) * 256 + 64 * s;
+    for (int e = tid; e < 4096 / 4; e += NR) {
+        const int l = e >> 4, c4 = (e & 15) * 4;
+        *reinterpret_cast<float4*>(Gt + l * 64 + c4) = *reinterpret_cast<const float4*>(G + (int64_t)l * 256 + c4);
+    }
+    if (tid < 64) {
+        const int64_t j = blk * 256 + 64 * s + tid;
+        MtConsts<NT> K;
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+            for (int c = 0; c < NT; ++c) {
+                K.Rinv[a][c] = P->Rinv[a * NT + c];
+                K.Ginv[a][c] = has_marker_cov(METHOD) ? ginv_mat[j * (NT * NT) + a * NT + c] : P->Ginv[a * NT + c];
+            }
+        float A[NT][NT];
+        mt1_linear_A<NT>(K, xpx[j], A);
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+            for (int c = 0; c < NT; ++c) Al[tid * NT * NT + a * NT + c] = A[a][c];
+    }
+    __syncthreads();
+    // thread = column (jc, mc); rows above the column's marker are zero (not stored), its own marker's rows are the identity
+    const int mc = tid >> 6, jc = tid & 63;                         // column index c = mc * 64 + jc
+    auto xoff = [](int l, int k) { return NT * NT * (l * (l + 1) / 2) + k * (l + 1) * NT; };      // row (l,k): columns (j <= l, m) at + j * NT + m
+#pragma unroll
+    for (int k = 0; k < NT; ++k) Xp[xoff(jc, k) + jc * NT + mc] = (k == mc) ? 1.f : 0.f;
+    // (a thread reads back only what it wrote itself: no synchronisation inside the substitution)
+#pragma unroll 1
+    for (int l = jc + 1; l < 64; ++l) {
+        double u[NT];
+#pragma unroll
+        for (int m = 0; m < NT; ++m) u[m] = 0.0;
+#pragma unroll 1
+        for (int j = jc; j < l; ++j) {
+            const double g = (double)Gt[l * 64 + j];
+#pragma unroll
+            for (int m = 0; m < NT; ++m) u[m] = fma(g, (double)Xp[xoff(j, m) + jc * NT + mc], u[m]);
+        }
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            double v = 0.0;
+#pragma unroll
+            for (int m = 0; m < NT; ++m) v = fma((double)Al[l * NT * NT + k * NT + m], u[m], v);
+            Xp[xoff(l, k) + jc * NT + mc] = (float)(-v);
+        }
+    }
+    __syncthreads();
+    // coalesced write-out in the sampler's layout: [cg][r][4], r = k*64 + l, column = m*64 + j
+    float* dst = tsec + sec * tsec_floats<NT>();
+    for (int e = tid; e < (NR / 4) * NR; e += NR) {
+        const int cg = e / NR, r = e - cg * NR;
+        const int k = r >> 6, l = r & 63;
+        float4 v;
+        float* vv = reinterpret_cast<float*>(&v);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = 4 * cg + q, m = c >> 6, j = c & 63;
+            vv[q] = (j <= l) ? Xp[xoff(l, k) + j * NT + m] : 0.f;
+        }
+        *reinterpret_cast<float4*>(dst + (int64_t)e * 4) = v;
+    }
+}
+template <int NT> __host__ __device__ constexpr int tsec_inverse_lds_bytes() { return 4 * (4096 + 64 * NT * NT + NT * NT * 2080); }
 
 // Gibbs sampler I (MTBayesABC.jl:85-120); LIN: apply Rule L to the result (off only where the result's VALUES are not kept).
 // Apre / cpre: Rule L's coefficients of this marker when the caller has formed them already (the dense walk: once per
@@ -821,6 +953,411 @@ __device__ __forceinline__ void dense_big_mt(char* smem, const StepSmem& SM, con
     if (lane == 0 && nredo) atomicAdd(&A.counters[7], (unsigned long long)nredo);      // sections walked again
 }
 
+// acc[t] = fmaf(D[t][u], pq[u], acc[t]) for the 64 changes u of a section in marker order (D: LDS, trait stride dstride; pq: the
+// thread's 64 Gram / cross-Gram values).  Batches of eight with the next batch's broadcast reads in flight behind the current
+// one's multiply-adds -- and a scheduling barrier per batch: left alone the compiler hoists all 64 NT reads to the top (192
+// registers on top of pq: spills).
+template <int NT>
+__device__ __forceinline__ void apply_section_changes(const float* D, int dstride, float (&acc)[NT], const float (&pq)[64])
+{
+    float dn[NT][8];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float4 d0 = *reinterpret_cast<const float4*>(D + t * dstride + k0);
+            const float4 d1 = *reinterpret_cast<const float4*>(D + t * dstride + k0 + 4);
+            dn[t][0] = d0.x; dn[t][1] = d0.y; dn[t][2] = d0.z; dn[t][3] = d0.w; dn[t][4] = d1.x; dn[t][5] = d1.y; dn[t][6] = d1.z; dn[t][7] = d1.w;
+        }
+    };
+    fetch(0);
+#pragma unroll
+    for (int k0 = 0; k0 < 64; k0 += 8) {
+        float dv[NT][8];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) dv[t][u] = dn[t][u];
+        if (k0 + 8 < 64) fetch(k0 + 8);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = fmaf(dv[t][u], pq[k0 + u], acc[t]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(acc[t]) :: "memory");
+    }
+}
+
+// ---- dense_big_mt under RULE T (jwas_sweep_params.section_solve; the comment block above k_section_inverse_mt).  The same
+// plan -- thread c (waves 0..3) owns marker c, one 64-marker section after the other; the next block's lookahead correction is
+// formed by a HELPER workgroup (corr_helper_mt) from the changes each section publishes -- but a section in which every marker
+// is in the model for every trait is SOLVED, not walked: wave s forms y (one evaluation of the linear form per lane), waves 4..7 multiply it with the section's inverse (wave
+// 4 + q: the q-th quarter of the columns for all NT rows of every marker, one float4 of T per lane, trait and column group,
+// fetched a section ahead), wave s adds the four partial products, forms the new effects and verifies them with ONE literal
+// evaluation per lane while everybody else already applies the section's changes (undone if the verification fails: the
+// section is then walked as in dense_big_mt).  The two roles run SEPARATE loops with the same sequence of barriers, so that the
+// registers of one role (the walker's state and Gram prefetch / the solver's 4 NT^2 float4 of T) are not live in the other.
+// NT <= 3 (4 traits: 64 float4 of T per lane).
+template <int METHOD, int NT>
+__device__ __forceinline__ void dense_big_mt_solve(char* smem, const StepSmem& SM, const SamplerArgs& A, const MtConsts<NT>& K,
+                                                   const double* lpr, long long tk0, long long tk1)
+{
+    static_assert(is_sampler1(METHOD) && NT <= 3, "sampler I, at most three traits");
+    constexpr int kB = 256, kSec = kB / 64;
+    static_assert(kStepThreads == 2 * kB, "waves 0..3: markers, waves 4..7: the solve");
+    const int B = SM.B, b = A.b, bn = A.b_next;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t j0 = A.j0, p = A.p;
+    float* rhs_lds = reinterpret_cast<float*>(smem + SM.rhs_off);       // entry rhs; reused as D[t][c] = alpha_old - alpha_new
+    float* acur = reinterpret_cast<float*>(smem + SM.acur_off);
+    const float* astart = reinterpret_cast<const float*>(smem + SM.astart_off);
+    float* bcur = reinterpret_cast<float*>(smem + SM.bcur_off);
+    float* dcur = reinterpret_cast<float*>(smem + SM.dcur_off);
+    const double* lpd = reinterpret_cast<const double*>(smem + SM.prepd_off);
+    const float* lpf = reinterpret_cast<const float*>(smem + SM.prepf_off);
+    const float* tiles = reinterpret_cast<const float*>(smem + SM.rows_off);      // [4][64][64], strictly upper (the walk's)
+    // scratch behind the tiles: y of the section [NT][64], the four partial products [4][NT][64], flags
+    float* ybuf = reinterpret_cast<float*>(smem + SM.rows_off) + kSec * 4096;
+    float* part = ybuf + NT * 64;
+    int* sflag = reinterpret_cast<int*>(part + 4 * NT * 64);           // [s]: section s is solved; [4 + s]: ... and its verification failed
+    int* wcnt = reinterpret_cast<int*>(smem + SM.wcnt_off);
+    float* delta = reinterpret_cast<float*>(A.delta);
+    auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    // D of section s (rhs_lds) times 64 prefetched Gram values: fmaf chains in marker order, traits interleaved
+    auto apply_changes = [&](int s, float (&acc)[NT], const float (&pq)[64]) { apply_section_changes<NT>(rhs_lds + 64 * s, B, acc, pq); };
+    if (wave < 4) {
+        // =================================== markers (thread c = marker c) ===================================
+        const int c = tid;
+        float rhs[NT], a[NT], bb[NT], dd[NT], lc[NT];
+        double thr[NT], z[NT];
+        const float dj = lpf[c];
+        bool in_all = true;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            rhs[t] = rhs_lds[t * B + c]; a[t] = acur[t * B + c]; bb[t] = bcur[t * B + c]; dd[t] = dcur[t * B + c];
+            thr[t] = lpd[t * B + c]; z[t] = lpd[(NT + t) * B + c]; lc[t] = lpf[(1 + t) * B + c];
+            in_all = in_all && (dd[t] == 1.f);
+        }
+        const MtPre<NT> Q = mt_precompute<METHOD, NT>(K, dj, lc);
+        float pq[64];
+        auto load_g = [&](int s) {
+            const char* base = reinterpret_cast<const char*>(A.gram + (int64_t)(64 * s) * b);
+            unsigned off = 4u * (unsigned)c;
+#pragma unroll
+            for (int u = 0; u < 64; ++u) { pq[u] = *reinterpret_cast<const float*>(base + off); off += 4u * (unsigned)b; asm volatile("" : "+v"(off)); }
+        };
+        if (wave > 0) load_g(0);
+        // Rule L's coefficients of the thread's own marker: all four waves at once, before the chain starts
+        float Al[NT][NT], cl[NT], da[NT];
+        mt1_linear_coeffs<NT>(K, Q, dj, bb, z, Al, cl);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) da[t] = dj * a[t];                                                  // MTBayesABC.jl:82
+        {
+            const unsigned long long slow0 = __ballot(!in_all);
+            if (lane == 0) { sflag[wave] = (slow0 == 0ull) ? 1 : 0; sflag[4 + wave] = 0; }
+        }
+        lds_barrier();                                                                                  // B0
+        int nredo = 0, nsolved = 0, nfailed = 0;
+#pragma unroll 1
+        for (int s = 0; s < kSec; ++s) {
+            const bool fast = sflag[s] != 0;
+            bool redo = !fast;
+            if (fast) {
+                float rsv[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) rsv[t] = rhs[t];
+                if (wave == s) {                                         // y of the section
+                    float w[NT], bo[NT];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) w[t] = rhs[t] + da[t];
+                    mt1_linear_beta<NT>(Al, cl, w, bo);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) ybuf[t * 64 + lane] = a[t] - bo[t];
+                }
+                lds_barrier();                                           // B1: y is there
+                lds_barrier();                                           // B2: the four partial products are there
+                float Dt[NT], yv[NT], bo[NT];
+                if (wave == s) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        Dt[t] = (part[t * 64 + lane] + part[(NT + t) * 64 + lane]) + (part[(2 * NT + t) * 64 + lane] + part[(3 * NT + t) * 64 + lane]);
+                        yv[t] = ybuf[t * 64 + lane];
+                        bo[t] = a[t] - Dt[t];
+                        rhs_lds[t * B + c] = a[t] - bo[t];               // D of this marker, read by everybody after the barrier
+                    }
+                }
+                lds_barrier();                                           // B3: D is there
+                if (wave == s) {
+                    // the literal evaluation at the right-hand side these effects imply:  rhs + R Lc (y - D~)
+                    float v[NT], qv[NT], wev[NT];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) v[t] = yv[t] - Dt[t];
+#pragma unroll
+                    for (int k = 0; k < NT; ++k) {
+                        float acc = Q.C11[k] * v[k];
+#pragma unroll
+                        for (int j = 0; j < k; ++j) acc = fmaf(K.Ginv[k][j] + (dj * 1.f) * K.Rinv[k][j], v[j], acc);
+                        qv[k] = acc;
+                    }
+#pragma unroll
+                    for (int m = 0; m < NT; ++m) {
+                        float acc = 0.f;
+#pragma unroll
+                        for (int k = 0; k < NT; ++k) acc = fmaf(K.Rm[m][k], qv[k], acc);
+                        wev[m] = (rhs[m] + acc) + da[m];
+                    }
+                    float ao[NT], bv[NT], dv2[NT], Dl2[NT];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) { ao[t] = a[t]; bv[t] = bb[t]; dv2[t] = dd[t]; Dl2[t] = 0.f; }
+                    mt1_eval<NT, false>(K, Q, PriorMem{lpr, 1}, wev, dj, thr, z, ao, bv, dv2, Dl2);
+                    bool ok = true;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) ok = ok && (dv2[t] == 1.f);
+                    if (__any(!ok)) { if (lane == 0) sflag[4 + s] = 1; ++nfailed; }
+                    else {
+                        ++nsolved;
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) { acur[t * B + c] = bo[t]; bcur[t * B + c] = bo[t]; dcur[t * B + c] = 1.f; }
+                    }
+                } else if (wave > s) apply_changes(s, rhs, pq);          // (optimistic: undone below if the verification failed)
+                lds_barrier();                                           // B4: the verdict
+                redo = sflag[4 + s] != 0;
+                if (redo) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) rhs[t] = rsv[t];
+                }
+            }
+            if (redo) {
+                if (wave == s) {
+                    // ---- walk section s (lane = marker 64 s + lane) on its strictly-upper diagonal tile, as dense_big_mt does
+                    const float* tile = tiles + s * 4096;
+                    float rs[NT], wev[NT], an[NT], bnw[NT], dn[NT];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) rs[t] = rhs[t];
+                    auto eval_own = [&](const float (&w)[NT], float (&ao)[NT], float (&bo)[NT], float (&d_o)[NT], float (&Dl)[NT]) {
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) { ao[t] = a[t]; bo[t] = bb[t]; d_o[t] = dd[t]; Dl[t] = 0.f; }
+                        mt1_eval<NT>(K, Q, PriorMem{lpr, 1}, w, dj, thr, z, ao, bo, d_o, Dl, Al, cl);
+                    };
+                    auto walk_mixed = [&](unsigned long long slow) {
+                        float g = tile[lane];
+#pragma unroll 1
+                        for (int l = 0; l < 64; ++l) {
+                            float w[NT], ao[NT], bo[NT], d_o[NT], Dl[NT];
+#pragma unroll
+                            for (int t = 0; t < NT; ++t) w[t] = rhs[t] + da[t];
+                            if ((slow >> l) & 1ull) eval_own(w, ao, bo, d_o, Dl);                         // (wave-uniform)
+                            else {
+                                mt1_linear_beta<NT>(Al, cl, w, bo);
+#pragma unroll
+                                for (int t = 0; t < NT; ++t) Dl[t] = a[t] - bo[t];
+                            }
+                            const float gl = g;
+                            g = tile[(l + 1 < 64 ? l + 1 : 63) * 64 + lane];
+#pragma unroll
+                            for (int t = 0; t < NT; ++t) {
+                                const float D = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Dl[t]), l));
+                                rhs[t] = fmaf(D, gl, rhs[t]);                                             // (strictly upper tile: lanes <= l are not moved)
+                            }
+                        }
+                    };
+                    // (one loop serves the all-fast case too: this path is the exception here, code size matters more than its speed)
+                    unsigned long long slow = __ballot(!in_all);
+                    if (__popcll(slow) * 4 > 64) slow = ~0ull;
+                    walk_mixed(slow);
+                    float Dl[NT];
+                    for (int pass = 0; pass < 64; ++pass) {
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) wev[t] = rhs[t] + da[t];                             // what the lane's marker was evaluated with
+                        eval_own(wev, an, bnw, dn, Dl);
+                        bool ok = true;
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) ok = ok && (dn[t] == 1.f);
+                        const unsigned long long bad = __ballot(!ok) & ~slow;
+                        if (bad == 0ull) break;
+                        slow |= bad;
+                        if (__popcll(slow) * 4 > 64) slow = ~0ull;
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) rhs[t] = rs[t];
+                        walk_mixed(slow);
+                        ++nredo;
+                    }
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        acur[t * B + c] = an[t]; bcur[t * B + c] = bnw[t]; dcur[t * B + c] = dn[t];
+                        rhs_lds[t * B + c] = a[t] - an[t];
+                    }
+                }
+                lds_barrier();                                           // B5
+                if (wave > s) apply_changes(s, rhs, pq);
+            }
+            // the section's changes are final: hand them to the helper workgroup that forms the NEXT block's lookahead correction
+            // (corr_helper_mt).  Write-through stores, acknowledged (vmcnt), then the flag -- the ordering of update_role's
+            // cooperative apply.  Nobody in THIS workgroup waits for anything: the walker of the next section is already at work.
+            if (wave == s) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    __hip_atomic_store(reinterpret_cast<int*>(A.xch + t * kB + c), __float_as_int(rhs_lds[t * B + c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_store(A.xch_flag, A.xch_epoch + s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (s + 1 < kSec && wave > s + 1) load_g(s + 1);
+        }
+        if (lane == 0 && nredo) atomicAdd(&A.counters[7], (unsigned long long)nredo);      // sections walked again
+        if (lane == 0 && (nsolved | nfailed)) {                                             // Rule T: sections solved / fallen back to the walk
+            atomicAdd(&A.counters[16], (unsigned long long)nsolved);
+            atomicAdd(&A.counters[17], (unsigned long long)nfailed);
+        }
+    } else {
+        // ============================ the solve (wave 4 + q: column quarter q of the section's inverse) ============================
+        const int q4 = __builtin_amdgcn_readfirstlane(wave - 4);        // (wave-uniform, and the compiler knows)
+        constexpr int QG = 4 * NT;                                       // column groups of four per quarter
+        v4f tq[NT][QG];
+        auto load_t = [&](int s) {
+            // buffer loads: ONE vector register (the lane's 16-byte offset) addresses all of them, the (group, trait) offset is a
+            // scalar operand
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(A.tsec + (int64_t)s * tsec_floats<NT>() + (int64_t)(q4 * QG) * (64 * NT) * 4), 0, 0x7fffffff, 0x00020000);
+            const unsigned voff = 16u * (unsigned)lane;
+#pragma unroll
+            for (int g = 0; g < QG; ++g)
+#pragma unroll
+                for (int k = 0; k < NT; ++k) {
+                    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+                    const v4u raw = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (unsigned)((g * (64 * NT) + k * 64) * 16), 0);
+                    tq[k][g] = __builtin_bit_cast(v4f, raw);
+                }
+        };
+        load_t(0);
+        lds_barrier();                                                                                  // B0
+#pragma unroll 1
+        for (int s = 0; s < kSec; ++s) {
+            const bool fast = sflag[s] != 0;
+            bool redo = !fast;
+            if (fast) {
+                lds_barrier();                                           // B1: y is there
+                {
+                    float acc[NT];
+#pragma unroll
+                    for (int k = 0; k < NT; ++k) acc[k] = 0.f;
+                    const v4f* y4 = reinterpret_cast<const v4f*>(ybuf) + q4 * QG;
+#pragma unroll
+                    for (int g = 0; g < QG; ++g) {
+                        const v4f yv = y4[g];                            // (broadcast read: columns 4 (q QG + g) .. + 3)
+#pragma unroll
+                        for (int k = 0; k < NT; ++k) {
+                            acc[k] = fmaf(tq[k][g].x, yv.x, acc[k]); acc[k] = fmaf(tq[k][g].y, yv.y, acc[k]);
+                            acc[k] = fmaf(tq[k][g].z, yv.z, acc[k]); acc[k] = fmaf(tq[k][g].w, yv.w, acc[k]);
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < NT; ++k) part[(q4 * NT + k) * 64 + lane] = acc[k];
+                }
+                __builtin_amdgcn_sched_barrier(0);                       // (the next section's loads AFTER this one's products: the registers are the same)
+                if (s + 1 < kSec) load_t(s + 1);
+                lds_barrier();                                           // B2: the partial products are there
+                lds_barrier();                                           // B3: D is there
+                lds_barrier();                                           // B4: the verdict
+                redo = sflag[4 + s] != 0;
+            }
+            if (redo) {
+                lds_barrier();                                           // B5
+                if (!fast && s + 1 < kSec) load_t(s + 1);
+            }
+        }
+    }
+    __syncthreads();
+    const long long tk4 = clock64();
+    // the block's change list in marker order
+    const bool rowthr = tid < kB;
+    const int c = rowthr ? tid : 0;
+    bool changed = false;
+    if (rowthr) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) changed = changed || (astart[t * B + c] != acur[t * B + c]);
+    }
+    const unsigned long long cm = __ballot(changed);
+    if (lane == 0) wcnt[wave] = __popcll(cm);
+    __syncthreads();
+    int base = 0, nfin = 0;
+#pragma unroll
+    for (int q = 0; q < kStepThreads / 64; ++q) { const int v = wcnt[q]; base += (q < wave) ? v : 0; nfin += v; }
+    // ---- global stores last
+    if (changed) {
+        const int e = base + __popcll(cm & ((1ull << lane) - 1ull));
+        A.ev_out->idx[e] = (int32_t)(j0 + c);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) A.ev_out->delta[t][e] = astart[t * B + c] - acur[t * B + c];
+    }
+    if (rowthr) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float a_fin = acur[t * B + c];
+            if (a_fin != astart[t * B + c]) A.alpha[(int64_t)t * p + j0 + c] = a_fin;
+            A.beta[(int64_t)t * p + j0 + c] = bcur[t * B + c];
+            delta[(int64_t)t * p + j0 + c] = dcur[t * B + c];
+        }
+    }
+    if (tid == 0) {
+        A.ev_out->count = (int32_t)nfin;
+        atomicAdd(&A.counters[0], (unsigned long long)nfin);
+        atomicAdd(&A.counters[2], (unsigned long long)(tk1 - tk0));      // front
+        atomicAdd(&A.counters[5], (unsigned long long)(tk4 - tk1));      // sections (solves / walks + off-diagonal applies)
+    }
+}
+
+// The HELPER workgroup of a Rule T launch (workgroup 8: on the sampler's XCD; sweep.hpp): the lookahead correction of the NEXT
+// block,  corr[t][c'] = fmaf(D_e[t], C[e][c'], corr)  from 0 over the markers e of the block in marker order  (C = X_this'X_next),
+// from the changes the sampler workgroup publishes section by section (A.xch, A.xch_flag) -- the cross-Gram block (256 KB) and
+// three quarters of the block's off-diagonal multiply-adds no longer go through the sampler's CU.  Thread c' < 256 owns column
+// c'; the section's 64 cross-Gram values per thread are fetched a section ahead.  The wait is one-directional (the sampler
+// workgroup waits for nobody and is dispatched before this one), its result is consumed by the NEXT launch.  Same operations
+// in the same order as the in-workgroup form: bit-identical.
+template <int NT>
+__device__ __forceinline__ void corr_helper_mt(char* smem, const SamplerArgs& A)
+{
+    constexpr int kB = 256, kSec = 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int bn = A.b_next, B = A.bsz;
+    float* dl = reinterpret_cast<float*>(smem);                          // [NT][64] the section's changes
+    int* seen = reinterpret_cast<int*>(dl + NT * 64);
+    const bool colthr = tid < bn && tid < kB;
+    const int cn = colthr ? tid : 0;
+    float corr[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) corr[t] = 0.f;
+    float pq[64];
+    auto load_c = [&](int s) {
+        const char* base = reinterpret_cast<const char*>(A.cross_next + (int64_t)(64 * s) * bn);
+        unsigned off = 4u * (unsigned)cn;
+#pragma unroll
+        for (int u = 0; u < 64; ++u) { pq[u] = *reinterpret_cast<const float*>(base + off); off += 4u * (unsigned)bn; asm volatile("" : "+v"(off)); }
+    };
+    if (bn > 0 && tid < kB) load_c(0);
+#pragma unroll 1
+    for (int s = 0; s < kSec; ++s) {
+        if (tid == 0) {
+            while (__hip_atomic_load(A.xch_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (A.xch_epoch + s + 1) < 0) __builtin_amdgcn_s_sleep(8);
+            *seen = 1;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // (LDS only: the cross-Gram loads stay in flight)
+        if (tid < NT * 64) {
+            const int t = tid >> 6;
+            dl[tid] = __int_as_float(__hip_atomic_load(reinterpret_cast<const int*>(A.xch + t * kB + 64 * s + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+        __syncthreads();
+        if (bn > 0 && tid < kB) {
+            apply_section_changes<NT>(dl, 64, corr, pq);
+            if (s + 1 < kSec) load_c(s + 1);
+        }
+        __syncthreads();                                                     // (dl is rewritten for the next section)
+    }
+    if (bn > 0 && tid < kB) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) A.corr_out[t * B + tid] = colthr ? corr[t] : 0.f;
+    }
+}
+
 template <int METHOD, int NT, bool DW = false>
 __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A)
 {
@@ -851,7 +1388,7 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
 #pragma unroll
     for (int a = 0; a < NT; ++a) {
 #pragma unroll
-        for (int c = 0; c < NT; ++c) { K.Rinv[a][c] = P->Rinv[a * NT + c]; K.Ginv[a][c] = P->Ginv[a * NT + c]; }
+        for (int c = 0; c < NT; ++c) { K.Rinv[a][c] = P->Rinv[a * NT + c]; K.Ginv[a][c] = P->Ginv[a * NT + c]; K.Rm[a][c] = P->vare[a * NT + c]; }
         K.invG[a] = 1.0f / K.Ginv[a][a];                            // MTBayesABC.jl:92
         K.lG[a] = logf_via_double(K.Ginv[a][a]);
         K.sG[a] = sqrtf(K.invG[a]);
@@ -1075,6 +1612,11 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
         if constexpr (is_sampler1(METHOD)) {
             if (big_try) {
                 finish_tiles();
+                // (Rule T launches: the host sets tsec exactly for the blocks that meet big_try, and the helper workgroup then counts on
+                // the sampler to publish every section's changes)
+                if constexpr (NT <= 3) {
+                    if (A.tsec != nullptr) { dense_big_mt_solve<METHOD, NT>(smem, SM, A, consts_of(tid < 256 ? tid : 0), lpr, tk0, clock64()); return; }
+                }
                 dense_big_mt<METHOD, NT>(smem, SM, A, consts_of(tid < 256 ? tid : 0), lpr, tk0, clock64());
                 return;
             }

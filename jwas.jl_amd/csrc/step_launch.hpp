@@ -28,6 +28,11 @@ hipError_t launch_step_mtb1(const StepLaunch& L, int nt, const UpdateArgs& U, co
 hipError_t launch_step_mt2(const StepLaunch& L, int method, int nt, const UpdateArgs& U, const SamplerArgs& S, int do_sample, bool dense);
 hipError_t launch_step_mega(const StepLaunch& L, int method, int nt, const UpdateArgs& U, const SamplerArgs& S, int do_sample, bool dense);
 
+// Rule T (jwas_sweep_params.section_solve): the inverses of all 64-marker sections of the full 256-marker blocks, once per sweep
+// (k_section_inverse_mt; nsections = 4 per full block, tsec: nsections * (64 nt)^2 floats)
+hipError_t launch_section_inverse_mtc1(const StepLaunch& L, int nt, const DevParams* P, const float* xpx, const float* gram, int64_t nsections, float* tsec);
+hipError_t launch_section_inverse_mtb1(const StepLaunch& L, int nt, const DevParams* P, const float* xpx, const float* gram, const float* ginv_mat, int64_t nsections, float* tsec);
+
 // independent-block sweeps: k_indep_rhs + k_indep_sample
 hipError_t launch_indep_st(const StepLaunch& L, int method, const UpdateArgs& U, const SamplerArgs& S, int64_t pstride, bool dense);
 hipError_t launch_indep_mtc1(const StepLaunch& L, int nt, const UpdateArgs& U, const SamplerArgs& S, int64_t pstride);

@@ -56,7 +56,8 @@ hipError_t launch_step_cx(const StepLaunch& L, const CX& cx, const UpdateArgs& U
     constexpr int dbg = 0;
 #endif
     const int nwork = L.nrg * U.ncg;
-    const unsigned grid = (dbg == 2) ? 1u : (U.quiet_xcd ? (unsigned)(1 + (nwork + 6) / 7 * 8) : (unsigned)(1 + nwork));
+    unsigned grid = (dbg == 2) ? 1u : (U.quiet_xcd ? (unsigned)(1 + (nwork + 6) / 7 * 8) : (unsigned)(1 + nwork));
+    if (S.tsec != nullptr && do_sample && grid < 17u) grid = 17u;      // Rule T: workgroup 16 is the helper the sampler publishes to (sweep.hpp)
     const int ds = (dbg == 1) ? 0 : do_sample;
     if constexpr (kHasDense) {
         if (dn) {       // uniform pi = 0: the sampler that follows Rule D (and takes dense_big_st on full 256- / 512-marker blocks)
@@ -130,6 +131,24 @@ hipError_t launch_indep(const StepLaunch& L, const UpdateArgs& U, const SamplerA
 {
     if (L.packed) return launch_indep_cx<METHOD, NT, PackedCols>(L, L.pc, U, S, pstride, dense);
     return launch_indep_cx<METHOD, NT, DenseCols>(L, L.dc, U, S, pstride, dense);
+}
+
+template <int METHOD, int NT>
+hipError_t launch_section_inverse(const StepLaunch& L, const DevParams* P, const float* xpx, const float* gram, const float* ginv_mat,
+                                  int64_t nsections, float* tsec)
+{
+    static std::atomic<unsigned long long> attr_set{0ull};
+    const unsigned long long dev_bit = 1ull << (L.device & 63);
+    if (!(attr_set.load(std::memory_order_acquire) & dev_bit)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_section_inverse_mt<METHOD, NT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set.fetch_or(dev_bit, std::memory_order_release);
+    }
+    if (nsections <= 0) return hipSuccess;
+    hipLaunchKernelGGL((k_section_inverse_mt<METHOD, NT>), dim3((unsigned)nsections), dim3(64 * NT), tsec_inverse_lds_bytes<NT>(), L.stream,
+                       P, xpx, gram, ginv_mat, tsec);
+    return hipGetLastError();
 }
 
 }  // namespace

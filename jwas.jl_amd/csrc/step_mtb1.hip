@@ -12,4 +12,11 @@ hipError_t launch_step_mtb1(const StepLaunch& L, int nt, const UpdateArgs& U, co
     return launch_step<kMTBayesB1, 4>(L, U, S, do_sample, dense);
 }
 
+hipError_t launch_section_inverse_mtb1(const StepLaunch& L, int nt, const DevParams* P, const float* xpx, const float* gram, const float* ginv_mat, int64_t nsections, float* tsec)
+{
+    if (nt == 2) return launch_section_inverse<kMTBayesB1, 2>(L, P, xpx, gram, ginv_mat, nsections, tsec);
+    if (nt == 3) return launch_section_inverse<kMTBayesB1, 3>(L, P, xpx, gram, ginv_mat, nsections, tsec);
+    return launch_section_inverse<kMTBayesB1, 4>(L, P, xpx, gram, ginv_mat, nsections, tsec);
+}
+
 }  // namespace jw

@@ -12,6 +12,13 @@ hipError_t launch_step_mtc1(const StepLaunch& L, int nt, const UpdateArgs& U, co
     return launch_step<kMTBayesC1, 4>(L, U, S, do_sample, dense);
 }
 
+hipError_t launch_section_inverse_mtc1(const StepLaunch& L, int nt, const DevParams* P, const float* xpx, const float* gram, int64_t nsections, float* tsec)
+{
+    if (nt == 2) return launch_section_inverse<kMTBayesC1, 2>(L, P, xpx, gram, nullptr, nsections, tsec);
+    if (nt == 3) return launch_section_inverse<kMTBayesC1, 3>(L, P, xpx, gram, nullptr, nsections, tsec);
+    return launch_section_inverse<kMTBayesC1, 4>(L, P, xpx, gram, nullptr, nsections, tsec);
+}
+
 hipError_t launch_indep_mtc1(const StepLaunch& L, int nt, const UpdateArgs& U, const SamplerArgs& S, int64_t pstride)
 {
     if (nt == 2) return launch_indep<kMTBayesC1, 2>(L, U, S, pstride);

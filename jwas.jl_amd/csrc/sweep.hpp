@@ -138,14 +138,15 @@ __global__ __launch_bounds__(kStepThreads) void k_block_step(UpdateArgsT<CX> U, 
             if (blockIdx.x == 8 && do_sample && (S.bsz == 256 || S.bsz == 512) && !S.dense_big_off) {
                 const int nl_g = (S.gram_next != nullptr) ? (S.b_next * S.b_next + 31) / 32 : 0;
                 const int nl_c = (S.cross_after != nullptr) ? S.lines_after : 0;
+                const int nl_t = (S.tsec_next != nullptr) ? S.tsec_lines : 0;          // Rule T: the next block's section inverses
                 float sink = 0.f;
-                for (int l0 = 0; l0 < nl_g + nl_c; l0 += 8 * kStepThreads) {
+                for (int l0 = 0; l0 < nl_g + nl_c + nl_t; l0 += 8 * kStepThreads) {
                     float v[8];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         int l = l0 + u * kStepThreads + (int)threadIdx.x;
-                        l = l < nl_g + nl_c ? l : nl_g + nl_c - 1;
-                        v[u] = (l < nl_g) ? S.gram_next[(int64_t)l * 32] : S.cross_after[(int64_t)(l - nl_g) * 32];
+                        l = l < nl_g + nl_c + nl_t ? l : nl_g + nl_c + nl_t - 1;
+                        v[u] = (l < nl_g) ? S.gram_next[(int64_t)l * 32] : (l < nl_g + nl_c ? S.cross_after[(int64_t)(l - nl_g) * 32] : S.tsec_next[(int64_t)(l - nl_g - nl_c) * 32]);
                     }
 #pragma unroll
                     for (int u = 0; u < 8; ++u) sink += v[u];
@@ -153,6 +154,12 @@ __global__ __launch_bounds__(kStepThreads) void k_block_step(UpdateArgsT<CX> U, 
                 asm volatile("" ::"v"(sink));
                 return;
             }
+        }
+        if constexpr (DENSE && is_sampler1(METHOD) && NT <= 3) {
+            // Rule T launches (S.tsec: multi-trait sampler I, sampler_mt.hpp): workgroup 16 -- another idle one on the sampler's XCD --
+            // forms the next block's lookahead correction from the changes the sampler workgroup publishes (the launcher makes
+            // sure the grid holds it)
+            if (blockIdx.x == 16 && do_sample && S.tsec != nullptr) { corr_helper_mt<NT>(smem, S); return; }
         }
         if ((blockIdx.x & 7) == 0) return;
         w = (int)(blockIdx.x - 1) - (int)((blockIdx.x - 1) >> 3);

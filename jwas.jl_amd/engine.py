@@ -328,6 +328,12 @@ class HipEngine:
         """r_trait += shift on the device (the intercept's residual correction; no host copy of the residual)."""
         self._chk(self._L.jwas_hip_residual_add_scalar(self._h, int(trait), float(shift)))
 
+    def last_sweep_counters(self):
+        """The sampler's diagnostics counters of the last sweep (jwas_hip_last_sweep_counters)."""
+        out = (C.c_uint64 * 24)()
+        self._chk(self._L.jwas_hip_last_sweep_counters(self._h, out, 24))
+        return [int(v) for v in out]
+
     def set_kernel_timing(self, stride):
         self._chk(self._L.jwas_hip_set_kernel_timing(self._h, int(stride)))
 
@@ -440,7 +446,7 @@ class HipEngine:
 
     def sweep(self, *, iteration, seed, vare, var_effect, pi=0.0, pi_classes=None, gamma=BAYESR_GAMMA,
               log_prior_states=None, var_effect_vec=None, var_effect_matrix=None, pi_vec=None, pi_matrix=None, nreps=1,
-              marker_offset=0, independent_blocks=False, _sharded=False):
+              marker_offset=0, independent_blocks=False, section_solve=False, _sharded=False):
         """One marker sweep.  Argument meaning follows BayesABC!/BayesR!/MTBayesABC!:
         vare: residual variance (scalar or t x t); var_effect: marker effect variance (BayesC scalar,
         BayesR sigmaSq, MT t x t); pi: Pr(effect = 0) scalar, or pi_vec per marker (length p, else the
@@ -450,6 +456,7 @@ class HipEngine:
         P.method, P.ntraits, P.nreps = self.method, t, int(nreps)
         P.iteration, P.seed, P.marker_offset = int(iteration), int(seed), int(marker_offset)
         P.independent_blocks = 1 if independent_blocks else 0          # BayesABC_block_independent! (BayesABC.jl:190-255)
+        P.section_solve = 1 if section_solve else 0                    # Rule T: dense chains as triangular solves (jwas_hip.h)
         ve = np.asarray(vare, dtype=np.float32).reshape(-1)
         vg = np.asarray(var_effect, dtype=np.float32).reshape(-1)
         if ve.size != t * t or vg.size != t * t:

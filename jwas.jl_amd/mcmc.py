@@ -489,6 +489,7 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         # the markers' own covariances are parked in LDS beside their draws (sampler_mt.hpp): known before anything is loaded
         raise NotImplementedError(f"multi-trait BayesA/B needs fast_blocks * traits <= 2048 on the device (got {block_size} x {t})")
     adaptive = False
+    section_solve = False
     if block_size is None:
         # Device block size.  Sparse priors (few markers change per sweep): big blocks amortise the per-launch cost.
         # Dense priors (every marker is in the model: Pi = 0 / BayesA / the multi-trait default of all-ones) change
@@ -514,6 +515,10 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
             block_size //= 2
         while mt_pervar and block_size * t > 2048:                      # the markers' own constants are parked in LDS
             block_size //= 2
+        # Rule T (jwas_sweep_params.section_solve, round 5): the dense 256-marker blocks of sampler I as triangular solves with
+        # per-sweep section inverses (at most three traits, Float32 context, the plain single-pass schedule)
+        section_solve = bool(dense and mt_big and t <= 3 and block_size == 256 and not double_precision and fast_blocks is False
+                             and not independent_blocks)
         # Sparse priors: keep a second, larger block size resident and pick per sweep from the previous sweep's number
         # of effect changes (a chain quantity, so runs stay reproducible): 1024-marker blocks amortise the per-launch cost
         # once fewer than ~1.3 % of the markers change per sweep (measured crossover at 50k x 600k: 8 900 changes).
@@ -734,6 +739,8 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
             kw = dict(iteration=it, seed=seed_int, vare=vare, nreps=nreps)
             if independent_blocks:
                 kw["independent_blocks"] = True
+            if section_solve:
+                kw["section_solve"] = True
             if mega:
                 kw.update(var_effect=Gval, pi=pi_t)
                 if mt_pervar:

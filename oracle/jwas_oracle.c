@@ -586,8 +586,8 @@ static inline const float* marker_ginv(int64_t j, int t, const float* Ginv_all, 
 static int g_mt_linear = 1;
 void orc_set_mt_linear_form(int on) { g_mt_linear = on; }
 
-static inline void mt1_linear(int t, const float* w, float d, const float* Rinv, const float* Ginv, const float* b_old,
-                              const double* z, float* b_new)
+static inline void mt1_linear_coeffs(int t, float d, const float* Rinv, const float* Ginv, const float* b_old, const double* z,
+                                     float* Af /* t x t */, float* cf /* t */)
 {
     double Ad[ORC_MAXT][ORC_MAXT], cd[ORC_MAXT];
     for (int k = 0; k < t; ++k) {
@@ -607,10 +607,24 @@ static inline void mt1_linear(int t, const float* w, float d, const float* Rinv,
         cd[k] = il * acc + z[k] * (double)sqrtf(invLhs1);
     }
     for (int k = 0; k < t; ++k) {
-        float v = (float)cd[k];
-        for (int m = 0; m < t; ++m) v = fmaf((float)Ad[k][m], w[m], v);
+        cf[k] = (float)cd[k];
+        for (int m = 0; m < t; ++m) Af[k * t + m] = (float)Ad[k][m];
+    }
+}
+static inline void mt1_linear_beta(int t, const float* Af, const float* cf, const float* w, float* b_new)
+{
+    for (int k = 0; k < t; ++k) {
+        float v = cf[k];
+        for (int m = 0; m < t; ++m) v = fmaf(Af[k * t + m], w[m], v);
         b_new[k] = v;
     }
+}
+static inline void mt1_linear(int t, const float* w, float d, const float* Rinv, const float* Ginv, const float* b_old,
+                              const double* z, float* b_new)
+{
+    float Af[ORC_MAXT * ORC_MAXT], cf[ORC_MAXT];
+    mt1_linear_coeffs(t, d, Rinv, Ginv, b_old, z, Af, cf);
+    mt1_linear_beta(t, Af, cf, w, b_new);
 }
 
 /* One marker.  w[k] = x'r_k + d*alpha_old_k already formed.  Writes axpy coefficients a[k]. */
@@ -1026,6 +1040,138 @@ int orc_bayesr_lookahead_sweep(const float* X, int64_t n, int64_t p, int64_t ld,
     return 0;
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* RULE T (the device's jwas_sweep_params.section_solve; csrc/sampler_mt.hpp): the dense chain of a */
+/* 64-marker section as the triangular solve it is.  Sampler I, full 256-marker blocks, single     */
+/* pass.  A section in which every marker is in the model for every trait at entry: Rule L makes   */
+/* its chain (I + L) D = y,  L[(l,k),(j,m)] = A_l[k][m] G_lj (j < l),  y_l = alpha_l - (A_l (rhs_l */
+/* + d_l alpha_l) + c_l),  D = alpha_old - alpha_new.  The device forms T = (I + L)^-1 once per     */
+/* sweep (k_section_inverse_mt) and a section's effects with one mat-vec D~ = T y; the literal     */
+/* evaluation (MTBayesABC.jl:85-120) at the right-hand side those effects imply verifies that every */
+/* indicator stays 1, otherwise the section runs through the sequential chain.  Restated operation  */
+/* for operation (same accumulation types and orders), so that the comparison stays bit for bit:    */
+/*   T column (jc, mc): rows of markers l < jc are 0, of jc the identity; for l > jc                 */
+/*       u_m = sum_{j=jc}^{l-1} fma(G_lj, T[(j,m)], u_m)   (double, ascending j)                     */
+/*       T[(l,k)] = fl32( -( sum_m fma(A_l[k][m], u_m, .) ) )  (double, ascending m)                 */
+/*   D~[(l,k)] = (p0 + p1) + (p2 + p3),  p_q = fmaf chain (float, from 0) over the columns           */
+/*       c = m*64 + j in [16 t q, 16 t (q+1)), ascending                                              */
+/*   alpha_new = alpha - D~ ;  D = alpha - alpha_new ;  rhs~ = rhs + R Lc (y - D~)                    */
+/* Reference chain it stands for: MTBayesABC.jl:243-333 (block form of sampler I).                  */
+/* ------------------------------------------------------------------------------------------ */
+static int g_section_solve = 0;
+void orc_set_section_solve(int on) { g_section_solve = on; }
+static int64_t g_solve_sections = 0, g_solve_fallbacks = 0;      /* diagnostics: sections solved / fallen back since the last reset */
+void orc_section_solve_counts(int64_t* solved, int64_t* fallbacks, int reset)
+{
+    if (solved) *solved = g_solve_sections;
+    if (fallbacks) *fallbacks = g_solve_fallbacks;
+    if (reset) { g_solve_sections = 0; g_solve_fallbacks = 0; }
+}
+
+/* One 64-marker section [c0, c0 + 64) of a 256-marker block.  Returns 1 if it was solved (state, rhs_b updated), 0 if the
+ * caller has to run it through the sequential chain (nothing touched). */
+static int mt1_section_solve(int t, int64_t p, int64_t j0, int64_t b, int64_t c0, const float* G, const float* xpx,
+                             float* rhs_b, float* alpha, float* beta, float* delta,
+                             const float* vare, const float* Rinv, const float* Ginv_shared,
+                             const double* log_prior, uint64_t seed, uint32_t iter, uint32_t marker0)
+{
+    enum { S = 64 };
+    const int nr = S * t;
+    for (int l = 0; l < S; ++l)
+        for (int k = 0; k < t; ++k) if (delta[k * p + j0 + c0 + l] != 1.0f) return 0;
+    float* A   = (float*)malloc(sizeof(float) * (size_t)(S * t * t));
+    float* cc  = (float*)malloc(sizeof(float) * (size_t)(S * t));
+    float* y   = (float*)malloc(sizeof(float) * (size_t)nr);           /* [m*64 + j] */
+    float* T   = (float*)calloc((size_t)nr * nr, sizeof(float));       /* [row (l,k) = k*64 + l][col m*64 + j] */
+    float* Dt  = (float*)malloc(sizeof(float) * (size_t)nr);           /* [k*64 + l] */
+    float* Gi  = (float*)malloc(sizeof(float) * (size_t)(S * t * t));  /* each marker's Ginv */
+    float Gtmp[ORC_MAXT * ORC_MAXT];
+    for (int l = 0; l < S; ++l) {
+        const int64_t j = j0 + c0 + l;
+        const float* Gl = marker_ginv(j, t, Ginv_shared, Gtmp);
+        memcpy(Gi + l * t * t, Gl, sizeof(float) * (size_t)(t * t));
+        float b_old[ORC_MAXT], w[ORC_MAXT], bo[ORC_MAXT];
+        double z[ORC_MAXT];
+        for (int k = 0; k < t; ++k) { b_old[k] = beta[k * p + j]; z[k] = orc_normal(seed, marker0 + (uint32_t)j, iter, 0, (uint32_t)k); }
+        mt1_linear_coeffs(t, xpx[j], Rinv, Gi + l * t * t, b_old, z, A + l * t * t, cc + l * t);
+        for (int k = 0; k < t; ++k) w[k] = rhs_b[k * b + c0 + l] + xpx[j] * alpha[k * p + j];
+        mt1_linear_beta(t, A + l * t * t, cc + l * t, w, bo);
+        for (int k = 0; k < t; ++k) y[k * S + l] = alpha[k * p + j] - bo[k];
+    }
+    for (int mc = 0; mc < t; ++mc)
+        for (int jc = 0; jc < S; ++jc) {
+            const int col = mc * S + jc;
+            for (int k = 0; k < t; ++k) T[(size_t)(k * S + jc) * nr + col] = (k == mc) ? 1.0f : 0.0f;
+            for (int l = jc + 1; l < S; ++l) {
+                double u[ORC_MAXT];
+                for (int m = 0; m < t; ++m) u[m] = 0.0;
+                for (int j = jc; j < l; ++j) {
+                    const double g = (double)G[(c0 + l) * b + c0 + j];
+                    for (int m = 0; m < t; ++m) u[m] = fma(g, (double)T[(size_t)(m * S + j) * nr + col], u[m]);
+                }
+                for (int k = 0; k < t; ++k) {
+                    double v = 0.0;
+                    for (int m = 0; m < t; ++m) v = fma((double)A[l * t * t + k * t + m], u[m], v);
+                    T[(size_t)(k * S + l) * nr + col] = (float)(-v);
+                }
+            }
+        }
+    const int qc = 16 * t;                                                  /* columns per quarter */
+    for (int r = 0; r < nr; ++r) {
+        float pq[4];
+        for (int q = 0; q < 4; ++q) {
+            float acc = 0.0f;
+            for (int cidx = qc * q; cidx < qc * (q + 1); ++cidx) acc = fmaf(T[(size_t)r * nr + cidx], y[cidx], acc);
+            pq[q] = acc;
+        }
+        Dt[r] = (pq[0] + pq[1]) + (pq[2] + pq[3]);
+    }
+    /* the new effects, and the verification of every marker (nothing is written before all of them passed) */
+    float* bo_all = (float*)malloc(sizeof(float) * (size_t)nr);
+    int ok = 1;
+    const int lin_save = g_mt_linear;
+    for (int l = 0; l < S && ok; ++l) {
+        const int64_t j = j0 + c0 + l;
+        const float d = xpx[j];
+        const float* Gl = Gi + l * t * t;
+        float v[ORC_MAXT], q[ORC_MAXT], wev[ORC_MAXT], ta[ORC_MAXT], tb[ORC_MAXT], td[ORC_MAXT], aout[ORC_MAXT];
+        for (int k = 0; k < t; ++k) {
+            bo_all[k * S + l] = alpha[k * p + j] - Dt[k * S + l];
+            v[k] = y[k * S + l] - Dt[k * S + l];
+        }
+        for (int k = 0; k < t; ++k) {
+            const float C11 = Gl[k * t + k] + Rinv[k * t + k] * d;
+            float acc = C11 * v[k];
+            for (int jj = 0; jj < k; ++jj) acc = fmaf(Gl[k * t + jj] + (d * 1.0f) * Rinv[k * t + jj], v[jj], acc);
+            q[k] = acc;
+        }
+        for (int m = 0; m < t; ++m) {
+            float acc = 0.0f;
+            for (int k = 0; k < t; ++k) acc = fmaf(vare[m * t + k], q[k], acc);
+            wev[m] = (rhs_b[m * b + c0 + l] + acc) + d * alpha[m * p + j];
+        }
+        for (int k = 0; k < t; ++k) { ta[k] = alpha[k * p + j]; tb[k] = beta[k * p + j]; td[k] = delta[k * p + j]; }
+        g_mt_linear = 0;                                                       /* the literal order: decisions only */
+        mt1_update(t, wev, d, ta, tb, td, 1, Rinv, Gl, log_prior, seed, marker0 + (uint32_t)j, iter, 0, aout);
+        g_mt_linear = lin_save;
+        for (int k = 0; k < t; ++k) if (td[k] != 1.0f) ok = 0;
+    }
+    if (ok) {
+        for (int l = 0; l < S; ++l) {
+            const int64_t j = j0 + c0 + l;
+            for (int k = 0; k < t; ++k) {
+                const float a_old = alpha[k * p + j], bn = bo_all[k * S + l];
+                const float D = a_old - bn;
+                alpha[k * p + j] = bn; beta[k * p + j] = bn; delta[k * p + j] = 1.0f;
+                if (D != 0.0f) axpy_f32(D, G + (c0 + l) * b, rhs_b + k * b, b);       /* later sections see the changes in marker order */
+            }
+        }
+        ++g_solve_sections;
+    } else ++g_solve_fallbacks;
+    free(A); free(cc); free(y); free(T); free(Dt); free(Gi); free(bo_all);
+    return ok;
+}
+
 int orc_mt_lookahead_sweep(int kind, const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
                                    const int64_t* block_starts, int64_t nblocks, const float* grams,
                                    int t, float* r, int64_t ld_r, float* alpha, float* beta, float* delta,
@@ -1050,8 +1196,15 @@ int orc_mt_lookahead_sweep(int kind, const float* X, int64_t n, int64_t p, int64
         la_block_rhs(&L, t, r, ld_r, j0, b, jprev, bprev, dprev, rhs_b);
         for (int k = 0; k < t; ++k) memcpy(a0 + k * b, alpha + k * p + j0, sizeof(float) * (size_t)b);
         const int nreps = nreps_arg > 0 ? nreps_arg : (int)b;
+        /* Rule T (above): full 256-marker blocks of sampler I in a single pass, section by section */
+        const int solve = g_section_solve && kind == MT_SAMPLER_I && b == 256 && nreps == 1 && !prior_is_matrix && t <= 3;
         for (int rep = 0; rep < nreps; ++rep)
             for (int64_t c = 0; c < b; ++c) {
+                if (solve && (c & 63) == 0 &&
+                    mt1_section_solve(t, p, j0, b, c, G, xpx, rhs_b, alpha, beta, delta, vare, Rinv, Ginv, log_prior, seed, iter, marker0)) {
+                    c += 63;
+                    continue;
+                }
                 const int64_t j = j0 + c;
                 float w[ORC_MAXT], a[ORC_MAXT];
                 for (int k = 0; k < t; ++k) w[k] = rhs_b[k * b + c];

@@ -164,6 +164,10 @@ void orc_set_var_effect_matrix(const float* mat);
 void orc_set_mt_linear_form(int on);
 /* Rule D of single-trait BayesA/B/C sweeps under a uniform pi = 0 (see abc_update): 1 = on, 0 = the literal order (default). */
 void orc_set_abc_rule_d(int on);
+/* Rule T (the device's jwas_sweep_params.section_solve; see mt1_section_solve / abc_section_solve): dense 64-marker sections of
+ * the lookahead forms' full blocks as triangular solves.  1 = on, 0 = the sequential chain (default). */
+void orc_set_section_solve(int on);
+void orc_section_solve_counts(int64_t* solved, int64_t* fallbacks, int reset);
 /* One InverseWishart(df, scale + b_j b_j') draw per marker (variance_components.jl:181-186; df = the reference's df + 1),
  * Bartlett on the counter RNG: the restatement the device's k_sample_marker_covariances is compared with. */
 void orc_sample_marker_covariances(int t, int64_t p, const float* beta, double df, const double* scale,

@@ -142,6 +142,17 @@ def _vec_or_fill(v, p, dtype):
 RULE_D = True        # (tests switch the rule off to compare with the literal operation order)
 
 
+def set_section_solve(on):
+    """Rule T (the device's section_solve): dense sections of the lookahead forms' full blocks as triangular solves."""
+    lib().orc_set_section_solve(C.c_int(1 if on else 0))
+
+
+def section_solve_counts(reset=False):
+    a, b = C.c_int64(0), C.c_int64(0)
+    lib().orc_section_solve_counts(C.byref(a), C.byref(b), C.c_int(1 if reset else 0))
+    return int(a.value), int(b.value)
+
+
 def bayesabc_sweep(X, xpx_, r, alpha, beta, delta, vare, var_effects, pi, seed, it,
                    marker0=0, acc=ACC_F64, block_starts=None, grams=None, nreps=1, lookahead=False, independent=False):
     """In-place sweep.  block_starts=None -> non-block form (BayesABC.jl:60-80); lookahead=True ->

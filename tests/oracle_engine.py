@@ -159,7 +159,7 @@ class OracleEngine:
 
     def sweep(self, *, iteration, seed, vare, var_effect, pi=0.0, pi_classes=None, gamma=O.GAMMA,
               log_prior_states=None, var_effect_vec=None, var_effect_matrix=None, pi_vec=None, pi_matrix=None, nreps=1,
-              marker_offset=0, independent_blocks=False):
+              marker_offset=0, independent_blocks=False, section_solve=False):
         t = self.ntraits
         blk = (dict(block_starts=self._bs, grams=self._grams, nreps=nreps, lookahead=(self.form == "lookahead"),
                     independent=bool(independent_blocks))
@@ -176,10 +176,12 @@ class OracleEngine:
             assert vm.shape == (self.p, t, t)
             O.set_var_effect_matrix(vm)
             var_effect = np.eye(t, dtype=np.float32)  # (unused)
+        O.set_section_solve(bool(section_solve) and self.form == "lookahead" and not independent_blocks)      # Rule T (the device's section_solve)
         try:
             self._sweep_inner(t, blk, iteration, seed, vare, var_effect, pi, pi_classes, gamma, log_prior_states,
                               var_effect_vec, pi_vec, pi_matrix, marker_offset)
         finally:
+            O.set_section_solve(False)
             O.set_weights(None)
             O.set_var_effect_matrix(None)
         return self._stats(a_before, gamma)
