@@ -82,7 +82,7 @@ struct jwas_hip_ctx {
     double* mt2_tab = nullptr;          // sampler II, <= 3 traits: [2^t * (t(t+1)/2 + 1)][p] state tables
     float*  tsec = nullptr;             // Rule T (section_solve): the section inverses of the current sweep, [sections][(64 t)^2]
     size_t  tsec_cap = 0;               // ... capacity in floats
-    float*  xch = nullptr;              // Rule T: [kMaxT][256] floats + the flag: the sampler workgroup's hand-over to the helper workgroup
+    unsigned long long* xch = nullptr;  // Rule T: [kMaxT][256] {value, tag} words: the sampler workgroup's hand-over to the helper workgroup
     int     xch_epoch = 0;              // ... grows by 8 per launch
     float*  Xout = nullptr;             // output (EBV) rows: [p][ld_out] fp32, Mi.output_genotypes (tools4genotypes.jl:290-296)
     int64_t n_out = 0, ld_out = 0;
@@ -1681,8 +1681,8 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
             c->tsec_cap = need;
         }
         if (!c->xch) {
-            HIPCHK(c, hipMalloc(&c->xch, sizeof(float) * (kMaxT * 256 + 64)));
-            HIPCHK(c, hipMemsetAsync(c->xch, 0, sizeof(float) * (kMaxT * 256 + 64), c->stream));
+            HIPCHK(c, hipMalloc(&c->xch, sizeof(unsigned long long) * kMaxT * 256));
+            HIPCHK(c, hipMemsetAsync(c->xch, 0, sizeof(unsigned long long) * kMaxT * 256, c->stream));
         }
         const StepLaunch L = step_launch_of(c);
         if (c->method == JWAS_HIP_MTBAYESB1) HIPCHK(c, launch_section_inverse_mtb1(L, t, c->dparams, c->xpx, c->gram, c->ginv_mat, solve_blocks * 4, c->tsec));
@@ -1749,7 +1749,7 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
             S.tsec_next = (sb + 1 < solve_blocks) ? c->tsec + (size_t)(sb + 1) * 4 * tsf : nullptr;
             S.tsec_lines = (int)(4 * tsf / 32);
             if (S.tsec != nullptr) {       // (the helper workgroup lives on the quiet XCD: ids = 0 mod 8 do no streaming)
-                S.xch = c->xch; S.xch_flag = reinterpret_cast<int*>(c->xch + kMaxT * 256); c->xch_epoch += 8; S.xch_epoch = c->xch_epoch;
+                S.xch = c->xch; c->xch_epoch += 8; S.xch_epoch = c->xch_epoch;
                 U.quiet_xcd = 1;
             }
             S.lines_after = (sb + 2 < nb) ? (int)(((int64_t)blk_b(c, sb + 1) * blk_b(c, sb + 2) + 31) / 32) : 0;
@@ -1863,7 +1863,7 @@ static int sweep_collect(jwas_hip_ctx* c, jwas_sweep_stats* S, size_t ntimed, do
     c->last_events = (double)h_cnt[0];
     for (int i = 0; i < kNCounters; ++i) c->last_counters[i] = h_cnt[i];
     if (std::getenv("JWAS_HIP_DEBUG_PHASES"))
-        std::fprintf(stderr, "[jwas_hip] blocks=%lld events=%llu unstaged=%llu cycles: front=%llu cand=%llu stage=%llu serial=%llu write=%llu corr=%llu rounds=%llu slow_rounds=%llu stage: assign=%llu issue=%llu wait=%llu update wg0: share=%llu wait=%llu rest=%llu compact: blocks=%llu fallback=%llu walk=%llu verify=%llu role=%llu tailwait=%llu xwrite=%llu xchain=%llu\n",
+        std::fprintf(stderr, "[jwas_hip] blocks=%lld events=%llu unstaged=%llu cycles: front=%llu cand=%llu stage=%llu serial=%llu write=%llu corr=%llu rounds=%llu slow_rounds=%llu stage: assign=%llu issue=%llu wait=%llu update wg0: share=%llu wait=%llu rest=%llu compact: blocks=%llu fallback=%llu walk=%llu verify=%llu role=%llu tailwait=%llu xwrite=%llu xchain=%llu (section_solve: blocks = sections solved, fallback = fallen back, walk..xwrite = cycles of y | mat-vec | combine | verify+apply | tail)\n",
                      (long long)c->nblocks, h_cnt[0], h_cnt[1], h_cnt[2], h_cnt[3], h_cnt[4], h_cnt[5], h_cnt[6], h_cnt[9], h_cnt[7], h_cnt[8], h_cnt[10], h_cnt[11], h_cnt[12], h_cnt[13], h_cnt[14], h_cnt[15], h_cnt[16], h_cnt[17], h_cnt[18], h_cnt[19], h_cnt[20], h_cnt[21], h_cnt[22], h_cnt[23]);
     float ms = 0.f;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev_start, c->ev_stop));

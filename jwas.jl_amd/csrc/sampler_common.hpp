@@ -33,9 +33,9 @@ struct SamplerArgs {
                                   // sampler_st.hpp), or NULL = the sequential chain
     const float* tsec_next;       // ... of the NEXT block (L2 prefetch only), or NULL
     int tsec_lines;               // ... its size in 128-byte lines
-    float* xch;                   // Rule T: [kMaxT][256] the changes of the block's sections, published by the sampler workgroup for the
-    int* xch_flag;                // helper workgroup (corr_helper_mt); *xch_flag = xch_epoch + (sections published so far)
-    int xch_epoch;                // ... of THIS launch (grows by 8 per launch: no reset between launches)
+    unsigned long long* xch;      // Rule T: [kMaxT][256] the changes of the block's sections, published by the sampler workgroup for the helper
+                                  // workgroup (corr_helper_mt): {bits of the change, tag} in ONE 8-byte word, tag = xch_epoch + section + 1
+    int xch_epoch;                // ... of THIS launch (grows by 8 per launch: a tag is never seen twice, nothing is reset between launches)
     const float* corr_in;         // [NT][bsz] lookahead correction of THIS block (written by the previous sampler)
     float* corr_out;              // [NT][bsz] lookahead correction of the NEXT block
     const double* prep_d; const float* prep_f;

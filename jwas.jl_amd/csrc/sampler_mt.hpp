@@ -166,7 +166,8 @@ __device__ __forceinline__ void mt1_linear_A(const MtConsts<NT>& K, float dj, fl
 // operation for operation: orc mt1_section_solve); off = the sequential chain everywhere, bit for bit as before.
 // Layout of T_s in HBM: float [16 NT][64 NT][4] -- column group cg (columns 4 cg .. 4 cg + 3; column = m * 64 + j for trait m
 // of marker j), row r = k * 64 + l, the row's four values of the group: one float4 per lane, 1 KB per wave load.
-// Summation order of D~[(l,k)]: two fmaf chains from 0 over the columns [0, 32 NT) and [32 NT, 64 NT) in ascending order, added.
+// Summation order of D~[(l,k)]: four fmaf chains from 0 over the columns [16 NT q, 16 NT (q + 1)), q = 0..3, in ascending order,
+// added as (p0 + p1) + (p2 + p3).
 // ---------------------------------------------------------------------------------------------
 template <int NT> __host__ __device__ constexpr int64_t tsec_floats() { return (int64_t)(64 * NT) * (64 * NT); }
 
@@ -954,32 +955,33 @@ __device__ __forceinline__ void dense_big_mt(char* smem, const StepSmem& SM, con
 }
 
 // acc[t] = fmaf(D[t][u], pq[u], acc[t]) for the 64 changes u of a section in marker order (D: LDS, trait stride dstride; pq: the
-// thread's 64 Gram / cross-Gram values).  Batches of eight with the next batch's broadcast reads in flight behind the current
-// one's multiply-adds -- and a scheduling barrier per batch: left alone the compiler hoists all 64 NT reads to the top (192
-// registers on top of pq: spills).
-template <int NT>
+// thread's 64 Gram / cross-Gram values).  Batches of KB with the next batch's broadcast reads in flight behind the current
+// one's multiply-adds -- pinned by a data dependence per batch: left alone the compiler hoists all 64 NT reads to the top (192
+// registers on top of pq: spills); every batch boundary exposes one LDS latency, so few, big batches (16: 96 registers).
+template <int NT, int KB = 8>
 __device__ __forceinline__ void apply_section_changes(const float* D, int dstride, float (&acc)[NT], const float (&pq)[64])
 {
-    float dn[NT][8];
+    float dn[NT][KB];
     auto fetch = [&](int k0) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const float4 d0 = *reinterpret_cast<const float4*>(D + t * dstride + k0);
-            const float4 d1 = *reinterpret_cast<const float4*>(D + t * dstride + k0 + 4);
-            dn[t][0] = d0.x; dn[t][1] = d0.y; dn[t][2] = d0.z; dn[t][3] = d0.w; dn[t][4] = d1.x; dn[t][5] = d1.y; dn[t][6] = d1.z; dn[t][7] = d1.w;
-        }
-    };
-    fetch(0);
-#pragma unroll
-    for (int k0 = 0; k0 < 64; k0 += 8) {
-        float dv[NT][8];
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int u = 0; u < 8; ++u) dv[t][u] = dn[t][u];
-        if (k0 + 8 < 64) fetch(k0 + 8);
+            for (int q = 0; q < KB; q += 4) {
+                const float4 d0 = *reinterpret_cast<const float4*>(D + t * dstride + k0 + q);
+                dn[t][q] = d0.x; dn[t][q + 1] = d0.y; dn[t][q + 2] = d0.z; dn[t][q + 3] = d0.w;
+            }
+    };
+    fetch(0);
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+    for (int k0 = 0; k0 < 64; k0 += KB) {
+        float dv[NT][KB];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int u = 0; u < KB; ++u) dv[t][u] = dn[t][u];
+        if (k0 + KB < 64) fetch(k0 + KB);
+#pragma unroll
+        for (int u = 0; u < KB; ++u)
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t] = fmaf(dv[t][u], pq[k0 + u], acc[t]);
 #pragma unroll
@@ -997,8 +999,8 @@ __device__ __forceinline__ void apply_section_changes(const float* D, int dstrid
 // section is then walked as in dense_big_mt).  The two roles run SEPARATE loops with the same sequence of barriers, so that the
 // registers of one role (the walker's state and Gram prefetch / the solver's 4 NT^2 float4 of T) are not live in the other.
 // NT <= 3 (4 traits: 64 float4 of T per lane).
-template <int METHOD, int NT>
-__device__ __forceinline__ void dense_big_mt_solve(char* smem, const StepSmem& SM, const SamplerArgs& A, const MtConsts<NT>& K,
+template <int METHOD, int NT, class KF>
+__device__ __forceinline__ void dense_big_mt_solve(char* smem, const StepSmem& SM, const SamplerArgs& A, const KF& consts_of_marker,
                                                    const double* lpr, long long tk0, long long tk1)
 {
     static_assert(is_sampler1(METHOD) && NT <= 3, "sampler I, at most three traits");
@@ -1025,22 +1027,73 @@ __device__ __forceinline__ void dense_big_mt_solve(char* smem, const StepSmem& S
     typedef float v4f __attribute__((ext_vector_type(4)));
     // D of section s (rhs_lds) times 64 prefetched Gram values: fmaf chains in marker order, traits interleaved
     auto apply_changes = [&](int s, float (&acc)[NT], const float (&pq)[64]) { apply_section_changes<NT>(rhs_lds + 64 * s, B, acc, pq); };
+    // ---- the mat-vec D~ = T y: waves 4..7, wave 4 + q the q-th quarter of the columns (4 NT column groups of four) for the NT rows of
+    // every marker.  (All eight waves with an eighth each -- twice the issue rate -- was measured: the 147 KB of a section's T pass
+    // the CU's vector memory pipe at 64 B/clk = 2.3 k cycles, and a wave that is stuck issuing loads is late at the next barrier;
+    // the solver waves issue theirs while the verification / the apply run and nobody waits for them.)
+    constexpr int QG = 4 * NT;                                           // column groups of four per quarter
+    const int w8 = __builtin_amdgcn_readfirstlane(wave & 3);            // (wave-uniform, and the compiler knows)
+    // (g0, g1: the wave's column groups [g0, g1) only -- the solver waves fetch a section's T in four pieces, one per barrier
+    // interval, so that no interval carries the whole 2.3 k cycles the 147 KB take through the CU's vector memory pipe)
+    auto load_t = [&](int s, v4f (&tq)[NT][QG], int g0 = 0, int g1 = 64) {
+        // buffer loads: ONE vector register (the lane's 16-byte offset) addresses all of them, the (group, trait) offset is a
+        // scalar operand
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(A.tsec + (int64_t)s * tsec_floats<NT>() + (int64_t)(w8 * QG) * (64 * NT) * 4), 0, 0x7fffffff, 0x00020000);
+        const unsigned voff = 16u * (unsigned)lane;
+#pragma unroll
+        for (int g = 0; g < QG; ++g)
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+                if (g < g0 || g >= g1) continue;                         // (compile-time after inlining: g0 / g1 are literals at every call)
+                typedef unsigned v4u __attribute__((ext_vector_type(4)));
+                const v4u raw = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (unsigned)((g * (64 * NT) + k * 64) * 16), 0);
+                tq[k][g] = __builtin_bit_cast(v4f, raw);
+            }
+    };
+    auto matvec = [&](const v4f (&tq)[NT][QG]) {
+        float acc[NT];
+#pragma unroll
+        for (int k = 0; k < NT; ++k) acc[k] = 0.f;
+        const v4f* y4 = reinterpret_cast<const v4f*>(ybuf) + w8 * QG;
+#pragma unroll
+        for (int g = 0; g < QG; ++g) {
+            const v4f yv = y4[g];                                        // (broadcast read: columns 4 (w QG + g) .. + 3)
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+                acc[k] = fmaf(tq[k][g].x, yv.x, acc[k]); acc[k] = fmaf(tq[k][g].y, yv.y, acc[k]);
+                acc[k] = fmaf(tq[k][g].z, yv.z, acc[k]); acc[k] = fmaf(tq[k][g].w, yv.w, acc[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NT; ++k) part[(w8 * NT + k) * 64 + lane] = acc[k];
+    };
     if (wave < 4) {
         // =================================== markers (thread c = marker c) ===================================
         const int c = tid;
-        float rhs[NT], a[NT], bb[NT], dd[NT], lc[NT];
-        double thr[NT], z[NT];
+        const MtConsts<NT> K = consts_of_marker(c);                     // (the shared constants, or the marker's own: multi-trait BayesA/B)
+        float rhs[NT], a[NT], bb[NT], dd[NT];
         const float dj = lpf[c];
         bool in_all = true;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             rhs[t] = rhs_lds[t * B + c]; a[t] = acur[t * B + c]; bb[t] = bcur[t * B + c]; dd[t] = dcur[t * B + c];
-            thr[t] = lpd[t * B + c]; z[t] = lpd[(NT + t) * B + c]; lc[t] = lpf[(1 + t) * B + c];
             in_all = in_all && (dd[t] == 1.f);
         }
-        const MtPre<NT> Q = mt_precompute<METHOD, NT>(K, dj, lc);
+        // the marker's draws and x'x-only terms are needed by its own evaluations only (the coefficients below, the verification /
+        // the walk of its section): fetched from LDS there, not held in registers across the other sections (the registers
+        // carry the wave's eighth of T and its Gram prefetch)
+        auto draws_of = [&](double (&thr)[NT], double (&z)[NT], MtPre<NT>& Q) {
+            float lc[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { thr[t] = lpd[t * B + c]; z[t] = lpd[(NT + t) * B + c]; lc[t] = lpf[(1 + t) * B + c]; }
+            Q = mt_precompute<METHOD, NT>(K, dj, lc);
+        };
         float pq[64];
         auto load_g = [&](int s) {
+            // column c of the Gram rows of section s: one dword per lane, coalesced; the row pointer is uniform.  (Buffer loads with
+            // the row offset as a scalar operand -- one instruction per load instead of two -- were measured: 2.7 k cycles per
+            // section instead of 0.5 k.)
             const char* base = reinterpret_cast<const char*>(A.gram + (int64_t)(64 * s) * b);
             unsigned off = 4u * (unsigned)c;
 #pragma unroll
@@ -1049,7 +1102,12 @@ __device__ __forceinline__ void dense_big_mt_solve(char* smem, const StepSmem& S
         if (wave > 0) load_g(0);
         // Rule L's coefficients of the thread's own marker: all four waves at once, before the chain starts
         float Al[NT][NT], cl[NT], da[NT];
-        mt1_linear_coeffs<NT>(K, Q, dj, bb, z, Al, cl);
+        {
+            double thr[NT], z[NT];
+            MtPre<NT> Q;
+            draws_of(thr, z, Q);
+            mt1_linear_coeffs<NT>(K, Q, dj, bb, z, Al, cl);
+        }
 #pragma unroll
         for (int t = 0; t < NT; ++t) da[t] = dj * a[t];                                                  // MTBayesABC.jl:82
         {
@@ -1058,10 +1116,13 @@ __device__ __forceinline__ void dense_big_mt_solve(char* smem, const StepSmem& S
         }
         lds_barrier();                                                                                  // B0
         int nredo = 0, nsolved = 0, nfailed = 0;
+        long long cy_y = 0, cy_mv = 0, cy_cmb = 0, cy_ver = 0, cy_tail = 0;      // (diagnostics: the phases of a solved section, wave 0's clock)
 #pragma unroll 1
         for (int s = 0; s < kSec; ++s) {
             const bool fast = sflag[s] != 0;
             bool redo = !fast;
+            const long long ts0 = clock64();
+            long long ts4 = ts0;
             if (fast) {
                 float rsv[NT];
 #pragma unroll
@@ -1075,8 +1136,10 @@ __device__ __forceinline__ void dense_big_mt_solve(char* smem, const StepSmem& S
                     for (int t = 0; t < NT; ++t) ybuf[t * 64 + lane] = a[t] - bo[t];
                 }
                 lds_barrier();                                           // B1: y is there
+                const long long ts1 = clock64();
                 lds_barrier();                                           // B2: the four partial products are there
-                float Dt[NT], yv[NT], bo[NT];
+                const long long ts2 = clock64();
+                float bo[NT], Dt[NT], yv[NT];
                 if (wave == s) {
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
@@ -1087,8 +1150,12 @@ __device__ __forceinline__ void dense_big_mt_solve(char* smem, const StepSmem& S
                     }
                 }
                 lds_barrier();                                           // B3: D is there
+                const long long ts3 = clock64();
                 if (wave == s) {
                     // the literal evaluation at the right-hand side these effects imply:  rhs + R Lc (y - D~)
+                    double thr[NT], z[NT];
+                    MtPre<NT> Q;
+                    draws_of(thr, z, Q);
                     float v[NT], qv[NT], wev[NT];
 #pragma unroll
                     for (int t = 0; t < NT; ++t) v[t] = yv[t] - Dt[t];
@@ -1113,24 +1180,43 @@ __device__ __forceinline__ void dense_big_mt_solve(char* smem, const StepSmem& S
                     bool ok = true;
 #pragma unroll
                     for (int t = 0; t < NT; ++t) ok = ok && (dv2[t] == 1.f);
-                    if (__any(!ok)) { if (lane == 0) sflag[4 + s] = 1; ++nfailed; }
-                    else {
-                        ++nsolved;
-#pragma unroll
-                        for (int t = 0; t < NT; ++t) { acur[t * B + c] = bo[t]; bcur[t * B + c] = bo[t]; dcur[t * B + c] = 1.f; }
-                    }
-                } else if (wave > s) apply_changes(s, rhs, pq);          // (optimistic: undone below if the verification failed)
+                    if (__any(!ok) && lane == 0) sflag[4 + s] = 1;
+                } else if (wave > s) {
+                    apply_changes(s, rhs, pq);                           // (optimistic: undone below if the verdict is "no")
+                }
                 lds_barrier();                                           // B4: the verdict
+                ts4 = clock64();
+                cy_y += ts1 - ts0; cy_mv += ts2 - ts1; cy_cmb += ts3 - ts2; cy_ver += ts4 - ts3;
                 redo = sflag[4 + s] != 0;
                 if (redo) {
 #pragma unroll
                     for (int t = 0; t < NT; ++t) rhs[t] = rsv[t];
+                    if (wave == s) ++nfailed;
+                } else if (wave == s) {
+                    ++nsolved;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) { acur[t * B + c] = bo[t]; bcur[t * B + c] = bo[t]; dcur[t * B + c] = 1.f; }
                 }
             }
             if (redo) {
                 if (wave == s) {
-                    // ---- walk section s (lane = marker 64 s + lane) on its strictly-upper diagonal tile, as dense_big_mt does
+                    // ---- walk section s (lane = marker 64 s + lane) on its strictly-upper diagonal tile, as dense_big_mt does; the
+                    // tile is fetched HERE (direct loads: 4 rows of 64 floats per instruction), by the wave that walks it -- the
+                    // launch's front does not pay for tiles that nine sections in ten never read
+                    {
+                        typedef __attribute__((address_space(3))) void lds_void;
+                        float* tw = reinterpret_cast<float*>(smem + SM.rows_off) + s * 4096;
+                        const float* src = A.gram + (int64_t)(64 * s + (lane >> 4)) * kB + 64 * s + (lane & 15) * 4;
+#pragma unroll 1
+                        for (int r4 = 0; r4 < 16; ++r4)
+                            __builtin_amdgcn_global_load_lds(src + (int64_t)(4 * r4) * kB, (lds_void*)(tw + r4 * 256), 16, 0, 0);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        mask_diagonal_tile(tw, 64, lane, 64);
+                    }
                     const float* tile = tiles + s * 4096;
+                    double thr[NT], z[NT];
+                    MtPre<NT> Q;
+                    draws_of(thr, z, Q);
                     float rs[NT], wev[NT], an[NT], bnw[NT], dn[NT];
 #pragma unroll
                     for (int t = 0; t < NT; ++t) rs[t] = rhs[t];
@@ -1192,16 +1278,22 @@ __device__ __forceinline__ void dense_big_mt_solve(char* smem, const StepSmem& S
                 if (wave > s) apply_changes(s, rhs, pq);
             }
             // the section's changes are final: hand them to the helper workgroup that forms the NEXT block's lookahead correction
-            // (corr_helper_mt).  Write-through stores, acknowledged (vmcnt), then the flag -- the ordering of update_role's
-            // cooperative apply.  Nobody in THIS workgroup waits for anything: the walker of the next section is already at work.
+            // (corr_helper_mt) -- value and tag in one 8-byte write-through store per trait, fire and forget: the reader polls the tag,
+            // so no acknowledgement (s_waitcnt vmcnt) and no flag are needed, and nobody in THIS workgroup waits for anything.
             if (wave == s) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
-                    __hip_atomic_store(reinterpret_cast<int*>(A.xch + t * kB + c), __float_as_int(rhs_lds[t * B + c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0) __hip_atomic_store(A.xch_flag, A.xch_epoch + s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(A.xch + t * kB + c,
+                                       ((unsigned long long)(unsigned)(A.xch_epoch + s + 1) << 32) | (unsigned long long)__float_as_uint(rhs_lds[t * B + c]),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (s + 1 < kSec && wave > s + 1) load_g(s + 1);
+            if (!redo) cy_tail += clock64() - ts4;
+        }
+        if (tid == 0) {
+            atomicAdd(&A.counters[18], (unsigned long long)cy_y); atomicAdd(&A.counters[19], (unsigned long long)cy_mv);
+            atomicAdd(&A.counters[20], (unsigned long long)cy_cmb); atomicAdd(&A.counters[21], (unsigned long long)cy_ver);
+            atomicAdd(&A.counters[22], (unsigned long long)cy_tail);
         }
         if (lane == 0 && nredo) atomicAdd(&A.counters[7], (unsigned long long)nredo);      // sections walked again
         if (lane == 0 && (nsolved | nfailed)) {                                             // Rule T: sections solved / fallen back to the walk
@@ -1209,26 +1301,9 @@ __device__ __forceinline__ void dense_big_mt_solve(char* smem, const StepSmem& S
             atomicAdd(&A.counters[17], (unsigned long long)nfailed);
         }
     } else {
-        // ============================ the solve (wave 4 + q: column quarter q of the section's inverse) ============================
-        const int q4 = __builtin_amdgcn_readfirstlane(wave - 4);        // (wave-uniform, and the compiler knows)
-        constexpr int QG = 4 * NT;                                       // column groups of four per quarter
+        // ====================== waves 4..7: their quarters of the mat-vec, nothing else (the same barriers as above) ======================
         v4f tq[NT][QG];
-        auto load_t = [&](int s) {
-            // buffer loads: ONE vector register (the lane's 16-byte offset) addresses all of them, the (group, trait) offset is a
-            // scalar operand
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<float*>(A.tsec + (int64_t)s * tsec_floats<NT>() + (int64_t)(q4 * QG) * (64 * NT) * 4), 0, 0x7fffffff, 0x00020000);
-            const unsigned voff = 16u * (unsigned)lane;
-#pragma unroll
-            for (int g = 0; g < QG; ++g)
-#pragma unroll
-                for (int k = 0; k < NT; ++k) {
-                    typedef unsigned v4u __attribute__((ext_vector_type(4)));
-                    const v4u raw = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (unsigned)((g * (64 * NT) + k * 64) * 16), 0);
-                    tq[k][g] = __builtin_bit_cast(v4f, raw);
-                }
-        };
-        load_t(0);
+        load_t(0, tq);
         lds_barrier();                                                                                  // B0
 #pragma unroll 1
         for (int s = 0; s < kSec; ++s) {
@@ -1236,33 +1311,20 @@ __device__ __forceinline__ void dense_big_mt_solve(char* smem, const StepSmem& S
             bool redo = !fast;
             if (fast) {
                 lds_barrier();                                           // B1: y is there
-                {
-                    float acc[NT];
-#pragma unroll
-                    for (int k = 0; k < NT; ++k) acc[k] = 0.f;
-                    const v4f* y4 = reinterpret_cast<const v4f*>(ybuf) + q4 * QG;
-#pragma unroll
-                    for (int g = 0; g < QG; ++g) {
-                        const v4f yv = y4[g];                            // (broadcast read: columns 4 (q QG + g) .. + 3)
-#pragma unroll
-                        for (int k = 0; k < NT; ++k) {
-                            acc[k] = fmaf(tq[k][g].x, yv.x, acc[k]); acc[k] = fmaf(tq[k][g].y, yv.y, acc[k]);
-                            acc[k] = fmaf(tq[k][g].z, yv.z, acc[k]); acc[k] = fmaf(tq[k][g].w, yv.w, acc[k]);
-                        }
-                    }
-#pragma unroll
-                    for (int k = 0; k < NT; ++k) part[(q4 * NT + k) * 64 + lane] = acc[k];
-                }
-                __builtin_amdgcn_sched_barrier(0);                       // (the next section's loads AFTER this one's products: the registers are the same)
-                if (s + 1 < kSec) load_t(s + 1);
+                matvec(tq);
+                __builtin_amdgcn_sched_barrier(0);
+                if (s + 1 < kSec) load_t(s + 1, tq, 0, QG / 4);          // the next section's T: a quarter per barrier interval
                 lds_barrier();                                           // B2: the partial products are there
+                if (s + 1 < kSec) load_t(s + 1, tq, QG / 4, QG / 2);
                 lds_barrier();                                           // B3: D is there
+                if (s + 1 < kSec) load_t(s + 1, tq, QG / 2, 3 * QG / 4);
                 lds_barrier();                                           // B4: the verdict
+                if (s + 1 < kSec) load_t(s + 1, tq, 3 * QG / 4, QG);
                 redo = sflag[4 + s] != 0;
             }
             if (redo) {
+                if (!fast && s + 1 < kSec) load_t(s + 1, tq);
                 lds_barrier();                                           // B5
-                if (!fast && s + 1 < kSec) load_t(s + 1);
             }
         }
     }
@@ -1308,7 +1370,7 @@ __device__ __forceinline__ void dense_big_mt_solve(char* smem, const StepSmem& S
 
 // The HELPER workgroup of a Rule T launch (workgroup 8: on the sampler's XCD; sweep.hpp): the lookahead correction of the NEXT
 // block,  corr[t][c'] = fmaf(D_e[t], C[e][c'], corr)  from 0 over the markers e of the block in marker order  (C = X_this'X_next),
-// from the changes the sampler workgroup publishes section by section (A.xch, A.xch_flag) -- the cross-Gram block (256 KB) and
+// from the changes the sampler workgroup publishes section by section (A.xch: value + tag per word) -- the cross-Gram block (256 KB) and
 // three quarters of the block's off-diagonal multiply-adds no longer go through the sampler's CU.  Thread c' < 256 owns column
 // c'; the section's 64 cross-Gram values per thread are fetched a section ahead.  The wait is one-directional (the sampler
 // workgroup waits for nobody and is dispatched before this one), its result is consumed by the NEXT launch.  Same operations
@@ -1320,7 +1382,6 @@ __device__ __forceinline__ void corr_helper_mt(char* smem, const SamplerArgs& A)
     const int tid = threadIdx.x, lane = tid & 63;
     const int bn = A.b_next, B = A.bsz;
     float* dl = reinterpret_cast<float*>(smem);                          // [NT][64] the section's changes
-    int* seen = reinterpret_cast<int*>(dl + NT * 64);
     const bool colthr = tid < bn && tid < kB;
     const int cn = colthr ? tid : 0;
     float corr[NT];
@@ -1336,21 +1397,24 @@ __device__ __forceinline__ void corr_helper_mt(char* smem, const SamplerArgs& A)
     if (bn > 0 && tid < kB) load_c(0);
 #pragma unroll 1
     for (int s = 0; s < kSec; ++s) {
-        if (tid == 0) {
-            while (__hip_atomic_load(A.xch_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (A.xch_epoch + s + 1) < 0) __builtin_amdgcn_s_sleep(8);
-            *seen = 1;
+        if (tid < NT * 64) {
+            // thread (t, lane): its value of the section, valid once the word carries this section's tag
+            const int t = tid >> 6;
+            const unsigned long long* src = A.xch + t * kB + 64 * s + lane;
+            const unsigned want = (unsigned)(A.xch_epoch + s + 1);
+            unsigned long long v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while ((unsigned)(v >> 32) != want) {
+                __builtin_amdgcn_s_sleep(8);
+                v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            dl[tid] = __uint_as_float((unsigned)v);
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // (LDS only: the cross-Gram loads stay in flight)
-        if (tid < NT * 64) {
-            const int t = tid >> 6;
-            dl[tid] = __int_as_float(__hip_atomic_load(reinterpret_cast<const int*>(A.xch + t * kB + 64 * s + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        }
-        __syncthreads();
         if (bn > 0 && tid < kB) {
             apply_section_changes<NT>(dl, 64, corr, pq);
             if (s + 1 < kSec) load_c(s + 1);
         }
-        __syncthreads();                                                     // (dl is rewritten for the next section)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // (dl is rewritten for the next section)
     }
     if (bn > 0 && tid < kB) {
 #pragma unroll
@@ -1470,7 +1534,7 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
     };
     if constexpr (is_sampler1(METHOD)) {
         big_try = (B == 256) && (b == B) && !pm && parked && (P->nreps == 1) && !A.dense_big_off;      // (any next block: its columns are threads 256 .. 256 + b_next - 1)
-        if constexpr (kDW) { if (big_try) fetch_tiles(); }
+        if constexpr (kDW) { if (big_try && A.tsec == nullptr) fetch_tiles(); }      // (Rule T: a tile is fetched only by a section that has to be walked)
     }
     float4 gpre[8];
     if (prestage && !gram_dma) {
@@ -1559,7 +1623,12 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
         } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         for (int c = tid; c < B; c += kStepThreads) { slot_p[c] = (short)(c < b ? c : -1); cand_p[c] = (short)c; }
     }
+    const long long tkf1 = clock64();
     __syncthreads();
+    const long long tkf2 = clock64();
+    if (tid == 0) {       // (diagnostics: the front up to its LDS stores | the wait for its loads at the barrier)
+        atomicAdd(&A.counters[10], (unsigned long long)(tkf1 - tk0)); atomicAdd(&A.counters[11], (unsigned long long)(tkf2 - tkf1));
+    }
     // marker c's table of log prior state probabilities: the shared one (stride 1) or its own column of the parked
     // marker-specific priors (stride B)
     const int ls = pm ? B : 1;
@@ -1611,12 +1680,12 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
         first_sub = 0; ncand_all = b; dense_walk = true;
         if constexpr (is_sampler1(METHOD)) {
             if (big_try) {
-                finish_tiles();
                 // (Rule T launches: the host sets tsec exactly for the blocks that meet big_try, and the helper workgroup then counts on
                 // the sampler to publish every section's changes)
                 if constexpr (NT <= 3) {
-                    if (A.tsec != nullptr) { dense_big_mt_solve<METHOD, NT>(smem, SM, A, consts_of(tid < 256 ? tid : 0), lpr, tk0, clock64()); return; }
+                    if (A.tsec != nullptr) { dense_big_mt_solve<METHOD, NT>(smem, SM, A, consts_of, lpr, tk0, clock64()); return; }
                 }
+                finish_tiles();
                 dense_big_mt<METHOD, NT>(smem, SM, A, consts_of(tid < 256 ? tid : 0), lpr, tk0, clock64());
                 return;
             }

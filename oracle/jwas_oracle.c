@@ -1116,7 +1116,7 @@ static int mt1_section_solve(int t, int64_t p, int64_t j0, int64_t b, int64_t c0
                 }
             }
         }
-    const int qc = 16 * t;                                                  /* columns per quarter */
+    const int qc = 16 * t;                                                  /* columns per quarter (one wave's share on the device) */
     for (int r = 0; r < nr; ++r) {
         float pq[4];
         for (int q = 0; q < 4; ++q) {
