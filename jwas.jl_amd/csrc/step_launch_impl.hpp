@@ -146,7 +146,7 @@ hipError_t launch_section_inverse(const StepLaunch& L, const DevParams* P, const
         attr_set.fetch_or(dev_bit, std::memory_order_release);
     }
     if (nsections <= 0) return hipSuccess;
-    hipLaunchKernelGGL((k_section_inverse_mt<METHOD, NT>), dim3((unsigned)nsections), dim3(64 * NT), tsec_inverse_lds_bytes<NT>(), L.stream,
+    hipLaunchKernelGGL((k_section_inverse_mt<METHOD, NT>), dim3((unsigned)nsections), dim3(256 * NT), tsec_inverse_lds_bytes<NT>(), L.stream,
                        P, xpx, gram, ginv_mat, tsec);
     return hipGetLastError();
 }

@@ -633,8 +633,8 @@ static inline void mt1_update(int t, const float* w, float d, float* alpha, floa
                               const double* log_prior, uint64_t seed, uint32_t marker, uint32_t iter,
                               uint32_t rep, float* a_out)
 {
-    float b[ORC_MAXT], dl[ORC_MAXT], b_in[ORC_MAXT], a_in[ORC_MAXT];
-    double zz[ORC_MAXT];
+    float b[ORC_MAXT], dl[ORC_MAXT], b_in[ORC_MAXT] = {0}, a_in[ORC_MAXT] = {0};
+    double zz[ORC_MAXT] = {0};
     int all1 = g_mt_linear;
     for (int k = 0; k < t; ++k) { b[k] = beta[k * stride]; dl[k] = delta[k * stride]; b_in[k] = b[k]; a_in[k] = alpha[k * stride]; all1 = all1 && (dl[k] == 1.0f); }
     for (int k = 0; k < t; ++k) {                                                /* :85 */
@@ -1051,7 +1051,8 @@ int orc_bayesr_lookahead_sweep(const float* X, int64_t n, int64_t p, int64_t ld,
 /* indicator stays 1, otherwise the section runs through the sequential chain.  Restated operation  */
 /* for operation (same accumulation types and orders), so that the comparison stays bit for bit:    */
 /*   T column (jc, mc): rows of markers l < jc are 0, of jc the identity; for l > jc                 */
-/*       u_m = sum_{j=jc}^{l-1} fma(G_lj, T[(j,m)], u_m)   (double, ascending j)                     */
+/*       u_m = (p0 + p1) + (p2 + p3),  p_q = sum over j = jc + q, jc + q + 4, ... < l of                */
+/*             fma(G_lj, T[(j,m)], p_q)   (double, ascending j: the device's four lanes per column)   */
 /*       T[(l,k)] = fl32( -( sum_m fma(A_l[k][m], u_m, .) ) )  (double, ascending m)                 */
 /*   D~[(l,k)] = (p0 + p1) + (p2 + p3),  p_q = fmaf chain (float, from 0) over the columns           */
 /*       c = m*64 + j in [16 t q, 16 t (q+1)), ascending                                              */
@@ -1103,12 +1104,15 @@ static int mt1_section_solve(int t, int64_t p, int64_t j0, int64_t b, int64_t c0
             const int col = mc * S + jc;
             for (int k = 0; k < t; ++k) T[(size_t)(k * S + jc) * nr + col] = (k == mc) ? 1.0f : 0.0f;
             for (int l = jc + 1; l < S; ++l) {
-                double u[ORC_MAXT];
-                for (int m = 0; m < t; ++m) u[m] = 0.0;
-                for (int j = jc; j < l; ++j) {
-                    const double g = (double)G[(c0 + l) * b + c0 + j];
-                    for (int m = 0; m < t; ++m) u[m] = fma(g, (double)T[(size_t)(m * S + j) * nr + col], u[m]);
+                double u[ORC_MAXT], pu[4][ORC_MAXT];
+                for (int q = 0; q < 4; ++q) {                                   /* the device's four lanes per column: j = jc + q, + 4, ... */
+                    for (int m = 0; m < t; ++m) pu[q][m] = 0.0;
+                    for (int j = jc + q; j < l; j += 4) {
+                        const double g = (double)G[(c0 + l) * b + c0 + j];
+                        for (int m = 0; m < t; ++m) pu[q][m] = fma(g, (double)T[(size_t)(m * S + j) * nr + col], pu[q][m]);
+                    }
                 }
+                for (int m = 0; m < t; ++m) u[m] = (pu[0][m] + pu[1][m]) + (pu[2][m] + pu[3][m]);
                 for (int k = 0; k < t; ++k) {
                     double v = 0.0;
                     for (int m = 0; m < t; ++m) v = fma((double)A[l * t * t + k * t + m], u[m], v);
