@@ -1265,6 +1265,8 @@ int jwas_hip_window_sums2(jwas_hip_ctx* c, int32_t use_output_rows, int32_t nwin
 
 // ---- the sweep --------------------------------------------------------------------------------------
 // The step kernel's instantiations live in one translation unit per sampler family (step_launch.hpp).
+static inline bool bs_is_dense_big(int bs) { return bs == 256 || bs == 512; }
+
 static StepLaunch step_launch_of(const jwas_hip_ctx* c)
 {
     StepLaunch L;
@@ -1672,17 +1674,20 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
     const int64_t solve_blocks = (P->section_solve && dense_mt256 && P->nreps == 1 && !independent && c->starts.empty() && !c->row_mode && !dense_big_off)
                                      ? c->p / 256 : 0;
     const size_t tsf = (size_t)(64 * t) * (size_t)(64 * t);
+    // dense sweeps hand the next block's lookahead correction to a helper workgroup (corr_helper): multi-trait Rule T blocks, and
+    // single-trait dense_big_st blocks (uniform pi = 0 on full 256- / 512-marker blocks; JWAS_HIP_CORR_HELPER=0: in the sampler)
+    static const int corr_helper_on = std::getenv("JWAS_HIP_CORR_HELPER") ? std::atoi(std::getenv("JWAS_HIP_CORR_HELPER")) : 1;
+    const bool st_helper = corr_helper_on && dense_big && P->nreps == 1 && !independent && !c->row_mode && !dense_big_off && (bs_is_dense_big(c->block_size));
+    if ((solve_blocks > 0 || st_helper) && !c->xch) {
+        HIPCHK(c, hipMalloc(&c->xch, sizeof(unsigned long long) * kMaxT * 512));
+        HIPCHK(c, hipMemsetAsync(c->xch, 0, sizeof(unsigned long long) * kMaxT * 512, c->stream));
+    }
     if (solve_blocks > 0) {
         const size_t need = (size_t)solve_blocks * 4 * tsf;
         if (c->tsec_cap < need) {
             (void)hipFree(c->tsec); c->tsec = nullptr; c->tsec_cap = 0;
-    (void)hipFree(c->xch); c->xch = nullptr;
             HIPCHK(c, hipMalloc(&c->tsec, sizeof(float) * need));
             c->tsec_cap = need;
-        }
-        if (!c->xch) {
-            HIPCHK(c, hipMalloc(&c->xch, sizeof(unsigned long long) * kMaxT * 256));
-            HIPCHK(c, hipMemsetAsync(c->xch, 0, sizeof(unsigned long long) * kMaxT * 256, c->stream));
         }
         const StepLaunch L = step_launch_of(c);
         if (c->method == JWAS_HIP_MTBAYESB1) HIPCHK(c, launch_section_inverse_mtb1(L, t, c->dparams, c->xpx, c->gram, c->ginv_mat, solve_blocks * 4, c->tsec));
@@ -1748,8 +1753,8 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
             S.tsec = (sb < solve_blocks) ? c->tsec + (size_t)sb * 4 * tsf : nullptr;
             S.tsec_next = (sb + 1 < solve_blocks) ? c->tsec + (size_t)(sb + 1) * 4 * tsf : nullptr;
             S.tsec_lines = (int)(4 * tsf / 32);
-            if (S.tsec != nullptr) {       // (the helper workgroup lives on the quiet XCD: ids = 0 mod 8 do no streaming)
-                S.xch = c->xch; c->xch_epoch += 8; S.xch_epoch = c->xch_epoch;
+            if (S.tsec != nullptr || (st_helper && S.b == bs && S.b_next > 0)) {       // (the helper workgroup lives on the quiet XCD: ids = 0 mod 8 do no streaming)
+                S.xch = c->xch; c->xch_epoch = (c->xch_epoch + 8) & 0x3fffffff; S.xch_epoch = c->xch_epoch;
                 U.quiet_xcd = 1;
             }
             S.lines_after = (sb + 2 < nb) ? (int)(((int64_t)blk_b(c, sb + 1) * blk_b(c, sb + 2) + 31) / 32) : 0;

@@ -432,6 +432,100 @@ __device__ __forceinline__ int stage_rows(char* smem, const StepSmem& SM, const 
     return ncand;
 }
 
+// acc[t] = fmaf(D[t][u], pq[u], acc[t]) for the 64 changes u of a section in marker order (D: LDS, trait stride dstride; pq: the
+// thread's 64 Gram / cross-Gram values).  Batches of KB with the next batch's broadcast reads in flight behind the current
+// one's multiply-adds -- pinned by a data dependence per batch: left alone the compiler hoists all 64 NT reads to the top (192
+// registers on top of pq: spills); every batch boundary exposes one LDS latency, so few, big batches (16: 96 registers).
+template <int NT, int KB = 8>
+__device__ __forceinline__ void apply_section_changes(const float* D, int dstride, float (&acc)[NT], const float (&pq)[64])
+{
+    float dn[NT][KB];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int q = 0; q < KB; q += 4) {
+                const float4 d0 = *reinterpret_cast<const float4*>(D + t * dstride + k0 + q);
+                dn[t][q] = d0.x; dn[t][q + 1] = d0.y; dn[t][q + 2] = d0.z; dn[t][q + 3] = d0.w;
+            }
+    };
+    fetch(0);
+#pragma unroll
+    for (int k0 = 0; k0 < 64; k0 += KB) {
+        float dv[NT][KB];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int u = 0; u < KB; ++u) dv[t][u] = dn[t][u];
+        if (k0 + KB < 64) fetch(k0 + KB);
+#pragma unroll
+        for (int u = 0; u < KB; ++u)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = fmaf(dv[t][u], pq[k0 + u], acc[t]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(acc[t]) :: "memory");
+    }
+}
+
+// The HELPER workgroup of a dense launch (workgroup 16: an idle one on the sampler's XCD; sweep.hpp): the lookahead correction of
+// the NEXT block,  corr[t][c'] = fmaf(D_e[t], C[e][c'], corr)  from 0 over the markers e of the block in marker order  (C =
+// X_this'X_next), from the changes the sampler workgroup publishes section by section (A.xch: value + tag per 8-byte word) --
+// the cross-Gram block (256 KB at 256 markers, 1 MB at 512) and most of the block's off-diagonal multiply-adds no longer go
+// through the sampler's CU.  Thread c' < b_next owns column c'; the section's 64 cross-Gram values per thread are fetched a
+// section ahead.  The wait is one-directional (the sampler workgroup waits for nobody and is dispatched before this one), its
+// result is consumed by the NEXT launch.  Same operations in the same order as the in-workgroup form: bit-identical.
+// A sampler that does not take the path that publishes (dense_big_st's vote failed) says so with the ABORT tag in section 0.
+constexpr unsigned kXchAbort = 0x80000000u;
+template <int NT>
+__device__ __forceinline__ void corr_helper(char* smem, const SamplerArgs& A)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int bn = A.b_next, B = A.bsz, nsec = A.b >> 6;
+    if (bn <= 0) return;                                                 // (the sweep's last block: no correction to form)
+    float* dl = reinterpret_cast<float*>(smem);                          // [NT][64] the section's changes
+    int* stop = reinterpret_cast<int*>(dl + NT * 64);
+    const bool colthr = tid < bn;
+    const int cn = colthr ? tid : 0;
+    float corr[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) corr[t] = 0.f;
+    float pq[64];
+    auto load_c = [&](int s) {
+        const char* base = reinterpret_cast<const char*>(A.cross_next + (int64_t)(64 * s) * bn);
+        unsigned off = 4u * (unsigned)cn;
+#pragma unroll
+        for (int u = 0; u < 64; ++u) { pq[u] = *reinterpret_cast<const float*>(base + off); off += 4u * (unsigned)bn; asm volatile("" : "+v"(off)); }
+    };
+    if (tid == 0) *stop = 0;
+    load_c(0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll 1
+    for (int s = 0; s < nsec; ++s) {
+        if (tid < NT * 64) {
+            // thread (t, lane): its value of the section, valid once the word carries this section's tag
+            const int t = tid >> 6;
+            const unsigned long long* src = A.xch + t * B + 64 * s + lane;
+            const unsigned want = (unsigned)(A.xch_epoch + s + 1) & 0x7fffffffu;
+            unsigned long long v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while (((unsigned)(v >> 32) & 0x7fffffffu) != want) {
+                __builtin_amdgcn_s_sleep(8);
+                v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if ((unsigned)(v >> 32) & kXchAbort) *stop = 1;
+            dl[tid] = __uint_as_float((unsigned)v);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // (LDS only: the cross-Gram loads stay in flight)
+        if (*stop) return;                                                   // (the sampler forms the correction itself)
+        if (colthr) apply_section_changes<NT>(dl, 64, corr, pq);
+        if (s + 1 < nsec) load_c(s + 1);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // (dl is rewritten for the next section)
+    }
+    if (tid < B) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) A.corr_out[t * B + tid] = colthr ? corr[t] : 0.f;
+    }
+}
+
 // rhs[t][:] += D[t] * G[ce][:]  for the committed marker ce (BayesABC.jl:169,172); one wave.
 template <int NT>
 __device__ __forceinline__ void apply_gram_row(char* smem, const StepSmem& SM, const SamplerArgs& A, int ce,

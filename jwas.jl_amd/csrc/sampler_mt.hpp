@@ -966,44 +966,9 @@ __device__ __forceinline__ void dense_big_mt(char* smem, const StepSmem& SM, con
     if (lane == 0 && nredo) atomicAdd(&A.counters[7], (unsigned long long)nredo);      // sections walked again
 }
 
-// acc[t] = fmaf(D[t][u], pq[u], acc[t]) for the 64 changes u of a section in marker order (D: LDS, trait stride dstride; pq: the
-// thread's 64 Gram / cross-Gram values).  Batches of KB with the next batch's broadcast reads in flight behind the current
-// one's multiply-adds -- pinned by a data dependence per batch: left alone the compiler hoists all 64 NT reads to the top (192
-// registers on top of pq: spills); every batch boundary exposes one LDS latency, so few, big batches (16: 96 registers).
-template <int NT, int KB = 8>
-__device__ __forceinline__ void apply_section_changes(const float* D, int dstride, float (&acc)[NT], const float (&pq)[64])
-{
-    float dn[NT][KB];
-    auto fetch = [&](int k0) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int q = 0; q < KB; q += 4) {
-                const float4 d0 = *reinterpret_cast<const float4*>(D + t * dstride + k0 + q);
-                dn[t][q] = d0.x; dn[t][q + 1] = d0.y; dn[t][q + 2] = d0.z; dn[t][q + 3] = d0.w;
-            }
-    };
-    fetch(0);
-#pragma unroll
-    for (int k0 = 0; k0 < 64; k0 += KB) {
-        float dv[NT][KB];
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int u = 0; u < KB; ++u) dv[t][u] = dn[t][u];
-        if (k0 + KB < 64) fetch(k0 + KB);
-#pragma unroll
-        for (int u = 0; u < KB; ++u)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = fmaf(dv[t][u], pq[k0 + u], acc[t]);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(acc[t]) :: "memory");
-    }
-}
-
 // ---- dense_big_mt under RULE T (jwas_sweep_params.section_solve; the comment block above k_section_inverse_mt).  The same
 // plan -- thread c (waves 0..3) owns marker c, one 64-marker section after the other; the next block's lookahead correction is
-// formed by a HELPER workgroup (corr_helper_mt) from the changes each section publishes -- but a section in which every marker
+// formed by a HELPER workgroup (corr_helper, sampler_common.hpp) from the changes each section publishes -- but a section in which every marker
 // is in the model for every trait is SOLVED, not walked: wave s forms y (one evaluation of the linear form per lane), waves 4..7 multiply it with the section's inverse (wave
 // 4 + q: the q-th quarter of the columns for all NT rows of every marker, one float4 of T per lane, trait and column group,
 // fetched a section ahead), wave s adds the four partial products, forms the new effects and verifies them with ONE literal
@@ -1290,7 +1255,7 @@ __device__ __forceinline__ void dense_big_mt_solve(char* smem, const StepSmem& S
                 if (wave > s) apply_changes(s, rhs, pq);
             }
             // the section's changes are final: hand them to the helper workgroup that forms the NEXT block's lookahead correction
-            // (corr_helper_mt) -- value and tag in one 8-byte write-through store per trait, fire and forget: the reader polls the tag,
+            // (corr_helper, sampler_common.hpp) -- value and tag in one 8-byte write-through store per trait, fire and forget: the reader polls the tag,
             // so no acknowledgement (s_waitcnt vmcnt) and no flag are needed, and nobody in THIS workgroup waits for anything.
             if (wave == s) {
 #pragma unroll
@@ -1377,60 +1342,6 @@ __device__ __forceinline__ void dense_big_mt_solve(char* smem, const StepSmem& S
         atomicAdd(&A.counters[0], (unsigned long long)nfin);
         atomicAdd(&A.counters[2], (unsigned long long)(tk1 - tk0));      // front
         atomicAdd(&A.counters[5], (unsigned long long)(tk4 - tk1));      // sections (solves / walks + off-diagonal applies)
-    }
-}
-
-// The HELPER workgroup of a Rule T launch (workgroup 8: on the sampler's XCD; sweep.hpp): the lookahead correction of the NEXT
-// block,  corr[t][c'] = fmaf(D_e[t], C[e][c'], corr)  from 0 over the markers e of the block in marker order  (C = X_this'X_next),
-// from the changes the sampler workgroup publishes section by section (A.xch: value + tag per word) -- the cross-Gram block (256 KB) and
-// three quarters of the block's off-diagonal multiply-adds no longer go through the sampler's CU.  Thread c' < 256 owns column
-// c'; the section's 64 cross-Gram values per thread are fetched a section ahead.  The wait is one-directional (the sampler
-// workgroup waits for nobody and is dispatched before this one), its result is consumed by the NEXT launch.  Same operations
-// in the same order as the in-workgroup form: bit-identical.
-template <int NT>
-__device__ __forceinline__ void corr_helper_mt(char* smem, const SamplerArgs& A)
-{
-    constexpr int kB = 256, kSec = 4;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int bn = A.b_next, B = A.bsz;
-    float* dl = reinterpret_cast<float*>(smem);                          // [NT][64] the section's changes
-    const bool colthr = tid < bn && tid < kB;
-    const int cn = colthr ? tid : 0;
-    float corr[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) corr[t] = 0.f;
-    float pq[64];
-    auto load_c = [&](int s) {
-        const char* base = reinterpret_cast<const char*>(A.cross_next + (int64_t)(64 * s) * bn);
-        unsigned off = 4u * (unsigned)cn;
-#pragma unroll
-        for (int u = 0; u < 64; ++u) { pq[u] = *reinterpret_cast<const float*>(base + off); off += 4u * (unsigned)bn; asm volatile("" : "+v"(off)); }
-    };
-    if (bn > 0 && tid < kB) load_c(0);
-#pragma unroll 1
-    for (int s = 0; s < kSec; ++s) {
-        if (tid < NT * 64) {
-            // thread (t, lane): its value of the section, valid once the word carries this section's tag
-            const int t = tid >> 6;
-            const unsigned long long* src = A.xch + t * kB + 64 * s + lane;
-            const unsigned want = (unsigned)(A.xch_epoch + s + 1);
-            unsigned long long v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            while ((unsigned)(v >> 32) != want) {
-                __builtin_amdgcn_s_sleep(8);
-                v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            dl[tid] = __uint_as_float((unsigned)v);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // (LDS only: the cross-Gram loads stay in flight)
-        if (bn > 0 && tid < kB) {
-            apply_section_changes<NT>(dl, 64, corr, pq);
-            if (s + 1 < kSec) load_c(s + 1);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // (dl is rewritten for the next section)
-    }
-    if (bn > 0 && tid < kB) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) A.corr_out[t * B + tid] = colthr ? corr[t] : 0.f;
     }
 }
 

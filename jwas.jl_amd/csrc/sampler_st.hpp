@@ -111,7 +111,10 @@ __device__ __forceinline__ void dense_big_st(char* smem, const StepSmem& SM, con
     const float da = dj * ao;                                           // d * alpha_old (BayesABC.jl:36)
     float an_own = 0.f;
     const int nsec = (b + 63) >> 6;                                     // (a ragged last block: its last section is partial)
-    const bool has_col = tid < bn;
+    // (A.xch: a HELPER workgroup forms the next block's lookahead correction from the changes each section publishes --
+    // corr_helper, sampler_common.hpp: the cross-Gram block, 1 MB of the 1.5 MB a 512-marker block moves, stays off this CU)
+    const bool offload = A.xch != nullptr;
+    const bool has_col = tid < bn && !offload;
     float corr = 0.f;
     float gq[64], cq[64];
     // thread c reads column c of the Gram rows / cross-Gram rows of a section: one dword per lane, coalesced (256 bytes = two
@@ -150,6 +153,9 @@ __device__ __forceinline__ void dense_big_st(char* smem, const StepSmem& SM, con
             an_own = fmaf(kc1, rev, kc0);
             acur[c] = an_own;
             rhs_lds[c] = ao - an_own;                                   // D of this marker, read by everybody after the barrier
+            if (offload)                                                // ... and by the helper workgroup: value + tag, fire and forget
+                __hip_atomic_store(A.xch + c, ((unsigned long long)((unsigned)(A.xch_epoch + s + 1) & 0x7fffffffu) << 32) | (unsigned long long)__float_as_uint(ao - an_own),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         lds_barrier();
         // (Keep this body simple: a variant in which the next walker skipped the correction and caught up in a loop after its
@@ -193,7 +199,7 @@ __device__ __forceinline__ void dense_big_st(char* smem, const StepSmem& SM, con
 #pragma unroll
     for (int q = 0; q < kStepThreads / 64; ++q) { const int v = wcnt[q]; base += (q < wave) ? v : 0; nfin += v; }
     // ---- global stores last
-    if (tid < B && bn > 0) A.corr_out[tid] = has_col ? corr : 0.f;
+    if (tid < B && bn > 0 && !offload) A.corr_out[tid] = has_col ? corr : 0.f;
     if (changed) {
         const int e = base + __popcll(cm & ((1ull << lane) - 1ull));
         const float d = ao - an_own;
@@ -558,6 +564,9 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
 #pragma unroll
             for (int q = 0; q < kStepThreads / 64; ++q) all_in = all_in && ((wc[q] >> 18) & 1);
             if (all_in) { dense_big_st<METHOD>(smem, SM, A, ie, tk0); return; }
+            // (a helper workgroup is waiting for this block's sections: tell it that the general path forms the correction itself)
+            if (A.xch != nullptr && tid < 64)
+                __hip_atomic_store(A.xch + tid, (unsigned long long)(kXchAbort | ((unsigned)(A.xch_epoch + 1) & 0x7fffffffu)) << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     // single-pass sweeps with a next block: waves 1..4 accumulate its lookahead correction while the serial wave runs

@@ -57,7 +57,7 @@ hipError_t launch_step_cx(const StepLaunch& L, const CX& cx, const UpdateArgs& U
 #endif
     const int nwork = L.nrg * U.ncg;
     unsigned grid = (dbg == 2) ? 1u : (U.quiet_xcd ? (unsigned)(1 + (nwork + 6) / 7 * 8) : (unsigned)(1 + nwork));
-    if (S.tsec != nullptr && do_sample && grid < 17u) grid = 17u;      // Rule T: workgroup 16 is the helper the sampler publishes to (sweep.hpp)
+    if (S.xch != nullptr && do_sample && grid < 17u) grid = 17u;       // workgroup 16 is the helper the sampler publishes to (sweep.hpp)
     const int ds = (dbg == 1) ? 0 : do_sample;
     if constexpr (kHasDense) {
         if (dn) {       // uniform pi = 0: the sampler that follows Rule D (and takes dense_big_st on full 256- / 512-marker blocks)

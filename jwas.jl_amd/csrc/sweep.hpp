@@ -155,11 +155,11 @@ __global__ __launch_bounds__(kStepThreads) void k_block_step(UpdateArgsT<CX> U, 
                 return;
             }
         }
-        if constexpr (DENSE && is_sampler1(METHOD) && NT <= 3) {
-            // Rule T launches (S.tsec: multi-trait sampler I, sampler_mt.hpp): workgroup 16 -- another idle one on the sampler's XCD --
-            // forms the next block's lookahead correction from the changes the sampler workgroup publishes (the launcher makes
-            // sure the grid holds it)
-            if (blockIdx.x == 16 && do_sample && S.tsec != nullptr) { corr_helper_mt<NT>(smem, S); return; }
+        if constexpr (DENSE) {
+            // launches whose sampler publishes its sections' changes (S.xch: multi-trait Rule T, single-trait dense_big_st): workgroup
+            // 16 -- another idle one on the sampler's XCD -- forms the next block's lookahead correction from them (corr_helper,
+            // sampler_common.hpp; the launcher makes sure the grid holds it)
+            if (blockIdx.x == 16 && do_sample && S.xch != nullptr) { corr_helper<NT>(smem, S); return; }
         }
         if ((blockIdx.x & 7) == 0) return;
         w = (int)(blockIdx.x - 1) - (int)((blockIdx.x - 1) >> 3);
