@@ -32,6 +32,7 @@ struct jwas_hip_ctx {
 
     int64_t n = 0, p = 0, ld = 0;
     int nslices = 0;                    // 256-row slices
+    int upd_nslices = 0;                // slices of the UPDATE role: = nslices (dense), 1024-row slices on 2-bit packed storage (update_role_wide)
     int nrg = 0, ncg = 1;               // k_update_partial grid: row groups x column groups
     int spg = 8;                        // slices per row group
     float* X = nullptr;                 // dense fp32 storage ...
@@ -352,6 +353,8 @@ static int alloc_storage(jwas_hip_ctx* c, int64_t n, int64_t p, bool packed = fa
     c->method = -1; c->block_size = 0; c->nblocks = 0;
     c->n = n; c->p = p; c->ld = round_up(n, kSliceRows);
     c->nslices = (int)(c->ld / kSliceRows);
+    c->upd_nslices = packed ? (int)((c->ld + kWideRows - 1) / kWideRows) : c->nslices;
+    const int usl = c->upd_nslices;
     // Update-role geometry.  A workgroup is one row group (spg slices of 256 rows, one wave each, spg <= 8) x one column
     // group.  The step kernel's dynamic LDS (sized for the sampler role) allows one workgroup per CU and the quiet-XCD
     // placement leaves every 8th CU idle, so 224 of the 256 CUs stream; more workgroups than that run as a second round
@@ -367,18 +370,18 @@ static int alloc_storage(jwas_hip_ctx* c, int64_t n, int64_t p, bool packed = fa
     {
         const char* e_spg = std::getenv("JWAS_HIP_SPG");                 // (experiments)
         const char* e_cap = std::getenv("JWAS_HIP_MAX_NCG");
-        int best_spg = kRowGroupSlices, best_ncg = 1, best_nrg = (c->nslices + kRowGroupSlices - 1) / kRowGroupSlices;
+        int best_spg = kRowGroupSlices, best_ncg = 1, best_nrg = (usl + kRowGroupSlices - 1) / kRowGroupSlices;
         long best_waves = -1, best_wgs = -1;
         for (int spg = kRowGroupSlices; spg >= 4; --spg) {
             if (e_spg && spg != std::max(1, std::min(kRowGroupSlices, std::atoi(e_spg)))) continue;
-            const int nrg = (c->nslices + spg - 1) / spg;
+            const int nrg = (usl + spg - 1) / spg;
             int ncg = 224 / nrg; if (ncg < 1) ncg = 1;
             const int cap = e_cap ? std::atoi(e_cap) : (nrg < 8 ? 32 : 16);
             if (ncg > cap) ncg = cap;
-            const long waves = (long)c->nslices * ncg, wgs = (long)nrg * ncg;
+            const long waves = (long)usl * ncg, wgs = (long)nrg * ncg;
             // (ties are only broken for tall matrices, where the launch is bound by the update role; shorter ones are
             // bound by the sampler and measured neutral to slightly worse with 6-7 slices per group)
-            if (waves > best_waves || (waves == best_waves && wgs > best_wgs && wgs <= 224 && c->nslices >= 128)) {
+            if (waves > best_waves || (waves == best_waves && wgs > best_wgs && wgs <= 224 && usl >= 128)) {
                 best_waves = waves; best_wgs = wgs; best_spg = spg; best_ncg = ncg; best_nrg = nrg;
             }
         }
@@ -386,7 +389,8 @@ static int alloc_storage(jwas_hip_ctx* c, int64_t n, int64_t p, bool packed = fa
     }
     size_t fb = 0, tb = 0;
     HIPCHK(c, hipMemGetInfo(&fb, &tb));
-    const size_t need = packed ? (size_t)(c->ld >> 2) * p : (size_t)4 * c->ld * p;
+    // (packed: + 1 KB -- the last 1024-row slice of the LAST column may reach past the column's end; what it reads there meets r = 0)
+    const size_t need = packed ? (size_t)(c->ld >> 2) * p + 1024 : (size_t)4 * c->ld * p;
     NEED(c, need < fb, JWAS_HIP_ENOMEM, "genotype matrix needs %.2f GB but only %.2f GB of HBM is free", need / 1e9, fb / 1e9);
     c->packed = packed;
     if (packed) {
@@ -1323,7 +1327,7 @@ static int sweep_independent(jwas_hip_ctx* c, EventList* out, bool dense, int de
     std::memset(&U, 0, sizeof U);
     U.r_in = c->r; U.r_out = nullptr;
     U.ev = &c->ev[0];                               // count zeroed by the caller: nothing to apply
-    U.nslices = c->nslices; U.nrg = c->nrg; U.ncg = c->ncg; U.spg = c->spg;
+    U.nslices = c->upd_nslices; U.nrg = c->nrg; U.ncg = c->ncg; U.spg = c->spg;
     U.partials = c->ipartials; U.bstride = bs;
     SamplerArgs S;
     std::memset(&S, 0, sizeof S);
@@ -1715,7 +1719,7 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
         U.ev = &c->ev[k & 1];
         U.j0 = (k < nb) ? blk_j0(c, k) : 0;
         U.b = (k < nb) ? blk_b(c, k) : 0;
-        U.nslices = c->nslices; U.nrg = c->nrg; U.spg = c->spg;
+        U.nslices = c->upd_nslices; U.nrg = c->nrg; U.spg = c->spg;
         U.ncg = (U.b > 0 && c->ncg > U.b) ? U.b : c->ncg;
         U.partials = c->partials + (k & 1) * pstride; U.bstride = bs;
         U.dbg = c->counters;

@@ -97,6 +97,7 @@ struct DenseCols {
     typedef float4 SRaw;
     static constexpr int kDepth = 1;
     static constexpr bool kCoopApply = true;          // update role: the cooperative dense apply is available (load1 is one dword)
+    static constexpr bool kWide = false;              // (the update role's 256-row slices, four rows per lane)
     // column stream of the update role: element i = rows row..row+3 of marker j0 + i*jstride
     struct Stream {
         const float* p; int64_t stride;
@@ -138,6 +139,7 @@ struct PackedCols {
     struct Raw { unsigned byte; float mu; };
     static constexpr int kDepth = 8;
     static constexpr bool kCoopApply = false;
+    static constexpr bool kWide = true;               // update role: 1024-row slices, one dword = 16 rows per lane (update_role_wide)
     __device__ __forceinline__ Raw load_raw(int64_t j, int64_t row) const
     {
         return Raw{Q[j * (ld >> 2) + (row >> 2)], mean[j]};

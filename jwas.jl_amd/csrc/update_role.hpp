@@ -15,6 +15,189 @@ namespace jw {
 // ---------------------------------------------------------------------------------------------
 // UPDATE/PARTIAL role
 // ---------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------
+// UPDATE/PARTIAL role on 2-BIT PACKED storage (round 5): its own geometry.  A wave owns a 1024-row slice of the residual, a lane
+// SIXTEEN rows = ONE DWORD of a column (the byte-per-lane form of rounds 2-4 moved 64 B per wave load and spent ~9 instructions
+// per row and column: 16x fewer bytes than dense bought 1.19x).  Per column and lane: one dword load, then per row a bit-field
+// extract, a conversion and one fp64 multiply-add; the centring is factored OUT of the loop --
+//     sum_i (v_i - mu) w_i r_i  =  sum_i c_i w_i r_i  -  mu (R - M),    c_i = code (0 for a missing one), R = sum_i w_i r_i, M = sum_missing w_i r_i
+// (decode_marker!, streaming_genotypes.jl:978-1002: v = code == 3 ? mu : code, x = centered ? v - mu : v; uncentred: + mu M) -- so the
+// marker mean enters once per column and lane, and R once per launch.  The sum is the exact-product fp64 sum of the decoded
+// column up to the rounding of fl32(code - mu) the dense matrix carries: the packed path's OWN order (oracle: dot_xr with
+// orc_set_packed_source), within 1e-7 relative of the dense path's right-hand side (the reference's own stream-vs-dense
+// tolerance is 1e-4, test/unit/test_streaming_codec.jl:100,104).  The residual update r += x d stays the decoded form
+// fmaf(d, fl32(v - mu), r) of every other kernel.  Reductions (transposed butterfly over 8 columns, LDS combine over the
+// row group's waves, one fp64 partial per column and row group) are the dense role's.
+// ---------------------------------------------------------------------------------------------
+constexpr int kWideRows = 1024;            // rows of r owned by one wave of the packed update role
+template <int NT, class CX>
+__device__ __forceinline__ void update_role_wide(char* smem, int rg, int g, const CX& cx,
+                                                 const float* __restrict__ r_in, float* __restrict__ r_out,
+                                                 const Events* __restrict__ ev,
+                                                 int64_t j0, int b, int nslices, int nrg, int ncg,
+                                                 double* __restrict__ partials, int bstride, int spg)
+{
+    typedef double RedT[kColChunk][NT];
+    RedT* red = reinterpret_cast<RedT*>(smem);                 // [kRowGroupSlices][kColChunk][NT]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int slice = rg * spg + wave;
+    const bool active = wave < spg && slice < nslices;
+    const int64_t ld = cx.ld;
+    const int64_t row = (int64_t)(active ? slice : 0) * kWideRows + lane * 16;        // (the last slice may reach beyond ld: masked below)
+    const int ncols = (b > g) ? (b - g + ncg - 1) / ncg : 0;
+    const int64_t jc0 = j0 + (ncols > 0 ? g : 0);
+    const int nc1 = ncols > 0 ? ncols - 1 : 0;
+    const int64_t qrow = row >> 2;                              // byte offset of the lane's dword inside a column (a multiple of 4)
+    const int64_t cstride = ld >> 2;                            // bytes per column
+    const uint8_t* qcol = cx.Q + jc0 * cstride + qrow;
+    const int64_t qstep = (int64_t)ncg * cstride;
+    auto load_code = [&](int i) -> unsigned {                   // stream element i = marker jc0 + i * ncg (clamped: always a valid address)
+        return *reinterpret_cast<const unsigned*>(qcol + (int64_t)(i < ncols ? i : nc1) * qstep);
+    };
+    constexpr int D = 4;                                        // register batches of kU dwords in flight per wave
+    unsigned xr[D][kU];
+    float mnext = cx.mean[jc0 + (int64_t)(lane < ncols ? lane : nc1) * ncg];          // means of the first 64 stream elements
+#pragma unroll
+    for (int s = 0; s < D; ++s)
+#pragma unroll
+        for (int u = 0; u < kU; ++u) xr[s][u] = active ? load_code(s * kU + u) : 0u;
+
+    // the residual slice and the weights: 16 rows per lane (rows >= ld: 0)
+    float rv[NT][16], wv[16];
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+        const bool in = active && (row + 4 * q4 < ld);
+        const int64_t rr = in ? row + 4 * q4 : 0;
+        const float4 w4 = *reinterpret_cast<const float4*>(cx.w + rr);
+        wv[4 * q4] = in ? w4.x : 0.f; wv[4 * q4 + 1] = in ? w4.y : 0.f; wv[4 * q4 + 2] = in ? w4.z : 0.f; wv[4 * q4 + 3] = in ? w4.w : 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float4 r4 = *reinterpret_cast<const float4*>(r_in + t * ld + rr);
+            rv[t][4 * q4] = in ? r4.x : 0.f; rv[t][4 * q4 + 1] = in ? r4.y : 0.f; rv[t][4 * q4 + 2] = in ? r4.z : 0.f; rv[t][4 * q4 + 3] = in ? r4.w : 0.f;
+        }
+    }
+    // sparse exit update (BayesABC.jl:181-185): r += x d per changed marker in list order, x the decoded column (pad rows: 0)
+    const int64_t nleft = cx.n - row;
+    const unsigned vmask = nleft >= 16 ? 0xffffu : (nleft <= 0 ? 0u : ((1u << (int)nleft) - 1u));
+    const int ne = ev->count;
+    for (int e0 = 0; e0 < ne; e0 += 64) {
+        const int el = e0 + lane, ec = el < ne ? el : ne - 1;
+        const int liv = ev->idx[ec];
+        const float lmu = cx.mean[liv];
+        float ldv[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) ldv[t] = ev->delta[t][ec];
+        const int rem0 = (ne - e0) < 64 ? (ne - e0) : 64;
+        for (int h = 0; h < rem0; h += 8) {
+            unsigned cq[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int jj = __builtin_amdgcn_readlane(liv, h + u < rem0 ? h + u : rem0 - 1);
+                cq[u] = *reinterpret_cast<const unsigned*>(cx.Q + (int64_t)jj * cstride + qrow);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (h + u < rem0) {
+                    const float mu = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lmu), h + u));
+                    float dd[NT];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) dd[t] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ldv[t]), h + u));
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const float x = ((vmask >> i) & 1u) ? cx.dec((cq[u] >> (2 * i)) & 3u, mu) : 0.f;
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) rv[t][i] = fmaf(dd[t], x, rv[t][i]);
+                    }
+                }
+            }
+        }
+    }
+    if (active && g == 0 && r_out != nullptr) {
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4)
+            if (row + 4 * q4 < ld)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    *reinterpret_cast<float4*>(r_out + t * ld + row + 4 * q4) = float4{rv[t][4 * q4], rv[t][4 * q4 + 1], rv[t][4 * q4 + 2], rv[t][4 * q4 + 3]};
+    }
+    if (ncols == 0) return;
+    // fl32(w r) once per launch (weights = 1: exact); one trait keeps it in double (no conversion in the loop)
+    typedef typename std::conditional<NT == 1, double, float>::type RT;
+    RT rd[NT][16];
+    double Rl[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        Rl[t] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const float wr = rv[t][i] * wv[i]; rd[t][i] = (RT)wr; Rl[t] += (double)wr; }
+    }
+    const bool centered = cx.centered != 0;
+    for (int i0 = 0; i0 < ncols; i0 += kColChunk) {
+        const int iend = (i0 + kColChunk < ncols) ? i0 + kColChunk : ncols;
+        const float mcur = mnext;                                // lane i: mean of stream element i0 + i
+        if (i0 + kColChunk < ncols) mnext = cx.mean[jc0 + (int64_t)(i0 + kColChunk + lane < ncols ? i0 + kColChunk + lane : nc1) * ncg];
+        for (int ib0 = i0; ib0 < iend; ib0 += kU * D) {
+#pragma unroll
+            for (int s = 0; s < D; ++s) {
+                const int ib = ib0 + s * kU;
+                if (ib >= iend) break;
+                double acc[NT][kU];
+                unsigned anymiss = 0u;
+#pragma unroll
+                for (int u = 0; u < kU; ++u) anymiss |= xr[s][u] & (xr[s][u] >> 1) & 0x55555555u;
+                const bool patch = __any(anymiss != 0u);           // (wave-uniform)
+#pragma unroll
+                for (int u = 0; u < kU; ++u) {
+                    const unsigned q = xr[s][u];
+                    const double mu = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(mcur), ib + u - i0));
+                    double sm[NT];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) { acc[t][u] = 0.0; sm[t] = 0.0; }
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const double c = (double)((q >> (2 * i)) & 3u);
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) acc[t][u] = fma(c, (double)rd[t][i], acc[t][u]);
+                    }
+                    if (patch) {                                     // a missing code was counted as 3: take it out, remember its w r
+                        const unsigned m = q & (q >> 1) & 0x55555555u;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i)
+                            if ((m >> (2 * i)) & 1u) {
+#pragma unroll
+                                for (int t = 0; t < NT; ++t) sm[t] += (double)rd[t][i];
+                            }
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) acc[t][u] = fma(-3.0, sm[t], acc[t][u]);
+                    }
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[t][u] = centered ? fma(-mu, Rl[t] - sm[t], acc[t][u]) : fma(mu, sm[t], acc[t][u]);
+                }
+                if (ib + kU * D < ncols) {
+#pragma unroll
+                    for (int u = 0; u < kU; ++u) xr[s][u] = active ? load_code(ib + kU * D + u) : 0u;
+                }
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const double sum = butterfly8(acc[t], lane);
+                    const int u = lane >> 3;                   // column of this 8-lane group
+                    if ((lane & 7) == 0 && ib + u < ncols) red[wave][ib + u - i0][t] = sum;
+                }
+            }
+        }
+        __syncthreads();
+        for (int q = tid; q < (iend - i0) * NT; q += kStepThreads) {
+            const int i = q / NT, t = q - i * NT;
+            double s = 0.0;
+#pragma unroll
+            for (int w = 0; w < kRowGroupSlices; ++w) s += red[w][i][t];
+            const int c = g + (i0 + i) * ncg;
+            partials[((int64_t)t * nrg + rg) * bstride + c] = s;
+        }
+        __syncthreads();
+    }
+}
+
 // ROLL: the rolling-window apply for 33..64 changes (below) -- only where the kernel's register budget carries it (the
 // instantiation's sampler role decides: single-trait BayesA/B/C; with BayesR's or the multi-trait samplers' it spilled)
 template <int NT, class CX, bool COOP = false, bool ROLL = false>
@@ -26,6 +209,11 @@ __device__ __forceinline__ void update_role(char* smem, int rg, int g,
                                             double* __restrict__ partials, int bstride, int spg = kRowGroupSlices,
                                             int* sync_now = nullptr, int* sync_next = nullptr, unsigned long long* dbg = nullptr)
 {
+    if constexpr (CX::kWide) {       // 2-bit packed storage: its own geometry (above)
+        (void)sync_now; (void)sync_next; (void)dbg;
+        update_role_wide<NT, CX>(smem, rg, g, cx, r_in, r_out, ev, j0, b, nslices, nrg, ncg, partials, bstride, spg);
+        return;
+    }
 #ifdef JWAS_HIP_DEV_KNOBS
 #define JW_UPD_CLOCK(v) v = clock64()
 #else

@@ -130,6 +130,36 @@ static float dot_acc(const float* a, const float* b, int64_t n, int acc)
     return s;
 }
 
+/* The block right-hand side x'R^-1 r on 2-BIT PACKED storage, in the packed update role's own order (csrc/update_role.hpp
+ * update_role_wide): the centring is factored out of the sum,
+ *     sum_i (v_i - mu) w_i r_i = sum_i c_i w_i r_i - mu (R - M),   c_i = code (0 for a missing one), R = sum_i w_i r_i, M = sum_missing w_i r_i
+ * (decode_marker!, streaming_genotypes.jl:978-1002; uncentred: + mu M), every sum in fp64 over exact products, rounded to fp32
+ * once.  orc_set_packed_source (harness state): the codes of the matrix X the sweeps are called with, one code 0..3 per byte,
+ * column-major [p][n]; NULL = off (the decoded matrix's own products, as for dense storage). */
+static const uint8_t* g_pk_codes = NULL;
+static const float* g_pk_means = NULL;
+static const float* g_pk_X = NULL;
+static int64_t g_pk_ld = 0, g_pk_n = 0;
+static int g_pk_centered = 1;
+void orc_set_packed_source(const uint8_t* codes, const float* means, int centered, const float* X, int64_t n, int64_t ld)
+{
+    g_pk_codes = codes; g_pk_means = means; g_pk_centered = centered; g_pk_X = X; g_pk_n = n; g_pk_ld = ld;
+}
+static float dot_xr(const float* x, const float* r, int64_t n, int acc)
+{
+    if (!g_pk_codes) return dot_acc(x, r, n, acc);
+    const int64_t j = (x - g_pk_X) / g_pk_ld;
+    const uint8_t* c = g_pk_codes + j * g_pk_n;
+    const double mu = (double)g_pk_means[j];
+    double s1 = 0.0, R = 0.0, M = 0.0;
+    for (int64_t i = 0; i < n; ++i) {
+        const float wr = g_rinv ? r[i] * g_rinv[i] : r[i];
+        if (c[i] == 3) M += (double)wr; else s1 = fma((double)c[i], (double)wr, s1);
+        R += (double)wr;
+    }
+    return (float)(g_pk_centered ? fma(-mu, R - M, s1) : fma(mu, M, s1));
+}
+
 static void axpy_f32(float a, const float* x, float* y, int64_t n)
 {
     for (int64_t i = 0; i < n; ++i) y[i] = fmaf(a, x[i], y[i]);
@@ -240,7 +270,7 @@ int orc_bayesabc_sweep(const float* X, int64_t n, int64_t p, int64_t ld, const f
     for (int64_t j = 0; j < p; ++j) {                                  /* BayesABC.jl:73-79 */
         const float* x = X + j * ld;
         const uint32_t m = marker0 + (uint32_t)j;
-        const float s = dot_acc(x, r, n, acc);                         /* :76 */
+        const float s = dot_xr(x, r, n, acc);                         /* :76 */
         const double u = orc_uniform(seed, m, iter, 0, 0);
         const double z = orc_normal(seed, m, iter, 0, 0);
         const float a = abc_update(s, xpx[j], &alpha[j], &beta[j], &delta[j], ie,
@@ -273,7 +303,7 @@ static int bayesabc_block_sweep_impl(const float* X, int64_t n, int64_t p, int64
         float* a_old_blk = (float*)malloc(sizeof(float) * (size_t)b);
         float* rhs_b     = (float*)malloc(sizeof(float) * (size_t)b);
         memcpy(a_old_blk, alpha + j0, sizeof(float) * (size_t)b);       /* :150 */
-        for (int64_t k = 0; k < b; ++k) rhs_b[k] = dot_acc(X + (j0 + k) * ld, r, n, acc); /* :152 */
+        for (int64_t k = 0; k < b; ++k) rhs_b[k] = dot_xr(X + (j0 + k) * ld, r, n, acc); /* :152 */
         const int nreps = nreps_arg > 0 ? nreps_arg : (int)b;           /* :153 */
         for (int rep = 0; rep < nreps; ++rep)
             for (int64_t k = 0; k < b; ++k) {                           /* :155-178 */
@@ -367,7 +397,7 @@ int orc_bayesr_sweep(const float* X, int64_t n, int64_t p, int64_t ld, const flo
     for (int64_t j = 0; j < p; ++j) {
         const float* x = X + j * ld;
         const uint32_t m = marker0 + (uint32_t)j;
-        const float s = dot_acc(x, r, n, acc);
+        const float s = dot_xr(x, r, n, acc);
         const double u = orc_uniform(seed, m, iter, 0, 0);
         const double z = orc_normal(seed, m, iter, 0, 0);
         const float a = bayesr_update(s, xpx[j], &alpha[j], &delta[j], ie, sigma_sq,
@@ -396,7 +426,7 @@ static int bayesr_block_sweep_impl(const float* X, int64_t n, int64_t p, int64_t
         float* a_old_blk = (float*)malloc(sizeof(float) * (size_t)b);
         float* rhs_b     = (float*)malloc(sizeof(float) * (size_t)b);
         memcpy(a_old_blk, alpha + j0, sizeof(float) * (size_t)b);
-        for (int64_t k = 0; k < b; ++k) rhs_b[k] = dot_acc(X + (j0 + k) * ld, r, n, acc);
+        for (int64_t k = 0; k < b; ++k) rhs_b[k] = dot_xr(X + (j0 + k) * ld, r, n, acc);
         const int nreps = nreps_arg > 0 ? nreps_arg : (int)b;
         for (int rep = 0; rep < nreps; ++rep)
             for (int64_t k = 0; k < b; ++k) {
@@ -849,7 +879,7 @@ int orc_mt_sweep(int kind, const float* X, int64_t n, int64_t p, int64_t ld, con
     for (int64_t j = 0; j < p; ++j) {
         const float* x = X + j * ld;
         float w[ORC_MAXT], a[ORC_MAXT];
-        for (int k = 0; k < t; ++k) w[k] = dot_acc(x, r + k * ld_r, n, acc);     /* :82 */
+        for (int k = 0; k < t; ++k) w[k] = dot_xr(x, r + k * ld_r, n, acc);     /* :82 */
         mt_update(kind, t, w, xpx[j], alpha + j, beta + j, delta + j, p, Rinv, marker_ginv(j, t, Ginv, Gtmp_), vare, marker_var(j, t, var_effect),
                   prior_is_matrix ? log_prior + (int64_t)nstates * j : log_prior,
                   seed, marker0 + (uint32_t)j, iter, 0, a);
@@ -881,7 +911,7 @@ static int mt_block_sweep_impl(int kind, const float* X, int64_t n, int64_t p, i
         for (int k = 0; k < t; ++k) {
             memcpy(a_old_blk + k * b, alpha + k * p + j0, sizeof(float) * (size_t)b);
             for (int64_t c = 0; c < b; ++c)
-                rhs_b[k * b + c] = dot_acc(X + (j0 + c) * ld, r + k * ld_r, n, acc);
+                rhs_b[k * b + c] = dot_xr(X + (j0 + c) * ld, r + k * ld_r, n, acc);
         }
         const int nreps = nreps_arg > 0 ? nreps_arg : (int)b;
         for (int rep = 0; rep < nreps; ++rep)
@@ -938,7 +968,7 @@ static void la_block_rhs(const la_ctx* L, int t, float* r, int64_t ld_r, int64_t
 {
     for (int k = 0; k < t; ++k)
         for (int64_t c = 0; c < b; ++c)
-            rhs[k * b + c] = dot_acc(L->X + (j0 + c) * L->ld, r + k * ld_r, L->n, L->acc);
+            rhs[k * b + c] = dot_xr(L->X + (j0 + c) * L->ld, r + k * ld_r, L->n, L->acc);
     /* corr[c] = sum over the changed markers of the previous block, accumulated from 0 in marker order with
      * fmaf; then ONE fp32 add onto the rounded dot product (the device forms corr at the end of the previous
      * block's sampler, before this block's partial sums exist). */

@@ -167,6 +167,9 @@ void orc_set_abc_rule_d(int on);
 /* Rule T (the device's jwas_sweep_params.section_solve; see mt1_section_solve / abc_section_solve): dense 64-marker sections of
  * the lookahead forms' full blocks as triangular solves.  1 = on, 0 = the sequential chain (default). */
 void orc_set_section_solve(int on);
+/* The block right-hand sides in the 2-bit packed update role's own order (see dot_xr): codes [p][n], one code 0..3 per byte,
+ * of the matrix X the sweeps are called with; NULL = off. */
+void orc_set_packed_source(const uint8_t* codes, const float* means, int centered, const float* X, int64_t n, int64_t ld);
 void orc_section_solve_counts(int64_t* solved, int64_t* fallbacks, int reset);
 /* One InverseWishart(df, scale + b_j b_j') draw per marker (variance_components.jl:181-186; df = the reference's df + 1),
  * Bartlett on the counter RNG: the restatement the device's k_sample_marker_covariances is compared with. */

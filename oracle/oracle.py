@@ -142,6 +142,26 @@ def _vec_or_fill(v, p, dtype):
 RULE_D = True        # (tests switch the rule off to compare with the literal operation order)
 
 
+def set_packed_source(codes, means, centered, X):
+    """The block right-hand sides in the 2-bit packed update role's own order (jwas_oracle.c dot_xr): codes (n x p, 0..3; 3 =
+    missing) of the matrix X (the decoded, Fortran-ordered float32 matrix the sweeps are called with).  codes=None switches it
+    off.  The arrays are borrowed: keep them alive while the mode is on."""
+    global _PK_KEEP
+    if codes is None:
+        lib().orc_set_packed_source(None, None, C.c_int(1), None, C.c_int64(0), C.c_int64(0))
+        _PK_KEEP = None
+        return
+    cc = np.ascontiguousarray(np.asarray(codes, dtype=np.uint8).T)          # [p][n]
+    mm = np.ascontiguousarray(means, dtype=np.float32)
+    n, p, ld = _xinfo(X)
+    _PK_KEEP = (cc, mm, X)
+    lib().orc_set_packed_source(cc.ctypes.data_as(C.c_void_p), mm.ctypes.data_as(C.c_void_p), C.c_int(1 if centered else 0),
+                                X.ctypes.data_as(C.c_void_p), C.c_int64(n), C.c_int64(ld))
+
+
+_PK_KEEP = None
+
+
 def set_section_solve(on):
     """Rule T (the device's section_solve): dense sections of the lookahead forms' full blocks as triangular solves."""
     lib().orc_set_section_solve(C.c_int(1 if on else 0))

@@ -157,6 +157,14 @@ class OracleEngine:
     def mul_alpha_output(self, trait=0):
         return (self.X_out.astype(np.float64) @ self.alpha[trait].astype(np.float64)).astype(np.float32)
 
+    def set_packed_source(self, codes, means, centered=True):
+        """Block right-hand sides in the 2-bit packed update role's own order (oracle.set_packed_source) for THIS engine's matrix:
+        codes n x p (0..3, 3 = missing) whose decoded form was loaded with load_dense.  codes=None: off."""
+        if codes is None:
+            O.set_packed_source(None, None, True, None)
+        else:
+            O.set_packed_source(codes, means, centered, self.X)
+
     def sweep(self, *, iteration, seed, vare, var_effect, pi=0.0, pi_classes=None, gamma=O.GAMMA,
               log_prior_states=None, var_effect_vec=None, var_effect_matrix=None, pi_vec=None, pi_matrix=None, nreps=1,
               marker_offset=0, independent_blocks=False, section_solve=False):
