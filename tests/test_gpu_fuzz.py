@@ -200,3 +200,71 @@ def test_random_configurations_against_the_oracle(hip, seed, monkeypatch):
         assert np.array_equal(do, dh), f"{c}"
         assert np.array_equal(ah, ao) and np.array_equal(bh, bo), f"{c}: max |d alpha| {np.abs(ah - ao).max()}"
         assert np.array_equal(hip.get_residual(k), orc.get_residual(k)), f"{c}"
+
+
+@pytest.mark.parametrize("seed", list(range(max(40, int(__import__("os").environ.get("JWAS_FUZZ_CASES", "400")) // 8))))
+def test_random_rule_t_configurations_against_the_oracle(hip, seed):
+    """Differential fuzzing of RULE T (jwas_sweep_params.section_solve: dense 64-marker sections of multi-trait sampler I as
+    triangular solves with per-sweep section inverses, csrc/sampler_mt.hpp): random shapes (one to four full 256-marker blocks
+    and a ragged tail), two or three traits, a shared or a per-marker effect covariance, priors from "nothing ever leaves the
+    model" to "verifications fail in most sweeps", some markers outside the model at the start (sections that are walked),
+    residual weights -- with the oracle's sums in the device's order and the oracle's Grams on the device, the chains are equal
+    BIT FOR BIT, and the same sections are solved / fall back on both sides."""
+    import oracle as O
+    rng = np.random.default_rng(77_000 + seed)
+    t = int(rng.integers(2, 4))
+    method = "MTBayesB" if rng.random() < 0.35 else "MTBayesC"
+    n = int(rng.integers(300, 900)) if rng.random() < 0.7 else int(rng.integers(1500, 3300))
+    p = 256 * int(rng.integers(1, 5)) + int(rng.choice([0, 0, 17, 130, 255]))
+    leak = float(rng.choice([0.0, 1e-9, 1e-4, 3e-3]))
+    d = make_dataset(n=n, p=p, ncausal=min(10, p), seed=int(rng.integers(0, 1000)))
+    y = (d["y"] - d["y"].mean()).astype(np.float32)
+    w = rng.uniform(0.3, 3.0, n).astype(np.float32) if rng.random() < 0.25 else None
+    hip.load_dense(d["X"]); hip.set_weights(w)
+    O.set_device_order(hip.update_geometry()[0])
+    orc = OracleEngine("lookahead", acc=O.ACC_DEVICE)
+    orc.load_dense(d["X"]); orc.set_weights(w)
+    for e in (orc, hip):
+        e.setup_blocks(256, "f64")
+    hip.set_xpx(orc._xpx); hip.set_grams_packed(orc._grams)
+    orc._w()
+    st_ = list(orc._bs) + [p]
+    for kb in range(1, len(st_) - 1):
+        hip.set_cross_gram(kb, O.cross_gram(d["X"], st_[kb - 1], st_[kb] - st_[kb - 1], st_[kb], st_[kb + 1] - st_[kb], O.ACC_DEVICE))
+    O.set_weights(None)
+    d0 = np.ones((t, p), dtype=np.float32)
+    if rng.random() < 0.4:                                              # a few markers start outside the model for a trait
+        k_out = int(rng.integers(1, 12))
+        d0[rng.integers(0, t, k_out), rng.choice(p, k_out, replace=False)] = 0.0
+    for e in (orc, hip):
+        e.init_state(method, t)
+        for k in range(t):
+            e.set_residual(((1 + 0.3 * k) * y).astype(np.float32), k)
+            e.set_state(k, delta=d0[k])
+    v = np.float32(max(float(np.var(y)), 0.1))
+    A = rng.standard_normal((t, t)); Rm = ((A @ A.T / t + np.eye(t)) * v).astype(np.float32)
+    Bm = rng.standard_normal((t, t)); Gm = ((Bm @ Bm.T / t + np.eye(t)) * 0.02).astype(np.float32)
+    prior = np.full(1 << t, leak); prior[-1] = 1.0; prior /= prior.sum()
+    with np.errstate(divide="ignore"):
+        kw = dict(vare=Rm, var_effect=Gm, log_prior_states=np.log(prior), section_solve=True)
+    if method == "MTBayesB":
+        Wm = rng.standard_normal((p, t, t))
+        kw["var_effect_matrix"] = ((Wm @ Wm.transpose(0, 2, 1) / t + np.eye(t)) * (0.02 * np.exp(rng.uniform(-1, 1, p)))[:, None, None]).astype(np.float32)
+    O.section_solve_counts(reset=True)
+    solved = fallen = 0
+    try:
+        for it in range(1, 5):
+            so = orc.sweep(iteration=it, seed=1000 + seed, **kw)
+            sh = hip.sweep(iteration=it, seed=1000 + seed, **kw)
+            cnt = hip.last_sweep_counters()
+            solved += cnt[16]; fallen += cnt[17]
+            assert so["n_events"] == sh["n_events"], f"seed {seed} iteration {it}"
+    finally:
+        O.set_device_order(8)
+    assert (solved, fallen) == O.section_solve_counts(), f"seed {seed}"
+    for k in range(t):
+        ao, bo, do = orc.get_state(k)
+        ah, bh, dh = hip.get_state(k)
+        assert np.array_equal(do, dh), f"seed {seed}"
+        assert np.array_equal(ah, ao) and np.array_equal(bh, bo), f"seed {seed}: max |d alpha| {np.abs(ah - ao).max()}"
+        assert np.array_equal(hip.get_residual(k), orc.get_residual(k)), f"seed {seed}"
