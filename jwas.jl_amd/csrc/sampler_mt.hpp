@@ -1478,6 +1478,21 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
     bool cand[2] = {false, false};
     float djq_[2], a0[2][NT], b0[2][NT], d0[2][NT], w0[2][NT], lc0[2][NT], gq_[2][kPG ? NT * NT : 1];
     double thr0[2][NT], z0[2][NT];
+    // Rule T launches (full 256-marker blocks): the front is bound by the instruction issue of its four marker waves (~50 loads
+    // with their addresses, ~35 LDS stores per thread) -- waves 4..7, idle otherwise, take the right-hand sides (the row-group
+    // partial sums + the lookahead correction: 3 nrg + 3 loads per marker) off them
+    bool split_front = false;
+    if constexpr (kDW && is_sampler1(METHOD) && NT <= 3) split_front = A.tsec != nullptr;
+    if (split_front && tid >= 256) {
+        const int c = tid - 256;
+        float co[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) co[t] = A.corr_in[t * B + c];
+        double psum[NT];
+        sum_partials_traits<NT>(A.partials + c, (int64_t)A.nrg * A.bstride, A.nrg, A.bstride, psum);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) rhs_lds[t * B + c] = (float)psum[t] + co[t];
+    }
 #pragma unroll
     for (int q = 0; q < (kDW ? 1 : 2); ++q) {
         const int c = tid + q * kStepThreads;
@@ -1504,13 +1519,17 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
             for (int st = 0; st < (1 << NT); ++st) lpm[st] = A.lpr_mat[(int64_t)(1 << NT) * j + st];
         }
         double psum[NT];
-        sum_partials_traits<NT>(A.partials + cc, (int64_t)A.nrg * A.bstride, A.nrg, A.bstride, psum);
+        if (!split_front) sum_partials_traits<NT>(A.partials + cc, (int64_t)A.nrg * A.bstride, A.nrg, A.bstride, psum);
+        else {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) psum[t] = 0.0;
+        }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const double sum = psum[t];
             const float rhs0 = (float)sum + co[t];
             const float a_in = (c < b) ? a0[q][t] : 0.f;
-            rhs_lds[t * B + c] = rhs0;
+            if (!split_front) rhs_lds[t * B + c] = rhs0;
             acur[t * B + c] = a_in; astart[t * B + c] = a_in;
             bcur[t * B + c] = b0[q][t]; dcur[t * B + c] = d0[q][t];
             w0[q][t] = rhs0 + dj * a_in;                                                             // :82

@@ -140,6 +140,30 @@ __global__ __launch_bounds__(kStepThreads) void k_block_step(UpdateArgsT<CX> U, 
                 const int nl_c = (S.cross_after != nullptr) ? S.lines_after : 0;
                 const int nl_t = (S.tsec_next != nullptr) ? S.tsec_lines : 0;          // Rule T: the next block's section inverses
                 float sink = 0.f;
+                if constexpr (is_mt_method(METHOD)) {
+                    // ... and, first, the per-marker state the next launch's FRONT reads (x'x, alpha / beta / delta, the sweep's draws
+                    // and logs: ~30 KB per 256 markers): the front is ONE memory latency -- 3.5 us from HBM under the stream's load
+                    const int bnx = S.b_next;
+                    const int64_t jn = S.j0 + S.b, pp = S.p;
+                    if (bnx > 0) {
+                        const int nlf = (bnx + 31) / 32, nld = (bnx + 15) / 16, nfa = 1 + 4 * NT;
+                        int task = (int)threadIdx.x;
+                        if (task < nfa * nlf) {
+                            const int ar = task / nlf, l = task - ar * nlf;
+                            const float* base = ar == 0 ? S.xpx
+                                              : ar <= NT ? S.alpha + (int64_t)(ar - 1) * pp
+                                              : ar <= 2 * NT ? S.beta + (int64_t)(ar - NT - 1) * pp
+                                              : ar <= 3 * NT ? reinterpret_cast<const float*>(S.delta) + (int64_t)(ar - 2 * NT - 1) * pp
+                                              : S.prep_f + (int64_t)(ar - 3 * NT - 1) * pp;
+                            sink += base[jn + (int64_t)l * 32];
+                        }
+                        task -= nfa * nlf;
+                        if (task >= 0 && task < 2 * NT * nld) {
+                            const int ar = task / nld, l = task - ar * nld;
+                            sink += (float)S.prep_d[(int64_t)ar * pp + jn + (int64_t)l * 16];
+                        }
+                    }
+                }
                 for (int l0 = 0; l0 < nl_g + nl_c + nl_t; l0 += 8 * kStepThreads) {
                     float v[8];
 #pragma unroll

@@ -599,3 +599,88 @@ def test_rule_d_stays_within_float32_rounding_of_the_literal_order():
         e.sweep(iteration=1, seed=3, vare=np.float32(0.6), var_effect=np.float32(0.002), pi=pi)
         out.append(e.get_state(0)[0])
     assert (out[0] != out[1]).any() and np.abs(out[0] - out[1]).max() < 1e-5
+
+
+def test_rule_t_stays_within_float32_rounding_of_the_literal_chain():
+    """Rule T (csrc/sampler_mt.hpp dense_big_mt_solve, oracle mt1_section_solve): a 64-marker section of a full 256-marker block in
+    which every marker is in the model for every trait is evaluated as D = T y with the section's inverse T = (I + L)^-1 instead
+    of the 64-step chain.  Against the LITERAL restatement of the block form (_MTBayesABC_samplerI!, MTBayesABC.jl:243-333: no
+    linear form, no solve): the same inclusion decisions in every sweep, effects within 2e-5 of their scale after eight dense
+    sweeps (the chain is a contraction in this regime: rounding differences do not grow); with a prior that lets markers leave
+    the model the verification sends sections back to the sequential chain and the agreement stays."""
+    import oracle as O
+    from oracle_engine import OracleEngine
+    t = 3
+    d = make_dataset(n=700, p=3 * 256 + 40, ncausal=12, seed=8)
+    y = d["y"] - d["y"].mean()
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((t, t)); B = rng.standard_normal((t, t))
+    vare = ((A @ A.T / t + np.eye(t)) * 0.5).astype(np.float32)
+    varg = ((B @ B.T / t + np.eye(t)) * 0.003).astype(np.float32)
+    for leak, expect_fallback in ((1e-9, False), (2e-3, True)):
+        prior = np.full(1 << t, leak); prior[-1] = 1.0; prior /= prior.sum()
+        kw = dict(vare=vare, var_effect=varg, log_prior_states=np.log(prior))
+        res = {}
+        try:
+            for tag in ("literal", "solve"):
+                O.lib().orc_set_mt_linear_form(0 if tag == "literal" else 1)
+                e = OracleEngine("lookahead")
+                e.load_dense(d["X"]); e.setup_blocks(256); e.init_state("MTBayesC", t)
+                for k in range(t):
+                    e.set_residual(((1 + 0.2 * k) * y).astype(np.float32), k)
+                    e.set_state(k, delta=np.ones(e.p, dtype=np.float32))
+                O.section_solve_counts(reset=True)
+                traj = []
+                for it in range(1, 9):
+                    e.sweep(iteration=it, seed=5, section_solve=(tag == "solve"), **kw)
+                    traj.append(np.stack([e.get_state(k)[2] for k in range(t)]).copy())
+                res[tag] = ([e.get_state(k) for k in range(t)], traj, O.section_solve_counts())
+        finally:
+            O.lib().orc_set_mt_linear_form(1)
+        assert res["literal"][2] == (0, 0) and res["solve"][2][0] > 0
+        assert (res["solve"][2][1] > 0) == expect_fallback
+        if not expect_fallback:                  # (with a leaky prior single decisions may flip at rounding level: the chains are compared while they agree)
+            for a, b in zip(res["literal"][1], res["solve"][1]):
+                assert np.array_equal(a, b)
+            for k in range(t):
+                scale = np.abs(res["literal"][0][k][0]).max()
+                np.testing.assert_allclose(res["solve"][0][k][0], res["literal"][0][k][0], atol=2e-5 * scale)
+                assert (res["solve"][0][k][0] != res["literal"][0][k][0]).any()
+
+
+def test_packed_order_right_hand_side_equals_the_decoded_dot_product():
+    """The 2-bit packed update role forms x'R^-1 r with the centring factored out of the sum (oracle dot_xr; decode_marker!,
+    streaming_genotypes.jl:978-1002): sum_i c_i w_i r_i - mu (R - M).  Against the dot product of the decoded Float32 column --
+    what the dense path and the reference's streaming path compute -- within 1e-6 relative (the decoded matrix carries the
+    rounding of fl32(code - mu)); missing codes, residual weights, centred and uncentred storage; and a whole BayesC chain in
+    that order stays within the reference's own stream-vs-dense tolerance (1e-4, test_streaming_codec.jl:100,104) of the chain
+    on the decoded matrix."""
+    import oracle as O
+    from oracle_engine import OracleEngine
+    rng = np.random.default_rng(11)
+    n, p = 333, 150
+    codes = rng.integers(0, 3, size=(n, p)).astype(np.uint8)
+    codes[rng.integers(0, n, 60), rng.integers(0, p, 60)] = 3
+    miss = codes == 3
+    means = np.array([codes[~miss[:, j], j].mean(dtype=np.float32) for j in range(p)], dtype=np.float32)
+    y = rng.standard_normal(n).astype(np.float32)
+    for centered in (True, False):
+        v = np.where(miss, means[None, :], codes.astype(np.float32)).astype(np.float32)
+        X = np.asfortranarray(v - means[None, :] if centered else v)
+        for weights in (None, rng.uniform(0.5, 2.0, n).astype(np.float32)):
+            res = {}
+            for tag in ("decoded", "packed"):
+                e = OracleEngine("lookahead")
+                e.load_dense(X); e.set_weights(weights); e.setup_blocks(64); e.init_state("BayesC", 1)
+                e.set_residual(y - y.mean())
+                try:
+                    if tag == "packed":
+                        e.set_packed_source(codes, means, centered=centered)
+                    for it in range(1, 7):
+                        e.sweep(iteration=it, seed=2, vare=np.float32(0.8), var_effect=np.float32(0.01), pi=0.7)
+                finally:
+                    e.set_packed_source(None, None)
+                res[tag] = (e.get_state(0), e.get_residual(0))
+            scale = max(float(np.abs(res["decoded"][0][0]).max()), 1e-3)
+            np.testing.assert_allclose(res["packed"][0][0], res["decoded"][0][0], rtol=0, atol=1e-4 * scale)
+            assert (res["packed"][0][2] == res["decoded"][0][2]).mean() > 0.98
