@@ -448,7 +448,7 @@ def main():
         bytes_per_launch = acc["bytes"] / launches                 # algorithmic: 4 B (2 bits if packed) x n per marker, X read once
         bs_now = state["bs"]
         achieved = bytes_per_launch / 1e9 / (avg_launch_us * 1e-6)
-        variant = f"{a.mt_method}/{a.mt_prior}" if t > 1 else None          # (config 4: sampler family and prior of the run)
+        variant = (f"{a.mt_method}/{a.mt_prior}" + ("/walk" if (a.no_section_solve and mt_big and t <= 3 and bs == 256) else "")) if t > 1 else None   # (config 4: sampler family, prior, chain form)
         traffic, traffic_src = traffic_from_profiles(wl, n, p_total, bs_now, a.storage, world, a.pi_fixed, variant)
         if t == 1 and method == "BayesC":
             in_model = float(last["sum_delta"][0])
@@ -467,7 +467,7 @@ def main():
             "metric": "MCMC iters/sec (full marker sweep)", "value": a.steps / elapsed, "unit": "iterations/s",
             "n_gpus": comm_world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": desc, "name": wl, "variant": (f"{a.mt_method}/{a.mt_prior}" if t > 1 else None), "storage": a.storage,
+            "config": {"workload": desc, "name": wl, "variant": variant, "storage": a.storage,
                        "n": n, "p": p_total, "block_size": bs_now, "block_policy": "adaptive 512/1024" if adaptive else "fixed",
                        "parallelism": (f"{'row' if rows_mode else 'marker'}-shard x{world}" + (" (exact chain of the pooled data; one all-reduce of the block RHS per block launch)" if rows_mode else " (one all-reduce of the residual delta per sweep; residual resident in HBM)")) if world > 1 else "single GPU",
                        "ranks_reported_by_communicator": comm_world,

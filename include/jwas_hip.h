@@ -195,7 +195,8 @@ int  jwas_hip_get_columns(jwas_hip_ctx* ctx, int64_t j0, int64_t count, float* o
  * a matrix that is produced in marker chunks -- impute_genotypes (single_step/SSBR.jl:112-135: 1000 markers at a time) --
  * goes to HBM chunk by chunk and never exists on the host as a whole.  Resident block configurations are dropped. */
 int  jwas_hip_set_columns(jwas_hip_ctx* ctx, int64_t j0, int64_t count, const float* cols_host, int64_t ld_host);
-/* Memory guard (tools4genotypes.jl:99-235 analogue for HBM): bytes the dense path needs. */
+/* Memory guard (tools4genotypes.jl:99-235 analogue for HBM): bytes the dense path needs (2 or 3 traits on 256-marker
+ * blocks: incl. the per-sweep section inverses of jwas_sweep_params.section_solve, p * 64 * ntraits^2 * 4 bytes). */
 int64_t jwas_hip_estimate_bytes(int64_t n, int64_t p, int32_t ntraits, int32_t block_size);
 /* Same for a given storage kind (estimate_marker_memory(...; storage_mode), tools4genotypes.jl:99-235). */
 int64_t jwas_hip_estimate_bytes_storage(int64_t n, int64_t p, int32_t ntraits, int32_t block_size, int32_t storage);
@@ -217,6 +218,10 @@ int  jwas_hip_synth_single_step(jwas_hip_ctx* ctx, uint64_t seed, int64_t n_geno
  * (variance_components.jl:82-98); the residual update itself uses the plain column (BayesABC.jl:48).
  * Call after loading genotypes and BEFORE jwas_hip_setup_blocks (resident block configurations are dropped). */
 int  jwas_hip_set_weights(jwas_hip_ctx* ctx, const float* rinv_n);
+/* The same for a Float64 context (jwas_hip_set_precision(ctx, 64)): the weights as the Float64 values the reference holds under
+ * double_precision = true (invweights, build_MME.jl:310) -- jwas_hip_set_weights on such a context widens Float32 values.
+ * A Float32 context rejects it (JWAS_HIP_ESTATE). */
+int  jwas_hip_set_weights_f64(jwas_hip_ctx* ctx, const double* rinv_n);
 
 /* ---- precompute: x'x and block Grams ----------------------------------------------------------- */
 /* block_size in {64,128,256,512,1024}; markers are processed in consecutive blocks of this size. */

@@ -29,7 +29,7 @@ SYMBOLS = [
     "jwas_hip_accumulate", "jwas_hip_get_posterior",
     "jwas_hip_load_jgb2", "jwas_hip_load_packed2bit", "jwas_hip_alloc_packed2bit", "jwas_hip_storage_info",
     "jwas_hip_set_xpx", "jwas_hip_estimate_bytes_storage", "jwas_hip_add_block_size", "jwas_hip_select_block_size",
-    "jwas_hip_set_weights", "jwas_hip_synth_single_step", "jwas_hip_setup_blocks_explicit",
+    "jwas_hip_set_weights", "jwas_hip_set_weights_f64", "jwas_hip_synth_single_step", "jwas_hip_setup_blocks_explicit",
     "jwas_hip_comm_row_shards", "jwas_hip_comm_init_loopback", "jwas_hip_update_geometry", "jwas_hip_set_cross_gram",
     "jwas_hip_set_columns", "jwas_hip_get_alpha_sparse", "jwas_hip_comm_unique_id", "jwas_hip_comm_init", "jwas_hip_comm_destroy", "jwas_hip_sweep_sharded",
     "jwas_hip_residual_add_scalar", "jwas_hip_comm_info", "jwas_hip_sample_marker_covariances", "jwas_hip_get_marker_covariances",
@@ -163,6 +163,7 @@ def load():
     L.jwas_hip_storage_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
     L.jwas_hip_set_xpx.argtypes = [vp, vp]
     L.jwas_hip_set_weights.argtypes = [vp, vp]
+    L.jwas_hip_set_weights_f64.argtypes = [vp, vp]
     L.jwas_hip_add_block_size.argtypes = [vp, i32, i32]
     L.jwas_hip_setup_blocks_explicit.argtypes = [vp, C.POINTER(C.c_int64), i64, i32]
     L.jwas_hip_comm_row_shards.argtypes = [vp, i32]

@@ -201,7 +201,7 @@ static auto with_cols(jwas_hip_ctx* c, int64_t j_off, F&& f)
 #define ONLY_F64(c) NEED(c, IS_F64(c), JWAS_HIP_ESTATE, "this entry point needs a Float64 context (jwas_hip_set_precision(ctx, 64))")
 static int f64_setup_blocks(jwas_hip_ctx* c, int32_t bs);
 static int f64_setup_blocks_explicit(jwas_hip_ctx* c, const int64_t* starts, int64_t nblocks);
-static int f64_set_weights(jwas_hip_ctx* c, const float* rinv);
+static int f64_set_weights(jwas_hip_ctx* c, const float* rinv32, const double* rinv64);
 static int f64_init_state(jwas_hip_ctx* c, int32_t method, int32_t nt);
 
 
@@ -331,6 +331,8 @@ int64_t jwas_hip_estimate_bytes(int64_t n, int64_t p, int32_t ntraits, int32_t b
     bytes += (int64_t)ntraits * p * 4 * 6;                       // alpha, beta, delta, 3 running means
     bytes += (int64_t)kMaxT * ld * 4;                            // residuals
     bytes += (int64_t)block_size * (ld / kSliceRows) * ntraits * 8;   // slice partials
+    if (ntraits >= 2 && ntraits <= 3 && block_size == 256)       // Rule T (section_solve): the per-sweep section inverses, (64 t)^2 floats per 64 markers
+        bytes += (p / 256) * 4 * (int64_t)(64 * ntraits) * (64 * ntraits) * 4;
     return bytes;
 }
 
@@ -543,7 +545,7 @@ int jwas_hip_load_jgb2(jwas_hip_ctx* c, const char* path)
 
 int jwas_hip_set_weights(jwas_hip_ctx* c, const float* rinv)
 {
-    if (c && IS_F64(c)) return f64_set_weights(c, rinv);
+    if (c && IS_F64(c)) return f64_set_weights(c, rinv, nullptr);
     NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
     NEED(c, HAVE_STORAGE(c), JWAS_HIP_ESTATE, "no genotype matrix loaded");
     HIPCHK(c, hipSetDevice(c->device));
@@ -560,6 +562,13 @@ int jwas_hip_set_weights(jwas_hip_ctx* c, const float* rinv)
     c->weighted = !unit;
     free_blocks(c);                                             // x'R^-1 x and the Grams depend on the weights
     return JWAS_HIP_OK;
+}
+
+int jwas_hip_set_weights_f64(jwas_hip_ctx* c, const double* rinv)
+{
+    NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
+    NEED(c, IS_F64(c), JWAS_HIP_ESTATE, "jwas_hip_set_weights_f64 needs a Float64 context (jwas_hip_set_precision(ctx, 64)); a Float32 context takes jwas_hip_set_weights");
+    return f64_set_weights(c, nullptr, rinv);
 }
 
 int jwas_hip_storage_info(jwas_hip_ctx* c, int32_t* kind, int64_t* n, int64_t* p, int64_t* bytes)
@@ -1990,7 +1999,7 @@ static int f64_init_state(jwas_hip_ctx* c, int32_t method, int32_t nt)
 
 // Residual weights of a Float64 context: taken as the Float32 values the C ABI carries, widened (the reference casts whatever
 // it is given, JWAS.jl:349-366); x'R^-1 x and the Grams depend on them, so the blocks are rebuilt.
-static int f64_set_weights(jwas_hip_ctx* c, const float* rinv)
+static int f64_set_weights(jwas_hip_ctx* c, const float* rinv32, const double* rinv64)
 {
     auto* F = c->f64;
     NEED(c, F->X, JWAS_HIP_ESTATE, "no genotype matrix loaded");
@@ -1998,9 +2007,9 @@ static int f64_set_weights(jwas_hip_ctx* c, const float* rinv)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     std::vector<double> wv((size_t)c->ld, 0.0);
     for (int64_t i = 0; i < c->n; ++i) {
-        const float v = rinv ? rinv[i] : 1.f;
-        NEED(c, std::isfinite(v) && v > 0.f, JWAS_HIP_EINVAL, "residual weights must be positive and finite (row %lld: %g)", (long long)i, (double)v);
-        wv[(size_t)i] = (double)v;
+        const double v = rinv64 ? rinv64[i] : rinv32 ? (double)rinv32[i] : 1.0;      // (Float64 weights as they are: build_MME.jl:310)
+        NEED(c, std::isfinite(v) && v > 0.0, JWAS_HIP_EINVAL, "residual weights must be positive and finite (row %lld: %g)", (long long)i, v);
+        wv[(size_t)i] = v;
     }
     HIPCHK(c, hipMemcpy(F->w, wv.data(), sizeof(double) * (size_t)c->ld, hipMemcpyHostToDevice));
     if (!F->starts.empty()) return f64_build_blocks(c);

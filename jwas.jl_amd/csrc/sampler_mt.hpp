@@ -170,6 +170,15 @@ __device__ __forceinline__ void mt1_linear_A(const MtConsts<NT>& K, float dj, fl
 // added as (p0 + p1) + (p2 + p3).
 // ---------------------------------------------------------------------------------------------
 template <int NT> __host__ __device__ constexpr int64_t tsec_floats() { return (int64_t)(64 * NT) * (64 * NT); }
+// EXCEPTIONS of a solved section (a marker that is not in the model for every trait at entry, or that the verification finds
+// leaving it).  T_s is lower block triangular, so everything before the first exception e is final; the literal evaluation of e
+// at the right-hand side the solve implies for it, rhs_e + R Lc_e (y_e - D~_e), IS the chain's evaluation of e (whatever y_e
+// was: the row only recovers sum_{j<e} G_ej D_j from D~); its result v = alpha_old - alpha_new replaces D~_e and the rows
+// behind it take the rank-NT correction  D~_r += sum_m T_s[r,(e,m)] (v_m - D~_(e,m))  -- the solve of the same system with row e
+// replaced by "D_e = v".  Exceptions are taken in marker order until none is left.  A section with more than kSolveMaxOdd
+// markers outside the model at entry is walked; one with more than kSolveMaxExc exceptions in all falls back to the walk.
+// (oracle: ORC_SOLVE_MAX_ODD / ORC_SOLVE_MAX_EXC, mt1_section_solve)
+constexpr int kSolveMaxOdd = 4, kSolveMaxExc = 6;
 
 // One section's inverse.  grid = sections (4 per full 256-marker block), block = 256 NT threads: FOUR adjacent lanes per column
 // (column (jc, mc) = thread / 4), lane q of the quad sums the terms j = jc + q, jc + q + 4, ... of a row's dot product, the quad adds
@@ -1089,10 +1098,10 @@ __device__ __forceinline__ void dense_big_mt_solve(char* smem, const StepSmem& S
         for (int t = 0; t < NT; ++t) da[t] = dj * a[t];                                                  // MTBayesABC.jl:82
         {
             const unsigned long long slow0 = __ballot(!in_all);
-            if (lane == 0) { sflag[wave] = (slow0 == 0ull) ? 1 : 0; sflag[4 + wave] = 0; }
+            if (lane == 0) { sflag[wave] = (__popcll(slow0) <= kSolveMaxOdd) ? 1 : 0; sflag[4 + wave] = 0; }
         }
         lds_barrier();                                                                                  // B0
-        int nredo = 0, nsolved = 0, nfailed = 0;
+        int nredo = 0, nsolved = 0, nfailed = 0, nexc_all = 0;
         long long cy_y = 0, cy_mv = 0, cy_cmb = 0, cy_ver = 0, cy_tail = 0;      // (diagnostics: the phases of a solved section, wave 0's clock)
 #pragma unroll 1
         for (int s = 0; s < kSec; ++s) {
@@ -1117,6 +1126,8 @@ __device__ __forceinline__ void dense_big_mt_solve(char* smem, const StepSmem& S
                 lds_barrier();                                           // B2: the four partial products are there
                 const long long ts2 = clock64();
                 float bo[NT], Dt[NT], yv[NT];
+                bool isexc = false;                                      // the lane's marker was taken by its literal evaluation (results already in LDS)
+                int nexc = 0;
                 if (wave == s) {
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
@@ -1129,50 +1140,97 @@ __device__ __forceinline__ void dense_big_mt_solve(char* smem, const StepSmem& S
                 lds_barrier();                                           // B3: D is there
                 const long long ts3 = clock64();
                 if (wave == s) {
-                    // the literal evaluation at the right-hand side these effects imply:  rhs + R Lc (y - D~)
+                    // the literal evaluation at the right-hand side these effects imply:  rhs + R Lc (y - D~); exceptions in marker
+                    // order (the comment above kSolveMaxOdd)
                     double thr[NT], z[NT];
                     MtPre<NT> Q;
                     draws_of(thr, z, Q);
-                    float v[NT], qv[NT], wev[NT];
+                    const float* Ts = A.tsec + (int64_t)s * tsec_floats<NT>();
+                    unsigned long long fixed = 0ull;
+                    bool failed = false;
+#pragma unroll 1
+                    for (;;) {
+                        float v[NT], qv[NT], wev[NT];
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) v[t] = yv[t] - Dt[t];
+                        for (int t = 0; t < NT; ++t) v[t] = yv[t] - Dt[t];
 #pragma unroll
-                    for (int k = 0; k < NT; ++k) {
-                        float acc = Q.C11[k] * v[k];
+                        for (int k = 0; k < NT; ++k) {
+                            float acc = Q.C11[k] * v[k];
 #pragma unroll
-                        for (int j = 0; j < k; ++j) acc = fmaf(K.Ginv[k][j] + (dj * 1.f) * K.Rinv[k][j], v[j], acc);
-                        qv[k] = acc;
+                            for (int j = 0; j < k; ++j) acc = fmaf(K.Ginv[k][j] + (dj * 1.f) * K.Rinv[k][j], v[j], acc);
+                            qv[k] = acc;
+                        }
+#pragma unroll
+                        for (int m = 0; m < NT; ++m) {
+                            float acc = 0.f;
+#pragma unroll
+                            for (int k = 0; k < NT; ++k) acc = fmaf(K.Rm[m][k], qv[k], acc);
+                            wev[m] = (rhs[m] + acc) + da[m];
+                        }
+                        float ao[NT], bv[NT], dv2[NT], Dl2[NT];
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) { ao[t] = a[t]; bv[t] = bb[t]; dv2[t] = dd[t]; Dl2[t] = 0.f; }
+                        mt1_eval<NT, false>(K, Q, PriorMem{lpr, 1}, wev, dj, thr, z, ao, bv, dv2, Dl2);
+                        bool ok = in_all;
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) ok = ok && (dv2[t] == 1.f);
+                        const unsigned long long bad = __ballot(!ok) & ~fixed;
+                        if (bad == 0ull) break;
+                        if (++nexc > kSolveMaxExc) { failed = true; break; }
+                        const int e = __builtin_amdgcn_readfirstlane(__builtin_ctzll(bad));      // the first exception: final up to here
+                        float del[NT];
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            const float ve = a[t] - ao[t];
+                            del[t] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ve - Dt[t]), e));
+                            if (lane == e) {                     // its results go to LDS at once (a section that falls back is walked: rewritten)
+                                acur[t * B + c] = ao[t]; bcur[t * B + c] = bv[t]; dcur[t * B + c] = dv2[t];
+                                rhs_lds[t * B + c] = ve; Dt[t] = ve;
+                            }
+                        }
+                        if (lane == e) isexc = true;
+                        if (lane > e) {
+#pragma unroll
+                            for (int k = 0; k < NT; ++k)
+#pragma unroll
+                                for (int m = 0; m < NT; ++m) {
+                                    const int cidx = m * 64 + e;
+                                    Dt[k] = fmaf(Ts[((int64_t)(cidx >> 2) * (64 * NT) + (k * 64 + lane)) * 4 + (cidx & 3)], del[m], Dt[k]);
+                                }
+                        }
+                        fixed |= 1ull << e;
                     }
+                    if (failed) { if (lane == 0) sflag[4 + s] = 1; }
+                    else if (nexc > 0) {
+                        // the optimistic apply of the others used the first D~: they restore and apply these
+                        if (!isexc) {
 #pragma unroll
-                    for (int m = 0; m < NT; ++m) {
-                        float acc = 0.f;
-#pragma unroll
-                        for (int k = 0; k < NT; ++k) acc = fmaf(K.Rm[m][k], qv[k], acc);
-                        wev[m] = (rhs[m] + acc) + da[m];
+                            for (int t = 0; t < NT; ++t) { bo[t] = a[t] - Dt[t]; rhs_lds[t * B + c] = a[t] - bo[t]; }
+                        }
+                        if (lane == 0) sflag[4 + s] = 2;
                     }
-                    float ao[NT], bv[NT], dv2[NT], Dl2[NT];
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) { ao[t] = a[t]; bv[t] = bb[t]; dv2[t] = dd[t]; Dl2[t] = 0.f; }
-                    mt1_eval<NT, false>(K, Q, PriorMem{lpr, 1}, wev, dj, thr, z, ao, bv, dv2, Dl2);
-                    bool ok = true;
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) ok = ok && (dv2[t] == 1.f);
-                    if (__any(!ok) && lane == 0) sflag[4 + s] = 1;
                 } else if (wave > s) {
                     apply_changes(s, rhs, pq);                           // (optimistic: undone below if the verdict is "no")
                 }
                 lds_barrier();                                           // B4: the verdict
                 ts4 = clock64();
                 cy_y += ts1 - ts0; cy_mv += ts2 - ts1; cy_cmb += ts3 - ts2; cy_ver += ts4 - ts3;
-                redo = sflag[4 + s] != 0;
+                const int verdict = sflag[4 + s];                        // 0: solved; 2: solved with exceptions; 1: to the walk
+                redo = verdict == 1;
                 if (redo) {
 #pragma unroll
                     for (int t = 0; t < NT; ++t) rhs[t] = rsv[t];
                     if (wave == s) ++nfailed;
                 } else if (wave == s) {
-                    ++nsolved;
+                    ++nsolved; nexc_all += nexc;
+                    if (!isexc) {
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) { acur[t * B + c] = bo[t]; bcur[t * B + c] = bo[t]; dcur[t * B + c] = 1.f; }
+                        for (int t = 0; t < NT; ++t) { acur[t * B + c] = bo[t]; bcur[t * B + c] = bo[t]; dcur[t * B + c] = 1.f; }
+                    }
+                } else if (verdict == 2 && wave > s) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) rhs[t] = rsv[t];
+                    apply_changes(s, rhs, pq);
                 }
             }
             if (redo) {
@@ -1276,6 +1334,7 @@ __device__ __forceinline__ void dense_big_mt_solve(char* smem, const StepSmem& S
         if (lane == 0 && (nsolved | nfailed)) {                                             // Rule T: sections solved / fallen back to the walk
             atomicAdd(&A.counters[16], (unsigned long long)nsolved);
             atomicAdd(&A.counters[17], (unsigned long long)nfailed);
+            if (nexc_all) atomicAdd(&A.counters[23], (unsigned long long)nexc_all);         // ... exceptions taken inside the solved ones
         }
     } else {
         // ====================== waves 4..7: their quarters of the mat-vec, nothing else (the same barriers as above) ======================
@@ -1297,7 +1356,7 @@ __device__ __forceinline__ void dense_big_mt_solve(char* smem, const StepSmem& S
                 if (s + 1 < kSec) load_t(s + 1, tq, QG / 2, 3 * QG / 4);
                 lds_barrier();                                           // B4: the verdict
                 if (s + 1 < kSec) load_t(s + 1, tq, 3 * QG / 4, QG);
-                redo = sflag[4 + s] != 0;
+                redo = sflag[4 + s] == 1;
             }
             if (redo) {
                 if (!fast && s + 1 < kSec) load_t(s + 1, tq);

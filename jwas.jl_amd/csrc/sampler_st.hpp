@@ -612,6 +612,11 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
         // after it -- the wait below is for the rows only (vmcnt counts in order), the pieces arrive while wave 0 walks
         // (waiting for both cost 5.8 k cycles per block: ~190 KB through one CU's memory pipe under the stream's load)
         const bool split = xreg && stage_load(smem, SM, A, nstaged, tss, 1);
+        // The wait of phase 2 counts on EXACTLY the kXR loads below being younger than the direct loads: the two compiler
+        // barriers pin them between phase 1 and the wait (no global load may be hoisted above the direct loads or sunk below
+        // the wait); a 16-byte load is the widest there is, so they cannot be merged into fewer, and all kXR results are used.
+        // (Splitting one into several would only make the wait longer.)
+        asm volatile("" ::: "memory");
         if (xreg && wave != 0) {
             const short* cl = reinterpret_cast<const short*>(smem + SM.cand_off);
             const int xtask = ncand_total << xsh;
@@ -622,6 +627,7 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
             }
         }
         static_assert(kXR == kStageYounger, "the number of loads stage_load leaves in flight");
+        asm volatile("" ::: "memory");
         if (split) stage_load(smem, SM, A, nstaged, tss, 2, true);
         else stage_load(smem, SM, A, nstaged, tss);
     }

@@ -149,10 +149,10 @@ class HipEngine:
         if rinv is None:
             self._chk(self._L.jwas_hip_set_weights(self._h, None))
         else:
-            w = np.ascontiguousarray(rinv, dtype=np.float32)
+            w = np.ascontiguousarray(rinv, dtype=self.dtype)             # Float64 contexts keep the weights' Float64 values (build_MME.jl:310)
             if w.shape != (self.n,):
                 raise ValueError(f"one weight per individual is required ({self.n}), got {w.shape}")
-            self._chk(self._L.jwas_hip_set_weights(self._h, _ptr(w)))
+            self._chk((self._L.jwas_hip_set_weights_f64 if self.precision == 64 else self._L.jwas_hip_set_weights)(self._h, _ptr(w)))
         self._weighted = rinv is not None
         self.block_size = 0
 

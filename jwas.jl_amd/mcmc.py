@@ -434,14 +434,24 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
             explicit_starts = True
             if max(sizes) > max(DEVICE_BLOCK_SIZES):
                 # a block of more than 1024 markers does not fit the sampler's LDS plan: the nearest legal partition is the
-                # given one with every oversized block cut into pieces of at most 1024 markers (each piece repeated its own
-                # size, BayesABC.jl:153) -- said out loud, as the reference prints its block size (JWAS.jl:308-316)
+                # given one with every oversized block cut into k = ceil(size / 1024) BALANCED pieces (sizes differ by at
+                # most one marker: no sliver of a tail piece), each piece repeated its own size (BayesABC.jl:153) -- a valid
+                # chain with MORE within-block sweeps per outer iteration than the request (a block of 1150 markers becomes
+                # 575 + 575 repetitions of half-blocks instead of 1150 of the whole); chain_length, the number of saved
+                # samples and of hyper-parameter updates are unchanged.  Said out loud, as the reference prints its block
+                # size (JWAS.jl:308-316).
                 lim = max(DEVICE_BLOCK_SIZES)
                 cut = []
                 for a_, sz in zip(starts, sizes):
-                    cut.extend(range(a_, a_ + sz, lim))
+                    k_ = -(-sz // lim)
+                    base, extra = divmod(sz, k_)
+                    pos = a_
+                    for i_ in range(k_):
+                        cut.append(pos)
+                        pos += base + (1 if i_ < extra else 0)
                 print(f"NOTICE: fast_blocks blocks of up to {max(sizes)} markers exceed the device limit of {lim}; "
-                      f"running {len(cut)} blocks (oversized blocks cut into pieces of at most {lim} markers)")
+                      f"running {len(cut)} blocks (oversized blocks cut into balanced pieces of at most {lim} markers, each "
+                      f"repeated its own size: the schedule differs from the request's, the number of saved samples does not)")
                 starts = cut
                 sizes = [b_ - a_ for a_, b_ in zip(starts, starts[1:])] + [p - starts[-1] + 1]
             if len(set(sizes[:-1])) != 1 or sizes[-1] > sizes[0]:
@@ -459,9 +469,11 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         #   * `want` is one of the device's uniform block sizes (64 ... 1024): the uniform layout IS that partition
         #     (nreps <= 0 = every block its own size);
         #   * any other size <= 1024: the ragged-partition form (jwas_hip_setup_blocks_explicit) with those starts;
-        #   * more than 1024 markers per block do not fit the sampler's LDS plan: an explicit error;
+        #   * more than 1024 markers per block do not fit the sampler's LDS plan: the nearest legal schedule with a printed
+        #     NOTICE (below: blocks of 1024 markers, chain_length / 1024 outer iterations -- fewer saved samples and
+        #     hyper-parameter updates per requested iteration than chain_length / want would give)
         #     (independent_blocks alone may ask for more: uniform device blocks of 1024 markers with `want` repetitions
-        #     each -- independent blocks are the reference's own approximation; DESIGN.md section 12).
+        #     each -- independent blocks are the reference's own approximation).
         if want > max(DEVICE_BLOCK_SIZES) and not explicit_starts and not independent_blocks:
             # fast_blocks = true on more than 1024^2 records, or a number above 1024: the sampler's LDS plan holds the draws,
             # constants and staged Gram rows of at most 1024 markers.  The nearest legal schedule is the reference's own at

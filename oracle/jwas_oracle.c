@@ -1078,8 +1078,17 @@ int orc_bayesr_lookahead_sweep(const float* X, int64_t n, int64_t p, int64_t ld,
 /* + d_l alpha_l) + c_l),  D = alpha_old - alpha_new.  The device forms T = (I + L)^-1 once per     */
 /* sweep (k_section_inverse_mt) and a section's effects with one mat-vec D~ = T y; the literal     */
 /* evaluation (MTBayesABC.jl:85-120) at the right-hand side those effects imply verifies that every */
-/* indicator stays 1, otherwise the section runs through the sequential chain.  Restated operation  */
-/* for operation (same accumulation types and orders), so that the comparison stays bit for bit:    */
+/* indicator stays 1.  EXCEPTIONS (a marker that is not in the model for every trait at entry, or    */
+/* that the verification finds leaving it) are taken in marker order: T is lower block triangular,  */
+/* so everything before the first exception e is final, the literal evaluation of e at the          */
+/* right-hand side the solve implies for it, rhs + R Lc_e (y_e - D~_e), IS the chain's evaluation   */
+/* of e (whatever y_e was: the row only recovers sum_{j<e} G_ej D_j from D~), its result v =         */
+/* alpha_old - alpha_new replaces D~_e, and the rows behind it take the rank-t correction             */
+/* D~_r += sum_m T[r,(e,m)] (v_m - D~_(e,m)) -- the solve of the same system with row e replaced by  */
+/* "D_e = v".  More than ORC_SOLVE_MAX_ODD markers outside the model at entry: the section is not    */
+/* tried; more than ORC_SOLVE_MAX_EXC exceptions in all: it falls back to the sequential chain.      */
+/* Restated operation for operation (same accumulation types and orders), so that the comparison    */
+/* stays bit for bit:                                                                                 */
 /*   T column (jc, mc): rows of markers l < jc are 0, of jc the identity; for l > jc                 */
 /*       u_m = (p0 + p1) + (p2 + p3),  p_q = sum over j = jc + q, jc + q + 4, ... < l of                */
 /*             fma(G_lj, T[(j,m)], p_q)   (double, ascending j: the device's four lanes per column)   */
@@ -1087,17 +1096,21 @@ int orc_bayesr_lookahead_sweep(const float* X, int64_t n, int64_t p, int64_t ld,
 /*   D~[(l,k)] = (p0 + p1) + (p2 + p3),  p_q = fmaf chain (float, from 0) over the columns           */
 /*       c = m*64 + j in [16 t q, 16 t (q+1)), ascending                                              */
 /*   alpha_new = alpha - D~ ;  D = alpha - alpha_new ;  rhs~ = rhs + R Lc (y - D~)                    */
+/*   exception e:  v_k = alpha_k - alpha_new_k (literal) ; del_k = v_k - D~[(e,k)] ;  for l > e:          */
+/*       D~[(l,k)] = fmaf(T[(l,k),(e,m)], del_m, D~[(l,k)]) for m ascending ;  D~[(e,k)] = v_k            */
 /* Reference chain it stands for: MTBayesABC.jl:243-333 (block form of sampler I).                  */
 /* ------------------------------------------------------------------------------------------ */
 static int g_section_solve = 0;
 void orc_set_section_solve(int on) { g_section_solve = on; }
-static int64_t g_solve_sections = 0, g_solve_fallbacks = 0;      /* diagnostics: sections solved / fallen back since the last reset */
+enum { ORC_SOLVE_MAX_ODD = 4, ORC_SOLVE_MAX_EXC = 6 };            /* (csrc/sampler_mt.hpp: kSolveMaxOdd, kSolveMaxExc) */
+static int64_t g_solve_sections = 0, g_solve_fallbacks = 0, g_solve_exceptions = 0;      /* diagnostics: sections solved / fallen back, exceptions of the solved ones, since the last reset */
 void orc_section_solve_counts(int64_t* solved, int64_t* fallbacks, int reset)
 {
     if (solved) *solved = g_solve_sections;
     if (fallbacks) *fallbacks = g_solve_fallbacks;
-    if (reset) { g_solve_sections = 0; g_solve_fallbacks = 0; }
+    if (reset) { g_solve_sections = 0; g_solve_fallbacks = 0; g_solve_exceptions = 0; }
 }
+int64_t orc_section_solve_exceptions(void) { return g_solve_exceptions; }
 
 /* One 64-marker section [c0, c0 + 64) of a 256-marker block.  Returns 1 if it was solved (state, rhs_b updated), 0 if the
  * caller has to run it through the sequential chain (nothing touched). */
@@ -1108,8 +1121,13 @@ static int mt1_section_solve(int t, int64_t p, int64_t j0, int64_t b, int64_t c0
 {
     enum { S = 64 };
     const int nr = S * t;
-    for (int l = 0; l < S; ++l)
-        for (int k = 0; k < t; ++k) if (delta[k * p + j0 + c0 + l] != 1.0f) return 0;
+    int in_all[64], nodd = 0;
+    for (int l = 0; l < S; ++l) {
+        in_all[l] = 1;
+        for (int k = 0; k < t; ++k) if (delta[k * p + j0 + c0 + l] != 1.0f) in_all[l] = 0;
+        nodd += !in_all[l];
+    }
+    if (nodd > ORC_SOLVE_MAX_ODD) return 0;
     float* A   = (float*)malloc(sizeof(float) * (size_t)(S * t * t));
     float* cc  = (float*)malloc(sizeof(float) * (size_t)(S * t));
     float* y   = (float*)malloc(sizeof(float) * (size_t)nr);           /* [m*64 + j] */
@@ -1160,19 +1178,18 @@ static int mt1_section_solve(int t, int64_t p, int64_t j0, int64_t b, int64_t c0
         }
         Dt[r] = (pq[0] + pq[1]) + (pq[2] + pq[3]);
     }
-    /* the new effects, and the verification of every marker (nothing is written before all of them passed) */
-    float* bo_all = (float*)malloc(sizeof(float) * (size_t)nr);
-    int ok = 1;
+    /* the new effects: every marker verified in order, exceptions taken as they come (nothing is written before the end) */
+    float* bo_all = (float*)malloc(sizeof(float) * (size_t)nr);          /* new alpha */
+    float* bb_all = (float*)malloc(sizeof(float) * (size_t)nr);          /* new beta  */
+    float* dd_all = (float*)malloc(sizeof(float) * (size_t)nr);          /* new delta */
+    int ok = 1, nexc = 0;
     const int lin_save = g_mt_linear;
     for (int l = 0; l < S && ok; ++l) {
         const int64_t j = j0 + c0 + l;
         const float d = xpx[j];
         const float* Gl = Gi + l * t * t;
         float v[ORC_MAXT], q[ORC_MAXT], wev[ORC_MAXT], ta[ORC_MAXT], tb[ORC_MAXT], td[ORC_MAXT], aout[ORC_MAXT];
-        for (int k = 0; k < t; ++k) {
-            bo_all[k * S + l] = alpha[k * p + j] - Dt[k * S + l];
-            v[k] = y[k * S + l] - Dt[k * S + l];
-        }
+        for (int k = 0; k < t; ++k) v[k] = y[k * S + l] - Dt[k * S + l];
         for (int k = 0; k < t; ++k) {
             const float C11 = Gl[k * t + k] + Rinv[k * t + k] * d;
             float acc = C11 * v[k];
@@ -1185,23 +1202,46 @@ static int mt1_section_solve(int t, int64_t p, int64_t j0, int64_t b, int64_t c0
             wev[m] = (rhs_b[m * b + c0 + l] + acc) + d * alpha[m * p + j];
         }
         for (int k = 0; k < t; ++k) { ta[k] = alpha[k * p + j]; tb[k] = beta[k * p + j]; td[k] = delta[k * p + j]; }
-        g_mt_linear = 0;                                                       /* the literal order: decisions only */
+        g_mt_linear = 0;                                                       /* the literal order */
         mt1_update(t, wev, d, ta, tb, td, 1, Rinv, Gl, log_prior, seed, marker0 + (uint32_t)j, iter, 0, aout);
         g_mt_linear = lin_save;
-        for (int k = 0; k < t; ++k) if (td[k] != 1.0f) ok = 0;
+        int stays = in_all[l];
+        for (int k = 0; k < t; ++k) if (td[k] != 1.0f) stays = 0;
+        if (stays) {                                                           /* the solve's own values */
+            for (int k = 0; k < t; ++k) {
+                bo_all[k * S + l] = alpha[k * p + j] - Dt[k * S + l];
+                bb_all[k * S + l] = bo_all[k * S + l]; dd_all[k * S + l] = 1.0f;
+            }
+            continue;
+        }
+        if (++nexc > ORC_SOLVE_MAX_EXC) { ok = 0; break; }
+        float del[ORC_MAXT];
+        for (int k = 0; k < t; ++k) {                                          /* the literal evaluation IS the chain's: take it */
+            const float ve = alpha[k * p + j] - ta[k];
+            del[k] = ve - Dt[k * S + l];
+            bo_all[k * S + l] = ta[k]; bb_all[k * S + l] = tb[k]; dd_all[k * S + l] = td[k];
+        }
+        for (int l2 = l + 1; l2 < S; ++l2)
+            for (int k = 0; k < t; ++k) {
+                float acc = Dt[k * S + l2];
+                for (int m = 0; m < t; ++m) acc = fmaf(T[(size_t)(k * S + l2) * nr + m * S + l], del[m], acc);
+                Dt[k * S + l2] = acc;
+            }
+        for (int k = 0; k < t; ++k) Dt[k * S + l] = alpha[k * p + j] - ta[k];
     }
     if (ok) {
         for (int l = 0; l < S; ++l) {
             const int64_t j = j0 + c0 + l;
             for (int k = 0; k < t; ++k) {
-                const float a_old = alpha[k * p + j], bn = bo_all[k * S + l];
-                const float D = a_old - bn;
-                alpha[k * p + j] = bn; beta[k * p + j] = bn; delta[k * p + j] = 1.0f;
+                const float a_old = alpha[k * p + j], an = bo_all[k * S + l];
+                const float D = a_old - an;
+                alpha[k * p + j] = an; beta[k * p + j] = bb_all[k * S + l]; delta[k * p + j] = dd_all[k * S + l];
                 if (D != 0.0f) axpy_f32(D, G + (c0 + l) * b, rhs_b + k * b, b);       /* later sections see the changes in marker order */
             }
         }
-        ++g_solve_sections;
+        ++g_solve_sections; g_solve_exceptions += nexc;
     } else ++g_solve_fallbacks;
+    free(bb_all); free(dd_all);
     free(A); free(cc); free(y); free(T); free(Dt); free(Gi); free(bo_all);
     return ok;
 }

@@ -171,6 +171,7 @@ void orc_set_section_solve(int on);
  * of the matrix X the sweeps are called with; NULL = off. */
 void orc_set_packed_source(const uint8_t* codes, const float* means, int centered, const float* X, int64_t n, int64_t ld);
 void orc_section_solve_counts(int64_t* solved, int64_t* fallbacks, int reset);
+int64_t orc_section_solve_exceptions(void);      /* exceptions taken inside the solved sections since the last reset */
 /* One InverseWishart(df, scale + b_j b_j') draw per marker (variance_components.jl:181-186; df = the reference's df + 1),
  * Bartlett on the counter RNG: the restatement the device's k_sample_marker_covariances is compared with. */
 void orc_sample_marker_covariances(int t, int64_t p, const float* beta, double df, const double* scale,

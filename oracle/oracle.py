@@ -173,6 +173,13 @@ def section_solve_counts(reset=False):
     return int(a.value), int(b.value)
 
 
+def section_solve_exceptions():
+    """Exceptions (markers taken by their literal evaluation inside a solved section) since the last reset of the counts."""
+    f = lib().orc_section_solve_exceptions
+    f.restype = C.c_int64
+    return int(f())
+
+
 def bayesabc_sweep(X, xpx_, r, alpha, beta, delta, vare, var_effects, pi, seed, it,
                    marker0=0, acc=ACC_F64, block_starts=None, grams=None, nreps=1, lookahead=False, independent=False):
     """In-place sweep.  block_starts=None -> non-block form (BayesABC.jl:60-80); lookahead=True ->

@@ -288,7 +288,7 @@ class OracleEngine64:
         self._xpx = O.xpx64_w(self.X, getattr(self, "_w", None))
 
     def set_weights(self, rinv):
-        self._w = None if rinv is None else np.asarray(np.asarray(rinv, dtype=np.float32), dtype=np.float64)      # (the C ABI carries Float32 weights)
+        self._w = None if rinv is None else np.asarray(rinv, dtype=np.float64)      # (jwas_hip_set_weights_f64: the Float64 values as they are)
         if getattr(self, "_xpx", None) is not None:
             self._xpx = O.xpx64_w(self.X, self._w)
 

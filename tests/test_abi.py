@@ -46,6 +46,9 @@ def test_memory_estimate_formula():
     assert HipEngine.estimate_bytes(n, p, t, b) == 4 * ld * p + rest
     assert HipEngine.estimate_bytes(n, p, t, b, storage="stream") == (ld // 4) * p + 4 * p + rest
     assert HipEngine.estimate_bytes(50_000, 600_000, 1, 256) < 288e9        # config 2 fits one MI355X
+    # multi-trait sampler I on 256-marker blocks: + the per-sweep section inverses of Rule T, (64 t)^2 floats per 64-marker section
+    t3 = HipEngine.estimate_bytes(n, p, 3, 256) - HipEngine.estimate_bytes(n, p, 3, 128)
+    assert t3 == 2 * 4 * 128 * p + 128 * (ld // 256) * 3 * 8 + (p // 256) * 4 * (192 * 192) * 4
 
 
 def test_no_cpu_fallback_without_gpu():

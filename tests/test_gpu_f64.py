@@ -215,11 +215,12 @@ def test_f64_weights_and_independent_blocks_parity(bs, nreps, independent):
     independent_blocks (BayesABC.jl:190-255) in the Float64 context, against the general Float64 block oracle."""
     d, X, orc, hip = _pair(450, bs * 2 + 57, bs, "BayesC", seed=43)
     try:
-        w = (1.0 + np.random.default_rng(2).uniform(0, 1.5, 450)).astype(np.float32)
+        w = 1.0 + np.random.default_rng(2).uniform(0, 1.5, 450)            # Float64 weights that no Float32 holds (build_MME.jl:310)
+        assert (w != w.astype(np.float32)).any()
         for e in (orc, hip):
             e.set_weights(w); e.setup_blocks(bs); e.init_state("BayesC", 1)
             e.set_residual(d["y"] - d["y"].mean())
-        np.testing.assert_allclose(hip.xpx(), (X * X * w.astype(np.float64)[:, None]).sum(axis=0), rtol=1e-13)
+        np.testing.assert_allclose(hip.xpx(), (X * X * w[:, None]).sum(axis=0), rtol=1e-13)       # (Float32-rounded weights would be 6e-8 off)
         for it in range(1, 6):
             so = orc.sweep(iteration=it, seed=8, vare=0.5, var_effect=0.004, pi=0.9, nreps=nreps, independent_blocks=independent)
             sh = hip.sweep(iteration=it, seed=8, vare=0.5, var_effect=0.004, pi=0.9, nreps=nreps, independent_blocks=independent)

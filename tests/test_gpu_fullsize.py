@@ -136,6 +136,75 @@ def test_full_size_config4_three_trait_invariants(prior, bs):
         assert (res["a"][1][:, big] != 0).any(axis=0).mean() > 0.5
 
 
+def test_full_size_config4_rule_t_against_the_sequential_chain():
+    """Config 4 at full size under RULE T (jwas_sweep_params.section_solve: the dense 64-marker sections of the 256-marker blocks as
+    triangular solves, MTBayesABC.jl:243-333 being the chain they stand for) against the SAME device's sequential chain on the same
+    seeds: the same joint-state trajectory in every sweep, effects within 1e-4 of their scale (the reference's dense-vs-stream
+    tolerance, test/unit/test_streaming_codec.jl:100,104), residual identity, statistics = direct reductions, bit-reproducibility;
+    under the fixed all-ones prior EVERY section of every full block is solved, with pi estimated some fall back to the walk."""
+    n, p, t = 20_000, 100_000, 3
+    e = _engine(20e9)
+    e.alloc_dense(n, p); e.synth(2026, 0, True)
+    e.setup_blocks(256, "mfma")
+    e.init_state("MTBayesC", t)
+    rng = np.random.default_rng(1)
+    Y, idx, eff = _phenotypes(e, n, p, t, 100, rng)
+    s2pq = float(e.xpx().astype(np.float64).sum()) / n
+    ns = 1 << t
+    G = (np.eye(t) * 0.5 / s2pq).astype(np.float32)
+    R = (np.eye(t) * 0.5 + 0.1).astype(np.float32)
+    nsec = 4 * (p // 256)
+    res = {}
+    for tag, solve, est in (("solve", True, False), ("walk", False, False), ("again", True, False), ("solve_pi", True, True), ("walk_pi", False, True)):
+        for k in range(t):
+            e.set_state(k, alpha=np.zeros(p), beta=np.zeros(p), delta=np.ones(p))
+            e.set_residual(Y[k], k)
+        pi = np.zeros(ns); pi[ns - 1] = 1.0
+        solved = fallen = 0
+        traj = []
+        for it in range(1, 6):
+            with np.errstate(divide="ignore"):
+                st = e.sweep(iteration=it, seed=7, vare=R, var_effect=G, log_prior_states=np.log(pi), section_solve=solve)
+            c = e.last_sweep_counters()
+            solved += c[16]; fallen += c[17]
+            traj.append(st["state_counts"].copy())
+            if est:
+                pi = (st["state_counts"] + 1.0) / (p + ns)
+        A, B, D = (np.stack(v) for v in zip(*[e.get_state(k) for k in range(t)]))
+        Rr = np.stack([e.get_residual(k) for k in range(t)])
+        for k in range(t):
+            np.testing.assert_allclose(Rr[k], Y[k] - e.mul_alpha(k), atol=5e-3)                  # residual identity per trait
+        assert np.array_equal(A != 0, D != 0) and np.array_equal(A[D != 0], B[D != 0])           # alpha = delta * beta
+        codes = (D != 0).T @ (1 << np.arange(t))
+        assert np.array_equal(st["state_counts"], np.bincount(codes, minlength=ns).astype(np.float64))
+        B64, R64 = B.astype(np.float64), Rr.astype(np.float64)
+        np.testing.assert_allclose(st["beta_ss"], B64 @ B64.T, rtol=1e-9)
+        np.testing.assert_allclose(st["resid_ss"], R64 @ R64.T, rtol=1e-9)
+        if solve and not est:
+            assert (solved, fallen) == (5 * nsec, 0)                                             # nothing leaves the model: every section solved
+        if solve and est:
+            assert solved > 0.5 * 5 * nsec and fallen > 0                                        # markers do leave: the fallback runs at full size
+        if not solve:
+            assert solved == 0 and fallen == 0
+        res[tag] = (A, D, Rr, traj)
+    e.close()
+    for q in range(3):
+        assert np.array_equal(res["solve"][q], res["again"][q])                                  # reproducible, bit for bit
+    # fixed all-ones prior: no marker can leave the model, so the two chains differ by the rule's float rounding only
+    scale = float(np.abs(res["walk"][0]).max())
+    assert np.array_equal(res["solve"][1], res["walk"][1])
+    assert np.abs(res["solve"][0] - res["walk"][0]).max() < 1e-4 * scale
+    assert (res["solve"][0] != res["walk"][0]).any()                                             # the rule is not a no-op
+    # pi estimated: ~10 % of the sections see a marker leave and are walked; 1.5 million inclusion decisions whose right-hand sides
+    # differ in the last bits may flip a handful of them (an MCMC chain is chaotic), everything else agrees to rounding
+    for x, y in zip(res["solve_pi"][3], res["walk_pi"][3]):
+        assert np.abs(x - y).max() <= 1e-3 * p
+    same = res["solve_pi"][1] == res["walk_pi"][1]
+    assert same.mean() > 0.999
+    scale = float(np.abs(res["walk_pi"][0]).max())
+    assert np.quantile(np.abs(res["solve_pi"][0] - res["walk_pi"][0])[same], 0.999) < 1e-4 * scale
+
+
 def test_full_size_config5_shard_invariants():
     """One GPU's share of config 5 (single-step shaped input, SSBR.jl:137-138): 280 000 rows -- 80 000 integer-coded
     genotyped rows + 200 000 real-valued imputed rows -- x 75 000 markers fp32 (84 GB); single-trait BayesC."""

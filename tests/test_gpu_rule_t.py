@@ -52,11 +52,14 @@ def _mt_hyper(t, rng):
     return vare, varg
 
 
-@pytest.mark.parametrize("method,t,leak", [("MTBayesC", 3, 1e-9), ("MTBayesC", 2, 1e-9), ("MTBayesB", 3, 1e-9), ("MTBayesC", 3, 2e-3)])
+@pytest.mark.parametrize("method,t,leak", [("MTBayesC", 3, 1e-9), ("MTBayesC", 2, 1e-9), ("MTBayesB", 3, 1e-9), ("MTBayesC", 3, 2e-3),
+                                           ("MTBayesC", 3, 1e-2), ("MTBayesB", 2, 5e-3)])
 def test_rule_t_multitrait_device_vs_its_oracle_restatement(hip, method, t, leak):
     """Sampler I, 256-marker blocks (three full ones and a ragged tail), every marker in the model at the start.  leak = the prior
-    mass of every other joint state: at 2e-3 markers do leave the model, so verifications fail (fall back to the walk) and later
-    sweeps hold sections that are not eligible at all -- the device and the oracle must take the same decisions everywhere."""
+    mass of every other joint state: at 2e-3 markers do leave the model -- the solve takes them as EXCEPTIONS (their literal
+    evaluation replaces their row of the solution, the rows behind take a rank-t correction), also the markers that are outside
+    the model when a later sweep enters their section; at 1e-2 sections collect more exceptions than the rule allows and fall
+    back to the walk, or are not tried at all -- the device and the oracle must take the same decisions everywhere."""
     rng = np.random.default_rng(70 + t)
     data = make_dataset(n=1100, p=3 * 256 + 77, ncausal=14, seed=700 + t)
     orc, hip = _mt_setup(hip, data, t, method, rng)
@@ -66,13 +69,13 @@ def test_rule_t_multitrait_device_vs_its_oracle_restatement(hip, method, t, leak
     if method == "MTBayesB":
         Vm = np.stack([varg * rng.uniform(0.6, 1.6) for _ in range(orc.p)]).astype(np.float32)
         kw["var_effect_matrix"] = Vm
-    solved = fallen = 0
+    solved = fallen = exceptions = 0
     O.section_solve_counts(reset=True)
     for it in range(1, 9):
         so = orc.sweep(iteration=it, seed=31, **kw)
         sh = hip.sweep(iteration=it, seed=31, **kw)
         cnt = hip.last_sweep_counters()
-        solved += cnt[16]; fallen += cnt[17]
+        solved += cnt[16]; fallen += cnt[17]; exceptions += cnt[23]
         assert so["n_events"] == sh["n_events"], f"iteration {it}"
         assert np.array_equal(so["state_counts"], sh["state_counts"]), f"iteration {it}"
         for k in range(t):
@@ -83,9 +86,12 @@ def test_rule_t_multitrait_device_vs_its_oracle_restatement(hip, method, t, leak
             np.testing.assert_allclose(bh, bo, rtol=0, atol=5e-6)
     o_solved, o_fallen = O.section_solve_counts()
     assert (solved, fallen) == (o_solved, o_fallen)          # the same sections solved / fallen back on both sides
+    assert exceptions == O.section_solve_exceptions()       # ... and the same number of exceptions taken inside the solved ones
     assert solved > 0
     if leak > 1e-3:
-        assert fallen > 0                                    # the fallback was exercised
+        assert exceptions > 0                                # the exception path was exercised
+    if leak >= 1e-2:
+        assert fallen > 0                                    # ... and the fallback
     for k in range(t):
         np.testing.assert_allclose(hip.get_residual(k), orc.get_residual(k), rtol=0, atol=3e-5)
 

@@ -856,8 +856,8 @@ def test_fast_blocks_above_the_device_limit_falls_back_to_the_nearest_legal_part
     model = api.build_model("y1 = intercept + geno")
     out = api.runMCMC(model, ph, chain_length=3, fast_blocks=[1, 301, 1601], output_folder=str(tmp_path / "y"), outputEBV=False,
                       _engine=OracleEngine("block"))
-    assert "cut into pieces" in capsys.readouterr().out
-    assert out["_timing"]["block_starts"] == [1, 301, 1325, 1601]              # the 1300-marker block in two pieces
+    assert "cut into balanced pieces" in capsys.readouterr().out
+    assert out["_timing"]["block_starts"] == [1, 301, 951, 1601]               # the 1300-marker block in two halves of 650 (no 276-marker sliver)
     assert out["_timing"]["iterations"] == 3                                   # explicit starts: chain length as given
 
 

@@ -606,8 +606,10 @@ def test_rule_t_stays_within_float32_rounding_of_the_literal_chain():
     which every marker is in the model for every trait is evaluated as D = T y with the section's inverse T = (I + L)^-1 instead
     of the 64-step chain.  Against the LITERAL restatement of the block form (_MTBayesABC_samplerI!, MTBayesABC.jl:243-333: no
     linear form, no solve): the same inclusion decisions in every sweep, effects within 2e-5 of their scale after eight dense
-    sweeps (the chain is a contraction in this regime: rounding differences do not grow); with a prior that lets markers leave
-    the model the verification sends sections back to the sequential chain and the agreement stays."""
+    sweeps (the chain is a contraction in this regime: rounding differences do not grow).  With a prior that lets markers
+    leave the model the solve takes EXCEPTIONS (a marker outside the model at entry, or one the verification finds leaving:
+    its literal evaluation replaces its row of the solution and the rows behind it take a rank-t correction) and the
+    agreement stays; with many of them the section falls back to the sequential chain."""
     import oracle as O
     from oracle_engine import OracleEngine
     t = 3
@@ -617,7 +619,7 @@ def test_rule_t_stays_within_float32_rounding_of_the_literal_chain():
     A = rng.standard_normal((t, t)); B = rng.standard_normal((t, t))
     vare = ((A @ A.T / t + np.eye(t)) * 0.5).astype(np.float32)
     varg = ((B @ B.T / t + np.eye(t)) * 0.003).astype(np.float32)
-    for leak, expect_fallback in ((1e-9, False), (2e-3, True)):
+    for leak, expect_exceptions, expect_fallback in ((1e-9, False, False), (2e-3, True, False), (1e-2, True, True)):
         prior = np.full(1 << t, leak); prior[-1] = 1.0; prior /= prior.sum()
         kw = dict(vare=vare, var_effect=varg, log_prior_states=np.log(prior))
         res = {}
@@ -634,18 +636,24 @@ def test_rule_t_stays_within_float32_rounding_of_the_literal_chain():
                 for it in range(1, 9):
                     e.sweep(iteration=it, seed=5, section_solve=(tag == "solve"), **kw)
                     traj.append(np.stack([e.get_state(k)[2] for k in range(t)]).copy())
-                res[tag] = ([e.get_state(k) for k in range(t)], traj, O.section_solve_counts())
+                res[tag] = ([e.get_state(k) for k in range(t)], traj, O.section_solve_counts(), O.section_solve_exceptions())
         finally:
             O.lib().orc_set_mt_linear_form(1)
         assert res["literal"][2] == (0, 0) and res["solve"][2][0] > 0
-        assert (res["solve"][2][1] > 0) == expect_fallback
-        if not expect_fallback:                  # (with a leaky prior single decisions may flip at rounding level: the chains are compared while they agree)
+        assert (res["solve"][2][1] > 0) == expect_fallback and (res["solve"][3] > 0) == expect_exceptions
+        if not expect_exceptions:
             for a, b in zip(res["literal"][1], res["solve"][1]):
                 assert np.array_equal(a, b)
             for k in range(t):
                 scale = np.abs(res["literal"][0][k][0]).max()
                 np.testing.assert_allclose(res["solve"][0][k][0], res["literal"][0][k][0], atol=2e-5 * scale)
                 assert (res["solve"][0][k][0] != res["literal"][0][k][0]).any()
+        else:
+            # a leaky prior: single decisions may flip at rounding level (an MCMC chain is chaotic), so the first sweep -- one
+            # pass over identical inputs -- is compared exactly and the rest statistically
+            assert np.array_equal(res["literal"][1][0], res["solve"][1][0])
+            agree = np.mean(res["literal"][1][-1] == res["solve"][1][-1])
+            assert agree > 0.97, agree
 
 
 def test_packed_order_right_hand_side_equals_the_decoded_dot_product():
