@@ -340,6 +340,8 @@ def main():
     if t > 1 and a.mt_method == "BayesB":
         state["Gmat"] = np.tile(np.asarray(Gval, dtype=np.float32), (p_loc, 1, 1))      # MCMC_BayesianAlphabet.jl:67-69
     acc = {"sweep_ms": 0.0, "events": 0.0, "launches": 0.0, "bytes": 0.0}
+    from jwas_jl_amd.engine import SectionSolvePolicy
+    solve_policy = SectionSolvePolicy(section_solve, 4 * (p_loc // 256))       # (mcmc.run_chain's: off while most sections are not solved)
 
     def step():
         s = state
@@ -359,7 +361,7 @@ def main():
             eng.residual_add_scalar(mu_old[k] - s["mu"][k], k)
         # 2. marker sweep on the device (+ shard reconcile)
         kw = dict(iteration=s["it"], seed=a.seed, vare=s["vare"], var_effect=s["G"], nreps=1)
-        if section_solve:
+        if solve_policy.use(s["it"]):
             kw["section_solve"] = True
         if method == "BayesR":
             kw["pi_classes"] = s["pi"]
@@ -372,6 +374,7 @@ def main():
             kw["pi"] = s["pi"]
         st = shard.sweep_resident(**kw)
         s["rsum"] = np.asarray(st["resid_sum"], dtype=np.float64).copy()
+        solve_policy.observe(s["it"], eng)
         if adaptive:       # n_events is the all-shard total after the reconcile: every rank takes the same decision
             eng.select_block_size(pick_block_size(st["n_events"], p_total))
         acc["launches"] += -(-p_loc // s["bs"]) + 1
@@ -385,6 +388,8 @@ def main():
         elif t > 1:
             from scipy.stats import invwishart
             s["pi"] = rng.dirichlet(st["state_counts"] + 1.0)
+            if os.environ.get("JWAS_BENCH_LOG_STATES") and s["it"] % int(os.environ["JWAS_BENCH_LOG_STATES"]) == 0:
+                log(f"sweep {s['it']}: joint-state counts {[int(v) for v in st['state_counts']]} sweep_ms={st['sweep_ms']:.2f}")
             if mt_pervar:                    # one InverseWishart(df + 1, scale + b_j b_j') draw per marker (variance_components.jl:181-186):
                 eng.sample_marker_covariances(df_g + 1.0, scale_g, seed=a.seed, iteration=s["it"], marker_offset=lo)   # on the device, from the resident beta
                 s["Gmat"] = None             # (the next sweep uses the resident covariances)

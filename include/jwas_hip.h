@@ -127,16 +127,17 @@ typedef struct jwas_sweep_params {
     double   vare_f64[JWAS_HIP_MAX_TRAITS * JWAS_HIP_MAX_TRAITS];
     double   var_effect_f64[JWAS_HIP_MAX_TRAITS * JWAS_HIP_MAX_TRAITS];
     const double* var_effect_vec_f64;   /* BayesB: p per-marker variances (host), else NULL                                */
-    int32_t  section_solve;             /* != 0: Rule T -- dense chains as triangular solves.  Where every marker of a 64-marker   */
-                                        /* section of a FULL block is certain to be in the model (multi-trait sampler I with a       */
-                                        /* shared or per-marker covariance on 256-marker blocks: every indicator 1 at entry and,   */
-                                        /* by the literal evaluation MTBayesABC.jl:85-120, afterwards; single-trait BayesA/B/C       */
-                                        /* under a uniform pi = 0 on 256- / 512-marker blocks) the section's chain                  */
-                                        /* (BayesABC.jl:153-179, MTBayesABC.jl:243-333) is evaluated as D = T y with the section's   */
-                                        /* inverse T = (I + L)^-1 formed once per sweep on the device: the same conditional means    */
-                                        /* and draws, another association (effects within float32 rounding of the sequential        */
-                                        /* chain).  Needs nreps = 1, no independent_blocks, no marker-specific priors.  0 = the      */
-                                        /* sequential chain everywhere (bit-identical to earlier releases).                          */
+    int32_t  section_solve;             /* != 0: Rule T -- dense chains as triangular solves.  Multi-trait sampler I (shared or     */
+                                        /* per-marker covariance, <= 3 traits) on FULL 256-marker blocks: a 64-marker section's     */
+                                        /* chain (MTBayesABC.jl:243-333) is evaluated as D = T y with the section's inverse         */
+                                        /* T = (I + L)^-1 formed once per sweep on the device, every marker then verified with the  */
+                                        /* literal evaluation (MTBayesABC.jl:85-120); a marker that is not in the model for every   */
+                                        /* trait before and after is an EXCEPTION -- its literal evaluation replaces its row of the */
+                                        /* solution and the rows behind it are corrected, in marker order; sections with many       */
+                                        /* exceptions run the sequential chain.  The same conditional means and draws, another      */
+                                        /* association (effects within float32 rounding of the sequential chain).  Needs nreps = 1, */
+                                        /* no independent_blocks, no marker-specific priors; every other sweep ignores the flag.    */
+                                        /* 0 = the sequential chain everywhere (bit-identical to earlier releases).                 */
     int32_t  reserved0;                 /* (keeps the struct a multiple of 8 bytes; must be 0)                                      */
 } jwas_sweep_params;
 
@@ -311,7 +312,8 @@ int  jwas_hip_set_kernel_timing(jwas_hip_ctx* ctx, int32_t stride);
 int  jwas_hip_sweep(jwas_hip_ctx* ctx, const jwas_sweep_params* params, jwas_sweep_stats* stats);
 /* Diagnostics of the LAST sweep (no reference counterpart; what JWAS_HIP_DEBUG_PHASES prints): the sampler's counters, n <= 24
  * values -- [0] effect changes, [1] Gram rows fetched on demand, [2..6] phase cycles, [7] rounds / sections walked again,
- * [16] / [17] compact-chain blocks tried / fallen back, or (section_solve) sections solved / fallen back to the walk. */
+ * [16] / [17] compact-chain blocks tried / fallen back, or (section_solve) sections solved / fallen back to the walk,
+ * [23] (section_solve) exceptions taken inside the solved sections. */
 int  jwas_hip_last_sweep_counters(jwas_hip_ctx* ctx, uint64_t* out, int32_t n);
 
 /* ---- marker shards over the GPUs of one node (one context per GPU / process) -------------------------------

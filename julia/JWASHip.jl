@@ -132,7 +132,7 @@ function HipSweepParams(method::Integer, iter::Integer, seed::Integer; vare::Rea
                    NTuple{4,Float64}(gamma), _z16(Float64), var_effect_vec, pi_vec, pi_matrix, Ptr{Float64}(C_NULL),
                    Ptr{Float32}(C_NULL), Base.setindex(_z16(Float64), Float64(vare), 1),
                    Base.setindex(_z16(Float64), Float64(var_effect), 1), Ptr{Float64}(C_NULL),      # (the Float64 context's copies)
-                   Int32(section_solve), Int32(0))                                                   # Rule T (dense priors, pi = 0)
+                   Int32(section_solve), Int32(0))                                                   # Rule T (multi-trait sampler I, dense prior)
 end
 
 "One marker sweep = one call of BayesABC! / BayesR! / MTBayesABC! (BayesABC.jl:60-80, BayesR.jl:45-97, MTBayesABC.jl:57-127)."

@@ -178,7 +178,7 @@ template <int NT> __host__ __device__ constexpr int64_t tsec_floats() { return (
 // replaced by "D_e = v".  Exceptions are taken in marker order until none is left.  A section with more than kSolveMaxOdd
 // markers outside the model at entry is walked; one with more than kSolveMaxExc exceptions in all falls back to the walk.
 // (oracle: ORC_SOLVE_MAX_ODD / ORC_SOLVE_MAX_EXC, mt1_section_solve)
-constexpr int kSolveMaxOdd = 4, kSolveMaxExc = 6;
+constexpr int kSolveMaxOdd = 16, kSolveMaxExc = 24;      // (an exception costs ~1.9 k cycles, a walked marker outside the model ~1.5 k on top of the 16 k walk)
 
 // One section's inverse.  grid = sections (4 per full 256-marker block), block = 256 NT threads: FOUR adjacent lanes per column
 // (column (jc, mc) = thread / 4), lane q of the quad sums the terms j = jc + q, jc + q + 4, ... of a row's dot product, the quad adds
@@ -1007,6 +1007,7 @@ __device__ __forceinline__ void dense_big_mt_solve(char* smem, const StepSmem& S
     float* ybuf = reinterpret_cast<float*>(smem + SM.rows_off) + kSec * 4096;
     float* part = ybuf + NT * 64;
     int* sflag = reinterpret_cast<int*>(part + 4 * NT * 64);           // [s]: section s is solved; [4 + s]: ... and its verification failed
+    float* tcol = reinterpret_cast<float*>(sflag + 8);                 // [kSolveMaxOdd][NT][NT][64]: the columns of T_s of the section's markers outside the model at entry
     int* wcnt = reinterpret_cast<int*>(smem + SM.wcnt_off);
     float* delta = reinterpret_cast<float*>(A.delta);
     auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
@@ -1085,6 +1086,13 @@ __device__ __forceinline__ void dense_big_mt_solve(char* smem, const StepSmem& S
 #pragma unroll
             for (int u = 0; u < 64; ++u) { pq[u] = *reinterpret_cast<const float*>(base + off); off += 4u * (unsigned)b; asm volatile("" : "+v"(off)); }
         };
+        // The Gram prefetch is dead in the wave that OWNS the running section (it applies nothing any more), but the compiler sees
+        // one loop for all waves and keeps the 64 registers alive through the owner's verification, which then spills.  An empty
+        // asm that "defines" them at the end of the owner's regions ends their live range there: the registers are free inside.
+        auto kill_pq = [&] {
+#pragma unroll
+            for (int u = 0; u < 64; ++u) asm volatile("" : "=v"(pq[u]));
+        };
         if (wave > 0) load_g(0);
         // Rule L's coefficients of the thread's own marker: all four waves at once, before the chain starts
         float Al[NT][NT], cl[NT], da[NT];
@@ -1102,7 +1110,7 @@ __device__ __forceinline__ void dense_big_mt_solve(char* smem, const StepSmem& S
         }
         lds_barrier();                                                                                  // B0
         int nredo = 0, nsolved = 0, nfailed = 0, nexc_all = 0;
-        long long cy_y = 0, cy_mv = 0, cy_cmb = 0, cy_ver = 0, cy_tail = 0;      // (diagnostics: the phases of a solved section, wave 0's clock)
+        long long cy_y = 0, cy_mv = 0, cy_cmb = 0, cy_ver = 0, cy_tail = 0, cy_x1 = 0, cy_xn = 0;      // (diagnostics: the phases of a solved section, wave 0's clock)
 #pragma unroll 1
         for (int s = 0; s < kSec; ++s) {
             const bool fast = sflag[s] != 0;
@@ -1123,6 +1131,27 @@ __device__ __forceinline__ void dense_big_mt_solve(char* smem, const StepSmem& S
                 }
                 lds_barrier();                                           // B1: y is there
                 const long long ts1 = clock64();
+                // the markers of the section that are outside the model at entry WILL be exceptions: their NT columns of T_s go to LDS
+                // now (direct loads, no registers), while this wave has nothing to do -- the correction below then costs no memory latency
+                unsigned long long odd0 = 0ull;
+                if (wave == s) {
+                    odd0 = __ballot(!in_all);
+                    typedef __attribute__((address_space(3))) void lds_void;
+                    const float* Ts = A.tsec + (int64_t)s * tsec_floats<NT>();
+                    int o = 0;
+#pragma unroll 1
+                    for (unsigned long long m_ = odd0; m_ != 0ull; m_ &= m_ - 1ull, ++o) {
+                        const int e = __builtin_amdgcn_readfirstlane(__builtin_ctzll(m_));
+#pragma unroll
+                        for (int k = 0; k < NT; ++k)
+#pragma unroll
+                            for (int m = 0; m < NT; ++m) {
+                                const int cidx = m * 64 + e;
+                                __builtin_amdgcn_global_load_lds(Ts + ((int64_t)(cidx >> 2) * (64 * NT) + (k * 64 + lane)) * 4 + (cidx & 3),
+                                                                 (lds_void*)(tcol + ((o * NT + k) * NT + m) * 64), 4, 0, 0);
+                            }
+                    }
+                }
                 lds_barrier();                                           // B2: the four partial products are there
                 const long long ts2 = clock64();
                 float bo[NT], Dt[NT], yv[NT];
@@ -1148,9 +1177,15 @@ __device__ __forceinline__ void dense_big_mt_solve(char* smem, const StepSmem& S
                     const float* Ts = A.tsec + (int64_t)s * tsec_floats<NT>();
                     unsigned long long fixed = 0ull;
                     bool failed = false;
+                    const long long tx0 = clock64();
+                    float ao[NT], bv[NT], dv2[NT];
+                    long long tx1 = 0;
+                    // (ONE copy of the evaluation, inside the loop: a straight-line first pass plus a loop for the exceptions was
+                    // measured SLOWER -- 2.8 k instead of 2.3 k cycles for the first pass: the sampler workgroup runs cold code,
+                    // its time is instruction fetch, and code size is what counts)
 #pragma unroll 1
                     for (;;) {
-                        float v[NT], qv[NT], wev[NT];
+                        float v[NT], qv[NT], wev[NT], Dl2[NT];
 #pragma unroll
                         for (int t = 0; t < NT; ++t) v[t] = yv[t] - Dt[t];
 #pragma unroll
@@ -1167,7 +1202,6 @@ __device__ __forceinline__ void dense_big_mt_solve(char* smem, const StepSmem& S
                             for (int k = 0; k < NT; ++k) acc = fmaf(K.Rm[m][k], qv[k], acc);
                             wev[m] = (rhs[m] + acc) + da[m];
                         }
-                        float ao[NT], bv[NT], dv2[NT], Dl2[NT];
 #pragma unroll
                         for (int t = 0; t < NT; ++t) { ao[t] = a[t]; bv[t] = bb[t]; dv2[t] = dd[t]; Dl2[t] = 0.f; }
                         mt1_eval<NT, false>(K, Q, PriorMem{lpr, 1}, wev, dj, thr, z, ao, bv, dv2, Dl2);
@@ -1175,6 +1209,7 @@ __device__ __forceinline__ void dense_big_mt_solve(char* smem, const StepSmem& S
 #pragma unroll
                         for (int t = 0; t < NT; ++t) ok = ok && (dv2[t] == 1.f);
                         const unsigned long long bad = __ballot(!ok) & ~fixed;
+                        if (tx1 == 0) tx1 = clock64();
                         if (bad == 0ull) break;
                         if (++nexc > kSolveMaxExc) { failed = true; break; }
                         const int e = __builtin_amdgcn_readfirstlane(__builtin_ctzll(bad));      // the first exception: final up to here
@@ -1189,17 +1224,33 @@ __device__ __forceinline__ void dense_big_mt_solve(char* smem, const StepSmem& S
                             }
                         }
                         if (lane == e) isexc = true;
-                        if (lane > e) {
+                        float tv[NT][NT];
+                        if ((odd0 >> e) & 1ull) {                                   // (wave-uniform) prefetched above
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            const int o = __popcll(odd0 & ((1ull << e) - 1ull));
+#pragma unroll
+                            for (int k = 0; k < NT; ++k)
+#pragma unroll
+                                for (int m = 0; m < NT; ++m) tv[k][m] = tcol[((o * NT + k) * NT + m) * 64 + lane];
+                        } else {
 #pragma unroll
                             for (int k = 0; k < NT; ++k)
 #pragma unroll
                                 for (int m = 0; m < NT; ++m) {
                                     const int cidx = m * 64 + e;
-                                    Dt[k] = fmaf(Ts[((int64_t)(cidx >> 2) * (64 * NT) + (k * 64 + lane)) * 4 + (cidx & 3)], del[m], Dt[k]);
+                                    tv[k][m] = Ts[((int64_t)(cidx >> 2) * (64 * NT) + (k * 64 + lane)) * 4 + (cidx & 3)];
                                 }
+                        }
+                        if (lane > e) {
+#pragma unroll
+                            for (int k = 0; k < NT; ++k)
+#pragma unroll
+                                for (int m = 0; m < NT; ++m) Dt[k] = fmaf(tv[k][m], del[m], Dt[k]);
                         }
                         fixed |= 1ull << e;
                     }
+                    if (lane == 0) { cy_x1 += tx1 - tx0; cy_xn += clock64() - tx1; }
+                    kill_pq();
                     if (failed) { if (lane == 0) sflag[4 + s] = 1; }
                     else if (nexc > 0) {
                         // the optimistic apply of the others used the first D~: they restore and apply these
@@ -1308,6 +1359,7 @@ __device__ __forceinline__ void dense_big_mt_solve(char* smem, const StepSmem& S
                         acur[t * B + c] = an[t]; bcur[t * B + c] = bnw[t]; dcur[t * B + c] = dn[t];
                         rhs_lds[t * B + c] = a[t] - an[t];
                     }
+                    kill_pq();
                 }
                 lds_barrier();                                           // B5
                 if (wave > s) apply_changes(s, rhs, pq);
@@ -1335,6 +1387,8 @@ __device__ __forceinline__ void dense_big_mt_solve(char* smem, const StepSmem& S
             atomicAdd(&A.counters[16], (unsigned long long)nsolved);
             atomicAdd(&A.counters[17], (unsigned long long)nfailed);
             if (nexc_all) atomicAdd(&A.counters[23], (unsigned long long)nexc_all);         // ... exceptions taken inside the solved ones
+            atomicAdd(&A.counters[13], (unsigned long long)cy_x1);                         // (the first verification pass | the exception passes, cycles)
+            atomicAdd(&A.counters[14], (unsigned long long)cy_xn);
         }
     } else {
         // ====================== waves 4..7: their quarters of the mat-vec, nothing else (the same barriers as above) ======================

@@ -30,6 +30,28 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
+class SectionSolvePolicy:
+    """When the host sets jwas_sweep_params.section_solve (Rule T) along a chain.  A multi-trait sampler-I chain that starts from
+    the reference's default prior (every marker in the model) drifts, with Pi estimated, towards sparser joint states; once
+    most 64-marker sections hold more markers outside the model than the rule takes as exceptions, the per-sweep section
+    inverses and the lazily fetched Gram tiles are pure overhead.  The rule is therefore switched off for `probe` sweeps when
+    the last sweep solved fewer than half of its sections, and tried again afterwards (speed only: on or off, a sweep samples
+    the same conditionals)."""
+
+    def __init__(self, enabled, nsections, probe=50):
+        self.enabled, self.nsections, self.probe = bool(enabled), int(nsections), int(probe)
+        self.off_until = 0
+
+    def use(self, it):
+        return self.enabled and it >= self.off_until
+
+    def observe(self, it, engine):
+        if not self.enabled or it < self.off_until or not hasattr(engine, "last_sweep_counters"):
+            return
+        if engine.last_sweep_counters()[16] * 2 < self.nsections:
+            self.off_until = it + 1 + self.probe
+
+
 class HipEngine:
     def __init__(self, device=0, precision=32):
         """precision: 32 (the reference's default Float32 path) or 64 (runMCMC(double_precision=true): a Float64 context --

@@ -561,6 +561,9 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
             raise NotImplementedError(f"double_precision=true needs fast_blocks * traits <= 2048 on the device (got {block_size} x {t})")
         adaptive = False
 
+    from .engine import SectionSolvePolicy
+    solve_policy = SectionSolvePolicy(section_solve, 4 * (p // 256))
+
     # ---- engine (the only engine shipped is the HIP one; there is no CPU fallback)
     own_engine = engine is None
     if own_engine:
@@ -751,7 +754,7 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
             kw = dict(iteration=it, seed=seed_int, vare=vare, nreps=nreps)
             if independent_blocks:
                 kw["independent_blocks"] = True
-            if section_solve:
+            if solve_policy.use(it):
                 kw["section_solve"] = True
             if mega:
                 kw.update(var_effect=Gval, pi=pi_t)
@@ -775,6 +778,7 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
             else:
                 kw.update(var_effect=Gval, pi=pi)
             st = engine.sweep(**kw)
+            solve_policy.observe(it, engine)
             t_sweep += st["sweep_ms"]
             if adaptive:
                 engine.select_block_size(pick_block_size(st["n_events"], p))

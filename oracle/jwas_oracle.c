@@ -1102,7 +1102,7 @@ int orc_bayesr_lookahead_sweep(const float* X, int64_t n, int64_t p, int64_t ld,
 /* ------------------------------------------------------------------------------------------ */
 static int g_section_solve = 0;
 void orc_set_section_solve(int on) { g_section_solve = on; }
-enum { ORC_SOLVE_MAX_ODD = 4, ORC_SOLVE_MAX_EXC = 6 };            /* (csrc/sampler_mt.hpp: kSolveMaxOdd, kSolveMaxExc) */
+enum { ORC_SOLVE_MAX_ODD = 16, ORC_SOLVE_MAX_EXC = 24 };            /* (csrc/sampler_mt.hpp: kSolveMaxOdd, kSolveMaxExc) */
 static int64_t g_solve_sections = 0, g_solve_fallbacks = 0, g_solve_exceptions = 0;      /* diagnostics: sections solved / fallen back, exceptions of the solved ones, since the last reset */
 void orc_section_solve_counts(int64_t* solved, int64_t* fallbacks, int reset)
 {

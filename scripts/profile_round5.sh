@@ -36,4 +36,10 @@ run config2_packed 10 --storage packed2bit
 ( time JWAS_FUZZ_CASES=6000 timeout 1500 python -m pytest tests/test_gpu_fuzz.py -q -n 8 -k "random" 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" | tail -15 ) > "$OUT/fuzz_6000_cases.log" 2>&1
 # single-trait helper workgroup A/B on the reference's own benchmark
 JWAS_HIP_CORR_HELPER=0 python bench.py --no-cpu-baseline --via-api 0 --workload refbench --warmup 10 --burnin 0 > "$OUT/bench_refbench_nohelper.json" 2> /dev/null
+# config 4 along a LONG chain (reference default prior, Pi estimated): joint-state counts and sweep time every 100 sweeps, and the
+# bench line of sweeps 2901..3000 (the chain's real steady state: the sparse regime)
+JWAS_BENCH_VERBOSE=1 JWAS_BENCH_LOG_STATES=100 python bench.py --no-cpu-baseline --via-api 0 --steps 100 --workload config4 --warmup 0 --burnin 2900 > "$OUT/bench_config4_longrun.json" 2> "$OUT/config4_chain.err"
+grep "joint-state" "$OUT/config4_chain.err" > "$OUT/config4_chain.log"
+# BayesR on 8 marker shards (emulated as 8 contexts on this GPU) against the exact chain, 400 iterations
+python scripts/shard_check.py --method BayesR --iters 400 --json "$OUT/shard_check_bayesr.json" > "$OUT/shard_check_bayesr.log" 2>&1
 ls "$OUT"

@@ -217,7 +217,7 @@ def test_random_rule_t_configurations_against_the_oracle(hip, seed):
     method = "MTBayesB" if rng.random() < 0.35 else "MTBayesC"
     n = int(rng.integers(300, 900)) if rng.random() < 0.7 else int(rng.integers(1500, 3300))
     p = 256 * int(rng.integers(1, 5)) + int(rng.choice([0, 0, 17, 130, 255]))
-    leak = float(rng.choice([0.0, 1e-9, 1e-4, 3e-3, 1e-2]))
+    leak = float(rng.choice([0.0, 1e-9, 1e-4, 3e-3, 2e-2, 6e-2]))
     d = make_dataset(n=n, p=p, ncausal=min(10, p), seed=int(rng.integers(0, 1000)))
     y = (d["y"] - d["y"].mean()).astype(np.float32)
     w = rng.uniform(0.3, 3.0, n).astype(np.float32) if rng.random() < 0.25 else None

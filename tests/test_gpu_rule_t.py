@@ -53,12 +53,12 @@ def _mt_hyper(t, rng):
 
 
 @pytest.mark.parametrize("method,t,leak", [("MTBayesC", 3, 1e-9), ("MTBayesC", 2, 1e-9), ("MTBayesB", 3, 1e-9), ("MTBayesC", 3, 2e-3),
-                                           ("MTBayesC", 3, 1e-2), ("MTBayesB", 2, 5e-3)])
+                                           ("MTBayesC", 3, 6e-2), ("MTBayesB", 2, 2e-2)])
 def test_rule_t_multitrait_device_vs_its_oracle_restatement(hip, method, t, leak):
     """Sampler I, 256-marker blocks (three full ones and a ragged tail), every marker in the model at the start.  leak = the prior
     mass of every other joint state: at 2e-3 markers do leave the model -- the solve takes them as EXCEPTIONS (their literal
     evaluation replaces their row of the solution, the rows behind take a rank-t correction), also the markers that are outside
-    the model when a later sweep enters their section; at 1e-2 sections collect more exceptions than the rule allows and fall
+    the model when a later sweep enters their section; at 6e-2 sections collect more exceptions than the rule allows and fall
     back to the walk, or are not tried at all -- the device and the oracle must take the same decisions everywhere."""
     rng = np.random.default_rng(70 + t)
     data = make_dataset(n=1100, p=3 * 256 + 77, ncausal=14, seed=700 + t)
@@ -90,7 +90,7 @@ def test_rule_t_multitrait_device_vs_its_oracle_restatement(hip, method, t, leak
     assert solved > 0
     if leak > 1e-3:
         assert exceptions > 0                                # the exception path was exercised
-    if leak >= 1e-2:
+    if leak >= 5e-2:
         assert fallen > 0                                    # ... and the fallback
     for k in range(t):
         np.testing.assert_allclose(hip.get_residual(k), orc.get_residual(k), rtol=0, atol=3e-5)
