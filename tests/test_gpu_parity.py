@@ -188,15 +188,17 @@ def test_bayesc_all_included_pi0(hip, small_data):
     _compare_state(orc, hip, atol=5e-6)
 
 
-@pytest.mark.parametrize("method,bs", [("BayesC", 512), ("BayesC", 128), ("BayesB", 256)])
-def test_rule_d_device_against_the_literal_oracle(hip, method, bs):
+@pytest.mark.parametrize("method,bs,n,gram", [("BayesC", 512, 1100, "f64"), ("BayesC", 128, 1100, "f64"), ("BayesB", 256, 1100, "f64"),
+                                              ("BayesC", 512, 5200, "mfma")])
+def test_rule_d_device_against_the_literal_oracle(hip, method, bs, n, gram):
     """The device (Rule D: alpha = fmaf(c1, x, c0) under a uniform pi = 0, csrc/kernels.hpp AbcMarker::rule_d; dense_big_st on
     full 256- / 512-marker blocks, the in-lane walk on 128-marker ones) against the oracle in the reference's LITERAL operation
     order (bayesabc_update_marker!, BayesABC.jl:36-46: rhs -> gHat -> alpha, RULE_D off) on the reference benchmark's shape
     (Pi = 0, every marker in the model, benchmarks/jwas_nonblock_benchmark.jl:34-51).  Not bit for bit -- the two associate
     differently -- but within the stated floating-point tolerance: every marker included every sweep on both sides, effects
-    and posterior means within 1e-4 of the effects' scale, the residual within 2e-4."""
-    data = make_dataset(n=1100, p=2 * bs + 77, ncausal=30, seed=4100 + bs)
+    and posterior means within 1e-4 of the effects' scale, the residual within 2e-4.  The last case is the production geometry:
+    512-marker blocks through dense_big_st with the helper workgroup forming the lookahead correction, n = 5 200, MFMA Grams."""
+    data = make_dataset(n=n, p=2 * bs + 77, ncausal=30, seed=4100 + bs)
     rng = np.random.default_rng(bs)
     kw = dict(vare=np.float32(0.6), var_effect=np.float32(0.002), pi=0.0)
     if method == "BayesB":
@@ -204,7 +206,7 @@ def test_rule_d_device_against_the_literal_oracle(hip, method, bs):
     r0 = data["y"] - data["y"].mean()
     try:
         O.RULE_D = False
-        orc, hip = _pair(hip, data, bs, method)
+        orc, hip = _pair(hip, data, bs, method, gram_mode=gram)
         orc.set_residual(r0); hip.set_residual(r0)
         mean_o = np.zeros(orc.p); mean_h = np.zeros(orc.p)
         nit = 20
