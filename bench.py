@@ -388,8 +388,14 @@ def main():
         elif t > 1:
             from scipy.stats import invwishart
             s["pi"] = rng.dirichlet(st["state_counts"] + 1.0)
-            if os.environ.get("JWAS_BENCH_LOG_STATES") and s["it"] % int(os.environ["JWAS_BENCH_LOG_STATES"]) == 0:
-                log(f"sweep {s['it']}: joint-state counts {[int(v) for v in st['state_counts']]} sweep_ms={st['sweep_ms']:.2f}")
+            if os.environ.get("JWAS_BENCH_LOG_STATES") and s["it"] % int(os.environ["JWAS_BENCH_LOG_STATES"]) in (0, 1):
+                codes = sum((eng.get_state(k)[2] != 0).astype(np.int64) << k for k in range(t))      # the markers' joint states
+                if s["it"] % int(os.environ["JWAS_BENCH_LOG_STATES"]) == 0:
+                    log(f"sweep {s['it']}: joint-state counts {[int(v) for v in st['state_counts']]} sweep_ms={st['sweep_ms']:.2f}")
+                    s["_codes"] = codes
+                elif "_codes" in s:          # how many markers changed their joint state from one sweep to the next
+                    log(f"sweep {s['it']}: {int((codes != s['_codes']).sum())} markers changed their joint state since the last sweep "
+                        f"({int(((codes != s['_codes']) & (s['_codes'] != (1 << t) - 1)).sum())} of them were not in the all-ones state)")
             if mt_pervar:                    # one InverseWishart(df + 1, scale + b_j b_j') draw per marker (variance_components.jl:181-186):
                 eng.sample_marker_covariances(df_g + 1.0, scale_g, seed=a.seed, iteration=s["it"], marker_offset=lo)   # on the device, from the resident beta
                 s["Gmat"] = None             # (the next sweep uses the resident covariances)

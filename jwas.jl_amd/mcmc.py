@@ -571,6 +571,11 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         need = HipEngine.estimate_bytes(n, p, t, block_size, "stream" if stream else "dense") * (2 if double_precision else 1)
         if adaptive:
             need += 2 * 4 * 1024 * p                               # the second resident block size (Grams + cross-Grams)
+        if double_precision and independent_blocks:
+            # Float64 independent blocks: one change list of 1024 entries per block (4 + 4 x 8 bytes per entry, whatever the
+            # block size) and one partial-sum buffer per block (4 traits x row slices x block doubles)
+            nb_ = -(-p // max(1, block_size))
+            need += nb_ * (4 + 1024 * (4 + 4 * 8)) + 4 * 8 * (-(-n // 256)) * nb_ * block_size
         if outputEBV and not out_same:                             # Mi.output_genotypes: a second dense matrix (n_out x p)
             need += 4 * ((len(out_rows) + 255) // 256 * 256) * p
         engine = HipEngine(device, precision=64 if double_precision else 32)
