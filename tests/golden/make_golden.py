@@ -27,6 +27,12 @@ CASES = {
                              kw=dict(vare=np.array([[0.5, 0.1], [0.1, 0.4]], dtype=np.float32),
                                      var_effect=np.array([[0.004, 0.001], [0.001, 0.003]], dtype=np.float32),
                                      log_prior_states=np.log(np.array([0.7, 0.05, 0.05, 0.2])))),
+    # Rule T (jwas_sweep_params.section_solve): one full 256-marker block (four sections solved with the per-sweep inverses; a
+    # prior that lets markers leave: exceptions inside the solved sections) and a ragged tail that is walked
+    "mt3_rule_t_b256": dict(method="MTBayesC", bs=256, sweeps=8, t=3,
+                            kw=dict(vare=np.array([[0.5, 0.1, 0.05], [0.1, 0.4, 0.08], [0.05, 0.08, 0.45]], dtype=np.float32),
+                                    var_effect=np.array([[0.004, 0.001, 0.0005], [0.001, 0.003, 0.0008], [0.0005, 0.0008, 0.0035]], dtype=np.float32),
+                                    log_prior_states=np.log(np.array([3e-3] * 7 + [1.0]) / (1.0 + 7 * 3e-3)), section_solve=True)),
     "mega2_b128": dict(method="MegaBayesC", bs=128, sweeps=8, t=2,
                        kw=dict(vare=np.diag([0.5, 0.4]).astype(np.float32),
                                var_effect=np.diag([0.004, 0.003]).astype(np.float32), pi=np.array([0.9, 0.8]))),
@@ -39,6 +45,10 @@ def inputs():
     raw = d["raw"].astype(np.uint8)
     y2 = (0.5 * d["y"] + np.random.default_rng(9).standard_normal(len(d["y"])).astype(np.float32) * 0.7).astype(np.float32)
     return raw, d["y"].astype(np.float32), y2
+
+
+def third_trait(y1, y2):
+    return (0.7 * y1 - 0.3 * y2).astype(np.float32)
 
 
 def centered(raw):
@@ -71,7 +81,7 @@ def main():
     X = centered(raw)
     blob = {"raw": raw, "y1": y1, "y2": y2, "seed": np.int64(SEED)}
     for name, case in CASES.items():
-        res = run_case(OracleEngine("lookahead"), X, [y1, y2], case)
+        res = run_case(OracleEngine("lookahead"), X, [y1, y2, third_trait(y1, y2)], case)
         for k, v in res.items():
             blob[f"{name}/{k}"] = v
     np.savez_compressed(os.path.join(HERE, "sweep_golden.npz"), **blob)

@@ -16,7 +16,7 @@ def _check(engine, name):
     g = np.load(os.path.join(HERE, "golden", "sweep_golden.npz"))
     X = MG.centered(g["raw"])
     case = MG.CASES[name]
-    res = MG.run_case(engine, X, [g["y1"], g["y2"]], case)
+    res = MG.run_case(engine, X, [g["y1"], g["y2"], MG.third_trait(g["y1"], g["y2"])], case)
     for k, v in res.items():
         ref = g[f"{name}/{k}"]
         if k.startswith("delta") or k == "n_events_last":
