@@ -196,7 +196,7 @@ def main():
         dist.init_process_group("nccl", rank=0, world_size=1)
     import jwas_jl_amd as J
     from jwas_jl_amd.dist import MarkerShard, RowShard, shard_range
-    from jwas_jl_amd.mcmc import pick_block_size
+    from jwas_jl_amd.mcmc import pick_block_size, pick_block_size_mt
 
     wl = a.workload
     n, p_arg, method, t = WORKLOADS[wl]
@@ -218,6 +218,7 @@ def main():
     bs = a.block_size or ((512 if all_in else (256 if mt_big else 128)) if dense_prior else 512)
     # Rule T (mcmc.run_chain's policy): the dense 256-marker blocks of sampler I as triangular solves; --no-section-solve = the walk
     section_solve = bool(mt_big and t <= 3 and bs == 256 and not a.no_section_solve)
+    adaptive_mt = bool(a.block_size == 0 and mt_big and bs == 256 and 512 * t <= 2048)      # (256 while the chain is dense, 512 once it is sparse)
     rows_mode = a.shard == "rows"
     if rows_mode and (weak or a.storage != "dense"):
         raise SystemExit("--shard rows runs the dense strong-scaling workloads (config2 / config3 / config4 / refbench)")
@@ -253,6 +254,8 @@ def main():
     eng.setup_blocks(bs, "mfma")
     if adaptive:
         eng.add_block_size(1024, "mfma")
+    elif adaptive_mt:
+        eng.add_block_size(512, "mfma")
     log('setup_blocks done')
     eng.init_state("MTBayesB" if mt_pervar else method, t)
     if not rows_mode:
@@ -361,7 +364,7 @@ def main():
             eng.residual_add_scalar(mu_old[k] - s["mu"][k], k)
         # 2. marker sweep on the device (+ shard reconcile)
         kw = dict(iteration=s["it"], seed=a.seed, vare=s["vare"], var_effect=s["G"], nreps=1)
-        if solve_policy.use(s["it"]):
+        if solve_policy.use(s["it"]) and eng.block_size == 256:
             kw["section_solve"] = True
         if method == "BayesR":
             kw["pi_classes"] = s["pi"]
@@ -377,6 +380,8 @@ def main():
         solve_policy.observe(s["it"], eng)
         if adaptive:       # n_events is the all-shard total after the reconcile: every rank takes the same decision
             eng.select_block_size(pick_block_size(st["n_events"], p_total))
+        elif adaptive_mt:
+            eng.select_block_size(pick_block_size_mt(st["n_events"], p_total))
         acc["launches"] += -(-p_loc // s["bs"]) + 1
         acc["bytes"] += 4.0 * n_loc * p_loc if a.storage == "dense" else 0.25 * n_loc * p_loc
         s["bs"] = eng.block_size
@@ -479,7 +484,7 @@ def main():
             "n_gpus": comm_world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "name": wl, "variant": variant, "storage": a.storage,
-                       "n": n, "p": p_total, "block_size": bs_now, "block_policy": "adaptive 512/1024" if adaptive else "fixed",
+                       "n": n, "p": p_total, "block_size": bs_now, "block_policy": "adaptive 512/1024" if adaptive else ("256 while dense / 512 once sparse" if adaptive_mt else "fixed"),
                        "parallelism": (f"{'row' if rows_mode else 'marker'}-shard x{world}" + (" (exact chain of the pooled data; one all-reduce of the block RHS per block launch)" if rows_mode else " (one all-reduce of the residual delta per sweep; residual resident in HBM)")) if world > 1 else "single GPU",
                        "ranks_reported_by_communicator": comm_world,
                        "device_sweep_ms": acc["sweep_ms"] / a.steps, "per_rank_device_sweep_ms": per_rank_sweep_ms, "events_per_sweep": acc["events"] / a.steps,
