@@ -225,12 +225,13 @@ def test_rule_d_device_against_the_literal_oracle(hip, method, bs, n, gram):
     np.testing.assert_allclose(hip.get_residual(0), orc.get_residual(0), rtol=0, atol=2e-4)
 
 
-@pytest.mark.parametrize("t,bs", [(3, 128), (2, 64)])
+@pytest.mark.parametrize("t,bs", [(3, 128), (2, 64), (3, 256)])
 def test_rule_l_device_against_the_literal_oracle(hip, t, bs):
     """The device (Rule L: the linear form beta = A w + c of a marker that is and stays in the model for every trait,
     sampler_mt.hpp mt1_linear_coeffs) against the oracle in the reference's LITERAL conditional-by-conditional order
     (_MTBayesABC_samplerI!, MTBayesABC.jl:85-120; orc_set_mt_linear_form(0)) under the reference's default all-ones prior
-    (config 4's regime): identical inclusion trajectories in every sweep, effects within 1e-4 of their scale."""
+    (config 4's regime): identical inclusion trajectories in every sweep, effects within 1e-4 of their scale.  (3, 256) is the
+    dense_big_mt geometry (the sequential walk of 256-marker blocks; Rule T on the same geometry: tests/test_gpu_rule_t.py)."""
     data = make_dataset(n=900, p=4 * bs + 29, ncausal=12, seed=4200 + t)
     rng = np.random.default_rng(40 + t)
     Y = np.stack([(1 + 0.2 * k) * (data["y"] - data["y"].mean()) + 0.3 * rng.standard_normal(len(data["y"])).astype(np.float32)

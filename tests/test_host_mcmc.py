@@ -903,3 +903,38 @@ def test_runmcmc_double_precision_host_loop(tmp_path):
     model = api.build_model("y1 = intercept + geno")
     with pytest.raises(NotImplementedError, match="runMCMC\\(double_precision=true\\)"):
         api.runMCMC(model, ph, chain_length=10, output_folder=str(tmp_path / "e3"), _engine=OracleEngine64())      # Float64 genotypes, Float32 run
+
+
+def test_multitrait_host_policies():
+    """Host policies of a multi-trait sampler-I chain that starts dense (mcmc.pick_block_size_mt, engine.SectionSolvePolicy):
+    256-marker blocks while at least a quarter of the markers change per sweep, 512 afterwards; jwas_sweep_params.section_solve
+    on while the last sweep solved at least half of its sections, off for `probe` sweeps otherwise, then tried again."""
+    from jwas_jl_amd.mcmc import pick_block_size_mt
+    from jwas_jl_amd.engine import SectionSolvePolicy
+    assert pick_block_size_mt(99_000, 100_000) == 256 and pick_block_size_mt(25_000, 100_000) == 256
+    assert pick_block_size_mt(24_999, 100_000) == 512 and pick_block_size_mt(100, 100_000) == 512
+
+    class Eng:
+        def __init__(self): self.solved = 0
+        def last_sweep_counters(self): return [0] * 16 + [self.solved] + [0] * 7
+
+    e = Eng()
+    pol = SectionSolvePolicy(True, nsections=1560, probe=50)
+    used = []
+    for it in range(1, 161):
+        on = pol.use(it)
+        used.append(on)
+        e.solved = 1560 if it <= 20 else (700 if on else 0)        # from sweep 21 on fewer than half of the sections are solved
+        pol.observe(it, e)
+    assert all(used[:21])                                           # on, including the sweep that found out
+    assert not any(used[21:71]) and used[71]                        # off for 50 sweeps, then one probe ...
+    assert not any(used[72:122]) and used[122]                      # ... which fails again
+    off = SectionSolvePolicy(False, 1560)
+    assert not off.use(1)
+    off.observe(1, e)                                               # (a no-op)
+
+    class NoCounters:                                               # the CPU oracle engine of the host tests has no counters
+        pass
+    pol2 = SectionSolvePolicy(True, 1560)
+    pol2.observe(1, NoCounters())
+    assert pol2.use(2)
