@@ -99,6 +99,9 @@ def parse():
     ap.add_argument("--storage", choices=["dense", "packed2bit"], default="dense",
                     help="dense = the metric's fp32 dense genotypes (default); packed2bit = the reference's 2-bit packed "
                          "streaming payload kept packed in HBM (same genotypes, same chain; extra, not the headline config)")
+    ap.add_argument("--groups", type=int, default=int(os.environ.get("JWAS_BENCH_GROUPS", "-1")), choices=[-1, 0, 2, 4],
+                    help="blocks per launch of the step kernel in the sparse steady state (grouped launches, jwas_hip_setup_groups); "
+                         "0 = one block per launch; -1 = the host policy's default (mcmc.GROUPED_BLOCKS_PER_LAUNCH)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-markers", type=int, default=20000)
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target CPU time per thread-count leg")
@@ -117,7 +120,7 @@ def log(msg):
         print(f"[bench {time.time() - _T0:8.2f}s] {msg}", file=sys.stderr, flush=True)
 
 
-def traffic_from_profiles(workload, n, p, bs, storage, world, pi_fixed, variant=None):
+def traffic_from_profiles(workload, n, p, bs, storage, world, pi_fixed, variant=None, groups=0):
     """HBM bytes per k_block_step launch from the PMC summaries committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and
     --pmc WRITE_SIZE in separate runs of this command; FETCH_SIZE x2 per the guide's gfx950 correction, checked on k_xpx
     which reads X exactly once).  Only returned when the summaries' recorded configuration matches this run."""
@@ -133,7 +136,7 @@ def traffic_from_profiles(workload, n, p, bs, storage, world, pi_fixed, variant=
         c = row.get("config", {})
         if (c.get("workload") == workload and c.get("n") == n and c.get("p") == p and c.get("block_size") == bs
                 and c.get("storage") == storage and c.get("n_gpus") == world and c.get("pi_fixed") == pi_fixed
-                and c.get("variant") == variant):
+                and c.get("variant") == variant and int(c.get("blocks_per_launch", 0) or 0) == (groups if groups >= 2 else 0)):
             return float(row["bytes_per_launch"]), row.get("source")
     return None, None
 
@@ -256,6 +259,16 @@ def main():
         eng.add_block_size(1024, "mfma")
     elif adaptive_mt:
         eng.add_block_size(512, "mfma")
+    # grouped launches (single-trait sparse steady state: the 1024-marker set of the adaptive policy, or the fixed block size of a
+    # packed / explicitly sized run): mcmc.run_chain's policy
+    from jwas_jl_amd.mcmc import GROUPED_BLOCKS_PER_LAUNCH, grouped_launch_size
+    groups = GROUPED_BLOCKS_PER_LAUNCH if a.groups < 0 else a.groups
+    group_bs = 0 if a.storage != "dense" else grouped_launch_size(method, t, rows_mode, (1024 if adaptive else bs), groups, dense_prior=dense_prior)
+    if group_bs:
+        cur = eng.block_size
+        eng.select_block_size(group_bs)
+        eng.setup_groups(groups, "mfma")
+        eng.select_block_size(cur)
     log('setup_blocks done')
     eng.init_state("MTBayesB" if mt_pervar else method, t)
     if not rows_mode:
@@ -375,6 +388,9 @@ def main():
                 kw["var_effect_matrix"] = s["Gmat"]
         else:
             kw["pi"] = s["pi"]
+        m_now = eng.blocks_per_launch()
+        if m_now >= 2:
+            kw["group_launch"] = True
         st = shard.sweep_resident(**kw)
         s["rsum"] = np.asarray(st["resid_sum"], dtype=np.float64).copy()
         solve_policy.observe(s["it"], eng)
@@ -382,7 +398,8 @@ def main():
             eng.select_block_size(pick_block_size(st["n_events"], p_total))
         elif adaptive_mt:
             eng.select_block_size(pick_block_size_mt(st["n_events"], p_total))
-        acc["launches"] += -(-p_loc // s["bs"]) + 1
+        acc["launches"] += -(-p_loc // (s["bs"] * max(m_now, 1))) + 1
+        acc["grouped"] = max(acc.get("grouped", 0), m_now)
         acc["bytes"] += 4.0 * n_loc * p_loc if a.storage == "dense" else 0.25 * n_loc * p_loc
         s["bs"] = eng.block_size
         # 3-5. pi, marker-effect variance, residual variance (Pi.jl:7-42, variance_components.jl:60-112,151-189)
@@ -465,7 +482,8 @@ def main():
         bs_now = state["bs"]
         achieved = bytes_per_launch / 1e9 / (avg_launch_us * 1e-6)
         variant = (f"{a.mt_method}/{a.mt_prior}" + ("/walk" if (a.no_section_solve and mt_big and t <= 3 and bs == 256) else "")) if t > 1 else None   # (config 4: sampler family, prior, chain form)
-        traffic, traffic_src = traffic_from_profiles(wl, n, p_total, bs_now, a.storage, world, a.pi_fixed, variant)
+        m_used = int(acc.get("grouped", 0))
+        traffic, traffic_src = traffic_from_profiles(wl, n, p_total, bs_now, a.storage, world, a.pi_fixed, variant, m_used)
         if t == 1 and method == "BayesC":
             in_model = float(last["sum_delta"][0])
         elif method == "BayesR":
@@ -485,6 +503,7 @@ def main():
             "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "name": wl, "variant": variant, "storage": a.storage,
                        "n": n, "p": p_total, "block_size": bs_now, "block_policy": "adaptive 512/1024" if adaptive else ("256 while dense / 512 once sparse" if adaptive_mt else "fixed"),
+                       "blocks_per_launch": (m_used if m_used >= 2 else 1),
                        "parallelism": (f"{'row' if rows_mode else 'marker'}-shard x{world}" + (" (exact chain of the pooled data; one all-reduce of the block RHS per block launch)" if rows_mode else " (one all-reduce of the residual delta per sweep; residual resident in HBM)")) if world > 1 else "single GPU",
                        "ranks_reported_by_communicator": comm_world,
                        "device_sweep_ms": acc["sweep_ms"] / a.steps, "per_rank_device_sweep_ms": per_rank_sweep_ms, "events_per_sweep": acc["events"] / a.steps,
@@ -492,7 +511,7 @@ def main():
                        "host_ms_per_step": ms_per_step - acc["sweep_ms"] / a.steps,
                        "sharded_path": bool(getattr(shard, "_lib_comm", False)),
                        "chain_sweeps_before_timing": nburn + a.warmup},
-            "roofline": {"bound": "hbm", "kernel": "k_block_step", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": ("k_group_step" if m_used >= 2 else "k_block_step"), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "bytes_per_launch": bytes_per_launch, "avg_launch_us": avg_launch_us, "launches_timed": launches},
         }

@@ -138,7 +138,13 @@ typedef struct jwas_sweep_params {
                                         /* association (effects within float32 rounding of the sequential chain).  Needs nreps = 1, */
                                         /* no independent_blocks, no marker-specific priors; every other sweep ignores the flag.    */
                                         /* 0 = the sequential chain everywhere (bit-identical to earlier releases).                 */
-    int32_t  reserved0;                 /* (keeps the struct a multiple of 8 bytes; must be 0)                                      */
+    int32_t  group_launch;              /* != 0: GROUPED LAUNCHES -- every launch streams the 2 or 4 consecutive blocks that         */
+                                        /* jwas_hip_setup_groups prepared and samples the previous group's blocks in order: the     */
+                                        /* same chain with the per-launch cost shared by the group; the block right-hand sides are  */
+                                        /* assembled from an older residual plus up to three cross-Gram corrections (float32        */
+                                        /* rounding of the plain schedule).  Single-trait methods, nreps = 1, uniform blocks, no     */
+                                        /* independent_blocks; every other sweep, and a context without jwas_hip_setup_groups,      */
+                                        /* ignores the flag.  0 = one block per launch (bit-identical to earlier releases).         */
 } jwas_sweep_params;
 
 /* Reductions the host-side conjugate draws need (Pi.jl, variance_components.jl). */
@@ -246,6 +252,11 @@ int  jwas_hip_update_geometry(jwas_hip_ctx* ctx, int32_t* slices_per_row_group, 
  * a free tuning knob too: fast_blocks=<number>, JWAS.jl:293-316).  get/set_gram and num_blocks act on the selected size. */
 int  jwas_hip_add_block_size(jwas_hip_ctx* ctx, int32_t block_size, int32_t gram_mode);
 int  jwas_hip_select_block_size(jwas_hip_ctx* ctx, int32_t block_size);
+/* Grouped launches (jwas_sweep_params.group_launch) for the SELECTED block size: blocks_per_launch = 2 or 4 consecutive blocks
+ * per launch of the step kernel (block_size * blocks_per_launch <= 4096), 0 = free the buffers again.  Builds the cross-Grams of
+ * consecutive pairs (and, 4: fours) of blocks -- 8 * p * block_size bytes per level -- once; needs uniform blocks.  The
+ * reference has no counterpart: like the block size it is a schedule knob of the device (BayesABC.jl:145-187 is the chain). */
+int  jwas_hip_setup_groups(jwas_hip_ctx* ctx, int32_t blocks_per_launch, int32_t gram_mode);
 /* Explicit, possibly non-uniform block partition: fast_blocks = a vector of block starts (JWAS.jl:298-304,
  * validate_fast_block_starts JWAS.jl:73-79).  starts: nblocks 0-based first markers, starts[0] = 0, strictly increasing;
  * block k = [starts[k], starts[k+1]) (the last one ends at p); at most 1024 markers per block and 32768 blocks.  With

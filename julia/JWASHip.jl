@@ -44,7 +44,7 @@ struct HipSweepParams
     var_effect_f64::NTuple{16,Float64}
     var_effect_vec_f64::Ptr{Float64}
     section_solve::Int32
-    reserved0::Int32
+    group_launch::Int32
 end
 
 struct HipSweepStats

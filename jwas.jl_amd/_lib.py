@@ -35,6 +35,7 @@ SYMBOLS = [
     "jwas_hip_residual_add_scalar", "jwas_hip_comm_info", "jwas_hip_sample_marker_covariances", "jwas_hip_get_marker_covariances",
     "jwas_hip_set_precision", "jwas_hip_load_dense_f64", "jwas_hip_get_xpx_f64", "jwas_hip_set_state_f64", "jwas_hip_get_state_f64",
     "jwas_hip_set_residual_f64", "jwas_hip_get_residual_f64", "jwas_hip_mul_alpha_f64", "jwas_hip_get_posterior_f64",
+    "jwas_hip_setup_groups",
 ]
 STORAGE_DENSE_F32, STORAGE_PACKED2BIT = 0, 1
 
@@ -56,7 +57,7 @@ class SweepParams(C.Structure):
         ("var_effect_f64", C.c_double * (MAX_TRAITS * MAX_TRAITS)),
         ("var_effect_vec_f64", C.POINTER(C.c_double)),
         ("section_solve", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("group_launch", C.c_int32),
     ]
 
 
@@ -171,6 +172,7 @@ def load():
     L.jwas_hip_set_cross_gram.argtypes = [vp, i64, vp]
     L.jwas_hip_comm_init_loopback.argtypes = [vp, i32, i32, i32]
     L.jwas_hip_select_block_size.argtypes = [vp, i32]
+    L.jwas_hip_setup_groups.argtypes = [vp, i32, i32]
     L.jwas_hip_estimate_bytes_storage.argtypes = [i64, i64, i32, i32, i32]
     L.jwas_hip_estimate_bytes_storage.restype = i64
     for name in SYMBOLS:

@@ -45,7 +45,14 @@ struct jwas_hip_ctx {
 
     // Active block configuration (a view of one entry of `sets`; several block sizes can be resident so the host
     // can pick per sweep: big blocks when few markers change, smaller ones when many do).
-    struct BlockSet { int bs; int64_t nblocks; float *gram, *cross, *corr; double* partials; };
+    struct BlockSet {
+        int bs; int64_t nblocks; float *gram, *cross, *corr; double* partials;
+        // grouped launches (jwas_hip_setup_groups; k_group_step): gm = 2 or 4 blocks per launch (0: not set up); gcross[0]: cross-Grams
+        // of consecutive PAIRS of blocks (2 bs markers: pair q at q (2 bs)^2, rows = markers of pair q-1), gcross[1] (gm = 4): of
+        // consecutive groups of four; gcbuf: the corrections [2][gm bs] cG | [2][bs] cW | [2 bs] cP | [bs] zeros; gidx / gdelta:
+        // [2][gm bs] the merged change lists of a group (ping-pong; header lines: ctx.ev[parity])
+        int gm; float* gcross[2]; float* gcbuf; int32_t* gidx; float* gdelta;
+    };
     int set_index = 0;                  // entry of `sets` that is selected
     std::vector<BlockSet> sets;
     std::vector<int64_t> starts;        // explicit block starts (nblocks + 1 entries, last = p), empty = uniform blocks
@@ -252,7 +259,10 @@ static void free_state(jwas_hip_ctx* c)
 static void free_blocks(jwas_hip_ctx* c)
 {
     (void)hipFree(c->xpx);
-    for (auto& b : c->sets) { (void)hipFree(b.gram); (void)hipFree(b.cross); (void)hipFree(b.corr); (void)hipFree(b.partials); }
+    for (auto& b : c->sets) {
+        (void)hipFree(b.gram); (void)hipFree(b.cross); (void)hipFree(b.corr); (void)hipFree(b.partials);
+        (void)hipFree(b.gcross[0]); (void)hipFree(b.gcross[1]); (void)hipFree(b.gcbuf); (void)hipFree(b.gidx); (void)hipFree(b.gdelta);
+    }
     c->sets.clear();
     c->xpx = c->gram = c->cross = c->corr = nullptr; c->partials = nullptr;
     c->block_size = 0; c->nblocks = 0;
@@ -838,6 +848,64 @@ int jwas_hip_select_block_size(jwas_hip_ctx* c, int32_t bs)
     for (size_t i = 0; i < c->sets.size(); ++i)
         if (c->sets[i].bs == bs) { if (c->block_size != bs) select_set(c, i); return JWAS_HIP_OK; }
     return fail(c, JWAS_HIP_EINVAL, "block size %d is not resident (jwas_hip_setup_blocks / jwas_hip_add_block_size)", bs);
+}
+
+static void free_groups(jwas_hip_ctx::BlockSet& B)
+{
+    (void)hipFree(B.gcross[0]); (void)hipFree(B.gcross[1]); (void)hipFree(B.gcbuf); (void)hipFree(B.gidx); (void)hipFree(B.gdelta);
+    B.gcross[0] = B.gcross[1] = B.gcbuf = B.gdelta = nullptr; B.gidx = nullptr; B.gm = 0;
+}
+
+// Grouped launches for the SELECTED block size: the cross-Grams of consecutive pairs (and, m = 4, fours) of blocks, the
+// correction buffers and the merged change lists (sweep.hpp, k_group_step).  m = 0 frees them.
+int jwas_hip_setup_groups(jwas_hip_ctx* c, int32_t m, int32_t gram_mode)
+{
+    if (c) NOT_F64(c, "grouped launches");
+    NEED(c, c, JWAS_HIP_EINVAL, "ctx is NULL");
+    NEED(c, !c->sets.empty(), JWAS_HIP_ESTATE, "jwas_hip_setup_blocks has not been called");
+    NEED(c, m == 0 || m == 2 || m == 4, JWAS_HIP_EINVAL, "blocks per launch must be 0 (off), 2 or 4 (got %d)", m);
+    NEED(c, gram_mode == JWAS_HIP_GRAM_F64 || gram_mode == JWAS_HIP_GRAM_MFMA, JWAS_HIP_EINVAL, "unknown gram_mode %d", gram_mode);
+    NEED(c, c->starts.empty(), JWAS_HIP_EUNSUP, "grouped launches need uniform blocks (not an explicit block partition)");
+    NEED(c, !c->row_mode, JWAS_HIP_EUNSUP, "grouped launches are not available on row shards");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    auto& B = c->sets[(size_t)c->set_index];
+    free_groups(B);
+    if (m == 0) return JWAS_HIP_OK;
+    const int bs = B.bs;
+    NEED(c, m * bs <= 4096, JWAS_HIP_EUNSUP, "a launch streams at most 4096 markers (got %d blocks of %d)", m, bs);
+    for (int lvl = 0; lvl < (m == 4 ? 2 : 1); ++lvl) {
+        const int gb = (2 << lvl) * bs;                                  // markers per pair / per four
+        const int64_t ngr = (c->p + gb - 1) / gb;
+        // (m = 4 reads the pair -> pair cross-Grams INSIDE a four only: the odd pairs; the even ones are part of level 1)
+        const bool odd_only = (m == 4 && lvl == 0);
+        const int64_t nlaunch = odd_only ? ngr / 2 : ngr - 1;            // cross blocks 1, 3, 5, ... < ngr  /  1 .. ngr - 1
+        HIPCHK(c, hipMalloc(&B.gcross[lvl], sizeof(float) * (size_t)ngr * gb * gb));
+        if (nlaunch > 0) {
+            NEED(c, nlaunch <= 65535, JWAS_HIP_EUNSUP, "grouped launches: too many groups (%lld)", (long long)ngr);
+            with_cols(c, 0, [&](auto Xc) {
+                using CX = decltype(Xc);
+                if (gram_mode == JWAS_HIP_GRAM_F64)
+                    hipLaunchKernelGGL((k_cross_f64<CX>), dim3(gb, (unsigned)nlaunch), dim3(256), 0, c->stream, Xc, c->p, gb, B.gcross[lvl], (const int64_t*)nullptr, odd_only ? 1 : 0);
+                else {
+                    const int nt = gb / 64;
+                    hipLaunchKernelGGL((k_gram_mfma<CX>), dim3(nt * nt, (unsigned)nlaunch), dim3(256), 0, c->stream, Xc, c->p, gb, B.gcross[lvl], odd_only ? 2 : 1, (const int64_t*)nullptr);
+                }
+                return 0;
+            });
+            HIPCHK(c, hipGetLastError());
+        }
+    }
+    const size_t ncb = (size_t)2 * m * bs + 5 * (size_t)bs;
+    HIPCHK(c, hipMalloc(&B.gcbuf, sizeof(float) * ncb));
+    HIPCHK(c, hipMemsetAsync(B.gcbuf, 0, sizeof(float) * ncb, c->stream));
+    HIPCHK(c, hipMalloc(&B.gidx, sizeof(int32_t) * 2 * (size_t)m * bs));
+    HIPCHK(c, hipMalloc(&B.gdelta, sizeof(float) * 2 * (size_t)m * bs));
+    HIPCHK(c, hipMemsetAsync(B.gidx, 0, sizeof(int32_t) * 2 * (size_t)m * bs, c->stream));
+    HIPCHK(c, hipMemsetAsync(B.gdelta, 0, sizeof(float) * 2 * (size_t)m * bs, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    B.gm = m;
+    return JWAS_HIP_OK;
 }
 
 int jwas_hip_num_blocks(jwas_hip_ctx* c, int64_t* nb, int32_t* bs)
@@ -1707,9 +1775,88 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
         else HIPCHK(c, launch_section_inverse_mtc1(L, t, c->dparams, c->xpx, c->gram, solve_blocks * 4, c->tsec));
     }
     const int compact_off = std::getenv("JWAS_HIP_COMPACT_OFF") != nullptr ? std::atoi(std::getenv("JWAS_HIP_COMPACT_OFF")) : 0;          // (tests: the speculative rounds instead of the compact chain)
+    // GROUPED LAUNCHES (jwas_sweep_params.group_launch; jwas_hip_setup_groups; sweep.hpp k_group_step): gm blocks per launch.
+    // Single-trait single-pass sweeps on uniform blocks; every other sweep ignores the flag.  JWAS_HIP_GROUPS=0 switches it off.
+    static const int groups_env = std::getenv("JWAS_HIP_GROUPS") ? std::atoi(std::getenv("JWAS_HIP_GROUPS")) : 1;
+    const auto& SET = c->sets[(size_t)c->set_index];
+    const bool grouped = P->group_launch != 0 && groups_env != 0 && SET.gm >= 2 && !is_mt_method(c->method) && P->nreps == 1 && !independent &&
+                         !c->row_mode && c->starts.empty() && !dense_big;
+    int64_t last_launch = nb;                                   // index of the sweep's last launch
     if (independent) {
         int rc = sweep_independent(c, &ev_list, dense_big, dense_big_off, compact_off);
         if (rc) return rc;
+    } else if (grouped) {
+        const int m = SET.gm;
+        const int64_t gb = (int64_t)m * bs, ng = (nb + m - 1) / m;
+        const size_t pstride_g = (size_t)gb * c->nrg;           // (fits the ping-pong buffers: gm <= kMaxT, one trait)
+        HIPCHK(c, hipMemcpyAsync(c->r + rstride, c->r, sizeof(float) * (size_t)c->ld, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemsetAsync(&c->ev[1].count, 0, sizeof(int32_t), c->stream));
+        HIPCHK(c, hipMemsetAsync(SET.gcbuf, 0, sizeof(float) * ((size_t)2 * gb + 5 * (size_t)bs), c->stream));   // group 0 has no predecessor
+        const int off_w = (int)(2 * gb), off_p = off_w + 2 * bs, off_z = off_p + 2 * bs;
+        for (int64_t K = 0; K <= ng; ++K) {
+            UpdateArgs U;
+            std::memset(&U, 0, sizeof U);
+            U.r_in = c->r + ((K + 1) & 1) * rstride; U.r_out = c->r + (K & 1) * rstride;
+            U.ev = &c->ev[K & 1];
+            const int32_t* uidx = SET.gidx + (K & 1) * gb;
+            const float* udel = SET.gdelta + (K & 1) * gb;
+            U.j0 = (K < ng) ? K * gb : 0;
+            U.b = (K < ng) ? (int)std::min<int64_t>(gb, c->p - U.j0) : 0;
+            U.nslices = c->upd_nslices; U.nrg = c->nrg; U.spg = c->spg;
+            U.ncg = (U.b > 0 && c->ncg > U.b) ? U.b : c->ncg;
+            U.partials = c->partials + (K & 1) * pstride_g; U.bstride = (int)gb;
+            U.dbg = c->counters;
+            {
+                static const int qx = std::getenv("JWAS_HIP_QUIET_XCD") ? std::atoi(std::getenv("JWAS_HIP_QUIET_XCD")) : -1;
+                U.quiet_xcd = qx >= 0 ? qx : (c->last_events < 0 || c->last_events > 0.0125 * (double)c->p ? 1 : 0);
+            }
+            SamplerArgs S;
+            GroupArgs G;
+            std::memset(&S, 0, sizeof S);
+            std::memset(&G, 0, sizeof G);
+            G.m = m;
+            if (K >= 1) {
+                const int64_t gs = K - 1, first = gs * m;
+                S.P = c->dparams;
+                S.partials = c->partials + (gs & 1) * pstride_g; S.nrg = c->nrg; S.bstride = (int)gb;
+                S.j0 = first * bs; S.b = blk_b(c, first); S.p = c->p; S.bsz = bs;
+                S.xpx = c->xpx;
+                S.compact_off = compact_off;
+                S.prep_d = c->prep_d; S.prep_f = c->prep_f;
+                S.alpha = c->alpha; S.beta = c->beta; S.delta = c->delta;
+                S.ev_out = &c->ev[gs & 1];
+                S.counters = c->counters;
+                G.ns = (int)std::min<int64_t>(m, nb - first);
+                G.first = first; G.nb = nb;
+                G.gram_all = c->gram; G.cross_all = c->cross;
+                if (gs + 1 < ng) {
+                    G.cross_grp = SET.gcross[m == 4 ? 1 : 0] + (size_t)(gs + 1) * gb * gb;
+                    G.bn_grp = (int)std::min<int64_t>(gb, c->p - (gs + 1) * gb);
+                }
+                if (m == 4 && G.ns > 2) {
+                    G.cross_pair = SET.gcross[0] + (size_t)(2 * gs + 1) * (2 * (size_t)bs) * (2 * (size_t)bs);
+                    G.bn_pair = (int)std::min<int64_t>(2 * (int64_t)bs, c->p - (first + 2) * bs);
+                }
+                G.cbuf = SET.gcbuf;
+                G.off_g_in = (int)((gs & 1) * gb); G.off_g_out = (int)(((gs + 1) & 1) * gb);
+                G.off_w = off_w; G.off_p = off_p; G.off_z = off_z;
+                G.ev_idx = SET.gidx + (gs & 1) * gb; G.ev_delta = SET.gdelta + (gs & 1) * gb;
+            }
+            const bool timed = c->timing_stride > 0 && K < ng && (K % c->timing_stride) == 0;
+            if (timed) {
+                while (c->kev.size() < 2 * (ntimed + 1)) { hipEvent_t e; HIPCHK(c, hipEventCreate(&e)); c->kev.push_back(e); }
+                HIPCHK(c, hipEventRecord(c->kev[2 * ntimed], c->stream));
+            }
+            HIPCHK(c, launch_group_st(step_launch_of(c), c->method, U, uidx, udel, S, G));
+            if (timed) {
+                HIPCHK(c, hipEventRecord(c->kev[2 * ntimed + 1], c->stream));
+                ++ntimed;
+                timed_bytes += 4.0 * (double)c->n * (double)U.b;
+            }
+        }
+        const int64_t par = (ng - 1) & 1;
+        ev_list = EventList{&c->ev[par].count, SET.gidx + par * gb, SET.gdelta + par * gb, gb};
+        last_launch = ng;
     } else {
     // one-block lookahead pipeline (sweep.hpp): launch k = sampler(block k-1) || update/partial(block k)
     HIPCHK(c, hipMemcpyAsync(c->r + rstride, c->r, sizeof(float) * (size_t)t * c->ld, hipMemcpyDeviceToDevice, c->stream));
@@ -1804,8 +1951,8 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
     }
     }   // lookahead pipeline
     if (!independent) {
-        ev_list = event_list(&c->ev[(nb - 1) & 1]);
-        r_last = c->r + (nb & 1) * rstride;                   // r(nb-2), written by the last step
+        if (!grouped) ev_list = event_list(&c->ev[(nb - 1) & 1]);
+        r_last = c->r + (last_launch & 1) * rstride;          // r(nb-2), written by the last step
     }
     const int nfin = t * t + t;
     with_cols(c, 0, [&](auto cx) {

@@ -61,6 +61,25 @@ struct Events {
     int32_t idx[kMaxBlock];                 // local column index of the changed marker
     float   delta[kMaxT][kMaxBlock];        // alpha_old - alpha_new per trait (the axpy coefficient)
 };
+// How the update role reads a change list.  EvPlain: one block's Events.  EvGroup (grouped launches, sweep.hpp k_group_step:
+// single trait): the merged list of a GROUP of consecutive blocks -- the header line of an Events (count and the first 7 changes)
+// plus index / coefficient arrays of the group's capacity.
+struct EvPlain {
+    const Events* ev;
+    __device__ __forceinline__ int count() const { return ev->count; }
+    __device__ __forceinline__ int idx(int e) const { return ev->idx[e]; }
+    __device__ __forceinline__ float delta(int t, int e) const { return ev->delta[t][e]; }
+    __device__ __forceinline__ int hidx(int u) const { return ev->hidx[u]; }
+    __device__ __forceinline__ float hdelta(int u) const { return ev->hdelta[u]; }
+};
+struct EvGroup {
+    const Events* hdr; const int32_t* gidx; const float* gdelta;
+    __device__ __forceinline__ int count() const { return hdr->count; }
+    __device__ __forceinline__ int idx(int e) const { return gidx[e]; }
+    __device__ __forceinline__ float delta(int, int e) const { return gdelta[e]; }
+    __device__ __forceinline__ int hidx(int u) const { return hdr->hidx[u]; }
+    __device__ __forceinline__ float hdelta(int u) const { return hdr->hdelta[u]; }
+};
 
 // Per-sweep scalars, device resident (rewritten before every sweep).
 struct DevParams {
@@ -927,7 +946,7 @@ __global__ __launch_bounds__(256) void k_gram_mfma(CX cx, int64_t p, int bsize,
     const int64_t ld = cx.ld;
     __shared__ __attribute__((aligned(16))) float As[64 * kGramLd];
     __shared__ __attribute__((aligned(16))) float Bs[64 * kGramLd];
-    const int64_t blk = cross ? (int64_t)blockIdx.y + 1 : (int64_t)blockIdx.y;
+    const int64_t blk = cross == 2 ? 2 * (int64_t)blockIdx.y + 1 : (cross ? (int64_t)blockIdx.y + 1 : (int64_t)blockIdx.y);   // (cross = 2: the odd blocks only)
     const int64_t j0 = starts ? starts[blk] : blk * bsize;                        // block of the B operand (columns of the output)
     const int b = starts ? (int)(starts[blk + 1] - j0) : (int)((j0 + bsize <= p) ? bsize : (p - j0));
     const int64_t jA = cross ? (starts ? starts[blk - 1] : j0 - bsize) : j0;      // block of the A operand (rows of the output)

@@ -45,6 +45,11 @@ struct SamplerArgs {
     float* alpha; float* beta; void* delta;
     Events* ev_out;
     unsigned long long* counters;
+    // grouped launches (k_group_step, sweep.hpp; single trait): two further lookahead corrections of THIS block, added to corr_in
+    // (always valid pointers there: a zero buffer when a block has none), and the group's merged change list -- this block's
+    // changes go behind the ones of the group's earlier blocks, the header line (count, first 7 changes) is ev_out's
+    const float* corr_in2; const float* corr_in3;
+    int32_t* ev_idx; float* ev_delta;
 };
 
 // fp64 sum of one column's row-group partials in fixed (ascending row group) order; the first N loads are issued

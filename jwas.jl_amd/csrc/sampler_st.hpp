@@ -393,9 +393,12 @@ __host__ __device__ constexpr int st_park_nf(int method, bool dense = false) { (
 // DENSE: the instantiation for sweeps under a UNIFORM PRIOR pi = 0 (single-trait BayesA/B/C: RR-BLUP, BayesA, BayesL, the
 // reference's benchmark setting), selected by the host: every marker follows Rule D (AbcMarker::rule_d) on every path of
 // it, and full 256- / 512-marker blocks take dense_big_st.  The steady-state kernel is compiled without any of it.
-template <int METHOD, bool DENSE = false>
-__device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A)
+// GROUP (k_group_step): the block is one of a group of consecutive blocks sampled by ONE launch -- three lookahead corrections
+// instead of one, its changes appended to the group's merged list at ev_base.  Returns the number of changes of the block.
+template <int METHOD, bool DENSE = false, bool GROUP = false>
+__device__ __forceinline__ int sampler_role_st(char* smem, const SamplerArgs& A, int ev_base = 0)
 {
+    static_assert(!(GROUP && DENSE), "grouped launches run the general single-trait sampler");
     constexpr bool kR = (METHOD == kBayesR);
     constexpr int ND = st_park_nd(METHOD), NF = st_park_nf(METHOD, DENSE);
     const StepSmem SM(A.bsz, 1, ND, NF);
@@ -479,7 +482,8 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
         const int64_t j = j0 + cc;
         const float a0 = A.alpha[j];
         const float dj = A.xpx[j];
-        const float co = A.corr_in[c];
+        float co = A.corr_in[c];
+        if constexpr (GROUP) { const float co2 = A.corr_in2[c], co3 = A.corr_in3[c]; co = (co + co2) + co3; }
         if constexpr (kR) {
             BayesRMarker bm;
             bm.load_fast_global(A.prep_d, p, j, dj, ie);
@@ -563,7 +567,7 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
             bool all_in = true;
 #pragma unroll
             for (int q = 0; q < kStepThreads / 64; ++q) all_in = all_in && ((wc[q] >> 18) & 1);
-            if (all_in) { dense_big_st<METHOD>(smem, SM, A, ie, tk0); return; }
+            if (all_in) { dense_big_st<METHOD>(smem, SM, A, ie, tk0); return 0; }
             // (a helper workgroup is waiting for this block's sections: tell it that the general path forms the correction itself)
             if (A.xch != nullptr && tid < 64)
                 __hip_atomic_store(A.xch + tid, (unsigned long long)(kXchAbort | ((unsigned)(A.xch_epoch + 1) & 0x7fffffffu)) << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1174,12 +1178,16 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
     {
         const int* fin = reinterpret_cast<const int*>(smem + SM.log_off);
         const bool pairs = from_log && (stream_corr || A.b_next <= 0);          // (else the list was turned into plain columns)
+        int32_t* eidx; float* edel;
+        if constexpr (GROUP) { eidx = A.ev_idx + ev_base; edel = A.ev_delta + ev_base; }
+        else { eidx = A.ev_out->idx; edel = A.ev_out->delta[0]; }
+        const int hb = GROUP ? ev_base : 0;                                     // (entries of the list in front of this block's)
         for (int e = tid; e < nfin; e += kStepThreads) {
             const int ce = pairs ? fin[2 * e] : fin[e];
             const float d = astart[ce] - acur[ce];
-            A.ev_out->idx[e] = (int32_t)(j0 + ce);
-            A.ev_out->delta[0][e] = d;
-            if (e < 7) { A.ev_out->hidx[e] = (int32_t)(j0 + ce); A.ev_out->hdelta[e] = d; }
+            eidx[e] = (int32_t)(j0 + ce);
+            edel[e] = d;
+            if (hb + e < 7) { A.ev_out->hidx[hb + e] = (int32_t)(j0 + ce); A.ev_out->hdelta[hb + e] = d; }
             A.alpha[j0 + ce] = acur[ce];
         }
         // single-pass BayesA/B/C: a marker is in the model iff its effect is nonzero, beta = the effect, else its
@@ -1196,7 +1204,7 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
         }
     }
     if (tid == 0) {
-        A.ev_out->count = (int32_t)nfin;
+        A.ev_out->count = (int32_t)((GROUP ? ev_base : 0) + nfin);
         atomicAdd(&A.counters[0], (unsigned long long)nfin);
         atomicAdd(&A.counters[2], (unsigned long long)(tk1 - tk0));      // phase cycle counts (diagnostics)
         atomicAdd(&A.counters[3], (unsigned long long)(tk2 - tk1));
@@ -1222,6 +1230,7 @@ __device__ __forceinline__ void sampler_role_st(char* smem, const SamplerArgs& A
             }
         }
     }
+    return nfin;
 }
 
 

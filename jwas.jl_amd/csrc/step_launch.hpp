@@ -28,6 +28,10 @@ hipError_t launch_step_mtb1(const StepLaunch& L, int nt, const UpdateArgs& U, co
 hipError_t launch_step_mt2(const StepLaunch& L, int method, int nt, const UpdateArgs& U, const SamplerArgs& S, int do_sample, bool dense);
 hipError_t launch_step_mega(const StepLaunch& L, int method, int nt, const UpdateArgs& U, const SamplerArgs& S, int do_sample, bool dense);
 
+// grouped launches (k_group_step): sampler(blocks of group K-1) || update/partial(group K); single trait
+hipError_t launch_group_st(const StepLaunch& L, int method, const UpdateArgs& U, const int32_t* uev_idx, const float* uev_delta,
+                           const SamplerArgs& S, const GroupArgs& G);
+
 // Rule T (jwas_sweep_params.section_solve): the inverses of all 64-marker sections of the full 256-marker blocks, once per sweep
 // (k_section_inverse_mt; nsections = 4 per full block, tsec: nsections * (64 nt)^2 floats)
 hipError_t launch_section_inverse_mtc1(const StepLaunch& L, int nt, const DevParams* P, const float* xpx, const float* gram, int64_t nsections, float* tsec);

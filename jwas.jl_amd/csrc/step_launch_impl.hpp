@@ -88,6 +88,35 @@ hipError_t launch_step(const StepLaunch& L, const UpdateArgs& U, const SamplerAr
     return launch_step_cx<METHOD, NT, DenseCols>(L, L.dc, U, S, do_sample, dense);
 }
 
+template <int METHOD, class CX>
+hipError_t launch_group_cx(const StepLaunch& L, const CX& cx, const UpdateArgs& U0, const int32_t* uev_idx, const float* uev_delta,
+                           const SamplerArgs& S, const GroupArgs& G)
+{
+    UpdateArgsT<CX> U;
+    static_cast<UpdateArgs&>(U) = U0;
+    U.cx = cx;
+    const StepSmem SM = step_smem<METHOD, 1>(L.block_size, S, false);
+    static std::atomic<unsigned long long> attr_set{0ull};
+    const unsigned long long dev_bit = 1ull << (L.device & 63);
+    if (!(attr_set.load(std::memory_order_acquire) & dev_bit)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_group_step<METHOD, CX>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set.fetch_or(dev_bit, std::memory_order_release);
+    }
+    const int nwork = L.nrg * U.ncg;
+    const unsigned grid = U.quiet_xcd ? (unsigned)(1 + (nwork + 6) / 7 * 8) : (unsigned)(1 + nwork);
+    hipLaunchKernelGGL((k_group_step<METHOD, CX>), dim3(grid), dim3(kStepThreads), SM.bytes, L.stream, U, uev_idx, uev_delta, S, G);
+    return hipSuccess;
+}
+
+template <int METHOD>
+hipError_t launch_group(const StepLaunch& L, const UpdateArgs& U, const int32_t* uev_idx, const float* uev_delta, const SamplerArgs& S, const GroupArgs& G)
+{
+    if (L.packed) return launch_group_cx<METHOD, PackedCols>(L, L.pc, U, uev_idx, uev_delta, S, G);
+    return launch_group_cx<METHOD, DenseCols>(L, L.dc, U, uev_idx, uev_delta, S, G);
+}
+
 // Independent-block sweep (BayesABC_block_independent!, BayesABC.jl:190-255): all block RHS from the residual
 // snapshot (one pass over X), all blocks sampled concurrently; the caller compacts the change lists.
 template <int METHOD, int NT, class CX>

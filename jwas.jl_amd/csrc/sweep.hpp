@@ -191,18 +191,147 @@ __global__ __launch_bounds__(kStepThreads) void k_block_step(UpdateArgsT<CX> U, 
     if (w >= U.nrg * U.ncg) return;
     if (U.dbg_throttle > 1 && (w % U.dbg_throttle) != 0) return;       // timing experiments only
     constexpr bool kRoll = (METHOD == kBayesC || METHOD == kBayesB) && NT == 1 && !DENSE && CX::kDepth == 1;      // (see update_role; dense storage: the packed stream keeps 8 batches in registers)
-    update_role<NT, CX, COOP, kRoll>(smem, w % U.nrg, w / U.nrg, U.cx, U.r_in, U.r_out, U.ev, U.j0, U.b,
+    update_role<NT, CX, COOP, kRoll>(smem, w % U.nrg, w / U.nrg, U.cx, U.r_in, U.r_out, EvPlain{U.ev}, U.j0, U.b,
                                             U.nslices, U.nrg, U.ncg, U.partials, U.bstride, U.spg, U.sync_now, U.sync_next, U.dbg);
+}
+
+// ---------------------------------------------------------------------------------------------
+// GROUPED LAUNCHES (round 5; single trait, single-pass sweeps with a sparse prior in their steady state).  A launch of
+// k_block_step costs ~3.5 us that are not bandwidth (dispatch gap, ramp-up, drain: NOTES R1.1) -- 11 % of a 1024-marker
+// launch.  k_group_step streams a GROUP of m = 2 or 4 consecutive blocks per launch and its sampler workgroup samples the m
+// blocks of the previous group one after the other (the same sampler_role_st, the same code warm in the instruction cache):
+//
+//   launch K:  workgroup 0      = SAMPLER of blocks m(K-1) .. m(K-1)+m-1, in order
+//              workgroups 1..   = UPDATE/PARTIAL: apply the changes of group K-2 (ONE merged list), stream group K
+//
+// Same chain, another lookahead: the partial sums of ALL blocks of group K were formed from the residual that holds the changes
+// up to group K-2, so block s of the group is corrected for (oracle: orc_set_lookahead_group, la_group_*)
+//   cG  the changes of the WHOLE previous group          (group_corr at the end of the previous launch, cross-Gram group -> group)
+//   cW  s odd: the changes of block s-1, its pair's first (the sampler's own lookahead correction: corr_out -> corr_in, as ever)
+//   cP  m = 4, s >= 2: the changes of blocks 0 and 1     (group_corr after block 1, cross-Gram pair -> pair)
+// each a fused-multiply-add chain from 0 over the changed markers in marker order, and  rhs = fl32(sum of partials) + ((cW + cG) + cP)
+// (absent terms are +0).  A hierarchy: block -> block inside a pair, pair -> pair inside a four, group -> group.
+// ---------------------------------------------------------------------------------------------
+struct GroupArgs {
+    int ns;                        // blocks of the SAMPLED group (0 = none: first launch of a sweep)
+    int m;                         // blocks per group: 2 or 4
+    int64_t first, nb;             // index of the sampled group's first block; blocks of the partition (uniform, the last may be short)
+    const float* gram_all;         // [nb][bs * bs]
+    const float* cross_all;        // [nb][bs * bs]   entry i: X_{i-1}' X_i
+    const float* cross_grp;        // X_group' X_nextgroup (row stride bn_grp), or NULL: the sampled group is the last one
+    int bn_grp;
+    const float* cross_pair;       // m = 4: X_{blocks 0,1}' X_{blocks 2,3} of the sampled group (row stride bn_pair), or NULL
+    int bn_pair;
+    float* cbuf;                   // ONE buffer for every correction (offsets in floats below: a select between offsets keeps the
+                                   // accesses global; a select between pointers made hipcc emit flat ones)
+    int off_g_in;                  // [m * bs] cG of the sampled group
+    int off_g_out;                 // [m * bs] cG of the next group
+    int off_w;                     // [bs]     cW (room for two)
+    int off_p;                     // [2 * bs] cP
+    int off_z;                     // [bs]     zeros
+    int32_t* ev_idx; float* ev_delta;     // merged change list of the sampled group (capacity m * bs; header: S.ev_out)
+};
+
+// corr[c] = fmaf(d_e, C[row_e][c], corr[c]) from 0 over list entries [0, ne) in list (= marker) order, for ncols_out columns
+// (columns >= bn: 0).  All threads; the list is staged through LDS in chunks of 512 entries, 8 columns per thread.
+__device__ __forceinline__ void group_corr(char* smem, const int32_t* __restrict__ eidx, const float* __restrict__ edel, int ne, int64_t jrow0,
+                                           const float* __restrict__ cross, int bn, float* __restrict__ out, int ncols_out)
+{
+    int* lrow = reinterpret_cast<int*>(smem);
+    float* ld = reinterpret_cast<float*>(smem) + kStepThreads;
+    const int tid = threadIdx.x;
+    float corr[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) corr[q] = 0.f;
+    for (int e0 = 0; e0 < ne; e0 += kStepThreads) {
+        const int nc = (ne - e0) < kStepThreads ? (ne - e0) : kStepThreads;
+        __syncthreads();
+        if (tid < nc) { lrow[tid] = (int)((int64_t)eidx[e0 + tid] - jrow0); ld[tid] = edel[e0 + tid]; }
+        __syncthreads();
+        for (int h = 0; h < nc; h += 4) {
+            float g[4][8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t row = lrow[h + u < nc ? h + u : nc - 1];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int c = tid + q * kStepThreads;
+                    g[u][q] = cross[row * bn + (c < bn ? c : 0)];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (h + u < nc) {
+                    const float d = ld[h + u];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) corr[q] = fmaf(d, g[u][q], corr[q]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int c = tid + q * kStepThreads;
+        if (c < ncols_out) out[c] = (c < bn) ? corr[q] : 0.f;
+    }
+    __syncthreads();
+}
+
+template <int METHOD, class CX>
+__global__ __launch_bounds__(kStepThreads) void k_group_step(UpdateArgsT<CX> U, const int32_t* uev_idx, const float* uev_delta,
+                                                             SamplerArgs S, GroupArgs G)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (blockIdx.x == 0) {
+        if (G.ns <= 0) return;
+        const int bs = S.bsz;
+        const int64_t bb = (int64_t)bs * bs;
+        int nev = 0;
+#pragma unroll 1
+        for (int s = 0; s < G.ns; ++s) {
+            SamplerArgs A = S;                                  // S: block 0 of the group (partials, j0); the rest follows from the uniform partition
+            const int64_t i = G.first + s;
+            A.j0 = S.j0 + (int64_t)s * bs;
+            { const int64_t left = S.p - A.j0; A.b = left < bs ? (int)left : bs; }
+            A.partials = S.partials + s * bs;
+            A.gram = G.gram_all + i * bb;
+            const bool inner = !(s & 1) && s + 1 < G.ns;         // the first block of a PAIR: the sampler forms the cW of the second
+            { const int64_t left = S.p - (A.j0 + bs); A.b_next = inner ? (left < bs ? (int)left : bs) : 0; }
+            A.cross_next = G.cross_all + (inner ? i + 1 : i) * bb;
+            A.gram_next = G.gram_all + (inner ? i + 1 : i) * bb;          // (L2 prefetch only, and only when b_next > 0)
+            A.cross_after = nullptr; A.lines_after = 0;
+            A.corr_in = G.cbuf + ((s & 1) ? G.off_w : G.off_z);                        // cW: the pair's first block (or +0)
+            A.corr_out = G.cbuf + G.off_w;
+            A.corr_in2 = G.cbuf + G.off_g_in + s * bs;                                 // cG: the previous group
+            A.corr_in3 = G.cbuf + ((s >= 2) ? G.off_p + (s - 2) * bs : G.off_z);       // cP: the group's first pair (or +0)
+            A.ev_idx = G.ev_idx; A.ev_delta = G.ev_delta;
+            nev += sampler_role_st<METHOD, false, true>(smem, A, nev);
+            __syncthreads();                                    // the block's global stores (cW, the list) are visible to the workgroup
+            if (s == 1 && G.cross_pair != nullptr && G.ns > 2)
+                group_corr(smem, G.ev_idx, G.ev_delta, nev, S.j0, G.cross_pair, G.bn_pair, G.cbuf + G.off_p, 2 * bs);
+        }
+        if (G.cross_grp != nullptr) group_corr(smem, G.ev_idx, G.ev_delta, nev, S.j0, G.cross_grp, G.bn_grp, G.cbuf + G.off_g_out, G.m * bs);
+        return;
+    }
+    int w = blockIdx.x - 1;
+    if (U.quiet_xcd) {                                          // (see k_block_step)
+        if ((blockIdx.x & 7) == 0) return;
+        w = (int)(blockIdx.x - 1) - (int)((blockIdx.x - 1) >> 3);
+    }
+    if (w >= U.nrg * U.ncg) return;
+    constexpr bool kRoll = (METHOD == kBayesC || METHOD == kBayesB) && CX::kDepth == 1;
+    update_role<1, CX, false, kRoll, EvGroup>(smem, w % U.nrg, w / U.nrg, U.cx, U.r_in, U.r_out, EvGroup{U.ev, uev_idx, uev_delta}, U.j0, U.b,
+                                              U.nslices, U.nrg, U.ncg, U.partials, U.bstride, U.spg, nullptr, nullptr, U.dbg);
 }
 
 // Cross-Gram of consecutive blocks, exact (fp64-accumulated): C[a][c] = x_{jp+a}' x_{j0+c}.
 // grid = (bsize, nblocks-1), block = 256; workgroup (a, i) writes row a of cross block i+1.
 template <class CX>
 __global__ __launch_bounds__(256) void k_cross_f64(CX cx, int64_t p, int bsize,
-                                                   float* __restrict__ cross, const int64_t* __restrict__ starts = nullptr)
+                                                   float* __restrict__ cross, const int64_t* __restrict__ starts = nullptr, int odd_only = 0)
 {
     const int64_t ld = cx.ld;
-    const int64_t blk = (int64_t)blockIdx.y + 1;
+    const int64_t blk = odd_only ? 2 * (int64_t)blockIdx.y + 1 : (int64_t)blockIdx.y + 1;
     const int64_t j0 = starts ? starts[blk] : blk * bsize, jp = starts ? starts[blk - 1] : j0 - bsize;
     const int b = starts ? (int)(starts[blk + 1] - j0) : (int)((j0 + bsize <= p) ? bsize : (p - j0));
     const int a = blockIdx.x;
@@ -243,7 +372,7 @@ __global__ __launch_bounds__(kStepThreads) void k_indep_rhs(UpdateArgsT<CX> U, i
     const int ncg = U.ncg < b ? U.ncg : b;
     const int w = blockIdx.x;
     if (w >= U.nrg * ncg) return;
-    update_role<NT, CX>(smem, w % U.nrg, w / U.nrg, U.cx, U.r_in, nullptr, U.ev, j0, b,
+    update_role<NT, CX>(smem, w % U.nrg, w / U.nrg, U.cx, U.r_in, nullptr, EvPlain{U.ev}, j0, b,
                         U.nslices, U.nrg, ncg, U.partials + blk * pstride, U.bstride, U.spg);
 }
 

@@ -30,10 +30,10 @@ namespace jw {
 // row group's waves, one fp64 partial per column and row group) are the dense role's.
 // ---------------------------------------------------------------------------------------------
 constexpr int kWideRows = 1024;            // rows of r owned by one wave of the packed update role
-template <int NT, class CX>
+template <int NT, class CX, class EV>
 __device__ __forceinline__ void update_role_wide(char* smem, int rg, int g, const CX& cx,
                                                  const float* __restrict__ r_in, float* __restrict__ r_out,
-                                                 const Events* __restrict__ ev,
+                                                 const EV& ev,
                                                  int64_t j0, int b, int nslices, int nrg, int ncg,
                                                  double* __restrict__ partials, int bstride, int spg)
 {
@@ -79,14 +79,14 @@ __device__ __forceinline__ void update_role_wide(char* smem, int rg, int g, cons
     // sparse exit update (BayesABC.jl:181-185): r += x d per changed marker in list order, x the decoded column (pad rows: 0)
     const int64_t nleft = cx.n - row;
     const unsigned vmask = nleft >= 16 ? 0xffffu : (nleft <= 0 ? 0u : ((1u << (int)nleft) - 1u));
-    const int ne = ev->count;
+    const int ne = ev.count();
     for (int e0 = 0; e0 < ne; e0 += 64) {
         const int el = e0 + lane, ec = el < ne ? el : ne - 1;
-        const int liv = ev->idx[ec];
+        const int liv = ev.idx(ec);
         const float lmu = cx.mean[liv];
         float ldv[NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) ldv[t] = ev->delta[t][ec];
+        for (int t = 0; t < NT; ++t) ldv[t] = ev.delta(t, ec);
         const int rem0 = (ne - e0) < 64 ? (ne - e0) : 64;
         for (int h = 0; h < rem0; h += 8) {
             unsigned cq[8];
@@ -200,18 +200,18 @@ __device__ __forceinline__ void update_role_wide(char* smem, int rg, int g, cons
 
 // ROLL: the rolling-window apply for 33..64 changes (below) -- only where the kernel's register budget carries it (the
 // instantiation's sampler role decides: single-trait BayesA/B/C; with BayesR's or the multi-trait samplers' it spilled)
-template <int NT, class CX, bool COOP = false, bool ROLL = false>
+template <int NT, class CX, bool COOP = false, bool ROLL = false, class EV = EvPlain>
 __device__ __forceinline__ void update_role(char* smem, int rg, int g,
                                             const CX& cx,
                                             const float* __restrict__ r_in, float* __restrict__ r_out,
-                                            const Events* __restrict__ ev,
+                                            const EV& ev,
                                             int64_t j0, int b, int nslices, int nrg, int ncg,
                                             double* __restrict__ partials, int bstride, int spg = kRowGroupSlices,
                                             int* sync_now = nullptr, int* sync_next = nullptr, unsigned long long* dbg = nullptr)
 {
     if constexpr (CX::kWide) {       // 2-bit packed storage: its own geometry (above)
         (void)sync_now; (void)sync_next; (void)dbg;
-        update_role_wide<NT, CX>(smem, rg, g, cx, r_in, r_out, ev, j0, b, nslices, nrg, ncg, partials, bstride, spg);
+        update_role_wide<NT, CX, EV>(smem, rg, g, cx, r_in, r_out, ev, j0, b, nslices, nrg, ncg, partials, bstride, spg);
         return;
     }
 #ifdef JWAS_HIP_DEV_KNOBS
@@ -268,16 +268,16 @@ __device__ __forceinline__ void update_role(char* smem, int rg, int g,
     float4 wv = *reinterpret_cast<const float4*>(cx.w + row);
     // (dense priors apply a whole block of changes here: 16 column loads in flight per wave, the fmaf chain per row
     // stays in list order)
-    const int ne = ev->count;
+    const int ne = ev.count();
     // the head of the list, one entry per lane, issued with the count (not after it: the arrays are always there, what lies
     // beyond the count is never used as an address or a coefficient) -- the general apply below then needs ONE further
     // memory latency per 32 changes instead of two per 16 (a scalar index load, then the columns: with 30-40 changes per
     // 512-marker block -- BayesR, a fixed pi, the first sweeps of a chain -- that was 4-6 dependent round trips, ~12 us of a
     // 29 us launch)
-    int liv_n = ev->idx[lane];
+    int liv_n = ev.idx(lane);
     float ldv_n[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) ldv_n[t] = ev->delta[t][lane];
+    for (int t = 0; t < NT; ++t) ldv_n[t] = ev.delta(t, lane);
     // ---- COOPERATIVE DENSE APPLY.  With a dense prior every launch applies a whole block of changes (ne ~ b), and every
     // column group of a row group re-reading the same ne columns makes the update role the bottleneck of the launch (8 x
     // 25.6 MB at n = 50 000, b = 128).  Here the ncg workgroups of a row group SPLIT the rows of every slice: wave w of
@@ -317,9 +317,9 @@ __device__ __forceinline__ void update_role(char* smem, int rg, int g,
             int iv_n; float dv_n[NT];
             auto load_list = [&](int e0) {
                 const int el = e0 + lane, ec = el < ne ? el : ne - 1;
-                iv_n = ev->idx[ec];
+                iv_n = ev.idx(ec);
 #pragma unroll
-                for (int t = 0; t < NT; ++t) { const float d = ev->delta[t][ec]; dv_n[t] = (el < ne) ? d : 0.f; }
+                for (int t = 0; t < NT; ++t) { const float d = ev.delta(t, ec); dv_n[t] = (el < ne) ? d : 0.f; }
             };
             if (slice_map ? (wave < 4 && g < spg) : (wave * pack < spg)) {   // (wave-uniform: the other waves have no share)
             load_list(0);
@@ -387,11 +387,11 @@ __device__ __forceinline__ void update_role(char* smem, int rg, int g,
         // header path: indices and coefficients arrived with the count (one 64-byte line)
         float4 x[7];
 #pragma unroll
-        for (int u = 0; u < 7; ++u) x[u] = cx.load4(u < ne ? ev->hidx[u] : 0, row);     // (unused slots: column 0, always valid)
+        for (int u = 0; u < 7; ++u) x[u] = cx.load4(u < ne ? ev.hidx(u) : 0, row);     // (unused slots: column 0, always valid)
 #pragma unroll
         for (int u = 0; u < 7; ++u) {
             if (u < ne) {
-                const float d = ev->hdelta[u];
+                const float d = ev.hdelta(u);
                 rv[0].x = fmaf(d, x[u].x, rv[0].x); rv[0].y = fmaf(d, x[u].y, rv[0].y);
                 rv[0].z = fmaf(d, x[u].z, rv[0].z); rv[0].w = fmaf(d, x[u].w, rv[0].w);
             }
@@ -405,9 +405,9 @@ __device__ __forceinline__ void update_role(char* smem, int rg, int g,
         for (int t = 0; t < NT; ++t) ldv[t] = ldv_n[t];
         if (e0 + 64 < ne) {
             const int el = e0 + 64 + lane, ec = el < ne ? el : ne - 1;
-            liv_n = ev->idx[ec];
+            liv_n = ev.idx(ec);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) ldv_n[t] = ev->delta[t][ec];
+            for (int t = 0; t < NT; ++t) ldv_n[t] = ev.delta(t, ec);
         }
         // K columns in flight per lane (addresses from v_readlane: no scalar memory access), the fused multiply-add chain per
         // row in list order; entries past the end re-read the last valid column and are skipped

@@ -209,6 +209,7 @@ class HipEngine:
         self._chk(self._L.jwas_hip_setup_blocks(self._h, int(block_size), mode))
         self.block_size = int(block_size)
         self._resident = [int(block_size)]
+        self._groups = {}
         self._explicit_starts = None
 
     def setup_blocks_explicit(self, starts, gram_mode="mfma"):
@@ -221,6 +222,7 @@ class HipEngine:
         self._chk(self._L.jwas_hip_num_blocks(self._h, C.byref(nb), C.byref(bs)))
         self.block_size = int(bs.value)
         self._resident = [self.block_size]
+        self._groups = {}
         self._explicit_starts = st.copy()
 
     def add_block_size(self, block_size, gram_mode="mfma"):
@@ -228,6 +230,18 @@ class HipEngine:
         mode = {"f64": _lib.GRAM_F64, "mfma": _lib.GRAM_MFMA}[gram_mode]
         self._chk(self._L.jwas_hip_add_block_size(self._h, int(block_size), mode))
         self._resident.append(int(block_size))
+
+    def setup_groups(self, blocks_per_launch, gram_mode="mfma"):
+        """Grouped launches for the selected block size (jwas_hip_setup_groups): 2 or 4 consecutive blocks per launch of the step
+        kernel, used by the sweeps that pass group_launch=True; 0 frees the buffers."""
+        mode = {"f64": _lib.GRAM_F64, "mfma": _lib.GRAM_MFMA}[gram_mode]
+        self._chk(self._L.jwas_hip_setup_groups(self._h, int(blocks_per_launch), mode))
+        self._groups = dict(getattr(self, "_groups", {}))
+        self._groups[self.block_size] = int(blocks_per_launch)
+
+    def blocks_per_launch(self, block_size=None):
+        """Blocks per grouped launch set up for a block size (0: none)."""
+        return getattr(self, "_groups", {}).get(self.block_size if block_size is None else int(block_size), 0)
 
     def resident_block_sizes(self):
         """Block sizes whose Grams are resident (setup_blocks / add_block_size)."""
@@ -468,7 +482,7 @@ class HipEngine:
 
     def sweep(self, *, iteration, seed, vare, var_effect, pi=0.0, pi_classes=None, gamma=BAYESR_GAMMA,
               log_prior_states=None, var_effect_vec=None, var_effect_matrix=None, pi_vec=None, pi_matrix=None, nreps=1,
-              marker_offset=0, independent_blocks=False, section_solve=False, _sharded=False):
+              marker_offset=0, independent_blocks=False, section_solve=False, group_launch=False, _sharded=False):
         """One marker sweep.  Argument meaning follows BayesABC!/BayesR!/MTBayesABC!:
         vare: residual variance (scalar or t x t); var_effect: marker effect variance (BayesC scalar,
         BayesR sigmaSq, MT t x t); pi: Pr(effect = 0) scalar, or pi_vec per marker (length p, else the
@@ -479,6 +493,7 @@ class HipEngine:
         P.iteration, P.seed, P.marker_offset = int(iteration), int(seed), int(marker_offset)
         P.independent_blocks = 1 if independent_blocks else 0          # BayesABC_block_independent! (BayesABC.jl:190-255)
         P.section_solve = 1 if section_solve else 0                    # Rule T: dense chains as triangular solves (jwas_hip.h)
+        P.group_launch = 1 if group_launch else 0                      # grouped launches (setup_groups; jwas_hip.h)
         ve = np.asarray(vare, dtype=np.float32).reshape(-1)
         vg = np.asarray(var_effect, dtype=np.float32).reshape(-1)
         if ve.size != t * t or vg.size != t * t:

@@ -104,6 +104,28 @@ def pick_block_size(n_events, p, small=512, large=1024):
     return large if n_events < ADAPTIVE_CHANGE_FRACTION * p else small
 
 
+# Grouped launches (jwas_hip_setup_groups / jwas_sweep_params.group_launch): blocks per launch of the step kernel on the LARGE block
+# size of a single-trait chain -- the size the adaptive policy selects once few markers change per sweep, where a launch's fixed
+# cost (~3.5 us of a 32 us launch at 50 000 x 1024) is what separates the sweep from the copy rate.  0 = off.
+GROUPED_BLOCKS_PER_LAUNCH = 4
+
+
+def grouped_blocks_for_chain(chain_length):
+    """Blocks per grouped launch a chain of this length pays for: the group cross-Grams are set-up work (at 50 000 x 600 000:
+    +1.7 s for 2 blocks per launch, +5 s for 4) against 0.6 / 0.9 ms saved per sweep of the sparse steady state."""
+    return GROUPED_BLOCKS_PER_LAUNCH if chain_length >= 8000 else (2 if chain_length >= 3000 else 0)
+
+
+def grouped_launch_size(method, ntraits, row_shards, block_size, groups=GROUPED_BLOCKS_PER_LAUNCH, dense_prior=False):
+    """Block size on which grouped launches are set up (0: none): single-trait BayesA/B/C/R chains with a sparse prior on uniform
+    blocks of one GPU's markers (marker shards included, row shards not), groups * block_size <= 4096."""
+    if groups not in (2, 4) or ntraits != 1 or row_shards or dense_prior or method not in ("BayesC", "BayesB", "BayesA", "BayesR"):
+        return 0
+    if block_size < 512 or groups * block_size > 4096:
+        return 0
+    return int(block_size)
+
+
 MT_SPARSE_CHANGE_FRACTION = 0.25          # the share of markers changing per sweep below which a dense-start multi-trait chain is sparse
 
 
@@ -575,6 +597,15 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         adaptive = False
         adaptive_mt = False
 
+    # grouped launches (engine.setup_groups): the adaptive policy's 1024-marker sweeps of a single-trait chain on dense storage,
+    # when the chain is long enough to pay for the group cross-Grams; a weighted / explicitly partitioned / row-sharded run keeps
+    # one block per launch
+    group_m = 0
+    if adaptive and not stream and not double_precision and explicit_partition is None and not independent_blocks and fast_blocks is False:
+        group_m = grouped_blocks_for_chain(chain_length)
+        if not grouped_launch_size(method, t, False, 1024, group_m):
+            group_m = 0
+
     from .engine import SectionSolvePolicy
     solve_policy = SectionSolvePolicy(section_solve, 4 * (p // 256))
 
@@ -585,6 +616,8 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         need = HipEngine.estimate_bytes(n, p, t, block_size, "stream" if stream else "dense") * (2 if double_precision else 1)
         if adaptive or adaptive_mt:
             need += 2 * 4 * (1024 if adaptive else 512) * p        # the second resident block size (Grams + cross-Grams)
+        if group_m:
+            need += 4 * p * 2048 * (3 if group_m == 4 else 1)      # grouped launches: pair (and four) cross-Grams of the 1024-marker set
         if double_precision and independent_blocks:
             # Float64 independent blocks: one change list of 1024 entries per block (4 + 4 x 8 bytes per entry, whatever the
             # block size) and one partial-sum buffer per block (4 traits x row slices x block doubles)
@@ -631,6 +664,12 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         engine.setup_blocks(block_size, gram_mode)
         if adaptive or adaptive_mt:
             engine.add_block_size(1024 if adaptive else 512, gram_mode)
+    if group_m:            # grouped launches on the large block size of the adaptive policy (setup work, once)
+        if engine.blocks_per_launch(1024) != group_m:
+            cur_bs = engine.block_size
+            engine.select_block_size(1024)
+            engine.setup_groups(group_m, gram_mode)
+            engine.select_block_size(cur_bs)
     engine.init_state(mt_method if t > 1 else method, t)
 
     # ---- fixed effects
@@ -796,6 +835,8 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
                 kw.update(var_effect=Gval, pi_vec=pi)
             else:
                 kw.update(var_effect=Gval, pi=pi)
+            if group_m and engine.blocks_per_launch() >= 2:
+                kw["group_launch"] = True
             st = engine.sweep(**kw)
             solve_policy.observe(it, engine)
             t_sweep += st["sweep_ms"]

@@ -990,6 +990,122 @@ static void la_block_rhs(const la_ctx* L, int t, float* r, int64_t ld_r, int64_t
             if (dprev[k * bprev + e] != 0.0f) axpy_f32(dprev[k * bprev + e], L->X + (jprev + e) * L->ld, r + k * ld_r, L->n);
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* GROUPED LOOKAHEAD (the device's grouped launches: jwas_sweep_params.group_launch, csrc/sweep.hpp  */
+/* k_group_step).  m = 2 or 4 consecutive blocks form a group; the partial sums of ALL blocks of     */
+/* group g come from the residual that holds the exit updates of the groups <= g-2, and block s of    */
+/* the group is corrected for                                                                        */
+/*   cG  the changes of the whole group g-1,                                                          */
+/*   cW  (s odd) the changes of block s-1, the first block of its pair,                                */
+/*   cP  (m = 4, s >= 2) the changes of blocks 0 and 1 of its own group,                               */
+/* each  c[col] = fmaf(d_j, fl32(x_j'x_col), c[col])  from 0 over the changed markers j in marker       */
+/* order;  rhs = fl32(x'r) + ((cW + cG) + cP)  (absent terms +0).  Exact arithmetic: the block chain    */
+/* of BayesABC.jl:145-187 / BayesR.jl:111-193.                                                          */
+/* ------------------------------------------------------------------------------------------ */
+static int g_la_group = 1;
+void orc_set_lookahead_group(int m) { g_la_group = (m == 2 || m == 4) ? m : 1; }
+
+typedef struct { int64_t* j; float* d; int64_t n, cap; } la_list;
+static void la_list_push(la_list* l, int64_t j, float d)
+{
+    if (l->n == l->cap) { l->cap = l->cap ? 2 * l->cap : 64; l->j = (int64_t*)realloc(l->j, sizeof(int64_t) * (size_t)l->cap); l->d = (float*)realloc(l->d, sizeof(float) * (size_t)l->cap); }
+    l->j[l->n] = j; l->d[l->n] = d; ++l->n;
+}
+/* corr (zeroed here) = the chain over list entries [e0, e1) for the columns of block [j0, j0+b) */
+static void la_chain(const la_ctx* L, const la_list* ev, int64_t e0, int64_t e1, int64_t j0, int64_t b, float* corr)
+{
+    for (int64_t c = 0; c < b; ++c) corr[c] = 0.0f;
+    for (int64_t e = e0; e < e1; ++e) {
+        const float* xe = L->X + ev->j[e] * L->ld;
+        for (int64_t c = 0; c < b; ++c) {
+            const float g = dot_acc(xe, L->X + (j0 + c) * L->ld, L->n, L->acc);
+            corr[c] = fmaf(ev->d[e], g, corr[c]);
+        }
+    }
+}
+static void la_apply(const la_ctx* L, const la_list* ev, float* r)
+{
+    for (int64_t e = 0; e < ev->n; ++e) axpy_f32(ev->d[e], L->X + ev->j[e] * L->ld, r, L->n);
+}
+typedef void (*la_block_fn)(void* u, int64_t j0, int64_t b, float* rhs_b, const float* G);
+static int la_group_sweep(const la_ctx* L, int64_t p, const int64_t* block_starts, int64_t nblocks, const float* grams,
+                          float* r, const float* alpha, la_block_fn fn, void* u)
+{
+    const int m = g_la_group;
+    la_list prev = {0}, prevprev = {0};
+    const float* G = grams;
+    int64_t bmax = 0;
+    for (int64_t bi = 0; bi < nblocks; ++bi) { const int64_t b = (bi + 1 < nblocks ? block_starts[bi + 1] : p) - block_starts[bi]; if (b > bmax) bmax = b; }
+    float* srhs = (float*)malloc(sizeof(float) * (size_t)(bmax * m));
+    float* cG = (float*)malloc(sizeof(float) * (size_t)bmax), *cW = (float*)malloc(sizeof(float) * (size_t)bmax), *cP = (float*)malloc(sizeof(float) * (size_t)bmax);
+    float* a0 = (float*)malloc(sizeof(float) * (size_t)bmax);
+    for (int64_t bi0 = 0; bi0 < nblocks; bi0 += m) {
+        const int ns = (int)((nblocks - bi0) < m ? (nblocks - bi0) : m);
+        la_apply(L, &prevprev, r);                                      /* the residual now holds the groups <= g-2 */
+        prevprev.n = 0;
+        for (int s = 0; s < ns; ++s) {
+            const int64_t j0 = block_starts[bi0 + s], b = (bi0 + s + 1 < nblocks ? block_starts[bi0 + s + 1] : p) - j0;
+            for (int64_t c = 0; c < b; ++c) srhs[s * bmax + c] = dot_xr(L->X + (j0 + c) * L->ld, r, L->n, L->acc);
+        }
+        la_list cur = {0};
+        int64_t bound[5] = {0, 0, 0, 0, 0};                             /* cur entries of block s: [bound[s], bound[s+1]) */
+        for (int s = 0; s < ns; ++s) {
+            const int64_t j0 = block_starts[bi0 + s], b = (bi0 + s + 1 < nblocks ? block_starts[bi0 + s + 1] : p) - j0;
+            float* rhs_b = srhs + s * bmax;
+            la_chain(L, &prev, 0, prev.n, j0, b, cG);
+            if (s & 1) la_chain(L, &cur, bound[s - 1], bound[s], j0, b, cW); else for (int64_t c = 0; c < b; ++c) cW[c] = 0.0f;
+            if (m == 4 && s >= 2) la_chain(L, &cur, 0, bound[2], j0, b, cP); else for (int64_t c = 0; c < b; ++c) cP[c] = 0.0f;
+            for (int64_t c = 0; c < b; ++c) rhs_b[c] = rhs_b[c] + ((cW[c] + cG[c]) + cP[c]);
+            memcpy(a0, alpha + j0, sizeof(float) * (size_t)b);
+            fn(u, j0, b, rhs_b, G);
+            for (int64_t c = 0; c < b; ++c) { const float d = a0[c] - alpha[j0 + c]; if (d != 0.0f) la_list_push(&cur, j0 + c, d); }
+            bound[s + 1] = cur.n;
+            G += b * b;
+        }
+        free(prevprev.j); free(prevprev.d);
+        prevprev = prev; prev = cur;
+    }
+    la_apply(L, &prevprev, r);
+    la_apply(L, &prev, r);
+    free(prevprev.j); free(prevprev.d); free(prev.j); free(prev.d);
+    free(srhs); free(cG); free(cW); free(cP); free(a0);
+    return 0;
+}
+
+typedef struct { const float* xpx; float *alpha, *beta, *delta; float ie; const float* var_effects; const double* pi; int nreps_arg;
+                 uint64_t seed; uint32_t iter, marker0; } la_abc_user;
+static void la_abc_block(void* uu, int64_t j0, int64_t b, float* rhs_b, const float* G)
+{
+    la_abc_user* U = (la_abc_user*)uu;
+    const int nreps = U->nreps_arg > 0 ? U->nreps_arg : (int)b;
+    for (int rep = 0; rep < nreps; ++rep)
+        for (int64_t k = 0; k < b; ++k) {
+            const int64_t j = j0 + k;
+            const uint32_t mk = U->marker0 + (uint32_t)j;
+            const double u = orc_uniform(U->seed, mk, U->iter, (uint32_t)rep, 0);
+            const double z = orc_normal(U->seed, mk, U->iter, (uint32_t)rep, 0);
+            const float a = abc_update(rhs_b[k], U->xpx[j], &U->alpha[j], &U->beta[j], &U->delta[j], U->ie, U->var_effects[j], U->pi[j], u, z);
+            if (a != 0.0f) axpy_f32(a, G + k * b, rhs_b, b);
+        }
+}
+typedef struct { const float* xpx; float* alpha; int32_t* delta; float ie, sigma_sq; const double* pi; int pi_is_matrix; const double* gamma;
+                 int nreps_arg; uint64_t seed; uint32_t iter, marker0; } la_r_user;
+static void la_r_block(void* uu, int64_t j0, int64_t b, float* rhs_b, const float* G)
+{
+    la_r_user* U = (la_r_user*)uu;
+    const int nreps = U->nreps_arg > 0 ? U->nreps_arg : (int)b;
+    for (int rep = 0; rep < nreps; ++rep)
+        for (int64_t k = 0; k < b; ++k) {
+            const int64_t j = j0 + k;
+            const uint32_t mk = U->marker0 + (uint32_t)j;
+            const double u = orc_uniform(U->seed, mk, U->iter, (uint32_t)rep, 0);
+            const double z = orc_normal(U->seed, mk, U->iter, (uint32_t)rep, 0);
+            const float a = bayesr_update(rhs_b[k], U->xpx[j], &U->alpha[j], &U->delta[j], U->ie, U->sigma_sq,
+                                          U->pi_is_matrix ? U->pi + 4 * j : U->pi, U->gamma, u, z);
+            if (a != 0.0f) axpy_f32(a, G + k * b, rhs_b, b);
+        }
+}
+
 int orc_bayesabc_lookahead_sweep(const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
                                  const int64_t* block_starts, int64_t nblocks, const float* grams,
                                  float* r, float* alpha, float* beta, float* delta,
@@ -999,6 +1115,10 @@ int orc_bayesabc_lookahead_sweep(const float* X, int64_t n, int64_t p, int64_t l
     if (!abc_args_ok(n, p, ld, vare) || !blocks_ok(block_starts, nblocks, p)) return -1;
     const float ie = 1.0f / vare;
     const la_ctx L = { n, ld, X, acc };
+    if (g_la_group > 1) {
+        la_abc_user U = { xpx, alpha, beta, delta, ie, var_effects, pi, nreps_arg, seed, iter, marker0 };
+        return la_group_sweep(&L, p, block_starts, nblocks, grams, r, alpha, la_abc_block, &U);
+    }
     const float* G = grams;
     float* dprev = NULL; int64_t jprev = 0, bprev = 0;
     for (int64_t bi = 0; bi < nblocks; ++bi) {
@@ -1040,6 +1160,10 @@ int orc_bayesr_lookahead_sweep(const float* X, int64_t n, int64_t p, int64_t ld,
     if (!(sigma_sq > 0.0f)) return -2;
     const float ie = 1.0f / vare;
     const la_ctx L = { n, ld, X, acc };
+    if (g_la_group > 1) {
+        la_r_user U = { xpx, alpha, delta, ie, sigma_sq, pi, pi_is_matrix, gamma, nreps_arg, seed, iter, marker0 };
+        return la_group_sweep(&L, p, block_starts, nblocks, grams, r, alpha, la_r_block, &U);
+    }
     const float* G = grams;
     float* dprev = NULL; int64_t jprev = 0, bprev = 0;
     for (int64_t bi = 0; bi < nblocks; ++bi) {

@@ -132,6 +132,9 @@ int orc_mtbayesc_I_block_sweep(const float* X, int64_t n, int64_t p, int64_t ld,
  * residual that lacks the previous block's exit update, then corrected with the cross-Gram of the
  * previous block's changed markers (see jwas_oracle.c).  Lets the device overlap sampling of block b
  * with streaming block b+1. */
+/* Grouped lookahead (the device's grouped launches, jwas_sweep_params.group_launch): m = 2 or 4 blocks per group in the
+ * single-trait lookahead sweeps below; anything else = 1 = the one-block lookahead (default). */
+void orc_set_lookahead_group(int m);
 int orc_bayesabc_lookahead_sweep(const float* X, int64_t n, int64_t p, int64_t ld, const float* xpx,
                                  const int64_t* block_starts, int64_t nblocks, const float* grams,
                                  float* r, float* alpha, float* beta, float* delta,

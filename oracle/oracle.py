@@ -167,6 +167,11 @@ def set_section_solve(on):
     lib().orc_set_section_solve(C.c_int(1 if on else 0))
 
 
+def set_lookahead_group(m):
+    """Grouped lookahead (the device's grouped launches, group_launch): m = 2 or 4 blocks per group; 1 = the one-block lookahead."""
+    lib().orc_set_lookahead_group(C.c_int(int(m)))
+
+
 def section_solve_counts(reset=False):
     a, b = C.c_int64(0), C.c_int64(0)
     lib().orc_section_solve_counts(C.byref(a), C.byref(b), C.c_int(1 if reset else 0))

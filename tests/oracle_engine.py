@@ -57,6 +57,7 @@ class OracleEngine:
         self._bs = O.block_starts_for(self.p, self.block_size)
         self._grams = O.grams_for(self.X, self._bs, self.acc)
         self._sets = {self.block_size: (self._bs, self._grams)}
+        self._groups = {}
         O.set_weights(None)
 
     def setup_blocks_explicit(self, starts, gram_mode="f64"):
@@ -67,6 +68,7 @@ class OracleEngine:
         sizes = np.diff(np.append(self._bs, self.p))
         self.block_size = int(sizes.max())
         self._sets = {self.block_size: (self._bs, self._grams)}
+        self._groups = {}
         O.set_weights(None)
 
     def add_block_size(self, block_size, gram_mode="f64"):
@@ -165,9 +167,13 @@ class OracleEngine:
         else:
             O.set_packed_source(codes, means, centered, self.X)
 
+    def setup_groups(self, blocks_per_launch, gram_mode="f64"):
+        """jwas_hip_setup_groups: the sweeps that pass group_launch=True run the grouped lookahead (oracle: la_group_sweep)."""
+        self._groups[self.block_size] = int(blocks_per_launch)
+
     def sweep(self, *, iteration, seed, vare, var_effect, pi=0.0, pi_classes=None, gamma=O.GAMMA,
               log_prior_states=None, var_effect_vec=None, var_effect_matrix=None, pi_vec=None, pi_matrix=None, nreps=1,
-              marker_offset=0, independent_blocks=False, section_solve=False):
+              marker_offset=0, independent_blocks=False, section_solve=False, group_launch=False):
         t = self.ntraits
         blk = (dict(block_starts=self._bs, grams=self._grams, nreps=nreps, lookahead=(self.form == "lookahead"),
                     independent=bool(independent_blocks))
@@ -185,11 +191,17 @@ class OracleEngine:
             O.set_var_effect_matrix(vm)
             var_effect = np.eye(t, dtype=np.float32)  # (unused)
         O.set_section_solve(bool(section_solve) and self.form == "lookahead" and not independent_blocks)      # Rule T (the device's section_solve)
+        # grouped launches (the device's group_launch after setup_groups): single trait, one pass, uniform blocks, not a uniform pi = 0
+        grouped = (bool(group_launch) and self.form == "lookahead" and not independent_blocks and self._groups.get(self.block_size, 0) >= 2 and
+                   self.method in (BAYESC, BAYESB, BAYESR) and nreps == 1 and
+                   not (self.method in (BAYESC, BAYESB) and pi_vec is None and np.ndim(pi) == 0 and float(pi) == 0.0))
+        O.set_lookahead_group(self._groups[self.block_size] if grouped else 1)
         try:
             self._sweep_inner(t, blk, iteration, seed, vare, var_effect, pi, pi_classes, gamma, log_prior_states,
                               var_effect_vec, pi_vec, pi_matrix, marker_offset)
         finally:
             O.set_section_solve(False)
+            O.set_lookahead_group(1)
             O.set_weights(None)
             O.set_var_effect_matrix(None)
         return self._stats(a_before, gamma)
