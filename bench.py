@@ -269,6 +269,8 @@ def main():
         eng.select_block_size(group_bs)
         eng.setup_groups(groups, "mfma")
         eng.select_block_size(cur)
+    if os.environ.get("JWAS_BENCH_GROUPS_SMALL") and adaptive and a.storage == "dense":      # (experiments: grouped launches on the 512-marker set too)
+        eng.setup_groups(int(os.environ["JWAS_BENCH_GROUPS_SMALL"]), "mfma")
     log('setup_blocks done')
     eng.init_state("MTBayesB" if mt_pervar else method, t)
     if not rows_mode:

@@ -382,18 +382,20 @@ static int alloc_storage(jwas_hip_ctx* c, int64_t n, int64_t p, bool packed = fa
     {
         const char* e_spg = std::getenv("JWAS_HIP_SPG");                 // (experiments)
         const char* e_cap = std::getenv("JWAS_HIP_MAX_NCG");
+        const char* e_bud = std::getenv("JWAS_HIP_WG_BUDGET");           // (experiments) streaming workgroups per launch: 224 of the 256 CUs
+        const int budget = e_bud ? std::max(8, std::min(255, std::atoi(e_bud))) : 224;
         int best_spg = kRowGroupSlices, best_ncg = 1, best_nrg = (usl + kRowGroupSlices - 1) / kRowGroupSlices;
         long best_waves = -1, best_wgs = -1;
         for (int spg = kRowGroupSlices; spg >= 4; --spg) {
             if (e_spg && spg != std::max(1, std::min(kRowGroupSlices, std::atoi(e_spg)))) continue;
             const int nrg = (usl + spg - 1) / spg;
-            int ncg = 224 / nrg; if (ncg < 1) ncg = 1;
+            int ncg = budget / nrg; if (ncg < 1) ncg = 1;
             const int cap = e_cap ? std::atoi(e_cap) : (nrg < 8 ? 32 : 16);
             if (ncg > cap) ncg = cap;
             const long waves = (long)usl * ncg, wgs = (long)nrg * ncg;
             // (ties are only broken for tall matrices, where the launch is bound by the update role; shorter ones are
             // bound by the sampler and measured neutral to slightly worse with 6-7 slices per group)
-            if (waves > best_waves || (waves == best_waves && wgs > best_wgs && wgs <= 224 && usl >= 128)) {
+            if (waves > best_waves || (waves == best_waves && wgs > best_wgs && wgs <= budget && usl >= 128)) {
                 best_waves = waves; best_wgs = wgs; best_spg = spg; best_ncg = ncg; best_nrg = nrg;
             }
         }

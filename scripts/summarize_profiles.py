@@ -20,6 +20,11 @@ def find(sub, pat):
     return hits[0] if hits else None
 
 
+def is_step(name):
+    """The step kernel: k_block_step (one block per launch) or k_group_step (grouped launches)."""
+    return "k_block_step" in name or "k_group_step" in name
+
+
 def short(name):
     return name.split("(")[0].replace("void ", "")
 
@@ -36,7 +41,7 @@ if kt:
         if "k_prepare" in name:
             cur = []
             sweeps.append(cur)
-        elif "k_block_step" in name and cur is not None:
+        elif is_step(name) and cur is not None:
             cur.append(e - s)
     allk = [d for sw in sweeps for d in sw]
     timed = [d for sw in sweeps[-timed_steps:] for d in sw]
@@ -45,6 +50,8 @@ if kt:
            "avg_ns_timed_region": sum(timed) / max(1, len(timed))}
     try:
         b = json.loads(open(os.path.join(root, "bench_under_rocprof.json")).read().strip().splitlines()[-1])
+        out["kernel"] = b["roofline"].get("kernel", "k_block_step")
+        out["blocks_per_launch"] = b["config"].get("blocks_per_launch", 1)
         out["bench_avg_launch_us_same_run"] = b["roofline"]["avg_launch_us"]
         out["bench_value_same_run"] = b["value"]
     except Exception as ex:                                     # noqa: BLE001
@@ -75,14 +82,14 @@ for tag, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         if "k_prepare" in name:
             cur = []
             sweeps.append(cur)
-        elif "k_block_step" in name and cur is not None:
+        elif is_step(name) and cur is not None:
             cur.append(v)
     last = [v for sw in sweeps[-pmc_steps:] for v in sw]
     with open(os.path.join(root, f"pmc_{tag}_summary.csv"), "w") as fh:
         fh.write(f"kernel,dispatches,{counter}_sum_KB,{counter}_per_dispatch_KB\n")
         for k, (n, v) in sorted(tot.items(), key=lambda kv: -kv[1][1]):
             fh.write(f"\"{k}\",{n},{v:.1f},{v / n:.2f}\n")
-        fh.write(f"\"k_block_step: last {pmc_steps} sweeps (steady state)\",{len(last)},{sum(last):.1f},{sum(last) / max(1, len(last)):.2f}\n")
+        fh.write(f"\"step kernel: last {pmc_steps} sweeps (steady state)\",{len(last)},{sum(last):.1f},{sum(last) / max(1, len(last)):.2f}\n")
     print(tag, "steady-state per dispatch KB:", sum(last) / max(1, len(last)), "dispatches", len(last))
     traffic[tag] = sum(last) / max(1, len(last))
 
@@ -93,7 +100,8 @@ if "fetch" in traffic and "write" in traffic:
         b = json.loads(open(os.path.join(root, "bench_under_pmc_fetch.json")).read().strip().splitlines()[-1])
         cfg = b["config"]
         row = {"config": {"workload": cfg["name"], "n": cfg["n"], "p": cfg["p"], "block_size": cfg["block_size"], "storage": cfg["storage"],
-                          "n_gpus": b["n_gpus"], "pi_fixed": (0.95 if "pifixed" in wname else None), "variant": cfg.get("variant")},
+                          "n_gpus": b["n_gpus"], "pi_fixed": (0.95 if "pifixed" in wname else None), "variant": cfg.get("variant"),
+                          **({"blocks_per_launch": cfg["blocks_per_launch"]} if cfg.get("blocks_per_launch", 1) >= 2 else {})},
                "bytes_per_launch": (traffic["fetch"] * 2 + traffic["write"]) * 1024.0,
                "fetch_KB_per_launch": traffic["fetch"], "write_KB_per_launch": traffic["write"],
                "algorithmic_bytes_per_launch": b["roofline"]["bytes_per_launch"],
