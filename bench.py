@@ -552,7 +552,8 @@ def via_api(eng, y, n, p, a, nsteps):
     folder = tempfile.mkdtemp(prefix="jwas_bench_")
     try:
         out = J.runMCMC(model, ph, chain_length=warm + nsteps, burnin=warm, seed=a.seed, outputEBV=False,
-                        output_samples_frequency=warm + nsteps + 1, output_folder=os.path.join(folder, "results"), printout_model_info=False)
+                        output_samples_frequency=warm + nsteps + 1, output_folder=os.path.join(folder, "results"), printout_model_info=False,
+                        blocks_per_launch=eng.blocks_per_launch(1024))      # (the chain-length rule would pick 0 for this short run)
     finally:
         shutil.rmtree(folder, ignore_errors=True)
     ts = out["_timing"]["iteration_end_s"]

@@ -374,7 +374,7 @@ def runMCMC(model, df, *, heterogeneous_residuals=False, chain_length=100, start
             memory_guard="error", memory_guard_ratio=0.80, output_folder="results",
             output_samples_for_all_parameters=False,
             # device options (the analogue of storage=:stream's opt-in knobs)
-            device=0, block_size=None, gram_mode="mfma", _engine=None):
+            device=0, block_size=None, gram_mode="mfma", blocks_per_launch=None, _engine=None):
     """JWAS.jl:161-511.  Returns the reference's output Dict (output.jl:108-212) as a dict of pandas
     DataFrames and writes the same text files under `output_folder`.
 
@@ -426,5 +426,5 @@ def runMCMC(model, df, *, heterogeneous_residuals=False, chain_length=100, start
                      output_folder=output_folder, printout_frequency=printout_frequency,
                      memory_guard=memory_guard, memory_guard_ratio=memory_guard_ratio,
                      missing_phenotypes=missing_phenotypes, device=device, block_size=block_size,
-                     gram_mode=gram_mode, engine=_engine, printout_model_info=printout_model_info,
+                     gram_mode=gram_mode, blocks_per_launch=blocks_per_launch, engine=_engine, printout_model_info=printout_model_info,
                      output_samples_for_all_parameters=output_samples_for_all_parameters)

@@ -200,7 +200,7 @@ def _gibbs(A, x, b, rng, vare=None):
 def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed, starting_value,
               fast_blocks, independent_blocks=False, heterogeneous_residuals=False, outputEBV, output_heritability=True, output_folder, printout_frequency, memory_guard, memory_guard_ratio,
               missing_phenotypes, device, block_size, gram_mode, engine, printout_model_info,
-              output_samples_for_all_parameters, double_precision=False):
+              output_samples_for_all_parameters, double_precision=False, blocks_per_launch=None):
     import pandas as pd
     Mi = model.M[0]
     t = model.nModels
@@ -602,7 +602,8 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
     # one block per launch
     group_m = 0
     if adaptive and not stream and not double_precision and explicit_partition is None and not independent_blocks and fast_blocks is False:
-        group_m = grouped_blocks_for_chain(chain_length)
+        # (blocks_per_launch: None = by the chain's length; 0 / 2 / 4 = the caller's choice -- a device option like block_size)
+        group_m = grouped_blocks_for_chain(chain_length) if blocks_per_launch is None else int(blocks_per_launch)
         if not grouped_launch_size(method, t, False, 1024, group_m):
             group_m = 0
 

@@ -234,13 +234,16 @@ def test_full_size_config2_invariants():
     assert xpx.min() > 0 and np.isfinite(xpx).all()
     varg = np.float32(1.0 / (0.05 * float(xpx.astype(np.float64).sum()) / n))
     res = {}
-    for tag, bs in (("a", 512), ("b", 1024), ("c", 512)):
+    # ("d" .. "f": GROUPED LAUNCHES on the 1024-marker blocks -- 4 blocks per launch, twice, then 2: jwas_hip_setup_groups)
+    for tag, bs, m in (("a", 512, 0), ("b", 1024, 0), ("c", 512, 0), ("d", 1024, 4), ("e", 1024, 4), ("f", 1024, 2)):
         e.select_block_size(bs)
+        if m and e.blocks_per_launch() != m:
+            e.setup_groups(m, "mfma")
         e.set_state(alpha=np.zeros(p), beta=np.zeros(p), delta=np.ones(p))
         e.set_residual(y)
         pi = 0.95
         for it in range(1, 7):
-            st = e.sweep(iteration=it, seed=2026, vare=np.float32(1.0), var_effect=varg, pi=pi)
+            st = e.sweep(iteration=it, seed=2026, vare=np.float32(1.0), var_effect=varg, pi=pi, group_launch=bool(m))
             pi = float(1 - (st["sum_delta"][0] + 1) / (p + 2))
         a, b, dlt = e.get_state()
         r = e.get_residual()
@@ -271,6 +274,12 @@ def test_full_size_config2_invariants():
     assert (res["a"][1] == res["b"][1]).mean() > 0.998                                          # block-size invariant draws (the chains differ only by the fp32 rounding of the two Gram layouts, amplified over 6 cold-start sweeps)
     both = (res["a"][1] != 0) & (res["b"][1] != 0)
     assert np.abs(res["a"][0][both] - res["b"][0][both]).max() < 5e-3
+    # grouped launches: bit-reproducible, and the plain 1024-marker chain up to the rounding of the regrouped right-hand sides
+    assert np.array_equal(res["d"][0], res["e"][0]) and np.array_equal(res["d"][2], res["e"][2])
+    for tag in ("d", "f"):
+        assert (res[tag][1] == res["b"][1]).mean() > 0.998
+        bothg = (res[tag][1] != 0) & (res["b"][1] != 0)
+        assert np.abs(res[tag][0][bothg] - res["b"][0][bothg]).max() < 5e-3
     # the simulated QTL with large effects are found
     big = idx[np.abs(a_true[idx]) > 1.5]
     assert (res["a"][1][big] != 0).mean() > 0.5
@@ -317,23 +326,27 @@ print("NCCL_ONE_RANK_OK")
     assert out.returncode == 0 and "NCCL_ONE_RANK_OK" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
 
 
-def test_library_sharded_sweep_single_rank():
+@pytest.mark.parametrize("groups", [0, 2])
+def test_library_sharded_sweep_single_rank(groups):
     """jwas_hip_comm_init / jwas_hip_sweep_sharded through the C ABI with a one-rank RCCL communicator: the on-device
     reconcile (pack kernel, ncclAllReduce, apply kernel) must reproduce the plain sweep up to the fp32 rounding of
-    snapshot + (local - snapshot), with identical statistics."""
+    snapshot + (local - snapshot), with identical statistics.  groups = 2: both sides with grouped launches (the shard's own
+    sweep is the same launch sequence, jwas_sweep_params.group_launch)."""
     import jwas_jl_amd as J
     d = make_dataset(n=700, p=900, ncausal=6, seed=18)
     r0 = (d["y"] - d["y"].mean()).astype(np.float32)
     outs = []
     for sharded in (False, True):
         e = J.HipEngine(0)
-        e.load_dense(d["X"]); e.setup_blocks(256, "f64"); e.init_state("BayesC")
+        e.load_dense(d["X"]); e.setup_blocks(256 if not groups else 128, "f64"); e.init_state("BayesC")
+        if groups:
+            e.setup_groups(groups, "f64")
         e.set_residual(r0)
         if sharded:
             e.comm_init(J.HipEngine.comm_unique_id(), 0, 1)
         for it in range(1, 5):
             fn = e.sweep_sharded if sharded else e.sweep
-            st = fn(iteration=it, seed=3, vare=np.float32(0.5), var_effect=np.float32(0.004), pi=0.9)
+            st = fn(iteration=it, seed=3, vare=np.float32(0.5), var_effect=np.float32(0.004), pi=0.9, group_launch=bool(groups))
         outs.append((e.get_state()[0], e.get_residual(), st))
         e.close()
     (a0, r0_, s0), (a1, r1_, s1) = outs
