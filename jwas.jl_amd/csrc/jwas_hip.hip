@@ -890,8 +890,8 @@ int jwas_hip_setup_groups(jwas_hip_ctx* c, int32_t m, int32_t gram_mode)
                 if (gram_mode == JWAS_HIP_GRAM_F64)
                     hipLaunchKernelGGL((k_cross_f64<CX>), dim3(gb, (unsigned)nlaunch), dim3(256), 0, c->stream, Xc, c->p, gb, B.gcross[lvl], (const int64_t*)nullptr, odd_only ? 1 : 0);
                 else {
-                    const int nt = gb / 64;
-                    hipLaunchKernelGGL((k_gram_mfma<CX>), dim3(nt * nt, (unsigned)nlaunch), dim3(256), 0, c->stream, Xc, c->p, gb, B.gcross[lvl], odd_only ? 2 : 1, (const int64_t*)nullptr);
+                    const int nt = gb / 128;
+                    hipLaunchKernelGGL((k_cross_mfma128<CX>), dim3(nt * nt, (unsigned)nlaunch), dim3(256), 0, c->stream, Xc, c->p, gb, B.gcross[lvl], odd_only ? 2 : 1);
                 }
                 return 0;
             });

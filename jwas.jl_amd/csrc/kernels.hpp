@@ -1042,6 +1042,113 @@ __global__ __launch_bounds__(256) void k_gram_mfma(CX cx, int64_t p, int bsize,
     }
 }
 
+// The cross-Grams of grouped launches (sweep.hpp k_group_step: bsize = 2 or 4 marker blocks, 2048 / 4096 markers): the same
+// contraction as k_gram_mfma's cross mode -- same K order, same fp32 chunks folded into fp64, so the same numbers -- on 128 x 128
+// output tiles: each wave owns a 64 x 64 quarter (2 x 2 MFMA tiles), every LDS fragment feeds two MFMAs and every global load
+// half as many tiles' worth of re-reads (a 4096-marker group is 1024 tiles instead of 4096).  cross = 1: blocks 1, 2, ...;
+// cross = 2: the odd blocks only.  Uniform partitions, bsize a multiple of 128.
+template <class CX>
+__global__ __launch_bounds__(256) void k_cross_mfma128(CX cx, int64_t p, int bsize, float* __restrict__ gram, int cross)
+{
+    const int64_t ld = cx.ld;
+    __shared__ __attribute__((aligned(16))) float As[128 * kGramLd];
+    __shared__ __attribute__((aligned(16))) float Bs[128 * kGramLd];
+    const int64_t blk = cross == 2 ? 2 * (int64_t)blockIdx.y + 1 : (int64_t)blockIdx.y + 1;
+    const int64_t j0 = blk * bsize;                                  // block of the B operand (columns of the output)
+    const int b = (int)((j0 + bsize <= p) ? bsize : (p - j0));
+    const int64_t jA = j0 - bsize;                                   // block of the A operand (rows of the output): always full
+    const int bA = bsize;
+    const int nt = bsize / 128;
+    const int ti = blockIdx.x / nt, tj = blockIdx.x % nt;
+    if (tj * 128 >= b) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;                         // wave's 64 x 64 quarter
+    float* G = gram + blk * (int64_t)bsize * bsize;
+
+    // staging: thread -> (marker m = tid/8 + 32 u, float4 q = tid%8), u = 0..3
+    const int sm = tid >> 3, sq = tid & 7;
+    int64_t ja[4], jb[4];
+    bool okb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        ja[u] = jA + ti * 128 + sm + 32 * u;
+        const int mb = tj * 128 + sm + 32 * u;
+        okb[u] = mb < b;
+        jb[u] = j0 + (okb[u] ? mb : 0);
+    }
+    f32x16 acc[2][2];
+    double accd[2][2][16];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { acc[x][y][i] = 0.f; accd[x][y][i] = 0.0; }
+    const int am = lane & 31, ah = lane >> 5;
+    const float* a_rd = As + (wm * 64 + am) * kGramLd + 4 * ah;
+    const float* b_rd = Bs + (wn * 64 + am) * kGramLd + 4 * ah;
+    const float4 zero4{0.f, 0.f, 0.f, 0.f};
+    int chunk_rows = 0;
+    for (int64_t k0 = 0; k0 < ld; k0 += kGramKT) {
+        float4 va[4], vb[4];
+        const float4 wv = *reinterpret_cast<const float4*>(cx.w + k0 + sq * 4);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) va[u] = cx.load4(ja[u], k0 + sq * 4);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            vb[u] = cx.load4(jb[u], k0 + sq * 4);
+            if (!okb[u]) vb[u] = zero4;
+            vb[u].x *= wv.x; vb[u].y *= wv.y; vb[u].z *= wv.z; vb[u].w *= wv.w;       // the B operand carries R^-1
+        }
+        __syncthreads();      // previous tile fully consumed
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            *reinterpret_cast<float4*>(&As[(sm + 32 * u) * kGramLd + sq * 4]) = va[u];
+            *reinterpret_cast<float4*>(&Bs[(sm + 32 * u) * kGramLd + sq * 4]) = vb[u];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < kGramKT / 8; ++q) {
+            const float4 fa0 = *reinterpret_cast<const float4*>(a_rd + 8 * q);
+            const float4 fa1 = *reinterpret_cast<const float4*>(a_rd + 32 * kGramLd + 8 * q);
+            const float4 fb0 = *reinterpret_cast<const float4*>(b_rd + 8 * q);
+            const float4 fb1 = *reinterpret_cast<const float4*>(b_rd + 32 * kGramLd + 8 * q);
+#define JW_MFMA4(A_, B_, ACC_)                                                      \
+            ACC_ = __builtin_amdgcn_mfma_f32_32x32x2f32(A_.x, B_.x, ACC_, 0, 0, 0); \
+            ACC_ = __builtin_amdgcn_mfma_f32_32x32x2f32(A_.y, B_.y, ACC_, 0, 0, 0); \
+            ACC_ = __builtin_amdgcn_mfma_f32_32x32x2f32(A_.z, B_.z, ACC_, 0, 0, 0); \
+            ACC_ = __builtin_amdgcn_mfma_f32_32x32x2f32(A_.w, B_.w, ACC_, 0, 0, 0);
+            JW_MFMA4(fa0, fb0, acc[0][0])
+            JW_MFMA4(fa0, fb1, acc[0][1])
+            JW_MFMA4(fa1, fb0, acc[1][0])
+            JW_MFMA4(fa1, fb1, acc[1][1])
+#undef JW_MFMA4
+        }
+        chunk_rows += kGramKT;
+        if (chunk_rows >= kGramChunk) {
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { accd[x][y][i] += (double)acc[x][y][i]; acc[x][y][i] = 0.f; }
+            chunk_rows = 0;
+        }
+    }
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const double v = accd[x][y][i] + (double)acc[x][y][i];
+                const int rr = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                const int ga = ti * 128 + wm * 64 + 32 * x + rr;
+                const int gc = tj * 128 + wn * 64 + 32 * y + (lane & 31);
+                if (ga < bA && gc < b) G[(int64_t)ga * b + gc] = (float)v;
+            }
+}
+
 // ---------------------------------------------------------------------------------------------
 // X * alpha (EBV, output.jl:302) and r -= X*alpha0 (MCMC_BayesianAlphabet.jl:142)
 // grid = nslices, block = 256: one row per thread, columns in marker order.

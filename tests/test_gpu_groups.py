@@ -203,3 +203,30 @@ def test_random_grouped_launches_against_the_oracle(hip, seed):
     np.testing.assert_allclose(ah, ao, rtol=0, atol=1e-5, err_msg=str(cfg))
     np.testing.assert_allclose(hip.get_residual(0), orc.get_residual(0), rtol=0, atol=5e-5, err_msg=str(cfg))
     hip.set_weights(None)
+
+
+@pytest.mark.parametrize("bs,m", [(64, 2), (64, 4), (256, 4), (512, 2), (1024, 4)])
+def test_group_cross_grams_mfma_against_f64(hip, bs, m):
+    """The pair / four cross-Grams from the MFMA kernel (k_cross_mfma128: fp32 products, fp32 chunks folded into fp64) against the
+    exact fp64-accumulated ones (k_cross_f64): the same grouped chain -- every correction the chain takes from them agrees to
+    float32 rounding, so trajectories and effects do (ragged last group, a last group of fewer blocks)."""
+    data = make_dataset(n=900, p=bs * (2 * m + 1) + bs // 2 + 3, ncausal=12, seed=bs + m)
+    kw = _kw("BayesC", data, 0.7)                       # (many changes per sweep: every cross-Gram block is exercised)
+    res = {}
+    for mode in ("f64", "mfma"):
+        hip.load_dense(data["X"])
+        hip.setup_blocks(bs, "f64")
+        hip.setup_groups(m, mode)
+        hip.init_state("BayesC")
+        hip.set_residual(data["y"] - data["y"].mean())
+        ev = 0
+        for it in range(1, 9):
+            ev += int(hip.sweep(iteration=it, seed=5, group_launch=True, **kw)["n_events"])
+        res[mode] = (hip.get_state(0), hip.get_residual(0), ev)
+    (a0, _, d0), r0, ev0 = res["f64"]
+    (a1, _, d1), r1, _ = res["mfma"]
+    assert ev0 > 8 * 0.1 * data["X"].shape[1]
+    assert (d0 == d1).mean() >= 0.999
+    same = d0 == d1
+    assert np.abs(a0[same] - a1[same]).max() <= 1e-4 * max(np.abs(a0).max(), 1e-3)
+    assert np.abs(r0 - r1).max() <= 2e-3 * np.abs(r0).max()
