@@ -633,14 +633,15 @@ class _Dummy:
         self.n, self.p, self.block_size, self._weighted = n, p, 64, False
 
 
-@pytest.mark.parametrize("method,nranks", [("BayesC", 2), ("BayesR", 3), ("BayesC", 4)])
-def test_library_sharded_sweep_with_several_ranks_over_the_loopback_transport(method, nranks):
+@pytest.mark.parametrize("method,nranks,groups", [("BayesC", 2, 0), ("BayesR", 3, 0), ("BayesC", 4, 0), ("BayesC", 2, 2), ("BayesR", 2, 4)])
+def test_library_sharded_sweep_with_several_ranks_over_the_loopback_transport(method, nranks, groups):
     """jwas_hip_sweep_sharded with MORE THAN ONE rank: marker shards, one context per rank (here engines of one process on
     different host threads; the all-reduce goes through the loopback transport, the same call site RCCL uses).  Per sweep
     every rank sweeps its own markers from the same residual snapshot, packs (fl64(r_local) - fl64(r_snapshot), its marker
     statistics), ONE all-reduce, r = fl32(r_snapshot + sum): the reference's independent-block reconcile (BayesABC.jl:205-253)
     with one block per rank.  Against a single-process emulation on the oracle: the reconciled residual is the same on every
-    rank bit for bit, the shards' chains equal the oracle's (indicators exactly), the statistics are the all-rank sums."""
+    rank bit for bit, the shards' chains equal the oracle's (indicators exactly), the statistics are the all-rank sums.
+    groups > 0: every rank's sweep with grouped launches (jwas_hip_setup_groups on each shard, jwas_sweep_params.group_launch)."""
     import threading
     import jwas_jl_amd as J
     from jwas_jl_amd.dist import shard_range
@@ -659,6 +660,8 @@ def test_library_sharded_sweep_with_several_ranks_over_the_loopback_transport(me
     for lo, hi in shards:
         o = OracleEngine("lookahead")
         o.load_dense(np.asfortranarray(X[:, lo:hi])); o.setup_blocks(bs); o.init_state(method, 1)
+        if groups:
+            o.setup_groups(groups)
         if method == "BayesR":
             o.set_state(0, delta=np.ones(hi - lo, dtype=np.int32))
         orcs.append(o)
@@ -670,7 +673,7 @@ def test_library_sharded_sweep_with_several_ranks_over_the_loopback_transport(me
         nev, sd = 0.0, 0.0
         for o, (lo, hi) in zip(orcs, shards):
             o.set_residual(snap)
-            st = o.sweep(iteration=it, seed=31, marker_offset=lo, **kw)
+            st = o.sweep(iteration=it, seed=31, marker_offset=lo, group_launch=bool(groups), **kw)
             tot += o.get_residual().astype(np.float64) - snap.astype(np.float64)
             nev += st["n_events"]; sd += st["sum_delta"][0] if method != "BayesR" else st["class_counts"][1:].sum()
         r = (snap.astype(np.float64) + tot).astype(np.float32)
@@ -686,10 +689,12 @@ def test_library_sharded_sweep_with_several_ranks_over_the_loopback_transport(me
             e.comm_init_loopback(2, rank, nranks)
             assert e.comm_info() == (rank, nranks)
             e.setup_blocks(bs, "f64"); e.init_state(method, 1)
+            if groups:
+                e.setup_groups(groups, "f64")
             if method == "BayesR":
                 e.set_state(0, delta=np.ones(hi - lo, dtype=np.int32))
             e.set_residual(y)
-            sts = [e.sweep_sharded(iteration=it, seed=31, marker_offset=lo, **kw) for it in range(1, nsweeps + 1)]
+            sts = [e.sweep_sharded(iteration=it, seed=31, marker_offset=lo, group_launch=bool(groups), **kw) for it in range(1, nsweeps + 1)]
             out[rank] = (e.get_state(0), e.get_residual(0), sts)
             e.close()
         except Exception as ex:                          # noqa: BLE001
