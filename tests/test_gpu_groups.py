@@ -230,3 +230,20 @@ def test_group_cross_grams_mfma_against_f64(hip, bs, m):
     same = d0 == d1
     assert np.abs(a0[same] - a1[same]).max() <= 1e-4 * max(np.abs(a0).max(), 1e-3)
     assert np.abs(r0 - r1).max() <= 2e-3 * np.abs(r0).max()
+
+
+def test_setup_groups_contract_errors(hip):
+    """jwas_hip_setup_groups: what it refuses (the error strings are the library's), and that 0 frees the groups again."""
+    data = make_dataset(n=300, p=400, ncausal=4, seed=1)
+    hip.load_dense(data["X"])
+    hip.setup_blocks(64, "f64")
+    with pytest.raises(RuntimeError, match="must be 0 .off., 2 or 4"):
+        hip.setup_groups(3, "f64")
+    hip.setup_groups(2, "f64")
+    assert hip.blocks_per_launch() == 2
+    hip.setup_groups(0, "f64")
+    assert hip.blocks_per_launch() == 0
+    hip.setup_blocks_explicit(np.array([0, 50, 130, 300]), "f64")
+    with pytest.raises(RuntimeError, match="uniform blocks"):
+        hip.setup_groups(2, "f64")
+    hip.setup_blocks(64, "f64")                       # (leave the shared engine on a uniform partition)
