@@ -263,7 +263,9 @@ def main():
     # packed / explicitly sized run): mcmc.run_chain's policy
     from jwas_jl_amd.mcmc import GROUPED_BLOCKS_PER_LAUNCH, grouped_launch_size
     groups = GROUPED_BLOCKS_PER_LAUNCH if a.groups < 0 else a.groups
-    group_bs = 0 if a.storage != "dense" else grouped_launch_size(method, t, rows_mode, (1024 if adaptive else bs), groups, dense_prior=dense_prior)
+    if os.environ.get("JWAS_BENCH_FORCE_PACKED_GROUPS") and a.storage != "dense":      # (experiments: grouped launches on packed storage)
+        groups = int(os.environ["JWAS_BENCH_FORCE_PACKED_GROUPS"])
+    group_bs = 0 if (a.storage != "dense" and not os.environ.get("JWAS_BENCH_FORCE_PACKED_GROUPS")) else grouped_launch_size(method, t, rows_mode, (1024 if adaptive else bs), groups, dense_prior=dense_prior)
     if group_bs:
         cur = eng.block_size
         eng.select_block_size(group_bs)

@@ -109,6 +109,11 @@ hip_set_residual!(b::HipBackend, trait::Integer, r::Vector{Float32}) =
 hip_get_residual!(b::HipBackend, trait::Integer, r::Vector{Float32}) =
     hip_check(b.ctx, ccall((:jwas_hip_get_residual, LIBJWAS_HIP), Cint, (Ptr{Cvoid}, Int32, Ptr{Float32}), b.ctx, trait, r))
 
+"Grouped launches for the selected block size: 2 or 4 consecutive blocks per launch of the step kernel (0 frees the buffers); the sweeps
+whose HipSweepParams carry group_launch = 1 then use them.  Worth its set-up time from a few thousand iterations on (INTEGRATION.md)."
+hip_setup_groups!(b::HipBackend, blocks_per_launch::Integer) =
+    hip_check(b.ctx, ccall((:jwas_hip_setup_groups, LIBJWAS_HIP), Cint, (Ptr{Cvoid}, Int32, Int32), b.ctx, blocks_per_launch, JWAS_HIP_GRAM_MFMA))
+
 "Float64 context (runMCMC(double_precision=true), JWAS.jl:349-366): call before loading genotypes; the data entry points are then
 jwas_hip_load_dense_f64 / _set_state_f64 / _get_state_f64 / _set_residual_f64 / _get_residual_f64 / _get_posterior_f64 (Ptr{Float64})."
 hip_set_precision!(ctx::Ptr{Cvoid}, bits::Integer) =
@@ -125,14 +130,14 @@ function HipSweepParams(method::Integer, iter::Integer, seed::Integer; vare::Rea
                         pi_classes=(0.0, 0.0, 0.0, 0.0), gamma=(0.0, 0.01, 0.1, 1.0), nreps::Integer=1,
                         marker_offset::Integer=0, independent_blocks::Bool=false,
                         pi_vec::Ptr{Float64}=Ptr{Float64}(C_NULL), pi_matrix::Ptr{Float64}=Ptr{Float64}(C_NULL),
-                        var_effect_vec::Ptr{Float32}=Ptr{Float32}(C_NULL), section_solve::Bool=false)
+                        var_effect_vec::Ptr{Float32}=Ptr{Float32}(C_NULL), section_solve::Bool=false, group_launch::Bool=false)
     HipSweepParams(Int32(method), Int32(1), Int32(nreps), UInt32(iter), UInt64(seed), UInt32(marker_offset),
                    UInt32(independent_blocks), Base.setindex(_z16(Float32), Float32(vare), 1),
                    Base.setindex(_z16(Float32), Float32(var_effect), 1), Float64(pi), NTuple{4,Float64}(pi_classes),
                    NTuple{4,Float64}(gamma), _z16(Float64), var_effect_vec, pi_vec, pi_matrix, Ptr{Float64}(C_NULL),
                    Ptr{Float32}(C_NULL), Base.setindex(_z16(Float64), Float64(vare), 1),
                    Base.setindex(_z16(Float64), Float64(var_effect), 1), Ptr{Float64}(C_NULL),      # (the Float64 context's copies)
-                   Int32(section_solve), Int32(0))                                                   # Rule T (multi-trait sampler I, dense prior)
+                   Int32(section_solve), Int32(group_launch))                                        # Rule T (multi-trait sampler I, dense prior); grouped launches
 end
 
 "One marker sweep = one call of BayesABC! / BayesR! / MTBayesABC! (BayesABC.jl:60-80, BayesR.jl:45-97, MTBayesABC.jl:57-127)."

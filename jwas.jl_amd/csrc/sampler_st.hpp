@@ -601,6 +601,10 @@ __device__ __forceinline__ int sampler_role_st(char* smem, const SamplerArgs& A,
     // take their place in LDS, so the correction is a chain of LDS reads -- no global access after the walk.  (Left to the
     // log-consuming helper waves it was 21 k cycles of L2 / HBM round trips per block behind the walk.)
     constexpr int kXR = 19, kXL = kStepThreads - 64;
+    // (1024-marker blocks: from ONE candidate on -- the speculative rounds walk every 64-marker sub-block behind the first candidate,
+    // ~8 rounds of ~1.1 k cycles per block in a sparse steady state; 2-bit packed config 2 10.74 -> 10.26 ms per sweep, NOTES R5.
+    // JWAS_HIP_COMPACT_OFF = 256 n: experiments -- the chain from n candidates on)
+    const int cmin = (A.compact_off >> 8) ? (A.compact_off >> 8) : (B == 1024 ? 1 : kCompactMin);
     const bool xreg_geom = !DENSE && single_pass_st && !prestage && !(A.compact_off & 1) &&
                            (A.b_next == B) && (b == B) && (B == 256 || B == 512 || B == 1024);
     const int xsh = (B == 1024) ? 8 : (B == 512 ? 7 : 6);
@@ -611,7 +615,7 @@ __device__ __forceinline__ int sampler_role_st(char* smem, const SamplerArgs& A,
     int nstaged = prestage ? b : 0;
     if (!prestage && !(first_sub >= 16 && single_pass_st)) {
         nstaged = stage_assign(smem, SM, A, cand, ncand_total);
-        xreg = xreg_geom && ncand_total >= kCompactMin && ncand_total <= kCompactMax && ncand_total <= SM.max_cand;
+        xreg = xreg_geom && ncand_total >= cmin && ncand_total <= kCompactMax && ncand_total <= SM.max_cand;
         // the Gram rows' direct loads FIRST, the cross-Gram pieces behind them: the walk needs the rows, the pieces are needed
         // after it -- the wait below is for the rows only (vmcnt counts in order), the pieces arrive while wave 0 walks
         // (waiting for both cost 5.8 k cycles per block: ~190 KB through one CU's memory pipe under the stream's load)
@@ -640,7 +644,7 @@ __device__ __forceinline__ int sampler_role_st(char* smem, const SamplerArgs& A,
     float corr_cd[2] = {0.f, 0.f};
     long long tkc[3] = {0, 0, 0}, tkx[3] = {0, 0, 0};
     if constexpr (!DENSE) {
-        const bool compact_try = single_pass_st && !prestage && !(A.compact_off & 1) && ncand_total >= kCompactMin &&
+        const bool compact_try = single_pass_st && !prestage && !(A.compact_off & 1) && ncand_total >= cmin &&
                                  ncand_total <= kCompactMax && ncand_total <= SM.max_cand;
         if (compact_try) {
             int* wc = reinterpret_cast<int*>(smem + SM.wcnt_off);
