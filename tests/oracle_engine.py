@@ -171,6 +171,9 @@ class OracleEngine:
         """jwas_hip_setup_groups: the sweeps that pass group_launch=True run the grouped lookahead (oracle: la_group_sweep)."""
         self._groups[self.block_size] = int(blocks_per_launch)
 
+    def blocks_per_launch(self, block_size=None):
+        return self._groups.get(self.block_size if block_size is None else int(block_size), 0)
+
     def sweep(self, *, iteration, seed, vare, var_effect, pi=0.0, pi_classes=None, gamma=O.GAMMA,
               log_prior_states=None, var_effect_vec=None, var_effect_matrix=None, pi_vec=None, pi_matrix=None, nreps=1,
               marker_offset=0, independent_blocks=False, section_solve=False, group_launch=False):

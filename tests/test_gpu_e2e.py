@@ -22,6 +22,26 @@ def _setup(method, Pi, n=400, p=1500, seed=31):
     return gdf, ph, d
 
 
+@pytest.mark.parametrize("groups", [2, 4])
+def test_runmcmc_with_grouped_launches_matches_oracle_chain(tmp_path, groups):
+    """runMCMC(..., blocks_per_launch=...) on a problem large enough for the adaptive block policy (512-marker blocks while many
+    markers change, 1024 with grouped launches afterwards): the same host loop on the oracle engine takes the same decisions
+    (they depend on the sweeps' change counts only) and the posterior means agree."""
+    gdf, ph, d = _setup("BayesC", 0.99, n=300, p=4500, seed=77)
+    outs, used = {}, {}
+    for tag, eng in (("orc", OracleEngine("lookahead")), ("hip", None)):
+        geno = api.get_genotypes(gdf, method="BayesC", Pi=0.99)
+        model = api.build_model("y1 = intercept + geno")
+        outs[tag] = api.runMCMC(model, ph, chain_length=120, burnin=20, seed=11, output_folder=str(tmp_path / tag),
+                                _engine=eng, gram_mode="f64", blocks_per_launch=groups, outputEBV=False)
+    eo = outs["orc"]["marker effects geno"]
+    eh = outs["hip"]["marker effects geno"]
+    np.testing.assert_allclose(eh["Estimate"], eo["Estimate"], atol=1e-4)
+    np.testing.assert_allclose(eh["Model_Frequency"], eo["Model_Frequency"], atol=1e-4)
+    assert float(outs["hip"]["residual variance"]["Estimate"][0]) == pytest.approx(
+        float(outs["orc"]["residual variance"]["Estimate"][0]), rel=1e-4)
+
+
 @pytest.mark.parametrize("method,Pi", [("BayesC", 0.95), ("BayesR", 0.0), ("BayesB", 0.9)])
 def test_runmcmc_gpu_matches_oracle_chain(tmp_path, method, Pi):
     gdf, ph, d = _setup(method, Pi)

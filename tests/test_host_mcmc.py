@@ -938,3 +938,22 @@ def test_multitrait_host_policies():
     pol2 = SectionSolvePolicy(True, 1560)
     pol2.observe(1, NoCounters())
     assert pol2.use(2)
+
+
+def test_grouped_launch_policy():
+    """Host policy of grouped launches (mcmc.grouped_blocks_for_chain / grouped_launch_size): by chain length, on the large block size
+    of single-trait sparse chains only."""
+    from jwas_jl_amd import mcmc as M
+    assert M.grouped_blocks_for_chain(100) == 0 and M.grouped_blocks_for_chain(2999) == 0
+    assert M.grouped_blocks_for_chain(3000) == 2 and M.grouped_blocks_for_chain(7999) == 2
+    assert M.grouped_blocks_for_chain(8000) == M.GROUPED_BLOCKS_PER_LAUNCH == 4
+    for method in ("BayesC", "BayesB", "BayesA", "BayesR"):
+        assert M.grouped_launch_size(method, 1, False, 1024, 4) == 1024
+        assert M.grouped_launch_size(method, 1, False, 512, 4) == 512
+    assert M.grouped_launch_size("BayesC", 1, False, 1024, 0) == 0          # off
+    assert M.grouped_launch_size("BayesC", 1, False, 1024, 3) == 0          # 2 or 4
+    assert M.grouped_launch_size("BayesC", 3, False, 1024, 4) == 0          # multi-trait
+    assert M.grouped_launch_size("BayesC", 1, True, 1024, 4) == 0           # row shards
+    assert M.grouped_launch_size("BayesC", 1, False, 256, 4) == 0           # small blocks: the sampler is the critical path there
+    assert M.grouped_launch_size("BayesC", 1, False, 1024, 4, dense_prior=True) == 0
+    assert M.grouped_launch_size("MTBayesC", 1, False, 1024, 4) == 0
