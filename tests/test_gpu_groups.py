@@ -192,7 +192,10 @@ def test_random_grouped_launches_against_the_oracle(hip, seed):
         kw = dict(vare=v, var_effect=g, var_effect_vec=rng.uniform(0.005, 0.04, p).astype(np.float32), pi=sp)
     else:
         kw = dict(vare=v, var_effect=np.float32(0.1), pi_classes=np.concatenate([[sp], np.array([0.5, 0.3, 0.2]) * (1 - sp)]))
-    cfg = dict(method=method, m=m, bs=bs, n=n, p=p, sp=sp, weights=w is not None)
+        if seed % 4 == 3:                                               # per-marker class priors (annotated BayesR, BayesR.jl:62-66)
+            pm = np.random.default_rng(seed).dirichlet(np.ones(4), size=p) * 0.5 + 0.5 * kw["pi_classes"]
+            kw["pi_matrix"] = pm / pm.sum(axis=1, keepdims=True)
+    cfg = dict(method=method, m=m, bs=bs, n=n, p=p, sp=sp, weights=w is not None, marker_prior=("pi_matrix" in kw or "pi_vec" in kw))
     for it in range(1, 6):
         so = orc.sweep(iteration=it, seed=seed, group_launch=True, **kw)
         sh = hip.sweep(iteration=it, seed=seed, group_launch=True, **kw)
