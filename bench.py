@@ -263,15 +263,13 @@ def main():
     # packed / explicitly sized run): mcmc.run_chain's policy
     from jwas_jl_amd.mcmc import GROUPED_BLOCKS_PER_LAUNCH, grouped_launch_size
     groups = GROUPED_BLOCKS_PER_LAUNCH if a.groups < 0 else a.groups
-    if os.environ.get("JWAS_BENCH_FORCE_PACKED_GROUPS") and a.storage != "dense":      # (experiments: grouped launches on packed storage)
-        groups = int(os.environ["JWAS_BENCH_FORCE_PACKED_GROUPS"])
-    group_bs = 0 if (a.storage != "dense" and not os.environ.get("JWAS_BENCH_FORCE_PACKED_GROUPS")) else grouped_launch_size(method, t, rows_mode, (1024 if adaptive else bs), groups, dense_prior=dense_prior)
+    group_bs = grouped_launch_size(method, t, rows_mode, (1024 if adaptive else bs), groups, dense_prior=dense_prior)
     if group_bs:
         cur = eng.block_size
         eng.select_block_size(group_bs)
         eng.setup_groups(groups, "mfma")
         eng.select_block_size(cur)
-    if os.environ.get("JWAS_BENCH_GROUPS_SMALL") and adaptive and a.storage == "dense":      # (experiments: grouped launches on the 512-marker set too)
+    if os.environ.get("JWAS_BENCH_GROUPS_SMALL") and adaptive:      # (experiments: grouped launches on the 512-marker set too)
         eng.setup_groups(int(os.environ["JWAS_BENCH_GROUPS_SMALL"]), "mfma")
     log('setup_blocks done')
     eng.init_state("MTBayesB" if mt_pervar else method, t)

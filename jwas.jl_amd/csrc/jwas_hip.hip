@@ -1812,25 +1812,19 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
                 static const int qx = std::getenv("JWAS_HIP_QUIET_XCD") ? std::atoi(std::getenv("JWAS_HIP_QUIET_XCD")) : -1;
                 U.quiet_xcd = qx >= 0 ? qx : (c->last_events < 0 || c->last_events > 0.0125 * (double)c->p ? 1 : 0);
             }
-            SamplerArgs S;
+            GroupSamplers SS;
             GroupArgs G;
-            std::memset(&S, 0, sizeof S);
+            std::memset(&SS, 0, sizeof SS);
             std::memset(&G, 0, sizeof G);
             G.m = m;
+            SS.a[0].bsz = bs;
             if (K >= 1) {
                 const int64_t gs = K - 1, first = gs * m;
-                S.P = c->dparams;
-                S.partials = c->partials + (gs & 1) * pstride_g; S.nrg = c->nrg; S.bstride = (int)gb;
-                S.j0 = first * bs; S.b = blk_b(c, first); S.p = c->p; S.bsz = bs;
-                S.xpx = c->xpx;
-                S.compact_off = compact_off;
-                S.prep_d = c->prep_d; S.prep_f = c->prep_f;
-                S.alpha = c->alpha; S.beta = c->beta; S.delta = c->delta;
-                S.ev_out = &c->ev[gs & 1];
-                S.counters = c->counters;
+                const int64_t bb = (int64_t)bs * bs;
+                float* cb = SET.gcbuf;
+                const int off_g_in = (int)((gs & 1) * gb), off_g_out = (int)(((gs + 1) & 1) * gb);
                 G.ns = (int)std::min<int64_t>(m, nb - first);
-                G.first = first; G.nb = nb;
-                G.gram_all = c->gram; G.cross_all = c->cross;
+                G.j0 = first * bs;
                 if (gs + 1 < ng) {
                     G.cross_grp = SET.gcross[m == 4 ? 1 : 0] + (size_t)(gs + 1) * gb * gb;
                     G.bn_grp = (int)std::min<int64_t>(gb, c->p - (gs + 1) * gb);
@@ -1839,17 +1833,38 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
                     G.cross_pair = SET.gcross[0] + (size_t)(2 * gs + 1) * (2 * (size_t)bs) * (2 * (size_t)bs);
                     G.bn_pair = (int)std::min<int64_t>(2 * (int64_t)bs, c->p - (first + 2) * bs);
                 }
-                G.cbuf = SET.gcbuf;
-                G.off_g_in = (int)((gs & 1) * gb); G.off_g_out = (int)(((gs + 1) & 1) * gb);
-                G.off_w = off_w; G.off_p = off_p; G.off_z = off_z;
+                G.corr_g_out = cb + off_g_out; G.corr_p = cb + off_p;
                 G.ev_idx = SET.gidx + (gs & 1) * gb; G.ev_delta = SET.gdelta + (gs & 1) * gb;
+                for (int s2 = 0; s2 < G.ns; ++s2) {
+                    SamplerArgs& S = SS.a[s2];
+                    const int64_t i = first + s2;
+                    S.P = c->dparams;
+                    S.partials = c->partials + (gs & 1) * pstride_g + (size_t)s2 * bs; S.nrg = c->nrg; S.bstride = (int)gb;
+                    S.j0 = i * bs; S.b = blk_b(c, i); S.p = c->p; S.bsz = bs;
+                    S.xpx = c->xpx;
+                    S.gram = c->gram + i * bb;
+                    const bool inner = !(s2 & 1) && s2 + 1 < G.ns;      // the first block of a PAIR: its sampler forms the cW of the second
+                    S.b_next = inner ? blk_b(c, i + 1) : 0;
+                    S.cross_next = c->cross + (inner ? i + 1 : i) * bb;
+                    S.gram_next = c->gram + (inner ? i + 1 : i) * bb;   // (L2 prefetch only, and only when b_next > 0)
+                    S.compact_off = compact_off;
+                    S.corr_in = cb + ((s2 & 1) ? off_w : off_z);                          // cW: the pair's first block (or +0)
+                    S.corr_out = cb + off_w;
+                    S.corr_in2 = cb + off_g_in + (size_t)s2 * bs;                         // cG: the previous group
+                    S.corr_in3 = cb + ((s2 >= 2) ? off_p + (s2 - 2) * bs : off_z);        // cP: the group's first pair (or +0)
+                    S.prep_d = c->prep_d; S.prep_f = c->prep_f;
+                    S.alpha = c->alpha; S.beta = c->beta; S.delta = c->delta;
+                    S.ev_out = &c->ev[gs & 1];
+                    S.ev_idx = SET.gidx + (gs & 1) * gb; S.ev_delta = SET.gdelta + (gs & 1) * gb;
+                    S.counters = c->counters;
+                }
             }
             const bool timed = c->timing_stride > 0 && K < ng && (K % c->timing_stride) == 0;
             if (timed) {
                 while (c->kev.size() < 2 * (ntimed + 1)) { hipEvent_t e; HIPCHK(c, hipEventCreate(&e)); c->kev.push_back(e); }
                 HIPCHK(c, hipEventRecord(c->kev[2 * ntimed], c->stream));
             }
-            HIPCHK(c, launch_group_st(step_launch_of(c), c->method, U, uidx, udel, S, G));
+            HIPCHK(c, launch_group_st(step_launch_of(c), c->method, U, uidx, udel, SS, G));
             if (timed) {
                 HIPCHK(c, hipEventRecord(c->kev[2 * ntimed + 1], c->stream));
                 ++ntimed;

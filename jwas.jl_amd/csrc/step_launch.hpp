@@ -30,7 +30,7 @@ hipError_t launch_step_mega(const StepLaunch& L, int method, int nt, const Updat
 
 // grouped launches (k_group_step): sampler(blocks of group K-1) || update/partial(group K); single trait
 hipError_t launch_group_st(const StepLaunch& L, int method, const UpdateArgs& U, const int32_t* uev_idx, const float* uev_delta,
-                           const SamplerArgs& S, const GroupArgs& G);
+                           const GroupSamplers& SS, const GroupArgs& G);
 
 // Rule T (jwas_sweep_params.section_solve): the inverses of all 64-marker sections of the full 256-marker blocks, once per sweep
 // (k_section_inverse_mt; nsections = 4 per full block, tsec: nsections * (64 nt)^2 floats)

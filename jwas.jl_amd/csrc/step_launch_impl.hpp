@@ -90,12 +90,12 @@ hipError_t launch_step(const StepLaunch& L, const UpdateArgs& U, const SamplerAr
 
 template <int METHOD, class CX>
 hipError_t launch_group_cx(const StepLaunch& L, const CX& cx, const UpdateArgs& U0, const int32_t* uev_idx, const float* uev_delta,
-                           const SamplerArgs& S, const GroupArgs& G)
+                           const GroupSamplers& SS, const GroupArgs& G)
 {
     UpdateArgsT<CX> U;
     static_cast<UpdateArgs&>(U) = U0;
     U.cx = cx;
-    const StepSmem SM = step_smem<METHOD, 1>(L.block_size, S, false);
+    const StepSmem SM = step_smem<METHOD, 1>(L.block_size, SS.a[0], false);
     static std::atomic<unsigned long long> attr_set{0ull};
     const unsigned long long dev_bit = 1ull << (L.device & 63);
     if (!(attr_set.load(std::memory_order_acquire) & dev_bit)) {
@@ -106,15 +106,15 @@ hipError_t launch_group_cx(const StepLaunch& L, const CX& cx, const UpdateArgs& 
     }
     const int nwork = L.nrg * U.ncg;
     const unsigned grid = U.quiet_xcd ? (unsigned)(1 + (nwork + 6) / 7 * 8) : (unsigned)(1 + nwork);
-    hipLaunchKernelGGL((k_group_step<METHOD, CX>), dim3(grid), dim3(kStepThreads), SM.bytes, L.stream, U, uev_idx, uev_delta, S, G);
+    hipLaunchKernelGGL((k_group_step<METHOD, CX>), dim3(grid), dim3(kStepThreads), SM.bytes, L.stream, U, uev_idx, uev_delta, SS, G);
     return hipSuccess;
 }
 
 template <int METHOD>
-hipError_t launch_group(const StepLaunch& L, const UpdateArgs& U, const int32_t* uev_idx, const float* uev_delta, const SamplerArgs& S, const GroupArgs& G)
+hipError_t launch_group(const StepLaunch& L, const UpdateArgs& U, const int32_t* uev_idx, const float* uev_delta, const GroupSamplers& SS, const GroupArgs& G)
 {
-    if (L.packed) return launch_group_cx<METHOD, PackedCols>(L, L.pc, U, uev_idx, uev_delta, S, G);
-    return launch_group_cx<METHOD, DenseCols>(L, L.dc, U, uev_idx, uev_delta, S, G);
+    if (L.packed) return launch_group_cx<METHOD, PackedCols>(L, L.pc, U, uev_idx, uev_delta, SS, G);
+    return launch_group_cx<METHOD, DenseCols>(L, L.dc, U, uev_idx, uev_delta, SS, G);
 }
 
 // Independent-block sweep (BayesABC_block_independent!, BayesABC.jl:190-255): all block RHS from the residual

@@ -12,11 +12,11 @@ hipError_t launch_step_st(const StepLaunch& L, int method, const UpdateArgs& U, 
 }
 
 hipError_t launch_group_st(const StepLaunch& L, int method, const UpdateArgs& U, const int32_t* uev_idx, const float* uev_delta,
-                           const SamplerArgs& S, const GroupArgs& G)
+                           const GroupSamplers& SS, const GroupArgs& G)
 {
-    if (method == kBayesB) return launch_group<kBayesB>(L, U, uev_idx, uev_delta, S, G);
-    if (method == kBayesR) return launch_group<kBayesR>(L, U, uev_idx, uev_delta, S, G);
-    return launch_group<kBayesC>(L, U, uev_idx, uev_delta, S, G);
+    if (method == kBayesB) return launch_group<kBayesB>(L, U, uev_idx, uev_delta, SS, G);
+    if (method == kBayesR) return launch_group<kBayesR>(L, U, uev_idx, uev_delta, SS, G);
+    return launch_group<kBayesC>(L, U, uev_idx, uev_delta, SS, G);
 }
 
 hipError_t launch_indep_st(const StepLaunch& L, int method, const UpdateArgs& U, const SamplerArgs& S, int64_t pstride, bool dense)

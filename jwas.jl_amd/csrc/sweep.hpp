@@ -215,22 +215,19 @@ __global__ __launch_bounds__(kStepThreads) void k_block_step(UpdateArgsT<CX> U, 
 struct GroupArgs {
     int ns;                        // blocks of the SAMPLED group (0 = none: first launch of a sweep)
     int m;                         // blocks per group: 2 or 4
-    int64_t first, nb;             // index of the sampled group's first block; blocks of the partition (uniform, the last may be short)
-    const float* gram_all;         // [nb][bs * bs]
-    const float* cross_all;        // [nb][bs * bs]   entry i: X_{i-1}' X_i
+    int64_t j0;                    // first marker of the sampled group (rows of the cross-Grams below)
     const float* cross_grp;        // X_group' X_nextgroup (row stride bn_grp), or NULL: the sampled group is the last one
     int bn_grp;
     const float* cross_pair;       // m = 4: X_{blocks 0,1}' X_{blocks 2,3} of the sampled group (row stride bn_pair), or NULL
     int bn_pair;
-    float* cbuf;                   // ONE buffer for every correction (offsets in floats below: a select between offsets keeps the
-                                   // accesses global; a select between pointers made hipcc emit flat ones)
-    int off_g_in;                  // [m * bs] cG of the sampled group
-    int off_g_out;                 // [m * bs] cG of the next group
-    int off_w;                     // [bs]     cW (room for two)
-    int off_p;                     // [2 * bs] cP
-    int off_z;                     // [bs]     zeros
-    int32_t* ev_idx; float* ev_delta;     // merged change list of the sampled group (capacity m * bs; header: S.ev_out)
+    float* corr_g_out;             // [m * bs] cG of the next group
+    float* corr_p;                 // [2 * bs] cP
+    const int32_t* ev_idx; const float* ev_delta;     // merged change list of the sampled group (capacity m * bs; header: the blocks' ev_out)
 };
+// The sampler arguments of the group's blocks, one full set per block, filled by the host (sweep_enqueue): block s reads ITS set
+// from the kernel-argument segment -- a copy of one set edited per block inside the kernel kept ~80 scalars live across the whole
+// sampler (492 scalar and 277 vector registers spilled).
+struct GroupSamplers { SamplerArgs a[4]; };
 
 // corr[c] = fmaf(d_e, C[row_e][c], corr[c]) from 0 over list entries [0, ne) in list (= marker) order, for ncols_out columns
 // (columns >= bn: 0).  All threads; the list is staged through LDS in chunks of 512 entries, 8 columns per thread.
@@ -279,38 +276,20 @@ __device__ __forceinline__ void group_corr(char* smem, const int32_t* __restrict
 
 template <int METHOD, class CX>
 __global__ __launch_bounds__(kStepThreads) void k_group_step(UpdateArgsT<CX> U, const int32_t* uev_idx, const float* uev_delta,
-                                                             SamplerArgs S, GroupArgs G)
+                                                             GroupSamplers SS, GroupArgs G)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (blockIdx.x == 0) {
         if (G.ns <= 0) return;
-        const int bs = S.bsz;
-        const int64_t bb = (int64_t)bs * bs;
         int nev = 0;
 #pragma unroll 1
         for (int s = 0; s < G.ns; ++s) {
-            SamplerArgs A = S;                                  // S: block 0 of the group (partials, j0); the rest follows from the uniform partition
-            const int64_t i = G.first + s;
-            A.j0 = S.j0 + (int64_t)s * bs;
-            { const int64_t left = S.p - A.j0; A.b = left < bs ? (int)left : bs; }
-            A.partials = S.partials + s * bs;
-            A.gram = G.gram_all + i * bb;
-            const bool inner = !(s & 1) && s + 1 < G.ns;         // the first block of a PAIR: the sampler forms the cW of the second
-            { const int64_t left = S.p - (A.j0 + bs); A.b_next = inner ? (left < bs ? (int)left : bs) : 0; }
-            A.cross_next = G.cross_all + (inner ? i + 1 : i) * bb;
-            A.gram_next = G.gram_all + (inner ? i + 1 : i) * bb;          // (L2 prefetch only, and only when b_next > 0)
-            A.cross_after = nullptr; A.lines_after = 0;
-            A.corr_in = G.cbuf + ((s & 1) ? G.off_w : G.off_z);                        // cW: the pair's first block (or +0)
-            A.corr_out = G.cbuf + G.off_w;
-            A.corr_in2 = G.cbuf + G.off_g_in + s * bs;                                 // cG: the previous group
-            A.corr_in3 = G.cbuf + ((s >= 2) ? G.off_p + (s - 2) * bs : G.off_z);       // cP: the group's first pair (or +0)
-            A.ev_idx = G.ev_idx; A.ev_delta = G.ev_delta;
-            nev += sampler_role_st<METHOD, false, true>(smem, A, nev);
+            nev += sampler_role_st<METHOD, false, true>(smem, SS.a[s], nev);
             __syncthreads();                                    // the block's global stores (cW, the list) are visible to the workgroup
             if (s == 1 && G.cross_pair != nullptr && G.ns > 2)
-                group_corr(smem, G.ev_idx, G.ev_delta, nev, S.j0, G.cross_pair, G.bn_pair, G.cbuf + G.off_p, 2 * bs);
+                group_corr(smem, G.ev_idx, G.ev_delta, nev, G.j0, G.cross_pair, G.bn_pair, G.corr_p, 2 * SS.a[0].bsz);
         }
-        if (G.cross_grp != nullptr) group_corr(smem, G.ev_idx, G.ev_delta, nev, S.j0, G.cross_grp, G.bn_grp, G.cbuf + G.off_g_out, G.m * bs);
+        if (G.cross_grp != nullptr) group_corr(smem, G.ev_idx, G.ev_delta, nev, G.j0, G.cross_grp, G.bn_grp, G.corr_g_out, G.m * SS.a[0].bsz);
         return;
     }
     int w = blockIdx.x - 1;

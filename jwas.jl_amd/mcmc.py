@@ -597,11 +597,11 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         adaptive = False
         adaptive_mt = False
 
-    # grouped launches (engine.setup_groups): the adaptive policy's 1024-marker sweeps of a single-trait chain on dense storage,
-    # when the chain is long enough to pay for the group cross-Grams; a weighted / explicitly partitioned / row-sharded run keeps
+    # grouped launches (engine.setup_groups): the adaptive policy's 1024-marker sweeps of a single-trait chain (dense or 2-bit packed
+    # storage), when the chain is long enough to pay for the group cross-Grams; an explicitly partitioned / row-sharded run keeps
     # one block per launch
     group_m = 0
-    if adaptive and not stream and not double_precision and explicit_partition is None and not independent_blocks and fast_blocks is False:
+    if adaptive and not double_precision and explicit_partition is None and not independent_blocks and fast_blocks is False:
         # (blocks_per_launch: None = by the chain's length; 0 / 2 / 4 = the caller's choice -- a device option like block_size)
         group_m = grouped_blocks_for_chain(chain_length) if blocks_per_launch is None else int(blocks_per_launch)
         if not grouped_launch_size(method, t, False, 1024, group_m):
