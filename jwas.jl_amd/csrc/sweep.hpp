@@ -231,7 +231,7 @@ struct GroupSamplers { SamplerArgs a[4]; };
 
 // corr[c] = fmaf(d_e, C[row_e][c], corr[c]) from 0 over list entries [0, ne) in list (= marker) order, for ncols_out columns
 // (columns >= bn: 0).  All threads; the list is staged through LDS in chunks of 512 entries, 8 columns per thread.
-__device__ __forceinline__ void group_corr(char* smem, const int32_t* __restrict__ eidx, const float* __restrict__ edel, int ne, int64_t jrow0,
+__device__ __attribute__((noinline)) void group_corr(char* smem, const int32_t* __restrict__ eidx, const float* __restrict__ edel, int ne, int64_t jrow0,
                                            const float* __restrict__ cross, int bn, float* __restrict__ out, int ncols_out)
 {
     int* lrow = reinterpret_cast<int*>(smem);
@@ -298,8 +298,9 @@ __global__ __launch_bounds__(kStepThreads) void k_group_step(UpdateArgsT<CX> U, 
         w = (int)(blockIdx.x - 1) - (int)((blockIdx.x - 1) >> 3);
     }
     if (w >= U.nrg * U.ncg) return;
-    constexpr bool kRoll = (METHOD == kBayesC || METHOD == kBayesB) && CX::kDepth == 1;
-    update_role<1, CX, false, kRoll, EvGroup>(smem, w % U.nrg, w / U.nrg, U.cx, U.r_in, U.r_out, EvGroup{U.ev, uev_idx, uev_delta}, U.j0, U.b,
+    // (no rolling-window apply here: grouped launches run the sparse steady state -- a handful of changes per group -- and the
+    // window's 32 columns in registers are what pushed this kernel, with its sampler loop, into scratch memory)
+    update_role<1, CX, false, false, EvGroup>(smem, w % U.nrg, w / U.nrg, U.cx, U.r_in, U.r_out, EvGroup{U.ev, uev_idx, uev_delta}, U.j0, U.b,
                                               U.nslices, U.nrg, U.ncg, U.partials, U.bstride, U.spg, nullptr, nullptr, U.dbg);
 }
 
