@@ -385,6 +385,10 @@ def runMCMC(model, df, *, heterogeneous_residuals=False, chain_length=100, start
     sampled concurrently on the device (BayesABC.jl:190-255) -- the reference's approximate parallel mode.
     `_engine` (private, not part of the reference's surface) lets the test-suite inject a sweep engine; the default and
     only shipped engine is HipEngine.
+    blocks_per_launch (device option, like block_size): None = by the chain's length (mcmc.grouped_blocks_for_chain: 2 from
+    3 000 iterations on, 4 from 8 000), 0 / 2 / 4 = one / two / four 1024-marker blocks per launch of the step kernel in the
+    sparse steady state of a single-trait chain (grouped launches) -- the same chain up to float32
+    rounding of the block right-hand sides; the group cross-Grams are set-up work (8 / 24 KB per marker).
 
     double_precision=True (JWAS.jl:349-366): genotypes, residual, effects and the samplers' arithmetic all Float64 -- a
     Float64 device context (jwas_hip_set_precision; csrc/f64_path.hpp): single-trait BayesA/B/C, RR-BLUP, BayesL, BayesR and
