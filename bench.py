@@ -267,7 +267,10 @@ def main():
     if group_bs:
         cur = eng.block_size
         eng.select_block_size(group_bs)
-        eng.setup_groups(groups, "mfma")
+        try:
+            eng.setup_groups(groups, "mfma")
+        except Exception as ex:      # noqa: BLE001  (e.g. no HBM left for the group cross-Grams: one block per launch, said in the log and in config.blocks_per_launch)
+            log(f"grouped launches not set up ({ex}); running one block per launch")
         eng.select_block_size(cur)
     if os.environ.get("JWAS_BENCH_GROUPS_SMALL") and adaptive:      # (experiments: grouped launches on the 512-marker set too)
         eng.setup_groups(int(os.environ["JWAS_BENCH_GROUPS_SMALL"]), "mfma")
