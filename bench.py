@@ -76,6 +76,12 @@ def parse():
                     help="chain iterations run as part of the SETUP (untimed, before the warm-up steps): the metric is defined "
                          "on the steady state of the chain (SURVEY.md section 8d), which a start from alpha = 0 reaches after "
                          "~25 sweeps; with --warmup >= 30 (the default) nothing extra runs")
+    ap.add_argument("--chain", type=int, default=0,
+                    help="run this many chain sweeps FROM THE START before the warm-up (instead of --burnin) and record every one of them: "
+                         "the line gets a `chain` object -- chain_total_s, worst sweep, means per 100-sweep window with the effect changes, "
+                         "markers in the model and block size of each window -- so that a workload whose chain passes through several "
+                         "regimes (config 3: BayesR sheds markers for hundreds of sweeps; config 4: dense start -> transition -> sparse) is "
+                         "reported on its transient AND on its steady state (the timed region that follows)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="config2")
     ap.add_argument("--n", type=int, default=0, help="override the workload's number of individuals")
     ap.add_argument("--p", type=int, default=0, help="override the workload's number of markers (per GPU for config5shard)")
@@ -260,15 +266,20 @@ def main():
     elif adaptive_mt:
         eng.add_block_size(512, "mfma")
     # grouped launches (single-trait sparse steady state: the 1024-marker set of the adaptive policy, or the fixed block size of a
-    # packed / explicitly sized run): mcmc.run_chain's policy
+    # packed / explicitly sized run).  The metric is defined on the steady state of a long chain, so the bench sets the
+    # groups up whatever --steps is; mcmc.run_chain asks for them only when the chain is long enough to pay for the set-up
+    # (mcmc.grouped_blocks_for_chain) -- the set-up cost is reported in config.group_setup_s, outside the timed region like every Gram.
     from jwas_jl_amd.mcmc import GROUPED_BLOCKS_PER_LAUNCH, grouped_launch_size
     groups = GROUPED_BLOCKS_PER_LAUNCH if a.groups < 0 else a.groups
+    group_setup_s = 0.0
     group_bs = grouped_launch_size(method, t, rows_mode, (1024 if adaptive else bs), groups, dense_prior=dense_prior)
     if group_bs:
         cur = eng.block_size
         eng.select_block_size(group_bs)
         try:
+            t_g = time.time()
             eng.setup_groups(groups, "mfma")
+            group_setup_s = time.time() - t_g
         except Exception as ex:      # noqa: BLE001  (e.g. no HBM left for the group cross-Grams: one block per launch, said in the log and in config.blocks_per_launch)
             log(f"grouped launches not set up ({ex}); running one block per launch")
         eng.select_block_size(cur)
@@ -398,7 +409,7 @@ def main():
             kw["group_launch"] = True
         st = shard.sweep_resident(**kw)
         s["rsum"] = np.asarray(st["resid_sum"], dtype=np.float64).copy()
-        solve_policy.observe(s["it"], eng)
+        solve_policy.observe(s["it"], eng, ran=bool(kw.get("section_solve")))
         if adaptive:       # n_events is the all-shard total after the reconcile: every rank takes the same decision
             eng.select_block_size(pick_block_size(st["n_events"], p_total))
         elif adaptive_mt:
@@ -448,9 +459,36 @@ def main():
         torch.cuda.synchronize()
 
     # chain burn-in (setup): only when the warm-up alone would not reach the steady state
-    nburn = max(0, a.burnin - a.warmup)
-    for _ in range(nburn):
-        step()
+    nburn = a.chain if a.chain > 0 else max(0, a.burnin - a.warmup)
+    chain_rec = None
+    if a.chain > 0:
+        # --chain: every sweep from the start on the clock (wall time per iteration incl. the host draws; each step ends with the
+        # statistics' device-to-host copy, i.e. synchronised)
+        rec = {"wall_ms": [], "sweep_ms": [], "events": [], "in_model": [], "bs": []}
+        barrier()
+        tc0 = time.perf_counter()
+        for _ in range(nburn):
+            t1 = time.perf_counter()
+            st_ = step()
+            rec["wall_ms"].append(1e3 * (time.perf_counter() - t1))
+            rec["sweep_ms"].append(float(st_["sweep_ms"]))
+            rec["events"].append(float(st_["n_events"]))
+            rec["in_model"].append(float(st_["class_counts"][1:].sum()) if method == "BayesR" else
+                                   (float(p_total - st_["state_counts"][0]) if t > 1 else float(st_["sum_delta"][0])))
+            rec["bs"].append(int(state["bs"]))
+        barrier()
+        chain_total = time.perf_counter() - tc0
+        W = 100
+        wm = np.asarray(rec["wall_ms"])
+        win = lambda key, f=np.mean: [float(f(np.asarray(rec[key][i:i + W]))) for i in range(0, nburn, W)]      # noqa: E731
+        chain_rec = {"sweeps": nburn, "chain_total_s": chain_total, "mean_ms": float(wm.mean()), "worst_sweep_ms": float(wm.max()),
+                     "worst_sweep_index": int(wm.argmax()) + 1, "window": W,
+                     "window_mean_ms": win("wall_ms"), "window_max_ms": win("wall_ms", np.max), "window_device_sweep_ms": win("sweep_ms"),
+                     "window_events_per_sweep": win("events"), "window_markers_in_model": win("in_model"),
+                     "window_block_size": [int(np.bincount(np.asarray(rec["bs"][i:i + W])).argmax()) for i in range(0, nburn, W)]}
+    else:
+        for _ in range(nburn):
+            step()
     log(f"burn-in done: {nburn} sweeps")
     for _ in range(a.warmup):
         st_ = step(); log(f"warmup step: sweep_ms={st_['sweep_ms']:.1f} events={st_['n_events']:.0f} in_model={st_['sum_delta'][0]:.0f}")
@@ -508,7 +546,7 @@ def main():
             "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "name": wl, "variant": variant, "storage": a.storage,
                        "n": n, "p": p_total, "block_size": bs_now, "block_policy": "adaptive 512/1024" if adaptive else ("256 while dense / 512 once sparse" if adaptive_mt else "fixed"),
-                       "blocks_per_launch": (m_used if m_used >= 2 else 1),
+                       "blocks_per_launch": (m_used if m_used >= 2 else 1), "group_setup_s": group_setup_s,
                        "parallelism": (f"{'row' if rows_mode else 'marker'}-shard x{world}" + (" (exact chain of the pooled data; one all-reduce of the block RHS per block launch)" if rows_mode else " (one all-reduce of the residual delta per sweep; residual resident in HBM)")) if world > 1 else "single GPU",
                        "ranks_reported_by_communicator": comm_world,
                        "device_sweep_ms": acc["sweep_ms"] / a.steps, "per_rank_device_sweep_ms": per_rank_sweep_ms, "events_per_sweep": acc["events"] / a.steps,
@@ -520,6 +558,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "bytes_per_launch": bytes_per_launch, "avg_launch_us": avg_launch_us, "launches_timed": launches},
         }
+        if chain_rec is not None:
+            out["chain"] = chain_rec
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a, eng, method, t, n, p_total, min(a.cpu_sample_markers, p_loc), Y, state, refbench)
         nvia = a.via_api if a.via_api >= 0 else (20 if (wl == "config2" and world == 1 and a.pi_fixed is None and a.storage == "dense") else 0)

@@ -1753,8 +1753,10 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
                           (edm ? std::atoi(edm) != 0 : c->last_events >= 0.6 * (double)c->p);
     const int dense_big_off = std::getenv("JWAS_HIP_DENSE_BIG_OFF") != nullptr ? 1 : 0;      // (tests: the same chain through the general path)
     // Rule T (jwas_sweep_params.section_solve): the dense chain of a 64-marker section as a mat-vec with the section's inverse,
-    // formed here for all sections of the full blocks in parallel (sampler_mt.hpp).  Multi-trait sampler I on uniform 256-marker blocks.
-    const int64_t solve_blocks = (P->section_solve && dense_mt256 && P->nreps == 1 && !independent && c->starts.empty() && !c->row_mode && !dense_big_off)
+    // formed here for all sections of the full blocks in parallel (sampler_mt.hpp).  Multi-trait sampler I with <= 3 traits on uniform
+    // 256-marker blocks; every other sweep ignores the flag (4 traits: the sampler has no solve path, and a helper workgroup waiting
+    // for sections nobody publishes would spin).
+    const int64_t solve_blocks = (P->section_solve && t <= 3 && dense_mt256 && P->nreps == 1 && !independent && c->starts.empty() && !c->row_mode && !dense_big_off)
                                      ? c->p / 256 : 0;
     const size_t tsf = (size_t)(64 * t) * (size_t)(64 * t);
     // dense sweeps hand the next block's lookahead correction to a helper workgroup (corr_helper): multi-trait Rule T blocks, and

@@ -45,8 +45,10 @@ class SectionSolvePolicy:
     def use(self, it):
         return self.enabled and it >= self.off_until
 
-    def observe(self, it, engine):
-        if not self.enabled or it < self.off_until or not hasattr(engine, "last_sweep_counters"):
+    def observe(self, it, engine, ran=True):
+        """After sweep `it`.  ran: the sweep really passed section_solve (a sweep on another block size did not, and its
+        counter 16 means something else -- reading it would switch the rule off without evidence)."""
+        if not ran or not self.enabled or it < self.off_until or not hasattr(engine, "last_sweep_counters"):
             return
         if engine.last_sweep_counters()[16] * 2 < self.nsections:
             self.off_until = it + 1 + self.probe

@@ -164,3 +164,29 @@ def test_rule_t_device_against_the_literal_oracle_t3_bs256(hip, method):
         ao, ah = orc.get_state(k)[0], hip.get_state(k)[0]
         scale = max(float(np.abs(ao).max()), 1e-3)
         np.testing.assert_allclose(ah, ao, rtol=0, atol=1e-4 * scale)
+
+
+@pytest.mark.timeout(120)
+def test_four_traits_ignore_the_flag(hip):
+    """jwas_hip.h: '<= 3 traits ... every other sweep ignores the flag'.  With 4 traits the sampler has no solve path (the
+    host used to set up the hand-over words anyway and the helper workgroup waited for sections nobody published): section_solve = 1
+    must run the sequential walk, bit for bit."""
+    t = 4
+    rng = np.random.default_rng(9)
+    data = make_dataset(n=800, p=3 * 256 + 40, ncausal=10, seed=81)
+    vare, varg = _mt_hyper(t, rng)
+    prior = np.full(1 << t, 1e-9); prior[-1] = 1.0; prior /= prior.sum()
+    out = {}
+    for solve in (True, False):
+        hip.load_dense(data["X"]); hip.setup_blocks(256, "f64")
+        hip.init_state("MTBayesC", t)
+        y = data["y"] - data["y"].mean()
+        for k in range(t):
+            hip.set_residual(((1 + 0.25 * k) * y).astype(np.float32), k)
+            hip.set_state(k, delta=np.ones(hip.p, dtype=np.float32))
+        for it in range(1, 5):
+            hip.sweep(iteration=it, seed=23, vare=vare, var_effect=varg, log_prior_states=np.log(prior), section_solve=solve)
+        assert hip.last_sweep_counters()[16] == 0
+        out[solve] = [hip.get_state(k) for k in range(t)] + [hip.get_residual(k) for k in range(t)]
+    for a, b in zip(out[True], out[False]):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
