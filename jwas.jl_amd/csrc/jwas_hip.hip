@@ -52,7 +52,9 @@ struct jwas_hip_ctx {
         // consecutive groups of four; gcbuf: the corrections [2][gm bs] cG | [2][bs] cW | [2 bs] cP | [bs] zeros; gidx / gdelta:
         // [2][gm bs] the merged change lists of a group (ping-pong; header lines: ctx.ev[parity])
         int gm; float* gcross[2]; float* gcbuf; int32_t* gidx; float* gdelta;
+        unsigned long long* gpp;        // gm = 2: [3 bs + 8] tagged hand-over words of the ping-pong samplers (SamplerArgs::pp_words)
     };
+    unsigned pp_epoch = 0;              // tag of the last ping-pong launch (31 bits, never 0: a word of the zeroed buffer matches no launch)
     int set_index = 0;                  // entry of `sets` that is selected
     std::vector<BlockSet> sets;
     std::vector<int64_t> starts;        // explicit block starts (nblocks + 1 entries, last = p), empty = uniform blocks
@@ -261,7 +263,7 @@ static void free_blocks(jwas_hip_ctx* c)
     (void)hipFree(c->xpx);
     for (auto& b : c->sets) {
         (void)hipFree(b.gram); (void)hipFree(b.cross); (void)hipFree(b.corr); (void)hipFree(b.partials);
-        (void)hipFree(b.gcross[0]); (void)hipFree(b.gcross[1]); (void)hipFree(b.gcbuf); (void)hipFree(b.gidx); (void)hipFree(b.gdelta);
+        (void)hipFree(b.gcross[0]); (void)hipFree(b.gcross[1]); (void)hipFree(b.gcbuf); (void)hipFree(b.gidx); (void)hipFree(b.gdelta); (void)hipFree(b.gpp);
     }
     c->sets.clear();
     c->xpx = c->gram = c->cross = c->corr = nullptr; c->partials = nullptr;
@@ -854,8 +856,8 @@ int jwas_hip_select_block_size(jwas_hip_ctx* c, int32_t bs)
 
 static void free_groups(jwas_hip_ctx::BlockSet& B)
 {
-    (void)hipFree(B.gcross[0]); (void)hipFree(B.gcross[1]); (void)hipFree(B.gcbuf); (void)hipFree(B.gidx); (void)hipFree(B.gdelta);
-    B.gcross[0] = B.gcross[1] = B.gcbuf = B.gdelta = nullptr; B.gidx = nullptr; B.gm = 0;
+    (void)hipFree(B.gcross[0]); (void)hipFree(B.gcross[1]); (void)hipFree(B.gcbuf); (void)hipFree(B.gidx); (void)hipFree(B.gdelta); (void)hipFree(B.gpp);
+    B.gcross[0] = B.gcross[1] = B.gcbuf = B.gdelta = nullptr; B.gidx = nullptr; B.gpp = nullptr; B.gm = 0;
 }
 
 // Grouped launches for the SELECTED block size: the cross-Grams of consecutive pairs (and, m = 4, fours) of blocks, the
@@ -905,6 +907,10 @@ int jwas_hip_setup_groups(jwas_hip_ctx* c, int32_t m, int32_t gram_mode)
     HIPCHK(c, hipMalloc(&B.gdelta, sizeof(float) * 2 * (size_t)m * bs));
     HIPCHK(c, hipMemsetAsync(B.gidx, 0, sizeof(int32_t) * 2 * (size_t)m * bs, c->stream));
     HIPCHK(c, hipMemsetAsync(B.gdelta, 0, sizeof(float) * 2 * (size_t)m * bs, c->stream));
+    if (m == 2) {
+        HIPCHK(c, hipMalloc(&B.gpp, sizeof(unsigned long long) * (3 * (size_t)bs + 8)));
+        HIPCHK(c, hipMemsetAsync(B.gpp, 0, sizeof(unsigned long long) * (3 * (size_t)bs + 8), c->stream));
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     B.gm = m;
     return JWAS_HIP_OK;
@@ -1819,6 +1825,12 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
             std::memset(&SS, 0, sizeof SS);
             std::memset(&G, 0, sizeof G);
             G.m = m;
+            // PING-PONG samplers (2 blocks per launch; sweep.hpp): while the sampler chain is the critical path (many changes per
+            // sweep: the regime in which ids = 0 mod 8 do no update work anyway) the pair's second block is sampled by workgroup 8, its
+            // front running beside the first block's chain.  Same chain, same bits; JWAS_HIP_PINGPONG=0|1 overrides (1: also in the
+            // steady state, with the quiet XCD forced on).
+            static const int pp_env = std::getenv("JWAS_HIP_PINGPONG") ? std::atoi(std::getenv("JWAS_HIP_PINGPONG")) : -1;
+            const bool pp_want = m == 2 && SET.gpp != nullptr && (pp_env >= 0 ? pp_env != 0 : U.quiet_xcd != 0);
             SS.a[0].bsz = bs;
             if (K >= 1) {
                 const int64_t gs = K - 1, first = gs * m;
@@ -1837,6 +1849,12 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
                 }
                 G.corr_g_out = cb + off_g_out; G.corr_p = cb + off_p;
                 G.ev_idx = SET.gidx + (gs & 1) * gb; G.ev_delta = SET.gdelta + (gs & 1) * gb;
+                unsigned pp_tag = 0;
+                if (pp_want && G.ns == 2) {
+                    G.pp = 1; U.quiet_xcd = 1;
+                    c->pp_epoch = (c->pp_epoch + 1) & 0x7fffffffu; if (c->pp_epoch == 0) c->pp_epoch = 1;
+                    pp_tag = c->pp_epoch;
+                }
                 for (int s2 = 0; s2 < G.ns; ++s2) {
                     SamplerArgs& S = SS.a[s2];
                     const int64_t i = first + s2;
@@ -1859,6 +1877,7 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
                     S.ev_out = &c->ev[gs & 1];
                     S.ev_idx = SET.gidx + (gs & 1) * gb; S.ev_delta = SET.gdelta + (gs & 1) * gb;
                     S.counters = c->counters;
+                    if (G.pp) { S.pp_words = SET.gpp; S.pp_role = s2 + 1; S.pp_tag = pp_tag; }
                 }
             }
             const bool timed = c->timing_stride > 0 && K < ng && (K % c->timing_stride) == 0;
@@ -2046,6 +2065,8 @@ static int sweep_collect(jwas_hip_ctx* c, jwas_sweep_stats* S, size_t ntimed, do
     S->n_events = packed_dev ? h_stat[kNStat] : (double)h_cnt[0];
     c->last_events = (double)h_cnt[0];
     for (int i = 0; i < kNCounters; ++i) c->last_counters[i] = h_cnt[i];
+    NEED(c, h_cnt[kPpTimeoutCounter] == 0, JWAS_HIP_EHIP, "grouped launches: %llu hand-over words between the two sampler workgroups never arrived (results of this sweep are invalid)",
+         h_cnt[kPpTimeoutCounter]);
     if (std::getenv("JWAS_HIP_DEBUG_PHASES"))
         std::fprintf(stderr, "[jwas_hip] blocks=%lld events=%llu unstaged=%llu cycles: front=%llu cand=%llu stage=%llu serial=%llu write=%llu corr=%llu rounds=%llu slow_rounds=%llu stage: assign=%llu issue=%llu wait=%llu update wg0: share=%llu wait=%llu rest=%llu compact: blocks=%llu fallback=%llu walk=%llu verify=%llu role=%llu tailwait=%llu xwrite=%llu xchain=%llu (section_solve: blocks = sections solved, fallback = fallen back, walk..xwrite = cycles of y | mat-vec | combine | verify+apply | tail)\n",
                      (long long)c->nblocks, h_cnt[0], h_cnt[1], h_cnt[2], h_cnt[3], h_cnt[4], h_cnt[5], h_cnt[6], h_cnt[9], h_cnt[7], h_cnt[8], h_cnt[10], h_cnt[11], h_cnt[12], h_cnt[13], h_cnt[14], h_cnt[15], h_cnt[16], h_cnt[17], h_cnt[18], h_cnt[19], h_cnt[20], h_cnt[21], h_cnt[22], h_cnt[23]);

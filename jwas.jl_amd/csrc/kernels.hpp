@@ -806,7 +806,7 @@ __global__ __launch_bounds__(256) void k_prepare(const DevParams* __restrict__ P
 // ---------------------------------------------------------------------------------------------
 // post-sweep reductions over markers (K11).  out[blockIdx.x][kNStat]
 // ---------------------------------------------------------------------------------------------
-constexpr int kNCounters = 24;            // diagnostics counters of a sweep (events, phase cycles, compact-chain blocks)
+constexpr int kNCounters = 32;            // diagnostics counters of a sweep (events, phase cycles, compact-chain blocks)
 constexpr int kNStat = 4 + 16 + 16 + 4 + 2 + 16;   // sum_delta[4] alpha_ss[16] beta_ss[16] class[4] ssq,nnz state[16]
 
 template <int NT>

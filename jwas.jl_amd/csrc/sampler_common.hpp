@@ -50,7 +50,36 @@ struct SamplerArgs {
     // changes go behind the ones of the group's earlier blocks, the header line (count, first 7 changes) is ev_out's
     const float* corr_in2; const float* corr_in3;
     int32_t* ev_idx; float* ev_delta;
+    // PING-PONG samplers (round 6; k_group_step with 2 blocks per launch): the pair's blocks are sampled by TWO workgroups -- block 0 by
+    // workgroup 0, block 1 by workgroup 8, whose front (state, constants, row-group partial sums: one memory latency) runs while block
+    // 0 is walked.  Block 0 hands over its lookahead correction cW and its number of changes through TAGGED 8-byte words
+    // {tag << 32 | payload} (one relaxed agent-scope store each, self-validating: the reader polls the word it needs until the tag is
+    // this launch's; nothing is ever reset, a tag is never seen twice).  One-directional -- workgroup 0 waits for nobody.
+    unsigned long long* pp_words; // [bsz] cW of block 1 (float bits); [bsz] = number of changes of block 0 (its list entries are visible then);
+                                  // [bsz + 8 ...) block 0's half of the next group's correction chain (k_group_step)
+    int pp_role;                  // 0: none; 1: block 0 of a split pair (publishes); 2: block 1 (waits)
+    unsigned pp_tag;              // this launch's tag
 };
+
+constexpr int kPpTimeoutCounter = 24;      // sweep counter: hand-over words that never arrived (must stay 0; the host fails the sweep otherwise)
+// Poll one tagged word until it carries this launch's tag.  Bounded (~1 s): a hand-over that never arrives is reported, never a hang.
+__device__ __forceinline__ unsigned pp_wait_word(const unsigned long long* w, unsigned tag, unsigned long long* counters)
+{
+    unsigned long long v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int spins = 0;
+    while ((unsigned)(v >> 32) != tag) {
+        if (++spins > (1 << 21)) { atomicAdd(&counters[kPpTimeoutCounter], 1ull); break; }
+        __builtin_amdgcn_s_sleep(8);
+        v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return (unsigned)v;
+}
+__device__ __forceinline__ void pp_post_word(unsigned long long* w, unsigned tag, unsigned payload)
+{
+    __hip_atomic_store(w, ((unsigned long long)tag << 32) | (unsigned long long)payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// ping-pong, second block's workgroup: the number of changes of the pair's first block (posted with its list entries acknowledged)
+__device__ __forceinline__ int pp_first_count(const SamplerArgs& A) { return (int)pp_wait_word(A.pp_words + A.bsz, A.pp_tag, A.counters); }
 
 // fp64 sum of one column's row-group partials in fixed (ascending row group) order; the first N loads are issued
 // back to back from clamped addresses (no load depends on another).

@@ -344,6 +344,139 @@ __device__ __forceinline__ void mt1_eval(const MtConsts<NT>& K, const MtPre<NT>&
     }
 }
 
+// ---- mt1_eval with everything that does not depend on the running right-hand side HOISTED out of it (round 6).  A dense walk
+// through MIXED joint states -- the transition of a default-prior chain from "every marker in the model" to its sparse steady state,
+// ~1 000 sweeps in which every marker needs the literal evaluation at its own step -- is one wave issuing mt1_eval once per marker:
+// ~250 instructions, bound by their COUNT.  When trait k is sampled, the traits after it still hold the marker's ENTRY state, so
+// every product and sum over m > k (MTBayesABC.jl:90,93,96), the draws' scaled normals, C12 with delta_m = 1, and for trait 0 the
+// whole "excluded" branch are functions of the marker's entry state, draws and constants only: formed ONCE per marker (all lanes
+// in parallel, before the walk), they leave ~140 instructions per step.  The SAME operations on the same numbers in the same
+// association as mt1_eval<NT, true> (every sum keeps its order: the m < k terms first, then the m > k terms one by one) -- bit for
+// bit the same decisions and values (dense_big_mt verifies every lane once more with mt1_eval itself after the walk).
+template <int NT>
+struct Mt1Hoist {
+    float tg[NT][NT];          // m > k: Ginv[k][m] * b_entry[m]                                   (a term of rhs0, :93)
+    float tc[NT][NT];          // m > k: (Ginv[k][m] + (dj * d_entry[m]) * Rinv[k][m]) * b_entry[m] (a term of C12' beta, :90,:96)
+    float c12on[NT][NT];       // m < k: Ginv[k][m] + (dj * 1) * Rinv[k][m]   (C12 when trait m is in the model; out of it: Ginv[k][m])
+    double zs1[NT], zs0[NT];   // z_k sqrt(1 / C11_k),  z_k sqrt(1 / Ginv_kk)                       (:109,:114)
+    double ld0_0, lp1_0;       // trait 0: logDelta0 (nothing in it moves with the rhs), log prior of its "in the model" state
+    float c12b_0, b0_excl;     // trait 0: C12' beta; its effect when it stays out
+    bool all1_in;              // the marker entered with every indicator 1 (Rule L applies if it also leaves that way)
+    // traits 1 and 2: the log prior probabilities of the two joint states the conditional compares, for every configuration of the
+    // traits BELOW it (the ones above hold their entry state): [configuration of traits 0..k-1][delta_k] -- registers instead of an
+    // LDS lookup whose address depends on the trait before it (two LDS latencies on the chain of every step)
+    double lpt1[2][2], lpt2[4][2];
+};
+template <int NT, class LP>
+__device__ __forceinline__ Mt1Hoist<NT> mt1_hoist(const MtConsts<NT>& K, const MtPre<NT>& Q, const LP& lp, float dj,
+                                                  const float (&b_in)[NT], const float (&d_in)[NT], const double (&z)[NT])
+{
+    Mt1Hoist<NT> H;
+    H.all1_in = true;
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+        H.all1_in = H.all1_in && (d_in[k] == 1.f);
+        H.zs1[k] = z[k] * (double)Q.s1[k];
+        H.zs0[k] = z[k] * (double)K.sG[k];
+#pragma unroll
+        for (int m = 0; m < NT; ++m) {
+            H.tg[k][m] = 0.f; H.tc[k][m] = 0.f; H.c12on[k][m] = 0.f;
+            if (m > k) {
+                const float C12m = K.Ginv[k][m] + (dj * d_in[m]) * K.Rinv[k][m];                   // :90
+                H.tg[k][m] = K.Ginv[k][m] * b_in[m];
+                H.tc[k][m] = C12m * b_in[m];
+            } else if (m < k) H.c12on[k][m] = K.Ginv[k][m] + (dj * 1.f) * K.Rinv[k][m];
+        }
+    }
+    float rhs0 = 0.f, c12b = 0.f;
+#pragma unroll
+    for (int m = 1; m < NT; ++m) { rhs0 = rhs0 + H.tg[0][m]; c12b = c12b + H.tc[0][m]; }
+    rhs0 = -rhs0;                                                                                   // :93
+    const float gHat0 = rhs0 * K.invG[0];
+    double lp0, lp1;
+    lp.template pair<NT>(0, d_in, lp0, lp1);
+    const float in0 = K.lG[0] - (gHat0 * gHat0) * K.Ginv[0][0];                                     // :104
+    H.ld0_0 = -0.5 * (double)in0 + lp0;
+    H.lp1_0 = lp1;
+    H.c12b_0 = c12b;
+    H.b0_excl = (float)((double)gHat0 + H.zs0[0]);
+#pragma unroll
+    for (int cfg = 0; cfg < 4; ++cfg) {
+        float dc[NT];
+#pragma unroll
+        for (int m = 0; m < NT; ++m) dc[m] = d_in[m];
+        dc[0] = (cfg & 1) ? 1.f : 0.f;
+        if (cfg < 2) {
+            if constexpr (NT >= 2) lp.template pair<NT>(1, dc, H.lpt1[cfg][0], H.lpt1[cfg][1]);
+            else { H.lpt1[cfg][0] = 0.0; H.lpt1[cfg][1] = 0.0; }
+        }
+        if constexpr (NT >= 3) { dc[1] = (cfg & 2) ? 1.f : 0.f; lp.template pair<NT>(2, dc, H.lpt2[cfg][0], H.lpt2[cfg][1]); }
+        else { H.lpt2[cfg][0] = 0.0; H.lpt2[cfg][1] = 0.0; }
+    }
+    return H;
+}
+// a_in / d_in: the marker's entry alpha / delta; out: bn, dn, Dl = alpha_old - alpha_new (what the walk broadcasts)
+template <int NT, class LP>
+__device__ __forceinline__ void mt1_eval_hoisted(const MtConsts<NT>& K, const MtPre<NT>& Q, const Mt1Hoist<NT>& H, const LP& lp,
+                                                 const float (&w)[NT], const float (&a_in)[NT], const float (&d_in)[NT],
+                                                 const double (&thr)[NT], const float (&Al)[NT][NT], const float (&cl)[NT],
+                                                 float (&bn)[NT], float (&dn)[NT], float (&Dl)[NT])
+{
+    float dcomb[NT];                                 // the indicators as the conditional of trait k sees them: new below k, entry above
+#pragma unroll
+    for (int k = 0; k < NT; ++k) dcomb[k] = d_in[k];
+    bool all1 = H.all1_in;
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+        float wR = 0.f;
+#pragma unroll
+        for (int m = 0; m < NT; ++m) wR = wR + w[m] * K.Rinv[m][k];
+        float c12b, gHat0 = 0.f;
+        double ld0, lp1;
+        if (k == 0) { c12b = H.c12b_0; ld0 = H.ld0_0; lp1 = H.lp1_0; }
+        else {
+            float rhs0 = 0.f;
+            c12b = 0.f;
+#pragma unroll
+            for (int m = 0; m < NT; ++m) {
+                if (m < k) {
+                    const float C12m = (dn[m] != 0.f) ? H.c12on[k][m] : K.Ginv[k][m];              // :90
+                    rhs0 = rhs0 + K.Ginv[k][m] * bn[m];
+                    c12b = c12b + C12m * bn[m];
+                } else if (m > k) {
+                    rhs0 = rhs0 + H.tg[k][m];
+                    c12b = c12b + H.tc[k][m];
+                }
+            }
+            rhs0 = -rhs0;                                                                           // :93
+            gHat0 = rhs0 * K.invG[k];
+            double lp0;
+            if (k == 1) { const bool d0 = dn[0] != 0.f; lp0 = d0 ? H.lpt1[1][0] : H.lpt1[0][0]; lp1 = d0 ? H.lpt1[1][1] : H.lpt1[0][1]; }
+            else if (k == 2) {
+                const bool d0 = dn[0] != 0.f, d1 = dn[1] != 0.f;
+                const double a0 = d0 ? H.lpt2[1][0] : H.lpt2[0][0], a1 = d0 ? H.lpt2[3][0] : H.lpt2[2][0];
+                const double c0 = d0 ? H.lpt2[1][1] : H.lpt2[0][1], c1 = d0 ? H.lpt2[3][1] : H.lpt2[2][1];
+                lp0 = d1 ? a1 : a0; lp1 = d1 ? c1 : c0;
+            } else lp.template pair<NT>(k, dcomb, lp0, lp1);
+            const float in0 = K.lG[k] - (gHat0 * gHat0) * K.Ginv[k][k];                             // :104
+            ld0 = (double)(-0.5f * in0) + lp0;             // (-0.5 * (double)in0: the scaling by a power of two is exact in either type)
+        }
+        const float rhs1 = wR - c12b;                                                               // :96
+        const float gHat1 = rhs1 * Q.invLhs1[k];
+        const float in1 = Q.lC11[k] - (gHat1 * gHat1) * Q.C11[k];                                   // :105
+        const double ld1 = (double)(-0.5f * in1) + lp1;
+        const bool take = (ld0 - ld1) < thr[k];                                                     // :107-111
+        if (k == 0) bn[k] = take ? (float)((double)gHat1 + H.zs1[k]) : H.b0_excl;
+        else bn[k] = (float)((double)(take ? gHat1 : gHat0) + (take ? H.zs1[k] : H.zs0[k]));      // (one value chain: the branch taken)
+        dn[k] = take ? 1.f : 0.f;
+        dcomb[k] = dn[k];
+        all1 = all1 && take;
+    }
+    if (all1) mt1_linear_beta<NT>(Al, cl, w, bn);                                                   // Rule L
+#pragma unroll
+    for (int k = 0; k < NT; ++k) Dl[k] = (dn[k] != 0.f) ? a_in[k] - bn[k] : a_in[k];
+}
+
 // megaBayesABC! (BayesABC.jl:1-8): trait k is an independent single-trait BayesC update (BayesABC.jl:24-58)
 template <int NT>
 __device__ __forceinline__ void mega_eval(const MtConsts<NT>& K, const MtPre<NT>& Q, const float (&w)[NT], float dj,
@@ -860,14 +993,16 @@ __device__ __forceinline__ void dense_big_mt(char* smem, const StepSmem& SM, con
                     for (int u = 0; u < 8; ++u) step_fast(l + u, g[u]);
                 }
             };
+            // (the rhs-independent part of the literal evaluation, once per marker: mt1_hoist)
+            const Mt1Hoist<NT> Hh = mt1_hoist<NT>(K, Q, PriorMem{lpr, 1}, dj, bb, dd, z);
             auto walk_mixed = [&](unsigned long long slow) {
                 float g = tile[lane];
 #pragma unroll 1
                 for (int l = 0; l < 64; ++l) {
-                    float w[NT], ao[NT], bo[NT], d_o[NT], Dl[NT];
+                    float w[NT], bo[NT], d_o[NT], Dl[NT];
 #pragma unroll
                     for (int t = 0; t < NT; ++t) w[t] = rhs[t] + da[t];
-                    if ((slow >> l) & 1ull) eval_own(w, ao, bo, d_o, Dl);                             // (wave-uniform)
+                    if ((slow >> l) & 1ull) mt1_eval_hoisted<NT>(K, Q, Hh, PriorMem{lpr, 1}, w, a, dd, thr, Al, cl, bo, d_o, Dl);      // (wave-uniform)
                     else {
                         mt1_linear_beta<NT>(Al, cl, w, bo);
 #pragma unroll
@@ -1311,14 +1446,15 @@ __device__ __forceinline__ void dense_big_mt_solve(char* smem, const StepSmem& S
                         for (int t = 0; t < NT; ++t) { ao[t] = a[t]; bo[t] = bb[t]; d_o[t] = dd[t]; Dl[t] = 0.f; }
                         mt1_eval<NT>(K, Q, PriorMem{lpr, 1}, w, dj, thr, z, ao, bo, d_o, Dl, Al, cl);
                     };
+                    const Mt1Hoist<NT> Hh = mt1_hoist<NT>(K, Q, PriorMem{lpr, 1}, dj, bb, dd, z);      // (the rhs-independent part, once per marker)
                     auto walk_mixed = [&](unsigned long long slow) {
                         float g = tile[lane];
 #pragma unroll 1
                         for (int l = 0; l < 64; ++l) {
-                            float w[NT], ao[NT], bo[NT], d_o[NT], Dl[NT];
+                            float w[NT], bo[NT], d_o[NT], Dl[NT];
 #pragma unroll
                             for (int t = 0; t < NT; ++t) w[t] = rhs[t] + da[t];
-                            if ((slow >> l) & 1ull) eval_own(w, ao, bo, d_o, Dl);                         // (wave-uniform)
+                            if ((slow >> l) & 1ull) mt1_eval_hoisted<NT>(K, Q, Hh, PriorMem{lpr, 1}, w, a, dd, thr, Al, cl, bo, d_o, Dl);      // (wave-uniform)
                             else {
                                 mt1_linear_beta<NT>(Al, cl, w, bo);
 #pragma unroll

@@ -394,7 +394,7 @@ __host__ __device__ constexpr int st_park_nf(int method, bool dense = false) { (
 // reference's benchmark setting), selected by the host: every marker follows Rule D (AbcMarker::rule_d) on every path of
 // it, and full 256- / 512-marker blocks take dense_big_st.  The steady-state kernel is compiled without any of it.
 // GROUP (k_group_step): the block is one of a group of consecutive blocks sampled by ONE launch -- three lookahead corrections
-// instead of one, its changes appended to the group's merged list at ev_base.  Returns the number of changes of the block.
+// instead of one, its changes appended to the group's merged list at ev_base.  Returns the length of that list behind the block.
 template <int METHOD, bool DENSE = false, bool GROUP = false>
 __device__ __forceinline__ int sampler_role_st(char* smem, const SamplerArgs& A, int ev_base = 0)
 {
@@ -474,6 +474,12 @@ __device__ __forceinline__ int sampler_role_st(char* smem, const SamplerArgs& A,
         }
     }
     bool cand[2] = {false, false};
+    // PING-PONG (SamplerArgs::pp_role == 2: the second block of a pair, sampled by its own workgroup while the first block's
+    // workgroup is still walking): cW does not exist yet.  Everything else of the front -- one memory latency -- happens now; the
+    // right-hand side and the candidacy are finished below, when block 0's sampler has posted cW.
+    bool pp_wait = false;
+    if constexpr (GROUP) pp_wait = A.pp_role == 2;
+    float pp_sum[2] = {0.f, 0.f}, pp_c2[2] = {0.f, 0.f}, pp_c3[2] = {0.f, 0.f};
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int c = tid + q * kStepThreads;
@@ -482,13 +488,18 @@ __device__ __forceinline__ int sampler_role_st(char* smem, const SamplerArgs& A,
         const int64_t j = j0 + cc;
         const float a0 = A.alpha[j];
         const float dj = A.xpx[j];
-        float co = A.corr_in[c];
-        if constexpr (GROUP) { const float co2 = A.corr_in2[c], co3 = A.corr_in3[c]; co = (co + co2) + co3; }
+        float co = 0.f;
+        if constexpr (GROUP) {
+            const float co2 = A.corr_in2[c], co3 = A.corr_in3[c];
+            pp_c2[q] = co2; pp_c3[q] = co3;
+            if (!pp_wait) { co = A.corr_in[c]; co = (co + co2) + co3; }
+        } else co = A.corr_in[c];
         if constexpr (kR) {
             BayesRMarker bm;
             bm.load_fast_global(A.prep_d, p, j, dj, ie);
             const float thrx = A.prep_f[j];
             const double sum = sum_partials(A.partials + cc, A.nrg, A.bstride);
+            pp_sum[q] = (float)sum;
             const float rhs0 = (float)sum + co;
             rhs_lds[c] = rhs0;
             const float a_in = (c < b) ? a0 : 0.f;
@@ -501,6 +512,7 @@ __device__ __forceinline__ int sampler_role_st(char* smem, const SamplerArgs& A,
             const double zs = A.prep_d[3 * p + j];
             const float invLhs = A.prep_f[j], bex = A.prep_f[2 * p + j], lo = A.prep_f[3 * p + j], hi = A.prep_f[4 * p + j];
             const double sum = sum_partials(A.partials + cc, A.nrg, A.bstride);
+            pp_sum[q] = (float)sum;
             const float rhs0 = (float)sum + co;       // + lookahead correction formed by the previous block's sampler
             rhs_lds[c] = rhs0;
             const float a_in = (c < b) ? a0 : 0.f;
@@ -513,6 +525,24 @@ __device__ __forceinline__ int sampler_role_st(char* smem, const SamplerArgs& A,
             cand[q] = (c < b) && ((a_in != 0.f) || abc_included(rhs0, lo * kCandMargin, hi * kCandMargin));      // (alpha = 0: lo <= 0 <= hi)
             always_mine = always_mine && ((c >= b) || (lo == hi));           // thresholds(): lo = hi <=> always included
             bpark0[c] = bex; dpark0[c] = 0.f;     // a marker that stays out: delta 0, beta = its excluded draw
+        }
+    }
+    if constexpr (GROUP) {
+        if (pp_wait) {
+            // the hand-over: every thread polls the tagged words of ITS markers (block 0's sampler posts them the moment its
+            // correction chain is done), then   rhs = fl32(sum) + ((cW + cG) + cP)   and the candidacy, exactly as above
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int c = tid + q * kStepThreads;
+                if (c >= B) continue;
+                const float cw = __uint_as_float(pp_wait_word(A.pp_words + c, A.pp_tag, A.counters));
+                const float co = (cw + pp_c2[q]) + pp_c3[q];
+                const float rhs0 = pp_sum[q] + co;
+                rhs_lds[c] = rhs0;
+                const float a_in = acur[c];
+                if constexpr (kR) cand[q] = (c < b) && ((a_in != 0.f) || (fabsf(rhs0) >= lpf[B + c] * kCandMargin));
+                else cand[q] = (c < b) && ((a_in != 0.f) || abc_included(rhs0, lpf[3 * B + c] * kCandMargin, lpf[4 * B + c] * kCandMargin));
+            }
         }
     }
     if (prestage) {
@@ -641,6 +671,7 @@ __device__ __forceinline__ int sampler_role_st(char* smem, const SamplerArgs& A,
     }
     // ---- COMPACT CHAIN (see compact_walk): all candidates staged, one lane each
     bool compact_done = false, compact_corr = false;      // compact_corr: ... and the next block's lookahead correction is in corr_cd
+    bool pp_posted = false;                                // ping-pong, first block: cW has been posted to the second block's workgroup
     float corr_cd[2] = {0.f, 0.f};
     long long tkc[3] = {0, 0, 0}, tkx[3] = {0, 0, 0};
     if constexpr (!DENSE) {
@@ -695,7 +726,10 @@ __device__ __forceinline__ int sampler_role_st(char* smem, const SamplerArgs& A,
                         for (int u = 0; u < 8; ++u) if (e0 + u < nc) corr = fmaf(dd[u], g[u], corr);     // (a marker that did not move: d = 0, an exact no-op)
                     }
                     corr_cd[q] = corr;
+                    // (ping-pong: block 1's workgroup is waiting for exactly this)
+                    if constexpr (GROUP) { if (A.pp_role == 1) pp_post_word(A.pp_words + c, A.pp_tag, __float_as_uint(corr)); }
                 }
+                if constexpr (GROUP) pp_posted = A.pp_role == 1;
                 compact_corr = true;
                 tkx[2] = clock64();
             }
@@ -1167,6 +1201,16 @@ __device__ __forceinline__ int sampler_role_st(char* smem, const SamplerArgs& A,
         corr_phase<1>(smem, SM, A, nfin, cross_lds);
     }
     const long long tk7 = clock64();
+    // ping-pong, second block: where its changes go in the pair's merged list = how many block 0 had (posted when block 0's list
+    // entries were acknowledged by the memory side -- long ago by now)
+    int evb = ev_base;
+    if constexpr (GROUP) {
+        if (A.pp_role == 2) {
+            if (tid == 0) wcnt_s[10] = (int)pp_wait_word(A.pp_words + B, A.pp_tag, A.counters);
+            __syncthreads();
+            evb = wcnt_s[10];
+        }
+    }
     // ---- global stores LAST (nothing in this launch waits for them; a barrier after a global store waits for the store):
     // the change list for the next update role, alpha of the changed markers, beta / delta of the whole block
     if (compact_corr) {
@@ -1183,14 +1227,18 @@ __device__ __forceinline__ int sampler_role_st(char* smem, const SamplerArgs& A,
         const int* fin = reinterpret_cast<const int*>(smem + SM.log_off);
         const bool pairs = from_log && (stream_corr || A.b_next <= 0);          // (else the list was turned into plain columns)
         int32_t* eidx; float* edel;
-        if constexpr (GROUP) { eidx = A.ev_idx + ev_base; edel = A.ev_delta + ev_base; }
+        if constexpr (GROUP) { eidx = A.ev_idx + evb; edel = A.ev_delta + evb; }
         else { eidx = A.ev_out->idx; edel = A.ev_out->delta[0]; }
-        const int hb = GROUP ? ev_base : 0;                                     // (entries of the list in front of this block's)
+        const int hb = GROUP ? evb : 0;                                         // (entries of the list in front of this block's)
+        bool pp_first = false;                                                  // (ping-pong, first block: the second block's workgroup
+        if constexpr (GROUP) pp_first = A.pp_role == 1;                         //  reads these entries in THIS launch: write-through stores)
         for (int e = tid; e < nfin; e += kStepThreads) {
             const int ce = pairs ? fin[2 * e] : fin[e];
             const float d = astart[ce] - acur[ce];
-            eidx[e] = (int32_t)(j0 + ce);
-            edel[e] = d;
+            if (pp_first) {
+                __hip_atomic_store(eidx + e, (int32_t)(j0 + ce), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(edel + e, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else { eidx[e] = (int32_t)(j0 + ce); edel[e] = d; }
             if (hb + e < 7) { A.ev_out->hidx[hb + e] = (int32_t)(j0 + ce); A.ev_out->hdelta[hb + e] = d; }
             A.alpha[j0 + ce] = acur[ce];
         }
@@ -1207,8 +1255,20 @@ __device__ __forceinline__ int sampler_role_st(char* smem, const SamplerArgs& A,
             else { A.beta[j0 + c] = bpark0[c]; reinterpret_cast<float*>(A.delta)[j0 + c] = dpark0[c]; }
         }
     }
+    if constexpr (GROUP) {
+        if (A.pp_role == 1) {
+            // the hand-over to the second block's workgroup: every store of this workgroup -- cW through corr_out on the paths that did
+            // not post it themselves, the list entries -- has been acknowledged by the memory side (vmcnt counts a store out then)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (!pp_posted)
+                for (int c = tid; c < B; c += kStepThreads)
+                    pp_post_word(A.pp_words + c, A.pp_tag, __hip_atomic_load(reinterpret_cast<const unsigned*>(A.corr_out) + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            if (tid == 0) pp_post_word(A.pp_words + B, A.pp_tag, (unsigned)nfin);
+        }
+    }
     if (tid == 0) {
-        A.ev_out->count = (int32_t)((GROUP ? ev_base : 0) + nfin);
+        if (!(GROUP && A.pp_role == 1)) A.ev_out->count = (int32_t)((GROUP ? evb : 0) + nfin);      // (a split pair's count: its second block's)
         atomicAdd(&A.counters[0], (unsigned long long)nfin);
         atomicAdd(&A.counters[2], (unsigned long long)(tk1 - tk0));      // phase cycle counts (diagnostics)
         atomicAdd(&A.counters[3], (unsigned long long)(tk2 - tk1));
@@ -1234,7 +1294,7 @@ __device__ __forceinline__ int sampler_role_st(char* smem, const SamplerArgs& A,
             }
         }
     }
-    return nfin;
+    return evb + nfin;                                     // (grouped launches: the length of the merged list behind this block)
 }
 
 

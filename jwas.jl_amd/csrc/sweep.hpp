@@ -223,55 +223,88 @@ struct GroupArgs {
     float* corr_g_out;             // [m * bs] cG of the next group
     float* corr_p;                 // [2 * bs] cP
     const int32_t* ev_idx; const float* ev_delta;     // merged change list of the sampled group (capacity m * bs; header: the blocks' ev_out)
+    int pp;                        // PING-PONG samplers (m = 2, a full pair): block 0 in workgroup 0, block 1 + the group's correction in
+                                   // workgroup 8 (SamplerArgs::pp_role; the launcher keeps workgroup ids = 0 mod 8 free of update work)
 };
 // The sampler arguments of the group's blocks, one full set per block, filled by the host (sweep_enqueue): block s reads ITS set
 // from the kernel-argument segment -- a copy of one set edited per block inside the kernel kept ~80 scalars live across the whole
 // sampler (492 scalar and 277 vector registers spilled).
 struct GroupSamplers { SamplerArgs a[4]; };
 
-// corr[c] = fmaf(d_e, C[row_e][c], corr[c]) from 0 over list entries [0, ne) in list (= marker) order, for ncols_out columns
-// (columns >= bn: 0).  All threads; the list is staged through LDS in chunks of 512 entries, 8 columns per thread.
-__device__ __attribute__((noinline)) void group_corr(char* smem, const int32_t* __restrict__ eidx, const float* __restrict__ edel, int ne, int64_t jrow0,
-                                           const float* __restrict__ cross, int bn, float* __restrict__ out, int ncols_out)
+// corr[c] = fmaf(d_e, C[row_e][c], corr[c]) over list entries [e_lo, e_hi) in list (= marker) order, for ncols_out columns (columns
+// >= bn: 0), starting from 0 -- or, seed != NULL, from the chain another workgroup formed over the entries before e_lo and posted as
+// tagged words (ping-pong samplers: block 0's workgroup runs ITS part of the next group's correction while block 1 is still being
+// walked; continuing a fused-multiply-add chain where it stopped gives the bits of the one chain).  post != NULL: the result goes
+// out as tagged words instead of to `out`.  All threads; the list is staged through LDS in chunks of 512 entries; NQ column slots
+// per thread (ncols_out <= NQ * 512), 64 / NQ rows = 64 loads in flight per thread and pass: a pass is one memory round trip, and
+// with 30-60 changes per group (BayesR, a fixed pi) four rows per pass were 15 dependent round trips at the end of every launch.
+// coherent: part of the list was written by ANOTHER workgroup of this launch (write-through stores, acknowledged before the count
+// was handed over) -- read it at the coherence point, not through this XCD's L2.
+template <int NQ>
+__device__ __attribute__((noinline)) void group_corr_n(char* smem, const int32_t* eidx, const float* edel, int e_lo, int e_hi, int64_t jrow0,
+                                                       const float* __restrict__ cross, int bn, float* __restrict__ out, int ncols_out, bool coherent,
+                                                       const unsigned long long* seed, unsigned long long* post, unsigned tag, unsigned long long* counters)
 {
+    constexpr int R = 64 / NQ;
     int* lrow = reinterpret_cast<int*>(smem);
     float* ld = reinterpret_cast<float*>(smem) + kStepThreads;
     const int tid = threadIdx.x;
-    float corr[8];
+    float corr[NQ];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) corr[q] = 0.f;
-    for (int e0 = 0; e0 < ne; e0 += kStepThreads) {
-        const int nc = (ne - e0) < kStepThreads ? (ne - e0) : kStepThreads;
+    for (int q = 0; q < NQ; ++q) {
+        const int c = tid + q * kStepThreads;
+        corr[q] = (seed != nullptr && c < ncols_out) ? __uint_as_float(pp_wait_word(seed + c, tag, counters)) : 0.f;
+    }
+    for (int e0 = e_lo; e0 < e_hi; e0 += kStepThreads) {
+        const int nc = (e_hi - e0) < kStepThreads ? (e_hi - e0) : kStepThreads;
         __syncthreads();
-        if (tid < nc) { lrow[tid] = (int)((int64_t)eidx[e0 + tid] - jrow0); ld[tid] = edel[e0 + tid]; }
+        if (tid < nc) {
+            if (coherent) {
+                lrow[tid] = (int)((int64_t)__hip_atomic_load(eidx + e0 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - jrow0);
+                ld[tid] = __hip_atomic_load(edel + e0 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else { lrow[tid] = (int)((int64_t)eidx[e0 + tid] - jrow0); ld[tid] = edel[e0 + tid]; }
+        }
         __syncthreads();
-        for (int h = 0; h < nc; h += 4) {
-            float g[4][8];
+        for (int h = 0; h < nc; h += R) {
+            float g[R][NQ];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < R; ++u) {
                 const int64_t row = lrow[h + u < nc ? h + u : nc - 1];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
+                for (int q = 0; q < NQ; ++q) {
                     const int c = tid + q * kStepThreads;
                     g[u][q] = cross[row * bn + (c < bn ? c : 0)];
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < R; ++u) {
                 if (h + u < nc) {
                     const float d = ld[h + u];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) corr[q] = fmaf(d, g[u][q], corr[q]);
+                    for (int q = 0; q < NQ; ++q) corr[q] = fmaf(d, g[u][q], corr[q]);
                 }
             }
         }
     }
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < NQ; ++q) {
         const int c = tid + q * kStepThreads;
-        if (c < ncols_out) out[c] = (c < bn) ? corr[q] : 0.f;
+        if (c < ncols_out) {
+            const float v = (c < bn) ? corr[q] : 0.f;
+            if (post != nullptr) pp_post_word(post + c, tag, __float_as_uint(v)); else out[c] = v;
+        }
     }
     __syncthreads();
+}
+__device__ __forceinline__ void group_corr(char* smem, const int32_t* eidx, const float* edel, int e_lo, int e_hi, int64_t jrow0,
+                                           const float* __restrict__ cross, int bn, float* __restrict__ out, int ncols_out, bool coherent = false,
+                                           const unsigned long long* seed = nullptr, unsigned long long* post = nullptr, unsigned tag = 0u,
+                                           unsigned long long* counters = nullptr)
+{
+    if (ncols_out <= kStepThreads) group_corr_n<1>(smem, eidx, edel, e_lo, e_hi, jrow0, cross, bn, out, ncols_out, coherent, seed, post, tag, counters);
+    else if (ncols_out <= 2 * kStepThreads) group_corr_n<2>(smem, eidx, edel, e_lo, e_hi, jrow0, cross, bn, out, ncols_out, coherent, seed, post, tag, counters);
+    else if (ncols_out <= 4 * kStepThreads) group_corr_n<4>(smem, eidx, edel, e_lo, e_hi, jrow0, cross, bn, out, ncols_out, coherent, seed, post, tag, counters);
+    else group_corr_n<8>(smem, eidx, edel, e_lo, e_hi, jrow0, cross, bn, out, ncols_out, coherent, seed, post, tag, counters);
 }
 
 template <int METHOD, class CX>
@@ -279,17 +312,30 @@ __global__ __launch_bounds__(kStepThreads) void k_group_step(UpdateArgsT<CX> U, 
                                                              GroupSamplers SS, GroupArgs G)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (blockIdx.x == 0) {
-        if (G.ns <= 0) return;
+    // ping-pong (G.pp: a full pair, m = 2): workgroup 0 samples block 0, workgroup 8 -- idle on the sampler's XCD -- block 1, whose
+    // front overlaps block 0's chain (sampler_role_st, pp_role); the last block's workgroup forms the next group's correction
+    const bool second = G.pp != 0 && blockIdx.x == 8;
+    if (blockIdx.x == 0 || second) {
+        if (G.ns <= 0 || (second && G.ns < 2)) return;
+        const int s_lo = second ? 1 : 0, s_hi = (G.pp != 0 && !second) ? 1 : G.ns;
         int nev = 0;
 #pragma unroll 1
-        for (int s = 0; s < G.ns; ++s) {
-            nev += sampler_role_st<METHOD, false, true>(smem, SS.a[s], nev);
+        for (int s = s_lo; s < s_hi; ++s) {
+            nev = sampler_role_st<METHOD, false, true>(smem, SS.a[s], nev);      // (block 1 of a split pair: block 0's count + its own)
             __syncthreads();                                    // the block's global stores (cW, the list) are visible to the workgroup
             if (s == 1 && G.cross_pair != nullptr && G.ns > 2)
-                group_corr(smem, G.ev_idx, G.ev_delta, nev, G.j0, G.cross_pair, G.bn_pair, G.corr_p, 2 * SS.a[0].bsz);
+                group_corr(smem, G.ev_idx, G.ev_delta, 0, nev, G.j0, G.cross_pair, G.bn_pair, G.corr_p, 2 * SS.a[0].bsz);
         }
-        if (G.cross_grp != nullptr) group_corr(smem, G.ev_idx, G.ev_delta, nev, G.j0, G.cross_grp, G.bn_grp, G.corr_g_out, G.m * SS.a[0].bsz);
+        if (G.cross_grp != nullptr) {
+            const int ncols = G.m * SS.a[0].bsz;
+            if (G.pp != 0 && G.ns == 2) {
+                // the next group's correction in two halves: workgroup 0 runs the chain over block 0's changes while block 1 is still
+                // being walked and posts it; workgroup 8 continues it over block 1's changes
+                unsigned long long* half = SS.a[0].pp_words + SS.a[0].bsz + 8;
+                if (!second) group_corr(smem, G.ev_idx, G.ev_delta, 0, nev, G.j0, G.cross_grp, G.bn_grp, nullptr, ncols, true, nullptr, half, SS.a[0].pp_tag, SS.a[0].counters);
+                else group_corr(smem, G.ev_idx, G.ev_delta, pp_first_count(SS.a[1]), nev, G.j0, G.cross_grp, G.bn_grp, G.corr_g_out, ncols, false, half, nullptr, SS.a[1].pp_tag, SS.a[1].counters);
+            } else if (s_hi == G.ns) group_corr(smem, G.ev_idx, G.ev_delta, 0, nev, G.j0, G.cross_grp, G.bn_grp, G.corr_g_out, ncols);
+        }
         return;
     }
     int w = blockIdx.x - 1;

@@ -96,7 +96,7 @@ def genetic2marker(Mi, pi, method, t=1):
     return float(Vg) / ((1 - float(pi)) * Mi.sum2pq)                   # :457-459
 
 
-ADAPTIVE_CHANGE_FRACTION = 0.0125        # measured crossover of block 512 vs 1024
+ADAPTIVE_CHANGE_FRACTION = float(os.environ.get("JWAS_ADAPTIVE_FRACTION", "0.0125"))      # measured crossover of block 512 vs 1024
 
 
 def pick_block_size(n_events, p, small=512, large=1024):
