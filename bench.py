@@ -283,8 +283,19 @@ def main():
         except Exception as ex:      # noqa: BLE001  (e.g. no HBM left for the group cross-Grams: one block per launch, said in the log and in config.blocks_per_launch)
             log(f"grouped launches not set up ({ex}); running one block per launch")
         eng.select_block_size(cur)
-    if os.environ.get("JWAS_BENCH_GROUPS_SMALL") and adaptive:      # (experiments: grouped launches on the 512-marker set too)
-        eng.setup_groups(int(os.environ["JWAS_BENCH_GROUPS_SMALL"]), "mfma")
+    # ... and ping-pong pairs on the 512-marker set of a high-turnover chain (BayesR, a fixed pi): mcmc.pingpong_pairs_for_chain
+    from jwas_jl_amd.mcmc import pingpong_pairs_for_chain
+    pair_m = int(os.environ["JWAS_BENCH_GROUPS_SMALL"]) if os.environ.get("JWAS_BENCH_GROUPS_SMALL") else \
+        (pingpong_pairs_for_chain(method, estimate_pi, 10 ** 6) if (groups and a.storage == "dense") else 0)
+    pairs_on = False
+    if pair_m and adaptive and not rows_mode and grouped_launch_size(method, t, rows_mode, 512, pair_m, dense_prior=dense_prior):
+        try:
+            t_g = time.time()
+            eng.setup_groups(pair_m, "mfma")          # (the selected size is the 512-marker set here)
+            group_setup_s += time.time() - t_g
+            pairs_on = True
+        except Exception as ex:      # noqa: BLE001
+            log(f"ping-pong pairs not set up ({ex})")
     log('setup_blocks done')
     eng.init_state("MTBayesB" if mt_pervar else method, t)
     if not rows_mode:
@@ -411,7 +422,7 @@ def main():
         s["rsum"] = np.asarray(st["resid_sum"], dtype=np.float64).copy()
         solve_policy.observe(s["it"], eng, ran=bool(kw.get("section_solve")))
         if adaptive:       # n_events is the all-shard total after the reconcile: every rank takes the same decision
-            eng.select_block_size(pick_block_size(st["n_events"], p_total))
+            eng.select_block_size(pick_block_size(st["n_events"], p_total, pairs=pairs_on))
         elif adaptive_mt:
             eng.select_block_size(pick_block_size_mt(st["n_events"], p_total))
         acc["launches"] += -(-p_loc // (s["bs"] * max(m_now, 1))) + 1

@@ -1753,10 +1753,14 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
     // single pass over <= 128-marker blocks: the dense-walk-only instantiation of the sampler (sampler_role_mt<.., DW>: the same
     // chain, a fraction of the code).  JWAS_HIP_DENSE_MT=0|1 overrides (tests: both instantiations give the same bits).
     const char* edm = std::getenv("JWAS_HIP_DENSE_MT");
+    // (the share of markers that changed in the previous sweep from which the dense walk of 256-marker blocks is taken: it costs one
+    // step per marker IN the model -- markers outside it that stay there take no step since round 6 -- so it pays far below "most markers
+    // change": config 4's chain at 22 000 changes per sweep, 19 ms on the walk against 42 ms through the speculative rounds)
+    static const double dense_mt_fraction = std::getenv("JWAS_HIP_DENSE_MT_FRACTION") ? std::atof(std::getenv("JWAS_HIP_DENSE_MT_FRACTION")) : 0.1;
     // ... and full 256-marker blocks of sampler I with one shared covariance (dense_big_mt: decided per launch below)
     const bool dense_mt256 = c->block_size == 256 && (c->method == JWAS_HIP_MTBAYESC1 || c->method == JWAS_HIP_MTBAYESB1) && !P->log_prior_states_matrix;
     const bool dense_mt = is_mt_method(c->method) && !is_sampler2(c->method) && (c->block_size <= 128 || dense_mt256) && P->nreps == 1 && !P->independent_blocks &&
-                          (edm ? std::atoi(edm) != 0 : c->last_events >= 0.6 * (double)c->p);
+                          (edm ? std::atoi(edm) != 0 : c->last_events >= (dense_mt256 ? dense_mt_fraction : 0.6) * (double)c->p);
     const int dense_big_off = std::getenv("JWAS_HIP_DENSE_BIG_OFF") != nullptr ? 1 : 0;      // (tests: the same chain through the general path)
     // Rule T (jwas_sweep_params.section_solve): the dense chain of a 64-marker section as a mat-vec with the section's inverse,
     // formed here for all sections of the full blocks in parallel (sampler_mt.hpp).  Multi-trait sampler I with <= 3 traits on uniform

@@ -995,10 +995,18 @@ __device__ __forceinline__ void dense_big_mt(char* smem, const StepSmem& SM, con
             };
             // (the rhs-independent part of the literal evaluation, once per marker: mt1_hoist)
             const Mt1Hoist<NT> Hh = mt1_hoist<NT>(K, Q, PriorMem{lpr, 1}, dj, bb, dd, z);
-            auto walk_mixed = [&](unsigned long long slow) {
-                float g = tile[lane];
+            // skip: markers that take NO step -- out of the model for every trait at entry and predicted to stay there (below): their
+            // alpha_old - alpha_new is 0 for every trait, and applying a zero change is an exact no-op on every running rhs, so leaving the
+            // step out changes no bit.  The prediction is verified like everything else by the literal evaluation after the walk.
+            auto walk_mixed = [&](unsigned long long slow, unsigned long long skip) {
+                unsigned long long todo = ~skip;
+                if (todo == 0ull) return;
+                int l = __builtin_ctzll(todo);
+                float g = tile[l * 64 + lane];
 #pragma unroll 1
-                for (int l = 0; l < 64; ++l) {
+                while (true) {
+                    todo &= todo - 1ull;
+                    const int ln = todo ? __builtin_ctzll(todo) : 63;
                     float w[NT], bo[NT], d_o[NT], Dl[NT];
 #pragma unroll
                     for (int t = 0; t < NT; ++t) w[t] = rhs[t] + da[t];
@@ -1009,31 +1017,47 @@ __device__ __forceinline__ void dense_big_mt(char* smem, const StepSmem& SM, con
                         for (int t = 0; t < NT; ++t) Dl[t] = a[t] - bo[t];
                     }
                     const float gl = g;
-                    g = tile[(l + 1 < 64 ? l + 1 : 63) * 64 + lane];
+                    g = tile[ln * 64 + lane];
                     bcast(l, Dl, gl);
+                    if (todo == 0ull) break;
+                    l = ln;
                 }
             };
-            bool in_all = true;
+            bool in_all = true, out_all = true;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) in_all = in_all && (dd[t] == 1.f);
-            unsigned long long slow = __ballot(!in_all);
-            if (__popcll(slow) * 4 > 64) slow = ~0ull;
-            if (slow == 0ull) walk_fast(); else walk_mixed(slow);
+            for (int t = 0; t < NT; ++t) { in_all = in_all && (dd[t] == 1.f); out_all = out_all && (dd[t] == 0.f) && (a[t] == 0.f); }
+            unsigned long long slow = __ballot(!in_all), skip = 0ull;
+            if (__any(out_all)) {
+                // markers outside the model: one evaluation against the SECTION-ENTRY rhs predicts which of them stay out (the changes
+                // inside a section move a marker's rhs by a few percent of what it takes to bring it in)
+                float w0[NT], bo[NT], d_o[NT], Dp[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) w0[t] = rhs[t] + da[t];
+                mt1_eval_hoisted<NT>(K, Q, Hh, PriorMem{lpr, 1}, w0, a, dd, thr, Al, cl, bo, d_o, Dp);
+                bool stays = out_all;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) stays = stays && (d_o[t] == 0.f);
+                skip = __ballot(stays);
+                slow &= ~skip;
+            }
+            if (__popcll(slow) * 4 > 64) slow = ~skip;
+            if (slow == 0ull && skip == 0ull) walk_fast(); else walk_mixed(slow, skip);
             float Dl[NT];
             for (int pass = 0; pass < 64; ++pass) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) wev[t] = rhs[t] + da[t];                                 // what the lane's marker was evaluated with
                 eval_own(wev, an, bnw, dn, Dl);
-                bool ok = true;
+                bool ok = true, moved = false;
 #pragma unroll
-                for (int t = 0; t < NT; ++t) ok = ok && (dn[t] == 1.f);
-                const unsigned long long bad = __ballot(!ok) & ~slow;
+                for (int t = 0; t < NT; ++t) { ok = ok && (dn[t] == 1.f); moved = moved || (Dl[t] != 0.f); }
+                // a marker walked with the linear form must have stayed in the model for every trait; one that took no step must not have moved
+                const unsigned long long bad = (__ballot(!ok) & ~slow & ~skip) | (__ballot(moved) & skip);
                 if (bad == 0ull) break;
-                slow |= bad;
-                if (__popcll(slow) * 4 > 64) slow = ~0ull;
+                slow |= bad; skip &= ~bad;
+                if (__popcll(slow) * 4 > 64) slow = ~skip;
 #pragma unroll
                 for (int t = 0; t < NT; ++t) rhs[t] = rs[t];
-                walk_mixed(slow);
+                walk_mixed(slow, skip);
                 ++nredo;
             }
 #pragma unroll

@@ -38,8 +38,9 @@ class SectionSolvePolicy:
     the last sweep solved fewer than half of its sections, and tried again afterwards (speed only: on or off, a sweep samples
     the same conditionals)."""
 
-    def __init__(self, enabled, nsections, probe=50):
-        self.enabled, self.nsections, self.probe = bool(enabled), int(nsections), int(probe)
+    def __init__(self, enabled, nsections, probe=50, probe_max=800):
+        self.enabled, self.nsections, self.probe, self.probe_max = bool(enabled), int(nsections), int(probe), int(probe_max)
+        self.probe0 = self.probe
         self.off_until = 0
 
     def use(self, it):
@@ -51,7 +52,11 @@ class SectionSolvePolicy:
         if not ran or not self.enabled or it < self.off_until or not hasattr(engine, "last_sweep_counters"):
             return
         if engine.last_sweep_counters()[16] * 2 < self.nsections:
+            # (a probe sweep that fails costs more than a sweep without the rule: back off -- 50, 100, 200 ... sweeps between tries)
             self.off_until = it + 1 + self.probe
+            self.probe = min(2 * self.probe, self.probe_max)
+        else:
+            self.probe = self.probe0
 
 
 class HipEngine:

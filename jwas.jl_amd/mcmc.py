@@ -99,9 +99,14 @@ def genetic2marker(Mi, pi, method, t=1):
 ADAPTIVE_CHANGE_FRACTION = float(os.environ.get("JWAS_ADAPTIVE_FRACTION", "0.0125"))      # measured crossover of block 512 vs 1024
 
 
-def pick_block_size(n_events, p, small=512, large=1024):
-    """Block size of the next sweep from the number of markers whose effect changed in the last one."""
-    return large if n_events < ADAPTIVE_CHANGE_FRACTION * p else small
+ADAPTIVE_CHANGE_FRACTION_PAIRS = float(os.environ.get("JWAS_ADAPTIVE_FRACTION_PAIRS", "0.009"))    # ... when the 512-marker sweeps run as ping-pong pairs
+
+
+def pick_block_size(n_events, p, small=512, large=1024, pairs=False):
+    """Block size of the next sweep from the number of markers whose effect changed in the last one.  pairs: the small size runs as
+    ping-pong pairs (pingpong_pairs_for_chain), which moves the crossover down (config 3's chain: 24 ms per sweep on 512-marker pairs at
+    8 700 changes per sweep, 26.5 ms on 4 x 1024-marker launches at 7 500, 22.6 ms at 4 700)."""
+    return large if n_events < (ADAPTIVE_CHANGE_FRACTION_PAIRS if pairs else ADAPTIVE_CHANGE_FRACTION) * p else small
 
 
 # Grouped launches (jwas_hip_setup_groups / jwas_sweep_params.group_launch): blocks per launch of the step kernel on the LARGE block
@@ -116,6 +121,15 @@ def grouped_blocks_for_chain(chain_length):
     return GROUPED_BLOCKS_PER_LAUNCH if chain_length >= 8000 else (2 if chain_length >= 3000 else 0)
 
 
+def pingpong_pairs_for_chain(method, estimate_pi, chain_length):
+    """Pairs of 512-marker blocks per launch (ping-pong samplers: csrc/sweep.hpp k_group_step, SamplerArgs::pp_role) for the
+    HIGH-TURNOVER sweeps of a single-trait chain -- the ones the adaptive policy runs on 512-marker blocks because the sampler is the
+    critical path: BayesR sheds its markers over hundreds of sweeps, a fixed pi keeps ~(1 - pi) p markers in the model for ever
+    (config 3: 29.5 -> 26.8 ms per sweep, fixed pi = 0.95: 29.4 -> 27.0).  BayesC with pi estimated leaves that regime after ~25
+    sweeps: not worth the pair cross-Grams (4 p 1024 bytes, 0.7 s at 50 000 x 600 000)."""
+    return 2 if (chain_length >= 300 and (method == "BayesR" or not estimate_pi)) else 0
+
+
 def grouped_launch_size(method, ntraits, row_shards, block_size, groups=GROUPED_BLOCKS_PER_LAUNCH, dense_prior=False):
     """Block size on which grouped launches are set up (0: none): single-trait BayesA/B/C/R chains with a sparse prior on uniform
     blocks of one GPU's markers (marker shards included, row shards not), groups * block_size <= 4096."""
@@ -126,7 +140,7 @@ def grouped_launch_size(method, ntraits, row_shards, block_size, groups=GROUPED_
     return int(block_size)
 
 
-MT_SPARSE_CHANGE_FRACTION = 0.25          # the share of markers changing per sweep below which a dense-start multi-trait chain is sparse
+MT_SPARSE_CHANGE_FRACTION = float(os.environ.get("JWAS_MT_SPARSE_FRACTION", "0.1"))          # the share of markers changing per sweep below which a dense-start multi-trait chain is sparse
 
 
 def pick_block_size_mt(n_events, p):
@@ -606,6 +620,11 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         group_m = grouped_blocks_for_chain(chain_length) if blocks_per_launch is None else int(blocks_per_launch)
         if not grouped_launch_size(method, t, False, 1024, group_m):
             group_m = 0
+    pair_m = 0                                 # ... and ping-pong pairs on the 512-marker sweeps of a high-turnover chain (dense storage)
+    if adaptive and not double_precision and explicit_partition is None and not independent_blocks and fast_blocks is False and not stream:
+        pair_m = pingpong_pairs_for_chain(method, bool(Mi.estimatePi), chain_length) if blocks_per_launch is None else (2 if int(blocks_per_launch) else 0)
+        if not grouped_launch_size(method, t, False, 512, pair_m):
+            pair_m = 0
 
     from .engine import SectionSolvePolicy
     solve_policy = SectionSolvePolicy(section_solve, 4 * (p // 256))
@@ -619,6 +638,8 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
             need += 2 * 4 * (1024 if adaptive else 512) * p        # the second resident block size (Grams + cross-Grams)
         if group_m:
             need += 4 * p * 2048 * (3 if group_m == 4 else 1)      # grouped launches: pair (and four) cross-Grams of the 1024-marker set
+        if pair_m:
+            need += 4 * p * 1024                                   # ... and the pair cross-Grams of the 512-marker set
         if double_precision and independent_blocks:
             # Float64 independent blocks: one change list of 1024 entries per block (4 + 4 x 8 bytes per entry, whatever the
             # block size) and one partial-sum buffer per block (4 traits x row slices x block doubles)
@@ -675,6 +696,15 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
                 print(f"NOTICE: grouped launches not set up ({ex}); the chain runs one block per launch.")
                 group_m = 0
             engine.select_block_size(cur_bs)
+    if pair_m and engine.blocks_per_launch(512) != pair_m:
+        cur_bs = engine.block_size
+        engine.select_block_size(512)
+        try:
+            engine.setup_groups(pair_m, gram_mode)
+        except Exception as ex:      # noqa: BLE001
+            print(f"NOTICE: ping-pong pairs not set up ({ex}); the 512-marker sweeps run one block per launch.")
+            pair_m = 0
+        engine.select_block_size(cur_bs)
     engine.init_state(mt_method if t > 1 else method, t)
 
     # ---- fixed effects
@@ -840,13 +870,13 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
                 kw.update(var_effect=Gval, pi_vec=pi)
             else:
                 kw.update(var_effect=Gval, pi=pi)
-            if group_m and engine.blocks_per_launch() >= 2:
+            if (group_m or pair_m) and engine.blocks_per_launch() >= 2:
                 kw["group_launch"] = True
             st = engine.sweep(**kw)
             solve_policy.observe(it, engine, ran=bool(kw.get("section_solve")))
             t_sweep += st["sweep_ms"]
             if adaptive:
-                engine.select_block_size(pick_block_size(st["n_events"], p))
+                engine.select_block_size(pick_block_size(st["n_events"], p, pairs=bool(pair_m)))
             elif adaptive_mt:
                 engine.select_block_size(pick_block_size_mt(st["n_events"], p))
 

@@ -20,6 +20,10 @@ ap.add_argument("--bs", type=int, default=512)
 ap.add_argument("--seed", type=int, default=2026)
 ap.add_argument("--method", choices=["BayesC", "BayesR"], default="BayesC")
 ap.add_argument("--json", default=None)
+ap.add_argument("--time-shards", action="store_true",
+                help="record every shard's device sweep time (HIP events) and number of effect changes per iteration: what ONE RANK of the "
+                     "sharded FULL chain does per iteration (its share of the full chain's turnover, not a standalone problem's)")
+ap.add_argument("--pairs", action="store_true", help="with --time-shards: ping-pong pairs on the 512-marker blocks (mcmc.pingpong_pairs_for_chain)")
 a = ap.parse_args()
 n, p = a.n, a.p
 GAMMA = np.array([0.0, 0.01, 0.1, 1.0])                  # JWAS.jl:12
@@ -36,6 +40,8 @@ for G in a.shards:
         lo, hi = shard_range(p, k, G, align=a.bs)
         e = J.HipEngine(0)
         e.alloc_dense(n, hi - lo); e.synth(a.seed, kind=0, center=True, marker_offset=lo); e.setup_blocks(a.bs, "mfma")
+        if a.pairs:
+            e.setup_groups(2, "mfma")
         e.init_state(a.method, 1)
         at = np.zeros(hi - lo, dtype=np.float32)
         m = (causal >= lo) & (causal < hi)
@@ -60,7 +66,9 @@ for G in a.shards:
     scale_e = float(vare) * (df_ - 2) / df_; scale_g = float(Gval) * (df_ - 2) / df_
     r = y.astype(np.float64).copy(); mu = 0.0
     hist = []
+    shard_ms, shard_ev = [], []                            # [iteration][shard]
     for it in range(1, a.iters + 1):
+        shard_ms.append([]); shard_ev.append([])
         r += mu
         mu = rng.standard_normal() * np.sqrt(float(vare) / n) + r.sum() / n
         r -= mu
@@ -69,11 +77,12 @@ for G in a.shards:
         for e, lo, hi in engs:
             e.set_residual(snap)
             if a.method == "BayesR":
-                st = e.sweep(iteration=it, seed=a.seed, vare=vare, var_effect=Gval, pi_classes=pi, nreps=1, marker_offset=lo)
+                st = e.sweep(iteration=it, seed=a.seed, vare=vare, var_effect=Gval, pi_classes=pi, nreps=1, marker_offset=lo, group_launch=a.pairs)
                 cls += st["class_counts"]; ssq += st["bayesr_ssq"]; nnz += st["bayesr_nnz"]
             else:
-                st = e.sweep(iteration=it, seed=a.seed, vare=vare, var_effect=Gval, pi=pi, nreps=1, marker_offset=lo)
+                st = e.sweep(iteration=it, seed=a.seed, vare=vare, var_effect=Gval, pi=pi, nreps=1, marker_offset=lo, group_launch=a.pairs)
                 nl += st["sum_delta"][0]; ass += st["alpha_ss"][0, 0]
+            shard_ms[-1].append(float(st["sweep_ms"])); shard_ev[-1].append(float(st["n_events"]))
             dr += e.get_residual() - snap
         r = (snap + dr).astype(np.float64)
         if a.method == "BayesR":
@@ -101,6 +110,17 @@ for G in a.shards:
                               "second_half_sd": {k: float(h[:, i].std()) for i, k in enumerate(names)},
                               "vare_peak": {"iteration": peak + 1, "value": float(H[peak, 1])},
                               "trajectory": {k: [float(x) for x in H[:, i]] for i, k in enumerate(names)}}
+    if a.time_shards:
+        M, E = np.array(shard_ms), np.array(shard_ev)
+        wins = [(lo_, min(lo_ + 30, a.iters)) for lo_ in range(30, a.iters, 30)]
+        report["runs"][str(G)]["rank_share"] = {
+            "what": "device sweep time (HIP events on the context's stream) of every emulated shard, per iteration of the SHARDED FULL chain",
+            "pairs": bool(a.pairs),
+            "windows": [{"iterations": [lo_ + 1, hi_], "ms_mean_over_shards": float(M[lo_:hi_].mean()), "ms_slowest_shard_mean": float(M[lo_:hi_].max(axis=1).mean()),
+                         "events_per_shard_mean": float(E[lo_:hi_].mean()), "events_all_shards": float(E[lo_:hi_].sum(axis=1).mean())} for lo_, hi_ in wins]}
+        for w in report["runs"][str(G)]["rank_share"]["windows"]:
+            print(f"G={G} rank share, iterations {w['iterations']}: {w['ms_mean_over_shards']:.3f} ms per shard sweep (slowest shard {w['ms_slowest_shard_mean']:.3f}), "
+                  f"{w['events_per_shard_mean']:.0f} changes per shard, {w['events_all_shards']:.0f} in all", flush=True)
     for e, _, _ in engs:
         e.close()
 if a.json:
