@@ -52,7 +52,7 @@ struct jwas_hip_ctx {
         // consecutive groups of four; gcbuf: the corrections [2][gm bs] cG | [2][bs] cW | [2 bs] cP | [bs] zeros; gidx / gdelta:
         // [2][gm bs] the merged change lists of a group (ping-pong; header lines: ctx.ev[parity])
         int gm; float* gcross[2]; float* gcbuf; int32_t* gidx; float* gdelta;
-        unsigned long long* gpp;        // gm = 2: [3 bs + 8] tagged hand-over words of the ping-pong samplers (SamplerArgs::pp_words)
+        unsigned long long* gpp;        // tagged hand-over words of the ping-pong samplers (SamplerArgs::pp_*, GroupArgs::pp_*): (6 + 3 gm) bs + 8
     };
     unsigned pp_epoch = 0;              // tag of the last ping-pong launch (31 bits, never 0: a word of the zeroed buffer matches no launch)
     int set_index = 0;                  // entry of `sets` that is selected
@@ -907,9 +907,10 @@ int jwas_hip_setup_groups(jwas_hip_ctx* c, int32_t m, int32_t gram_mode)
     HIPCHK(c, hipMalloc(&B.gdelta, sizeof(float) * 2 * (size_t)m * bs));
     HIPCHK(c, hipMemsetAsync(B.gidx, 0, sizeof(int32_t) * 2 * (size_t)m * bs, c->stream));
     HIPCHK(c, hipMemsetAsync(B.gdelta, 0, sizeof(float) * 2 * (size_t)m * bs, c->stream));
-    if (m == 2) {
-        HIPCHK(c, hipMalloc(&B.gpp, sizeof(unsigned long long) * (3 * (size_t)bs + 8)));
-        HIPCHK(c, hipMemsetAsync(B.gpp, 0, sizeof(unsigned long long) * (3 * (size_t)bs + 8), c->stream));
+    {   // hand-over words of the ping-pong samplers: cW [2][bs] | counts [8] | cP part [2 bs] | cP [2 bs] | cG relay [3][m bs]
+        const size_t nw = 6 * (size_t)bs + 8 + 3 * (size_t)m * bs;
+        HIPCHK(c, hipMalloc(&B.gpp, sizeof(unsigned long long) * nw));
+        HIPCHK(c, hipMemsetAsync(B.gpp, 0, sizeof(unsigned long long) * nw, c->stream));
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     B.gm = m;
@@ -1834,7 +1835,7 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
             // front running beside the first block's chain.  Same chain, same bits; JWAS_HIP_PINGPONG=0|1 overrides (1: also in the
             // steady state, with the quiet XCD forced on).
             static const int pp_env = std::getenv("JWAS_HIP_PINGPONG") ? std::atoi(std::getenv("JWAS_HIP_PINGPONG")) : -1;
-            const bool pp_want = m == 2 && SET.gpp != nullptr && (pp_env >= 0 ? pp_env != 0 : U.quiet_xcd != 0);
+            const bool pp_want = SET.gpp != nullptr && (pp_env >= 0 ? pp_env != 0 : U.quiet_xcd != 0);
             SS.a[0].bsz = bs;
             if (K >= 1) {
                 const int64_t gs = K - 1, first = gs * m;
@@ -1854,10 +1855,14 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
                 G.corr_g_out = cb + off_g_out; G.corr_p = cb + off_p;
                 G.ev_idx = SET.gidx + (gs & 1) * gb; G.ev_delta = SET.gdelta + (gs & 1) * gb;
                 unsigned pp_tag = 0;
-                if (pp_want && G.ns == 2) {
+                // hand-over words (SET.gpp): cW [2][bs] | counts [8] | cP part [2 bs] | cP [2 bs] | cG relay [3][m bs]
+                unsigned long long* const pw_cw = SET.gpp, * const pw_cnt = pw_cw + 2 * (size_t)bs, * const pw_ph = pw_cnt + 8,
+                                  * const pw_cp = pw_ph + 2 * (size_t)bs, * const pw_h = pw_cp + 2 * (size_t)bs;
+                if (pp_want && G.ns >= 2) {
                     G.pp = 1; U.quiet_xcd = 1;
                     c->pp_epoch = (c->pp_epoch + 1) & 0x7fffffffu; if (c->pp_epoch == 0) c->pp_epoch = 1;
                     pp_tag = c->pp_epoch;
+                    G.pp_ph = pw_ph; G.pp_cp = pw_cp; G.pp_h = pw_h;
                 }
                 for (int s2 = 0; s2 < G.ns; ++s2) {
                     SamplerArgs& S = SS.a[s2];
@@ -1881,7 +1886,14 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
                     S.ev_out = &c->ev[gs & 1];
                     S.ev_idx = SET.gidx + (gs & 1) * gb; S.ev_delta = SET.gdelta + (gs & 1) * gb;
                     S.counters = c->counters;
-                    if (G.pp) { S.pp_words = SET.gpp; S.pp_role = s2 + 1; S.pp_tag = pp_tag; }
+                    if (G.pp) {
+                        S.pp_tag = pp_tag;
+                        S.pp_cw_in = (s2 & 1) ? pw_cw + (size_t)(s2 >> 1) * bs : nullptr;
+                        S.pp_cw_out = inner ? pw_cw + (size_t)(s2 >> 1) * bs : nullptr;
+                        S.pp_cp_in = (m == 4 && s2 >= 2) ? pw_cp + (size_t)(s2 - 2) * bs : nullptr;
+                        S.pp_cnt_in = s2 > 0 ? pw_cnt + (s2 - 1) : nullptr;
+                        S.pp_cnt_out = s2 + 1 < G.ns ? pw_cnt + s2 : nullptr;
+                    }
                 }
             }
             const bool timed = c->timing_stride > 0 && K < ng && (K % c->timing_stride) == 0;
@@ -2072,8 +2084,8 @@ static int sweep_collect(jwas_hip_ctx* c, jwas_sweep_stats* S, size_t ntimed, do
     NEED(c, h_cnt[kPpTimeoutCounter] == 0, JWAS_HIP_EHIP, "grouped launches: %llu hand-over words between the two sampler workgroups never arrived (results of this sweep are invalid)",
          h_cnt[kPpTimeoutCounter]);
     if (std::getenv("JWAS_HIP_DEBUG_PHASES"))
-        std::fprintf(stderr, "[jwas_hip] blocks=%lld events=%llu unstaged=%llu cycles: front=%llu cand=%llu stage=%llu serial=%llu write=%llu corr=%llu rounds=%llu slow_rounds=%llu stage: assign=%llu issue=%llu wait=%llu update wg0: share=%llu wait=%llu rest=%llu compact: blocks=%llu fallback=%llu walk=%llu verify=%llu role=%llu tailwait=%llu xwrite=%llu xchain=%llu (section_solve: blocks = sections solved, fallback = fallen back, walk..xwrite = cycles of y | mat-vec | combine | verify+apply | tail)\n",
-                     (long long)c->nblocks, h_cnt[0], h_cnt[1], h_cnt[2], h_cnt[3], h_cnt[4], h_cnt[5], h_cnt[6], h_cnt[9], h_cnt[7], h_cnt[8], h_cnt[10], h_cnt[11], h_cnt[12], h_cnt[13], h_cnt[14], h_cnt[15], h_cnt[16], h_cnt[17], h_cnt[18], h_cnt[19], h_cnt[20], h_cnt[21], h_cnt[22], h_cnt[23]);
+        std::fprintf(stderr, "[jwas_hip] blocks=%lld events=%llu unstaged=%llu cycles: front=%llu cand=%llu stage=%llu serial=%llu write=%llu corr=%llu rounds=%llu slow_rounds=%llu stage: assign=%llu issue=%llu wait=%llu update wg0: share=%llu wait=%llu rest=%llu compact: blocks=%llu fallback=%llu walk=%llu verify=%llu role=%llu tailwait=%llu xwrite=%llu xchain=%llu (section_solve: blocks = sections solved, fallback = fallen back, walk..xwrite = cycles of y | mat-vec | combine | verify+apply | tail) group: cP=%llu tail=%llu workgroups=%llu\n",
+                     (long long)c->nblocks, h_cnt[0], h_cnt[1], h_cnt[2], h_cnt[3], h_cnt[4], h_cnt[5], h_cnt[6], h_cnt[9], h_cnt[7], h_cnt[8], h_cnt[10], h_cnt[11], h_cnt[12], h_cnt[13], h_cnt[14], h_cnt[15], h_cnt[16], h_cnt[17], h_cnt[18], h_cnt[19], h_cnt[20], h_cnt[21], h_cnt[22], h_cnt[23], h_cnt[25], h_cnt[26], h_cnt[27]);
     float ms = 0.f;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev_start, c->ev_stop));
     S->sweep_ms = ms;

@@ -50,15 +50,17 @@ struct SamplerArgs {
     // changes go behind the ones of the group's earlier blocks, the header line (count, first 7 changes) is ev_out's
     const float* corr_in2; const float* corr_in3;
     int32_t* ev_idx; float* ev_delta;
-    // PING-PONG samplers (round 6; k_group_step with 2 blocks per launch): the pair's blocks are sampled by TWO workgroups -- block 0 by
-    // workgroup 0, block 1 by workgroup 8, whose front (state, constants, row-group partial sums: one memory latency) runs while block
-    // 0 is walked.  Block 0 hands over its lookahead correction cW and its number of changes through TAGGED 8-byte words
+    // PING-PONG samplers (round 6; k_group_step in the sampler-bound regimes): the blocks of a group are sampled by ONE WORKGROUP EACH
+    // (block s by workgroup 8 s, all idle on the sampler's XCD), every front -- state, constants, row-group partial sums: one memory
+    // latency -- running at launch start.  What a block needs from the blocks before it travels as TAGGED 8-byte words
     // {tag << 32 | payload} (one relaxed agent-scope store each, self-validating: the reader polls the word it needs until the tag is
-    // this launch's; nothing is ever reset, a tag is never seen twice).  One-directional -- workgroup 0 waits for nobody.
-    unsigned long long* pp_words; // [bsz] cW of block 1 (float bits); [bsz] = number of changes of block 0 (its list entries are visible then);
-                                  // [bsz + 8 ...) block 0's half of the next group's correction chain (k_group_step)
-    int pp_role;                  // 0: none; 1: block 0 of a split pair (publishes); 2: block 1 (waits)
-    unsigned pp_tag;              // this launch's tag
+    // this launch's; nothing is ever reset, a tag is never seen twice).  One-directional: a workgroup only ever waits for lower ones.
+    const unsigned long long* pp_cw_in;   // [bsz] cW of THIS block from the workgroup of the pair's first block, or NULL (corr_in is read)
+    const unsigned long long* pp_cp_in;   // [bsz] cP of THIS block from the workgroup of block 1 (4 blocks per launch), or NULL (corr_in3)
+    unsigned long long* pp_cw_out;        // [bsz] where this block posts the cW of the pair's second block, or NULL
+    const unsigned long long* pp_cnt_in;  // the number of list entries in front of this block's (posted by the block before), or NULL = ev_base
+    unsigned long long* pp_cnt_out;       // where this block posts the list length behind it (its entries acknowledged), or NULL = last block
+    unsigned pp_tag;                      // this launch's tag
 };
 
 constexpr int kPpTimeoutCounter = 24;      // sweep counter: hand-over words that never arrived (must stay 0; the host fails the sweep otherwise)
@@ -78,8 +80,8 @@ __device__ __forceinline__ void pp_post_word(unsigned long long* w, unsigned tag
 {
     __hip_atomic_store(w, ((unsigned long long)tag << 32) | (unsigned long long)payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// ping-pong, second block's workgroup: the number of changes of the pair's first block (posted with its list entries acknowledged)
-__device__ __forceinline__ int pp_first_count(const SamplerArgs& A) { return (int)pp_wait_word(A.pp_words + A.bsz, A.pp_tag, A.counters); }
+// ping-pong: the number of list entries in front of this block's (posted by the block before with its entries acknowledged)
+__device__ __forceinline__ int pp_count_in(const SamplerArgs& A) { return A.pp_cnt_in != nullptr ? (int)pp_wait_word(A.pp_cnt_in, A.pp_tag, A.counters) : 0; }
 
 // fp64 sum of one column's row-group partials in fixed (ascending row group) order; the first N loads are issued
 // back to back from clamped addresses (no load depends on another).

@@ -474,12 +474,12 @@ __device__ __forceinline__ int sampler_role_st(char* smem, const SamplerArgs& A,
         }
     }
     bool cand[2] = {false, false};
-    // PING-PONG (SamplerArgs::pp_role == 2: the second block of a pair, sampled by its own workgroup while the first block's
-    // workgroup is still walking): cW does not exist yet.  Everything else of the front -- one memory latency -- happens now; the
-    // right-hand side and the candidacy are finished below, when block 0's sampler has posted cW.
+    // PING-PONG (SamplerArgs::pp_cw_in / pp_cp_in: a block sampled by its own workgroup while the blocks before it are still being
+    // walked): cW and / or cP do not exist yet.  Everything else of the front -- one memory latency -- happens now; the right-hand side
+    // and the candidacy are finished below, when the workgroups before this one have posted them.
     bool pp_wait = false;
-    if constexpr (GROUP) pp_wait = A.pp_role == 2;
-    float pp_sum[2] = {0.f, 0.f}, pp_c2[2] = {0.f, 0.f}, pp_c3[2] = {0.f, 0.f};
+    if constexpr (GROUP) pp_wait = A.pp_cw_in != nullptr || A.pp_cp_in != nullptr;
+    float pp_sum[2] = {0.f, 0.f}, pp_c1[2] = {0.f, 0.f}, pp_c2[2] = {0.f, 0.f}, pp_c3[2] = {0.f, 0.f};
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int c = tid + q * kStepThreads;
@@ -490,9 +490,14 @@ __device__ __forceinline__ int sampler_role_st(char* smem, const SamplerArgs& A,
         const float dj = A.xpx[j];
         float co = 0.f;
         if constexpr (GROUP) {
-            const float co2 = A.corr_in2[c], co3 = A.corr_in3[c];
-            pp_c2[q] = co2; pp_c3[q] = co3;
-            if (!pp_wait) { co = A.corr_in[c]; co = (co + co2) + co3; }
+            const float co2 = A.corr_in2[c];
+            // (unconditional loads from always-valid buffers, the VALUE selected: a load under a condition on a pointer makes hipcc
+            // choose between address spaces)
+            float co1 = A.corr_in[c], co3 = A.corr_in3[c];
+            if (A.pp_cw_in != nullptr) co1 = 0.f;
+            if (A.pp_cp_in != nullptr) co3 = 0.f;
+            pp_c1[q] = co1; pp_c2[q] = co2; pp_c3[q] = co3;
+            co = (co1 + co2) + co3;                                       // (final unless a term is still on its way: pp_wait)
         } else co = A.corr_in[c];
         if constexpr (kR) {
             BayesRMarker bm;
@@ -535,8 +540,9 @@ __device__ __forceinline__ int sampler_role_st(char* smem, const SamplerArgs& A,
             for (int q = 0; q < 2; ++q) {
                 const int c = tid + q * kStepThreads;
                 if (c >= B) continue;
-                const float cw = __uint_as_float(pp_wait_word(A.pp_words + c, A.pp_tag, A.counters));
-                const float co = (cw + pp_c2[q]) + pp_c3[q];
+                const float cw = (A.pp_cw_in != nullptr) ? __uint_as_float(pp_wait_word(A.pp_cw_in + c, A.pp_tag, A.counters)) : pp_c1[q];
+                const float cp = (A.pp_cp_in != nullptr) ? __uint_as_float(pp_wait_word(A.pp_cp_in + c, A.pp_tag, A.counters)) : pp_c3[q];
+                const float co = (cw + pp_c2[q]) + cp;
                 const float rhs0 = pp_sum[q] + co;
                 rhs_lds[c] = rhs0;
                 const float a_in = acur[c];
@@ -727,9 +733,9 @@ __device__ __forceinline__ int sampler_role_st(char* smem, const SamplerArgs& A,
                     }
                     corr_cd[q] = corr;
                     // (ping-pong: block 1's workgroup is waiting for exactly this)
-                    if constexpr (GROUP) { if (A.pp_role == 1) pp_post_word(A.pp_words + c, A.pp_tag, __float_as_uint(corr)); }
+                    if constexpr (GROUP) { if (A.pp_cw_out != nullptr) pp_post_word(A.pp_cw_out + c, A.pp_tag, __float_as_uint(corr)); }
                 }
-                if constexpr (GROUP) pp_posted = A.pp_role == 1;
+                if constexpr (GROUP) pp_posted = A.pp_cw_out != nullptr;
                 compact_corr = true;
                 tkx[2] = clock64();
             }
@@ -1205,8 +1211,8 @@ __device__ __forceinline__ int sampler_role_st(char* smem, const SamplerArgs& A,
     // entries were acknowledged by the memory side -- long ago by now)
     int evb = ev_base;
     if constexpr (GROUP) {
-        if (A.pp_role == 2) {
-            if (tid == 0) wcnt_s[10] = (int)pp_wait_word(A.pp_words + B, A.pp_tag, A.counters);
+        if (A.pp_cnt_in != nullptr) {
+            if (tid == 0) wcnt_s[10] = (int)pp_wait_word(A.pp_cnt_in, A.pp_tag, A.counters);
             __syncthreads();
             evb = wcnt_s[10];
         }
@@ -1231,7 +1237,7 @@ __device__ __forceinline__ int sampler_role_st(char* smem, const SamplerArgs& A,
         else { eidx = A.ev_out->idx; edel = A.ev_out->delta[0]; }
         const int hb = GROUP ? evb : 0;                                         // (entries of the list in front of this block's)
         bool pp_first = false;                                                  // (ping-pong, first block: the second block's workgroup
-        if constexpr (GROUP) pp_first = A.pp_role == 1;                         //  reads these entries in THIS launch: write-through stores)
+        if constexpr (GROUP) pp_first = A.pp_cnt_out != nullptr;                //  reads these entries in THIS launch: write-through stores)
         for (int e = tid; e < nfin; e += kStepThreads) {
             const int ce = pairs ? fin[2 * e] : fin[e];
             const float d = astart[ce] - acur[ce];
@@ -1256,19 +1262,19 @@ __device__ __forceinline__ int sampler_role_st(char* smem, const SamplerArgs& A,
         }
     }
     if constexpr (GROUP) {
-        if (A.pp_role == 1) {
-            // the hand-over to the second block's workgroup: every store of this workgroup -- cW through corr_out on the paths that did
+        if (A.pp_cnt_out != nullptr) {
+            // the hand-over to the next block's workgroup: every store of this workgroup -- cW through corr_out on the paths that did
             // not post it themselves, the list entries -- has been acknowledged by the memory side (vmcnt counts a store out then)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (!pp_posted)
+            if (A.pp_cw_out != nullptr && !pp_posted)
                 for (int c = tid; c < B; c += kStepThreads)
-                    pp_post_word(A.pp_words + c, A.pp_tag, __hip_atomic_load(reinterpret_cast<const unsigned*>(A.corr_out) + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-            if (tid == 0) pp_post_word(A.pp_words + B, A.pp_tag, (unsigned)nfin);
+                    pp_post_word(A.pp_cw_out + c, A.pp_tag, __hip_atomic_load(reinterpret_cast<const unsigned*>(A.corr_out) + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            if (tid == 0) pp_post_word(A.pp_cnt_out, A.pp_tag, (unsigned)(evb + nfin));
         }
     }
     if (tid == 0) {
-        if (!(GROUP && A.pp_role == 1)) A.ev_out->count = (int32_t)((GROUP ? evb : 0) + nfin);      // (a split pair's count: its second block's)
+        if (!(GROUP && A.pp_cnt_out != nullptr)) A.ev_out->count = (int32_t)((GROUP ? evb : 0) + nfin);      // (a split group's count: its last block's)
         atomicAdd(&A.counters[0], (unsigned long long)nfin);
         atomicAdd(&A.counters[2], (unsigned long long)(tk1 - tk0));      // phase cycle counts (diagnostics)
         atomicAdd(&A.counters[3], (unsigned long long)(tk2 - tk1));

@@ -105,7 +105,8 @@ hipError_t launch_group_cx(const StepLaunch& L, const CX& cx, const UpdateArgs& 
         attr_set.fetch_or(dev_bit, std::memory_order_release);
     }
     const int nwork = L.nrg * U.ncg;
-    const unsigned grid = U.quiet_xcd ? (unsigned)(1 + (nwork + 6) / 7 * 8) : (unsigned)(1 + nwork);
+    unsigned grid = U.quiet_xcd ? (unsigned)(1 + (nwork + 6) / 7 * 8) : (unsigned)(1 + nwork);
+    if (G.pp != 0 && grid < 8u * (unsigned)(G.ns - 1) + 1u) grid = 8u * (unsigned)(G.ns - 1) + 1u;      // ping-pong: block s is sampled by workgroup 8 s
     hipLaunchKernelGGL((k_group_step<METHOD, CX>), dim3(grid), dim3(kStepThreads), SM.bytes, L.stream, U, uev_idx, uev_delta, SS, G);
     return hipSuccess;
 }

@@ -223,8 +223,11 @@ struct GroupArgs {
     float* corr_g_out;             // [m * bs] cG of the next group
     float* corr_p;                 // [2 * bs] cP
     const int32_t* ev_idx; const float* ev_delta;     // merged change list of the sampled group (capacity m * bs; header: the blocks' ev_out)
-    int pp;                        // PING-PONG samplers (m = 2, a full pair): block 0 in workgroup 0, block 1 + the group's correction in
-                                   // workgroup 8 (SamplerArgs::pp_role; the launcher keeps workgroup ids = 0 mod 8 free of update work)
+    int pp;                        // PING-PONG samplers: block s in workgroup 8 s (SamplerArgs::pp_*; the launcher keeps workgroup ids = 0 mod 8 free
+                                   // of update work and the grid large enough); relay buffers of tagged words:
+    unsigned long long* pp_ph;     // [2 bs] block 0's part of the cP chain
+    unsigned long long* pp_cp;     // [2 bs] cP (read by blocks 2 and 3)
+    unsigned long long* pp_h;      // [3][m bs] the cG chain after blocks 0, 1, 2
 };
 // The sampler arguments of the group's blocks, one full set per block, filled by the host (sweep_enqueue): block s reads ITS set
 // from the kernel-argument segment -- a copy of one set edited per block inside the kernel kept ~80 scalars live across the whole
@@ -245,7 +248,7 @@ __device__ __attribute__((noinline)) void group_corr_n(char* smem, const int32_t
                                                        const float* __restrict__ cross, int bn, float* __restrict__ out, int ncols_out, bool coherent,
                                                        const unsigned long long* seed, unsigned long long* post, unsigned tag, unsigned long long* counters)
 {
-    constexpr int R = 64 / NQ;
+    constexpr int R = NQ >= 8 ? 4 : 64 / NQ;          // (8 column slots = 4 x 1024-marker launches: a handful of changes per group; the pass of round 5)
     int* lrow = reinterpret_cast<int*>(smem);
     float* ld = reinterpret_cast<float*>(smem) + kStepThreads;
     const int tid = threadIdx.x;
@@ -312,29 +315,49 @@ __global__ __launch_bounds__(kStepThreads) void k_group_step(UpdateArgsT<CX> U, 
                                                              GroupSamplers SS, GroupArgs G)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // ping-pong (G.pp: a full pair, m = 2): workgroup 0 samples block 0, workgroup 8 -- idle on the sampler's XCD -- block 1, whose
-    // front overlaps block 0's chain (sampler_role_st, pp_role); the last block's workgroup forms the next group's correction
-    const bool second = G.pp != 0 && blockIdx.x == 8;
-    if (blockIdx.x == 0 || second) {
-        if (G.ns <= 0 || (second && G.ns < 2)) return;
-        const int s_lo = second ? 1 : 0, s_hi = (G.pp != 0 && !second) ? 1 : G.ns;
+    // ping-pong (G.pp): block s of the sampled group has its own workgroup, id 8 s -- idle on the sampler's XCD --, so that every
+    // block's front runs at launch start and only the chain itself is sequential (sampler_role_st, SamplerArgs::pp_*); the
+    // corrections for the blocks behind (cP inside a four, cG for the next group) are RELAYED: each workgroup continues the
+    // fused-multiply-add chain over its own block's changes from where the workgroup before it stopped (group_corr: seed / post)
+    const int pp_s = (G.pp != 0 && (blockIdx.x & 7u) == 0u && blockIdx.x < 32u) ? (int)(blockIdx.x >> 3) : -1;
+    if (blockIdx.x == 0 || pp_s > 0) {
+        if (G.ns <= 0 || pp_s >= G.ns) return;
+        const int s_lo = pp_s >= 0 ? pp_s : 0, s_hi = pp_s >= 0 ? pp_s + 1 : G.ns;
         int nev = 0;
+        const long long tg0 = clock64();
+        long long tgp = 0;
 #pragma unroll 1
         for (int s = s_lo; s < s_hi; ++s) {
-            nev = sampler_role_st<METHOD, false, true>(smem, SS.a[s], nev);      // (block 1 of a split pair: block 0's count + its own)
+            nev = sampler_role_st<METHOD, false, true>(smem, SS.a[s], nev);      // (-> the length of the merged list behind block s)
             __syncthreads();                                    // the block's global stores (cW, the list) are visible to the workgroup
-            if (s == 1 && G.cross_pair != nullptr && G.ns > 2)
+            if (pp_s < 0 && s == 1 && G.cross_pair != nullptr && G.ns > 2) {
+                const long long t0 = clock64();
                 group_corr(smem, G.ev_idx, G.ev_delta, 0, nev, G.j0, G.cross_pair, G.bn_pair, G.corr_p, 2 * SS.a[0].bsz);
+                tgp = clock64() - t0;
+            }
         }
-        if (G.cross_grp != nullptr) {
-            const int ncols = G.m * SS.a[0].bsz;
-            if (G.pp != 0 && G.ns == 2) {
-                // the next group's correction in two halves: workgroup 0 runs the chain over block 0's changes while block 1 is still
-                // being walked and posts it; workgroup 8 continues it over block 1's changes
-                unsigned long long* half = SS.a[0].pp_words + SS.a[0].bsz + 8;
-                if (!second) group_corr(smem, G.ev_idx, G.ev_delta, 0, nev, G.j0, G.cross_grp, G.bn_grp, nullptr, ncols, true, nullptr, half, SS.a[0].pp_tag, SS.a[0].counters);
-                else group_corr(smem, G.ev_idx, G.ev_delta, pp_first_count(SS.a[1]), nev, G.j0, G.cross_grp, G.bn_grp, G.corr_g_out, ncols, false, half, nullptr, SS.a[1].pp_tag, SS.a[1].counters);
-            } else if (s_hi == G.ns) group_corr(smem, G.ev_idx, G.ev_delta, 0, nev, G.j0, G.cross_grp, G.bn_grp, G.corr_g_out, ncols);
+        const long long tg1 = clock64();
+        const int bsz = SS.a[0].bsz, ncols = G.m * bsz;
+        if (pp_s >= 0) {
+            const SamplerArgs& A = SS.a[pp_s];
+            const int e_lo = pp_count_in(A);                    // this block's entries of the merged list: [e_lo, nev)
+            const bool mine_wt = A.pp_cnt_out != nullptr;       // (written through: read them back at the coherence point)
+            // cP (4 blocks per launch): the chain over blocks 0 and 1 for the columns of blocks 2 and 3 -- block 0's part, then block 1's
+            if (G.cross_pair != nullptr && G.ns > 2 && pp_s < 2)
+                group_corr(smem, G.ev_idx, G.ev_delta, e_lo, nev, G.j0, G.cross_pair, G.bn_pair, nullptr, 2 * bsz, mine_wt,
+                           pp_s == 0 ? nullptr : G.pp_ph, pp_s == 0 ? G.pp_ph : G.pp_cp, A.pp_tag, A.counters);
+            // cG of the next group: block s continues the chain of blocks 0 .. s-1; the last block stores the result
+            if (G.cross_grp != nullptr) {
+                const bool last = pp_s == G.ns - 1;
+                group_corr(smem, G.ev_idx, G.ev_delta, e_lo, nev, G.j0, G.cross_grp, G.bn_grp, last ? G.corr_g_out : nullptr, ncols, mine_wt,
+                           pp_s == 0 ? nullptr : G.pp_h + (size_t)(pp_s - 1) * ncols, last ? nullptr : G.pp_h + (size_t)pp_s * ncols, A.pp_tag, A.counters);
+            }
+        } else if (G.cross_grp != nullptr) group_corr(smem, G.ev_idx, G.ev_delta, 0, nev, G.j0, G.cross_grp, G.bn_grp, G.corr_g_out, ncols);
+        if (threadIdx.x == 0) {                                 // (diagnostics: cP pass | the corrections behind the last block | the whole workgroup)
+            const long long tg2 = clock64();
+            atomicAdd(&SS.a[0].counters[25], (unsigned long long)tgp);
+            atomicAdd(&SS.a[0].counters[26], (unsigned long long)(tg2 - tg1));
+            atomicAdd(&SS.a[0].counters[27], (unsigned long long)(tg2 - tg0));
         }
         return;
     }

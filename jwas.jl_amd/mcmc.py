@@ -118,7 +118,9 @@ GROUPED_BLOCKS_PER_LAUNCH = 4
 def grouped_blocks_for_chain(chain_length):
     """Blocks per grouped launch a chain of this length pays for: the group cross-Grams are set-up work (at 50 000 x 600 000:
     +1.7 s for 2 blocks per launch, +5 s for 4) against 0.6 / 0.9 ms saved per sweep of the sparse steady state."""
-    return GROUPED_BLOCKS_PER_LAUNCH if chain_length >= 8000 else (2 if chain_length >= 3000 else 0)
+    # (measured break-even, round 6: 4 blocks per launch + 4.1 s of set-up / 1.07 ms per sweep = 3 800 sweeps; 2 blocks: + 1.4 s / 0.6 ms
+    # = 2 300 -- the thresholds leave a margin of 1.3x, they were 8 000 / 3 000)
+    return GROUPED_BLOCKS_PER_LAUNCH if chain_length >= 5000 else (2 if chain_length >= 3000 else 0)
 
 
 def pingpong_pairs_for_chain(method, estimate_pi, chain_length):
@@ -127,6 +129,10 @@ def pingpong_pairs_for_chain(method, estimate_pi, chain_length):
     critical path: BayesR sheds its markers over hundreds of sweeps, a fixed pi keeps ~(1 - pi) p markers in the model for ever
     (config 3: 29.5 -> 26.8 ms per sweep, fixed pi = 0.95: 29.4 -> 27.0).  BayesC with pi estimated leaves that regime after ~25
     sweeps: not worth the pair cross-Grams (4 p 1024 bytes, 0.7 s at 50 000 x 600 000)."""
+    # (4 blocks per launch, one sampler workgroup per block: config 3 25.5 ms, fixed pi 26.1 ms per sweep for + 5 GB and + 1.1 s of
+    # cross-Grams -- pays for the chains that STAY in the regime: a fixed pi from 2 000 iterations on; BayesR leaves it after ~600 sweeps)
+    if chain_length >= 2000 and not estimate_pi and method != "BayesR":
+        return 4
     return 2 if (chain_length >= 300 and (method == "BayesR" or not estimate_pi)) else 0
 
 
@@ -623,6 +629,8 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
     pair_m = 0                                 # ... and ping-pong pairs on the 512-marker sweeps of a high-turnover chain (dense storage)
     if adaptive and not double_precision and explicit_partition is None and not independent_blocks and fast_blocks is False and not stream:
         pair_m = pingpong_pairs_for_chain(method, bool(Mi.estimatePi), chain_length) if blocks_per_launch is None else (2 if int(blocks_per_launch) else 0)
+        if pair_m == 4 and 4 * p * 512 * 6 > 0.05 * 288e9:      # (pair + four cross-Grams of the 512-marker set: keep them a small part of the HBM)
+            pair_m = 2
         if not grouped_launch_size(method, t, False, 512, pair_m):
             pair_m = 0
 
@@ -639,7 +647,7 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         if group_m:
             need += 4 * p * 2048 * (3 if group_m == 4 else 1)      # grouped launches: pair (and four) cross-Grams of the 1024-marker set
         if pair_m:
-            need += 4 * p * 1024                                   # ... and the pair cross-Grams of the 512-marker set
+            need += 4 * p * 1024 * (3 if pair_m == 4 else 1)      # ... and the pair (and four) cross-Grams of the 512-marker set
         if double_precision and independent_blocks:
             # Float64 independent blocks: one change list of 1024 entries per block (4 + 4 x 8 bytes per entry, whatever the
             # block size) and one partial-sum buffer per block (4 traits x row slices x block doubles)

@@ -9,6 +9,7 @@ the literal test caught it.  Cases here:
     bench.py config2), p >= 13 000 so that three full groups + a ragged one run and cG (group -> group), cP (pair -> pair) and cW
     (block -> block) all form; n = 5 200 (21 row slices, several row groups);
   * the same from 2-bit packed storage (bench.py --storage packed2bit): literal chain on the DECODED matrix;
+  * 512-marker pairs (2 blocks per launch, the ping-pong samplers of the sampler-bound sweeps: bench.py config3, --pi-fixed);
   * one block per launch at 512 markers with MANY candidates per block -- the compact candidate chain of config 3 (BayesR) and of
     a fixed pi (BayesC) -- and at 1024 markers (the compact chain from one candidate on).
 
@@ -66,12 +67,13 @@ def _compare(orc, hip, moved, min_moved):
 
 
 @pytest.mark.parametrize("method", ["BayesC", "BayesR"])
-@pytest.mark.parametrize("m", [2, 4])
-def test_grouped_1024_marker_launches_against_the_literal_chain(hip, method, m):
+@pytest.mark.parametrize("m,bs", [(2, 1024), (4, 1024), (2, 512)])
+def test_grouped_1024_marker_launches_against_the_literal_chain(hip, method, m, bs):
     """bench.py's headline schedule (k_group_step, 1024-marker blocks, MFMA Grams + k_cross_mfma128 group cross-Grams): 13 full
-    blocks + a ragged one = three full groups of four and a group of two (m = 4) / seven pairs (m = 2)."""
-    bs = 1024
-    data = make_dataset(n=5200, p=bs * 13 + 300, ncausal=40, seed=600 + m)
+    blocks + a ragged one = three full groups of four and a group of two (m = 4) / seven pairs (m = 2); and the 512-marker PAIRS of
+    the high-turnover sweeps (config 3, a fixed pi: the ping-pong samplers -- the first sweep of a chain and every sweep in which more
+    than 1.25 % of the markers changed run them)."""
+    data = make_dataset(n=5200, p=1024 * 13 + 300, ncausal=40, seed=600 + m)
     y = (data["y"] - data["y"].mean()).astype(np.float32)
     orc = _literal(data["X"], method, y)
     hip.load_dense(data["X"])

@@ -911,8 +911,8 @@ def test_multitrait_host_policies():
     on while the last sweep solved at least half of its sections, off for `probe` sweeps otherwise, then tried again."""
     from jwas_jl_amd.mcmc import pick_block_size_mt
     from jwas_jl_amd.engine import SectionSolvePolicy
-    assert pick_block_size_mt(99_000, 100_000) == 256 and pick_block_size_mt(25_000, 100_000) == 256
-    assert pick_block_size_mt(24_999, 100_000) == 512 and pick_block_size_mt(100, 100_000) == 512
+    assert pick_block_size_mt(99_000, 100_000) == 256 and pick_block_size_mt(10_000, 100_000) == 256      # (round 6: the dense walk down to 10 % turnover)
+    assert pick_block_size_mt(9_999, 100_000) == 512 and pick_block_size_mt(100, 100_000) == 512
 
     class Eng:
         def __init__(self): self.solved = 0
@@ -921,14 +921,14 @@ def test_multitrait_host_policies():
     e = Eng()
     pol = SectionSolvePolicy(True, nsections=1560, probe=50)
     used = []
-    for it in range(1, 161):
+    for it in range(1, 261):
         on = pol.use(it)
         used.append(on)
         e.solved = 1560 if it <= 20 else (700 if on else 0)        # from sweep 21 on fewer than half of the sections are solved
         pol.observe(it, e)
     assert all(used[:21])                                           # on, including the sweep that found out
     assert not any(used[21:71]) and used[71]                        # off for 50 sweeps, then one probe ...
-    assert not any(used[72:122]) and used[122]                      # ... which fails again
+    assert not any(used[72:172]) and used[172]                      # ... which fails again: back-off, 100 sweeps until the next probe (round 6)
     off = SectionSolvePolicy(False, 1560)
     assert not off.use(1)
     off.observe(1, e)                                               # (a no-op)
@@ -945,8 +945,13 @@ def test_grouped_launch_policy():
     of single-trait sparse chains only."""
     from jwas_jl_amd import mcmc as M
     assert M.grouped_blocks_for_chain(100) == 0 and M.grouped_blocks_for_chain(2999) == 0
-    assert M.grouped_blocks_for_chain(3000) == 2 and M.grouped_blocks_for_chain(7999) == 2
-    assert M.grouped_blocks_for_chain(8000) == M.GROUPED_BLOCKS_PER_LAUNCH == 4
+    assert M.grouped_blocks_for_chain(3000) == 2 and M.grouped_blocks_for_chain(4999) == 2
+    assert M.grouped_blocks_for_chain(5000) == M.GROUPED_BLOCKS_PER_LAUNCH == 4
+    # ping-pong pairs on the 512-marker sweeps: the chains that stay in the high-turnover regime (BayesR, a fixed pi)
+    assert M.pingpong_pairs_for_chain("BayesR", True, 300) == 2 and M.pingpong_pairs_for_chain("BayesC", False, 1000) == 2
+    assert M.pingpong_pairs_for_chain("BayesC", False, 2000) == 4 and M.pingpong_pairs_for_chain("BayesR", True, 10 ** 6) == 2
+    assert M.pingpong_pairs_for_chain("BayesC", True, 10 ** 6) == 0 and M.pingpong_pairs_for_chain("BayesR", True, 299) == 0
+    assert M.pick_block_size(5500, 600_000) == 1024 and M.pick_block_size(5500, 600_000, pairs=True) == 512
     for method in ("BayesC", "BayesB", "BayesA", "BayesR"):
         assert M.grouped_launch_size(method, 1, False, 1024, 4) == 1024
         assert M.grouped_launch_size(method, 1, False, 512, 4) == 512
