@@ -4,7 +4,7 @@ cd $GRAFT_REPO_ROOT
 L=jwas.jl_amd/csrc/libjwas_hip.so
 cp $L /tmp/new.so
 B="--no-cpu-baseline --via-api 0"
-for v in new r05 oldcorr oldfront new r05 oldcorr oldfront; do
+for v in new r05 notg notgrl new r05 notg notgrl; do
   if [ $v = new ]; then cp /tmp/new.so $L; else cp jwas.jl_amd/csrc/_dev/libjwas_hip_$v.so $L; fi
   JWAS_BENCH_GROUPS_SMALL=0 python bench.py $B --groups 4 --storage packed2bit 2>/dev/null | python -c "
 import json,sys

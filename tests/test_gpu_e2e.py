@@ -42,6 +42,47 @@ def test_runmcmc_with_grouped_launches_matches_oracle_chain(tmp_path, groups):
         float(outs["orc"]["residual variance"]["Estimate"][0]), rel=1e-4)
 
 
+@pytest.mark.parametrize("method,est", [("BayesR", True), ("BayesC", False)])
+def test_runmcmc_pingpong_pair_policy_matches_oracle_chain(tmp_path, method, est):
+    """The host's own choice (mcmc.pingpong_pairs_for_chain: BayesR and fixed-pi chains of >= 300 iterations run their 512-marker
+    sweeps as pairs with one sampler workgroup per block) -- nothing passed by the caller: the same host loop on the oracle engine
+    sets the same groups up (its grouped restatement) and takes the same decisions: the same number of effect changes in every one of
+    the first 100 sweeps (a chain of 450 changes per sweep at n = 300 is chaotic: the two hosts' float32-level differences in r'r flip
+    a decision somewhere beyond sweep 100 of the fixed-pi chain, after which only the BayesR pair is compared on its posterior means)."""
+    from jwas_jl_amd import engine as E
+    gdf, ph, d = _setup(method, 0.95, n=300, p=4700, seed=78)
+    outs, events, flags = {}, {}, {}
+    for tag, eng in (("orc", OracleEngine("lookahead")), ("hip", None)):
+        rec, grp = [], []
+        events[tag], flags[tag] = rec, grp
+        if eng is not None:
+            orig = eng.sweep
+            eng.sweep = lambda _o=orig, **kw: (lambda st: (rec.append(float(st["n_events"])), grp.append(bool(kw.get("group_launch"))), st)[2])(_o(**kw))
+        else:
+            orig_cls = E.HipEngine.sweep
+            def sw(self, _o=orig_cls, **kw):
+                st = _o(self, **kw); rec.append(float(st["n_events"])); grp.append(bool(kw.get("group_launch"))); return st
+            E.HipEngine.sweep = sw
+        try:
+            geno = api.get_genotypes(gdf, method=method, Pi=(0.0 if method == "BayesR" else 0.95), estimatePi=est)
+            model = api.build_model("y1 = intercept + geno")
+            outs[tag] = api.runMCMC(model, ph, chain_length=300, burnin=50, seed=13, output_folder=str(tmp_path / tag),
+                                    _engine=eng, gram_mode="f64", outputEBV=False)
+        finally:
+            if eng is None:
+                E.HipEngine.sweep = orig_cls
+        if tag == "orc":
+            assert eng.blocks_per_launch(512) == 2                      # (the policy did ask for the pairs)
+    assert all(flags["hip"][:100]) and all(flags["orc"][:100])          # ... and the sweeps ran them
+    assert events["hip"][:100] == events["orc"][:100]
+    assert min(events["hip"][:100]) > 0.0125 * 4700                     # (the high-turnover regime throughout)
+    if method == "BayesR":
+        eo = outs["orc"]["marker effects geno"]
+        eh = outs["hip"]["marker effects geno"]
+        np.testing.assert_allclose(eh["Estimate"], eo["Estimate"], atol=1e-4)
+        np.testing.assert_allclose(eh["Model_Frequency"], eo["Model_Frequency"], atol=1e-4)
+
+
 @pytest.mark.parametrize("method,Pi", [("BayesC", 0.95), ("BayesR", 0.0), ("BayesB", 0.9)])
 def test_runmcmc_gpu_matches_oracle_chain(tmp_path, method, Pi):
     gdf, ph, d = _setup(method, Pi)

@@ -67,11 +67,11 @@ def _compare(orc, hip, moved, min_moved):
 
 
 @pytest.mark.parametrize("method", ["BayesC", "BayesR"])
-@pytest.mark.parametrize("m,bs", [(2, 1024), (4, 1024), (2, 512)])
+@pytest.mark.parametrize("m,bs", [(2, 1024), (4, 1024), (2, 512), (4, 512)])
 def test_grouped_1024_marker_launches_against_the_literal_chain(hip, method, m, bs):
     """bench.py's headline schedule (k_group_step, 1024-marker blocks, MFMA Grams + k_cross_mfma128 group cross-Grams): 13 full
-    blocks + a ragged one = three full groups of four and a group of two (m = 4) / seven pairs (m = 2); and the 512-marker PAIRS of
-    the high-turnover sweeps (config 3, a fixed pi: the ping-pong samplers -- the first sweep of a chain and every sweep in which more
+    blocks + a ragged one = three full groups of four and a group of two (m = 4) / seven pairs (m = 2); and the 512-marker PAIRS / FOURS of
+    the high-turnover sweeps (config 3 / a fixed pi: the ping-pong samplers, one sampler workgroup per block -- the first sweep of a chain and every sweep in which more
     than 1.25 % of the markers changed run them)."""
     data = make_dataset(n=5200, p=1024 * 13 + 300, ncausal=40, seed=600 + m)
     y = (data["y"] - data["y"].mean()).astype(np.float32)
