@@ -1657,7 +1657,7 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
         NEED(c, P->var_effect_matrix || c->var_mat_resident, JWAS_HIP_EINVAL, "multi-trait BayesA/B needs per-marker effect covariances (var_effect_matrix, or jwas_hip_sample_marker_covariances)");
         NEED(c, !P->independent_blocks, JWAS_HIP_EUNSUP, "independent_blocks is not available with per-marker effect covariances");
         NEED(c, !P->log_prior_states_matrix, JWAS_HIP_EUNSUP, "marker-specific joint priors are not available with per-marker effect covariances");
-        NEED(c, mt_park_nf(c->block_size, t) != 0, JWAS_HIP_EUNSUP, "per-marker effect covariances need block_size * ntraits <= 2048 (got %d x %d)", c->block_size, t);
+        NEED(c, c->block_size * t <= 2048, JWAS_HIP_EUNSUP, "per-marker effect covariances need block_size * ntraits <= 2048 (got %d x %d)", c->block_size, t);
         const size_t mb = sizeof(float) * (size_t)t * t * c->p;
         if (P->var_effect_matrix) { int rc = upload_vec(c, (void**)&c->var_mat, P->var_effect_matrix, mb); if (rc) return rc; c->var_mat_resident = true; }
         if (!c->ginv_mat) HIPCHK(c, hipMalloc(&c->ginv_mat, mb));

@@ -76,8 +76,10 @@ struct StepSmem {
 
 // Multi-trait samplers park the per-marker draws of repetition 0 (NT thresholds + NT normals, fp64) and x'x in LDS
 // when the block is small enough to leave room for the staged Gram rows; otherwise the serial wave reads them from HBM.
-__host__ __device__ constexpr int mt_park_nd(int B, int NT) { return (B * NT <= 2048) ? 2 * NT : 0; }
-__host__ __device__ constexpr int mt_park_nf(int B, int NT) { return (B * NT <= 2048) ? 1 + NT : 0; }   // x'x, log C11 per trait
+// (round 6: up to 3072 = 1024 markers x 3 traits -- four Gram rows still fit beside them, which is what the SPARSE steady state of a
+// multi-trait chain needs: half the launches and fronts of 512-marker blocks)
+__host__ __device__ constexpr int mt_park_nd(int B, int NT) { return (B * NT <= 3072) ? 2 * NT : 0; }
+__host__ __device__ constexpr int mt_park_nf(int B, int NT) { return (B * NT <= 3072) ? 1 + NT : 0; }   // x'x, log C11 per trait
 
 }  // namespace jw
 
