@@ -254,8 +254,8 @@ int  jwas_hip_add_block_size(jwas_hip_ctx* ctx, int32_t block_size, int32_t gram
 int  jwas_hip_select_block_size(jwas_hip_ctx* ctx, int32_t block_size);
 /* Grouped launches (jwas_sweep_params.group_launch) for the SELECTED block size: blocks_per_launch = 2 or 4 consecutive blocks
  * per launch of the step kernel (block_size * blocks_per_launch <= 4096), 0 = free the buffers again.  Builds the cross-Grams of
- * consecutive pairs (and, 4: fours) of blocks -- 8 * p * block_size bytes for the pairs, 16 * p * block_size for the fours
- * (24 * p * block_size in all at 4 blocks per launch) -- once; needs uniform blocks.  The
+ * consecutive pairs (2 blocks per launch: 8 * p * block_size bytes) or of the odd pairs and the fours (4 blocks per launch:
+ * 4 + 16 = 20 * p * block_size bytes) -- once; needs uniform blocks.  The
  * reference has no counterpart: like the block size it is a schedule knob of the device (BayesABC.jl:145-187 is the chain). */
 int  jwas_hip_setup_groups(jwas_hip_ctx* ctx, int32_t blocks_per_launch, int32_t gram_mode);
 /* Explicit, possibly non-uniform block partition: fast_blocks = a vector of block starts (JWAS.jl:298-304,

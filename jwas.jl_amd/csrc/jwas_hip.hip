@@ -884,7 +884,8 @@ int jwas_hip_setup_groups(jwas_hip_ctx* c, int32_t m, int32_t gram_mode)
         // (m = 4 reads the pair -> pair cross-Grams INSIDE a four only: the odd pairs; the even ones are part of level 1)
         const bool odd_only = (m == 4 && lvl == 0);
         const int64_t nlaunch = odd_only ? ngr / 2 : ngr - 1;            // cross blocks 1, 3, 5, ... < ngr  /  1 .. ngr - 1
-        HIPCHK(c, hipMalloc(&B.gcross[lvl], sizeof(float) * (size_t)ngr * gb * gb));
+        // (the odd pairs are stored compactly -- pair 2q + 1 at q: half the bytes of the pair level at 4 blocks per launch)
+        HIPCHK(c, hipMalloc(&B.gcross[lvl], sizeof(float) * (size_t)(odd_only ? std::max<int64_t>(nlaunch, 1) : ngr) * gb * gb));
         if (nlaunch > 0) {
             NEED(c, nlaunch <= 65535, JWAS_HIP_EUNSUP, "grouped launches: too many groups (%lld)", (long long)ngr);
             with_cols(c, 0, [&](auto Xc) {
@@ -1852,7 +1853,7 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
                     G.bn_grp = (int)std::min<int64_t>(gb, c->p - (gs + 1) * gb);
                 }
                 if (m == 4 && G.ns > 2) {
-                    G.cross_pair = SET.gcross[0] + (size_t)(2 * gs + 1) * (2 * (size_t)bs) * (2 * (size_t)bs);
+                    G.cross_pair = SET.gcross[0] + (size_t)gs * (2 * (size_t)bs) * (2 * (size_t)bs);      // (pair 2 gs + 1, stored at gs)
                     G.bn_pair = (int)std::min<int64_t>(2 * (int64_t)bs, c->p - (first + 2) * bs);
                 }
                 G.corr_g_out = cb + off_g_out; G.corr_p = cb + off_p;

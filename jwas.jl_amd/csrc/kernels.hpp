@@ -1063,7 +1063,7 @@ __global__ __launch_bounds__(256) void k_cross_mfma128(CX cx, int64_t p, int bsi
     if (tj * 128 >= b) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;                         // wave's 64 x 64 quarter
-    float* G = gram + blk * (int64_t)bsize * bsize;
+    float* G = gram + (cross == 2 ? (blk >> 1) : blk) * (int64_t)bsize * bsize;      // (odd blocks only: stored compactly, block 2q + 1 at q)
 
     // staging: thread -> (marker m = tid/8 + 32 u, float4 q = tid%8), u = 0..3
     const int sm = tid >> 3, sq = tid & 7;

@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256) void k_cross_f64(CX cx, int64_t p, int bsize,
     const int b = starts ? (int)(starts[blk + 1] - j0) : (int)((j0 + bsize <= p) ? bsize : (p - j0));
     const int a = blockIdx.x;
     if (a >= (int)(j0 - jp)) return;                   // (explicit starts: the previous block may be shorter than bsize)
-    float* C = cross + blk * (int64_t)bsize * bsize;
+    float* C = cross + (odd_only ? (blk >> 1) : blk) * (int64_t)bsize * bsize;      // (odd blocks only: stored compactly, block 2q + 1 at q)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int c = wave; c < b; c += 4) {
         double s = 0.0;

@@ -629,7 +629,7 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
     pair_m = 0                                 # ... and ping-pong pairs on the 512-marker sweeps of a high-turnover chain (dense storage)
     if adaptive and not double_precision and explicit_partition is None and not independent_blocks and fast_blocks is False and not stream:
         pair_m = pingpong_pairs_for_chain(method, bool(Mi.estimatePi), chain_length) if blocks_per_launch is None else (2 if int(blocks_per_launch) else 0)
-        if pair_m == 4 and 4 * p * 512 * 6 > 0.05 * 288e9:      # (pair + four cross-Grams of the 512-marker set: keep them a small part of the HBM)
+        if pair_m == 4 and 4 * p * 512 * 5 > 0.05 * 288e9:      # (pair + four cross-Grams of the 512-marker set: keep them a small part of the HBM)
             pair_m = 2
         if not grouped_launch_size(method, t, False, 512, pair_m):
             pair_m = 0
@@ -645,9 +645,9 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         if adaptive or adaptive_mt:
             need += 2 * 4 * (1024 if adaptive else 512) * p        # the second resident block size (Grams + cross-Grams)
         if group_m:
-            need += 4 * p * 2048 * (3 if group_m == 4 else 1)      # grouped launches: pair (and four) cross-Grams of the 1024-marker set
+            need += 4 * p * 1024 * (5 if group_m == 4 else 2)      # grouped launches: pair (4 blocks: the odd pairs + the fours) cross-Grams of the 1024-marker set
         if pair_m:
-            need += 4 * p * 1024 * (3 if pair_m == 4 else 1)      # ... and the pair (and four) cross-Grams of the 512-marker set
+            need += 4 * p * 512 * (5 if pair_m == 4 else 2)       # ... and the pair (4 blocks: odd pairs + fours) cross-Grams of the 512-marker set
         if double_precision and independent_blocks:
             # Float64 independent blocks: one change list of 1024 entries per block (4 + 4 x 8 bytes per entry, whatever the
             # block size) and one partial-sum buffer per block (4 traits x row slices x block doubles)
