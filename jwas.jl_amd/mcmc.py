@@ -129,9 +129,10 @@ def pingpong_pairs_for_chain(method, estimate_pi, chain_length):
     critical path: BayesR sheds its markers over hundreds of sweeps, a fixed pi keeps ~(1 - pi) p markers in the model for ever
     (config 3: 29.5 -> 26.8 ms per sweep, fixed pi = 0.95: 29.4 -> 27.0).  BayesC with pi estimated leaves that regime after ~25
     sweeps: not worth the pair cross-Grams (4 p 1024 bytes, 0.7 s at 50 000 x 600 000)."""
-    # (4 blocks per launch, one sampler workgroup per block: config 3 25.5 ms, fixed pi 26.1 ms per sweep for + 5 GB and + 1.1 s of
-    # cross-Grams -- pays for the chains that STAY in the regime: a fixed pi from 2 000 iterations on; BayesR leaves it after ~600 sweeps)
-    if chain_length >= 2000 and not estimate_pi and method != "BayesR":
+    # (4 blocks per launch, one sampler workgroup per block: config 3 25.2 ms, fixed pi 26.1 ms per sweep against 26.6 / 27.0 with pairs,
+    # for + 2.5 GB and + 1.1 s of cross-Grams: pays from ~800 high-turnover sweeps on -- a fixed pi stays in the regime for ever, config 3's
+    # BayesR chain runs its first ~1 300 sweeps on 512-marker blocks)
+    if chain_length >= 2000 and (method == "BayesR" or not estimate_pi):
         return 4
     return 2 if (chain_length >= 300 and (method == "BayesR" or not estimate_pi)) else 0
 

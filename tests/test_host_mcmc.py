@@ -949,7 +949,7 @@ def test_grouped_launch_policy():
     assert M.grouped_blocks_for_chain(5000) == M.GROUPED_BLOCKS_PER_LAUNCH == 4
     # ping-pong pairs on the 512-marker sweeps: the chains that stay in the high-turnover regime (BayesR, a fixed pi)
     assert M.pingpong_pairs_for_chain("BayesR", True, 300) == 2 and M.pingpong_pairs_for_chain("BayesC", False, 1000) == 2
-    assert M.pingpong_pairs_for_chain("BayesC", False, 2000) == 4 and M.pingpong_pairs_for_chain("BayesR", True, 10 ** 6) == 2
+    assert M.pingpong_pairs_for_chain("BayesC", False, 2000) == 4 and M.pingpong_pairs_for_chain("BayesR", True, 10 ** 6) == 4
     assert M.pingpong_pairs_for_chain("BayesC", True, 10 ** 6) == 0 and M.pingpong_pairs_for_chain("BayesR", True, 299) == 0
     assert M.pick_block_size(5500, 600_000) == 1024 and M.pick_block_size(5500, 600_000, pairs=True) == 512
     for method in ("BayesC", "BayesB", "BayesA", "BayesR"):
