@@ -241,6 +241,7 @@ __device__ __forceinline__ void dense_big_st(char* smem, const StepSmem& SM, con
 // (fixed pi = 0.95: 17 % of the blocks without the margin).  A candidate that does not move is an exact no-op everywhere
 // (its row is staged, it is walked, its change is 0): the margin changes speed only.
 constexpr float kCandMargin = 0.9375f;
+constexpr float kCandMarginLate = 0.90f;       // ping-pong blocks that stage before their right-hand side is finished (sampler_role_st, pp_late)
 constexpr int kCompactMin = 6;          // fewer candidates: the speculative rounds are as fast
 constexpr int kCompactMax = 64;         // one lane per candidate
 
@@ -479,6 +480,16 @@ __device__ __forceinline__ int sampler_role_st(char* smem, const SamplerArgs& A,
     // and the candidacy are finished below, when the workgroups before this one have posted them.
     bool pp_wait = false;
     if constexpr (GROUP) pp_wait = A.pp_cw_in != nullptr || A.pp_cp_in != nullptr;
+    // LATE hand-over (single-pass sweeps of >= 256-marker blocks): the candidacy is decided PROVISIONALLY from the right-hand side
+    // without the terms that are still on their way, with a wider margin (kCandMarginLate), and the slots, the candidates' Gram rows
+    // and the cross-Gram pieces are staged BEFORE the block waits -- slot assignment and the rows' memory latency leave the chain of the
+    // group's blocks too.  When the terms arrive the right-hand side is finished; a marker that is a candidate only now (rare: it
+    // needs a shift of > 4 % of its threshold) sends the block through the speculative rounds from its first sub-block, where every
+    // marker is evaluated against the finished right-hand side (rows that are not staged are fetched on demand) -- exact either way,
+    // the provisional set only decides what is walked and staged.  (Final form: such a block is simply staged a second time with the
+    // union of the two candidate sets -- what it cost before -- and goes on as ever.)
+    const bool pp_late = pp_wait && !prestage && ((P->nreps > 0 ? P->nreps : b) == 1);
+    const float cmarg = pp_late ? kCandMarginLate : kCandMargin;
     float pp_sum[2] = {0.f, 0.f}, pp_c1[2] = {0.f, 0.f}, pp_c2[2] = {0.f, 0.f}, pp_c3[2] = {0.f, 0.f};
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -511,7 +522,7 @@ __device__ __forceinline__ int sampler_role_st(char* smem, const SamplerArgs& A,
             acur[c] = a_in; astart[c] = a_in;
             bm.store_fast(lpd, B, c);
             lpf[c] = dj; lpf[B + c] = thrx;
-            cand[q] = (c < b) && ((a_in != 0.f) || (fabsf(rhs0) >= thrx * kCandMargin));
+            cand[q] = (c < b) && ((a_in != 0.f) || (fabsf(rhs0) >= thrx * cmarg));
             dpark0[c] = 1.f;                      // a marker that stays out: class 1 (see the prefix skip below)
         } else {
             const double zs = A.prep_d[3 * p + j];
@@ -527,13 +538,13 @@ __device__ __forceinline__ int sampler_role_st(char* smem, const SamplerArgs& A,
             // Rule D sweeps: nothing is ever excluded, so the slots of the "excluded" draw and of the lower threshold carry
             // c1 and c0 instead (512-marker blocks leave no LDS for two more rows next to dense_big_st's 128 KB of tiles)
             if constexpr (DENSE) { lpf[B + c] = A.prep_f[5 * p + j]; lpf[3 * B + c] = A.prep_f[6 * p + j]; }
-            cand[q] = (c < b) && ((a_in != 0.f) || abc_included(rhs0, lo * kCandMargin, hi * kCandMargin));      // (alpha = 0: lo <= 0 <= hi)
+            cand[q] = (c < b) && ((a_in != 0.f) || abc_included(rhs0, lo * cmarg, hi * cmarg));      // (alpha = 0: lo <= 0 <= hi)
             always_mine = always_mine && ((c >= b) || (lo == hi));           // thresholds(): lo = hi <=> always included
             bpark0[c] = bex; dpark0[c] = 0.f;     // a marker that stays out: delta 0, beta = its excluded draw
         }
     }
     if constexpr (GROUP) {
-        if (pp_wait) {
+        if (pp_wait && !pp_late) {
             // the hand-over: every thread polls the tagged words of ITS markers (block 0's sampler posts them the moment its
             // correction chain is done), then   rhs = fl32(sum) + ((cW + cG) + cP)   and the candidacy, exactly as above
 #pragma unroll
@@ -611,7 +622,7 @@ __device__ __forceinline__ int sampler_role_st(char* smem, const SamplerArgs& A,
     }
     // single-pass sweeps with a next block: waves 1..4 accumulate its lookahead correction while the serial wave runs
     const bool stream_corr = ((P->nreps > 0 ? P->nreps : b) == 1) && !prestage && A.b_next > 0;
-    if (tid == 0) { int* wc0 = reinterpret_cast<int*>(smem + SM.wcnt_off); wc0[8] = 0; wc0[9] = 0; wc0[12] = 0; wc0[13] = 0; wc0[14] = 0; }
+    if (tid == 0) { int* wc0 = reinterpret_cast<int*>(smem + SM.wcnt_off); wc0[8] = 0; wc0[9] = 0; wc0[10] = 0; wc0[12] = 0; wc0[13] = 0; wc0[14] = 0; }
     if (stream_corr) for (int c = tid; c < B; c += kStepThreads) reinterpret_cast<int2*>(smem + SM.log_off)[c] = make_int2(-1, 0);
     // small dense blocks (most markers are candidates): the serial wave walks them section by section (below) -- on strictly
     // upper diagonal tiles (mask_diagonal_tile); the rows are not read again after the walk (single pass)
@@ -649,6 +660,11 @@ __device__ __forceinline__ int sampler_role_st(char* smem, const SamplerArgs& A,
     xr_v4f xr[kXR];
     bool xreg = false;
     int nstaged = prestage ? b : 0;
+    bool pp_newc = false;
+    // (two passes at most: the second one only for a ping-pong block whose finished right-hand side shows a candidate the
+    // provisional staging did not see -- it is staged again with the union, i.e. at the cost the block had before pp_late)
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
     if (!prestage && !(first_sub >= 16 && single_pass_st)) {
         nstaged = stage_assign(smem, SM, A, cand, ncand_total);
         xreg = xreg_geom && ncand_total >= cmin && ncand_total <= kCompactMax && ncand_total <= SM.max_cand;
@@ -675,6 +691,51 @@ __device__ __forceinline__ int sampler_role_st(char* smem, const SamplerArgs& A,
         if (split) stage_load(smem, SM, A, nstaged, tss, 2, true);
         else stage_load(smem, SM, A, nstaged, tss);
     }
+    if (pass == 1) break;
+    // ---- the LATE hand-over (pp_late, above): the block has staged everything it could; now it waits
+    bool again = false;
+    if constexpr (GROUP) {
+        if (pp_late) {
+            bool nw = false;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int c = tid + q * kStepThreads;
+                if (c >= B) continue;
+                const float cw = (A.pp_cw_in != nullptr) ? __uint_as_float(pp_wait_word(A.pp_cw_in + c, A.pp_tag, A.counters)) : pp_c1[q];
+                const float cp = (A.pp_cp_in != nullptr) ? __uint_as_float(pp_wait_word(A.pp_cp_in + c, A.pp_tag, A.counters)) : pp_c3[q];
+                const float co = (cw + pp_c2[q]) + cp;
+                const float rhs0 = pp_sum[q] + co;            // rhs = fl32(sum) + ((cW + cG) + cP), as ever
+                rhs_lds[c] = rhs0;
+                const float a_in = acur[c];
+                bool ct;
+                if constexpr (kR) ct = (c < b) && ((a_in != 0.f) || (fabsf(rhs0) >= lpf[B + c] * kCandMargin));
+                else ct = (c < b) && ((a_in != 0.f) || abc_included(rhs0, lpf[3 * B + c] * kCandMargin, lpf[4 * B + c] * kCandMargin));
+                nw = nw || (ct && !cand[q]);
+                cand[q] = cand[q] || ct;                      // (the union: what was staged stays a candidate -- a no-op where it does not move)
+            }
+            int* wc = reinterpret_cast<int*>(smem + SM.wcnt_off);
+            if (__any(nw) && lane == 0) wc[10] = 1;
+            // (the sub-blocks that hold a candidate, once more: wave slots 0..7 of the vote are free again)
+            const int f0 = __any(cand[0]) ? 1 : 0, f1 = __any(cand[1]) ? 2 : 0;
+            __syncthreads();                                  // (every wave has read the first vote long ago; rhs_lds is complete)
+            pp_newc = wc[10] != 0;
+            if (pp_newc) {
+                // a candidate the provisional evaluation did not see: slots, rows and pieces once more for the union, and the first
+                // sub-block with a candidate from the finished right-hand side
+                if (lane == 0) wc[wave] = f0 | f1;
+                __syncthreads();
+                unsigned mask = 0u;
+#pragma unroll
+                for (int q = 0; q < kStepThreads / 64; ++q) { const int v = wc[q]; mask |= (unsigned)(v & 1) << q | (unsigned)((v >> 1) & 1) << (8 + q); }
+                first_sub = mask ? __builtin_ctz(mask) : 16;
+                if (tid == 0) atomicAdd(&A.counters[29], 1ull);
+                __syncthreads();                              // (stage_assign reuses the wave slots)
+                again = true;
+            }
+        }
+    }
+    if (!again) break;
+    }   // staging passes
     // ---- COMPACT CHAIN (see compact_walk): all candidates staged, one lane each
     bool compact_done = false, compact_corr = false;      // compact_corr: ... and the next block's lookahead correction is in corr_cd
     bool pp_posted = false;                                // ping-pong, first block: cW has been posted to the second block's workgroup

@@ -360,6 +360,7 @@ __global__ __launch_bounds__(kStepThreads) void k_group_step(UpdateArgsT<CX> U, 
             atomicAdd(&SS.a[0].counters[25], (unsigned long long)tgp);
             atomicAdd(&SS.a[0].counters[26], (unsigned long long)(tg2 - tg1));
             atomicAdd(&SS.a[0].counters[27], (unsigned long long)(tg2 - tg0));
+            if (pp_s == G.ns - 1) atomicAdd(&SS.a[0].counters[28], (unsigned long long)(tg2 - tg0));      // ping-pong: the LAST block's workgroup, start to end
         }
         return;
     }
@@ -371,8 +372,10 @@ __global__ __launch_bounds__(kStepThreads) void k_group_step(UpdateArgsT<CX> U, 
     if (w >= U.nrg * U.ncg) return;
     // (no rolling-window apply here: grouped launches run the sparse steady state -- a handful of changes per group -- and the
     // window's 32 columns in registers are what pushed this kernel, with its sampler loop, into scratch memory)
-    update_role<1, CX, false, false, EvGroup>(smem, w % U.nrg, w / U.nrg, U.cx, U.r_in, U.r_out, EvGroup{U.ev, uev_idx, uev_delta}, U.j0, U.b,
-                                              U.nslices, U.nrg, U.ncg, U.partials, U.bstride, U.spg, nullptr, nullptr, U.dbg);
+    // (the cooperative apply -- the column groups of a row group share the rows of the merged list's columns instead of every one of
+    // them re-reading all of them -- when the host passes the arrival counters: the high-turnover sweeps, 60-120 changes per launch)
+    update_role<1, CX, true, false, EvGroup>(smem, w % U.nrg, w / U.nrg, U.cx, U.r_in, U.r_out, EvGroup{U.ev, uev_idx, uev_delta}, U.j0, U.b,
+                                             U.nslices, U.nrg, U.ncg, U.partials, U.bstride, U.spg, U.sync_now, U.sync_next, U.dbg);
 }
 
 // Cross-Gram of consecutive blocks, exact (fp64-accumulated): C[a][c] = x_{jp+a}' x_{j0+c}.
