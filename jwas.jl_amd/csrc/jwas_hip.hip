@@ -1850,6 +1850,7 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
             // count was -- the host keeps those sweeps on 512-marker pairs down to 0.9 % turnover, and without it a pair costs 46.9 instead
             // of 40.2 us at 6 300 changes per sweep)
             const bool pp_want = SET.gpp != nullptr && (pp_env >= 0 ? pp_env != 0 : (U.quiet_xcd != 0 || bs <= 512));
+            G.pp_kernel = (pp_want || gcoop) ? 1 : 0;            // (constant over the sweep's launches)
             SS.a[0].bsz = bs;
             if (K >= 1) {
                 const int64_t gs = K - 1, first = gs * m;

@@ -396,9 +396,13 @@ __host__ __device__ constexpr int st_park_nf(int method, bool dense = false) { (
 // it, and full 256- / 512-marker blocks take dense_big_st.  The steady-state kernel is compiled without any of it.
 // GROUP (k_group_step): the block is one of a group of consecutive blocks sampled by ONE launch -- three lookahead corrections
 // instead of one, its changes appended to the group's merged list at ev_base.  Returns the length of that list behind the block.
-template <int METHOD, bool DENSE = false, bool GROUP = false>
+// PP: the grouped kernel's ping-pong instantiation (hand-over words, late hand-over); without it none of that code exists in the kernel
+// (the steady-state grouped launches: its mere presence cost the 2-bit packed sweep 7 %).
+template <int METHOD, bool DENSE = false, bool GROUP = false, bool PP = false>
 __device__ __forceinline__ int sampler_role_st(char* smem, const SamplerArgs& A, int ev_base = 0)
 {
+    static_assert(GROUP || !PP, "ping-pong samplers exist in grouped launches only");
+    constexpr bool kPP = GROUP && PP;
     static_assert(!(GROUP && DENSE), "grouped launches run the general single-trait sampler");
     constexpr bool kR = (METHOD == kBayesR);
     constexpr int ND = st_park_nd(METHOD), NF = st_park_nf(METHOD, DENSE);
@@ -479,7 +483,7 @@ __device__ __forceinline__ int sampler_role_st(char* smem, const SamplerArgs& A,
     // walked): cW and / or cP do not exist yet.  Everything else of the front -- one memory latency -- happens now; the right-hand side
     // and the candidacy are finished below, when the workgroups before this one have posted them.
     bool pp_wait = false;
-    if constexpr (GROUP) pp_wait = A.pp_cw_in != nullptr || A.pp_cp_in != nullptr;
+    if constexpr (kPP) pp_wait = A.pp_cw_in != nullptr || A.pp_cp_in != nullptr;
     // LATE hand-over (single-pass sweeps of >= 256-marker blocks): the candidacy is decided PROVISIONALLY from the right-hand side
     // without the terms that are still on their way, with a wider margin (kCandMarginLate), and the slots, the candidates' Gram rows
     // and the cross-Gram pieces are staged BEFORE the block waits -- slot assignment and the rows' memory latency leave the chain of the
@@ -488,7 +492,7 @@ __device__ __forceinline__ int sampler_role_st(char* smem, const SamplerArgs& A,
     // marker is evaluated against the finished right-hand side (rows that are not staged are fetched on demand) -- exact either way,
     // the provisional set only decides what is walked and staged.  (Final form: such a block is simply staged a second time with the
     // union of the two candidate sets -- what it cost before -- and goes on as ever.)
-    const bool pp_late = pp_wait && !prestage && ((P->nreps > 0 ? P->nreps : b) == 1);
+    const bool pp_late = kPP && pp_wait && !prestage && ((P->nreps > 0 ? P->nreps : b) == 1) && !(A.compact_off & 4);
     const float cmarg = pp_late ? kCandMarginLate : kCandMargin;
     float pp_sum[2] = {0.f, 0.f}, pp_c1[2] = {0.f, 0.f}, pp_c2[2] = {0.f, 0.f}, pp_c3[2] = {0.f, 0.f};
 #pragma unroll
@@ -505,9 +509,11 @@ __device__ __forceinline__ int sampler_role_st(char* smem, const SamplerArgs& A,
             // (unconditional loads from always-valid buffers, the VALUE selected: a load under a condition on a pointer makes hipcc
             // choose between address spaces)
             float co1 = A.corr_in[c], co3 = A.corr_in3[c];
-            if (A.pp_cw_in != nullptr) co1 = 0.f;
-            if (A.pp_cp_in != nullptr) co3 = 0.f;
-            pp_c1[q] = co1; pp_c2[q] = co2; pp_c3[q] = co3;
+            if constexpr (kPP) {
+                if (A.pp_cw_in != nullptr) co1 = 0.f;
+                if (A.pp_cp_in != nullptr) co3 = 0.f;
+                pp_c1[q] = co1; pp_c2[q] = co2; pp_c3[q] = co3;
+            }
             co = (co1 + co2) + co3;                                       // (final unless a term is still on its way: pp_wait)
         } else co = A.corr_in[c];
         if constexpr (kR) {
@@ -515,7 +521,7 @@ __device__ __forceinline__ int sampler_role_st(char* smem, const SamplerArgs& A,
             bm.load_fast_global(A.prep_d, p, j, dj, ie);
             const float thrx = A.prep_f[j];
             const double sum = sum_partials(A.partials + cc, A.nrg, A.bstride);
-            pp_sum[q] = (float)sum;
+            if constexpr (kPP) pp_sum[q] = (float)sum;
             const float rhs0 = (float)sum + co;
             rhs_lds[c] = rhs0;
             const float a_in = (c < b) ? a0 : 0.f;
@@ -528,7 +534,7 @@ __device__ __forceinline__ int sampler_role_st(char* smem, const SamplerArgs& A,
             const double zs = A.prep_d[3 * p + j];
             const float invLhs = A.prep_f[j], bex = A.prep_f[2 * p + j], lo = A.prep_f[3 * p + j], hi = A.prep_f[4 * p + j];
             const double sum = sum_partials(A.partials + cc, A.nrg, A.bstride);
-            pp_sum[q] = (float)sum;
+            if constexpr (kPP) pp_sum[q] = (float)sum;
             const float rhs0 = (float)sum + co;       // + lookahead correction formed by the previous block's sampler
             rhs_lds[c] = rhs0;
             const float a_in = (c < b) ? a0 : 0.f;
@@ -543,7 +549,7 @@ __device__ __forceinline__ int sampler_role_st(char* smem, const SamplerArgs& A,
             bpark0[c] = bex; dpark0[c] = 0.f;     // a marker that stays out: delta 0, beta = its excluded draw
         }
     }
-    if constexpr (GROUP) {
+    if constexpr (kPP) {
         if (pp_wait && !pp_late) {
             // the hand-over: every thread polls the tagged words of ITS markers (block 0's sampler posts them the moment its
             // correction chain is done), then   rhs = fl32(sum) + ((cW + cG) + cP)   and the candidacy, exactly as above
@@ -664,7 +670,7 @@ __device__ __forceinline__ int sampler_role_st(char* smem, const SamplerArgs& A,
     // (two passes at most: the second one only for a ping-pong block whose finished right-hand side shows a candidate the
     // provisional staging did not see -- it is staged again with the union, i.e. at the cost the block had before pp_late)
 #pragma unroll 1
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int pass = 0; pass < (kPP ? 2 : 1); ++pass) {
     if (!prestage && !(first_sub >= 16 && single_pass_st)) {
         nstaged = stage_assign(smem, SM, A, cand, ncand_total);
         xreg = xreg_geom && ncand_total >= cmin && ncand_total <= kCompactMax && ncand_total <= SM.max_cand;
@@ -691,10 +697,10 @@ __device__ __forceinline__ int sampler_role_st(char* smem, const SamplerArgs& A,
         if (split) stage_load(smem, SM, A, nstaged, tss, 2, true);
         else stage_load(smem, SM, A, nstaged, tss);
     }
-    if (pass == 1) break;
+    if (!kPP || pass == 1) break;
     // ---- the LATE hand-over (pp_late, above): the block has staged everything it could; now it waits
     bool again = false;
-    if constexpr (GROUP) {
+    if constexpr (kPP) {
         if (pp_late) {
             bool nw = false;
 #pragma unroll
@@ -794,9 +800,9 @@ __device__ __forceinline__ int sampler_role_st(char* smem, const SamplerArgs& A,
                     }
                     corr_cd[q] = corr;
                     // (ping-pong: block 1's workgroup is waiting for exactly this)
-                    if constexpr (GROUP) { if (A.pp_cw_out != nullptr) pp_post_word(A.pp_cw_out + c, A.pp_tag, __float_as_uint(corr)); }
+                    if constexpr (kPP) { if (A.pp_cw_out != nullptr) pp_post_word(A.pp_cw_out + c, A.pp_tag, __float_as_uint(corr)); }
                 }
-                if constexpr (GROUP) pp_posted = A.pp_cw_out != nullptr;
+                if constexpr (kPP) pp_posted = A.pp_cw_out != nullptr;
                 compact_corr = true;
                 tkx[2] = clock64();
             }
@@ -1271,7 +1277,7 @@ __device__ __forceinline__ int sampler_role_st(char* smem, const SamplerArgs& A,
     // ping-pong, second block: where its changes go in the pair's merged list = how many block 0 had (posted when block 0's list
     // entries were acknowledged by the memory side -- long ago by now)
     int evb = ev_base;
-    if constexpr (GROUP) {
+    if constexpr (kPP) {
         if (A.pp_cnt_in != nullptr) {
             if (tid == 0) wcnt_s[10] = (int)pp_wait_word(A.pp_cnt_in, A.pp_tag, A.counters);
             __syncthreads();
@@ -1298,7 +1304,7 @@ __device__ __forceinline__ int sampler_role_st(char* smem, const SamplerArgs& A,
         else { eidx = A.ev_out->idx; edel = A.ev_out->delta[0]; }
         const int hb = GROUP ? evb : 0;                                         // (entries of the list in front of this block's)
         bool pp_first = false;                                                  // (ping-pong, first block: the second block's workgroup
-        if constexpr (GROUP) pp_first = A.pp_cnt_out != nullptr;                //  reads these entries in THIS launch: write-through stores)
+        if constexpr (kPP) pp_first = A.pp_cnt_out != nullptr;                  //  reads these entries in THIS launch: write-through stores)
         for (int e = tid; e < nfin; e += kStepThreads) {
             const int ce = pairs ? fin[2 * e] : fin[e];
             const float d = astart[ce] - acur[ce];
@@ -1322,7 +1328,7 @@ __device__ __forceinline__ int sampler_role_st(char* smem, const SamplerArgs& A,
             else { A.beta[j0 + c] = bpark0[c]; reinterpret_cast<float*>(A.delta)[j0 + c] = dpark0[c]; }
         }
     }
-    if constexpr (GROUP) {
+    if constexpr (kPP) {
         if (A.pp_cnt_out != nullptr) {
             // the hand-over to the next block's workgroup: every store of this workgroup -- cW through corr_out on the paths that did
             // not post it themselves, the list entries -- has been acknowledged by the memory side (vmcnt counts a store out then)
@@ -1335,7 +1341,7 @@ __device__ __forceinline__ int sampler_role_st(char* smem, const SamplerArgs& A,
         }
     }
     if (tid == 0) {
-        if (!(GROUP && A.pp_cnt_out != nullptr)) A.ev_out->count = (int32_t)((GROUP ? evb : 0) + nfin);      // (a split group's count: its last block's)
+        if (!(kPP && A.pp_cnt_out != nullptr)) A.ev_out->count = (int32_t)((GROUP ? evb : 0) + nfin);      // (a split group's count: its last block's)
         atomicAdd(&A.counters[0], (unsigned long long)nfin);
         atomicAdd(&A.counters[2], (unsigned long long)(tk1 - tk0));      // phase cycle counts (diagnostics)
         atomicAdd(&A.counters[3], (unsigned long long)(tk2 - tk1));

@@ -99,15 +99,20 @@ hipError_t launch_group_cx(const StepLaunch& L, const CX& cx, const UpdateArgs& 
     static std::atomic<unsigned long long> attr_set{0ull};
     const unsigned long long dev_bit = 1ull << (L.device & 63);
     if (!(attr_set.load(std::memory_order_acquire) & dev_bit)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_group_step<METHOD, CX>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_group_step<METHOD, CX, false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_group_step<METHOD, CX, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set.fetch_or(dev_bit, std::memory_order_release);
     }
     const int nwork = L.nrg * U.ncg;
     unsigned grid = U.quiet_xcd ? (unsigned)(1 + (nwork + 6) / 7 * 8) : (unsigned)(1 + nwork);
     if (G.pp != 0 && grid < 8u * (unsigned)(G.ns - 1) + 1u) grid = 8u * (unsigned)(G.ns - 1) + 1u;      // ping-pong: block s is sampled by workgroup 8 s
-    hipLaunchKernelGGL((k_group_step<METHOD, CX>), dim3(grid), dim3(kStepThreads), SM.bytes, L.stream, U, uev_idx, uev_delta, SS, G);
+    // (G.pp_kernel: the host's choice per SWEEP -- a sweep's launches share the arrival counters of the cooperative apply)
+    if (G.pp_kernel != 0) hipLaunchKernelGGL((k_group_step<METHOD, CX, true>), dim3(grid), dim3(kStepThreads), SM.bytes, L.stream, U, uev_idx, uev_delta, SS, G);
+    else hipLaunchKernelGGL((k_group_step<METHOD, CX, false>), dim3(grid), dim3(kStepThreads), SM.bytes, L.stream, U, uev_idx, uev_delta, SS, G);
     return hipSuccess;
 }
 

@@ -230,6 +230,7 @@ struct GroupArgs {
     unsigned long long* pp_ph;     // [2 bs] block 0's part of the cP chain
     unsigned long long* pp_cp;     // [2 bs] cP (read by blocks 2 and 3)
     unsigned long long* pp_h;      // [3][m bs] the cG chain after blocks 0, 1, 2
+    int pp_kernel;                 // launch k_group_step<., ., PP = true> (the host's choice per sweep: ping-pong samplers and / or cooperative apply wanted)
 };
 // The sampler arguments of the group's blocks, one full set per block, filled by the host (sweep_enqueue): block s reads ITS set
 // from the kernel-argument segment -- a copy of one set edited per block inside the kernel kept ~80 scalars live across the whole
@@ -312,7 +313,9 @@ __device__ __forceinline__ void group_corr(char* smem, const int32_t* eidx, cons
     else group_corr_n<8>(smem, eidx, edel, e_lo, e_hi, jrow0, cross, bn, out, ncols_out, coherent, seed, post, tag, counters);
 }
 
-template <int METHOD, class CX>
+// PP: the instantiation of the high-turnover sweeps -- ping-pong samplers (G.pp) and the cooperative apply of the merged list
+// (U.sync_now); the steady-state sweeps launch the one without either (neither code path exists in it).
+template <int METHOD, class CX, bool PP = false>
 __global__ __launch_bounds__(kStepThreads) void k_group_step(UpdateArgsT<CX> U, const int32_t* uev_idx, const float* uev_delta,
                                                              GroupSamplers SS, GroupArgs G)
 {
@@ -321,7 +324,7 @@ __global__ __launch_bounds__(kStepThreads) void k_group_step(UpdateArgsT<CX> U, 
     // block's front runs at launch start and only the chain itself is sequential (sampler_role_st, SamplerArgs::pp_*); the
     // corrections for the blocks behind (cP inside a four, cG for the next group) are RELAYED: each workgroup continues the
     // fused-multiply-add chain over its own block's changes from where the workgroup before it stopped (group_corr: seed / post)
-    const int pp_s = (G.pp != 0 && (blockIdx.x & 7u) == 0u && blockIdx.x < 32u) ? (int)(blockIdx.x >> 3) : -1;
+    const int pp_s = (PP && G.pp != 0 && (blockIdx.x & 7u) == 0u && blockIdx.x < 32u) ? (int)(blockIdx.x >> 3) : -1;
     if (blockIdx.x == 0 || pp_s > 0) {
         if (G.ns <= 0 || pp_s >= G.ns) return;
         const int s_lo = pp_s >= 0 ? pp_s : 0, s_hi = pp_s >= 0 ? pp_s + 1 : G.ns;
@@ -330,7 +333,7 @@ __global__ __launch_bounds__(kStepThreads) void k_group_step(UpdateArgsT<CX> U, 
         long long tgp = 0;
 #pragma unroll 1
         for (int s = s_lo; s < s_hi; ++s) {
-            nev = sampler_role_st<METHOD, false, true>(smem, SS.a[s], nev);      // (-> the length of the merged list behind block s)
+            nev = sampler_role_st<METHOD, false, true, PP>(smem, SS.a[s], nev);      // (-> the length of the merged list behind block s)
             __syncthreads();                                    // the block's global stores (cW, the list) are visible to the workgroup
             if (pp_s < 0 && s == 1 && G.cross_pair != nullptr && G.ns > 2) {
                 const long long t0 = clock64();
@@ -340,7 +343,7 @@ __global__ __launch_bounds__(kStepThreads) void k_group_step(UpdateArgsT<CX> U, 
         }
         const long long tg1 = clock64();
         const int bsz = SS.a[0].bsz, ncols = G.m * bsz;
-        if (pp_s >= 0) {
+        if (PP && pp_s >= 0) {
             const SamplerArgs& A = SS.a[pp_s];
             const int e_lo = pp_count_in(A);                    // this block's entries of the merged list: [e_lo, nev)
             const bool mine_wt = A.pp_cnt_out != nullptr;       // (written through: read them back at the coherence point)
@@ -374,8 +377,8 @@ __global__ __launch_bounds__(kStepThreads) void k_group_step(UpdateArgsT<CX> U, 
     // window's 32 columns in registers are what pushed this kernel, with its sampler loop, into scratch memory)
     // (the cooperative apply -- the column groups of a row group share the rows of the merged list's columns instead of every one of
     // them re-reading all of them -- when the host passes the arrival counters: the high-turnover sweeps, 60-120 changes per launch)
-    update_role<1, CX, true, false, EvGroup>(smem, w % U.nrg, w / U.nrg, U.cx, U.r_in, U.r_out, EvGroup{U.ev, uev_idx, uev_delta}, U.j0, U.b,
-                                             U.nslices, U.nrg, U.ncg, U.partials, U.bstride, U.spg, U.sync_now, U.sync_next, U.dbg);
+    update_role<1, CX, PP, false, EvGroup>(smem, w % U.nrg, w / U.nrg, U.cx, U.r_in, U.r_out, EvGroup{U.ev, uev_idx, uev_delta}, U.j0, U.b,
+                                             U.nslices, U.nrg, U.ncg, U.partials, U.bstride, U.spg, PP ? U.sync_now : nullptr, PP ? U.sync_next : nullptr, U.dbg);
 }
 
 // Cross-Gram of consecutive blocks, exact (fp64-accumulated): C[a][c] = x_{jp+a}' x_{j0+c}.
