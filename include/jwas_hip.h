@@ -322,10 +322,12 @@ int  jwas_hip_window_sums2(jwas_hip_ctx* ctx, int32_t use_output_rows, int32_t n
  * sweep's stream (0 = off); the sums come back in jwas_sweep_stats.update_kernel_*. */
 int  jwas_hip_set_kernel_timing(jwas_hip_ctx* ctx, int32_t stride);
 int  jwas_hip_sweep(jwas_hip_ctx* ctx, const jwas_sweep_params* params, jwas_sweep_stats* stats);
-/* Diagnostics of the LAST sweep (no reference counterpart; what JWAS_HIP_DEBUG_PHASES prints): the sampler's counters, n <= 24
+/* Diagnostics of the LAST sweep (no reference counterpart; what JWAS_HIP_DEBUG_PHASES prints): the sampler's counters, n <= 32
  * values -- [0] effect changes, [1] Gram rows fetched on demand, [2..6] phase cycles, [7] rounds / sections walked again,
  * [16] / [17] compact-chain blocks tried / fallen back, or (section_solve) sections solved / fallen back to the walk,
- * [23] (section_solve) exceptions taken inside the solved sections. */
+ * [23] (section_solve) exceptions taken inside the solved sections, [24] hand-over words that never arrived (the sweep fails),
+ * [29] ping-pong blocks staged a second time, [30] / [31] multi-trait skip and verify: blocks in which the serial wave took the
+ * chain over again / 64-marker sub-blocks evaluated by a helper wave. */
 int  jwas_hip_last_sweep_counters(jwas_hip_ctx* ctx, uint64_t* out, int32_t n);
 
 /* ---- marker shards over the GPUs of one node (one context per GPU / process) -------------------------------

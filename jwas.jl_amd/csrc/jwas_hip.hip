@@ -2099,8 +2099,8 @@ static int sweep_collect(jwas_hip_ctx* c, jwas_sweep_stats* S, size_t ntimed, do
     NEED(c, h_cnt[kPpTimeoutCounter] == 0, JWAS_HIP_EHIP, "grouped launches: %llu hand-over words between the two sampler workgroups never arrived (results of this sweep are invalid)",
          h_cnt[kPpTimeoutCounter]);
     if (std::getenv("JWAS_HIP_DEBUG_PHASES"))
-        std::fprintf(stderr, "[jwas_hip] blocks=%lld events=%llu unstaged=%llu cycles: front=%llu cand=%llu stage=%llu serial=%llu write=%llu corr=%llu rounds=%llu slow_rounds=%llu stage: assign=%llu issue=%llu wait=%llu update wg0: share=%llu wait=%llu rest=%llu compact: blocks=%llu fallback=%llu walk=%llu verify=%llu role=%llu tailwait=%llu xwrite=%llu xchain=%llu (section_solve: blocks = sections solved, fallback = fallen back, walk..xwrite = cycles of y | mat-vec | combine | verify+apply | tail) group: cP=%llu tail=%llu workgroups=%llu last_workgroup=%llu\n",
-                     (long long)c->nblocks, h_cnt[0], h_cnt[1], h_cnt[2], h_cnt[3], h_cnt[4], h_cnt[5], h_cnt[6], h_cnt[9], h_cnt[7], h_cnt[8], h_cnt[10], h_cnt[11], h_cnt[12], h_cnt[13], h_cnt[14], h_cnt[15], h_cnt[16], h_cnt[17], h_cnt[18], h_cnt[19], h_cnt[20], h_cnt[21], h_cnt[22], h_cnt[23], h_cnt[25], h_cnt[26], h_cnt[27], h_cnt[28]);
+        std::fprintf(stderr, "[jwas_hip] blocks=%lld events=%llu unstaged=%llu cycles: front=%llu cand=%llu stage=%llu serial=%llu write=%llu corr=%llu rounds=%llu slow_rounds=%llu stage: assign=%llu issue=%llu wait=%llu update wg0: share=%llu wait=%llu rest=%llu compact: blocks=%llu fallback=%llu walk=%llu verify=%llu role=%llu tailwait=%llu xwrite=%llu xchain=%llu (section_solve: blocks = sections solved, fallback = fallen back, walk..xwrite = cycles of y | mat-vec | combine | verify+apply | tail) group: cP=%llu tail=%llu workgroups=%llu last_workgroup=%llu late_new_candidates=%llu mt_taken_over=%llu mt_helped=%llu\n",
+                     (long long)c->nblocks, h_cnt[0], h_cnt[1], h_cnt[2], h_cnt[3], h_cnt[4], h_cnt[5], h_cnt[6], h_cnt[9], h_cnt[7], h_cnt[8], h_cnt[10], h_cnt[11], h_cnt[12], h_cnt[13], h_cnt[14], h_cnt[15], h_cnt[16], h_cnt[17], h_cnt[18], h_cnt[19], h_cnt[20], h_cnt[21], h_cnt[22], h_cnt[23], h_cnt[25], h_cnt[26], h_cnt[27], h_cnt[28], h_cnt[29], h_cnt[30], h_cnt[31]);
     float ms = 0.f;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev_start, c->ev_stop));
     S->sweep_ms = ms;

@@ -563,9 +563,12 @@ __device__ __forceinline__ void corr_helper(char* smem, const SamplerArgs& A)
 }
 
 // rhs[t][:] += D[t] * G[ce][:]  for the committed marker ce (BayesABC.jl:169,172); one wave.
+// c_from (a multiple of 64): only the columns from there on -- a single pass never reads the right-hand side of a marker in front of
+// the committed one again, and the multi-trait skip-and-verify pass (sampler_role_mt) counts on their values staying what they
+// were at those markers' own steps.
 template <int NT>
 __device__ __forceinline__ void apply_gram_row(char* smem, const StepSmem& SM, const SamplerArgs& A, int ce,
-                                               const float (&D)[NT], int lane)
+                                               const float (&D)[NT], int lane, int c_from = 0)
 {
     const int B = SM.B, b = A.b;
     float* rhs_lds = reinterpret_cast<float*>(smem + SM.rhs_off);
@@ -573,7 +576,7 @@ __device__ __forceinline__ void apply_gram_row(char* smem, const StepSmem& SM, c
     const float* rows = reinterpret_cast<const float*>(smem + SM.rows_off);
     const int sl = __builtin_amdgcn_readfirstlane((int)slot_of[ce]);
     if (sl >= 0) {                                               // staged row: LDS only (explicit branch --
-        for (int c2 = lane; c2 < B; c2 += 64) {                  // a select would still issue the global load)
+        for (int c2 = c_from + lane; c2 < B; c2 += 64) {         // a select would still issue the global load)
             const float g = rows[sl * B + c2];
 #pragma unroll
             for (int t = 0; t < NT; ++t)
@@ -581,7 +584,7 @@ __device__ __forceinline__ void apply_gram_row(char* smem, const StepSmem& SM, c
         }
     } else {
         const float* grow = A.gram + (int64_t)ce * b;             // symmetric: row = column
-        for (int c2 = lane; c2 < B; c2 += 64) {
+        for (int c2 = c_from + lane; c2 < B; c2 += 64) {
             const float g = grow[c2 < b ? c2 : 0];
 #pragma unroll
             for (int t = 0; t < NT; ++t)

@@ -315,6 +315,58 @@ __device__ __forceinline__ void group_corr(char* smem, const int32_t* eidx, cons
 
 // PP: the instantiation of the high-turnover sweeps -- ping-pong samplers (G.pp) and the cooperative apply of the merged list
 // (U.sync_now); the steady-state sweeps launch the one without either (neither code path exists in it).
+// The steady-state kernel's form: the whole list [0, ne) of ONE workgroup, from 0, to `out` -- no seed, no tagged words, no coherent
+// reads (a handful of changes per group: four rows x NQ column slots per pass).
+template <int NQ>
+__device__ __attribute__((noinline)) void group_corr_plain_n(char* smem, const int32_t* __restrict__ eidx, const float* __restrict__ edel, int ne, int64_t jrow0,
+                                                             const float* __restrict__ cross, int bn, float* __restrict__ out, int ncols_out)
+{
+    int* lrow = reinterpret_cast<int*>(smem);
+    float* ld = reinterpret_cast<float*>(smem) + kStepThreads;
+    const int tid = threadIdx.x;
+    float corr[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) corr[q] = 0.f;
+    for (int e0 = 0; e0 < ne; e0 += kStepThreads) {
+        const int nc = (ne - e0) < kStepThreads ? (ne - e0) : kStepThreads;
+        __syncthreads();
+        if (tid < nc) { lrow[tid] = (int)((int64_t)eidx[e0 + tid] - jrow0); ld[tid] = edel[e0 + tid]; }
+        __syncthreads();
+        for (int h = 0; h < nc; h += 4) {
+            float g[4][NQ];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t row = lrow[h + u < nc ? h + u : nc - 1];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const int c = tid + q * kStepThreads;
+                    g[u][q] = cross[row * bn + (c < bn ? c : 0)];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (h + u < nc) {
+                    const float d = ld[h + u];
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) corr[q] = fmaf(d, g[u][q], corr[q]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int c = tid + q * kStepThreads;
+        if (c < ncols_out) out[c] = (c < bn) ? corr[q] : 0.f;
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void group_corr_plain(char* smem, const int32_t* eidx, const float* edel, int ne, int64_t jrow0,
+                                                 const float* cross, int bn, float* out, int ncols_out)
+{
+    if (ncols_out <= 4 * kStepThreads) group_corr_plain_n<4>(smem, eidx, edel, ne, jrow0, cross, bn, out, ncols_out);
+    else group_corr_plain_n<8>(smem, eidx, edel, ne, jrow0, cross, bn, out, ncols_out);
+}
+
 template <int METHOD, class CX, bool PP = false>
 __global__ __launch_bounds__(kStepThreads) void k_group_step(UpdateArgsT<CX> U, const int32_t* uev_idx, const float* uev_delta,
                                                              GroupSamplers SS, GroupArgs G)
@@ -324,8 +376,23 @@ __global__ __launch_bounds__(kStepThreads) void k_group_step(UpdateArgsT<CX> U, 
     // block's front runs at launch start and only the chain itself is sequential (sampler_role_st, SamplerArgs::pp_*); the
     // corrections for the blocks behind (cP inside a four, cG for the next group) are RELAYED: each workgroup continues the
     // fused-multiply-add chain over its own block's changes from where the workgroup before it stopped (group_corr: seed / post)
+    if constexpr (!PP) {
+        if (blockIdx.x == 0) {
+            if (G.ns <= 0) return;
+            int nev = 0;
+#pragma unroll 1
+            for (int s = 0; s < G.ns; ++s) {
+                nev = sampler_role_st<METHOD, false, true, false>(smem, SS.a[s], nev);      // (-> the length of the merged list behind block s)
+                __syncthreads();                                // the block's global stores (cW, the list) are visible to the workgroup
+                if (s == 1 && G.cross_pair != nullptr && G.ns > 2)
+                    group_corr_plain(smem, G.ev_idx, G.ev_delta, nev, G.j0, G.cross_pair, G.bn_pair, G.corr_p, 2 * SS.a[0].bsz);
+            }
+            if (G.cross_grp != nullptr) group_corr_plain(smem, G.ev_idx, G.ev_delta, nev, G.j0, G.cross_grp, G.bn_grp, G.corr_g_out, G.m * SS.a[0].bsz);
+            return;
+        }
+    }
     const int pp_s = (PP && G.pp != 0 && (blockIdx.x & 7u) == 0u && blockIdx.x < 32u) ? (int)(blockIdx.x >> 3) : -1;
-    if (blockIdx.x == 0 || pp_s > 0) {
+    if (PP && (blockIdx.x == 0 || pp_s > 0)) {
         if (G.ns <= 0 || pp_s >= G.ns) return;
         const int s_lo = pp_s >= 0 ? pp_s : 0, s_hi = pp_s >= 0 ? pp_s + 1 : G.ns;
         int nev = 0;

@@ -373,8 +373,8 @@ class HipEngine:
 
     def last_sweep_counters(self):
         """The sampler's diagnostics counters of the last sweep (jwas_hip_last_sweep_counters)."""
-        out = (C.c_uint64 * 24)()
-        self._chk(self._L.jwas_hip_last_sweep_counters(self._h, out, 24))
+        out = (C.c_uint64 * 32)()
+        self._chk(self._L.jwas_hip_last_sweep_counters(self._h, out, 32))
         return [int(v) for v in out]
 
     def set_kernel_timing(self, stride):

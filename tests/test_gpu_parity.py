@@ -397,6 +397,59 @@ def test_mt_sampler1_parity(hip, t, bs):
         _compare_state(orc, hip, k, atol=5e-6)
 
 
+# SKIP AND VERIFY (sampler_role_mt): sparse multi-trait blocks of 256 / 512 markers -- the serial wave walks only the 64-marker
+# sub-blocks that hold a candidate, the helper waves evaluate the others; the chain must be the oracle's, and the helpers must
+# have run (sweep counter 31).  `dup`: copies of the causal columns a few sub-blocks behind the originals -- when a causal marker's
+# effect changes, its copy's right-hand side moves with it and the copy enters the model from a skipped sub-block (counter 30: the
+# serial wave took the chain over again from there).
+@pytest.mark.parametrize("method,t,bs,dup", [("MTBayesC", 3, 512, False), ("MTBayesC", 3, 256, False), ("MTBayesC", 2, 512, True),
+                                             ("MTBayesC", 3, 512, True), ("MTBayesC_II", 3, 512, True), ("MTBayesC_II", 2, 256, False),
+                                             ("MegaBayesC", 3, 512, True), ("MTBayesB", 3, 512, False)])
+def test_mt_skip_and_verify_sparse_blocks(hip, method, t, bs, dup):
+    data = make_dataset(n=600, p=3 * bs + 150, ncausal=24, h2=0.7, seed=910 + t + bs)
+    X = data["X"].copy()
+    if dup:
+        for j in data["causal"]:
+            for off in (64, 130, 200):
+                k = j + off
+                if k // bs == j // bs and k < X.shape[1] and k not in data["causal"]:      # (same block, a later sub-block)
+                    X[:, k] = X[:, j]
+        data = dict(data, X=np.asfortranarray(X))
+    orc, hip = _pair(hip, data, bs, method, ntraits=t)
+    rng = np.random.default_rng(17 + t)
+    Y = np.stack([data["y"] - data["y"].mean() + 0.3 * rng.standard_normal(len(data["y"])).astype(np.float32)
+                  for _ in range(t)]).astype(np.float32)
+    for k in range(t):
+        orc.set_residual(Y[k], k)
+        hip.set_residual(Y[k], k)
+    A = rng.standard_normal((t, t))
+    vare = (A @ A.T / t + np.eye(t)).astype(np.float32) * 0.5
+    B = rng.standard_normal((t, t))
+    varg = ((B @ B.T / t + np.eye(t)) * 0.01).astype(np.float32)
+    kw = dict(vare=vare, var_effect=varg)
+    if method == "MegaBayesC":
+        kw = dict(vare=np.diag(np.diag(vare)).astype(np.float32), var_effect=np.diag(np.diag(varg)).astype(np.float32), pi=np.full(t, 0.998))
+    else:
+        prior = np.full(1 << t, 0.03 / ((1 << t) - 1))
+        prior[0] = 0.97
+        kw["log_prior_states"] = np.log(prior)
+        if method == "MTBayesB":                     # a covariance per marker (the helper waves use the marker's own constants)
+            Bm = rng.standard_normal((orc.p, t, t))
+            kw["var_effect_matrix"] = ((Bm @ Bm.transpose(0, 2, 1) / t + np.eye(t)) * 0.01).astype(np.float32)
+    helped, taken_over = 0, 0
+    for it in range(1, 31):
+        so = orc.sweep(iteration=it, seed=23, **kw)
+        sh = hip.sweep(iteration=it, seed=23, **kw)
+        assert so["n_events"] == sh["n_events"], f"iteration {it}"
+        c = hip.last_sweep_counters()
+        helped += int(c[31]); taken_over += int(c[30])
+    for k in range(t):
+        _compare_state(orc, hip, k, atol=5e-6)
+    assert helped > 20, f"the helper waves evaluated only {helped} sub-blocks"
+    if dup and method in ("MTBayesC", "MTBayesC_II"):
+        assert taken_over > 0, "no skipped marker ever moved: the take-over path did not run"
+
+
 # t <= 3: per-marker state tables (k_prepare_mt2); t = 4: states evaluated on the fly
 @pytest.mark.parametrize("t,bs,nreps", [(2, 64, 1), (2, 128, 1), (3, 128, 1), (4, 64, 1), (2, 64, 2), (3, 512, 1), (3, 1024, 1), (4, 256, 1), (3, 64, 2)])
 def test_mt_sampler2_parity(hip, t, bs, nreps):
