@@ -1392,7 +1392,7 @@ static int upload_vec(jwas_hip_ctx* c, void** dev, const void* host, size_t byte
 // Independent-block sweep (BayesABC_block_independent!, BayesABC.jl:190-255): all block RHS from the residual
 // snapshot (one pass over X), all blocks sampled concurrently, change lists compacted in (block, marker) order;
 // the caller's k_finish applies them to the residual.
-static int sweep_independent(jwas_hip_ctx* c, EventList* out, bool dense, int dense_big_off, int compact_off)
+static int sweep_independent(jwas_hip_ctx* c, EventList* out, bool dense, int dense_big_off, int compact_off, int nreps)
 {
     const int t = c->ntraits, bs = c->block_size;
     const int64_t nb = c->nblocks;
@@ -1426,7 +1426,7 @@ static int sweep_independent(jwas_hip_ctx* c, EventList* out, bool dense, int de
     S.alpha = c->alpha; S.beta = c->beta; S.delta = c->delta;
     S.counters = c->counters;
     S.dense_big_off = dense_big_off;
-    S.compact_off = compact_off;
+    S.compact_off = compact_off; S.nreps = nreps;
     hipError_t e;
     const StepLaunch L = step_launch_of(c);
     switch (c->method) {
@@ -1799,7 +1799,7 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
                          !c->row_mode && c->starts.empty() && !dense_big;
     int64_t last_launch = nb;                                   // index of the sweep's last launch
     if (independent) {
-        int rc = sweep_independent(c, &ev_list, dense_big, dense_big_off, compact_off);
+        int rc = sweep_independent(c, &ev_list, dense_big, dense_big_off, compact_off, P->nreps);
         if (rc) return rc;
     } else if (grouped) {
         const int m = SET.gm;
@@ -1891,7 +1891,7 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
                     S.b_next = inner ? blk_b(c, i + 1) : 0;
                     S.cross_next = c->cross + (inner ? i + 1 : i) * bb;
                     S.gram_next = c->gram + (inner ? i + 1 : i) * bb;   // (L2 prefetch only, and only when b_next > 0)
-                    S.compact_off = compact_off;
+                    S.compact_off = compact_off; S.nreps = P->nreps;
                     S.corr_in = cb + ((s2 & 1) ? off_w : off_z);                          // cW: the pair's first block (or +0)
                     S.corr_out = cb + off_w;
                     S.corr_in2 = cb + off_g_in + (size_t)s2 * bs;                         // cG: the previous group
@@ -1978,7 +1978,7 @@ static int sweep_enqueue(jwas_hip_ctx* c, const jwas_sweep_params* P, size_t* nt
             S.gram_next = (sb + 1 < nb) ? c->gram + (sb + 1) * (int64_t)bs * bs : nullptr;
             S.cross_after = (sb + 2 < nb) ? c->cross + (sb + 2) * (int64_t)bs * bs : nullptr;
             S.dense_big_off = dense_big_off;
-            S.compact_off = compact_off;
+            S.compact_off = compact_off; S.nreps = P->nreps;
             S.tsec = (sb < solve_blocks) ? c->tsec + (size_t)sb * 4 * tsf : nullptr;
             S.tsec_next = (sb + 1 < solve_blocks) ? c->tsec + (size_t)(sb + 1) * 4 * tsf : nullptr;
             S.tsec_lines = (int)(4 * tsf / 32);

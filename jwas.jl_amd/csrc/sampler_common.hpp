@@ -61,6 +61,8 @@ struct SamplerArgs {
     const unsigned long long* pp_cnt_in;  // the number of list entries in front of this block's (posted by the block before), or NULL = ev_base
     unsigned long long* pp_cnt_out;       // where this block posts the list length behind it (its entries acknowledged), or NULL = last block
     unsigned pp_tag;                      // this launch's tag
+    int nreps;                            // = P->nreps (jwas_sweep_params.nreps), from the argument segment: control flow that precedes the front's
+                                          // loads must not wait for a load through P (a memory latency under the stream, sampler_role_mt)
 };
 
 constexpr int kPpTimeoutCounter = 24;      // sweep counter: hand-over words that never arrived (must stay 0; the host fails the sweep otherwise)
@@ -103,6 +105,31 @@ __device__ __forceinline__ double sum_partials_n(const double* pp, int nrg, int6
     }
     return sum;
 }
+// The same in two steps, so that a caller can ISSUE the loads of several columns (and whatever else it needs) before the first sum
+// waits for any of them: load_partials_n issues the first N loads (clamped addresses), sum_loaded_n is the rest of sum_partials_n --
+// the same additions in the same order.
+template <int N>
+__device__ __forceinline__ void load_partials_n(const double* pp, int nrg, int64_t stride, double (&v)[N])
+{
+#pragma unroll
+    for (int u = 0; u < N; ++u) v[u] = *(pp + (int64_t)(u < nrg ? u : nrg - 1) * stride);
+}
+template <int N>
+__device__ __forceinline__ double sum_loaded_n(const double (&v)[N], const double* pp, int nrg, int64_t stride)
+{
+    double sum = 0.0;
+#pragma unroll
+    for (int u = 0; u < N; ++u) if (u < nrg) sum += v[u];
+    if (nrg > N)
+    for (int rg = N; rg < nrg; rg += 16) {                        // very tall matrices only
+        double w[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) w[u] = *(pp + (int64_t)(rg + u < nrg ? rg + u : nrg - 1) * stride);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) if (rg + u < nrg) sum += w[u];
+    }
+    return sum;
+}
 __device__ __forceinline__ double sum_partials(const double* pp, int nrg, int64_t stride)
 {
     if (nrg <= 8) return sum_partials_n<8>(pp, nrg, stride);      // (uniform branches: nrg is a launch constant)
@@ -116,9 +143,24 @@ template <int NT>
 __device__ __forceinline__ void sum_partials_traits(const double* pp, int64_t tstride, int nrg, int64_t stride, double (&sum)[NT])
 {
     constexpr int kC = (NT <= 2) ? 16 : (NT == 3 ? 12 : 8);
+    // the first chunk as STRAIGHT-LINE code: in front of a loop that holds loads the compiler waits for every load in flight
+    // (s_waitcnt vmcnt(0) at the loop's entry) -- the markers' state loads issued just before, i.e. a second memory latency in the
+    // sampler's front.  The loop below is only entered by very tall matrices (more row groups than one chunk).
+    {
+        double v[NT][kC];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) sum[t] = 0.0;
-    for (int rg = 0; rg < nrg; rg += kC) {
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int u = 0; u < kC; ++u) v[t][u] = *(pp + t * tstride + (int64_t)(u < nrg ? u : nrg - 1) * stride);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            sum[t] = 0.0;
+#pragma unroll
+            for (int u = 0; u < kC; ++u) if (u < nrg) sum[t] += v[t][u];
+        }
+    }
+    if (nrg > kC)
+    for (int rg = kC; rg < nrg; rg += kC) {
         double v[NT][kC];
 #pragma unroll
         for (int t = 0; t < NT; ++t)

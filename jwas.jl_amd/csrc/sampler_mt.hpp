@@ -1644,24 +1644,39 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
     float* delta = reinterpret_cast<float*>(A.delta);
     const long long tk0 = clock64();
 
+    // The sweep's constants come through P: loads (one memory latency -- microseconds under the update role's stream).  Here they are only
+    // ISSUED; everything computed from them (fill_K, below) waits until the front has issued the loads of the markers' state and partial
+    // sums, so that the role starts with ONE memory latency.  (Computing K first, and reading P->nreps for the branches in front of the
+    // marker loads, was three dependent latencies before the first marker load: ~5 k of the front's 19 k cycles per block.)
     MtConsts<NT> K;
+    float rawR[NT * NT], rawG[NT * NT], rawV[NT * NT], rawVe[NT];
+    double rawPi[NT];
+#pragma unroll
+    for (int i = 0; i < NT * NT; ++i) { rawR[i] = P->Rinv[i]; rawG[i] = P->Ginv[i]; rawV[i] = P->vare[i]; }
 #pragma unroll
     for (int a = 0; a < NT; ++a) {
-#pragma unroll
-        for (int c = 0; c < NT; ++c) { K.Rinv[a][c] = P->Rinv[a * NT + c]; K.Ginv[a][c] = P->Ginv[a * NT + c]; K.Rm[a][c] = P->vare[a * NT + c]; }
-        K.invG[a] = 1.0f / K.Ginv[a][a];                            // MTBayesABC.jl:92
-        K.lG[a] = logf_via_double(K.Ginv[a][a]);
-        K.sG[a] = sqrtf(K.invG[a]);
-        if constexpr (is_mega(METHOD)) {
-            K.ie[a]  = 1.0f / P->vare[a * NT + a];                  // invVarRes          BayesABC.jl:69
-            K.var[a] = P->var_effect[a * NT + a];
-            K.iv[a]  = 1.0f / K.var[a];                             // invVarEffects[j]   :70
-            K.lv[a]  = logf_via_double(K.var[a]);                   // logVarEffects[j]   :71
-            K.sv[a]  = sqrtf(K.var[a]);
-            K.lp0[a] = log(P->pi4[a]);                              // logPi              :67
-            K.lp1[a] = log(1.0 - P->pi4[a]);                        // logPiComp          :68
-        }
+        rawVe[a] = 0.f; rawPi[a] = 0.0;
+        if constexpr (is_mega(METHOD)) { rawVe[a] = P->var_effect[a * NT + a]; rawPi[a] = P->pi4[a]; }
     }
+    auto fill_K = [&]() {
+#pragma unroll
+        for (int a = 0; a < NT; ++a) {
+#pragma unroll
+            for (int c = 0; c < NT; ++c) { K.Rinv[a][c] = rawR[a * NT + c]; K.Ginv[a][c] = rawG[a * NT + c]; K.Rm[a][c] = rawV[a * NT + c]; }
+            K.invG[a] = 1.0f / K.Ginv[a][a];                            // MTBayesABC.jl:92
+            K.lG[a] = logf_via_double(K.Ginv[a][a]);
+            K.sG[a] = sqrtf(K.invG[a]);
+            if constexpr (is_mega(METHOD)) {
+                K.ie[a]  = 1.0f / rawV[a * NT + a];                     // invVarRes          BayesABC.jl:69
+                K.var[a] = rawVe[a];
+                K.iv[a]  = 1.0f / K.var[a];                             // invVarEffects[j]   :70
+                K.lv[a]  = logf_via_double(K.var[a]);                   // logVarEffects[j]   :71
+                K.sv[a]  = sqrtf(K.var[a]);
+                K.lp0[a] = log(rawPi[a]);                               // logPi              :67
+                K.lp1[a] = log(1.0 - rawPi[a]);                         // logPiComp          :68
+            }
+        }
+    };
     // multi-trait BayesA/B: the constants that depend on G are the marker's own (its inverse was formed by k_prepare)
     auto with_ginv = [&](const float (&g)[NT * NT]) {
         MtConsts<NT> Kj = K;
@@ -1729,7 +1744,7 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
         __syncthreads();
     };
     if constexpr (is_sampler1(METHOD)) {
-        big_try = (B == 256) && (b == B) && !pm && parked && (P->nreps == 1) && !A.dense_big_off;      // (any next block: its columns are threads 256 .. 256 + b_next - 1)
+        big_try = (B == 256) && (b == B) && !pm && parked && (A.nreps == 1) && !A.dense_big_off;      // (any next block: its columns are threads 256 .. 256 + b_next - 1)
         if constexpr (kDW) { if (big_try && A.tsec == nullptr) fetch_tiles(); }      // (Rule T: a tile is fetched only by a section that has to be walked)
     }
     float4 gpre[8];
@@ -1819,6 +1834,7 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
             for (int st = 0; st < (1 << NT); ++st) lpd[(2 * NT + st) * B + c] = lpm[st];
         }
     }
+    fill_K();
     if (tid < (1 << NT)) lpr[tid] = lpr_mine;
     if (tid == 0) { int* wz = reinterpret_cast<int*>(smem + SM.wcnt_off); wz[14] = 0; wz[8] = 0; wz[9] = 0; wz[10] = 16; }      // [14]: set by the dense walk; [8..10]: skip and verify
     if (prestage) {
@@ -1933,7 +1949,7 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
 #pragma unroll
         for (int q = 0; q < kStepThreads / 64; ++q) { const int v = wc[q]; ncand_all += v >> 8; mask |= (unsigned)(v & 1) << q | (unsigned)((v >> 1) & 1) << (8 + q); }
         if (mask) first_sub = __builtin_ctz(mask);
-        const bool single_pass = (P->nreps > 0 ? P->nreps : b) == 1;
+        const bool single_pass = (A.nreps > 0 ? A.nreps : b) == 1;
         if (!single_pass) first_sub = 0;
         cand_mask = mask;
         if (single_pass && !prestage && (B == 256 || B == 512) && first_sub < 16 && !(A.compact_off & 8))
@@ -1987,7 +2003,7 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
 
 
     const int nsub = (b + 63) / 64;
-    const int nreps = P->nreps > 0 ? P->nreps : b;
+    const int nreps = A.nreps > 0 ? A.nreps : b;
     RngKey key{P->seed_lo, P->seed_hi, P->iter, 0u};
 
     // ---- DENSE blocks (every marker of a <= 128-marker block is in the model for some trait -- the default all-ones

@@ -495,58 +495,107 @@ __device__ __forceinline__ int sampler_role_st(char* smem, const SamplerArgs& A,
     const bool pp_late = kPP && pp_wait && !prestage && ((P->nreps > 0 ? P->nreps : b) == 1) && !(A.compact_off & 4);
     const float cmarg = pp_late ? kCandMarginLate : kCandMargin;
     float pp_sum[2] = {0.f, 0.f}, pp_c1[2] = {0.f, 0.f}, pp_c2[2] = {0.f, 0.f}, pp_c3[2] = {0.f, 0.f};
+    // TWO STEPS (round 6): the loads of the front -- state, constants and lookahead corrections of BOTH columns of a thread when the
+    // block has more than 512 markers, and the first column's row-group partial sums -- are issued before anything waits for one of
+    // them; the second column's partial sums follow when the first column's have been summed (all of them at once do not fit the
+    // registers: the compiler then spills the first column's values, i.e. waits for them, before it issues the second's).  Written
+    // as one loop over the columns with the sums inside, the compiler finished column 0 (loads, sums, LDS stores) before it issued
+    // column 1's loads, and split 28 partial sums into two batches with a full wait between them: four memory latencies at the start
+    // of every 1024-marker block (n = 50 000), each of them microseconds under the update role's stream.  N = partial sums loaded
+    // per batch (nrg <= N, else the tall-matrix loop of sum_loaded_n), NQ = columns per thread; uniform branches pick the instantiation.
+    auto front = [&](auto Nc, auto NQc) {
+        constexpr int N = decltype(Nc)::value, NQ = decltype(NQc)::value;
+        float a0q[NQ], djq[NQ], co1q[NQ], co2q[NQ], co3q[NQ];
+        float thrxq[NQ], invLhsq[NQ], bexq[NQ], loq[NQ], hiq[NQ], c1q[NQ], c0q[NQ];
+        double zsq[NQ], pv0[N];
+        BayesRMarker bmq[NQ];
+        // ---- step 1: loads only
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int c = tid + q * kStepThreads;
-        if (c >= B) continue;                     // (B may be smaller than the workgroup)
-        const int cc = c < b ? c : 0;
-        const int64_t j = j0 + cc;
-        const float a0 = A.alpha[j];
-        const float dj = A.xpx[j];
-        float co = 0.f;
-        if constexpr (GROUP) {
-            const float co2 = A.corr_in2[c];
-            // (unconditional loads from always-valid buffers, the VALUE selected: a load under a condition on a pointer makes hipcc
-            // choose between address spaces)
-            float co1 = A.corr_in[c], co3 = A.corr_in3[c];
-            if constexpr (kPP) {
-                if (A.pp_cw_in != nullptr) co1 = 0.f;
-                if (A.pp_cp_in != nullptr) co3 = 0.f;
-                pp_c1[q] = co1; pp_c2[q] = co2; pp_c3[q] = co3;
+        for (int q = 0; q < NQ; ++q) {
+            const int c = tid + q * kStepThreads;
+            const int cc = c < b ? c : 0, cx = c < B ? c : 0;       // (a column the block does not have: marker 0's values, never used)
+            const int64_t j = j0 + cc;
+            a0q[q] = A.alpha[j];
+            djq[q] = A.xpx[j];
+            co1q[q] = A.corr_in[cx]; co2q[q] = 0.f; co3q[q] = 0.f;
+            // (grouped launches: unconditional loads from always-valid buffers, the VALUE selected below: a load under a condition on
+            // a pointer makes hipcc choose between address spaces)
+            if constexpr (GROUP) { co2q[q] = A.corr_in2[cx]; co3q[q] = A.corr_in3[cx]; }
+            thrxq[q] = 0.f; invLhsq[q] = 0.f; bexq[q] = 0.f; loq[q] = 0.f; hiq[q] = 0.f; c1q[q] = 0.f; c0q[q] = 0.f; zsq[q] = 0.0;
+            if constexpr (kR) {
+                bmq[q].load_fast_global(A.prep_d, p, j, djq[q], ie);
+                thrxq[q] = A.prep_f[j];
+            } else {
+                zsq[q] = A.prep_d[3 * p + j];
+                invLhsq[q] = A.prep_f[j]; bexq[q] = A.prep_f[2 * p + j]; loq[q] = A.prep_f[3 * p + j]; hiq[q] = A.prep_f[4 * p + j];
+                if constexpr (DENSE) { c1q[q] = A.prep_f[5 * p + j]; c0q[q] = A.prep_f[6 * p + j]; }
             }
-            co = (co1 + co2) + co3;                                       // (final unless a term is still on its way: pp_wait)
-        } else co = A.corr_in[c];
-        if constexpr (kR) {
-            BayesRMarker bm;
-            bm.load_fast_global(A.prep_d, p, j, dj, ie);
-            const float thrx = A.prep_f[j];
-            const double sum = sum_partials(A.partials + cc, A.nrg, A.bstride);
-            if constexpr (kPP) pp_sum[q] = (float)sum;
-            const float rhs0 = (float)sum + co;
-            rhs_lds[c] = rhs0;
-            const float a_in = (c < b) ? a0 : 0.f;
-            acur[c] = a_in; astart[c] = a_in;
-            bm.store_fast(lpd, B, c);
-            lpf[c] = dj; lpf[B + c] = thrx;
-            cand[q] = (c < b) && ((a_in != 0.f) || (fabsf(rhs0) >= thrx * cmarg));
-            dpark0[c] = 1.f;                      // a marker that stays out: class 1 (see the prefix skip below)
-        } else {
-            const double zs = A.prep_d[3 * p + j];
-            const float invLhs = A.prep_f[j], bex = A.prep_f[2 * p + j], lo = A.prep_f[3 * p + j], hi = A.prep_f[4 * p + j];
-            const double sum = sum_partials(A.partials + cc, A.nrg, A.bstride);
+            if (q == 0) load_partials_n<N>(A.partials + cc, A.nrg, A.bstride, pv0);
+        }
+        // (nothing of step 2 may be scheduled in between: the first addition of a sum needs one load only, and hoisted above the
+        // other loads it makes the wait that follows it a wait for everything issued so far)
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- step 2: sums, right-hand sides, candidacy, LDS
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int c = tid + q * kStepThreads;
+            if (c >= B) continue;                     // (B may be smaller than the workgroup)
+            const int cc = c < b ? c : 0;
+            const float a0 = a0q[q], dj = djq[q];
+            float co = 0.f;
+            if constexpr (GROUP) {
+                const float co2 = co2q[q];
+                float co1 = co1q[q], co3 = co3q[q];
+                if constexpr (kPP) {
+                    if (A.pp_cw_in != nullptr) co1 = 0.f;
+                    if (A.pp_cp_in != nullptr) co3 = 0.f;
+                    pp_c1[q] = co1; pp_c2[q] = co2; pp_c3[q] = co3;
+                }
+                co = (co1 + co2) + co3;                                       // (final unless a term is still on its way: pp_wait)
+            } else co = co1q[q];
+            double sum;
+            if (q == 0) sum = sum_loaded_n<N>(pv0, A.partials + cc, A.nrg, A.bstride);
+            else {
+                double pv1[N];
+                load_partials_n<N>(A.partials + cc, A.nrg, A.bstride, pv1);
+                __builtin_amdgcn_sched_barrier(0);
+                sum = sum_loaded_n<N>(pv1, A.partials + cc, A.nrg, A.bstride);
+            }
             if constexpr (kPP) pp_sum[q] = (float)sum;
             const float rhs0 = (float)sum + co;       // + lookahead correction formed by the previous block's sampler
             rhs_lds[c] = rhs0;
             const float a_in = (c < b) ? a0 : 0.f;
             acur[c] = a_in; astart[c] = a_in;
-            lpd[c] = zs;
-            lpf[c] = invLhs; lpf[B + c] = bex; lpf[2 * B + c] = dj; lpf[3 * B + c] = lo; lpf[4 * B + c] = hi;
-            // Rule D sweeps: nothing is ever excluded, so the slots of the "excluded" draw and of the lower threshold carry
-            // c1 and c0 instead (512-marker blocks leave no LDS for two more rows next to dense_big_st's 128 KB of tiles)
-            if constexpr (DENSE) { lpf[B + c] = A.prep_f[5 * p + j]; lpf[3 * B + c] = A.prep_f[6 * p + j]; }
-            cand[q] = (c < b) && ((a_in != 0.f) || abc_included(rhs0, lo * cmarg, hi * cmarg));      // (alpha = 0: lo <= 0 <= hi)
-            always_mine = always_mine && ((c >= b) || (lo == hi));           // thresholds(): lo = hi <=> always included
-            bpark0[c] = bex; dpark0[c] = 0.f;     // a marker that stays out: delta 0, beta = its excluded draw
+            if constexpr (kR) {
+                const float thrx = thrxq[q];
+                bmq[q].store_fast(lpd, B, c);
+                lpf[c] = dj; lpf[B + c] = thrx;
+                cand[q] = (c < b) && ((a_in != 0.f) || (fabsf(rhs0) >= thrx * cmarg));
+                dpark0[c] = 1.f;                      // a marker that stays out: class 1 (see the prefix skip below)
+            } else {
+                const float invLhs = invLhsq[q], bex = bexq[q], lo = loq[q], hi = hiq[q];
+                lpd[c] = zsq[q];
+                lpf[c] = invLhs; lpf[B + c] = bex; lpf[2 * B + c] = dj; lpf[3 * B + c] = lo; lpf[4 * B + c] = hi;
+                // Rule D sweeps: nothing is ever excluded, so the slots of the "excluded" draw and of the lower threshold carry
+                // c1 and c0 instead (512-marker blocks leave no LDS for two more rows next to dense_big_st's 128 KB of tiles)
+                if constexpr (DENSE) { lpf[B + c] = c1q[q]; lpf[3 * B + c] = c0q[q]; }
+                cand[q] = (c < b) && ((a_in != 0.f) || abc_included(rhs0, lo * cmarg, hi * cmarg));      // (alpha = 0: lo <= 0 <= hi)
+                always_mine = always_mine && ((c >= b) || (lo == hi));           // thresholds(): lo = hi <=> always included
+                bpark0[c] = bex; dpark0[c] = 0.f;     // a marker that stays out: delta 0, beta = its excluded draw
+            }
+        }
+    };
+    {
+        using std::integral_constant;
+        typedef integral_constant<int, 1> Q1; typedef integral_constant<int, 2> Q2;
+        if (B > kStepThreads) {
+            if (A.nrg <= 8) front(integral_constant<int, 8>{}, Q2{});
+            else if (A.nrg <= 16) front(integral_constant<int, 16>{}, Q2{});
+            else front(integral_constant<int, 32>{}, Q2{});
+        } else {
+            if (A.nrg <= 8) front(integral_constant<int, 8>{}, Q1{});
+            else if (A.nrg <= 16) front(integral_constant<int, 16>{}, Q1{});
+            else front(integral_constant<int, 32>{}, Q1{});
         }
     }
     if constexpr (kPP) {
