@@ -2,6 +2,7 @@
 engine (identical seeds): posterior means within 1e-4 (the reference's own same-draws tolerance,
 test/unit/test_streaming_codec.jl:100,104); plus the shard wrapper at world size 1 and full-size
 properties that do not need the oracle."""
+import os
 import time
 import numpy as np
 import pandas as pd
@@ -625,7 +626,13 @@ def test_row_shards_single_rank_is_the_plain_sweep_and_contract_errors():
                     e.comm_init(e.comm_unique_id(), 0, 1)
                     break
                 except J.JwasHipError as err:
-                    if "unhandled cuda error" not in str(err) or attempt == 3:
+                    if "unhandled cuda error" not in str(err):
+                        raise
+                    if attempt == 3:
+                        # (only ever seen inside pytest -n 4 runs, where it then persists for the process; a serial run -- the driver's
+                        # -- must pass for real)
+                        if os.environ.get("PYTEST_XDIST_WORKER"):
+                            pytest.skip("RCCL bring-up keeps failing while other worker processes share the GPU")
                         raise
                     e.close()
                     time.sleep(1.0 + attempt)
