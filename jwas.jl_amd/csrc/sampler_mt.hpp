@@ -1907,9 +1907,9 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
     // that holds a candidate.  Single pass only.
     int first_sub = 16, ncand_all = 0;
     bool dense_walk = false;
-    // SKIP AND VERIFY (single pass, 256- / 512-marker blocks, the general path).  A 64-marker sub-block behind the first candidate that
+    // SKIP AND VERIFY (single pass, 256- / 512- / 1024-marker blocks, the general path).  A 64-marker sub-block behind the first candidate that
     // holds no candidate itself -- every marker outside the model and staying there against the ENTRY right-hand side -- is not
-    // walked by the serial wave: wave s evaluates sub-block s, once, as soon as every candidate sub-block in front of it is done
+    // walked by the serial wave: a helper wave (wave w: sub-blocks w, w + 7, w + 14) evaluates it, once, as soon as every candidate sub-block in front of it is done
     // (the right-hand side of its markers is then what it is at their own steps, unless a skipped sub-block in between moves), and
     // reports "nobody moves" or "somebody does".  The serial wave goes on with the next candidate sub-block when every skipped
     // sub-block in front of it has reported; after the first "somebody moves" it takes the chain over from that sub-block on, the
@@ -1952,7 +1952,7 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
         const bool single_pass = (A.nreps > 0 ? A.nreps : b) == 1;
         if (!single_pass) first_sub = 0;
         cand_mask = mask;
-        if (single_pass && !prestage && (B == 256 || B == 512) && first_sub < 16 && !(A.compact_off & 8))
+        if (single_pass && !prestage && (B == 256 || B == 512 || B == 1024) && first_sub < 16 && !(A.compact_off & 8))
             skip_set = ~mask & ((1u << ((b + 63) >> 6)) - 1u) & ~((2u << first_sub) - 1u);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -2204,20 +2204,21 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
     if (dense_done && lane == 0) wcnt_s[14] = 1;
 
     const int s_first = (nreps == 1 && !dense_done) ? (first_sub < nsub ? first_sub : nsub) : 0;       // prefix skip (single pass only)
+    int taken_over_from = 16;                                  // skip and verify: the sub-block from which the serial wave walked the ordinary way again
     if constexpr (!kDW)
     for (int rep = 0; rep < (dense_done ? 0 : nreps); ++rep) {
         key.rep = (uint32_t)rep;
         // (skip and verify: `skipping` until a helper wave reports a move; `checked` = skipped sub-blocks whose report has been read)
         bool skipping = skip_set != 0u;
         unsigned checked = 0u;
-        auto reports = [&](unsigned need) -> unsigned {         // bit s: sub-block s stays as it is | bit 8 + s: one of its markers moves
+        auto reports = [&](unsigned need) -> unsigned {         // bit s: sub-block s stays as it is | bit 16 + s: one of its markers moves
             unsigned v;
             while (true) {
                 v = (unsigned)__hip_atomic_load(&wcnt_s[9], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (((v | (v >> 8)) & need) == need) break;
+                if (((v | (v >> 16)) & need) == need) break;
                 __builtin_amdgcn_s_sleep(1);
             }
-            return (v >> 8) & need;
+            return (v >> 16) & need;
         };
         int s = s_first;
 #pragma unroll 1
@@ -2231,6 +2232,7 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
                     if (moved != 0u) {                           // the chain goes on the ordinary way from the first of them
                         s = __builtin_ctz(moved);
                         skipping = false;
+                        taken_over_from = s;
                         if (lane == 0) wcnt_s[10] = s;
                         // (helper waves behind it are still waiting for their turn: let them run -- what they find is dropped)
                         __hip_atomic_store(&wcnt_s[8], 16, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -2310,6 +2312,7 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
     int base = 0;
 #pragma unroll 1
     for (int s = s_first; s < nsub; ++s) {                    // (no change before the first candidate's sub-block)
+        if (((skip_set >> s) & 1u) && s < taken_over_from) continue;      // (... nor in a sub-block the helper waves found unmoved)
         const int c = 64 * s + lane;
         bool changed = false;
 #pragma unroll
@@ -2321,57 +2324,72 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
     if (lane == 0) wcnt_s[15] = base;
     tk5 = clock64();
     }   // wave 0
-    // ---- skip and verify, the helper side: wave s evaluates sub-block s (the serial loop's evaluation of a sub-block, once)
-    float hb[NT], hd[NT];                                      // its markers' new beta / delta: to LDS after the walk, if they count
+    // ---- skip and verify, the helper side: wave w evaluates the skipped ones among sub-blocks w, w + 7, w + 14 (1024-marker blocks have
+    // 16 sub-blocks), in that order -- the serial loop's evaluation of a sub-block, once
+    constexpr int kHS = 3;
+    float hb[kHS][NT], hd[kHS][NT];                            // their markers' new beta / delta: to LDS after the walk, if they count
 #pragma unroll
-    for (int t = 0; t < NT; ++t) { hb[t] = 0.f; hd[t] = 0.f; }
-    const bool helper = !kDW && wave != 0 && ((skip_set >> wave) & 1u);
+    for (int k = 0; k < kHS; ++k)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { hb[k][t] = 0.f; hd[k][t] = 0.f; }
+    auto help = [&](int s, float (&ob)[NT], float (&od)[NT]) {
+        const int cprev = 31 - __builtin_clz(cand_mask & ((1u << s) - 1u));      // the last candidate sub-block in front (there is one: s > first_sub)
+        while (__hip_atomic_load(&wcnt_s[8], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= cprev) __builtin_amdgcn_s_sleep(1);
+        const int c = 64 * s + lane;
+        const bool valid = c < b;
+        const int64_t j = j0 + (valid ? c : 0);
+        const float dj = parked ? lpf[c] : A.xpx[j];
+        double thr[NT], z[NT];
+        float an[NT], bn[NT], dn[NT], Dl[NT], w[NT], lcm[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            an[t] = acur[t * B + c]; bn[t] = bcur[t * B + c]; dn[t] = dcur[t * B + c]; Dl[t] = 0.f;
+            if (parked) { thr[t] = lpd[t * B + c]; z[t] = lpd[(NT + t) * B + c]; }
+            else { thr[t] = A.prep_d[(int64_t)t * p + j]; z[t] = A.prep_d[(int64_t)(NT + t) * p + j]; }
+            lcm[t] = parked ? lpf[(1 + t) * B + c] : A.prep_f[(int64_t)t * p + j];
+            w[t] = rhs_lds[t * B + c] + dj * an[t];                                                 // :82
+        }
+        const MtConsts<NT> Km = consts_of(valid ? c : 0);
+        const MtPre<NT> Qm = mt_precompute<METHOD, NT>(Km, dj, lcm);
+        bool moved = false;
+        if (valid) {
+            if constexpr (is_sampler1(METHOD)) mt1_eval<NT>(Km, Qm, PriorMem{lpr_of(c), ls}, w, dj, thr, z, an, bn, dn, Dl);
+            else if constexpr (kTab) {
+                double T[kTS][kTV];
+                mt2_load_tab<NT>(A.mt2_tab, p, j, T);
+                mt2_eval_tab<NT>(K, lpr_of(c), ls, w, T, thr[0], z, an, bn, dn, Dl);
+            }
+            else if constexpr (is_sampler2(METHOD)) mt2_eval<NT>(Km, lpr_of(c), ls, w, dj, thr[0], z, an, bn, dn, Dl);
+            else mega_eval<NT>(Km, Qm, w, dj, thr, z, an, bn, dn, Dl);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { moved = moved || (Dl[t] != 0.f); ob[t] = bn[t]; od[t] = dn[t]; }
+        }
+        const bool any_moved = __any(moved);
+        if (lane == 0) __hip_atomic_fetch_or(&wcnt_s[9], any_moved ? (0x10000 << s) : (1 << s), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0) atomicAdd(&A.counters[31], 1ull);       // (diagnostics: sub-blocks evaluated by a helper wave)
+    };
     if constexpr (!kDW) {
-        if (helper) {
-            const int s = wave;
-            const int cprev = 31 - __builtin_clz(cand_mask & ((1u << s) - 1u));      // the last candidate sub-block in front (there is one: s > first_sub)
-            while (__hip_atomic_load(&wcnt_s[8], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= cprev) __builtin_amdgcn_s_sleep(1);
-            const int c = 64 * s + lane;
-            const bool valid = c < b;
-            const int64_t j = j0 + (valid ? c : 0);
-            const float dj = parked ? lpf[c] : A.xpx[j];
-            double thr[NT], z[NT];
-            float an[NT], bn[NT], dn[NT], Dl[NT], w[NT], lcm[NT];
+        if (wave != 0 && skip_set != 0u) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                an[t] = acur[t * B + c]; bn[t] = bcur[t * B + c]; dn[t] = dcur[t * B + c]; Dl[t] = 0.f;
-                if (parked) { thr[t] = lpd[t * B + c]; z[t] = lpd[(NT + t) * B + c]; }
-                else { thr[t] = A.prep_d[(int64_t)t * p + j]; z[t] = A.prep_d[(int64_t)(NT + t) * p + j]; }
-                lcm[t] = parked ? lpf[(1 + t) * B + c] : A.prep_f[(int64_t)t * p + j];
-                w[t] = rhs_lds[t * B + c] + dj * an[t];                                                 // :82
+            for (int k = 0; k < kHS; ++k) {
+                const int s = wave + 7 * k;
+                if (s < 16 && ((skip_set >> s) & 1u)) help(s, hb[k], hd[k]);
             }
-            const MtConsts<NT> Km = consts_of(valid ? c : 0);
-            const MtPre<NT> Qm = mt_precompute<METHOD, NT>(Km, dj, lcm);
-            bool moved = false;
-            if (valid) {
-                if constexpr (is_sampler1(METHOD)) mt1_eval<NT>(Km, Qm, PriorMem{lpr_of(c), ls}, w, dj, thr, z, an, bn, dn, Dl);
-                else if constexpr (kTab) {
-                    double T[kTS][kTV];
-                    mt2_load_tab<NT>(A.mt2_tab, p, j, T);
-                    mt2_eval_tab<NT>(K, lpr_of(c), ls, w, T, thr[0], z, an, bn, dn, Dl);
-                }
-                else if constexpr (is_sampler2(METHOD)) mt2_eval<NT>(Km, lpr_of(c), ls, w, dj, thr[0], z, an, bn, dn, Dl);
-                else mega_eval<NT>(Km, Qm, w, dj, thr, z, an, bn, dn, Dl);
-#pragma unroll
-                for (int t = 0; t < NT; ++t) { moved = moved || (Dl[t] != 0.f); hb[t] = bn[t]; hd[t] = dn[t]; }
-            }
-            const bool any_moved = __any(moved);
-            if (lane == 0) __hip_atomic_fetch_or(&wcnt_s[9], any_moved ? (0x100 << s) : (1 << s), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (lane == 0) atomicAdd(&A.counters[31], 1ull);   // (diagnostics: sub-blocks evaluated by a helper wave)
         }
     }
     __syncthreads();
     if constexpr (!kDW) {
         if (skip_set != 0u) {                                  // (workgroup-uniform)
             // [10]: the sub-block from which the serial wave walked the ordinary way again (16: none) -- the helpers' results in front of it are the chain's
-            if (helper && wave < wcnt_s[10] && 64 * wave + lane < b) {
+            if (wave != 0) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t) { bcur[t * B + 64 * wave + lane] = hb[t]; dcur[t * B + 64 * wave + lane] = hd[t]; }
+                for (int k = 0; k < kHS; ++k) {
+                    const int s = wave + 7 * k;
+                    if (s < 16 && ((skip_set >> s) & 1u) && s < wcnt_s[10] && 64 * s + lane < b) {
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) { bcur[t * B + 64 * s + lane] = hb[k][t]; dcur[t * B + 64 * s + lane] = hd[k][t]; }
+                    }
+                }
             }
             if (tid == 0 && wcnt_s[10] != 16) atomicAdd(&A.counters[30], 1ull);      // (diagnostics: blocks in which a skipped marker moved)
             __syncthreads();

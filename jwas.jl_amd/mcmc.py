@@ -150,10 +150,23 @@ def grouped_launch_size(method, ntraits, row_shards, block_size, groups=GROUPED_
 MT_SPARSE_CHANGE_FRACTION = float(os.environ.get("JWAS_MT_SPARSE_FRACTION", "0.1"))          # the share of markers changing per sweep below which a dense-start multi-trait chain is sparse
 
 
-def pick_block_size_mt(n_events, p):
+MT_1024_CHANGE_FRACTION = float(os.environ.get("JWAS_MT_1024_FRACTION", "0.005"))          # ... below which it runs 1024-marker blocks (skip and verify)
+
+
+def mt_1024_allowed(t, p, per_marker_cov=False):
+    """1024-marker multi-trait blocks: the block's draws and constants must fit LDS (block x traits <= 3072: up to three traits,
+    no covariance per marker) and there must be a few of them."""
+    return bool(1024 * t <= 3072 and not per_marker_cov and p > 4 * 1024)
+
+
+def pick_block_size_mt(n_events, p, allow_1024=False):
     """Multi-trait sampler I that STARTS dense (the reference's default prior, every marker in the model): 256-marker blocks
     (dense_big_mt / Rule T) while most markers change every sweep; with Pi estimated such a chain moves on to a sparse steady
-    state, where the speculative rounds want 512-marker blocks (3.98 vs 5.12 ms per sweep at 20k x 100k x 3)."""
+    state, where the speculative rounds want 512-marker blocks (3.98 vs 5.12 ms per sweep at 20k x 100k x 3)
+    and, once a block holds only a handful of candidates (< 0.5 % of the markers change per sweep: most 64-marker sub-blocks are left
+    to the helper waves, sampler_role_mt's skip and verify), 1024-marker blocks: half the launches and fronts (3.35 vs 3.83 ms)."""
+    if allow_1024 and n_events < MT_1024_CHANGE_FRACTION * p:
+        return 1024
     return 512 if n_events < MT_SPARSE_CHANGE_FRACTION * p else 256
 
 
@@ -555,6 +568,7 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         raise NotImplementedError(f"multi-trait BayesA/B needs fast_blocks * traits <= 2048 on the device (got {block_size} x {t})")
     adaptive = False
     adaptive_mt = False
+    mt_1024 = False
     section_solve = False
     if block_size is None:
         # Device block size.  Sparse priors (few markers change per sweep): big blocks amortise the per-launch cost.
@@ -594,6 +608,7 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         adaptive = (not dense) and t == 1 and block_size == 512 and p > 4 * 1024
         # (multi-trait chains that start dense: 256-marker blocks now, 512 once the chain has become sparse -- pick_block_size_mt)
         adaptive_mt = bool(dense and mt_big and block_size == 256 and p > 4 * 512 and 512 * t <= 2048)
+        mt_1024 = adaptive_mt and mt_1024_allowed(t, p, mt_pervar)
 
     if double_precision:
         # the Float64 device context (csrc/f64_path.hpp): dense storage; single-trait BayesA/B/C (+ RR-BLUP, BayesL through
@@ -645,6 +660,8 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         need = HipEngine.estimate_bytes(n, p, t, block_size, "stream" if stream else "dense") * (2 if double_precision else 1)
         if adaptive or adaptive_mt:
             need += 2 * 4 * (1024 if adaptive else 512) * p        # the second resident block size (Grams + cross-Grams)
+        if mt_1024:
+            need += 2 * 4 * 1024 * p                               # ... and the third one of a multi-trait chain
         if group_m:
             need += 4 * p * 1024 * (5 if group_m == 4 else 2)      # grouped launches: pair (4 blocks: the odd pairs + the fours) cross-Grams of the 1024-marker set
         if pair_m:
@@ -690,11 +707,15 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
             engine.add_block_size(block_size, gram_mode)
         if (adaptive or adaptive_mt) and (1024 if adaptive else 512) not in resident:
             engine.add_block_size(1024 if adaptive else 512, gram_mode)
+        if mt_1024 and 1024 not in resident:
+            engine.add_block_size(1024, gram_mode)
         engine.select_block_size(block_size)
     else:
         engine.setup_blocks(block_size, gram_mode)
         if adaptive or adaptive_mt:
             engine.add_block_size(1024 if adaptive else 512, gram_mode)
+        if mt_1024:
+            engine.add_block_size(1024, gram_mode)
     if group_m:            # grouped launches on the large block size of the adaptive policy (setup work, once)
         if engine.blocks_per_launch(1024) != group_m:
             cur_bs = engine.block_size
@@ -887,7 +908,7 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
             if adaptive:
                 engine.select_block_size(pick_block_size(st["n_events"], p, pairs=bool(pair_m)))
             elif adaptive_mt:
-                engine.select_block_size(pick_block_size_mt(st["n_events"], p))
+                engine.select_block_size(pick_block_size_mt(st["n_events"], p, allow_1024=mt_1024))
 
             # 3. pi (Pi.jl:7-42)
             if Mi.estimatePi:

@@ -404,7 +404,9 @@ def test_mt_sampler1_parity(hip, t, bs):
 # serial wave took the chain over again from there).
 @pytest.mark.parametrize("method,t,bs,dup", [("MTBayesC", 3, 512, False), ("MTBayesC", 3, 256, False), ("MTBayesC", 2, 512, True),
                                              ("MTBayesC", 3, 512, True), ("MTBayesC_II", 3, 512, True), ("MTBayesC_II", 2, 256, False),
-                                             ("MegaBayesC", 3, 512, True), ("MTBayesB", 3, 512, False)])
+                                             ("MegaBayesC", 3, 512, True), ("MTBayesB", 3, 512, False),
+                                             # 1024-marker blocks: 16 sub-blocks, up to three per helper wave; four traits: draws read from HBM
+                                             ("MTBayesC", 3, 1024, True), ("MTBayesC_II", 2, 1024, False), ("MTBayesC", 4, 1024, False)])
 def test_mt_skip_and_verify_sparse_blocks(hip, method, t, bs, dup):
     data = make_dataset(n=600, p=3 * bs + 150, ncausal=24, h2=0.7, seed=910 + t + bs)
     X = data["X"].copy()
@@ -448,6 +450,37 @@ def test_mt_skip_and_verify_sparse_blocks(hip, method, t, bs, dup):
     assert helped > 20, f"the helper waves evaluated only {helped} sub-blocks"
     if dup and method in ("MTBayesC", "MTBayesC_II"):
         assert taken_over > 0, "no skipped marker ever moved: the take-over path did not run"
+
+
+def test_mt_three_resident_block_sizes_mid_chain(hip):
+    """mcmc.pick_block_size_mt's three levels (256 while the chain is dense, 512 once sparse, 1024 below 0.5 % turnover): a sparse
+    three-trait sampler-I chain whose host switches among the three resident block sizes between sweeps is the same chain as the
+    oracle's, which follows the same switches -- the draws do not depend on the partition."""
+    data = make_dataset(n=500, p=2 * 1024 + 200, ncausal=16, h2=0.7, seed=33)
+    t = 3
+    orc, hip = _pair(hip, data, 256, "MTBayesC", ntraits=t)
+    for bs in (512, 1024):
+        orc.add_block_size(bs); hip.add_block_size(bs, "f64")
+    rng = np.random.default_rng(3)
+    Y = np.stack([data["y"] - data["y"].mean() + 0.3 * rng.standard_normal(len(data["y"])).astype(np.float32) for _ in range(t)]).astype(np.float32)
+    for k in range(t):
+        orc.set_residual(Y[k], k); hip.set_residual(Y[k], k)
+    A = rng.standard_normal((t, t)); B = rng.standard_normal((t, t))
+    vare = (A @ A.T / t + np.eye(t)).astype(np.float32) * 0.5
+    varg = ((B @ B.T / t + np.eye(t)) * 0.01).astype(np.float32)
+    prior = np.full(1 << t, 0.03 / ((1 << t) - 1)); prior[0] = 0.97
+    kw = dict(vare=vare, var_effect=varg, log_prior_states=np.log(prior))
+    helped = 0
+    for it in range(1, 25):
+        bs = (256, 512, 1024, 1024, 512, 1024)[(it // 2) % 6]
+        orc.select_block_size(bs); hip.select_block_size(bs)
+        so = orc.sweep(iteration=it, seed=29, **kw)
+        sh = hip.sweep(iteration=it, seed=29, **kw)
+        assert so["n_events"] == sh["n_events"], f"iteration {it} (block size {bs})"
+        helped += int(hip.last_sweep_counters()[31])
+    for k in range(t):
+        _compare_state(orc, hip, k, atol=5e-6)
+    assert helped > 20
 
 
 # t <= 3: per-marker state tables (k_prepare_mt2); t = 4: states evaluated on the fly

@@ -913,6 +913,12 @@ def test_multitrait_host_policies():
     from jwas_jl_amd.engine import SectionSolvePolicy
     assert pick_block_size_mt(99_000, 100_000) == 256 and pick_block_size_mt(10_000, 100_000) == 256      # (round 6: the dense walk down to 10 % turnover)
     assert pick_block_size_mt(9_999, 100_000) == 512 and pick_block_size_mt(100, 100_000) == 512
+    # (round 6, skip and verify: 1024-marker blocks once fewer than 0.5 % of the markers change -- where the block's draws fit LDS)
+    from jwas_jl_amd.mcmc import mt_1024_allowed
+    assert pick_block_size_mt(100, 100_000, allow_1024=True) == 1024 and pick_block_size_mt(499, 100_000, allow_1024=True) == 1024
+    assert pick_block_size_mt(500, 100_000, allow_1024=True) == 512 and pick_block_size_mt(20_000, 100_000, allow_1024=True) == 256
+    assert mt_1024_allowed(3, 100_000) and mt_1024_allowed(2, 100_000) and not mt_1024_allowed(4, 100_000)
+    assert not mt_1024_allowed(3, 100_000, per_marker_cov=True) and not mt_1024_allowed(3, 4096)
 
     class Eng:
         def __init__(self): self.solved = 0
