@@ -269,3 +269,72 @@ def test_random_rule_t_configurations_against_the_oracle(hip, seed):
         assert np.array_equal(do, dh), f"seed {seed}"
         assert np.array_equal(ah, ao) and np.array_equal(bh, bo), f"seed {seed}: max |d alpha| {np.abs(ah - ao).max()}"
         assert np.array_equal(hip.get_residual(k), orc.get_residual(k)), f"seed {seed}"
+
+
+@pytest.mark.parametrize("seed", list(range(max(24, int(__import__("os").environ.get("JWAS_FUZZ_CASES", "400")) // 8))))
+def test_random_multitrait_skip_and_verify_configurations_against_the_oracle(hip, seed):
+    """Differential fuzzing of the multi-trait SKIP AND VERIFY pass (csrc/sampler_mt.hpp: helper waves evaluate the 64-marker
+    sub-blocks without a candidate, the serial wave takes the chain over again when one of their markers moves): random shapes (one to
+    three blocks of 256 / 512 / 1024 markers and a ragged tail), two to four traits, samplers I / II / constraint = true / a covariance per
+    marker, sparse priors of different strength, copies of the causal columns a few sub-blocks behind the originals (they make skipped
+    markers move), residual weights -- bit for bit against the oracle summing in the device's order."""
+    import oracle as O
+    rng = np.random.default_rng(91_000 + seed)
+    method = str(rng.choice(["MTBayesC", "MTBayesC", "MTBayesC_II", "MegaBayesC", "MTBayesB"]))
+    bs = int(rng.choice([256, 512, 512, 1024]))
+    t = int(rng.integers(2, 5)) if method != "MTBayesB" else int(rng.integers(2, 4))
+    while method == "MTBayesB" and bs * t > 2048:
+        bs //= 2
+    n = int(rng.integers(300, 900))
+    p = bs * int(rng.integers(1, 4)) + int(rng.choice([0, 17, 130, bs // 2 + 3]))
+    d = make_dataset(n=n, p=p, ncausal=min(24, p), h2=0.7, seed=int(rng.integers(0, 1000)))
+    X = d["X"].copy()
+    if rng.random() < 0.6:
+        for j in d["causal"]:
+            k = int(j) + int(rng.choice([64, 130, 200, 330]))
+            if k < p and k // bs == int(j) // bs:
+                X[:, k] = X[:, j]
+    X = np.asfortranarray(X)
+    y = (d["y"] - d["y"].mean()).astype(np.float32)
+    w = rng.uniform(0.3, 3.0, n).astype(np.float32) if rng.random() < 0.25 else None
+    hip.load_dense(X); hip.set_weights(w)
+    O.set_device_order(hip.update_geometry()[0])
+    orc = OracleEngine("lookahead", acc=O.ACC_DEVICE)
+    orc.load_dense(X); orc.set_weights(w)
+    for e in (orc, hip):
+        e.setup_blocks(bs, "f64")
+    hip.set_xpx(orc._xpx); hip.set_grams_packed(orc._grams)
+    orc._w()
+    st_ = list(orc._bs) + [p]
+    for kb in range(1, len(st_) - 1):
+        hip.set_cross_gram(kb, O.cross_gram(X, st_[kb - 1], st_[kb] - st_[kb - 1], st_[kb], st_[kb + 1] - st_[kb], O.ACC_DEVICE))
+    O.set_weights(None)
+    for e in (orc, hip):
+        e.init_state(method, t)
+        for k in range(t):
+            e.set_residual(((1 + 0.3 * k) * y + 0.3 * np.random.default_rng(seed * 7 + k).standard_normal(n)).astype(np.float32), k)
+    v = np.float32(max(float(np.var(y)), 0.1))
+    A = rng.standard_normal((t, t)); Rm = ((A @ A.T / t + np.eye(t)) * v * 0.5).astype(np.float32)
+    Bm = rng.standard_normal((t, t)); Gm = ((Bm @ Bm.T / t + np.eye(t)) * 0.01).astype(np.float32)
+    sp = float(rng.choice([0.9, 0.97, 0.995]))
+    if method == "MegaBayesC":
+        kw = dict(vare=np.diag(np.diag(Rm)).astype(np.float32), var_effect=np.diag(np.diag(Gm)).astype(np.float32), pi=np.full(t, 1 - (1 - sp) / t))
+    else:
+        prior = np.full(1 << t, (1 - sp) / ((1 << t) - 1)); prior[0] = sp
+        kw = dict(vare=Rm, var_effect=Gm, log_prior_states=np.log(prior))
+        if method == "MTBayesB":
+            Wm = rng.standard_normal((p, t, t))
+            kw["var_effect_matrix"] = ((Wm @ Wm.transpose(0, 2, 1) / t + np.eye(t)) * 0.01).astype(np.float32)
+    try:
+        for it in range(1, 9):
+            so = orc.sweep(iteration=it, seed=2000 + seed, **kw)
+            sh = hip.sweep(iteration=it, seed=2000 + seed, **kw)
+            assert so["n_events"] == sh["n_events"], f"seed {seed} iteration {it} ({method}, t = {t}, block {bs}, p = {p})"
+    finally:
+        O.set_device_order(8)
+    for k in range(t):
+        ao, bo, do = orc.get_state(k)
+        ah, bh, dh = hip.get_state(k)
+        assert np.array_equal(do, dh), f"seed {seed}"
+        assert np.array_equal(ah, ao) and np.array_equal(bh, bo), f"seed {seed}: max |d alpha| {np.abs(ah - ao).max()}"
+        assert np.array_equal(hip.get_residual(k), orc.get_residual(k)), f"seed {seed}"
