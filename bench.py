@@ -205,7 +205,7 @@ def main():
         dist.init_process_group("nccl", rank=0, world_size=1)
     import jwas_jl_amd as J
     from jwas_jl_amd.dist import MarkerShard, RowShard, shard_range
-    from jwas_jl_amd.mcmc import pick_block_size, pick_block_size_mt, mt_1024_allowed
+    from jwas_jl_amd.mcmc import pick_block_size, pick_block_size_mt, mt_1024_allowed, MT_1024_CHANGE_FRACTION
 
     wl = a.workload
     n, p_arg, method, t = WORKLOADS[wl]
@@ -229,6 +229,8 @@ def main():
     section_solve = bool(mt_big and t <= 3 and bs == 256 and not a.no_section_solve)
     adaptive_mt = bool(a.block_size == 0 and mt_big and bs == 256 and 512 * t <= 2048)      # (256 while the chain is dense, 512 once it is sparse,
     mt_1024 = adaptive_mt and mt_1024_allowed(t, p_total, a.mt_method == "BayesB")           #  1024 once a block holds a handful of candidates)
+    # (a multi-trait chain that starts sparse: 512-marker blocks, 1024 below 0.5 % turnover -- mcmc.run_chain's policy)
+    adaptive_mts = bool(a.block_size == 0 and t > 1 and not dense_prior and bs == 512 and mt_1024_allowed(t, p_total, a.mt_method == "BayesB"))
     rows_mode = a.shard == "rows"
     if rows_mode and (weak or a.storage != "dense"):
         raise SystemExit("--shard rows runs the dense strong-scaling workloads (config2 / config3 / config4 / refbench)")
@@ -268,6 +270,8 @@ def main():
         eng.add_block_size(512, "mfma")
         if mt_1024:
             eng.add_block_size(1024, "mfma")
+    elif adaptive_mts:
+        eng.add_block_size(1024, "mfma")
     # grouped launches (single-trait sparse steady state: the 1024-marker set of the adaptive policy, or the fixed block size of a
     # packed / explicitly sized run).  The metric is defined on the steady state of a long chain, so the bench sets the
     # groups up whatever --steps is; mcmc.run_chain asks for them only when the chain is long enough to pay for the set-up
@@ -428,6 +432,8 @@ def main():
             eng.select_block_size(pick_block_size(st["n_events"], p_total, pairs=pairs_on))
         elif adaptive_mt:
             eng.select_block_size(pick_block_size_mt(st["n_events"], p_total, allow_1024=mt_1024))
+        elif adaptive_mts:
+            eng.select_block_size(1024 if st["n_events"] < MT_1024_CHANGE_FRACTION * p_total else 512)
         acc["launches"] += -(-p_loc // (s["bs"] * max(m_now, 1))) + 1
         acc["grouped"] = max(acc.get("grouped", 0), m_now)
         acc["bytes"] += 4.0 * n_loc * p_loc if a.storage == "dense" else 0.25 * n_loc * p_loc
@@ -559,7 +565,7 @@ def main():
             "n_gpus": comm_world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "name": wl, "variant": variant, "storage": a.storage,
-                       "n": n, "p": p_total, "block_size": bs_now, "block_policy": "adaptive 512/1024" if adaptive else (("256 while dense / 512 once sparse" + (" / 1024 below 0.5 % turnover" if mt_1024 else "")) if adaptive_mt else "fixed"),
+                       "n": n, "p": p_total, "block_size": bs_now, "block_policy": "adaptive 512/1024" if adaptive else (("256 while dense / 512 once sparse" + (" / 1024 below 0.5 % turnover" if mt_1024 else "")) if adaptive_mt else ("512 / 1024 below 0.5 % turnover" if adaptive_mts else "fixed")),
                        "blocks_per_launch": (m_used if m_used >= 2 else 1), "group_setup_s": group_setup_s,
                        "parallelism": (f"{'row' if rows_mode else 'marker'}-shard x{world}" + (" (exact chain of the pooled data; one all-reduce of the block RHS per block launch)" if rows_mode else " (one all-reduce of the residual delta per sweep; residual resident in HBM)")) if world > 1 else "single GPU",
                        "ranks_reported_by_communicator": comm_world,

@@ -568,6 +568,7 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         raise NotImplementedError(f"multi-trait BayesA/B needs fast_blocks * traits <= 2048 on the device (got {block_size} x {t})")
     adaptive = False
     adaptive_mt = False
+    adaptive_mts = False
     mt_1024 = False
     section_solve = False
     if block_size is None:
@@ -609,6 +610,10 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
         # (multi-trait chains that start dense: 256-marker blocks now, 512 once the chain has become sparse -- pick_block_size_mt)
         adaptive_mt = bool(dense and mt_big and block_size == 256 and p > 4 * 512 and 512 * t <= 2048)
         mt_1024 = adaptive_mt and mt_1024_allowed(t, p, mt_pervar)
+        # (multi-trait chains that START sparse: 512-marker blocks, 1024 for the sweeps below 0.5 % turnover -- the same last level)
+        adaptive_mts = bool((not dense) and t > 1 and block_size == 512 and mt_1024_allowed(t, p, mt_pervar)
+                            and getattr(Mi, "annotations", False) is False)      # (marker-specific prior tables: their LDS copy does not fit at 1024 x 3)
+        mt_1024 = mt_1024 or adaptive_mts
 
     if double_precision:
         # the Float64 device context (csrc/f64_path.hpp): dense storage; single-trait BayesA/B/C (+ RR-BLUP, BayesL through
@@ -632,6 +637,8 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
             raise NotImplementedError(f"double_precision=true needs fast_blocks * traits <= 2048 on the device (got {block_size} x {t})")
         adaptive = False
         adaptive_mt = False
+        adaptive_mts = False
+        mt_1024 = False
 
     # grouped launches (engine.setup_groups): the adaptive policy's 1024-marker sweeps of a single-trait chain (dense or 2-bit packed
     # storage), when the chain is long enough to pay for the group cross-Grams; an explicitly partitioned / row-sharded run keeps
@@ -909,6 +916,8 @@ def run_chain(model, df, *, chain_length, burnin, output_samples_frequency, seed
                 engine.select_block_size(pick_block_size(st["n_events"], p, pairs=bool(pair_m)))
             elif adaptive_mt:
                 engine.select_block_size(pick_block_size_mt(st["n_events"], p, allow_1024=mt_1024))
+            elif adaptive_mts:
+                engine.select_block_size(1024 if st["n_events"] < MT_1024_CHANGE_FRACTION * p else 512)
 
             # 3. pi (Pi.jl:7-42)
             if Mi.estimatePi:
