@@ -2334,7 +2334,6 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
         for (int t = 0; t < NT; ++t) { hb[k][t] = 0.f; hd[k][t] = 0.f; }
     auto help = [&](int s, float (&ob)[NT], float (&od)[NT]) {
         const int cprev = 31 - __builtin_clz(cand_mask & ((1u << s) - 1u));      // the last candidate sub-block in front (there is one: s > first_sub)
-        while (__hip_atomic_load(&wcnt_s[8], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= cprev) __builtin_amdgcn_s_sleep(1);
         const int c = 64 * s + lane;
         const bool valid = c < b;
         const int64_t j = j0 + (valid ? c : 0);
@@ -2347,10 +2346,14 @@ __device__ __forceinline__ void sampler_role_mt(char* smem, const SamplerArgs& A
             if (parked) { thr[t] = lpd[t * B + c]; z[t] = lpd[(NT + t) * B + c]; }
             else { thr[t] = A.prep_d[(int64_t)t * p + j]; z[t] = A.prep_d[(int64_t)(NT + t) * p + j]; }
             lcm[t] = parked ? lpf[(1 + t) * B + c] : A.prep_f[(int64_t)t * p + j];
-            w[t] = rhs_lds[t * B + c] + dj * an[t];                                                 // :82
         }
         const MtConsts<NT> Km = consts_of(valid ? c : 0);
         const MtPre<NT> Qm = mt_precompute<METHOD, NT>(Km, dj, lcm);
+        // (state, draws and the x'x-only terms are the block-entry ones whatever the serial wave does meanwhile: everything above runs
+        // BEFORE the wait; only the right-hand sides have to be the ones of this sub-block's own steps)
+        while (__hip_atomic_load(&wcnt_s[8], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= cprev) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) w[t] = rhs_lds[t * B + c] + dj * an[t];                            // :82
         bool moved = false;
         if (valid) {
             if constexpr (is_sampler1(METHOD)) mt1_eval<NT>(Km, Qm, PriorMem{lpr_of(c), ls}, w, dj, thr, z, an, bn, dn, Dl);
